@@ -1,0 +1,125 @@
+/*
+ * oracle/oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of vgan's per-read likelihood hot path (HaploCart / euka / soibean), written
+ * from the reference's arithmetic (including its behaviour-defining quirks Q1..Q15).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and
+ * only as the checker / reported CPU baseline -- never as part of the product path.
+ *
+ * Parity pinning:
+ *   - a1 (reconstruct_graph_sequence) is pinned by the reference's own 10 reconstruction KATs
+ *     (src/test.cpp:855-994) on test/reconstructInputSeq/{target_graph.gfa,test_reads.gam}:
+ *     tests/test_oracle_golden.py checks all 20 strings.
+ *   - The numeric log-likelihoods / posteriors are NOT pinned by any reference test
+ *     (src/test.cpp holds classification-level asserts only) and the reference cannot be built
+ *     here (vg/libbdsg/libgab/protobuf absent, fetched from the network by src/Makefile:102-128):
+ *     for those values this oracle says "parity unpinned"; it is anchored on closed-form KATs
+ *      checked with mpmath in tests/test_oracle_kat.py.
+ *   - libgab (unpinned git HEAD, src/Makefile:121) is absent: oplusnatl / oplusInitnatl /
+ *     isValidDNA are restated from their published semantics.
+ *
+ * Layouts are plain flat arrays so numpy can fill them through ctypes.
+ */
+#ifndef VGAN_ORACLE_H
+#define VGAN_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Graph as the reference sees it after readPathHandleGraph (src/readPathHandleGraph.cpp:14-37). */
+typedef struct orc_graph {
+    int64_t min_id, max_id;        /* graph.min_node_id()/max_node_id() */
+    const int64_t *node_seq_off;   /* [max_id-min_id+2] offsets into node_seq, index = id-min_id */
+    const char *node_seq;          /* forward-strand node sequences, concatenated */
+    int32_t n_paths;               /* nbpaths */
+    const uint8_t *pathsgo;        /* [(max_id+1)*n_paths] row = NODE ID (path_supports[i][j], :28-31) */
+    const int32_t *pangenome_base; /* [max_id+1] pangenome_map.at(to_string(id)), <0 = key absent */
+    const double *mappability;     /* load_mappabilities() vector (src/load.cpp:6-24) */
+    int64_t n_mappability;
+} orc_graph_t;
+
+/* Decoded GAM: what readGAM keeps per vg::Alignment (src/readGAM.h:37-49). */
+typedef struct orc_alnset {
+    int64_t n_reads;
+    const int64_t *seq_off;   /* [n_reads+1] */
+    const char *seq;          /* a.sequence() */
+    const int64_t *qual_off;  /* [n_reads+1] */
+    const char *qual;         /* a.quality(): raw phred bytes */
+    const int32_t *mapq;      /* a.mapping_quality() */
+    const double *identity;   /* a.identity() */
+    const int64_t *map_off;   /* [n_reads+1] -> mappings */
+    const int64_t *m_node;    /* position.node_id */
+    const int64_t *m_offset;  /* position.offset */
+    const uint8_t *m_rev;     /* position.is_reverse */
+    const int64_t *edit_off;  /* [n_mappings+1] -> edits */
+    const int32_t *e_from;    /* edit.from_length */
+    const int32_t *e_to;      /* edit.to_length */
+    const int64_t *e_seq_off; /* [n_edits+1] */
+    const char *e_seq;        /* edit.sequence */
+} orc_alnset_t;
+
+typedef struct orc_hc_params {
+    double background_error_prob;      /* -e, default 0.0001 (src/HaploCart.cpp:70) */
+    int32_t use_background_error_prob; /* true for -f FASTA input (src/HaploCart.cpp:399) */
+    int32_t is_consensus_fasta;
+} orc_hc_params_t;
+
+/* status codes (the reference would std::terminate / read out of bounds in these cases) */
+enum {
+    ORC_OK = 0,
+    ORC_ERR_NODE = -1,     /* node id not in graph / pangenome_map.at() throws */
+    ORC_ERR_SUBSTR = -2,   /* std::string::substr / insert out_of_range */
+    ORC_ERR_SIZES = -3,    /* mppg_sizes[i] past its end (mapping without edits) */
+    ORC_ERR_TABLE = -4,    /* mappabilities[] index out of range */
+    ORC_ERR_CAP = -5       /* caller buffer too small */
+};
+
+/* a1: reconstruct_graph_sequence (src/vgan_utils.h:6-79). lens[0..2] = |graph_seq|, |read_seq|, #sizes */
+int orc_reconstruct(const orc_graph_t *g, const orc_alnset_t *a, int64_t r,
+                    char *graph_seq, char *read_seq, int32_t *sizes, int64_t cap, int64_t *lens);
+
+/* a2+a3 for one read starting from a zero vector (src/update_likelihood.cpp:19-53,
+ * src/process_mapping.cpp:26-91); out[n_paths] as long double. flags bit0: a Q/mapq >= 100 was clamped. */
+int orc_hc_read(const orc_graph_t *g, const orc_alnset_t *a, int64_t r, const orc_hc_params_t *p,
+                long double *out, int32_t *flags);
+
+/* Per-segment scalars of one read (test aid): S_m (supported sum), U_m (unsupported sum), node id.
+ * Derived by calling the literal a3 on a graph view with one always-supported and one never-supported path. */
+int orc_hc_read_segments(const orc_graph_t *g, const orc_alnset_t *a, int64_t r, const orc_hc_params_t *p,
+                         double *S, double *U, int64_t *node, int64_t cap, int64_t *n_seg);
+
+/* a8: the OpenMP loop of src/HaploCart.cpp:408-421 over reads [r0,r1). final_ld/final_d: [n_paths].
+ * faithful=1 restates the reference literally (unsupported penalty recomputed per path, vectors by value);
+ * faithful=0 is the "hoisted" variant (S_m/U_m once per mapping) -- NOT the reference, same results.
+ * n_bad receives the number of reads whose processing would have terminated the reference. */
+int orc_hc_run(const orc_graph_t *g, const orc_alnset_t *a, int64_t r0, int64_t r1, const orc_hc_params_t *p,
+               int n_threads, int faithful, long double *final_ld, double *final_d, int64_t *n_bad);
+
+/* a9: get_posterior (src/get_posterior.cpp:36-127). Text inputs use the sidecar formats
+ * (graph_paths: one name per line; parents.txt/children.txt: "name tok tok ..." per line).
+ * Output: '\t'-joined "clade\tconfidence(%.17g)\tdepth" records separated by '\n' into out (cap bytes);
+ * conf[] receives the confidences as double; returns number of records or <0. */
+int orc_hc_posterior(const long double *final_vec, int32_t n_paths, const char *path_names_txt,
+                     const char *parents_txt, const char *children_txt, const char *predicted,
+                     char *out, int64_t cap, double *conf, int32_t conf_cap);
+
+/* helpers restated from src/miscfunc.h:180-212, src/haplocart_functions.cpp:81-107, libgab */
+double orc_p_seq_error(int Q);
+double orc_qscore(int Q);
+double orc_p_incorrect_mapping(int Q);
+double orc_background_freq(char c);
+long double orc_oplusnatl(long double x, long double y);
+long double orc_oplusInitnatl(long double x, long double y);
+long double orc_p_obs_base(int pangenome_base, double epsilon, int generations);
+
+/* sidecar loaders restated from src/load.cpp:6-58,283-345 (text already inflated by the caller). */
+int64_t orc_load_mappabilities(const char *txt, double *out, int64_t cap);
+int64_t orc_load_pangenome_map(const char *txt, int32_t *base_by_id, int64_t cap); /* fills base_by_id[node]=coord+1 */
+int64_t orc_load_path_supports(const char *txt, int32_t n_paths, uint8_t *out, int64_t cap_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

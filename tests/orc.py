@@ -1,0 +1,251 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class OrcGraph(C.Structure):
+    _fields_ = [("min_id", C.c_int64), ("max_id", C.c_int64),
+                ("node_seq_off", C.c_void_p), ("node_seq", C.c_void_p),
+                ("n_paths", C.c_int32),
+                ("pathsgo", C.c_void_p), ("pangenome_base", C.c_void_p),
+                ("mappability", C.c_void_p), ("n_mappability", C.c_int64)]
+
+
+class OrcAlnSet(C.Structure):
+    _fields_ = [("n_reads", C.c_int64),
+                ("seq_off", C.c_void_p), ("seq", C.c_void_p),
+                ("qual_off", C.c_void_p), ("qual", C.c_void_p),
+                ("mapq", C.c_void_p), ("identity", C.c_void_p),
+                ("map_off", C.c_void_p), ("m_node", C.c_void_p), ("m_offset", C.c_void_p), ("m_rev", C.c_void_p),
+                ("edit_off", C.c_void_p), ("e_from", C.c_void_p), ("e_to", C.c_void_p),
+                ("e_seq_off", C.c_void_p), ("e_seq", C.c_void_p)]
+
+
+class OrcHcParams(C.Structure):
+    _fields_ = [("background_error_prob", C.c_double),
+                ("use_background_error_prob", C.c_int32),
+                ("is_consensus_fasta", C.c_int32)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h"))]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            build()
+        _lib = C.CDLL(so)
+        _lib.orc_p_seq_error.restype = C.c_double
+        _lib.orc_qscore.restype = C.c_double
+        _lib.orc_p_incorrect_mapping.restype = C.c_double
+        _lib.orc_background_freq.restype = C.c_double
+        _lib.orc_background_freq.argtypes = [C.c_char]
+        _lib.orc_oplusnatl.restype = C.c_longdouble
+        _lib.orc_oplusnatl.argtypes = [C.c_longdouble, C.c_longdouble]
+        _lib.orc_oplusInitnatl.restype = C.c_longdouble
+        _lib.orc_oplusInitnatl.argtypes = [C.c_longdouble, C.c_longdouble]
+        _lib.orc_p_obs_base.restype = C.c_longdouble
+        _lib.orc_p_obs_base.argtypes = [C.c_int, C.c_double, C.c_int]
+        for f in ("orc_load_mappabilities", "orc_load_pangenome_map", "orc_load_path_supports"):
+            getattr(_lib, f).restype = C.c_int64
+    return _lib
+
+
+def _p(arr):
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+class Graph:
+    """Graph view for the oracle. node_seqs: dict id -> forward sequence (bytes)."""
+
+    def __init__(self, node_seqs, n_paths, pathsgo, pangenome_base, mappability):
+        ids = sorted(node_seqs)
+        self.min_id, self.max_id = ids[0], ids[-1]
+        offs = [0]
+        blob = bytearray()
+        for i in range(self.min_id, self.max_id + 1):
+            blob += node_seqs.get(i, b"")
+            offs.append(len(blob))
+        self.node_seq_off = np.asarray(offs, dtype=np.int64)
+        self.node_seq = np.frombuffer(bytes(blob) + b"\0", dtype=np.uint8).copy()
+        self.n_paths = int(n_paths)
+        self.pathsgo = np.ascontiguousarray(pathsgo, dtype=np.uint8)
+        assert self.pathsgo.shape == (self.max_id + 1, self.n_paths)
+        self.pangenome_base = np.ascontiguousarray(pangenome_base, dtype=np.int32)
+        assert self.pangenome_base.shape == (self.max_id + 1,)
+        self.mappability = np.ascontiguousarray(mappability, dtype=np.float64)
+        self.node_seqs = dict(node_seqs)
+        self.c = OrcGraph(self.min_id, self.max_id, _p(self.node_seq_off), _p(self.node_seq), self.n_paths,
+                          _p(self.pathsgo), _p(self.pangenome_base), _p(self.mappability), len(self.mappability))
+
+
+class AlnSet:
+    """Flat arrays from a list of gamio-style alignment dicts."""
+
+    def __init__(self, alns):
+        seq_off, qual_off, map_off, edit_off, e_seq_off = [0], [0], [0], [0], [0]
+        seq, qual, e_seq = bytearray(), bytearray(), bytearray()
+        mapq, ident, m_node, m_offset, m_rev, e_from, e_to = [], [], [], [], [], [], []
+        for a in alns:
+            seq += a["sequence"]
+            seq_off.append(len(seq))
+            qual += a["quality"]
+            qual_off.append(len(qual))
+            mapq.append(a["mapping_quality"])
+            ident.append(a["identity"])
+            for m in a["path"]["mapping"]:
+                m_node.append(m["position"]["node_id"])
+                m_offset.append(m["position"]["offset"])
+                m_rev.append(1 if m["position"]["is_reverse"] else 0)
+                for e in m["edit"]:
+                    e_from.append(e["from_length"])
+                    e_to.append(e["to_length"])
+                    e_seq += e["sequence"]
+                    e_seq_off.append(len(e_seq))
+                edit_off.append(len(e_from))
+            map_off.append(len(m_node))
+        self.n_reads = len(alns)
+        self.seq_off = np.asarray(seq_off, np.int64)
+        self.seq = np.frombuffer(bytes(seq) + b"\0", np.uint8).copy()
+        self.qual_off = np.asarray(qual_off, np.int64)
+        self.qual = np.frombuffer(bytes(qual) + b"\0", np.uint8).copy()
+        self.mapq = np.asarray(mapq, np.int32)
+        self.identity = np.asarray(ident, np.float64)
+        self.map_off = np.asarray(map_off, np.int64)
+        self.m_node = np.asarray(m_node, np.int64)
+        self.m_offset = np.asarray(m_offset, np.int64)
+        self.m_rev = np.asarray(m_rev, np.uint8)
+        self.edit_off = np.asarray(edit_off, np.int64)
+        self.e_from = np.asarray(e_from, np.int32)
+        self.e_to = np.asarray(e_to, np.int32)
+        self.e_seq_off = np.asarray(e_seq_off, np.int64)
+        self.e_seq = np.frombuffer(bytes(e_seq) + b"\0", np.uint8).copy()
+        self.c = OrcAlnSet(self.n_reads, _p(self.seq_off), _p(self.seq), _p(self.qual_off), _p(self.qual),
+                           _p(self.mapq), _p(self.identity), _p(self.map_off), _p(self.m_node), _p(self.m_offset),
+                           _p(self.m_rev), _p(self.edit_off), _p(self.e_from), _p(self.e_to), _p(self.e_seq_off),
+                           _p(self.e_seq))
+
+    @classmethod
+    def from_arrays(cls, **kw):
+        """Build from the product's flat alignment-set arrays (same field names)."""
+        self = cls.__new__(cls)
+        self.n_reads = int(kw["n_reads"])
+        for k in ("seq_off", "qual_off", "map_off", "m_node", "m_offset", "edit_off", "e_seq_off"):
+            setattr(self, k, np.ascontiguousarray(kw[k], np.int64))
+        for k in ("seq", "qual", "m_rev", "e_seq"):
+            v = np.ascontiguousarray(kw[k], np.uint8)
+            setattr(self, k, np.concatenate([v, np.zeros(1, np.uint8)]))
+        for k in ("mapq", "e_from", "e_to"):
+            setattr(self, k, np.ascontiguousarray(kw[k], np.int32))
+        self.identity = np.ascontiguousarray(kw["identity"], np.float64)
+        self.c = OrcAlnSet(self.n_reads, _p(self.seq_off), _p(self.seq), _p(self.qual_off), _p(self.qual),
+                           _p(self.mapq), _p(self.identity), _p(self.map_off), _p(self.m_node), _p(self.m_offset),
+                           _p(self.m_rev), _p(self.edit_off), _p(self.e_from), _p(self.e_to), _p(self.e_seq_off),
+                           _p(self.e_seq))
+        return self
+
+
+def hc_params(background_error_prob=0.0001, use_background_error_prob=False, is_consensus_fasta=False):
+    return OrcHcParams(background_error_prob, int(use_background_error_prob), int(is_consensus_fasta))
+
+
+def reconstruct(g, a, r, cap=4096):
+    gs = C.create_string_buffer(cap)
+    rs = C.create_string_buffer(cap)
+    sizes = np.zeros(cap, np.int32)
+    lens = np.zeros(3, np.int64)
+    rc = lib().orc_reconstruct(C.byref(g.c), C.byref(a.c), C.c_int64(r), gs, rs, _p(sizes), C.c_int64(cap), _p(lens))
+    if rc != 0:
+        return rc, None, None, None
+    return 0, gs.raw[:lens[0]], rs.raw[:lens[1]], sizes[:lens[2]].tolist()
+
+
+def hc_read(g, a, r, params=None):
+    params = params or hc_params()
+    out = np.zeros(g.n_paths, np.longdouble)
+    flags = C.c_int32(0)
+    rc = lib().orc_hc_read(C.byref(g.c), C.byref(a.c), C.c_int64(r), C.byref(params), _p(out), C.byref(flags))
+    return rc, out, flags.value
+
+
+def hc_read_segments(g, a, r, params=None, cap=4096):
+    params = params or hc_params()
+    S = np.zeros(cap)
+    U = np.zeros(cap)
+    node = np.zeros(cap, np.int64)
+    n = C.c_int64(0)
+    rc = lib().orc_hc_read_segments(C.byref(g.c), C.byref(a.c), C.c_int64(r), C.byref(params), _p(S), _p(U), _p(node),
+                                    C.c_int64(cap), C.byref(n))
+    return rc, S[:n.value].copy(), U[:n.value].copy(), node[:n.value].copy()
+
+
+def hc_run(g, a, params=None, r0=0, r1=None, n_threads=1, faithful=True):
+    params = params or hc_params()
+    r1 = a.n_reads if r1 is None else r1
+    fld = np.zeros(g.n_paths, np.longdouble)
+    fd = np.zeros(g.n_paths, np.float64)
+    bad = C.c_int64(0)
+    rc = lib().orc_hc_run(C.byref(g.c), C.byref(a.c), C.c_int64(r0), C.c_int64(r1), C.byref(params),
+                          C.c_int(n_threads), C.c_int(int(faithful)), _p(fld), _p(fd), C.byref(bad))
+    assert rc == 0
+    return fld, fd, bad.value
+
+
+def hc_posterior(final_vec, path_names, parents_txt, children_txt, predicted):
+    fv = np.ascontiguousarray(final_vec, np.longdouble)
+    out = C.create_string_buffer(1 << 20)
+    conf = np.zeros(4096)
+    n = lib().orc_hc_posterior(_p(fv), C.c_int32(len(fv)), "\n".join(path_names).encode() + b"\n",
+                               parents_txt.encode(), children_txt.encode(), predicted.encode(), out,
+                               C.c_int64(1 << 20), _p(conf), C.c_int32(4096))
+    if n < 0:
+        raise RuntimeError("orc_hc_posterior rc=%d" % n)
+    recs = [ln.split("\t") for ln in out.value.decode().splitlines()]
+    return [(r[0], float(r[1]), int(r[2])) for r in recs]
+
+
+# ---------------------------------------------------------------- GFA (test-side reader)
+def read_gfa(path):
+    node_seqs, paths = {}, []
+    with open(path) as f:
+        for line in f:
+            t = line.rstrip("\n").split("\t")
+            if t[0] == "S":
+                node_seqs[int(t[1])] = t[2].encode()
+            elif t[0] == "P":
+                steps = [(int(s[:-1]), s[-1] == "-") for s in t[2].split(",")]
+                paths.append((t[1], steps))
+    return node_seqs, paths
+
+
+def graph_from_gfa(path, pangenome_base=None, mappability=None):
+    node_seqs, paths = read_gfa(path)
+    max_id = max(node_seqs)
+    P = len(paths)
+    pathsgo = np.zeros((max_id + 1, P), np.uint8)
+    for j, (_, steps) in enumerate(paths):
+        for nid, _rev in steps:
+            pathsgo[nid, j] = 1
+    if pangenome_base is None:
+        # coordinate = 1 + running offset of the node in id order (a stand-in for parsed_pangenome_mapping)
+        pangenome_base = np.full(max_id + 1, -1, np.int32)
+        pos = 0
+        for i in sorted(node_seqs):
+            pangenome_base[i] = pos + 1
+            pos += len(node_seqs[i])
+    if mappability is None:
+        mappability = np.ones(int(max(pangenome_base)) + 2)
+    return Graph(node_seqs, P, pathsgo, pangenome_base, mappability), [p[0] for p in paths]

@@ -1,0 +1,135 @@
+"""Closed-form known-answer tests for the HaploCart oracle, checked with mpmath.
+The reference pins no numeric likelihood, so these anchor the restated arithmetic (Q1-Q5, Q10)."""
+import mpmath as mp
+import numpy as np
+import pytest
+
+import orc
+
+mp.mp.dps = 40
+BG = {"A": mp.mpf("0.27532"), "C": mp.mpf("0.30044"), "G": mp.mpf("0.16644"), "T": mp.mpf("0.25780")}
+
+
+def one_node_graph(seq, coord, n_map=17000, mappability=1.0):
+    pathsgo = np.zeros((2, 2), np.uint8)
+    pathsgo[1, 0] = 1  # path 0 supports node 1, path 1 does not
+    pb = np.array([-1, coord], np.int32)
+    return orc.Graph({1: seq}, 2, pathsgo, pb, np.full(n_map, mappability))
+
+
+def aln(seq, qual, mapq=60, node=1, edits=None, rev=False):
+    edits = edits or [{"from_length": len(seq), "to_length": len(seq), "sequence": b""}]
+    return {"sequence": seq, "quality": bytes(qual), "mapping_quality": mapq, "identity": 1.0, "name": b"r",
+            "path": {"name": b"", "mapping": [{"position": {"node_id": node, "offset": 0, "is_reverse": rev},
+                                                 "edit": edits, "rank": 1}]}}
+
+
+def expected_supported(read, graph, quals, mu, mapq=60, mappability=1):
+    pcm = (1 - mp.mpf(10) ** (-mp.mpf(mapq) / 10)) * mappability
+    match = (1 - 30 * mp.mpf(mu)) ** 8
+    tot = mp.mpf(0)
+    for r, g, q in zip(read, graph, quals):
+        e = mp.mpf("0.25") if q <= 2 else mp.mpf(10) ** (-mp.mpf(q) / 10)
+        eps = e if r == g else 1 - e
+        tot += mp.log((1 - pcm) * BG[r] + pcm * match * (1 - eps))
+    return tot
+
+
+def test_survey_kats():
+    # protein-coding coordinate (mu = 0 by integer division, Q2)
+    g = one_node_graph(b"ACGT", 4000)
+    a = orc.AlnSet([aln(b"ACGT", [40] * 4)])
+    rc, ll, flags = orc.hc_read(g, a, 0)
+    assert rc == 0 and flags == 0
+    assert float(ll[0]) == pytest.approx(-4.03019902453559e-4, rel=1e-12)
+    assert float(ll[1]) == pytest.approx(-36.8413614879047, rel=1e-13)
+    assert float(ll[0]) == pytest.approx(float(expected_supported("ACGT", "ACGT", [40] * 4, 0)), rel=1e-13)
+    # HVS-I coordinate 57..372
+    g = one_node_graph(b"ACGT", 100)
+    rc, ll, _ = orc.hc_read(g, a, 0)
+    assert float(ll[0]) == pytest.approx(-5.60722331616443e-4, rel=1e-12)
+    assert float(ll[0]) == pytest.approx(float(expected_supported("ACGT", "ACGT", [40] * 4, "1.64273e-7")), rel=1e-13)
+    # a mismatching A column at mu = 0 (graph C, read A via a substitution edit)
+    g = one_node_graph(b"C", 4000)
+    a = orc.AlnSet([aln(b"A", [40], edits=[{"from_length": 1, "to_length": 1, "sequence": b"A"}])])
+    rc, ll, _ = orc.hc_read(g, a, 0)
+    assert float(ll[0]) == pytest.approx(-9.20759195234389, rel=1e-13)
+
+
+@pytest.mark.parametrize("coord,mu", [(10, "2.29640e-8"), (400, "2.29640e-8"), (16400, "1.54555e-8"), (600, "6.91285e-9"),
+                                      (1000, "6.91285e-9"), (16100, "2.48537e-8"), (5000, 0), (3306, "2.48537e-8")])
+def test_regions(coord, mu):
+    g = one_node_graph(b"ACGTAC", coord, mappability=0.7)
+    quals = [2, 3, 17, 40, 41, 0]
+    a = orc.AlnSet([aln(b"ACGTAC", quals, mapq=37)])
+    rc, ll, _ = orc.hc_read(g, a, 0)
+    assert rc == 0
+    exp = expected_supported("ACGTAC", "ACGTAC", quals, mu, mapq=37, mappability=mp.mpf("0.7"))
+    assert float(ll[0]) == pytest.approx(float(exp), rel=1e-13)
+    # unsupported: sum over the whole quality window (Q3), Q<=2 -> 0.25 (Q10)
+    unsup = sum(mp.log(mp.mpf("0.25") if q <= 2 else mp.mpf(10) ** (-mp.mpf(q) / 10)) for q in quals)
+    assert float(ll[1]) == pytest.approx(float(unsup), rel=1e-13)
+
+
+def test_q4_q5_window_and_whole_read_compare():
+    """Two mappings: the second segment compares its graph bases with the START of the read (Q4) and its
+    unsupported penalty runs |algnseq| entries from its offset, zero-padded past the end (Q5)."""
+    pathsgo = np.zeros((3, 2), np.uint8)
+    pathsgo[1, 0] = pathsgo[2, 0] = 1
+    g = orc.Graph({1: b"ACG", 2: b"TTA"}, 2, pathsgo, np.array([-1, 4000, 4003], np.int32), np.ones(17000))
+    quals = [30, 31, 32, 33, 34, 35]
+    al = {"sequence": b"ACGTTA", "quality": bytes(quals), "mapping_quality": 60, "identity": 1.0, "name": b"r",
+          "path": {"name": b"", "mapping": [
+              {"position": {"node_id": 1, "offset": 0, "is_reverse": False},
+               "edit": [{"from_length": 3, "to_length": 3, "sequence": b""}], "rank": 1},
+              {"position": {"node_id": 2, "offset": 0, "is_reverse": False},
+               "edit": [{"from_length": 3, "to_length": 3, "sequence": b""}], "rank": 2}]}}
+    a = orc.AlnSet([al])
+    rc, S, U, node = orc.hc_read_segments(g, a, 0)
+    assert rc == 0 and node.tolist() == [1, 2]
+    s0 = expected_supported("ACG", "ACG", quals[0:3], 0)
+    s1 = expected_supported("ACG", "TTA", quals[3:6], 0)  # read bases from the read start, qualities offset
+    assert S[0] == pytest.approx(float(s0), rel=1e-13)
+    assert S[1] == pytest.approx(float(s1), rel=1e-13)
+    lq = lambda q: mp.log(mp.mpf("0.25") if q <= 2 else mp.mpf(10) ** (-mp.mpf(q) / 10))
+    assert U[0] == pytest.approx(float(sum(lq(q) for q in quals)), rel=1e-13)
+    assert U[1] == pytest.approx(float(sum(lq(q) for q in quals[3:]) + 3 * mp.log(mp.mpf("0.25"))), rel=1e-13)
+    rc, ll, _ = orc.hc_read(g, a, 0)
+    assert float(ll[0]) == pytest.approx(S[0] + S[1], rel=1e-13)
+    assert float(ll[1]) == pytest.approx(U[0] + U[1], rel=1e-13)
+
+
+def test_sticky_background_error_prob():
+    g = one_node_graph(b"ACGT", 4000)
+    a = orc.AlnSet([aln(b"ACGT", [40, 93, 40, 40])])  # Q >= 90 flips to the background error probability
+    rc, ll, _ = orc.hc_read(g, a, 0)
+    pcm = 1 - mp.mpf(10) ** -6
+    bep = mp.mpf("0.0001")
+    exp = sum(mp.log((1 - pcm) * BG[c] + pcm * (1 - bep)) for c in "ACGT")
+    assert float(ll[0]) == pytest.approx(float(exp), rel=1e-12)
+
+
+def test_consensus_fasta_mode():
+    g = one_node_graph(b"ACGT", 100)
+    a = orc.AlnSet([aln(b"ACTT", [40] * 4, edits=[{"from_length": 2, "to_length": 2, "sequence": b""},
+                                                    {"from_length": 1, "to_length": 1, "sequence": b"T"},
+                                                    {"from_length": 1, "to_length": 1, "sequence": b""}])])
+    p = orc.hc_params(background_error_prob=0.001, use_background_error_prob=True, is_consensus_fasta=True)
+    rc, S, U, node = orc.hc_read_segments(g, a, 0, p)
+    # Q6: one mapping with three edits -> only mppg_sizes[0] = 2 columns are scored
+    match = (1 - 30 * mp.mpf("1.64273e-7")) ** 8
+    bep = mp.mpf("0.001")
+    exp = 2 * mp.log((1 - bep) * match * (1 - bep))
+    assert len(S) == 1 and S[0] == pytest.approx(float(exp), rel=1e-13)
+
+
+def test_helpers():
+    L = orc.lib()
+    assert L.orc_p_seq_error(2) == 0.25 and L.orc_p_seq_error(3) == 10 ** (-3 * 0.1)
+    assert L.orc_qscore(0) == 0.25 and L.orc_qscore(1) == 0.25 and L.orc_qscore(2) == 0.25
+    assert L.orc_qscore(40) == pytest.approx(1e-4, rel=1e-15)
+    assert L.orc_background_freq(b"N") == 0.25 and L.orc_background_freq(b"G") == 0.16644
+    # oplusInitnatl: 0 means "no value" (Q11)
+    assert float(L.orc_oplusInitnatl(0.0, -3.0)) == -3.0
+    assert float(L.orc_oplusInitnatl(-3.0, 0.0)) == pytest.approx(float(mp.log(mp.e ** -3 + 1)), rel=1e-15)
+    assert float(L.orc_oplusnatl(-1000.0, -1001.0)) == pytest.approx(float(-1000 + mp.log1p(mp.e ** -1)), rel=1e-15)
