@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/sec through the HaploCart posterior path on MI355X (BASELINE.json metric).
+
+A "step" is one complete pass of the hot path over one batch of synthetic reads already resident in HBM:
+reset accumulators -> per-read likelihood kernels over the batch -> final_vec[P] on the device
+(-> RCCL sum-reduce of the P doubles to rank 0 when N > 1).  Workload at N=1: BASELINE configs[1]
+(1M synthetic 150 bp reads against the hcfiles-shaped graph: 11821 nodes, 5179 paths); with N ranks each rank
+holds its own 1M-read shard (weak scaling; reads shard with no data-path collective).
+
+One JSON line on rank 0.  `roofline` is the dominant kernel's ALGORITHMIC bytes per launch / its mean launch
+duration (HIP events on the launch stream, measured live by the library) against the 8 TB/s HBM peak.
+`cpu_baseline` is the CPU oracle (a port: the reference cannot be built here) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--mode", choices=["node_weights", "per_read", "per_read_dense"], default="node_weights")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x76676131)
+    ap.add_argument("--no-parity", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(graph, alns, budget_s):
+    """The oracle's literal restatement of the reference loop (OpenMP over reads, per-read vector, critical
+    accumulate: src/HaploCart.cpp:408-421) on the host cores, on as many reads as fit the budget."""
+    import orc
+    import util
+    og, oa = util.orc_graph_from_product(graph), util.orc_alnset_from_product(alns)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    done, t_used = 0, 0.0
+    chunk = cores
+    t0 = time.perf_counter()
+    while t_used < budget_s and done < alns.n_reads:
+        n = min(chunk, alns.n_reads - done)
+        orc.hc_run(og, oa, r0=done, r1=done + n, n_threads=cores, faithful=True)
+        done += n
+        t_used = time.perf_counter() - t0
+        if t_used < budget_s / 4:
+            chunk *= 2
+    faithful = done / t_used
+    # hoisted variant (S_m/U_m once per mapping; NOT the reference's cost profile) on a larger sample
+    n_h = min(alns.n_reads, 20000)
+    t0 = time.perf_counter()
+    orc.hc_run(og, oa, r0=0, r1=n_h, n_threads=cores, faithful=False)
+    hoisted = n_h / (time.perf_counter() - t0)
+    return {"value": faithful, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d of the workload's reads, literal reference loops (oracle, long double, OpenMP x%d)" % (done, cores),
+            "hoisted_variant_reads_per_s": hoisted}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vgan_amd import haplocart as hc
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic workload (same graph on every rank, a different read shard per rank)
+    graph = hc.synth_graph(seed=args.seed)
+    alns = hc.synth_reads(graph, args.reads, seed=args.seed + 1000003 * rank, read_len=args.read_len)
+    hb = hc.HostBatch(graph, alns)
+    db = hc.DeviceBatch(hb, dev)
+    algo = hb.algorithmic_bytes(graph.n_paths)
+    n_reads, n_seg = hb.n_reads, hb.n_segments
+    ctx = hc.HcContext(graph, device=local_rank)
+    ctx.use_torch_stream()
+    mode = {"node_weights": hc.MODE_NODE_WEIGHTS, "per_read": hc.MODE_PER_READ, "per_read_dense": hc.MODE_PER_READ_DENSE}[args.mode]
+    ctx.set_mode(mode)
+    final_dev = torch.zeros(graph.n_paths, dtype=torch.float64, device=dev)
+
+    def step():
+        ctx.reset()
+        ctx.accumulate(db)
+        ctx.finalize_device(final_dev)
+        if world > 1:
+            dist.reduce(final_dev, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 41 KB of per-path sums
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(n_reads)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_reads = float(tot.item())
+    else:
+        total_reads = float(n_reads)
+
+    # ---- parity spot check outside the timed region (oracle = checker)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        import orc
+        import util
+        n_chk = 64
+        sub = hc.HostBatch(graph, alns, 0, n_chk)
+        ctx.reset()
+        ctx.accumulate(sub)
+        got = ctx.finalize()
+        og, oa = util.orc_graph_from_product(graph), util.orc_alnset_from_product(alns)
+        _, ref, _ = orc.hc_run(og, oa, r0=0, r1=n_chk, n_threads=8, faithful=False)
+        parity = {"reads": n_chk, "max_rel_err_vs_oracle": float(util.rel_err(got, ref)), "tolerance": 1e-6}
+
+    if rank == 0:
+        # dominant kernel and its algorithmic bytes per launch (DESIGN.md "Roofline accounting")
+        if mode == hc.MODE_NODE_WEIGHTS:
+            kname, kbytes = "segment", algo["node_weights"]
+        else:
+            kname, kbytes = "sweep_segments", n_seg * (8 * ((graph.n_paths + 63) // 64) + 4 + 8)
+        k_ms, k_n = prof[kname]
+        avg_ms = k_ms / max(k_n, 1)
+        achieved = kbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "reads/sec (whole node) through HaploCart posterior path, 150bp",
+            "value": total_reads * args.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "HaploCart %d synthetic %dbp reads per GPU vs hcfiles-shaped mtDNA graph (11821 nodes, 5179 paths), posteriors diffed vs CPU"
+                                   % (args.reads, args.read_len),
+                       "reads_per_gpu": n_reads, "segments_per_read": n_seg / max(n_reads, 1), "mode": args.mode,
+                       "sharding": "reads x%d, RCCL reduce of final_vec[5179]" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": {"segment": "hc_segment_kernel", "sweep_segments": "hc_sweep_kernel"}[kname],
+                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": avg_ms, "launches": k_n},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "parity": parity,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(graph, alns, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

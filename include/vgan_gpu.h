@@ -1,0 +1,239 @@
+/*
+ * include/vgan_gpu.h -- C-ABI of the MI355X-native per-read likelihood engine for vgan.
+ *
+ * The reference (grenaud/vgan) has no plugin / FFI layer: its hot path is reached through internal C++
+ * calls.  Each entry point below replaces one of those call sites (paths relative to the reference's src/):
+ *
+ *   vgan_hc_*      Haplocart::update() loop + accumulate     HaploCart.cpp:408-421, HaploCart.h:46-50
+ *                  (update_likelihood.cpp:19-53, process_mapping.cpp:4-91, get_p_obs_base.cpp:3-69)
+ *   vgan_hc_posterior   Haplocart::get_posterior()           HaploCart.cpp:460, get_posterior.cpp:36-127
+ *   vgan_aln_* / vgan_hc_flatten   readGAM() + reconstruct_graph_sequence() front half
+ *                                                            readGAM.h:20-68, vgan_utils.h:6-79,
+ *                                                            update_likelihood.cpp:28-45
+ *   vgan_graph_*   readPathHandleGraph() + load_*()          readPathHandleGraph.cpp:14-37, load.cpp:6-58,283-345
+ *
+ * Plain pointers and sizes only; every function returns 0 on success or a negative VGAN_E* code and never
+ * throws or aborts (the reference std::terminate()s on malformed reads: here they are counted and skipped).
+ * One context per GPU; contexts are independent; a context is not re-entrant.
+ * There is NO CPU fallback: without a HIP device every compute entry point returns VGAN_ENODEV.
+ */
+#ifndef VGAN_GPU_H
+#define VGAN_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGAN_ABI_VERSION 1
+
+enum {
+    VGAN_OK = 0,
+    VGAN_EINVAL = -1,  /* bad argument */
+    VGAN_ENODEV = -2,  /* no HIP device / HIP runtime error (see vgan_last_error) */
+    VGAN_ENOMEM = -3,
+    VGAN_EIO = -4,     /* file could not be read / parsed */
+    VGAN_ERANGE = -5,  /* value outside what the device layout can hold */
+    VGAN_ESTATE = -6   /* call order violated */
+};
+
+const char *vgan_last_error(void); /* thread-local message of the last failing call */
+int vgan_abi_version(void);
+int vgan_device_count(void);       /* number of visible HIP devices (0 if none) */
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph (host side).  Replaces bdsg::ODGI + NodeInfo[] + the hcfiles sidecars.
+ * .og (ODGI/sdsl binary) cannot be parsed without libbdsg: the graph is read from GFA (S and P lines).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_graph vgan_graph; /* opaque */
+
+typedef struct vgan_graph_view {
+    int64_t min_id, max_id;         /* node ids present: min..max (gaps allowed, empty sequence) */
+    const int64_t *node_seq_off;    /* [max_id+2], indexed by NODE ID (row 0..min_id-1 empty) */
+    const char *node_seq;           /* forward strand, concatenated */
+    uint32_t n_paths;               /* P */
+    uint32_t mask_words;            /* W = ceil(P/64) */
+    const uint64_t *mask;           /* [(max_id+1)*W] bit p of row i = path_supports[i][p] (load.cpp:283-300) */
+    const int32_t *pangenome_base;  /* [max_id+1] 1-based rCRS coordinate of the node (load.cpp:27-41), -1 absent */
+    const double *mappability;      /* load_mappabilities() vector (load.cpp:6-24) */
+    uint64_t n_mappability;
+    const char *path_names;         /* P names, '\n' separated (load.cpp:43-58) */
+    const char *parents_txt;        /* parents.txt / children.txt contents (load.cpp:303-345), may be "" */
+    const char *children_txt;
+} vgan_graph_view;
+
+/* Load <dir>/graph.gfa (or the path given) and, when present in hcfiles_dir, the sidecars path_supports,
+ * parsed_pangenome_mapping, mappability.tsv, graph_paths, parents.txt, children.txt (plain or .gz).
+ * Missing path_supports => mask derived from the GFA P lines; missing pangenome mapping => running
+ * coordinate in node-id order; missing mappability => 1.0. */
+int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vgan_graph **out);
+/* Build from arrays the caller already holds (copied). */
+int vgan_graph_from_arrays(const vgan_graph_view *v, vgan_graph **out);
+int vgan_graph_view_get(const vgan_graph *g, vgan_graph_view *out);
+int vgan_graph_write(const vgan_graph *g, const char *dir); /* graph.gfa + sidecars, the formats above */
+void vgan_graph_free(vgan_graph *g);
+
+/* ------------------------------------------------------------------------------------------------
+ * Alignment set (host side) = what readGAM keeps of each vg::Alignment (readGAM.h:37-49).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_alnset vgan_alnset; /* opaque */
+
+typedef struct vgan_alnset_view {
+    int64_t n_reads;
+    const int64_t *seq_off;   /* [n_reads+1] */
+    const char *seq;
+    const int64_t *qual_off;  /* [n_reads+1] */
+    const char *qual;         /* raw phred bytes */
+    const int32_t *mapq;
+    const double *identity;
+    const int64_t *name_off;  /* [n_reads+1] */
+    const char *name;
+    const int64_t *map_off;   /* [n_reads+1] */
+    const int64_t *m_node;
+    const int64_t *m_offset;
+    const uint8_t *m_rev;
+    const int64_t *edit_off;  /* [n_mappings+1] */
+    const int32_t *e_from;
+    const int32_t *e_to;
+    const int64_t *e_seq_off; /* [n_edits+1] */
+    const char *e_seq;
+} vgan_alnset_view;
+
+/* GAM = gzip/BGZF stream of groups {varint count, count x {varint len, bytes}}, first item the tag "GAM",
+ * messages = protobuf vg.Alignment (field numbers: SURVEY.md 8b).  keep_unmapped=0 drops identity==0 reads
+ * exactly as readGAM.h:47 does. */
+int vgan_aln_read_gam(const char *path, int keep_unmapped, vgan_alnset **out);
+int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped, vgan_alnset **out);
+int vgan_aln_from_arrays(const vgan_alnset_view *v, vgan_alnset **out);
+int vgan_aln_write_gam(const vgan_alnset *a, const char *path, int group_size);
+int vgan_aln_view_get(const vgan_alnset *a, vgan_alnset_view *out);
+void vgan_aln_free(vgan_alnset *a);
+
+/* ------------------------------------------------------------------------------------------------
+ * HaploCart batch: SoA produced by the front half (a1 + the slicing of update_likelihood.cpp:33-45).
+ * Segment m of a read is mapping m: {node, start = position_in_read, len = |graph_seq.substr(start, mppg_sizes[m])|}.
+ * The kernel compares graph_seq[col_off+start+j] with algnseq[col_off+j] (sic: from the read start,
+ * update_likelihood.cpp:46) using quality qual[qual_off+start+j].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_hc_batch {
+    uint32_t n_reads;
+    uint32_t n_segments;
+    uint64_t n_cols;              /* bytes in graph_seq / algnseq */
+    uint64_t n_qual;              /* bytes in qual */
+    const uint32_t *read_seg_off; /* [n_reads+1] */
+    const uint32_t *read_col_off; /* [n_reads+1] region of the read in graph_seq/algnseq (zero padded) */
+    const uint32_t *read_qual_off;/* [n_reads+1] */
+    const uint16_t *read_algn_len;/* [n_reads] |algnseq| (= quality window length, update_likelihood.cpp:40) */
+    const uint8_t *read_mapq;     /* [n_reads] mapping quality, clamped to 99 */
+    const uint32_t *seg_node;     /* [n_segments] node id */
+    const uint16_t *seg_start;    /* [n_segments] */
+    const uint16_t *seg_len;      /* [n_segments] */
+    const uint8_t *graph_seq;     /* [n_cols] ASCII incl. 'S' softclip and '-' gap marks */
+    const uint8_t *algnseq;       /* [n_cols] ASCII path_string with '-' at deletions */
+    const uint8_t *qual;          /* [n_qual] raw phred */
+    int32_t on_device;            /* 0: host pointers (copied by accumulate); 1: device pointers (zero copy) */
+    int32_t reserved;
+} vgan_hc_batch;
+
+typedef struct vgan_hc_host_batch vgan_hc_host_batch; /* opaque owner of a host-side batch */
+
+typedef struct vgan_hc_flatten_stats {
+    int64_t n_in, n_out;
+    int64_t n_unmapped;   /* identity < 1e-10 (HaploCart.cpp:410) */
+    int64_t n_bad;        /* reads on which the reference would std::terminate (unknown node, bad substr, ...) */
+    int64_t n_clamped;    /* mapq >= 100 clamped (reference reads out of bounds) */
+    int64_t n_segments;
+    int64_t n_cols;
+} vgan_hc_flatten_stats;
+
+/* reads [r0, r1) of the alignment set -> batch.  n_threads <= 0: all hardware threads. */
+int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
+                    vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
+int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out);
+void vgan_hc_host_batch_free(vgan_hc_host_batch *b);
+/* a1 on its own, for the reconstruction KATs: strings are NUL terminated into caller buffers of cap bytes. */
+int vgan_reconstruct(const vgan_graph *g, const vgan_alnset *a, int64_t r, char *graph_seq, char *read_seq,
+                     int32_t *mppg_sizes, int64_t cap, int64_t *lens /* [3] */);
+
+/* ------------------------------------------------------------------------------------------------
+ * HaploCart device context.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_hc_ctx vgan_hc_ctx; /* opaque */
+
+typedef struct vgan_hc_params {
+    double background_error_prob;      /* -e (HaploCart.cpp:70,105-113) */
+    int32_t use_background_error_prob; /* set for -f consensus FASTA (HaploCart.cpp:397-400) */
+    int32_t is_consensus_fasta;
+} vgan_hc_params;
+
+enum {
+    /* ll[p] accumulated through per-node weights: W[node] += S_m - U_m, then one bitmask pass
+     * (SURVEY.md 8a "K1 algebra"); same sums, O(R*M) instead of O(R*M*P). Default. */
+    VGAN_HC_MODE_NODE_WEIGHTS = 0,
+    /* every segment streams its 8*ceil(P/64)-byte mask row and updates all P accumulators
+     * (the reference's per-read x per-path loop, process_mapping.cpp:54-88). */
+    VGAN_HC_MODE_PER_READ = 1,
+    /* as PER_READ but without skipping mask tiles that are all-supported: every row's words are applied
+     * (data-independent cost; the figure the dense roofline is quoted on). */
+    VGAN_HC_MODE_PER_READ_DENSE = 2
+};
+
+int vgan_hc_create(const vgan_graph_view *graph, const vgan_hc_params *params, int device, vgan_hc_ctx **out);
+int vgan_hc_set_stream(vgan_hc_ctx *c, void *hip_stream); /* NULL = the context's own stream */
+int vgan_hc_set_mode(vgan_hc_ctx *c, int mode);
+int vgan_hc_reset(vgan_hc_ctx *c);                         /* zero the accumulators */
+/* Asynchronous on the context's stream: adds the batch's reads into the device accumulators. */
+int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *batch);
+/* Per-segment scalars of a batch (test / debug aid): S_m, U_m as the kernel computes them. Host outputs. */
+int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *batch, double *S, double *U);
+/* Per-read log-likelihood vectors (the value Haplocart::update returns), [n_reads*n_paths] host doubles. */
+int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *batch, double *out);
+/* final_vec[P] (HaploCart.cpp:420) of everything accumulated so far. d_out: device double[P], filled
+ * asynchronously on the stream (hand it to RCCL); out: host double[P] (synchronises). Either may be NULL. */
+int vgan_hc_finalize(vgan_hc_ctx *c, double *d_out, double *out);
+int vgan_hc_synchronize(vgan_hc_ctx *c);
+void vgan_hc_destroy(vgan_hc_ctx *c);
+
+/* Per-kernel device timing with HIP events on the context's stream (bench.py's roofline figure).
+ * Slots: 0 segment kernel, 1 per-segment mask sweep, 2 per-node mask sweep, 3 finish. */
+enum { VGAN_HC_K_SEGMENT = 0, VGAN_HC_K_SWEEP_SEG = 1, VGAN_HC_K_SWEEP_NODE = 2, VGAN_HC_K_FINISH = 3, VGAN_HC_K_COUNT = 4 };
+int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable);  /* also clears the counters */
+/* synchronises the stream; ms[i] = summed device time of kernel i, launches[i] = number of launches timed */
+int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[4], uint64_t launches[4]);
+
+/* get_posterior (get_posterior.cpp:87-127) on the device: log-sum-exp over the P paths and over the strict
+ * descendants of each ancestor of `predicted`.  clades: '\n'-joined names into clade_buf; conf[i] beside it.
+ * Returns the number of records (>= 1) or a negative error. */
+int vgan_hc_posterior(vgan_hc_ctx *c, const double *final_vec /* host [P] */, const char *predicted,
+                      char *clade_buf, int64_t clade_cap, double *conf, int32_t conf_cap);
+/* argmax with the reference's first-maximum tie rule (std::max_element, HaploCart.cpp:423). */
+int vgan_hc_argmax(const double *final_vec, uint32_t n_paths);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic inputs of the published shape: hcfiles-like graph + reads.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_synth_graph_cfg {
+    uint64_t seed;
+    uint32_t genome_len;  /* 16569 */
+    uint32_t n_nodes;     /* 11821 */
+    uint32_t n_paths;     /* 5179 */
+} vgan_synth_graph_cfg;
+
+typedef struct vgan_synth_reads_cfg {
+    uint64_t seed;
+    uint64_t n_reads;
+    uint32_t read_len;       /* 150 */
+    double indel_rate;       /* 0.005 reads with a 1-3 bp indel */
+    double softclip_rate;    /* 0.01 reads with a 5-20 bp softclip */
+    double low_mapq_rate;    /* 0.1 reads with mapq U{0..59}, else 60 */
+    int32_t errors;          /* 1: substitutions with prob 10^(-Q/10) */
+} vgan_synth_reads_cfg;
+
+int vgan_synth_hc_graph(const vgan_synth_graph_cfg *cfg, vgan_graph **out);
+int vgan_synth_hc_reads(const vgan_graph *g, const vgan_synth_reads_cfg *cfg, vgan_alnset **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,226 @@
+"""GPU parity tests of the HaploCart path (run with -m gpu on an MI355X).  Everything goes through the C-ABI
+(libvgan_gpu.so); the oracle (oracle/liboracle.so) is the checker.  Tolerance: 1e-6 relative is the bar
+BASELINE.json's north_star states; these tests hold the device path to 1e-9 (fp64 vs long double)."""
+import os
+
+import numpy as np
+import pytest
+
+import gamio
+import orc
+import util
+from vgan_amd import haplocart as hc
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def toy(golden_dir):
+    d = os.path.join(golden_dir, "reconstruct")
+    g = hc.Graph.load(os.path.join(d, "target_graph.gfa"))
+    a = hc.AlnSet.read_gam(os.path.join(d, "test_reads.gam"))
+    return g, a
+
+
+def check_final(ctx, batch, og, oa, faithful, modes=(hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ, hc.MODE_PER_READ_DENSE)):
+    _, ref, bad = orc.hc_run(og, oa, n_threads=8, faithful=faithful)
+    for mode in modes:
+        ctx.reset()
+        ctx.set_mode(mode)
+        ctx.accumulate(batch)
+        got = ctx.finalize()
+        assert util.rel_err(got, ref) < RTOL, (mode, util.rel_err(got, ref))
+    return ref
+
+
+def test_toy_graph_segments_reads_final(golden_dir):
+    g, a = toy(golden_dir)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    b = hc.HostBatch(g, a)
+    ctx = hc.HcContext(g)
+    S, U = ctx.segment_scalars(b)
+    arr = b.arrays()
+    for r in range(a.n_reads):
+        rc, So, Uo, node = orc.hc_read_segments(og, oa, r)
+        assert rc == 0
+        s0, s1 = arr["read_seg_off"][r], arr["read_seg_off"][r + 1]
+        assert util.rel_err(S[s0:s1], So) < 1e-12 and util.rel_err(U[s0:s1], Uo) < 1e-12
+    ll = ctx.read_loglik(b)
+    for r in range(a.n_reads):
+        rc, ref, _ = orc.hc_read(og, oa, r)  # the literal per-path loops
+        assert rc == 0
+        assert util.rel_err(ll[r], ref.astype(np.float64)) < 1e-12, r
+    check_final(ctx, b, og, oa, faithful=True)
+
+
+def test_bundled_alignments_as_plumbing(golden_dir):
+    """BASELINE config 1: the reference's real-graph GAMs run against a synthetic hcfiles-shaped graph (node ids fit)."""
+    g = hc.synth_graph(seed=0x76676131)
+    assert (g.max_id, g.n_paths) == (11821, 5179)
+    og = util.orc_graph_from_product(g)
+    ctx = hc.HcContext(g)
+    for f in ["J2a1a1a1.gam", "two_unique.gam", "all_the_same_reverse.gam"]:
+        a = hc.AlnSet.read_gam(os.path.join(golden_dir, "alignments", f))
+        b = hc.HostBatch(g, a)
+        assert b.stats.n_out + b.stats.n_bad == a.n_reads
+        oa = util.orc_alnset_from_product(a)
+        _, ref, bad = orc.hc_run(og, oa, n_threads=8, faithful=False)
+        assert bad == b.stats.n_bad
+        ctx.reset()
+        ctx.set_mode(hc.MODE_NODE_WEIGHTS)
+        ctx.accumulate(b)
+        got = ctx.finalize()
+        assert util.rel_err(got, ref) < RTOL
+        if b.n_reads:
+            assert ctx.argmax(got) == int(np.argmax(ref))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(background_error_prob=0.01, use_background_error_prob=True, is_consensus_fasta=True),
+                                dict(background_error_prob=0.3)])
+def test_small_synth_all_modes_vs_faithful_oracle(kw):
+    g = hc.synth_graph(seed=21, genome_len=1500, n_nodes=1000, n_paths=200)
+    a = hc.synth_reads(g, 120, seed=5, read_len=150, indel_rate=0.2, softclip_rate=0.2)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    b = hc.HostBatch(g, a)
+    ctx = hc.HcContext(g, **kw)
+    p = orc.hc_params(kw.get("background_error_prob", 0.0001), kw.get("use_background_error_prob", False),
+                      kw.get("is_consensus_fasta", False))
+    _, ref, _ = orc.hc_run(og, oa, p, n_threads=8, faithful=True)
+    for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ, hc.MODE_PER_READ_DENSE):
+        ctx.reset()
+        ctx.set_mode(mode)
+        ctx.accumulate(b)
+        assert util.rel_err(ctx.finalize(), ref) < RTOL, mode
+    ll = ctx.read_loglik(b)
+    k = 0
+    ident = a.arrays()["identity"]
+    for r in range(a.n_reads):
+        rc, refr, _ = orc.hc_read(og, oa, r, p)
+        if rc != 0 or ident[r] < 1e-10:
+            continue
+        if k % 7 == 0:
+            assert util.rel_err(ll[k], refr.astype(np.float64)) < 1e-11, r
+        k += 1
+    assert k == b.n_reads
+
+
+def _aln(seq, quals, node_edits, mapq=60):
+    return {"sequence": seq, "quality": bytes(quals), "mapping_quality": mapq, "identity": 1.0, "name": b"r",
+            "path": {"name": b"", "mapping": [{"position": {"node_id": n, "offset": o, "is_reverse": rv},
+                                                 "edit": [{"from_length": f, "to_length": t, "sequence": s} for f, t, s in ed],
+                                                 "rank": i + 1} for i, (n, o, rv, ed) in enumerate(node_edits)]}}
+
+
+def test_closed_form_kats_and_edge_cases():
+    """SURVEY.md 8c closed forms through the device path + Q>=90 sticky flag, Q<=2, negative / >=100 qualities,
+    a read longer than the LDS quality window, an empty batch."""
+    # one node ACGT (id 1) at a protein-coding coordinate; node 2 TTAC at HVS-I; paths: 0 supports both, 1 none
+    mask = np.zeros((3, 1), np.uint64)
+    mask[1, 0] = 1
+    mask[2, 0] = 1
+    off = np.array([0, 0, 4, 8], np.int64)
+    g = hc.Graph.from_arrays(1, 2, off, b"ACGTTTAC", 2, mask, np.array([-1, 4000, 100], np.int32), np.ones(17000),
+                             "a\nb\n", "", "")
+    ctx = hc.HcContext(g)
+    alns = [
+        _aln(b"ACGT", [40] * 4, [(1, 0, False, [(4, 4, b"")])]),
+        _aln(b"ACGT", [40, 93, 40, 40], [(1, 0, False, [(4, 4, b"")])]),           # sticky background error prob
+        _aln(b"ACGTTTAC", [2, 0, 1, 3, 200, 130, 99, 100], [(1, 0, False, [(4, 4, b"")]), (2, 0, False, [(4, 4, b"")])]),
+        _aln(b"TTAC" * 400, [30 + (i % 11) for i in range(1600)], [(2, 0, False, [(4, 4, b"")])] * 400),  # QL > 1024
+        _aln(b"GTAAACGT", [35] * 8, [(2, 0, True, [(4, 4, b"")]), (1, 0, True, [(2, 2, b""), (1, 1, b"G"), (1, 1, b"")])]),
+    ]
+    a = hc.AlnSet.parse_gam(gamio.write_gam(alns))
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    b = hc.HostBatch(g, a)
+    assert b.n_reads == len(alns)
+    ll = ctx.read_loglik(b)
+    assert ll[0, 0] == pytest.approx(-4.03019902453559e-4, rel=1e-12)
+    assert ll[0, 1] == pytest.approx(-36.8413614879047, rel=1e-13)
+    for r in range(len(alns)):
+        rc, ref, _ = orc.hc_read(og, oa, r)
+        assert rc == 0
+        assert util.rel_err(ll[r], ref.astype(np.float64)) < 1e-12, r
+    check_final(ctx, b, og, oa, faithful=True)
+    # empty batch and empty accumulators: final = 0, posterior of all-zero vector is 1 (oplusInitnatl quirk Q11)
+    empty = hc.HostBatch(g, a, 0, 0)
+    ctx.reset()
+    ctx.accumulate(empty)
+    z = ctx.finalize()
+    assert np.all(z == 0.0)
+    assert ctx.posterior(z, "a")[0][1] == 1.0
+
+
+def test_posterior_matches_oracle():
+    g = hc.synth_graph(seed=33, genome_len=1200, n_nodes=800, n_paths=300)
+    a = hc.synth_reads(g, 400, seed=8, read_len=100)
+    b = hc.HostBatch(g, a)
+    ctx = hc.HcContext(g)
+    ctx.accumulate(b)
+    fv = ctx.finalize()
+    names = g.path_names
+    pred = names[ctx.argmax(fv)]
+    for predicted in (pred, names[299], names[0]):
+        got = ctx.posterior(fv, predicted)
+        ref = orc.hc_posterior(fv.astype(np.longdouble), names, g.parents_txt, g.children_txt, predicted)
+        assert [x[0] for x in got] == [x[0] for x in ref]
+        assert [x[2] for x in got] == [x[2] for x in ref]
+        for (n1, c1, _), (n2, c2, _) in zip(got, ref):
+            assert c1 == pytest.approx(c2, rel=1e-9, abs=1e-300), n1
+    # flat likelihoods: every clade's confidence = |descendant paths| / P
+    flat = np.full(300, -5.0)
+    got = ctx.posterior(flat, names[299])
+    ref = orc.hc_posterior(flat.astype(np.longdouble), names, g.parents_txt, g.children_txt, names[299])
+    for (_, c1, _), (_, c2, _) in zip(got, ref):
+        assert c1 == pytest.approx(c2, rel=1e-12)
+
+
+def test_full_size_graph_properties():
+    """hcfiles-shaped graph (11821 nodes / 5179 paths), 20k reads of 150 bp: the three device modes agree, the
+    accumulation is linear and order independent, device-resident batches equal host batches, and a read subset
+    matches the oracle."""
+    import torch
+    g = hc.synth_graph(seed=0x76676131)
+    a = hc.synth_reads(g, 20000, seed=0x76676131, read_len=150)
+    b = hc.HostBatch(g, a)
+    assert b.stats.n_bad == 0
+    ctx = hc.HcContext(g)
+    out = {}
+    for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ, hc.MODE_PER_READ_DENSE):
+        ctx.reset()
+        ctx.set_mode(mode)
+        ctx.accumulate(b)
+        out[mode] = ctx.finalize()
+    assert util.rel_err(out[hc.MODE_PER_READ], out[hc.MODE_NODE_WEIGHTS]) < 1e-10
+    assert util.rel_err(out[hc.MODE_PER_READ_DENSE], out[hc.MODE_PER_READ]) < 1e-12
+    # linearity: the same batch twice doubles every entry; split batches sum to the whole
+    ctx.reset()
+    ctx.set_mode(hc.MODE_NODE_WEIGHTS)
+    ctx.accumulate(b)
+    ctx.accumulate(b)
+    assert util.rel_err(ctx.finalize(), 2 * out[hc.MODE_NODE_WEIGHTS]) < 1e-12
+    ctx.reset()
+    for r0 in range(0, 20000, 6000):
+        ctx.accumulate(hc.HostBatch(g, a, r0, min(20000, r0 + 6000)))
+    assert util.rel_err(ctx.finalize(), out[hc.MODE_NODE_WEIGHTS]) < 1e-11
+    # device-resident batch on torch's stream
+    db = hc.DeviceBatch(b, "cuda:0")
+    ctx.use_torch_stream()
+    ctx.reset()
+    ctx.accumulate(db)
+    dev_out = torch.zeros(g.n_paths, dtype=torch.float64, device="cuda:0")
+    got = ctx.finalize(dev_out)
+    assert util.rel_err(got, out[hc.MODE_NODE_WEIGHTS]) < 1e-12
+    assert np.array_equal(dev_out.cpu().numpy(), got)
+    ctx.set_stream(None)
+    # oracle on the first 150 reads (hoisted variant, validated against the literal loops in the small tests)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    _, ref, bad = orc.hc_run(og, oa, r0=0, r1=150, n_threads=8, faithful=False)
+    ctx.reset()
+    ctx.accumulate(hc.HostBatch(g, a, 0, 150))
+    assert util.rel_err(ctx.finalize(), ref) < RTOL
+    # and the literal reference loops on 4 reads
+    _, ref4, _ = orc.hc_run(og, oa, r0=0, r1=4, n_threads=4, faithful=True)
+    ctx.reset()
+    ctx.set_mode(hc.MODE_PER_READ)
+    ctx.accumulate(hc.HostBatch(g, a, 0, 4))
+    assert util.rel_err(ctx.finalize(), ref4) < RTOL

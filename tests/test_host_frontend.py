@@ -1,0 +1,199 @@
+"""CPU tests of the product's host front end (no GPU): library loads and exports every declared symbol,
+GAM reader vs the independent Python decoder, reconstruction KATs through the product, flatten vs the oracle."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gamio
+import orc
+import util
+import vgan_amd
+from vgan_amd import _native as N
+from vgan_amd import haplocart as hc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = vgan_amd.load()
+    hdr = open(os.path.join(ROOT, "include", "vgan_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vgan_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), "libvgan_gpu.so does not export %s" % name
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+    assert L.vgan_abi_version() == 1
+
+
+def test_no_device_is_an_error_not_a_fallback(golden_dir):
+    if N.lib().vgan_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    g = hc.Graph.load(os.path.join(golden_dir, "reconstruct", "target_graph.gfa"))
+    with pytest.raises(N.NativeError) as e:
+        hc.HcContext(g)
+    assert e.value.code == N.VGAN_ENODEV
+
+
+def test_gam_reader_matches_python_decoder(golden_dir):
+    for f in ["reconstruct/test_reads.gam", "alignments/J2a1a1a1.gam", "alignments/all_the_same.gam",
+              "alignments/all_the_same_reverse.gam", "alignments/two_unique.gam"]:
+        p = os.path.join(golden_dir, f)
+        ref = orc.AlnSet([a for a in gamio.read_gam(p) if a["identity"] != 0])
+        got = hc.AlnSet.read_gam(p).arrays()
+        assert got["n_reads"] == ref.n_reads
+        for k in ("seq_off", "qual_off", "map_off", "m_node", "m_offset", "m_rev", "edit_off", "e_from", "e_to",
+                  "e_seq_off", "mapq", "identity"):
+            assert np.array_equal(got[k], getattr(ref, k)), (f, k)
+        for k in ("seq", "qual", "e_seq"):
+            assert got[k].tobytes() == getattr(ref, k)[:-1].tobytes(), (f, k)
+
+
+def test_gam_unmapped_filter_and_roundtrip(tmp_path):
+    alns = gamio.read_gam(os.path.join(ROOT, "tests/golden/reconstruct/test_reads.gam"))
+    alns[3]["identity"] = 0.0  # readGAM.h:47 drops it
+    data = gamio.write_gam(alns, group=4)
+    a = hc.AlnSet.parse_gam(data)
+    assert a.n_reads == 9
+    b = hc.AlnSet.parse_gam(data, keep_unmapped=True)
+    assert b.n_reads == 10
+    out = str(tmp_path / "rt.gam")
+    b.write_gam(out, group_size=3)
+    again = gamio.read_gam(out)
+    assert [x["sequence"] for x in again] == [x["sequence"] for x in alns]
+    strip = lambda a: [(m["position"], m["edit"]) for m in a["path"]["mapping"]]  # rank is not kept
+    assert [strip(x) for x in again] == [strip(x) for x in alns]
+    assert [x["quality"] for x in again] == [x["quality"] for x in alns]
+    # malformed stream -> error code, not a crash
+    with pytest.raises(N.NativeError):
+        hc.AlnSet.parse_gam(gamio.gunzip_all(data)[:-7])
+
+
+def test_reconstruction_kats_through_product(golden_dir):
+    d = os.path.join(golden_dir, "reconstruct")
+    g = hc.Graph.load(os.path.join(d, "target_graph.gfa"))
+    assert g.n_paths == 5 and g.path_names == ["seq_1", "seq_2", "seq_3", "seq_4", "seq_5"]
+    a = hc.AlnSet.read_gam(os.path.join(d, "test_reads.gam"))
+    for case in json.load(open(os.path.join(d, "expected.json")))["cases"]:
+        gs, rs, sizes = hc.reconstruct(g, a, case["read"])
+        assert gs.decode() == case["graph_seq"], case["name"]
+        assert rs.decode() == case["read_seq"], case["name"]
+        assert sizes == case["mppg_sizes"], case["name"]
+
+
+def _check_flatten_against_oracle(g, a, batch):
+    og = util.orc_graph_from_product(g)
+    oa = util.orc_alnset_from_product(a)
+    arr = batch.arrays()
+    ident = a.arrays()["identity"]
+    k = 0
+    for r in range(a.n_reads):
+        if ident[r] < 1e-10:
+            continue
+        rc, gs, rs, sizes = orc.reconstruct(og, oa, r)
+        rc2, S, U, node = orc.hc_read_segments(og, oa, r)
+        if rc != 0 or rc2 != 0:
+            continue  # the reference would terminate: product skips the read
+        s0, s1 = arr["read_seg_off"][k], arr["read_seg_off"][k + 1]
+        c0 = arr["read_col_off"][k]
+        assert arr["read_algn_len"][k] == len(rs)
+        assert arr["graph_seq"][c0:c0 + len(gs)].tobytes() == gs
+        assert arr["algnseq"][c0:c0 + len(rs)].tobytes() == rs
+        assert arr["seg_node"][s0:s1].tolist() == node.tolist()
+        # segment starts/lengths follow update_likelihood.cpp:36-45
+        pos = 0
+        n_map = len(node)
+        for i in range(n_map):
+            assert arr["seg_start"][s0 + i] == pos
+            assert arr["seg_len"][s0 + i] == min(sizes[i], len(gs) - pos)
+            pos += min(sizes[i], len(rs) - pos)
+        k += 1
+    assert k == batch.n_reads
+
+
+def test_flatten_matches_oracle_on_fixtures(golden_dir):
+    d = os.path.join(golden_dir, "reconstruct")
+    g = hc.Graph.load(os.path.join(d, "target_graph.gfa"))
+    a = hc.AlnSet.read_gam(os.path.join(d, "test_reads.gam"))
+    b = hc.HostBatch(g, a)
+    assert b.stats.n_in == 10 and b.stats.n_out == 10 and b.stats.n_bad == 0
+    _check_flatten_against_oracle(g, a, b)
+
+
+def test_synth_graph_shape_and_flatten():
+    g = hc.synth_graph(seed=7, genome_len=2000, n_nodes=1400, n_paths=130)
+    assert g.min_id == 1 and g.max_id == 1400 and g.n_paths == 130
+    lens = np.diff(g.node_seq_off)[1:]
+    assert lens.max() <= 8 and lens.min() >= 1
+    # every path visits exactly one node per site
+    pg = g.pathsgo()
+    site = g.pangenome_base[1:]
+    for p in (0, 17, 129):
+        sup = pg[1:, p].astype(bool)
+        assert len(np.unique(site[sup])) == len(np.unique(site)) == sup.sum()
+    assert len(g.path_names) == 130
+    a = hc.synth_reads(g, 300, seed=3, read_len=150, indel_rate=0.2, softclip_rate=0.2)
+    assert a.n_reads == 300
+    b = hc.HostBatch(g, a, n_threads=3)
+    assert b.stats.n_out + b.stats.n_bad + b.stats.n_unmapped == 300
+    assert b.stats.n_out >= 295
+    _check_flatten_against_oracle(g, a, b)
+    # deterministic regardless of thread count
+    b1 = hc.HostBatch(g, a, n_threads=1)
+    for k, v in b.arrays().items():
+        if k != "_owner":
+            assert np.array_equal(v, b1.arrays()[k]), k
+
+
+def test_flatten_counts_reads_the_reference_would_die_on():
+    g = hc.synth_graph(seed=1, genome_len=600, n_nodes=420, n_paths=20)
+    a = hc.synth_reads(g, 50, seed=9, read_len=60)
+    arr = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in a.arrays().items()}
+    arr["m_node"][arr["map_off"][5]] = 99999          # unknown node -> pangenome_map.at() throws
+    arr["identity"][7] = 0.0                          # unmapped
+    arr["mapq"][9] = 150                              # out-of-range table index (Q10): clamped and counted
+    oa = orc.AlnSet.from_arrays(**arr)
+    v = N.AlnSetView(oa.n_reads, *[getattr(oa, k).ctypes.data for k in
+                                   ("seq_off", "seq", "qual_off", "qual", "mapq", "identity")],
+                     None, None,
+                     *[getattr(oa, k).ctypes.data for k in ("map_off", "m_node", "m_offset", "m_rev", "edit_off",
+                                                            "e_from", "e_to", "e_seq_off", "e_seq")])
+    h = N.vp()
+    N.check(N.lib().vgan_aln_from_arrays(v, h))
+    a2 = hc.AlnSet(h)
+    b = hc.HostBatch(g, a2)
+    assert b.stats.n_bad == 1 and b.stats.n_unmapped == 1 and b.stats.n_clamped == 1 and b.stats.n_out == 48
+
+
+def test_graph_write_and_reload(tmp_path):
+    g = hc.synth_graph(seed=5, genome_len=500, n_nodes=330, n_paths=70)
+    g.write(str(tmp_path))
+    g2 = hc.Graph.load(str(tmp_path / "graph.gfa"), str(tmp_path))
+    assert g2.n_paths == 70 and g2.max_id == g.max_id
+    assert np.array_equal(g2.mask, g.mask)
+    assert np.array_equal(g2.pangenome_base, g.pangenome_base)
+    assert np.array_equal(g2.mappability, g.mappability)
+    assert g2.node_seq.tobytes() == g.node_seq.tobytes()
+    assert g2.path_names == g.path_names and g2.parents_txt == g.parents_txt
+
+
+def test_sidecar_loaders_match_oracle(tmp_path):
+    import ctypes as C
+    g = hc.synth_graph(seed=11, genome_len=400, n_nodes=260, n_paths=33)
+    g.write(str(tmp_path))
+    L = orc.lib()
+    txt = gamio.gunzip_all(open(tmp_path / "path_supports.gz", "rb").read())
+    rows = np.zeros((g.max_id + 1, 33), np.uint8)
+    n = L.orc_load_path_supports(txt, C.c_int32(33), rows.ctypes.data_as(C.c_void_p), C.c_int64(g.max_id + 1))
+    assert n == g.max_id + 1 and np.array_equal(rows, g.pathsgo())
+    pb = np.full(g.max_id + 1, -1, np.int32)
+    L.orc_load_pangenome_map(open(tmp_path / "parsed_pangenome_mapping", "rb").read(),
+                             pb.ctypes.data_as(C.c_void_p), C.c_int64(g.max_id + 1))
+    assert np.array_equal(pb, g.pangenome_base)
+    mp = np.zeros(len(g.mappability) + 8)
+    n = L.orc_load_mappabilities(open(tmp_path / "mappability.tsv", "rb").read(), mp.ctypes.data_as(C.c_void_p),
+                                 C.c_int64(len(mp)))
+    assert n == len(g.mappability) and np.array_equal(mp[:n], g.mappability)

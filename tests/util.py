@@ -1,0 +1,25 @@
+"""Shared helpers for the test-suite: bridge product objects (vgan_amd) to the oracle's views (orc)."""
+import numpy as np
+
+import orc
+
+
+def orc_graph_from_product(g):
+    """Oracle graph view of a product Graph (same arrays, reference-style bool-per-byte pathsgo)."""
+    off = g.node_seq_off
+    seq = g.node_seq.tobytes()
+    node_seqs = {}
+    for i in range(g.min_id, g.max_id + 1):
+        node_seqs[i] = seq[off[i]:off[i + 1]]
+    return orc.Graph(node_seqs, g.n_paths, g.pathsgo(), g.pangenome_base.copy(), g.mappability.copy())
+
+
+def orc_alnset_from_product(a):
+    return orc.AlnSet.from_arrays(**a.arrays())
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    den = np.maximum(np.abs(b), 1e-300)
+    return np.max(np.abs(a - b) / den) if a.size else 0.0

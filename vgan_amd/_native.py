@@ -1,0 +1,127 @@
+"""ctypes binding of libvgan_gpu.so (include/vgan_gpu.h).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libvgan_gpu.so")
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vgan native call failed (%d): %s" % (code, msg))
+        self.code = code
+
+
+VGAN_OK, VGAN_EINVAL, VGAN_ENODEV, VGAN_ENOMEM, VGAN_EIO, VGAN_ERANGE, VGAN_ESTATE = 0, -1, -2, -3, -4, -5, -6
+
+vp = C.c_void_p
+
+
+class GraphView(C.Structure):
+    _fields_ = [("min_id", C.c_int64), ("max_id", C.c_int64), ("node_seq_off", vp), ("node_seq", vp),
+                ("n_paths", C.c_uint32), ("mask_words", C.c_uint32), ("mask", vp), ("pangenome_base", vp),
+                ("mappability", vp), ("n_mappability", C.c_uint64), ("path_names", C.c_char_p),
+                ("parents_txt", C.c_char_p), ("children_txt", C.c_char_p)]
+
+
+class AlnSetView(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("seq_off", vp), ("seq", vp), ("qual_off", vp), ("qual", vp), ("mapq", vp),
+                ("identity", vp), ("name_off", vp), ("name", vp), ("map_off", vp), ("m_node", vp), ("m_offset", vp),
+                ("m_rev", vp), ("edit_off", vp), ("e_from", vp), ("e_to", vp), ("e_seq_off", vp), ("e_seq", vp)]
+
+
+class HcBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_segments", C.c_uint32), ("n_cols", C.c_uint64), ("n_qual", C.c_uint64),
+                ("read_seg_off", vp), ("read_col_off", vp), ("read_qual_off", vp), ("read_algn_len", vp),
+                ("read_mapq", vp), ("seg_node", vp), ("seg_start", vp), ("seg_len", vp), ("graph_seq", vp),
+                ("algnseq", vp), ("qual", vp), ("on_device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class FlattenStats(C.Structure):
+    _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64), ("n_unmapped", C.c_int64), ("n_bad", C.c_int64),
+                ("n_clamped", C.c_int64), ("n_segments", C.c_int64), ("n_cols", C.c_int64)]
+
+
+class HcParams(C.Structure):
+    _fields_ = [("background_error_prob", C.c_double), ("use_background_error_prob", C.c_int32),
+                ("is_consensus_fasta", C.c_int32)]
+
+
+class SynthGraphCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint32), ("n_nodes", C.c_uint32), ("n_paths", C.c_uint32)]
+
+
+class SynthReadsCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("indel_rate", C.c_double),
+                ("softclip_rate", C.c_double), ("low_mapq_rate", C.c_double), ("errors", C.c_int32)]
+
+
+# every symbol include/vgan_gpu.h declares: (restype, argtypes)
+SYMBOLS = {
+    "vgan_last_error": (C.c_char_p, []),
+    "vgan_abi_version": (C.c_int, []),
+    "vgan_device_count": (C.c_int, []),
+    "vgan_graph_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp)]),
+    "vgan_graph_from_arrays": (C.c_int, [C.POINTER(GraphView), C.POINTER(vp)]),
+    "vgan_graph_view_get": (C.c_int, [vp, C.POINTER(GraphView)]),
+    "vgan_graph_write": (C.c_int, [vp, C.c_char_p]),
+    "vgan_graph_free": (None, [vp]),
+    "vgan_aln_read_gam": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
+    "vgan_aln_parse_gam": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(vp)]),
+    "vgan_aln_from_arrays": (C.c_int, [C.POINTER(AlnSetView), C.POINTER(vp)]),
+    "vgan_aln_write_gam": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "vgan_aln_view_get": (C.c_int, [vp, C.POINTER(AlnSetView)]),
+    "vgan_aln_free": (None, [vp]),
+    "vgan_hc_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
+    "vgan_hc_host_batch_get": (C.c_int, [vp, C.POINTER(HcBatch)]),
+    "vgan_hc_host_batch_free": (None, [vp]),
+    "vgan_reconstruct": (C.c_int, [vp, vp, C.c_int64, C.c_char_p, C.c_char_p, vp, C.c_int64, vp]),
+    "vgan_hc_create": (C.c_int, [C.POINTER(GraphView), C.POINTER(HcParams), C.c_int, C.POINTER(vp)]),
+    "vgan_hc_set_stream": (C.c_int, [vp, vp]),
+    "vgan_hc_set_mode": (C.c_int, [vp, C.c_int]),
+    "vgan_hc_reset": (C.c_int, [vp]),
+    "vgan_hc_accumulate": (C.c_int, [vp, C.POINTER(HcBatch)]),
+    "vgan_hc_segment_scalars": (C.c_int, [vp, C.POINTER(HcBatch), vp, vp]),
+    "vgan_hc_read_loglik": (C.c_int, [vp, C.POINTER(HcBatch), vp]),
+    "vgan_hc_finalize": (C.c_int, [vp, vp, vp]),
+    "vgan_hc_synchronize": (C.c_int, [vp]),
+    "vgan_hc_destroy": (None, [vp]),
+    "vgan_hc_profile_enable": (C.c_int, [vp, C.c_int]),
+    "vgan_hc_profile_read": (C.c_int, [vp, vp, vp]),
+    "vgan_hc_posterior": (C.c_int, [vp, vp, C.c_char_p, C.c_char_p, C.c_int64, vp, C.c_int32]),
+    "vgan_hc_argmax": (C.c_int, [vp, C.c_uint32]),
+    "vgan_synth_hc_graph": (C.c_int, [C.POINTER(SynthGraphCfg), C.POINTER(vp)]),
+    "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Load the native library; raise if it is not there (no Python/CPU fallback exists)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            "vgan_amd: native library %s is missing -- build it with `python -m vgan_amd.build` "
+            "(or __graft_entry__.build()); there is no fallback path" % p)
+    L = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(L, name)  # AttributeError if the symbol is not exported
+        f.restype = res
+        f.argtypes = args
+    if path is None:
+        _lib = L
+    return L
+
+
+def lib():
+    return load()
+
+
+def check(rc):
+    if rc < 0:
+        raise NativeError(rc, (lib().vgan_last_error() or b"").decode(errors="replace"))
+    return rc

@@ -1,0 +1,573 @@
+// C-ABI of the HaploCart device path (include/vgan_gpu.h): context, uploads, launches.
+// There is no CPU fallback here: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "hc_device.h"
+#include "host/common.h"
+#include "vgan_gpu.h"
+
+using namespace vgan;
+
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(VGAN_ENODEV, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+namespace {
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return VGAN_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 8 + 64;
+        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return VGAN_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+inline bool in_range(unsigned lo, unsigned hi, unsigned x) { return lo <= x && x <= hi; }
+
+// src/get_p_obs_base.cpp:44-64 (Q1/Q2: the protein-coding rate is 0 by integer division)
+double match_prob(int pangenome_base) {
+    const unsigned b = (unsigned)pangenome_base;
+    double mu;
+    if (in_range(57, 372, b)) mu = 1.64273e-7;
+    else if (in_range(1, 56, b) || in_range(373, 576, b)) mu = 2.29640e-8;
+    else if (in_range(16384, 16569, b)) mu = 1.54555e-8;
+    else if (in_range(3307, 4262, b) || in_range(4470, 5511, b) || in_range(5904, 7445, b) || in_range(7586, 8269, b) ||
+             in_range(8366, 9990, b) || in_range(10059, 10403, b) || in_range(10470, 12137, b) ||
+             in_range(12337, 14673, b) || in_range(14747, 15886, b))
+        mu = 0.0;
+    else if (in_range(577, 647, b) || in_range(1602, 1670, b) || in_range(3230, 3304, b) || in_range(4263, 4400, b) ||
+             in_range(4402, 4469, b) || in_range(5512, 5579, b) || in_range(5587, 5654, b) || in_range(5657, 5728, b) ||
+             in_range(5761, 5891, b) || in_range(7446, 7514, b) || in_range(7518, 7585, b) || in_range(8295, 8364, b) ||
+             in_range(15888, 15953, b) || in_range(15956, 16023, b))
+        mu = 6.91285e-9;
+    else if (in_range(648, 1601, b) || in_range(1671, 3229, b)) mu = 6.91285e-9;
+    else mu = 2.48537e-8;
+    mu *= 30;
+    return pow((1 - mu), 8);
+}
+
+} // namespace
+
+struct vgan_hc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int mode = VGAN_HC_MODE_NODE_WEIGHTS;
+    uint32_t P = 0, W = 0, rows = 0, row_words = 0;
+    HcGraphDev g{};
+    HcParamsDev prm{};
+    DevBuf<uint64_t> umask;
+    DevBuf<HcNodeDev> node_tab;
+    DevBuf<double> tables; // lq[256] qscore[100] incmap[100]
+    DevBuf<double> nodeW, acc_seg, acc_node, totals, final_vec;
+    DevBuf<double> segD, segS, segU, dump;
+    // staging for host batches
+    DevBuf<uint32_t> s_u32;
+    DevBuf<uint16_t> s_u16;
+    DevBuf<uint8_t> s_u8;
+    // posterior
+    std::vector<std::string> path_names;
+    std::unordered_map<std::string, uint32_t> path_index;
+    std::unordered_map<std::string, std::vector<std::string>> parents, children;
+    DevBuf<uint64_t> sets;
+    DevBuf<double> conf;
+    // profiling: pairs of events per timed launch, resolved in vgan_hc_profile_read
+    bool profiling = false;
+    struct Timed {
+        int slot;
+        hipEvent_t a, b;
+    };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[VGAN_HC_K_COUNT] = {0, 0, 0, 0};
+    uint64_t prof_n[VGAN_HC_K_COUNT] = {0, 0, 0, 0};
+};
+
+namespace {
+struct ScopedTimer {
+    vgan_hc_ctx *c;
+    int slot;
+    hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(vgan_hc_ctx *c) {
+        if (!c->event_pool.empty()) {
+            hipEvent_t e = c->event_pool.back();
+            c->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    ScopedTimer(vgan_hc_ctx *ctx, int s) : c(ctx), slot(s) {
+        if (!c->profiling) return;
+        a = get(c);
+        b = get(c);
+        if (a) (void)hipEventRecord(a, c->stream);
+    }
+    ~ScopedTimer() {
+        if (!c->profiling || !a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->timed.push_back({slot, a, b});
+    }
+};
+} // namespace
+
+namespace {
+
+void parse_relatives(const char *txt, std::unordered_map<std::string, std::vector<std::string>> &rel) {
+    // src/load.cpp:303-345: "name tok tok ...", tokens containing '[' dropped, first insertion wins
+    std::istringstream in(txt ? txt : "");
+    std::string line, tok;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::vector<std::string> t;
+        while (ls >> tok) t.push_back(tok);
+        if (t.empty()) continue;
+        std::vector<std::string> v;
+        for (size_t j = 1; j < t.size(); ++j)
+            if (t[j].find('[') == std::string::npos) v.push_back(t[j]);
+        rel.emplace(t[0], std::move(v));
+    }
+}
+
+int stage_batch(vgan_hc_ctx *c, const vgan_hc_batch *b, HcBatchDev &d) {
+    d.n_reads = b->n_reads;
+    d.n_segments = b->n_segments;
+    if (b->on_device) {
+        d.read_seg_off = b->read_seg_off;
+        d.read_col_off = b->read_col_off;
+        d.read_qual_off = b->read_qual_off;
+        d.read_algn_len = b->read_algn_len;
+        d.read_mapq = b->read_mapq;
+        d.seg_node = b->seg_node;
+        d.seg_start = b->seg_start;
+        d.seg_len = b->seg_len;
+        d.graph_seq = b->graph_seq;
+        d.algnseq = b->algnseq;
+        d.qual = b->qual;
+        return VGAN_OK;
+    }
+    const size_t R = b->n_reads, S = b->n_segments;
+    auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    const size_t n32 = 3 * up(R + 1) + up(S);
+    const size_t n16 = up(R) + 2 * up(S);
+    const size_t n8 = up(R) + 2 * up(b->n_cols) + up(b->n_qual);
+    int rc;
+    if ((rc = c->s_u32.reserve(n32)) || (rc = c->s_u16.reserve(n16)) || (rc = c->s_u8.reserve(n8))) return rc;
+    uint32_t *p32 = c->s_u32.p;
+    uint16_t *p16 = c->s_u16.p;
+    uint8_t *p8 = c->s_u8.p;
+#define COPY(dst, src, n)                                                                                \
+    do {                                                                                                 \
+        if ((n) > 0) HIPCHK(hipMemcpyAsync((void *)(dst), (src), (n) * sizeof(*(src)), hipMemcpyHostToDevice, c->stream)); \
+    } while (0)
+    d.read_seg_off = p32;
+    COPY(p32, b->read_seg_off, R + 1);
+    p32 += up(R + 1);
+    d.read_col_off = p32;
+    COPY(p32, b->read_col_off, R + 1);
+    p32 += up(R + 1);
+    d.read_qual_off = p32;
+    COPY(p32, b->read_qual_off, R + 1);
+    p32 += up(R + 1);
+    d.seg_node = p32;
+    COPY(p32, b->seg_node, S);
+    d.read_algn_len = p16;
+    COPY(p16, b->read_algn_len, R);
+    p16 += up(R);
+    d.seg_start = p16;
+    COPY(p16, b->seg_start, S);
+    p16 += up(S);
+    d.seg_len = p16;
+    COPY(p16, b->seg_len, S);
+    d.read_mapq = p8;
+    COPY(p8, b->read_mapq, R);
+    p8 += up(R);
+    d.graph_seq = p8;
+    COPY(p8, b->graph_seq, (size_t)b->n_cols);
+    p8 += up(b->n_cols);
+    d.algnseq = p8;
+    COPY(p8, b->algnseq, (size_t)b->n_cols);
+    p8 += up(b->n_cols);
+    d.qual = p8;
+    COPY(p8, b->qual, (size_t)b->n_qual);
+#undef COPY
+    return VGAN_OK;
+}
+
+int check_batch(const vgan_hc_batch *b) {
+    if (!b) return fail(VGAN_EINVAL, "null batch");
+    if (b->n_reads == 0) return VGAN_OK;
+    if (!b->read_seg_off || !b->read_col_off || !b->read_qual_off || !b->read_algn_len || !b->read_mapq)
+        return fail(VGAN_EINVAL, "batch: null per-read array");
+    if (b->n_segments && (!b->seg_node || !b->seg_start || !b->seg_len)) return fail(VGAN_EINVAL, "batch: null per-segment array");
+    if (b->n_cols && (!b->graph_seq || !b->algnseq)) return fail(VGAN_EINVAL, "batch: null sequence array");
+    if (b->n_qual && !b->qual) return fail(VGAN_EINVAL, "batch: null quality array");
+    return VGAN_OK;
+}
+
+} // namespace
+
+extern "C" int vgan_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *params, int device, vgan_hc_ctx **out) {
+    if (!gv || !params || !out) return fail(VGAN_EINVAL, "vgan_hc_create: null argument");
+    if (gv->n_paths == 0 || gv->max_id < 0 || !gv->mask || !gv->pangenome_base || !gv->mappability)
+        return fail(VGAN_EINVAL, "vgan_hc_create: incomplete graph view");
+    if (!(params->background_error_prob >= 0.0 && params->background_error_prob <= 1.0))
+        return fail(VGAN_EINVAL, "Error: background error probability must be between 0 and 1"); // HaploCart.cpp:107-113
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(VGAN_ENODEV, "vgan_hc_create: no HIP device is visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(VGAN_EINVAL, "vgan_hc_create: device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    auto c = new vgan_hc_ctx();
+    c->device = device;
+    c->P = gv->n_paths;
+    c->W = (gv->n_paths + 63) / 64;
+    c->rows = (uint32_t)gv->max_id + 1;
+    c->row_words = (c->W + HC_SWEEP_TILE_WORDS - 1) / HC_SWEEP_TILE_WORDS * HC_SWEEP_TILE_WORDS;
+    c->prm.bep = params->background_error_prob;
+    c->prm.use_bep = params->use_background_error_prob != 0;
+    c->prm.consensus = params->is_consensus_fasta != 0;
+    int rc = VGAN_OK;
+    auto bail = [&](int code) {
+        vgan_hc_destroy(c);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(VGAN_ENODEV, "hipStreamCreate failed"));
+    c->stream = c->own_stream;
+    // unsupported-path mask, padded rows
+    std::vector<uint64_t> um((size_t)c->rows * c->row_words, 0);
+    for (uint32_t r = 0; r < c->rows; ++r) {
+        const uint64_t *src = gv->mask + (size_t)r * c->W;
+        uint64_t *dst = &um[(size_t)r * c->row_words];
+        for (uint32_t w = 0; w < c->W; ++w) {
+            uint64_t valid = ~0ull;
+            if (w == c->W - 1 && (c->P & 63)) valid = (1ull << (c->P & 63)) - 1;
+            dst[w] = ~src[w] & valid;
+        }
+    }
+    std::vector<HcNodeDev> nt(c->rows);
+    for (uint32_t r = 0; r < c->rows; ++r) {
+        const int32_t pb = gv->pangenome_base[r];
+        if (pb >= 0 && (uint64_t)pb < gv->n_mappability) nt[r] = {gv->mappability[pb], match_prob(pb)};
+        else nt[r] = {0.0, 1.0};
+    }
+    std::vector<double> tb(456);
+    for (int bte = 0; bte < 256; ++bte) { // src/miscfunc.h:180-188 on int(char)
+        const int Q = (int)(int8_t)bte;
+        tb[bte] = log(Q > 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25);
+    }
+    for (int Q = 0; Q < 100; ++Q) { // src/miscfunc.h:199-212, src/haplocart_functions.cpp:101-107
+        tb[256 + Q] = Q > 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25;
+        tb[356 + Q] = pow(10, ((-1 * Q) * 0.1));
+    }
+    const size_t accn = (size_t)c->row_words * 64;
+    if ((rc = c->umask.reserve(um.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(456)) ||
+        (rc = c->nodeW.reserve(c->rows)) || (rc = c->acc_seg.reserve(accn)) || (rc = c->acc_node.reserve(accn)) ||
+        (rc = c->totals.reserve(2)) || (rc = c->final_vec.reserve(c->P)))
+        return bail(rc);
+    if (hipMemcpy(c->umask.p, um.data(), um.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->node_tab.p, nt.data(), nt.size() * sizeof(HcNodeDev), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->tables.p, tb.data(), tb.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(VGAN_ENODEV, "vgan_hc_create: upload failed"));
+    c->g.umask = c->umask.p;
+    c->g.node_tab = c->node_tab.p;
+    c->g.lq = c->tables.p;
+    c->g.qscore = c->tables.p + 256;
+    c->g.incmap = c->tables.p + 356;
+    c->g.rows = c->rows;
+    c->g.row_words = c->row_words;
+    c->g.n_paths = c->P;
+    // posterior side tables
+    {
+        std::istringstream in(gv->path_names ? gv->path_names : "");
+        std::string line;
+        while (std::getline(in, line)) {
+            std::istringstream ls(line);
+            std::string tok;
+            if (!(ls >> tok)) continue;
+            c->path_index.emplace(tok, (uint32_t)c->path_names.size());
+            c->path_names.push_back(tok);
+        }
+        parse_relatives(gv->parents_txt, c->parents);
+        parse_relatives(gv->children_txt, c->children);
+    }
+    if ((rc = vgan_hc_reset(c))) return bail(rc);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: sync failed"));
+    *out = c;
+    return VGAN_OK;
+}
+
+extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    c->umask.release();
+    c->node_tab.release();
+    c->tables.release();
+    c->nodeW.release();
+    c->acc_seg.release();
+    c->acc_node.release();
+    c->totals.release();
+    c->final_vec.release();
+    c->segD.release();
+    c->segS.release();
+    c->segU.release();
+    c->dump.release();
+    c->s_u32.release();
+    c->s_u16.release();
+    c->s_u8.release();
+    c->sets.release();
+    c->conf.release();
+    for (auto &t : c->timed) {
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int vgan_hc_set_stream(vgan_hc_ctx *c, void *hip_stream) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_set_stream: null context");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_set_mode(vgan_hc_ctx *c, int mode) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_set_mode: null context");
+    if (mode != VGAN_HC_MODE_NODE_WEIGHTS && mode != VGAN_HC_MODE_PER_READ && mode != VGAN_HC_MODE_PER_READ_DENSE)
+        return fail(VGAN_EINVAL, "vgan_hc_set_mode: unknown mode %d", mode);
+    c->mode = mode;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_reset(vgan_hc_ctx *c) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_reset: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->nodeW.p, 0, (size_t)c->rows * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->acc_seg.p, 0, (size_t)c->row_words * 64 * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->acc_node.p, 0, (size_t)c->row_words * 64 * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->totals.p, 0, 16, c->stream));
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *b) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_accumulate: null context");
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (b->n_reads == 0) return VGAN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HcBatchDev d{};
+    if ((rc = stage_batch(c, b, d))) return rc;
+    if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) {
+        ScopedTimer t(c, VGAN_HC_K_SEGMENT);
+        launch_hc_segments(c->g, d, c->prm, nullptr, nullptr, nullptr, c->nodeW.p, c->totals.p, c->stream);
+    } else {
+        if ((rc = c->segD.reserve(b->n_segments))) return rc;
+        {
+            ScopedTimer t(c, VGAN_HC_K_SEGMENT);
+            launch_hc_segments(c->g, d, c->prm, nullptr, nullptr, c->segD.p, nullptr, c->totals.p, c->stream);
+        }
+        ScopedTimer t(c, VGAN_HC_K_SWEEP_SEG);
+        launch_hc_sweep(c->g, d.seg_node, c->segD.p, d.n_segments, c->mode == VGAN_HC_MODE_PER_READ, c->acc_seg.p, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *b, double *S, double *U) {
+    if (!c || !S || !U) return fail(VGAN_EINVAL, "vgan_hc_segment_scalars: null argument");
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (b->n_reads == 0 || b->n_segments == 0) return VGAN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HcBatchDev d{};
+    if ((rc = stage_batch(c, b, d))) return rc;
+    if ((rc = c->segS.reserve(b->n_segments)) || (rc = c->segU.reserve(b->n_segments))) return rc;
+    launch_hc_segments(c->g, d, c->prm, c->segS.p, c->segU.p, nullptr, nullptr, nullptr, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(S, c->segS.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(U, c->segU.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *b, double *out) {
+    if (!c || !out) return fail(VGAN_EINVAL, "vgan_hc_read_loglik: null argument");
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (b->n_reads == 0) return VGAN_OK;
+    if (b->n_reads > 65535) return fail(VGAN_ERANGE, "vgan_hc_read_loglik: at most 65535 reads per call");
+    HIPCHK(hipSetDevice(c->device));
+    HcBatchDev d{};
+    if ((rc = stage_batch(c, b, d))) return rc;
+    const size_t n = (size_t)b->n_reads * c->P;
+    if ((rc = c->segS.reserve(b->n_segments + 1)) || (rc = c->segU.reserve(b->n_segments + 1)) || (rc = c->dump.reserve(n)))
+        return rc;
+    launch_hc_segments(c->g, d, c->prm, c->segS.p, c->segU.p, nullptr, nullptr, nullptr, c->stream);
+    launch_hc_read_loglik(c->g, d, c->segS.p, c->segU.p, c->dump.p, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->dump.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_finalize(vgan_hc_ctx *c, double *d_out, double *out) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_finalize: null context");
+    HIPCHK(hipSetDevice(c->device));
+    // NODE_WEIGHTS accumulations: one pass of the unsupported-path bitmask over the node weights
+    HIPCHK(hipMemsetAsync(c->acc_node.p, 0, (size_t)c->row_words * 64 * 8, c->stream));
+    {
+        ScopedTimer t(c, VGAN_HC_K_SWEEP_NODE);
+        launch_hc_sweep(c->g, nullptr, c->nodeW.p, c->rows, 1, c->acc_node.p, c->stream);
+    }
+    {
+        ScopedTimer t(c, VGAN_HC_K_FINISH);
+        launch_hc_finish(c->totals.p, c->acc_seg.p, c->acc_node.p, c->P, c->final_vec.p, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    if (d_out) HIPCHK(hipMemcpyAsync(d_out, c->final_vec.p, (size_t)c->P * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (out) {
+        HIPCHK(hipMemcpyAsync(out, c->final_vec.p, (size_t)c->P * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_synchronize(vgan_hc_ctx *c) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_synchronize: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VGAN_OK;
+}
+
+static void resolve_timers(vgan_hc_ctx *c) {
+    for (auto &t : c->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            c->prof_ms[t.slot] += ms;
+            c->prof_n[t.slot] += 1;
+        }
+        c->event_pool.push_back(t.a);
+        c->event_pool.push_back(t.b);
+    }
+    c->timed.clear();
+}
+
+extern "C" int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_profile_enable: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    resolve_timers(c);
+    for (int i = 0; i < VGAN_HC_K_COUNT; ++i) {
+        c->prof_ms[i] = 0;
+        c->prof_n[i] = 0;
+    }
+    c->profiling = enable != 0;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[4], uint64_t launches[4]) {
+    if (!c || !ms || !launches) return fail(VGAN_EINVAL, "vgan_hc_profile_read: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    resolve_timers(c);
+    for (int i = 0; i < VGAN_HC_K_COUNT; ++i) {
+        ms[i] = c->prof_ms[i];
+        launches[i] = c->prof_n[i];
+    }
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_argmax(const double *v, uint32_t n) {
+    if (!v || n == 0) return fail(VGAN_EINVAL, "vgan_hc_argmax: empty vector");
+    uint32_t best = 0;
+    for (uint32_t i = 1; i < n; ++i)
+        if (v[i] > v[best]) best = i; // std::max_element: first maximum
+    return (int)best;
+}
+
+extern "C" int vgan_hc_posterior(vgan_hc_ctx *c, const double *final_vec, const char *predicted, char *clade_buf,
+                                 int64_t clade_cap, double *conf, int32_t conf_cap) {
+    if (!c || !final_vec || !predicted || !clade_buf || !conf) return fail(VGAN_EINVAL, "vgan_hc_posterior: null argument");
+    if (c->path_names.size() != c->P) return fail(VGAN_ESTATE, "vgan_hc_posterior: graph has %zu path names for %u paths", c->path_names.size(), c->P);
+    auto pi = c->path_index.find(predicted);
+    if (pi == c->path_index.end()) return fail(VGAN_EINVAL, "vgan_hc_posterior: '%s' is not a path name", predicted);
+    // src/get_posterior.cpp:94-123: the predicted haplotype, then each ancestor with its strict descendants
+    std::vector<std::string> parent_vec;
+    auto pv = c->parents.find(predicted);
+    if (pv != c->parents.end()) parent_vec = pv->second;
+    std::vector<std::string> clades{predicted};
+    std::vector<std::vector<uint64_t>> sets;
+    sets.emplace_back(c->W, 0);
+    sets[0][pi->second >> 6] |= 1ull << (pi->second & 63);
+    for (size_t j = 0; j < parent_vec.size(); ++j) {
+        if (j > 0 && parent_vec[j] == parent_vec[j - 1]) continue; // :110,117 (Q9: j = 0 always emitted)
+        clades.push_back(parent_vec[j]);
+        std::vector<uint64_t> set(c->W, 0);
+        std::unordered_set<std::string> seen;
+        std::deque<std::string> todo{parent_vec[j]};
+        while (!todo.empty()) { // get_children() recursion, :36-76
+            const std::string cur = todo.front();
+            todo.pop_front();
+            auto ch = c->children.find(cur);
+            if (ch == c->children.end()) continue;
+            for (const std::string &k : ch->second) {
+                if (!seen.insert(k).second) continue;
+                auto ki = c->path_index.find(k);
+                if (ki != c->path_index.end()) set[ki->second >> 6] |= 1ull << (ki->second & 63);
+                todo.push_back(k);
+            }
+        }
+        sets.push_back(std::move(set));
+    }
+    const uint32_t ns = (uint32_t)sets.size();
+    if ((int32_t)ns > conf_cap) return fail(VGAN_ERANGE, "vgan_hc_posterior: conf_cap too small (%u records)", ns);
+    std::string joined;
+    for (auto &s : clades) joined += s + "\n";
+    if ((int64_t)joined.size() + 1 > clade_cap) return fail(VGAN_ERANGE, "vgan_hc_posterior: clade buffer too small");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->sets.reserve((size_t)ns * c->W)) || (rc = c->conf.reserve(ns))) return rc;
+    std::vector<uint64_t> flat((size_t)ns * c->W);
+    for (uint32_t i = 0; i < ns; ++i) std::copy(sets[i].begin(), sets[i].end(), flat.begin() + (size_t)i * c->W);
+    HIPCHK(hipMemcpyAsync(c->sets.p, flat.data(), flat.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->final_vec.p, final_vec, (size_t)c->P * 8, hipMemcpyHostToDevice, c->stream));
+    launch_hc_posterior(c->final_vec.p, c->P, c->sets.p, c->W, ns, c->conf.p, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(conf, c->conf.p, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(clade_buf, joined.c_str(), joined.size() + 1);
+    return (int)ns;
+}

@@ -1,0 +1,291 @@
+// Front half of the HaploCart hot path on the host: alignment -> (graph_seq, algnseq, per-edit sizes)
+// -> per-mapping segments -> SoA batch for the device.
+//
+// Mirrors what the reference does before its per-path loops, quirks included:
+//   reconstruct_graph_sequence  src/vgan_utils.h:6-79      (Q7 softclip = insertion at running offset 0,
+//                                                           Q8 deletion gap inserted at sum(from_length))
+//   slicing                     src/update_likelihood.cpp:33-45 (Q6 sizes are per EDIT, indexed per MAPPING)
+//   read filter                 src/HaploCart.cpp:410       (identity < 1e-10 skipped)
+// Reads on which the reference would std::terminate (unknown node, substr/insert out of range, a mapping
+// without edits) are skipped and counted instead.
+#include "common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
+using namespace vgan;
+
+void vgan_hc_host_batch::fill(vgan_hc_batch *b) const {
+    memset(b, 0, sizeof *b);
+    b->n_reads = (uint32_t)read_algn_len.size();
+    b->n_segments = (uint32_t)seg_node.size();
+    b->n_cols = graph_seq.size();
+    b->n_qual = qual.size();
+    b->read_seg_off = read_seg_off.data();
+    b->read_col_off = read_col_off.data();
+    b->read_qual_off = read_qual_off.data();
+    b->read_algn_len = read_algn_len.data();
+    b->read_mapq = read_mapq.data();
+    b->seg_node = seg_node.data();
+    b->seg_start = seg_start.data();
+    b->seg_len = seg_len.data();
+    b->graph_seq = graph_seq.data();
+    b->algnseq = algnseq.data();
+    b->qual = qual.data();
+    b->on_device = 0;
+}
+
+namespace {
+
+enum { BAD_NODE = 1, BAD_SUBSTR = 2, BAD_SIZES = 3, BAD_TABLE = 4, BAD_RANGE = 5 };
+
+inline char comp(char c) {
+    switch (c) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    case 'a': return 't';
+    case 'c': return 'g';
+    case 'g': return 'c';
+    case 't': return 'a';
+    default: return 'N';
+    }
+}
+
+struct Recon {
+    std::string gseq, ps;
+    std::vector<int32_t> sizes;
+};
+
+// appends oriented_node[off, off+n) (clamped like std::string::substr); false if off > node length
+inline bool append_node(const vgan_graph &g, int64_t id, bool rev, int64_t off, int64_t n, std::string &out,
+                        int64_t *appended) {
+    const int64_t len = g.seq_len(id);
+    if (off > len || off < 0) return false;
+    if (n < 0) n = len - off; // substr(pos, npos-like) for negative counts converted to size_t
+    n = std::min(n, len - off);
+    const char *s = g.seq_ptr(id);
+    if (!rev) {
+        out.append(s + off, (size_t)n);
+    } else {
+        for (int64_t k = 0; k < n; ++k) out += comp(s[len - 1 - (off + k)]);
+    }
+    if (appended) *appended = n;
+    return true;
+}
+
+int reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Recon &o) {
+    o.gseq.clear();
+    o.ps.clear();
+    o.sizes.clear();
+    const int64_t m0 = a.map_off[r], m1 = a.map_off[r + 1];
+    // path_string: node bases for matches, edit.sequence for substitutions/insertions
+    for (int64_t m = m0; m < m1; ++m) {
+        const int64_t id = a.m_node[m];
+        if (!g.has_node(id)) return BAD_NODE;
+        int64_t f = a.m_offset[m];
+        for (int64_t e = a.edit_off[m]; e < a.edit_off[m + 1]; ++e) {
+            const int32_t from = a.e_from[e], to = a.e_to[e];
+            const int64_t sl = a.e_seq_off[e + 1] - a.e_seq_off[e];
+            if (from == to && sl == 0) {
+                if (!append_node(g, id, a.m_rev[m], f, from, o.ps, nullptr)) return BAD_SUBSTR;
+            } else if ((from == to && sl > 0) || (from == 0 && to > 0 && sl > 0)) {
+                o.ps.append(a.e_seq.data() + a.e_seq_off[e], (size_t)sl);
+            }
+            f += from;
+        }
+    }
+    int64_t f = 0;
+    for (int64_t m = m0; m < m1; ++m) {
+        const int64_t id = a.m_node[m];
+        const bool rev = a.m_rev[m];
+        int64_t offset = (int32_t)a.m_offset[m];
+        int32_t aligned = 0;
+        for (int64_t e = a.edit_off[m]; e < a.edit_off[m + 1]; ++e) {
+            const int32_t from = a.e_from[e], to = a.e_to[e];
+            const int64_t sl = a.e_seq_off[e + 1] - a.e_seq_off[e];
+            const bool is_ins = from == 0 && to > 0 && sl > 0;
+            if (from == to) { // match or substitution
+                int64_t n;
+                if (!append_node(g, id, rev, offset, from, o.gseq, &n)) return BAD_SUBSTR;
+                aligned = (int32_t)n;
+            } else if (is_ins) {
+                o.gseq.append((size_t)to, offset == 0 ? 'S' : '-'); // Q7
+                aligned = to;
+            } else if (from > 0 && to == 0) { // deletion
+                int64_t n;
+                if (!append_node(g, id, rev, offset, from, o.gseq, &n)) return BAD_SUBSTR;
+                aligned = (int32_t)n;
+                if (f < 0 || (size_t)f > o.ps.size()) return BAD_SUBSTR;
+                o.ps.insert((size_t)f, (size_t)from, '-'); // Q8
+            }
+            offset += from;
+            f += from;
+            o.sizes.push_back(aligned);
+        }
+    }
+    return 0;
+}
+
+struct Chunk {
+    vgan_hc_host_batch b;
+    vgan_hc_flatten_stats st{};
+};
+
+void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, Chunk &c) {
+    Recon rc;
+    auto &b = c.b;
+    for (int64_t r = r0; r < r1; ++r) {
+        c.st.n_in++;
+        if (a.identity[r] < 1e-10) {
+            c.st.n_unmapped++;
+            continue;
+        }
+        int bad = reconstruct(g, a, r, rc);
+        const int64_t nm = a.map_off[r + 1] - a.map_off[r];
+        const size_t A = rc.ps.size(), G = rc.gseq.size();
+        if (!bad && (A > 65535 || G > 65535 || nm > 65535)) bad = BAD_RANGE;
+        const size_t seg_mark = b.seg_node.size();
+        if (!bad) {
+            size_t pos = 0;
+            for (int64_t i = 0; i < nm; ++i) {
+                if ((size_t)i >= rc.sizes.size()) {
+                    bad = BAD_SIZES;
+                    break;
+                }
+                if (pos > G || pos > A) {
+                    bad = BAD_SUBSTR;
+                    break;
+                }
+                const int64_t id = a.m_node[a.map_off[r] + i];
+                const int32_t pb = g.pangenome_base[id]; // id validated by reconstruct()
+                if (pb < 0) {
+                    bad = BAD_NODE;
+                    break;
+                }
+                if ((uint64_t)pb >= g.mappability.size()) {
+                    bad = BAD_TABLE;
+                    break;
+                }
+                const size_t n = (size_t)std::max(0, rc.sizes[i]);
+                b.seg_node.push_back((uint32_t)id);
+                b.seg_start.push_back((uint16_t)pos);
+                b.seg_len.push_back((uint16_t)std::min(n, G - pos));
+                pos += std::min(n, A - pos);
+            }
+        }
+        if (bad) {
+            b.seg_node.resize(seg_mark);
+            b.seg_start.resize(seg_mark);
+            b.seg_len.resize(seg_mark);
+            c.st.n_bad++;
+            continue;
+        }
+        int32_t mq = a.mapq[r];
+        if (mq < 0 || mq > 99) {
+            mq = mq < 0 ? 0 : 99;
+            c.st.n_clamped++;
+        }
+        const size_t region = std::max(A, G);
+        b.graph_seq.insert(b.graph_seq.end(), rc.gseq.begin(), rc.gseq.end());
+        b.graph_seq.insert(b.graph_seq.end(), region - G, 0);
+        b.algnseq.insert(b.algnseq.end(), rc.ps.begin(), rc.ps.end());
+        b.algnseq.insert(b.algnseq.end(), region - A, 0);
+        const char *q = a.qual.data() + a.qual_off[r];
+        b.qual.insert(b.qual.end(), q, q + (a.qual_off[r + 1] - a.qual_off[r]));
+        b.read_algn_len.push_back((uint16_t)A);
+        b.read_mapq.push_back((uint8_t)mq);
+        b.read_seg_off.push_back((uint32_t)b.seg_node.size());
+        b.read_col_off.push_back((uint32_t)b.graph_seq.size());
+        b.read_qual_off.push_back((uint32_t)b.qual.size());
+        c.st.n_out++;
+    }
+}
+
+template <class T> void append_shifted(std::vector<T> &dst, const std::vector<T> &src, T shift) {
+    // src[0] == 0 is the leading offset; skip it
+    for (size_t i = 1; i < src.size(); ++i) dst.push_back((T)(src[i] + shift));
+}
+
+} // namespace
+
+extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
+                               vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    if (!g || !a || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten: null argument");
+    if (r0 < 0 || r1 > a->n_reads() || r0 > r1) return fail(VGAN_EINVAL, "vgan_hc_flatten: bad read range");
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int64_t n = r1 - r0;
+    n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (n + 4095) / 4096));
+    std::vector<Chunk> chunks((size_t)n_threads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) {
+        const int64_t b0 = r0 + n * t / n_threads, b1 = r0 + n * (t + 1) / n_threads;
+        if (n_threads == 1) flatten_range(*g, *a, b0, b1, chunks[t]);
+        else th.emplace_back(flatten_range, std::cref(*g), std::cref(*a), b0, b1, std::ref(chunks[t]));
+    }
+    for (auto &t : th) t.join();
+    auto res = new vgan_hc_host_batch();
+    vgan_hc_flatten_stats st{};
+    uint64_t tot_cols = 0, tot_segs = 0, tot_qual = 0;
+    for (auto &c : chunks) {
+        tot_cols += c.b.graph_seq.size();
+        tot_segs += c.b.seg_node.size();
+        tot_qual += c.b.qual.size();
+    }
+    if (tot_cols > 0xFFFFFFF0ull || tot_segs > 0xFFFFFFF0ull || tot_qual > 0xFFFFFFF0ull) {
+        delete res;
+        return fail(VGAN_ERANGE, "vgan_hc_flatten: batch exceeds 32-bit offsets; flatten fewer reads per batch");
+    }
+    for (auto &c : chunks) {
+        append_shifted(res->read_seg_off, c.b.read_seg_off, (uint32_t)res->seg_node.size());
+        append_shifted(res->read_col_off, c.b.read_col_off, (uint32_t)res->graph_seq.size());
+        append_shifted(res->read_qual_off, c.b.read_qual_off, (uint32_t)res->qual.size());
+        res->read_algn_len.insert(res->read_algn_len.end(), c.b.read_algn_len.begin(), c.b.read_algn_len.end());
+        res->read_mapq.insert(res->read_mapq.end(), c.b.read_mapq.begin(), c.b.read_mapq.end());
+        res->seg_node.insert(res->seg_node.end(), c.b.seg_node.begin(), c.b.seg_node.end());
+        res->seg_start.insert(res->seg_start.end(), c.b.seg_start.begin(), c.b.seg_start.end());
+        res->seg_len.insert(res->seg_len.end(), c.b.seg_len.begin(), c.b.seg_len.end());
+        res->graph_seq.insert(res->graph_seq.end(), c.b.graph_seq.begin(), c.b.graph_seq.end());
+        res->algnseq.insert(res->algnseq.end(), c.b.algnseq.begin(), c.b.algnseq.end());
+        res->qual.insert(res->qual.end(), c.b.qual.begin(), c.b.qual.end());
+        st.n_in += c.st.n_in;
+        st.n_out += c.st.n_out;
+        st.n_unmapped += c.st.n_unmapped;
+        st.n_bad += c.st.n_bad;
+        st.n_clamped += c.st.n_clamped;
+        c.b = vgan_hc_host_batch(); // release early
+    }
+    st.n_segments = (int64_t)res->seg_node.size();
+    st.n_cols = (int64_t)res->graph_seq.size();
+    if (stats) *stats = st;
+    *out = res;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out) {
+    if (!b || !out) return fail(VGAN_EINVAL, "vgan_hc_host_batch_get: null argument");
+    b->fill(out);
+    return VGAN_OK;
+}
+
+extern "C" void vgan_hc_host_batch_free(vgan_hc_host_batch *b) { delete b; }
+
+extern "C" int vgan_reconstruct(const vgan_graph *g, const vgan_alnset *a, int64_t r, char *graph_seq, char *read_seq,
+                                int32_t *mppg_sizes, int64_t cap, int64_t *lens) {
+    if (!g || !a || !graph_seq || !read_seq || !mppg_sizes || !lens) return fail(VGAN_EINVAL, "vgan_reconstruct: null argument");
+    if (r < 0 || r >= a->n_reads()) return fail(VGAN_EINVAL, "vgan_reconstruct: read index out of range");
+    Recon rc;
+    const int bad = reconstruct(*g, *a, r, rc);
+    if (bad) return fail(VGAN_ERANGE, "vgan_reconstruct: the reference would terminate on this read (code %d)", bad);
+    if ((int64_t)rc.gseq.size() + 1 > cap || (int64_t)rc.ps.size() + 1 > cap || (int64_t)rc.sizes.size() > cap)
+        return fail(VGAN_ERANGE, "vgan_reconstruct: buffers too small");
+    memcpy(graph_seq, rc.gseq.c_str(), rc.gseq.size() + 1);
+    memcpy(read_seq, rc.ps.c_str(), rc.ps.size() + 1);
+    std::copy(rc.sizes.begin(), rc.sizes.end(), mppg_sizes);
+    lens[0] = (int64_t)rc.gseq.size();
+    lens[1] = (int64_t)rc.ps.size();
+    lens[2] = (int64_t)rc.sizes.size();
+    return VGAN_OK;
+}

@@ -1,0 +1,347 @@
+// GAM reader/writer: the host-side replacement of readGAM() (reference src/readGAM.h:20-68), which goes
+// through libvgio + protobuf.  Here: zlib inflate of the gzip/BGZF members, then a zero-copy walk of the
+// type-tagged length-prefixed groups and of the protobuf wire format of vg.Alignment
+// (field numbers verified on the reference's fixture test_reads.gam).
+#include "common.h"
+
+#include <cstring>
+
+using namespace vgan;
+
+void vgan_alnset::fill_view(vgan_alnset_view *v) const {
+    v->n_reads = n_reads();
+    v->seq_off = seq_off.data();
+    v->seq = seq.data();
+    v->qual_off = qual_off.data();
+    v->qual = qual.data();
+    v->mapq = mapq.data();
+    v->identity = identity.data();
+    v->name_off = name_off.data();
+    v->name = name.data();
+    v->map_off = map_off.data();
+    v->m_node = m_node.data();
+    v->m_offset = m_offset.data();
+    v->m_rev = m_rev.data();
+    v->edit_off = edit_off.data();
+    v->e_from = e_from.data();
+    v->e_to = e_to.data();
+    v->e_seq_off = e_seq_off.data();
+    v->e_seq = e_seq.data();
+}
+
+namespace {
+
+struct Cur {
+    const uint8_t *p, *e;
+    bool ok = true;
+    bool done() const { return p >= e; }
+    uint64_t varint() {
+        uint64_t v = 0;
+        int shift = 0;
+        while (p < e) {
+            const uint8_t b = *p++;
+            v |= (uint64_t)(b & 0x7f) << shift;
+            if (!(b & 0x80)) return v;
+            shift += 7;
+            if (shift > 63) break;
+        }
+        ok = false;
+        return 0;
+    }
+    Cur sub() {
+        const uint64_t n = varint();
+        if (!ok || n > (uint64_t)(e - p)) {
+            ok = false;
+            return Cur{p, p, false};
+        }
+        Cur c{p, p + n, true};
+        p += n;
+        return c;
+    }
+    void skip(int wt) {
+        switch (wt) {
+        case 0: varint(); break;
+        case 1: if (e - p >= 8) p += 8; else ok = false; break;
+        case 2: sub(); break;
+        case 5: if (e - p >= 4) p += 4; else ok = false; break;
+        default: ok = false;
+        }
+    }
+};
+
+bool parse_edit(Cur c, vgan_alnset &a) {
+    int32_t from = 0, to = 0;
+    const uint8_t *sb = nullptr, *se = nullptr;
+    while (!c.done() && c.ok) {
+        const uint64_t key = c.varint();
+        const int f = (int)(key >> 3), wt = (int)(key & 7);
+        if (f == 1 && wt == 0) from = (int32_t)c.varint();
+        else if (f == 2 && wt == 0) to = (int32_t)c.varint();
+        else if (f == 3 && wt == 2) {
+            Cur s = c.sub();
+            sb = s.p;
+            se = s.e;
+        } else c.skip(wt);
+    }
+    if (!c.ok) return false;
+    a.e_from.push_back(from);
+    a.e_to.push_back(to);
+    if (sb) a.e_seq.append((const char *)sb, se - sb);
+    a.e_seq_off.push_back((int64_t)a.e_seq.size());
+    return true;
+}
+
+bool parse_mapping(Cur c, vgan_alnset &a) {
+    int64_t node = 0, off = 0;
+    uint8_t rev = 0;
+    while (!c.done() && c.ok) {
+        const uint64_t key = c.varint();
+        const int f = (int)(key >> 3), wt = (int)(key & 7);
+        if (f == 1 && wt == 2) {
+            Cur p = c.sub();
+            while (!p.done() && p.ok) {
+                const uint64_t k2 = p.varint();
+                const int f2 = (int)(k2 >> 3), w2 = (int)(k2 & 7);
+                if (f2 == 1 && w2 == 0) node = (int64_t)p.varint();
+                else if (f2 == 2 && w2 == 0) off = (int64_t)p.varint();
+                else if (f2 == 4 && w2 == 0) rev = p.varint() != 0;
+                else p.skip(w2);
+            }
+            if (!p.ok) return false;
+        } else if (f == 2 && wt == 2) {
+            if (!parse_edit(c.sub(), a)) return false;
+        } else c.skip(wt);
+    }
+    if (!c.ok) return false;
+    a.m_node.push_back(node);
+    a.m_offset.push_back(off);
+    a.m_rev.push_back(rev);
+    a.edit_off.push_back((int64_t)a.e_from.size());
+    return true;
+}
+
+struct Mark {
+    size_t seq, qual, name, e_seq, m, e;
+};
+
+bool parse_alignment(Cur c, vgan_alnset &a, int keep_unmapped) {
+    const Mark mk{a.seq.size(), a.qual.size(), a.name.size(), a.e_seq.size(), a.m_node.size(), a.e_from.size()};
+    int32_t mapq = 0;
+    double identity = 0.0;
+    while (!c.done() && c.ok) {
+        const uint64_t key = c.varint();
+        const int f = (int)(key >> 3), wt = (int)(key & 7);
+        if (f == 1 && wt == 2) {
+            Cur s = c.sub();
+            a.seq.append((const char *)s.p, s.e - s.p);
+        } else if (f == 2 && wt == 2) {
+            Cur path = c.sub();
+            while (!path.done() && path.ok) {
+                const uint64_t k2 = path.varint();
+                const int f2 = (int)(k2 >> 3), w2 = (int)(k2 & 7);
+                if (f2 == 2 && w2 == 2) {
+                    if (!parse_mapping(path.sub(), a)) return false;
+                } else path.skip(w2);
+            }
+            if (!path.ok) return false;
+        } else if (f == 3 && wt == 2) {
+            Cur s = c.sub();
+            a.name.append((const char *)s.p, s.e - s.p);
+        } else if (f == 4 && wt == 2) {
+            Cur s = c.sub();
+            a.qual.append((const char *)s.p, s.e - s.p);
+        } else if (f == 5 && wt == 0) {
+            mapq = (int32_t)c.varint();
+        } else if (f == 16 && wt == 1) {
+            if (c.e - c.p < 8) return false;
+            memcpy(&identity, c.p, 8);
+            c.p += 8;
+        } else c.skip(wt);
+    }
+    if (!c.ok) return false;
+    if (!keep_unmapped && identity == 0.0) { // readGAM.h:47: "Discard unmapped reads"
+        a.seq.resize(mk.seq);
+        a.qual.resize(mk.qual);
+        a.name.resize(mk.name);
+        a.e_seq.resize(mk.e_seq);
+        a.m_node.resize(mk.m);
+        a.m_offset.resize(mk.m);
+        a.m_rev.resize(mk.m);
+        a.edit_off.resize(mk.m + 1);
+        a.e_from.resize(mk.e);
+        a.e_to.resize(mk.e);
+        a.e_seq_off.resize(mk.e + 1);
+        return true;
+    }
+    a.seq_off.push_back((int64_t)a.seq.size());
+    a.qual_off.push_back((int64_t)a.qual.size());
+    a.name_off.push_back((int64_t)a.name.size());
+    a.map_off.push_back((int64_t)a.m_node.size());
+    a.mapq.push_back(mapq);
+    a.identity.push_back(identity);
+    return true;
+}
+
+void put_varint(std::string &o, uint64_t v) {
+    while (v >= 0x80) {
+        o += (char)((v & 0x7f) | 0x80);
+        v >>= 7;
+    }
+    o += (char)v;
+}
+void put_ld(std::string &o, int f, const std::string &payload) {
+    put_varint(o, ((uint64_t)f << 3) | 2);
+    put_varint(o, payload.size());
+    o += payload;
+}
+void put_ld(std::string &o, int f, const char *p, size_t n) {
+    put_varint(o, ((uint64_t)f << 3) | 2);
+    put_varint(o, n);
+    o.append(p, n);
+}
+void put_vi(std::string &o, int f, uint64_t v) {
+    put_varint(o, (uint64_t)f << 3);
+    put_varint(o, v);
+}
+
+} // namespace
+
+extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped, vgan_alnset **out) {
+    if (!bytes || !out) return fail(VGAN_EINVAL, "vgan_aln_parse_gam: null argument");
+    std::string inflated;
+    const uint8_t *p = (const uint8_t *)bytes;
+    if (n >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
+        if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
+        p = (const uint8_t *)inflated.data();
+        n = inflated.size();
+    }
+    auto a = new vgan_alnset();
+    Cur c{p, p + n, true};
+    while (!c.done()) {
+        const uint64_t count = c.varint();
+        if (!c.ok) break;
+        bool first = true;
+        for (uint64_t i = 0; i < count && c.ok; ++i) {
+            Cur item = c.sub();
+            if (!c.ok) break;
+            if (first) {
+                first = false;
+                if (item.e - item.p == 3 && memcmp(item.p, "GAM", 3) == 0) continue; // type tag
+            }
+            if (!parse_alignment(item, *a, keep_unmapped)) {
+                c.ok = false;
+                break;
+            }
+        }
+        if (!c.ok) break;
+    }
+    if (!c.ok) {
+        delete a;
+        return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+    }
+    *out = a;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_aln_read_gam(const char *path, int keep_unmapped, vgan_alnset **out) {
+    if (!path || !out) return fail(VGAN_EINVAL, "vgan_aln_read_gam: null argument");
+    std::string raw;
+    if (!read_file(path, raw, false)) return fail(VGAN_EIO, "cannot read %s", path);
+    return vgan_aln_parse_gam(raw.data(), raw.size(), keep_unmapped, out);
+}
+
+extern "C" int vgan_aln_write_gam(const vgan_alnset *a, const char *path, int group_size) {
+    if (!a || !path) return fail(VGAN_EINVAL, "vgan_aln_write_gam: null argument");
+    if (group_size <= 0) group_size = 512;
+    std::string body, msg, pth, mp, pos, ed, gz, file;
+    const int64_t R = a->n_reads();
+    for (int64_t g0 = 0; g0 < R; g0 += group_size) {
+        const int64_t g1 = std::min<int64_t>(R, g0 + group_size);
+        body.clear();
+        put_varint(body, (uint64_t)(g1 - g0 + 1));
+        put_varint(body, 3);
+        body += "GAM";
+        for (int64_t r = g0; r < g1; ++r) {
+            msg.clear();
+            if (a->seq_off[r + 1] > a->seq_off[r]) put_ld(msg, 1, a->seq.data() + a->seq_off[r], a->seq_off[r + 1] - a->seq_off[r]);
+            pth.clear();
+            for (int64_t m = a->map_off[r]; m < a->map_off[r + 1]; ++m) {
+                mp.clear();
+                pos.clear();
+                if (a->m_node[m]) put_vi(pos, 1, (uint64_t)a->m_node[m]);
+                if (a->m_offset[m]) put_vi(pos, 2, (uint64_t)a->m_offset[m]);
+                if (a->m_rev[m]) put_vi(pos, 4, 1);
+                put_ld(mp, 1, pos);
+                for (int64_t e = a->edit_off[m]; e < a->edit_off[m + 1]; ++e) {
+                    ed.clear();
+                    if (a->e_from[e]) put_vi(ed, 1, (uint64_t)(int64_t)a->e_from[e]);
+                    if (a->e_to[e]) put_vi(ed, 2, (uint64_t)(int64_t)a->e_to[e]);
+                    if (a->e_seq_off[e + 1] > a->e_seq_off[e])
+                        put_ld(ed, 3, a->e_seq.data() + a->e_seq_off[e], a->e_seq_off[e + 1] - a->e_seq_off[e]);
+                    put_ld(mp, 2, ed);
+                }
+                put_vi(mp, 5, (uint64_t)(m - a->map_off[r] + 1));
+                put_ld(pth, 2, mp);
+            }
+            put_ld(msg, 2, pth);
+            if (a->name_off[r + 1] > a->name_off[r]) put_ld(msg, 3, a->name.data() + a->name_off[r], a->name_off[r + 1] - a->name_off[r]);
+            if (a->qual_off[r + 1] > a->qual_off[r]) put_ld(msg, 4, a->qual.data() + a->qual_off[r], a->qual_off[r + 1] - a->qual_off[r]);
+            if (a->mapq[r]) put_vi(msg, 5, (uint64_t)a->mapq[r]);
+            if (a->identity[r] != 0.0) {
+                put_varint(msg, (16u << 3) | 1);
+                msg.append((const char *)&a->identity[r], 8);
+            }
+            put_varint(body, msg.size());
+            body += msg;
+        }
+        // one gzip member per group (the BGZF-style framing vg emits is also a concatenation of members)
+        if (!gzip_bytes(body, gz)) return fail(VGAN_EIO, "gzip failed");
+        file += gz;
+    }
+    if (R == 0) {
+        body.clear();
+        if (!gzip_bytes(body, gz)) return fail(VGAN_EIO, "gzip failed");
+        file = gz;
+    }
+    if (!write_file(path, file)) return fail(VGAN_EIO, "cannot write %s", path);
+    return VGAN_OK;
+}
+
+extern "C" int vgan_aln_from_arrays(const vgan_alnset_view *v, vgan_alnset **out) {
+    if (!v || !out || v->n_reads < 0) return fail(VGAN_EINVAL, "vgan_aln_from_arrays: bad view");
+    auto a = new vgan_alnset();
+    const int64_t R = v->n_reads;
+    a->seq_off.assign(v->seq_off, v->seq_off + R + 1);
+    a->seq.assign(v->seq, (size_t)v->seq_off[R]);
+    a->qual_off.assign(v->qual_off, v->qual_off + R + 1);
+    a->qual.assign(v->qual, (size_t)v->qual_off[R]);
+    if (v->name_off) {
+        a->name_off.assign(v->name_off, v->name_off + R + 1);
+        a->name.assign(v->name, (size_t)v->name_off[R]);
+    } else {
+        a->name_off.assign((size_t)R + 1, 0);
+    }
+    a->mapq.assign(v->mapq, v->mapq + R);
+    a->identity.assign(v->identity, v->identity + R);
+    a->map_off.assign(v->map_off, v->map_off + R + 1);
+    const int64_t M = v->map_off[R];
+    a->m_node.assign(v->m_node, v->m_node + M);
+    a->m_offset.assign(v->m_offset, v->m_offset + M);
+    a->m_rev.assign(v->m_rev, v->m_rev + M);
+    a->edit_off.assign(v->edit_off, v->edit_off + M + 1);
+    const int64_t E = v->edit_off[M];
+    a->e_from.assign(v->e_from, v->e_from + E);
+    a->e_to.assign(v->e_to, v->e_to + E);
+    a->e_seq_off.assign(v->e_seq_off, v->e_seq_off + E + 1);
+    a->e_seq.assign(v->e_seq, (size_t)v->e_seq_off[E]);
+    *out = a;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_aln_view_get(const vgan_alnset *a, vgan_alnset_view *out) {
+    if (!a || !out) return fail(VGAN_EINVAL, "vgan_aln_view_get: null argument");
+    a->fill_view(out);
+    return VGAN_OK;
+}
+
+extern "C" void vgan_aln_free(vgan_alnset *a) { delete a; }

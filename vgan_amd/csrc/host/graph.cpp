@@ -1,0 +1,329 @@
+// Graph + hcfiles sidecars: the host-side replacement of readPathHandleGraph() and the load_*() readers
+// (reference src/readPathHandleGraph.cpp:14-37, src/load.cpp:6-58,283-345).  The ODGI .og binary cannot
+// be parsed without libbdsg, so the node sequences and paths come from GFA S/P lines.
+#include "common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <set>
+#include <sstream>
+
+using namespace vgan;
+
+void vgan_graph::fill_view(vgan_graph_view *v) const {
+    v->min_id = min_id;
+    v->max_id = max_id;
+    v->node_seq_off = node_seq_off.data();
+    v->node_seq = node_seq.data();
+    v->n_paths = n_paths;
+    v->mask_words = mask_words;
+    v->mask = mask.data();
+    v->pangenome_base = pangenome_base.data();
+    v->mappability = mappability.data();
+    v->n_mappability = mappability.size();
+    v->path_names = path_names.c_str();
+    v->parents_txt = parents_txt.c_str();
+    v->children_txt = children_txt.c_str();
+}
+
+namespace {
+
+struct LineIter {
+    const std::string &s;
+    size_t pos = 0;
+    explicit LineIter(const std::string &str) : s(str) {}
+    bool next(const char *&b, const char *&e) {
+        if (pos >= s.size()) return false;
+        size_t nl = s.find('\n', pos);
+        if (nl == std::string::npos) nl = s.size();
+        b = s.data() + pos;
+        e = s.data() + nl;
+        if (e > b && e[-1] == '\r') --e;
+        pos = nl + 1;
+        return true;
+    }
+};
+
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
+
+void tokens_ws(const char *b, const char *e, std::vector<std::pair<const char *, const char *>> &out) {
+    out.clear();
+    while (b < e) {
+        while (b < e && is_ws(*b)) ++b;
+        if (b >= e) break;
+        const char *t = b;
+        while (b < e && !is_ws(*b)) ++b;
+        out.emplace_back(t, b);
+    }
+}
+
+bool parse_i64(const char *b, const char *e, int64_t &v) {
+    if (b >= e) return false;
+    bool neg = false;
+    if (*b == '-' || *b == '+') {
+        neg = *b == '-';
+        ++b;
+    }
+    if (b >= e || *b < '0' || *b > '9') return false;
+    int64_t x = 0;
+    while (b < e && *b >= '0' && *b <= '9') x = x * 10 + (*b++ - '0'); // stoi semantics: stop at first non-digit
+    v = neg ? -x : x;
+    return true;
+}
+
+int load_gfa(const std::string &txt, vgan_graph &g) {
+    std::map<int64_t, std::string> seqs;
+    std::vector<std::string> names;
+    LineIter it(txt);
+    const char *b, *e;
+    while (it.next(b, e)) {
+        if (b >= e) continue;
+        if (*b == 'S') {
+            const char *t1 = (const char *)memchr(b, '\t', e - b);
+            if (!t1) return fail(VGAN_EIO, "GFA: malformed S line");
+            const char *t2 = (const char *)memchr(t1 + 1, '\t', e - t1 - 1);
+            if (!t2) return fail(VGAN_EIO, "GFA: malformed S line");
+            const char *t3 = (const char *)memchr(t2 + 1, '\t', e - t2 - 1);
+            if (!t3) t3 = e;
+            int64_t id;
+            if (!parse_i64(t1 + 1, t2, id) || id < 0) return fail(VGAN_EIO, "GFA: non-numeric segment name");
+            seqs[id].assign(t2 + 1, t3);
+        } else if (*b == 'P') {
+            const char *t1 = (const char *)memchr(b, '\t', e - b);
+            if (!t1) return fail(VGAN_EIO, "GFA: malformed P line");
+            const char *t2 = (const char *)memchr(t1 + 1, '\t', e - t1 - 1);
+            if (!t2) return fail(VGAN_EIO, "GFA: malformed P line");
+            const char *t3 = (const char *)memchr(t2 + 1, '\t', e - t2 - 1);
+            if (!t3) t3 = e;
+            names.emplace_back(t1 + 1, t2);
+            std::vector<std::pair<int64_t, bool>> steps;
+            const char *p = t2 + 1;
+            while (p < t3) {
+                const char *c = (const char *)memchr(p, ',', t3 - p);
+                if (!c) c = t3;
+                if (c - p >= 2) {
+                    int64_t id;
+                    if (!parse_i64(p, c - 1, id)) return fail(VGAN_EIO, "GFA: bad path step");
+                    steps.emplace_back(id, c[-1] == '-');
+                }
+                p = c + 1;
+            }
+            g.path_steps.push_back(std::move(steps));
+        }
+    }
+    if (seqs.empty()) return fail(VGAN_EIO, "GFA: no S lines");
+    g.min_id = seqs.begin()->first;
+    g.max_id = seqs.rbegin()->first;
+    g.node_seq_off.assign((size_t)g.max_id + 2, 0);
+    g.node_seq.clear();
+    for (int64_t id = 0; id <= g.max_id; ++id) {
+        g.node_seq_off[id] = (int64_t)g.node_seq.size();
+        auto f = seqs.find(id);
+        if (f != seqs.end()) g.node_seq += f->second;
+    }
+    g.node_seq_off[g.max_id + 1] = (int64_t)g.node_seq.size();
+    g.path_names.clear();
+    for (auto &n : names) g.path_names += n + "\n";
+    g.n_paths = (uint32_t)names.size();
+    return VGAN_OK;
+}
+
+void mask_from_steps(vgan_graph &g) {
+    g.mask_words = (g.n_paths + 63) / 64;
+    g.mask.assign((size_t)(g.max_id + 1) * g.mask_words, 0);
+    for (size_t p = 0; p < g.path_steps.size(); ++p)
+        for (auto &st : g.path_steps[p])
+            if (st.first >= 0 && st.first <= g.max_id) g.mask[(size_t)st.first * g.mask_words + p / 64] |= 1ull << (p % 64);
+}
+
+} // namespace
+
+extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vgan_graph **out) {
+    if (!gfa_path || !out) return fail(VGAN_EINVAL, "vgan_graph_load: null argument");
+    std::string txt;
+    if (!read_file(gfa_path, txt)) return fail(VGAN_EIO, "cannot read %s", gfa_path);
+    auto g = new vgan_graph();
+    int rc = load_gfa(txt, *g);
+    if (rc) {
+        delete g;
+        return rc;
+    }
+    std::string dir = hcfiles_dir ? hcfiles_dir : "";
+    if (!dir.empty() && dir.back() != '/') dir += '/';
+    std::string side;
+    // graph_paths (load.cpp:43-58): first whitespace token of each line
+    if (!dir.empty() && read_text_maybe_gz(dir + "graph_paths", side)) {
+        g->path_names.clear();
+        uint32_t n = 0;
+        LineIter it(side);
+        const char *b, *e;
+        std::vector<std::pair<const char *, const char *>> tk;
+        while (it.next(b, e)) {
+            tokens_ws(b, e, tk);
+            if (tk.empty()) continue;
+            g->path_names.append(tk[0].first, tk[0].second);
+            g->path_names += '\n';
+            ++n;
+        }
+        if (g->n_paths && n != g->n_paths && !g->path_steps.empty()) {
+            // sidecar wins (it is what indexes path_supports); GFA P lines are then only used for writing
+            g->path_steps.clear();
+        }
+        g->n_paths = n;
+    }
+    // path_supports (load.cpp:283-300): row = line index = node id, first P characters
+    if (!dir.empty() && read_text_maybe_gz(dir + "path_supports", side)) {
+        g->mask_words = (g->n_paths + 63) / 64;
+        g->mask.assign((size_t)(g->max_id + 1) * g->mask_words, 0);
+        LineIter it(side);
+        const char *b, *e;
+        int64_t row = 0;
+        while (it.next(b, e)) {
+            if (row <= g->max_id) {
+                const int64_t n = std::min<int64_t>(e - b, g->n_paths);
+                uint64_t *w = &g->mask[(size_t)row * g->mask_words];
+                for (int64_t j = 0; j < n; ++j)
+                    if (b[j] == '1') w[j >> 6] |= 1ull << (j & 63);
+            }
+            ++row;
+        }
+    } else {
+        mask_from_steps(*g);
+    }
+    // parsed_pangenome_mapping (load.cpp:27-41): value = stoi(tok[1]) + 1
+    g->pangenome_base.assign((size_t)g->max_id + 1, -1);
+    if (!dir.empty() && read_text_maybe_gz(dir + "parsed_pangenome_mapping", side)) {
+        LineIter it(side);
+        const char *b, *e;
+        std::vector<std::pair<const char *, const char *>> tk;
+        while (it.next(b, e)) {
+            tokens_ws(b, e, tk);
+            if (tk.size() < 2) continue;
+            int64_t id, v;
+            if (!parse_i64(tk[0].first, tk[0].second, id) || !parse_i64(tk[1].first, tk[1].second, v)) continue;
+            // the reference keys the map by the token string; "007" != "7": keep only canonical decimal keys
+            if (id >= 0 && id <= g->max_id && std::to_string(id).size() == (size_t)(tk[0].second - tk[0].first))
+                g->pangenome_base[id] = (int32_t)(v + 1);
+        }
+    } else {
+        int64_t pos = 0;
+        for (int64_t id = g->min_id; id <= g->max_id; ++id) {
+            if (g->seq_len(id) > 0) g->pangenome_base[id] = (int32_t)(pos + 1);
+            pos += g->seq_len(id);
+        }
+    }
+    // mappability.tsv (load.cpp:6-24): append value for i in [start,end)
+    g->mappability.clear();
+    if (!dir.empty() && read_text_maybe_gz(dir + "mappability.tsv", side)) {
+        LineIter it(side);
+        const char *b, *e;
+        std::vector<std::pair<const char *, const char *>> tk;
+        while (it.next(b, e)) {
+            tokens_ws(b, e, tk);
+            if (tk.size() < 4) continue;
+            int64_t s0, s1;
+            if (!parse_i64(tk[1].first, tk[1].second, s0) || !parse_i64(tk[2].first, tk[2].second, s1)) continue;
+            const double v = strtod(std::string(tk[3].first, tk[3].second).c_str(), nullptr);
+            for (int64_t i = s0; i < s1; ++i) g->mappability.push_back(v);
+        }
+    } else {
+        int32_t mx = 0;
+        for (int32_t v : g->pangenome_base) mx = std::max(mx, v);
+        g->mappability.assign((size_t)mx + 16, 1.0);
+    }
+    if (!dir.empty()) {
+        read_text_maybe_gz(dir + "parents.txt", g->parents_txt);
+        read_text_maybe_gz(dir + "children.txt", g->children_txt);
+    }
+    *out = g;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_graph_from_arrays(const vgan_graph_view *v, vgan_graph **out) {
+    if (!v || !out || v->max_id < 0 || !v->node_seq_off) return fail(VGAN_EINVAL, "vgan_graph_from_arrays: bad view");
+    auto g = new vgan_graph();
+    g->min_id = v->min_id;
+    g->max_id = v->max_id;
+    g->node_seq_off.assign(v->node_seq_off, v->node_seq_off + v->max_id + 2);
+    g->node_seq.assign(v->node_seq, (size_t)v->node_seq_off[v->max_id + 1]);
+    g->n_paths = v->n_paths;
+    g->mask_words = (v->n_paths + 63) / 64;
+    g->mask.assign(v->mask, v->mask + (size_t)(v->max_id + 1) * g->mask_words);
+    g->pangenome_base.assign(v->pangenome_base, v->pangenome_base + v->max_id + 1);
+    g->mappability.assign(v->mappability, v->mappability + v->n_mappability);
+    g->path_names = v->path_names ? v->path_names : "";
+    g->parents_txt = v->parents_txt ? v->parents_txt : "";
+    g->children_txt = v->children_txt ? v->children_txt : "";
+    *out = g;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_graph_view_get(const vgan_graph *g, vgan_graph_view *out) {
+    if (!g || !out) return fail(VGAN_EINVAL, "vgan_graph_view_get: null argument");
+    g->fill_view(out);
+    return VGAN_OK;
+}
+
+extern "C" int vgan_graph_write(const vgan_graph *g, const char *dir_c) {
+    if (!g || !dir_c) return fail(VGAN_EINVAL, "vgan_graph_write: null argument");
+    std::string dir = dir_c;
+    if (!dir.empty() && dir.back() != '/') dir += '/';
+    std::string gfa = "H\tVN:Z:1.0\n";
+    for (int64_t id = g->min_id; id <= g->max_id; ++id) {
+        if (g->seq_len(id) == 0) continue;
+        gfa += "S\t" + std::to_string(id) + "\t";
+        gfa.append(g->seq_ptr(id), (size_t)g->seq_len(id));
+        gfa += "\n";
+    }
+    {
+        std::istringstream names(g->path_names);
+        std::string nm;
+        std::set<std::pair<std::pair<int64_t, bool>, std::pair<int64_t, bool>>> links;
+        for (size_t p = 0; p < g->path_steps.size(); ++p) {
+            std::getline(names, nm);
+            gfa += "P\t" + nm + "\t";
+            const auto &st = g->path_steps[p];
+            for (size_t i = 0; i < st.size(); ++i) {
+                if (i) gfa += ",";
+                gfa += std::to_string(st[i].first) + (st[i].second ? "-" : "+");
+                if (i) links.insert({st[i - 1], st[i]});
+            }
+            gfa += "\t*\n";
+        }
+        for (auto &l : links) {
+            gfa += "L\t" + std::to_string(l.first.first) + "\t" + (l.first.second ? "-" : "+") + "\t" +
+                   std::to_string(l.second.first) + "\t" + (l.second.second ? "-" : "+") + "\t*\n";
+        }
+    }
+    if (!write_file(dir + "graph.gfa", gfa)) return fail(VGAN_EIO, "cannot write %sgraph.gfa", dir.c_str());
+    std::string ps;
+    ps.reserve((size_t)(g->max_id + 1) * (g->n_paths + 1));
+    for (int64_t id = 0; id <= g->max_id; ++id) {
+        const uint64_t *w = &g->mask[(size_t)id * g->mask_words];
+        for (uint32_t p = 0; p < g->n_paths; ++p) ps += ((w[p >> 6] >> (p & 63)) & 1) ? '1' : '0';
+        ps += '\n';
+    }
+    std::string gz;
+    if (!gzip_bytes(ps, gz) || !write_file(dir + "path_supports.gz", gz)) return fail(VGAN_EIO, "cannot write path_supports");
+    std::string pm;
+    for (int64_t id = 0; id <= g->max_id; ++id)
+        if (g->pangenome_base[id] >= 0) pm += std::to_string(id) + "\t" + std::to_string(g->pangenome_base[id] - 1) + "\n";
+    if (!write_file(dir + "parsed_pangenome_mapping", pm)) return fail(VGAN_EIO, "cannot write parsed_pangenome_mapping");
+    std::string mp;
+    char buf[128];
+    for (size_t i = 0; i < g->mappability.size();) {
+        size_t j = i + 1;
+        while (j < g->mappability.size() && g->mappability[j] == g->mappability[i]) ++j;
+        snprintf(buf, sizeof buf, "chrM\t%zu\t%zu\t%.17g\n", i, j, g->mappability[i]);
+        mp += buf;
+        i = j;
+    }
+    if (!write_file(dir + "mappability.tsv", mp)) return fail(VGAN_EIO, "cannot write mappability.tsv");
+    if (!write_file(dir + "graph_paths", g->path_names)) return fail(VGAN_EIO, "cannot write graph_paths");
+    if (!write_file(dir + "parents.txt", g->parents_txt)) return fail(VGAN_EIO, "cannot write parents.txt");
+    if (!write_file(dir + "children.txt", g->children_txt)) return fail(VGAN_EIO, "cannot write children.txt");
+    return VGAN_OK;
+}
+
+extern "C" void vgan_graph_free(vgan_graph *g) { delete g; }

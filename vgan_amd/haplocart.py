@@ -1,0 +1,356 @@
+"""Python plumbing around the HaploCart C-ABI (include/vgan_gpu.h): owners for the native objects, numpy
+views of their arrays, torch tensors for device-resident batches.  No arithmetic of the hot path lives here.
+
+Reference call sites mirrored: Haplocart::update loop (src/HaploCart.cpp:408-421) -> HcContext.accumulate /
+finalize; Haplocart::get_posterior (src/get_posterior.cpp:87-127) -> HcContext.posterior.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+MODE_NODE_WEIGHTS, MODE_PER_READ, MODE_PER_READ_DENSE = 0, 1, 2
+
+
+def _np_view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class Graph:
+    """Owner of a native vgan_graph (GFA + hcfiles sidecars, or synthetic)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.view = N.GraphView()
+        N.check(N.lib().vgan_graph_view_get(self._h, C.byref(self.view)))
+
+    @classmethod
+    def load(cls, gfa_path, hcfiles_dir=None):
+        h = N.vp()
+        N.check(N.lib().vgan_graph_load(gfa_path.encode(), hcfiles_dir.encode() if hcfiles_dir else None, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, min_id, max_id, node_seq_off, node_seq, n_paths, mask, pangenome_base, mappability,
+                    path_names="", parents_txt="", children_txt=""):
+        keep = dict(
+            node_seq_off=np.ascontiguousarray(node_seq_off, np.int64),
+            node_seq=np.ascontiguousarray(np.frombuffer(bytes(node_seq) + b"\0", np.uint8)),
+            mask=np.ascontiguousarray(mask, np.uint64),
+            pangenome_base=np.ascontiguousarray(pangenome_base, np.int32),
+            mappability=np.ascontiguousarray(mappability, np.float64))
+        v = N.GraphView(min_id, max_id, keep["node_seq_off"].ctypes.data, keep["node_seq"].ctypes.data, n_paths,
+                        (n_paths + 63) // 64, keep["mask"].ctypes.data, keep["pangenome_base"].ctypes.data,
+                        keep["mappability"].ctypes.data, len(keep["mappability"]), path_names.encode(),
+                        parents_txt.encode(), children_txt.encode())
+        h = N.vp()
+        N.check(N.lib().vgan_graph_from_arrays(C.byref(v), C.byref(h)))
+        return cls(h)
+
+    def write(self, directory):
+        N.check(N.lib().vgan_graph_write(self._h, directory.encode()))
+
+    # numpy views (valid while self is alive)
+    @property
+    def n_paths(self):
+        return self.view.n_paths
+
+    @property
+    def max_id(self):
+        return self.view.max_id
+
+    @property
+    def min_id(self):
+        return self.view.min_id
+
+    @property
+    def mask(self):
+        w = self.view.mask_words
+        return _np_view(self.view.mask, (self.view.max_id + 1) * w, np.uint64).reshape(self.view.max_id + 1, w)
+
+    @property
+    def node_seq_off(self):
+        return _np_view(self.view.node_seq_off, self.view.max_id + 2, np.int64)
+
+    @property
+    def node_seq(self):
+        return _np_view(self.view.node_seq, int(self.node_seq_off[-1]), np.uint8)
+
+    @property
+    def pangenome_base(self):
+        return _np_view(self.view.pangenome_base, self.view.max_id + 1, np.int32)
+
+    @property
+    def mappability(self):
+        return _np_view(self.view.mappability, self.view.n_mappability, np.float64)
+
+    @property
+    def path_names(self):
+        return (self.view.path_names or b"").decode().split()
+
+    @property
+    def parents_txt(self):
+        return (self.view.parents_txt or b"").decode()
+
+    @property
+    def children_txt(self):
+        return (self.view.children_txt or b"").decode()
+
+    def pathsgo(self):
+        """bool-per-byte [max_id+1, P] matrix as the reference's NodeInfo::pathsgo (for the oracle)."""
+        m = self.mask
+        bits = np.unpackbits(m.view(np.uint8).reshape(m.shape[0], -1), axis=1, bitorder="little")
+        return np.ascontiguousarray(bits[:, : self.n_paths])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_graph_free(self._h)
+            self._h = None
+
+
+class AlnSet:
+    """Owner of a native vgan_alnset (decoded GAM)."""
+
+    FIELDS = (("seq_off", np.int64), ("qual_off", np.int64), ("name_off", np.int64), ("map_off", np.int64))
+
+    def __init__(self, handle):
+        self._h = handle
+        self.view = N.AlnSetView()
+        N.check(N.lib().vgan_aln_view_get(self._h, C.byref(self.view)))
+
+    @classmethod
+    def read_gam(cls, path, keep_unmapped=False):
+        h = N.vp()
+        N.check(N.lib().vgan_aln_read_gam(path.encode(), int(keep_unmapped), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def parse_gam(cls, data, keep_unmapped=False):
+        h = N.vp()
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        N.check(N.lib().vgan_aln_parse_gam(C.addressof(buf), len(data), int(keep_unmapped), C.byref(h)))
+        return cls(h)
+
+    def write_gam(self, path, group_size=512):
+        N.check(N.lib().vgan_aln_write_gam(self._h, path.encode(), group_size))
+
+    @property
+    def n_reads(self):
+        return self.view.n_reads
+
+    def arrays(self):
+        """dict of numpy views with the field names of vgan_alnset_view (and of the oracle's orc_alnset)."""
+        v = self.view
+        R = v.n_reads
+        out = {"n_reads": R, "_owner": self}
+        out["seq_off"] = _np_view(v.seq_off, R + 1, np.int64)
+        out["qual_off"] = _np_view(v.qual_off, R + 1, np.int64)
+        out["name_off"] = _np_view(v.name_off, R + 1, np.int64)
+        out["map_off"] = _np_view(v.map_off, R + 1, np.int64)
+        out["seq"] = _np_view(v.seq, int(out["seq_off"][-1]), np.uint8)
+        out["qual"] = _np_view(v.qual, int(out["qual_off"][-1]), np.uint8)
+        out["name"] = _np_view(v.name, int(out["name_off"][-1]), np.uint8)
+        out["mapq"] = _np_view(v.mapq, R, np.int32)
+        out["identity"] = _np_view(v.identity, R, np.float64)
+        M = int(out["map_off"][-1])
+        out["m_node"] = _np_view(v.m_node, M, np.int64)
+        out["m_offset"] = _np_view(v.m_offset, M, np.int64)
+        out["m_rev"] = _np_view(v.m_rev, M, np.uint8)
+        out["edit_off"] = _np_view(v.edit_off, M + 1, np.int64)
+        E = int(out["edit_off"][-1])
+        out["e_from"] = _np_view(v.e_from, E, np.int32)
+        out["e_to"] = _np_view(v.e_to, E, np.int32)
+        out["e_seq_off"] = _np_view(v.e_seq_off, E + 1, np.int64)
+        out["e_seq"] = _np_view(v.e_seq, int(out["e_seq_off"][-1]), np.uint8)
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_aln_free(self._h)
+            self._h = None
+
+
+def reconstruct(graph, alns, r, cap=1 << 16):
+    """a1 of the product front end (for the reconstruction KATs)."""
+    gs = C.create_string_buffer(cap)
+    rs = C.create_string_buffer(cap)
+    sizes = np.zeros(cap, np.int32)
+    lens = np.zeros(3, np.int64)
+    N.check(N.lib().vgan_reconstruct(graph._h, alns._h, r, gs, rs, sizes.ctypes.data, cap, lens.ctypes.data))
+    return gs.raw[: lens[0]], rs.raw[: lens[1]], sizes[: lens[2]].tolist()
+
+
+_BATCH_FIELDS = (("read_seg_off", np.uint32, "R1"), ("read_col_off", np.uint32, "R1"), ("read_qual_off", np.uint32, "R1"),
+                 ("read_algn_len", np.uint16, "R"), ("read_mapq", np.uint8, "R"), ("seg_node", np.uint32, "S"),
+                 ("seg_start", np.uint16, "S"), ("seg_len", np.uint16, "S"), ("graph_seq", np.uint8, "C"),
+                 ("algnseq", np.uint8, "C"), ("qual", np.uint8, "Q"))
+
+
+class HostBatch:
+    """Flattened HaploCart batch in host memory (vgan_hc_flatten)."""
+
+    def __init__(self, graph, alns, r0=0, r1=None, n_threads=0):
+        r1 = alns.n_reads if r1 is None else r1
+        self._h = N.vp()
+        self.stats = N.FlattenStats()
+        N.check(N.lib().vgan_hc_flatten(graph._h, alns._h, r0, r1, n_threads, C.byref(self._h), C.byref(self.stats)))
+        self.c = N.HcBatch()
+        N.check(N.lib().vgan_hc_host_batch_get(self._h, C.byref(self.c)))
+
+    @property
+    def n_reads(self):
+        return self.c.n_reads
+
+    @property
+    def n_segments(self):
+        return self.c.n_segments
+
+    def arrays(self):
+        c = self.c
+        n = {"R1": c.n_reads + 1, "R": c.n_reads, "S": c.n_segments, "C": c.n_cols, "Q": c.n_qual}
+        out = {name: _np_view(getattr(c, name), n[k], dt) for name, dt, k in _BATCH_FIELDS}
+        out["_owner"] = self
+        return out
+
+    def algorithmic_bytes(self, n_paths):
+        """bases + quals + segment descriptors (+ one mask row per segment in PER_READ mode)."""
+        c = self.c
+        io = 2 * c.n_cols + c.n_qual + 8 * c.n_segments + 15 * c.n_reads
+        return {"node_weights": io, "per_read": io + c.n_segments * (8 * ((n_paths + 63) // 64) + 8)}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_hc_host_batch_free(self._h)
+            self._h = None
+
+
+class DeviceBatch:
+    """The same SoA resident in HBM as torch tensors (zero-copy hand-over to vgan_hc_accumulate)."""
+
+    def __init__(self, host_batch, device="cuda:0"):
+        import torch
+        self.t = {}
+        arrs = host_batch.arrays()
+        for name, dt, _ in _BATCH_FIELDS:
+            a = arrs[name]
+            # torch has no uint16/uint32 arithmetic but can hold the bytes: ship as int16/int32 views
+            if dt == np.uint32:
+                a = a.view(np.int32)
+            elif dt == np.uint16:
+                a = a.view(np.int16)
+            self.t[name] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        c = N.HcBatch()
+        c.n_reads, c.n_segments = host_batch.c.n_reads, host_batch.c.n_segments
+        c.n_cols, c.n_qual = host_batch.c.n_cols, host_batch.c.n_qual
+        for name, _, _ in _BATCH_FIELDS:
+            setattr(c, name, self.t[name].data_ptr() if self.t[name].numel() else None)
+        c.on_device = 1
+        self.c = c
+        self.n_reads, self.n_segments = c.n_reads, c.n_segments
+
+
+class HcContext:
+    """One HaploCart device context (vgan_hc_ctx) on one GPU."""
+
+    def __init__(self, graph, background_error_prob=0.0001, use_background_error_prob=False,
+                 is_consensus_fasta=False, device=0):
+        self.graph = graph
+        self._h = N.vp()
+        p = N.HcParams(background_error_prob, int(use_background_error_prob), int(is_consensus_fasta))
+        N.check(N.lib().vgan_hc_create(C.byref(graph.view), C.byref(p), device, C.byref(self._h)))
+        self.n_paths = graph.n_paths
+        self.device = device
+
+    def set_stream(self, stream_ptr):
+        N.check(N.lib().vgan_hc_set_stream(self._h, stream_ptr))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_mode(self, mode):
+        N.check(N.lib().vgan_hc_set_mode(self._h, mode))
+
+    def reset(self):
+        N.check(N.lib().vgan_hc_reset(self._h))
+
+    def accumulate(self, batch):
+        N.check(N.lib().vgan_hc_accumulate(self._h, C.byref(batch.c)))
+
+    def segment_scalars(self, batch):
+        S = np.zeros(batch.n_segments)
+        U = np.zeros(batch.n_segments)
+        N.check(N.lib().vgan_hc_segment_scalars(self._h, C.byref(batch.c), S.ctypes.data, U.ctypes.data))
+        return S, U
+
+    def read_loglik(self, batch):
+        out = np.zeros((batch.n_reads, self.n_paths))
+        N.check(N.lib().vgan_hc_read_loglik(self._h, C.byref(batch.c), out.ctypes.data))
+        return out
+
+    def finalize(self, device_out=None):
+        """final_vec[P] as numpy (synchronises); device_out: optional torch float64 tensor filled on the stream."""
+        out = np.zeros(self.n_paths)
+        N.check(N.lib().vgan_hc_finalize(self._h, device_out.data_ptr() if device_out is not None else None,
+                                         out.ctypes.data))
+        return out
+
+    def finalize_device(self, device_out):
+        N.check(N.lib().vgan_hc_finalize(self._h, device_out.data_ptr(), None))
+
+    def profile_enable(self, enable=True):
+        N.check(N.lib().vgan_hc_profile_enable(self._h, int(enable)))
+
+    def profile_read(self):
+        """{kernel: (summed device ms, launches)} measured with HIP events on the context's stream."""
+        ms = np.zeros(4)
+        n = np.zeros(4, np.uint64)
+        N.check(N.lib().vgan_hc_profile_read(self._h, ms.ctypes.data, n.ctypes.data))
+        names = ("segment", "sweep_segments", "sweep_nodes", "finish")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
+
+    def synchronize(self):
+        N.check(N.lib().vgan_hc_synchronize(self._h))
+
+    def posterior(self, final_vec, predicted=None):
+        fv = np.ascontiguousarray(final_vec, np.float64)
+        if predicted is None:
+            predicted = self.graph.path_names[self.argmax(fv)]
+        buf = C.create_string_buffer(1 << 20)
+        conf = np.zeros(4096)
+        n = N.check(N.lib().vgan_hc_posterior(self._h, fv.ctypes.data, predicted.encode(), buf, 1 << 20,
+                                              conf.ctypes.data, 4096))
+        names = buf.value.decode().split("\n")[:n]
+        return [(names[i], float(conf[i]), i) for i in range(n)]
+
+    @staticmethod
+    def argmax(final_vec):
+        fv = np.ascontiguousarray(final_vec, np.float64)
+        return N.check(N.lib().vgan_hc_argmax(fv.ctypes.data, len(fv)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_hc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def synth_graph(seed=0x76676131, genome_len=16569, n_nodes=11821, n_paths=5179):
+    cfg = N.SynthGraphCfg(seed, genome_len, n_nodes, n_paths)
+    h = N.vp()
+    N.check(N.lib().vgan_synth_hc_graph(C.byref(cfg), C.byref(h)))
+    return Graph(h)
+
+
+def synth_reads(graph, n_reads, seed=0x76676131, read_len=150, indel_rate=0.005, softclip_rate=0.01,
+                low_mapq_rate=0.1, errors=True):
+    cfg = N.SynthReadsCfg(seed, n_reads, read_len, indel_rate, softclip_rate, low_mapq_rate, int(errors))
+    h = N.vp()
+    N.check(N.lib().vgan_synth_hc_reads(graph._h, C.byref(cfg), C.byref(h)))
+    return AlnSet(h)
