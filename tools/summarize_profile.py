@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag> directory (rocprofv3 kernel stats + PMC passes + the bench JSON line)
+into profiles/<name>.md + the raw kernel_stats.csv, for the judge.  usage: summarize_profile.py <tag> <name>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+lines = ["# %s" % name, ""]
+bench = None
+for ln in open(os.path.join(src, "bench_trace.log")):
+    if ln.startswith("{"):
+        bench = json.loads(ln)
+if bench:
+    lines += ["Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --mode %s --steps %d --warmup %d --cpu-seconds 0 --no-parity`"
+              % (bench["config"]["mode"], bench["steps"], bench["warmup"]), "",
+              "bench.py line under the profiler: value = %.4g %s, ms_per_step = %.4f" % (bench["value"], bench["unit"], bench["ms_per_step"]),
+              "roofline (HIP events in bench.py): %s avg %.4f ms/launch, %.1f GB/s algorithmic = %.4f of 8 TB/s" % (
+                  bench["roofline"]["kernel"], bench["roofline"]["avg_launch_ms"], bench["roofline"]["achieved"], bench["roofline"]["frac"]), ""]
+ks = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(dst, name + "_kernel_stats.csv"))
+    lines += ["## rocprofv3 --kernel-trace --stats", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
+    for row in csv.DictReader(open(ks[0])):
+        lines.append("| `%s` | %s | %.0f | %s | %s | %s |" % (row["Name"].split("(")[0], row["Calls"], float(row["AverageNs"]),
+                                                          row["MinNs"], row["MaxNs"], row["Percentage"]))
+    lines.append("")
+pm = {}
+for kind in ("fetch", "write"):
+    f = glob.glob(os.path.join(src, "pmc_" + kind, "*", "*counter_collection.csv"))
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f[0])):
+        agg[(row["Kernel_Name"].split("(")[0], row["Counter_Name"])].append(float(row["Counter_Value"]))
+    for (k, c), v in agg.items():
+        pm.setdefault(k, {})[c] = (len(v), sum(v) / len(v), max(v))
+if pm:
+    lines += ["## PMC (separate passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; units KB per dispatch)", "",
+              "Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half the bytes of a wide (16 B/lane) coalesced "
+              "stream and is uncalibrated for narrower accesses; WRITE_SIZE is exact for 8/16-B stores and float atomics. "
+              "Infinity-Cache hits are counted.", "",
+              "| kernel | FETCH_SIZE mean KB (n, max) | WRITE_SIZE mean KB (n, max) |", "|---|---|---|"]
+    for k, d in pm.items():
+        if not k.startswith("vgan::"):
+            continue
+        f = d.get("FETCH_SIZE", (0, 0, 0))
+        w = d.get("WRITE_SIZE", (0, 0, 0))
+        lines.append("| `%s` | %.1f (%d, %.1f) | %.1f (%d, %.1f) |" % (k, f[1], f[0], f[2], w[1], w[0], w[2]))
+    lines.append("")
+open(os.path.join(dst, name + ".md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))

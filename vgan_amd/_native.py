@@ -103,6 +103,12 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch-ROCm wheels bundle their own libamdhip64; whichever HIP runtime is loaded first owns the GPUs of
+    # the process.  Load torch's first so tensors and this library's kernels share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise ImportError(
             "vgan_amd: native library %s is missing -- build it with `python -m vgan_amd.build` "
