@@ -133,8 +133,13 @@ typedef struct vgan_hc_batch {
     const uint8_t *algnseq;       /* [n_cols] ASCII path_string with '-' at deletions */
     const uint8_t *qual;          /* [n_qual] raw phred */
     int32_t on_device;            /* 0: host pointers (copied by accumulate); 1: device pointers (zero copy) */
-    int32_t reserved;
+    /* largest per-read extents in the batch (vgan_hc_flatten fills them); 0 = unknown.  Batches whose reads fit
+     * 256 columns / 256 quality bytes / 128 segments take the LDS-tiled kernel, others the general one. */
+    uint32_t max_read_cols, max_read_qual, max_read_segs;
 } vgan_hc_batch;
+/* Batch contract: read_*_off ascending; the segments of a read ascend in seg_start; when max_read_* are set the
+ * column ranges [seg_start, seg_start+seg_len) of one read must not overlap (vgan_hc_flatten reports 0 = unknown
+ * for batches where they do, which routes them to the general kernel). */
 
 typedef struct vgan_hc_host_batch vgan_hc_host_batch; /* opaque owner of a host-side batch */
 
@@ -196,11 +201,12 @@ int vgan_hc_synchronize(vgan_hc_ctx *c);
 void vgan_hc_destroy(vgan_hc_ctx *c);
 
 /* Per-kernel device timing with HIP events on the context's stream (bench.py's roofline figure).
- * Slots: 0 segment kernel, 1 per-segment mask sweep, 2 per-node mask sweep, 3 finish. */
-enum { VGAN_HC_K_SEGMENT = 0, VGAN_HC_K_SWEEP_SEG = 1, VGAN_HC_K_SWEEP_NODE = 2, VGAN_HC_K_FINISH = 3, VGAN_HC_K_COUNT = 4 };
+ * Slots: 0 segment kernel, 1 per-segment mask sweep, 2 per-node mask sweep, 3 finish, 4 node-weight accumulate. */
+enum { VGAN_HC_K_SEGMENT = 0, VGAN_HC_K_SWEEP_SEG = 1, VGAN_HC_K_SWEEP_NODE = 2, VGAN_HC_K_FINISH = 3, VGAN_HC_K_NODEACC = 4,
+       VGAN_HC_K_COUNT = 5 };
 int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable);  /* also clears the counters */
 /* synchronises the stream; ms[i] = summed device time of kernel i, launches[i] = number of launches timed */
-int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[4], uint64_t launches[4]);
+int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[5], uint64_t launches[5]);
 
 /* get_posterior (get_posterior.cpp:87-127) on the device: log-sum-exp over the P paths and over the strict
  * descendants of each ancestor of `predicted`.  clades: '\n'-joined names into clade_buf; conf[i] beside it.

@@ -76,10 +76,11 @@ struct vgan_hc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     int mode = VGAN_HC_MODE_NODE_WEIGHTS;
-    uint32_t P = 0, W = 0, rows = 0, row_words = 0;
+    uint32_t P = 0, W = 0, rows = 0, n_tiles = 0;
     HcGraphDev g{};
     HcParamsDev prm{};
     DevBuf<uint64_t> umask;
+    DevBuf<uint16_t> umaskT, tile_word0;
     DevBuf<HcNodeDev> node_tab;
     DevBuf<double> tables; // lq[256] qscore[100] incmap[100]
     DevBuf<double> nodeW, acc_seg, acc_node, totals, final_vec;
@@ -102,8 +103,8 @@ struct vgan_hc_ctx {
     };
     std::vector<Timed> timed;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[VGAN_HC_K_COUNT] = {0, 0, 0, 0};
-    uint64_t prof_n[VGAN_HC_K_COUNT] = {0, 0, 0, 0};
+    double prof_ms[VGAN_HC_K_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t prof_n[VGAN_HC_K_COUNT] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -218,6 +219,11 @@ int stage_batch(vgan_hc_ctx *c, const vgan_hc_batch *b, HcBatchDev &d) {
     return VGAN_OK;
 }
 
+bool tiled_ok(const vgan_hc_batch *b) {
+    return b->max_read_cols > 0 && b->max_read_cols <= HC_TILE_MAX_READ_COLS && b->max_read_qual <= HC_TILE_MAX_READ_QUAL &&
+           b->max_read_segs > 0 && b->max_read_segs <= HC_TILE_MAX_READ_SEGS;
+}
+
 int check_batch(const vgan_hc_batch *b) {
     if (!b) return fail(VGAN_EINVAL, "null batch");
     if (b->n_reads == 0) return VGAN_OK;
@@ -253,7 +259,7 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     c->P = gv->n_paths;
     c->W = (gv->n_paths + 63) / 64;
     c->rows = (uint32_t)gv->max_id + 1;
-    c->row_words = (c->W + HC_SWEEP_TILE_WORDS - 1) / HC_SWEEP_TILE_WORDS * HC_SWEEP_TILE_WORDS;
+    c->n_tiles = 8 * ((c->W + 127) / 128);
     c->prm.bep = params->background_error_prob;
     c->prm.use_bep = params->use_background_error_prob != 0;
     c->prm.consensus = params->is_consensus_fasta != 0;
@@ -265,15 +271,34 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(VGAN_ENODEV, "hipStreamCreate failed"));
     c->stream = c->own_stream;
-    // unsupported-path mask, padded rows
-    std::vector<uint64_t> um((size_t)c->rows * c->row_words, 0);
+    // unsupported-path mask: plain rows + the per-tile bit-transposed copy the sweep reads (hc_device.h)
+    std::vector<uint64_t> um((size_t)c->rows * c->W, 0);
     for (uint32_t r = 0; r < c->rows; ++r) {
         const uint64_t *src = gv->mask + (size_t)r * c->W;
-        uint64_t *dst = &um[(size_t)r * c->row_words];
+        uint64_t *dst = &um[(size_t)r * c->W];
         for (uint32_t w = 0; w < c->W; ++w) {
             uint64_t valid = ~0ull;
             if (w == c->W - 1 && (c->P & 63)) valid = (1ull << (c->P & 63)) - 1;
             dst[w] = ~src[w] & valid;
+        }
+    }
+    const uint32_t tile_base = c->W / c->n_tiles, tile_rem = c->W % c->n_tiles;
+    std::vector<uint16_t> tw0(c->n_tiles + 1, 0);
+    for (uint32_t t = 0; t < c->n_tiles; ++t) tw0[t + 1] = (uint16_t)(tw0[t] + tile_base + (t < tile_rem ? 1 : 0));
+    const uint32_t row_entries = c->n_tiles * 64;
+    std::vector<uint16_t> umT((size_t)c->rows * row_entries, 0);
+    for (uint32_t r = 0; r < c->rows; ++r) {
+        const uint64_t *src = &um[(size_t)r * c->W];
+        uint16_t *dst = &umT[(size_t)r * row_entries];
+        for (uint32_t t = 0; t < c->n_tiles; ++t) {
+            for (uint32_t k = 0; k < (uint32_t)(tw0[t + 1] - tw0[t]); ++k) {
+                uint64_t bits = src[tw0[t] + k];
+                while (bits) {
+                    const int l = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    dst[t * 64 + l] |= (uint16_t)(1u << (15 - k));
+                }
+            }
         }
     }
     std::vector<HcNodeDev> nt(c->rows);
@@ -291,22 +316,30 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         tb[256 + Q] = Q > 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25;
         tb[356 + Q] = pow(10, ((-1 * Q) * 0.1));
     }
-    const size_t accn = (size_t)c->row_words * 64;
-    if ((rc = c->umask.reserve(um.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(456)) ||
+    const size_t accn = (size_t)c->W * 64;
+    if ((rc = c->umask.reserve(um.size())) || (rc = c->umaskT.reserve(umT.size())) ||
+        (rc = c->tile_word0.reserve(tw0.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(456)) ||
         (rc = c->nodeW.reserve(c->rows)) || (rc = c->acc_seg.reserve(accn)) || (rc = c->acc_node.reserve(accn)) ||
         (rc = c->totals.reserve(2)) || (rc = c->final_vec.reserve(c->P)))
         return bail(rc);
     if (hipMemcpy(c->umask.p, um.data(), um.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->umaskT.p, umT.data(), umT.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->tile_word0.p, tw0.data(), tw0.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->node_tab.p, nt.data(), nt.size() * sizeof(HcNodeDev), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->tables.p, tb.data(), tb.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(VGAN_ENODEV, "vgan_hc_create: upload failed"));
     c->g.umask = c->umask.p;
+    c->g.umaskT = c->umaskT.p;
+    c->g.tile_word0 = c->tile_word0.p;
     c->g.node_tab = c->node_tab.p;
     c->g.lq = c->tables.p;
     c->g.qscore = c->tables.p + 256;
     c->g.incmap = c->tables.p + 356;
     c->g.rows = c->rows;
-    c->g.row_words = c->row_words;
+    c->g.mask_words = c->W;
+    c->g.row_entries = row_entries;
+    c->g.n_tiles = c->n_tiles;
+    c->g.tile_base_words = tile_base;
     c->g.n_paths = c->P;
     // posterior side tables
     {
@@ -333,6 +366,8 @@ extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     c->umask.release();
+    c->umaskT.release();
+    c->tile_word0.release();
     c->node_tab.release();
     c->tables.release();
     c->nodeW.release();
@@ -376,8 +411,8 @@ extern "C" int vgan_hc_reset(vgan_hc_ctx *c) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_reset: null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->nodeW.p, 0, (size_t)c->rows * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->acc_seg.p, 0, (size_t)c->row_words * 64 * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->acc_node.p, 0, (size_t)c->row_words * 64 * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->acc_seg.p, 0, (size_t)c->W * 64 * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->acc_node.p, 0, (size_t)c->W * 64 * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->totals.p, 0, 16, c->stream));
     return VGAN_OK;
 }
@@ -390,15 +425,16 @@ extern "C" int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *b) {
     HIPCHK(hipSetDevice(c->device));
     HcBatchDev d{};
     if ((rc = stage_batch(c, b, d))) return rc;
-    if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) {
+    if ((rc = c->segD.reserve(b->n_segments))) return rc;
+    {
         ScopedTimer t(c, VGAN_HC_K_SEGMENT);
-        launch_hc_segments(c->g, d, c->prm, nullptr, nullptr, nullptr, c->nodeW.p, c->totals.p, c->stream);
+        launch_hc_segments(c->g, d, c->prm, tiled_ok(b), nullptr, nullptr, c->segD.p, c->totals.p, c->stream);
+    }
+    if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) {
+        ScopedTimer t(c, VGAN_HC_K_NODEACC);
+        if (launch_hc_nodeacc(d.seg_node, c->segD.p, d.n_segments, c->rows, c->nodeW.p, c->stream))
+            return fail(VGAN_ENODEV, "hipFuncSetAttribute(dynamic LDS) failed");
     } else {
-        if ((rc = c->segD.reserve(b->n_segments))) return rc;
-        {
-            ScopedTimer t(c, VGAN_HC_K_SEGMENT);
-            launch_hc_segments(c->g, d, c->prm, nullptr, nullptr, c->segD.p, nullptr, c->totals.p, c->stream);
-        }
         ScopedTimer t(c, VGAN_HC_K_SWEEP_SEG);
         launch_hc_sweep(c->g, d.seg_node, c->segD.p, d.n_segments, c->mode == VGAN_HC_MODE_PER_READ, c->acc_seg.p, c->stream);
     }
@@ -415,7 +451,7 @@ extern "C" int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *b, d
     HcBatchDev d{};
     if ((rc = stage_batch(c, b, d))) return rc;
     if ((rc = c->segS.reserve(b->n_segments)) || (rc = c->segU.reserve(b->n_segments))) return rc;
-    launch_hc_segments(c->g, d, c->prm, c->segS.p, c->segU.p, nullptr, nullptr, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, tiled_ok(b), c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(S, c->segS.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(U, c->segU.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
@@ -435,7 +471,7 @@ extern "C" int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *b, doubl
     const size_t n = (size_t)b->n_reads * c->P;
     if ((rc = c->segS.reserve(b->n_segments + 1)) || (rc = c->segU.reserve(b->n_segments + 1)) || (rc = c->dump.reserve(n)))
         return rc;
-    launch_hc_segments(c->g, d, c->prm, c->segS.p, c->segU.p, nullptr, nullptr, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, tiled_ok(b), c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
     launch_hc_read_loglik(c->g, d, c->segS.p, c->segU.p, c->dump.p, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, c->dump.p, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -447,7 +483,7 @@ extern "C" int vgan_hc_finalize(vgan_hc_ctx *c, double *d_out, double *out) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_finalize: null context");
     HIPCHK(hipSetDevice(c->device));
     // NODE_WEIGHTS accumulations: one pass of the unsupported-path bitmask over the node weights
-    HIPCHK(hipMemsetAsync(c->acc_node.p, 0, (size_t)c->row_words * 64 * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->acc_node.p, 0, (size_t)c->W * 64 * 8, c->stream));
     {
         ScopedTimer t(c, VGAN_HC_K_SWEEP_NODE);
         launch_hc_sweep(c->g, nullptr, c->nodeW.p, c->rows, 1, c->acc_node.p, c->stream);
@@ -498,7 +534,7 @@ extern "C" int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable) {
     return VGAN_OK;
 }
 
-extern "C" int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[4], uint64_t launches[4]) {
+extern "C" int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[5], uint64_t launches[5]) {
     if (!c || !ms || !launches) return fail(VGAN_EINVAL, "vgan_hc_profile_read: null argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));

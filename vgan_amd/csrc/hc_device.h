@@ -11,19 +11,30 @@ struct HcNodeDev {
 };
 
 // HBM layout of the graph side:
-//   umask     uint64 [rows][row_words]  UNSUPPORTED-path bitmask: bit p of row i = !path_supports[i][p], zero beyond
-//             P; row_words = ceil(P/64) rounded up to the sweep tile so a wave's tile is one aligned scalar burst.
+//   umask     uint64 [rows][mask_words]  UNSUPPORTED-path bitmask: bit p of row i = !path_supports[i][p], zero
+//             beyond P (plain layout; debug kernel only).
+//   umaskT    uint16 [rows][n_tiles][64]  the same bits, transposed per tile for the sweep: the ceil(P/64) mask words
+//             are dealt as evenly as possible to n_tiles = 8*ceil(W/128) tiles (tile t owns words
+//             tile_word0[t] .. tile_word0[t+1]-1, i.e. tile_base_words or one more); entry [row][t][l] holds, from bit
+//             15 downwards, bit l of each of the tile's words.  One wave-wide 2-byte load (128 B, coalesced) gives
+//             every lane the membership bits of "its" path in all words of the tile.  With tile = blockIdx % 8 each
+//             XCD's L2 sees one eighth of the table (1.5 MB for the hcfiles shape).
 //   node_tab  {mappability, match} per node id: the two per-node scalars the likelihood needs.
 //   lq        log(p_seq_error((int8)byte)) for every raw quality byte (src/miscfunc.h:180-188, process_mapping.cpp:12)
 //   qscore    qscore_vec[100] (src/miscfunc.h:199-212);  incmap: incorrect_mapping_vec[100]
 struct HcGraphDev {
     const uint64_t *umask;
+    const uint16_t *umaskT;
+    const uint16_t *tile_word0; // [n_tiles+1]
     const HcNodeDev *node_tab;
     const double *lq;
     const double *qscore;
     const double *incmap;
     uint32_t rows;
-    uint32_t row_words;
+    uint32_t mask_words;
+    uint32_t row_entries; // n_tiles * 64
+    uint32_t n_tiles;
+    uint32_t tile_base_words;
     uint32_t n_paths;
 };
 
@@ -43,8 +54,15 @@ struct HcParamsDev {
     int consensus;
 };
 
-void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, double *segS, double *segU,
-                        double *segD, double *nodeW, double *totals, hipStream_t st);
+// per-read limits of the LDS-tiled segment kernel
+constexpr uint32_t HC_TILE_MAX_READ_COLS = 256;
+constexpr uint32_t HC_TILE_MAX_READ_QUAL = 256;
+constexpr uint32_t HC_TILE_MAX_READ_SEGS = 128;
+
+void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, bool tiled, double *segS,
+                        double *segU, double *segD, double *totals, hipStream_t st);
+int launch_hc_nodeacc(const uint32_t *seg_node, const double *segD, uint32_t n_items, uint32_t rows, double *nodeW,
+                      hipStream_t st);
 void launch_hc_sweep(const HcGraphDev &g, const uint32_t *item_node, const double *D, uint32_t n_items, int skip_zero,
                      double *acc, hipStream_t st);
 void launch_hc_finish(const double *totals, const double *acc_seg, const double *acc_node, uint32_t n_paths, double *out,
@@ -53,7 +71,5 @@ void launch_hc_read_loglik(const HcGraphDev &g, const HcBatchDev &b, const doubl
                            hipStream_t st);
 void launch_hc_posterior(const double *final_vec, uint32_t n_paths, const uint64_t *sets, uint32_t set_words,
                          uint32_t n_sets, double *conf, hipStream_t st);
-
-constexpr uint32_t HC_SWEEP_TILE_WORDS = 16;
 
 } // namespace vgan

@@ -75,5 +75,6 @@ struct vgan_hc_host_batch {
     std::vector<uint32_t> seg_node;
     std::vector<uint16_t> seg_start, seg_len;
     std::vector<uint8_t> graph_seq, algnseq, qual;
+    bool irregular = false; // some read has |graph_seq| != |algnseq|: its segments may overlap in columns
     void fill(vgan_hc_batch *b) const;
 };

@@ -34,6 +34,12 @@ void vgan_hc_host_batch::fill(vgan_hc_batch *b) const {
     b->algnseq = algnseq.data();
     b->qual = qual.data();
     b->on_device = 0;
+    for (size_t r = 0; r + 1 < read_seg_off.size(); ++r) {
+        b->max_read_cols = std::max(b->max_read_cols, read_col_off[r + 1] - read_col_off[r]);
+        b->max_read_qual = std::max(b->max_read_qual, read_qual_off[r + 1] - read_qual_off[r]);
+        b->max_read_segs = std::max(b->max_read_segs, read_seg_off[r + 1] - read_seg_off[r]);
+    }
+    if (irregular) b->max_read_cols = b->max_read_qual = b->max_read_segs = 0;
 }
 
 namespace {
@@ -189,6 +195,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             c.st.n_clamped++;
         }
         const size_t region = std::max(A, G);
+        if (A != G) b.irregular = true;
         b.graph_seq.insert(b.graph_seq.end(), rc.gseq.begin(), rc.gseq.end());
         b.graph_seq.insert(b.graph_seq.end(), region - G, 0);
         b.algnseq.insert(b.algnseq.end(), rc.ps.begin(), rc.ps.end());
@@ -255,6 +262,7 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
         st.n_unmapped += c.st.n_unmapped;
         st.n_bad += c.st.n_bad;
         st.n_clamped += c.st.n_clamped;
+        res->irregular = res->irregular || c.b.irregular;
         c.b = vgan_hc_host_batch(); // release early
     }
     st.n_segments = (int64_t)res->seg_node.size();

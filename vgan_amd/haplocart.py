@@ -249,6 +249,8 @@ class DeviceBatch:
         for name, _, _ in _BATCH_FIELDS:
             setattr(c, name, self.t[name].data_ptr() if self.t[name].numel() else None)
         c.on_device = 1
+        c.max_read_cols, c.max_read_qual, c.max_read_segs = (host_batch.c.max_read_cols, host_batch.c.max_read_qual,
+                                                             host_batch.c.max_read_segs)
         self.c = c
         self.n_reads, self.n_segments = c.n_reads, c.n_segments
 
@@ -307,10 +309,10 @@ class HcContext:
 
     def profile_read(self):
         """{kernel: (summed device ms, launches)} measured with HIP events on the context's stream."""
-        ms = np.zeros(4)
-        n = np.zeros(4, np.uint64)
+        ms = np.zeros(5)
+        n = np.zeros(5, np.uint64)
         N.check(N.lib().vgan_hc_profile_read(self._h, ms.ctypes.data, n.ctypes.data))
-        names = ("segment", "sweep_segments", "sweep_nodes", "finish")
+        names = ("segment", "sweep_segments", "sweep_nodes", "finish", "node_accumulate")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def synchronize(self):
