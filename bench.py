@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x76676131)
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the per-read-mode kernel measurement")
     return ap.parse_args()
 
 
@@ -69,21 +70,18 @@ def cpu_baseline(graph, alns, budget_s):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import numpy as np
     import torch
     import torch.distributed as dist
+    from vgan_amd import distributed as vd
     from vgan_amd import haplocart as hc
 
+    rank, world, local_rank = vd.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    vd.init(backend="nccl", device=dev)
 
     # ---- synthetic workload (same graph on every rank, a different read shard per rank)
     graph = hc.synth_graph(seed=args.seed)
@@ -102,8 +100,7 @@ def main():
         ctx.reset()
         ctx.accumulate(db)
         ctx.finalize_device(final_dev)
-        if world > 1:
-            dist.reduce(final_dev, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 41 KB of per-path sums
+        vd.reduce_loglik(final_dev, dst=0)  # RCCL over xGMI when N > 1: 41 KB of per-path sums
 
     def fence():
         if world > 1:
@@ -130,6 +127,30 @@ def main():
         total_reads = float(tot.item())
     else:
         total_reads = float(n_reads)
+
+    # ---- the reference's loop order (one mask row per segment) measured beside the default mode: the kernel
+    # BASELINE.json's north_star puts the >= 30 % HBM-roofline target on.  Outside the timed region.
+    per_read = None
+    if rank == 0 and mode == hc.MODE_NODE_WEIGHTS and not args.no_extra:
+        per_read = {}
+        row_bytes = 8 * ((graph.n_paths + 63) // 64) + 4 + 8
+        for label, m in (("dense", hc.MODE_PER_READ_DENSE), ("skip_unset_tiles", hc.MODE_PER_READ)):
+            ctx.set_mode(m)
+            ctx.reset()
+            ctx.accumulate(db)
+            ctx.synchronize()
+            ctx.profile_enable(True)
+            for _ in range(3):
+                ctx.reset()
+                ctx.accumulate(db)
+            pr = ctx.profile_read()
+            ctx.profile_enable(False)
+            ms = pr["sweep_segments"][0] / max(pr["sweep_segments"][1], 1)
+            gbs = n_seg * row_bytes / (ms * 1e-3) / 1e9
+            per_read[label] = {"kernel": "hc_sweep_kernel", "avg_launch_ms": ms, "achieved": gbs, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": n_seg * row_bytes,
+                               "reads_per_s_kernel_only": n_reads / (ms * 1e-3)}
+        ctx.set_mode(mode)
 
     # ---- parity spot check outside the timed region (oracle = checker)
     parity = None
@@ -177,6 +198,7 @@ def main():
                          "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": avg_ms, "launches": k_n},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "parity": parity,
+            "per_read_kernel": per_read,
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(graph, alns, args.cpu_seconds)

@@ -108,6 +108,10 @@ int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped, vgan_alns
 int vgan_aln_from_arrays(const vgan_alnset_view *v, vgan_alnset **out);
 int vgan_aln_write_gam(const vgan_alnset *a, const char *path, int group_size);
 int vgan_aln_view_get(const vgan_alnset *a, vgan_alnset_view *out);
+/* Dup_Remover::remove_duplicates_internal (rmdup.cpp:68-110), single-end rule: is_dup[r] = 1 when an earlier read
+ * has the same (node id, offset) in its first mapping.  O(n) instead of the reference's O(n^2); same marks. */
+int vgan_aln_mark_duplicates(const vgan_alnset *a, uint8_t *is_dup, int64_t *n_dup);
+int vgan_aln_filter(const vgan_alnset *a, const uint8_t *drop, vgan_alnset **out); /* copy without drop[r] != 0 */
 void vgan_aln_free(vgan_alnset *a);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1,0 +1,63 @@
+"""CLI surface of `vgan haplocart` (reference src/HaploCart.cpp:87-261): validation errors and the duplicate
+removal rule, on CPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from vgan_amd import _native as N
+from vgan_amd import haplocart as hc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VGAN = os.path.join(ROOT, "vgan_amd", "bin", "vgan")
+
+
+def run(*args):
+    return subprocess.run([VGAN] + list(args), capture_output=True, text=True)
+
+
+def test_cli_validation_errors(tmp_path):
+    assert os.path.exists(VGAN), "build the CLI with __graft_entry__.build()"
+    r = run("haplocart", "-e", "1.5")
+    assert r.returncode != 0 and "option -e is not a valid probability" in r.stderr      # HaploCart.cpp:107-113
+    r = run("haplocart", "-t", "0")
+    assert r.returncode != 0 and "invalid number of threads" in r.stderr                # HaploCart.cpp:183-194
+    r = run("haplocart", "-t", "-2")
+    assert r.returncode != 0
+    r = run("haplocart", "-g", str(tmp_path / "missing.gam"))
+    assert r.returncode != 0 and "does not exist" in r.stderr
+    r = run("haplocart", "-fq1", "x.fq")
+    assert r.returncode != 0 and "giraffe" in r.stderr
+    r = run("version")
+    assert r.returncode == 0 and "ABI" in r.stdout
+
+
+def test_cli_needs_a_gpu_not_a_fallback(tmp_path):
+    if N.lib().vgan_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    g = hc.synth_graph(seed=5, genome_len=800, n_nodes=560, n_paths=40)
+    a = hc.synth_reads(g, 50, seed=1, read_len=100)
+    g.write(str(tmp_path))
+    a.write_gam(str(tmp_path / "r.gam"))
+    r = run("haplocart", "-g", str(tmp_path / "r.gam"), "--hc-files", str(tmp_path), "-q")
+    assert r.returncode != 0 and "no HIP device" in r.stderr and r.stdout == ""
+
+
+def test_duplicate_marks_match_the_quadratic_rule():
+    g = hc.synth_graph(seed=5, genome_len=300, n_nodes=210, n_paths=10)
+    a = hc.synth_reads(g, 400, seed=3, read_len=40)
+    arr = a.arrays()
+    first = [(int(arr["m_node"][arr["map_off"][r]]), int(arr["m_offset"][arr["map_off"][r]])) for r in range(a.n_reads)]
+    ref = np.zeros(a.n_reads, bool)
+    for i in range(a.n_reads):          # rmdup.cpp:20-41,82-93 literally
+        for j in range(i + 1, a.n_reads):
+            if first[j] == first[i]:
+                ref[j] = True
+    got = a.mark_duplicates()
+    assert got.sum() > 0 and np.array_equal(got, ref)
+    kept = a.without(got)
+    assert kept.n_reads == int((~ref).sum())
+    k = kept.arrays()
+    assert [bytes(k["name"][k["name_off"][i]:k["name_off"][i + 1]]) for i in range(3)] == \
+        [bytes(arr["name"][arr["name_off"][i]:arr["name_off"][i + 1]]) for i in np.flatnonzero(~ref)[:3]]

@@ -224,3 +224,32 @@ def test_full_size_graph_properties():
     ctx.set_mode(hc.MODE_PER_READ)
     ctx.accumulate(hc.HostBatch(g, a, 0, 4))
     assert util.rel_err(ctx.finalize(), ref4) < RTOL
+
+
+def test_cli_end_to_end(tmp_path):
+    """vgan haplocart -g ... prints the reference's result lines (HaploCart.cpp:437-438, get_posterior.cpp:9-11)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = hc.synth_graph(seed=5, genome_len=800, n_nodes=560, n_paths=40)
+    a = hc.synth_reads(g, 300, seed=1, read_len=100)
+    g.write(str(tmp_path))
+    a.write_gam(str(tmp_path / "r.gam"))
+    out = str(tmp_path / "out.tsv")
+    pf = str(tmp_path / "post.txt")
+    r = subprocess.run([os.path.join(root, "vgan_amd", "bin", "vgan"), "haplocart", "-g", str(tmp_path / "r.gam"),
+                        "--hc-files", str(tmp_path), "-q", "-o", out, "-pf", pf, "-s", "my sample"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    kept = a.without(a.mark_duplicates())
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(kept)
+    fld, ref, _ = orc.hc_run(og, oa, n_threads=4, faithful=False)
+    pred = g.path_names[int(np.argmax(ref))]
+    lines = open(out).read().splitlines()
+    assert lines[0] == "#sample\tpredicted haplogroup\treads"
+    assert lines[1] == "my_sample\t%s\t%d" % (pred, kept.n_reads)
+    post = open(pf).read()
+    assert post.startswith("\nClade-level posterior confidence values\nmy_sample\t")
+    fields = post.split("\n")[2].split("\t")
+    exp = orc.hc_posterior(fld, g.path_names, g.parents_txt, g.children_txt, pred)
+    assert fields[1] == exp[0][0] and float(fields[2]) == pytest.approx(exp[0][1], rel=1e-5)
+    assert len(fields) // 3 == len(exp)

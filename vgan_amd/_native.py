@@ -72,6 +72,8 @@ SYMBOLS = {
     "vgan_aln_from_arrays": (C.c_int, [C.POINTER(AlnSetView), C.POINTER(vp)]),
     "vgan_aln_write_gam": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "vgan_aln_view_get": (C.c_int, [vp, C.POINTER(AlnSetView)]),
+    "vgan_aln_mark_duplicates": (C.c_int, [vp, vp, vp]),
+    "vgan_aln_filter": (C.c_int, [vp, vp, C.POINTER(vp)]),
     "vgan_aln_free": (None, [vp]),
     "vgan_hc_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
     "vgan_hc_host_batch_get": (C.c_int, [vp, C.POINTER(HcBatch)]),

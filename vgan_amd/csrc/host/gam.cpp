@@ -345,3 +345,63 @@ extern "C" int vgan_aln_view_get(const vgan_alnset *a, vgan_alnset_view *out) {
 }
 
 extern "C" void vgan_aln_free(vgan_alnset *a) { delete a; }
+
+// Duplicate marking with the reference's single-end semantics (src/rmdup.cpp:20-41,68-110): a read is a
+// duplicate when an EARLIER read of the set has the same (node id, offset) in its first mapping -- strand is not
+// compared.  The reference does this in O(n^2); a hash of first-seen keys gives the same marks in O(n).
+// (The reference's paired branch reads mapping()[n_mappings], one past the end: undefined, not reproduced.)
+#include <unordered_set>
+
+extern "C" int vgan_aln_mark_duplicates(const vgan_alnset *a, uint8_t *is_dup, int64_t *n_dup) {
+    if (!a || !is_dup) return fail(VGAN_EINVAL, "vgan_aln_mark_duplicates: null argument");
+    struct KeyHash {
+        size_t operator()(const std::pair<int64_t, int64_t> &k) const {
+            return (size_t)(k.first * 0x9E3779B97F4A7C15ull) ^ (size_t)(k.second + 0x7F4A7C15ull + ((uint64_t)k.first << 6));
+        }
+    };
+    std::unordered_set<std::pair<int64_t, int64_t>, KeyHash> seen;
+    seen.reserve((size_t)a->n_reads());
+    int64_t nd = 0;
+    for (int64_t r = 0; r < a->n_reads(); ++r) {
+        is_dup[r] = 0;
+        if (a->map_off[r + 1] == a->map_off[r]) continue; // the reference would index mapping()[0] of an empty path (UB)
+        const int64_t m = a->map_off[r];
+        if (!seen.insert({a->m_node[m], a->m_offset[m]}).second) {
+            is_dup[r] = 1;
+            ++nd;
+        }
+    }
+    if (n_dup) *n_dup = nd;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_aln_filter(const vgan_alnset *a, const uint8_t *drop, vgan_alnset **out) {
+    if (!a || !drop || !out) return fail(VGAN_EINVAL, "vgan_aln_filter: null argument");
+    auto o = new vgan_alnset();
+    for (int64_t r = 0; r < a->n_reads(); ++r) {
+        if (drop[r]) continue;
+        o->seq.append(a->seq, (size_t)a->seq_off[r], (size_t)(a->seq_off[r + 1] - a->seq_off[r]));
+        o->seq_off.push_back((int64_t)o->seq.size());
+        o->qual.append(a->qual, (size_t)a->qual_off[r], (size_t)(a->qual_off[r + 1] - a->qual_off[r]));
+        o->qual_off.push_back((int64_t)o->qual.size());
+        o->name.append(a->name, (size_t)a->name_off[r], (size_t)(a->name_off[r + 1] - a->name_off[r]));
+        o->name_off.push_back((int64_t)o->name.size());
+        o->mapq.push_back(a->mapq[r]);
+        o->identity.push_back(a->identity[r]);
+        for (int64_t m = a->map_off[r]; m < a->map_off[r + 1]; ++m) {
+            o->m_node.push_back(a->m_node[m]);
+            o->m_offset.push_back(a->m_offset[m]);
+            o->m_rev.push_back(a->m_rev[m]);
+            for (int64_t e = a->edit_off[m]; e < a->edit_off[m + 1]; ++e) {
+                o->e_from.push_back(a->e_from[e]);
+                o->e_to.push_back(a->e_to[e]);
+                o->e_seq.append(a->e_seq, (size_t)a->e_seq_off[e], (size_t)(a->e_seq_off[e + 1] - a->e_seq_off[e]));
+                o->e_seq_off.push_back((int64_t)o->e_seq.size());
+            }
+            o->edit_off.push_back((int64_t)o->e_from.size());
+        }
+        o->map_off.push_back((int64_t)o->m_node.size());
+    }
+    *out = o;
+    return VGAN_OK;
+}

@@ -1,0 +1,249 @@
+// vgan -- C++ host driver keeping the reference's subcommand surface for the GPU hot path.
+//
+//   vgan haplocart  -g reads.gam --hc-files DIR [-e P] [-o OUT] [-s NAME] [-np] [-pf FILE] [-q] [-t N] [-d] ...
+//
+// Mirrors Haplocart::run (reference src/HaploCart.cpp:58-488): same flags, same validation messages, same
+// output lines.  What differs, and why:
+//   * the graph is read from DIR/graph.gfa (+ the hcfiles sidecars): the ODGI .og binary needs libbdsg;
+//   * FASTQ / FASTA inputs need vg giraffe in-process (src/map_giraffe.cpp), which is not available: map with vg
+//     and pass the sorted GAM with -g (for a consensus FASTA mapped that way add -f NAME to get the reference's
+//     consensus arithmetic);
+//   * the likelihood loop runs on the GPU through the C-ABI (include/vgan_gpu.h); -t only sizes the host front end.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "vgan_gpu.h"
+
+namespace {
+
+[[noreturn]] void die(const std::string &msg) { throw std::runtime_error(msg); }
+
+void check(int rc, const char *what) {
+    if (rc < 0) die(std::string("[vgan] ") + what + ": " + vgan_last_error());
+}
+
+std::string haplocart_usage() {
+    return "\n vgan haplocart [options]\n\n"
+           " Predict the mitochondrial haplogroup of a sample on the GPU (MI355X).\n\n"
+           " Input:\n"
+           "   -g  [STR]        GAM input (sorted; FASTQ/FASTA input needs vg giraffe: map first)\n"
+           "   -f  [STR]        treat the GAM as a mapped consensus FASTA (consensus arithmetic)\n"
+           "   --hc-files [STR] HaploCart graph directory: graph.gfa + path_supports, parsed_pangenome_mapping,\n"
+           "                    mappability.tsv, graph_paths, parents.txt, children.txt (plain or .gz)\n"
+           " Options:\n"
+           "   -e  [FLOAT]      background error probability for FASTA input (default 0.0001)\n"
+           "   -o  [STR]        output file (default: stdout)\n"
+           "   -s  [STR]        sample name\n"
+           "   -np              do not compute clade-level posteriors\n"
+           "   -pf [STR]        posterior output file (default: stdout)\n"
+           "   -t  [INT]        host threads (-1 for all available)\n"
+           "   -d               write per-haplogroup log-likelihoods to <out>.loglik.tsv\n"
+           "   -q               quiet\n"
+           "   --keep-duplicates   skip duplicate removal\n"
+           "   --per-read       stream the path-membership mask per read (the reference's loop order)\n"
+           "   --device [INT]   GPU index (default 0)\n";
+}
+
+int haplocart(int argc, char **argv) {
+    bool debug = false, quiet = false, compute_posteriors = true, rmdup = true, per_read = false, webapp = false;
+    std::string posteriorfilename = "/dev/stdout", outputfilename = "/dev/stdout", hcfiledir = "../share/vgan/hcfiles/";
+    std::string gamfilename, fastafilename, fastq1, fastq2, samplename;
+    bool invoked_samplename = false;
+    double background_error_prob = 0.0001;
+    int n_threads = 1, device = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](const char *flag) -> std::string {
+            if (i + 1 >= argc) die(std::string("[HaploCart] Error, option ") + flag + " needs a value");
+            return argv[++i];
+        };
+        if (a == "-" || a == "-h" || a == "--help") {
+            std::cerr << haplocart_usage() << std::endl;
+            return 0;
+        } else if (a == "-d") debug = true;
+        else if (a == "--hc-files") {
+            hcfiledir = need("--hc-files");
+            if (hcfiledir.back() != '/') hcfiledir += '/';
+        } else if (a == "-e") {
+            background_error_prob = std::stod(need("-e"));
+            if (background_error_prob < 0 || background_error_prob > 1)
+                die("[HaploCart] Error, option -e is not a valid probability."); // HaploCart.cpp:107-113
+        } else if (a == "-g") gamfilename = need("-g");
+        else if (a == "-f") fastafilename = need("-f");
+        else if (a == "-fq1") fastq1 = need("-fq1");
+        else if (a == "-fq2") fastq2 = need("-fq2");
+        else if (a == "-i") die("[HaploCart] interleaved FASTQ input needs vg giraffe; map with vg and pass -g");
+        else if (a == "-j" || a == "-jf") die("[HaploCart] JSON dump is not part of the GPU path");
+        else if (a == "-o") outputfilename = need("-o");
+        else if (a == "-np") compute_posteriors = false;
+        else if (a == "-pf") posteriorfilename = need("-pf");
+        else if (a == "-q") quiet = true;
+        else if (a == "-s") {
+            samplename = need("-s");
+            invoked_samplename = true;
+        } else if (a == "-t") {
+            n_threads = std::stoi(need("-t"));
+            if (n_threads == 0 || n_threads < -1)
+                die("[HaploCart] Error, invalid number of threads"); // HaploCart.cpp:183-194
+            if (n_threads == -1) n_threads = 0;                      // all hardware threads
+        } else if (a == "-w") webapp = true;
+        else if (a == "-z") (void)need("-z");
+        else if (a == "--keep-duplicates") rmdup = false;
+        else if (a == "--per-read") per_read = true;
+        else if (a == "--device") device = std::stoi(need("--device"));
+        else die("[HaploCart] Error, unrecognized option " + a);
+    }
+    if (webapp) die("[HaploCart] webapp mode is not part of the GPU path");
+    if (!fastq1.empty() || !fastq2.empty())
+        die("[HaploCart] FASTQ input needs vg giraffe in-process, which this build does not have; map with vg and pass -g");
+    if (gamfilename.empty()) die("[HaploCart] Error, no input file given (use -g)");
+    if (!std::ifstream(gamfilename)) die("[HaploCart] Error, GAM input file " + gamfilename + " does not exist");
+    if (!invoked_samplename) samplename = !fastafilename.empty() ? fastafilename : gamfilename;
+
+    vgan_graph *graph = nullptr;
+    check(vgan_graph_load((hcfiledir + "graph.gfa").c_str(), hcfiledir.c_str(), &graph), "loading graph");
+    vgan_graph_view gv;
+    check(vgan_graph_view_get(graph, &gv), "graph view");
+    std::vector<std::string> path_names;
+    {
+        std::string all = gv.path_names ? gv.path_names : "";
+        size_t p = 0;
+        while (p < all.size()) {
+            size_t nl = all.find('\n', p);
+            if (nl == std::string::npos) nl = all.size();
+            if (nl > p) path_names.emplace_back(all, p, nl - p);
+            p = nl + 1;
+        }
+    }
+    if (path_names.size() != gv.n_paths) die("[HaploCart] graph_paths does not name every path of path_supports");
+
+    vgan_alnset *alns = nullptr;
+    check(vgan_aln_read_gam(gamfilename.c_str(), 0, &alns), "reading GAM");
+    vgan_alnset_view av;
+    check(vgan_aln_view_get(alns, &av), "alignment view");
+    if (!quiet) std::cerr << "Found " << av.n_reads << " reads." << '\n';
+    if (rmdup && fastafilename.empty()) { // HaploCart.cpp:386-393
+        std::vector<uint8_t> dup((size_t)av.n_reads);
+        int64_t nd = 0;
+        check(vgan_aln_mark_duplicates(alns, dup.data(), &nd), "duplicate removal");
+        if (nd) {
+            vgan_alnset *kept = nullptr;
+            check(vgan_aln_filter(alns, dup.data(), &kept), "duplicate removal");
+            vgan_aln_free(alns);
+            alns = kept;
+            check(vgan_aln_view_get(alns, &av), "alignment view");
+        }
+        if (!quiet) std::cerr << "PCR duplicates removed." << std::endl;
+    }
+    int64_t n_reads = av.n_reads;
+
+    vgan_hc_params prm;
+    prm.background_error_prob = background_error_prob;
+    prm.use_background_error_prob = !fastafilename.empty(); // HaploCart.cpp:397-400
+    prm.is_consensus_fasta = !fastafilename.empty();
+    if (!fastafilename.empty() && !quiet) std::cerr << "Using background error probability of " << background_error_prob << '\n';
+    if (vgan_device_count() <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
+    vgan_hc_ctx *ctx = nullptr;
+    check(vgan_hc_create(&gv, &prm, device, &ctx), "creating the device context");
+    check(vgan_hc_set_mode(ctx, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS), "mode");
+    if (!quiet && fastafilename.empty()) std::cerr << "Computing haplogroup likelihoods from " << n_reads << " reads." << '\n';
+
+    const int64_t BATCH = 2000000; // reads per device batch
+    vgan_hc_flatten_stats tot{};
+    for (int64_t r0 = 0; r0 < n_reads; r0 += BATCH) {
+        const int64_t r1 = std::min(n_reads, r0 + BATCH);
+        vgan_hc_host_batch *hb = nullptr;
+        vgan_hc_flatten_stats st;
+        check(vgan_hc_flatten(graph, alns, r0, r1, n_threads, &hb, &st), "flattening");
+        vgan_hc_batch b;
+        check(vgan_hc_host_batch_get(hb, &b), "batch");
+        check(vgan_hc_accumulate(ctx, &b), "accumulate");
+        check(vgan_hc_synchronize(ctx), "synchronize");
+        vgan_hc_host_batch_free(hb);
+        tot.n_bad += st.n_bad;
+        tot.n_unmapped += st.n_unmapped;
+        tot.n_out += st.n_out;
+    }
+    if (tot.n_bad && !quiet)
+        std::cerr << "[HaploCart] warning: " << tot.n_bad << " reads skipped (the reference would terminate on them)\n";
+    std::vector<double> final_vec(gv.n_paths);
+    check(vgan_hc_finalize(ctx, nullptr, final_vec.data()), "finalize");
+    const int maxh = vgan_hc_argmax(final_vec.data(), gv.n_paths); // HaploCart.cpp:423
+    const std::string predicted = path_names[(size_t)maxh];
+
+    if (!fastafilename.empty()) n_reads = 1; // HaploCart.cpp:427
+    std::replace(samplename.begin(), samplename.end(), ' ', '_');
+    {
+        std::ofstream out(outputfilename, std::ios::app);
+        if (outputfilename == "/dev/stdout" && !quiet) out << "\n\n";
+        out << "#sample\tpredicted haplogroup\treads" << std::endl; // HaploCart.cpp:437-438
+        out << samplename << '\t' << predicted << '\t' << n_reads << std::endl;
+    }
+    if (compute_posteriors) { // get_posterior.cpp:4-33 (non-webapp branch)
+        std::vector<char> clades(1 << 20);
+        std::vector<double> conf(8192);
+        const int n = vgan_hc_posterior(ctx, final_vec.data(), predicted.c_str(), clades.data(), (int64_t)clades.size(),
+                                        conf.data(), (int32_t)conf.size());
+        check(n, "posterior");
+        std::ofstream pf(posteriorfilename, std::ios::app);
+        pf << "\nClade-level posterior confidence values\n" << samplename << '\t';
+        const char *p = clades.data();
+        for (int i = 0; i < n; ++i) {
+            const char *nl = strchr(p, '\n');
+            pf << std::string(p, nl ? (size_t)(nl - p) : strlen(p)) << '\t' << conf[(size_t)i] << '\t' << i << '\t';
+            p = nl ? nl + 1 : p + strlen(p);
+        }
+        pf << "\n" << std::endl;
+    }
+    if (debug) { // HaploCart.cpp:464-479: names sorted by descending log-likelihood
+        std::vector<int> idx(final_vec.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::sort(idx.begin(), idx.end(), [&](int A, int B) { return final_vec[(size_t)A] > final_vec[(size_t)B]; });
+        const std::string dbg = (outputfilename == "/dev/stdout" ? std::string("haplocart") : outputfilename) + ".loglik.tsv";
+        std::ofstream d(dbg);
+        d.precision(10);
+        for (int k : idx) d << path_names[(size_t)k] << '\t' << final_vec[(size_t)k] << '\n';
+        if (!quiet) std::cerr << "Writing log likelihoods to " << dbg << std::endl;
+    }
+    vgan_hc_destroy(ctx);
+    vgan_aln_free(alns);
+    vgan_graph_free(graph);
+    return 0;
+}
+
+std::string usage() {
+    return "vgan (MI355X build): per-read likelihood hot path on the GPU\n\n"
+           "   vgan haplocart   mitochondrial haplogroup prediction (see: vgan haplocart -h)\n"
+           "   vgan version\n\n"
+           "euka / soibean / duprm / gam2prof / keelime are reached through the C-ABI of this build as they are added;\n"
+           "the CPU-only subcommands of the reference are not part of it.\n";
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+    try {
+        if (argc < 2) {
+            std::cerr << usage();
+            return 1;
+        }
+        const std::string cmd = argv[1];
+        if (cmd == "haplocart") return haplocart(argc - 1, argv + 1);
+        if (cmd == "version") {
+            std::cout << "vgan-mi355x ABI " << vgan_abi_version() << std::endl;
+            return 0;
+        }
+        std::cerr << usage();
+        return 1;
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+}

@@ -142,6 +142,18 @@ class AlnSet:
     def n_reads(self):
         return self.view.n_reads
 
+    def mark_duplicates(self):
+        """bool mask with the reference's keep-first rule on the first mapping's (node, offset) (rmdup.cpp:68-110)."""
+        m = np.zeros(self.n_reads, np.uint8)
+        N.check(N.lib().vgan_aln_mark_duplicates(self._h, m.ctypes.data, None))
+        return m.astype(bool)
+
+    def without(self, drop):
+        d = np.ascontiguousarray(drop, np.uint8)
+        h = N.vp()
+        N.check(N.lib().vgan_aln_filter(self._h, d.ctypes.data, C.byref(h)))
+        return AlnSet(h)
+
     def arrays(self):
         """dict of numpy views with the field names of vgan_alnset_view (and of the oracle's orc_alnset)."""
         v = self.view
