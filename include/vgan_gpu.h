@@ -221,6 +221,107 @@ int vgan_hc_posterior(vgan_hc_ctx *c, const double *final_vec /* host [P] */, co
 int vgan_hc_argmax(const double *final_vec, uint32_t n_paths);
 
 /* ------------------------------------------------------------------------------------------------
+ * euka: per-read two-model likelihood with ancient-DNA damage (readGAM3's per-alignment lambda,
+ * readGAM_Euka.h:67-577; Damage::initDeamProbabilities, damage.cpp:41-323; Baseshift::baseshift_calc,
+ * baseshift.cpp:57-88).  Replaces the call `readGAM3(...)` at Euka.cpp:534-537.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_euka_db vgan_euka_db; /* opaque: clade table + bins */
+
+typedef struct vgan_euka_db_view {
+    uint32_t n_clades;
+    const int32_t *clade_id;      /* *.clade column 0 (load.cpp:118-152) */
+    const double *clade_dist;     /* column 2: pairwise average distance */
+    const int32_t *clade_npaths, *clade_snode, *clade_enode;
+    const char *clade_names;      /* '\n' joined */
+    const uint32_t *bin_off;      /* [n_clades+1] bins of clade c: *.bins line c (load.cpp:71-99) */
+    const int32_t *bin_lo, *bin_hi; /* node id range, stoi of "1836.0"-style tokens */
+    const double *bin_entropy;
+} vgan_euka_db_view;
+
+int vgan_euka_db_load(const char *clade_path, const char *bins_path, vgan_euka_db **out); /* plain or .gz */
+int vgan_euka_db_from_arrays(const vgan_euka_db_view *v, vgan_euka_db **out);
+int vgan_euka_db_view_get(const vgan_euka_db *d, vgan_euka_db_view *out);
+void vgan_euka_db_free(vgan_euka_db *d);
+
+typedef struct vgan_damage vgan_damage; /* opaque: 5' / 3' substitution matrices per position */
+typedef struct vgan_damage_view {
+    uint32_t n5, n3;      /* rows kept: positions >= n-1 repeat the last row (damage.cpp:91-93,134-136) */
+    const double *sub5p;  /* [n5][4][4] row-stochastic, original base x damaged base (damage.cpp:66-88) */
+    const double *sub3p;  /* [n3][4][4] */
+} vgan_damage_view;
+/* 12-column .prof text (header A>C ... T>G; miscfunc.h:84-136); NULL or "" = no damage (damage.cpp:47-55) */
+int vgan_damage_from_text(const char *prof5_text, const char *prof3_text, vgan_damage **out);
+int vgan_damage_load(const char *prof5_path, const char *prof3_path, vgan_damage **out);
+int vgan_damage_view_get(const vgan_damage *d, vgan_damage_view *out);
+void vgan_damage_free(vgan_damage *d);
+
+/* SoA batch of the front half (reconstruct_graph_sequence + what the lambda reads off the Alignment). */
+typedef struct vgan_euka_batch {
+    uint32_t n_reads;
+    uint64_t n_cols, n_qual, n_maps;
+    const uint32_t *read_col_off;  /* [n_reads+1] region of graph_seq / read_seq (zero padded to the longer) */
+    const uint32_t *read_qual_off; /* [n_reads+1] */
+    const uint32_t *read_map_off;  /* [n_reads+1] */
+    const uint16_t *read_gseq_len; /* [n_reads] |graph_seq| */
+    const uint16_t *read_rseq_len; /* [n_reads] |read_seq| */
+    const uint16_t *read_seq_len;  /* [n_reads] a.sequence().size() = Lseq, within 15..1000 */
+    const int32_t *read_mapq;      /* [n_reads] */
+    const uint8_t *read_rev;       /* [n_reads] first mapping is_reverse */
+    const uint32_t *read_src;      /* [n_reads] index of the read in the alignment set */
+    const uint32_t *map_node;      /* [n_maps] node id of every mapping */
+    const uint8_t *graph_seq, *read_seq, *qual;
+    int32_t on_device;
+    uint32_t reserved;
+} vgan_euka_batch;
+
+typedef struct vgan_euka_host_batch vgan_euka_host_batch;
+typedef struct vgan_euka_flatten_stats {
+    int64_t n_in, n_out, n_unmapped /* identity == 0, readGAM_Euka.h:72 */, n_bad /* reference reads out of bounds */;
+} vgan_euka_flatten_stats;
+int vgan_euka_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
+                      vgan_euka_host_batch **out, vgan_euka_flatten_stats *stats);
+int vgan_euka_host_batch_get(const vgan_euka_host_batch *b, vgan_euka_batch *out);
+void vgan_euka_host_batch_free(vgan_euka_host_batch *b);
+
+typedef struct vgan_euka_params {
+    uint32_t min_mapq;       /* MINIMUMMQ, --minMQ (Euka.cpp:152-190: 29) */
+    int32_t length_to_prof;  /* -l (5); at most 32 */
+} vgan_euka_params;
+
+/* per-read results (arrays of n_reads, host memory for host batches, device memory for device batches) */
+typedef struct vgan_euka_read_out {
+    int32_t *clade;     /* c_n (line index in *.clade), -1 = the reference would index out of bounds on this read */
+    double *in_lik;     /* in_clade_lik */
+    double *out_lik;    /* not_in_clade_lik */
+    double *like;       /* value pushed to Clade::clade_like (readGAM_Euka.h:491) */
+    double *not_like;   /* ... Clade::clade_not_like (:492) */
+    uint8_t *pass;      /* in - out > 1 && mapq > MINIMUMMQ (:504-510) */
+} vgan_euka_read_out;
+
+typedef struct vgan_euka_ctx vgan_euka_ctx;
+int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_view *dmg, const vgan_euka_params *prm, int device,
+                     vgan_euka_ctx **out);
+int vgan_euka_set_stream(vgan_euka_ctx *c, void *hip_stream);
+int vgan_euka_reset(vgan_euka_ctx *c);
+int vgan_euka_accumulate(vgan_euka_ctx *c, const vgan_euka_batch *b, const vgan_euka_read_out *out);
+/* per-clade results of everything accumulated: Clade::count [n_clades], baseshift_clade_array
+ * [n_clades][2*length_to_prof][16], bin coverage get<3>(chunks[c][j]) [n_bins]; host arrays; synchronises */
+int vgan_euka_finalize(vgan_euka_ctx *c, int32_t *clade_count, uint32_t *baseshift, double *bin_cov, int64_t *n_bad);
+int vgan_euka_kernel_ms(vgan_euka_ctx *c, double *ms, uint64_t *launches); /* HIP-event time of the read kernel */
+void vgan_euka_destroy(vgan_euka_ctx *c);
+
+typedef struct vgan_synth_euka_cfg {
+    uint64_t seed;
+    uint32_t n_clades;        /* 335 */
+    uint32_t nodes_per_clade; /* contiguous node-id range per clade */
+    uint64_t n_reads;
+    uint32_t read_len_mean;   /* 75, clipped 30..150 */
+} vgan_synth_euka_cfg;
+/* clade graph (nodes <= 5 bp), its clade/bin tables, and aDNA-like reads with the given damage applied */
+int vgan_synth_euka(const vgan_synth_euka_cfg *cfg, const vgan_damage *dmg, vgan_graph **g, vgan_euka_db **db,
+                    vgan_alnset **reads);
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic inputs of the published shape: hcfiles-like graph + reads.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct vgan_synth_graph_cfg {

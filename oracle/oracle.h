@@ -119,6 +119,43 @@ int64_t orc_load_mappabilities(const char *txt, double *out, int64_t cap);
 int64_t orc_load_pangenome_map(const char *txt, int32_t *base_by_id, int64_t cap); /* fills base_by_id[node]=coord+1 */
 int64_t orc_load_path_supports(const char *txt, int32_t n_paths, uint8_t *out, int64_t cap_rows);
 
+/* ------------------------------------------------------------------ euka (oracle/euka_oracle.cpp) */
+typedef struct orc_euka_db {
+    int32_t n_clades;
+    const double *clade_dist;  /* [n_clades] Clade::dist of line c (consumers index c*6+1, src/load.cpp:118-152) */
+    const int32_t *bin_off;    /* [n_clades+1] */
+    const int32_t *bin_lo;     /* stoi of "1836.0"-style tokens (src/load.cpp:81-88) */
+    const int32_t *bin_hi;
+    const double *bin_entropy;
+} orc_euka_db;
+
+typedef struct orc_euka_params {
+    uint32_t MINIMUMMQ;   /* --minMQ, default 29 (src/Euka.cpp:152-190) */
+    int32_t lengthToProf; /* -l, default 5 */
+} orc_euka_params;
+
+typedef struct orc_euka_out {
+    int32_t *read_clade;        /* [n_reads] c_n, -1 = read skipped (identity 0, or a read the oracle defines as bad) */
+    double *read_in, *read_out; /* in_clade_lik, not_in_clade_lik */
+    double *read_like, *read_not_like; /* the values pushed to Clade::clade_like / clade_not_like */
+    uint8_t *read_pass;
+    int32_t *clade_count;       /* [n_clades] Clade::count */
+    uint32_t *baseshift;        /* [n_clades][2*lengthToProf][16] */
+    double *bin_cov;            /* [n_bins] get<3>(chunks[c][j]) */
+    int64_t n_bad;
+} orc_euka_out;
+
+void *orc_damage_create(const char *prof5_text, const char *prof3_text); /* NULL on a malformed profile; "" = no file */
+void orc_damage_free(void *d);
+int orc_damage_matrix(const void *dmg, uint32_t L, uint32_t l, double *out16); /* subDeamDiNuc[L][l].p row-major */
+/* output arrays must be zeroed by the caller (counts / coverages accumulate) */
+int orc_euka_run(const orc_graph_t *g, const orc_alnset_t *a, const orc_euka_db *db, const void *dmg,
+                 const orc_euka_params *prm, orc_euka_out *o);
+int64_t orc_load_clade_chunks(const char *txt, int32_t *bin_off, int32_t *lo, int32_t *hi, double *entropy,
+                              int64_t cap_clades, int64_t cap_bins);
+int64_t orc_load_clade_info(const char *txt, int32_t *id, double *dist, int32_t *npaths, int32_t *snode, int32_t *enode,
+                            char *names, int64_t names_cap, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,3 +249,66 @@ def graph_from_gfa(path, pangenome_base=None, mappability=None):
     if mappability is None:
         mappability = np.ones(int(max(pangenome_base)) + 2)
     return Graph(node_seqs, P, pathsgo, pangenome_base, mappability), [p[0] for p in paths]
+
+
+# ---------------------------------------------------------------- euka
+class OrcEukaDb(C.Structure):
+    _fields_ = [("n_clades", C.c_int32), ("clade_dist", C.c_void_p), ("bin_off", C.c_void_p), ("bin_lo", C.c_void_p),
+                ("bin_hi", C.c_void_p), ("bin_entropy", C.c_void_p)]
+
+
+class OrcEukaParams(C.Structure):
+    _fields_ = [("MINIMUMMQ", C.c_uint32), ("lengthToProf", C.c_int32)]
+
+
+class OrcEukaOut(C.Structure):
+    _fields_ = [("read_clade", C.c_void_p), ("read_in", C.c_void_p), ("read_out", C.c_void_p), ("read_like", C.c_void_p),
+                ("read_not_like", C.c_void_p), ("read_pass", C.c_void_p), ("clade_count", C.c_void_p),
+                ("baseshift", C.c_void_p), ("bin_cov", C.c_void_p), ("n_bad", C.c_int64)]
+
+
+class EukaDb:
+    def __init__(self, clade_dist, bin_off, bin_lo, bin_hi, bin_entropy=None):
+        self.clade_dist = np.ascontiguousarray(clade_dist, np.float64)
+        self.bin_off = np.ascontiguousarray(bin_off, np.int32)
+        self.bin_lo = np.ascontiguousarray(bin_lo, np.int32)
+        self.bin_hi = np.ascontiguousarray(bin_hi, np.int32)
+        self.bin_entropy = np.ascontiguousarray(bin_entropy if bin_entropy is not None else np.zeros(len(self.bin_lo)), np.float64)
+        self.n_clades = len(self.clade_dist)
+        self.c = OrcEukaDb(self.n_clades, _p(self.clade_dist), _p(self.bin_off), _p(self.bin_lo), _p(self.bin_hi),
+                           _p(self.bin_entropy))
+
+
+class OrcDamage:
+    def __init__(self, prof5="", prof3=""):
+        L = lib()
+        L.orc_damage_create.restype = C.c_void_p
+        self.h = L.orc_damage_create(prof5.encode(), prof3.encode())
+        if not self.h:
+            raise ValueError("malformed damage profile")
+
+    def matrix(self, L_, l):
+        out = np.zeros(16)
+        rc = lib().orc_damage_matrix(C.c_void_p(self.h), C.c_uint32(L_), C.c_uint32(l), _p(out))
+        assert rc == 0
+        return out.reshape(4, 4)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_damage_free(C.c_void_p(self.h))
+            self.h = None
+
+
+def euka_run(g, a, db, dmg, min_mapq=29, length_to_prof=5):
+    R, Cn, nb = a.n_reads, db.n_clades, len(db.bin_lo)
+    o = {"clade": np.zeros(R, np.int32), "in_lik": np.zeros(R), "out_lik": np.zeros(R), "like": np.zeros(R),
+         "not_like": np.zeros(R), "pass": np.zeros(R, np.uint8), "clade_count": np.zeros(Cn, np.int32),
+         "baseshift": np.zeros((Cn, 2 * length_to_prof, 16), np.uint32), "bin_cov": np.zeros(max(nb, 1))}
+    oc = OrcEukaOut(_p(o["clade"]), _p(o["in_lik"]), _p(o["out_lik"]), _p(o["like"]), _p(o["not_like"]), _p(o["pass"]),
+                    _p(o["clade_count"]), _p(o["baseshift"]), _p(o["bin_cov"]), 0)
+    prm = OrcEukaParams(min_mapq, length_to_prof)
+    rc = lib().orc_euka_run(C.byref(g.c), C.byref(a.c), C.byref(db.c), C.c_void_p(dmg.h), C.byref(prm), C.byref(oc))
+    assert rc == 0
+    o["n_bad"] = oc.n_bad
+    o["bin_cov"] = o["bin_cov"][:nb]
+    return o

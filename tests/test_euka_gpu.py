@@ -1,0 +1,109 @@
+"""GPU parity tests of the euka path (run with -m gpu): product (C-ABI, HIP) vs oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import gamio
+import orc
+import util
+from vgan_amd import euka as ek
+from vgan_amd import haplocart as hc
+from test_euka_cpu import _mk, GOLD
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(g, db, a, dm_texts, min_mapq=29, ltp=5):
+    dm = ek.Damage.from_text(*dm_texts)
+    hb = ek.EukaHostBatch(g, a)
+    ctx = ek.EukaContext(db, dm, min_mapq=min_mapq, length_to_prof=ltp)
+    got = ctx.accumulate(hb)
+    fin = ctx.finalize()
+    og, oa = util.orc_graph_nodes_only(g), util.orc_alnset_from_product(a)
+    ref = orc.euka_run(og, oa, util.orc_euka_db_from_product(db), orc.OrcDamage(*dm_texts), min_mapq, ltp)
+    src = hb.arrays()["read_src"]
+    kept = np.zeros(a.n_reads, bool)
+    kept[src] = True
+    assert np.all(ref["clade"][~kept] == -1)  # reads the flatten step drops are the ones the oracle skips
+    assert np.array_equal(got["clade"], ref["clade"][src])
+    ok = got["clade"] >= 0
+    for k in ("in_lik", "out_lik", "like"):
+        assert util.rel_err(got[k][ok], ref[k][src][ok]) < 1e-10, k
+    assert np.allclose(got["not_like"][ok], ref["not_like"][src][ok], rtol=0, atol=1e-12)
+    assert np.array_equal(got["pass"], ref["pass"][src])
+    assert np.array_equal(fin["clade_count"], ref["clade_count"])
+    assert np.array_equal(fin["baseshift"], ref["baseshift"])
+    assert np.allclose(fin["bin_cov"], ref["bin_cov"], rtol=1e-12, atol=1e-12)
+    assert fin["n_bad"] + hb.stats.n_bad == ref["n_bad"]
+    return got, fin, ref
+
+
+def test_synthetic_clades_with_damage():
+    d = os.path.join(GOLD, "damageProfiles")
+    texts = (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    dm = ek.Damage.from_text(*texts)
+    g, db, a = ek.synth_euka(3000, dm, seed=5, n_clades=12, nodes_per_clade=200)
+    got, fin, ref = compare(g, db, a, texts)
+    assert got["pass"].sum() > 1000 and fin["baseshift"].sum() > 10000
+    # no damage model, other thresholds
+    compare(g, db, a, ("", ""), min_mapq=0, ltp=3)
+
+
+def test_special_columns_and_filters():
+    seqs = [b"ACGTNACGTRACGTACGTACGTAAAA", b"CCCCGGGGTTTTAAAACCCCGGGGTTTT", b"ACGTACGTACGTACGTACGT"]
+    node_seq = b"".join(seqs)
+    off = np.array([0, 0, 26, 54, 74], np.int64)
+    g = hc.Graph.from_arrays(1, 3, off, node_seq, 1, np.zeros((4, 1), np.uint64), np.full(4, -1, np.int32), np.ones(1))
+    import ctypes as C
+    from vgan_amd import _native as N
+    cd = np.array([0.2, 0.07])
+    bo = np.array([0, 2, 3], np.uint32)
+    lo, hi = np.array([1, 2, 3], np.int32), np.array([1, 2, 3], np.int32)
+    en = np.zeros(3)
+    v = N.EukaDbView(2, None, cd.ctypes.data, None, None, None, b"c0\nc1\n", bo.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                     en.ctypes.data)
+    h = N.vp()
+    N.check(N.lib().vgan_euka_db_from_arrays(C.byref(v), C.byref(h)))
+    db = ek.EukaDb(h)
+    q = list(range(20, 60))
+    ed = [(0, 3, b"GGG"), (4, 4, b""), (1, 1, b""), (2, 2, b""), (0, 2, b"TT"), (2, 2, b""), (1, 1, b""), (3, 3, b""), (2, 0, b""), (6, 6, b"")]
+    read = b"GGG" + b"ACGT" + b"N" + b"AC" + b"TT" + b"GT" + b"R" + b"ACG" + b"CGTACG"
+    alns = [
+        _mk(read, q[:len(read)], [(1, 0, False, ed)], mapq=40),
+        _mk(b"AAAACGGGGAAAACCCC", [2, 0, 1, 93] + [30] * 13, [(2, 4, True, [(8, 8, b""), (1, 1, b"C"), (8, 8, b"")])], mapq=60),
+        _mk(b"ACGTACGTACGTACGTACGT", [35] * 20, [(3, 0, False, [(20, 20, b"")]), (2, 0, False, [(0, 0, b"")])], mapq=29),  # mapq == MINIMUMMQ fails
+        _mk(b"ACGTACGTACGTACGTACGT", [35] * 20, [(3, 0, False, [(20, 20, b"")])], mapq=30),
+        _mk(b"ACGTACGT", [30] * 8, [(3, 0, False, [(8, 8, b"")])]),                        # Lseq < 15: skipped
+        _mk(b"ACGTACGTACGTACGTACGT", [30] * 20, [(3, 0, False, [(20, 20, b"")])], identity=0.0),  # unmapped
+        _mk(b"ACGTACGTACGTACG", [30] * 15, [(3, 0, False, [(20, 20, b"")])]),              # path longer than the read: n runs out
+    ]
+    a = hc.AlnSet.parse_gam(gamio.write_gam(alns), keep_unmapped=True)
+    d = os.path.join(GOLD, "damageProfiles")
+    got, fin, ref = compare(g, db, a, (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read()))
+    assert ref["n_bad"] >= 1 and list(got["pass"][:4]) == [ref["pass"][i] for i in range(4)]
+
+
+def test_shipped_bins_table_clade_lookup():
+    """Real euka_db.{clade,bins} (335 clades, 3929 overlapping bins): the device's breakpoint search returns the
+    clade the reference's double loop ends on, for reads starting anywhere in the id space."""
+    db = ek.EukaDb.load(GOLD + "/euka_dir/euka_db.clade", GOLD + "/euka_dir/euka_db.bins")
+    rng = np.random.default_rng(3)
+    # a tiny graph whose node ids are spread over the whole table: ids listed explicitly
+    ids = np.unique(np.concatenate([rng.integers(1, 6_930_000, 400), db.bin_lo[::37], db.bin_hi[::41], [1, 2, 28140, 28141]]))
+    ids = ids[ids > 0]
+    max_id = int(ids.max())
+    off = np.zeros(max_id + 2, np.int64)
+    seq = bytearray()
+    present = np.zeros(max_id + 2, bool)
+    present[ids] = True
+    pos = 0
+    lens = np.where(present[:max_id + 1], 20, 0)
+    off[1:] = np.cumsum(lens)
+    node_seq = b"ACGTACGTACGTACGTACGT" * len(ids)
+    g = hc.Graph.from_arrays(int(ids.min()), max_id, off, node_seq, 1, np.zeros((max_id + 1, 1), np.uint64),
+                             np.full(max_id + 1, -1, np.int32), np.ones(1))
+    alns = [_mk(b"ACGTACGTACGTACGTACGT", [37] * 20, [(int(i), 0, False, [(20, 20, b"")])]) for i in ids]
+    a = hc.AlnSet.parse_gam(gamio.write_gam(alns))
+    got, fin, ref = compare(g, db, a, ("", ""))
+    assert len(set(got["clade"].tolist())) > 50

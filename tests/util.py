@@ -23,3 +23,16 @@ def rel_err(a, b):
     b = np.asarray(b, np.float64)
     den = np.maximum(np.abs(b), 1e-300)
     return np.max(np.abs(a - b) / den) if a.size else 0.0
+
+
+def orc_graph_nodes_only(g):
+    """Oracle graph view for euka / soibean: node sequences only (no path matrix)."""
+    off = g.node_seq_off
+    seq = g.node_seq.tobytes()
+    node_seqs = {i: seq[off[i]:off[i + 1]] for i in range(g.min_id, g.max_id + 1)}
+    return orc.Graph(node_seqs, 1, np.zeros((g.max_id + 1, 1), np.uint8), np.full(g.max_id + 1, -1, np.int32), np.ones(1))
+
+
+def orc_euka_db_from_product(db):
+    return orc.EukaDb(db.clade_dist.copy(), db.bin_off.astype(np.int32), db.bin_lo.copy(), db.bin_hi.copy(),
+                      db.bin_entropy.copy())

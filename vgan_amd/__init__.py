@@ -10,3 +10,4 @@ from .haplocart import (  # noqa: F401
     MODE_NODE_WEIGHTS, MODE_PER_READ, MODE_PER_READ_DENSE,
     synth_graph, synth_reads,
 )
+from .euka import EukaDb, Damage, EukaHostBatch, EukaDeviceBatch, EukaContext, synth_euka  # noqa: F401

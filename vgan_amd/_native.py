@@ -48,6 +48,41 @@ class HcParams(C.Structure):
                 ("is_consensus_fasta", C.c_int32)]
 
 
+class EukaDbView(C.Structure):
+    _fields_ = [("n_clades", C.c_uint32), ("clade_id", vp), ("clade_dist", vp), ("clade_npaths", vp), ("clade_snode", vp),
+                ("clade_enode", vp), ("clade_names", C.c_char_p), ("bin_off", vp), ("bin_lo", vp), ("bin_hi", vp),
+                ("bin_entropy", vp)]
+
+
+class DamageView(C.Structure):
+    _fields_ = [("n5", C.c_uint32), ("n3", C.c_uint32), ("sub5p", vp), ("sub3p", vp)]
+
+
+class EukaBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_cols", C.c_uint64), ("n_qual", C.c_uint64), ("n_maps", C.c_uint64),
+                ("read_col_off", vp), ("read_qual_off", vp), ("read_map_off", vp), ("read_gseq_len", vp),
+                ("read_rseq_len", vp), ("read_seq_len", vp), ("read_mapq", vp), ("read_rev", vp), ("read_src", vp),
+                ("map_node", vp), ("graph_seq", vp), ("read_seq", vp), ("qual", vp), ("on_device", C.c_int32),
+                ("reserved", C.c_uint32)]
+
+
+class EukaFlattenStats(C.Structure):
+    _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64), ("n_unmapped", C.c_int64), ("n_bad", C.c_int64)]
+
+
+class EukaParams(C.Structure):
+    _fields_ = [("min_mapq", C.c_uint32), ("length_to_prof", C.c_int32)]
+
+
+class EukaReadOut(C.Structure):
+    _fields_ = [("clade", vp), ("in_lik", vp), ("out_lik", vp), ("like", vp), ("not_like", vp), ("pass_", vp)]
+
+
+class SynthEukaCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_clades", C.c_uint32), ("nodes_per_clade", C.c_uint32), ("n_reads", C.c_uint64),
+                ("read_len_mean", C.c_uint32)]
+
+
 class SynthGraphCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint32), ("n_nodes", C.c_uint32), ("n_paths", C.c_uint32)]
 
@@ -93,6 +128,25 @@ SYMBOLS = {
     "vgan_hc_profile_read": (C.c_int, [vp, vp, vp]),
     "vgan_hc_posterior": (C.c_int, [vp, vp, C.c_char_p, C.c_char_p, C.c_int64, vp, C.c_int32]),
     "vgan_hc_argmax": (C.c_int, [vp, C.c_uint32]),
+    "vgan_euka_db_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp)]),
+    "vgan_euka_db_from_arrays": (C.c_int, [C.POINTER(EukaDbView), C.POINTER(vp)]),
+    "vgan_euka_db_view_get": (C.c_int, [vp, C.POINTER(EukaDbView)]),
+    "vgan_euka_db_free": (None, [vp]),
+    "vgan_damage_from_text": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp)]),
+    "vgan_damage_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp)]),
+    "vgan_damage_view_get": (C.c_int, [vp, C.POINTER(DamageView)]),
+    "vgan_damage_free": (None, [vp]),
+    "vgan_euka_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(EukaFlattenStats)]),
+    "vgan_euka_host_batch_get": (C.c_int, [vp, C.POINTER(EukaBatch)]),
+    "vgan_euka_host_batch_free": (None, [vp]),
+    "vgan_euka_create": (C.c_int, [C.POINTER(EukaDbView), C.POINTER(DamageView), C.POINTER(EukaParams), C.c_int, C.POINTER(vp)]),
+    "vgan_euka_set_stream": (C.c_int, [vp, vp]),
+    "vgan_euka_reset": (C.c_int, [vp]),
+    "vgan_euka_accumulate": (C.c_int, [vp, C.POINTER(EukaBatch), C.POINTER(EukaReadOut)]),
+    "vgan_euka_finalize": (C.c_int, [vp, vp, vp, vp, vp]),
+    "vgan_euka_kernel_ms": (C.c_int, [vp, vp, vp]),
+    "vgan_euka_destroy": (None, [vp]),
+    "vgan_synth_euka": (C.c_int, [C.POINTER(SynthEukaCfg), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "vgan_synth_hc_graph": (C.c_int, [C.POINTER(SynthGraphCfg), C.POINTER(vp)]),
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),
 }

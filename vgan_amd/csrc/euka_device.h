@@ -1,0 +1,52 @@
+// Device-side views of the euka path (euka_kernels.hip / euka_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vgan {
+
+// HBM layout, graph/db side (built once per context):
+//   bp / bp_clade   sorted node-id breakpoints of all bins and, per elementary interval, the clade the reference's
+//                   scan ends on ("last (clade, bin) containing the node", readGAM_Euka.h:120-140); -1 = no bin.
+//   sub5p / sub3p   [n][4][4] fp64 damage matrices per distance from the 5' / 3' end (damage.cpp:66-136); positions
+//                   beyond the last row reuse it, so subDeamDiNuc[L][l] (128 MB in the reference) is never built:
+//                   row b1 comes from the 5' matrix at l when its diagonal <= the 3' matrix's at L-l-1 (damage.cpp:18-36).
+struct EukaDev {
+    const uint32_t *bp;
+    const int32_t *bp_clade;
+    uint32_t n_bp;
+    const double *clade_dist;
+    const uint32_t *bin_off;
+    const int32_t *bin_lo, *bin_hi;
+    const double *sub5p, *sub3p;
+    uint32_t n5, n3;
+    const double *qscore;  // [100] Euka::get_qscore_vec (Euka.cpp:38-51)
+    const double *mapq_ok; // [256] 1 - pow(10, -mapq*0.1)  (miscfunc.h:215-216)
+    uint32_t n_clades;
+    uint32_t min_mapq;
+    int32_t ltp; // lengthToProf
+};
+
+struct EukaBatchDev {
+    uint32_t n_reads;
+    const uint32_t *read_col_off, *read_qual_off, *read_map_off;
+    const uint16_t *read_gseq_len, *read_rseq_len, *read_seq_len;
+    const int32_t *read_mapq;
+    const uint8_t *read_rev;
+    const uint32_t *map_node;
+    const uint8_t *graph_seq, *read_seq, *qual;
+};
+
+struct EukaOutDev {
+    int32_t *clade;
+    double *in_lik, *out_lik, *like, *not_like;
+    uint8_t *pass;
+    int32_t *clade_count;
+    uint32_t *baseshift;
+    double *bin_cov;
+    unsigned long long *n_bad;
+};
+
+void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev &o, hipStream_t st);
+
+} // namespace vgan

@@ -37,6 +37,18 @@ struct SplitMix64 {
     uint64_t below(uint64_t n) { return n ? next() % n : 0; }
 };
 
+struct Recon {
+    std::string gseq, ps;
+    std::vector<int32_t> sizes;
+};
+
+} // namespace vgan
+
+struct vgan_graph;
+struct vgan_alnset;
+namespace vgan {
+// reconstruct_graph_sequence (reference src/vgan_utils.h:6-79); 0 or a code for reads the reference dies on
+int reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Recon &o);
 } // namespace vgan
 
 struct vgan_graph {

@@ -60,11 +60,6 @@ inline char comp(char c) {
     }
 }
 
-struct Recon {
-    std::string gseq, ps;
-    std::vector<int32_t> sizes;
-};
-
 // appends oriented_node[off, off+n) (clamped like std::string::substr); false if off > node length
 inline bool append_node(const vgan_graph &g, int64_t id, bool rev, int64_t off, int64_t n, std::string &out,
                         int64_t *appended) {
@@ -82,7 +77,10 @@ inline bool append_node(const vgan_graph &g, int64_t id, bool rev, int64_t off, 
     return true;
 }
 
-int reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Recon &o) {
+} // namespace
+
+// a1, shared by the HaploCart / euka / soibean front halves.  Returns 0 or a BAD_* code.
+int vgan::reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Recon &o) {
     o.gseq.clear();
     o.ps.clear();
     o.sizes.clear();
@@ -134,6 +132,8 @@ int reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Recon &o) 
     }
     return 0;
 }
+
+namespace {
 
 struct Chunk {
     vgan_hc_host_batch b;
