@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x76676131)
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-read-mode kernel measurement")
+    ap.add_argument("--path", choices=["haplocart", "euka"], default="haplocart",
+                    help="haplocart = the BASELINE metric; euka = the euka per-read kernel (config 4 shape, extra line)")
     return ap.parse_args()
 
 
@@ -68,8 +70,59 @@ def cpu_baseline(graph, alns, budget_s):
             "hoisted_variant_reads_per_s": hoisted}
 
 
+def bench_euka(args):
+    """BASELINE config 4 shape: synthetic 75 bp aDNA reads with the dhigh damage profiles against a 335-clade graph."""
+    import torch
+    from vgan_amd import distributed as vd
+    from vgan_amd import euka as ek
+    rank, world, local_rank = vd.env_rank()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    vd.init(backend="nccl", device=dev)
+    gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
+    dm = ek.Damage.load(os.path.join(gold, "dhigh5p.prof"), os.path.join(gold, "dhigh3p.prof"))
+    g, db, alns = ek.synth_euka(args.reads, dm, seed=args.seed + 1000003 * rank, n_clades=335, nodes_per_clade=400,
+                                read_len_mean=75)
+    hb = ek.EukaHostBatch(g, alns)
+    dbt = ek.EukaDeviceBatch(hb, dev)
+    ctx = ek.EukaContext(db, dm, device=local_rank)
+    ctx.use_torch_stream()
+
+    def step():
+        ctx.reset()
+        ctx.accumulate(dbt)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.kernel_ms()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms, n = ctx.kernel_ms()
+    fin = ctx.finalize()
+    if rank == 0:
+        kb = hb.algorithmic_bytes()
+        avg = ms / max(n, 1)
+        gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        print(json.dumps({
+            "metric": "reads/sec through euka per-read two-model likelihood (readGAM3), 75bp aDNA", "value": hb.n_reads * args.steps / elapsed,
+            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "euka %d synthetic 75bp aDNA reads per GPU, dhigh damage profiles, 335-clade graph" % args.reads,
+                       "reads_per_gpu": hb.n_reads, "passing_reads": int(fin["clade_count"].sum())},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "euka_read_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
+                         "launches": n, "note": "fp64 transcendental bound (SURVEY 8d): ~4 log-equivalents + 16 FMA per base"}}),
+              flush=True)
+
+
 def main():
     args = parse()
+    if args.path == "euka":
+        return bench_euka(args)
     import numpy as np
     import torch
     import torch.distributed as dist
