@@ -310,6 +310,77 @@ int vgan_euka_finalize(vgan_euka_ctx *c, int32_t *clade_count, uint32_t *baseshi
 int vgan_euka_kernel_ms(vgan_euka_ctx *c, double *ms, uint64_t *launches); /* HIP-event time of the read kernel */
 void vgan_euka_destroy(vgan_euka_ctx *c);
 
+/* ------------------------------------------------------------------------------------------------
+ * soibean: per-read x per-path likelihood (analyse_GAM, getLCAfromGAM.h:31-732; replaces the call at
+ * soibean.cpp:558) and the per-MCMC-iteration likelihood refresh (MCMC.cpp:738-993 inside
+ * MCMC::run_tree_proportion, MCMC.h:87; computeBaseLogLike MCMC.h:111-296).
+ *
+ * The reference keeps, per read and path, a list of per-base records (detailMap: reads x paths x bases x 16 B) and
+ * re-walks it every iteration.  Here analyse_GAM's result is factorised once into, per (read, path):
+ *   pm   = sum of the per-base log-likelihoods (pathMap)
+ *   cnt  = 5x5 counts of (reference base, read base) over the path-supported bases (the only bases that get the HKY
+ *          term, which depends on nothing but that pair and the branch time)
+ * so one refresh is  LL(read, path, t) = pm + sum_j cnt[j] * hky_t[j]  -- a streaming reduction over HBM-resident
+ * tables laid out [path][j][read] so that the 2k paths an iteration touches are read fully coalesced.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_sb_batch {
+    uint32_t n_reads, n_segments;
+    uint64_t n_cols, n_qual;
+    const uint32_t *read_seg_off;  /* [n_reads+1] edit-level segments (mppg_sizes entries, getLCAfromGAM.h:139) */
+    const uint32_t *read_col_off;  /* [n_reads+1] */
+    const uint32_t *read_qual_off; /* [n_reads+1] */
+    const uint16_t *read_gseq_len; /* [n_reads] |graph_seq| = Lseq of the damage table (getLCAfromGAM.h:109), 15..1000 */
+    const uint16_t *read_rseq_len; /* [n_reads] |read_seq| */
+    const uint8_t *read_rev;       /* [n_reads] */
+    const uint32_t *read_src;      /* [n_reads] index in the alignment set */
+    const uint32_t *seg_node;      /* [n_segments] node id of mapping i, 0 = "No_support" (:156-160) */
+    const uint16_t *seg_col;       /* [n_segments] first column of the slice (baseIX, or startIndex on the reverse strand) */
+    const uint16_t *seg_len;       /* [n_segments] |nodeSeq| */
+    const uint16_t *seg_base_ix;   /* [n_segments] baseIX: damage position and start of the penalty pattern */
+    const uint8_t *graph_seq, *read_seq, *qual;
+    int32_t on_device;
+    uint32_t reserved;
+} vgan_sb_batch;
+
+typedef struct vgan_sb_host_batch vgan_sb_host_batch;
+typedef struct vgan_sb_flatten_stats {
+    int64_t n_in, n_out, n_unmapped, n_bad;
+} vgan_sb_flatten_stats;
+int vgan_sb_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
+                    vgan_sb_host_batch **out, vgan_sb_flatten_stats *stats);
+int vgan_sb_host_batch_get(const vgan_sb_host_batch *b, vgan_sb_batch *out);
+void vgan_sb_host_batch_free(vgan_sb_host_batch *b);
+
+typedef struct vgan_sb_params {
+    int32_t penalty; /* PENALTY, -P (soibean.cpp: 7) */
+    int32_t reserved;
+} vgan_sb_params;
+
+typedef struct vgan_sb_source { /* one source of an MCMC state (MCMC.cpp:885-980) */
+    int32_t child, parent;  /* path indices: pathNames[y], parentpathNames[y] */
+    double dist;            /* positions_tree[y].pos->dist, the child's branch length (0 -> 1e-5) */
+    double pos;             /* positions_tree[y].pos_branch */
+    double theta;           /* proportions[y] (ignored when k = 1) */
+} vgan_sb_source;
+
+typedef struct vgan_sb_ctx vgan_sb_ctx;
+/* graph view: mask = nodepaths (paths through each node), path_names for the 101-character rule; at most 256 paths */
+int vgan_sb_create(const vgan_graph_view *graph, const vgan_damage_view *dmg, const vgan_sb_params *prm, int device,
+                   vgan_sb_ctx **out);
+int vgan_sb_set_stream(vgan_sb_ctx *c, void *hip_stream);
+/* analyse_GAM over the batch: (re)builds the device-resident factorised tables.  n_bad: reads excluded on the device */
+int vgan_sb_precompute(vgan_sb_ctx *c, const vgan_sb_batch *b, int64_t *n_bad);
+/* test aid: pm [n_paths][r1-r0], cnt [n_paths][25][r1-r0], ok [r1-r0] of the resident reads, host arrays */
+int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, double *pm, uint16_t *cnt, uint8_t *ok);
+/* n_states likelihood refreshes in one launch (e.g. the independent chains, soibean.cpp:805-840); src has n_states*k
+ * entries; freqs7 = {A, C, G, T, R, Y, M} (soibean.cpp:609-640); out: host double[n_states] (synchronises) and/or
+ * d_out: device double[n_states] for an RCCL all-reduce.  guard[n_states] (host, optional) counts reads on which one
+ * of the reference's runtime_error guards would fire. */
+int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                    double *out, double *d_out, uint64_t *guard);
+int vgan_sb_kernel_ms(vgan_sb_ctx *c, double ms[2], uint64_t launches[2]); /* 0 precompute kernel, 1 refresh kernel */
+void vgan_sb_destroy(vgan_sb_ctx *c);
+
 typedef struct vgan_synth_euka_cfg {
     uint64_t seed;
     uint32_t n_clades;        /* 335 */

@@ -156,6 +156,21 @@ int64_t orc_load_clade_chunks(const char *txt, int32_t *bin_off, int32_t *lo, in
 int64_t orc_load_clade_info(const char *txt, int32_t *id, double *dist, int32_t *npaths, int32_t *snode, int32_t *enode,
                             char *names, int64_t names_cap, int64_t cap);
 
+/* ------------------------------------------------------------------ soibean (oracle/sb_oracle.cpp) */
+/* analyse_GAM (src/getLCAfromGAM.h:31-732): g->pathsgo[node][p] = path p goes through the node (nodepaths);
+ * path_findable[p] = 0 for path names longer than 101 characters (never matched, :80-88).  Returns a handle holding
+ * pathMap / detailMap of every read. */
+void *orc_sb_analyse(const orc_graph_t *g, const orc_alnset_t *a, const uint8_t *path_findable, const void *dmg, int PENALTY,
+                     int64_t *n_bad);
+void orc_sb_free(void *h);
+int orc_sb_read_ok(const void *h, int64_t r);
+int orc_sb_pathmap(const void *h, int64_t r, double *out /* [n_paths] */);
+int orc_sb_counts(const void *h, int64_t r, int32_t p, uint32_t *out25, uint32_t *n_bases);
+/* one likelihood refresh of the tree-placement MCMC (src/MCMC.cpp:738-993, src/MCMC.h:111-315);
+ * freqs7 = {A, C, G, T, R, Y, M}; dist[y] = branch length of the child node */
+int orc_sb_loglike(const void *h, int32_t k, const int32_t *child, const int32_t *parent, const double *dist, const double *pos,
+                   const double *theta, double con, const double *freqs7, int n_threads, double *logLike);
+
 #ifdef __cplusplus
 }
 #endif

@@ -312,3 +312,50 @@ def euka_run(g, a, db, dmg, min_mapq=29, length_to_prof=5):
     o["n_bad"] = oc.n_bad
     o["bin_cov"] = o["bin_cov"][:nb]
     return o
+
+
+# ---------------------------------------------------------------- soibean
+class SbOracle:
+    """analyse_GAM result (pathMap / detailMap per read) held by the oracle."""
+
+    def __init__(self, g, a, dmg, penalty=7, path_findable=None):
+        L = lib()
+        L.orc_sb_analyse.restype = C.c_void_p
+        self.P = g.n_paths
+        pf = np.ones(self.P, np.uint8) if path_findable is None else np.ascontiguousarray(path_findable, np.uint8)
+        bad = C.c_int64(0)
+        self.h = L.orc_sb_analyse(C.byref(g.c), C.byref(a.c), _p(pf), C.c_void_p(dmg.h), C.c_int(penalty), C.byref(bad))
+        self.n_bad = bad.value
+        self._keep = (g, a, dmg, pf)
+
+    def ok(self, r):
+        return bool(lib().orc_sb_read_ok(C.c_void_p(self.h), C.c_int64(r)))
+
+    def pathmap(self, r):
+        out = np.zeros(self.P)
+        rc = lib().orc_sb_pathmap(C.c_void_p(self.h), C.c_int64(r), _p(out))
+        return out if rc == 0 else None
+
+    def counts(self, r, p):
+        out = np.zeros(25, np.uint32)
+        n = C.c_uint32(0)
+        rc = lib().orc_sb_counts(C.c_void_p(self.h), C.c_int64(r), C.c_int32(p), _p(out), C.byref(n))
+        return (out, n.value) if rc == 0 else (None, 0)
+
+    def loglike(self, sources, con, freqs7, n_threads=8):
+        k = len(sources)
+        child = np.array([s[0] for s in sources], np.int32)
+        parent = np.array([s[1] for s in sources], np.int32)
+        dist = np.array([s[2] for s in sources], np.float64)
+        pos = np.array([s[3] for s in sources], np.float64)
+        theta = np.array([s[4] for s in sources], np.float64)
+        f = np.ascontiguousarray(freqs7, np.float64)
+        out = C.c_double(0)
+        rc = lib().orc_sb_loglike(C.c_void_p(self.h), C.c_int32(k), _p(child), _p(parent), _p(dist), _p(pos), _p(theta),
+                                  C.c_double(con), _p(f), C.c_int(n_threads), C.byref(out))
+        return rc, out.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_sb_free(C.c_void_p(self.h))
+            self.h = None

@@ -1,0 +1,122 @@
+"""GPU parity tests of the soibean path (run with -m gpu): factorised tables and likelihood refresh vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import gamio
+import orc
+import util
+from vgan_amd import euka as ek
+from vgan_amd import haplocart as hc
+from vgan_amd import soibean as sb
+from test_euka_cpu import _mk, GOLD
+from test_sb_cpu import FREQS
+
+pytestmark = pytest.mark.gpu
+
+
+def tree_pairs(g):
+    """(child, parent, branch length) for every non-root path of the synthetic tree."""
+    names = g.path_names
+    idx = {n: i for i, n in enumerate(names)}
+    pairs = []
+    for line in g.parents_txt.splitlines():
+        t = line.split()
+        if len(t) >= 2:
+            pairs.append((idx[t[0]], idx[t[1]]))
+    return pairs
+
+
+def run_case(g, a, texts, penalty, states_k1, states_k3):
+    dm = ek.Damage.from_text(*texts)
+    hb = sb.SbHostBatch(g, a)
+    ctx = sb.SbContext(g, dm, penalty=penalty)
+    dev_bad = ctx.precompute(hb)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    findable = np.array([len(n) <= 101 for n in g.path_names], np.uint8)
+    o = orc.SbOracle(og, oa, orc.OrcDamage(*texts), penalty=penalty, path_findable=findable)
+    assert o.n_bad == hb.stats.n_bad + dev_bad
+    pm, cnt, ok = ctx.read_tables()
+    src = hb.arrays()["read_src"]
+    assert ok.all()
+    step = max(1, hb.n_reads // 150)
+    for k in range(0, hb.n_reads, step):
+        r = int(src[k])
+        ref = o.pathmap(r)
+        assert util.rel_err(pm[:, k], ref) < 1e-11, r
+        for p in range(0, g.n_paths, max(1, g.n_paths // 5)):
+            c, _ = o.counts(r, p)
+            assert np.array_equal(cnt[p, :, k].astype(np.uint32), c), (r, p)
+    # the oracle must hold exactly the reads the device holds for the refresh comparison
+    assert sum(o.ok(r) for r in range(a.n_reads)) == hb.n_reads
+    got, guard = ctx.loglike(states_k1 + [], 0.01, FREQS)
+    for st, v, gd in zip(states_k1, got, guard):
+        rc, ref = o.loglike(st, 0.01, FREQS)
+        assert rc == 0 and gd == 0
+        assert v == pytest.approx(ref, rel=1e-10)
+    got, guard = ctx.loglike(states_k3, 0.02, FREQS)
+    for st, v in zip(states_k3, got):
+        rc, ref = o.loglike(st, 0.02, FREQS)
+        assert rc == 0 and v == pytest.approx(ref, rel=1e-10)
+    # determinism of the refresh: identical bits on a second evaluation
+    again, _ = ctx.loglike(states_k3, 0.02, FREQS)
+    assert np.array_equal(again, got)
+    return ctx, o
+
+
+def test_tree_of_28_paths_with_damage():
+    g = hc.synth_graph(seed=17, genome_len=6000, n_nodes=4000, n_paths=28)
+    a = hc.synth_reads(g, 1500, seed=6, read_len=60, indel_rate=0.1, softclip_rate=0.1)
+    pairs = tree_pairs(g)
+    d = os.path.join(GOLD, "damageProfiles")
+    texts = (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    k1 = [[(c, p, 0.02 + 0.001 * i, 0.1 + 0.08 * i, 1.0)] for i, (c, p) in enumerate(pairs[:9])] + [[(pairs[3][0], pairs[3][1], 0.0, 0.5, 1.0)]]
+    k3 = [[(pairs[1][0], pairs[1][1], 0.03, 0.35, 0.5), (pairs[7][0], pairs[7][1], 0.011, 0.8, 0.3), (pairs[12][0], pairs[12][1], 0.04, 0.02, 0.2)],
+          [(pairs[20][0], pairs[20][1], 0.0, 0.5, 0.2), (pairs[5][0], pairs[5][1], 0.2, 0.99, 0.2), (pairs[9][0], pairs[9][1], 0.003, 0.5, 0.6)]]
+    run_case(g, a, texts, 7, k1, k3)
+
+
+def test_many_paths_long_names_and_other_penalty():
+    """130 paths (3 path slots per lane), a path name longer than 101 characters (never supported), PENALTY 3."""
+    g0 = hc.synth_graph(seed=23, genome_len=3000, n_nodes=2000, n_paths=130)
+    names = g0.path_names
+    names[5] = "x" * 120
+    g = hc.Graph.from_arrays(g0.min_id, g0.max_id, g0.node_seq_off, g0.node_seq.tobytes(), 130, g0.mask, g0.pangenome_base,
+                             g0.mappability, "\n".join(names) + "\n", g0.parents_txt, g0.children_txt)
+    a = hc.synth_reads(g0, 600, seed=2, read_len=80)
+    pairs = [(c, p) for c, p in tree_pairs(g0) if c != 5 and p != 5]
+    k1 = [[(pairs[10][0], pairs[10][1], 0.05, 0.3, 1.0)], [(5, pairs[0][1], 0.05, 0.3, 1.0)]]
+    k3 = [[(pairs[40][0], pairs[40][1], 0.03, 0.35, 0.5), (pairs[80][0], pairs[80][1], 0.011, 0.8, 0.3), (pairs[100][0], pairs[100][1], 0.04, 0.2, 0.2)]]
+    ctx, o = run_case(g, a, ("", ""), 3, k1, k3)
+    pm, cnt, ok = ctx.read_tables(0, 50)
+    assert cnt[5].sum() == 0  # no base of the over-long path is ever "supported"
+
+
+def test_special_reads():
+    """N / softclip / gap columns, reverse strand slicing, reads the reference cannot process."""
+    seqs = {1: b"ACGTNACGTAACGTACGTACGTAAAA", 2: b"CCCCGGGGTTTTAAAACCCCGGGGTTTT", 3: b"ACGTACGTACGTACGTACGT"}
+    node_seq = b"".join(seqs[i] for i in (1, 2, 3))
+    off = np.array([0, 0, 26, 54, 74], np.int64)
+    mask = np.zeros((4, 1), np.uint64)
+    mask[1, 0] = 0b011
+    mask[2, 0] = 0b101
+    mask[3, 0] = 0b111
+    g = hc.Graph.from_arrays(1, 3, off, node_seq, 3, mask, np.full(4, -1, np.int32), np.ones(1), "p0\np1\np2\n",
+                             "p1 p0\np2 p0\n", "p0 p1 p2\n")
+    q = list(range(20, 60))
+    ed = [(0, 3, b"GGG"), (4, 4, b""), (1, 1, b""), (2, 2, b""), (0, 2, b"TT"), (2, 2, b""), (1, 1, b""), (3, 3, b""), (2, 0, b""), (6, 6, b"")]
+    read = b"GGG" + b"ACGT" + b"N" + b"AC" + b"TT" + b"GT" + b"A" + b"ACG" + b"CGTACG"
+    alns = [
+        _mk(read, q[:len(read)], [(1, 0, False, ed)], mapq=40),
+        _mk(b"AAAACGGGGAAAACCCC", [2, 0, 1, 93] + [30] * 13, [(2, 4, True, [(8, 8, b""), (1, 1, b"C"), (8, 8, b"")])]),
+        _mk(b"ACGTACGTACGTACGTACGT", [35] * 20, [(3, 0, False, [(20, 20, b"")]), (2, 0, True, [(5, 5, b"")])]),
+        _mk(b"ACGTACGT", [30] * 8, [(3, 0, False, [(8, 8, b"")])]),                                  # |graph_seq| < 15
+        _mk(b"ACGTACGTACGTACGTACGT", [30] * 20, [(3, 0, False, [(20, 20, b"")])], identity=0.0),   # unmapped
+    ]
+    a = hc.AlnSet.parse_gam(gamio.write_gam(alns), keep_unmapped=True)
+    d = os.path.join(GOLD, "damageProfiles")
+    texts = (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    k1 = [[(1, 0, 0.02, 0.3, 1.0)], [(2, 0, 0.05, 0.9, 1.0)]]
+    k3 = [[(1, 0, 0.02, 0.3, 0.2), (2, 0, 0.05, 0.9, 0.5), (0, 1, 0.01, 0.5, 0.3)]]
+    run_case(g, a, texts, 7, k1, k3)

@@ -11,3 +11,4 @@ from .haplocart import (  # noqa: F401
     synth_graph, synth_reads,
 )
 from .euka import EukaDb, Damage, EukaHostBatch, EukaDeviceBatch, EukaContext, synth_euka  # noqa: F401
+from .soibean import SbHostBatch, SbContext  # noqa: F401

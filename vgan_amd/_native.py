@@ -78,6 +78,26 @@ class EukaReadOut(C.Structure):
     _fields_ = [("clade", vp), ("in_lik", vp), ("out_lik", vp), ("like", vp), ("not_like", vp), ("pass_", vp)]
 
 
+class SbBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_segments", C.c_uint32), ("n_cols", C.c_uint64), ("n_qual", C.c_uint64),
+                ("read_seg_off", vp), ("read_col_off", vp), ("read_qual_off", vp), ("read_gseq_len", vp),
+                ("read_rseq_len", vp), ("read_rev", vp), ("read_src", vp), ("seg_node", vp), ("seg_col", vp),
+                ("seg_len", vp), ("seg_base_ix", vp), ("graph_seq", vp), ("read_seq", vp), ("qual", vp),
+                ("on_device", C.c_int32), ("reserved", C.c_uint32)]
+
+
+class SbFlattenStats(C.Structure):
+    _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64), ("n_unmapped", C.c_int64), ("n_bad", C.c_int64)]
+
+
+class SbParams(C.Structure):
+    _fields_ = [("penalty", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SbSource(C.Structure):
+    _fields_ = [("child", C.c_int32), ("parent", C.c_int32), ("dist", C.c_double), ("pos", C.c_double), ("theta", C.c_double)]
+
+
 class SynthEukaCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_clades", C.c_uint32), ("nodes_per_clade", C.c_uint32), ("n_reads", C.c_uint64),
                 ("read_len_mean", C.c_uint32)]
@@ -146,6 +166,16 @@ SYMBOLS = {
     "vgan_euka_finalize": (C.c_int, [vp, vp, vp, vp, vp]),
     "vgan_euka_kernel_ms": (C.c_int, [vp, vp, vp]),
     "vgan_euka_destroy": (None, [vp]),
+    "vgan_sb_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(SbFlattenStats)]),
+    "vgan_sb_host_batch_get": (C.c_int, [vp, C.POINTER(SbBatch)]),
+    "vgan_sb_host_batch_free": (None, [vp]),
+    "vgan_sb_create": (C.c_int, [C.POINTER(GraphView), C.POINTER(DamageView), C.POINTER(SbParams), C.c_int, C.POINTER(vp)]),
+    "vgan_sb_set_stream": (C.c_int, [vp, vp]),
+    "vgan_sb_precompute": (C.c_int, [vp, C.POINTER(SbBatch), vp]),
+    "vgan_sb_read_tables": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp]),
+    "vgan_sb_loglike": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_double, vp, vp, vp, vp]),
+    "vgan_sb_kernel_ms": (C.c_int, [vp, vp, vp]),
+    "vgan_sb_destroy": (None, [vp]),
     "vgan_synth_euka": (C.c_int, [C.POINTER(SynthEukaCfg), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "vgan_synth_hc_graph": (C.c_int, [C.POINTER(SynthGraphCfg), C.POINTER(vp)]),
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),

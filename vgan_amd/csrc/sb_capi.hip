@@ -1,0 +1,347 @@
+// C-ABI of the soibean device path (include/vgan_gpu.h).  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+#include "host/common.h"
+#include "sb_device.h"
+#include "vgan_gpu.h"
+
+using namespace vgan;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(VGAN_ENODEV, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+template <class T> struct Buf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap && p) return VGAN_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + 64;
+        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return VGAN_OK;
+    }
+    int upload(const T *src, size_t n) {
+        int rc = reserve(n);
+        if (rc) return rc;
+        if (n) HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return VGAN_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+} // namespace
+
+struct vgan_sb_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    SbGraphDev g{};
+    SbTablesDev t{};
+    uint32_t P = 0;
+    Buf<uint64_t> mask;
+    Buf<uint8_t> findable;
+    Buf<double> sub5p, sub3p, qscore;
+    Buf<double> pm;
+    Buf<uint16_t> cnt;
+    Buf<uint8_t> ok;
+    Buf<unsigned long long> n_bad, guard;
+    Buf<uint32_t> s32;
+    Buf<uint16_t> s16;
+    Buf<uint8_t> s8;
+    Buf<SbSourceDev> src;
+    Buf<double> hky, partial, out, freqs;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool pending[2] = {false, false};
+    double ms[2] = {0, 0};
+    uint64_t launches[2] = {0, 0};
+};
+
+static void resolve(vgan_sb_ctx *c, int i) {
+    if (!c->pending[i]) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(c->ev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]) == hipSuccess) {
+        c->ms[i] += ms;
+        c->launches[i] += 1;
+    }
+    c->pending[i] = false;
+}
+
+extern "C" int vgan_sb_create(const vgan_graph_view *gv, const vgan_damage_view *dmg, const vgan_sb_params *prm, int device,
+                              vgan_sb_ctx **out) {
+    if (!gv || !dmg || !prm || !out) return fail(VGAN_EINVAL, "vgan_sb_create: null argument");
+    if (gv->n_paths == 0 || gv->n_paths > SB_MAX_PATHS) return fail(VGAN_ERANGE, "vgan_sb_create: 1..%u paths supported, got %u", SB_MAX_PATHS, gv->n_paths);
+    if (!gv->mask || gv->max_id < 0) return fail(VGAN_EINVAL, "vgan_sb_create: graph has no path membership mask");
+    if (prm->penalty <= 0) return fail(VGAN_EINVAL, "vgan_sb_create: penalty must be positive");
+    if (dmg->n5 == 0 || dmg->n3 == 0) return fail(VGAN_EINVAL, "vgan_sb_create: empty damage tables");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(VGAN_ENODEV, "vgan_sb_create: no HIP device is visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(VGAN_EINVAL, "vgan_sb_create: device %d out of range", device);
+    HIPCHK(hipSetDevice(device));
+    auto c = new vgan_sb_ctx();
+    c->device = device;
+    c->P = gv->n_paths;
+    const uint32_t W = (gv->n_paths + 63) / 64, rows = (uint32_t)gv->max_id + 1;
+    std::vector<uint8_t> findable(c->P, 1);
+    {
+        std::istringstream in(gv->path_names ? gv->path_names : "");
+        std::string line;
+        uint32_t p = 0;
+        while (std::getline(in, line) && p < c->P) findable[p++] = line.size() > 101 ? 0 : 1; // getLCAfromGAM.h:80-88
+    }
+    std::vector<double> qs(100);
+    for (int Q = 0; Q < 100; ++Q) qs[(size_t)Q] = Q >= 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25;
+    auto bail = [&](int code) {
+        vgan_sb_destroy(c);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(VGAN_ENODEV, "stream creation failed"));
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(fail(VGAN_ENODEV, "event creation failed"));
+    c->stream = c->own_stream;
+    int rc;
+    if ((rc = c->mask.upload(gv->mask, (size_t)rows * W)) || (rc = c->findable.upload(findable.data(), findable.size())) ||
+        (rc = c->sub5p.upload(dmg->sub5p, (size_t)dmg->n5 * 16)) || (rc = c->sub3p.upload(dmg->sub3p, (size_t)dmg->n3 * 16)) ||
+        (rc = c->qscore.upload(qs.data(), 100)) || (rc = c->n_bad.reserve(1)) || (rc = c->freqs.reserve(8)))
+        return bail(rc);
+    c->g.mask = c->mask.p;
+    c->g.findable = c->findable.p;
+    c->g.sub5p = c->sub5p.p;
+    c->g.sub3p = c->sub3p.p;
+    c->g.n5 = dmg->n5;
+    c->g.n3 = dmg->n3;
+    c->g.qscore = c->qscore.p;
+    c->g.rows = rows;
+    c->g.mask_words = W;
+    c->g.n_paths = c->P;
+    c->g.penalty = prm->penalty;
+    *out = c;
+    return VGAN_OK;
+}
+
+extern "C" void vgan_sb_destroy(vgan_sb_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    c->mask.release();
+    c->findable.release();
+    c->sub5p.release();
+    c->sub3p.release();
+    c->qscore.release();
+    c->pm.release();
+    c->cnt.release();
+    c->ok.release();
+    c->n_bad.release();
+    c->guard.release();
+    c->s32.release();
+    c->s16.release();
+    c->s8.release();
+    c->src.release();
+    c->hky.release();
+    c->partial.release();
+    c->out.release();
+    c->freqs.release();
+    for (auto e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int vgan_sb_set_stream(vgan_sb_ctx *c, void *s) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_sb_set_stream: null context");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_sb_precompute(vgan_sb_ctx *c, const vgan_sb_batch *b, int64_t *n_bad) {
+    if (!c || !b) return fail(VGAN_EINVAL, "vgan_sb_precompute: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    resolve(c, 0);
+    const size_t R = b->n_reads, S = b->n_segments;
+    int rc;
+    if ((rc = c->pm.reserve((size_t)c->P * std::max<size_t>(R, 1))) ||
+        (rc = c->cnt.reserve((size_t)c->P * SB_NCNT * std::max<size_t>(R, 1))) || (rc = c->ok.reserve(std::max<size_t>(R, 1))))
+        return rc;
+    c->t.pm = c->pm.p;
+    c->t.cnt = c->cnt.p;
+    c->t.ok = c->ok.p;
+    c->t.n_reads = (uint32_t)R;
+    HIPCHK(hipMemsetAsync(c->n_bad.p, 0, 8, c->stream));
+    if (R == 0) {
+        if (n_bad) *n_bad = 0;
+        return VGAN_OK;
+    }
+    SbBatchDev d{};
+    d.n_reads = b->n_reads;
+    if (b->on_device) {
+        d.read_seg_off = b->read_seg_off;
+        d.read_col_off = b->read_col_off;
+        d.read_qual_off = b->read_qual_off;
+        d.read_gseq_len = b->read_gseq_len;
+        d.read_rseq_len = b->read_rseq_len;
+        d.read_rev = b->read_rev;
+        d.seg_node = b->seg_node;
+        d.seg_col = b->seg_col;
+        d.seg_len = b->seg_len;
+        d.seg_base_ix = b->seg_base_ix;
+        d.graph_seq = b->graph_seq;
+        d.read_seq = b->read_seq;
+        d.qual = b->qual;
+    } else {
+        auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+        if ((rc = c->s32.reserve(3 * up(R + 1) + up(S))) || (rc = c->s16.reserve(2 * up(R) + 3 * up(S))) ||
+            (rc = c->s8.reserve(up(R) + 2 * up(b->n_cols) + up(b->n_qual))))
+            return rc;
+#define COPY(dst, src, n)                                                                                                \
+    do {                                                                                                                 \
+        if ((n) > 0) HIPCHK(hipMemcpyAsync((void *)(dst), (src), (n) * sizeof(*(src)), hipMemcpyHostToDevice, c->stream)); \
+    } while (0)
+        uint32_t *p32 = c->s32.p;
+        uint16_t *p16 = c->s16.p;
+        uint8_t *p8 = c->s8.p;
+        d.read_seg_off = p32;
+        COPY(p32, b->read_seg_off, R + 1);
+        p32 += up(R + 1);
+        d.read_col_off = p32;
+        COPY(p32, b->read_col_off, R + 1);
+        p32 += up(R + 1);
+        d.read_qual_off = p32;
+        COPY(p32, b->read_qual_off, R + 1);
+        p32 += up(R + 1);
+        d.seg_node = p32;
+        COPY(p32, b->seg_node, S);
+        d.read_gseq_len = p16;
+        COPY(p16, b->read_gseq_len, R);
+        p16 += up(R);
+        d.read_rseq_len = p16;
+        COPY(p16, b->read_rseq_len, R);
+        p16 += up(R);
+        d.seg_col = p16;
+        COPY(p16, b->seg_col, S);
+        p16 += up(S);
+        d.seg_len = p16;
+        COPY(p16, b->seg_len, S);
+        p16 += up(S);
+        d.seg_base_ix = p16;
+        COPY(p16, b->seg_base_ix, S);
+        d.read_rev = p8;
+        COPY(p8, b->read_rev, R);
+        p8 += up(R);
+        d.graph_seq = p8;
+        COPY(p8, b->graph_seq, (size_t)b->n_cols);
+        p8 += up(b->n_cols);
+        d.read_seq = p8;
+        COPY(p8, b->read_seq, (size_t)b->n_cols);
+        p8 += up(b->n_cols);
+        d.qual = p8;
+        COPY(p8, b->qual, (size_t)b->n_qual);
+#undef COPY
+    }
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    launch_sb_precompute(c->g, d, c->t, c->n_bad.p, c->stream);
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    c->pending[0] = true;
+    HIPCHK(hipGetLastError());
+    unsigned long long nb = 0;
+    HIPCHK(hipMemcpyAsync(&nb, c->n_bad.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_bad) *n_bad = (int64_t)nb;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, double *pm, uint16_t *cnt, uint8_t *ok) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_sb_read_tables: null context");
+    if (r0 > r1 || r1 > c->t.n_reads) return fail(VGAN_EINVAL, "vgan_sb_read_tables: bad range");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = r1 - r0, R = c->t.n_reads;
+    if (n == 0) return VGAN_OK;
+    for (uint32_t p = 0; p < c->P; ++p) {
+        if (pm) HIPCHK(hipMemcpyAsync(pm + (size_t)p * n, c->t.pm + (size_t)p * R + r0, n * 8, hipMemcpyDeviceToHost, c->stream));
+        if (cnt)
+            for (uint32_t j = 0; j < SB_NCNT; ++j)
+                HIPCHK(hipMemcpyAsync(cnt + ((size_t)p * SB_NCNT + j) * n, c->t.cnt + ((size_t)p * SB_NCNT + j) * R + r0, n * 2,
+                                      hipMemcpyDeviceToHost, c->stream));
+    }
+    if (ok) HIPCHK(hipMemcpyAsync(ok, c->t.ok + r0, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VGAN_OK;
+}
+
+extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con,
+                               const double *freqs7, double *out, double *d_out, uint64_t *guard) {
+    if (!c || !src || !freqs7) return fail(VGAN_EINVAL, "vgan_sb_loglike: null argument");
+    if (n_states == 0 || k == 0) return fail(VGAN_EINVAL, "vgan_sb_loglike: need at least one state and one source");
+    if ((size_t)n_states * k * 2 * SB_NCNT * 8 > 60000) return fail(VGAN_ERANGE, "vgan_sb_loglike: n_states*k too large for one launch (<= 150)");
+    HIPCHK(hipSetDevice(c->device));
+    resolve(c, 1);
+    const uint32_t ne = n_states * k;
+    std::vector<SbSourceDev> sd(ne);
+    for (uint32_t i = 0; i < ne; ++i) {
+        if (src[i].child < 0 || src[i].parent < 0 || (uint32_t)src[i].child >= c->P || (uint32_t)src[i].parent >= c->P)
+            return fail(VGAN_EINVAL, "vgan_sb_loglike: path index out of range");
+        double t = src[i].dist;
+        if (t == 0.0) t = 0.00001; // MCMC.cpp:753-755,893-895
+        sd[i].child = src[i].child;
+        sd[i].parent = src[i].parent;
+        sd[i].t1 = src[i].pos * t;
+        sd[i].t2 = t - sd[i].t1;
+        sd[i].pos = src[i].pos;
+        sd[i].log_pos = log(src[i].pos);
+        sd[i].log_1mpos = log((1 - src[i].pos));
+        sd[i].log_theta = log(src[i].theta);
+    }
+    const uint32_t R = c->t.n_reads;
+    const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
+    int rc;
+    if ((rc = c->src.reserve(ne)) || (rc = c->hky.reserve((size_t)ne * 2 * SB_NCNT)) || (rc = c->partial.reserve((size_t)n_states * n_blocks)) ||
+        (rc = c->out.reserve(n_states)) || (rc = c->guard.reserve(n_states)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(c->src.p, sd.data(), ne * sizeof(SbSourceDev), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->freqs.p, freqs7, 7 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->guard.p, 0, (size_t)n_states * 8, c->stream));
+    launch_sb_hky(ne, c->src.p, con, c->freqs.p, c->hky.p, c->stream);
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    launch_sb_loglike(c->t, c->P, n_states, k, c->src.p, c->hky.p, c->partial.p, n_blocks, c->out.p, c->guard.p, c->stream);
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    c->pending[1] = true;
+    HIPCHK(hipGetLastError());
+    if (d_out) HIPCHK(hipMemcpyAsync(d_out, c->out.p, (size_t)n_states * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (out || guard) {
+        std::vector<unsigned long long> gd(n_states);
+        if (out) HIPCHK(hipMemcpyAsync(out, c->out.p, (size_t)n_states * 8, hipMemcpyDeviceToHost, c->stream));
+        if (guard) HIPCHK(hipMemcpyAsync(gd.data(), c->guard.p, (size_t)n_states * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (guard)
+            for (uint32_t i = 0; i < n_states; ++i) guard[i] = gd[i];
+    }
+    return VGAN_OK;
+}
+
+extern "C" int vgan_sb_kernel_ms(vgan_sb_ctx *c, double ms[2], uint64_t launches[2]) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_sb_kernel_ms: null context");
+    HIPCHK(hipSetDevice(c->device));
+    resolve(c, 0);
+    resolve(c, 1);
+    for (int i = 0; i < 2; ++i) {
+        if (ms) ms[i] = c->ms[i];
+        if (launches) launches[i] = c->launches[i];
+        c->ms[i] = 0;
+        c->launches[i] = 0;
+    }
+    return VGAN_OK;
+}

@@ -1,0 +1,55 @@
+// Device-side views of the soibean path (sb_kernels.hip / sb_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vgan {
+
+constexpr uint32_t SB_MAX_PATHS = 256;
+constexpr uint32_t SB_NCNT = 25; // (reference base, read base) in {A, C, G, T, other}^2
+
+struct SbGraphDev {
+    const uint64_t *mask;   // [rows][mask_words] paths through each node (nodepaths, soibean.cpp:476-491)
+    const uint8_t *findable; // [n_paths] 0 for names longer than 101 characters (getLCAfromGAM.h:80-88)
+    const double *sub5p, *sub3p;
+    uint32_t n5, n3;
+    const double *qscore; // [100]
+    uint32_t rows, mask_words, n_paths;
+    int32_t penalty;
+};
+
+struct SbBatchDev {
+    uint32_t n_reads;
+    const uint32_t *read_seg_off, *read_col_off, *read_qual_off;
+    const uint16_t *read_gseq_len, *read_rseq_len;
+    const uint8_t *read_rev;
+    const uint32_t *seg_node;
+    const uint16_t *seg_col, *seg_len, *seg_base_ix;
+    const uint8_t *graph_seq, *read_seq, *qual;
+};
+
+// Factorised result of analyse_GAM, HBM resident: the 2k paths one MCMC iteration touches are whole rows.
+//   pm  double [n_paths][R]          sum of per-base log-likelihoods (pathMap)
+//   cnt uint16 [n_paths][25][R]      counts of (reference, read) pairs over path-supported bases
+//   ok  uint8  [R]
+struct SbTablesDev {
+    double *pm;
+    uint16_t *cnt;
+    uint8_t *ok;
+    uint32_t n_reads;
+};
+
+struct SbSourceDev {
+    int32_t child, parent;
+    double t1, t2;      // pos*t, t - t1
+    double log_pos, log_1mpos, log_theta, pos;
+};
+
+void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, unsigned long long *n_bad,
+                          hipStream_t st);
+void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states, uint32_t k, const SbSourceDev *src,
+                       const double *hky /* [n_states*k][2][25] */, double *partial, uint32_t n_blocks, double *out,
+                       unsigned long long *guard, hipStream_t st);
+void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky, hipStream_t st);
+
+} // namespace vgan

@@ -1,0 +1,298 @@
+// soibean kernels for gfx950.
+//
+//   sb_precompute_kernel  analyse_GAM (reference src/getLCAfromGAM.h:92-560), one wave per read:
+//       (A) one lane per edit-level segment: the supported sum, the unsupported sum (penalty pattern on the running
+//           read position) and the 5x5 (reference, read) counts of its regular columns -- none depends on the path;
+//       (B) one lane per path: pm[p] = sum_m (path through node_m ? sup_m : uns_m), cnt[p] = sum of the supported
+//           segments' counts; bit p of the node's path mask decides.
+//   sb_hky_kernel         the 25-entry HKY tables of an MCMC state (src/MCMC.h:111-296; kappa = 1/22 = 0, Q13).
+//   sb_loglike_kernel     one likelihood refresh (src/MCMC.cpp:738-993): per read and source
+//       LL = pm[child] + sum_j cnt[child][j] * hky_t2[j], LLP likewise for the parent with t1, mixed over the branch
+//       position and the sources; reads reduced with wave shuffles, per-block partials summed in a fixed order
+//       (deterministic: the MCMC's accept/reject must not depend on atomics' arrival order).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "sb_device.h"
+
+namespace vgan {
+
+__device__ __forceinline__ int acgt5(uint32_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+
+constexpr int SBP_WAVES = 4;
+constexpr double SB_LOG_025 = -1.3862943611198906;      // log(0.25)
+constexpr double SB_LOG_002 = -3.912023005428146;       // log(0.02)
+constexpr double SB_LOG_CLAMP = -1.0000000494736474e-07; // log(0.9999999)
+
+struct SbSegLds {
+    double sup, uns;
+    uint32_t node;
+    uint8_t cnt[SB_NCNT];
+    uint8_t pad[3];
+};
+
+template <int PP>
+__global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDev g, SbBatchDev b, SbTablesDev t,
+                                                                        unsigned long long *n_bad) {
+    __shared__ double qs_s[100];
+    __shared__ SbSegLds seg_s[SBP_WAVES][64];
+    for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = g.qscore[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t R = t.n_reads;
+
+    for (uint32_t r = blockIdx.x * SBP_WAVES + wave; r < b.n_reads; r += gridDim.x * SBP_WAVES) {
+        const uint32_t s0 = b.read_seg_off[r], s1 = b.read_seg_off[r + 1];
+        const uint32_t col0 = b.read_col_off[r];
+        const uint32_t q0 = b.read_qual_off[r], QL = b.read_qual_off[r + 1] - q0;
+        const uint32_t Lseq = b.read_gseq_len[r], A = b.read_rseq_len[r];
+        const bool rev = b.read_rev[r] != 0;
+        double pm[PP];
+        uint32_t cnt[PP][SB_NCNT];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            pm[u] = 0.0;
+#pragma unroll
+            for (int j = 0; j < (int)SB_NCNT; ++j) cnt[u][j] = 0;
+        }
+        bool bad = false;
+        for (uint32_t sb = s0; sb < s1; sb += 64) {
+            // ---- (A) one lane per segment
+            const uint32_t s = sb + lane;
+            if (s < s1) {
+                const uint32_t node = b.seg_node[s], col = b.seg_col[s], len = b.seg_len[s];
+                const int32_t bix = b.seg_base_ix[s];
+                double sup = 0.0, uns = 0.0;
+                uint8_t c25[SB_NCNT];
+#pragma unroll
+                for (int j = 0; j < (int)SB_NCNT; ++j) c25[j] = 0;
+                if (len > 0 && (uint32_t)bix >= Lseq) bad = true;
+                const uint32_t nn = min((uint32_t)bix, Lseq - 1u);
+                const double *m5 = g.sub5p + 16u * min(nn, g.n5 - 1u);
+                const double *m3 = g.sub3p + 16u * min(Lseq - 1u - nn, g.n3 - 1u);
+                // row sums of the combined damage matrix are what the supported marginal needs (it adds log(post[b]) for
+                // every b, getLCAfromGAM.h:338-348): sum_b post[b] = sum_o pre[o] * rowsum(M[o])
+                double rowsum[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const double *row5 = m5 + 4 * o, *row3 = m3 + 4 * o;
+                    const double *row = row5[o] <= row3[o] ? row5 : row3; // damage.cpp:18-36
+                    rowsum[o] = ((row[0] + row[1]) + row[2]) + row[3];
+                }
+                int32_t bo = bix; // baseOnRead of the unsupported walk
+                for (uint32_t k = 0; k < len; ++k) {
+                    const uint32_t gc = b.graph_seq[col0 + col + k];
+                    const uint32_t rc = (col + k) < A ? b.read_seq[col0 + col + k] : 0u;
+                    int q = k < QL ? (int)(int8_t)b.qual[q0 + k] : 0; // Q12: within-segment index
+                    q = q < 0 ? 0 : (q > 99 ? 99 : q);
+                    const double qs = qs_s[q];
+                    double ls, lu;
+                    if (gc == 'N' || rc == 'N') {
+                        ls = lu = SB_LOG_025;
+                    } else if (gc == 'S' || rc == 'S') {
+                        ls = lu = log_pos(qs / 3.0);
+                    } else if (gc == '-' || rc == '-') {
+                        ls = lu = SB_LOG_002;
+                    } else {
+                        const int gi = acgt5(gc);
+                        double p = 0.0;
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) p += (o == gi ? 1.0 - qs : qs / 3.0) * rowsum[o];
+                        ls = log_pos(p);
+                        ls = ls > SB_LOG_CLAMP ? SB_LOG_CLAMP : ls; // :349-351
+                        const uint32_t ab = (uint32_t)(bo < 0 ? -bo : bo);
+                        lu = (ab % (uint32_t)g.penalty == 0u) ? log_pos(1.0 - qs) : log_pos(qs / 3.0); // :473-512
+                        const int j = gi * 5 + acgt5(rc);
+#pragma unroll
+                        for (int jj = 0; jj < (int)SB_NCNT; ++jj) c25[jj] += (jj == j) ? 1 : 0;
+                    }
+                    sup += ls;
+                    uns += lu;
+                    if (rc != '-') bo += rev ? -1 : 1; // :515-519
+                }
+                SbSegLds &o = seg_s[wave][lane];
+                o.sup = sup;
+                o.uns = uns;
+                o.node = node;
+#pragma unroll
+                for (int j = 0; j < (int)SB_NCNT; ++j) o.cnt[j] = c25[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- (B) one lane per path (PP paths per lane)
+            const uint32_t nseg = min(64u, s1 - sb);
+            for (uint32_t m = 0; m < nseg; ++m) {
+                const SbSegLds &sg = seg_s[wave][m];
+                const uint32_t node = sg.node;
+#pragma unroll
+                for (int u = 0; u < PP; ++u) {
+                    const uint32_t p = u * 64 + lane;
+                    bool sup = false;
+                    if (p < g.n_paths && node != 0u && node < g.rows)
+                        sup = ((g.mask[(size_t)node * g.mask_words + (p >> 6)] >> (p & 63)) & 1ull) && g.findable[p];
+                    pm[u] += sup ? sg.sup : sg.uns;
+                    if (sup) {
+#pragma unroll
+                        for (int j = 0; j < (int)SB_NCNT; ++j) cnt[u][j] += sg.cnt[j];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+        bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) {
+            t.ok[r] = bad ? 0 : 1;
+            if (bad) atomicAdd(n_bad, 1ull);
+        }
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const uint32_t p = u * 64 + lane;
+            if (p < g.n_paths) {
+                t.pm[(size_t)p * R + r] = pm[u];
+#pragma unroll
+                for (int j = 0; j < (int)SB_NCNT; ++j) t.cnt[((size_t)p * SB_NCNT + j) * R + r] = (uint16_t)min(cnt[u][j], 65535u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- HKY tables
+// hky[e][which][ref*5+read]: which = 0 child (t2), 1 parent (t1); MCMC.h:111-296 minus the "+ detail.logLikelihood"
+__global__ void sb_hky_kernel(uint32_t n_entries, const SbSourceDev *__restrict__ src, double con,
+                              const double *__restrict__ freqs7, double *__restrict__ hky) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries * 2 * SB_NCNT) return;
+    const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
+    const int ref = j / 5, rd = j % 5;
+    const double t = which ? src[e].t1 : src[e].t2;
+    const double fR = freqs7[4], fY = freqs7[5], mu = freqs7[6];
+    const double kappa = 0.0; // 1/22 in integer arithmetic (MCMC.h:66)
+    double P[4];
+    for (int bpo = 0; bpo < 4; ++bpo) {
+        const double f = freqs7[bpo];
+        const bool pur = bpo == 0 || bpo == 2; // A, G
+        const double grp = pur ? fR : fY;
+        const double Aexp = 1 + grp * (kappa - 1);
+        double v;
+        if (bpo == ref) {
+            const double jut1 = f + f * ((1 / grp) - 1) * exp(-(mu * t));
+            const double jut11 = ((grp - f) / grp) * exp(-(mu * t * Aexp));
+            v = jut1 + jut11;
+        } else if (ref < 4 && (bpo ^ ref) == 2) { // transition partner: A<->G, C<->T
+            const double jut1 = f + f * ((1 / grp) - 1) * exp(-(mu * t));
+            const double jut11 = (f / grp) * exp(-(mu * t * Aexp));
+            v = jut1 > jut11 ? jut1 - jut11 : jut11 - jut1;
+        } else {
+            v = f * (1 - exp(-(mu * t)));
+        }
+        P[bpo] = v < 1e-8 ? 1e-8 : v; // NaN stays NaN and trips the guard downstream
+    }
+    // log-sum-exp over the four post-mutation bases of log P_b + log(b == read ? 1 - con : con/3), folded as the reference does
+    double acc = -INFINITY;
+    for (int bpd = 0; bpd < 4; ++bpd) {
+        const double y = log(P[bpd]) + (bpd == rd ? log(1 - con) : log(con / 3));
+        if (acc == 0.0) acc = y; // oplusInitnatl
+        else if (acc == -INFINITY) acc = y;
+        else acc = fmax(acc, y) + log1p(exp(-fabs(acc - y)));
+    }
+    if (acc > 1e-8) acc = log(0.999999999);
+    hky[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- refresh
+constexpr int SBL_THREADS = 256;
+
+__global__ __launch_bounds__(SBL_THREADS) void sb_loglike_kernel(SbTablesDev t, uint32_t n_states, uint32_t k,
+                                                                  const SbSourceDev *__restrict__ src,
+                                                                  const double *__restrict__ hky, double *__restrict__ partial,
+                                                                  unsigned long long *__restrict__ guard) {
+    extern __shared__ double hk_s[]; // [n_states*k][2][25]
+    __shared__ double red_s[SBL_THREADS / 64];
+    const uint32_t n_tab = n_states * k * 2 * SB_NCNT;
+    for (uint32_t i = threadIdx.x; i < n_tab; i += SBL_THREADS) hk_s[i] = hky[i];
+    __syncthreads();
+    const uint32_t R = t.n_reads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t e = 0; e < n_states; ++e) {
+        double sum = 0.0;
+        unsigned long long bad = 0;
+        for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
+            if (!t.ok[r]) continue;
+            double inter = -INFINITY;
+            for (uint32_t y = 0; y < k; ++y) {
+                const SbSourceDev s = src[e * k + y];
+                const double *hc = hk_s + (size_t)(e * k + y) * 2 * SB_NCNT, *hp = hc + SB_NCNT;
+                double LL = t.pm[(size_t)s.child * R + r], LLP = t.pm[(size_t)s.parent * R + r];
+                const uint16_t *cc = t.cnt + (size_t)s.child * SB_NCNT * R + r;
+                const uint16_t *cp = t.cnt + (size_t)s.parent * SB_NCNT * R + r;
+#pragma unroll
+                for (int j = 0; j < (int)SB_NCNT; ++j) {
+                    LL += (double)cc[(size_t)j * R] * hc[j];
+                    LLP += (double)cp[(size_t)j * R] * hp[j];
+                }
+                if (!(LL <= 0.0) || !(LLP <= 0.0) || isinf(LL) || isinf(LLP)) bad++; // MCMC.cpp:857-862,953-958
+                if (k == 1) { // calculateLogWeightedAverage (MCMC.h:299-315)
+                    const double a = LL + s.log_pos, bb = LLP + s.log_1mpos;
+                    const double mx = fmax(a, bb);
+                    const double lse = mx + log(exp(a - mx) + exp(bb - mx));
+                    const double lws = log(s.pos + (1 - s.pos));
+                    inter = isinf(lws) ? -INFINITY : lse - lws;
+                } else { // :967-974
+                    const double a = s.log_pos + LL, bb = s.log_1mpos + LLP;
+                    const double inter2 = fmax(a, bb) + log1p(exp(-fabs(a - bb)));
+                    const double yv = inter2 + s.log_theta;
+                    if (inter == 0.0 || inter == -INFINITY) inter = yv;
+                    else inter = fmax(inter, yv) + log1p(exp(-fabs(inter - yv)));
+                }
+            }
+            sum += inter;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) red_s[wave] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s2 = 0.0;
+            for (int w = 0; w < SBL_THREADS / 64; ++w) s2 += red_s[w];
+            partial[(size_t)e * gridDim.x + blockIdx.x] = s2;
+        }
+        if (bad) atomicAdd(&guard[e], bad);
+        __syncthreads();
+    }
+}
+
+__global__ void sb_finish_kernel(const double *__restrict__ partial, uint32_t n_blocks, uint32_t n_states, double *__restrict__ out) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_states) return;
+    double s = 0.0;
+    for (uint32_t i = 0; i < n_blocks; ++i) s += partial[(size_t)e * n_blocks + i]; // fixed order: reproducible
+    out[e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, unsigned long long *n_bad,
+                          hipStream_t st) {
+    if (b.n_reads == 0) return;
+    const uint32_t blocks = min((b.n_reads + SBP_WAVES - 1) / SBP_WAVES, 256u * 8u);
+    const uint32_t pp = (g.n_paths + 63) / 64;
+    if (pp <= 1) hipLaunchKernelGGL(sb_precompute_kernel<1>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
+    else if (pp == 2) hipLaunchKernelGGL(sb_precompute_kernel<2>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
+    else if (pp == 3) hipLaunchKernelGGL(sb_precompute_kernel<3>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
+    else hipLaunchKernelGGL(sb_precompute_kernel<4>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
+}
+
+void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky, hipStream_t st) {
+    const uint32_t n = n_entries * 2 * SB_NCNT;
+    hipLaunchKernelGGL(sb_hky_kernel, dim3((n + 127) / 128), dim3(128), 0, st, n_entries, src, con, freqs7, hky);
+}
+
+void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states, uint32_t k, const SbSourceDev *src,
+                       const double *hky, double *partial, uint32_t n_blocks, double *out, unsigned long long *guard,
+                       hipStream_t st) {
+    (void)n_paths;
+    const size_t lds = (size_t)n_states * k * 2 * SB_NCNT * sizeof(double);
+    hipLaunchKernelGGL(sb_loglike_kernel, dim3(n_blocks), dim3(SBL_THREADS), lds, st, t, n_states, k, src, hky, partial, guard);
+    hipLaunchKernelGGL(sb_finish_kernel, dim3((n_states + 63) / 64), dim3(64), 0, st, partial, n_blocks, n_states, out);
+}
+
+} // namespace vgan

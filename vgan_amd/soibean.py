@@ -1,0 +1,96 @@
+"""Python plumbing around the soibean C-ABI (include/vgan_gpu.h): analyse_GAM's factorised tables on the device and
+the per-iteration likelihood refresh of MCMC::run_tree_proportion.  No arithmetic here."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .haplocart import _np_view
+
+_SB_FIELDS = (("read_seg_off", np.uint32, "R1"), ("read_col_off", np.uint32, "R1"), ("read_qual_off", np.uint32, "R1"),
+              ("read_gseq_len", np.uint16, "R"), ("read_rseq_len", np.uint16, "R"), ("read_rev", np.uint8, "R"),
+              ("read_src", np.uint32, "R"), ("seg_node", np.uint32, "S"), ("seg_col", np.uint16, "S"),
+              ("seg_len", np.uint16, "S"), ("seg_base_ix", np.uint16, "S"), ("graph_seq", np.uint8, "C"),
+              ("read_seq", np.uint8, "C"), ("qual", np.uint8, "Q"))
+
+
+class SbHostBatch:
+    def __init__(self, graph, alns, r0=0, r1=None, n_threads=0):
+        r1 = alns.n_reads if r1 is None else r1
+        self._h = N.vp()
+        self.stats = N.SbFlattenStats()
+        N.check(N.lib().vgan_sb_flatten(graph._h, alns._h, r0, r1, n_threads, C.byref(self._h), C.byref(self.stats)))
+        self.c = N.SbBatch()
+        N.check(N.lib().vgan_sb_host_batch_get(self._h, C.byref(self.c)))
+        self.n_reads, self.n_segments = self.c.n_reads, self.c.n_segments
+
+    def arrays(self):
+        c = self.c
+        n = {"R1": c.n_reads + 1, "R": c.n_reads, "S": c.n_segments, "C": c.n_cols, "Q": c.n_qual}
+        out = {name: _np_view(getattr(c, name), n[k], dt) for name, dt, k in _SB_FIELDS}
+        out["_owner"] = self
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_sb_host_batch_free(self._h)
+            self._h = None
+
+
+class SbContext:
+    def __init__(self, graph, damage, penalty=7, device=0):
+        self.graph, self.damage = graph, damage
+        self.n_paths = graph.n_paths
+        self._h = N.vp()
+        p = N.SbParams(penalty, 0)
+        N.check(N.lib().vgan_sb_create(C.byref(graph.view), C.byref(damage.view), C.byref(p), device, C.byref(self._h)))
+        self.device = device
+        self.n_reads = 0
+
+    def use_torch_stream(self):
+        import torch
+        N.check(N.lib().vgan_sb_set_stream(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+
+    def precompute(self, batch):
+        bad = C.c_int64(0)
+        N.check(N.lib().vgan_sb_precompute(self._h, C.byref(batch.c), C.byref(bad)))
+        self.n_reads = batch.n_reads
+        return bad.value
+
+    def read_tables(self, r0=0, r1=None):
+        r1 = self.n_reads if r1 is None else r1
+        n = r1 - r0
+        pm = np.zeros((self.n_paths, n))
+        cnt = np.zeros((self.n_paths, 25, n), np.uint16)
+        ok = np.zeros(n, np.uint8)
+        N.check(N.lib().vgan_sb_read_tables(self._h, r0, r1, pm.ctypes.data, cnt.ctypes.data, ok.ctypes.data))
+        return pm, cnt, ok
+
+    def loglike(self, states, con, freqs7, device_out=None):
+        """states: list of lists of (child, parent, dist, pos, theta); returns (logLike[n_states], guard[n_states])."""
+        k = len(states[0])
+        assert all(len(s) == k for s in states)
+        arr = (N.SbSource * (len(states) * k))()
+        for e, st in enumerate(states):
+            for y, (c, p, d, pos, th) in enumerate(st):
+                arr[e * k + y] = N.SbSource(c, p, d, pos, th)
+        f = np.ascontiguousarray(freqs7, np.float64)
+        out = np.zeros(len(states))
+        guard = np.zeros(len(states), np.uint64)
+        N.check(N.lib().vgan_sb_loglike(self._h, len(states), k, arr, con, f.ctypes.data, out.ctypes.data,
+                                        device_out.data_ptr() if device_out is not None else None, guard.ctypes.data))
+        return out, guard
+
+    def kernel_ms(self):
+        ms = np.zeros(2)
+        n = np.zeros(2, np.uint64)
+        N.check(N.lib().vgan_sb_kernel_ms(self._h, ms.ctypes.data, n.ctypes.data))
+        return {"precompute": (float(ms[0]), int(n[0])), "refresh": (float(ms[1]), int(n[1]))}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_sb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
