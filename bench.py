@@ -37,8 +37,8 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x76676131)
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-read-mode kernel measurement")
-    ap.add_argument("--path", choices=["haplocart", "euka"], default="haplocart",
-                    help="haplocart = the BASELINE metric; euka = the euka per-read kernel (config 4 shape, extra line)")
+    ap.add_argument("--path", choices=["haplocart", "euka", "soibean"], default="haplocart",
+                    help="haplocart = the BASELINE metric; euka / soibean = configs 4 / 5 as extra lines")
     return ap.parse_args()
 
 
@@ -119,10 +119,91 @@ def bench_euka(args):
               flush=True)
 
 
+def bench_soibean(args):
+    """BASELINE config 5 shape: k = 3 sources, synthetic reads against a 28-path tree; a host Metropolis loop proposes
+    branch positions / proportions and the GPU refreshes the likelihood every iteration (one step = one iteration)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vgan_amd import distributed as vd
+    from vgan_amd import euka as ek
+    from vgan_amd import haplocart as hc
+    from vgan_amd import soibean as sb
+    rank, world, local_rank = vd.env_rank()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    vd.init(backend="nccl", device=dev)
+    g = hc.synth_graph(seed=args.seed, genome_len=16569, n_nodes=11000, n_paths=28)
+    alns = hc.synth_reads(g, args.reads, seed=args.seed + 1000003 * rank, read_len=65, indel_rate=0.005, softclip_rate=0.01)
+    dm = ek.Damage.from_text("", "")
+    hb = sb.SbHostBatch(g, alns)
+    ctx = sb.SbContext(g, dm, device=local_rank)
+    ctx.use_torch_stream()
+    t0 = time.perf_counter()
+    ctx.precompute(hb)
+    t_pre = time.perf_counter() - t0
+    names = g.path_names
+    idx = {n: i for i, n in enumerate(names)}
+    pairs = [(idx[t[0]], idx[t[1]]) for t in (ln.split() for ln in g.parents_txt.splitlines()) if len(t) >= 2]
+    freqs = [0.31, 0.27, 0.13, 0.29, 0.44, 0.56, 0.0012]
+    rng = np.random.default_rng(args.seed)  # same proposal sequence on every rank
+    d_out = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def state():
+        src = []
+        th = rng.dirichlet([1, 1, 1])
+        for y in range(3):
+            c, p = pairs[rng.integers(len(pairs))]
+            src.append((c, p, 0.01 + 0.05 * rng.random(), rng.random() * 0.98 + 0.01, float(th[y])))
+        return [src]
+
+    cur = None
+    accepted = 0
+
+    def iteration():
+        nonlocal cur, accepted
+        st = state()
+        ctx.loglike(st, 0.01, freqs, device_out=d_out)
+        if world > 1:
+            dist.all_reduce(d_out, op=dist.ReduceOp.SUM)  # one scalar per iteration over RCCL
+        ll = float(d_out.item())
+        if cur is None or np.log(rng.random()) < ll - cur:
+            cur = ll
+            accepted += 1
+
+    for _ in range(args.warmup):
+        iteration()
+    torch.cuda.synchronize()
+    ctx.kernel_ms()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    km = ctx.kernel_ms()
+    if rank == 0:
+        R = hb.n_reads
+        avg = km["refresh"][0] / max(km["refresh"][1], 1)
+        kb = R * 3 * 2 * (8 + 25 * 2) + R  # 2k path rows of pm (8 B) + cnt (25 x 2 B) + ok flags
+        gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        print(json.dumps({
+            "metric": "read-iterations/sec through the soibean MCMC likelihood refresh (k=3)", "value": R * world * args.steps / elapsed,
+            "unit": "reads*iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "soibean k=3, %d synthetic reads per GPU, 28-path tree, host Metropolis loop + GPU refresh per iteration" % args.reads,
+                       "reads_per_gpu": R, "precompute_s": t_pre, "accepted": accepted},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "sb_loglike_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
+                         "launches": km["refresh"][1]}}), flush=True)
+
+
 def main():
     args = parse()
     if args.path == "euka":
         return bench_euka(args)
+    if args.path == "soibean":
+        return bench_soibean(args)
     import numpy as np
     import torch
     import torch.distributed as dist
