@@ -308,6 +308,18 @@ def main():
             kname, kbytes = "sweep_segments", n_seg * (8 * ((graph.n_paths + 63) // 64) + 4 + 8)
         k_ms, k_n = prof[kname]
         avg_ms = k_ms / max(k_n, 1)
+        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected
+        # in separate runs of this very command, profiles/round1_v2_*_pmc.json); null when no such pass is committed.
+        traffic = None
+        try:
+            tag = {"node_weights": "node", "per_read": "skip", "per_read_dense": "dense"}[args.mode]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_v2_%s_pmc.json" % tag)))
+            want = "hc_segment_tile_kernel" if kname == "segment" else "hc_sweep_kernel<10, false>"
+            for kn, v in pmc.items():
+                if want in kn and args.reads == 1_000_000 and args.read_len == 150:
+                    traffic = v["fetch_bytes"] + v["write_bytes"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         achieved = kbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "reads/sec (whole node) through HaploCart posterior path, 150bp",
@@ -327,8 +339,8 @@ def main():
                        "reads_per_gpu": n_reads, "segments_per_read": n_seg / max(n_reads, 1), "mode": args.mode,
                        "sharding": "reads x%d, RCCL reduce of final_vec[5179]" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": {"segment": "hc_segment_kernel", "sweep_segments": "hc_sweep_kernel"}[kname],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": {"segment": "hc_segment_tile_kernel", "sweep_segments": "hc_sweep_kernel"}[kname],
                          "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": avg_ms, "launches": k_n},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "parity": parity,

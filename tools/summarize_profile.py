@@ -25,7 +25,7 @@ if bench:
               "bench.py line under the profiler: value = %.4g %s, ms_per_step = %.4f" % (bench["value"], bench["unit"], bench["ms_per_step"]),
               "roofline (HIP events in bench.py): %s avg %.4f ms/launch, %.1f GB/s algorithmic = %.4f of 8 TB/s" % (
                   bench["roofline"]["kernel"], bench["roofline"]["avg_launch_ms"], bench["roofline"]["achieved"], bench["roofline"]["frac"]), ""]
-ks = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if ks:
     shutil.copy(ks[0], os.path.join(dst, name + "_kernel_stats.csv"))
     lines += ["## rocprofv3 --kernel-trace --stats", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
@@ -35,7 +35,7 @@ if ks:
     lines.append("")
 pm = {}
 for kind in ("fetch", "write"):
-    f = glob.glob(os.path.join(src, "pmc_" + kind, "*", "*counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, "pmc_" + kind, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not f:
         continue
     agg = collections.defaultdict(list)
@@ -50,11 +50,15 @@ if pm:
               "Infinity-Cache hits are counted.", "",
               "| kernel | FETCH_SIZE mean KB (n, max) | WRITE_SIZE mean KB (n, max) |", "|---|---|---|"]
     for k, d in pm.items():
-        if not k.startswith("vgan::"):
+        if "vgan::" not in k:
             continue
         f = d.get("FETCH_SIZE", (0, 0, 0))
         w = d.get("WRITE_SIZE", (0, 0, 0))
         lines.append("| `%s` | %.1f (%d, %.1f) | %.1f (%d, %.1f) |" % (k, f[1], f[0], f[2], w[1], w[0], w[2]))
     lines.append("")
 open(os.path.join(dst, name + ".md"), "w").write("\n".join(lines) + "\n")
+# machine-readable PMC figures for bench.py's roofline.traffic (bytes per dispatch = (FETCH_SIZE + WRITE_SIZE) * 1024, uncorrected)
+traffic = {k: {"fetch_bytes": d.get("FETCH_SIZE", (0, 0, 0))[2] * 1024, "write_bytes": d.get("WRITE_SIZE", (0, 0, 0))[2] * 1024}
+           for k, d in pm.items() if "vgan::" in k}
+json.dump(traffic, open(os.path.join(dst, name + "_pmc.json"), "w"), indent=1)
 print("\n".join(lines))
