@@ -147,14 +147,13 @@ constexpr int ST_QUAL = 1280; //                        quality bytes,
 constexpr int ST_SEGS = 512;  //                        segments
 constexpr int ST_MAXQ = HC_TILE_MAX_READ_QUAL;
 
-struct alignas(16) StHdr {
-    uint32_t colbase; // first column of the read, local to the tile
-    uint32_t A, QL;
-    uint32_t qoff;    // first quality byte of the read, local to the tile
-};
 struct alignas(16) StSeg {
-    double pcm;   // (1 - incorrect_mapping_vec[mapq]) * mappability[node]   (process_mapping.cpp:41)
-    double match; // pow(1 - mu(node), 8)                                     (get_p_obs_base.cpp:64)
+    double pcm;      // (1 - incorrect_mapping_vec[mapq]) * mappability[node]   (process_mapping.cpp:41)
+    double match;    // pow(1 - mu(node), 8)                                     (get_p_obs_base.cpp:64)
+    uint32_t cstart; // tile-local column of the segment's first base
+    uint32_t rbase;  // tile-local column of the read's first base (Q4: read bases are taken from the read start)
+    uint32_t A;      // |algnseq| of the read
+    uint32_t use_bep;
 };
 
 // Copies bytes [g0, g0+n) of src into dst (LDS) as aligned dwords; dst[i + (g0 & 3)] = src[g0 + i].
@@ -174,8 +173,6 @@ __device__ __forceinline__ void stage_bytes(uint8_t *dst, const uint8_t *__restr
 
 __global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
                                                                       uint32_t reads_per_block,
-                                                                      double *__restrict__ segS_out,
-                                                                      double *__restrict__ segU_out,
                                                                       double *__restrict__ segD_out,
                                                                       double *__restrict__ totals) {
     __shared__ double lq_s[256];
@@ -183,22 +180,20 @@ __global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev 
     __shared__ double bg_s[4];
     __shared__ double ps_s[ST_WAVES][ST_MAXQ + 1];
     __shared__ double segS_s[ST_SEGS];
-    __shared__ double segU_s[ST_SEGS];
     __shared__ StSeg segpm_s[ST_SEGS];
-    __shared__ uint16_t segmeta_s[ST_SEGS]; // start | read << 9 | use_bep << 12
     __shared__ uint16_t colseg_s[ST_COLS];
+    __shared__ __attribute__((aligned(16))) uint8_t qcol_s[ST_COLS + 8]; // clamped quality per tile column (0 past the read's qualities)
     __shared__ __attribute__((aligned(16))) uint8_t gseq_s[ST_COLS + 8];
     __shared__ __attribute__((aligned(16))) uint8_t rseq_s[ST_COLS + 8];
     __shared__ __attribute__((aligned(16))) uint8_t qual_s[ST_QUAL + 8];
     __shared__ uint32_t off_s[3][ST_READS + 1];
-    __shared__ StHdr hdr_s[ST_READS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 256; i += ST_THREADS) lq_s[i] = g.lq[i];
     for (int i = tid; i < 100; i += ST_THREADS) qs_s[i] = g.qscore[i];
     if (tid < 4) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : 0.16644; // A C T G by (c>>1)&3
     const double lq0 = g.lq[0];
-    double sumS = 0.0, sumU = 0.0;
+    double sumT = 0.0, sumU = 0.0; // sum of the column terms (= sum of S_m) and of U_m, each without cancellation
 
     const uint32_t rb0 = blockIdx.x * reads_per_block;
     const uint32_t rb1 = min(b.n_reads, rb0 + reads_per_block);
@@ -225,11 +220,13 @@ __global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev 
         stage_bytes(qual_s, b.qual, q_base, n_q, tid);
         {
             uint32_t *cs32 = reinterpret_cast<uint32_t *>(colseg_s);
-            const uint32_t nc2 = (n_col + 1) >> 1;
+            uint32_t *qc32 = reinterpret_cast<uint32_t *>(qcol_s);
+            const uint32_t nc2 = (n_col + 1) >> 1, nc4 = (n_col + 3) >> 2;
 #pragma unroll
             for (int it = 0; it < (ST_COLS / 2 + ST_THREADS - 1) / ST_THREADS; ++it) {
                 const uint32_t i = tid + it * ST_THREADS;
                 if (i < nc2) cs32[i] = 0xFFFFFFFFu;
+                if (i < nc4) qc32[i] = 0u;
             }
         }
         __syncthreads();
@@ -240,6 +237,7 @@ __global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev 
             const uint32_t qoff = off_s[2][k] - q_base, QL = off_s[2][k + 1] - off_s[2][k];
             const uint32_t A = b.read_algn_len[r];
             const uint32_t colbase = off_s[1][k] - col_base;
+            const uint32_t ncols_k = off_s[1][k + 1] - off_s[1][k];
             const double pinc = g.incmap[b.read_mapq[r]];
             double *ps = ps_s[wave];
             // prefix sums of log p_err over the read's quality bytes: each lane owns E consecutive bytes
@@ -255,6 +253,10 @@ __global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev 
                 const bool in = e < E && j < QL;
                 const uint32_t qb = in ? qual_s[qoff + qshift + j] : 0u;
                 if (in && (int)(int8_t)qb >= 90) hot = min(hot, j);
+                if (in && j < ncols_k) { // quality by alignment column for phase 2, clamped as qscore_vec's index
+                    const int qi = (int)(int8_t)qb;
+                    qcol_s[colbase + j] = (uint8_t)(qi < 0 ? 0 : (qi > 99 ? 99 : qi));
+                }
                 tot += in ? lq_s[qb] : 0.0;
                 loc[e] = tot;
             }
@@ -267,10 +269,7 @@ __global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev 
             const uint64_t hot_lanes = __builtin_amdgcn_ballot_w64(hot != 0xFFFFFFFFu);
             const uint32_t first90 =
                 hot_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)hot, (int)__builtin_ctzll(hot_lanes)) : 0xFFFFFFFFu;
-            if (lane == 0) {
-                ps[0] = 0.0;
-                hdr_s[k] = StHdr{colbase, A, QL, qoff};
-            }
+            if (lane == 0) ps[0] = 0.0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t s0 = off_s[0][k], s1 = off_s[0][k + 1];
@@ -281,11 +280,11 @@ __global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev 
                     const uint32_t start = b.seg_start[s], len = b.seg_len[s];
                     const HcNodeDev nd = g.node_tab[b.seg_node[s]];
                     const uint32_t lo = min(start, QL), hi = min(start + A, QL);
-                    segU_s[ls] = (ps[hi] - ps[lo]) + (double)(A - (hi - lo)) * lq0; // Q5 zero padding
-                    segS_s[ls] = 0.0;
-                    segpm_s[ls] = StSeg{(1.0 - pinc) * nd.mappability, nd.match};
+                    const double U = (ps[hi] - ps[lo]) + (double)(A - (hi - lo)) * lq0; // Q5 zero padding
+                    segS_s[ls] = -U; // phase 2 adds the column terms: the slot ends as D_m = S_m - U_m
+                    sumU += U;
                     const uint32_t use_bep = (prm.use_bep || first90 < hi) ? 1u : 0u; // update_likelihood.cpp:42
-                    segmeta_s[ls] = (uint16_t)(start | (k << 9) | (use_bep << 12));
+                    segpm_s[ls] = StSeg{(1.0 - pinc) * nd.mappability, nd.match, colbase + start, colbase, A, use_bep};
                     const uint32_t cend = min(colbase + start + len, n_col);
                     for (uint32_t c = colbase + start; c < cend; ++c) colseg_s[c] = (uint16_t)ls;
                 }
@@ -294,48 +293,43 @@ __global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev 
         }
         __syncthreads();
 
-        // ---- phase 2: one lane per alignment column, flat over the tile; everything comes from LDS
+        // ---- phase 2: one lane per alignment column, flat over the tile; everything comes from LDS.
+        // Loads are issued up front and the arithmetic is unconditional (no early exits): the dependency chain is
+        // column -> {segment id, graph base, quality} -> segment record -> read base.
         for (uint32_t c = tid; c < n_col; c += ST_THREADS) {
-            const uint32_t ls = colseg_s[c];
-            if (ls == 0xFFFFu) continue; // column not scored by any mapping (Q6 tail)
-            const uint32_t meta = segmeta_s[ls];
-            const uint32_t start = meta & 511u;
-            const StHdr h = hdr_s[(meta >> 9) & 7u];
-            const uint32_t j = c - h.colbase - start;
+            const uint32_t ls_raw = colseg_s[c];
             const uint32_t gc = gseq_s[c + cshift];
-            uint32_t rc = rseq_s[min(h.colbase + j, n_col - 1) + cshift]; // Q4: read bases from the read start
-            rc = j < h.A ? rc : 0u;
-            const uint32_t qi = start + j;
-            int q = (int)(int8_t)qual_s[h.qoff + min(qi, h.QL - (h.QL > 0)) + qshift];
-            q = qi < h.QL ? q : 0; // Q5
-            q = q < 0 ? 0 : (q > 99 ? 99 : q);
-            if (!is_acgt(gc) || !is_acgt(rc)) continue; // process_mapping.cpp:62-63
-            const StSeg pm = segpm_s[ls];
-            const double e = ((meta >> 12) & 1u) ? prm.bep : qs_s[q];
-            const double eps = gc == rc ? e : 1.0 - e;           // get_p_obs_base.cpp:3-27
-            const double pobs = pm.match * (1.0 - eps);          // get_p_obs_base.cpp:67 with tv = ts = 0
-            const double x = prm.consensus ? (1.0 - prm.bep) * pobs : (1.0 - pm.pcm) * bg_s[(rc >> 1) & 3u] + pm.pcm * pobs;
-            unsafeAtomicAdd(&segS_s[ls], log_pos(x));
+            const uint32_t q = qcol_s[c];
+            const bool in_seg = ls_raw != 0xFFFFu; // columns no mapping scores (Q6 tail) carry 0xFFFF
+            const uint32_t ls = in_seg ? ls_raw : 0u;
+            const StSeg sg = segpm_s[ls];
+            const double qsv = qs_s[q];
+            const uint32_t j = c - sg.cstart;
+            uint32_t rc = rseq_s[min(sg.rbase + j, n_col - 1) + cshift]; // Q4: read bases from the read start
+            rc = j < sg.A ? rc : 0u;
+            const bool valid = in_seg && is_acgt(gc) && is_acgt(rc); // process_mapping.cpp:62-63
+            const double e = sg.use_bep ? prm.bep : qsv;
+            const double eps = gc == rc ? e : 1.0 - e;          // get_p_obs_base.cpp:3-27
+            const double pobs = sg.match * (1.0 - eps);         // get_p_obs_base.cpp:67 with tv = ts = 0
+            const double bgv = bg_s[(rc >> 1) & 3u];
+            const double x = prm.consensus ? (1.0 - prm.bep) * pobs : (1.0 - sg.pcm) * bgv + sg.pcm * pobs;
+            const double t = log_pos(valid ? x : 1.0); // log(1) = 0 for the lanes that do not count
+            sumT += t;
+            if (valid) unsafeAtomicAdd(&segS_s[ls], t);
         }
         __syncthreads();
 
         // ---- phase 3: one lane per segment
         for (uint32_t ls = tid; ls < n_seg; ls += ST_THREADS) {
-            const double S = segS_s[ls], U = segU_s[ls];
-            const uint32_t s = seg_base + ls;
-            if (segS_out) segS_out[s] = S;
-            if (segU_out) segU_out[s] = U;
-            if (segD_out) segD_out[s] = S - U;
-            sumS += S;
-            sumU += U;
+            if (segD_out) segD_out[seg_base + ls] = segS_s[ls];
         }
         r0 += n;
         // the next tile's barriers order phase 3 against the next phase 1 (phase 3 touches segS/segU only)
     }
-    sumS = wave_sum(sumS);
+    sumT = wave_sum(sumT);
     sumU = wave_sum(sumU);
     if (lane == 0 && totals) {
-        unsafeAtomicAdd(&totals[0], sumS);
+        unsafeAtomicAdd(&totals[0], sumT);
         unsafeAtomicAdd(&totals[1], sumU);
     }
 }
@@ -571,14 +565,13 @@ __global__ __launch_bounds__(256) void hc_posterior_kernel(const double *__restr
 void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, bool tiled, double *segS,
                         double *segU, double *segD, double *totals, hipStream_t st) {
     if (b.n_reads == 0) return;
-    if (tiled) {
+    if (tiled && !segS && !segU) { // the tiled kernel produces D_m only; separate S_m / U_m (debug API) come from the general one
         // ~6 resident workgroups per CU; contiguous read ranges per workgroup
         const uint32_t want_blocks = 256u * 6u * 2u;
         uint32_t per = (b.n_reads + want_blocks - 1) / want_blocks;
         per = std::max(per, (uint32_t)ST_READS);
         const uint32_t blocks = (b.n_reads + per - 1) / per;
-        hipLaunchKernelGGL(hc_segment_tile_kernel, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, per, segS, segU, segD,
-                           totals);
+        hipLaunchKernelGGL(hc_segment_tile_kernel, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, per, segD, totals);
     } else {
         const uint32_t blocks =
             (uint32_t)std::min<uint64_t>(((uint64_t)b.n_reads + SEG_WAVES - 1) / SEG_WAVES, 256u * 8u);
