@@ -15,13 +15,20 @@ __device__ __forceinline__ double bg_freq(uint32_t c) { // src/haplocart_functio
     return c == 'A' ? 0.27532 : c == 'C' ? 0.30044 : c == 'G' ? 0.16644 : c == 'T' ? 0.25780 : 0.25;
 }
 
-// Natural log of a positive normal double, fdlibm e_log.c scheme (error < 1 ulp): x = 2^k * m, m in
-// [sqrt(1/2), sqrt(2)), log(m) from the odd series in s = f/(2+f).  ~35 fp64 instructions instead of the
-// ~100 of the device library's double-double log; anything that is not a positive normal goes to log().
+// Natural log in fp64, fdlibm e_log.c scheme (error < 1 ulp): x = 2^k * m, m in [sqrt(1/2), sqrt(2)), log(m) from the
+// odd series in s = f/(2+f).  ~35 fp64 instructions instead of the ~100 of the device library's double-double log.
+// Special values as log(): 0 -> -inf, negative / NaN -> NaN, +inf -> +inf, subnormals are rescaled.
 __device__ __forceinline__ double log_pos(double x) {
-    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);
+    int kadj = 0;
+    if (!(x >= 2.2250738585072014e-308)) { // zero, subnormal, negative or NaN
+        if (x == 0.0) return -INFINITY;
+        if (!(x > 0.0)) return __builtin_nan("");
+        x *= 18014398509481984.0; // 2^54
+        kadj = -54;
+    }
+    if (!(x <= 1.7976931348623157e308)) return x; // +inf
     double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
-    int k = __builtin_amdgcn_frexp_exp(x);
+    int k = __builtin_amdgcn_frexp_exp(x) + kadj;
     const bool lo = m < 0.70710678118654752440;
     m = lo ? m + m : m;
     k = lo ? k - 1 : k;
@@ -31,7 +38,7 @@ __device__ __forceinline__ double log_pos(double x) {
     r = fma(fma(-den, r, 1.0), r, r);
     r = fma(fma(-den, r, 1.0), r, r);
     double sq = f * r;
-    sq = fma(fma(-den, sq, f), r, sq); // s = f / (2 + f), correctly rounded to within an ulp
+    sq = fma(fma(-den, sq, f), r, sq); // s = f / (2 + f) to within an ulp
     const double z = sq * sq, w = z * z;
     const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
     const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),

@@ -36,7 +36,7 @@ __device__ __forceinline__ double tT_ratio(int g, int b) { // Euka.cpp:453-468
 
 constexpr int EK_WAVES = 4;
 
-__global__ __launch_bounds__(EK_WAVES * 64) void euka_read_kernel(EukaDev d, EukaBatchDev b, EukaOutDev o) {
+__global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, EukaBatchDev b, EukaOutDev o) {
     __shared__ double qs_s[100];
     for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = d.qscore[i];
     __syncthreads();
@@ -89,18 +89,19 @@ __global__ __launch_bounds__(EK_WAVES * 64) void euka_read_kernel(EukaDev d, Euk
             int q = m < QL ? (int)(int8_t)b.qual[q0 + m] : 0; // Q15
             q = q < 0 ? 0 : (q > 99 ? 99 : q);
             const double qs = qs_s[q];
-            double l1 = 0.0, l2 = 0.0;
+            // model 1 = c1 + log(a1), model 2 = l2; the branches only pick a1 / c1 / l2 so that one log serves all of them
+            double a1 = 1.0, c1 = 0.0, l2 = 0.0;
             if (active) {
                 if (isN) { // :236-241
-                    l1 = l2 = base_freq_log(rc);
+                    c1 = l2 = base_freq_log(rc);
                 } else if (isgap) { // :244-249
-                    l1 = -6.214608098422191;  // log(0.002)
+                    c1 = -6.214608098422191;  // log(0.002)
                     l2 = -1.6094379124341003; // log(0.2)
                 } else if (israre) { // :252-257
-                    l1 = log_pos((1.0 - pair_dist) * 0.001);
+                    a1 = (1.0 - pair_dist) * 0.001;
                     l2 = -6.907755278982137; // log(0.001)
                 } else if (isS) { // :263-280
-                    l1 = (sc_index % 3u == 0u) ? log_pos(1.0 - qs) : log_pos(qs / 3.0);
+                    a1 = (sc_index % 3u == 0u) ? 1.0 - qs : qs / 3.0;
                     l2 = -1.3862943611198906; // log(0.25)
                 } else {
                     if (n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
@@ -108,23 +109,27 @@ __global__ __launch_bounds__(EK_WAVES * 64) void euka_read_kernel(EukaDev d, Euk
                     const uint32_t nn = min(n, Lseq - 1u);
                     const double *m5 = d.sub5p + 16u * min(nn, d.n5 - 1u);
                     const double *m3 = d.sub3p + 16u * min(Lseq - 1u - nn, d.n3 - 1u);
-                    double post[4] = {0.0, 0.0, 0.0, 0.0};
+                    // p = sum_bpd post[bpd] * w[bpd] with post = pre x M (:337-340, :385-394), accumulated row by row:
+                    // p = sum_bpo pre[bpo] * (M[bpo] . w), so only one matrix row is live at a time
+                    const double w_hit = 1.0 - qs, w_miss = qs / 3.0;
+                    double p = 0.0;
 #pragma unroll
                     for (int bpo = 0; bpo < 4; ++bpo) {
                         // :312-318; a graph base outside ACGT has no t_T_ratio entry (0)
                         const double pre = gi < 0 ? 0.0 : (bpo == gi ? 1.0 - pair_dist : pair_dist * tT_ratio(gi, bpo));
                         const double *row5 = m5 + 4 * bpo, *row3 = m3 + 4 * bpo;
                         const double *row = row5[bpo] <= row3[bpo] ? row5 : row3; // damage.cpp:18-36
-#pragma unroll
-                        for (int bpd = 0; bpd < 4; ++bpd) post[bpd] += pre * row[bpd]; // :337-340
+                        const double2 r01 = *reinterpret_cast<const double2 *>(row);
+                        const double2 r23 = *reinterpret_cast<const double2 *>(row + 2);
+                        const double dot = ((r01.x * (ri == 0 ? w_hit : w_miss) + r01.y * (ri == 1 ? w_hit : w_miss)) +
+                                            r23.x * (ri == 2 ? w_hit : w_miss)) + r23.y * (ri == 3 ? w_hit : w_miss);
+                        p += pre * dot;
                     }
-                    double p = 0.0;
-#pragma unroll
-                    for (int bpd = 0; bpd < 4; ++bpd) p += post[bpd] * (bpd == ri ? 1.0 - qs : qs / 3.0); // :385-394
-                    l1 = log_pos(p);
+                    a1 = p;
                     l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
                 }
             }
+            const double l1 = c1 + log_pos(a1); // log_pos(1) == 0 exactly
             lik += l1;
             lik2 += l2;
             carry_n += (uint32_t)__builtin_popcountll(nongap);
@@ -155,7 +160,9 @@ __global__ __launch_bounds__(EK_WAVES * 64) void euka_read_kernel(EukaDev d, Euk
             }
         }
         // clade_like / clade_not_like (:485-492)
-        const double map_q = (mapq >= 0 && mapq < 256) ? d.mapq_ok[mapq] : 1.0 - pow(10.0, (-1.0 * mapq) * 0.1);
+        // 1 - 10^(-mapq/10): table for 0..255; beyond it the subtrahend is below 1 ulp of 1 (negative mapq cannot be encoded
+        // by a well-formed GAM, it is evaluated with exp for completeness)
+        const double map_q = mapq >= 256 ? 1.0 : (mapq >= 0 ? d.mapq_ok[mapq] : 1.0 - exp(-0.1 * mapq * 2.302585092994046));
         double lse;
         if (in == 0.0) lse = out; // oplusInitnatl: a running value of 0 means "empty"
         else lse = fmax(in, out) + log1p(exp(-fabs(in - out)));

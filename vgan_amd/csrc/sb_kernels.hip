@@ -87,26 +87,31 @@ __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDe
                     int q = k < QL ? (int)(int8_t)b.qual[q0 + k] : 0; // Q12: within-segment index
                     q = q < 0 ? 0 : (q > 99 ? 99 : q);
                     const double qs = qs_s[q];
-                    double ls, lu;
+                    // supported term = cs + log(as) (clamped), unsupported term = cu + log(au): one log each
+                    double as = 1.0, au = 1.0, cs = 0.0;
+                    bool regular = false;
                     if (gc == 'N' || rc == 'N') {
-                        ls = lu = SB_LOG_025;
+                        cs = SB_LOG_025;
                     } else if (gc == 'S' || rc == 'S') {
-                        ls = lu = log_pos(qs / 3.0);
+                        as = au = qs / 3.0;
                     } else if (gc == '-' || rc == '-') {
-                        ls = lu = SB_LOG_002;
+                        cs = SB_LOG_002;
                     } else {
+                        regular = true;
                         const int gi = acgt5(gc);
                         double p = 0.0;
 #pragma unroll
                         for (int o = 0; o < 4; ++o) p += (o == gi ? 1.0 - qs : qs / 3.0) * rowsum[o];
-                        ls = log_pos(p);
-                        ls = ls > SB_LOG_CLAMP ? SB_LOG_CLAMP : ls; // :349-351
+                        as = p;
                         const uint32_t ab = (uint32_t)(bo < 0 ? -bo : bo);
-                        lu = (ab % (uint32_t)g.penalty == 0u) ? log_pos(1.0 - qs) : log_pos(qs / 3.0); // :473-512
+                        au = (ab % (uint32_t)g.penalty == 0u) ? 1.0 - qs : qs / 3.0; // :473-512
                         const int j = gi * 5 + acgt5(rc);
 #pragma unroll
                         for (int jj = 0; jj < (int)SB_NCNT; ++jj) c25[jj] += (jj == j) ? 1 : 0;
                     }
+                    double ls = cs + log_pos(as);
+                    const double lu = cs + log_pos(au);
+                    if (regular && ls > SB_LOG_CLAMP) ls = SB_LOG_CLAMP; // :349-351
                     sup += ls;
                     uns += lu;
                     if (rc != '-') bo += rev ? -1 : 1; // :515-519
