@@ -49,6 +49,7 @@ struct vgan_alnset;
 namespace vgan {
 // reconstruct_graph_sequence (reference src/vgan_utils.h:6-79); 0 or a code for reads the reference dies on
 int reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Recon &o);
+
 } // namespace vgan
 
 struct vgan_graph {
@@ -79,6 +80,10 @@ struct vgan_alnset {
     int64_t n_reads() const { return (int64_t)mapq.size(); }
     void fill_view(vgan_alnset_view *v) const;
 };
+
+namespace vgan {
+void merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &out); // parts are consumed
+}
 
 struct vgan_hc_host_batch {
     std::vector<uint32_t> read_seg_off{0}, read_col_off{0}, read_qual_off{0};

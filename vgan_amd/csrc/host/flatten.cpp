@@ -143,6 +143,21 @@ struct Chunk {
 void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, Chunk &c) {
     Recon rc;
     auto &b = c.b;
+    { // size the chunk's arrays from the input volume so that they grow at most once or twice
+        const size_t nr = (size_t)(r1 - r0), nm = (size_t)(a.map_off[r1] - a.map_off[r0]);
+        const size_t nb = (size_t)(a.seq_off[r1] - a.seq_off[r0]), nq = (size_t)(a.qual_off[r1] - a.qual_off[r0]);
+        b.read_seg_off.reserve(nr + 1);
+        b.read_col_off.reserve(nr + 1);
+        b.read_qual_off.reserve(nr + 1);
+        b.read_algn_len.reserve(nr);
+        b.read_mapq.reserve(nr);
+        b.seg_node.reserve(nm);
+        b.seg_start.reserve(nm);
+        b.seg_len.reserve(nm);
+        b.graph_seq.reserve(nb + nb / 16 + 64);
+        b.algnseq.reserve(nb + nb / 16 + 64);
+        b.qual.reserve(nq);
+    }
     for (int64_t r = r0; r < r1; ++r) {
         c.st.n_in++;
         if (a.identity[r] < 1e-10) {
@@ -235,35 +250,73 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
     for (auto &t : th) t.join();
     auto res = new vgan_hc_host_batch();
     vgan_hc_flatten_stats st{};
-    uint64_t tot_cols = 0, tot_segs = 0, tot_qual = 0;
-    for (auto &c : chunks) {
-        tot_cols += c.b.graph_seq.size();
-        tot_segs += c.b.seg_node.size();
-        tot_qual += c.b.qual.size();
+    uint64_t tot_cols = 0, tot_segs = 0, tot_qual = 0, tot_reads = 0;
+    struct Base {
+        size_t r, s, c, q;
+    };
+    std::vector<Base> base(chunks.size());
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        base[i] = {(size_t)tot_reads, (size_t)tot_segs, (size_t)tot_cols, (size_t)tot_qual};
+        tot_cols += chunks[i].b.graph_seq.size();
+        tot_segs += chunks[i].b.seg_node.size();
+        tot_qual += chunks[i].b.qual.size();
+        tot_reads += chunks[i].b.read_mapq.size();
     }
     if (tot_cols > 0xFFFFFFF0ull || tot_segs > 0xFFFFFFF0ull || tot_qual > 0xFFFFFFF0ull) {
         delete res;
         return fail(VGAN_ERANGE, "vgan_hc_flatten: batch exceeds 32-bit offsets; flatten fewer reads per batch");
     }
+    // one allocation per array, then every chunk is copied (offsets shifted) by its own thread
+    res->read_seg_off.resize(tot_reads + 1);
+    res->read_col_off.resize(tot_reads + 1);
+    res->read_qual_off.resize(tot_reads + 1);
+    res->read_algn_len.resize(tot_reads);
+    res->read_mapq.resize(tot_reads);
+    res->seg_node.resize(tot_segs);
+    res->seg_start.resize(tot_segs);
+    res->seg_len.resize(tot_segs);
+    res->graph_seq.resize(tot_cols);
+    res->algnseq.resize(tot_cols);
+    res->qual.resize(tot_qual);
+    res->read_seg_off[0] = res->read_col_off[0] = res->read_qual_off[0] = 0;
+    auto copy_chunk = [&](size_t i) {
+        auto &cb = chunks[i].b;
+        const Base &bs = base[i];
+        for (size_t k = 1; k < cb.read_seg_off.size(); ++k) {
+            res->read_seg_off[bs.r + k] = cb.read_seg_off[k] + (uint32_t)bs.s;
+            res->read_col_off[bs.r + k] = cb.read_col_off[k] + (uint32_t)bs.c;
+            res->read_qual_off[bs.r + k] = cb.read_qual_off[k] + (uint32_t)bs.q;
+        }
+        auto cp = [](auto &dst, size_t at, const auto &src) {
+            if (!src.empty()) memcpy(&dst[at], src.data(), src.size() * sizeof(src[0]));
+        };
+        cp(res->read_algn_len, bs.r, cb.read_algn_len);
+        cp(res->read_mapq, bs.r, cb.read_mapq);
+        cp(res->seg_node, bs.s, cb.seg_node);
+        cp(res->seg_start, bs.s, cb.seg_start);
+        cp(res->seg_len, bs.s, cb.seg_len);
+        cp(res->graph_seq, bs.c, cb.graph_seq);
+        cp(res->algnseq, bs.c, cb.algnseq);
+        cp(res->qual, bs.q, cb.qual);
+        const bool irr = cb.irregular;
+        cb = vgan_hc_host_batch();
+        cb.irregular = irr;
+    };
+    {
+        std::vector<std::thread> cth;
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            if (chunks.size() == 1) copy_chunk(i);
+            else cth.emplace_back(copy_chunk, i);
+        }
+        for (auto &t : cth) t.join();
+    }
     for (auto &c : chunks) {
-        append_shifted(res->read_seg_off, c.b.read_seg_off, (uint32_t)res->seg_node.size());
-        append_shifted(res->read_col_off, c.b.read_col_off, (uint32_t)res->graph_seq.size());
-        append_shifted(res->read_qual_off, c.b.read_qual_off, (uint32_t)res->qual.size());
-        res->read_algn_len.insert(res->read_algn_len.end(), c.b.read_algn_len.begin(), c.b.read_algn_len.end());
-        res->read_mapq.insert(res->read_mapq.end(), c.b.read_mapq.begin(), c.b.read_mapq.end());
-        res->seg_node.insert(res->seg_node.end(), c.b.seg_node.begin(), c.b.seg_node.end());
-        res->seg_start.insert(res->seg_start.end(), c.b.seg_start.begin(), c.b.seg_start.end());
-        res->seg_len.insert(res->seg_len.end(), c.b.seg_len.begin(), c.b.seg_len.end());
-        res->graph_seq.insert(res->graph_seq.end(), c.b.graph_seq.begin(), c.b.graph_seq.end());
-        res->algnseq.insert(res->algnseq.end(), c.b.algnseq.begin(), c.b.algnseq.end());
-        res->qual.insert(res->qual.end(), c.b.qual.begin(), c.b.qual.end());
         st.n_in += c.st.n_in;
         st.n_out += c.st.n_out;
         st.n_unmapped += c.st.n_unmapped;
         st.n_bad += c.st.n_bad;
         st.n_clamped += c.st.n_clamped;
         res->irregular = res->irregular || c.b.irregular;
-        c.b = vgan_hc_host_batch(); // release early
     }
     st.n_segments = (int64_t)res->seg_node.size();
     st.n_cols = (int64_t)res->graph_seq.size();

@@ -4,7 +4,10 @@
 // (field numbers verified on the reference's fixture test_reads.gam).
 #include "common.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 using namespace vgan;
 
@@ -206,6 +209,89 @@ void put_vi(std::string &o, int f, uint64_t v) {
 
 } // namespace
 
+// Concatenates per-thread alignment sets: sizes first, one allocation per array, then block copies with the offsets
+// of each part shifted (no per-element push_back, no reallocation).
+void vgan::merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &o) {
+    size_t R = 0, M = 0, E = 0, nseq = 0, nqual = 0, nname = 0, neseq = 0;
+    for (auto &p : parts) {
+        R += p.mapq.size();
+        M += p.m_node.size();
+        E += p.e_from.size();
+        nseq += p.seq.size();
+        nqual += p.qual.size();
+        nname += p.name.size();
+        neseq += p.e_seq.size();
+    }
+    o.seq_off.resize(R + 1);
+    o.qual_off.resize(R + 1);
+    o.name_off.resize(R + 1);
+    o.map_off.resize(R + 1);
+    o.mapq.resize(R);
+    o.identity.resize(R);
+    o.m_node.resize(M);
+    o.m_offset.resize(M);
+    o.m_rev.resize(M);
+    o.edit_off.resize(M + 1);
+    o.e_from.resize(E);
+    o.e_to.resize(E);
+    o.e_seq_off.resize(E + 1);
+    o.seq.resize(nseq);
+    o.qual.resize(nqual);
+    o.name.resize(nname);
+    o.e_seq.resize(neseq);
+    o.seq_off[0] = o.qual_off[0] = o.name_off[0] = o.map_off[0] = o.edit_off[0] = o.e_seq_off[0] = 0;
+    struct Base {
+        size_t r, m, e, seq, qual, name, eseq;
+    };
+    std::vector<Base> base(parts.size());
+    Base acc{0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < parts.size(); ++i) {
+        base[i] = acc;
+        acc.r += parts[i].mapq.size();
+        acc.m += parts[i].m_node.size();
+        acc.e += parts[i].e_from.size();
+        acc.seq += parts[i].seq.size();
+        acc.qual += parts[i].qual.size();
+        acc.name += parts[i].name.size();
+        acc.eseq += parts[i].e_seq.size();
+    }
+    auto copy_part = [&](size_t i) {
+        vgan_alnset &p = parts[i];
+        const Base &bs = base[i];
+        auto shift = [](const std::vector<int64_t> &src, int64_t *dst, int64_t by) {
+            for (size_t k = 1; k < src.size(); ++k) dst[k - 1] = src[k] + by;
+        };
+        shift(p.seq_off, &o.seq_off[bs.r + 1], (int64_t)bs.seq);
+        shift(p.qual_off, &o.qual_off[bs.r + 1], (int64_t)bs.qual);
+        shift(p.name_off, &o.name_off[bs.r + 1], (int64_t)bs.name);
+        shift(p.map_off, &o.map_off[bs.r + 1], (int64_t)bs.m);
+        shift(p.edit_off, &o.edit_off[bs.m + 1], (int64_t)bs.e);
+        shift(p.e_seq_off, &o.e_seq_off[bs.e + 1], (int64_t)bs.eseq);
+        auto cp = [](auto &dst, size_t at, const auto &src) {
+            if (!src.empty()) memcpy(&dst[at], src.data(), src.size() * sizeof(src[0]));
+        };
+        cp(o.mapq, bs.r, p.mapq);
+        cp(o.identity, bs.r, p.identity);
+        cp(o.m_node, bs.m, p.m_node);
+        cp(o.m_offset, bs.m, p.m_offset);
+        cp(o.m_rev, bs.m, p.m_rev);
+        cp(o.e_from, bs.e, p.e_from);
+        cp(o.e_to, bs.e, p.e_to);
+        cp(o.seq, bs.seq, p.seq);
+        cp(o.qual, bs.qual, p.qual);
+        cp(o.name, bs.name, p.name);
+        cp(o.e_seq, bs.eseq, p.e_seq);
+        p = vgan_alnset();
+    };
+    if (parts.size() <= 1) {
+        for (size_t i = 0; i < parts.size(); ++i) copy_part(i);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < parts.size(); ++i) th.emplace_back(copy_part, i);
+        for (auto &t : th) t.join();
+    }
+}
+
 extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped, vgan_alnset **out) {
     if (!bytes || !out) return fail(VGAN_EINVAL, "vgan_aln_parse_gam: null argument");
     std::string inflated;
@@ -215,30 +301,71 @@ extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped
         p = (const uint8_t *)inflated.data();
         n = inflated.size();
     }
-    auto a = new vgan_alnset();
-    Cur c{p, p + n, true};
-    while (!c.done()) {
-        const uint64_t count = c.varint();
-        if (!c.ok) break;
-        bool first = true;
-        for (uint64_t i = 0; i < count && c.ok; ++i) {
-            Cur item = c.sub();
+    // framing pass: groups of {count, count x (len, bytes)}; the first item of a group may be the type tag "GAM"
+    std::vector<std::pair<const uint8_t *, const uint8_t *>> msgs;
+    msgs.reserve(n / 600 + 16);
+    {
+        Cur c{p, p + n, true};
+        while (!c.done()) {
+            const uint64_t count = c.varint();
             if (!c.ok) break;
-            if (first) {
-                first = false;
-                if (item.e - item.p == 3 && memcmp(item.p, "GAM", 3) == 0) continue; // type tag
+            bool first = true;
+            for (uint64_t i = 0; i < count && c.ok; ++i) {
+                Cur item = c.sub();
+                if (!c.ok) break;
+                if (first) {
+                    first = false;
+                    if (item.e - item.p == 3 && memcmp(item.p, "GAM", 3) == 0) continue;
+                }
+                msgs.emplace_back(item.p, item.e);
             }
-            if (!parse_alignment(item, *a, keep_unmapped)) {
-                c.ok = false;
-                break;
+            if (!c.ok) break;
+        }
+        if (!c.ok) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+    }
+    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, msgs.size() / 2048));
+    std::vector<vgan_alnset> parts(nt);
+    std::atomic<bool> ok{true};
+    auto work = [&](unsigned t) {
+        const size_t m0 = msgs.size() * t / nt, m1 = msgs.size() * (t + 1) / nt;
+        vgan_alnset &a = parts[t];
+        if (m1 > m0) { // reserve from the byte volume of the slice: ~1 mapping per 20 bytes, ~1 edit per 16
+            const size_t nbytes = (size_t)(msgs[m1 - 1].second - msgs[m0].first), nr = m1 - m0;
+            a.seq_off.reserve(nr + 1);
+            a.qual_off.reserve(nr + 1);
+            a.name_off.reserve(nr + 1);
+            a.map_off.reserve(nr + 1);
+            a.mapq.reserve(nr);
+            a.identity.reserve(nr);
+            a.seq.reserve(nbytes / 6);
+            a.qual.reserve(nbytes / 6);
+            a.name.reserve(nr * 16);
+            a.m_node.reserve(nbytes / 18);
+            a.m_offset.reserve(nbytes / 18);
+            a.m_rev.reserve(nbytes / 18);
+            a.edit_off.reserve(nbytes / 18);
+            a.e_from.reserve(nbytes / 14);
+            a.e_to.reserve(nbytes / 14);
+            a.e_seq_off.reserve(nbytes / 14);
+        }
+        for (size_t m = m0; m < m1; ++m) {
+            if (!parse_alignment(Cur{msgs[m].first, msgs[m].second, true}, a, keep_unmapped)) {
+                ok = false;
+                return;
             }
         }
-        if (!c.ok) break;
+    };
+    if (nt <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto &t : th) t.join();
     }
-    if (!c.ok) {
-        delete a;
-        return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
-    }
+    if (!ok) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+    auto a = new vgan_alnset();
+    merge_alnsets(parts, *a);
     *out = a;
     return VGAN_OK;
 }
@@ -253,11 +380,10 @@ extern "C" int vgan_aln_read_gam(const char *path, int keep_unmapped, vgan_alnse
 extern "C" int vgan_aln_write_gam(const vgan_alnset *a, const char *path, int group_size) {
     if (!a || !path) return fail(VGAN_EINVAL, "vgan_aln_write_gam: null argument");
     if (group_size <= 0) group_size = 512;
-    std::string body, msg, pth, mp, pos, ed, gz, file;
+    std::string body, msg, pth, mp, pos, ed, file;
     const int64_t R = a->n_reads();
     for (int64_t g0 = 0; g0 < R; g0 += group_size) {
         const int64_t g1 = std::min<int64_t>(R, g0 + group_size);
-        body.clear();
         put_varint(body, (uint64_t)(g1 - g0 + 1));
         put_varint(body, 3);
         body += "GAM";
@@ -294,15 +420,8 @@ extern "C" int vgan_aln_write_gam(const vgan_alnset *a, const char *path, int gr
             put_varint(body, msg.size());
             body += msg;
         }
-        // one gzip member per group (the BGZF-style framing vg emits is also a concatenation of members)
-        if (!gzip_bytes(body, gz)) return fail(VGAN_EIO, "gzip failed");
-        file += gz;
     }
-    if (R == 0) {
-        body.clear();
-        if (!gzip_bytes(body, gz)) return fail(VGAN_EIO, "gzip failed");
-        file = gz;
-    }
+    if (!gzip_bytes(body, file)) return fail(VGAN_EIO, "BGZF compression failed"); // BGZF blocks, as vg writes GAM
     if (!write_file(path, file)) return fail(VGAN_EIO, "cannot write %s", path);
     return VGAN_OK;
 }

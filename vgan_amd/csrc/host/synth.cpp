@@ -407,26 +407,7 @@ extern "C" int vgan_synth_hc_reads(const vgan_graph *g, const vgan_synth_reads_c
     }
     for (auto &t : th) t.join();
     auto a = new vgan_alnset();
-    for (auto &p : parts) {
-        cat(a->seq_off, p.seq_off, 1, (int64_t)a->seq.size());
-        a->seq += p.seq;
-        cat(a->qual_off, p.qual_off, 1, (int64_t)a->qual.size());
-        a->qual += p.qual;
-        cat(a->name_off, p.name_off, 1, (int64_t)a->name.size());
-        a->name += p.name;
-        cat(a->map_off, p.map_off, 1, (int64_t)a->m_node.size());
-        cat(a->edit_off, p.edit_off, 1, (int64_t)a->e_from.size());
-        cat(a->e_seq_off, p.e_seq_off, 1, (int64_t)a->e_seq.size());
-        a->e_seq += p.e_seq;
-        a->mapq.insert(a->mapq.end(), p.mapq.begin(), p.mapq.end());
-        a->identity.insert(a->identity.end(), p.identity.begin(), p.identity.end());
-        a->m_node.insert(a->m_node.end(), p.m_node.begin(), p.m_node.end());
-        a->m_offset.insert(a->m_offset.end(), p.m_offset.begin(), p.m_offset.end());
-        a->m_rev.insert(a->m_rev.end(), p.m_rev.begin(), p.m_rev.end());
-        a->e_from.insert(a->e_from.end(), p.e_from.begin(), p.e_from.end());
-        a->e_to.insert(a->e_to.end(), p.e_to.begin(), p.e_to.end());
-        p = vgan_alnset();
-    }
+    merge_alnsets(parts, *a);
     *out = a;
     return VGAN_OK;
 }

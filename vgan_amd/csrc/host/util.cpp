@@ -3,9 +3,13 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <fstream>
 #include <sys/stat.h>
+#include <thread>
+#include <vector>
 
 namespace vgan {
 
@@ -33,9 +37,80 @@ bool file_exists(const std::string &path) {
     return stat(path.c_str(), &st) == 0 && !S_ISDIR(st.st_mode);
 }
 
+namespace {
+
+struct BgzfBlock {
+    size_t in_off, in_size, out_off, out_size;
+};
+
+// BGZF = gzip members with an extra subfield 'B','C' holding the member size - 1 (SAM spec 4.1).  Returns true and the
+// block list when the whole buffer is a sequence of such members.
+bool bgzf_index(const unsigned char *p, size_t n, std::vector<BgzfBlock> &blocks) {
+    blocks.clear();
+    size_t off = 0, out = 0;
+    while (off < n) {
+        if (n - off < 18 || p[off] != 0x1f || p[off + 1] != 0x8b || p[off + 2] != 8 || !(p[off + 3] & 4)) return false;
+        const size_t xlen = p[off + 10] | (p[off + 11] << 8);
+        if (n - off < 12 + xlen) return false;
+        size_t bsize = 0;
+        for (size_t x = off + 12; x + 4 <= off + 12 + xlen;) {
+            const size_t slen = p[x + 2] | (p[x + 3] << 8);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= off + 12 + xlen) bsize = (size_t)(p[x + 4] | (p[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || bsize > n - off) return false;
+        const unsigned char *tail = p + off + bsize - 4;
+        const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+        blocks.push_back({off, bsize, out, isize});
+        off += bsize;
+        out += isize;
+    }
+    return true;
+}
+
+bool inflate_member(const unsigned char *in, size_t in_size, unsigned char *out, size_t out_size) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;
+    zs.next_in = const_cast<unsigned char *>(in);
+    zs.avail_in = (uInt)in_size;
+    zs.next_out = out;
+    zs.avail_out = (uInt)out_size;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.avail_out == 0;
+    inflateEnd(&zs);
+    return ok || (rc == Z_STREAM_END && out_size == 0);
+}
+
+} // namespace
+
+// Inflates a concatenation of gzip members.  BGZF input (what vg writes) is inflated block-parallel straight into its
+// final position; other gzip streams sequentially.
 bool gunzip_members(const void *data, size_t n, std::string &out) {
     const unsigned char *p = (const unsigned char *)data;
     out.clear();
+    std::vector<BgzfBlock> blocks;
+    if (bgzf_index(p, n, blocks)) {
+        const size_t total = blocks.empty() ? 0 : blocks.back().out_off + blocks.back().out_size;
+        out.resize(total);
+        unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, blocks.size() / 64));
+        std::atomic<bool> ok{true};
+        auto work = [&](size_t b0, size_t b1) {
+            for (size_t i = b0; i < b1 && ok.load(std::memory_order_relaxed); ++i)
+                if (!inflate_member(p + blocks[i].in_off, blocks[i].in_size, (unsigned char *)&out[0] + blocks[i].out_off, blocks[i].out_size))
+                    ok = false;
+        };
+        if (nt <= 1) {
+            work(0, blocks.size());
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, blocks.size() * t / nt, blocks.size() * (t + 1) / nt);
+            for (auto &t : th) t.join();
+        }
+        return ok;
+    }
+    out.reserve(n * 4 + 1024);
     std::vector<unsigned char> buf(1 << 20);
     while (n > 0) {
         z_stream zs;
@@ -66,19 +141,66 @@ bool gunzip_members(const void *data, size_t n, std::string &out) {
     return true;
 }
 
+// BGZF writer: blocks of at most 0xff00 input bytes, deflated in parallel, plus the 28-byte EOF marker block.
 bool gzip_bytes(const std::string &in, std::string &out) {
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, 1, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    out.resize(deflateBound(&zs, in.size()) + 32);
-    zs.next_in = (unsigned char *)in.data();
-    zs.avail_in = (uInt)in.size();
-    zs.next_out = (unsigned char *)&out[0];
-    zs.avail_out = (uInt)out.size();
-    const int rc = deflate(&zs, Z_FINISH);
-    out.resize(zs.total_out);
-    deflateEnd(&zs);
-    return rc == Z_STREAM_END;
+    const size_t BLK = 0xff00;
+    const size_t nb = (in.size() + BLK - 1) / BLK;
+    std::vector<std::string> parts(nb);
+    std::atomic<bool> ok{true};
+    auto work = [&](size_t b0, size_t b1) {
+        std::vector<unsigned char> buf(BLK + 1024);
+        for (size_t b = b0; b < b1; ++b) {
+            const size_t off = b * BLK, len = std::min(BLK, in.size() - off);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+                ok = false;
+                return;
+            }
+            zs.next_in = (unsigned char *)in.data() + off;
+            zs.avail_in = (uInt)len;
+            zs.next_out = buf.data();
+            zs.avail_out = (uInt)buf.size();
+            const int rc = deflate(&zs, Z_FINISH);
+            const size_t clen = zs.total_out;
+            deflateEnd(&zs);
+            if (rc != Z_STREAM_END || clen + 26 > 65536) {
+                ok = false;
+                return;
+            }
+            std::string &o = parts[b];
+            const size_t bsize = clen + 26;
+            const unsigned char hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
+                                           (unsigned char)((bsize - 1) & 0xff), (unsigned char)((bsize - 1) >> 8)};
+            o.assign((const char *)hdr, 18);
+            o.append((const char *)buf.data(), clen);
+            const uLong crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)in.data() + off, (uInt)len);
+            unsigned char tail[8];
+            for (int i = 0; i < 4; ++i) {
+                tail[i] = (unsigned char)((crc >> (8 * i)) & 0xff);
+                tail[4 + i] = (unsigned char)((len >> (8 * i)) & 0xff);
+            }
+            o.append((const char *)tail, 8);
+        }
+    };
+    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, nb / 16));
+    if (nt <= 1) {
+        work(0, nb);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, nb * t / nt, nb * (t + 1) / nt);
+        for (auto &t : th) t.join();
+    }
+    if (!ok) return false;
+    out.clear();
+    size_t tot = 28;
+    for (auto &s : parts) tot += s.size();
+    out.reserve(tot);
+    for (auto &s : parts) out += s;
+    static const unsigned char eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    out.append((const char *)eof, 28);
+    return true;
 }
 
 bool read_file(const std::string &path, std::string &out, bool inflate_if_gzip) {
