@@ -1,0 +1,102 @@
+"""Robustness of the host front end: corrupted / truncated GAM input must produce an error code, never a crash or
+an out-of-bounds read (this file is also what the AddressSanitizer build of the host sources runs)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import gamio
+from vgan_amd import _native as N
+from vgan_amd import haplocart as hc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_truncated_and_corrupted_gam_streams():
+    alns = gamio.read_gam(os.path.join(ROOT, "tests/golden/alignments/J2a1a1a1.gam"))
+    plain = gamio.write_gam(alns, compress=False)
+    ok = hc.AlnSet.parse_gam(plain)
+    assert ok.n_reads == len(alns)
+    rng = random.Random(7)
+    n_err = 0
+    for trial in range(300):
+        data = bytearray(plain)
+        kind = trial % 3
+        if kind == 0:
+            data = data[: rng.randrange(1, len(data))]
+        elif kind == 1:
+            for _ in range(rng.randrange(1, 8)):
+                data[rng.randrange(len(data))] = rng.randrange(256)
+        else:
+            i = rng.randrange(len(data))
+            data[i:i] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 6)))
+        try:
+            a = hc.AlnSet.parse_gam(bytes(data))
+            arr = a.arrays()  # whatever was parsed must be internally consistent
+            assert arr["seq_off"][-1] == len(arr["seq"]) and arr["map_off"][-1] == len(arr["m_node"])
+            assert arr["edit_off"][-1] == len(arr["e_from"]) and arr["e_seq_off"][-1] == len(arr["e_seq"])
+        except N.NativeError as e:
+            assert e.code == N.VGAN_EIO
+            n_err += 1
+    assert n_err > 50
+
+
+def test_corrupted_gzip_and_bgzf_roundtrip(tmp_path):
+    g = hc.synth_graph(seed=4, genome_len=900, n_nodes=620, n_paths=30)
+    a = hc.synth_reads(g, 3000, seed=1, read_len=120)
+    p = str(tmp_path / "x.gam")
+    a.write_gam(p)
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC"  # BGZF, as vg writes GAM
+    assert raw[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")  # BGZF EOF block
+    b = hc.AlnSet.read_gam(p)
+    for k, v in a.arrays().items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(v, b.arrays()[k]), k
+    assert gamio.read_gam(raw)[5]["sequence"] == bytes(a.arrays()["seq"][a.arrays()["seq_off"][5]:a.arrays()["seq_off"][6]])
+    bad = bytearray(raw)
+    bad[len(bad) // 2] ^= 0xFF
+    with pytest.raises(N.NativeError):
+        hc.AlnSet.parse_gam(bytes(bad))
+    with pytest.raises(N.NativeError):
+        hc.AlnSet.parse_gam(raw[: len(raw) // 3])
+    # plain (non-BGZF) gzip members are still accepted
+    import gzip
+    plain = gamio.gunzip_all(raw)
+    c = hc.AlnSet.parse_gam(gzip.compress(plain[: len(plain)]))
+    assert c.n_reads == a.n_reads
+
+
+def test_flatten_rejects_nonsense_without_crashing():
+    g = hc.synth_graph(seed=4, genome_len=900, n_nodes=620, n_paths=30)
+    a = hc.synth_reads(g, 200, seed=1, read_len=80)
+    arr = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in a.arrays().items()}
+    rng = np.random.default_rng(5)
+    for _ in range(60):  # corrupt mappings / edits at random
+        i = rng.integers(len(arr["m_node"]))
+        arr["m_node"][i] = rng.integers(0, 5000)
+        j = rng.integers(len(arr["e_from"]))
+        arr["e_from"][j] = rng.integers(0, 50)
+        arr["e_to"][rng.integers(len(arr["e_to"]))] = rng.integers(0, 50)
+        arr["m_offset"][rng.integers(len(arr["m_offset"]))] = rng.integers(0, 12)
+    import orc
+    import util
+    oa = orc.AlnSet.from_arrays(**arr)
+    v = N.AlnSetView(oa.n_reads, *[getattr(oa, k).ctypes.data for k in ("seq_off", "seq", "qual_off", "qual", "mapq", "identity")],
+                     None, None, *[getattr(oa, k).ctypes.data for k in ("map_off", "m_node", "m_offset", "m_rev", "edit_off",
+                                                                        "e_from", "e_to", "e_seq_off", "e_seq")])
+    h = N.vp()
+    N.check(N.lib().vgan_aln_from_arrays(v, h))
+    a2 = hc.AlnSet(h)
+    b = hc.HostBatch(g, a2)
+    assert b.stats.n_out + b.stats.n_bad + b.stats.n_unmapped == 200 and b.stats.n_bad > 0
+    # the oracle rejects exactly the same reads
+    og = util.orc_graph_from_product(g)
+    _, _, bad = orc.hc_run(og, oa, n_threads=2, faithful=False)
+    assert bad == b.stats.n_bad
+    from vgan_amd import euka as ek
+    from vgan_amd import soibean as sb
+    e = ek.EukaHostBatch(g, a2)
+    s = sb.SbHostBatch(g, a2)
+    assert e.stats.n_out + e.stats.n_bad == 200 and s.stats.n_out + s.stats.n_bad == 200

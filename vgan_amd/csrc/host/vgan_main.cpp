@@ -155,7 +155,7 @@ int haplocart(int argc, char **argv) {
     check(vgan_hc_set_mode(ctx, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS), "mode");
     if (!quiet && fastafilename.empty()) std::cerr << "Computing haplogroup likelihoods from " << n_reads << " reads." << '\n';
 
-    const int64_t BATCH = 2000000; // reads per device batch
+    const int64_t BATCH = 500000; // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i
     vgan_hc_flatten_stats tot{};
     for (int64_t r0 = 0; r0 < n_reads; r0 += BATCH) {
         const int64_t r1 = std::min(n_reads, r0 + BATCH);
@@ -164,8 +164,9 @@ int haplocart(int argc, char **argv) {
         check(vgan_hc_flatten(graph, alns, r0, r1, n_threads, &hb, &st), "flattening");
         vgan_hc_batch b;
         check(vgan_hc_host_batch_get(hb, &b), "batch");
+        // the copy out of the host batch completes inside the call (pageable memory is staged by the runtime); the
+        // kernels run asynchronously while the next batch is flattened on the host threads
         check(vgan_hc_accumulate(ctx, &b), "accumulate");
-        check(vgan_hc_synchronize(ctx), "synchronize");
         vgan_hc_host_batch_free(hb);
         tot.n_bad += st.n_bad;
         tot.n_unmapped += st.n_unmapped;
