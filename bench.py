@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x76676131)
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-read-mode kernel measurement")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test rigs with fewer GPUs than ranks)")
     ap.add_argument("--path", choices=["haplocart", "euka", "soibean"], default="haplocart",
                     help="haplocart = the BASELINE metric; euka / soibean = configs 4 / 5 as extra lines")
     return ap.parse_args()
@@ -213,9 +214,11 @@ def main():
     rank, world, local_rank = vd.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    if args.dist_backend == "gloo":  # several ranks may share one GPU on a test rig
+        local_rank = min(local_rank, torch.cuda.device_count() - 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    vd.init(backend="nccl", device=dev)
+    vd.init(backend=args.dist_backend, device=dev)
 
     # ---- synthetic workload (same graph on every rank, a different read shard per rank)
     graph = hc.synth_graph(seed=args.seed)
@@ -252,15 +255,8 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(n_reads)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_reads = float(tot.item())
-    else:
-        total_reads = float(n_reads)
+    elapsed = vd.all_reduce_max(elapsed, dev)            # MAX over ranks
+    total_reads = vd.all_reduce_sum(float(n_reads), dev)  # whole-job reads per step
 
     # ---- the reference's loop order (one mask row per segment) measured beside the default mode: the kernel
     # BASELINE.json's north_star puts the >= 30 % HBM-roofline target on.  Outside the timed region.

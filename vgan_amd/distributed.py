@@ -37,5 +37,33 @@ def reduce_loglik(final_vec, dst=0):
     """Sum the per-rank final_vec tensors (float64[P]) onto rank dst.  Returns the tensor (complete on dst only)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(final_vec, dst=dst, op=dist.ReduceOp.SUM)
+        if final_vec.is_cuda and dist.get_backend() == "gloo":  # test rigs without RCCL: stage through the host
+            host = final_vec.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            final_vec.copy_(host)
+        else:
+            dist.reduce(final_vec, dst=dst, op=dist.ReduceOp.SUM)
     return final_vec
+
+
+def all_reduce_max(value, device=None):
+    """max over ranks of a python float (bench timing)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    on = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_reduce_sum(value, device=None):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    on = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
