@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x76676131)
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-read-mode kernel measurement")
+    ap.add_argument("--clades", type=int, default=335, help="euka path: number of clades the synthetic reads spread over")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test rigs with fewer GPUs than ranks)")
     ap.add_argument("--path", choices=["haplocart", "euka", "soibean"], default="haplocart",
                     help="haplocart = the BASELINE metric; euka / soibean = configs 4 / 5 as extra lines")
@@ -82,7 +83,7 @@ def bench_euka(args):
     vd.init(backend="nccl", device=dev)
     gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
     dm = ek.Damage.load(os.path.join(gold, "dhigh5p.prof"), os.path.join(gold, "dhigh3p.prof"))
-    g, db, alns = ek.synth_euka(args.reads, dm, seed=args.seed + 1000003 * rank, n_clades=335, nodes_per_clade=400,
+    g, db, alns = ek.synth_euka(args.reads, dm, seed=args.seed + 1000003 * rank, n_clades=args.clades, nodes_per_clade=400,
                                 read_len_mean=75)
     hb = ek.EukaHostBatch(g, alns)
     dbt = ek.EukaDeviceBatch(hb, dev)

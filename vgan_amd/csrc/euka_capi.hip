@@ -124,9 +124,9 @@ extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_v
         (rc = c->bin_hi.upload(std::vector<int32_t>(db->bin_hi, db->bin_hi + c->n_bins))) ||
         (rc = c->sub5p.upload(std::vector<double>(dmg->sub5p, dmg->sub5p + (size_t)dmg->n5 * 16))) ||
         (rc = c->sub3p.upload(std::vector<double>(dmg->sub3p, dmg->sub3p + (size_t)dmg->n3 * 16))) ||
-        (rc = c->tables.upload(tb)) || (rc = c->clade_count.reserve(c->n_clades)) ||
-        (rc = c->baseshift.reserve((size_t)c->n_clades * 2 * std::max(1, c->ltp) * 16)) ||
-        (rc = c->bin_cov.reserve(std::max<uint32_t>(1, c->n_bins))) || (rc = c->n_bad.reserve(1)))
+        (rc = c->tables.upload(tb)) || (rc = c->clade_count.reserve((size_t)EUKA_REPLICAS * c->n_clades)) ||
+        (rc = c->baseshift.reserve((size_t)EUKA_REPLICAS * c->n_clades * 2 * std::max(1, c->ltp) * 16)) ||
+        (rc = c->bin_cov.reserve((size_t)EUKA_REPLICAS * std::max<uint32_t>(1, c->n_bins))) || (rc = c->n_bad.reserve(1)))
         return bail(rc);
     c->d.bp = c->bp.p;
     c->d.bp_clade = c->bp_clade.p;
@@ -189,9 +189,9 @@ extern "C" int vgan_euka_set_stream(vgan_euka_ctx *c, void *s) {
 extern "C" int vgan_euka_reset(vgan_euka_ctx *c) {
     if (!c) return fail(VGAN_EINVAL, "vgan_euka_reset: null context");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->clade_count.p, 0, (size_t)c->n_clades * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->baseshift.p, 0, (size_t)c->n_clades * 2 * std::max(1, c->ltp) * 16 * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->bin_cov.p, 0, (size_t)std::max<uint32_t>(1, c->n_bins) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->clade_count.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->baseshift.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 2 * std::max(1, c->ltp) * 16 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->bin_cov.p, 0, (size_t)EUKA_REPLICAS * std::max<uint32_t>(1, c->n_bins) * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->n_bad.p, 0, 8, c->stream));
     return VGAN_OK;
 }
@@ -293,6 +293,7 @@ extern "C" int vgan_euka_accumulate(vgan_euka_ctx *c, const vgan_euka_batch *b, 
     o.clade_count = c->clade_count.p;
     o.baseshift = c->baseshift.p;
     o.bin_cov = c->bin_cov.p;
+    o.n_bins = c->n_bins;
     o.n_bad = c->n_bad.p;
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     launch_euka_reads(c->d, d, o, c->stream);
@@ -314,6 +315,15 @@ extern "C" int vgan_euka_accumulate(vgan_euka_ctx *c, const vgan_euka_batch *b, 
 extern "C" int vgan_euka_finalize(vgan_euka_ctx *c, int32_t *clade_count, uint32_t *baseshift, double *bin_cov, int64_t *n_bad) {
     if (!c) return fail(VGAN_EINVAL, "vgan_euka_finalize: null context");
     HIPCHK(hipSetDevice(c->device));
+    {
+        EukaOutDev o{};
+        o.clade_count = c->clade_count.p;
+        o.baseshift = c->baseshift.p;
+        o.bin_cov = c->bin_cov.p;
+        o.n_bins = c->n_bins;
+        launch_euka_reduce(o, c->n_clades, c->ltp, c->stream); // fold the replicas into replica 0
+        HIPCHK(hipGetLastError());
+    }
     if (clade_count) HIPCHK(hipMemcpyAsync(clade_count, c->clade_count.p, (size_t)c->n_clades * 4, hipMemcpyDeviceToHost, c->stream));
     if (baseshift && c->ltp > 0)
         HIPCHK(hipMemcpyAsync(baseshift, c->baseshift.p, (size_t)c->n_clades * 2 * c->ltp * 16 * 4, hipMemcpyDeviceToHost, c->stream));

@@ -37,16 +37,24 @@ struct EukaBatchDev {
     const uint8_t *graph_seq, *read_seq, *qual;
 };
 
+// Per-clade accumulators are kept in EUKA_REPLICAS copies (replica = blockIdx % EUKA_REPLICAS) and summed at finalize:
+// a real sample concentrates on a handful of clades, and every read of a clade hits the same ~200 counters --
+// same-address atomics serialise in L2 (1 clade: 18.8 ms per 1M reads without replicas).
+constexpr uint32_t EUKA_REPLICAS = 32;
+
 struct EukaOutDev {
     int32_t *clade;
     double *in_lik, *out_lik, *like, *not_like;
     uint8_t *pass;
-    int32_t *clade_count;
-    uint32_t *baseshift;
-    double *bin_cov;
+    int32_t *clade_count; // [EUKA_REPLICAS][n_clades]
+    uint32_t *baseshift;  // [EUKA_REPLICAS][n_clades][2*ltp][16]
+    double *bin_cov;      // [EUKA_REPLICAS][n_bins]
+    uint32_t n_bins;
     unsigned long long *n_bad;
 };
 
 void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev &o, hipStream_t st);
+// sums the replicas into replica 0 (count/baseshift/bin_cov element-wise)
+void launch_euka_reduce(const EukaOutDev &o, uint32_t n_clades, int32_t ltp, hipStream_t st);
 
 } // namespace vgan

@@ -42,6 +42,11 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // this workgroup's replica of the per-clade accumulators
+    const uint32_t rep = blockIdx.x % EUKA_REPLICAS;
+    int32_t *const clade_count = o.clade_count + (size_t)rep * d.n_clades;
+    uint32_t *const baseshift = o.baseshift + (size_t)rep * d.n_clades * 2 * (d.ltp > 0 ? d.ltp : 1) * 16;
+    double *const bin_cov = o.bin_cov + (size_t)rep * o.n_bins;
 
     for (uint32_t r = blockIdx.x * EK_WAVES + wave; r < b.n_reads; r += gridDim.x * EK_WAVES) {
         const uint32_t col0 = b.read_col_off[r];
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 gb = (gb >= 'a' && gb <= 'z') ? gb - 32u : gb;
                 rb = (rb >= 'a' && rb <= 'z') ? rb - 32u : rb;
                 const int g4 = acgt_index(gb), r4 = acgt_index(rb);
-                if (g4 >= 0 && r4 >= 0) atomicAdd(&o.baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4 * 4 + r4], 1u);
+                if (g4 >= 0 && r4 >= 0) atomicAdd(&baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4 * 4 + r4], 1u);
             }
         }
         // clade_like / clade_not_like (:485-492)
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             o.like[r] = like;
             o.not_like[r] = 1.0 - like;
             o.pass[r] = pass ? 1 : 0;
-            if (pass) atomicAdd(&o.clade_count[c_n], 1);
+            if (pass) atomicAdd(&clade_count[c_n], 1);
         }
         if (pass) { // bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546)
             const uint32_t b0 = d.bin_off[c_n], b1 = d.bin_off[c_n + 1];
@@ -185,11 +190,46 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 const int32_t node = mi < m1 ? (int32_t)b.map_node[mi] : -1;
                 for (uint32_t j = b0; j < b1; ++j) {
                     const uint64_t hit = __builtin_amdgcn_ballot_w64(mi < m1 && node >= d.bin_lo[j] && node <= d.bin_hi[j]);
-                    if (hit && lane == 0) unsafeAtomicAdd(&o.bin_cov[j], (double)__builtin_popcountll(hit) * inv);
+                    if (hit && lane == 0) unsafeAtomicAdd(&bin_cov[j], (double)__builtin_popcountll(hit) * inv);
                 }
             }
         }
     }
+}
+
+// replica r > 0 added onto replica 0, replicas cleared: fixed order, so the sums do not depend on scheduling
+__global__ void euka_reduce_kernel(EukaOutDev o, uint32_t n_count, uint32_t n_shift, uint32_t n_cov) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_count) {
+        int32_t s = o.clade_count[i];
+        for (uint32_t r = 1; r < EUKA_REPLICAS; ++r) {
+            s += o.clade_count[(size_t)r * n_count + i];
+            o.clade_count[(size_t)r * n_count + i] = 0;
+        }
+        o.clade_count[i] = s;
+    }
+    if (i < n_shift) {
+        uint32_t s = o.baseshift[i];
+        for (uint32_t r = 1; r < EUKA_REPLICAS; ++r) {
+            s += o.baseshift[(size_t)r * n_shift + i];
+            o.baseshift[(size_t)r * n_shift + i] = 0;
+        }
+        o.baseshift[i] = s;
+    }
+    if (i < n_cov) {
+        double s = o.bin_cov[i];
+        for (uint32_t r = 1; r < EUKA_REPLICAS; ++r) {
+            s += o.bin_cov[(size_t)r * n_cov + i];
+            o.bin_cov[(size_t)r * n_cov + i] = 0.0;
+        }
+        o.bin_cov[i] = s;
+    }
+}
+
+void launch_euka_reduce(const EukaOutDev &o, uint32_t n_clades, int32_t ltp, hipStream_t st) {
+    const uint32_t n_shift = n_clades * 2 * (ltp > 0 ? ltp : 1) * 16;
+    const uint32_t n = n_shift > o.n_bins ? n_shift : o.n_bins;
+    hipLaunchKernelGGL(euka_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, o, n_clades, n_shift, o.n_bins);
 }
 
 void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev &o, hipStream_t st) {
