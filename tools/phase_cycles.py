@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Developer aid: per-phase cycle split of hc_segment_tile_kernel.
+
+Needs a library built with VGAN_EXTRA_FLAGS=-DVGAN_PHASE_TIMING (python vgan_amd/build.py --force); rebuild without
+the flag afterwards.  Prints the share of wave-0 cycles spent in each phase / barrier wait.
+"""
+import ctypes
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from vgan_amd import _native, haplocart as hc  # noqa: E402
+
+NAMES = ["top: windows -> LDS", "barrier 1", "B quality prefix", "barrier 2", "C segments", "barrier 3",
+         "next tile: extents + requests", "D columns", "next tile: node gather", "barrier 4", "E store", "-"]
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+    lib = _native.load()
+    fn = lib.vgan_hc_debug_phase_cycles
+    fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    g = hc.synth_graph(seed=1)
+    a = hc.synth_reads(g, n, seed=2, read_len=150)
+    hb = hc.HostBatch(g, a)
+    db = hc.DeviceBatch(hb)
+    ctx = hc.HcContext(g)
+    out = (ctypes.c_ulonglong * 12)()
+    for rep in range(3):
+        ctx.reset()
+        fn(out, 1)
+        ctx.accumulate(db)
+        ctx.synchronize()
+        fn(out, 0)
+    v = np.array(list(out), dtype=np.float64)
+    for name, x in zip(NAMES, v):
+        print("%-28s %6.2f %%  %.3e cycles" % (name, 100 * x / v.sum(), x))
+
+
+if __name__ == "__main__":
+    main()

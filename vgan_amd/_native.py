@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libvgan_gpu.so")
+LIB_PATH = os.environ.get("VGAN_GPU_LIB") or os.path.join(HERE, "lib", "libvgan_gpu.so")  # override: developer A/B builds
 
 
 class NativeError(RuntimeError):

@@ -16,6 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("VGAN_EXTRA_FLAGS", "").split()  # developer builds, e.g. -DVGAN_PHASE_TIMING
 
 
 def sources():

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "log_tab.h"
+
 namespace vgan {
 
 // libgab isValidDNA: upper-case A, C, G, T only.  Branch-free: 'A'-'A'=0, 'C'=2, 'G'=6, 'T'=19.
@@ -47,6 +49,15 @@ __device__ __forceinline__ double log_pos(double x) {
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     return dk * 6.93147180369123816490e-01 - ((hfsq - fma(sq, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
+// log(x) through the 128-entry table staged in LDS (log_tab.h); anything outside the normal positive range takes the
+// series above (a wave-uniform branch that is not taken in practice).
+__device__ __forceinline__ double log_tab(double x, const LogTabEntry *tab_lds) {
+    const bool ok = log_tab_in_domain(x);
+    double r = log_tab_eval(ok ? x : 1.0, tab_lds);
+    if (__builtin_expect(!ok, 0)) r = log_pos(x);
+    return r;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -139,193 +139,383 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
 }
 
 // ---------------------------------------------------------------------------------------------- segments (tiled)
+// Everything is flat over a tile of up to ST_READS reads staged in LDS -- no per-read wave work:
+//   top  the tile's graph / read / quality bytes go from registers to LDS (they were requested from HBM during the
+//        previous tile's phase D, like the segment records and, a tile earlier still, the read offsets)
+//   B  lane per 5 quality bytes: log p_err prefix sums (thread-local + one DPP wave scan; wave totals folded in by the
+//      consumers), so that U_m is a difference of two prefix values
+//   C  lane per segment: U_m, the segment record {pcm, match, columns, read geometry}; a head bit per first column
+//   D  lane per alignment column: owner segment = nearest head bit at or below the column (the segments of a regular
+//      read tile its columns in order), one table-driven log, LDS fp64 atomic into the segment's sum
+//   E  lane per segment: D_m = S_m - U_m streamed out
 constexpr int ST_THREADS = 256;
 constexpr int ST_WAVES = ST_THREADS / 64;
 constexpr int ST_READS = 8;   // reads per tile (at most)
 constexpr int ST_COLS = 1280; // LDS capacity per tile: alignment columns,
 constexpr int ST_QUAL = 1280; //                        quality bytes,
 constexpr int ST_SEGS = 512;  //                        segments
-constexpr int ST_MAXQ = HC_TILE_MAX_READ_QUAL;
+constexpr int ST_QB = ST_QUAL / ST_THREADS;         // quality bytes per lane in phase B
+constexpr int ST_QW = ST_QB * 64;                   // quality bytes per wave in phase B
+constexpr int ST_SEG_ITERS = ST_SEGS / ST_THREADS;  // segments per lane in phases C and E
+static_assert(ST_QB * ST_THREADS == ST_QUAL && ST_SEG_ITERS * ST_THREADS == ST_SEGS && ST_WAVES == 4,
+              "tile shape");
+static_assert(ST_COLS <= 2 * 4 * ST_THREADS - 8 && ST_QUAL <= 2 * 4 * ST_THREADS - 8, "byte windows: two dwords per thread");
 
-struct alignas(16) StSeg {
-    double pcm;      // (1 - incorrect_mapping_vec[mapq]) * mappability[node]   (process_mapping.cpp:41)
-    double match;    // pow(1 - mu(node), 8)                                     (get_p_obs_base.cpp:64)
-    uint32_t cstart; // tile-local column of the segment's first base
-    uint32_t rbase;  // tile-local column of the read's first base (Q4: read bases are taken from the read start)
-    uint32_t A;      // |algnseq| of the read
-    uint32_t use_bep;
+// x = wbg * bg(read base) + wobs * (1 - eps) per column, with pcm = (1 - incorrect_mapping_vec[mapq]) * mappability[node]
+// (process_mapping.cpp:41) and match = pow(1 - mu(node), 8) (get_p_obs_base.cpp:64):
+struct alignas(16) StSegPm {
+    double wbg;  // 1 - pcm             (0 for a consensus FASTA, process_mapping.cpp:66-70)
+    double wobs; // pcm * match         ((1 - bep) * match for a consensus FASTA)
+};
+// Per-segment column bounds and index shifts, tile-local, so that a column c of the segment needs one compare or add
+// for each: it is scored when c < cend; its read base is rseq_s[c + rshift] while c < aend (Q4: the read bases are
+// taken from the read start, so rshift = read column 0 - segment column 0); its quality is qual_s[c + qshift] while
+// c < qend (Q5: zero beyond the read's quality string).
+struct StSegGeo {
+    uint16_t cend_bep; // first column past the segment | use_bep << 15
+    int16_t rshift;
+    uint16_t aend;
+    int16_t qshift;
+    uint16_t qend;
+    uint16_t pad;
+};
+static_assert(sizeof(StSegGeo) == 12, "StSegGeo is three dwords");
+
+__device__ const LogTabEntry hc_log_table[64] = {VGAN_LOG_TABLE};
+
+#ifdef VGAN_PHASE_TIMING // developer aid: cycles per phase of the tile kernel (thread 0 of every workgroup)
+__device__ unsigned long long hc_phase_cycles[12];
+#define PT_MARK(slot)                                                  \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        pt_acc[slot] += now_ - pt_last;                                \
+        pt_last = now_;                                                \
+    } while (0)
+#else
+#define PT_MARK(slot)
+#endif
+
+struct StTile { // extents of one tile (wave uniform)
+    uint32_t n, seg_base, n_seg, col_base, n_col, q_base, n_q;
 };
 
-// Copies bytes [g0, g0+n) of src into dst (LDS) as aligned dwords; dst[i + (g0 & 3)] = src[g0 + i].
-// n <= 1280, so every thread moves at most two dwords (fixed trip count: no loop bookkeeping).
-__device__ __forceinline__ void stage_bytes(uint8_t *dst, const uint8_t *__restrict__ src, uint32_t g0, uint32_t n, int tid) {
-    static_assert(ST_COLS <= 2 * 4 * ST_THREADS - 8 && ST_QUAL <= 2 * 4 * ST_THREADS - 8, "two dwords per thread");
+// a byte window [g0, g0+n) of src as aligned dwords: dword i of the window goes to dword i of the LDS array, so that
+// lds[i + (g0 & 3)] = src[g0 + i].  Every thread moves at most two dwords.
+struct StWindow {
+    uint32_t v0, v1;
+};
+__device__ __forceinline__ StWindow window_request(const uint8_t *__restrict__ src, uint32_t g0, uint32_t n, int tid) {
     const uint32_t a0 = g0 & ~3u;
     const uint32_t nd = (g0 + n - a0 + 3u) >> 2;
     const uint32_t *__restrict__ s32 = reinterpret_cast<const uint32_t *>(src + a0);
+    StWindow w;
+    w.v0 = (uint32_t)tid < nd ? s32[tid] : 0u;
+    w.v1 = (uint32_t)tid + ST_THREADS < nd ? s32[tid + ST_THREADS] : 0u;
+    return w;
+}
+__device__ __forceinline__ void window_store(uint8_t *dst, const StWindow &w, int tid) {
     uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
-    const uint32_t i0 = tid, i1 = tid + ST_THREADS;
-    const uint32_t v0 = i0 < nd ? s32[i0] : 0u;
-    const uint32_t v1 = i1 < nd ? s32[i1] : 0u;
-    if (i0 < nd) d32[i0] = v0;
-    if (i1 < nd) d32[i1] = v1;
+    d32[tid] = w.v0; // dwords past the window carry zeros
+    if (tid + ST_THREADS < (ST_COLS + 8) / 4) d32[tid + ST_THREADS] = w.v1;
 }
 
-__global__ __launch_bounds__(ST_THREADS) void hc_segment_tile_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
+struct StLoads { // one tile's HBM data in flight
+    StWindow gseq, rseq, qual;
+    uint32_t start[ST_SEG_ITERS], len[ST_SEG_ITERS], node[ST_SEG_ITERS];
+    HcNodeDev nd[ST_SEG_ITERS];
+};
+
+__global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
                                                                       uint32_t reads_per_block,
                                                                       double *__restrict__ segD_out,
                                                                       double *__restrict__ totals) {
     __shared__ double lq_s[256];
-    __shared__ double qs_s[100];
+    __shared__ double qs_s[101];      // qscore_vec, and the background error rate in slot 100
+    __shared__ double incmap_s[100];
     __shared__ double bg_s[4];
-    __shared__ double ps_s[ST_WAVES][ST_MAXQ + 1];
+    __shared__ uint8_t code_s[256];   // A C T G -> 0 1 2 3 (bg_s order), anything else 4 (libgab isValidDNA is false)
+    __shared__ LogTabEntry logtab_s[64];
+    __shared__ double ps_s[ST_QUAL + 1]; // wave-local prefix sums of log p_err over the tile's quality bytes
+    __shared__ double wsum_s[ST_WAVES];  // each wave's total
     __shared__ double segS_s[ST_SEGS];
-    __shared__ StSeg segpm_s[ST_SEGS];
-    __shared__ uint16_t colseg_s[ST_COLS];
-    __shared__ __attribute__((aligned(16))) uint8_t qcol_s[ST_COLS + 8]; // clamped quality per tile column (0 past the read's qualities)
+    __shared__ StSegPm segpm_s[ST_SEGS];
+    __shared__ StSegGeo seggeo_s[ST_SEGS];
+    __shared__ uint32_t flags_s[ST_COLS / 32]; // bit c: a segment starts at tile column c
+    __shared__ uint16_t colhead_s[ST_COLS];    // ... and which one (valid where the bit is set)
     __shared__ __attribute__((aligned(16))) uint8_t gseq_s[ST_COLS + 8];
     __shared__ __attribute__((aligned(16))) uint8_t rseq_s[ST_COLS + 8];
     __shared__ __attribute__((aligned(16))) uint8_t qual_s[ST_QUAL + 8];
-    __shared__ uint32_t off_s[3][ST_READS + 1];
+    // per-read header, double buffered: the next tile's is written while this tile's is in use
+    __shared__ uint32_t off_s[2][3][ST_READS + 1];
+    __shared__ uint32_t rdA_s[2][ST_READS];
+    __shared__ double rdpinc_s[2][ST_READS];
+    __shared__ uint32_t first90_s[ST_READS];
+    __shared__ StTile tile_s[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 256; i += ST_THREADS) lq_s[i] = g.lq[i];
-    for (int i = tid; i < 100; i += ST_THREADS) qs_s[i] = g.qscore[i];
+    for (int i = tid; i < 101; i += ST_THREADS) qs_s[i] = i < 100 ? g.qscore[i] : prm.bep;
+    for (int i = tid; i < 100; i += ST_THREADS) incmap_s[i] = g.incmap[i];
+    for (int i = tid; i < 256; i += ST_THREADS) code_s[i] = is_acgt((uint32_t)i) ? (uint8_t)((i >> 1) & 3) : (uint8_t)4;
+    for (int i = tid; i < 64; i += ST_THREADS) logtab_s[i] = hc_log_table[i];
     if (tid < 4) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : 0.16644; // A C T G by (c>>1)&3
     const double lq0 = g.lq[0];
     double sumT = 0.0, sumU = 0.0; // sum of the column terms (= sum of S_m) and of U_m, each without cancellation
 
     const uint32_t rb0 = blockIdx.x * reads_per_block;
     const uint32_t rb1 = min(b.n_reads, rb0 + reads_per_block);
-    uint32_t r0 = rb0;
-    while (r0 < rb1) {
-        // ---- tile header: offsets of up to ST_READS reads
+    if (rb0 >= rb1) return;
+
+    // header values travel in registers of threads 0..ST_READS until they are published in LDS
+    uint32_t h_seg = 0, h_col = 0, h_q = 0, h_A = 0, h_mapq = 0;
+    auto header_request = [&](uint32_t first) {
         if (tid <= ST_READS) {
-            const uint32_t r = min(r0 + tid, rb1);
-            off_s[0][tid] = b.read_seg_off[r];
-            off_s[1][tid] = b.read_col_off[r];
-            off_s[2][tid] = b.read_qual_off[r];
+            const uint32_t r = min(first + tid, rb1);
+            h_seg = b.read_seg_off[r];
+            h_col = b.read_col_off[r];
+            h_q = b.read_qual_off[r];
+            const uint32_t rr = min(r, b.n_reads - 1);
+            h_A = b.read_algn_len[rr];
+            h_mapq = b.read_mapq[rr];
         }
+    };
+    // Wave 0 publishes the header and the tile's extents: reads [first, first+n) with n the largest count whose
+    // segments, columns and quality bytes fit the LDS tile (one read always fits: the host selects this kernel only
+    // for reads within the per-read limits).  The offsets ascend, so "read t-1 still fits" is a prefix property and
+    // n is a popcount.
+    auto header_publish = [&](uint32_t buf, uint32_t first) {
+        if (wave == 0) {
+            const uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_seg);
+            const uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_col);
+            const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_q);
+            const bool fits = tid >= 1 && tid <= ST_READS && first + tid <= rb1 && h_seg - sb <= (uint32_t)ST_SEGS &&
+                              h_col - cb <= (uint32_t)ST_COLS && h_q - qb <= (uint32_t)ST_QUAL;
+            const uint32_t n = max(1u, (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fits)));
+            if (tid <= ST_READS) {
+                off_s[buf][0][tid] = h_seg;
+                off_s[buf][1][tid] = h_col;
+                off_s[buf][2][tid] = h_q;
+                if (tid < ST_READS) {
+                    rdA_s[buf][tid] = h_A;
+                    rdpinc_s[buf][tid] = incmap_s[min(h_mapq, 99u)];
+                }
+            }
+            if ((uint32_t)tid == n) tile_s[buf] = StTile{n, sb, h_seg - sb, cb, h_col - cb, qb, h_q - qb};
+        }
+    };
+    auto tile_extents = [&](uint32_t buf) { return tile_s[buf]; };
+    auto tile_request = [&](const StTile &t, StLoads &L) {
+#pragma unroll
+        for (int it = 0; it < ST_SEG_ITERS; ++it) {
+            const uint32_t ls = tid + it * ST_THREADS;
+            const uint32_t s = t.seg_base + min(ls, t.n_seg ? t.n_seg - 1 : 0u);
+            const bool on = ls < t.n_seg;
+            L.node[it] = on ? b.seg_node[s] : 0u;
+            L.start[it] = on ? b.seg_start[s] : 0u;
+            L.len[it] = on ? b.seg_len[s] : 0u;
+        }
+        L.gseq = window_request(b.graph_seq, t.col_base, t.n_col, tid);
+        L.rseq = window_request(b.algnseq, t.col_base, t.n_col, tid);
+        L.qual = window_request(b.qual, t.q_base, t.n_q, tid);
+    };
+    auto tile_gather = [&](const StTile &t, StLoads &L) { // needs L.node: issued well after tile_request
+#pragma unroll
+        for (int it = 0; it < ST_SEG_ITERS; ++it) {
+            const uint32_t ls = tid + it * ST_THREADS;
+            L.nd[it] = ls < t.n_seg ? g.node_tab[L.node[it]] : HcNodeDev{0.0, 0.0};
+        }
+    };
+
+#ifdef VGAN_PHASE_TIMING
+    unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt_last = __builtin_readcyclecounter();
+#endif
+    // ---- prologue: the first tile's header and data, the second tile's header
+    uint32_t r0 = rb0, cur = 0;
+    header_request(r0);
+    __syncthreads(); // the tables above are in place
+    header_publish(cur, r0);
+    __syncthreads();
+    StTile T = tile_extents(cur);
+    StLoads L;
+    tile_request(T, L);
+    tile_gather(T, L);
+    if (r0 + T.n < rb1) header_request(r0 + T.n);
+
+    while (true) {
+        const bool has_next = r0 + T.n < rb1; // wave (and workgroup) uniform
+        const uint32_t cshift = T.col_base & 3u, qshift = T.q_base & 3u;
+        // ---- top: byte windows into LDS, per-tile state reset
+        window_store(gseq_s, L.gseq, tid);
+        window_store(rseq_s, L.rseq, tid);
+        window_store(qual_s, L.qual, tid);
+        if (tid < ST_COLS / 32) flags_s[tid] = 0u;
+        if (tid < ST_READS) first90_s[tid] = 0xFFFFFFFFu;
+        PT_MARK(0);
         __syncthreads();
-        const uint32_t seg_base = off_s[0][0], col_base = off_s[1][0], q_base = off_s[2][0];
-        uint32_t n = 1; // one read always fits: the host selects this kernel only for reads within the per-read limits
-        while (n < (uint32_t)ST_READS && r0 + n < rb1 && off_s[0][n + 1] - seg_base <= (uint32_t)ST_SEGS &&
-               off_s[1][n + 1] - col_base <= (uint32_t)ST_COLS && off_s[2][n + 1] - q_base <= (uint32_t)ST_QUAL)
-            ++n;
-        const uint32_t n_seg = off_s[0][n] - seg_base, n_col = off_s[1][n] - col_base, n_q = off_s[2][n] - q_base;
-        const uint32_t cshift = col_base & 3u, qshift = q_base & 3u;
-        // ---- stage the tile's read / graph / quality windows in LDS (coalesced dword loads)
-        stage_bytes(gseq_s, b.graph_seq, col_base, n_col, tid);
-        stage_bytes(rseq_s, b.algnseq, col_base, n_col, tid);
-        stage_bytes(qual_s, b.qual, q_base, n_q, tid);
+        PT_MARK(1);
+
+        // ---- B: prefix sums of log p_err over the tile's quality bytes.  No bounds checks: slots past the tile's
+        // T.n_q bytes receive sums nobody reads (prefix values at or below T.n_q do not depend on what follows).
         {
-            uint32_t *cs32 = reinterpret_cast<uint32_t *>(colseg_s);
-            uint32_t *qc32 = reinterpret_cast<uint32_t *>(qcol_s);
-            const uint32_t nc2 = (n_col + 1) >> 1, nc4 = (n_col + 3) >> 2;
+            const uint32_t i0 = tid * ST_QB;
+            double loc[ST_QB];
+            double run = 0.0;
 #pragma unroll
-            for (int it = 0; it < (ST_COLS / 2 + ST_THREADS - 1) / ST_THREADS; ++it) {
-                const uint32_t i = tid + it * ST_THREADS;
-                if (i < nc2) cs32[i] = 0xFFFFFFFFu;
-                if (i < nc4) qc32[i] = 0u;
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 1: one wave per read: quality prefix sums (DPP scan), then one lane per segment
-        for (uint32_t k = wave; k < n; k += ST_WAVES) {
-            const uint32_t r = r0 + k;
-            const uint32_t qoff = off_s[2][k] - q_base, QL = off_s[2][k + 1] - off_s[2][k];
-            const uint32_t A = b.read_algn_len[r];
-            const uint32_t colbase = off_s[1][k] - col_base;
-            const uint32_t ncols_k = off_s[1][k + 1] - off_s[1][k];
-            const double pinc = g.incmap[b.read_mapq[r]];
-            double *ps = ps_s[wave];
-            // prefix sums of log p_err over the read's quality bytes: each lane owns E consecutive bytes
-            // (E <= 4 since QL <= 256), one DPP wave scan over the lane totals
-            const uint32_t E = (QL + 63u) >> 6;
-            const uint32_t jb = lane * E;
-            double loc[4];
-            double tot = 0.0;
-            uint32_t hot = 0xFFFFFFFFu;
-#pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-                const uint32_t j = jb + e;
-                const bool in = e < E && j < QL;
-                const uint32_t qb = in ? qual_s[qoff + qshift + j] : 0u;
-                if (in && (int)(int8_t)qb >= 90) hot = min(hot, j);
-                if (in && j < ncols_k) { // quality by alignment column for phase 2, clamped as qscore_vec's index
-                    const int qi = (int)(int8_t)qb;
-                    qcol_s[colbase + j] = (uint8_t)(qi < 0 ? 0 : (qi > 99 ? 99 : qi));
+            for (int e = 0; e < ST_QB; ++e) {
+                const uint32_t qb = qual_s[qshift + i0 + e];
+                if ((int)(int8_t)qb >= 90) { // rare: Q >= 90 switches the read to the background error rate
+                    const uint32_t i = i0 + e, gq = T.q_base + i;
+                    if (i < T.n_q) {
+                        uint32_t k = 0;
+                        for (uint32_t t = 1; t < T.n; ++t) k += gq >= off_s[cur][2][t] ? 1u : 0u;
+                        atomicMin(&first90_s[k], gq - off_s[cur][2][k]);
+                    }
                 }
-                tot += in ? lq_s[qb] : 0.0;
-                loc[e] = tot;
+                run += lq_s[qb];
+                loc[e] = run;
             }
-            const double base_sum = wave_incl_scan(tot) - tot;
+            const double incl = wave_incl_scan(run);
+            const double before = incl - run;
 #pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-                const uint32_t j = jb + e;
-                if (e < E && j < QL) ps[j + 1] = base_sum + loc[e];
-            }
-            const uint64_t hot_lanes = __builtin_amdgcn_ballot_w64(hot != 0xFFFFFFFFu);
-            const uint32_t first90 =
-                hot_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)hot, (int)__builtin_ctzll(hot_lanes)) : 0xFFFFFFFFu;
-            if (lane == 0) ps[0] = 0.0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t s0 = off_s[0][k], s1 = off_s[0][k + 1];
-            for (uint32_t sb = s0; sb < s1; sb += 64) {
-                const uint32_t s = sb + lane;
-                if (s < s1) {
-                    const uint32_t ls = s - seg_base;
-                    const uint32_t start = b.seg_start[s], len = b.seg_len[s];
-                    const HcNodeDev nd = g.node_tab[b.seg_node[s]];
+            for (int e = 0; e < ST_QB; ++e) ps_s[i0 + e + 1] = before + loc[e];
+            if (lane == 63) wsum_s[wave] = incl;
+            if (tid == 0) ps_s[0] = 0.0;
+        }
+        if (has_next) header_publish(cur ^ 1u, r0 + T.n); // requested a tile ago
+        PT_MARK(2);
+        __syncthreads();
+        PT_MARK(3);
+
+        // ---- C: one lane per segment
+        double segU[ST_SEG_ITERS];
+        {
+            uint32_t seg_off_r[ST_READS]; // segment offsets of reads 1.. (wave uniform), for the segment -> read lookup
+#pragma unroll
+            for (int t = 1; t < ST_READS; ++t) seg_off_r[t] = (uint32_t)t < T.n ? off_s[cur][0][t] : 0xFFFFFFFFu;
+            const double ws0 = wsum_s[0], ws1 = wsum_s[1], ws2 = wsum_s[2];
+#pragma unroll
+            for (int it = 0; it < ST_SEG_ITERS; ++it) {
+                const uint32_t ls = tid + it * ST_THREADS;
+                segU[it] = 0.0;
+                if (ls < T.n_seg) {
+                    const uint32_t s = T.seg_base + ls;
+                    uint32_t k = 0;
+#pragma unroll
+                    for (int t = 1; t < ST_READS; ++t) k += s >= seg_off_r[t] ? 1u : 0u;
+                    const uint32_t colbase = off_s[cur][1][k] - T.col_base;
+                    const uint32_t qo = off_s[cur][2][k], QL = off_s[cur][2][k + 1] - qo, qoff = qo - T.q_base;
+                    const uint32_t A = rdA_s[cur][k];
+                    const double pinc = rdpinc_s[cur][k];
+                    const uint32_t start = L.start[it], len = L.len[it];
                     const uint32_t lo = min(start, QL), hi = min(start + A, QL);
-                    const double U = (ps[hi] - ps[lo]) + (double)(A - (hi - lo)) * lq0; // Q5 zero padding
-                    segS_s[ls] = -U; // phase 2 adds the column terms: the slot ends as D_m = S_m - U_m
+                    const uint32_t ilo = qoff + lo, ihi = qoff + hi;
+                    // P(i) = ps_s[i] + the totals of the waves before the one that wrote slot i
+                    double U = ps_s[ihi] - ps_s[ilo];
+                    U += (ilo <= 1u * ST_QW && ihi > 1u * ST_QW) ? ws0 : 0.0;
+                    U += (ilo <= 2u * ST_QW && ihi > 2u * ST_QW) ? ws1 : 0.0;
+                    U += (ilo <= 3u * ST_QW && ihi > 3u * ST_QW) ? ws2 : 0.0;
+                    U += (double)(A - (hi - lo)) * lq0; // Q5 zero padding
+                    segU[it] = U;
                     sumU += U;
-                    const uint32_t use_bep = (prm.use_bep || first90 < hi) ? 1u : 0u; // update_likelihood.cpp:42
-                    segpm_s[ls] = StSeg{(1.0 - pinc) * nd.mappability, nd.match, colbase + start, colbase, A, use_bep};
-                    const uint32_t cend = min(colbase + start + len, n_col);
-                    for (uint32_t c = colbase + start; c < cend; ++c) colseg_s[c] = (uint16_t)ls;
+                    const uint32_t use_bep = (prm.use_bep || first90_s[k] < hi) ? 1u : 0u; // update_likelihood.cpp:42
+                    const uint32_t cs = colbase + start;
+                    const uint32_t cl = cs < T.n_col ? min(len, T.n_col - cs) : 0u;
+                    const double pcm = (1.0 - pinc) * L.nd[it].mappability;
+                    segpm_s[ls] = prm.consensus ? StSegPm{0.0, (1.0 - prm.bep) * L.nd[it].match}
+                                                : StSegPm{1.0 - pcm, pcm * L.nd[it].match};
+                    seggeo_s[ls] = StSegGeo{(uint16_t)((cs + cl) | (use_bep << 15)), (int16_t)((int)colbase - (int)cs + (int)cshift),
+                                            (uint16_t)(cs + A), (int16_t)((int)qoff - (int)colbase + (int)qshift),
+                                            (uint16_t)(colbase + QL), 0};
+                    segS_s[ls] = 0.0;
+                    if (cl) {
+                        atomicOr(&flags_s[cs >> 5], 1u << (cs & 31u));
+                        colhead_s[cs] = (uint16_t)ls;
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // ps is rewritten by this wave's next read
         }
+        PT_MARK(4);
         __syncthreads();
+        PT_MARK(5);
 
-        // ---- phase 2: one lane per alignment column, flat over the tile; everything comes from LDS.
-        // Loads are issued up front and the arithmetic is unconditional (no early exits): the dependency chain is
-        // column -> {segment id, graph base, quality} -> segment record -> read base.
-        for (uint32_t c = tid; c < n_col; c += ST_THREADS) {
-            const uint32_t ls_raw = colseg_s[c];
-            const uint32_t gc = gseq_s[c + cshift];
-            const uint32_t q = qcol_s[c];
-            const bool in_seg = ls_raw != 0xFFFFu; // columns no mapping scores (Q6 tail) carry 0xFFFF
-            const uint32_t ls = in_seg ? ls_raw : 0u;
-            const StSeg sg = segpm_s[ls];
-            const double qsv = qs_s[q];
-            const uint32_t j = c - sg.cstart;
-            uint32_t rc = rseq_s[min(sg.rbase + j, n_col - 1) + cshift]; // Q4: read bases from the read start
-            rc = j < sg.A ? rc : 0u;
-            const bool valid = in_seg && is_acgt(gc) && is_acgt(rc); // process_mapping.cpp:62-63
-            const double e = sg.use_bep ? prm.bep : qsv;
-            const double eps = gc == rc ? e : 1.0 - e;          // get_p_obs_base.cpp:3-27
-            const double pobs = sg.match * (1.0 - eps);         // get_p_obs_base.cpp:67 with tv = ts = 0
-            const double bgv = bg_s[(rc >> 1) & 3u];
-            const double x = prm.consensus ? (1.0 - prm.bep) * pobs : (1.0 - sg.pcm) * bgv + sg.pcm * pobs;
-            const double t = log_pos(valid ? x : 1.0); // log(1) = 0 for the lanes that do not count
-            sumT += t;
+        // the next tile's data leaves HBM now and lands during phase D
+        StTile Tn = T;
+        StLoads Ln;
+        if (has_next) {
+            Tn = tile_extents(cur ^ 1u);
+            tile_request(Tn, Ln);
+            if (r0 + T.n + Tn.n < rb1) header_request(r0 + T.n + Tn.n);
+        }
+        PT_MARK(6);
+
+        // ---- D: one lane per alignment column, flat over the tile; everything comes from LDS
+        for (uint32_t c = tid; c < T.n_col; c += ST_THREADS) {
+            uint32_t w = c >> 5;
+            uint32_t fw = flags_s[w] & (0xFFFFFFFFu >> (31u - (c & 31u)));
+            const uint32_t gcode = code_s[gseq_s[c + cshift]];
+            if (__builtin_amdgcn_ballot_w64(fw == 0u && w > 0u)) // rare: the owner starts in an earlier 32-column word
+                while (fw == 0u && w > 0u) fw = flags_s[--w];
+            const uint32_t head = (w << 5) + 31u - (uint32_t)__builtin_clz(fw | 1u);
+            // every LDS read below is unconditional (indices clamped, results selected afterwards): the reads of one
+            // column then overlap instead of each waiting behind its own branch
+            const uint32_t hv = colhead_s[min(head, (uint32_t)ST_COLS - 1u)];
+            const uint32_t ls = fw ? hv : (uint32_t)ST_SEGS - 1u;
+            const StSegGeo geo = seggeo_s[ls];
+            const StSegPm pm = segpm_s[ls];
+            const uint32_t cend = geo.cend_bep & 0x7FFFu;
+            const bool in_seg = fw != 0u && c < cend; // columns no mapping scores (Q6 tail) have no owner
+            const uint32_t ri = min((uint32_t)((int)c + geo.rshift), (uint32_t)ST_COLS + 7u);
+            const uint32_t qi = min((uint32_t)((int)c + geo.qshift), (uint32_t)ST_QUAL + 7u);
+            const uint32_t rraw = rseq_s[ri];
+            const int qraw = (int)(int8_t)qual_s[qi];
+            const uint32_t rlut = code_s[rraw];
+            const uint32_t rcode = c < geo.aend ? rlut : 4u;
+            int q = c < geo.qend ? qraw : 0;
+            q = q < 0 ? 0 : (q > 99 ? 99 : q);        // qscore_vec's index
+            q = (geo.cend_bep & 0x8000u) ? 100 : q;   // slot 100 holds the background error rate
+            const bool valid = in_seg && (gcode | rcode) < 4u; // process_mapping.cpp:62-63
+            const double e = qs_s[q];
+            const double bgv = bg_s[rlut & 3u];
+            const double om = gcode == rcode ? 1.0 - e : e;    // 1 - eps: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0
+            const double x = pm.wbg * bgv + pm.wobs * om;      // process_mapping.cpp:66-75
+#ifdef VGAN_EXP_NOLOG
+            const double t = valid ? x : 1.0;
+#else
+            const double t = log_tab(valid ? x : 1.0, logtab_s); // log(1) = 0 for the lanes that do not count
+#endif
+#ifndef VGAN_EXP_NOATOMIC
             if (valid) unsafeAtomicAdd(&segS_s[ls], t);
+#endif
         }
+        PT_MARK(7);
+        if (has_next) tile_gather(Tn, Ln); // the node ids arrived during D
+        PT_MARK(8);
         __syncthreads();
+        PT_MARK(9);
 
-        // ---- phase 3: one lane per segment
-        for (uint32_t ls = tid; ls < n_seg; ls += ST_THREADS) {
-            if (segD_out) segD_out[seg_base + ls] = segS_s[ls];
+        // ---- E: one lane per segment
+#pragma unroll
+        for (int it = 0; it < ST_SEG_ITERS; ++it) {
+            const uint32_t ls = tid + it * ST_THREADS;
+            if (ls < T.n_seg) {
+                const double S = segS_s[ls];
+                sumT += S;
+                if (segD_out) segD_out[T.seg_base + ls] = S - segU[it];
+            }
         }
-        r0 += n;
-        // the next tile's barriers order phase 3 against the next phase 1 (phase 3 touches segS/segU only)
+        PT_MARK(10);
+        if (!has_next) break;
+        // the next tile's barriers order E against its C (E reads segS_s only)
+        r0 += T.n;
+        T = Tn;
+        L = Ln;
+        cur ^= 1u;
     }
+#ifdef VGAN_PHASE_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&hc_phase_cycles[i], pt_acc[i]);
+#endif
     sumT = wave_sum(sumT);
     sumU = wave_sum(sumU);
     if (lane == 0 && totals) {
@@ -560,6 +750,17 @@ __global__ __launch_bounds__(256) void hc_posterior_kernel(const double *__restr
     const double part = block_lse(final_vec, sets + (size_t)blockIdx.x * set_words, n_paths, sh);
     if (threadIdx.x == 0) conf[blockIdx.x] = exp(part - total);
 }
+
+#ifdef VGAN_PHASE_TIMING
+extern "C" int vgan_hc_debug_phase_cycles(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hc_phase_cycles), sizeof(hc_phase_cycles)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hc_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------- launchers
 void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, bool tiled, double *segS,
