@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGAN_ABI_VERSION 1
+#define VGAN_ABI_VERSION 2
 
 enum {
     VGAN_OK = 0,
@@ -137,13 +137,15 @@ typedef struct vgan_hc_batch {
     const uint8_t *algnseq;       /* [n_cols] ASCII path_string with '-' at deletions */
     const uint8_t *qual;          /* [n_qual] raw phred */
     int32_t on_device;            /* 0: host pointers (copied by accumulate); 1: device pointers (zero copy) */
-    /* largest per-read extents in the batch (vgan_hc_flatten fills them); 0 = unknown.  Batches whose reads fit
-     * 256 columns / 256 quality bytes / 128 segments take the LDS-tiled kernel, others the general one. */
-    uint32_t max_read_cols, max_read_qual, max_read_segs;
+    /* Reads [0, n_tileable) satisfy the tile contract below and take the LDS-tiled kernel; the others take the
+     * general kernel (any length, overlapping segments).  0 is always valid.  vgan_hc_flatten orders the batch
+     * accordingly (tileable reads first). */
+    uint32_t n_tileable;
+    const uint32_t *read_src;     /* [n_reads] index of the read in the alignment set, or NULL (not used by the device) */
 } vgan_hc_batch;
-/* Batch contract: read_*_off ascending; the segments of a read ascend in seg_start; when max_read_* are set the
- * column ranges [seg_start, seg_start+seg_len) of one read must not overlap (vgan_hc_flatten reports 0 = unknown
- * for batches where they do, which routes them to the general kernel). */
+/* Batch contract: read_*_off ascending; the segments of a read ascend in seg_start.
+ * Tile contract (reads below n_tileable): at most 256 columns, 256 quality bytes and 128 segments; |algnseq| equals the
+ * length of the read's graph sequence; the column ranges [seg_start, seg_start+seg_len) of the read do not overlap. */
 
 typedef struct vgan_hc_host_batch vgan_hc_host_batch; /* opaque owner of a host-side batch */
 

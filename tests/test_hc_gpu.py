@@ -77,9 +77,11 @@ def test_bundled_alignments_as_plumbing(golden_dir):
 
 @pytest.mark.parametrize("kw", [dict(), dict(background_error_prob=0.01, use_background_error_prob=True, is_consensus_fasta=True),
                                 dict(background_error_prob=0.3)])
-def test_small_synth_all_modes_vs_faithful_oracle(kw):
+def test_small_synth_all_modes_vs_faithful_oracle(kw, tmp_path):
     g = hc.synth_graph(seed=21, genome_len=1500, n_nodes=1000, n_paths=200)
-    a = hc.synth_reads(g, 120, seed=5, read_len=150, indel_rate=0.2, softclip_rate=0.2)
+    # reads for the tiled kernel and, beyond 256 columns, for the general one, in one batch
+    a = util.concat_alnsets(tmp_path, hc.synth_reads(g, 90, seed=5, read_len=150, indel_rate=0.2, softclip_rate=0.2),
+                            hc.synth_reads(g, 30, seed=6, read_len=330, indel_rate=0.2, softclip_rate=0.2))
     og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
     b = hc.HostBatch(g, a)
     ctx = hc.HcContext(g, **kw)
@@ -92,16 +94,43 @@ def test_small_synth_all_modes_vs_faithful_oracle(kw):
         ctx.accumulate(b)
         assert util.rel_err(ctx.finalize(), ref) < RTOL, mode
     ll = ctx.read_loglik(b)
-    k = 0
+    src = b.read_src  # the batch holds the tileable reads first: map back to the alignment set
+    assert 0 < b.n_tileable < b.n_reads and sorted(src.tolist()) == sorted(set(src.tolist()))
     ident = a.arrays()["identity"]
-    for r in range(a.n_reads):
-        rc, refr, _ = orc.hc_read(og, oa, r, p)
-        if rc != 0 or ident[r] < 1e-10:
-            continue
-        if k % 7 == 0:
-            assert util.rel_err(ll[k], refr.astype(np.float64)) < 1e-11, r
-        k += 1
-    assert k == b.n_reads
+    kept = [r for r in range(a.n_reads) if ident[r] >= 1e-10 and orc.hc_read(og, oa, r, p)[0] == 0]
+    assert sorted(src.tolist()) == kept
+    for k in range(0, b.n_reads, 5):
+        rc, refr, _ = orc.hc_read(og, oa, int(src[k]), p)
+        assert rc == 0
+        assert util.rel_err(ll[k], refr.astype(np.float64)) < 1e-11, (k, src[k])
+
+
+@pytest.mark.parametrize("n_nodes,read_len", [(60, 150), (400, 100), (3000, 250)])
+def test_tiled_and_general_kernels_agree_per_segment(n_nodes, read_len):
+    """D_m from the LDS-tiled kernel (through NODE_WEIGHTS sums per node) against S_m - U_m of the general kernel, on
+    graphs with long nodes (owner marks across 32-column words) and short ones; regular reads only."""
+    g = hc.synth_graph(seed=77, genome_len=3000, n_nodes=n_nodes, n_paths=96)
+    a = hc.synth_reads(g, 4000, seed=9, read_len=read_len, indel_rate=0.0, softclip_rate=0.0)
+    b = hc.HostBatch(g, a)
+    assert b.n_tileable == b.n_reads > 0
+    ctx = hc.HcContext(g)
+    S, U = ctx.segment_scalars(b)  # general kernel
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    _, ref, _ = orc.hc_run(og, oa, n_threads=8, faithful=False)
+    for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ):
+        ctx.reset()
+        ctx.set_mode(mode)
+        ctx.accumulate(b)  # tiled kernel
+        got = ctx.finalize()
+        assert util.rel_err(got, ref) < RTOL
+    # the same final vector from the general kernel's S and U: final[p] = sum S - sum_{p unsupported} (S - U)
+    arr = b.arrays()
+    um = util.unsupported_mask(g)  # [rows][P] bool
+    D = S - U
+    W = np.zeros(um.shape[0])
+    np.add.at(W, arr["seg_node"], D)
+    want = S.sum() - um.T.astype(np.float64) @ W
+    assert util.rel_err(got, want) < 1e-12
 
 
 def _aln(seq, quals, node_edits, mapq=60):
@@ -134,12 +163,14 @@ def test_closed_form_kats_and_edge_cases():
     b = hc.HostBatch(g, a)
     assert b.n_reads == len(alns)
     ll = ctx.read_loglik(b)
+    src = b.read_src.tolist()  # the 1600-column read is not tileable and sits last in the batch
+    assert src == [0, 1, 2, 4, 3] and b.n_tileable == 4
     assert ll[0, 0] == pytest.approx(-4.03019902453559e-4, rel=1e-12)
     assert ll[0, 1] == pytest.approx(-36.8413614879047, rel=1e-13)
-    for r in range(len(alns)):
+    for k, r in enumerate(src):
         rc, ref, _ = orc.hc_read(og, oa, r)
         assert rc == 0
-        assert util.rel_err(ll[r], ref.astype(np.float64)) < 1e-12, r
+        assert util.rel_err(ll[k], ref.astype(np.float64)) < 1e-12, r
     check_final(ctx, b, og, oa, faithful=True)
     # empty batch and empty accumulators: final = 0, posterior of all-zero vector is 1 (oplusInitnatl quirk Q11)
     empty = hc.HostBatch(g, a, 0, 0)

@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libvgan_gpu.so does not export %s" % name
     assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
-    assert L.vgan_abi_version() == 1
+    m = re.search(r"#define VGAN_ABI_VERSION (\d+)", hdr)
+    assert m and L.vgan_abi_version() == int(m.group(1))
 
 
 def test_no_device_is_an_error_not_a_fallback(golden_dir):
@@ -197,3 +198,32 @@ def test_sidecar_loaders_match_oracle(tmp_path):
     n = L.orc_load_mappabilities(open(tmp_path / "mappability.tsv", "rb").read(), mp.ctypes.data_as(C.c_void_p),
                                  C.c_int64(len(mp)))
     assert n == len(g.mappability) and np.array_equal(mp[:n], g.mappability)
+
+
+def test_flatten_puts_tileable_reads_first(tmp_path):
+    """vgan_hc_flatten orders a batch as [reads satisfying the tile contract | the others] and reports the split point;
+    read_src maps batch order back to the alignment set."""
+    from vgan_amd import haplocart as hc
+    import util
+    g = hc.synth_graph(seed=3, genome_len=2000, n_nodes=900, n_paths=64)
+    short = hc.synth_reads(g, 1500, seed=4, read_len=120, indel_rate=0.3, softclip_rate=0.2)
+    long_reads = hc.synth_reads(g, 40, seed=5, read_len=400, indel_rate=0.0, softclip_rate=0.0)
+    short2 = hc.synth_reads(g, 1500, seed=6, read_len=250, indel_rate=0.1, softclip_rate=0.1)
+    mixed = util.concat_alnsets(tmp_path, short, long_reads, short2)
+    assert mixed.n_reads == 3040
+    for alns, kind in ((mixed, "mixed"), (long_reads, "general"), (short, "tiled")):
+        b = hc.HostBatch(g, alns, n_threads=3)
+        arr = b.arrays()
+        nt = b.n_tileable
+        src = b.read_src
+        assert len(set(src.tolist())) == b.n_reads and b.stats.n_out == b.n_reads
+        assert {"mixed": 0 < nt < b.n_reads, "general": nt < b.n_reads // 2, "tiled": nt == b.n_reads}[kind]
+        so, co, qo = arr["read_seg_off"], arr["read_col_off"], arr["read_qual_off"]
+        for r in range(b.n_reads):
+            cols = int(co[r + 1] - co[r])
+            st = arr["seg_start"][so[r]:so[r + 1]].astype(np.int64)
+            ln = arr["seg_len"][so[r]:so[r + 1]].astype(np.int64)
+            ok = (cols <= 256 and qo[r + 1] - qo[r] <= 256 and len(st) <= 128 and np.all(st[1:] >= st[:-1] + ln[:-1]))
+            assert ok == (r < nt), (r, nt, cols)
+        # within each part the input order is kept
+        assert np.all(np.diff(src[:nt].astype(np.int64)) > 0) and np.all(np.diff(src[nt:].astype(np.int64)) > 0)

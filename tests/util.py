@@ -36,3 +36,21 @@ def orc_graph_nodes_only(g):
 def orc_euka_db_from_product(db):
     return orc.EukaDb(db.clade_dist.copy(), db.bin_off.astype(np.int32), db.bin_lo.copy(), db.bin_hi.copy(),
                       db.bin_entropy.copy())
+
+
+def unsupported_mask(g):
+    """[rows][P] bool: path p is NOT supported by node row (the complement of pathsgo over the real paths)."""
+    return np.asarray(g.pathsgo())[:, :g.n_paths] == 0
+
+
+def concat_alnsets(tmp_path, *sets):
+    """One alignment set holding the reads of all `sets` in order (through GAM files: gzip members concatenate)."""
+    from vgan_amd import haplocart as hc
+    blob = b""
+    for i, a in enumerate(sets):
+        f = str(tmp_path / ("part%d.gam" % i))
+        a.write_gam(f)
+        blob += open(f, "rb").read()
+    out = str(tmp_path / "all.gam")
+    open(out, "wb").write(blob)
+    return hc.AlnSet.read_gam(out)

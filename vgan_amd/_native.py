@@ -34,8 +34,8 @@ class HcBatch(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("n_segments", C.c_uint32), ("n_cols", C.c_uint64), ("n_qual", C.c_uint64),
                 ("read_seg_off", vp), ("read_col_off", vp), ("read_qual_off", vp), ("read_algn_len", vp),
                 ("read_mapq", vp), ("seg_node", vp), ("seg_start", vp), ("seg_len", vp), ("graph_seq", vp),
-                ("algnseq", vp), ("qual", vp), ("on_device", C.c_int32), ("max_read_cols", C.c_uint32),
-                ("max_read_qual", C.c_uint32), ("max_read_segs", C.c_uint32)]
+                ("algnseq", vp), ("qual", vp), ("on_device", C.c_int32), ("n_tileable", C.c_uint32),
+                ("read_src", vp)]
 
 
 class FlattenStats(C.Structure):

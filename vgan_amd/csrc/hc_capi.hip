@@ -219,11 +219,6 @@ int stage_batch(vgan_hc_ctx *c, const vgan_hc_batch *b, HcBatchDev &d) {
     return VGAN_OK;
 }
 
-bool tiled_ok(const vgan_hc_batch *b) {
-    return b->max_read_cols > 0 && b->max_read_cols <= HC_TILE_MAX_READ_COLS && b->max_read_qual <= HC_TILE_MAX_READ_QUAL &&
-           b->max_read_segs > 0 && b->max_read_segs <= HC_TILE_MAX_READ_SEGS;
-}
-
 int check_batch(const vgan_hc_batch *b) {
     if (!b) return fail(VGAN_EINVAL, "null batch");
     if (b->n_reads == 0) return VGAN_OK;
@@ -428,7 +423,7 @@ extern "C" int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *b) {
     if ((rc = c->segD.reserve(b->n_segments))) return rc;
     {
         ScopedTimer t(c, VGAN_HC_K_SEGMENT);
-        launch_hc_segments(c->g, d, c->prm, tiled_ok(b), nullptr, nullptr, c->segD.p, c->totals.p, c->stream);
+        launch_hc_segments(c->g, d, c->prm, b->n_tileable, nullptr, nullptr, c->segD.p, c->totals.p, c->stream);
     }
     if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) {
         ScopedTimer t(c, VGAN_HC_K_NODEACC);
@@ -451,7 +446,7 @@ extern "C" int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *b, d
     HcBatchDev d{};
     if ((rc = stage_batch(c, b, d))) return rc;
     if ((rc = c->segS.reserve(b->n_segments)) || (rc = c->segU.reserve(b->n_segments))) return rc;
-    launch_hc_segments(c->g, d, c->prm, tiled_ok(b), c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(S, c->segS.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(U, c->segU.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
@@ -471,7 +466,7 @@ extern "C" int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *b, doubl
     const size_t n = (size_t)b->n_reads * c->P;
     if ((rc = c->segS.reserve(b->n_segments + 1)) || (rc = c->segU.reserve(b->n_segments + 1)) || (rc = c->dump.reserve(n)))
         return rc;
-    launch_hc_segments(c->g, d, c->prm, tiled_ok(b), c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
     launch_hc_read_loglik(c->g, d, c->segS.p, c->segU.p, c->dump.p, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, c->dump.p, n * 8, hipMemcpyDeviceToHost, c->stream));

@@ -54,12 +54,14 @@ struct HcParamsDev {
     int consensus;
 };
 
-// per-read limits of the LDS-tiled segment kernel
+// per-read limits of the LDS-tiled segment kernel (the tile contract of include/vgan_gpu.h; flatten.cpp applies them)
 constexpr uint32_t HC_TILE_MAX_READ_COLS = 256;
 constexpr uint32_t HC_TILE_MAX_READ_QUAL = 256;
 constexpr uint32_t HC_TILE_MAX_READ_SEGS = 128;
 
-void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, bool tiled, double *segS,
+// reads [0, n_tileable) go through the LDS-tiled kernel (D_m only), the rest -- or everything when S_m / U_m are asked
+// for separately -- through the general one
+void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable, double *segS,
                         double *segU, double *segD, double *totals, hipStream_t st);
 int launch_hc_nodeacc(const uint32_t *seg_node, const double *segD, uint32_t n_items, uint32_t rows, double *nodeW,
                       hipStream_t st);

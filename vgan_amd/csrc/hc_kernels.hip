@@ -51,6 +51,7 @@ constexpr int SEG_WAVES = 4;
 constexpr int SEG_MAXQ = 1024;
 
 __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
+                                                                             uint32_t r_begin,
                                                                              double *__restrict__ segS,
                                                                              double *__restrict__ segU,
                                                                              double *__restrict__ segD,
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
     double *ps = ps_s[wave];
     double sumS = 0.0, sumU = 0.0;
 
-    for (uint32_t r = blockIdx.x * SEG_WAVES + wave; r < b.n_reads; r += gridDim.x * SEG_WAVES) {
+    for (uint32_t r = r_begin + blockIdx.x * SEG_WAVES + wave; r < b.n_reads; r += gridDim.x * SEG_WAVES) {
         const uint32_t seg0 = b.read_seg_off[r], seg1 = b.read_seg_off[r + 1];
         const uint32_t col0 = b.read_col_off[r];
         const uint32_t q0 = b.read_qual_off[r];
@@ -157,6 +158,7 @@ constexpr int ST_SEGS = 512;  //                        segments
 constexpr int ST_QB = ST_QUAL / ST_THREADS;         // quality bytes per lane in phase B
 constexpr int ST_QW = ST_QB * 64;                   // quality bytes per wave in phase B
 constexpr int ST_SEG_ITERS = ST_SEGS / ST_THREADS;  // segments per lane in phases C and E
+static_assert((ST_SEGS & (ST_SEGS - 1)) == 0, "segment index mask");
 static_assert(ST_QB * ST_THREADS == ST_QUAL && ST_SEG_ITERS * ST_THREADS == ST_SEGS && ST_WAVES == 4,
               "tile shape");
 static_assert(ST_COLS <= 2 * 4 * ST_THREADS - 8 && ST_QUAL <= 2 * 4 * ST_THREADS - 8, "byte windows: two dwords per thread");
@@ -226,7 +228,7 @@ struct StLoads { // one tile's HBM data in flight
 };
 
 __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
-                                                                      uint32_t reads_per_block,
+                                                                      uint32_t n_tileable, uint32_t reads_per_block,
                                                                       double *__restrict__ segD_out,
                                                                       double *__restrict__ totals) {
     __shared__ double lq_s[256];
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     double sumT = 0.0, sumU = 0.0; // sum of the column terms (= sum of S_m) and of U_m, each without cancellation
 
     const uint32_t rb0 = blockIdx.x * reads_per_block;
-    const uint32_t rb1 = min(b.n_reads, rb0 + reads_per_block);
+    const uint32_t rb1 = min(n_tileable, rb0 + reads_per_block);
     if (rb0 >= rb1) return;
 
     // header values travel in registers of threads 0..ST_READS until they are published in LDS
@@ -428,9 +430,13 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                                             (uint16_t)(cs + A), (int16_t)((int)qoff - (int)colbase + (int)qshift),
                                             (uint16_t)(colbase + QL), 0};
                     segS_s[ls] = 0.0;
-                    if (cl) {
+                    if (cl) { // owner marks: the segment's first column, and column 0 of every further 32-column word it covers
                         atomicOr(&flags_s[cs >> 5], 1u << (cs & 31u));
                         colhead_s[cs] = (uint16_t)ls;
+                        for (uint32_t bc = (cs | 31u) + 1u; bc < cs + cl; bc += 32u) {
+                            atomicOr(&flags_s[bc >> 5], 1u);
+                            colhead_s[bc] = (uint16_t)ls;
+                        }
                     }
                 }
             }
@@ -451,16 +457,14 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
 
         // ---- D: one lane per alignment column, flat over the tile; everything comes from LDS
         for (uint32_t c = tid; c < T.n_col; c += ST_THREADS) {
-            uint32_t w = c >> 5;
-            uint32_t fw = flags_s[w] & (0xFFFFFFFFu >> (31u - (c & 31u)));
+            // owner = the nearest mark at or below the column within its 32-column word (C marks every word a segment covers)
+            const uint32_t w = c >> 5;
+            const uint32_t fw = flags_s[w] & (0xFFFFFFFFu >> (31u - (c & 31u)));
             const uint32_t gcode = code_s[gseq_s[c + cshift]];
-            if (__builtin_amdgcn_ballot_w64(fw == 0u && w > 0u)) // rare: the owner starts in an earlier 32-column word
-                while (fw == 0u && w > 0u) fw = flags_s[--w];
-            const uint32_t head = (w << 5) + 31u - (uint32_t)__builtin_clz(fw | 1u);
-            // every LDS read below is unconditional (indices clamped, results selected afterwards): the reads of one
+            const uint32_t head = (w << 5 | 31u) - (uint32_t)__builtin_clz(fw | 1u);
+            // every LDS read below is unconditional (indices in range, results selected afterwards): the reads of one
             // column then overlap instead of each waiting behind its own branch
-            const uint32_t hv = colhead_s[min(head, (uint32_t)ST_COLS - 1u)];
-            const uint32_t ls = fw ? hv : (uint32_t)ST_SEGS - 1u;
+            const uint32_t ls = (uint32_t)colhead_s[head] & ((uint32_t)ST_SEGS - 1u);
             const StSegGeo geo = seggeo_s[ls];
             const StSegPm pm = segpm_s[ls];
             const uint32_t cend = geo.cend_bep & 0x7FFFu;
@@ -480,9 +484,9 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             const double om = gcode == rcode ? 1.0 - e : e;    // 1 - eps: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0
             const double x = pm.wbg * bgv + pm.wobs * om;      // process_mapping.cpp:66-75
 #ifdef VGAN_EXP_NOLOG
-            const double t = valid ? x : 1.0;
+            const double t = x;
 #else
-            const double t = log_tab(valid ? x : 1.0, logtab_s); // log(1) = 0 for the lanes that do not count
+            const double t = log_tab(x, valid, logtab_s);
 #endif
 #ifndef VGAN_EXP_NOATOMIC
             if (valid) unsafeAtomicAdd(&segS_s[ls], t);
@@ -763,20 +767,23 @@ extern "C" int vgan_hc_debug_phase_cycles(unsigned long long *out, int reset) {
 #endif
 
 // ---------------------------------------------------------------------------------------------- launchers
-void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, bool tiled, double *segS,
+void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable, double *segS,
                         double *segU, double *segD, double *totals, hipStream_t st) {
     if (b.n_reads == 0) return;
-    if (tiled && !segS && !segU) { // the tiled kernel produces D_m only; separate S_m / U_m (debug API) come from the general one
-        // ~6 resident workgroups per CU; contiguous read ranges per workgroup
+    uint32_t nt = std::min(n_tileable, b.n_reads);
+    if (segS || segU) nt = 0; // the tiled kernel produces D_m only; separate S_m / U_m (debug API) come from the general one
+    if (nt) {
+        // ~6 workgroups per CU and launch round; contiguous read ranges per workgroup
         const uint32_t want_blocks = 256u * 6u * 2u;
-        uint32_t per = (b.n_reads + want_blocks - 1) / want_blocks;
+        uint32_t per = (nt + want_blocks - 1) / want_blocks;
         per = std::max(per, (uint32_t)ST_READS);
-        const uint32_t blocks = (b.n_reads + per - 1) / per;
-        hipLaunchKernelGGL(hc_segment_tile_kernel, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, per, segD, totals);
-    } else {
-        const uint32_t blocks =
-            (uint32_t)std::min<uint64_t>(((uint64_t)b.n_reads + SEG_WAVES - 1) / SEG_WAVES, 256u * 8u);
-        hipLaunchKernelGGL(hc_segment_general_kernel, dim3(blocks), dim3(SEG_WAVES * 64), 0, st, g, b, prm, segS, segU,
+        const uint32_t blocks = (nt + per - 1) / per;
+        hipLaunchKernelGGL(hc_segment_tile_kernel, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, totals);
+    }
+    if (nt < b.n_reads) {
+        const uint32_t rest = b.n_reads - nt;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)rest + SEG_WAVES - 1) / SEG_WAVES, 256u * 8u);
+        hipLaunchKernelGGL(hc_segment_general_kernel, dim3(blocks), dim3(SEG_WAVES * 64), 0, st, g, b, prm, nt, segS, segU,
                            segD, totals);
     }
 }

@@ -92,6 +92,7 @@ struct vgan_hc_host_batch {
     std::vector<uint32_t> seg_node;
     std::vector<uint16_t> seg_start, seg_len;
     std::vector<uint8_t> graph_seq, algnseq, qual;
-    bool irregular = false; // some read has |graph_seq| != |algnseq|: its segments may overlap in columns
+    std::vector<uint32_t> read_src; // index of each batch read in the alignment set
+    uint32_t n_tileable = 0;        // reads [0, n_tileable) satisfy the tile contract (include/vgan_gpu.h)
     void fill(vgan_hc_batch *b) const;
 };

@@ -34,12 +34,8 @@ void vgan_hc_host_batch::fill(vgan_hc_batch *b) const {
     b->algnseq = algnseq.data();
     b->qual = qual.data();
     b->on_device = 0;
-    for (size_t r = 0; r + 1 < read_seg_off.size(); ++r) {
-        b->max_read_cols = std::max(b->max_read_cols, read_col_off[r + 1] - read_col_off[r]);
-        b->max_read_qual = std::max(b->max_read_qual, read_qual_off[r + 1] - read_qual_off[r]);
-        b->max_read_segs = std::max(b->max_read_segs, read_seg_off[r + 1] - read_seg_off[r]);
-    }
-    if (irregular) b->max_read_cols = b->max_read_qual = b->max_read_segs = 0;
+    b->n_tileable = n_tileable;
+    b->read_src = read_src.size() == read_algn_len.size() ? read_src.data() : nullptr;
 }
 
 namespace {
@@ -135,15 +131,19 @@ int vgan::reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Reco
 
 namespace {
 
+// per-read limits of the device's LDS-tiled kernel (hc_device.h keeps the same numbers)
+constexpr size_t TILE_MAX_COLS = 256, TILE_MAX_QUAL = 256, TILE_MAX_SEGS = 128;
+
 struct Chunk {
-    vgan_hc_host_batch b;
+    vgan_hc_host_batch b;   // reads that satisfy the tile contract
+    vgan_hc_host_batch gen; // the others: indels / soft clips (|graph_seq| != |algnseq|, segments may overlap), long reads
     vgan_hc_flatten_stats st{};
 };
 
 void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, Chunk &c) {
     Recon rc;
-    auto &b = c.b;
-    { // size the chunk's arrays from the input volume so that they grow at most once or twice
+    { // size the chunk's arrays
+        auto &b = c.b; // from the input volume, so that they grow at most once or twice
         const size_t nr = (size_t)(r1 - r0), nm = (size_t)(a.map_off[r1] - a.map_off[r0]);
         const size_t nb = (size_t)(a.seq_off[r1] - a.seq_off[r0]), nq = (size_t)(a.qual_off[r1] - a.qual_off[r0]);
         b.read_seg_off.reserve(nr + 1);
@@ -151,6 +151,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         b.read_qual_off.reserve(nr + 1);
         b.read_algn_len.reserve(nr);
         b.read_mapq.reserve(nr);
+        b.read_src.reserve(nr);
         b.seg_node.reserve(nm);
         b.seg_start.reserve(nm);
         b.seg_len.reserve(nm);
@@ -168,6 +169,8 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         const int64_t nm = a.map_off[r + 1] - a.map_off[r];
         const size_t A = rc.ps.size(), G = rc.gseq.size();
         if (!bad && (A > 65535 || G > 65535 || nm > 65535)) bad = BAD_RANGE;
+        const size_t n_qual_r = (size_t)(a.qual_off[r + 1] - a.qual_off[r]);
+        auto &b = (!bad && A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && (size_t)nm <= TILE_MAX_SEGS) ? c.b : c.gen;
         const size_t seg_mark = b.seg_node.size();
         if (!bad) {
             size_t pos = 0;
@@ -210,7 +213,6 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             c.st.n_clamped++;
         }
         const size_t region = std::max(A, G);
-        if (A != G) b.irregular = true;
         b.graph_seq.insert(b.graph_seq.end(), rc.gseq.begin(), rc.gseq.end());
         b.graph_seq.insert(b.graph_seq.end(), region - G, 0);
         b.algnseq.insert(b.algnseq.end(), rc.ps.begin(), rc.ps.end());
@@ -219,6 +221,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         b.qual.insert(b.qual.end(), q, q + (a.qual_off[r + 1] - a.qual_off[r]));
         b.read_algn_len.push_back((uint16_t)A);
         b.read_mapq.push_back((uint8_t)mq);
+        b.read_src.push_back((uint32_t)r);
         b.read_seg_off.push_back((uint32_t)b.seg_node.size());
         b.read_col_off.push_back((uint32_t)b.graph_seq.size());
         b.read_qual_off.push_back((uint32_t)b.qual.size());
@@ -250,28 +253,34 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
     for (auto &t : th) t.join();
     auto res = new vgan_hc_host_batch();
     vgan_hc_flatten_stats st{};
+    // output order: every chunk's tileable reads, then every chunk's other reads
+    std::vector<vgan_hc_host_batch *> parts;
+    for (auto &c : chunks) parts.push_back(&c.b);
+    for (auto &c : chunks) parts.push_back(&c.gen);
     uint64_t tot_cols = 0, tot_segs = 0, tot_qual = 0, tot_reads = 0;
     struct Base {
         size_t r, s, c, q;
     };
-    std::vector<Base> base(chunks.size());
-    for (size_t i = 0; i < chunks.size(); ++i) {
+    std::vector<Base> base(parts.size());
+    for (size_t i = 0; i < parts.size(); ++i) {
+        if (i == chunks.size()) res->n_tileable = (uint32_t)tot_reads;
         base[i] = {(size_t)tot_reads, (size_t)tot_segs, (size_t)tot_cols, (size_t)tot_qual};
-        tot_cols += chunks[i].b.graph_seq.size();
-        tot_segs += chunks[i].b.seg_node.size();
-        tot_qual += chunks[i].b.qual.size();
-        tot_reads += chunks[i].b.read_mapq.size();
+        tot_cols += parts[i]->graph_seq.size();
+        tot_segs += parts[i]->seg_node.size();
+        tot_qual += parts[i]->qual.size();
+        tot_reads += parts[i]->read_mapq.size();
     }
     if (tot_cols > 0xFFFFFFF0ull || tot_segs > 0xFFFFFFF0ull || tot_qual > 0xFFFFFFF0ull) {
         delete res;
         return fail(VGAN_ERANGE, "vgan_hc_flatten: batch exceeds 32-bit offsets; flatten fewer reads per batch");
     }
-    // one allocation per array, then every chunk is copied (offsets shifted) by its own thread
+    // one allocation per array, then every part is copied (offsets shifted) by its own thread
     res->read_seg_off.resize(tot_reads + 1);
     res->read_col_off.resize(tot_reads + 1);
     res->read_qual_off.resize(tot_reads + 1);
     res->read_algn_len.resize(tot_reads);
     res->read_mapq.resize(tot_reads);
+    res->read_src.resize(tot_reads);
     res->seg_node.resize(tot_segs);
     res->seg_start.resize(tot_segs);
     res->seg_len.resize(tot_segs);
@@ -279,8 +288,8 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
     res->algnseq.resize(tot_cols);
     res->qual.resize(tot_qual);
     res->read_seg_off[0] = res->read_col_off[0] = res->read_qual_off[0] = 0;
-    auto copy_chunk = [&](size_t i) {
-        auto &cb = chunks[i].b;
+    auto copy_part = [&](size_t i) {
+        auto &cb = *parts[i];
         const Base &bs = base[i];
         for (size_t k = 1; k < cb.read_seg_off.size(); ++k) {
             res->read_seg_off[bs.r + k] = cb.read_seg_off[k] + (uint32_t)bs.s;
@@ -292,21 +301,20 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
         };
         cp(res->read_algn_len, bs.r, cb.read_algn_len);
         cp(res->read_mapq, bs.r, cb.read_mapq);
+        cp(res->read_src, bs.r, cb.read_src);
         cp(res->seg_node, bs.s, cb.seg_node);
         cp(res->seg_start, bs.s, cb.seg_start);
         cp(res->seg_len, bs.s, cb.seg_len);
         cp(res->graph_seq, bs.c, cb.graph_seq);
         cp(res->algnseq, bs.c, cb.algnseq);
         cp(res->qual, bs.q, cb.qual);
-        const bool irr = cb.irregular;
         cb = vgan_hc_host_batch();
-        cb.irregular = irr;
     };
     {
         std::vector<std::thread> cth;
-        for (size_t i = 0; i < chunks.size(); ++i) {
-            if (chunks.size() == 1) copy_chunk(i);
-            else cth.emplace_back(copy_chunk, i);
+        for (size_t i = 0; i < parts.size(); ++i) {
+            if (chunks.size() == 1) copy_part(i);
+            else cth.emplace_back(copy_part, i);
         }
         for (auto &t : cth) t.join();
     }
@@ -316,7 +324,6 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
         st.n_unmapped += c.st.n_unmapped;
         st.n_bad += c.st.n_bad;
         st.n_clamped += c.st.n_clamped;
-        res->irregular = res->irregular || c.b.irregular;
     }
     st.n_segments = (int64_t)res->seg_node.size();
     st.n_cols = (int64_t)res->graph_seq.size();

@@ -40,14 +40,14 @@ extern "C" int vgan_synth_hc_graph(const vgan_synth_graph_cfg *cfg, vgan_graph *
     SplitMix64 rg(cfg->seed ^ 0x6763726170680001ull);
     std::string genome(L, 'A');
     for (auto &c : genome) c = BASES[rg.below(4)];
-    // backbone segmentation: lengths {1:.35, 2:.30, 3:.15, 4:.08, 5..8:.12}; stretched when N is too small
+    // backbone segmentation: lengths {1:.35, 2:.30, 3:.15, 4:.08, 5..8:.12}; stretched (long nodes) when N is too small
     std::vector<uint32_t> site_start, site_len;
     {
         const double min_mean = (double)L / std::max<uint32_t>(1, N * 6 / 10);
         for (uint32_t pos = 0; pos < L;) {
             const double u = rg.uniform();
             uint32_t len = u < .35 ? 1 : u < .65 ? 2 : u < .80 ? 3 : u < .88 ? 4 : 5 + (uint32_t)rg.below(4);
-            if (min_mean > 2.6) len = std::min<uint32_t>(8, (uint32_t)std::ceil(len * min_mean / 2.5));
+            if (min_mean > 2.6) len = std::min<uint32_t>(std::max<uint32_t>(8, (uint32_t)(min_mean * 4)), (uint32_t)std::ceil(len * min_mean / 2.5));
             len = std::min(len, L - pos);
             site_start.push_back(pos);
             site_len.push_back(len);

@@ -225,8 +225,19 @@ class HostBatch:
         c = self.c
         n = {"R1": c.n_reads + 1, "R": c.n_reads, "S": c.n_segments, "C": c.n_cols, "Q": c.n_qual}
         out = {name: _np_view(getattr(c, name), n[k], dt) for name, dt, k in _BATCH_FIELDS}
+        out["read_src"] = _np_view(c.read_src, c.n_reads, np.uint32)
         out["_owner"] = self
         return out
+
+    @property
+    def n_tileable(self):
+        """Reads [0, n_tileable) take the LDS-tiled kernel (vgan_hc_flatten puts them first)."""
+        return self.c.n_tileable
+
+    @property
+    def read_src(self):
+        """Index in the alignment set of each batch read (the batch is not in input order)."""
+        return np.array(self.arrays()["read_src"])
 
     def algorithmic_bytes(self, n_paths):
         """bases + quals + segment descriptors (+ one mask row per segment in PER_READ mode)."""
@@ -261,8 +272,8 @@ class DeviceBatch:
         for name, _, _ in _BATCH_FIELDS:
             setattr(c, name, self.t[name].data_ptr() if self.t[name].numel() else None)
         c.on_device = 1
-        c.max_read_cols, c.max_read_qual, c.max_read_segs = (host_batch.c.max_read_cols, host_batch.c.max_read_qual,
-                                                             host_batch.c.max_read_segs)
+        c.n_tileable = host_batch.c.n_tileable
+        c.read_src = None  # host-side bookkeeping only
         self.c = c
         self.n_reads, self.n_segments = c.n_reads, c.n_segments
 
