@@ -53,8 +53,8 @@ struct vgan_euka_ctx {
     uint32_t n_clades = 0, n_bins = 0;
     int32_t ltp = 5;
     Buf<uint32_t> bp, bin_off;
-    Buf<int32_t> bp_clade, bin_lo, bin_hi;
-    Buf<double> clade_dist, sub5p, sub3p, tables;
+    Buf<int32_t> bp_clade, bin_lo, bin_hi, node_clade;
+    Buf<double> clade_dist, sub5p, sub3p, tables, dmg_pair;
     // accumulators
     Buf<int32_t> clade_count;
     Buf<uint32_t> baseshift;
@@ -105,6 +105,28 @@ extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_v
             for (uint32_t j = db->bin_off[cl]; j < db->bin_off[cl + 1]; ++j)
                 if (node >= db->bin_lo[j] && node <= db->bin_hi[j]) bpc[i] = (int32_t)cl;
     }
+    // the same lookup per node id
+    std::vector<int32_t> node_clade;
+    if (!bp.empty() && bp.back() < (1u << 26)) {
+        node_clade.assign((size_t)bp.back() + 1, 0);
+        for (size_t i = 0; i < bp.size(); ++i) {
+            const size_t end = i + 1 < bp.size() ? bp[i + 1] : (size_t)bp.back() + 1;
+            const int32_t cl = bpc[i] >= 0 ? bpc[i] : 0;
+            for (size_t node = bp[i]; node < end; ++node) node_clade[node] = cl;
+        }
+    }
+    // damage matrix per (5' row, 3' row) pair: row o from the end whose diagonal is smaller (damage.cpp:18-36)
+    std::vector<double> pair((size_t)dmg->n5 * dmg->n3 * 20);
+    for (uint32_t i5 = 0; i5 < dmg->n5; ++i5)
+        for (uint32_t i3 = 0; i3 < dmg->n3; ++i3) {
+            double *e = &pair[((size_t)i5 * dmg->n3 + i3) * 20];
+            for (int o = 0; o < 4; ++o) {
+                const double *r5 = dmg->sub5p + (size_t)i5 * 16 + 4 * o, *r3 = dmg->sub3p + (size_t)i3 * 16 + 4 * o;
+                const double *row = r5[o] <= r3[o] ? r5 : r3;
+                for (int b = 0; b < 4; ++b) e[4 * b + o] = row[b];
+                e[16 + o] = ((row[0] + row[1]) + row[2]) + row[3];
+            }
+        }
     std::vector<double> tb(356);
     for (int Q = 0; Q < 100; ++Q) tb[(size_t)Q] = Q >= 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25; // Euka.cpp:38-51
     for (int Q = 0; Q < 256; ++Q) tb[(size_t)(100 + Q)] = 1 - pow(10, ((-1 * Q) * 0.1));     // miscfunc.h:215-216
@@ -124,13 +146,17 @@ extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_v
         (rc = c->bin_hi.upload(std::vector<int32_t>(db->bin_hi, db->bin_hi + c->n_bins))) ||
         (rc = c->sub5p.upload(std::vector<double>(dmg->sub5p, dmg->sub5p + (size_t)dmg->n5 * 16))) ||
         (rc = c->sub3p.upload(std::vector<double>(dmg->sub3p, dmg->sub3p + (size_t)dmg->n3 * 16))) ||
-        (rc = c->tables.upload(tb)) || (rc = c->clade_count.reserve((size_t)EUKA_REPLICAS * c->n_clades)) ||
+        (rc = c->tables.upload(tb)) || (rc = c->dmg_pair.upload(pair)) ||
+        (!node_clade.empty() && (rc = c->node_clade.upload(node_clade))) || (rc = c->clade_count.reserve((size_t)EUKA_REPLICAS * c->n_clades)) ||
         (rc = c->baseshift.reserve((size_t)EUKA_REPLICAS * c->n_clades * 2 * std::max(1, c->ltp) * 16)) ||
         (rc = c->bin_cov.reserve((size_t)EUKA_REPLICAS * std::max<uint32_t>(1, c->n_bins))) || (rc = c->n_bad.reserve(1)))
         return bail(rc);
     c->d.bp = c->bp.p;
     c->d.bp_clade = c->bp_clade.p;
     c->d.n_bp = (uint32_t)bp.size();
+    c->d.node_clade = c->node_clade.p;
+    c->d.n_node_clade = (uint32_t)node_clade.size();
+    c->d.dmg_pair = c->dmg_pair.p;
     c->d.clade_dist = c->clade_dist.p;
     c->d.bin_off = c->bin_off.p;
     c->d.bin_lo = c->bin_lo.p;
@@ -157,6 +183,8 @@ extern "C" void vgan_euka_destroy(vgan_euka_ctx *c) {
     c->bp.release();
     c->bin_off.release();
     c->bp_clade.release();
+    c->node_clade.release();
+    c->dmg_pair.release();
     c->bin_lo.release();
     c->bin_hi.release();
     c->clade_dist.release();

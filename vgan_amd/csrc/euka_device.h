@@ -11,10 +11,19 @@ namespace vgan {
 //   sub5p / sub3p   [n][4][4] fp64 damage matrices per distance from the 5' / 3' end (damage.cpp:66-136); positions
 //                   beyond the last row reuse it, so subDeamDiNuc[L][l] (128 MB in the reference) is never built:
 //                   row b1 comes from the 5' matrix at l when its diagonal <= the 3' matrix's at L-l-1 (damage.cpp:18-36).
+//   node_clade      the same lookup tabulated per node id (one load instead of a 13-step search) while the largest
+//                   bin bound stays below 2^26; n_node_clade = 0 otherwise (the kernel searches bp then).
+//   dmg_pair        [n5][n3][20] fp64: for every (5' row i5, 3' row i3) pair the selected 4x4 matrix, TRANSPOSED
+//                   (MT[read base][original base]), followed by its four row sums.  Model 1 needs, per original base o,
+//                   sum_b M[o][b] * w[b] with w = qs/3 except w[read base] = 1 - qs, i.e. w_miss * rowsum[o] +
+//                   (w_hit - w_miss) * M[o][read base]: two 32-byte reads per column instead of sixteen 16-byte ones.
 struct EukaDev {
     const uint32_t *bp;
     const int32_t *bp_clade;
     uint32_t n_bp;
+    const int32_t *node_clade;
+    uint32_t n_node_clade;
+    const double *dmg_pair;
     const double *clade_dist;
     const uint32_t *bin_off;
     const int32_t *bin_lo, *bin_hi;

@@ -60,15 +60,19 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         int32_t c_n = 0;
         {
             const uint32_t node = b.map_node[m0];
-            uint32_t lo = 0, hi = d.n_bp; // first breakpoint > node
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (d.bp[mid] <= node) lo = mid + 1;
-                else hi = mid;
-            }
-            if (lo > 0) {
-                const int32_t c = d.bp_clade[lo - 1];
-                if (c >= 0) c_n = c;
+            if (d.n_node_clade) {
+                c_n = d.node_clade[min(node, d.n_node_clade - 1u)];
+            } else {
+                uint32_t lo = 0, hi = d.n_bp; // first breakpoint > node
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (d.bp[mid] <= node) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo > 0) {
+                    const int32_t c = d.bp_clade[lo - 1];
+                    if (c >= 0) c_n = c;
+                }
             }
         }
         const double pair_dist = d.clade_dist[c_n];
@@ -112,23 +116,23 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                     if (n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
                     const int gi = acgt_index(gc), ri = acgt_index(rc);
                     const uint32_t nn = min(n, Lseq - 1u);
-                    const double *m5 = d.sub5p + 16u * min(nn, d.n5 - 1u);
-                    const double *m3 = d.sub3p + 16u * min(Lseq - 1u - nn, d.n3 - 1u);
-                    // p = sum_bpd post[bpd] * w[bpd] with post = pre x M (:337-340, :385-394), accumulated row by row:
-                    // p = sum_bpo pre[bpo] * (M[bpo] . w), so only one matrix row is live at a time
+                    const double *e = d.dmg_pair + 20u * (min(nn, d.n5 - 1u) * d.n3 + min(Lseq - 1u - nn, d.n3 - 1u));
+                    // p = sum_o pre[o] * sum_b M[o][b] * w[b] (:337-340, :385-394), w = w_miss except w[read base] = w_hit
                     const double w_hit = 1.0 - qs, w_miss = qs / 3.0;
+                    const double2 rs01 = *reinterpret_cast<const double2 *>(e + 16);
+                    const double2 rs23 = *reinterpret_cast<const double2 *>(e + 18);
+                    const double *col = e + 4 * max(ri, 0); // M[.][read base]
+                    const double2 c01 = *reinterpret_cast<const double2 *>(col);
+                    const double2 c23 = *reinterpret_cast<const double2 *>(col + 2);
+                    const double dw = ri < 0 ? 0.0 : w_hit - w_miss; // a read base outside ACGT matches no column
+                    const double dot[4] = {w_miss * rs01.x + dw * c01.x, w_miss * rs01.y + dw * c01.y,
+                                           w_miss * rs23.x + dw * c23.x, w_miss * rs23.y + dw * c23.y};
                     double p = 0.0;
 #pragma unroll
                     for (int bpo = 0; bpo < 4; ++bpo) {
                         // :312-318; a graph base outside ACGT has no t_T_ratio entry (0)
                         const double pre = gi < 0 ? 0.0 : (bpo == gi ? 1.0 - pair_dist : pair_dist * tT_ratio(gi, bpo));
-                        const double *row5 = m5 + 4 * bpo, *row3 = m3 + 4 * bpo;
-                        const double *row = row5[bpo] <= row3[bpo] ? row5 : row3; // damage.cpp:18-36
-                        const double2 r01 = *reinterpret_cast<const double2 *>(row);
-                        const double2 r23 = *reinterpret_cast<const double2 *>(row + 2);
-                        const double dot = ((r01.x * (ri == 0 ? w_hit : w_miss) + r01.y * (ri == 1 ? w_hit : w_miss)) +
-                                            r23.x * (ri == 2 ? w_hit : w_miss)) + r23.y * (ri == 3 ? w_hit : w_miss);
-                        p += pre * dot;
+                        p += pre * dot[bpo];
                     }
                     a1 = p;
                     l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
@@ -185,12 +189,18 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         if (pass) { // bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546)
             const uint32_t b0 = d.bin_off[c_n], b1 = d.bin_off[c_n + 1];
             const double inv = 1.0 / (double)(m1 - m0);
-            for (uint32_t mb = m0; mb < m1; mb += 64) {
-                const uint32_t mi = mb + lane;
-                const int32_t node = mi < m1 ? (int32_t)b.map_node[mi] : -1;
-                for (uint32_t j = b0; j < b1; ++j) {
-                    const uint64_t hit = __builtin_amdgcn_ballot_w64(mi < m1 && node >= d.bin_lo[j] && node <= d.bin_hi[j]);
-                    if (hit && lane == 0) unsafeAtomicAdd(&bin_cov[j], (double)__builtin_popcountll(hit) * inv);
+            for (uint32_t jb = b0; jb < b1; jb += 64) { // lane j holds bin jb + j's bounds; the loop below reads them by lane
+                const uint32_t nb = min(64u, b1 - jb);
+                const int32_t my_lo = (uint32_t)lane < nb ? d.bin_lo[jb + lane] : 1;
+                const int32_t my_hi = (uint32_t)lane < nb ? d.bin_hi[jb + lane] : 0;
+                for (uint32_t mb = m0; mb < m1; mb += 64) {
+                    const uint32_t mi = mb + lane;
+                    const int32_t node = mi < m1 ? (int32_t)b.map_node[mi] : -1;
+                    for (uint32_t j = 0; j < nb; ++j) {
+                        const int32_t lo = __builtin_amdgcn_readlane(my_lo, (int)j), hi = __builtin_amdgcn_readlane(my_hi, (int)j);
+                        const uint64_t hit = __builtin_amdgcn_ballot_w64(mi < m1 && node >= lo && node <= hi);
+                        if (hit && lane == 0) unsafeAtomicAdd(&bin_cov[jb + j], (double)__builtin_popcountll(hit) * inv);
+                    }
                 }
             }
         }
