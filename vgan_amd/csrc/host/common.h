@@ -3,7 +3,12 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -18,11 +23,40 @@ const char *last_error();
 // whole file -> bytes; gzip/BGZF members are inflated when the magic is present
 bool read_file(const std::string &path, std::string &out, bool inflate_if_gzip = true);
 bool gunzip_members(const void *data, size_t n, std::string &out);
+struct ByteBuf;
+bool gunzip_members(const void *data, size_t n, ByteBuf &out); // large inputs: no zero fill, huge pages
 bool gzip_bytes(const std::string &in, std::string &out);
 bool write_file(const std::string &path, const std::string &bytes);
 bool file_exists(const std::string &path);
 // opens <path> or <path>.gz
 bool read_text_maybe_gz(const std::string &path, std::string &out);
+
+// Allocator for the front end's large arrays: default-initialises (resize() does not write, so the pages of a merged
+// array are first touched by the threads that fill it, not zeroed serially by the caller) and asks for transparent
+// huge pages on big blocks (512x fewer page faults where THP is in madvise mode).
+template <class T> struct BigAlloc {
+    using value_type = T;
+    BigAlloc() = default;
+    template <class U> BigAlloc(const BigAlloc<U> &) {}
+    T *allocate(size_t n);
+    void deallocate(T *p, size_t) { free(p); }
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const BigAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const BigAlloc<U> &) const { return false; }
+};
+void *big_alloc_bytes(size_t bytes); // util.cpp; throws std::bad_alloc
+template <class T> T *BigAlloc<T>::allocate(size_t n) { return static_cast<T *>(big_alloc_bytes(n * sizeof(T))); }
+template <class T> using BigVec = std::vector<T, BigAlloc<T>>;
+struct ByteBuf : BigVec<char> { // the few std::string operations the front end uses on byte arrays
+    void append(const char *p, size_t n) { insert(end(), p, p + n); }
+    void append(const ByteBuf &src, size_t pos, size_t n) { insert(end(), src.begin() + pos, src.begin() + pos + n); }
+    void assign(const char *p, size_t n) { BigVec<char>::assign(p, p + n); }
+    ByteBuf &operator+=(const std::string &s) {
+        insert(end(), s.begin(), s.end());
+        return *this;
+    }
+};
 
 struct SplitMix64 {
     uint64_t s;
@@ -50,6 +84,33 @@ namespace vgan {
 // reconstruct_graph_sequence (reference src/vgan_utils.h:6-79); 0 or a code for reads the reference dies on
 int reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Recon &o);
 
+// A file's bytes without a copy where the file can be mapped (util.cpp).
+struct MappedFile {
+    const void *p = nullptr;
+    size_t n = 0;
+    bool mapped = false;
+    std::string fallback;
+    MappedFile() = default;
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+    ~MappedFile();
+    bool open_path(const std::string &path);
+};
+
+// Phase timing of the host front end to stderr when VGAN_TIMING is set in the environment (developer aid).
+struct PhaseTimer {
+    const char *what;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(const char *w) : what(w), on(getenv("VGAN_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *phase) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vgan timing] %s: %s %.1f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 } // namespace vgan
 
 struct vgan_graph {
@@ -70,13 +131,13 @@ struct vgan_graph {
 };
 
 struct vgan_alnset {
-    std::vector<int64_t> seq_off{0}, qual_off{0}, name_off{0}, map_off{0}, edit_off{0}, e_seq_off{0};
-    std::string seq, qual, name, e_seq;
-    std::vector<int32_t> mapq;
-    std::vector<double> identity;
-    std::vector<int64_t> m_node, m_offset;
-    std::vector<uint8_t> m_rev;
-    std::vector<int32_t> e_from, e_to;
+    vgan::BigVec<int64_t> seq_off{0}, qual_off{0}, name_off{0}, map_off{0}, edit_off{0}, e_seq_off{0};
+    vgan::ByteBuf seq, qual, name, e_seq;
+    vgan::BigVec<int32_t> mapq;
+    vgan::BigVec<double> identity;
+    vgan::BigVec<int64_t> m_node, m_offset;
+    vgan::BigVec<uint8_t> m_rev;
+    vgan::BigVec<int32_t> e_from, e_to;
     int64_t n_reads() const { return (int64_t)mapq.size(); }
     void fill_view(vgan_alnset_view *v) const;
 };
@@ -86,13 +147,13 @@ void merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &out); // parts 
 }
 
 struct vgan_hc_host_batch {
-    std::vector<uint32_t> read_seg_off{0}, read_col_off{0}, read_qual_off{0};
-    std::vector<uint16_t> read_algn_len;
-    std::vector<uint8_t> read_mapq;
-    std::vector<uint32_t> seg_node;
-    std::vector<uint16_t> seg_start, seg_len;
-    std::vector<uint8_t> graph_seq, algnseq, qual;
-    std::vector<uint32_t> read_src; // index of each batch read in the alignment set
+    vgan::BigVec<uint32_t> read_seg_off{0}, read_col_off{0}, read_qual_off{0};
+    vgan::BigVec<uint16_t> read_algn_len;
+    vgan::BigVec<uint8_t> read_mapq;
+    vgan::BigVec<uint32_t> seg_node;
+    vgan::BigVec<uint16_t> seg_start, seg_len;
+    vgan::BigVec<uint8_t> graph_seq, algnseq, qual;
+    vgan::BigVec<uint32_t> read_src; // index of each batch read in the alignment set
     uint32_t n_tileable = 0;        // reads [0, n_tileable) satisfy the tile contract (include/vgan_gpu.h)
     void fill(vgan_hc_batch *b) const;
 };

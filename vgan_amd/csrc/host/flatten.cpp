@@ -243,6 +243,7 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     const int64_t n = r1 - r0;
     n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (n + 4095) / 4096));
+    PhaseTimer pt("hc_flatten");
     std::vector<Chunk> chunks((size_t)n_threads);
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t) {
@@ -251,6 +252,7 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
         else th.emplace_back(flatten_range, std::cref(*g), std::cref(*a), b0, b1, std::ref(chunks[t]));
     }
     for (auto &t : th) t.join();
+    pt.lap("chunks");
     auto res = new vgan_hc_host_batch();
     vgan_hc_flatten_stats st{};
     // output order: every chunk's tileable reads, then every chunk's other reads
@@ -325,6 +327,7 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
         st.n_bad += c.st.n_bad;
         st.n_clamped += c.st.n_clamped;
     }
+    pt.lap("merge");
     st.n_segments = (int64_t)res->seg_node.size();
     st.n_cols = (int64_t)res->graph_seq.size();
     if (stats) *stats = st;

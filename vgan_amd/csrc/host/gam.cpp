@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstring>
 #include <thread>
 
@@ -258,7 +261,7 @@ void vgan::merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &o) {
     auto copy_part = [&](size_t i) {
         vgan_alnset &p = parts[i];
         const Base &bs = base[i];
-        auto shift = [](const std::vector<int64_t> &src, int64_t *dst, int64_t by) {
+        auto shift = [](const BigVec<int64_t> &src, int64_t *dst, int64_t by) {
             for (size_t k = 1; k < src.size(); ++k) dst[k - 1] = src[k] + by;
         };
         shift(p.seq_off, &o.seq_off[bs.r + 1], (int64_t)bs.seq);
@@ -283,28 +286,103 @@ void vgan::merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &o) {
         cp(o.e_seq, bs.eseq, p.e_seq);
         p = vgan_alnset();
     };
-    if (parts.size() <= 1) {
+    const size_t nt = std::min<size_t>(parts.size(), std::max(1u, std::thread::hardware_concurrency()));
+    if (nt <= 1) {
         for (size_t i = 0; i < parts.size(); ++i) copy_part(i);
     } else {
         std::vector<std::thread> th;
-        for (size_t i = 0; i < parts.size(); ++i) th.emplace_back(copy_part, i);
+        for (size_t t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                for (size_t i = t; i < parts.size(); i += nt) copy_part(i);
+            });
         for (auto &t : th) t.join();
     }
 }
 
 extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped, vgan_alnset **out) {
     if (!bytes || !out) return fail(VGAN_EINVAL, "vgan_aln_parse_gam: null argument");
-    std::string inflated;
+    PhaseTimer pt("parse_gam");
+    ByteBuf inflated;
     const uint8_t *p = (const uint8_t *)bytes;
     if (n >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
         if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
         p = (const uint8_t *)inflated.data();
         n = inflated.size();
     }
-    // framing pass: groups of {count, count x (len, bytes)}; the first item of a group may be the type tag "GAM"
-    std::vector<std::pair<const uint8_t *, const uint8_t *>> msgs;
-    msgs.reserve(n / 600 + 16);
+    pt.lap("inflate");
+    // Framing (serial: groups of {count, count x (len, bytes)}, the first item of a group possibly the type tag "GAM")
+    // hands slices of messages to parser threads as it goes, so parsing overlaps it.
+    using Msg = std::pair<const uint8_t *, const uint8_t *>;
+    constexpr size_t SLICE = 8192;
+    std::deque<std::vector<Msg>> slices; // grown by the framing thread only, under mu
+    std::vector<vgan_alnset> parts;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t next_slice = 0;
+    bool framing_done = false;
+    std::atomic<bool> ok{true};
+    std::deque<vgan_alnset> slice_parts;
+    auto parse_slice = [&](const std::vector<Msg> &ms, vgan_alnset &a) {
+        if (ms.empty()) return;
+        // reserve from the byte volume of the slice: ~1 mapping per 20 bytes, ~1 edit per 16
+        const size_t nbytes = (size_t)(ms.back().second - ms.front().first), nr = ms.size();
+        a.seq_off.reserve(nr + 1);
+        a.qual_off.reserve(nr + 1);
+        a.name_off.reserve(nr + 1);
+        a.map_off.reserve(nr + 1);
+        a.mapq.reserve(nr);
+        a.identity.reserve(nr);
+        a.seq.reserve(nbytes / 6);
+        a.qual.reserve(nbytes / 6);
+        a.name.reserve(nr * 16);
+        a.m_node.reserve(nbytes / 18);
+        a.m_offset.reserve(nbytes / 18);
+        a.m_rev.reserve(nbytes / 18);
+        a.edit_off.reserve(nbytes / 18);
+        a.e_from.reserve(nbytes / 14);
+        a.e_to.reserve(nbytes / 14);
+        a.e_seq_off.reserve(nbytes / 14);
+        for (const Msg &m : ms) {
+            if (!parse_alignment(Cur{m.first, m.second, true}, a, keep_unmapped)) {
+                ok = false;
+                return;
+            }
+        }
+    };
+    auto worker = [&]() {
+        for (;;) {
+            std::vector<Msg> *ms;
+            vgan_alnset *dst;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return next_slice + 1 < slices.size() || (framing_done && next_slice < slices.size()) || framing_done; });
+                // a slice is complete once a later one exists, or framing has ended
+                if (next_slice + 1 < slices.size() || (framing_done && next_slice < slices.size())) {
+                    ms = &slices[next_slice];
+                    dst = &slice_parts[next_slice];
+                    ++next_slice;
+                } else {
+                    return;
+                }
+            }
+            parse_slice(*ms, *dst);
+        }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(hw, 64u), std::max<size_t>(1, n / (4u << 20)));
+    std::vector<std::thread> th;
+    if (nt > 1)
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker);
+    bool framed = true;
     {
+        auto open_slice = [&]() {
+            std::lock_guard<std::mutex> lk(mu);
+            slices.emplace_back();
+            slices.back().reserve(SLICE);
+            slice_parts.emplace_back();
+        };
+        open_slice();
+        std::vector<Msg> *cur = &slices.back();
         Cur c{p, p + n, true};
         while (!c.done()) {
             const uint64_t count = c.varint();
@@ -317,64 +395,45 @@ extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped
                     first = false;
                     if (item.e - item.p == 3 && memcmp(item.p, "GAM", 3) == 0) continue;
                 }
-                msgs.emplace_back(item.p, item.e);
+                cur->emplace_back(item.p, item.e);
+                if (cur->size() == SLICE) {
+                    open_slice();
+                    cur = &slices.back();
+                    cv.notify_one();
+                }
             }
             if (!c.ok) break;
         }
-        if (!c.ok) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+        framed = c.ok;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            framing_done = true;
+        }
+        cv.notify_all();
     }
-    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
-    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, msgs.size() / 2048));
-    std::vector<vgan_alnset> parts(nt);
-    std::atomic<bool> ok{true};
-    auto work = [&](unsigned t) {
-        const size_t m0 = msgs.size() * t / nt, m1 = msgs.size() * (t + 1) / nt;
-        vgan_alnset &a = parts[t];
-        if (m1 > m0) { // reserve from the byte volume of the slice: ~1 mapping per 20 bytes, ~1 edit per 16
-            const size_t nbytes = (size_t)(msgs[m1 - 1].second - msgs[m0].first), nr = m1 - m0;
-            a.seq_off.reserve(nr + 1);
-            a.qual_off.reserve(nr + 1);
-            a.name_off.reserve(nr + 1);
-            a.map_off.reserve(nr + 1);
-            a.mapq.reserve(nr);
-            a.identity.reserve(nr);
-            a.seq.reserve(nbytes / 6);
-            a.qual.reserve(nbytes / 6);
-            a.name.reserve(nr * 16);
-            a.m_node.reserve(nbytes / 18);
-            a.m_offset.reserve(nbytes / 18);
-            a.m_rev.reserve(nbytes / 18);
-            a.edit_off.reserve(nbytes / 18);
-            a.e_from.reserve(nbytes / 14);
-            a.e_to.reserve(nbytes / 14);
-            a.e_seq_off.reserve(nbytes / 14);
-        }
-        for (size_t m = m0; m < m1; ++m) {
-            if (!parse_alignment(Cur{msgs[m].first, msgs[m].second, true}, a, keep_unmapped)) {
-                ok = false;
-                return;
-            }
-        }
-    };
-    if (nt <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+    pt.lap("framing");
+    if (nt > 1) {
         for (auto &t : th) t.join();
+    } else if (framed) {
+        for (size_t i = 0; i < slices.size(); ++i) parse_slice(slices[i], slice_parts[i]);
     }
+    if (!framed) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+    parts.resize(slice_parts.size());
+    for (size_t i = 0; i < slice_parts.size(); ++i) parts[i] = std::move(slice_parts[i]);
     if (!ok) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+    pt.lap("parse");
     auto a = new vgan_alnset();
     merge_alnsets(parts, *a);
+    pt.lap("merge");
     *out = a;
     return VGAN_OK;
 }
 
 extern "C" int vgan_aln_read_gam(const char *path, int keep_unmapped, vgan_alnset **out) {
     if (!path || !out) return fail(VGAN_EINVAL, "vgan_aln_read_gam: null argument");
-    std::string raw;
-    if (!read_file(path, raw, false)) return fail(VGAN_EIO, "cannot read %s", path);
-    return vgan_aln_parse_gam(raw.data(), raw.size(), keep_unmapped, out);
+    MappedFile f;
+    if (!f.open_path(path)) return fail(VGAN_EIO, "cannot read %s", path);
+    return vgan_aln_parse_gam(f.p, f.n, keep_unmapped, out);
 }
 
 extern "C" int vgan_aln_write_gam(const vgan_alnset *a, const char *path, int group_size) {

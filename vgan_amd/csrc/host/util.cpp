@@ -1,6 +1,13 @@
 // Error reporting, file and gzip helpers of the host front end.
 #include "common.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+
 #include <zlib.h>
 
 #include <algorithm>
@@ -86,7 +93,7 @@ bool inflate_member(const unsigned char *in, size_t in_size, unsigned char *out,
 
 // Inflates a concatenation of gzip members.  BGZF input (what vg writes) is inflated block-parallel straight into its
 // final position; other gzip streams sequentially.
-bool gunzip_members(const void *data, size_t n, std::string &out) {
+bool gunzip_members(const void *data, size_t n, ByteBuf &out) {
     const unsigned char *p = (const unsigned char *)data;
     out.clear();
     std::vector<BgzfBlock> blocks;
@@ -98,7 +105,7 @@ bool gunzip_members(const void *data, size_t n, std::string &out) {
         std::atomic<bool> ok{true};
         auto work = [&](size_t b0, size_t b1) {
             for (size_t i = b0; i < b1 && ok.load(std::memory_order_relaxed); ++i)
-                if (!inflate_member(p + blocks[i].in_off, blocks[i].in_size, (unsigned char *)&out[0] + blocks[i].out_off, blocks[i].out_size))
+                if (!inflate_member(p + blocks[i].in_off, blocks[i].in_size, (unsigned char *)out.data() + blocks[i].out_off, blocks[i].out_size))
                     ok = false;
         };
         if (nt <= 1) {
@@ -138,6 +145,13 @@ bool gunzip_members(const void *data, size_t n, std::string &out) {
         p += used;
         n -= used;
     }
+    return true;
+}
+
+bool gunzip_members(const void *data, size_t n, std::string &out) {
+    ByteBuf b;
+    if (!gunzip_members(data, n, b)) return false;
+    out.assign(b.data(), b.size());
     return true;
 }
 
@@ -204,13 +218,69 @@ bool gzip_bytes(const std::string &in, std::string &out) {
 }
 
 bool read_file(const std::string &path, std::string &out, bool inflate_if_gzip) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return false;
-    std::string raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    std::string raw;
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) raw.reserve((size_t)st.st_size);
+    std::vector<char> buf(1 << 20); // regular files, FIFOs and pipes alike
+    for (;;) {
+        const ssize_t k = read(fd, buf.data(), buf.size());
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            close(fd);
+            return false;
+        }
+        if (k == 0) break;
+        raw.append(buf.data(), (size_t)k);
+    }
+    close(fd);
     if (inflate_if_gzip && raw.size() >= 2 && (unsigned char)raw[0] == 0x1f && (unsigned char)raw[1] == 0x8b) {
         return gunzip_members(raw.data(), raw.size(), out);
     }
     out.swap(raw);
+    return true;
+}
+
+void *big_alloc_bytes(size_t bytes) {
+    constexpr size_t HUGE = 2u << 20;
+    void *p = nullptr;
+    if (bytes >= HUGE) {
+        const size_t rounded = (bytes + HUGE - 1) / HUGE * HUGE;
+        if (posix_memalign(&p, HUGE, rounded) != 0) p = nullptr;
+        if (p) (void)madvise(p, rounded, MADV_HUGEPAGE);
+    } else {
+        p = malloc(bytes ? bytes : 1);
+    }
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+
+MappedFile::~MappedFile() {
+    if (p && p != MAP_FAILED && mapped) munmap(const_cast<void *>(p), n);
+}
+
+// Maps a regular file read-only (no copy); anything else (FIFO, pipe, empty file) is read into `fallback`.
+bool MappedFile::open_path(const std::string &path) {
+    const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            p = m;
+            n = (size_t)st.st_size;
+            mapped = true;
+            close(fd);
+            return true;
+        }
+    }
+    close(fd);
+    if (!read_file(path, fallback, false)) return false;
+    p = fallback.data();
+    n = fallback.size();
+    mapped = false;
     return true;
 }
 
