@@ -3,7 +3,7 @@
 // x = 2^k * m, the high word of m in [VGAN_LOG_OFF, VGAN_LOG_OFF + 2^20) (m in [0.707, 1.414)); the top 6 bits of that
 // range select {rcp, logc} with ln(m) = logc + log1p(r), r = fma(m, rcp, -1), |r| <= 2^-7; log1p by a degree-7 series
 // (next term r^8/8 < 2e-18).  ~20 fp64/int instructions and one 16-byte table read instead of ~45 for the
-// division-based series.  Error below 3 ulp (checked against logl in tests/test_log_tab_cpu.py); exact 0 at x = 1.
+// division-based series.  Error below 4 ulp, largest just outside the bin centred on 1 (checked against logl in tests/test_log_tab_cpu.py); exact 0 at x = 1.
 // Domain: normal positive finite x (callers route everything else to log_pos()).
 #pragma once
 #include <stdint.h>
