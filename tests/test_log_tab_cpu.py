@@ -14,7 +14,7 @@ def test_log_tab_matches_logl(tmp_path):
     out = subprocess.run([exe, "2000000"], capture_output=True, text=True, check=True).stdout.split()
     vals = dict(zip(out[0::2], map(float, out[1::2])))
     assert vals["worst_ulp"] < 4.0      # documented bound in log_tab.h
-    assert vals["worst_abs"] < 4.5e-16  # what the per-read sums see: |ln x| <= 50
+    assert vals["worst_abs"] < 4.5e-16  # error / max(1, |ln x|): what the per-read sums see
     assert vals["log1"] == 0.0          # a column that does not count contributes exactly nothing
 
 
