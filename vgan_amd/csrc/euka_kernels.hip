@@ -1,12 +1,10 @@
 // euka per-read kernel for gfx950: the body of readGAM3's per-alignment lambda (reference
 // src/readGAM_Euka.h:67-577) with Baseshift::baseshift_calc (src/baseshift.cpp:57-88).
 //
-// One wave per read, one lane per alignment column.  The two quantities the reference carries serially along the
-// read -- the damage position n (advanced on every non-gap read column, readGAM_Euka.h:457-461) and the softclip
-// counter (:269) -- are prefix popcounts of wave ballots, so the columns are independent.  Model 1 per column is
-// pre[4] (divergence) x the 4x4 damage matrix selected from the 5'/3' tables, marginalised over the sequencing
-// error: log(sum_b post[b] * w[b]) -- one log instead of the reference's four logs folded with oplusInitnatl
-// (identical value; a fold whose running value is exactly 0 cannot occur since every weight is < 1).
+// Sixteen lanes (one DPP row) per read, four reads per wave; a lane takes every 16th alignment column of its read.
+// Model 1 per column is pre[4] (divergence) x the 4x4 damage matrix selected from the 5'/3' tables, marginalised over
+// the sequencing error: log(sum_b post[b] * w[b]) -- one log instead of the reference's four logs folded with
+// oplusInitnatl (identical value; a fold whose running value is exactly 0 cannot occur since every weight is < 1).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -14,6 +12,8 @@
 #include "euka_device.h"
 
 namespace vgan {
+
+__device__ const LogTabEntry euka_log_table[64] = {VGAN_LOG_TABLE};
 
 __device__ __forceinline__ int acgt_index(uint32_t c) { // "ACGT" order; -1 otherwise
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
@@ -35,22 +35,56 @@ __device__ __forceinline__ double tT_ratio(int g, int b) { // Euka.cpp:453-468
 }
 
 constexpr int EK_WAVES = 4;
+constexpr int EK_GROUP = 16;                              // lanes per read: a DPP row
+constexpr int EK_READS_PER_WAVE = 64 / EK_GROUP;          // 4 reads per wave,
+constexpr int EK_READS_PER_BLOCK = EK_WAVES * EK_READS_PER_WAVE; // 16 per workgroup
+constexpr uint32_t EK_DMG_LDS_PAIRS = 64;                 // (5' row, 3' row) pairs kept in LDS (10 KB)
 
+// sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
+__device__ __forceinline__ double row_sum16(double v) {
+    v += dpp_mov0<0x128, 0xf>(v);
+    v += dpp_mov0<0x124, 0xf>(v);
+    v += dpp_mov0<0x122, 0xf>(v);
+    v += dpp_mov0<0x121, 0xf>(v);
+    return v;
+}
+
+// Four reads per wave, 16 lanes (one DPP row) per read, 16 alignment columns of each read per step.  The two
+// quantities the reference carries serially along a read -- the damage position n (advanced on every non-gap read
+// column, readGAM_Euka.h:457-461) and the softclip counter (:269) -- are prefix popcounts of the row's 16 ballot bits
+// plus a carry, so the columns are independent; per-read sums are row reductions; the per-read epilogue (log-sum-exp,
+// outputs, base shifts, bin coverage) runs for the wave's four reads at once.
+template <bool DMG_LDS>
 __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, EukaBatchDev b, EukaOutDev o) {
     __shared__ double qs_s[100];
+    __shared__ LogTabEntry logtab_s[64];
+    __shared__ double dmg_s[DMG_LDS ? EK_DMG_LDS_PAIRS * 20 : 1];
     for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = d.qscore[i];
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) logtab_s[i] = euka_log_table[i];
+    if (DMG_LDS)
+        for (uint32_t i = threadIdx.x; i < d.n5 * d.n3 * 20u; i += blockDim.x) dmg_s[i] = d.dmg_pair[i];
     __syncthreads();
+    const double *const dmg = DMG_LDS ? dmg_s : d.dmg_pair;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t sub = lane & 15u, gshift = lane & 48u, grp = (uint32_t)lane >> 4;
+    const uint32_t below = (1u << sub) - 1u;
+    auto row_bits = [&](bool p) { return (uint32_t)(__builtin_amdgcn_ballot_w64(p) >> gshift) & 0xFFFFu; };
+    auto wave_max4 = [&](uint32_t v) { // max over the four rows of a value that is uniform within each row
+        return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+                   max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+    };
     // this workgroup's replica of the per-clade accumulators
     const uint32_t rep = blockIdx.x % EUKA_REPLICAS;
     int32_t *const clade_count = o.clade_count + (size_t)rep * d.n_clades;
     uint32_t *const baseshift = o.baseshift + (size_t)rep * d.n_clades * 2 * (d.ltp > 0 ? d.ltp : 1) * 16;
     double *const bin_cov = o.bin_cov + (size_t)rep * o.n_bins;
 
-    for (uint32_t r = blockIdx.x * EK_WAVES + wave; r < b.n_reads; r += gridDim.x * EK_WAVES) {
+    for (uint32_t rbase = (blockIdx.x * EK_WAVES + wave) * EK_READS_PER_WAVE; rbase < b.n_reads;
+         rbase += gridDim.x * EK_READS_PER_BLOCK) {
+        const bool have = rbase + grp < b.n_reads; // this row has a read
+        const uint32_t r = min(rbase + grp, b.n_reads - 1u);
         const uint32_t col0 = b.read_col_off[r];
-        const uint32_t G = b.read_gseq_len[r], A = b.read_rseq_len[r];
+        const uint32_t G = have ? b.read_gseq_len[r] : 0u, A = b.read_rseq_len[r];
         const uint32_t q0 = b.read_qual_off[r], QL = b.read_qual_off[r + 1] - q0;
         const uint32_t Lseq = b.read_seq_len[r];
         const int32_t mapq = b.read_mapq[r];
@@ -80,87 +114,98 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         double lik = 0.0, lik2 = 0.0;
         uint32_t carry_n = 0, carry_sc = 0;
         bool bad = false;
-        for (uint32_t base = 0; base < G; base += 64) {
-            const uint32_t m = base + lane;
+        const uint32_t maxG = wave_max4(G);
+        for (uint32_t base = 0; base < maxG; base += EK_GROUP) {
+            const uint32_t m = base + sub;
             const bool active = m < G;
-            const uint32_t gc = active ? b.graph_seq[col0 + m] : 0u;
-            const uint32_t rc = (active && m < A) ? b.read_seq[col0 + m] : 0u;
-            const uint64_t nongap = __builtin_amdgcn_ballot_w64(active && rc != '-');
-            const uint32_t n_before = carry_n + (uint32_t)__builtin_popcountll(nongap & lt_mask);
+            // unconditional loads at clamped addresses, selected afterwards: the loads of a column overlap
+            const uint32_t mc = min(m, max(G, 1u) - 1u);
+            const uint32_t gc_raw = b.graph_seq[col0 + mc], rc_raw = b.read_seq[col0 + mc];
+            const int q_raw = (int)(int8_t)b.qual[q0 + min(m, max(QL, 1u) - 1u)];
+            const uint32_t gc = active ? gc_raw : 0u;
+            const uint32_t rc = (active && m < A) ? rc_raw : 0u;
+            const uint32_t nongap = row_bits(active && rc != '-');
+            const uint32_t n_before = carry_n + (uint32_t)__builtin_popcount(nongap & below);
             const uint32_t n = rev ? (Lseq - 1u - n_before) : n_before; // unsigned wrap as in the reference
             const bool isN = gc == 'N' || rc == 'N';
             const bool isgap = gc == '-' || rc == '-';
             const bool israre = is_rare(gc) || is_rare(rc);
             const bool isS = gc == 'S' || rc == 'S';
             const bool sc_col = active && !isN && !isgap && !israre && isS;
-            const uint64_t scb = __builtin_amdgcn_ballot_w64(sc_col);
-            const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcountll(scb & lt_mask) + 1u; // ++softclip_count
-            int q = m < QL ? (int)(int8_t)b.qual[q0 + m] : 0; // Q15
+            const uint32_t scb = row_bits(sc_col);
+            const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
+            int q = (m < QL && QL > 0u) ? q_raw : 0; // Q15
             q = q < 0 ? 0 : (q > 99 ? 99 : q);
             const double qs = qs_s[q];
-            // model 1 = c1 + log(a1), model 2 = l2; the branches only pick a1 / c1 / l2 so that one log serves all of them
-            double a1 = 1.0, c1 = 0.0, l2 = 0.0;
-            if (active) {
-                if (isN) { // :236-241
-                    c1 = l2 = base_freq_log(rc);
-                } else if (isgap) { // :244-249
-                    c1 = -6.214608098422191;  // log(0.002)
-                    l2 = -1.6094379124341003; // log(0.2)
-                } else if (israre) { // :252-257
-                    a1 = (1.0 - pair_dist) * 0.001;
-                    l2 = -6.907755278982137; // log(0.001)
-                } else if (isS) { // :263-280
-                    a1 = (sc_index % 3u == 0u) ? 1.0 - qs : qs / 3.0;
-                    l2 = -1.3862943611198906; // log(0.25)
-                } else {
-                    if (n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
-                    const int gi = acgt_index(gc), ri = acgt_index(rc);
-                    const uint32_t nn = min(n, Lseq - 1u);
-                    const double *e = d.dmg_pair + 20u * (min(nn, d.n5 - 1u) * d.n3 + min(Lseq - 1u - nn, d.n3 - 1u));
-                    // p = sum_o pre[o] * sum_b M[o][b] * w[b] (:337-340, :385-394), w = w_miss except w[read base] = w_hit
-                    const double w_hit = 1.0 - qs, w_miss = qs / 3.0;
-                    const double2 rs01 = *reinterpret_cast<const double2 *>(e + 16);
-                    const double2 rs23 = *reinterpret_cast<const double2 *>(e + 18);
-                    const double *col = e + 4 * max(ri, 0); // M[.][read base]
-                    const double2 c01 = *reinterpret_cast<const double2 *>(col);
-                    const double2 c23 = *reinterpret_cast<const double2 *>(col + 2);
-                    const double dw = ri < 0 ? 0.0 : w_hit - w_miss; // a read base outside ACGT matches no column
-                    const double dot[4] = {w_miss * rs01.x + dw * c01.x, w_miss * rs01.y + dw * c01.y,
-                                           w_miss * rs23.x + dw * c23.x, w_miss * rs23.y + dw * c23.y};
-                    double p = 0.0;
+            // the regular column (:283-400), evaluated for every lane: p = sum_o pre[o] * sum_b M[o][b] * w[b] with
+            // w = w_miss except w[read base] = w_hit, from the pair table (euka_device.h)
+            const int gi = acgt_index(gc), ri = acgt_index(rc);
+            const uint32_t nn = min(n, Lseq - 1u);
+            const double *e = dmg + 20u * (min(nn, d.n5 - 1u) * d.n3 + min(Lseq - 1u - nn, d.n3 - 1u));
+            const double w_hit = 1.0 - qs, w_miss = qs / 3.0;
+            const double2 rs01 = *reinterpret_cast<const double2 *>(e + 16);
+            const double2 rs23 = *reinterpret_cast<const double2 *>(e + 18);
+            const double *col = e + 4 * max(ri, 0); // M[.][read base]
+            const double2 c01 = *reinterpret_cast<const double2 *>(col);
+            const double2 c23 = *reinterpret_cast<const double2 *>(col + 2);
+            const double dw = ri < 0 ? 0.0 : w_hit - w_miss; // a read base outside ACGT matches no column
+            const double dot[4] = {w_miss * rs01.x + dw * c01.x, w_miss * rs01.y + dw * c01.y,
+                                   w_miss * rs23.x + dw * c23.x, w_miss * rs23.y + dw * c23.y};
+            double p = 0.0;
 #pragma unroll
-                    for (int bpo = 0; bpo < 4; ++bpo) {
-                        // :312-318; a graph base outside ACGT has no t_T_ratio entry (0)
-                        const double pre = gi < 0 ? 0.0 : (bpo == gi ? 1.0 - pair_dist : pair_dist * tT_ratio(gi, bpo));
-                        p += pre * dot[bpo];
-                    }
-                    a1 = p;
-                    l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
-                }
+            for (int bpo = 0; bpo < 4; ++bpo) {
+                // :312-318; a graph base outside ACGT has no t_T_ratio entry (0)
+                const double pre = gi < 0 ? 0.0 : (bpo == gi ? 1.0 - pair_dist : pair_dist * tT_ratio(gi, bpo));
+                p += pre * dot[bpo];
             }
-            const double l1 = c1 + log_pos(a1); // log_pos(1) == 0 exactly
+            // model 1 = c1 + log(a1), model 2 = l2; the cases only pick a1 / c1 / l2, so one log serves all of them
+            double a1 = p, c1 = 0.0;
+            double l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
+            const bool regular = !(isN || isgap || israre || isS);
+            if (regular && active && n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
+            if (isS) { // :263-280
+                a1 = (sc_index % 3u == 0u) ? 1.0 - qs : qs / 3.0;
+                l2 = -1.3862943611198906; // log(0.25)
+            }
+            if (israre) { // :252-257
+                a1 = (1.0 - pair_dist) * 0.001;
+                l2 = -6.907755278982137; // log(0.001)
+            }
+            if (isgap) { // :244-249
+                a1 = 1.0;
+                c1 = -6.214608098422191;  // log(0.002)
+                l2 = -1.6094379124341003; // log(0.2)
+            }
+            if (isN) { // :236-241
+                a1 = 1.0;
+                c1 = l2 = base_freq_log(rc);
+            }
+            if (!active) {
+                a1 = 1.0;
+                c1 = l2 = 0.0;
+            }
+            const double l1 = c1 + log_tab(a1, true, logtab_s); // log(1) == 0 exactly
             lik += l1;
             lik2 += l2;
-            carry_n += (uint32_t)__builtin_popcountll(nongap);
-            carry_sc += (uint32_t)__builtin_popcountll(scb);
+            carry_n += (uint32_t)__builtin_popcount(nongap);
+            carry_sc += (uint32_t)__builtin_popcount(scb);
         }
-        const double in = wave_sum(lik), out = wave_sum(lik2);
-        bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        const double in = row_sum16(lik), out = row_sum16(lik2);
+        bad = row_bits(bad) != 0u;
         if (bad) {
-            if (lane == 0) {
+            if (sub == 0 && have) {
                 o.clade[r] = -1;
                 o.in_lik[r] = o.out_lik[r] = o.like[r] = o.not_like[r] = 0.0;
                 o.pass[r] = 0;
                 atomicAdd(o.n_bad, 1ull);
             }
-            continue;
         }
+        const bool live = have && !bad;
         // Baseshift::baseshift_calc: first / last lengthToProf columns (baseshift.cpp:57-88)
-        if (lane < 2 * d.ltp) {
-            const int p = lane;
+        for (int p = (int)sub; p < 2 * d.ltp; p += EK_GROUP) {
             const int64_t gi = p < d.ltp ? p : (int64_t)G - 2 * d.ltp + p;
             const int64_t ri = p < d.ltp ? p : (int64_t)A - 2 * d.ltp + p;
-            if (gi >= 0 && ri >= 0 && gi < (int64_t)G && ri < (int64_t)A) {
+            if (live && gi >= 0 && ri >= 0 && gi < (int64_t)G && ri < (int64_t)A) {
                 uint32_t gb = b.graph_seq[col0 + gi], rb = b.read_seq[col0 + ri];
                 gb = (gb >= 'a' && gb <= 'z') ? gb - 32u : gb;
                 rb = (rb >= 'a' && rb <= 'z') ? rb - 32u : rb;
@@ -176,8 +221,8 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         if (in == 0.0) lse = out; // oplusInitnatl: a running value of 0 means "empty"
         else lse = fmax(in, out) + log1p(exp(-fabs(in - out)));
         const double like = map_q * exp(in - lse);
-        const bool pass = (in - out > 1.0) && ((uint32_t)mapq > d.min_mapq); // :504-510 (unsigned compare)
-        if (lane == 0) {
+        const bool pass = live && (in - out > 1.0) && ((uint32_t)mapq > d.min_mapq); // :504-510 (unsigned compare)
+        if (sub == 0 && live) {
             o.clade[r] = c_n;
             o.in_lik[r] = in;
             o.out_lik[r] = out;
@@ -186,20 +231,25 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             o.pass[r] = pass ? 1 : 0;
             if (pass) atomicAdd(&clade_count[c_n], 1);
         }
-        if (pass) { // bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546)
-            const uint32_t b0 = d.bin_off[c_n], b1 = d.bin_off[c_n + 1];
+        // bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546).  Lane j of a
+        // row holds the bounds of the clade's bin jb + j; 16 mappings of the read are tested against them per step.
+        if (__builtin_amdgcn_ballot_w64(pass)) {
+            const uint32_t b0 = d.bin_off[c_n], nb = pass ? d.bin_off[c_n + 1] - b0 : 0u;
+            const uint32_t nm = pass ? m1 - m0 : 0u;
             const double inv = 1.0 / (double)(m1 - m0);
-            for (uint32_t jb = b0; jb < b1; jb += 64) { // lane j holds bin jb + j's bounds; the loop below reads them by lane
-                const uint32_t nb = min(64u, b1 - jb);
-                const int32_t my_lo = (uint32_t)lane < nb ? d.bin_lo[jb + lane] : 1;
-                const int32_t my_hi = (uint32_t)lane < nb ? d.bin_hi[jb + lane] : 0;
-                for (uint32_t mb = m0; mb < m1; mb += 64) {
-                    const uint32_t mi = mb + lane;
-                    const int32_t node = mi < m1 ? (int32_t)b.map_node[mi] : -1;
-                    for (uint32_t j = 0; j < nb; ++j) {
-                        const int32_t lo = __builtin_amdgcn_readlane(my_lo, (int)j), hi = __builtin_amdgcn_readlane(my_hi, (int)j);
-                        const uint64_t hit = __builtin_amdgcn_ballot_w64(mi < m1 && node >= lo && node <= hi);
-                        if (hit && lane == 0) unsafeAtomicAdd(&bin_cov[jb + j], (double)__builtin_popcountll(hit) * inv);
+            const uint32_t max_nb = wave_max4(nb), max_nm = wave_max4(nm);
+            for (uint32_t jb = 0; jb < max_nb; jb += EK_GROUP) {
+                const bool mine = jb + sub < nb;
+                const int32_t my_lo = mine ? d.bin_lo[b0 + jb + sub] : 1;
+                const int32_t my_hi = mine ? d.bin_hi[b0 + jb + sub] : 0;
+                for (uint32_t mb = 0; mb < max_nm; mb += EK_GROUP) {
+                    const bool mok = mb + sub < nm;
+                    const int32_t node = mok ? (int32_t)b.map_node[m0 + mb + sub] : -1;
+                    const uint32_t jn = min((uint32_t)EK_GROUP, max_nb - jb);
+                    for (uint32_t j = 0; j < jn; ++j) {
+                        const int32_t lo = __shfl(my_lo, (int)(gshift + j), 64), hi = __shfl(my_hi, (int)(gshift + j), 64);
+                        const uint32_t hit = row_bits(mok && node >= lo && node <= hi);
+                        if (hit && sub == 0) unsafeAtomicAdd(&bin_cov[b0 + jb + j], (double)__builtin_popcount(hit) * inv);
                     }
                 }
             }
@@ -244,8 +294,12 @@ void launch_euka_reduce(const EukaOutDev &o, uint32_t n_clades, int32_t ltp, hip
 
 void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev &o, hipStream_t st) {
     if (b.n_reads == 0) return;
-    const uint32_t blocks = (uint32_t)((b.n_reads + EK_WAVES - 1) / EK_WAVES);
-    hipLaunchKernelGGL(euka_read_kernel, dim3(blocks < 256u * 8u ? blocks : 256u * 8u), dim3(EK_WAVES * 64), 0, st, d, b, o);
+    uint32_t blocks = (b.n_reads + EK_READS_PER_BLOCK - 1) / EK_READS_PER_BLOCK;
+    blocks = blocks < 256u * 8u ? blocks : 256u * 8u;
+    if (d.n5 * d.n3 <= EK_DMG_LDS_PAIRS)
+        hipLaunchKernelGGL(euka_read_kernel<true>, dim3(blocks), dim3(EK_WAVES * 64), 0, st, d, b, o);
+    else
+        hipLaunchKernelGGL(euka_read_kernel<false>, dim3(blocks), dim3(EK_WAVES * 64), 0, st, d, b, o);
 }
 
 } // namespace vgan
