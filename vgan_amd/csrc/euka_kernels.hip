@@ -59,6 +59,19 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     __shared__ double qs_s[100];
     __shared__ LogTabEntry logtab_s[64];
     __shared__ double dmg_s[DMG_LDS ? EK_DMG_LDS_PAIRS * 20 : 1];
+    // byte -> class: low nibble = ACGT index 0..3, else 8; high nibble = the rank of the lambda's special cases in
+    // the order it tests them (readGAM_Euka.h:236-280): 0 'N', 1 '-', 2 rare IUPAC code, 3 'S', 4 none
+    __shared__ uint8_t cls_s[256];
+    __shared__ double bfl_s[16]; // base_freq log of the read base by its low nibble; 0 unless A C G T / 'N' (slot 9)
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        const int ai = acgt_index((uint32_t)i);
+        const int rank = i == 'N' ? 0 : i == '-' ? 1 : is_rare((uint32_t)i) ? 2 : i == 'S' ? 3 : 4;
+        cls_s[i] = (uint8_t)((ai >= 0 ? ai : (i == 'N' ? 9 : 8)) | (rank << 4));
+    }
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        bfl_s[t] = base_freq_log(t == 0 ? 'A' : t == 1 ? 'C' : t == 2 ? 'G' : t == 3 ? 'T' : t == 9 ? 'N' : 0u);
+    }
     for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = d.qscore[i];
     for (int i = threadIdx.x; i < 64; i += blockDim.x) logtab_s[i] = euka_log_table[i];
     if (DMG_LDS)
@@ -124,62 +137,51 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             const int q_raw = (int)(int8_t)b.qual[q0 + min(m, max(QL, 1u) - 1u)];
             const uint32_t gc = active ? gc_raw : 0u;
             const uint32_t rc = (active && m < A) ? rc_raw : 0u;
+            const uint32_t gcl = cls_s[gc], rcl = cls_s[rc];
             const uint32_t nongap = row_bits(active && rc != '-');
             const uint32_t n_before = carry_n + (uint32_t)__builtin_popcount(nongap & below);
             const uint32_t n = rev ? (Lseq - 1u - n_before) : n_before; // unsigned wrap as in the reference
-            const bool isN = gc == 'N' || rc == 'N';
-            const bool isgap = gc == '-' || rc == '-';
-            const bool israre = is_rare(gc) || is_rare(rc);
-            const bool isS = gc == 'S' || rc == 'S';
-            const bool sc_col = active && !isN && !isgap && !israre && isS;
-            const uint32_t scb = row_bits(sc_col);
+            const uint32_t kind = min(gcl >> 4, rcl >> 4);                // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
+            const uint32_t scb = row_bits(active && kind == 3u);
             const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
             int q = (m < QL && QL > 0u) ? q_raw : 0; // Q15
             q = q < 0 ? 0 : (q > 99 ? 99 : q);
             const double qs = qs_s[q];
             // the regular column (:283-400), evaluated for every lane: p = sum_o pre[o] * sum_b M[o][b] * w[b] with
-            // w = w_miss except w[read base] = w_hit, from the pair table (euka_device.h)
-            const int gi = acgt_index(gc), ri = acgt_index(rc);
+            // w = w_miss except w[read base] = w_hit, i.e. per original base o: w_miss * rowsum[o] + (w_hit - w_miss) * M[o][rb],
+            // and pre = 1 - dist at the graph base g, dist * 0.95238 at its transition partner g^2, dist * 0.02381 at the
+            // other two (:312-318, Euka.cpp:453-468).  Pair table layout: euka_device.h.
+            const uint32_t gi = gcl & 15u, ri = rcl & 15u; // 0..3, or 8 / 9 outside ACGT
             const uint32_t nn = min(n, Lseq - 1u);
             const double *e = dmg + 20u * (min(nn, d.n5 - 1u) * d.n3 + min(Lseq - 1u - nn, d.n3 - 1u));
             const double w_hit = 1.0 - qs, w_miss = qs / 3.0;
-            const double2 rs01 = *reinterpret_cast<const double2 *>(e + 16);
-            const double2 rs23 = *reinterpret_cast<const double2 *>(e + 18);
-            const double *col = e + 4 * max(ri, 0); // M[.][read base]
-            const double2 c01 = *reinterpret_cast<const double2 *>(col);
-            const double2 c23 = *reinterpret_cast<const double2 *>(col + 2);
-            const double dw = ri < 0 ? 0.0 : w_hit - w_miss; // a read base outside ACGT matches no column
-            const double dot[4] = {w_miss * rs01.x + dw * c01.x, w_miss * rs01.y + dw * c01.y,
-                                   w_miss * rs23.x + dw * c23.x, w_miss * rs23.y + dw * c23.y};
-            double p = 0.0;
-#pragma unroll
-            for (int bpo = 0; bpo < 4; ++bpo) {
-                // :312-318; a graph base outside ACGT has no t_T_ratio entry (0)
-                const double pre = gi < 0 ? 0.0 : (bpo == gi ? 1.0 - pair_dist : pair_dist * tT_ratio(gi, bpo));
-                p += pre * dot[bpo];
-            }
+            const double dw = ri < 4u ? w_hit - w_miss : 0.0; // a read base outside ACGT matches no column
+            const double *mcol = e + 4u * (ri & 3u);        // M[.][read base]
+            const uint32_t o0 = gi & 3u, o1 = o0 ^ 1u, o2 = o0 ^ 2u, o3 = o0 ^ 3u;
+            const double d0 = w_miss * e[16 + o0] + dw * mcol[o0];
+            const double d2 = w_miss * e[16 + o2] + dw * mcol[o2];
+            const double d1 = w_miss * e[16 + o1] + dw * mcol[o1];
+            const double d3 = w_miss * e[16 + o3] + dw * mcol[o3];
+            double p = (1.0 - pair_dist) * d0 + pair_dist * (0.95238 * d2 + 0.02381 * (d1 + d3));
+            p = gi < 4u ? p : 0.0; // a graph base outside ACGT has no t_T_ratio entry
             // model 1 = c1 + log(a1), model 2 = l2; the cases only pick a1 / c1 / l2, so one log serves all of them
-            double a1 = p, c1 = 0.0;
+            if (kind == 4u && active && n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
+            const double bfl = bfl_s[rcl & 15u];
+            double a1 = kind == 4u ? p : 1.0, c1 = 0.0;
             double l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
-            const bool regular = !(isN || isgap || israre || isS);
-            if (regular && active && n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
-            if (isS) { // :263-280
-                a1 = (sc_index % 3u == 0u) ? 1.0 - qs : qs / 3.0;
+            if (kind == 3u) { // :263-280
+                a1 = (sc_index % 3u == 0u) ? w_hit : w_miss;
                 l2 = -1.3862943611198906; // log(0.25)
             }
-            if (israre) { // :252-257
+            if (kind == 2u) { // :252-257
                 a1 = (1.0 - pair_dist) * 0.001;
                 l2 = -6.907755278982137; // log(0.001)
             }
-            if (isgap) { // :244-249
-                a1 = 1.0;
+            if (kind == 1u) { // :244-249
                 c1 = -6.214608098422191;  // log(0.002)
                 l2 = -1.6094379124341003; // log(0.2)
             }
-            if (isN) { // :236-241
-                a1 = 1.0;
-                c1 = l2 = base_freq_log(rc);
-            }
+            if (kind == 0u) c1 = l2 = bfl; // :236-241
             if (!active) {
                 a1 = 1.0;
                 c1 = l2 = 0.0;
@@ -232,7 +234,8 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             if (pass) atomicAdd(&clade_count[c_n], 1);
         }
         // bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546).  Lane j of a
-        // row holds the bounds of the clade's bin jb + j; 16 mappings of the read are tested against them per step.
+        // row owns the clade's bin jb + j and counts the read's mappings that fall into it (16 nodes per step, handed
+        // round the row), then adds count / #mappings once.
         if (__builtin_amdgcn_ballot_w64(pass)) {
             const uint32_t b0 = d.bin_off[c_n], nb = pass ? d.bin_off[c_n + 1] - b0 : 0u;
             const uint32_t nm = pass ? m1 - m0 : 0u;
@@ -242,16 +245,16 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 const bool mine = jb + sub < nb;
                 const int32_t my_lo = mine ? d.bin_lo[b0 + jb + sub] : 1;
                 const int32_t my_hi = mine ? d.bin_hi[b0 + jb + sub] : 0;
+                uint32_t cnt = 0;
                 for (uint32_t mb = 0; mb < max_nm; mb += EK_GROUP) {
-                    const bool mok = mb + sub < nm;
-                    const int32_t node = mok ? (int32_t)b.map_node[m0 + mb + sub] : -1;
-                    const uint32_t jn = min((uint32_t)EK_GROUP, max_nb - jb);
-                    for (uint32_t j = 0; j < jn; ++j) {
-                        const int32_t lo = __shfl(my_lo, (int)(gshift + j), 64), hi = __shfl(my_hi, (int)(gshift + j), 64);
-                        const uint32_t hit = row_bits(mok && node >= lo && node <= hi);
-                        if (hit && sub == 0) unsafeAtomicAdd(&bin_cov[b0 + jb + j], (double)__builtin_popcount(hit) * inv);
+                    const int32_t node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1; // no bin holds -1 ...
+                    const uint32_t in = min((uint32_t)EK_GROUP, max_nm - mb);
+                    for (uint32_t i = 0; i < in; ++i) {
+                        const int32_t nd = __shfl(node, (int)(gshift + i), 64);
+                        cnt += (nd >= my_lo && nd <= my_hi && nd >= 0) ? 1u : 0u; // ... whatever its bounds
                     }
                 }
+                if (cnt) unsafeAtomicAdd(&bin_cov[b0 + jb + sub], (double)cnt * inv);
             }
         }
     }
