@@ -74,17 +74,20 @@ def cpu_baseline(graph, alns, budget_s):
 
 def bench_euka(args):
     """BASELINE config 4 shape: synthetic 75 bp aDNA reads with the dhigh damage profiles against a 335-clade graph."""
+    import numpy as np
     import torch
     from vgan_amd import distributed as vd
     from vgan_amd import euka as ek
     rank, world, local_rank = vd.env_rank()
+    if args.dist_backend == "gloo":  # several ranks may share one GPU on a test rig
+        local_rank = min(local_rank, torch.cuda.device_count() - 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    vd.init(backend="nccl", device=dev)
+    vd.init(backend=args.dist_backend, device=dev)
     gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
     dm = ek.Damage.load(os.path.join(gold, "dhigh5p.prof"), os.path.join(gold, "dhigh3p.prof"))
-    g, db, alns = ek.synth_euka(args.reads, dm, seed=args.seed + 1000003 * rank, n_clades=args.clades, nodes_per_clade=400,
-                                read_len_mean=75)
+    g, db, alns = ek.synth_euka(args.reads, dm, seed=args.seed, n_clades=args.clades, nodes_per_clade=400,
+                                read_len_mean=75, read_seed=args.seed + 1000003 * rank)
     hb = ek.EukaHostBatch(g, alns)
     dbt = ek.EukaDeviceBatch(hb, dev)
     ctx = ek.EukaContext(db, dm, device=local_rank)
@@ -94,23 +97,35 @@ def bench_euka(args):
         ctx.reset()
         ctx.accumulate(dbt)
 
+    import torch.distributed as dist
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     ctx.kernel_ms()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    elapsed = vd.all_reduce_max(time.perf_counter() - t0, dev)
     ms, n = ctx.kernel_ms()
     fin = ctx.finalize()
+    n_total = int(vd.all_reduce_sum(float(hb.n_reads), dev))
+    if world > 1:  # per-clade accumulators are summed over ranks once per job (per-read outputs stay sharded)
+        for k in ("clade_count", "baseshift", "bin_cov"):
+            t = torch.from_numpy(np.ascontiguousarray(fin[k])).to(dev if dist.get_backend() != "gloo" else "cpu")
+            t = t.to(torch.float64) if t.dtype not in (torch.float64, torch.int32, torch.int64) else t
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+            fin[k] = t.cpu().numpy()
     if rank == 0:
         kb = hb.algorithmic_bytes()
         avg = ms / max(n, 1)
         gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
         print(json.dumps({
-            "metric": "reads/sec through euka per-read two-model likelihood (readGAM3), 75bp aDNA", "value": hb.n_reads * args.steps / elapsed,
+            "metric": "reads/sec through euka per-read two-model likelihood (readGAM3), 75bp aDNA", "value": n_total * args.steps / elapsed,
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "euka %d synthetic 75bp aDNA reads per GPU, dhigh damage profiles, 335-clade graph" % args.reads,
@@ -132,9 +147,11 @@ def bench_soibean(args):
     from vgan_amd import haplocart as hc
     from vgan_amd import soibean as sb
     rank, world, local_rank = vd.env_rank()
+    if args.dist_backend == "gloo":  # several ranks may share one GPU on a test rig
+        local_rank = min(local_rank, torch.cuda.device_count() - 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    vd.init(backend="nccl", device=dev)
+    vd.init(backend=args.dist_backend, device=dev)
     g = hc.synth_graph(seed=args.seed, genome_len=16569, n_nodes=11000, n_paths=28)
     alns = hc.synth_reads(g, args.reads, seed=args.seed + 1000003 * rank, read_len=65, indel_rate=0.005, softclip_rate=0.01)
     dm = ek.Damage.from_text("", "")
@@ -166,8 +183,13 @@ def bench_soibean(args):
         nonlocal cur, accepted
         st = state()
         ctx.loglike(st, 0.01, freqs, device_out=d_out)
-        if world > 1:
-            dist.all_reduce(d_out, op=dist.ReduceOp.SUM)  # one scalar per iteration over RCCL
+        if world > 1:  # one scalar per iteration over RCCL
+            if dist.get_backend() == "gloo":
+                h = d_out.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                d_out.copy_(h)
+            else:
+                dist.all_reduce(d_out, op=dist.ReduceOp.SUM)
         ll = float(d_out.item())
         if cur is None or np.log(rng.random()) < ll - cur:
             cur = ll

@@ -389,6 +389,8 @@ typedef struct vgan_synth_euka_cfg {
     uint32_t nodes_per_clade; /* contiguous node-id range per clade */
     uint64_t n_reads;
     uint32_t read_len_mean;   /* 75, clipped 30..150 */
+    uint32_t reserved;
+    uint64_t read_seed;       /* reads only (0 = seed): ranks share the graph and draw different reads */
 } vgan_synth_euka_cfg;
 /* clade graph (nodes <= 5 bp), its clade/bin tables, and aDNA-like reads with the given damage applied */
 int vgan_synth_euka(const vgan_synth_euka_cfg *cfg, const vgan_damage *dmg, vgan_graph **g, vgan_euka_db **db,

@@ -103,7 +103,7 @@ int main(int argc, char **argv) {
     vgan_euka_db_free(db);
     vgan_damage *dm = nullptr;
     REQUIRE(vgan_damage_load((golden + "/damageProfiles/dhigh5p.prof").c_str(), (golden + "/damageProfiles/dhigh3p.prof").c_str(), &dm) == 0);
-    vgan_synth_euka_cfg ec{9, 6, 120, 500, 75};
+    vgan_synth_euka_cfg ec{9, 6, 120, 500, 75, 0, 0};
     REQUIRE(vgan_synth_euka(&ec, dm, &g, &db, &a) == 0);
     REQUIRE(vgan_euka_flatten(g, a, 0, 500, 2, &eb, &es) == 0 && es.n_out > 450);
     vgan_euka_host_batch_free(eb);

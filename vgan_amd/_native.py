@@ -100,7 +100,7 @@ class SbSource(C.Structure):
 
 class SynthEukaCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_clades", C.c_uint32), ("nodes_per_clade", C.c_uint32), ("n_reads", C.c_uint64),
-                ("read_len_mean", C.c_uint32)]
+                ("read_len_mean", C.c_uint32), ("reserved", C.c_uint32), ("read_seed", C.c_uint64)]
 
 
 class SynthGraphCfg(C.Structure):

@@ -423,8 +423,9 @@ extern "C" int vgan_synth_euka(const vgan_synth_euka_cfg *cfg, const vgan_damage
     if (dmg) vgan_damage_view_get(dmg, &dv);
     auto a = new vgan_alnset();
     const uint64_t R = cfg->n_reads;
+    const uint64_t rseed = cfg->read_seed ? cfg->read_seed : cfg->seed;
     for (uint64_t r = 0; r < R; ++r) {
-        SplitMix64 q(cfg->seed * 0x9E3779B97F4A7C15ull + r * 0xD1B54A32D192ED03ull + 0x61646e61ull);
+        SplitMix64 q(rseed * 0x9E3779B97F4A7C15ull + r * 0xD1B54A32D192ED03ull + 0x61646e61ull);
         const uint32_t c = (uint32_t)q.below(C);
         const auto &st = sites[c];
         // aDNA-like fragment length: mean read_len_mean, clipped 30..150

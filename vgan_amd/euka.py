@@ -210,8 +210,8 @@ class EukaContext:
         self.close()
 
 
-def synth_euka(n_reads, damage=None, seed=0x76676131, n_clades=335, nodes_per_clade=400, read_len_mean=75):
-    cfg = N.SynthEukaCfg(seed, n_clades, nodes_per_clade, n_reads, read_len_mean)
+def synth_euka(n_reads, damage=None, seed=0x76676131, n_clades=335, nodes_per_clade=400, read_len_mean=75, read_seed=0):
+    cfg = N.SynthEukaCfg(seed, n_clades, nodes_per_clade, n_reads, read_len_mean, 0, read_seed)
     g, d, a = N.vp(), N.vp(), N.vp()
     N.check(N.lib().vgan_synth_euka(C.byref(cfg), damage._h if damage is not None else None, C.byref(g), C.byref(d), C.byref(a)))
     return Graph(g), EukaDb(d), AlnSet(a)
