@@ -107,3 +107,72 @@ def test_shipped_bins_table_clade_lookup():
     a = hc.AlnSet.parse_gam(gamio.write_gam(alns))
     got, fin, ref = compare(g, db, a, ("", ""))
     assert len(set(got["clade"].tolist())) > 50
+
+
+def test_long_reads_and_ragged_read_counts():
+    """Reads of 15..960 columns (many 16-column steps per row, carries across steps), both strands, a read count that
+    does not fill the last wave, multi-node paths with more than 16 mappings and clades with more than 16 bins."""
+    import ctypes as C
+    from vgan_amd import _native as N
+    rng = np.random.default_rng(11)
+    n_nodes = 60
+    lens = rng.integers(3, 40, n_nodes)
+    seqs = [bytes(rng.choice(list(b"ACGT"), int(L)).astype(np.uint8)) for L in lens]
+    off = np.zeros(n_nodes + 2, np.int64)
+    off[2:] = np.cumsum(lens)
+    g = hc.Graph.from_arrays(1, n_nodes, off, b"".join(seqs), 1, np.zeros((n_nodes + 1, 1), np.uint64),
+                             np.full(n_nodes + 1, -1, np.int32), np.ones(1))
+    # clade 0: 20 single-node bins over nodes 1..20 (> 16 bins), clade 1: 3 wide bins over the rest
+    bo = np.array([0, 20, 23], np.uint32)
+    lo = np.array(list(range(1, 21)) + [21, 35, 50], np.int32)
+    hi = np.array(list(range(1, 21)) + [34, 49, 60], np.int32)
+    cd = np.array([0.11, 0.2])
+    en = np.zeros(23)
+    v = N.EukaDbView(2, None, cd.ctypes.data, None, None, None, b"c0\nc1\n", bo.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                     en.ctypes.data)
+    h = N.vp()
+    N.check(N.lib().vgan_euka_db_from_arrays(C.byref(v), C.byref(h)))
+    db = ek.EukaDb(h)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    alns = []
+    for i in range(37):  # 37 reads: the last wave holds one
+        first = int(rng.integers(1, 12)) if i % 3 else int(rng.integers(21, 30))
+        n_map = int(rng.integers(1, 45))
+        last = min(n_nodes, first + n_map - 1)
+        rev = bool(i % 4 == 1)
+        nodes = list(range(first, last + 1))
+        if rev:
+            nodes = nodes[::-1]
+        read = b""
+        maps = []
+        for nd in nodes:
+            s = seqs[nd - 1]
+            s = s.translate(comp)[::-1] if rev else s
+            sb = bytearray(s)
+            edits = []
+            run = 0
+            for k in range(len(sb)):
+                if rng.random() < 0.01:  # a substitution splits the match run
+                    if run:
+                        edits.append((run, run, b""))
+                        run = 0
+                    alt = b"ACGT"[(b"ACGT".index(sb[k]) + 1 + int(rng.integers(3))) % 4]
+                    sb[k] = alt
+                    edits.append((1, 1, bytes([alt])))
+                else:
+                    run += 1
+            if run:
+                edits.append((run, run, b""))
+            maps.append((nd, 0, rev, edits))
+            read += bytes(sb)
+        if len(read) < 15 or len(read) > 1000:
+            continue
+        q = rng.integers(0 if i % 5 == 0 else 28, 42, len(read)).tolist()
+        alns.append(_mk(read, q, maps, mapq=int(rng.integers(20, 61))))
+    if len(alns) % 4 == 0:
+        alns.pop()
+    assert max(len(x["sequence"]) for x in alns) > 300
+    a = hc.AlnSet.parse_gam(gamio.write_gam(alns))
+    d = os.path.join(GOLD, "damageProfiles")
+    got, fin, ref = compare(g, db, a, (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read()))
+    assert got["pass"].sum() >= 5 and (fin["bin_cov"] > 0).sum() >= 8

@@ -302,7 +302,10 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                     rdpinc_s[buf][tid] = incmap_s[min(h_mapq, 99u)];
                 }
             }
-            if ((uint32_t)tid == n) tile_s[buf] = StTile{n, sb, h_seg - sb, cb, h_col - cb, qb, h_q - qb};
+            // clamped: a read that breaks the tile contract (a caller's error) must not index past the LDS arrays
+            if ((uint32_t)tid == n)
+                tile_s[buf] = StTile{n, sb, (uint32_t)min(h_seg - sb, (uint32_t)ST_SEGS), cb,
+                                     (uint32_t)min(h_col - cb, (uint32_t)ST_COLS), qb, (uint32_t)min(h_q - qb, (uint32_t)ST_QUAL)};
         }
     };
     auto tile_extents = [&](uint32_t buf) { return tile_s[buf]; };
