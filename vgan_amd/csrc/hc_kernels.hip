@@ -364,20 +364,28 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         // T.n_q bytes receive sums nobody reads (prefix values at or below T.n_q do not depend on what follows).
         {
             const uint32_t i0 = tid * ST_QB;
-            double loc[ST_QB];
-            double run = 0.0;
+            uint32_t qb[ST_QB];
+            bool hot = false;
 #pragma unroll
-            for (int e = 0; e < ST_QB; ++e) {
-                const uint32_t qb = qual_s[qshift + i0 + e];
-                if ((int)(int8_t)qb >= 90) { // rare: Q >= 90 switches the read to the background error rate
+            for (int e = 0; e < ST_QB; ++e) { // all byte reads first, one rare branch for the lot
+                qb[e] = qual_s[qshift + i0 + e];
+                hot |= (int)(int8_t)qb[e] >= 90;
+            }
+            if (hot) { // rare: Q >= 90 switches the read to the background error rate
+                for (int e = 0; e < ST_QB; ++e) {
                     const uint32_t i = i0 + e, gq = T.q_base + i;
-                    if (i < T.n_q) {
+                    if ((int)(int8_t)qb[e] >= 90 && i < T.n_q) {
                         uint32_t k = 0;
                         for (uint32_t t = 1; t < T.n; ++t) k += gq >= off_s[cur][2][t] ? 1u : 0u;
                         atomicMin(&first90_s[k], gq - off_s[cur][2][k]);
                     }
                 }
-                run += lq_s[qb];
+            }
+            double loc[ST_QB];
+            double run = 0.0;
+#pragma unroll
+            for (int e = 0; e < ST_QB; ++e) {
+                run += lq_s[qb[e]];
                 loc[e] = run;
             }
             const double incl = wave_incl_scan(run);
