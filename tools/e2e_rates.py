@@ -31,4 +31,4 @@ dt = time.time() - t
 print("vgan haplocart end to end (graph load + GAM inflate/parse + flatten + GPU + posterior), rc=%d: %.2f s, %.0f reads/s"
       % (r.returncode, dt, n / dt))
 print(open(d + "/out.tsv").read().strip())
-print(r.stderr[-300:])
+print("\n".join(l for l in r.stderr.splitlines() if "haplocart:" in l or "parse_gam" in l or "warning" in l))

@@ -21,6 +21,23 @@
 
 #include "vgan_gpu.h"
 
+#include <chrono>
+#include <thread>
+
+namespace {
+// phase times to stderr when VGAN_TIMING is set (developer aid); this file is a plain client of the C-ABI
+struct PhaseTimer {
+    bool on = getenv("VGAN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *phase) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vgan timing] haplocart: %s %.1f ms\n", phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+} // namespace
+
 namespace {
 
 [[noreturn]] void die(const std::string &msg) { throw std::runtime_error(msg); }
@@ -107,8 +124,24 @@ int haplocart(int argc, char **argv) {
     if (!std::ifstream(gamfilename)) die("[HaploCart] Error, GAM input file " + gamfilename + " does not exist");
     if (!invoked_samplename) samplename = !fastafilename.empty() ? fastafilename : gamfilename;
 
+    PhaseTimer pt;
+    // the GAM is inflated and parsed on its own threads while this one loads the graph and brings the device up
+    vgan_alnset *alns = nullptr;
+    int gam_rc = 0;
+    std::string gam_err;
+    std::thread gam_reader([&] {
+        gam_rc = vgan_aln_read_gam(gamfilename.c_str(), 0, &alns);
+        if (gam_rc) gam_err = vgan_last_error(); // the message is per thread
+    });
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{gam_reader};
     vgan_graph *graph = nullptr;
     check(vgan_graph_load((hcfiledir + "graph.gfa").c_str(), hcfiledir.c_str(), &graph), "loading graph");
+    pt.lap("graph load");
     vgan_graph_view gv;
     check(vgan_graph_view_get(graph, &gv), "graph view");
     std::vector<std::string> path_names;
@@ -124,8 +157,19 @@ int haplocart(int argc, char **argv) {
     }
     if (path_names.size() != gv.n_paths) die("[HaploCart] graph_paths does not name every path of path_supports");
 
-    vgan_alnset *alns = nullptr;
-    check(vgan_aln_read_gam(gamfilename.c_str(), 0, &alns), "reading GAM");
+    vgan_hc_params prm;
+    prm.background_error_prob = background_error_prob;
+    prm.use_background_error_prob = !fastafilename.empty(); // HaploCart.cpp:397-400
+    prm.is_consensus_fasta = !fastafilename.empty();
+    if (vgan_device_count() <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
+    vgan_hc_ctx *ctx = nullptr;
+    check(vgan_hc_create(&gv, &prm, device, &ctx), "creating the device context");
+    check(vgan_hc_set_mode(ctx, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS), "mode");
+    pt.lap("device context");
+
+    gam_reader.join();
+    if (gam_rc) die("[HaploCart] reading GAM: " + gam_err);
+    pt.lap("read GAM (waited)");
     vgan_alnset_view av;
     check(vgan_aln_view_get(alns, &av), "alignment view");
     if (!quiet) std::cerr << "Found " << av.n_reads << " reads." << '\n';
@@ -143,16 +187,9 @@ int haplocart(int argc, char **argv) {
         if (!quiet) std::cerr << "PCR duplicates removed." << std::endl;
     }
     int64_t n_reads = av.n_reads;
+    pt.lap("duplicate removal");
 
-    vgan_hc_params prm;
-    prm.background_error_prob = background_error_prob;
-    prm.use_background_error_prob = !fastafilename.empty(); // HaploCart.cpp:397-400
-    prm.is_consensus_fasta = !fastafilename.empty();
     if (!fastafilename.empty() && !quiet) std::cerr << "Using background error probability of " << background_error_prob << '\n';
-    if (vgan_device_count() <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
-    vgan_hc_ctx *ctx = nullptr;
-    check(vgan_hc_create(&gv, &prm, device, &ctx), "creating the device context");
-    check(vgan_hc_set_mode(ctx, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS), "mode");
     if (!quiet && fastafilename.empty()) std::cerr << "Computing haplogroup likelihoods from " << n_reads << " reads." << '\n';
 
     const int64_t BATCH = 500000; // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i
@@ -176,6 +213,7 @@ int haplocart(int argc, char **argv) {
         std::cerr << "[HaploCart] warning: " << tot.n_bad << " reads skipped (the reference would terminate on them)\n";
     std::vector<double> final_vec(gv.n_paths);
     check(vgan_hc_finalize(ctx, nullptr, final_vec.data()), "finalize");
+    pt.lap("flatten + kernels");
     const int maxh = vgan_hc_argmax(final_vec.data(), gv.n_paths); // HaploCart.cpp:423
     const std::string predicted = path_names[(size_t)maxh];
 
@@ -213,9 +251,10 @@ int haplocart(int argc, char **argv) {
         for (int k : idx) d << path_names[(size_t)k] << '\t' << final_vec[(size_t)k] << '\n';
         if (!quiet) std::cerr << "Writing log likelihoods to " << dbg << std::endl;
     }
+    pt.lap("posterior + output");
     vgan_hc_destroy(ctx);
-    vgan_aln_free(alns);
-    vgan_graph_free(graph);
+    // the alignment set (GBs) and the graph are left to process exit: unmapping them page by page first costs ~0.1 s
+    pt.lap("teardown");
     return 0;
 }
 
