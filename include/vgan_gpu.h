@@ -198,6 +198,9 @@ int vgan_hc_reset(vgan_hc_ctx *c);                         /* zero the accumulat
 int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *batch);
 /* Per-segment scalars of a batch (test / debug aid): S_m, U_m as the kernel computes them. Host outputs. */
 int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *batch, double *S, double *U);
+/* D_m = S_m - U_m per segment as vgan_hc_accumulate computes it, i.e. through the LDS-tiled kernel for the batch's
+ * tileable reads (test / debug aid). Host output [n_segments]. */
+int vgan_hc_segment_weights(vgan_hc_ctx *c, const vgan_hc_batch *batch, double *D);
 /* Per-read log-likelihood vectors (the value Haplocart::update returns), [n_reads*n_paths] host doubles. */
 int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *batch, double *out);
 /* final_vec[P] (HaploCart.cpp:420) of everything accumulated so far. d_out: device double[P], filled

@@ -284,3 +284,77 @@ def test_cli_end_to_end(tmp_path):
     exp = orc.hc_posterior(fld, g.path_names, g.parents_txt, g.children_txt, pred)
     assert fields[1] == exp[0][0] and float(fields[2]) == pytest.approx(exp[0][1], rel=1e-5)
     assert len(fields) // 3 == len(exp)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_tiled_kernel_fuzz_against_general_kernel(seed):
+    """Random batches that satisfy the tile contract, built by hand over the C-ABI (no flatten step): ragged reads of
+    1..256 columns, quality strings shorter / longer than the read or empty, zero-length segments, segments that stop
+    before the read ends, bases outside ACGT, qualities >= 90 and negative.  D_m from the LDS-tiled kernel must equal
+    S_m - U_m from the general kernel (which the other tests hold against the oracle)."""
+    rng = np.random.default_rng(seed)
+    g = hc.synth_graph(seed=50 + seed, genome_len=1200, n_nodes=700, n_paths=70)
+    n_nodes = g.max_id
+    R = 3000 + 17 * seed
+    seg_off, col_off, qual_off = [0], [0], [0]
+    algn_len, mapq, seg_node, seg_start, seg_len = [], [], [], [], []
+    gseq, rseq, qual = [], [], []
+    alphabet = np.frombuffer(b"ACGT" * 12 + b"NacgtS-RY", np.uint8)
+    for r in range(R):
+        cols = int(rng.integers(1, 257)) if r % 7 else int(rng.choice([1, 2, 255, 256]))
+        A = cols
+        ql = int(rng.choice([cols, cols, cols, max(0, cols - int(rng.integers(1, 9))), min(256, cols + 5), 0]))
+        pos = 0
+        nseg = 0
+        max_run = int(rng.choice([3, 8, 40, 200]))
+        stop_early = rng.random() < 0.2
+        while pos < cols and nseg < 128:
+            if rng.random() < 0.05:
+                ln = 0  # a mapping without columns
+            else:
+                ln = int(min(cols - pos, rng.integers(1, max_run + 1)))
+            seg_node.append(int(rng.integers(1, n_nodes + 1)))
+            seg_start.append(pos)
+            seg_len.append(ln)
+            pos += ln
+            nseg += 1
+            if stop_early and pos > cols // 2:
+                break
+        seg_off.append(len(seg_node))
+        gseq.append(rng.choice(alphabet, cols))
+        rseq.append(rng.choice(alphabet, cols))
+        q = rng.integers(0, 42, ql).astype(np.uint8)
+        if ql and rng.random() < 0.15:
+            q[rng.integers(0, ql)] = rng.choice([90, 93, 120, 127, 128, 200, 255])
+        qual.append(q)
+        col_off.append(col_off[-1] + cols)
+        qual_off.append(qual_off[-1] + ql)
+        algn_len.append(A)
+        mapq.append(int(rng.integers(0, 61)))
+    arrays = {"read_seg_off": seg_off, "read_col_off": col_off, "read_qual_off": qual_off, "read_algn_len": algn_len,
+              "read_mapq": mapq, "seg_node": seg_node, "seg_start": seg_start, "seg_len": seg_len,
+              "graph_seq": np.concatenate(gseq), "algnseq": np.concatenate(rseq),
+              "qual": np.concatenate(qual) if sum(map(len, qual)) else np.zeros(0, np.uint8)}
+    tiled = hc.ArrayBatch(arrays, n_tileable=R)
+    general = hc.ArrayBatch(arrays, n_tileable=0)
+    for kw in (dict(), dict(background_error_prob=0.02, use_background_error_prob=True),
+               dict(background_error_prob=0.01, use_background_error_prob=True, is_consensus_fasta=True)):
+        ctx = hc.HcContext(g, **kw)
+        S, U = ctx.segment_scalars(general)
+        want = S - U
+        got = ctx.segment_weights(tiled)
+        also = ctx.segment_weights(general)
+        fin = np.isfinite(want)
+        assert np.array_equal(fin, np.isfinite(got)) and np.array_equal(got[~fin], want[~fin])
+        # U_m is a difference of two tile-wide prefix sums (up to 1280 terms of a few units each: ulp ~ 2e-12)
+        tol = 5e-12 + 1e-13 * np.maximum(np.abs(S), np.abs(U))
+        assert np.all(np.abs(got[fin] - want[fin]) <= tol[fin])
+        assert np.all(np.abs(also[fin] - want[fin]) <= tol[fin])
+        # and through the accumulators: the same final vector from both routes
+        outs = []
+        for b in (tiled, general):
+            ctx.reset()
+            ctx.accumulate(b)
+            outs.append(ctx.finalize())
+        if np.all(fin):
+            assert util.rel_err(outs[0], outs[1]) < 1e-12

@@ -454,6 +454,22 @@ extern "C" int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *b, d
     return VGAN_OK;
 }
 
+extern "C" int vgan_hc_segment_weights(vgan_hc_ctx *c, const vgan_hc_batch *b, double *D) {
+    if (!c || !D) return fail(VGAN_EINVAL, "vgan_hc_segment_weights: null argument");
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (b->n_reads == 0 || b->n_segments == 0) return VGAN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HcBatchDev d{};
+    if ((rc = stage_batch(c, b, d))) return rc;
+    if ((rc = c->segD.reserve(b->n_segments))) return rc;
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, nullptr, nullptr, c->segD.p, nullptr, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(D, c->segD.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VGAN_OK;
+}
+
 extern "C" int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *b, double *out) {
     if (!c || !out) return fail(VGAN_EINVAL, "vgan_hc_read_loglik: null argument");
     int rc = check_batch(b);

@@ -251,6 +251,26 @@ class HostBatch:
             self._h = None
 
 
+class ArrayBatch:
+    """A vgan_hc_batch over caller-built numpy arrays (host memory): what a C caller of the ABI hands over.
+    `arrays` uses the field names of vgan_hc_batch; n_tileable as in include/vgan_gpu.h (0 is always valid)."""
+
+    def __init__(self, arrays, n_tileable=0):
+        self._keep = {name: np.ascontiguousarray(arrays[name], dt) for name, dt, _ in _BATCH_FIELDS}
+        c = N.HcBatch()
+        c.n_reads = len(self._keep["read_algn_len"])
+        c.n_segments = len(self._keep["seg_node"])
+        c.n_cols = len(self._keep["graph_seq"])
+        c.n_qual = len(self._keep["qual"])
+        for name, _, _ in _BATCH_FIELDS:
+            setattr(c, name, self._keep[name].ctypes.data if self._keep[name].size else None)
+        c.on_device = 0
+        c.n_tileable = n_tileable
+        c.read_src = None
+        self.c = c
+        self.n_reads, self.n_segments = c.n_reads, c.n_segments
+
+
 class DeviceBatch:
     """The same SoA resident in HBM as torch tensors (zero-copy hand-over to vgan_hc_accumulate)."""
 
@@ -311,6 +331,12 @@ class HcContext:
         U = np.zeros(batch.n_segments)
         N.check(N.lib().vgan_hc_segment_scalars(self._h, C.byref(batch.c), S.ctypes.data, U.ctypes.data))
         return S, U
+
+    def segment_weights(self, batch):
+        """D_m = S_m - U_m per segment through the routed kernels (the tiled one for the batch's tileable reads)."""
+        D = np.zeros(batch.n_segments)
+        N.check(N.lib().vgan_hc_segment_weights(self._h, C.byref(batch.c), D.ctypes.data))
+        return D
 
     def read_loglik(self, batch):
         out = np.zeros((batch.n_reads, self.n_paths))
