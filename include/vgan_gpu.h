@@ -161,6 +161,10 @@ typedef struct vgan_hc_flatten_stats {
 /* reads [r0, r1) of the alignment set -> batch.  n_threads <= 0: all hardware threads. */
 int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
                     vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
+/* the same, leaving out the reads with skip[r] != 0 (skip is indexed like the alignment set, e.g. the marks of
+ * vgan_aln_mark_duplicates; NULL = none): duplicate removal without rebuilding the alignment set */
+int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
+                           int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
 int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out);
 void vgan_hc_host_batch_free(vgan_hc_host_batch *b);
 /* a1 on its own, for the reconstruction KATs: strings are NUL terminated into caller buffers of cap bytes. */

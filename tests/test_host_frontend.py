@@ -227,3 +227,21 @@ def test_flatten_puts_tileable_reads_first(tmp_path):
             assert ok == (r < nt), (r, nt, cols)
         # within each part the input order is kept
         assert np.all(np.diff(src[:nt].astype(np.int64)) > 0) and np.all(np.diff(src[nt:].astype(np.int64)) > 0)
+
+
+def test_masked_flatten_equals_flatten_of_filtered_set():
+    """vgan_hc_flatten_masked(skip = duplicate marks) gives the batch of the de-duplicated set without building it."""
+    from vgan_amd import haplocart as hc
+    g = hc.synth_graph(seed=8, genome_len=900, n_nodes=500, n_paths=32)
+    a = hc.synth_reads(g, 6000, seed=9, read_len=100)
+    dup = a.mark_duplicates()
+    assert 0 < dup.sum() < a.n_reads
+    masked = hc.HostBatch(g, a, n_threads=3, skip=dup)
+    plain = hc.HostBatch(g, a.without(dup), n_threads=3)
+    assert masked.n_reads == plain.n_reads == masked.stats.n_out and masked.n_tileable == plain.n_tileable
+    ma, pa = masked.arrays(), plain.arrays()
+    for k in ("read_seg_off", "read_col_off", "read_qual_off", "read_algn_len", "read_mapq", "seg_node", "seg_start",
+              "seg_len", "graph_seq", "algnseq", "qual"):
+        assert np.array_equal(ma[k], pa[k]), k
+    kept = np.flatnonzero(~dup)
+    assert np.array_equal(kept[pa["read_src"]], ma["read_src"])

@@ -31,4 +31,11 @@ dt = time.time() - t
 print("vgan haplocart end to end (graph load + GAM inflate/parse + flatten + GPU + posterior), rc=%d: %.2f s, %.0f reads/s"
       % (r.returncode, dt, n / dt))
 print(open(d + "/out.tsv").read().strip())
+t = time.time()
+r2 = subprocess.run([os.path.join(ROOT, "vgan_amd/bin/vgan"), "haplocart", "-g", d + "/r.gam", "--hc-files", d, "-q", "-t", "-1",
+                     "-o", d + "/out2.tsv", "-pf", d + "/post2.txt"], capture_output=True, text=True)
+dt = time.time() - t
+print("same with duplicate removal (dedup on, the reference's default), rc=%d: %.2f s, %.0f input reads/s" % (r2.returncode, dt, n / dt))
+print(open(d + "/out2.tsv").read().strip().splitlines()[-1])
+print("\n".join(l for l in r2.stderr.splitlines() if "haplocart:" in l))
 print("\n".join(l for l in r.stderr.splitlines() if "haplocart:" in l or "parse_gam" in l or "warning" in l))

@@ -131,6 +131,7 @@ SYMBOLS = {
     "vgan_aln_filter": (C.c_int, [vp, vp, C.POINTER(vp)]),
     "vgan_aln_free": (None, [vp]),
     "vgan_hc_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
+    "vgan_hc_flatten_masked": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
     "vgan_hc_host_batch_get": (C.c_int, [vp, C.POINTER(HcBatch)]),
     "vgan_hc_host_batch_free": (None, [vp]),
     "vgan_reconstruct": (C.c_int, [vp, vp, C.c_int64, C.c_char_p, C.c_char_p, vp, C.c_int64, vp]),

@@ -140,7 +140,7 @@ struct Chunk {
     vgan_hc_flatten_stats st{};
 };
 
-void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, Chunk &c) {
+void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, const uint8_t *skip, Chunk &c) {
     Recon rc;
     { // size the chunk's arrays
         auto &b = c.b; // from the input volume, so that they grow at most once or twice
@@ -160,6 +160,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         b.qual.reserve(nq);
     }
     for (int64_t r = r0; r < r1; ++r) {
+        if (skip && skip[r]) continue;
         c.st.n_in++;
         if (a.identity[r] < 1e-10) {
             c.st.n_unmapped++;
@@ -238,6 +239,11 @@ template <class T> void append_shifted(std::vector<T> &dst, const std::vector<T>
 
 extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
                                vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    return vgan_hc_flatten_masked(g, a, r0, r1, nullptr, n_threads, out, stats);
+}
+
+extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
+                                      int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
     if (!g || !a || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten: null argument");
     if (r0 < 0 || r1 > a->n_reads() || r0 > r1) return fail(VGAN_EINVAL, "vgan_hc_flatten: bad read range");
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -248,8 +254,8 @@ extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t) {
         const int64_t b0 = r0 + n * t / n_threads, b1 = r0 + n * (t + 1) / n_threads;
-        if (n_threads == 1) flatten_range(*g, *a, b0, b1, chunks[t]);
-        else th.emplace_back(flatten_range, std::cref(*g), std::cref(*a), b0, b1, std::ref(chunks[t]));
+        if (n_threads == 1) flatten_range(*g, *a, b0, b1, skip, chunks[t]);
+        else th.emplace_back(flatten_range, std::cref(*g), std::cref(*a), b0, b1, skip, std::ref(chunks[t]));
     }
     for (auto &t : th) t.join();
     pt.lap("chunks");

@@ -173,20 +173,14 @@ int haplocart(int argc, char **argv) {
     vgan_alnset_view av;
     check(vgan_aln_view_get(alns, &av), "alignment view");
     if (!quiet) std::cerr << "Found " << av.n_reads << " reads." << '\n';
+    std::vector<uint8_t> dup; // reads dropped by the flatten step
+    int64_t n_dup = 0;
     if (rmdup && fastafilename.empty()) { // HaploCart.cpp:386-393
-        std::vector<uint8_t> dup((size_t)av.n_reads);
-        int64_t nd = 0;
-        check(vgan_aln_mark_duplicates(alns, dup.data(), &nd), "duplicate removal");
-        if (nd) {
-            vgan_alnset *kept = nullptr;
-            check(vgan_aln_filter(alns, dup.data(), &kept), "duplicate removal");
-            vgan_aln_free(alns);
-            alns = kept;
-            check(vgan_aln_view_get(alns, &av), "alignment view");
-        }
+        dup.resize((size_t)av.n_reads);
+        check(vgan_aln_mark_duplicates(alns, dup.data(), &n_dup), "duplicate removal");
         if (!quiet) std::cerr << "PCR duplicates removed." << std::endl;
     }
-    int64_t n_reads = av.n_reads;
+    int64_t n_reads = av.n_reads - n_dup;
     pt.lap("duplicate removal");
 
     if (!fastafilename.empty() && !quiet) std::cerr << "Using background error probability of " << background_error_prob << '\n';
@@ -194,11 +188,11 @@ int haplocart(int argc, char **argv) {
 
     const int64_t BATCH = 500000; // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i
     vgan_hc_flatten_stats tot{};
-    for (int64_t r0 = 0; r0 < n_reads; r0 += BATCH) {
-        const int64_t r1 = std::min(n_reads, r0 + BATCH);
+    for (int64_t r0 = 0; r0 < av.n_reads; r0 += BATCH) {
+        const int64_t r1 = std::min<int64_t>(av.n_reads, r0 + BATCH);
         vgan_hc_host_batch *hb = nullptr;
         vgan_hc_flatten_stats st;
-        check(vgan_hc_flatten(graph, alns, r0, r1, n_threads, &hb, &st), "flattening");
+        check(vgan_hc_flatten_masked(graph, alns, r0, r1, dup.empty() ? nullptr : dup.data(), n_threads, &hb, &st), "flattening");
         vgan_hc_batch b;
         check(vgan_hc_host_batch_get(hb, &b), "batch");
         // the copy out of the host batch completes inside the call (pageable memory is staged by the runtime); the

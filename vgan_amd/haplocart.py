@@ -205,11 +205,15 @@ _BATCH_FIELDS = (("read_seg_off", np.uint32, "R1"), ("read_col_off", np.uint32, 
 class HostBatch:
     """Flattened HaploCart batch in host memory (vgan_hc_flatten)."""
 
-    def __init__(self, graph, alns, r0=0, r1=None, n_threads=0):
+    def __init__(self, graph, alns, r0=0, r1=None, n_threads=0, skip=None):
+        """skip: optional bool/uint8 mask over the alignment set (e.g. AlnSet.mark_duplicates()): reads left out."""
         r1 = alns.n_reads if r1 is None else r1
         self._h = N.vp()
         self.stats = N.FlattenStats()
-        N.check(N.lib().vgan_hc_flatten(graph._h, alns._h, r0, r1, n_threads, C.byref(self._h), C.byref(self.stats)))
+        sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+        assert sk is None or len(sk) == alns.n_reads
+        N.check(N.lib().vgan_hc_flatten_masked(graph._h, alns._h, r0, r1, None if sk is None else sk.ctypes.data, n_threads,
+                                               C.byref(self._h), C.byref(self.stats)))
         self.c = N.HcBatch()
         N.check(N.lib().vgan_hc_host_batch_get(self._h, C.byref(self.c)))
 
