@@ -8,6 +8,7 @@
 #include <deque>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -282,18 +283,31 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     for (uint32_t t = 0; t < c->n_tiles; ++t) tw0[t + 1] = (uint16_t)(tw0[t] + tile_base + (t < tile_rem ? 1 : 0));
     const uint32_t row_entries = c->n_tiles * 64;
     std::vector<uint16_t> umT((size_t)c->rows * row_entries, 0);
-    for (uint32_t r = 0; r < c->rows; ++r) {
-        const uint64_t *src = &um[(size_t)r * c->W];
-        uint16_t *dst = &umT[(size_t)r * row_entries];
-        for (uint32_t t = 0; t < c->n_tiles; ++t) {
-            for (uint32_t k = 0; k < (uint32_t)(tw0[t + 1] - tw0[t]); ++k) {
-                uint64_t bits = src[tw0[t] + k];
-                while (bits) {
-                    const int l = __builtin_ctzll(bits);
-                    bits &= bits - 1;
-                    dst[t * 64 + l] |= (uint16_t)(1u << (15 - k));
+    {
+        auto rows_range = [&](uint32_t r0, uint32_t r1) {
+            for (uint32_t r = r0; r < r1; ++r) {
+                const uint64_t *src = &um[(size_t)r * c->W];
+                uint16_t *dst = &umT[(size_t)r * row_entries];
+                for (uint32_t t = 0; t < c->n_tiles; ++t) {
+                    for (uint32_t k = 0; k < (uint32_t)(tw0[t + 1] - tw0[t]); ++k) {
+                        uint64_t bits = src[tw0[t] + k];
+                        while (bits) {
+                            const int l = __builtin_ctzll(bits);
+                            bits &= bits - 1;
+                            dst[t * 64 + l] |= (uint16_t)(1u << (15 - k));
+                        }
+                    }
                 }
             }
+        };
+        const uint32_t nth = std::min<uint32_t>(16, std::max<uint32_t>(1, std::min<uint32_t>(std::thread::hardware_concurrency(), c->rows / 256)));
+        if (nth <= 1) {
+            rows_range(0, c->rows);
+        } else {
+            std::vector<std::thread> th;
+            for (uint32_t t = 0; t < nth; ++t)
+                th.emplace_back(rows_range, (uint32_t)((uint64_t)c->rows * t / nth), (uint32_t)((uint64_t)c->rows * (t + 1) / nth));
+            for (auto &t : th) t.join();
         }
     }
     std::vector<HcNodeDev> nt(c->rows);

@@ -97,6 +97,23 @@ struct MappedFile {
     bool open_path(const std::string &path);
 };
 
+// Block-parallel BGZF inflate that hands out the prefix inflated so far: the consumer (GAM framing) starts while later
+// blocks are still being inflated (util.cpp).  start() returns false for anything that is not a BGZF stream.
+struct AsyncInflate {
+    ByteBuf out;
+    AsyncInflate();
+    ~AsyncInflate();
+    AsyncInflate(const AsyncInflate &) = delete;
+    AsyncInflate &operator=(const AsyncInflate &) = delete;
+    bool start(const void *data, size_t n);
+    bool wait_for(size_t upto); // until bytes [0, min(upto, out.size())) are final; false when a block was corrupt
+    bool finish();              // joins the workers; false when a block was corrupt
+
+  private:
+    struct Impl;
+    Impl *impl;
+};
+
 // Phase timing of the host front end to stderr when VGAN_TIMING is set in the environment (developer aid).
 struct PhaseTimer {
     const char *what;

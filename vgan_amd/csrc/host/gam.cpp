@@ -303,13 +303,27 @@ extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped
     if (!bytes || !out) return fail(VGAN_EINVAL, "vgan_aln_parse_gam: null argument");
     PhaseTimer pt("parse_gam");
     ByteBuf inflated;
+    AsyncInflate bg; // BGZF (what vg writes): framing below runs on the prefix inflated so far
     const uint8_t *p = (const uint8_t *)bytes;
+    bool streaming = false;
     if (n >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
-        if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
-        p = (const uint8_t *)inflated.data();
-        n = inflated.size();
+        if (bg.start(bytes, n)) {
+            streaming = true;
+            p = (const uint8_t *)bg.out.data();
+            n = bg.out.size();
+        } else {
+            if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
+            p = (const uint8_t *)inflated.data();
+            n = inflated.size();
+        }
     }
-    pt.lap("inflate");
+    pt.lap(streaming ? "inflate started" : "inflate");
+    // bytes [0, upto) of the stream must be final before the framing loop reads them
+    const uint8_t *const base = p;
+    bool inflate_ok = true;
+    auto need = [&](const uint8_t *upto) {
+        if (streaming && inflate_ok) inflate_ok = bg.wait_for((size_t)(upto - base));
+    };
     // Framing (serial: groups of {count, count x (len, bytes)}, the first item of a group possibly the type tag "GAM")
     // hands slices of messages to parser threads as it goes, so parsing overlaps it.
     using Msg = std::pair<const uint8_t *, const uint8_t *>;
@@ -384,19 +398,25 @@ extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped
         open_slice();
         std::vector<Msg> *cur = &slices.back();
         Cur c{p, p + n, true};
-        while (!c.done()) {
+        while (!c.done() && inflate_ok) {
+            need(c.p + 10); // a varint
             const uint64_t count = c.varint();
             if (!c.ok) break;
             bool first = true;
-            for (uint64_t i = 0; i < count && c.ok; ++i) {
-                Cur item = c.sub();
+            for (uint64_t i = 0; i < count && c.ok && inflate_ok; ++i) {
+                need(c.p + 10);
+                Cur item = c.sub(); // the length only: the payload is not touched here
                 if (!c.ok) break;
                 if (first) {
                     first = false;
-                    if (item.e - item.p == 3 && memcmp(item.p, "GAM", 3) == 0) continue;
+                    if (item.e - item.p == 3) {
+                        need(item.e);
+                        if (memcmp(item.p, "GAM", 3) == 0) continue;
+                    }
                 }
                 cur->emplace_back(item.p, item.e);
                 if (cur->size() == SLICE) {
+                    need(item.e); // the parsers read the payloads
                     open_slice();
                     cur = &slices.back();
                     cv.notify_one();
@@ -404,7 +424,8 @@ extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped
             }
             if (!c.ok) break;
         }
-        framed = c.ok;
+        need(p + n);
+        framed = c.ok && inflate_ok;
         {
             std::lock_guard<std::mutex> lk(mu);
             framing_done = true;
@@ -417,6 +438,8 @@ extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped
     } else if (framed) {
         for (size_t i = 0; i < slices.size(); ++i) parse_slice(slices[i], slice_parts[i]);
     }
+    if (streaming && !bg.finish()) inflate_ok = false;
+    if (!inflate_ok) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
     if (!framed) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
     parts.resize(slice_parts.size());
     for (size_t i = 0; i < slice_parts.size(); ++i) parts[i] = std::move(slice_parts[i]);

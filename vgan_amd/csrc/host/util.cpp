@@ -12,6 +12,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <memory>
+#include <condition_variable>
 #include <cstring>
 #include <fstream>
 #include <sys/stat.h>
@@ -146,6 +149,83 @@ bool gunzip_members(const void *data, size_t n, ByteBuf &out) {
         n -= used;
     }
     return true;
+}
+
+struct AsyncInflate::Impl {
+    std::vector<BgzfBlock> blocks;
+    const unsigned char *in = nullptr;
+    std::unique_ptr<std::atomic<uint8_t>[]> done;
+    std::atomic<size_t> next{0};
+    std::atomic<size_t> avail{0};
+    std::atomic<bool> failed{false};
+    size_t prefix = 0; // blocks [0, prefix) are done (under mu)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::thread> th;
+};
+
+AsyncInflate::AsyncInflate() : impl(new Impl()) {}
+
+AsyncInflate::~AsyncInflate() {
+    (void)finish();
+    delete impl;
+}
+
+bool AsyncInflate::start(const void *data, size_t n) {
+    Impl &m = *impl;
+    m.in = (const unsigned char *)data;
+    if (!bgzf_index(m.in, n, m.blocks) || m.blocks.empty()) return false;
+    out.resize(m.blocks.back().out_off + m.blocks.back().out_size);
+    m.done.reset(new std::atomic<uint8_t>[m.blocks.size()]);
+    for (size_t i = 0; i < m.blocks.size(); ++i) m.done[i].store(0, std::memory_order_relaxed);
+    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, m.blocks.size() / 64));
+    auto work = [this]() {
+        Impl &m = *impl;
+        constexpr size_t RUN = 32; // blocks per grab (~2 MB of output: a thread first-touches whole huge pages), in file order
+        for (;;) {
+            const size_t i0 = m.next.fetch_add(RUN, std::memory_order_relaxed);
+            if (i0 >= m.blocks.size() || m.failed.load(std::memory_order_relaxed)) break;
+            const size_t i1 = std::min(m.blocks.size(), i0 + RUN);
+            for (size_t i = i0; i < i1; ++i) {
+                const BgzfBlock &b = m.blocks[i];
+                if (!inflate_member(m.in + b.in_off, b.in_size, (unsigned char *)out.data() + b.out_off, b.out_size)) {
+                    m.failed = true;
+                    std::lock_guard<std::mutex> lk(m.mu);
+                    m.cv.notify_all();
+                    return;
+                }
+                m.done[i].store(1, std::memory_order_release);
+            }
+            std::lock_guard<std::mutex> lk(m.mu);
+            size_t p = m.prefix;
+            while (p < m.blocks.size() && m.done[p].load(std::memory_order_acquire)) ++p;
+            if (p != m.prefix) {
+                m.prefix = p;
+                m.avail.store(m.blocks[p - 1].out_off + m.blocks[p - 1].out_size, std::memory_order_release);
+                m.cv.notify_all();
+            }
+        }
+    };
+    for (unsigned t = 0; t < nt; ++t) m.th.emplace_back(work);
+    return true;
+}
+
+bool AsyncInflate::wait_for(size_t upto) {
+    Impl &m = *impl;
+    upto = std::min(upto, out.size());
+    if (m.avail.load(std::memory_order_acquire) >= upto) return !m.failed.load();
+    std::unique_lock<std::mutex> lk(m.mu);
+    m.cv.wait(lk, [&] { return m.avail.load(std::memory_order_acquire) >= upto || m.failed.load(); });
+    return !m.failed.load();
+}
+
+bool AsyncInflate::finish() {
+    Impl &m = *impl;
+    for (auto &t : m.th)
+        if (t.joinable()) t.join();
+    m.th.clear();
+    return !m.failed.load();
 }
 
 bool gunzip_members(const void *data, size_t n, std::string &out) {
