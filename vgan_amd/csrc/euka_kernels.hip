@@ -142,8 +142,6 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             const uint32_t n_before = carry_n + (uint32_t)__builtin_popcount(nongap & below);
             const uint32_t n = rev ? (Lseq - 1u - n_before) : n_before; // unsigned wrap as in the reference
             const uint32_t kind = min(gcl >> 4, rcl >> 4);                // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
-            const uint32_t scb = row_bits(active && kind == 3u);
-            const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
             int q = (m < QL && QL > 0u) ? q_raw : 0; // Q15
             q = q < 0 ? 0 : (q > 99 ? 99 : q);
             const double qs = qs_s[q];
@@ -166,22 +164,28 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             p = gi < 4u ? p : 0.0; // a graph base outside ACGT has no t_T_ratio entry
             // model 1 = c1 + log(a1), model 2 = l2; the cases only pick a1 / c1 / l2, so one log serves all of them
             if (kind == 4u && active && n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
-            const double bfl = bfl_s[rcl & 15u];
             double a1 = kind == 4u ? p : 1.0, c1 = 0.0;
             double l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
-            if (kind == 3u) { // :263-280
-                a1 = (sc_index % 3u == 0u) ? w_hit : w_miss;
-                l2 = -1.3862943611198906; // log(0.25)
+            // N / gap / rare / softclip columns are a few per thousand: the whole wave skips their selects unless it has one
+            if (__builtin_amdgcn_ballot_w64(active && kind != 4u)) {
+                const uint32_t scb = row_bits(active && kind == 3u);
+                const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
+                carry_sc += (uint32_t)__builtin_popcount(scb);
+                const double bfl = bfl_s[rcl & 15u];
+                if (kind == 3u) { // :263-280
+                    a1 = (sc_index % 3u == 0u) ? w_hit : w_miss;
+                    l2 = -1.3862943611198906; // log(0.25)
+                }
+                if (kind == 2u) { // :252-257
+                    a1 = (1.0 - pair_dist) * 0.001;
+                    l2 = -6.907755278982137; // log(0.001)
+                }
+                if (kind == 1u) { // :244-249
+                    c1 = -6.214608098422191;  // log(0.002)
+                    l2 = -1.6094379124341003; // log(0.2)
+                }
+                if (kind == 0u) c1 = l2 = bfl; // :236-241
             }
-            if (kind == 2u) { // :252-257
-                a1 = (1.0 - pair_dist) * 0.001;
-                l2 = -6.907755278982137; // log(0.001)
-            }
-            if (kind == 1u) { // :244-249
-                c1 = -6.214608098422191;  // log(0.002)
-                l2 = -1.6094379124341003; // log(0.2)
-            }
-            if (kind == 0u) c1 = l2 = bfl; // :236-241
             if (!active) {
                 a1 = 1.0;
                 c1 = l2 = 0.0;
@@ -190,7 +194,6 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             lik += l1;
             lik2 += l2;
             carry_n += (uint32_t)__builtin_popcount(nongap);
-            carry_sc += (uint32_t)__builtin_popcount(scb);
         }
         const double in = row_sum16(lik), out = row_sum16(lik2);
         bad = row_bits(bad) != 0u;
