@@ -144,7 +144,7 @@ typedef struct vgan_hc_batch {
     const uint32_t *read_src;     /* [n_reads] index of the read in the alignment set, or NULL (not used by the device) */
 } vgan_hc_batch;
 /* Batch contract: read_*_off ascending; the segments of a read ascend in seg_start.
- * Tile contract (reads below n_tileable): at most 256 columns, 256 quality bytes and 128 segments; |algnseq| equals the
+ * Tile contract (reads below n_tileable): at most 1280 columns, 1280 quality bytes and 512 segments; |algnseq| equals the
  * length of the read's graph sequence; the column ranges [seg_start, seg_start+seg_len) of the read do not overlap. */
 
 typedef struct vgan_hc_host_batch vgan_hc_host_batch; /* opaque owner of a host-side batch */

@@ -79,9 +79,10 @@ def test_bundled_alignments_as_plumbing(golden_dir):
                                 dict(background_error_prob=0.3)])
 def test_small_synth_all_modes_vs_faithful_oracle(kw, tmp_path):
     g = hc.synth_graph(seed=21, genome_len=1500, n_nodes=1000, n_paths=200)
-    # reads for the tiled kernel and, beyond 256 columns, for the general one, in one batch
+    # reads for the tiled kernel (up to a whole tile: 1280 columns / 512 mappings) and, beyond, for the general one
     a = util.concat_alnsets(tmp_path, hc.synth_reads(g, 90, seed=5, read_len=150, indel_rate=0.2, softclip_rate=0.2),
-                            hc.synth_reads(g, 30, seed=6, read_len=330, indel_rate=0.2, softclip_rate=0.2))
+                            hc.synth_reads(g, 20, seed=6, read_len=700, indel_rate=0.2, softclip_rate=0.2),
+                            hc.synth_reads(g, 20, seed=7, read_len=1400, indel_rate=0.2, softclip_rate=0.2))
     og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
     b = hc.HostBatch(g, a)
     ctx = hc.HcContext(g, **kw)
@@ -289,7 +290,7 @@ def test_cli_end_to_end(tmp_path):
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_tiled_kernel_fuzz_against_general_kernel(seed):
     """Random batches that satisfy the tile contract, built by hand over the C-ABI (no flatten step): ragged reads of
-    1..256 columns, quality strings shorter / longer than the read or empty, zero-length segments, segments that stop
+    1..1280 columns, quality strings shorter / longer than the read or empty, zero-length segments, segments that stop
     before the read ends, bases outside ACGT, qualities >= 90 and negative.  D_m from the LDS-tiled kernel must equal
     S_m - U_m from the general kernel (which the other tests hold against the oracle)."""
     rng = np.random.default_rng(seed)
@@ -301,14 +302,14 @@ def test_tiled_kernel_fuzz_against_general_kernel(seed):
     gseq, rseq, qual = [], [], []
     alphabet = np.frombuffer(b"ACGT" * 12 + b"NacgtS-RY", np.uint8)
     for r in range(R):
-        cols = int(rng.integers(1, 257)) if r % 7 else int(rng.choice([1, 2, 255, 256]))
+        cols = int(rng.integers(1, 257)) if r % 7 else int(rng.choice([1, 2, 255, 256, 700, 1279, 1280]))
         A = cols
-        ql = int(rng.choice([cols, cols, cols, max(0, cols - int(rng.integers(1, 9))), min(256, cols + 5), 0]))
+        ql = int(rng.choice([cols, cols, cols, max(0, cols - int(rng.integers(1, 9))), min(1280, cols + 5), 0]))
         pos = 0
         nseg = 0
         max_run = int(rng.choice([3, 8, 40, 200]))
         stop_early = rng.random() < 0.2
-        while pos < cols and nseg < 128:
+        while pos < cols and nseg < 512:
             if rng.random() < 0.05:
                 ln = 0  # a mapping without columns
             else:

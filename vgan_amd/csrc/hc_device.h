@@ -55,9 +55,10 @@ struct HcParamsDev {
 };
 
 // per-read limits of the LDS-tiled segment kernel (the tile contract of include/vgan_gpu.h; flatten.cpp applies them)
-constexpr uint32_t HC_TILE_MAX_READ_COLS = 256;
-constexpr uint32_t HC_TILE_MAX_READ_QUAL = 256;
-constexpr uint32_t HC_TILE_MAX_READ_SEGS = 128;
+// (a read has to fit one LDS tile; every phase of the kernel is flat over the tile, so there is no smaller per-read bound)
+constexpr uint32_t HC_TILE_MAX_READ_COLS = 1280;
+constexpr uint32_t HC_TILE_MAX_READ_QUAL = 1280;
+constexpr uint32_t HC_TILE_MAX_READ_SEGS = 512;
 
 // reads [0, n_tileable) go through the LDS-tiled kernel (D_m only), the rest -- or everything when S_m / U_m are asked
 // for separately -- through the general one

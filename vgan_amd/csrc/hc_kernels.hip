@@ -159,6 +159,9 @@ constexpr int ST_QB = ST_QUAL / ST_THREADS;         // quality bytes per lane in
 constexpr int ST_QW = ST_QB * 64;                   // quality bytes per wave in phase B
 constexpr int ST_SEG_ITERS = ST_SEGS / ST_THREADS;  // segments per lane in phases C and E
 static_assert((ST_SEGS & (ST_SEGS - 1)) == 0, "segment index mask");
+static_assert(HC_TILE_MAX_READ_COLS <= (uint32_t)ST_COLS && HC_TILE_MAX_READ_QUAL <= (uint32_t)ST_QUAL &&
+                  HC_TILE_MAX_READ_SEGS <= (uint32_t)ST_SEGS,
+              "a tileable read fits one tile");
 static_assert(ST_QB * ST_THREADS == ST_QUAL && ST_SEG_ITERS * ST_THREADS == ST_SEGS && ST_WAVES == 4,
               "tile shape");
 static_assert(ST_COLS <= 2 * 4 * ST_THREADS - 8 && ST_QUAL <= 2 * 4 * ST_THREADS - 8, "byte windows: two dwords per thread");

@@ -132,7 +132,7 @@ int vgan::reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Reco
 namespace {
 
 // per-read limits of the device's LDS-tiled kernel (hc_device.h keeps the same numbers)
-constexpr size_t TILE_MAX_COLS = 256, TILE_MAX_QUAL = 256, TILE_MAX_SEGS = 128;
+constexpr size_t TILE_MAX_COLS = 1280, TILE_MAX_QUAL = 1280, TILE_MAX_SEGS = 512;
 
 struct Chunk {
     vgan_hc_host_batch b;   // reads that satisfy the tile contract

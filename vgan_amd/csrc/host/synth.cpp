@@ -386,7 +386,7 @@ template <class T> void cat(std::vector<T> &d, const std::vector<T> &s, size_t s
 
 extern "C" int vgan_synth_hc_reads(const vgan_graph *g, const vgan_synth_reads_cfg *cfg, vgan_alnset **out) {
     if (!g || !cfg || !out) return fail(VGAN_EINVAL, "vgan_synth_hc_reads: null argument");
-    if (cfg->read_len < 1 || cfg->read_len > 1000) return fail(VGAN_EINVAL, "vgan_synth_hc_reads: read_len must be 1..1000");
+    if (cfg->read_len < 1 || cfg->read_len > 20000) return fail(VGAN_EINVAL, "vgan_synth_hc_reads: read_len must be 1..20000");
     Walk w;
     std::vector<uint32_t> first;
     build_walks(*g, w, first);
