@@ -287,7 +287,7 @@ def test_cli_end_to_end(tmp_path):
     assert len(fields) // 3 == len(exp)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
 def test_tiled_kernel_fuzz_against_general_kernel(seed):
     """Random batches that satisfy the tile contract, built by hand over the C-ABI (no flatten step): ragged reads of
     1..1280 columns, quality strings shorter / longer than the read or empty, zero-length segments, segments that stop
@@ -302,7 +302,10 @@ def test_tiled_kernel_fuzz_against_general_kernel(seed):
     gseq, rseq, qual = [], [], []
     alphabet = np.frombuffer(b"ACGT" * 12 + b"NacgtS-RY", np.uint8)
     for r in range(R):
-        cols = int(rng.integers(1, 257)) if r % 7 else int(rng.choice([1, 2, 255, 256, 700, 1279, 1280]))
+        if seed >= 4:  # short reads: the 24-reads-per-tile variant of the kernel (mean read below 110 columns)
+            cols = int(rng.integers(1, 90)) if r % 50 else int(rng.choice([1, 300, 1280]))
+        else:
+            cols = int(rng.integers(1, 257)) if r % 7 else int(rng.choice([1, 2, 255, 256, 700, 1279, 1280]))
         A = cols
         ql = int(rng.choice([cols, cols, cols, max(0, cols - int(rng.integers(1, 9))), min(1280, cols + 5), 0]))
         pos = 0

@@ -437,7 +437,7 @@ extern "C" int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *b) {
     if ((rc = c->segD.reserve(b->n_segments))) return rc;
     {
         ScopedTimer t(c, VGAN_HC_K_SEGMENT);
-        launch_hc_segments(c->g, d, c->prm, b->n_tileable, nullptr, nullptr, c->segD.p, c->totals.p, c->stream);
+        launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, c->segD.p, c->totals.p, c->stream);
     }
     if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) {
         ScopedTimer t(c, VGAN_HC_K_NODEACC);
@@ -460,7 +460,7 @@ extern "C" int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *b, d
     HcBatchDev d{};
     if ((rc = stage_batch(c, b, d))) return rc;
     if ((rc = c->segS.reserve(b->n_segments)) || (rc = c->segU.reserve(b->n_segments))) return rc;
-    launch_hc_segments(c->g, d, c->prm, b->n_tileable, c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(S, c->segS.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(U, c->segU.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
@@ -477,7 +477,7 @@ extern "C" int vgan_hc_segment_weights(vgan_hc_ctx *c, const vgan_hc_batch *b, d
     HcBatchDev d{};
     if ((rc = stage_batch(c, b, d))) return rc;
     if ((rc = c->segD.reserve(b->n_segments))) return rc;
-    launch_hc_segments(c->g, d, c->prm, b->n_tileable, nullptr, nullptr, c->segD.p, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, c->segD.p, nullptr, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(D, c->segD.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -496,7 +496,7 @@ extern "C" int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *b, doubl
     const size_t n = (size_t)b->n_reads * c->P;
     if ((rc = c->segS.reserve(b->n_segments + 1)) || (rc = c->segU.reserve(b->n_segments + 1)) || (rc = c->dump.reserve(n)))
         return rc;
-    launch_hc_segments(c->g, d, c->prm, b->n_tileable, c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
     launch_hc_read_loglik(c->g, d, c->segS.p, c->segU.p, c->dump.p, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, c->dump.p, n * 8, hipMemcpyDeviceToHost, c->stream));

@@ -62,8 +62,8 @@ constexpr uint32_t HC_TILE_MAX_READ_SEGS = 512;
 
 // reads [0, n_tileable) go through the LDS-tiled kernel (D_m only), the rest -- or everything when S_m / U_m are asked
 // for separately -- through the general one
-void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable, double *segS,
-                        double *segU, double *segD, double *totals, hipStream_t st);
+void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable,
+                        uint32_t mean_cols_per_read, double *segS, double *segU, double *segD, double *totals, hipStream_t st);
 int launch_hc_nodeacc(const uint32_t *seg_node, const double *segD, uint32_t n_items, uint32_t rows, double *nodeW,
                       hipStream_t st);
 void launch_hc_sweep(const HcGraphDev &g, const uint32_t *item_node, const double *D, uint32_t n_items, int skip_zero,

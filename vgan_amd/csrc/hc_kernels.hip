@@ -8,7 +8,7 @@
 // do not depend on p.  final[p] = sum_r ll_r[p]                                   (src/HaploCart.cpp:420).
 //
 // Kernels:
-//   hc_segment_tile_kernel   S_m, U_m per segment.  A 256-thread workgroup takes a tile of up to 8 reads:
+//   hc_segment_tile_kernel   S_m, U_m per segment.  A 256-thread workgroup takes a tile of up to 8 (24 for short) reads:
 //                       (1) one wave per read: quality-window prefix sums by a DPP wave scan into LDS, then one
 //                       lane per segment computes U_m and marks its columns; (2) one lane per alignment column,
 //                       flat over the tile: the log term, reduced per segment with LDS fp64 atomics; (3) one lane
@@ -151,7 +151,9 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
 //   E  lane per segment: D_m = S_m - U_m streamed out
 constexpr int ST_THREADS = 256;
 constexpr int ST_WAVES = ST_THREADS / 64;
-constexpr int ST_READS = 8;   // reads per tile (at most)
+constexpr int ST_READS_LONG = 8;   // reads per tile (at most) for batches of long reads (compare-sum read lookup),
+constexpr int ST_READS_SHORT = 24; // ... of short reads: 40-column reads (ancient DNA) still fill most of a tile
+constexpr int ST_READS_LOG2 = 5; // steps of the segment -> read search (2^5 >= ST_READS)
 constexpr int ST_COLS = 1280; // LDS capacity per tile: alignment columns,
 constexpr int ST_QUAL = 1280; //                        quality bytes,
 constexpr int ST_SEGS = 512;  //                        segments
@@ -159,6 +161,7 @@ constexpr int ST_QB = ST_QUAL / ST_THREADS;         // quality bytes per lane in
 constexpr int ST_QW = ST_QB * 64;                   // quality bytes per wave in phase B
 constexpr int ST_SEG_ITERS = ST_SEGS / ST_THREADS;  // segments per lane in phases C and E
 static_assert((ST_SEGS & (ST_SEGS - 1)) == 0, "segment index mask");
+static_assert((1 << ST_READS_LOG2) >= ST_READS_SHORT && ST_READS_SHORT < 64, "read search / header lanes");
 static_assert(HC_TILE_MAX_READ_COLS <= (uint32_t)ST_COLS && HC_TILE_MAX_READ_QUAL <= (uint32_t)ST_QUAL &&
                   HC_TILE_MAX_READ_SEGS <= (uint32_t)ST_SEGS,
               "a tileable read fits one tile");
@@ -230,14 +233,15 @@ struct StLoads { // one tile's HBM data in flight
     HcNodeDev nd[ST_SEG_ITERS];
 };
 
+template <int ST_READS>
 __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
                                                                       uint32_t n_tileable, uint32_t reads_per_block,
                                                                       double *__restrict__ segD_out,
                                                                       double *__restrict__ totals) {
     __shared__ double lq_s[256];
     __shared__ double qs_s[101];      // qscore_vec, and the background error rate in slot 100
-    __shared__ double incmap_s[100];
     __shared__ double bg_s[4];
+    __shared__ double incmap_s[ST_READS <= 8 ? 100 : 1]; // the long-read variant has the LDS to keep incorrect_mapping_vec
     __shared__ uint8_t code_s[256];   // A C T G -> 0 1 2 3 (bg_s order), anything else 4 (libgab isValidDNA is false)
     __shared__ LogTabEntry logtab_s[64];
     __shared__ double ps_s[ST_QUAL + 1]; // wave-local prefix sums of log p_err over the tile's quality bytes
@@ -260,7 +264,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 256; i += ST_THREADS) lq_s[i] = g.lq[i];
     for (int i = tid; i < 101; i += ST_THREADS) qs_s[i] = i < 100 ? g.qscore[i] : prm.bep;
-    for (int i = tid; i < 100; i += ST_THREADS) incmap_s[i] = g.incmap[i];
+    if constexpr (ST_READS <= 8)
+        for (int i = tid; i < 100; i += ST_THREADS) incmap_s[i] = g.incmap[i];
     for (int i = tid; i < 256; i += ST_THREADS) code_s[i] = is_acgt((uint32_t)i) ? (uint8_t)((i >> 1) & 3) : (uint8_t)4;
     for (int i = tid; i < 64; i += ST_THREADS) logtab_s[i] = hc_log_table[i];
     if (tid < 4) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : 0.16644; // A C T G by (c>>1)&3
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
 
     // header values travel in registers of threads 0..ST_READS until they are published in LDS
     uint32_t h_seg = 0, h_col = 0, h_q = 0, h_A = 0, h_mapq = 0;
+    double h_pinc = 0.0;
     auto header_request = [&](uint32_t first) {
         if (tid <= ST_READS) {
             const uint32_t r = min(first + tid, rb1);
@@ -283,6 +289,11 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             h_A = b.read_algn_len[rr];
             h_mapq = b.read_mapq[rr];
         }
+    };
+    // incorrect_mapping_vec[mapq]: a dependent load, issued a phase after the request so that nothing waits on it
+    auto header_resolve = [&]() {
+        if constexpr (ST_READS > 8)
+            if (tid <= ST_READS) h_pinc = g.incmap[min(h_mapq, 99u)];
     };
     // Wave 0 publishes the header and the tile's extents: reads [first, first+n) with n the largest count whose
     // segments, columns and quality bytes fit the LDS tile (one read always fits: the host selects this kernel only
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 off_s[buf][2][tid] = h_q;
                 if (tid < ST_READS) {
                     rdA_s[buf][tid] = h_A;
-                    rdpinc_s[buf][tid] = incmap_s[min(h_mapq, 99u)];
+                    rdpinc_s[buf][tid] = ST_READS <= 8 ? incmap_s[min(h_mapq, 99u)] : h_pinc;
                 }
             }
             // clamped: a read that breaks the tile contract (a caller's error) must not index past the LDS arrays
@@ -341,6 +352,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     // ---- prologue: the first tile's header and data, the second tile's header
     uint32_t r0 = rb0, cur = 0;
     header_request(r0);
+    header_resolve();
     __syncthreads(); // the tables above are in place
     header_publish(cur, r0);
     __syncthreads();
@@ -348,7 +360,10 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     StLoads L;
     tile_request(T, L);
     tile_gather(T, L);
-    if (r0 + T.n < rb1) header_request(r0 + T.n);
+    if (r0 + T.n < rb1) {
+        header_request(r0 + T.n);
+        header_resolve();
+    }
 
     while (true) {
         const bool has_next = r0 + T.n < rb1; // wave (and workgroup) uniform
@@ -406,9 +421,11 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         // ---- C: one lane per segment
         double segU[ST_SEG_ITERS];
         {
-            uint32_t seg_off_r[ST_READS]; // segment offsets of reads 1.. (wave uniform), for the segment -> read lookup
+            uint32_t seg_off_r[ST_READS <= 8 ? ST_READS : 1]; // segment offsets of reads 1.. (wave uniform) for the compare-sum
+            if constexpr (ST_READS <= 8) {
 #pragma unroll
-            for (int t = 1; t < ST_READS; ++t) seg_off_r[t] = (uint32_t)t < T.n ? off_s[cur][0][t] : 0xFFFFFFFFu;
+                for (int t = 1; t < ST_READS; ++t) seg_off_r[t] = (uint32_t)t < T.n ? off_s[cur][0][t] : 0xFFFFFFFFu;
+            }
             const double ws0 = wsum_s[0], ws1 = wsum_s[1], ws2 = wsum_s[2];
 #pragma unroll
             for (int it = 0; it < ST_SEG_ITERS; ++it) {
@@ -416,9 +433,21 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 segU[it] = 0.0;
                 if (ls < T.n_seg) {
                     const uint32_t s = T.seg_base + ls;
+                    // read of the segment: the last k < n with off[k] <= s
                     uint32_t k = 0;
+                    if constexpr (ST_READS <= 8) { // compare-sum over the (wave uniform) offsets
 #pragma unroll
-                    for (int t = 1; t < ST_READS; ++t) k += s >= seg_off_r[t] ? 1u : 0u;
+                        for (int t = 1; t < ST_READS; ++t) k += s >= seg_off_r[t] ? 1u : 0u;
+                    } else { // binary search, LDS broadcast reads
+                        uint32_t kend = T.n;
+#pragma unroll
+                        for (int step = 0; step < ST_READS_LOG2; ++step) {
+                            const uint32_t mid = (k + kend) >> 1;
+                            const bool up = mid > k && off_s[cur][0][mid] <= s;
+                            k = up ? mid : k;
+                            kend = up ? kend : (mid > k ? mid : kend);
+                        }
+                    }
                     const uint32_t colbase = off_s[cur][1][k] - T.col_base;
                     const uint32_t qo = off_s[cur][2][k], QL = off_s[cur][2][k + 1] - qo, qoff = qo - T.q_base;
                     const uint32_t A = rdA_s[cur][k];
@@ -507,7 +536,10 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
 #endif
         }
         PT_MARK(7);
-        if (has_next) tile_gather(Tn, Ln); // the node ids arrived during D
+        if (has_next) {
+            tile_gather(Tn, Ln); // the node ids arrived during D,
+            header_resolve();    // and so did the mapping qualities of the header requested before it
+        }
         PT_MARK(8);
         __syncthreads();
         PT_MARK(9);
@@ -781,8 +813,8 @@ extern "C" int vgan_hc_debug_phase_cycles(unsigned long long *out, int reset) {
 #endif
 
 // ---------------------------------------------------------------------------------------------- launchers
-void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable, double *segS,
-                        double *segU, double *segD, double *totals, hipStream_t st) {
+void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable,
+                        uint32_t mean_cols_per_read, double *segS, double *segU, double *segD, double *totals, hipStream_t st) {
     if (b.n_reads == 0) return;
     uint32_t nt = std::min(n_tileable, b.n_reads);
     if (segS || segU) nt = 0; // the tiled kernel produces D_m only; separate S_m / U_m (debug API) come from the general one
@@ -790,9 +822,13 @@ void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParams
         // ~6 workgroups per CU and launch round; contiguous read ranges per workgroup
         const uint32_t want_blocks = 256u * 6u * 2u;
         uint32_t per = (nt + want_blocks - 1) / want_blocks;
-        per = std::max(per, (uint32_t)ST_READS);
+        per = std::max(per, (uint32_t)ST_READS_SHORT);
         const uint32_t blocks = (nt + per - 1) / per;
-        hipLaunchKernelGGL(hc_segment_tile_kernel, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, totals);
+        // short reads: more of them per tile, or the tile's lanes idle (the estimate uses all reads of the batch)
+        if (mean_cols_per_read < 110u)
+            hipLaunchKernelGGL(hc_segment_tile_kernel<ST_READS_SHORT>, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, totals);
+        else
+            hipLaunchKernelGGL(hc_segment_tile_kernel<ST_READS_LONG>, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, totals);
     }
     if (nt < b.n_reads) {
         const uint32_t rest = b.n_reads - nt;
