@@ -8,12 +8,10 @@
 // do not depend on p.  final[p] = sum_r ll_r[p]                                   (src/HaploCart.cpp:420).
 //
 // Kernels:
-//   hc_segment_tile_kernel   S_m, U_m per segment.  A 256-thread workgroup takes a tile of up to 8 (24 for short) reads:
-//                       (1) one wave per read: quality-window prefix sums by a DPP wave scan into LDS, then one
-//                       lane per segment computes U_m and marks its columns; (2) one lane per alignment column,
-//                       flat over the tile: the log term, reduced per segment with LDS fp64 atomics; (3) one lane
-//                       per segment: D_m = S_m - U_m streamed out.  hc_segment_general_kernel is the same arithmetic
-//                       for reads of any length (one wave per read).
+//   hc_segment_tile_kernel   D_m = S_m - U_m per segment.  A 256-thread workgroup takes a tile of up to 8 (24 for short)
+//                       reads staged in LDS and works flat over it (phases B..E at the kernel); a tile's data leaves HBM
+//                       one tile ahead.  hc_segment_general_kernel is the same arithmetic for reads that do not fit a
+//                       tile (one wave per read, any length).
 //   hc_nodeacc_kernel   NODE_WEIGHTS mode: W[node] += D_m with a workgroup-private W in LDS (ds_add_f64),
 //                       flushed once per workgroup with coalesced global atomics.
 //   hc_sweep_kernel     the per-path update acc[p] += D for every path NOT supported by the node
