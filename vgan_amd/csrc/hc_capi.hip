@@ -84,7 +84,10 @@ struct vgan_hc_ctx {
     DevBuf<uint16_t> umaskT, tile_word0;
     DevBuf<HcNodeDev> node_tab;
     DevBuf<double> tables; // lq[256] qscore[100] incmap[100]
-    DevBuf<double> nodeW, acc_seg, acc_node, totals, final_vec;
+    DevBuf<double> accum;                                    // one block: nodeW | acc_seg | acc_node | totals (one memset)
+    struct View { double *p = nullptr; } nodeW, acc_seg, acc_node, totals;
+    size_t accum_n = 0;
+    DevBuf<double> final_vec;
     DevBuf<double> segD, segS, segU, dump;
     // staging for host batches
     DevBuf<uint32_t> s_u32;
@@ -328,9 +331,16 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     const size_t accn = (size_t)c->W * 64;
     if ((rc = c->umask.reserve(um.size())) || (rc = c->umaskT.reserve(umT.size())) ||
         (rc = c->tile_word0.reserve(tw0.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(456)) ||
-        (rc = c->nodeW.reserve(c->rows)) || (rc = c->acc_seg.reserve(accn)) || (rc = c->acc_node.reserve(accn)) ||
-        (rc = c->totals.reserve(2)) || (rc = c->final_vec.reserve(c->P)))
+        (rc = c->accum.reserve(((size_t)c->rows + 7) / 8 * 8 + 2 * accn + 8)) || (rc = c->final_vec.reserve(c->P)))
         return bail(rc);
+    { // sub-ranges of the accumulator block (sweep kernels read 64-byte aligned blocks of weights: keep 64-byte offsets)
+        const size_t nW = ((size_t)c->rows + 7) / 8 * 8;
+        c->nodeW.p = c->accum.p;
+        c->acc_seg.p = c->accum.p + nW;
+        c->acc_node.p = c->acc_seg.p + accn;
+        c->totals.p = c->acc_node.p + accn;
+        c->accum_n = nW + 2 * accn + 8;
+    }
     if (hipMemcpy(c->umask.p, um.data(), um.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->umaskT.p, umT.data(), umT.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->tile_word0.p, tw0.data(), tw0.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
@@ -379,10 +389,7 @@ extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
     c->tile_word0.release();
     c->node_tab.release();
     c->tables.release();
-    c->nodeW.release();
-    c->acc_seg.release();
-    c->acc_node.release();
-    c->totals.release();
+    c->accum.release();
     c->final_vec.release();
     c->segD.release();
     c->segS.release();
@@ -419,10 +426,7 @@ extern "C" int vgan_hc_set_mode(vgan_hc_ctx *c, int mode) {
 extern "C" int vgan_hc_reset(vgan_hc_ctx *c) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_reset: null context");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->nodeW.p, 0, (size_t)c->rows * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->acc_seg.p, 0, (size_t)c->W * 64 * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->acc_node.p, 0, (size_t)c->W * 64 * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->totals.p, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(c->accum.p, 0, c->accum_n * 8, c->stream));
     return VGAN_OK;
 }
 
