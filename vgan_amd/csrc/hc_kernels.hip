@@ -580,8 +580,22 @@ __global__ __launch_bounds__(1024) void hc_nodeacc_lds_kernel(const uint32_t *__
     extern __shared__ double w_s[];
     for (uint32_t j = threadIdx.x; j < rows; j += blockDim.x) w_s[j] = 0.0;
     __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x)
-        unsafeAtomicAdd(&w_s[seg_node[i]], segD[i]);
+    // four independent (node, weight) pairs in flight per lane: the stream is latency bound otherwise
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t NA_UNROLL = 4;
+    for (; (uint64_t)i + (uint64_t)(NA_UNROLL - 1) * stride < n_items; i += NA_UNROLL * stride) {
+        uint32_t nd[NA_UNROLL];
+        double dv[NA_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < NA_UNROLL; ++u) {
+            nd[u] = seg_node[i + u * stride];
+            dv[u] = segD[i + u * stride];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < NA_UNROLL; ++u) unsafeAtomicAdd(&w_s[nd[u]], dv[u]);
+    }
+    for (; i < n_items; i += stride) unsafeAtomicAdd(&w_s[seg_node[i]], segD[i]);
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < rows; j += blockDim.x) {
         const double v = w_s[j];
