@@ -328,11 +328,11 @@ def main():
         k_ms, k_n = prof[kname]
         avg_ms = k_ms / max(k_n, 1)
         # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected
-        # in separate runs of this very command, profiles/round1_v3_*_pmc.json); null when no such pass is committed.
+        # in separate runs of this very command, profiles/round1_v4_*_pmc.json); null when no such pass is committed.
         traffic = None
         try:
             tag = {"node_weights": "node", "per_read": "skip", "per_read_dense": "dense"}[args.mode]
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_v3_%s_pmc.json" % tag)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_v4_%s_pmc.json" % tag)))
             want = "hc_segment_tile_kernel" if kname == "segment" else "hc_sweep_kernel<10, false>"
             for kn, v in pmc.items():
                 if want in kn and args.reads == 1_000_000 and args.read_len == 150:

@@ -20,8 +20,10 @@ for ln in open(os.path.join(src, "bench_trace.log")):
     if ln.startswith("{"):
         bench = json.loads(ln)
 if bench:
-    lines += ["Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --mode %s --steps %d --warmup %d --cpu-seconds 0 --no-parity`"
-              % (bench["config"]["mode"], bench["steps"], bench["warmup"]), "",
+    which = ("--mode %s" % bench["config"]["mode"]) if "mode" in bench["config"] else (
+        "--path euka" if "euka" in bench["metric"] else "--path soibean --reads %d" % bench["config"].get("reads_per_gpu", 0))
+    lines += ["Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py %s --steps %d --warmup %d --cpu-seconds 0 --no-parity`"
+              % (which, bench["steps"], bench["warmup"]), "",
               "bench.py line under the profiler: value = %.4g %s, ms_per_step = %.4f" % (bench["value"], bench["unit"], bench["ms_per_step"]),
               "roofline (HIP events in bench.py): %s avg %.4f ms/launch, %.1f GB/s algorithmic = %.4f of 8 TB/s" % (
                   bench["roofline"]["kernel"], bench["roofline"]["avg_launch_ms"], bench["roofline"]["achieved"], bench["roofline"]["frac"]), ""]

@@ -266,12 +266,16 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_loglike_kernel(SbTablesDev t, 
     }
 }
 
-__global__ void sb_finish_kernel(const double *__restrict__ partial, uint32_t n_blocks, uint32_t n_states, double *__restrict__ out) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per state: lane l adds partials l, l+64, ... in order, then a shuffle tree -- a fixed order, so the sum is
+// reproducible (the first version walked all partials on one thread: 79 us of dependent loads per refresh).
+__global__ __launch_bounds__(64) void sb_finish_kernel(const double *__restrict__ partial, uint32_t n_blocks, uint32_t n_states,
+                                                       double *__restrict__ out) {
+    const uint32_t e = blockIdx.x;
     if (e >= n_states) return;
     double s = 0.0;
-    for (uint32_t i = 0; i < n_blocks; ++i) s += partial[(size_t)e * n_blocks + i]; // fixed order: reproducible
-    out[e] = s;
+    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) s += partial[(size_t)e * n_blocks + i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[e] = s;
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
@@ -297,7 +301,7 @@ void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states
     (void)n_paths;
     const size_t lds = (size_t)n_states * k * 2 * SB_NCNT * sizeof(double);
     hipLaunchKernelGGL(sb_loglike_kernel, dim3(n_blocks), dim3(SBL_THREADS), lds, st, t, n_states, k, src, hky, partial, guard);
-    hipLaunchKernelGGL(sb_finish_kernel, dim3((n_states + 63) / 64), dim3(64), 0, st, partial, n_blocks, n_states, out);
+    hipLaunchKernelGGL(sb_finish_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, n_states, out);
 }
 
 } // namespace vgan
