@@ -65,6 +65,7 @@ struct vgan_sb_ctx {
     Buf<uint8_t> s8;
     Buf<SbSourceDev> src;
     Buf<double> hky, partial, out, freqs;
+    std::vector<char> h_params; // host staging of one refresh's parameters
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[2] = {false, false};
     double ms[2] = {0, 0};
@@ -308,19 +309,22 @@ extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, co
     const uint32_t R = c->t.n_reads;
     const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
     int rc;
-    if ((rc = c->src.reserve(ne)) || (rc = c->hky.reserve((size_t)ne * 2 * SB_NCNT)) || (rc = c->partial.reserve((size_t)n_states * n_blocks)) ||
+    if ((rc = c->src.reserve(ne + 2)) || (rc = c->hky.reserve((size_t)ne * 2 * SB_NCNT)) || (rc = c->partial.reserve((size_t)n_states * n_blocks)) ||
         (rc = c->out.reserve(n_states)) || (rc = c->guard.reserve(n_states)))
         return rc;
-    HIPCHK(hipMemcpyAsync(c->src.p, sd.data(), ne * sizeof(SbSourceDev), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->freqs.p, freqs7, 7 * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->guard.p, 0, (size_t)n_states * 8, c->stream));
-    launch_sb_hky(ne, c->src.p, con, c->freqs.p, c->hky.p, c->stream);
+    // the sources and the seven frequencies travel in one copy: [SbSourceDev x ne][double x 7]
+    static_assert(sizeof(SbSourceDev) % 8 == 0, "freqs follow the sources at an 8-byte offset");
+    c->h_params.resize(ne * sizeof(SbSourceDev) + 7 * 8);
+    memcpy(c->h_params.data(), sd.data(), ne * sizeof(SbSourceDev));
+    memcpy(c->h_params.data() + ne * sizeof(SbSourceDev), freqs7, 7 * 8);
+    HIPCHK(hipMemcpyAsync(c->src.p, c->h_params.data(), c->h_params.size(), hipMemcpyHostToDevice, c->stream));
+    const double *d_freqs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(c->src.p) + ne * sizeof(SbSourceDev));
+    launch_sb_hky(ne, c->src.p, con, d_freqs, c->hky.p, c->guard.p, n_states, c->stream);
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    launch_sb_loglike(c->t, c->P, n_states, k, c->src.p, c->hky.p, c->partial.p, n_blocks, c->out.p, c->guard.p, c->stream);
+    launch_sb_loglike(c->t, c->P, n_states, k, c->src.p, c->hky.p, c->partial.p, n_blocks, c->out.p, d_out, c->guard.p, c->stream);
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     c->pending[1] = true;
     HIPCHK(hipGetLastError());
-    if (d_out) HIPCHK(hipMemcpyAsync(d_out, c->out.p, (size_t)n_states * 8, hipMemcpyDeviceToDevice, c->stream));
     if (out || guard) {
         std::vector<unsigned long long> gd(n_states);
         if (out) HIPCHK(hipMemcpyAsync(out, c->out.p, (size_t)n_states * 8, hipMemcpyDeviceToHost, c->stream));

@@ -49,7 +49,9 @@ void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTabl
                           hipStream_t st);
 void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states, uint32_t k, const SbSourceDev *src,
                        const double *hky /* [n_states*k][2][25] */, double *partial, uint32_t n_blocks, double *out,
-                       unsigned long long *guard, hipStream_t st);
-void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky, hipStream_t st);
+                       double *out2 /* optional second copy of out */, unsigned long long *guard, hipStream_t st);
+// also zeroes guard[0..n_states)
+void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky,
+                   unsigned long long *guard, uint32_t n_states, hipStream_t st);
 
 } // namespace vgan

@@ -165,8 +165,10 @@ __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDe
 // ---------------------------------------------------------------------------------------------- HKY tables
 // hky[e][which][ref*5+read]: which = 0 child (t2), 1 parent (t1); MCMC.h:111-296 minus the "+ detail.logLikelihood"
 __global__ void sb_hky_kernel(uint32_t n_entries, const SbSourceDev *__restrict__ src, double con,
-                              const double *__restrict__ freqs7, double *__restrict__ hky) {
+                              const double *__restrict__ freqs7, double *__restrict__ hky, unsigned long long *__restrict__ guard,
+                              uint32_t n_states) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_states) guard[i] = 0; // the refresh that follows counts into it
     if (i >= n_entries * 2 * SB_NCNT) return;
     const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
     const int ref = j / 5, rd = j % 5;
@@ -269,13 +271,16 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_loglike_kernel(SbTablesDev t, 
 // One wave per state: lane l adds partials l, l+64, ... in order, then a shuffle tree -- a fixed order, so the sum is
 // reproducible (the first version walked all partials on one thread: 79 us of dependent loads per refresh).
 __global__ __launch_bounds__(64) void sb_finish_kernel(const double *__restrict__ partial, uint32_t n_blocks, uint32_t n_states,
-                                                       double *__restrict__ out) {
+                                                       double *__restrict__ out, double *__restrict__ out2) {
     const uint32_t e = blockIdx.x;
     if (e >= n_states) return;
     double s = 0.0;
     for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) s += partial[(size_t)e * n_blocks + i];
     s = wave_sum(s);
-    if (threadIdx.x == 0) out[e] = s;
+    if (threadIdx.x == 0) {
+        out[e] = s;
+        if (out2) out2[e] = s; // the caller's device buffer (handed to RCCL)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
@@ -290,18 +295,19 @@ void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTabl
     else hipLaunchKernelGGL(sb_precompute_kernel<4>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
 }
 
-void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky, hipStream_t st) {
-    const uint32_t n = n_entries * 2 * SB_NCNT;
-    hipLaunchKernelGGL(sb_hky_kernel, dim3((n + 127) / 128), dim3(128), 0, st, n_entries, src, con, freqs7, hky);
+void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky,
+                   unsigned long long *guard, uint32_t n_states, hipStream_t st) {
+    const uint32_t n = n_entries * 2 * SB_NCNT; // >= n_states
+    hipLaunchKernelGGL(sb_hky_kernel, dim3((n + 127) / 128), dim3(128), 0, st, n_entries, src, con, freqs7, hky, guard, n_states);
 }
 
 void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states, uint32_t k, const SbSourceDev *src,
-                       const double *hky, double *partial, uint32_t n_blocks, double *out, unsigned long long *guard,
-                       hipStream_t st) {
+                       const double *hky, double *partial, uint32_t n_blocks, double *out, double *out2,
+                       unsigned long long *guard, hipStream_t st) {
     (void)n_paths;
     const size_t lds = (size_t)n_states * k * 2 * SB_NCNT * sizeof(double);
     hipLaunchKernelGGL(sb_loglike_kernel, dim3(n_blocks), dim3(SBL_THREADS), lds, st, t, n_states, k, src, hky, partial, guard);
-    hipLaunchKernelGGL(sb_finish_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, n_states, out);
+    hipLaunchKernelGGL(sb_finish_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, n_states, out, out2);
 }
 
 } // namespace vgan
