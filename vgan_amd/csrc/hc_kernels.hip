@@ -524,14 +524,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             const double bgv = bg_s[rlut & 3u];
             const double om = gcode == rcode ? 1.0 - e : e;    // 1 - eps: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0
             const double x = pm.wbg * bgv + pm.wobs * om;      // process_mapping.cpp:66-75
-#ifdef VGAN_EXP_NOLOG
-            const double t = x;
-#else
             const double t = log_tab(x, valid, logtab_s);
-#endif
-#ifndef VGAN_EXP_NOATOMIC
             if (valid) unsafeAtomicAdd(&segS_s[ls], t);
-#endif
         }
         PT_MARK(7);
         if (has_next) {
