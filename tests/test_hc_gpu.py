@@ -308,6 +308,18 @@ def test_tiled_kernel_fuzz_against_general_kernel(seed):
             cols = int(rng.integers(1, 257)) if r % 7 else int(rng.choice([1, 2, 255, 256, 700, 1279, 1280]))
         A = cols
         ql = int(rng.choice([cols, cols, cols, max(0, cols - int(rng.integers(1, 9))), min(1280, cols + 5), 0]))
+        if r % 97 == 5:  # degenerate reads: no columns at all, or columns that no mapping covers
+            cols = 0 if r % 2 else cols
+            A, ql = cols, min(ql, cols)
+            seg_off.append(len(seg_node))
+            gseq.append(rng.choice(alphabet, cols))
+            rseq.append(rng.choice(alphabet, cols))
+            qual.append(rng.integers(0, 42, ql).astype(np.uint8))
+            col_off.append(col_off[-1] + cols)
+            qual_off.append(qual_off[-1] + ql)
+            algn_len.append(A)
+            mapq.append(int(rng.integers(0, 61)))
+            continue
         pos = 0
         nseg = 0
         max_run = int(rng.choice([3, 8, 40, 200]))
