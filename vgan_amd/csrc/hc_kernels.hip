@@ -680,8 +680,10 @@ __global__ __launch_bounds__(256) void hc_sweep_kernel(const uint16_t *__restric
     const uint32_t w0 = tile_word0[tile];
     const uint32_t tw = tile_word0[tile + 1] - w0;
     const uint64_t i0_64 = (uint64_t)chunk * items_per_wave;
-    if (tw == 0 || i0_64 >= n_items) return;
-    const uint32_t i0 = (uint32_t)i0_64;
+    if (tw == 0) return; // the whole workgroup: the tile is uniform in it
+    if (!IDENT && i0_64 >= n_items) return;
+    // (the node pass keeps an item-less wave: it takes part in the workgroup's final reduction with zeros)
+    const uint32_t i0 = (uint32_t)min((uint64_t)n_items, i0_64);
     const uint32_t i1 = (uint32_t)min((uint64_t)n_items, i0_64 + items_per_wave);
     const uint32_t full = i0 + (i1 - i0) / SWEEP_UNROLL * SWEEP_UNROLL;
     const bool extra = tw > (uint32_t)TB;
@@ -725,9 +727,27 @@ __global__ __launch_bounds__(256) void hc_sweep_kernel(const uint16_t *__restric
         const uint32_t node = IDENT ? i : item_node[i];
         apply(umaskT[(size_t)node * row_entries + lane_off], D[i]);
     }
+    if constexpr (IDENT) {
+        // the node pass is short and ends in atomics on the same P accumulators from every wave: same-address device
+        // atomics serialise (~0.1 us each), so the four waves of a workgroup are summed in LDS first
+        __shared__ double red_s[3][TB + 1][64];
+        if (wave > 0) {
 #pragma unroll
-    for (int k = 0; k <= TB; ++k) {
-        if ((uint32_t)k < tw && acc[k] != 0.0) unsafeAtomicAdd(&acc_out[(size_t)(w0 + k) * 64 + lane], acc[k]);
+            for (int k = 0; k <= TB; ++k) red_s[wave - 1][k][lane] = acc[k];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k <= TB; ++k) {
+                const double v = ((acc[k] + red_s[0][k][lane]) + red_s[1][k][lane]) + red_s[2][k][lane];
+                if ((uint32_t)k < tw && v != 0.0) unsafeAtomicAdd(&acc_out[(size_t)(w0 + k) * 64 + lane], v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k <= TB; ++k) {
+            if ((uint32_t)k < tw && acc[k] != 0.0) unsafeAtomicAdd(&acc_out[(size_t)(w0 + k) * 64 + lane], acc[k]);
+        }
     }
 }
 
