@@ -114,6 +114,18 @@ int vgan_aln_mark_duplicates(const vgan_alnset *a, uint8_t *is_dup, int64_t *n_d
 int vgan_aln_filter(const vgan_alnset *a, const uint8_t *drop, vgan_alnset **out); /* copy without drop[r] != 0 */
 void vgan_aln_free(vgan_alnset *a);
 
+/* The same GAM kept as the slices its parser produced (input order, ~8192 reads each): duplicate marking and
+ * flattening walk them in place, so a front end that only feeds the device never builds the merged set (which costs
+ * as much memory again and a pass over all of it). */
+typedef struct vgan_alnparts vgan_alnparts;
+int vgan_alnparts_read_gam(const char *path, int keep_unmapped, vgan_alnparts **out);
+int64_t vgan_alnparts_n_reads(const vgan_alnparts *p);
+int64_t vgan_alnparts_count(const vgan_alnparts *p);                 /* number of slices */
+int64_t vgan_alnparts_first_read(const vgan_alnparts *p, int64_t i); /* index of slice i's first read (i = count: n_reads) */
+int vgan_alnparts_mark_duplicates(const vgan_alnparts *p, uint8_t *is_dup, int64_t *n_dup); /* as vgan_aln_mark_duplicates */
+int vgan_alnparts_merge(vgan_alnparts *p, vgan_alnset **out);        /* consumes the slices (p stays valid, empty) */
+void vgan_alnparts_free(vgan_alnparts *p);
+
 /* ------------------------------------------------------------------------------------------------
  * HaploCart batch: SoA produced by the front half (a1 + the slicing of update_likelihood.cpp:33-45).
  * Segment m of a read is mapping m: {node, start = position_in_read, len = |graph_seq.substr(start, mppg_sizes[m])|}.
@@ -165,6 +177,9 @@ int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64
  * vgan_aln_mark_duplicates; NULL = none): duplicate removal without rebuilding the alignment set */
 int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
                            int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
+/* slices [part0, part1) of a sliced set; skip is indexed by read over the WHOLE set (or NULL); read_src likewise */
+int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p, int64_t part0, int64_t part1, const uint8_t *skip,
+                          int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
 int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out);
 void vgan_hc_host_batch_free(vgan_hc_host_batch *b);
 /* a1 on its own, for the reconstruction KATs: strings are NUL terminated into caller buffers of cap bytes. */

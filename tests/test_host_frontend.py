@@ -245,3 +245,34 @@ def test_masked_flatten_equals_flatten_of_filtered_set():
         assert np.array_equal(ma[k], pa[k]), k
     kept = np.flatnonzero(~dup)
     assert np.array_equal(kept[pa["read_src"]], ma["read_src"])
+
+
+def test_sliced_alignment_set_matches_the_merged_one(tmp_path):
+    """vgan_alnparts_*: the GAM kept as its parser slices gives the same duplicate marks and the same flattened batch
+    (arrays and read_src) as the merged alignment set, whole or in slice ranges."""
+    from vgan_amd import haplocart as hc
+    g = hc.synth_graph(seed=12, genome_len=1500, n_nodes=900, n_paths=48)
+    a = hc.synth_reads(g, 30000, seed=13, read_len=90)
+    f = str(tmp_path / "x.gam")
+    a.write_gam(f)
+    parts = hc.AlnParts.read_gam(f)
+    merged = hc.AlnSet.read_gam(f)
+    n = merged.n_reads  # unmapped reads (identity 0) are dropped by both readers
+    assert parts.n_reads == n and 29990 <= n <= 30000 and parts.n_parts >= 3
+    assert [parts.first_read(i) for i in range(parts.n_parts + 1)][-1] == n
+    dup_p, dup_m = parts.mark_duplicates(), merged.mark_duplicates()
+    assert np.array_equal(dup_p, dup_m) and dup_m.sum() > 0
+    for skip in (None, dup_m):
+        bp = hc.HostBatch(g, parts, n_threads=3, skip=skip)
+        bm = hc.HostBatch(g, merged, n_threads=1, skip=skip)  # one chunk: tileable reads in input order
+        ap, am = bp.arrays(), bm.arrays()
+        assert bp.n_reads == bm.n_reads and bp.n_tileable == bm.n_tileable
+        for k in ("read_seg_off", "read_col_off", "read_qual_off", "read_algn_len", "read_mapq", "seg_node", "seg_start",
+                  "seg_len", "graph_seq", "algnseq", "qual", "read_src"):
+            assert np.array_equal(ap[k], am[k]), k
+    # a slice range covers exactly its reads
+    b01 = hc.HostBatch(g, parts, 0, 2, n_threads=2)
+    assert sorted(b01.read_src.tolist()) == list(range(parts.first_read(2)))
+    # merging afterwards gives the merged set
+    m2 = parts.merge()
+    assert m2.n_reads == n and np.array_equal(m2.arrays()["seq"], merged.arrays()["seq"])

@@ -131,6 +131,14 @@ SYMBOLS = {
     "vgan_aln_filter": (C.c_int, [vp, vp, C.POINTER(vp)]),
     "vgan_aln_free": (None, [vp]),
     "vgan_hc_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
+    "vgan_alnparts_read_gam": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
+    "vgan_alnparts_n_reads": (C.c_int64, [vp]),
+    "vgan_alnparts_count": (C.c_int64, [vp]),
+    "vgan_alnparts_first_read": (C.c_int64, [vp, C.c_int64]),
+    "vgan_alnparts_mark_duplicates": (C.c_int, [vp, vp, C.POINTER(C.c_int64)]),
+    "vgan_alnparts_merge": (C.c_int, [vp, C.POINTER(vp)]),
+    "vgan_alnparts_free": (None, [vp]),
+    "vgan_hc_flatten_parts": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
     "vgan_hc_flatten_masked": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
     "vgan_hc_host_batch_get": (C.c_int, [vp, C.POINTER(HcBatch)]),
     "vgan_hc_host_batch_free": (None, [vp]),

@@ -163,6 +163,12 @@ namespace vgan {
 void merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &out); // parts are consumed
 }
 
+// an alignment set kept as the slices the GAM parser produced, in input order
+struct vgan_alnparts {
+    std::vector<vgan_alnset> parts;
+    std::vector<int64_t> first{0}; // first[i] = index of slice i's first read; first.back() = number of reads
+};
+
 struct vgan_hc_host_batch {
     vgan::BigVec<uint32_t> read_seg_off{0}, read_col_off{0}, read_qual_off{0};
     vgan::BigVec<uint16_t> read_algn_len;

@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <thread>
 
@@ -140,7 +141,8 @@ struct Chunk {
     vgan_hc_flatten_stats st{};
 };
 
-void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, const uint8_t *skip, Chunk &c) {
+void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, const uint8_t *skip, int64_t src_base,
+                   Chunk &c) {
     Recon rc;
     { // size the chunk's arrays
         auto &b = c.b; // from the input volume, so that they grow at most once or twice
@@ -222,7 +224,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         b.qual.insert(b.qual.end(), q, q + (a.qual_off[r + 1] - a.qual_off[r]));
         b.read_algn_len.push_back((uint16_t)A);
         b.read_mapq.push_back((uint8_t)mq);
-        b.read_src.push_back((uint32_t)r);
+        b.read_src.push_back((uint32_t)(r + src_base));
         b.read_seg_off.push_back((uint32_t)b.seg_node.size());
         b.read_col_off.push_back((uint32_t)b.graph_seq.size());
         b.read_qual_off.push_back((uint32_t)b.qual.size());
@@ -237,28 +239,9 @@ template <class T> void append_shifted(std::vector<T> &dst, const std::vector<T>
 
 } // namespace
 
-extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
-                               vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
-    return vgan_hc_flatten_masked(g, a, r0, r1, nullptr, n_threads, out, stats);
-}
-
-extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
-                                      int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
-    if (!g || !a || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten: null argument");
-    if (r0 < 0 || r1 > a->n_reads() || r0 > r1) return fail(VGAN_EINVAL, "vgan_hc_flatten: bad read range");
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    const int64_t n = r1 - r0;
-    n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (n + 4095) / 4096));
-    PhaseTimer pt("hc_flatten");
-    std::vector<Chunk> chunks((size_t)n_threads);
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t) {
-        const int64_t b0 = r0 + n * t / n_threads, b1 = r0 + n * (t + 1) / n_threads;
-        if (n_threads == 1) flatten_range(*g, *a, b0, b1, skip, chunks[t]);
-        else th.emplace_back(flatten_range, std::cref(*g), std::cref(*a), b0, b1, skip, std::ref(chunks[t]));
-    }
-    for (auto &t : th) t.join();
-    pt.lap("chunks");
+namespace {
+// chunks -> one batch: every chunk's tileable reads, then every chunk's other reads (chunks are consumed)
+int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
     auto res = new vgan_hc_host_batch();
     vgan_hc_flatten_stats st{};
     // output order: every chunk's tileable reads, then every chunk's other reads
@@ -319,12 +302,17 @@ extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a,
         cb = vgan_hc_host_batch();
     };
     {
-        std::vector<std::thread> cth;
-        for (size_t i = 0; i < parts.size(); ++i) {
-            if (chunks.size() == 1) copy_part(i);
-            else cth.emplace_back(copy_part, i);
+        const size_t nt = std::min<size_t>(parts.size(), std::max(1u, std::thread::hardware_concurrency()));
+        if (chunks.size() == 1 || nt <= 1) {
+            for (size_t i = 0; i < parts.size(); ++i) copy_part(i);
+        } else {
+            std::vector<std::thread> cth;
+            for (size_t t = 0; t < nt; ++t)
+                cth.emplace_back([&, t] {
+                    for (size_t i = t; i < parts.size(); i += nt) copy_part(i);
+                });
+            for (auto &t : cth) t.join();
         }
-        for (auto &t : cth) t.join();
     }
     for (auto &c : chunks) {
         st.n_in += c.st.n_in;
@@ -339,6 +327,63 @@ extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a,
     if (stats) *stats = st;
     *out = res;
     return VGAN_OK;
+}
+} // namespace
+
+extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
+                               vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    return vgan_hc_flatten_masked(g, a, r0, r1, nullptr, n_threads, out, stats);
+}
+
+extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
+                                      int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    if (!g || !a || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten: null argument");
+    if (r0 < 0 || r1 > a->n_reads() || r0 > r1) return fail(VGAN_EINVAL, "vgan_hc_flatten: bad read range");
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int64_t n = r1 - r0;
+    n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (n + 4095) / 4096));
+    PhaseTimer pt("hc_flatten");
+    std::vector<Chunk> chunks((size_t)n_threads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) {
+        const int64_t b0 = r0 + n * t / n_threads, b1 = r0 + n * (t + 1) / n_threads;
+        if (n_threads == 1) flatten_range(*g, *a, b0, b1, skip, 0, chunks[t]);
+        else th.emplace_back(flatten_range, std::cref(*g), std::cref(*a), b0, b1, skip, (int64_t)0, std::ref(chunks[t]));
+    }
+    for (auto &t : th) t.join();
+    pt.lap("chunks");
+    return merge_chunks(chunks, pt, out, stats);
+}
+
+extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *ps, int64_t part0, int64_t part1, const uint8_t *skip,
+                                     int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    if (!g || !ps || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: null argument");
+    if (part0 < 0 || part1 > (int64_t)ps->parts.size() || part0 > part1) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: bad slice range");
+    if (ps->first.back() > 0xFFFFFFF0ll) return fail(VGAN_ERANGE, "vgan_hc_flatten_parts: more than 2^32 reads");
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const size_t np = (size_t)(part1 - part0);
+    n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, np));
+    PhaseTimer pt("hc_flatten_parts");
+    std::vector<Chunk> chunks(np); // one per slice, in order
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= np) break;
+            const size_t pi = (size_t)part0 + i;
+            const vgan_alnset &a = ps->parts[pi];
+            flatten_range(*g, a, 0, a.n_reads(), skip ? skip + ps->first[pi] : nullptr, ps->first[pi], chunks[i]);
+        }
+    };
+    if (n_threads == 1) {
+        work();
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work);
+        for (auto &t : th) t.join();
+    }
+    pt.lap("chunks");
+    return merge_chunks(chunks, pt, out, stats);
 }
 
 extern "C" int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out) {

@@ -299,8 +299,9 @@ void vgan::merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &o) {
     }
 }
 
-extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped, vgan_alnset **out) {
-    if (!bytes || !out) return fail(VGAN_EINVAL, "vgan_aln_parse_gam: null argument");
+// Inflate + frame + parse into slices of SLICE reads, in input order (no merged copy).
+static int parse_gam_parts(const void *bytes, size_t n, int keep_unmapped, std::vector<vgan_alnset> &parts) {
+    if (!bytes) return fail(VGAN_EINVAL, "GAM: null buffer");
     PhaseTimer pt("parse_gam");
     ByteBuf inflated;
     AsyncInflate bg; // BGZF (what vg writes): framing below runs on the prefix inflated so far
@@ -329,7 +330,6 @@ extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped
     using Msg = std::pair<const uint8_t *, const uint8_t *>;
     constexpr size_t SLICE = 8192;
     std::deque<std::vector<Msg>> slices; // grown by the framing thread only, under mu
-    std::vector<vgan_alnset> parts;
     std::mutex mu;
     std::condition_variable cv;
     size_t next_slice = 0;
@@ -444,10 +444,55 @@ extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped
     parts.resize(slice_parts.size());
     for (size_t i = 0; i < slice_parts.size(); ++i) parts[i] = std::move(slice_parts[i]);
     if (!ok) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+    while (!parts.empty() && parts.back().n_reads() == 0) parts.pop_back();
     pt.lap("parse");
+    return VGAN_OK;
+}
+
+extern "C" int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped, vgan_alnset **out) {
+    if (!bytes || !out) return fail(VGAN_EINVAL, "vgan_aln_parse_gam: null argument");
+    std::vector<vgan_alnset> parts;
+    const int rc = parse_gam_parts(bytes, n, keep_unmapped, parts);
+    if (rc) return rc;
+    PhaseTimer pt("parse_gam");
     auto a = new vgan_alnset();
     merge_alnsets(parts, *a);
     pt.lap("merge");
+    *out = a;
+    return VGAN_OK;
+}
+
+// ---- the same input kept as its slices: consumers that walk reads in order (duplicate marking, flattening) do not
+// need the merged copy (GBs for millions of reads)
+extern "C" int vgan_alnparts_read_gam(const char *path, int keep_unmapped, vgan_alnparts **out) {
+    if (!path || !out) return fail(VGAN_EINVAL, "vgan_alnparts_read_gam: null argument");
+    MappedFile f;
+    if (!f.open_path(path)) return fail(VGAN_EIO, "cannot read %s", path);
+    auto ps = new vgan_alnparts();
+    const int rc = parse_gam_parts(f.p, f.n, keep_unmapped, ps->parts);
+    if (rc) {
+        delete ps;
+        return rc;
+    }
+    ps->first.assign(ps->parts.size() + 1, 0);
+    for (size_t i = 0; i < ps->parts.size(); ++i) ps->first[i + 1] = ps->first[i] + ps->parts[i].n_reads();
+    *out = ps;
+    return VGAN_OK;
+}
+
+extern "C" int64_t vgan_alnparts_n_reads(const vgan_alnparts *p) { return p ? p->first.back() : 0; }
+extern "C" int64_t vgan_alnparts_count(const vgan_alnparts *p) { return p ? (int64_t)p->parts.size() : 0; }
+extern "C" int64_t vgan_alnparts_first_read(const vgan_alnparts *p, int64_t i) {
+    return (p && i >= 0 && i <= (int64_t)p->parts.size()) ? p->first[(size_t)i] : -1;
+}
+extern "C" void vgan_alnparts_free(vgan_alnparts *p) { delete p; }
+
+extern "C" int vgan_alnparts_merge(vgan_alnparts *p, vgan_alnset **out) {
+    if (!p || !out) return fail(VGAN_EINVAL, "vgan_alnparts_merge: null argument");
+    auto a = new vgan_alnset();
+    merge_alnsets(p->parts, *a); // consumes the slices
+    p->parts.clear();
+    p->first.assign(1, 0);
     *out = a;
     return VGAN_OK;
 }
@@ -570,6 +615,33 @@ extern "C" int vgan_aln_mark_duplicates(const vgan_alnset *a, uint8_t *is_dup, i
         if (!seen.insert({a->m_node[m], a->m_offset[m]}).second) {
             is_dup[r] = 1;
             ++nd;
+        }
+    }
+    if (n_dup) *n_dup = nd;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_alnparts_mark_duplicates(const vgan_alnparts *ps, uint8_t *is_dup, int64_t *n_dup) {
+    if (!ps || !is_dup) return fail(VGAN_EINVAL, "vgan_alnparts_mark_duplicates: null argument");
+    struct KeyHash {
+        size_t operator()(const std::pair<int64_t, int64_t> &k) const {
+            return (size_t)(k.first * 0x9E3779B97F4A7C15ull) ^ (size_t)(k.second + 0x7F4A7C15ull + ((uint64_t)k.first << 6));
+        }
+    };
+    std::unordered_set<std::pair<int64_t, int64_t>, KeyHash> seen;
+    seen.reserve((size_t)std::min<int64_t>(ps->first.back(), 1 << 22));
+    int64_t nd = 0;
+    for (size_t i = 0; i < ps->parts.size(); ++i) {
+        const vgan_alnset &a = ps->parts[i];
+        uint8_t *d = is_dup + ps->first[i];
+        for (int64_t r = 0; r < a.n_reads(); ++r) {
+            d[r] = 0;
+            if (a.map_off[r + 1] == a.map_off[r]) continue;
+            const int64_t m = a.map_off[r];
+            if (!seen.insert({a.m_node[m], a.m_offset[m]}).second) {
+                d[r] = 1;
+                ++nd;
+            }
         }
     }
     if (n_dup) *n_dup = nd;

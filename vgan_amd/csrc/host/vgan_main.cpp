@@ -126,11 +126,11 @@ int haplocart(int argc, char **argv) {
 
     PhaseTimer pt;
     // the GAM is inflated and parsed on its own threads while this one loads the graph and brings the device up
-    vgan_alnset *alns = nullptr;
+    vgan_alnparts *alns = nullptr; // kept as the parser's slices: nothing here needs the merged set
     int gam_rc = 0;
     std::string gam_err;
     std::thread gam_reader([&] {
-        gam_rc = vgan_aln_read_gam(gamfilename.c_str(), 0, &alns);
+        gam_rc = vgan_alnparts_read_gam(gamfilename.c_str(), 0, &alns);
         if (gam_rc) gam_err = vgan_last_error(); // the message is per thread
     });
     struct Joiner {
@@ -170,17 +170,16 @@ int haplocart(int argc, char **argv) {
     gam_reader.join();
     if (gam_rc) die("[HaploCart] reading GAM: " + gam_err);
     pt.lap("read GAM (waited)");
-    vgan_alnset_view av;
-    check(vgan_aln_view_get(alns, &av), "alignment view");
-    if (!quiet) std::cerr << "Found " << av.n_reads << " reads." << '\n';
+    const int64_t n_in = vgan_alnparts_n_reads(alns), n_slices = vgan_alnparts_count(alns);
+    if (!quiet) std::cerr << "Found " << n_in << " reads." << '\n';
     std::vector<uint8_t> dup; // reads dropped by the flatten step
     int64_t n_dup = 0;
     if (rmdup && fastafilename.empty()) { // HaploCart.cpp:386-393
-        dup.resize((size_t)av.n_reads);
-        check(vgan_aln_mark_duplicates(alns, dup.data(), &n_dup), "duplicate removal");
+        dup.resize((size_t)n_in);
+        check(vgan_alnparts_mark_duplicates(alns, dup.data(), &n_dup), "duplicate removal");
         if (!quiet) std::cerr << "PCR duplicates removed." << std::endl;
     }
-    int64_t n_reads = av.n_reads - n_dup;
+    int64_t n_reads = n_in - n_dup;
     pt.lap("duplicate removal");
 
     if (!fastafilename.empty() && !quiet) std::cerr << "Using background error probability of " << background_error_prob << '\n';
@@ -188,11 +187,12 @@ int haplocart(int argc, char **argv) {
 
     const int64_t BATCH = 500000; // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i
     vgan_hc_flatten_stats tot{};
-    for (int64_t r0 = 0; r0 < av.n_reads; r0 += BATCH) {
-        const int64_t r1 = std::min<int64_t>(av.n_reads, r0 + BATCH);
+    for (int64_t p0 = 0; p0 < n_slices;) {
+        int64_t p1 = p0 + 1;
+        while (p1 < n_slices && vgan_alnparts_first_read(alns, p1 + 1) - vgan_alnparts_first_read(alns, p0) <= BATCH) ++p1;
         vgan_hc_host_batch *hb = nullptr;
         vgan_hc_flatten_stats st;
-        check(vgan_hc_flatten_masked(graph, alns, r0, r1, dup.empty() ? nullptr : dup.data(), n_threads, &hb, &st), "flattening");
+        check(vgan_hc_flatten_parts(graph, alns, p0, p1, dup.empty() ? nullptr : dup.data(), n_threads, &hb, &st), "flattening");
         vgan_hc_batch b;
         check(vgan_hc_host_batch_get(hb, &b), "batch");
         // the copy out of the host batch completes inside the call (pageable memory is staged by the runtime); the
@@ -202,6 +202,7 @@ int haplocart(int argc, char **argv) {
         tot.n_bad += st.n_bad;
         tot.n_unmapped += st.n_unmapped;
         tot.n_out += st.n_out;
+        p0 = p1;
     }
     if (tot.n_bad && !quiet)
         std::cerr << "[HaploCart] warning: " << tot.n_bad << " reads skipped (the reference would terminate on them)\n";

@@ -186,6 +186,46 @@ class AlnSet:
             self._h = None
 
 
+class AlnParts:
+    """A GAM kept as the slices its parser produced (vgan_alnparts): what a front end that only feeds the device uses."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def read_gam(cls, path, keep_unmapped=False):
+        h = N.vp()
+        N.check(N.lib().vgan_alnparts_read_gam(path.encode(), int(keep_unmapped), C.byref(h)))
+        return cls(h)
+
+    @property
+    def n_reads(self):
+        return N.lib().vgan_alnparts_n_reads(self._h)
+
+    @property
+    def n_parts(self):
+        return N.lib().vgan_alnparts_count(self._h)
+
+    def first_read(self, i):
+        return N.lib().vgan_alnparts_first_read(self._h, i)
+
+    def mark_duplicates(self):
+        m = np.zeros(self.n_reads, np.uint8)
+        N.check(N.lib().vgan_alnparts_mark_duplicates(self._h, m.ctypes.data, None))
+        return m.astype(bool)
+
+    def merge(self):
+        """The merged alignment set (consumes the slices)."""
+        h = N.vp()
+        N.check(N.lib().vgan_alnparts_merge(self._h, C.byref(h)))
+        return AlnSet(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_alnparts_free(self._h)
+            self._h = None
+
+
 def reconstruct(graph, alns, r, cap=1 << 16):
     """a1 of the product front end (for the reconstruction KATs)."""
     gs = C.create_string_buffer(cap)
@@ -206,12 +246,20 @@ class HostBatch:
     """Flattened HaploCart batch in host memory (vgan_hc_flatten)."""
 
     def __init__(self, graph, alns, r0=0, r1=None, n_threads=0, skip=None):
-        """skip: optional bool/uint8 mask over the alignment set (e.g. AlnSet.mark_duplicates()): reads left out."""
-        r1 = alns.n_reads if r1 is None else r1
+        """skip: optional bool/uint8 mask over the alignment set (e.g. AlnSet.mark_duplicates()): reads left out.
+        alns may be an AlnParts: r0 / r1 then count slices."""
         self._h = N.vp()
         self.stats = N.FlattenStats()
         sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
         assert sk is None or len(sk) == alns.n_reads
+        if isinstance(alns, AlnParts):
+            r1 = alns.n_parts if r1 is None else r1
+            N.check(N.lib().vgan_hc_flatten_parts(graph._h, alns._h, r0, r1, None if sk is None else sk.ctypes.data, n_threads,
+                                                  C.byref(self._h), C.byref(self.stats)))
+            self.c = N.HcBatch()
+            N.check(N.lib().vgan_hc_host_batch_get(self._h, C.byref(self.c)))
+            return
+        r1 = alns.n_reads if r1 is None else r1
         N.check(N.lib().vgan_hc_flatten_masked(graph._h, alns._h, r0, r1, None if sk is None else sk.ctypes.data, n_threads,
                                                C.byref(self._h), C.byref(self.stats)))
         self.c = N.HcBatch()
