@@ -80,6 +80,25 @@ int main(int argc, char **argv) {
     REQUIRE(vgan_aln_filter(a, dup.data(), &kept) == 0);
     REQUIRE(vgan_hc_flatten(g, kept, 0, va.n_reads - nd, 3, &hb, &st) == 0);
     vgan_hc_host_batch_free(hb);
+    REQUIRE(vgan_hc_flatten_masked(g, a, 0, va.n_reads, dup.data(), 3, &hb, &st) == 0 && st.n_out + st.n_bad + st.n_unmapped == va.n_reads - nd);
+    vgan_hc_host_batch_free(hb);
+    { // the same GAM as the parser's slices: marks, slice-range flatten, merge
+        vgan_alnparts *ps = nullptr;
+        REQUIRE(vgan_alnparts_read_gam((tmp + "/s.gam").c_str(), 0, &ps) == 0);
+        REQUIRE(vgan_alnparts_n_reads(ps) == vb.n_reads && vgan_alnparts_count(ps) >= 1);
+        std::vector<uint8_t> dup2((size_t)vb.n_reads);
+        int64_t nd2 = 0;
+        REQUIRE(vgan_alnparts_mark_duplicates(ps, dup2.data(), &nd2) == 0 && nd2 == nd && dup2 == dup);
+        REQUIRE(vgan_hc_flatten_parts(g, ps, 0, vgan_alnparts_count(ps), dup2.data(), 3, &hb, &st) == 0);
+        vgan_hc_host_batch_free(hb);
+        vgan_alnset *m = nullptr;
+        REQUIRE(vgan_alnparts_merge(ps, &m) == 0);
+        vgan_alnset_view vm;
+        vgan_aln_view_get(m, &vm);
+        REQUIRE(vm.n_reads == vb.n_reads && vgan_alnparts_n_reads(ps) == 0);
+        vgan_aln_free(m);
+        vgan_alnparts_free(ps);
+    }
     vgan_euka_host_batch *eb = nullptr;
     vgan_euka_flatten_stats es;
     REQUIRE(vgan_euka_flatten(g, a, 0, va.n_reads, 3, &eb, &es) == 0);
