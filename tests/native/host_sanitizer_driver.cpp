@@ -28,6 +28,7 @@ static std::string slurp(const std::string &p) {
 int main(int argc, char **argv) {
     if (argc < 3) return 2;
     const std::string golden = argv[1], tmp = argv[2];
+    const uint64_t n_synth = argc > 3 ? strtoull(argv[3], nullptr, 10) : 3000; // reads of the synthetic section
     // graph from GFA, reconstruction KATs
     vgan_graph *g = nullptr;
     REQUIRE(vgan_graph_load((golden + "/reconstruct/target_graph.gfa").c_str(), nullptr, &g) == 0);
@@ -64,11 +65,11 @@ int main(int argc, char **argv) {
     // synthetic graph + reads through every flatten, GAM round trip, duplicate marks, graph round trip
     vgan_synth_graph_cfg gc{5, 1500, 1000, 40};
     REQUIRE(vgan_synth_hc_graph(&gc, &g) == 0);
-    vgan_synth_reads_cfg rc{3, 3000, 100, 0.2, 0.2, 0.1, 1};
+    vgan_synth_reads_cfg rc{3, n_synth, 100, 0.2, 0.2, 0.1, 1};
     REQUIRE(vgan_synth_hc_reads(g, &rc, &a) == 0);
     REQUIRE(vgan_aln_write_gam(a, (tmp + "/s.gam").c_str(), 100) == 0);
     vgan_alnset *b = nullptr;
-    REQUIRE(vgan_aln_read_gam((tmp + "/s.gam").c_str(), 0, &b) == 0);
+    REQUIRE(vgan_aln_read_gam((tmp + "/s.gam").c_str(), 1, &b) == 0); // unmapped reads kept: the round trip is exact
     vgan_alnset_view va, vb;
     vgan_aln_view_get(a, &va);
     vgan_aln_view_get(b, &vb);
@@ -84,7 +85,7 @@ int main(int argc, char **argv) {
     vgan_hc_host_batch_free(hb);
     { // the same GAM as the parser's slices: marks, slice-range flatten, merge
         vgan_alnparts *ps = nullptr;
-        REQUIRE(vgan_alnparts_read_gam((tmp + "/s.gam").c_str(), 0, &ps) == 0);
+        REQUIRE(vgan_alnparts_read_gam((tmp + "/s.gam").c_str(), 1, &ps) == 0);
         REQUIRE(vgan_alnparts_n_reads(ps) == vb.n_reads && vgan_alnparts_count(ps) >= 1);
         std::vector<uint8_t> dup2((size_t)vb.n_reads);
         int64_t nd2 = 0;

@@ -18,3 +18,21 @@ def test_host_sources_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe, os.path.join(ROOT, "tests/golden"), str(tmp_path)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "host sanitizer driver: ok" in r.stdout
+
+
+def test_host_sources_under_tsan(tmp_path):
+    """ThreadSanitizer over the threaded front end (block-parallel inflate feeding the framing pass feeding the parser
+    pool, parallel merges and flattening) on an input large enough for several slices and inflate runs."""
+    srcs = sorted(glob.glob(os.path.join(ROOT, "vgan_amd/csrc/host/*.cpp")))
+    srcs = [s for s in srcs if not s.endswith("_main.cpp")]
+    exe = str(tmp_path / "host_tsan")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vgan_amd/csrc"),
+           os.path.join(ROOT, "tests/native/host_sanitizer_driver.cpp")] + srcs + ["-o", exe, "-lz", "-lpthread"]
+    subprocess.check_call(cmd)
+    out = tmp_path / "o"
+    out.mkdir()
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests/golden"), str(out), "40000"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    assert "host sanitizer driver: ok" in r.stdout and "ThreadSanitizer" not in r.stderr
