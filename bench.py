@@ -28,8 +28,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--mode", choices=["node_weights", "per_read", "per_read_dense"], default="node_weights")
