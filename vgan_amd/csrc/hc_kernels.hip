@@ -80,12 +80,14 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
             const uint32_t j = base + lane;
             const uint32_t qb = j < QL ? b.qual[q0 + j] : 0u;
             if (j < QL && (int)(int8_t)qb >= 90) first90 = min(first90, j);
+            const double v = j < QL ? lq_s[qb] : 0.0;
+            const double s = wave_incl_scan(v);
             if (use_lds) {
-                const double v = j < QL ? lq_s[qb] : 0.0;
-                const double s = wave_incl_scan(v);
-                if (j < QL) ps[j + 1] = carry + s;
-                carry += __shfl(s, 63, 64);
+                if (j < QL) ps[j + 1] = carry + s; // every prefix
+            } else if (lane == 63) {
+                ps[(base >> 6) + 1] = carry + s;   // longer quality strings: one prefix per 64 bytes (QL <= 65535)
             }
+            carry += __shfl(s, 63, 64);
         }
         if (lane == 0) ps[0] = 0.0;
         first90 = wave_min_u32(first90);
@@ -103,10 +105,11 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
                 double U;
                 if (use_lds) {
                     U = (ps[hi] - ps[lo]) + (double)(A - (hi - lo)) * lq0;
-                } else {
-                    U = 0.0;
-                    for (uint32_t j = lo; j < hi; ++j) U += lq_s[b.qual[q0 + j]];
-                    U += (double)(A - (hi - lo)) * lq0;
+                } else { // coarse prefix + at most 63 terms at either end
+                    double Phi = ps[hi >> 6], Plo = ps[lo >> 6];
+                    for (uint32_t j = hi & ~63u; j < hi; ++j) Phi += lq_s[b.qual[q0 + j]];
+                    for (uint32_t j = lo & ~63u; j < lo; ++j) Plo += lq_s[b.qual[q0 + j]];
+                    U = (Phi - Plo) + (double)(A - (hi - lo)) * lq0;
                 }
                 const bool use_bep = prm.use_bep || first90 < hi; // sticky within the read (:42)
                 const HcNodeDev nd = g.node_tab[node];
