@@ -6,7 +6,7 @@ it has no CPU implementation of the hot path and raises if the native library is
 """
 from ._native import lib, load, NativeError  # noqa: F401
 from .haplocart import (  # noqa: F401
-    Graph, AlnSet, HostBatch, DeviceBatch, HcContext,
+    Graph, AlnSet, AlnParts, HostBatch, ArrayBatch, DeviceBatch, HcContext,
     MODE_NODE_WEIGHTS, MODE_PER_READ, MODE_PER_READ_DENSE,
     synth_graph, synth_reads,
 )
