@@ -126,6 +126,22 @@ int vgan_alnparts_mark_duplicates(const vgan_alnparts *p, uint8_t *is_dup, int64
 int vgan_alnparts_merge(vgan_alnparts *p, vgan_alnset **out);        /* consumes the slices (p stays valid, empty) */
 void vgan_alnparts_free(vgan_alnparts *p);
 
+/* The same decode pipeline handed out chunk by chunk, in input order: open() returns at once (inflate, framing and
+ * parsing run behind the caller), next() blocks until the next slices holding at least min_reads reads are parsed
+ * (fewer at the end; *out = NULL and VGAN_OK at the end of the stream).  Each chunk is an independent vgan_alnparts
+ * (caller frees); vgan_alnparts_base = index of its first read in the whole input (read_src of its batches counts
+ * from there; skip masks are indexed within the chunk). */
+typedef struct vgan_gam_stream vgan_gam_stream;
+int vgan_gam_stream_open(const char *path, int keep_unmapped, vgan_gam_stream **out);
+int vgan_gam_stream_next(vgan_gam_stream *s, int64_t min_reads, vgan_alnparts **out);
+void vgan_gam_stream_close(vgan_gam_stream *s);
+int64_t vgan_alnparts_base(const vgan_alnparts *p);
+/* keep-first duplicate marking across chunks (the state holds the keys seen so far; rmdup.cpp:68-110 semantics) */
+typedef struct vgan_dedup vgan_dedup;
+int vgan_dedup_create(vgan_dedup **out);
+int vgan_dedup_mark(vgan_dedup *d, const vgan_alnparts *chunk, uint8_t *is_dup, int64_t *n_dup);
+void vgan_dedup_free(vgan_dedup *d);
+
 /* ------------------------------------------------------------------------------------------------
  * HaploCart batch: SoA produced by the front half (a1 + the slicing of update_likelihood.cpp:33-45).
  * Segment m of a read is mapping m: {node, start = position_in_read, len = |graph_seq.substr(start, mppg_sizes[m])|}.
@@ -177,7 +193,7 @@ int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64
  * vgan_aln_mark_duplicates; NULL = none): duplicate removal without rebuilding the alignment set */
 int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
                            int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
-/* slices [part0, part1) of a sliced set; skip is indexed by read over the WHOLE set (or NULL); read_src likewise */
+/* slices [part0, part1) of a sliced set; skip (or NULL) is indexed by read within the set, read_src = base + that index */
 int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p, int64_t part0, int64_t part1, const uint8_t *skip,
                           int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
 int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out);

@@ -99,6 +99,33 @@ int main(int argc, char **argv) {
         REQUIRE(vm.n_reads == vb.n_reads && vgan_alnparts_n_reads(ps) == 0);
         vgan_aln_free(m);
         vgan_alnparts_free(ps);
+        // and as a stream of chunks with duplicate marks carried across them
+        vgan_gam_stream *gs = nullptr;
+        vgan_dedup *dd = nullptr;
+        REQUIRE(vgan_gam_stream_open((tmp + "/s.gam").c_str(), 1, &gs) == 0 && vgan_dedup_create(&dd) == 0);
+        int64_t seen = 0, nd3 = 0;
+        for (;;) {
+            vgan_alnparts *ch = nullptr;
+            REQUIRE(vgan_gam_stream_next(gs, 9000, &ch) == 0);
+            if (!ch) break;
+            REQUIRE(vgan_alnparts_base(ch) == seen);
+            const int64_t nr = vgan_alnparts_n_reads(ch);
+            std::vector<uint8_t> dm((size_t)nr);
+            int64_t k = 0;
+            REQUIRE(vgan_dedup_mark(dd, ch, dm.data(), &k) == 0);
+            REQUIRE(memcmp(dm.data(), dup.data() + seen, (size_t)nr) == 0);
+            REQUIRE(vgan_hc_flatten_parts(g, ch, 0, vgan_alnparts_count(ch), dm.data(), 2, &hb, &st) == 0);
+            vgan_hc_host_batch_free(hb);
+            vgan_alnparts_free(ch);
+            seen += nr;
+            nd3 += k;
+        }
+        REQUIRE(seen == vb.n_reads && nd3 == nd);
+        vgan_dedup_free(dd);
+        vgan_gam_stream_close(gs);
+        // a stream abandoned half way is torn down cleanly
+        REQUIRE(vgan_gam_stream_open((tmp + "/s.gam").c_str(), 1, &gs) == 0);
+        vgan_gam_stream_close(gs);
     }
     vgan_euka_host_batch *eb = nullptr;
     vgan_euka_flatten_stats es;

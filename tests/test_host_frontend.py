@@ -276,3 +276,42 @@ def test_sliced_alignment_set_matches_the_merged_one(tmp_path):
     # merging afterwards gives the merged set
     m2 = parts.merge()
     assert m2.n_reads == n and np.array_equal(m2.arrays()["seq"], merged.arrays()["seq"])
+
+
+def test_gam_stream_chunks_equal_the_whole(tmp_path):
+    """vgan_gam_stream_*: chunks arrive in input order with consecutive bases, their streamed duplicate marks equal the
+    marks over the whole file, and their batches concatenate to the whole file's batch content."""
+    from vgan_amd import haplocart as hc
+    g = hc.synth_graph(seed=14, genome_len=1500, n_nodes=900, n_paths=48)
+    a = hc.synth_reads(g, 50000, seed=15, read_len=80)
+    f = str(tmp_path / "y.gam")
+    a.write_gam(f)
+    whole = hc.AlnSet.read_gam(f)
+    dup_whole = whole.mark_duplicates()
+    bw = hc.HostBatch(g, whole, n_threads=1, skip=dup_whole)
+    want = {int(s): (int(n), int(c)) for s, n, c in zip(bw.read_src, np.diff(bw.arrays()["read_seg_off"]), np.diff(bw.arrays()["read_col_off"]))}
+    st = hc.GamStream(f)
+    dd = hc.Dedup()
+    base, marks, got = 0, [], {}
+    n_chunks = 0
+    for chunk in st.chunks(12000):
+        assert chunk.base == base and chunk.n_reads >= min(12000, whole.n_reads - base)
+        m = dd.mark(chunk)
+        marks.append(m)
+        b = hc.HostBatch(g, chunk, n_threads=2, skip=m)
+        arr = b.arrays()
+        for s, n, c in zip(b.read_src, np.diff(arr["read_seg_off"]), np.diff(arr["read_col_off"])):
+            got[int(s)] = (int(n), int(c))
+        base += chunk.n_reads
+        n_chunks += 1
+    assert n_chunks >= 3 and base == whole.n_reads
+    assert np.array_equal(np.concatenate(marks), dup_whole)
+    assert got == want
+    # a corrupt file fails in next(), not silently
+    blob = bytearray(open(f, "rb").read())
+    blob[len(blob) // 2] ^= 0xFF
+    bad = str(tmp_path / "bad.gam")
+    open(bad, "wb").write(bytes(blob))
+    with pytest.raises(Exception):
+        for _ in hc.GamStream(bad).chunks(12000):
+            pass

@@ -138,6 +138,13 @@ SYMBOLS = {
     "vgan_alnparts_mark_duplicates": (C.c_int, [vp, vp, C.POINTER(C.c_int64)]),
     "vgan_alnparts_merge": (C.c_int, [vp, C.POINTER(vp)]),
     "vgan_alnparts_free": (None, [vp]),
+    "vgan_alnparts_base": (C.c_int64, [vp]),
+    "vgan_gam_stream_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
+    "vgan_gam_stream_next": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),
+    "vgan_gam_stream_close": (None, [vp]),
+    "vgan_dedup_create": (C.c_int, [C.POINTER(vp)]),
+    "vgan_dedup_mark": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int64)]),
+    "vgan_dedup_free": (None, [vp]),
     "vgan_hc_flatten_parts": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
     "vgan_hc_flatten_masked": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
     "vgan_hc_host_batch_get": (C.c_int, [vp, C.POINTER(HcBatch)]),

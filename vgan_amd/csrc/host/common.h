@@ -30,6 +30,7 @@ bool write_file(const std::string &path, const std::string &bytes);
 bool file_exists(const std::string &path);
 // opens <path> or <path>.gz
 bool read_text_maybe_gz(const std::string &path, std::string &out);
+bool read_bytes_maybe_gz(const std::string &path, ByteBuf &out); // the same for large files (no copy, no zero fill)
 
 // Allocator for the front end's large arrays: default-initialises (resize() does not write, so the pages of a merged
 // array are first touched by the threads that fill it, not zeroed serially by the caller) and asks for transparent
@@ -167,6 +168,11 @@ void merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &out); // parts 
 struct vgan_alnparts {
     std::vector<vgan_alnset> parts;
     std::vector<int64_t> first{0}; // first[i] = index of slice i's first read; first.back() = number of reads
+    int64_t base = 0;              // index in the whole input of this object's first read (chunks of a stream)
+    void index() {
+        first.assign(parts.size() + 1, 0);
+        for (size_t i = 0; i < parts.size(); ++i) first[i + 1] = first[i] + parts[i].n_reads();
+    }
 };
 
 struct vgan_hc_host_batch {

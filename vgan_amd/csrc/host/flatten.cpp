@@ -359,7 +359,7 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
                                      int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
     if (!g || !ps || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: null argument");
     if (part0 < 0 || part1 > (int64_t)ps->parts.size() || part0 > part1) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: bad slice range");
-    if (ps->first.back() > 0xFFFFFFF0ll) return fail(VGAN_ERANGE, "vgan_hc_flatten_parts: more than 2^32 reads");
+    if (ps->base + ps->first.back() > 0xFFFFFFF0ll) return fail(VGAN_ERANGE, "vgan_hc_flatten_parts: more than 2^32 reads");
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     const size_t np = (size_t)(part1 - part0);
     n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, np));
@@ -372,7 +372,7 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
             if (i >= np) break;
             const size_t pi = (size_t)part0 + i;
             const vgan_alnset &a = ps->parts[pi];
-            flatten_range(*g, a, 0, a.n_reads(), skip ? skip + ps->first[pi] : nullptr, ps->first[pi], chunks[i]);
+            flatten_range(*g, a, 0, a.n_reads(), skip ? skip + ps->first[pi] : nullptr, ps->base + ps->first[pi], chunks[i]);
         }
     };
     if (n_threads == 1) {

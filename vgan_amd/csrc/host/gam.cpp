@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <climits>
 #include <cstring>
 #include <thread>
 
@@ -299,44 +300,67 @@ void vgan::merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &o) {
     }
 }
 
-// Inflate + frame + parse into slices of SLICE reads, in input order (no merged copy).
-static int parse_gam_parts(const void *bytes, size_t n, int keep_unmapped, std::vector<vgan_alnset> &parts) {
-    if (!bytes) return fail(VGAN_EINVAL, "GAM: null buffer");
-    PhaseTimer pt("parse_gam");
-    ByteBuf inflated;
-    AsyncInflate bg; // BGZF (what vg writes): framing below runs on the prefix inflated so far
-    const uint8_t *p = (const uint8_t *)bytes;
-    bool streaming = false;
-    if (n >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
-        if (bg.start(bytes, n)) {
-            streaming = true;
-            p = (const uint8_t *)bg.out.data();
-            n = bg.out.size();
-        } else {
-            if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
-            p = (const uint8_t *)inflated.data();
-            n = inflated.size();
-        }
-    }
-    pt.lap(streaming ? "inflate started" : "inflate");
-    // bytes [0, upto) of the stream must be final before the framing loop reads them
-    const uint8_t *const base = p;
-    bool inflate_ok = true;
-    auto need = [&](const uint8_t *upto) {
-        if (streaming && inflate_ok) inflate_ok = bg.wait_for((size_t)(upto - base));
-    };
-    // Framing (serial: groups of {count, count x (len, bytes)}, the first item of a group possibly the type tag "GAM")
-    // hands slices of messages to parser threads as it goes, so parsing overlaps it.
+// GAM bytes -> slices of ~SLICE reads in input order, as a pipeline that runs behind the caller: block-parallel
+// inflate (BGZF) hands its finished prefix to the serial framing pass, which hands slices of messages to the wire
+// parser pool; take() returns the next parsed slices as soon as they exist.
+struct vgan_gam_stream {
     using Msg = std::pair<const uint8_t *, const uint8_t *>;
-    constexpr size_t SLICE = 8192;
+    static constexpr size_t SLICE = 8192;
+    MappedFile file;
+    int keep_unmapped = 0;
+    ByteBuf inflated;
+    AsyncInflate bg; // BGZF (what vg writes): framing runs on the prefix inflated so far
+    bool streaming = false;
+    const uint8_t *p = nullptr;
+    size_t n = 0;
     std::deque<std::vector<Msg>> slices; // grown by the framing thread only, under mu
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t next_slice = 0;
-    bool framing_done = false;
-    std::atomic<bool> ok{true};
     std::deque<vgan_alnset> slice_parts;
-    auto parse_slice = [&](const std::vector<Msg> &ms, vgan_alnset &a) {
+    std::deque<uint8_t> parsed;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    size_t next_slice = 0, delivered = 0;
+    int64_t delivered_reads = 0;
+    bool framing_done = false, framed = true, inflate_ok = true;
+    std::atomic<bool> ok{true};
+    std::thread framer;
+    std::vector<std::thread> workers;
+    PhaseTimer pt{"parse_gam"};
+
+    ~vgan_gam_stream() { join(); }
+
+    void join() {
+        if (framer.joinable()) framer.join();
+        for (auto &t : workers)
+            if (t.joinable()) t.join();
+        workers.clear();
+        (void)bg.finish();
+    }
+
+    int start(const void *bytes, size_t nbytes, int keep) {
+        if (!bytes) return fail(VGAN_EINVAL, "GAM: null buffer");
+        keep_unmapped = keep;
+        p = (const uint8_t *)bytes;
+        n = nbytes;
+        if (n >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
+            if (bg.start(bytes, n)) {
+                streaming = true;
+                p = (const uint8_t *)bg.out.data();
+                n = bg.out.size();
+            } else {
+                if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
+                p = (const uint8_t *)inflated.data();
+                n = inflated.size();
+            }
+        }
+        pt.lap(streaming ? "inflate started" : "inflate");
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nt = (unsigned)std::min<size_t>(std::min(hw, 64u), std::max<size_t>(1, n / (4u << 20)));
+        for (unsigned t = 0; t < nt; ++t) workers.emplace_back([this] { work(); });
+        framer = std::thread([this] { frame(); });
+        return VGAN_OK;
+    }
+
+    void parse_slice(const std::vector<Msg> &ms, vgan_alnset &a) {
         if (ms.empty()) return;
         // reserve from the byte volume of the slice: ~1 mapping per 20 bytes, ~1 edit per 16
         const size_t nbytes = (size_t)(ms.back().second - ms.front().first), nr = ms.size();
@@ -362,38 +386,42 @@ static int parse_gam_parts(const void *bytes, size_t n, int keep_unmapped, std::
                 return;
             }
         }
-    };
-    auto worker = [&]() {
+    }
+
+    void work() { // parser pool
         for (;;) {
-            std::vector<Msg> *ms;
+            size_t i;
+            const std::vector<Msg> *ms;
             vgan_alnset *dst;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return next_slice + 1 < slices.size() || (framing_done && next_slice < slices.size()) || framing_done; });
                 // a slice is complete once a later one exists, or framing has ended
-                if (next_slice + 1 < slices.size() || (framing_done && next_slice < slices.size())) {
-                    ms = &slices[next_slice];
-                    dst = &slice_parts[next_slice];
-                    ++next_slice;
-                } else {
-                    return;
-                }
+                cv_work.wait(lk, [&] { return next_slice + 1 < slices.size() || framing_done; });
+                if (next_slice + 1 < slices.size() || (framing_done && next_slice < slices.size())) i = next_slice++;
+                else return;
+                ms = &slices[i]; // element addresses are stable while the framing thread appends; the deque's index
+                dst = &slice_parts[i]; // is not, so it is only walked under the lock
             }
             parse_slice(*ms, *dst);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                parsed[i] = 1;
+            }
+            cv_done.notify_all();
         }
-    };
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt = (unsigned)std::min<size_t>(std::min(hw, 64u), std::max<size_t>(1, n / (4u << 20)));
-    std::vector<std::thread> th;
-    if (nt > 1)
-        for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker);
-    bool framed = true;
-    {
+    }
+
+    void frame() { // serial: groups of {count, count x (len, bytes)}, the first item of a group possibly the tag "GAM"
+        const uint8_t *const base = p;
+        auto need = [&](const uint8_t *upto) { // bytes [0, upto) must be final before they are read
+            if (streaming && inflate_ok) inflate_ok = bg.wait_for((size_t)(upto - base));
+        };
         auto open_slice = [&]() {
             std::lock_guard<std::mutex> lk(mu);
             slices.emplace_back();
             slices.back().reserve(SLICE);
             slice_parts.emplace_back();
+            parsed.push_back(0);
         };
         open_slice();
         std::vector<Msg> *cur = &slices.back();
@@ -419,33 +447,63 @@ static int parse_gam_parts(const void *bytes, size_t n, int keep_unmapped, std::
                     need(item.e); // the parsers read the payloads
                     open_slice();
                     cur = &slices.back();
-                    cv.notify_one();
+                    cv_work.notify_one();
                 }
             }
             if (!c.ok) break;
         }
         need(p + n);
-        framed = c.ok && inflate_ok;
         {
             std::lock_guard<std::mutex> lk(mu);
+            framed = c.ok && inflate_ok;
             framing_done = true;
         }
-        cv.notify_all();
+        pt.lap("framing");
+        cv_work.notify_all();
+        cv_done.notify_all();
     }
-    pt.lap("framing");
-    if (nt > 1) {
-        for (auto &t : th) t.join();
-    } else if (framed) {
-        for (size_t i = 0; i < slices.size(); ++i) parse_slice(slices[i], slice_parts[i]);
+
+    // The next parsed slices in input order holding at least min_reads reads (fewer at the end); empty at the end.
+    int take(int64_t min_reads, std::vector<vgan_alnset> &out, int64_t *first_read) {
+        out.clear();
+        std::unique_lock<std::mutex> lk(mu);
+        if (first_read) *first_read = delivered_reads;
+        int64_t got = 0;
+        for (;;) {
+            cv_done.wait(lk, [&] { return !ok || (delivered < parsed.size() && parsed[delivered]) || (framing_done && delivered >= slices.size()); });
+            if (!ok) break;
+            if (delivered >= slices.size()) break; // end of the stream
+            if (!parsed[delivered]) continue;
+            vgan_alnset &a = slice_parts[delivered];
+            const int64_t nr = a.n_reads();
+            if (nr > 0) {
+                out.emplace_back(std::move(a));
+                got += nr;
+            }
+            a = vgan_alnset();
+            std::vector<Msg>().swap(slices[delivered]);
+            ++delivered;
+            if (got >= min_reads) break;
+        }
+        delivered_reads += got;
+        const bool bad_frame = framing_done && !framed, bad_inflate = framing_done && !inflate_ok;
+        lk.unlock();
+        if (bad_inflate) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
+        if (bad_frame || !ok) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+        return VGAN_OK;
     }
-    if (streaming && !bg.finish()) inflate_ok = false;
-    if (!inflate_ok) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
-    if (!framed) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
-    parts.resize(slice_parts.size());
-    for (size_t i = 0; i < slice_parts.size(); ++i) parts[i] = std::move(slice_parts[i]);
-    if (!ok) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
-    while (!parts.empty() && parts.back().n_reads() == 0) parts.pop_back();
-    pt.lap("parse");
+};
+
+// the whole input as slices
+static int parse_gam_parts(const void *bytes, size_t n, int keep_unmapped, std::vector<vgan_alnset> &parts) {
+    vgan_gam_stream st;
+    int rc = st.start(bytes, n, keep_unmapped);
+    if (rc) return rc;
+    rc = st.take(INT64_MAX, parts, nullptr);
+    st.join();
+    if (rc) return rc;
+    if (!st.bg.finish()) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
+    st.pt.lap("parse");
     return VGAN_OK;
 }
 
@@ -474,11 +532,46 @@ extern "C" int vgan_alnparts_read_gam(const char *path, int keep_unmapped, vgan_
         delete ps;
         return rc;
     }
-    ps->first.assign(ps->parts.size() + 1, 0);
-    for (size_t i = 0; i < ps->parts.size(); ++i) ps->first[i + 1] = ps->first[i] + ps->parts[i].n_reads();
+    ps->index();
     *out = ps;
     return VGAN_OK;
 }
+
+// ---- the same pipeline handed out chunk by chunk: the caller flattens / accumulates chunk i while the rest of the file
+// is still being inflated and parsed
+extern "C" int vgan_gam_stream_open(const char *path, int keep_unmapped, vgan_gam_stream **out) {
+    if (!path || !out) return fail(VGAN_EINVAL, "vgan_gam_stream_open: null argument");
+    auto st = new vgan_gam_stream();
+    if (!st->file.open_path(path)) {
+        delete st;
+        return fail(VGAN_EIO, "cannot read %s", path);
+    }
+    const int rc = st->start(st->file.p, st->file.n, keep_unmapped);
+    if (rc) {
+        delete st;
+        return rc;
+    }
+    *out = st;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_gam_stream_next(vgan_gam_stream *st, int64_t min_reads, vgan_alnparts **out) {
+    if (!st || !out) return fail(VGAN_EINVAL, "vgan_gam_stream_next: null argument");
+    *out = nullptr;
+    auto ps = new vgan_alnparts();
+    const int rc = st->take(std::max<int64_t>(1, min_reads), ps->parts, &ps->base);
+    if (rc || ps->parts.empty()) {
+        delete ps;
+        return rc; // VGAN_OK with *out == NULL: end of the stream
+    }
+    ps->index();
+    *out = ps;
+    return VGAN_OK;
+}
+
+extern "C" void vgan_gam_stream_close(vgan_gam_stream *st) { delete st; }
+
+extern "C" int64_t vgan_alnparts_base(const vgan_alnparts *p) { return p ? p->base : 0; }
 
 extern "C" int64_t vgan_alnparts_n_reads(const vgan_alnparts *p) { return p ? p->first.back() : 0; }
 extern "C" int64_t vgan_alnparts_count(const vgan_alnparts *p) { return p ? (int64_t)p->parts.size() : 0; }
@@ -621,31 +714,52 @@ extern "C" int vgan_aln_mark_duplicates(const vgan_alnset *a, uint8_t *is_dup, i
     return VGAN_OK;
 }
 
-extern "C" int vgan_alnparts_mark_duplicates(const vgan_alnparts *ps, uint8_t *is_dup, int64_t *n_dup) {
-    if (!ps || !is_dup) return fail(VGAN_EINVAL, "vgan_alnparts_mark_duplicates: null argument");
-    struct KeyHash {
-        size_t operator()(const std::pair<int64_t, int64_t> &k) const {
-            return (size_t)(k.first * 0x9E3779B97F4A7C15ull) ^ (size_t)(k.second + 0x7F4A7C15ull + ((uint64_t)k.first << 6));
-        }
-    };
-    std::unordered_set<std::pair<int64_t, int64_t>, KeyHash> seen;
-    seen.reserve((size_t)std::min<int64_t>(ps->first.back(), 1 << 22));
+namespace {
+struct DupKeyHash {
+    size_t operator()(const std::pair<int64_t, int64_t> &k) const {
+        return (size_t)(k.first * 0x9E3779B97F4A7C15ull) ^ (size_t)(k.second + 0x7F4A7C15ull + ((uint64_t)k.first << 6));
+    }
+};
+} // namespace
+
+// first-seen keys of everything marked so far: chunks of a stream are marked one after the other
+struct vgan_dedup {
+    std::unordered_set<std::pair<int64_t, int64_t>, DupKeyHash> seen;
+};
+
+extern "C" int vgan_dedup_create(vgan_dedup **out) {
+    if (!out) return fail(VGAN_EINVAL, "vgan_dedup_create: null argument");
+    *out = new vgan_dedup();
+    return VGAN_OK;
+}
+
+extern "C" void vgan_dedup_free(vgan_dedup *d) { delete d; }
+
+extern "C" int vgan_dedup_mark(vgan_dedup *d, const vgan_alnparts *ps, uint8_t *is_dup, int64_t *n_dup) {
+    if (!d || !ps || !is_dup) return fail(VGAN_EINVAL, "vgan_dedup_mark: null argument");
     int64_t nd = 0;
     for (size_t i = 0; i < ps->parts.size(); ++i) {
         const vgan_alnset &a = ps->parts[i];
-        uint8_t *d = is_dup + ps->first[i];
+        uint8_t *m = is_dup + ps->first[i];
         for (int64_t r = 0; r < a.n_reads(); ++r) {
-            d[r] = 0;
+            m[r] = 0;
             if (a.map_off[r + 1] == a.map_off[r]) continue;
-            const int64_t m = a.map_off[r];
-            if (!seen.insert({a.m_node[m], a.m_offset[m]}).second) {
-                d[r] = 1;
+            const int64_t k = a.map_off[r];
+            if (!d->seen.insert({a.m_node[k], a.m_offset[k]}).second) {
+                m[r] = 1;
                 ++nd;
             }
         }
     }
     if (n_dup) *n_dup = nd;
     return VGAN_OK;
+}
+
+extern "C" int vgan_alnparts_mark_duplicates(const vgan_alnparts *ps, uint8_t *is_dup, int64_t *n_dup) {
+    if (!ps || !is_dup) return fail(VGAN_EINVAL, "vgan_alnparts_mark_duplicates: null argument");
+    vgan_dedup d;
+    d.seen.reserve((size_t)std::min<int64_t>(ps->first.back(), 1 << 22));
+    return vgan_dedup_mark(&d, ps, is_dup, n_dup);
 }
 
 extern "C" int vgan_aln_filter(const vgan_alnset *a, const uint8_t *drop, vgan_alnset **out) {

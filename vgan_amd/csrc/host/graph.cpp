@@ -8,6 +8,7 @@
 #include <map>
 #include <set>
 #include <sstream>
+#include <thread>
 
 using namespace vgan;
 
@@ -141,10 +142,13 @@ void mask_from_steps(vgan_graph &g) {
 
 extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vgan_graph **out) {
     if (!gfa_path || !out) return fail(VGAN_EINVAL, "vgan_graph_load: null argument");
+    PhaseTimer pt("graph_load");
     std::string txt;
     if (!read_file(gfa_path, txt)) return fail(VGAN_EIO, "cannot read %s", gfa_path);
+    pt.lap("read gfa");
     auto g = new vgan_graph();
     int rc = load_gfa(txt, *g);
+    pt.lap("parse gfa");
     if (rc) {
         delete g;
         return rc;
@@ -172,25 +176,70 @@ extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vg
         }
         g->n_paths = n;
     }
+    pt.lap("graph_paths");
     // path_supports (load.cpp:283-300): row = line index = node id, first P characters
-    if (!dir.empty() && read_text_maybe_gz(dir + "path_supports", side)) {
+    ByteBuf ps_bytes;
+    if (!dir.empty() && read_bytes_maybe_gz(dir + "path_supports", ps_bytes)) {
+        pt.lap("read path_supports");
         g->mask_words = (g->n_paths + 63) / 64;
         g->mask.assign((size_t)(g->max_id + 1) * g->mask_words, 0);
-        LineIter it(side);
-        const char *b, *e;
-        int64_t row = 0;
-        while (it.next(b, e)) {
-            if (row <= g->max_id) {
-                const int64_t n = std::min<int64_t>(e - b, g->n_paths);
-                uint64_t *w = &g->mask[(size_t)row * g->mask_words];
-                for (int64_t j = 0; j < n; ++j)
-                    if (b[j] == '1') w[j >> 6] |= 1ull << (j & 63);
-            }
-            ++row;
+        // 60 MB of '0'/'1' text for the hcfiles shape: the rows are parsed by several threads, each starting at a line
+        // boundary and knowing its first row from a count of the newlines before it
+        const char *base = ps_bytes.data();
+        const size_t nbytes = ps_bytes.size();
+        const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), nbytes / (1u << 20) + 1}));
+        std::vector<size_t> cut(nth + 1, nbytes);
+        cut[0] = 0;
+        for (unsigned t = 1; t < nth; ++t) {
+            size_t pos = nbytes * t / nth;
+            const void *nl = pos < nbytes ? memchr(base + pos, '\n', nbytes - pos) : nullptr;
+            cut[t] = nl ? (size_t)((const char *)nl - base) + 1 : nbytes;
         }
+        std::vector<int64_t> rows_in(nth, 0);
+        auto count = [&](unsigned t) {
+            int64_t c = 0;
+            for (const char *q = base + cut[t], *e = base + cut[t + 1]; q < e;) {
+                const void *nl = memchr(q, '\n', (size_t)(e - q));
+                if (!nl) break;
+                ++c;
+                q = (const char *)nl + 1;
+            }
+            rows_in[t] = c;
+        };
+        auto parse = [&](unsigned t, int64_t row) {
+            const char *q = base + cut[t], *e = base + cut[t + 1];
+            while (q < e) {
+                const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q));
+                const char *le = nl ? nl : e;
+                if (row <= g->max_id) {
+                    int64_t len = le - q;
+                    if (len > 0 && q[len - 1] == '\r') --len;
+                    const int64_t n = std::min<int64_t>(len, g->n_paths);
+                    uint64_t *w = &g->mask[(size_t)row * g->mask_words];
+                    for (int64_t j = 0; j < n; ++j)
+                        if (q[j] == '1') w[j >> 6] |= 1ull << (j & 63);
+                }
+                ++row;
+                q = le + 1;
+            }
+        };
+        auto run = [&](auto &&fn) {
+            if (nth == 1) {
+                fn(0u);
+                return;
+            }
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nth; ++t) th.emplace_back(fn, t);
+            for (auto &x : th) x.join();
+        };
+        run(count);
+        std::vector<int64_t> first_row(nth, 0);
+        for (unsigned t = 1; t < nth; ++t) first_row[t] = first_row[t - 1] + rows_in[t - 1];
+        run([&](unsigned t) { parse(t, first_row[t]); });
     } else {
         mask_from_steps(*g);
     }
+    pt.lap("path_supports rows");
     // parsed_pangenome_mapping (load.cpp:27-41): value = stoi(tok[1]) + 1
     g->pangenome_base.assign((size_t)g->max_id + 1, -1);
     if (!dir.empty() && read_text_maybe_gz(dir + "parsed_pangenome_mapping", side)) {
@@ -236,6 +285,7 @@ extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vg
         read_text_maybe_gz(dir + "parents.txt", g->parents_txt);
         read_text_maybe_gz(dir + "children.txt", g->children_txt);
     }
+    pt.lap("other sidecars");
     *out = g;
     return VGAN_OK;
 }

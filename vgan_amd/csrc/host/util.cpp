@@ -371,6 +371,19 @@ bool write_file(const std::string &path, const std::string &bytes) {
     return (bool)f;
 }
 
+// large sidecars: straight into a buffer that is neither zero-filled nor copied (gzip members inflated in parallel)
+bool read_bytes_maybe_gz(const std::string &path, ByteBuf &out) {
+    std::string p = path;
+    if (!file_exists(p)) p += ".gz";
+    if (!file_exists(p)) return false;
+    MappedFile f;
+    if (!f.open_path(p)) return false;
+    const unsigned char *b = (const unsigned char *)f.p;
+    if (f.n >= 2 && b[0] == 0x1f && b[1] == 0x8b) return gunzip_members(f.p, f.n, out);
+    out.assign((const char *)f.p, f.n);
+    return true;
+}
+
 bool read_text_maybe_gz(const std::string &path, std::string &out) {
     if (file_exists(path)) return read_file(path, out);
     if (file_exists(path + ".gz")) return read_file(path + ".gz", out);

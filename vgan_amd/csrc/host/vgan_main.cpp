@@ -125,20 +125,13 @@ int haplocart(int argc, char **argv) {
     if (!invoked_samplename) samplename = !fastafilename.empty() ? fastafilename : gamfilename;
 
     PhaseTimer pt;
-    // the GAM is inflated and parsed on its own threads while this one loads the graph and brings the device up
-    vgan_alnparts *alns = nullptr; // kept as the parser's slices: nothing here needs the merged set
-    int gam_rc = 0;
-    std::string gam_err;
-    std::thread gam_reader([&] {
-        gam_rc = vgan_alnparts_read_gam(gamfilename.c_str(), 0, &alns);
-        if (gam_rc) gam_err = vgan_last_error(); // the message is per thread
-    });
-    struct Joiner {
-        std::thread &t;
-        ~Joiner() {
-            if (t.joinable()) t.join();
-        }
-    } joiner{gam_reader};
+    // the GAM is inflated, framed and parsed behind this thread (vgan_gam_stream) while it loads the graph and brings the
+    // device up; chunks are then flattened and sent to the device as they become available
+    struct StreamCloser {
+        vgan_gam_stream *s = nullptr;
+        ~StreamCloser() { vgan_gam_stream_close(s); }
+    } stream;
+    check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
     vgan_graph *graph = nullptr;
     check(vgan_graph_load((hcfiledir + "graph.gfa").c_str(), hcfiledir.c_str(), &graph), "loading graph");
     pt.lap("graph load");
@@ -167,42 +160,54 @@ int haplocart(int argc, char **argv) {
     check(vgan_hc_set_mode(ctx, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS), "mode");
     pt.lap("device context");
 
-    gam_reader.join();
-    if (gam_rc) die("[HaploCart] reading GAM: " + gam_err);
-    pt.lap("read GAM (waited)");
-    const int64_t n_in = vgan_alnparts_n_reads(alns), n_slices = vgan_alnparts_count(alns);
-    if (!quiet) std::cerr << "Found " << n_in << " reads." << '\n';
-    std::vector<uint8_t> dup; // reads dropped by the flatten step
-    int64_t n_dup = 0;
-    if (rmdup && fastafilename.empty()) { // HaploCart.cpp:386-393
-        dup.resize((size_t)n_in);
-        check(vgan_alnparts_mark_duplicates(alns, dup.data(), &n_dup), "duplicate removal");
-        if (!quiet) std::cerr << "PCR duplicates removed." << std::endl;
-    }
-    int64_t n_reads = n_in - n_dup;
-    pt.lap("duplicate removal");
-
-    if (!fastafilename.empty() && !quiet) std::cerr << "Using background error probability of " << background_error_prob << '\n';
-    if (!quiet && fastafilename.empty()) std::cerr << "Computing haplogroup likelihoods from " << n_reads << " reads." << '\n';
-
     const int64_t BATCH = 500000; // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i
+    struct DedupCloser {
+        vgan_dedup *d = nullptr;
+        ~DedupCloser() { vgan_dedup_free(d); }
+    } dedup;
+    if (rmdup && fastafilename.empty()) check(vgan_dedup_create(&dedup.d), "duplicate removal"); // HaploCart.cpp:386-393
+    int64_t n_in = 0, n_dup = 0;
+    std::vector<uint8_t> dup;
     vgan_hc_flatten_stats tot{};
-    for (int64_t p0 = 0; p0 < n_slices;) {
-        int64_t p1 = p0 + 1;
-        while (p1 < n_slices && vgan_alnparts_first_read(alns, p1 + 1) - vgan_alnparts_first_read(alns, p0) <= BATCH) ++p1;
+    for (;;) {
+        vgan_alnparts *chunk = nullptr;
+        check(vgan_gam_stream_next(stream.s, BATCH, &chunk), "reading GAM");
+        if (!chunk) break;
+        const int64_t nr = vgan_alnparts_n_reads(chunk);
+        n_in += nr;
+        const uint8_t *skip = nullptr;
+        if (dedup.d) {
+            dup.resize((size_t)nr);
+            int64_t nd = 0;
+            if (vgan_dedup_mark(dedup.d, chunk, dup.data(), &nd) < 0) {
+                vgan_alnparts_free(chunk);
+                check(-1, "duplicate removal");
+            }
+            n_dup += nd;
+            skip = dup.data();
+        }
         vgan_hc_host_batch *hb = nullptr;
-        vgan_hc_flatten_stats st;
-        check(vgan_hc_flatten_parts(graph, alns, p0, p1, dup.empty() ? nullptr : dup.data(), n_threads, &hb, &st), "flattening");
+        vgan_hc_flatten_stats st{};
+        int rc = vgan_hc_flatten_parts(graph, chunk, 0, vgan_alnparts_count(chunk), skip, n_threads, &hb, &st);
+        vgan_alnparts_free(chunk);
+        check(rc, "flattening");
         vgan_hc_batch b;
         check(vgan_hc_host_batch_get(hb, &b), "batch");
         // the copy out of the host batch completes inside the call (pageable memory is staged by the runtime); the
-        // kernels run asynchronously while the next batch is flattened on the host threads
-        check(vgan_hc_accumulate(ctx, &b), "accumulate");
+        // kernels run asynchronously while the next chunk is parsed and flattened on the host threads
+        rc = vgan_hc_accumulate(ctx, &b);
         vgan_hc_host_batch_free(hb);
+        check(rc, "accumulate");
         tot.n_bad += st.n_bad;
         tot.n_unmapped += st.n_unmapped;
         tot.n_out += st.n_out;
-        p0 = p1;
+    }
+    int64_t n_reads = n_in - n_dup;
+    if (!quiet) {
+        std::cerr << "Found " << n_in << " reads." << '\n';
+        if (dedup.d) std::cerr << "PCR duplicates removed." << std::endl;
+        if (!fastafilename.empty()) std::cerr << "Using background error probability of " << background_error_prob << '\n';
+        else std::cerr << "Computing haplogroup likelihoods from " << n_reads << " reads." << '\n';
     }
     if (tot.n_bad && !quiet)
         std::cerr << "[HaploCart] warning: " << tot.n_bad << " reads skipped (the reference would terminate on them)\n";

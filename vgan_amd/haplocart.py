@@ -186,6 +186,45 @@ class AlnSet:
             self._h = None
 
 
+class GamStream:
+    """A GAM decoded behind the caller and handed out in chunks of at least `min_reads` reads (vgan_gam_stream)."""
+
+    def __init__(self, path, keep_unmapped=False):
+        self._h = N.vp()
+        N.check(N.lib().vgan_gam_stream_open(path.encode(), int(keep_unmapped), C.byref(self._h)))
+
+    def chunks(self, min_reads=500000):
+        while True:
+            h = N.vp()
+            N.check(N.lib().vgan_gam_stream_next(self._h, min_reads, C.byref(h)))
+            if not h:
+                return
+            yield AlnParts(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_gam_stream_close(self._h)
+            self._h = None
+
+
+class Dedup:
+    """Keep-first duplicate marks across the chunks of a stream (vgan_dedup)."""
+
+    def __init__(self):
+        self._h = N.vp()
+        N.check(N.lib().vgan_dedup_create(C.byref(self._h)))
+
+    def mark(self, parts):
+        m = np.zeros(parts.n_reads, np.uint8)
+        N.check(N.lib().vgan_dedup_mark(self._h, parts._h, m.ctypes.data, None))
+        return m.astype(bool)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vgan_dedup_free(self._h)
+            self._h = None
+
+
 class AlnParts:
     """A GAM kept as the slices its parser produced (vgan_alnparts): what a front end that only feeds the device uses."""
 
@@ -205,6 +244,11 @@ class AlnParts:
     @property
     def n_parts(self):
         return N.lib().vgan_alnparts_count(self._h)
+
+    @property
+    def base(self):
+        """Index in the whole input of this object's first read (chunks of a GamStream)."""
+        return N.lib().vgan_alnparts_base(self._h)
 
     def first_read(self, i):
         return N.lib().vgan_alnparts_first_read(self._h, i)
