@@ -85,6 +85,39 @@ def cpu_baseline(graph, alns, budget_s, ctx=None, hc=None):
     return out, parity
 
 
+def cpu_baseline_euka(g, db, alns, dm_texts, ctx, ek, budget_s):
+    """The oracle's restatement of readGAM3's per-alignment lambda, serial as in the reference
+    (src/readGAM_Euka.h:581), on a bounded prefix of the workload; the device result of the same reads is diffed
+    against it (the only use of oracle/ in this leg)."""
+    import numpy as np
+    import orc
+    import util
+    og, odb, dmg = util.orc_graph_nodes_only(g), util.orc_euka_db_from_product(db), orc.OrcDamage(*dm_texts)
+    n, rate, ref, sub = 2000, None, None, None
+    while True:
+        n = min(n, alns.n_reads)
+        drop = np.ones(alns.n_reads, np.uint8)
+        drop[:n] = 0
+        sub = alns.without(drop)
+        t0 = time.perf_counter()
+        ref = orc.euka_run(og, util.orc_alnset_from_product(sub), odb, dmg)
+        dt = time.perf_counter() - t0
+        rate = n / dt
+        if dt >= budget_s / 3 or n >= alns.n_reads:
+            break
+        n = int(min(alns.n_reads, max(2 * n, n * budget_s / max(dt, 1e-3) * 0.6)))
+    hb = ek.EukaHostBatch(g, sub)
+    ctx.reset()
+    got = ctx.accumulate(hb)
+    src = hb.arrays()["read_src"]
+    ok = got["clade"] >= 0
+    err = max(float(util.rel_err(got[k][ok], ref[k][src][ok])) for k in ("in_lik", "out_lik", "like")) if ok.any() else 0.0
+    same = bool(np.array_equal(got["clade"], ref["clade"][src]) and np.array_equal(got["pass"], ref["pass"][src]))
+    return ({"value": rate, "unit": "reads/s", "cores": 1, "kind": "port",
+             "sample": "first %d of the workload's reads, per-alignment lambda restated serially (oracle, long double)" % n},
+            {"reads": int(n), "max_rel_err_vs_oracle": err, "clade_and_pass_identical": same, "tolerance": 1e-6})
+
+
 def bench_euka(args):
     """BASELINE config 4 shape: synthetic 75 bp aDNA reads with the dhigh damage profiles against a 335-clade graph."""
     import numpy as np
@@ -99,6 +132,7 @@ def bench_euka(args):
     vd.init(backend=args.dist_backend, device=dev)
     gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
     dm = ek.Damage.load(os.path.join(gold, "dhigh5p.prof"), os.path.join(gold, "dhigh3p.prof"))
+    dm_texts = (open(os.path.join(gold, "dhigh5p.prof")).read(), open(os.path.join(gold, "dhigh3p.prof")).read())
     g, db, alns = ek.synth_euka(args.reads, dm, seed=args.seed, n_clades=args.clades, nodes_per_clade=400,
                                 read_len_mean=75, read_seed=args.seed + 1000003 * rank)
     hb = ek.EukaHostBatch(g, alns)
@@ -137,7 +171,7 @@ def bench_euka(args):
         kb = hb.algorithmic_bytes()
         avg = ms / max(n, 1)
         gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
-        print(json.dumps({
+        out = {
             "metric": "reads/sec through euka per-read two-model likelihood (readGAM3), 75bp aDNA", "value": n_total * args.steps / elapsed,
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -145,8 +179,43 @@ def bench_euka(args):
                        "reads_per_gpu": hb.n_reads, "passing_reads": int(fin["clade_count"].sum())},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "euka_read_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
-                         "launches": n, "note": "fp64 transcendental bound (SURVEY 8d): ~4 log-equivalents + 16 FMA per base"}}),
-              flush=True)
+                         "launches": n, "note": "fp64 VALU bound (SURVEY 8d): one table log + the damage-matrix products per base"}}
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"], out["parity"] = cpu_baseline_euka(g, db, alns, dm_texts, ctx, ek, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_soibean(g, alns, dm, sb, state_fn, freqs, budget_s):
+    """The oracle's restatement of analyse_GAM + one MCMC likelihood refresh (OpenMP reduction over reads as
+    src/MCMC.cpp:739) on a bounded prefix of the workload; the device refresh of the same reads and the same state
+    is diffed against it (the only use of oracle/ in this leg)."""
+    import numpy as np
+    import orc
+    import util
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = min(alns.n_reads, 20000)
+    drop = np.ones(alns.n_reads, np.uint8)
+    drop[:n] = 0
+    sub = alns.without(drop)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(sub)
+    so = orc.SbOracle(og, oa, orc.OrcDamage("", ""))
+    st = state_fn()[0]
+    reps, t_used, ref = 0, 0.0, None
+    t0 = time.perf_counter()
+    while t_used < budget_s / 2 and reps < 200:
+        rc, ref = so.loglike(st, 0.01, freqs, n_threads=cores)
+        assert rc == 0
+        reps += 1
+        t_used = time.perf_counter() - t0
+    rate = n * reps / t_used
+    hb = sb.SbHostBatch(g, sub)
+    ctx = sb.SbContext(g, dm)
+    ctx.precompute(hb)
+    got = float(ctx.loglike([st], 0.01, freqs)[0][0])
+    err = abs(got - ref) / max(abs(ref), 1e-300)
+    return ({"value": rate, "unit": "reads*iterations/s", "cores": cores, "kind": "port",
+             "sample": "refresh over the first %d reads, %d repetitions (oracle, long double, OpenMP x%d)" % (n, reps, cores)},
+            {"reads": int(n), "max_rel_err_vs_oracle": float(err), "tolerance": 1e-6})
 
 
 def bench_soibean(args):
@@ -223,7 +292,7 @@ def bench_soibean(args):
         avg = km["refresh"][0] / max(km["refresh"][1], 1)
         kb = R * 3 * 2 * (8 + 25 * 2) + R  # 2k path rows of pm (8 B) + cnt (25 x 2 B) + ok flags
         gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
-        print(json.dumps({
+        out = {
             "metric": "read-iterations/sec through the soibean MCMC likelihood refresh (k=3)", "value": R * world * args.steps / elapsed,
             "unit": "reads*iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -232,7 +301,10 @@ def bench_soibean(args):
                        "reads_per_gpu": R, "precompute_s": t_pre, "accepted": accepted},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "sb_loglike_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
-                         "launches": km["refresh"][1]}}), flush=True)
+                         "launches": km["refresh"][1]}}
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"], out["parity"] = cpu_baseline_soibean(g, alns, dm, sb, state, freqs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
 
 
 def main():
