@@ -176,3 +176,28 @@ def test_long_reads_and_ragged_read_counts():
     d = os.path.join(GOLD, "damageProfiles")
     got, fin, ref = compare(g, db, a, (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read()))
     assert got["pass"].sum() >= 5 and (fin["bin_cov"] > 0).sum() >= 8
+
+
+def test_accumulate_in_batches_and_after_finalize():
+    """Per-clade accumulators are kept in replicas that finalize folds together: batches before and after a finalize
+    must add up to the single-batch result."""
+    d = os.path.join(GOLD, "damageProfiles")
+    dm = ek.Damage.load(d + "/dhigh5p.prof", d + "/dhigh3p.prof")
+    g, db, a = ek.synth_euka(6000, dm, seed=21, n_clades=9, nodes_per_clade=150)
+    whole = ek.EukaHostBatch(g, a)
+    ctx = ek.EukaContext(db, dm)
+    ctx.accumulate(whole)
+    want = ctx.finalize()
+    n = a.n_reads
+    parts = [ek.EukaHostBatch(g, a, 0, n // 3), ek.EukaHostBatch(g, a, n // 3, n // 2), ek.EukaHostBatch(g, a, n // 2, n)]
+    ctx.reset()
+    ctx.accumulate(parts[0])
+    mid = ctx.finalize()
+    assert mid["clade_count"].sum() < want["clade_count"].sum()
+    ctx.accumulate(parts[1])
+    ctx.accumulate(parts[2])
+    got = ctx.finalize()
+    assert np.array_equal(got["clade_count"], want["clade_count"]) and np.array_equal(got["baseshift"], want["baseshift"])
+    assert np.allclose(got["bin_cov"], want["bin_cov"], rtol=1e-12, atol=1e-12)
+    again = ctx.finalize()  # idempotent
+    assert np.array_equal(again["clade_count"], got["clade_count"]) and np.allclose(again["bin_cov"], got["bin_cov"], rtol=0, atol=0)

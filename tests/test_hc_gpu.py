@@ -374,3 +374,25 @@ def test_tiled_kernel_fuzz_against_general_kernel(seed):
             outs.append(ctx.finalize())
         if np.all(fin):
             assert util.rel_err(outs[0], outs[1]) < 1e-12
+
+
+def test_accumulate_in_batches_and_after_finalize():
+    g = hc.synth_graph(seed=61, genome_len=1300, n_nodes=800, n_paths=90)
+    a = hc.synth_reads(g, 5000, seed=62, read_len=110)
+    whole = hc.HostBatch(g, a)
+    n = a.n_reads
+    parts = [hc.HostBatch(g, a, 0, n // 4), hc.HostBatch(g, a, n // 4, n // 2), hc.HostBatch(g, a, n // 2, n)]
+    for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ):
+        ctx = hc.HcContext(g)
+        ctx.set_mode(mode)
+        ctx.accumulate(whole)
+        want = ctx.finalize()
+        ctx.reset()
+        ctx.accumulate(parts[0])
+        mid = ctx.finalize()
+        assert np.all(mid >= want - 1e-9 * np.abs(want))  # fewer reads: every log-likelihood sum is less negative
+        ctx.accumulate(parts[1])
+        ctx.accumulate(parts[2])
+        got = ctx.finalize()
+        assert util.rel_err(got, want) < 1e-12
+        assert util.rel_err(ctx.finalize(), got) < 1e-13  # finalize does not consume the accumulators (atomic order may differ)
