@@ -57,7 +57,7 @@ class EukaDb:
         return _np_view(self.view.bin_entropy, self.n_bins, np.float64)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_euka_db_free(self._h)
             self._h = None
 
@@ -89,7 +89,7 @@ class Damage:
         return _np_view(self.view.sub3p, self.view.n3 * 16, np.float64).reshape(-1, 4, 4)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_damage_free(self._h)
             self._h = None
 
@@ -122,7 +122,7 @@ class EukaHostBatch:
         return 2 * c.n_cols + c.n_qual + 4 * c.n_maps + 27 * c.n_reads + 37 * c.n_reads  # inputs + per-read outputs
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_euka_host_batch_free(self._h)
             self._h = None
 
@@ -202,7 +202,7 @@ class EukaContext:
         return ms.value, n.value
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_euka_destroy(self._h)
             self._h = None
 

@@ -107,7 +107,7 @@ class Graph:
         return np.ascontiguousarray(bits[:, : self.n_paths])
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_graph_free(self._h)
             self._h = None
 
@@ -181,7 +181,7 @@ class AlnSet:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_aln_free(self._h)
             self._h = None
 
@@ -202,7 +202,7 @@ class GamStream:
             yield AlnParts(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_gam_stream_close(self._h)
             self._h = None
 
@@ -220,7 +220,7 @@ class Dedup:
         return m.astype(bool)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_dedup_free(self._h)
             self._h = None
 
@@ -265,7 +265,7 @@ class AlnParts:
         return AlnSet(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_alnparts_free(self._h)
             self._h = None
 
@@ -342,7 +342,7 @@ class HostBatch:
         return {"node_weights": io, "per_read": io + c.n_segments * (8 * ((n_paths + 63) // 64) + 8)}
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_hc_host_batch_free(self._h)
             self._h = None
 
@@ -480,7 +480,7 @@ class HcContext:
         return N.check(N.lib().vgan_hc_argmax(fv.ctypes.data, len(fv)))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_hc_destroy(self._h)
             self._h = None
 

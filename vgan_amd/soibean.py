@@ -32,7 +32,7 @@ class SbHostBatch:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_sb_host_batch_free(self._h)
             self._h = None
 
@@ -88,7 +88,7 @@ class SbContext:
         return {"precompute": (float(ms[0]), int(n[0])), "refresh": (float(ms[1]), int(n[1]))}
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_sb_destroy(self._h)
             self._h = None
 
