@@ -201,3 +201,24 @@ def test_accumulate_in_batches_and_after_finalize():
     assert np.allclose(got["bin_cov"], want["bin_cov"], rtol=1e-12, atol=1e-12)
     again = ctx.finalize()  # idempotent
     assert np.array_equal(again["clade_count"], got["clade_count"]) and np.allclose(again["bin_cov"], got["bin_cov"], rtol=0, atol=0)
+
+
+def test_long_damage_profiles_take_the_global_table_path():
+    """Profiles of 12 x 11 rows make 132 (5' row, 3' row) pairs: more than the 64 the kernel keeps in LDS, so the
+    instantiation that reads the pair table from HBM runs; every substitution type non-zero, both ends different."""
+    hdr = "A>C\tA>G\tA>T\tC>A\tC>G\tC>T\tG>A\tG>C\tG>T\tT>A\tT>C\tT>G\n"
+    rng = np.random.default_rng(5)
+
+    def prof(rows, main_col):
+        out = hdr
+        for i in range(rows):
+            v = rng.uniform(0.0, 0.004, 12)
+            v[main_col] = 0.33 * 0.75 ** i
+            out += "\t".join("%.6g" % x for x in v) + "\n"
+        return out
+
+    texts = (prof(12, 5), prof(11, 6))  # C>T at the 5' end, G>A at the 3' end
+    dm = ek.Damage.from_text(*texts)
+    g, db, a = ek.synth_euka(2500, dm, seed=31, n_clades=7, nodes_per_clade=180)
+    got, fin, ref = compare(g, db, a, texts)
+    assert got["pass"].sum() > 500
