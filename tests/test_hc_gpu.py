@@ -396,3 +396,20 @@ def test_accumulate_in_batches_and_after_finalize():
         got = ctx.finalize()
         assert util.rel_err(got, want) < 1e-12
         assert util.rel_err(ctx.finalize(), got) < 1e-13  # finalize does not consume the accumulators (atomic order may differ)
+
+
+@pytest.mark.parametrize("P", [8128, 8192, 8200, 16384, 20000])
+def test_path_counts_around_the_tile_split_boundaries(P):
+    """The sweep deals the ceil(P/64) mask words to 8 x ceil(W/127) tiles of at most 16 words: path counts at and
+    beyond the points where the number of tiles changes (W = 127, 128, 129, 256 ...), every mode, against the oracle."""
+    g = hc.synth_graph(seed=P, genome_len=600, n_nodes=400, n_paths=P)
+    a = hc.synth_reads(g, 300, seed=3, read_len=80)
+    b = hc.HostBatch(g, a)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    _, ref, _ = orc.hc_run(og, oa, n_threads=8, faithful=False)
+    ctx = hc.HcContext(g)
+    for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ, hc.MODE_PER_READ_DENSE):
+        ctx.reset()
+        ctx.set_mode(mode)
+        ctx.accumulate(b)
+        assert util.rel_err(ctx.finalize(), ref) < RTOL, mode

@@ -258,7 +258,7 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     c->P = gv->n_paths;
     c->W = (gv->n_paths + 63) / 64;
     c->rows = (uint32_t)gv->max_id + 1;
-    c->n_tiles = 8 * ((c->W + 127) / 128);
+    c->n_tiles = 8 * ((c->W + 126) / 127); // at most 16 words per tile (one bit each in a 16-bit entry): floor(W / n_tiles) <= 15
     c->prm.bep = params->background_error_prob;
     c->prm.use_bep = params->use_background_error_prob != 0;
     c->prm.consensus = params->is_consensus_fasta != 0;
@@ -282,6 +282,7 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         }
     }
     const uint32_t tile_base = c->W / c->n_tiles, tile_rem = c->W % c->n_tiles;
+    if (tile_base > 15) return bail(fail(VGAN_ERANGE, "vgan_hc_create: internal tile split out of range (%u words per tile)", tile_base));
     std::vector<uint16_t> tw0(c->n_tiles + 1, 0);
     for (uint32_t t = 0; t < c->n_tiles; ++t) tw0[t + 1] = (uint16_t)(tw0[t] + tile_base + (t < tile_rem ? 1 : 0));
     const uint32_t row_entries = c->n_tiles * 64;

@@ -14,7 +14,7 @@ struct HcNodeDev {
 //   umask     uint64 [rows][mask_words]  UNSUPPORTED-path bitmask: bit p of row i = !path_supports[i][p], zero
 //             beyond P (plain layout; debug kernel only).
 //   umaskT    uint16 [rows][n_tiles][64]  the same bits, transposed per tile for the sweep: the ceil(P/64) mask words
-//             are dealt as evenly as possible to n_tiles = 8*ceil(W/128) tiles (tile t owns words
+//             are dealt as evenly as possible to n_tiles = 8*ceil(W/127) tiles (tile t owns words
 //             tile_word0[t] .. tile_word0[t+1]-1, i.e. tile_base_words or one more); entry [row][t][l] holds, from bit
 //             15 downwards, bit l of each of the tile's words.  One wave-wide 2-byte load (128 B, coalesced) gives
 //             every lane the membership bits of "its" path in all words of the tile.  With tile = blockIdx % 8 each
