@@ -413,3 +413,24 @@ def test_path_counts_around_the_tile_split_boundaries(P):
         ctx.set_mode(mode)
         ctx.accumulate(b)
         assert util.rel_err(ctx.finalize(), ref) < RTOL, mode
+
+
+@pytest.mark.parametrize("P,n_nodes,genome", [(1, 300, 500), (2, 300, 500), (63, 300, 500), (64, 300, 500), (65, 300, 500),
+                                              (127, 300, 500), (128, 300, 500), (129, 300, 500), (1024, 300, 500),
+                                              (40, 26000, 40000)])
+def test_small_path_counts_and_large_node_counts(P, n_nodes, genome):
+    """One path, word boundaries of the mask, and more nodes than the LDS-private node accumulator holds (> 19 200:
+    the global-atomic accumulate kernel), every mode, against the oracle."""
+    g = hc.synth_graph(seed=1000 + P, genome_len=genome, n_nodes=n_nodes, n_paths=P)
+    a = hc.synth_reads(g, 400, seed=4, read_len=70)
+    b = hc.HostBatch(g, a)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    _, ref, _ = orc.hc_run(og, oa, n_threads=8, faithful=False)
+    ctx = hc.HcContext(g)
+    for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ, hc.MODE_PER_READ_DENSE):
+        ctx.reset()
+        ctx.set_mode(mode)
+        ctx.accumulate(b)
+        got = ctx.finalize()
+        assert util.rel_err(got, ref) < RTOL, mode
+    assert ctx.argmax(got) == int(np.argmax(ref))
