@@ -20,7 +20,7 @@ worst_hc = 0.0
 for case in range(n_cases):
     L = int(rng.choice([400, 900, 2500, 6000]))
     n_nodes = int(L * rng.uniform(0.05, 0.75)) + 8
-    P = int(rng.choice([3, 64, 65, 200, 700]))
+    P = int(rng.choice([1, 3, 64, 65, 200, 700, 5179, 8192, 12000]))
     g = hc.synth_graph(seed=int(rng.integers(1 << 30)), genome_len=L, n_nodes=n_nodes, n_paths=P)
     rl = int(rng.choice([30, 60, 100, 150, 250, 400, 1000, 1500]))
     rl = min(rl, L - 10)
