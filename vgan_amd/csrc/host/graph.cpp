@@ -274,6 +274,10 @@ extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vg
             int64_t s0, s1;
             if (!parse_i64(tk[1].first, tk[1].second, s0) || !parse_i64(tk[2].first, tk[2].second, s1)) continue;
             const double v = strtod(std::string(tk[3].first, tk[3].second).c_str(), nullptr);
+            if (s1 - s0 > (int64_t)1 << 28 || g->mappability.size() > ((size_t)1 << 30)) { // a corrupt range, not a genome
+                delete g;
+                return fail(VGAN_ERANGE, "mappability.tsv: interval [%lld, %lld) is out of any plausible range", (long long)s0, (long long)s1);
+            }
             for (int64_t i = s0; i < s1; ++i) g->mappability.push_back(v);
         }
     } else {
