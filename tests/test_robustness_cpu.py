@@ -100,3 +100,88 @@ def test_flatten_rejects_nonsense_without_crashing():
     e = ek.EukaHostBatch(g, a2)
     s = sb.SbHostBatch(g, a2)
     assert e.stats.n_out + e.stats.n_bad == 200 and s.stats.n_out + s.stats.n_bad == 200
+
+
+def _mutate(b, rng):
+    b = bytearray(b)
+    mode = rng.randrange(5)
+    if mode == 0 and b:
+        del b[rng.randrange(len(b)):]
+    elif mode == 1 and b:
+        for _ in range(rng.randrange(1, 30)):
+            b[rng.randrange(len(b))] = rng.randrange(256)
+    elif mode == 2:
+        b = b[:len(b) // 3] + bytes(rng.randrange(32, 127) for _ in range(80)) + b[len(b) // 3:]
+    elif mode == 3:
+        b = bytearray(b.replace(b"\n", b"\r\n"))
+    else:
+        b = bytearray(b.replace(b"\t", b" ").replace(b"1", b"9999999999"))
+    return bytes(b)
+
+
+def test_table_and_sidecar_loaders_survive_corrupt_files(tmp_path, golden_dir):
+    """Corrupt / truncated euka tables, damage profiles, GFA and HaploCart sidecars are either loaded (tolerant parsing,
+    as the reference's whitespace tokenisers) or rejected with an error -- never a crash (a malformed *.bins line used to
+    read one token past the end)."""
+    import gzip
+    import random
+    import shutil
+    from vgan_amd import euka as ek
+    from vgan_amd import haplocart as hc
+    rng = random.Random(7)
+    srcs = {"clade": os.path.join(golden_dir, "euka_dir/euka_db.clade"), "bins": os.path.join(golden_dir, "euka_dir/euka_db.bins"),
+            "p5": os.path.join(golden_dir, "damageProfiles/dhigh5p.prof"), "p3": os.path.join(golden_dir, "damageProfiles/dhigh3p.prof")}
+    loaded = rejected = 0
+    for it in range(150):
+        d = tmp_path / ("e%d" % it)
+        d.mkdir()
+        paths = {k: str(d / k) for k in srcs}
+        for k, p in srcs.items():
+            shutil.copy(p, paths[k])
+        k = rng.choice(list(srcs))
+        open(paths[k], "wb").write(_mutate(open(paths[k], "rb").read(), rng))
+        try:
+            if k in ("clade", "bins"):
+                ek.EukaDb.load(paths["clade"], paths["bins"])
+            else:
+                ek.Damage.load(paths["p5"], paths["p3"])
+            loaded += 1
+        except Exception:
+            rejected += 1
+        shutil.rmtree(d)
+    assert loaded > 10 and rejected > 10
+    # a truncated bins line (name + 2 of 3 fields)
+    bad = tmp_path / "trunc.bins"
+    lines = open(srcs["bins"]).read().splitlines()
+    lines[0] = "\t".join(lines[0].split()[:3])
+    bad.write_text("\n".join(lines) + "\n")
+    ek.EukaDb.load(srcs["clade"], str(bad))
+    # HaploCart graph directory
+    g = hc.synth_graph(seed=5, genome_len=300, n_nodes=200, n_paths=70)
+    base = tmp_path / "hc"
+    base.mkdir()
+    g.write(str(base))
+    files = os.listdir(base)
+    for it in range(120):
+        d = tmp_path / ("g%d" % it)
+        shutil.copytree(base, d)
+        f = rng.choice(files)
+        p = str(d / f)
+        data = open(p, "rb").read()
+        if f.endswith(".gz"):
+            data = gzip.decompress(data)
+            os.remove(p)
+            p = p[:-3]
+        open(p, "wb").write(_mutate(data, rng))
+        try:
+            hc.Graph.load(str(d / "graph.gfa"), str(d))
+            loaded += 1
+        except Exception:
+            rejected += 1
+        shutil.rmtree(d)
+    # an absurd mappability interval is an error, not an allocation of gigabytes
+    d = tmp_path / "gm"
+    shutil.copytree(base, d)
+    (d / "mappability.tsv").write_text("chrM\t0\t4000000000\t1.0\n")
+    with pytest.raises(Exception):
+        hc.Graph.load(str(d / "graph.gfa"), str(d))

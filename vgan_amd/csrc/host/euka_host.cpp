@@ -70,7 +70,7 @@ int parse_db(const std::string &clade_txt, const std::string &bins_txt, vgan_euk
     std::istringstream inb(bins_txt);
     while (std::getline(inb, line)) {
         const auto t = ws_tokens(line);
-        for (size_t j = 1; j + 2 < t.size() + 1; j += 3) { // load.cpp:81-88
+        for (size_t j = 1; j + 2 < t.size(); j += 3) { // load.cpp:81-88 (an incomplete trailing triple is ignored)
             int32_t lo, hi;
             if (!stoi_like(t[j], lo) || !stoi_like(t[j + 1], hi)) return fail(VGAN_EIO, "bins file: non-numeric bound");
             d.bin_lo.push_back(lo);
