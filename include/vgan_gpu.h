@@ -229,6 +229,11 @@ int vgan_hc_create(const vgan_graph_view *graph, const vgan_hc_params *params, i
 int vgan_hc_set_stream(vgan_hc_ctx *c, void *hip_stream); /* NULL = the context's own stream */
 int vgan_hc_set_mode(vgan_hc_ctx *c, int mode);
 int vgan_hc_reset(vgan_hc_ctx *c);                         /* zero the accumulators */
+/* Full check of a batch held in host memory against the contracts above and the context's graph (offsets ascending
+ * and within the arrays, node ids known, segments inside their read's columns, the tile contract for the first
+ * n_tileable reads).  vgan_hc_accumulate only checks for null arrays: batches from vgan_hc_flatten* hold by
+ * construction, hand-built ones should be validated once (O(reads + segments) on the host). */
+int vgan_hc_batch_validate(const vgan_hc_ctx *c, const vgan_hc_batch *batch);
 /* Asynchronous on the context's stream: adds the batch's reads into the device accumulators. */
 int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *batch);
 /* Per-segment scalars of a batch (test / debug aid): S_m, U_m as the kernel computes them. Host outputs. */

@@ -434,3 +434,33 @@ def test_small_path_counts_and_large_node_counts(P, n_nodes, genome):
         got = ctx.finalize()
         assert util.rel_err(got, ref) < RTOL, mode
     assert ctx.argmax(got) == int(np.argmax(ref))
+
+
+def test_batch_validation(tmp_path):
+    """vgan_hc_batch_validate accepts what vgan_hc_flatten produces (tileable, long and irregular reads) and names the
+    broken contract of hand-built batches."""
+    from vgan_amd._native import NativeError
+    g = hc.synth_graph(seed=71, genome_len=2000, n_nodes=1200, n_paths=40)
+    a = util.concat_alnsets(tmp_path, hc.synth_reads(g, 300, seed=1, read_len=120, indel_rate=0.3, softclip_rate=0.3),
+                            hc.synth_reads(g, 10, seed=2, read_len=1500))
+    ctx = hc.HcContext(g)
+    b = hc.HostBatch(g, a)
+    ctx.validate(b)
+    base = {k: np.array(v) for k, v in b.arrays().items() if k not in ("_owner", "read_src")}
+
+    def broken(change, n_tileable=None):
+        arr = {k: v.copy() for k, v in base.items()}
+        change(arr)
+        bad = hc.ArrayBatch(arr, n_tileable=b.n_tileable if n_tileable is None else n_tileable)
+        with pytest.raises(NativeError):
+            ctx.validate(bad)
+
+    ctx.validate(hc.ArrayBatch(base, n_tileable=b.n_tileable))
+    ctx.validate(hc.ArrayBatch(base, n_tileable=0))
+    broken(lambda x: x["seg_node"].__setitem__(5, g.max_id + 1))                      # unknown node
+    broken(lambda x: x["read_seg_off"].__setitem__(3, x["read_seg_off"][4] + 1))      # offsets descend
+    broken(lambda x: x["seg_len"].__setitem__(0, 60000))                              # leaves the read
+    broken(lambda x: x["read_mapq"].__setitem__(7, 120))
+    broken(lambda x: x["seg_start"].__setitem__(1, 0) if x["seg_len"][0] else None, n_tileable=b.n_tileable)  # overlap / order
+    broken(lambda x: None, n_tileable=b.n_reads)                                      # the 1500-column reads are not tileable
+    broken(lambda x: x["read_col_off"].__setitem__(len(x["read_col_off"]) - 1, 5))    # final offset vs n_cols

@@ -156,6 +156,7 @@ SYMBOLS = {
     "vgan_hc_reset": (C.c_int, [vp]),
     "vgan_hc_accumulate": (C.c_int, [vp, C.POINTER(HcBatch)]),
     "vgan_hc_segment_scalars": (C.c_int, [vp, C.POINTER(HcBatch), vp, vp]),
+    "vgan_hc_batch_validate": (C.c_int, [vp, C.POINTER(HcBatch)]),
     "vgan_hc_segment_weights": (C.c_int, [vp, C.POINTER(HcBatch), vp]),
     "vgan_hc_read_loglik": (C.c_int, [vp, C.POINTER(HcBatch), vp]),
     "vgan_hc_finalize": (C.c_int, [vp, vp, vp]),

@@ -431,6 +431,44 @@ extern "C" int vgan_hc_reset(vgan_hc_ctx *c) {
     return VGAN_OK;
 }
 
+extern "C" int vgan_hc_batch_validate(const vgan_hc_ctx *c, const vgan_hc_batch *b) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_batch_validate: null context");
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (b->on_device) return fail(VGAN_EINVAL, "vgan_hc_batch_validate: the batch must be in host memory");
+    const uint64_t R = b->n_reads, S = b->n_segments;
+    if (R == 0) return VGAN_OK;
+    if (b->n_tileable > R) return fail(VGAN_EINVAL, "batch: n_tileable exceeds n_reads");
+    if (b->read_seg_off[0] != 0 || b->read_col_off[0] != 0 || b->read_qual_off[0] != 0)
+        return fail(VGAN_EINVAL, "batch: offsets do not start at 0");
+    if (b->read_seg_off[R] != S || b->read_col_off[R] != b->n_cols || b->read_qual_off[R] != b->n_qual)
+        return fail(VGAN_EINVAL, "batch: final offsets do not match n_segments / n_cols / n_qual");
+    for (uint64_t r = 0; r < R; ++r) {
+        const uint32_t s0 = b->read_seg_off[r], s1 = b->read_seg_off[r + 1], c0 = b->read_col_off[r], c1 = b->read_col_off[r + 1];
+        if (s1 < s0 || c1 < c0 || b->read_qual_off[r + 1] < b->read_qual_off[r])
+            return fail(VGAN_EINVAL, "batch: offsets of read %llu descend", (unsigned long long)r);
+        const uint32_t cols = c1 - c0, ql = b->read_qual_off[r + 1] - b->read_qual_off[r];
+        if (b->read_algn_len[r] > cols) return fail(VGAN_EINVAL, "batch: |algnseq| of read %llu exceeds its column region", (unsigned long long)r);
+        if (b->read_mapq[r] > 99) return fail(VGAN_EINVAL, "batch: mapping quality of read %llu exceeds 99", (unsigned long long)r);
+        const bool tile = r < b->n_tileable;
+        if (tile && (cols > HC_TILE_MAX_READ_COLS || ql > HC_TILE_MAX_READ_QUAL || s1 - s0 > HC_TILE_MAX_READ_SEGS))
+            return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but exceeds the tile limits", (unsigned long long)r);
+        if (tile && b->read_algn_len[r] != cols)
+            return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but |algnseq| differs from its column count", (unsigned long long)r);
+        uint32_t prev_end = 0, prev_start = 0;
+        for (uint32_t s = s0; s < s1; ++s) {
+            const uint32_t st = b->seg_start[s], ln = b->seg_len[s];
+            if (b->seg_node[s] >= c->rows) return fail(VGAN_EINVAL, "batch: segment %u names node %u, beyond the graph", s, b->seg_node[s]);
+            if ((uint64_t)st + ln > cols) return fail(VGAN_EINVAL, "batch: segment %u leaves the columns of read %llu", s, (unsigned long long)r);
+            if (st < prev_start) return fail(VGAN_EINVAL, "batch: segments of read %llu do not ascend in seg_start", (unsigned long long)r);
+            if (tile && ln && st < prev_end) return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but its segments overlap", (unsigned long long)r);
+            prev_start = st;
+            if (ln) prev_end = st + ln;
+        }
+    }
+    return VGAN_OK;
+}
+
 extern "C" int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *b) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_accumulate: null context");
     int rc = check_batch(b);

@@ -428,6 +428,10 @@ class HcContext:
         N.check(N.lib().vgan_hc_segment_scalars(self._h, C.byref(batch.c), S.ctypes.data, U.ctypes.data))
         return S, U
 
+    def validate(self, batch):
+        """Raises NativeError unless the (host) batch satisfies the batch and tile contracts for this context's graph."""
+        N.check(N.lib().vgan_hc_batch_validate(self._h, C.byref(batch.c)))
+
     def segment_weights(self, batch):
         """D_m = S_m - U_m per segment through the routed kernels (the tiled one for the batch's tileable reads)."""
         D = np.zeros(batch.n_segments)
