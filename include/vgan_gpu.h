@@ -180,7 +180,8 @@ typedef struct vgan_hc_host_batch vgan_hc_host_batch; /* opaque owner of a host-
 typedef struct vgan_hc_flatten_stats {
     int64_t n_in, n_out;
     int64_t n_unmapped;   /* identity < 1e-10 (HaploCart.cpp:410) */
-    int64_t n_bad;        /* reads on which the reference would std::terminate (unknown node, bad substr, ...) */
+    int64_t n_bad;        /* reads on which the reference would std::terminate (unknown node, bad substr, ...), and
+                           * reads beyond the batch layout's 16-bit limits (more than 65535 columns or mappings) */
     int64_t n_clamped;    /* mapq >= 100 clamped (reference reads out of bounds) */
     int64_t n_segments;
     int64_t n_cols;
