@@ -31,6 +31,31 @@ def test_cli_validation_errors(tmp_path):
     assert r.returncode != 0 and "giraffe" in r.stderr
     r = run("version")
     assert r.returncode == 0 and "ABI" in r.stdout
+    # numeric options are whole-token parses that name the option (not an uncaught stoi / stod)
+    for flag, val, word in (("-t", "abc", "integer"), ("-t", "4x", "integer"), ("-t", "99999999999999999999", "integer"),
+                            ("-e", "xyz", "number"), ("-e", "1e999", "number"), ("-e", "nan", "number"),
+                            ("--device", "one", "integer"), ("--device", "-3", "non-negative")):
+        r = run("haplocart", flag, val, "-g", "/dev/null")
+        assert r.returncode == 1 and flag in r.stderr and word in r.stderr, (flag, val, r.stderr)
+    for flag in ("-t", "-e", "-g", "-o", "-pf", "-s", "--hc-files", "--device"):
+        r = run("haplocart", flag)
+        assert r.returncode == 1 and "needs a value" in r.stderr
+
+
+def test_cli_garbage_arguments_are_errors_not_crashes(tmp_path):
+    """Random argument vectors end with exit code 0 (help) or 1 (a message on stderr) -- never a signal."""
+    import random
+    rng = random.Random(3)
+    vocab = ["haplocart", "version", "-g", "-e", "-t", "-o", "-pf", "-s", "-np", "-q", "-d", "-w", "-z", "-i", "-j", "-f", "-fq1",
+             "--hc-files", "--device", "--per-read", "--keep-duplicates", "-h", "", "0", "-1", "1e-3", "\xff\xfe", "a" * 5000,
+             str(tmp_path), "/dev/null", "/nonexistent/x", "--", "-", "%s%n", "9" * 40]
+    for _ in range(150):
+        args = [rng.choice(vocab) for _ in range(rng.randrange(0, 7))]
+        if rng.random() < 0.7:
+            args.insert(0, "haplocart")
+        r = run(*args)
+        assert r.returncode in (0, 1), (args, r.returncode, r.stderr[-200:])
+        assert r.returncode == 0 or r.stderr.strip(), args
 
 
 def test_cli_needs_a_gpu_not_a_fallback(tmp_path):

@@ -10,6 +10,9 @@
 //     consensus arithmetic);
 //   * the likelihood loop runs on the GPU through the C-ABI (include/vgan_gpu.h); -t only sizes the host front end.
 #include <algorithm>
+#include <cerrno>
+#include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -68,6 +71,25 @@ std::string haplocart_usage() {
            "   --device [INT]   GPU index (default 0)\n";
 }
 
+// whole-token numeric parses: "12x", "" and out-of-range values are errors with the option named, not an uncaught stoi
+static int parse_int(const std::string &v, const char *flag) {
+    errno = 0;
+    char *end = nullptr;
+    const long x = std::strtol(v.c_str(), &end, 10);
+    if (v.empty() || *end != '\0' || errno == ERANGE || x < INT32_MIN || x > INT32_MAX)
+        die(std::string("[HaploCart] Error, option ") + flag + " needs an integer, got '" + v + "'");
+    return (int)x;
+}
+
+static double parse_double(const std::string &v, const char *flag) {
+    errno = 0;
+    char *end = nullptr;
+    const double x = std::strtod(v.c_str(), &end);
+    if (v.empty() || *end != '\0' || errno == ERANGE || !(x == x))
+        die(std::string("[HaploCart] Error, option ") + flag + " needs a number, got '" + v + "'");
+    return x;
+}
+
 int haplocart(int argc, char **argv) {
     bool debug = false, quiet = false, compute_posteriors = true, rmdup = true, per_read = false, webapp = false;
     std::string posteriorfilename = "/dev/stdout", outputfilename = "/dev/stdout", hcfiledir = "../share/vgan/hcfiles/";
@@ -89,7 +111,7 @@ int haplocart(int argc, char **argv) {
             hcfiledir = need("--hc-files");
             if (hcfiledir.back() != '/') hcfiledir += '/';
         } else if (a == "-e") {
-            background_error_prob = std::stod(need("-e"));
+            background_error_prob = parse_double(need("-e"), "-e");
             if (background_error_prob < 0 || background_error_prob > 1)
                 die("[HaploCart] Error, option -e is not a valid probability."); // HaploCart.cpp:107-113
         } else if (a == "-g") gamfilename = need("-g");
@@ -106,7 +128,7 @@ int haplocart(int argc, char **argv) {
             samplename = need("-s");
             invoked_samplename = true;
         } else if (a == "-t") {
-            n_threads = std::stoi(need("-t"));
+            n_threads = parse_int(need("-t"), "-t");
             if (n_threads == 0 || n_threads < -1)
                 die("[HaploCart] Error, invalid number of threads"); // HaploCart.cpp:183-194
             if (n_threads == -1) n_threads = 0;                      // all hardware threads
@@ -114,7 +136,10 @@ int haplocart(int argc, char **argv) {
         else if (a == "-z") (void)need("-z");
         else if (a == "--keep-duplicates") rmdup = false;
         else if (a == "--per-read") per_read = true;
-        else if (a == "--device") device = std::stoi(need("--device"));
+        else if (a == "--device") {
+            device = parse_int(need("--device"), "--device");
+            if (device < 0) die("[HaploCart] Error, --device needs a non-negative GPU index");
+        }
         else die("[HaploCart] Error, unrecognized option " + a);
     }
     if (webapp) die("[HaploCart] webapp mode is not part of the GPU path");
