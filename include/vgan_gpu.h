@@ -356,6 +356,70 @@ int vgan_euka_finalize(vgan_euka_ctx *c, int32_t *clade_count, uint32_t *baseshi
 int vgan_euka_kernel_ms(vgan_euka_ctx *c, double *ms, uint64_t *launches); /* HIP-event time of the read kernel */
 void vgan_euka_destroy(vgan_euka_ctx *c);
 
+/* sum over the reads of clade c of log(clade_like[k]) and their number, for everything accumulated (valid after
+ * vgan_euka_finalize): all that MCMC::get_proposal_likelihood (MCMC.cpp:1175-1215) reads of clade_like / clade_not_like,
+ * because its `(1/334)` is the integer 0 and log(frac * like) = log(frac) + log(like).  A read with like == 0 (mapq 0, or
+ * exp underflow) makes the clade's sum -inf, as it does the reference's. */
+int vgan_euka_like_sums(vgan_euka_ctx *c, int64_t *n_like, double *sum_log_like);
+
+/* ------------------------------------------------------------------------------------------------
+ * euka downstream of the per-read pass (host only): the detected-clade list at the end of readGAM3
+ * (readGAM_Euka.h:582-630), Euka::compute_init_vec (compute_init_vec.cpp:9-84), the abundance MCMC
+ * (MCMC::generate_proposal / get_proposal_likelihood / run, MCMC.cpp:1095-1366) and the output files of
+ * Euka::run (Euka.cpp:540-1160).
+ *
+ * Randomness: the reference seeds a fresh std::mt19937 from std::random_device for every proposal and once for the
+ * acceptance draws, so its output is not reproducible.  seed = 0 does the same; any other seed replaces the successive
+ * random_device calls by the high 32 bits of a splitmix64 stream started at seed (run() first, then one per proposal).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_euka_detect_params {
+    uint32_t min_bins;        /* MINNUMOFBINS  --minBins (6), Euka.cpp:183 */
+    uint32_t min_reads;       /* MINNUMOFREADS --minFrag (10) */
+    int32_t max_zero_bins;    /* MAXIMUMOFBINS --maxBins (0) */
+    double entropy_threshold; /* ENTROPY_SCORE_THRESHOLD --entropy (1.17) */
+} vgan_euka_detect_params;
+/* ids[] (capacity n_clades) receives Clade::id of every detected clade in *.clade order.  A bin counts as empty when its
+ * coverage truncates to 0 (the reference collects the coverages in a vector<int>); the last bin of a clade is ignored. */
+int vgan_euka_detect(const vgan_euka_db_view *db, const int32_t *clade_count, const double *bin_cov,
+                     const vgan_euka_detect_params *p, int32_t *ids, int32_t *n_ids);
+/* est[5*n] = per clade {median of the recorded proposals, 15 %, 85 %, 5 %, 95 % quantile} (MCMC.cpp:1318-1360).
+ * init[n] = starting abundances, n_like / sum_log_like[n] = vgan_euka_like_sums rows of the n detected clades.
+ * iter must exceed burnin + 1 (the reference indexes an empty sample otherwise). */
+int vgan_euka_abundance_mcmc(int32_t n, const double *init, const int64_t *n_like, const double *sum_log_like, int32_t iter,
+                             int32_t burnin, uint64_t seed, double *est);
+
+typedef struct vgan_euka_report_cfg {
+    vgan_euka_detect_params detect;
+    int32_t length_to_prof;  /* -l, the baseshift array's lengthToProf */
+    int32_t run_mcmc;        /* 0 = --no-mcmc (also skipped with fewer than two detected clades, Euka.cpp:586) */
+    int32_t iter, burnin;    /* --iter (10000), --burnin (100) */
+    uint64_t seed;
+    int32_t out_frag;        /* --outFrag: <prefix>_FragNames.tsv */
+    uint32_t reserved;
+    const char *out_group;   /* --outGroup, NULL or "" = none */
+    const char *out_dir;     /* --out_dir: created when missing (Euka.cpp:738-747), NULL = none */
+} vgan_euka_report_cfg;
+
+typedef struct vgan_euka_results { /* what readGAM3 leaves behind (Euka.cpp:534-537) */
+    const vgan_euka_db_view *db;
+    const int32_t *clade_count;   /* vgan_euka_finalize */
+    const uint32_t *baseshift;
+    const double *bin_cov;
+    const int64_t *n_like;        /* vgan_euka_like_sums */
+    const double *sum_log_like;
+    int64_t n_reads;              /* per processed read, in input order: feeds Clade::inSize / nameStorage */
+    const int32_t *read_clade;    /* vgan_euka_read_out.clade */
+    const uint8_t *read_pass;
+    const uint16_t *read_seq_len; /* vgan_euka_batch.read_seq_len */
+    const int64_t *name_off;      /* [n_reads+1] into names; NULL unless out_frag */
+    const char *names;
+} vgan_euka_results;
+/* Writes <prefix>_{abundance,detected,coverage,inSize}.tsv, <prefix>_<clade>.prof per detected clade (and the out
+ * group), <prefix>_{5p,3p}.prof and, with out_frag, <prefix>_FragNames.tsv, byte for byte as Euka::run formats them.
+ * detected[] (capacity n_clades + 1) / estimates[5 per detected clade] may be NULL. */
+int vgan_euka_report(const vgan_euka_results *r, const vgan_euka_report_cfg *cfg, const char *prefix, int32_t *detected,
+                     int32_t *n_detected, double *estimates);
+
 /* ------------------------------------------------------------------------------------------------
  * soibean: per-read x per-path likelihood (analyse_GAM, getLCAfromGAM.h:31-732; replaces the call at
  * soibean.cpp:558) and the per-MCMC-iteration likelihood refresh (MCMC.cpp:738-993 inside

@@ -156,6 +156,25 @@ int64_t orc_load_clade_chunks(const char *txt, int32_t *bin_off, int32_t *lo, in
 int64_t orc_load_clade_info(const char *txt, int32_t *id, double *dist, int32_t *npaths, int32_t *snode, int32_t *enode,
                             char *names, int64_t names_cap, int64_t cap);
 
+/* what `vgan euka` does with that result (oracle/euka_abundance_oracle.cpp): detected clades (readGAM_Euka.h:582-630),
+ * compute_init_vec, the abundance MCMC (MCMC.cpp:1095-1366) and every output file (Euka.cpp:540-1160) written to
+ * <prefix>_*.  seed = 0 draws from std::random_device as the reference does; otherwise successive rd() calls are replaced
+ * by the high halves of a splitmix64 stream started at seed.  detected[] / estimates[5 per detected clade] may be NULL. */
+typedef struct orc_euka_report_cfg {
+    uint32_t MINNUMOFBINS, MINNUMOFREADS; /* --minBins 6, --minFrag 10 (Euka.cpp:183-184) */
+    int32_t MAXIMUMOFBINS;                /* --maxBins 0 */
+    double ENTROPY_SCORE_THRESHOLD;       /* --entropy 1.17 */
+    int32_t lengthToProf;
+    int32_t run_mcmc, iter, burnin;       /* --no-mcmc, --iter 10000, --burnin 100 */
+    uint64_t seed;
+    int32_t outFrag;
+    const char *outGroup, *out_dir;       /* NULL or "" = not given */
+} orc_euka_report_cfg;
+int orc_euka_report(const orc_euka_db *db, const int32_t *clade_id, const char *clade_names, const orc_euka_out *res,
+                    int64_t n_reads, const int32_t *read_seq_len, const char *names, const int64_t *name_off,
+                    const orc_euka_report_cfg *cfg, const char *prefix, int32_t *detected, int32_t *n_detected,
+                    double *estimates);
+
 /* ------------------------------------------------------------------ soibean (oracle/sb_oracle.cpp) */
 /* analyse_GAM (src/getLCAfromGAM.h:31-732): g->pathsgo[node][p] = path p goes through the node (nodepaths);
  * path_findable[p] = 0 for path names longer than 101 characters (never matched, :80-88).  Returns a handle holding

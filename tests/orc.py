@@ -314,6 +314,40 @@ def euka_run(g, a, db, dmg, min_mapq=29, length_to_prof=5):
     return o
 
 
+class OrcEukaReportCfg(C.Structure):
+    _fields_ = [("MINNUMOFBINS", C.c_uint32), ("MINNUMOFREADS", C.c_uint32), ("MAXIMUMOFBINS", C.c_int32),
+                ("ENTROPY_SCORE_THRESHOLD", C.c_double), ("lengthToProf", C.c_int32), ("run_mcmc", C.c_int32),
+                ("iter", C.c_int32), ("burnin", C.c_int32), ("seed", C.c_uint64), ("outFrag", C.c_int32),
+                ("outGroup", C.c_char_p), ("out_dir", C.c_char_p)]
+
+
+def euka_report(db, clade_id, clade_names, o, read_seq_len, prefix, names=None, min_bins=6, min_reads=10, max_zero_bins=0,
+                entropy=1.17, length_to_prof=5, run_mcmc=True, iters=10000, burnin=100, seed=1, out_frag=False,
+                out_group=None, out_dir=None):
+    """Euka::run after readGAM3 (oracle/euka_abundance_oracle.cpp) on an euka_run() result `o`; writes <prefix>_* files and
+    returns (detected clade ids, estimates[n, 5])."""
+    R = len(o["clade"])
+    oc = OrcEukaOut(_p(o["clade"]), _p(o["in_lik"]), _p(o["out_lik"]), _p(o["like"]), _p(o["not_like"]), _p(o["pass"]),
+                    _p(o["clade_count"]), _p(np.ascontiguousarray(o["baseshift"])), _p(np.ascontiguousarray(o["bin_cov"])), 0)
+    cid = np.ascontiguousarray(clade_id, np.int32)
+    sl = np.ascontiguousarray(read_seq_len, np.int32)
+    blob, off = None, None
+    if names is not None:
+        off = np.zeros(R + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in names])
+        blob = b"".join(names)
+    cfg = OrcEukaReportCfg(min_bins, min_reads, max_zero_bins, entropy, length_to_prof, int(run_mcmc), iters, burnin, seed,
+                           int(out_frag), out_group.encode() if out_group else None, out_dir.encode() if out_dir else None)
+    det = np.zeros(db.n_clades + 1, np.int32)
+    est = np.zeros((db.n_clades + 1, 5))
+    nd = C.c_int32(0)
+    rc = lib().orc_euka_report(C.byref(db.c), _p(cid), "\n".join(clade_names).encode(), C.byref(oc), C.c_int64(R), _p(sl), blob,
+                               _p(off) if off is not None else None, C.byref(cfg), prefix.encode(), _p(det), C.byref(nd), _p(est))
+    if rc != 0:
+        raise ValueError("orc_euka_report failed")
+    return det[:nd.value].copy(), est[:nd.value].copy()
+
+
 # ---------------------------------------------------------------- soibean
 class SbOracle:
     """analyse_GAM result (pathMap / detailMap per read) held by the oracle."""

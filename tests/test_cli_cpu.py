@@ -46,7 +46,7 @@ def test_cli_garbage_arguments_are_errors_not_crashes(tmp_path):
     """Random argument vectors end with exit code 0 (help) or 1 (a message on stderr) -- never a signal."""
     import random
     rng = random.Random(3)
-    vocab = ["haplocart", "version", "-g", "-e", "-t", "-o", "-pf", "-s", "-np", "-q", "-d", "-w", "-z", "-i", "-j", "-f", "-fq1",
+    vocab = ["haplocart", "version", "euka", "--iter", "--entropy", "--euka_dir", "--outGroup", "--minBins", "--no-mcmc", "-l", "-g", "-e", "-t", "-o", "-pf", "-s", "-np", "-q", "-d", "-w", "-z", "-i", "-j", "-f", "-fq1",
              "--hc-files", "--device", "--per-read", "--keep-duplicates", "-h", "", "0", "-1", "1e-3", "\xff\xfe", "a" * 5000,
              str(tmp_path), "/dev/null", "/nonexistent/x", "--", "-", "%s%n", "9" * 40]
     for _ in range(150):
@@ -56,6 +56,39 @@ def test_cli_garbage_arguments_are_errors_not_crashes(tmp_path):
         r = run(*args)
         assert r.returncode in (0, 1), (args, r.returncode, r.stderr[-200:])
         assert r.returncode == 0 or r.stderr.strip(), args
+
+
+def test_euka_cli_validation_errors(tmp_path):
+    """`vgan euka` flag checks (reference src/Euka.cpp:195-340,373-395)."""
+    for args, msg in ((("--entropy", "6"), "entropy thresold is too stringent"), (("--minBins", "21"), "minimum number of bins exceeds"),
+                      (("--maxBins", "21"), "maximum number of bins exceeds"), (("-t", "0"), "invalid number of threads"),
+                      (("-t", "-2"), "invalid number of threads"), (("-fq1", "x.fa"), "must be FASTQ, not FASTA"),
+                      (("-fq1", "x.fq", "-fq2", "y.fasta.gz"), "must be FASTQ, not FASTA"),
+                      (("-fq1", "x.fq", "-fq2", "y.fq", "-i"), "expects only one FASTQ file"), (("-fq1", "x.fq"), "giraffe"),
+                      (("--minMQ", "61"), "0..60"), (("--iter", "-5"), "must not be negative"), (("--iter", "abc"), "needs an integer"),
+                      (("--entropy", "x"), "needs a number"), (("--bogus",), "unrecognized option"), (("--iter",), "needs a value"),
+                      (("--euka_dir", str(tmp_path)), "euka_db.gfa does not exist.")):
+        r = run("euka", *args)
+        assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
+    assert run("euka", "-h").returncode == 0
+    from vgan_amd import euka as ek
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    g, db, a = ek.synth_euka(300, None, seed=2, n_clades=5, nodes_per_clade=120)
+    util.write_euka_db(db, g, tmp_path)
+    r = run("euka", "--euka_dir", str(tmp_path))
+    assert r.returncode == 1 and "no input file given" in r.stderr
+    r = run("euka", "--euka_dir", str(tmp_path), "-g", str(tmp_path / "none.gam"))
+    assert r.returncode == 1 and "does not exist" in r.stderr
+    a.write_gam(str(tmp_path / "r.gam"))
+    r = run("euka", "--euka_dir", str(tmp_path), "-g", str(tmp_path / "r.gam"), "--outGroup", "nope")
+    assert r.returncode == 1 and "Outgroup not found in reference graph" in r.stderr
+    r = run("euka", "--euka_dir", str(tmp_path), "-g", str(tmp_path / "r.gam"), "--iter", "10", "--burnin", "10")
+    assert r.returncode == 1 and "--iter must exceed --burnin" in r.stderr
+    if N.lib().vgan_device_count() <= 0:  # no CPU fallback for the per-read pass
+        r = run("euka", "--euka_dir", str(tmp_path), "-g", str(tmp_path / "r.gam"), "-o", str(tmp_path / "out"))
+        assert r.returncode == 1 and "no HIP device" in r.stderr and not list(tmp_path.glob("out_*"))
 
 
 def test_cli_needs_a_gpu_not_a_fallback(tmp_path):

@@ -222,3 +222,91 @@ def test_long_damage_profiles_take_the_global_table_path():
     g, db, a = ek.synth_euka(2500, dm, seed=31, n_clades=7, nodes_per_clade=180)
     got, fin, ref = compare(g, db, a, texts)
     assert got["pass"].sum() > 500
+
+
+def test_like_sums_feed_the_abundance_chain():
+    """vgan_euka_like_sums: per clade the number of clade_like entries and the sum of their logs (what
+    MCMC::get_proposal_likelihood reads, MCMC.cpp:1175-1215), accumulated by the read kernel."""
+    d = os.path.join(GOLD, "damageProfiles")
+    texts = (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    dm = ek.Damage.from_text(*texts)
+    g, db, a = ek.synth_euka(6000, dm, seed=8, n_clades=9, nodes_per_clade=150)
+    hb = ek.EukaHostBatch(g, a)
+    ctx = ek.EukaContext(db, dm)
+    got = ctx.accumulate(hb)
+    ctx.finalize()
+    n, s = ctx.like_sums()
+    ok = got["clade"] >= 0
+    assert np.array_equal(n, np.bincount(got["clade"][ok], minlength=db.n_clades))
+    with np.errstate(divide="ignore"):
+        want = np.bincount(got["clade"][ok], weights=np.log(got["like"][ok]), minlength=db.n_clades)
+    assert np.all(np.isfinite(want)) and util.rel_err(s, want) < 1e-12
+    # a second batch adds on; a read with mapq 0 (like == 0) makes its clade's sum -inf, as the reference's log(0)
+    arr = a.arrays()
+    arr = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in arr.items()}
+    arr["mapq"][:] = 0
+    oa = orc.AlnSet.from_arrays(**arr)
+    import ctypes as C
+    from vgan_amd import _native as N
+    v = N.AlnSetView(oa.n_reads, *[getattr(oa, k).ctypes.data for k in ("seq_off", "seq", "qual_off", "qual", "mapq", "identity")],
+                     None, None, *[getattr(oa, k).ctypes.data for k in ("map_off", "m_node", "m_offset", "m_rev", "edit_off",
+                                                                        "e_from", "e_to", "e_seq_off", "e_seq")])
+    h = N.vp()
+    N.check(N.lib().vgan_aln_from_arrays(v, h))
+    a0 = hc.AlnSet(h)
+    got0 = ctx.accumulate(ek.EukaHostBatch(g, a0, 0, 50))
+    ctx.finalize()
+    n2, s2 = ctx.like_sums()
+    hit = np.unique(got0["clade"][got0["clade"] >= 0])
+    assert np.all(got0["like"][got0["clade"] >= 0] == 0) and np.all(np.isneginf(s2[hit]))
+    assert np.array_equal(n2 - n, np.bincount(got0["clade"][got0["clade"] >= 0], minlength=db.n_clades))
+    rest = np.setdiff1d(np.arange(db.n_clades), hit)
+    assert util.rel_err(s2[rest], want[rest]) < 1e-12
+    ctx.reset()
+    ctx.finalize()
+    n3, s3 = ctx.like_sums()
+    assert not n3.any() and not s3.any()
+
+
+def _tree(prefix):
+    import glob
+    return {os.path.basename(p)[len(os.path.basename(prefix)):]: open(p, "rb").read() for p in sorted(glob.glob(prefix + "_*"))}
+
+
+@pytest.mark.parametrize("mcmc", [True, False])
+def test_vgan_euka_cli_end_to_end_matches_the_oracle(tmp_path, mcmc):
+    """`vgan euka -g` (GPU per-read pass + host abundance chain) writes the files the oracle's restatement of Euka::run
+    writes for the same GAM, tables and seed -- byte for byte."""
+    import subprocess
+    d = os.path.join(GOLD, "damageProfiles")
+    p5, p3 = d + "/dhigh5p.prof", d + "/dhigh3p.prof"
+    texts = (open(p5).read(), open(p3).read())
+    dm = ek.Damage.from_text(*texts)
+    g, db, a = ek.synth_euka(20000, dm, seed=21, n_clades=14, nodes_per_clade=180)
+    util.write_euka_db(db, g, tmp_path)
+    gam = str(tmp_path / "reads.gam")
+    a.write_gam(gam)
+    og_name = db.clade_names[3]
+    args = ["--entropy", "0", "--minBins", "2", "--minFrag", "40", "--outFrag", "--outGroup", og_name, "-l", "4", "--seed", "77",
+            "--iter", "800", "--burnin", "60", "--minMQ", "20"] + ([] if mcmc else ["--no-mcmc"])
+    exe = os.path.join(os.path.dirname(GOLD), "..", "vgan_amd", "bin", "vgan")
+    r = subprocess.run([exe, "euka", "-g", gam, "--euka_dir", str(tmp_path), "--deam5p", p5, "--deam3p", p3, "-o", str(tmp_path / "prod"),
+                        "-t", "-1"] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Number of fragments in input file: 20000" in r.stderr
+    # the same through the oracle, reading the same files back
+    db2 = ek.EukaDb.load(str(tmp_path / "euka_db.clade"), str(tmp_path / "euka_db.bins"))
+    a2 = hc.AlnSet.read_gam(gam, keep_unmapped=True)
+    og, oa = util.orc_graph_nodes_only(g), util.orc_alnset_from_product(a2)
+    odb = util.orc_euka_db_from_product(db2)
+    ref = orc.euka_run(og, oa, odb, orc.OrcDamage(*texts), 20, 4)
+    arr = a2.arrays()
+    names = [bytes(arr["name"][arr["name_off"][i]:arr["name_off"][i + 1]]) for i in range(a2.n_reads)]
+    orc.euka_report(odb, db2.clade_id, db2.clade_names, ref, np.diff(arr["seq_off"]), str(tmp_path / "orc"), names=names, min_bins=2,
+                    min_reads=40, entropy=0.0, length_to_prof=4, run_mcmc=mcmc, iters=800, burnin=60, seed=77, out_frag=True,
+                    out_group=og_name)
+    fo, fp = _tree(str(tmp_path / "orc")), _tree(str(tmp_path / "prod"))
+    assert sorted(fo) == sorted(fp) and len(fo) >= 8
+    for k in fo:
+        assert fo[k] == fp[k], (k, fo[k][:400], fp[k][:400])
+    assert b"yes" in fp["_abundance.tsv"] and ("_%s.prof" % og_name) in fp

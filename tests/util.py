@@ -54,3 +54,30 @@ def concat_alnsets(tmp_path, *sets):
     out = str(tmp_path / "all.gam")
     open(out, "wb").write(blob)
     return hc.AlnSet.read_gam(out)
+
+
+def write_euka_db(db, g, directory, prefix="euka_db"):
+    """<prefix>.clade / .bins in the reference's formats (src/load.cpp:71-157) and the graph as <prefix>.gfa."""
+    import os
+    import shutil
+    import tempfile
+    base = os.path.join(str(directory), prefix)
+    v = db.view
+    names = db.clade_names
+    from vgan_amd.haplocart import _np_view
+    npaths, sn, en = (_np_view(p, db.n_clades, np.int32) if p else np.zeros(db.n_clades, np.int32)
+                      for p in (v.clade_npaths, v.clade_snode, v.clade_enode))
+    with open(base + ".clade", "w") as f:
+        for c in range(db.n_clades):
+            f.write("%d\t%s\t%.17g\t%d\t%d\t%d\n" % (db.clade_id[c], names[c], db.clade_dist[c], npaths[c], sn[c], en[c]))
+    with open(base + ".bins", "w") as f:
+        for c in range(db.n_clades):
+            cols = [names[c]]
+            for j in range(int(db.bin_off[c]), int(db.bin_off[c + 1])):
+                cols += ["%d.0" % db.bin_lo[j], "%d.0" % db.bin_hi[j], "%.17g" % db.bin_entropy[j]]
+            f.write("\t".join(cols) + "\n")
+    tmp = tempfile.mkdtemp(dir=str(directory))
+    g.write(tmp)
+    shutil.move(os.path.join(tmp, "graph.gfa"), base + ".gfa")
+    shutil.rmtree(tmp)
+    return base

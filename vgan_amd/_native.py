@@ -74,6 +74,22 @@ class EukaParams(C.Structure):
     _fields_ = [("min_mapq", C.c_uint32), ("length_to_prof", C.c_int32)]
 
 
+class EukaDetectParams(C.Structure):
+    _fields_ = [("min_bins", C.c_uint32), ("min_reads", C.c_uint32), ("max_zero_bins", C.c_int32), ("entropy_threshold", C.c_double)]
+
+
+class EukaReportCfg(C.Structure):
+    _fields_ = [("detect", EukaDetectParams), ("length_to_prof", C.c_int32), ("run_mcmc", C.c_int32), ("iter", C.c_int32),
+                ("burnin", C.c_int32), ("seed", C.c_uint64), ("out_frag", C.c_int32), ("reserved", C.c_uint32),
+                ("out_group", C.c_char_p), ("out_dir", C.c_char_p)]
+
+
+class EukaResults(C.Structure):
+    _fields_ = [("db", vp), ("clade_count", vp), ("baseshift", vp), ("bin_cov", vp), ("n_like", vp), ("sum_log_like", vp),
+                ("n_reads", C.c_int64), ("read_clade", vp), ("read_pass", vp), ("read_seq_len", vp), ("name_off", vp),
+                ("names", vp)]
+
+
 class EukaReadOut(C.Structure):
     _fields_ = [("clade", vp), ("in_lik", vp), ("out_lik", vp), ("like", vp), ("not_like", vp), ("pass_", vp)]
 
@@ -183,6 +199,10 @@ SYMBOLS = {
     "vgan_euka_accumulate": (C.c_int, [vp, C.POINTER(EukaBatch), C.POINTER(EukaReadOut)]),
     "vgan_euka_finalize": (C.c_int, [vp, vp, vp, vp, vp]),
     "vgan_euka_kernel_ms": (C.c_int, [vp, vp, vp]),
+    "vgan_euka_like_sums": (C.c_int, [vp, vp, vp]),
+    "vgan_euka_detect": (C.c_int, [C.POINTER(EukaDbView), vp, vp, C.POINTER(EukaDetectParams), vp, vp]),
+    "vgan_euka_abundance_mcmc": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_uint64, vp]),
+    "vgan_euka_report": (C.c_int, [C.POINTER(EukaResults), C.POINTER(EukaReportCfg), C.c_char_p, vp, vp, vp]),
     "vgan_euka_destroy": (None, [vp]),
     "vgan_sb_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(SbFlattenStats)]),
     "vgan_sb_host_batch_get": (C.c_int, [vp, C.POINTER(SbBatch)]),

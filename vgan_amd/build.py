@@ -71,12 +71,13 @@ def build(verbose=False, force=False):
         subprocess.check_call(cmd)
     # the vgan CLI (C++ host driver keeping the reference's subcommand surface)
     main_src = os.path.join(CSRC, "host", "vgan_main.cpp")
+    main_srcs = sorted(os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host")) if f.endswith("_main.cpp"))
     if os.path.exists(main_src):
         bindir = os.path.join(HERE, "bin")
         os.makedirs(bindir, exist_ok=True)
         exe = os.path.join(bindir, "vgan")
-        if force or _stale(exe, [main_src, LIB] + hdrs):
-            cmd = [HIPCC] + COMMON + ["-x", "c++", main_src, "-x", "none", "-o", exe, "-L" + LIBDIR, "-lvgan_gpu",
+        if force or _stale(exe, main_srcs + [LIB] + hdrs):
+            cmd = [HIPCC] + COMMON + ["-x", "c++"] + main_srcs + ["-x", "none", "-o", exe, "-L" + LIBDIR, "-lvgan_gpu",
                                       "-Wl,-rpath,$ORIGIN/../lib"]
             if verbose:
                 print(" ".join(cmd), flush=True)

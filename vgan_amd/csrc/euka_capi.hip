@@ -59,6 +59,8 @@ struct vgan_euka_ctx {
     Buf<int32_t> clade_count;
     Buf<uint32_t> baseshift;
     Buf<double> bin_cov;
+    Buf<uint32_t> like_n;
+    Buf<double> like_logsum;
     Buf<unsigned long long> n_bad;
     // staging (host batches) and per-read outputs
     Buf<uint32_t> s32;
@@ -148,6 +150,7 @@ extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_v
         (rc = c->sub3p.upload(std::vector<double>(dmg->sub3p, dmg->sub3p + (size_t)dmg->n3 * 16))) ||
         (rc = c->tables.upload(tb)) || (rc = c->dmg_pair.upload(pair)) ||
         (!node_clade.empty() && (rc = c->node_clade.upload(node_clade))) || (rc = c->clade_count.reserve((size_t)EUKA_REPLICAS * c->n_clades)) ||
+        (rc = c->like_n.reserve((size_t)EUKA_REPLICAS * c->n_clades)) || (rc = c->like_logsum.reserve((size_t)EUKA_REPLICAS * c->n_clades)) ||
         (rc = c->baseshift.reserve((size_t)EUKA_REPLICAS * c->n_clades * 2 * std::max(1, c->ltp) * 16)) ||
         (rc = c->bin_cov.reserve((size_t)EUKA_REPLICAS * std::max<uint32_t>(1, c->n_bins))) || (rc = c->n_bad.reserve(1)))
         return bail(rc);
@@ -194,6 +197,8 @@ extern "C" void vgan_euka_destroy(vgan_euka_ctx *c) {
     c->clade_count.release();
     c->baseshift.release();
     c->bin_cov.release();
+    c->like_n.release();
+    c->like_logsum.release();
     c->n_bad.release();
     c->s32.release();
     c->s16.release();
@@ -220,6 +225,8 @@ extern "C" int vgan_euka_reset(vgan_euka_ctx *c) {
     HIPCHK(hipMemsetAsync(c->clade_count.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->baseshift.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 2 * std::max(1, c->ltp) * 16 * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->bin_cov.p, 0, (size_t)EUKA_REPLICAS * std::max<uint32_t>(1, c->n_bins) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->like_n.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->like_logsum.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->n_bad.p, 0, 8, c->stream));
     return VGAN_OK;
 }
@@ -321,6 +328,8 @@ extern "C" int vgan_euka_accumulate(vgan_euka_ctx *c, const vgan_euka_batch *b, 
     o.clade_count = c->clade_count.p;
     o.baseshift = c->baseshift.p;
     o.bin_cov = c->bin_cov.p;
+    o.like_n = c->like_n.p;
+    o.like_logsum = c->like_logsum.p;
     o.n_bins = c->n_bins;
     o.n_bad = c->n_bad.p;
     HIPCHK(hipEventRecord(c->ev0, c->stream));
@@ -348,6 +357,8 @@ extern "C" int vgan_euka_finalize(vgan_euka_ctx *c, int32_t *clade_count, uint32
         o.clade_count = c->clade_count.p;
         o.baseshift = c->baseshift.p;
         o.bin_cov = c->bin_cov.p;
+        o.like_n = c->like_n.p;
+        o.like_logsum = c->like_logsum.p;
         o.n_bins = c->n_bins;
         launch_euka_reduce(o, c->n_clades, c->ltp, c->stream); // fold the replicas into replica 0
         HIPCHK(hipGetLastError());
@@ -360,6 +371,20 @@ extern "C" int vgan_euka_finalize(vgan_euka_ctx *c, int32_t *clade_count, uint32
     HIPCHK(hipMemcpyAsync(&nb, c->n_bad.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n_bad) *n_bad = (int64_t)nb;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_euka_like_sums(vgan_euka_ctx *c, int64_t *n_like, double *sum_log_like) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_euka_like_sums: null context");
+    HIPCHK(hipSetDevice(c->device));
+    // valid after vgan_euka_finalize folded the replicas (replica 0 holds the totals, the others are zero)
+    std::vector<uint32_t> n(c->n_clades);
+    HIPCHK(hipMemcpyAsync(n.data(), c->like_n.p, (size_t)c->n_clades * 4, hipMemcpyDeviceToHost, c->stream));
+    if (sum_log_like)
+        HIPCHK(hipMemcpyAsync(sum_log_like, c->like_logsum.p, (size_t)c->n_clades * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_like)
+        for (uint32_t i = 0; i < c->n_clades; ++i) n_like[i] = n[i];
     return VGAN_OK;
 }
 

@@ -58,6 +58,8 @@ struct EukaOutDev {
     int32_t *clade_count; // [EUKA_REPLICAS][n_clades]
     uint32_t *baseshift;  // [EUKA_REPLICAS][n_clades][2*ltp][16]
     double *bin_cov;      // [EUKA_REPLICAS][n_bins]
+    uint32_t *like_n;     // [EUKA_REPLICAS][n_clades] entries pushed to Clade::clade_like (readGAM_Euka.h:491)
+    double *like_logsum;  // [EUKA_REPLICAS][n_clades] sum of log(clade_like[k]): what MCMC::get_proposal_likelihood needs
     uint32_t n_bins;
     unsigned long long *n_bad;
 };

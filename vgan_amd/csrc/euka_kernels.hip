@@ -89,6 +89,8 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     // this workgroup's replica of the per-clade accumulators
     const uint32_t rep = blockIdx.x % EUKA_REPLICAS;
     int32_t *const clade_count = o.clade_count + (size_t)rep * d.n_clades;
+    uint32_t *const like_n = o.like_n + (size_t)rep * d.n_clades;
+    double *const like_logsum = o.like_logsum + (size_t)rep * d.n_clades;
     uint32_t *const baseshift = o.baseshift + (size_t)rep * d.n_clades * 2 * (d.ltp > 0 ? d.ltp : 1) * 16;
     double *const bin_cov = o.bin_cov + (size_t)rep * o.n_bins;
 
@@ -235,6 +237,10 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             o.not_like[r] = 1.0 - like;
             o.pass[r] = pass ? 1 : 0;
             if (pass) atomicAdd(&clade_count[c_n], 1);
+            // the abundance MCMC only ever uses sum_k log(frac * clade_like[k]) per clade (MCMC.cpp:1175-1215, (1/334) == 0):
+            // keep the count and the sum of logs; a read with like == 0 (mapq 0, or exp underflow) makes the sum -inf as there
+            atomicAdd(&like_n[c_n], 1u);
+            unsafeAtomicAdd(&like_logsum[c_n], log(like));
         }
         // bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546).  Lane j of a
         // row owns the clade's bin jb + j and counts the read's mappings that fall into it (16 nodes per step, handed
@@ -273,6 +279,16 @@ __global__ void euka_reduce_kernel(EukaOutDev o, uint32_t n_count, uint32_t n_sh
             o.clade_count[(size_t)r * n_count + i] = 0;
         }
         o.clade_count[i] = s;
+        uint32_t n = o.like_n[i];
+        double ls = o.like_logsum[i];
+        for (uint32_t r = 1; r < EUKA_REPLICAS; ++r) {
+            n += o.like_n[(size_t)r * n_count + i];
+            ls += o.like_logsum[(size_t)r * n_count + i];
+            o.like_n[(size_t)r * n_count + i] = 0;
+            o.like_logsum[(size_t)r * n_count + i] = 0.0;
+        }
+        o.like_n[i] = n;
+        o.like_logsum[i] = ls;
     }
     if (i < n_shift) {
         uint32_t s = o.baseshift[i];

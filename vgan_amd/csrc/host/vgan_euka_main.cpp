@@ -1,0 +1,307 @@
+// vgan euka -- the reference's subcommand surface (src/Euka.cpp:144-1185) over the GPU per-read pass.
+//
+//   vgan euka -g reads.gam --euka_dir DIR [--dbprefix euka_db] [--deam5p F --deam3p F] [--no-mcmc] [--iter N] [--burnin N]
+//             [--entropy X] [--minBins N] [--maxBins N] [--minMQ N] [--minFrag N] [--outFrag] [--outGroup NAME] [-l N]
+//             [-o PREFIX] [--out_dir DIR] [-t N] [--seed N] [--device N]
+//
+// Same flags, defaults, validation and output files as Euka::run.  What differs, and why:
+//   * the graph is read from <dbprefix>.gfa: the ODGI .og / .gbwt pair needs libbdsg and libgbwt;
+//   * FASTQ input needs vg giraffe in-process (src/map_giraffe.cpp): map with vg and pass the GAM with -g;
+//   * readGAM3's per-alignment lambda runs on the GPU (vgan_euka_*), the abundance MCMC in closed form on the host
+//     (vgan_euka_report); --seed N makes the chain reproducible (default 0 = std::random_device, as the reference).
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <thread>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "cli_util.h"
+
+using namespace vgan_cli;
+
+namespace {
+
+std::string euka_usage() {
+    return "\n vgan euka [options]\n\n"
+           " Abundance estimation of eukaryotic taxa from an environmental DNA sample, per-read pass on the GPU (MI355X).\n\n"
+           " Input:\n"
+           "   --euka_dir [STR]  euka database location (default: ../share/vgan/euka_dir/)\n"
+           "   --dbprefix [STR]  database prefix (default: euka_db): <prefix>.gfa, <prefix>.clade, <prefix>.bins\n"
+           "   -g [STR]          GAM input (FASTQ input needs vg giraffe: map first)\n"
+           "   -o [STR]          output file prefix (default: euka_output)\n"
+           "   -t [INT]          host threads (-1 for all available)\n"
+           " Filter options:\n"
+           "   --minMQ [INT]     mapping quality minimum for a fragment (default: 29)\n"
+           "   --minFrag [INT]   minimum number of fragments per taxon (default: 10)\n"
+           "   --entropy [FLOAT] minimum entropy score of a bin (default: 1.17)\n"
+           "   --minBins [INT]   minimum number of bins above the entropy threshold (default: 6)\n"
+           "   --maxBins [INT]   maximum number of empty bins (default: 0)\n"
+           " Damage options:\n"
+           "   --deam5p [STR]    5' substitution profile (default: none)\n"
+           "   --deam3p [STR]    3' substitution profile (default: none)\n"
+           "   -l [INT]          length of the damage profiles written per taxon (default: 5)\n"
+           "   --out_dir [STR]   directory created for the profiles when missing\n"
+           " MCMC options:\n"
+           "   --no-mcmc         report the initial abundance estimates only\n"
+           "   --iter [INT]      iterations (default: 10000)\n"
+           "   --burnin [INT]    burn-in (default: 100)\n"
+           "   --seed [INT]      reproducible chain (default 0: std::random_device)\n"
+           " Output options:\n"
+           "   --outFrag         write the names of the fragments of every detected taxon\n"
+           "   --outGroup [STR]  always write coverage, fragment lengths and profile of this taxon\n"
+           "   --device [INT]    GPU index (default 0)\n";
+}
+
+bool is_file(const std::string &p) {
+    struct stat sb;
+    return stat(p.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+}
+
+bool ends_with(const std::string &s, const char *suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+void reject_fasta(const std::string &f) { // Euka.cpp:213-214,221-222
+    for (const char *suf : {".fa", ".fasta", ".fa.gz", ".fasta.gz"})
+        if (ends_with(f, suf)) die("[euka] Input file must be FASTQ, not FASTA");
+}
+
+template <class T> struct Handle { // frees a C-ABI object on every exit path
+    T *p = nullptr;
+    void (*release)(T *);
+    explicit Handle(void (*r)(T *)) : release(r) {}
+    ~Handle() {
+        if (p) release(p);
+    }
+    Handle(const Handle &) = delete;
+    Handle &operator=(const Handle &) = delete;
+};
+
+} // namespace
+
+int euka_main(int argc, char **argv) {
+    const char *T = "[euka]";
+    std::string euka_dir = "../share/vgan/euka_dir/", dbprefix = "euka_db", gam, fq1, fq2, out_prefix = "euka_output";
+    std::string deam5, deam3, out_group, out_dir;
+    bool interleaved = false, run_mcmc = true, out_frag = false;
+    int n_threads = 1, iter = 10000, burnin = 100, ltp = 5, device = 0; // Euka.cpp:171-190
+    int min_bins = 6, min_reads = 10, min_mq = 29, max_bins = 0;
+    double entropy = 1.17;
+    uint64_t seed = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](const char *flag) -> std::string {
+            if (i + 1 >= argc) die(std::string("[euka] Error, option ") + flag + " needs a value");
+            return argv[++i];
+        };
+        auto non_negative = [&](const char *flag) {
+            const int v = parse_int(need(flag), flag, T);
+            if (v < 0) die(std::string("[euka] Error, option ") + flag + " must not be negative"); // assert(... >= 0)
+            return v;
+        };
+        if (a == "-h" || a == "--help" || a == "-") {
+            std::cerr << euka_usage() << std::endl;
+            return 0;
+        } else if (a == "--euka_dir") {
+            euka_dir = need("--euka_dir");
+            if (euka_dir.empty() || euka_dir.back() != '/') euka_dir += '/';
+        } else if (a == "--dbprefix") dbprefix = need("--dbprefix");
+        else if (a == "-fq1") reject_fasta(fq1 = need("-fq1"));
+        else if (a == "-fq2") reject_fasta(fq2 = need("-fq2"));
+        else if (a == "-i") {
+            interleaved = true;
+            if (!fq2.empty()) die("[euka] If interleaved option chosen, Euka expects only one FASTQ file");
+        } else if (a == "-g") gam = need("-g");
+        else if (a == "-M") (void)need("-M"); // minimizer index prefix: only used by giraffe
+        else if (a == "--deam5p") deam5 = need("--deam5p");
+        else if (a == "--deam3p") deam3 = need("--deam3p");
+        else if (a == "--no-mcmc") run_mcmc = false;
+        else if (a == "--iter") iter = non_negative("--iter");
+        else if (a == "--burnin") burnin = non_negative("--burnin");
+        else if (a == "--entropy") {
+            entropy = parse_double(need("--entropy"), "--entropy", T);
+            if (entropy < 0) die("[euka] Error, option --entropy must not be negative");
+            if (entropy > 5.0) die("[euka] Error, entropy thresold is too stringent"); // Euka.cpp:267
+        } else if (a == "--minBins") {
+            min_bins = non_negative("--minBins");
+            if (min_bins > 20) die("[euka] Error, minimum number of bins exceeds the total number of bins");
+        } else if (a == "--maxBins") {
+            max_bins = non_negative("--maxBins");
+            if (max_bins > 20) die("[euka] Error, maximum number of bins exceeds the total number of bins");
+        } else if (a == "--minMQ") {
+            min_mq = non_negative("--minMQ");
+            if (min_mq > 60) die("[euka] Error, option --minMQ must lie in 0..60");
+        } else if (a == "--minFrag") min_reads = non_negative("--minFrag");
+        else if (a == "--outFrag") out_frag = true;
+        else if (a == "--outGroup") out_group = need("--outGroup");
+        else if (a == "-S") die("[euka] SAFARI minimizer mode belongs to the giraffe mapping step, which is not part of the GPU path");
+        else if (a == "-t") {
+            n_threads = parse_int(need("-t"), "-t", T);
+            if (n_threads < -1 || n_threads == 0) die("[euka] Error, invalid number of threads"); // Euka.cpp:298
+            const int hw = (int)std::thread::hardware_concurrency();
+            if (n_threads == -1) n_threads = hw;
+            else if (n_threads > hw) {
+                std::cerr << "[euka] Warning, specified number of threads is greater than the number available. Using " << hw << " threads\n";
+                n_threads = hw;
+            }
+        } else if (a == "-o") out_prefix = need("-o");
+        else if (a == "-z") (void)need("-z");
+        else if (a == "-l") {
+            ltp = parse_int(need("-l"), "-l", T);
+            if (ltp < 0 || ltp > 32) die("[euka] Error, option -l must lie in 0..32");
+        } else if (a == "--out_dir") out_dir = need("--out_dir");
+        else if (a == "--seed") seed = (uint64_t)std::strtoull(need("--seed").c_str(), nullptr, 10);
+        else if (a == "--device") {
+            device = parse_int(need("--device"), "--device", T);
+            if (device < 0) die("[euka] Error, --device needs a non-negative GPU index");
+        } else die("[euka] Error, unrecognized option " + a);
+    }
+    (void)interleaved;
+    if (!fq1.empty() || !fq2.empty())
+        die("[euka] FASTQ input needs vg giraffe in-process, which this build does not have; map with vg and pass -g");
+    const std::string prefix = euka_dir + dbprefix;
+    for (const char *ext : {".gfa", ".clade", ".bins"}) // Euka.cpp:373-384 (.og / .gbwt there)
+        if (!is_file(prefix + ext)) die(prefix + ext + " does not exist.");
+    if (gam.empty()) die("[euka] Error, no input file given (use -g)");
+    if (!is_file(gam)) die("[euka] Error, GAM input file " + gam + " does not exist");
+    if (run_mcmc && iter - burnin - 1 <= 0) die("[euka] Error, --iter must exceed --burnin + 1");
+
+    PhaseTimer pt("euka");
+    Handle<vgan_damage> dmg(vgan_damage_free);
+    check(vgan_damage_load(deam5.empty() ? nullptr : deam5.c_str(), deam3.empty() ? nullptr : deam3.c_str(), &dmg.p), "damage profiles");
+    std::cerr << "Reading in taxa information ..." << std::endl;
+    Handle<vgan_euka_db> db(vgan_euka_db_free);
+    check(vgan_euka_db_load((prefix + ".clade").c_str(), (prefix + ".bins").c_str(), &db.p), "clade / bins tables");
+    vgan_euka_db_view dv;
+    check(vgan_euka_db_view_get(db.p, &dv), "clade table");
+    if (dv.n_clades == 0) die("Error: The clade vector is empty. Unable to proceed. Check if the soibean.clade file is not empty.");
+    if (dv.bin_off[dv.n_clades] == 0) die("Bins file is empty unable to proceed");
+    if (!out_group.empty()) { // Euka.cpp:419-427
+        bool found = false;
+        const char *p = dv.clade_names;
+        for (uint32_t c = 0; c < dv.n_clades && p; ++c) {
+            const char *q = strchr(p, '\n');
+            found = found || std::string(p, q ? (size_t)(q - p) : strlen(p)) == out_group;
+            p = q ? q + 1 : nullptr;
+        }
+        if (!found) die("[euka] Outgroup not found in reference graph");
+    }
+    std::cerr << "Reading in variation graph ..." << std::endl;
+    Handle<vgan_graph> graph(vgan_graph_free);
+    check(vgan_graph_load((prefix + ".gfa").c_str(), nullptr, &graph.p), "loading graph");
+    pt.lap("tables + graph");
+
+    if (vgan_device_count() <= 0) die("[euka] no HIP device is visible: the per-read likelihood pass runs on the GPU only");
+    vgan_damage_view dmv;
+    check(vgan_damage_view_get(dmg.p, &dmv), "damage view");
+    vgan_euka_params prm;
+    prm.min_mapq = (uint32_t)min_mq;
+    prm.length_to_prof = ltp;
+    Handle<vgan_euka_ctx> ctx(vgan_euka_destroy);
+    check(vgan_euka_create(&dv, &dmv, &prm, device, &ctx.p), "creating the device context");
+    pt.lap("device context");
+
+    std::cerr << "Estimating clades: Please be patient! Depending on the size of your input file, this process can take some time." << std::endl;
+    Handle<vgan_alnset> aln(vgan_aln_free);
+    check(vgan_aln_read_gam(gam.c_str(), 1, &aln.p), "reading GAM"); // unmapped reads are kept so that they are counted
+    vgan_alnset_view av;
+    check(vgan_aln_view_get(aln.p, &av), "alignment view");
+    pt.lap("GAM decode");
+
+    // per processed read, in input order
+    std::vector<int32_t> read_clade;
+    std::vector<uint8_t> read_pass;
+    std::vector<uint16_t> read_len;
+    std::vector<int64_t> name_off{0};
+    std::string names;
+    int64_t n_mapped = 0, n_bad = 0;
+    const int64_t BATCH = 1000000;
+    std::vector<int32_t> o_clade;
+    std::vector<double> o_d;
+    std::vector<uint8_t> o_pass;
+    for (int64_t r0 = 0; r0 < av.n_reads; r0 += BATCH) {
+        const int64_t r1 = std::min(av.n_reads, r0 + BATCH);
+        Handle<vgan_euka_host_batch> hb(vgan_euka_host_batch_free);
+        vgan_euka_flatten_stats st{};
+        check(vgan_euka_flatten(graph.p, aln.p, r0, r1, n_threads, &hb.p, &st), "flattening");
+        n_mapped += st.n_in - st.n_unmapped;
+        n_bad += st.n_bad;
+        vgan_euka_batch b;
+        check(vgan_euka_host_batch_get(hb.p, &b), "batch");
+        if (b.n_reads == 0) continue;
+        const size_t R = b.n_reads;
+        o_clade.resize(R);
+        o_d.resize(4 * R);
+        o_pass.resize(R);
+        vgan_euka_read_out out{o_clade.data(), o_d.data(), o_d.data() + R, o_d.data() + 2 * R, o_d.data() + 3 * R, o_pass.data()};
+        check(vgan_euka_accumulate(ctx.p, &b, &out), "accumulate");
+        for (size_t k = 0; k < R; ++k) {
+            read_clade.push_back(o_clade[k]);
+            read_pass.push_back(o_pass[k]);
+            read_len.push_back(b.read_seq_len[k]);
+            if (out_frag) {
+                const int64_t src = b.read_src[k];
+                names.append(av.name + av.name_off[src], (size_t)(av.name_off[src + 1] - av.name_off[src]));
+                name_off.push_back((int64_t)names.size());
+            }
+        }
+    }
+    std::vector<int32_t> clade_count(dv.n_clades);
+    std::vector<uint32_t> baseshift((size_t)dv.n_clades * 2 * std::max(ltp, 1) * 16);
+    std::vector<double> bin_cov(dv.bin_off[dv.n_clades]), sum_log_like(dv.n_clades);
+    std::vector<int64_t> n_like(dv.n_clades);
+    int64_t n_bad_dev = 0;
+    check(vgan_euka_finalize(ctx.p, clade_count.data(), baseshift.data(), bin_cov.data(), &n_bad_dev), "finalize");
+    check(vgan_euka_like_sums(ctx.p, n_like.data(), sum_log_like.data()), "likelihood sums");
+    pt.lap("flatten + kernels");
+    std::cerr << " .. done!" << std::endl;
+    int64_t passed = 0;
+    for (int32_t c : clade_count) passed += c;
+    std::cerr << "Number of fragments in input file: " << av.n_reads << std::endl; // readGAM_Euka.h:635-637
+    std::cerr << "Number of mapped fragments: " << n_mapped << std::endl;
+    std::cerr << "Number of fragments after filtering: " << passed << std::endl;
+    if (n_bad + n_bad_dev)
+        std::cerr << "[euka] warning: " << n_bad + n_bad_dev << " fragments skipped (the reference would index out of bounds on them)\n";
+
+    vgan_euka_results res{};
+    res.db = &dv;
+    res.clade_count = clade_count.data();
+    res.baseshift = baseshift.data();
+    res.bin_cov = bin_cov.data();
+    res.n_like = n_like.data();
+    res.sum_log_like = sum_log_like.data();
+    res.n_reads = (int64_t)read_clade.size();
+    res.read_clade = read_clade.data();
+    res.read_pass = read_pass.data();
+    res.read_seq_len = read_len.data();
+    res.name_off = out_frag ? name_off.data() : nullptr;
+    res.names = out_frag ? names.data() : nullptr;
+    vgan_euka_report_cfg cfg{};
+    cfg.detect.min_bins = (uint32_t)min_bins;
+    cfg.detect.min_reads = (uint32_t)min_reads;
+    cfg.detect.max_zero_bins = max_bins;
+    cfg.detect.entropy_threshold = entropy;
+    cfg.length_to_prof = ltp;
+    cfg.run_mcmc = run_mcmc;
+    cfg.iter = iter;
+    cfg.burnin = burnin;
+    cfg.seed = seed;
+    cfg.out_frag = out_frag;
+    cfg.out_group = out_group.empty() ? nullptr : out_group.c_str();
+    cfg.out_dir = out_dir.empty() ? nullptr : out_dir.c_str();
+    int32_t n_detected = 0;
+    if (run_mcmc) std::cerr << "Computing MCMC:" << std::endl;
+    check(vgan_euka_report(&res, &cfg, out_prefix.c_str(), nullptr, &n_detected, nullptr), "writing the output files");
+    pt.lap("abundance + output");
+    std::cerr << "Abundance estimation completed! " << std::endl << '\n';
+    if (!run_mcmc || n_detected < 2)
+        std::cerr << "No MCMC was computed. It was either specified by the user or less than 2 groups were present in the sample." << std::endl;
+    const std::string base = out_prefix.substr(out_prefix.find_last_of('/') + 1);
+    std::cerr << "You can find all four output files (" << base << "_abundance.tsv, " << base << "_detected.tsv, " << base
+              << "_coverage.tsv, and the damage profiles) in your current working directory!" << std::endl;
+    return 0;
+}

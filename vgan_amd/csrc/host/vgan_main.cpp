@@ -27,27 +27,12 @@
 #include <chrono>
 #include <thread>
 
-namespace {
-// phase times to stderr when VGAN_TIMING is set (developer aid); this file is a plain client of the C-ABI
-struct PhaseTimer {
-    bool on = getenv("VGAN_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    void lap(const char *phase) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[vgan timing] haplocart: %s %.1f ms\n", phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-} // namespace
+#include "cli_util.h"
+
+int euka_main(int argc, char **argv); // vgan_euka_main.cpp
 
 namespace {
-
-[[noreturn]] void die(const std::string &msg) { throw std::runtime_error(msg); }
-
-void check(int rc, const char *what) {
-    if (rc < 0) die(std::string("[vgan] ") + what + ": " + vgan_last_error());
-}
+using namespace vgan_cli;
 
 std::string haplocart_usage() {
     return "\n vgan haplocart [options]\n\n"
@@ -71,25 +56,6 @@ std::string haplocart_usage() {
            "   --device [INT]   GPU index (default 0)\n";
 }
 
-// whole-token numeric parses: "12x", "" and out-of-range values are errors with the option named, not an uncaught stoi
-static int parse_int(const std::string &v, const char *flag) {
-    errno = 0;
-    char *end = nullptr;
-    const long x = std::strtol(v.c_str(), &end, 10);
-    if (v.empty() || *end != '\0' || errno == ERANGE || x < INT32_MIN || x > INT32_MAX)
-        die(std::string("[HaploCart] Error, option ") + flag + " needs an integer, got '" + v + "'");
-    return (int)x;
-}
-
-static double parse_double(const std::string &v, const char *flag) {
-    errno = 0;
-    char *end = nullptr;
-    const double x = std::strtod(v.c_str(), &end);
-    if (v.empty() || *end != '\0' || errno == ERANGE || !(x == x))
-        die(std::string("[HaploCart] Error, option ") + flag + " needs a number, got '" + v + "'");
-    return x;
-}
-
 int haplocart(int argc, char **argv) {
     bool debug = false, quiet = false, compute_posteriors = true, rmdup = true, per_read = false, webapp = false;
     std::string posteriorfilename = "/dev/stdout", outputfilename = "/dev/stdout", hcfiledir = "../share/vgan/hcfiles/";
@@ -111,7 +77,7 @@ int haplocart(int argc, char **argv) {
             hcfiledir = need("--hc-files");
             if (hcfiledir.back() != '/') hcfiledir += '/';
         } else if (a == "-e") {
-            background_error_prob = parse_double(need("-e"), "-e");
+            background_error_prob = parse_double(need("-e"), "-e", "[HaploCart]");
             if (background_error_prob < 0 || background_error_prob > 1)
                 die("[HaploCart] Error, option -e is not a valid probability."); // HaploCart.cpp:107-113
         } else if (a == "-g") gamfilename = need("-g");
@@ -128,7 +94,7 @@ int haplocart(int argc, char **argv) {
             samplename = need("-s");
             invoked_samplename = true;
         } else if (a == "-t") {
-            n_threads = parse_int(need("-t"), "-t");
+            n_threads = parse_int(need("-t"), "-t", "[HaploCart]");
             if (n_threads == 0 || n_threads < -1)
                 die("[HaploCart] Error, invalid number of threads"); // HaploCart.cpp:183-194
             if (n_threads == -1) n_threads = 0;                      // all hardware threads
@@ -137,7 +103,7 @@ int haplocart(int argc, char **argv) {
         else if (a == "--keep-duplicates") rmdup = false;
         else if (a == "--per-read") per_read = true;
         else if (a == "--device") {
-            device = parse_int(need("--device"), "--device");
+            device = parse_int(need("--device"), "--device", "[HaploCart]");
             if (device < 0) die("[HaploCart] Error, --device needs a non-negative GPU index");
         }
         else die("[HaploCart] Error, unrecognized option " + a);
@@ -149,7 +115,7 @@ int haplocart(int argc, char **argv) {
     if (!std::ifstream(gamfilename)) die("[HaploCart] Error, GAM input file " + gamfilename + " does not exist");
     if (!invoked_samplename) samplename = !fastafilename.empty() ? fastafilename : gamfilename;
 
-    PhaseTimer pt;
+    PhaseTimer pt("haplocart");
     // the GAM is inflated, framed and parsed behind this thread (vgan_gam_stream) while it loads the graph and brings the
     // device up; chunks are then flattened and sent to the device as they become available
     struct StreamCloser {
@@ -286,9 +252,10 @@ int haplocart(int argc, char **argv) {
 std::string usage() {
     return "vgan (MI355X build): per-read likelihood hot path on the GPU\n\n"
            "   vgan haplocart   mitochondrial haplogroup prediction (see: vgan haplocart -h)\n"
+           "   vgan euka        abundance estimation of eukaryotic taxa (see: vgan euka -h)\n"
            "   vgan version\n\n"
-           "euka / soibean / duprm / gam2prof / keelime are reached through the C-ABI of this build as they are added;\n"
-           "the CPU-only subcommands of the reference are not part of it.\n";
+           "soibean is reached through the C-ABI of this build (include/vgan_gpu.h); the CPU-only subcommands of the\n"
+           "reference are not part of it.\n";
 }
 
 } // namespace
@@ -301,6 +268,7 @@ int main(int argc, char **argv) {
         }
         const std::string cmd = argv[1];
         if (cmd == "haplocart") return haplocart(argc - 1, argv + 1);
+        if (cmd == "euka") return euka_main(argc - 1, argv + 1);
         if (cmd == "version") {
             std::cout << "vgan-mi355x ABI " << vgan_abi_version() << std::endl;
             return 0;

@@ -195,6 +195,13 @@ class EukaContext:
         N.check(N.lib().vgan_euka_finalize(self._h, count.ctypes.data, shift.ctypes.data, cov.ctypes.data, C.byref(bad)))
         return {"clade_count": count, "baseshift": shift, "bin_cov": cov, "n_bad": bad.value}
 
+    def like_sums(self):
+        """Per clade (number of clade_like entries, sum of their logs); call after finalize()."""
+        n = np.zeros(self.db.n_clades, np.int64)
+        s = np.zeros(self.db.n_clades)
+        N.check(N.lib().vgan_euka_like_sums(self._h, n.ctypes.data, s.ctypes.data))
+        return n, s
+
     def kernel_ms(self):
         ms = C.c_double(0)
         n = C.c_uint64(0)
@@ -208,6 +215,54 @@ class EukaContext:
 
     def __del__(self):
         self.close()
+
+
+def detect(db, clade_count, bin_cov, min_bins=6, min_reads=10, max_zero_bins=0, entropy=1.17):
+    """Detected clade ids (readGAM_Euka.h:582-630)."""
+    p = N.EukaDetectParams(min_bins, min_reads, max_zero_bins, entropy)
+    cc = np.ascontiguousarray(clade_count, np.int32)
+    cov = np.ascontiguousarray(bin_cov, np.float64)
+    ids = np.zeros(db.n_clades, np.int32)
+    n = C.c_int32(0)
+    N.check(N.lib().vgan_euka_detect(C.byref(db.view), cc.ctypes.data, cov.ctypes.data, C.byref(p), ids.ctypes.data, C.addressof(n)))
+    return ids[:n.value].copy()
+
+
+def abundance_mcmc(init, n_like, sum_log_like, iters=10000, burnin=100, seed=1):
+    """MCMC::run (MCMC.cpp:1217-1366) on the per-clade sums; returns [n, 5] = median, 15 %, 85 %, 5 %, 95 %."""
+    init = np.ascontiguousarray(init, np.float64)
+    nl = np.ascontiguousarray(n_like, np.int64)
+    sl = np.ascontiguousarray(sum_log_like, np.float64)
+    est = np.zeros((len(init), 5))
+    N.check(N.lib().vgan_euka_abundance_mcmc(len(init), init.ctypes.data, nl.ctypes.data, sl.ctypes.data, iters, burnin, seed,
+                                             est.ctypes.data))
+    return est
+
+
+def report(db, fin, n_like, sum_log_like, read_clade, read_pass, read_seq_len, prefix, names=None, min_bins=6, min_reads=10,
+           max_zero_bins=0, entropy=1.17, length_to_prof=5, run_mcmc=True, iters=10000, burnin=100, seed=1, out_frag=False,
+           out_group=None, out_dir=None):
+    """Euka::run after readGAM3 (Euka.cpp:540-1160): writes <prefix>_* and returns (detected ids, estimates[n, 5]).
+    fin = EukaContext.finalize() result; names = list of bytes per read (needed for out_frag)."""
+    keep = [np.ascontiguousarray(fin["clade_count"], np.int32), np.ascontiguousarray(fin["baseshift"], np.uint32),
+            np.ascontiguousarray(fin["bin_cov"], np.float64), np.ascontiguousarray(n_like, np.int64),
+            np.ascontiguousarray(sum_log_like, np.float64), np.ascontiguousarray(read_clade, np.int32),
+            np.ascontiguousarray(read_pass, np.uint8), np.ascontiguousarray(read_seq_len, np.uint16)]
+    R = len(keep[5])
+    off = blob = None
+    if names is not None:
+        off = np.zeros(R + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in names])
+        blob = C.create_string_buffer(b"".join(names))
+    res = N.EukaResults(C.addressof(db.view), *[k.ctypes.data for k in keep[:5]], R, *[k.ctypes.data for k in keep[5:]],
+                        off.ctypes.data if off is not None else None, C.addressof(blob) if blob is not None else None)
+    cfg = N.EukaReportCfg(N.EukaDetectParams(min_bins, min_reads, max_zero_bins, entropy), length_to_prof, int(run_mcmc), iters, burnin,
+                          seed, int(out_frag), 0, out_group.encode() if out_group else None, out_dir.encode() if out_dir else None)
+    det = np.zeros(db.n_clades + 1, np.int32)
+    est = np.zeros((db.n_clades + 1, 5))
+    n = C.c_int32(0)
+    N.check(N.lib().vgan_euka_report(C.byref(res), C.byref(cfg), prefix.encode(), det.ctypes.data, C.addressof(n), est.ctypes.data))
+    return det[:n.value].copy(), est[:n.value].copy()
 
 
 def synth_euka(n_reads, damage=None, seed=0x76676131, n_clades=335, nodes_per_clade=400, read_len_mean=75, read_seed=0):
