@@ -21,11 +21,16 @@ def _texts(kind="dhigh"):
     return (open(d + "/%s5p.prof" % kind).read(), open(d + "/%s3p.prof" % kind).read())
 
 
-def _per_read(n_reads, seed, n_clades=12, texts=None, read_seed=0):
+def _per_read(n_reads, seed, n_clades=12, texts=None, read_seed=0, min_mapq=1):
+    """Oracle per-read results on a synthetic sample.  min_mapq = 1 lifts the generator's mapq 0 reads: they have
+    clade_like == 0, which makes a clade's likelihood -inf and the chain never accept (covered separately)."""
     texts = texts or _texts()
     dm = ek.Damage.from_text(*texts)
     g, db, a = ek.synth_euka(n_reads, dm, seed=seed, n_clades=n_clades, nodes_per_clade=200, read_seed=read_seed)
-    og, oa = util.orc_graph_nodes_only(g), util.orc_alnset_from_product(a)
+    og = util.orc_graph_nodes_only(g)
+    arr = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in a.arrays().items()}
+    arr["mapq"] = np.maximum(arr["mapq"], min_mapq)
+    oa = orc.AlnSet.from_arrays(**arr)
     odb = util.orc_euka_db_from_product(db)
     ref = orc.euka_run(og, oa, odb, orc.OrcDamage(*texts), 29, 5)
     arr = a.arrays()
@@ -74,6 +79,12 @@ def test_outputs_match_the_oracle_byte_for_byte(tmp_path, seed):
     assert files2["_abundance.tsv"] == files["_abundance.tsv"]
     _, est3, _ = _both(tmp_path, "other", db, odb, ref, seq_len, names, iters=600, burnin=50, seed=seed + 100, min_bins=1, entropy=0.0)
     assert not np.array_equal(est3, est)
+    n, s = _sums(ref, db.n_clades)
+    assert np.all(np.isfinite(s[det]))  # finite likelihoods: the chain does accept and move
+    # with the generator's mapq 0 reads left in, some clades have clade_like == 0 entries: log-likelihood -inf, nothing accepted
+    db, odb, ref, seq_len, names = _per_read(4000, seed=5 + seed, min_mapq=0)
+    assert np.any(np.isneginf(_sums(ref, db.n_clades)[1]))
+    _both(tmp_path, "inf", db, odb, ref, seq_len, names, iters=400, burnin=50, seed=seed, min_bins=1, entropy=0.0)
 
 
 def test_no_mcmc_out_group_and_fragment_names(tmp_path):
