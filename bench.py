@@ -178,11 +178,31 @@ def bench_euka(args):
             "config": {"workload": "euka %d synthetic 75bp aDNA reads per GPU, dhigh damage profiles, 335-clade graph" % args.reads,
                        "reads_per_gpu": hb.n_reads, "passing_reads": int(fin["clade_count"].sum())},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "euka_read_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
+                         "traffic": committed_traffic("round1_v5_euka", "euka_read_kernel", args.reads == 1_000_000 and world == 1),
+                         "kernel": "euka_read_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
                          "launches": n, "note": "fp64 VALU bound (SURVEY 8d): one table log + the damage-matrix products per base"}}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline_euka(g, db, alns, dm_texts, ctx, ek, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+
+
+SB_PROFILED_READS = 1998288  # reads of the committed soibean PMC passes (bench.py --path soibean --reads 2000000)
+
+
+def committed_traffic(profile, kernel, applies):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of the same bench command, profiles/<profile>_pmc.json); None when the workload differs or no pass is
+    committed."""
+    if not applies:
+        return None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", profile + "_pmc.json")))
+        for kn, v in pmc.items():
+            if kernel in kn:
+                return v["fetch_bytes"] + v["write_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline_soibean(g, alns, dm, sb, state_fn, freqs, budget_s):
@@ -300,7 +320,8 @@ def bench_soibean(args):
             "config": {"workload": "soibean k=3, %d synthetic reads per GPU, 28-path tree, host Metropolis loop + GPU refresh per iteration" % args.reads,
                        "reads_per_gpu": R, "precompute_s": t_pre, "accepted": accepted},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "sb_loglike_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
+                         "traffic": committed_traffic("round1_v4_soibean", "sb_loglike_kernel", R == SB_PROFILED_READS and world == 1),
+                         "kernel": "sb_loglike_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
                          "launches": km["refresh"][1]}}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline_soibean(g, alns, dm, sb, state, freqs, args.cpu_seconds)
