@@ -488,6 +488,19 @@ int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, double *pm, ui
  * of the reference's runtime_error guards would fire. */
 int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
                     double *out, double *d_out, uint64_t *guard);
+/* analyse_GAM's per-read mostProbPath (getLCAfromGAM.h:563-579) over the resident reads: best[r] (host, n_reads of the
+ * batch, may be NULL) = the path holding the read's highest pathMap value when exactly one path does, -1 on a tie or for a
+ * read excluded on the device; sig_count[n_paths] = reads per uniquely best path, the "signature" frequencies of
+ * soibean.cpp:655-668; n_reads_ok = gam->size().  Paths with the same support pattern over a read have bit-identical sums,
+ * so the reference's ties are ties here. */
+int vgan_sb_best_paths(vgan_sb_ctx *c, int32_t *best, int64_t *sig_count, int64_t *n_reads_ok);
+/* the initial log-likelihood of soibean.cpp:737-756 over the resident reads: sum_r (+)_j (log_freq + pathMap_r[paths[j]])
+ * with oplusInitnatl as (+); one source and log_freq = 0 gives the plain sum of :744-747 */
+int vgan_sb_mixture_loglike(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double log_freq, double *out);
+/* host: the initial sources of soibean.cpp:669-712 from the signature counts: paths with at least 1 % of the reads, by
+ * descending count (equal counts: ascending path index; the reference's order among them is that of an unordered_map),
+ * cut to cutk when cutk > 0; every path with a count when none reaches the threshold.  paths[] capacity n_paths */
+int vgan_sb_signature_paths(const int64_t *sig_count, uint32_t n_paths, int64_t n_reads, int32_t cutk, int32_t *paths, int32_t *n);
 int vgan_sb_kernel_ms(vgan_sb_ctx *c, double ms[2], uint64_t launches[2]); /* 0 precompute kernel, 1 refresh kernel */
 void vgan_sb_destroy(vgan_sb_ctx *c);
 

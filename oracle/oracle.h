@@ -184,6 +184,8 @@ void *orc_sb_analyse(const orc_graph_t *g, const orc_alnset_t *a, const uint8_t 
 void orc_sb_free(void *h);
 int orc_sb_read_ok(const void *h, int64_t r);
 int orc_sb_pathmap(const void *h, int64_t r, double *out /* [n_paths] */);
+int64_t orc_sb_best_paths(const void *h, int32_t *best /* [n_reads] */, int64_t *sig_count /* [n_paths] */);
+double orc_sb_mixture_loglike(const void *h, int32_t n, const int32_t *paths, double log_freq);
 int orc_sb_counts(const void *h, int64_t r, int32_t p, uint32_t *out25, uint32_t *n_bases);
 /* one likelihood refresh of the tree-placement MCMC (src/MCMC.cpp:738-993, src/MCMC.h:111-315);
  * freqs7 = {A, C, G, T, R, Y, M}; dist[y] = branch length of the child node */

@@ -243,6 +243,44 @@ int orc_sb_pathmap(const void *h, int64_t r, double *out) {
     return 0;
 }
 
+/* mostProbPath of every read (getLCAfromGAM.h:563-579): best[r] = the path with the highest pathMap value when it is the only
+ * one, -1 on ties / skipped reads; sig_count[p] = frequencies[path] of soibean.cpp:655-668; returns gam->size() */
+int64_t orc_sb_best_paths(const void *h, int32_t *best, int64_t *sig_count) {
+    const SbHandle *H = (const SbHandle *)h;
+    for (int p = 0; p < H->n_paths; ++p) sig_count[p] = 0;
+    int64_t n = 0;
+    for (size_t r = 0; r < H->reads.size(); ++r) {
+        const SbRead &R = H->reads[r];
+        best[r] = -1;
+        if (!R.ok) continue;
+        ++n;
+        long double highestValue = std::numeric_limits<long double>::lowest();
+        for (double v : R.pathMap) highestValue = std::max(highestValue, (long double)v);
+        vector<int> keysWithHighestValue;
+        for (int p = 0; p < H->n_paths; ++p)
+            if (R.pathMap[(size_t)p] == highestValue) keysWithHighestValue.push_back(p);
+        if (keysWithHighestValue.size() == 1) {
+            best[r] = keysWithHighestValue[0];
+            sig_count[keysWithHighestValue[0]]++;
+        }
+    }
+    return n;
+}
+
+/* soibean.cpp:737-756: the initial log-likelihood of a set of source paths (n == 1: the caller passes log_freq = 0 for the
+ * plain sum of :744-747) */
+double orc_sb_mixture_loglike(const void *h, int32_t n, const int32_t *paths, double log_freq) {
+    const SbHandle *H = (const SbHandle *)h;
+    double logLike = 0.0L;
+    for (const SbRead &R : H->reads) {
+        if (!R.ok) continue;
+        double inter = log_freq + R.pathMap[(size_t)paths[0]];
+        for (int j = 1; j < n; ++j) inter = oplusInitnatl(inter, (log_freq + R.pathMap[(size_t)paths[j]]));
+        logLike += inter;
+    }
+    return logLike;
+}
+
 /* counts of (referenceBase, readBase) over the path-supported bases of (read r, path p): 5x5, index ACGT or 4 = other;
  * plus the number of bases in total (test aid for the factorised device layout) */
 int orc_sb_counts(const void *h, int64_t r, int32_t p, uint32_t *out25, uint32_t *n_bases) {

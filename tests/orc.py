@@ -376,6 +376,20 @@ class SbOracle:
         rc = lib().orc_sb_counts(C.c_void_p(self.h), C.c_int64(r), C.c_int32(p), _p(out), C.byref(n))
         return (out, n.value) if rc == 0 else (None, 0)
 
+    def best_paths(self, n_reads):
+        best = np.zeros(n_reads, np.int32)
+        sig = np.zeros(self.P, np.int64)
+        L = lib()
+        L.orc_sb_best_paths.restype = C.c_int64
+        n = L.orc_sb_best_paths(C.c_void_p(self.h), _p(best), _p(sig))
+        return best, sig, int(n)
+
+    def mixture_loglike(self, paths, log_freq):
+        p = np.ascontiguousarray(paths, np.int32)
+        L = lib()
+        L.orc_sb_mixture_loglike.restype = C.c_double
+        return L.orc_sb_mixture_loglike(C.c_void_p(self.h), C.c_int32(len(p)), _p(p), C.c_double(log_freq))
+
     def loglike(self, sources, con, freqs7, n_threads=8):
         k = len(sources)
         child = np.array([s[0] for s in sources], np.int32)

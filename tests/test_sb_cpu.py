@@ -121,3 +121,14 @@ def test_flatten_matches_oracle_slicing():
         nodes = arr["seg_node"][s0:s1]
         assert nodes[:min(nM, len(sizes))].tolist() == al["m_node"][al["map_off"][r]:al["map_off"][r] + min(nM, len(sizes))].tolist()
         assert np.all(nodes[nM:] == 0)
+
+
+def test_signature_paths_rule():
+    """Initial sources from the signature counts (soibean.cpp:669-712): >= 1 % of the reads, by descending count."""
+    from vgan_amd import soibean as sb
+    sig = np.array([0, 50, 3, 50, 700, 9, 0, 10], np.int64)
+    assert list(sb.signature_paths(sig, 1000)) == [4, 1, 3, 7]          # 10 reads is exactly 1 %
+    assert list(sb.signature_paths(sig, 1000, cutk=2)) == [4, 1]
+    assert list(sb.signature_paths(sig, 1000, cutk=9)) == [4, 1, 3, 7]
+    assert list(sb.signature_paths(np.array([0, 2, 0, 5], np.int64), 100000)) == [3, 1]  # nothing reaches 1 %: every seen path
+    assert list(sb.signature_paths(np.zeros(6, np.int64), 100)) == []

@@ -62,6 +62,20 @@ def run_case(g, a, texts, penalty, states_k1, states_k3):
     # determinism of the refresh: identical bits on a second evaluation
     again, _ = ctx.loglike(states_k3, 0.02, FREQS)
     assert np.array_equal(again, got)
+    # analyse_GAM's mostProbPath and the initial estimate of soibean.cpp:655-756
+    best, sig, n_ok = ctx.best_paths()
+    obest, osig, on = o.best_paths(a.n_reads)
+    assert n_ok == on == hb.n_reads and np.array_equal(best, obest[src]) and np.array_equal(sig, osig)
+    assert (best >= 0).sum() == sig.sum()
+    paths = sb.signature_paths(sig, n_ok)
+    want = [p for p in sorted(range(g.n_paths), key=lambda p: (-sig[p], p)) if sig[p] > 0 and sig[p] >= 0.01 * n_ok]
+    assert list(paths) == (want or [p for p in sorted(range(g.n_paths), key=lambda p: (-sig[p], p)) if sig[p] > 0])
+    use = list(paths[:4]) if len(paths) else [0, 1]
+    for n in range(1, len(use) + 1):
+        lf = float(np.log(1.0 / len(use))) if len(use) > 1 else 0.0
+        v = ctx.mixture_loglike(use[:n], lf)
+        assert v == pytest.approx(o.mixture_loglike(use[:n], lf), rel=1e-12)
+        assert v == ctx.mixture_loglike(use[:n], lf)  # fixed summation order
     return ctx, o
 
 

@@ -213,6 +213,9 @@ SYMBOLS = {
     "vgan_sb_read_tables": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "vgan_sb_loglike": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_double, vp, vp, vp, vp]),
     "vgan_sb_kernel_ms": (C.c_int, [vp, vp, vp]),
+    "vgan_sb_best_paths": (C.c_int, [vp, vp, vp, vp]),
+    "vgan_sb_mixture_loglike": (C.c_int, [vp, C.c_uint32, vp, C.c_double, vp]),
+    "vgan_sb_signature_paths": (C.c_int, [vp, C.c_uint32, C.c_int64, C.c_int32, vp, vp]),
     "vgan_sb_destroy": (None, [vp]),
     "vgan_synth_euka": (C.c_int, [C.POINTER(SynthEukaCfg), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "vgan_synth_hc_graph": (C.c_int, [C.POINTER(SynthGraphCfg), C.POINTER(vp)]),

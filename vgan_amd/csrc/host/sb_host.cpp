@@ -180,3 +180,21 @@ extern "C" int vgan_sb_host_batch_get(const vgan_sb_host_batch *b, vgan_sb_batch
 }
 
 extern "C" void vgan_sb_host_batch_free(vgan_sb_host_batch *b) { delete b; }
+
+// soibean.cpp:655-712: signature paths from the per-path counts of reads with a unique best path
+extern "C" int vgan_sb_signature_paths(const int64_t *sig_count, uint32_t n_paths, int64_t n_reads, int32_t cutk, int32_t *paths, int32_t *n) {
+    if (!sig_count || !paths || !n) return fail(VGAN_EINVAL, "vgan_sb_signature_paths: null argument");
+    std::vector<std::pair<int64_t, uint32_t>> seen; // (count, path) of the paths some read singles out
+    for (uint32_t p = 0; p < n_paths; ++p)
+        if (sig_count[p] > 0) seen.emplace_back(sig_count[p], p);
+    std::sort(seen.begin(), seen.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    const double thres = (double)n_reads * 0.01;
+    int32_t k = 0;
+    for (const auto &e : seen)
+        if ((double)e.first >= thres) paths[k++] = (int32_t)e.second;
+    if (cutk > 0 && k > cutk) k = cutk; // the reference resize()s: a cutk beyond the list would pad it with node 0, which no run relies on
+    if (k == 0)
+        for (const auto &e : seen) paths[k++] = (int32_t)e.second; // "Rerunning with no minimum threshold"
+    *n = k;
+    return VGAN_OK;
+}

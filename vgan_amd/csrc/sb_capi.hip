@@ -65,6 +65,8 @@ struct vgan_sb_ctx {
     Buf<uint8_t> s8;
     Buf<SbSourceDev> src;
     Buf<double> hky, partial, out, freqs;
+    Buf<int32_t> best, mix_paths;
+    Buf<unsigned long long> sig;
     std::vector<char> h_params; // host staging of one refresh's parameters
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[2] = {false, false};
@@ -157,6 +159,9 @@ extern "C" void vgan_sb_destroy(vgan_sb_ctx *c) {
     c->partial.release();
     c->out.release();
     c->freqs.release();
+    c->best.release();
+    c->mix_paths.release();
+    c->sig.release();
     for (auto e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -279,6 +284,43 @@ extern "C" int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, dou
                                       hipMemcpyDeviceToHost, c->stream));
     }
     if (ok) HIPCHK(hipMemcpyAsync(ok, c->t.ok + r0, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VGAN_OK;
+}
+
+extern "C" int vgan_sb_best_paths(vgan_sb_ctx *c, int32_t *best, int64_t *sig_count, int64_t *n_reads_ok) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_sb_best_paths: null context");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t R = c->t.n_reads;
+    int rc;
+    if ((rc = c->sig.reserve(c->P + 1)) || (best && (rc = c->best.reserve(R)))) return rc;
+    HIPCHK(hipMemsetAsync(c->sig.p, 0, (size_t)(c->P + 1) * 8, c->stream));
+    launch_sb_best_paths(c->t, c->P, best ? c->best.p : nullptr, c->sig.p, c->sig.p + c->P, c->stream);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> h(c->P + 1);
+    HIPCHK(hipMemcpyAsync(h.data(), c->sig.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    if (best && R) HIPCHK(hipMemcpyAsync(best, c->best.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (sig_count)
+        for (uint32_t p = 0; p < c->P; ++p) sig_count[p] = (int64_t)h[p];
+    if (n_reads_ok) *n_reads_ok = (int64_t)h[c->P];
+    return VGAN_OK;
+}
+
+extern "C" int vgan_sb_mixture_loglike(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double log_freq, double *out) {
+    if (!c || !paths || !out) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: null argument");
+    if (n == 0 || n > SB_MAX_PATHS) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: 1..%u sources, got %u", SB_MAX_PATHS, n);
+    for (uint32_t i = 0; i < n; ++i)
+        if (paths[i] < 0 || (uint32_t)paths[i] >= c->P) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: path index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t R = c->t.n_reads;
+    const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
+    int rc;
+    if ((rc = c->mix_paths.reserve(n)) || (rc = c->partial.reserve(n_blocks)) || (rc = c->out.reserve(1))) return rc;
+    HIPCHK(hipMemcpyAsync(c->mix_paths.p, paths, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    launch_sb_mixture(c->t, n, c->mix_paths.p, log_freq, c->partial.p, n_blocks, c->out.p, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->out.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return VGAN_OK;
 }

@@ -54,4 +54,11 @@ void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states
 void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky,
                    unsigned long long *guard, uint32_t n_states, hipStream_t st);
 
+// per-read best path (-1: tie or excluded read), per-path signature counts and the number of usable reads; counters zeroed by the caller
+void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
+                          unsigned long long *n_ok, hipStream_t st);
+// out[0] = sum over reads of (+)_j (log_freq + pm[paths[j]]); partial: n_blocks doubles of scratch
+void launch_sb_mixture(const SbTablesDev &t, uint32_t n, const int32_t *paths, double log_freq, double *partial, uint32_t n_blocks,
+                       double *out, hipStream_t st);
+
 } // namespace vgan

@@ -283,7 +283,92 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(const double *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------- read summaries
+// analyse_GAM's mostProbPath (getLCAfromGAM.h:563-579): the paths holding the read's highest pathMap value.  One lane per
+// read walks the pm rows (coalesced across lanes); best = that path when exactly one path holds the maximum, else -1.
+// Paths with the same support pattern over a read have bit-identical sums (same terms, same order), so the ties of the
+// reference are ties here.
+__global__ __launch_bounds__(256) void sb_best_path_kernel(SbTablesDev t, uint32_t n_paths, int32_t *__restrict__ best,
+                                                            unsigned long long *__restrict__ sig_count,
+                                                            unsigned long long *__restrict__ n_ok) {
+    __shared__ uint32_t hist_s[SB_MAX_PATHS];
+    __shared__ uint32_t ok_s;
+    for (uint32_t i = threadIdx.x; i < SB_MAX_PATHS; i += blockDim.x) hist_s[i] = 0;
+    if (threadIdx.x == 0) ok_s = 0;
+    __syncthreads();
+    const uint32_t R = t.n_reads;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        int32_t b = -1;
+        if (t.ok[r]) {
+            double hi = t.pm[r];
+            uint32_t arg = 0, ties = 1;
+            for (uint32_t p = 1; p < n_paths; ++p) {
+                const double v = t.pm[(size_t)p * R + r];
+                if (v > hi) {
+                    hi = v;
+                    arg = p;
+                    ties = 1;
+                } else if (v == hi)
+                    ++ties;
+            }
+            if (ties == 1) {
+                b = (int32_t)arg;
+                atomicAdd(&hist_s[arg], 1u);
+            }
+            atomicAdd(&ok_s, 1u);
+        }
+        if (best) best[r] = b;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_paths; i += blockDim.x)
+        if (hist_s[i]) atomicAdd(&sig_count[i], (unsigned long long)hist_s[i]);
+    if (threadIdx.x == 0 && ok_s) atomicAdd(n_ok, (unsigned long long)ok_s);
+}
+
+// soibean.cpp:737-756: per read inter = log_freq + pathMap[paths[0]], then inter = oplusInitnatl(inter, log_freq +
+// pathMap[paths[j]]) for the further sources; block partials in a fixed order as the refresh kernel's
+__global__ __launch_bounds__(SBL_THREADS) void sb_mixture_kernel(SbTablesDev t, uint32_t n, const int32_t *__restrict__ paths,
+                                                                  double log_freq, double *__restrict__ partial) {
+    __shared__ double red_s[SBL_THREADS / 64];
+    __shared__ int32_t path_s[SB_MAX_PATHS];
+    for (uint32_t i = threadIdx.x; i < n; i += SBL_THREADS) path_s[i] = paths[i];
+    __syncthreads();
+    const uint32_t R = t.n_reads;
+    double sum = 0.0;
+    for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
+        if (!t.ok[r]) continue;
+        double inter = log_freq + t.pm[(size_t)path_s[0] * R + r];
+        for (uint32_t j = 1; j < n; ++j) {
+            const double y = log_freq + t.pm[(size_t)path_s[j] * R + r];
+            if (inter == 0.0) inter = y; // oplusInitnatl: a running value of 0 means "empty" 
+            else inter = fmax(inter, y) + log1p(exp(-fabs(inter - y)));
+        }
+        sum += inter;
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s2 = 0.0;
+        for (int w = 0; w < SBL_THREADS / 64; ++w) s2 += red_s[w];
+        partial[blockIdx.x] = s2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- launchers
+void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
+                          unsigned long long *n_ok, hipStream_t st) {
+    if (t.n_reads == 0) return;
+    const uint32_t blocks = min((t.n_reads + 255u) / 256u, 2048u);
+    hipLaunchKernelGGL(sb_best_path_kernel, dim3(blocks), dim3(256), 0, st, t, n_paths, best, sig_count, n_ok);
+}
+
+void launch_sb_mixture(const SbTablesDev &t, uint32_t n, const int32_t *paths, double log_freq, double *partial, uint32_t n_blocks,
+                       double *out, hipStream_t st) {
+    hipLaunchKernelGGL(sb_mixture_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, n, paths, log_freq, partial);
+    hipLaunchKernelGGL(sb_finish_kernel, dim3(1), dim3(64), 0, st, partial, n_blocks, 1u, out, (double *)nullptr);
+}
+
 void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, unsigned long long *n_bad,
                           hipStream_t st) {
     if (b.n_reads == 0) return;

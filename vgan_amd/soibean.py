@@ -81,6 +81,21 @@ class SbContext:
                                         device_out.data_ptr() if device_out is not None else None, guard.ctypes.data))
         return out, guard
 
+    def best_paths(self):
+        """analyse_GAM's mostProbPath: (best[n_reads] with -1 for ties / excluded reads, sig_count[n_paths], n_reads_ok)."""
+        best = np.zeros(max(self.n_reads, 1), np.int32)
+        sig = np.zeros(self.n_paths, np.int64)
+        n = C.c_int64(0)
+        N.check(N.lib().vgan_sb_best_paths(self._h, best.ctypes.data, sig.ctypes.data, C.addressof(n)))
+        return best[:self.n_reads], sig, n.value
+
+    def mixture_loglike(self, paths, log_freq):
+        """soibean.cpp:737-756: sum over reads of the oplusInitnatl-fold of log_freq + pathMap[path]."""
+        p = np.ascontiguousarray(paths, np.int32)
+        out = C.c_double(0)
+        N.check(N.lib().vgan_sb_mixture_loglike(self._h, len(p), p.ctypes.data, log_freq, C.addressof(out)))
+        return out.value
+
     def kernel_ms(self):
         ms = np.zeros(2)
         n = np.zeros(2, np.uint64)
@@ -94,3 +109,12 @@ class SbContext:
 
     def __del__(self):
         self.close()
+
+
+def signature_paths(sig_count, n_reads, cutk=0):
+    """Initial sources from the signature counts (soibean.cpp:669-712)."""
+    sig = np.ascontiguousarray(sig_count, np.int64)
+    paths = np.zeros(len(sig), np.int32)
+    n = C.c_int32(0)
+    N.check(N.lib().vgan_sb_signature_paths(sig.ctypes.data, len(sig), n_reads, cutk, paths.ctypes.data, C.addressof(n)))
+    return paths[:n.value].copy()
