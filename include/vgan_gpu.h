@@ -504,6 +504,63 @@ int vgan_sb_signature_paths(const int64_t *sig_count, uint32_t n_paths, int64_t 
 int vgan_sb_kernel_ms(vgan_sb_ctx *c, double ms[2], uint64_t launches[2]); /* 0 precompute kernel, 1 refresh kernel */
 void vgan_sb_destroy(vgan_sb_ctx *c);
 
+/* ------------------------------------------------------------------------------------------------
+ * soibean downstream of analyse_GAM (host control flow around vgan_sb_loglike): the taxon tree
+ * (<dbprefix>.new.dnd, soibean.cpp:565-596), MCMC::run_tree_proportion (MCMC.cpp:522-1093) with MCMC::updatePosition
+ * (:169-470) and MCMC::sample_normal (:487-520), MCMC::processMCMCiterations (:23-150) and the chain loop with its R-hat
+ * diagnostics (soibean.cpp:738-944).
+ *
+ * Where the reference leaves the behaviour open this build defines it:
+ *  - randomness: every std::random_device call is replaced by the next output of a splitmix64 stream started at `seed`
+ *    (0 = the hardware source, as the reference); libc rand() -- never seeded there -- and the function-local static engine
+ *    of sample_normal by one std::mt19937 each per vgan_sb_estimate call, seeded from that stream first;
+ *  - tree nodes are numbered in pre-order of the Newick text (spidir, the reference's tree library, is not in its tree);
+ *  - getPatristicDistances indexes a vector of #leaves entries by node index: only indices below #leaves are compared;
+ *  - diagnostics rows come in branch-name order (an unordered_map there); a branch a chain did not end on takes the
+ *    reference's own defaults {1, 1, 1, 1} for that chain.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_tree vgan_tree; /* opaque */
+typedef struct vgan_tree_view {
+    uint32_t n_nodes, n_leaves;
+    int32_t root;
+    const int32_t *parent;    /* [n_nodes], -1 at the root */
+    const double *dist;       /* [n_nodes] branch length above the node (0 when absent) */
+    const int32_t *child_off; /* [n_nodes+1] into children */
+    const int32_t *children;
+    const char *names;        /* '\n' joined node labels (spidir longname) */
+} vgan_tree_view;
+int vgan_tree_parse(const char *newick, vgan_tree **out);
+int vgan_tree_load(const char *path, vgan_tree **out); /* plain or .gz */
+int vgan_tree_view_get(const vgan_tree *t, vgan_tree_view *out);
+void vgan_tree_free(vgan_tree *t);
+
+/* what the chain needs of the likelihood: one refresh (MCMC.cpp:738-993) and the initial mixture (soibean.cpp:737-756).
+ * Return VGAN_OK or a negative code; guard counts reads on which the reference would throw. */
+typedef struct vgan_sb_engine {
+    void *user;
+    int (*refresh)(void *user, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7, double *loglike, uint64_t *guard);
+    int (*mixture)(void *user, uint32_t n, const int32_t *paths, double log_freq, double *loglike);
+} vgan_sb_engine;
+int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out); /* vgan_sb_loglike / vgan_sb_mixture_loglike of the context */
+
+typedef struct vgan_sb_estimate_cfg {
+    uint32_t max_iter;  /* --iter (500000) */
+    uint32_t burn;      /* --burnin (75000), below max_iter */
+    uint32_t chains;    /* --chains (4) */
+    uint32_t n_paths;   /* paths of the graph = tree nodes: sizes the proposal (MCMC.cpp:541-546) and the random starts */
+    uint64_t seed;
+    double con;         /* shortest non-zero branch below 1, else 0.01 (soibean.cpp:598-602) */
+    double freqs7[7];   /* A, C, G, T, R, Y, M (soibean.cpp:609-640) */
+    int32_t run_mcmc;   /* 0 = --no-mcmc: initial log-likelihoods only */
+    int32_t quiet;
+} vgan_sb_estimate_cfg;
+/* soibean.cpp:738-944 for the starting nodes sig_nodes[0..n_sig): for k = 1..n_sig sources the initial log-likelihood, then
+ * `chains` chains (chain 0 from sig_nodes[0..k), the others from random nodes), each writing <prefix>Result<k><chain>.mcmc and
+ * <prefix>Trace<k><chain>.detail.mcmc (gzip), appending to <prefix>ProportionEstimates<k>.txt / <prefix>BranchEstimate<k>.txt,
+ * and <prefix>Diagnostics<k>0.txt.  node_path[n_nodes] = graph path index of every tree node (by name), -1 = none. */
+int vgan_sb_estimate(const vgan_sb_engine *engine, const vgan_tree *tree, const int32_t *node_path, const int32_t *sig_nodes,
+                     uint32_t n_sig, const vgan_sb_estimate_cfg *cfg, const char *out_prefix);
+
 typedef struct vgan_synth_euka_cfg {
     uint64_t seed;
     uint32_t n_clades;        /* 335 */

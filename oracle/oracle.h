@@ -192,6 +192,21 @@ int orc_sb_counts(const void *h, int64_t r, int32_t p, uint32_t *out25, uint32_t
 int orc_sb_loglike(const void *h, int32_t k, const int32_t *child, const int32_t *parent, const double *dist, const double *pos,
                    const double *theta, double con, const double *freqs7, int n_threads, double *logLike);
 
+/* `vgan soibean` after analyse_GAM (oracle/sb_chain_oracle.cpp): for k = 1..n_sig sources the initial log-likelihood and, with
+ * run_mcmc, `chains` chains of MCMC::run_tree_proportion, MCMC::processMCMCiterations per chain and the R-hat diagnostics
+ * (soibean.cpp:738-944); writes <prefix>Result<k><c>.mcmc, <prefix>Trace<k><c>.detail.mcmc (gzip), <prefix>ProportionEstimates<k>.txt,
+ * <prefix>BranchEstimate<k>.txt, <prefix>Diagnostics<k>0.txt.  path_names: one per line, index = path of the handle;
+ * sig_nodes: tree node numbers (pre-order of the Newick text). */
+typedef struct orc_sb_estimate_cfg {
+    uint32_t max_iter, burn, chains;
+    uint64_t seed;
+    double con;
+    double freqs7[7];
+    int32_t run_mcmc;
+} orc_sb_estimate_cfg;
+int orc_sb_estimate(const void *h, const char *newick, const char *path_names, const int32_t *sig_nodes, int32_t n_sig,
+                    const orc_sb_estimate_cfg *cfg, const char *prefix);
+
 #ifdef __cplusplus
 }
 #endif

@@ -390,6 +390,18 @@ class SbOracle:
         L.orc_sb_mixture_loglike.restype = C.c_double
         return L.orc_sb_mixture_loglike(C.c_void_p(self.h), C.c_int32(len(p)), _p(p), C.c_double(log_freq))
 
+    def estimate(self, newick, path_names, sig_nodes, prefix, freqs7, con=0.01, iters=2000, burnin=200, chains=2, seed=1, run_mcmc=True):
+        """oracle/sb_chain_oracle.cpp: the chain loop of soibean.cpp:738-944 on this handle's reads."""
+        class Cfg(C.Structure):
+            _fields_ = [("max_iter", C.c_uint32), ("burn", C.c_uint32), ("chains", C.c_uint32), ("seed", C.c_uint64), ("con", C.c_double),
+                        ("freqs7", C.c_double * 7), ("run_mcmc", C.c_int32)]
+        cfg = Cfg(iters, burnin, chains, seed, con, (C.c_double * 7)(*freqs7), int(run_mcmc))
+        sg = np.ascontiguousarray(sig_nodes, np.int32)
+        rc = lib().orc_sb_estimate(C.c_void_p(self.h), newick.encode(), ("\n".join(path_names) + "\n").encode(), _p(sg), C.c_int32(len(sg)),
+                                   C.byref(cfg), prefix.encode())
+        if rc != 0:
+            raise ValueError("orc_sb_estimate failed")
+
     def loglike(self, sources, con, freqs7, n_threads=8):
         k = len(sources)
         child = np.array([s[0] for s in sources], np.int32)

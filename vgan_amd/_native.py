@@ -94,6 +94,25 @@ class EukaReadOut(C.Structure):
     _fields_ = [("clade", vp), ("in_lik", vp), ("out_lik", vp), ("like", vp), ("not_like", vp), ("pass_", vp)]
 
 
+class TreeView(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("root", C.c_int32), ("parent", vp), ("dist", vp),
+                ("child_off", vp), ("children", vp), ("names", C.c_char_p)]
+
+
+SB_REFRESH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                            C.POINTER(C.c_uint64))
+SB_MIXTURE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.c_double, C.POINTER(C.c_double))
+
+
+class SbEngine(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("refresh", SB_REFRESH_FN), ("mixture", SB_MIXTURE_FN)]
+
+
+class SbEstimateCfg(C.Structure):
+    _fields_ = [("max_iter", C.c_uint32), ("burn", C.c_uint32), ("chains", C.c_uint32), ("n_paths", C.c_uint32), ("seed", C.c_uint64),
+                ("con", C.c_double), ("freqs7", C.c_double * 7), ("run_mcmc", C.c_int32), ("quiet", C.c_int32)]
+
+
 class SbBatch(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("n_segments", C.c_uint32), ("n_cols", C.c_uint64), ("n_qual", C.c_uint64),
                 ("read_seg_off", vp), ("read_col_off", vp), ("read_qual_off", vp), ("read_gseq_len", vp),
@@ -213,6 +232,12 @@ SYMBOLS = {
     "vgan_sb_read_tables": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "vgan_sb_loglike": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_double, vp, vp, vp, vp]),
     "vgan_sb_kernel_ms": (C.c_int, [vp, vp, vp]),
+    "vgan_tree_parse": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "vgan_tree_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "vgan_tree_view_get": (C.c_int, [vp, C.POINTER(TreeView)]),
+    "vgan_tree_free": (None, [vp]),
+    "vgan_sb_engine_gpu": (C.c_int, [vp, C.POINTER(SbEngine)]),
+    "vgan_sb_estimate": (C.c_int, [C.POINTER(SbEngine), vp, vp, vp, C.c_uint32, C.POINTER(SbEstimateCfg), C.c_char_p]),
     "vgan_sb_best_paths": (C.c_int, [vp, vp, vp, vp]),
     "vgan_sb_mixture_loglike": (C.c_int, [vp, C.c_uint32, vp, C.c_double, vp]),
     "vgan_sb_signature_paths": (C.c_int, [vp, C.c_uint32, C.c_int64, C.c_int32, vp, vp]),

@@ -118,3 +118,99 @@ def signature_paths(sig_count, n_reads, cutk=0):
     n = C.c_int32(0)
     N.check(N.lib().vgan_sb_signature_paths(sig.ctypes.data, len(sig), n_reads, cutk, paths.ctypes.data, C.addressof(n)))
     return paths[:n.value].copy()
+
+
+class Tree:
+    """The taxon tree (<dbprefix>.new.dnd, soibean.cpp:565-596); nodes numbered in pre-order of the Newick text."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.view = N.TreeView()
+        N.check(N.lib().vgan_tree_view_get(self._h, C.byref(self.view)))
+
+    @classmethod
+    def parse(cls, newick):
+        h = N.vp()
+        N.check(N.lib().vgan_tree_parse(newick.encode() if isinstance(newick, str) else newick, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, path):
+        h = N.vp()
+        N.check(N.lib().vgan_tree_load(path.encode(), C.byref(h)))
+        return cls(h)
+
+    @property
+    def n_nodes(self):
+        return self.view.n_nodes
+
+    @property
+    def n_leaves(self):
+        return self.view.n_leaves
+
+    @property
+    def parent(self):
+        return _np_view(self.view.parent, self.n_nodes, np.int32)
+
+    @property
+    def dist(self):
+        return _np_view(self.view.dist, self.n_nodes, np.float64)
+
+    @property
+    def names(self):
+        return (self.view.names or b"").decode().split("\n")[:self.n_nodes]
+
+    def children(self, v):
+        off = _np_view(self.view.child_off, self.n_nodes + 1, np.int32)
+        ch = _np_view(self.view.children, max(int(off[-1]), 1), np.int32)
+        return [int(x) for x in ch[off[v]:off[v + 1]]]
+
+    def node_paths(self, path_names):
+        """Graph path index of every tree node, by name (-1 when the graph has no such path)."""
+        idx = {n: i for i, n in enumerate(path_names)}
+        return np.array([idx.get(n, -1) for n in self.names], np.int32)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and N is not None:
+            N.lib().vgan_tree_free(self._h)
+            self._h = None
+
+
+def python_engine(refresh, mixture):
+    """A vgan_sb_engine from two Python callables (tests drive the chain logic with the oracle's likelihood this way):
+    refresh(list of (child, parent, dist, pos, theta), con, freqs7) -> (loglike, guard); mixture(paths, log_freq) -> loglike."""
+    def _refresh(user, k, src, con, freqs7, out, guard):
+        arr = C.cast(src, C.POINTER(N.SbSource))
+        st = [(arr[i].child, arr[i].parent, arr[i].dist, arr[i].pos, arr[i].theta) for i in range(k)]
+        try:
+            ll, g = refresh(st, con, [freqs7[i] for i in range(7)])
+        except Exception:  # noqa: BLE001 -- reported through the return code
+            return -1
+        out[0] = ll
+        guard[0] = g
+        return 0
+
+    def _mixture(user, n, paths, log_freq, out):
+        try:
+            out[0] = mixture([paths[i] for i in range(n)], log_freq)
+        except Exception:  # noqa: BLE001
+            return -1
+        return 0
+
+    e = N.SbEngine(None, N.SB_REFRESH_FN(_refresh), N.SB_MIXTURE_FN(_mixture))
+    e._keep = (_refresh, _mixture)
+    return e
+
+
+def estimate(engine, tree, node_path, sig_nodes, prefix, n_paths, freqs7, con=0.01, iters=500000, burnin=75000, chains=4, seed=1,
+             run_mcmc=True, quiet=True):
+    """soibean.cpp:738-944 (vgan_sb_estimate).  engine: an SbContext (GPU) or a python_engine()."""
+    if isinstance(engine, SbContext):
+        e = N.SbEngine()
+        N.check(N.lib().vgan_sb_engine_gpu(engine._h, C.byref(e)))
+    else:
+        e = engine
+    cfg = N.SbEstimateCfg(iters, burnin, chains, n_paths, seed, con, (C.c_double * 7)(*freqs7), int(run_mcmc), int(quiet))
+    np_ = np.ascontiguousarray(node_path, np.int32)
+    sg = np.ascontiguousarray(sig_nodes, np.int32)
+    N.check(N.lib().vgan_sb_estimate(C.byref(e), tree._h, np_.ctypes.data, sg.ctypes.data, len(sg), C.byref(cfg), prefix.encode()))
