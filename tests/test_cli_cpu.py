@@ -46,7 +46,7 @@ def test_cli_garbage_arguments_are_errors_not_crashes(tmp_path):
     """Random argument vectors end with exit code 0 (help) or 1 (a message on stderr) -- never a signal."""
     import random
     rng = random.Random(3)
-    vocab = ["haplocart", "version", "euka", "--iter", "--entropy", "--euka_dir", "--outGroup", "--minBins", "--no-mcmc", "-l", "-g", "-e", "-t", "-o", "-pf", "-s", "-np", "-q", "-d", "-w", "-z", "-i", "-j", "-f", "-fq1",
+    vocab = ["haplocart", "version", "euka", "soibean", "--dbprefix", "--chains", "-k", "--randStart", "-P", "--iter", "--entropy", "--euka_dir", "--outGroup", "--minBins", "--no-mcmc", "-l", "-g", "-e", "-t", "-o", "-pf", "-s", "-np", "-q", "-d", "-w", "-z", "-i", "-j", "-f", "-fq1",
              "--hc-files", "--device", "--per-read", "--keep-duplicates", "-h", "", "0", "-1", "1e-3", "\xff\xfe", "a" * 5000,
              str(tmp_path), "/dev/null", "/nonexistent/x", "--", "-", "%s%n", "9" * 40]
     for _ in range(150):
@@ -89,6 +89,42 @@ def test_euka_cli_validation_errors(tmp_path):
     if N.lib().vgan_device_count() <= 0:  # no CPU fallback for the per-read pass
         r = run("euka", "--euka_dir", str(tmp_path), "-g", str(tmp_path / "r.gam"), "-o", str(tmp_path / "out"))
         assert r.returncode == 1 and "no HIP device" in r.stderr and not list(tmp_path.glob("out_*"))
+
+
+def test_soibean_cli_validation_errors(tmp_path):
+    """`vgan soibean` flag checks (reference src/soibean.cpp:263-441)."""
+    for args, msg in ((("-g", "x.gam"), "No database specified"), (("--dbprefix", "T", "-t", "0"), "invalid number of threads"),
+                      (("--dbprefix", "T", "-fq1", "r.fasta"), "must be FASTQ, not FASTA"), (("--dbprefix", "T", "-fq1", "r.fq"), "giraffe"),
+                      (("--dbprefix", "T", "--iter", "10", "--burnin", "20"), "must be higher than the burn-in"),
+                      (("--dbprefix", "T", "--deam5p", "x.prof"), "damage profiles do not exist"),
+                      (("--dbprefix", "T", "-P", "0"), "must be positive"), (("--dbprefix", "T", "--chains", "x"), "needs an integer"),
+                      (("--dbprefix", "T", "--nope"), "unrecognized option"), (("--dbprefix", "T", "--alignment-detail"), "not kept on the GPU path"),
+                      (("--dbprefix", "T", "--soibean_dir", str(tmp_path)), "T.gfa does not exist.")):
+        r = run("soibean", *args)
+        assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
+    assert run("soibean", "-h").returncode == 0
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_sb_chain_cpu import _newick_of
+    g = hc.synth_graph(seed=17, genome_len=900, n_nodes=600, n_paths=12)
+    a = hc.synth_reads(g, 60, seed=1, read_len=60)
+    g.write(str(tmp_path))
+    os.rename(str(tmp_path / "graph.gfa"), str(tmp_path / "T.gfa"))
+    r = run("soibean", "--dbprefix", "T", "--soibean_dir", str(tmp_path))
+    assert r.returncode == 1 and "T.new.dnd does not exist." in r.stderr
+    (tmp_path / "tree_dir").mkdir()
+    (tmp_path / "tree_dir" / "T.new.dnd").write_text(_newick_of(g))
+    a.write_gam(str(tmp_path / "r.gam"))
+    r = run("soibean", "--dbprefix", "T", "--soibean_dir", str(tmp_path), "-g", str(tmp_path / "r.gam"))
+    assert r.returncode == 1 and "Failed to open the base frequency file." in r.stderr
+    (tmp_path / "soibean_db.baseFreq").write_text("T .3 .2 .2 .3\n")
+    (tmp_path / "tree_dir" / "T.new.dnd").write_text("(a:1,b:2)c;")
+    r = run("soibean", "--dbprefix", "T", "--soibean_dir", str(tmp_path), "-g", str(tmp_path / "r.gam"))
+    assert r.returncode == 1 and "number of tree nodes and paths in the graph is unequal" in r.stderr
+    (tmp_path / "tree_dir" / "T.new.dnd").write_text(_newick_of(g))
+    if N.lib().vgan_device_count() <= 0:
+        r = run("soibean", "--dbprefix", "T", "--soibean_dir", str(tmp_path), "-g", str(tmp_path / "r.gam"), "-o", str(tmp_path / "o_"))
+        assert r.returncode == 1 and "no HIP device" in r.stderr and not list(tmp_path.glob("o_*"))
 
 
 def test_cli_needs_a_gpu_not_a_fallback(tmp_path):

@@ -134,3 +134,116 @@ def test_special_reads():
     k1 = [[(1, 0, 0.02, 0.3, 1.0)], [(2, 0, 0.05, 0.9, 1.0)]]
     k3 = [[(1, 0, 0.02, 0.3, 0.2), (2, 0, 0.05, 0.9, 0.5), (0, 1, 0.01, 0.5, 0.3)]]
     run_case(g, a, texts, 7, k1, k3)
+
+
+def _same_tables(a, b, rel):
+    """Tab-separated text files field by field: words identical, numbers within rel."""
+    la, lb = a.decode().splitlines(), b.decode().splitlines()
+    assert len(la) == len(lb)
+    for x, y in zip(la, lb):
+        fx, fy = x.split("\t"), y.split("\t")
+        assert len(fx) == len(fy), (x, y)
+        for u, v in zip(fx, fy):
+            try:
+                fu, fv = float(u), float(v)
+            except ValueError:
+                assert u == v, (x, y)
+                continue
+            assert fu == pytest.approx(fv, rel=rel, abs=1e-12) or (np.isnan(fu) and np.isnan(fv)), (x, y)
+
+
+def _chain_files(prefix):
+    import glob
+    import gzip
+    out = {}
+    for p in sorted(glob.glob(prefix + "*")):
+        raw = open(p, "rb").read()
+        out[os.path.basename(p)[len(os.path.basename(prefix)):]] = gzip.decompress(raw) if p.endswith(".mcmc") else raw
+    return out
+
+
+def _soibean_case(n_reads=600):
+    from test_sb_chain_cpu import _newick_of
+    g = hc.synth_graph(seed=17, genome_len=6000, n_nodes=4000, n_paths=28)
+    a = hc.synth_reads(g, n_reads, seed=6, read_len=60, indel_rate=0.1, softclip_rate=0.1)
+    d = os.path.join(GOLD, "damageProfiles")
+    return g, a, (d + "/dhigh5p.prof", d + "/dhigh3p.prof"), _newick_of(g)
+
+
+def test_chain_over_the_gpu_refresh_follows_the_oracle_chain(tmp_path):
+    """vgan_sb_estimate with the device engine vs the oracle's restatement of run_tree_proportion / processMCMCiterations with
+    its own likelihood: same seed, so the same proposals; the likelihoods agree to ~1e-11, so every accept / reject decision
+    and every recorded state does too."""
+    g, a, profs, newick = _soibean_case()
+    texts = tuple(open(p).read() for p in profs)
+    dm = ek.Damage.from_text(*texts)
+    hb = sb.SbHostBatch(g, a)
+    ctx = sb.SbContext(g, dm, penalty=7)
+    ctx.precompute(hb)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    o = orc.SbOracle(og, oa, orc.OrcDamage(*texts), penalty=7, path_findable=np.ones(g.n_paths, np.uint8))
+    tree = sb.Tree.parse(newick)
+    node_path = tree.node_paths(g.path_names)
+    _, sig, n_ok = ctx.best_paths()
+    paths = sb.signature_paths(sig, n_ok, cutk=2)
+    inv = {int(p): v for v, p in enumerate(node_path)}
+    sig_nodes = [inv[int(p)] for p in paths]
+    kw = dict(con=0.004, iters=120, burnin=30, chains=2, seed=9)
+    sb.estimate(ctx, tree, node_path, sig_nodes, str(tmp_path / "gpu_"), g.n_paths, FREQS, **kw)
+    o.estimate(newick, g.path_names, sig_nodes, str(tmp_path / "orc_"), FREQS, **kw)
+    fg, fo = _chain_files(str(tmp_path / "gpu_")), _chain_files(str(tmp_path / "orc_"))
+    assert sorted(fg) == sorted(fo) and len(fg) == len(sig_nodes) * 7
+    for name in fg:
+        _same_tables(fg[name], fo[name], 1e-6 if name.endswith(".txt") else 1e-9)
+    moves = "".join(fg[n].decode() for n in fg if n.startswith("Trace"))
+    assert "rejected" in moves and "accepted" in moves
+
+
+def test_vgan_soibean_cli_end_to_end(tmp_path):
+    import shutil
+    import subprocess
+    g, a, profs, newick = _soibean_case(n_reads=500)
+    db = tmp_path / "db"
+    (db / "tree_dir").mkdir(parents=True)
+    g.write(str(db))
+    shutil.move(str(db / "graph.gfa"), str(db / "Synth.gfa"))
+    (db / "tree_dir" / "Synth.new.dnd").write_text(newick + "\n")
+    (db / "soibean_db.baseFreq").write_text("Other .25 .25 .25 .25\nSynth .31 .25 .15 .29\n")
+    gam = str(tmp_path / "reads.gam")
+    a.write_gam(gam)
+    exe = os.path.join(os.path.dirname(GOLD), "..", "vgan_amd", "bin", "vgan")
+    out = str(tmp_path / "bean_")
+    r = subprocess.run([exe, "soibean", "-g", gam, "--soibean_dir", str(db), "--dbprefix", "Synth", "--deam5p", profs[0], "--deam3p", profs[1],
+                        "-k", "2", "--iter", "100", "--burnin", "20", "--chains", "2", "--seed", "5", "-o", out, "-t", "-1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Number of paths: 28" in r.stderr and "Initial log-likelihood" in r.stderr
+    start = [int(x) for x in r.stderr.split("Random starting nodes: ")[1].splitlines()[0].split()]
+    assert len(start) == 2
+    # the oracle on the same files, same starting nodes, same seed
+    texts = tuple(open(p).read() for p in profs)
+    g2 = hc.Graph.load(str(db / "Synth.gfa"), None)
+    a2 = hc.AlnSet.read_gam(gam)
+    og, oa = util.orc_graph_from_product(g2), util.orc_alnset_from_product(a2)
+    o = orc.SbOracle(og, oa, orc.OrcDamage(*texts), penalty=7, path_findable=np.ones(g2.n_paths, np.uint8))
+    fr = [.31, .25, .15, .29]
+    f7 = fr + [fr[0] + fr[2], fr[1] + fr[3],
+               1 / (2 * ((22 * (fr[0] * fr[2])) + (22 * (fr[1] * fr[3])) + (fr[0] * fr[1] + (fr[0] * fr[3]) + (fr[2] * fr[1] + (fr[2] * fr[3])))))]
+    tree = sb.Tree.parse(newick)
+    # soibean.cpp:576-602 starts the search for the shortest branch at nodes[0] -- the root, length 0 -- so nothing is ever
+    # shorter and con falls back to 0.01 (the CLI does the same)
+    shortest = tree.dist[0]
+    for d in tree.dist:
+        if d < shortest and d != 0.0:
+            shortest = d
+    con = shortest if (shortest != 0 and shortest < 1) else 0.01
+    assert con == 0.01
+    o.estimate(newick, g2.path_names, start, str(tmp_path / "orc_"), f7, con=con, iters=100, burnin=20, chains=2, seed=5)
+    fg, fo = _chain_files(out), _chain_files(str(tmp_path / "orc_"))
+    assert sorted(fg) == sorted(fo) and len(fg) == 14
+    for name in fg:
+        _same_tables(fg[name], fo[name], 1e-6 if name.endswith(".txt") else 1e-9)
+    # without -k: the initial estimate from the signature counts; --no-mcmc stops after the initial log-likelihoods
+    r = subprocess.run([exe, "soibean", "-g", gam, "--soibean_dir", str(db), "--dbprefix", "Synth", "--no-mcmc", "-o", str(tmp_path / "nm_")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "Identified signature paths" in r.stderr and r.stderr.count("Initial log-likelihood") >= 1

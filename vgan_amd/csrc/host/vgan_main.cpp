@@ -29,7 +29,8 @@
 
 #include "cli_util.h"
 
-int euka_main(int argc, char **argv); // vgan_euka_main.cpp
+int euka_main(int argc, char **argv);    // vgan_euka_main.cpp
+int soibean_main(int argc, char **argv); // vgan_soibean_main.cpp
 
 namespace {
 using namespace vgan_cli;
@@ -253,9 +254,9 @@ std::string usage() {
     return "vgan (MI355X build): per-read likelihood hot path on the GPU\n\n"
            "   vgan haplocart   mitochondrial haplogroup prediction (see: vgan haplocart -h)\n"
            "   vgan euka        abundance estimation of eukaryotic taxa (see: vgan euka -h)\n"
+           "   vgan soibean     sources of one taxon and their proportions (see: vgan soibean -h)\n"
            "   vgan version\n\n"
-           "soibean is reached through the C-ABI of this build (include/vgan_gpu.h); the CPU-only subcommands of the\n"
-           "reference are not part of it.\n";
+           "The CPU-only subcommands of the reference are not part of this build.\n";
 }
 
 } // namespace
@@ -269,6 +270,7 @@ int main(int argc, char **argv) {
         const std::string cmd = argv[1];
         if (cmd == "haplocart") return haplocart(argc - 1, argv + 1);
         if (cmd == "euka") return euka_main(argc - 1, argv + 1);
+        if (cmd == "soibean") return soibean_main(argc - 1, argv + 1);
         if (cmd == "version") {
             std::cout << "vgan-mi355x ABI " << vgan_abi_version() << std::endl;
             return 0;
