@@ -159,6 +159,102 @@ int main(int argc, char **argv) {
     vgan_graph_free(g);
     vgan_damage_free(dm);
     REQUIRE(vgan_damage_from_text("A>C\tA>G\n0\t0\n", "", &dm) != 0);
+
+    // soibean chain driver over a stand-in engine (the likelihood of a state is a smooth function of its positions), on one
+    // of the shipped trees; malformed Newick texts are errors
+    {
+        vgan_tree *tr = nullptr;
+        REQUIRE(vgan_tree_load((golden + "/trees/Ursidae.new.dnd").c_str(), &tr) == 0);
+        vgan_tree_view tv;
+        REQUIRE(vgan_tree_view_get(tr, &tv) == 0 && tv.n_nodes > 10 && tv.n_leaves > 5);
+        std::vector<int32_t> node_path(tv.n_nodes);
+        for (uint32_t v = 0; v < tv.n_nodes; ++v) node_path[v] = (int32_t)v;
+        vgan_sb_engine eng;
+        eng.user = nullptr;
+        eng.refresh = [](void *, uint32_t k, const vgan_sb_source *src, double, const double *, double *ll, uint64_t *guard) {
+            double v = -100.0;
+            for (uint32_t y = 0; y < k; ++y) v -= 3.0 * (src[y].pos - 0.3) * (src[y].pos - 0.3) + 0.01 * src[y].child + src[y].theta;
+            *ll = v;
+            *guard = 0;
+            return 0;
+        };
+        eng.mixture = [](void *, uint32_t n, const int32_t *, double, double *ll) {
+            *ll = -50.0 * n;
+            return 0;
+        };
+        vgan_sb_estimate_cfg cfg{};
+        cfg.max_iter = 400;
+        cfg.burn = 100;
+        cfg.chains = 3;
+        cfg.n_paths = tv.n_nodes;
+        cfg.seed = 12;
+        cfg.con = 0.01;
+        cfg.run_mcmc = 1;
+        cfg.quiet = 1;
+        const int32_t start[3] = {1, (int32_t)tv.n_nodes - 1, 0};
+        REQUIRE(vgan_sb_estimate(&eng, tr, node_path.data(), start, 3, &cfg, (tmp + "/bean_").c_str()) == 0);
+        REQUIRE(!slurp(tmp + "/bean_Diagnostics30.txt").empty() && !slurp(tmp + "/bean_Result31.mcmc").empty());
+        cfg.burn = cfg.max_iter;
+        REQUIRE(vgan_sb_estimate(&eng, tr, node_path.data(), start, 1, &cfg, (tmp + "/bean2_").c_str()) != 0);
+        vgan_tree_free(tr);
+        for (const char *bad : {"", "(", "(a,b", "(a:1,b:)c;", "((((((", "a:1e999999999;x"}) {
+            vgan_tree *t2 = nullptr;
+            if (vgan_tree_parse(bad, &t2) == 0) vgan_tree_free(t2);
+        }
+    }
+    // euka downstream: detected clades, abundance chain and the output files on a made-up result
+    {
+        REQUIRE(vgan_euka_db_load((golden + "/euka_dir/euka_db.clade").c_str(), (golden + "/euka_dir/euka_db.bins").c_str(), &db) == 0);
+        vgan_euka_db_view dv;
+        REQUIRE(vgan_euka_db_view_get(db, &dv) == 0);
+        const uint32_t C = dv.n_clades, NB = dv.bin_off[C];
+        std::vector<int32_t> count(C, 0), rclade;
+        std::vector<uint32_t> shift((size_t)C * 10 * 16, 3);
+        std::vector<double> cov(NB, 0.0), sll(C, 0.0);
+        std::vector<int64_t> nl(C, 0);
+        std::vector<uint8_t> rpass;
+        std::vector<uint16_t> rlen;
+        for (uint32_t c = 0; c < C; c += 7) {
+            count[c] = 40 + (int32_t)c;
+            nl[c] = 60 + c;
+            sll[c] = -0.3 * (double)nl[c];
+            for (uint32_t j = dv.bin_off[c]; j < dv.bin_off[c + 1]; ++j) cov[j] = 2.5 + j % 3;
+            for (int k = 0; k < 5; ++k) {
+                rclade.push_back((int32_t)c);
+                rpass.push_back(k != 2);
+                rlen.push_back((uint16_t)(60 + k));
+            }
+        }
+        vgan_euka_results res{};
+        res.db = &dv;
+        res.clade_count = count.data();
+        res.baseshift = shift.data();
+        res.bin_cov = cov.data();
+        res.n_like = nl.data();
+        res.sum_log_like = sll.data();
+        res.n_reads = (int64_t)rclade.size();
+        res.read_clade = rclade.data();
+        res.read_pass = rpass.data();
+        res.read_seq_len = rlen.data();
+        vgan_euka_report_cfg rc2{};
+        rc2.detect = {1, 10, 0, 0.0};
+        rc2.length_to_prof = 5;
+        rc2.run_mcmc = 1;
+        rc2.iter = 300;
+        rc2.burnin = 30;
+        rc2.seed = 4;
+        std::vector<int32_t> det(C + 1);
+        std::vector<double> est((size_t)(C + 1) * 5);
+        int32_t nd2 = 0;
+        REQUIRE(vgan_euka_report(&res, &rc2, (tmp + "/euka").c_str(), det.data(), &nd2, est.data()) == 0 && nd2 >= 2);
+        rc2.run_mcmc = 0;
+        REQUIRE(vgan_euka_report(&res, &rc2, (tmp + "/euka_nm").c_str(), det.data(), &nd2, est.data()) == 0);
+        rc2.run_mcmc = 1;
+        rc2.iter = 10;
+        rc2.burnin = 10;
+        REQUIRE(vgan_euka_report(&res, &rc2, (tmp + "/euka_bad").c_str(), det.data(), &nd2, est.data()) != 0);
+        vgan_euka_db_free(db);
+    }
     puts("host sanitizer driver: ok");
     return 0;
 }

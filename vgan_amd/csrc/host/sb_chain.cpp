@@ -4,7 +4,8 @@
 // (run_tree_proportion), src/MCMC.h:424-505,507-625 (state initialisation, quantiles, patristic distances),
 // src/miscfunc.h:12-66 (mean / variance / autocorrelation / effective sample size), src/soibean.cpp:157-202,738-944.
 //
-// The likelihood itself is not computed here: the chain calls a vgan_sb_engine (the device context, vgan_sb_engine_gpu).
+// The likelihood itself is not computed here: the chain calls a vgan_sb_engine (vgan_sb_engine_gpu in sb_capi.hip binds the
+// device context); this file has no device dependency.
 //
 // Definitions where the reference leaves the behaviour open (all documented in include/vgan_gpu.h):
 //  * randomness: every std::random_device call is replaced by the next output of the caller's seed stream (seed 0 = the
@@ -551,13 +552,6 @@ class Estimator {
     std::mt19937 walk_, theta_engine_;
 };
 
-int gpu_refresh(void *user, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7, double *out, uint64_t *guard) {
-    return vgan_sb_loglike((vgan_sb_ctx *)user, 1, k, src, con, freqs7, out, nullptr, guard);
-}
-int gpu_mixture(void *user, uint32_t n, const int32_t *paths, double log_freq, double *out) {
-    return vgan_sb_mixture_loglike((vgan_sb_ctx *)user, n, paths, log_freq, out);
-}
-
 } // namespace
 
 extern "C" int vgan_tree_parse(const char *newick, vgan_tree **out) {
@@ -610,14 +604,6 @@ extern "C" int vgan_tree_view_get(const vgan_tree *t, vgan_tree_view *out) {
 }
 
 extern "C" void vgan_tree_free(vgan_tree *t) { delete t; }
-
-extern "C" int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out) {
-    if (!c || !out) return fail(VGAN_EINVAL, "vgan_sb_engine_gpu: null argument");
-    out->user = c;
-    out->refresh = gpu_refresh;
-    out->mixture = gpu_mixture;
-    return VGAN_OK;
-}
 
 extern "C" int vgan_sb_estimate(const vgan_sb_engine *engine, const vgan_tree *tree, const int32_t *node_path, const int32_t *sig_nodes,
                                 uint32_t n_sig, const vgan_sb_estimate_cfg *cfg, const char *out_prefix) {

@@ -378,6 +378,22 @@ extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, co
     return VGAN_OK;
 }
 
+// the chain driver's view of this context (host/sb_chain.cpp, vgan_sb_estimate)
+static int engine_refresh(void *user, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7, double *out, uint64_t *guard) {
+    return vgan_sb_loglike((vgan_sb_ctx *)user, 1, k, src, con, freqs7, out, nullptr, guard);
+}
+static int engine_mixture(void *user, uint32_t n, const int32_t *paths, double log_freq, double *out) {
+    return vgan_sb_mixture_loglike((vgan_sb_ctx *)user, n, paths, log_freq, out);
+}
+
+extern "C" int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out) {
+    if (!c || !out) return fail(VGAN_EINVAL, "vgan_sb_engine_gpu: null argument");
+    out->user = c;
+    out->refresh = engine_refresh;
+    out->mixture = engine_mixture;
+    return VGAN_OK;
+}
+
 extern "C" int vgan_sb_kernel_ms(vgan_sb_ctx *c, double ms[2], uint64_t launches[2]) {
     if (!c) return fail(VGAN_EINVAL, "vgan_sb_kernel_ms: null context");
     HIPCHK(hipSetDevice(c->device));
