@@ -433,7 +433,9 @@ def test_small_path_counts_and_large_node_counts(P, n_nodes, genome):
         ctx.accumulate(b)
         got = ctx.finalize()
         assert util.rel_err(got, ref) < RTOL, mode
-    assert ctx.argmax(got) == int(np.argmax(ref))
+    # paths with the same support over every read tie exactly in exact arithmetic; which of them wins depends on the last bit
+    # (and the device sums in a scheduling-dependent order), so: the chosen path is a maximum of the oracle's vector
+    assert ref[ctx.argmax(got)] >= ref.max() - 1e-9 * abs(ref.max())
 
 
 def test_batch_validation(tmp_path):
