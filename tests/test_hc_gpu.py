@@ -71,8 +71,8 @@ def test_bundled_alignments_as_plumbing(golden_dir):
         ctx.accumulate(b)
         got = ctx.finalize()
         assert util.rel_err(got, ref) < RTOL
-        if b.n_reads:
-            assert ctx.argmax(got) == int(np.argmax(ref))
+        if b.n_reads:  # exactly tied paths may resolve either way in the last bit
+            assert ref[ctx.argmax(got)] >= ref.max() - 1e-9 * abs(ref.max())
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(background_error_prob=0.01, use_background_error_prob=True, is_consensus_fasta=True),
