@@ -161,19 +161,26 @@ long double variance_of(const std::vector<long double> &v, long double m) {
     return s / (v.size() - 1);
 }
 
-long double autocorr(const std::vector<long double> &v, int lag) {
-    const long double m = mean_of(v), denom = variance_of(v, m);
+// autocorrelation(v, lag) of miscfunc.h recomputes mean and variance of v on every call; they do not depend on the lag, so
+// the effective-sample-size loop (hundreds of lags on a slowly mixing chain) passes them in -- same values, same arithmetic
+long double autocorr(const std::vector<long double> &v, int lag, long double m, long double denom) {
     double numer = 0.0;
     for (size_t i = 0; i + (size_t)lag < v.size(); ++i) numer = (double)(numer + (v[i] - m) * (v[i + (size_t)lag] - m));
     return numer / ((v.size() - (size_t)lag) * denom);
 }
 
+long double autocorr(const std::vector<long double> &v, int lag) {
+    const long double m = mean_of(v);
+    return autocorr(v, lag, m, variance_of(v, m));
+}
+
 double effective_sample_size(const std::vector<long double> &v) {
+    const long double m = mean_of(v), denom = variance_of(v, m);
     const int max_lag = (int)(v.size() / 2);
-    double even = 1.0, odd = (double)autocorr(v, 1), total = even + odd;
+    double even = 1.0, odd = (double)autocorr(v, 1, m, denom), total = even + odd;
     for (int t = 1; t < max_lag - 2 && even + odd > 0; t += 2) {
-        even = (double)autocorr(v, t + 1);
-        odd = (double)autocorr(v, t + 2);
+        even = (double)autocorr(v, t + 1, m, denom);
+        odd = (double)autocorr(v, t + 2, m, denom);
         total += 2.0 * (even + odd);
     }
     if (even + odd < 0) total -= even + odd;
