@@ -35,7 +35,7 @@ for n in (20000, 1000000):
         dt = (time.perf_counter() - t) / calls
         km = ctx.kernel_ms()["refresh"]
         print("reads %8d k=%d: vgan_sb_loglike %.1f us per call (ctypes included), refresh kernels %.1f us" % (n, k, dt * 1e6, km[0] / max(km[1], 1) * 1e3))
-        # the engine's refresh (what vgan_sb_estimate calls): a replayed HIP graph
+        # the engine's refresh (what vgan_sb_estimate calls): fused kernel + fold into pinned host memory
         import ctypes as C
         from vgan_amd import _native as N
         e = N.SbEngine()
@@ -50,7 +50,7 @@ for n in (20000, 1000000):
         for _ in range(calls):
             e.refresh(e.user, k, C.cast(arr, C.c_void_p), 0.01, f7, C.byref(out), C.byref(gd))
         dt = (time.perf_counter() - t) / calls
-        print("reads %8d k=%d: engine refresh (graph replay) %.1f us per call, identical result" % (n, k, dt * 1e6))
+        print("reads %8d k=%d: engine refresh (fused, two launches) %.1f us per call, identical result" % (n, k, dt * 1e6))
     # the chain driver itself (one chain, k = 2): iterations per second including the host side
     import tempfile
     d = tempfile.mkdtemp()

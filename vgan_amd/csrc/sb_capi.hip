@@ -68,34 +68,14 @@ struct vgan_sb_ctx {
     Buf<int32_t> best, mix_paths;
     Buf<unsigned long long> sig;
     std::vector<char> h_params; // host staging of one refresh's parameters
-    // the chain driver's refresh (one state per call, launch bound): the copy-in / three kernels / copy-out sequence is
-    // captured once per (k, con) into a HIP graph over pinned staging buffers and replayed every iteration
-    struct RefreshGraph {
-        uint32_t k = 0;
-        double con = 0.0;
-        hipStream_t stream = nullptr;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-    };
-    std::vector<RefreshGraph> graphs;
-    char *pin = nullptr; // [SbSourceDev x SB_GRAPH_MAX_K][7 doubles] | out double | guard u64
-    bool graphs_disabled = false;
+    // the chain driver's refresh (one state per call, launch bound) is one kernel writing into pinned host memory
+    char *pin = nullptr;                 // out double | guard u64
+    Buf<unsigned long long> ticket;      // guard count of the fused refresh, zero between refreshes
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[2] = {false, false};
     double ms[2] = {0, 0};
     uint64_t launches[2] = {0, 0};
 };
-
-constexpr uint32_t SB_GRAPH_MAX_K = 16;
-constexpr size_t SB_PIN_PARAMS = SB_GRAPH_MAX_K * sizeof(SbSourceDev) + 7 * 8;
-
-static void drop_graphs(vgan_sb_ctx *c) {
-    for (auto &g : c->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
-    c->graphs.clear();
-}
 
 static void resolve(vgan_sb_ctx *c, int i) {
     if (!c->pending[i]) return;
@@ -164,8 +144,8 @@ extern "C" void vgan_sb_destroy(vgan_sb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    drop_graphs(c);
     if (c->pin) (void)hipHostFree(c->pin);
+    c->ticket.release();
     c->mask.release();
     c->findable.release();
     c->sub5p.release();
@@ -203,7 +183,6 @@ extern "C" int vgan_sb_precompute(vgan_sb_ctx *c, const vgan_sb_batch *b, int64_
     if (!c || !b) return fail(VGAN_EINVAL, "vgan_sb_precompute: null argument");
     HIPCHK(hipSetDevice(c->device));
     resolve(c, 0);
-    drop_graphs(c); // they hold the table pointers and the read count
     const size_t R = b->n_reads, S = b->n_segments;
     int rc;
     if ((rc = c->pm.reserve((size_t)c->P * std::max<size_t>(R, 1))) ||
@@ -404,71 +383,44 @@ extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, co
     return VGAN_OK;
 }
 
-// One state, results to the host: the per-iteration call of the chain driver.  Replays a captured graph (see the context);
-// falls back to vgan_sb_loglike when capture is unavailable or k is beyond the pinned staging area.
+// One state, results to the host: the per-iteration call of the chain driver -- sb_refresh_fused_kernel with the sources as
+// kernel arguments, then a one-wave fold storing the two results into pinned host memory; bit-identical to vgan_sb_loglike.
 static int refresh_one(vgan_sb_ctx *c, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7, double *out, uint64_t *guard) {
     if (!c || !src || !freqs7 || !out) return fail(VGAN_EINVAL, "vgan_sb_engine refresh: null argument");
-    if (k == 0 || k > SB_GRAPH_MAX_K || c->graphs_disabled) return vgan_sb_loglike(c, 1, k, src, con, freqs7, out, nullptr, guard);
+    if (k == 0 || k > SB_FUSED_MAX_K) return vgan_sb_loglike(c, 1, k, src, con, freqs7, out, nullptr, guard);
     HIPCHK(hipSetDevice(c->device));
-    if (!c->pin) HIPCHK(hipHostMalloc((void **)&c->pin, SB_PIN_PARAMS + 16, hipHostMallocDefault));
-    SbSourceDev *sd = reinterpret_cast<SbSourceDev *>(c->pin);
+    SbFusedArgs a;
     for (uint32_t i = 0; i < k; ++i) {
         if (src[i].child < 0 || src[i].parent < 0 || (uint32_t)src[i].child >= c->P || (uint32_t)src[i].parent >= c->P)
             return fail(VGAN_EINVAL, "vgan_sb_loglike: path index out of range");
         double t = src[i].dist;
         if (t == 0.0) t = 0.00001; // MCMC.cpp:753-755,893-895
-        sd[i].child = src[i].child;
-        sd[i].parent = src[i].parent;
-        sd[i].t1 = src[i].pos * t;
-        sd[i].t2 = t - sd[i].t1;
-        sd[i].pos = src[i].pos;
-        sd[i].log_pos = log(src[i].pos);
-        sd[i].log_1mpos = log((1 - src[i].pos));
-        sd[i].log_theta = log(src[i].theta);
+        SbSourceDev &d = a.src[i];
+        d.child = src[i].child;
+        d.parent = src[i].parent;
+        d.t1 = src[i].pos * t;
+        d.t2 = t - d.t1;
+        d.pos = src[i].pos;
+        d.log_pos = log(src[i].pos);
+        d.log_1mpos = log((1 - src[i].pos));
+        d.log_theta = log(src[i].theta);
     }
-    memcpy(c->pin + k * sizeof(SbSourceDev), freqs7, 7 * 8);
-    double *pin_out = reinterpret_cast<double *>(c->pin + SB_PIN_PARAMS);
-    unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + SB_PIN_PARAMS + 8);
-    vgan_sb_ctx::RefreshGraph *g = nullptr;
-    for (auto &e : c->graphs)
-        if (e.k == k && e.con == con && e.stream == c->stream) g = &e;
-    if (!g) {
-        const uint32_t R = c->t.n_reads;
-        const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
-        int rc;
-        if ((rc = c->src.reserve(SB_GRAPH_MAX_K + 2)) || (rc = c->hky.reserve((size_t)SB_GRAPH_MAX_K * 2 * SB_NCNT)) ||
-            (rc = c->partial.reserve(n_blocks)) || (rc = c->out.reserve(1)) || (rc = c->guard.reserve(1)))
-            return rc;
-        resolve(c, 1);
-        HIPCHK(hipStreamSynchronize(c->stream));
-        vgan_sb_ctx::RefreshGraph ng;
-        ng.k = k;
-        ng.con = con;
-        ng.stream = c->stream;
-        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            const size_t bytes = k * sizeof(SbSourceDev) + 7 * 8;
-            ok = hipMemcpyAsync(c->src.p, c->pin, bytes, hipMemcpyHostToDevice, c->stream) == hipSuccess;
-            const double *d_freqs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(c->src.p) + k * sizeof(SbSourceDev));
-            launch_sb_hky(k, c->src.p, con, d_freqs, c->hky.p, c->guard.p, 1, c->stream);
-            launch_sb_loglike(c->t, c->P, 1, k, c->src.p, c->hky.p, c->partial.p, n_blocks, c->out.p, nullptr, c->guard.p, c->stream);
-            ok = ok && hipMemcpyAsync(pin_out, c->out.p, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-            ok = ok && hipMemcpyAsync(pin_guard, c->guard.p, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-            ok = (hipStreamEndCapture(c->stream, &ng.graph) == hipSuccess) && ok && ng.graph;
-            ok = ok && hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) == hipSuccess;
-        }
-        if (!ok) { // no graphs on this runtime: the plain path from now on
-            (void)hipGetLastError();
-            if (ng.exec) (void)hipGraphExecDestroy(ng.exec);
-            if (ng.graph) (void)hipGraphDestroy(ng.graph);
-            c->graphs_disabled = true;
-            return vgan_sb_loglike(c, 1, k, src, con, freqs7, out, nullptr, guard);
-        }
-        if (c->graphs.size() >= 8) drop_graphs(c);
-        c->graphs.push_back(ng);
-        g = &c->graphs.back();
+    for (uint32_t i = k; i < SB_FUSED_MAX_K; ++i) a.src[i] = a.src[0];
+    memcpy(a.freqs7, freqs7, 7 * 8);
+    a.con = con;
+    const uint32_t R = c->t.n_reads;
+    const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
+    int rc;
+    if ((rc = c->partial.reserve(n_blocks))) return rc;
+    if (!c->pin) HIPCHK(hipHostMalloc((void **)&c->pin, 16, hipHostMallocDefault));
+    if (!c->ticket.p) {
+        if ((rc = c->ticket.reserve(2))) return rc;
+        HIPCHK(hipMemsetAsync(c->ticket.p, 0, 16, c->stream));
     }
-    HIPCHK(hipGraphLaunch(g->exec, c->stream));
+    double *pin_out = reinterpret_cast<double *>(c->pin);
+    unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + 8);
+    launch_sb_refresh_fused(c->t, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, c->stream);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = *pin_out;
     if (guard) *guard = *pin_guard;

@@ -45,6 +45,14 @@ struct SbSourceDev {
     double log_pos, log_1mpos, log_theta, pos;
 };
 
+// kernel arguments of the single-launch refresh (the chain driver's per-iteration call)
+constexpr uint32_t SB_FUSED_MAX_K = 16;
+struct SbFusedArgs {
+    SbSourceDev src[SB_FUSED_MAX_K];
+    double freqs7[7];
+    double con;
+};
+
 void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, unsigned long long *n_bad,
                           hipStream_t st);
 void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states, uint32_t k, const SbSourceDev *src,
@@ -54,6 +62,10 @@ void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states
 void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky,
                    unsigned long long *guard, uint32_t n_states, hipStream_t st);
 
+// one state, two launches, no copies: out_host / guard_host are pinned host memory; guard = one zeroed device word (left
+// zeroed); partial: n_blocks doubles.  Bit-identical to launch_sb_hky + launch_sb_loglike for one state.
+void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
+                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st);
 // per-read best path (-1: tie or excluded read), per-path signature counts and the number of usable reads; counters zeroed by the caller
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
                           unsigned long long *n_ok, hipStream_t st);

@@ -164,15 +164,9 @@ __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDe
 
 // ---------------------------------------------------------------------------------------------- HKY tables
 // hky[e][which][ref*5+read]: which = 0 child (t2), 1 parent (t1); MCMC.h:111-296 minus the "+ detail.logLikelihood"
-__global__ void sb_hky_kernel(uint32_t n_entries, const SbSourceDev *__restrict__ src, double con,
-                              const double *__restrict__ freqs7, double *__restrict__ hky, unsigned long long *__restrict__ guard,
-                              uint32_t n_states) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_states) guard[i] = 0; // the refresh that follows counts into it
-    if (i >= n_entries * 2 * SB_NCNT) return;
-    const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
+__device__ __forceinline__ double sb_hky_entry(const SbSourceDev &s, uint32_t which, uint32_t j, double con, const double *__restrict__ freqs7) {
     const int ref = j / 5, rd = j % 5;
-    const double t = which ? src[e].t1 : src[e].t2;
+    const double t = which ? s.t1 : s.t2;
     const double fR = freqs7[4], fY = freqs7[5], mu = freqs7[6];
     const double kappa = 0.0; // 1/22 in integer arithmetic (MCMC.h:66)
     double P[4];
@@ -204,11 +198,55 @@ __global__ void sb_hky_kernel(uint32_t n_entries, const SbSourceDev *__restrict_
         else acc = fmax(acc, y) + log1p(exp(-fabs(acc - y)));
     }
     if (acc > 1e-8) acc = log(0.999999999);
-    hky[i] = acc;
+    return acc;
+}
+
+__global__ void sb_hky_kernel(uint32_t n_entries, const SbSourceDev *__restrict__ src, double con,
+                              const double *__restrict__ freqs7, double *__restrict__ hky, unsigned long long *__restrict__ guard,
+                              uint32_t n_states) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_states) guard[i] = 0; // the refresh that follows counts into it
+    if (i >= n_entries * 2 * SB_NCNT) return;
+    const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
+    hky[i] = sb_hky_entry(src[e], which, j, con, freqs7);
 }
 
 // ---------------------------------------------------------------------------------------------- refresh
 constexpr int SBL_THREADS = 256;
+
+// one read's contribution to a state's log-likelihood (MCMC.cpp:738-993): k sources, src / hk_s of that state
+__device__ __forceinline__ double sb_read_term(const SbTablesDev &t, uint32_t r, uint32_t k, const SbSourceDev *__restrict__ src,
+                                               const double *__restrict__ hk_s, unsigned long long &bad) {
+    const uint32_t R = t.n_reads;
+    double inter = -INFINITY;
+    for (uint32_t y = 0; y < k; ++y) {
+        const SbSourceDev s = src[y];
+        const double *hc = hk_s + (size_t)y * 2 * SB_NCNT, *hp = hc + SB_NCNT;
+        double LL = t.pm[(size_t)s.child * R + r], LLP = t.pm[(size_t)s.parent * R + r];
+        const uint16_t *cc = t.cnt + (size_t)s.child * SB_NCNT * R + r;
+        const uint16_t *cp = t.cnt + (size_t)s.parent * SB_NCNT * R + r;
+#pragma unroll
+        for (int j = 0; j < (int)SB_NCNT; ++j) {
+            LL += (double)cc[(size_t)j * R] * hc[j];
+            LLP += (double)cp[(size_t)j * R] * hp[j];
+        }
+        if (!(LL <= 0.0) || !(LLP <= 0.0) || isinf(LL) || isinf(LLP)) bad++; // MCMC.cpp:857-862,953-958
+        if (k == 1) { // calculateLogWeightedAverage (MCMC.h:299-315)
+            const double a = LL + s.log_pos, bb = LLP + s.log_1mpos;
+            const double mx = fmax(a, bb);
+            const double lse = mx + log(exp(a - mx) + exp(bb - mx));
+            const double lws = log(s.pos + (1 - s.pos));
+            inter = isinf(lws) ? -INFINITY : lse - lws;
+        } else { // :967-974
+            const double a = s.log_pos + LL, bb = s.log_1mpos + LLP;
+            const double inter2 = fmax(a, bb) + log1p(exp(-fabs(a - bb)));
+            const double yv = inter2 + s.log_theta;
+            if (inter == 0.0 || inter == -INFINITY) inter = yv;
+            else inter = fmax(inter, yv) + log1p(exp(-fabs(inter - yv)));
+        }
+    }
+    return inter;
+}
 
 __global__ __launch_bounds__(SBL_THREADS) void sb_loglike_kernel(SbTablesDev t, uint32_t n_states, uint32_t k,
                                                                   const SbSourceDev *__restrict__ src,
@@ -226,33 +264,7 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_loglike_kernel(SbTablesDev t, 
         unsigned long long bad = 0;
         for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
             if (!t.ok[r]) continue;
-            double inter = -INFINITY;
-            for (uint32_t y = 0; y < k; ++y) {
-                const SbSourceDev s = src[e * k + y];
-                const double *hc = hk_s + (size_t)(e * k + y) * 2 * SB_NCNT, *hp = hc + SB_NCNT;
-                double LL = t.pm[(size_t)s.child * R + r], LLP = t.pm[(size_t)s.parent * R + r];
-                const uint16_t *cc = t.cnt + (size_t)s.child * SB_NCNT * R + r;
-                const uint16_t *cp = t.cnt + (size_t)s.parent * SB_NCNT * R + r;
-#pragma unroll
-                for (int j = 0; j < (int)SB_NCNT; ++j) {
-                    LL += (double)cc[(size_t)j * R] * hc[j];
-                    LLP += (double)cp[(size_t)j * R] * hp[j];
-                }
-                if (!(LL <= 0.0) || !(LLP <= 0.0) || isinf(LL) || isinf(LLP)) bad++; // MCMC.cpp:857-862,953-958
-                if (k == 1) { // calculateLogWeightedAverage (MCMC.h:299-315)
-                    const double a = LL + s.log_pos, bb = LLP + s.log_1mpos;
-                    const double mx = fmax(a, bb);
-                    const double lse = mx + log(exp(a - mx) + exp(bb - mx));
-                    const double lws = log(s.pos + (1 - s.pos));
-                    inter = isinf(lws) ? -INFINITY : lse - lws;
-                } else { // :967-974
-                    const double a = s.log_pos + LL, bb = s.log_1mpos + LLP;
-                    const double inter2 = fmax(a, bb) + log1p(exp(-fabs(a - bb)));
-                    const double yv = inter2 + s.log_theta;
-                    if (inter == 0.0 || inter == -INFINITY) inter = yv;
-                    else inter = fmax(inter, yv) + log1p(exp(-fabs(inter - yv)));
-                }
-            }
+            const double inter = sb_read_term(t, r, k, src + (size_t)e * k, hk_s + (size_t)e * k * 2 * SB_NCNT, bad);
             sum += inter;
         }
         sum = wave_sum(sum);
@@ -280,6 +292,65 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(const double *__restrict_
     if (threadIdx.x == 0) {
         out[e] = s;
         if (out2) out2[e] = s; // the caller's device buffer (handed to RCCL)
+    }
+}
+
+// The chain driver's refresh: one state, no copies.  The sources and frequencies arrive as kernel arguments and every block
+// builds the HKY table it needs in LDS (150 entries for k = 3); a one-wave kernel then folds the partials in the order
+// sb_finish_kernel uses -- so the result is bit-identical to the three-kernel path -- and stores the log-likelihood and the
+// guard count straight into pinned host memory.  An MCMC iteration is launch bound at typical read counts (10 us of kernel
+// time at 20k reads): this takes it from five stream operations to two.  (Folding in the last block to finish, behind a
+// device-scope fence and a ticket per block, measured slower at 1024 blocks than the second launch.)
+__global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesDev t, uint32_t k, SbFusedArgs a, double *__restrict__ partial,
+                                                                        unsigned long long *__restrict__ guard) {
+    __shared__ double hk_s[SB_FUSED_MAX_K * 2 * SB_NCNT];
+    __shared__ SbSourceDev src_s[SB_FUSED_MAX_K];
+    __shared__ double red_s[SBL_THREADS / 64];
+#pragma unroll
+    for (uint32_t y = 0; y < SB_FUSED_MAX_K; ++y)
+        if (threadIdx.x == y && y < k) src_s[y] = a.src[y]; // constant indices into the kernel arguments
+    for (uint32_t i = threadIdx.x; i < k * 2 * SB_NCNT; i += SBL_THREADS) {
+        const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
+        SbSourceDev s;
+        s.t1 = 0.0, s.t2 = 0.0;
+#pragma unroll
+        for (uint32_t y = 0; y < SB_FUSED_MAX_K; ++y)
+            if (e == y) {
+                s.t1 = a.src[y].t1;
+                s.t2 = a.src[y].t2;
+            }
+        hk_s[i] = sb_hky_entry(s, which, j, a.con, a.freqs7);
+    }
+    __syncthreads();
+    const uint32_t R = t.n_reads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double sum = 0.0;
+    unsigned long long bad = 0;
+    for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
+        if (!t.ok[r]) continue;
+        sum += sb_read_term(t, r, k, src_s, hk_s, bad);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red_s[wave] = sum;
+    if (bad) atomicAdd(guard, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s2 = 0.0;
+        for (int w = 0; w < SBL_THREADS / 64; ++w) s2 += red_s[w];
+        partial[blockIdx.x] = s2;
+    }
+}
+
+__global__ __launch_bounds__(64) void sb_finish_host_kernel(const double *__restrict__ partial, uint32_t n_blocks,
+                                                            unsigned long long *__restrict__ guard, double *__restrict__ out_host,
+                                                            unsigned long long *__restrict__ guard_host) {
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        *out_host = s;
+        *guard_host = *guard;
+        *guard = 0; // ready for the next refresh (stream ordered)
     }
 }
 
@@ -356,6 +427,12 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_mixture_kernel(SbTablesDev t, 
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
+void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
+                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st) {
+    hipLaunchKernelGGL(sb_refresh_fused_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, k, a, partial, guard);
+    hipLaunchKernelGGL(sb_finish_host_kernel, dim3(1), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host);
+}
+
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
                           unsigned long long *n_ok, hipStream_t st) {
     if (t.n_reads == 0) return;
