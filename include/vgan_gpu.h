@@ -44,7 +44,9 @@ int vgan_device_count(void);       /* number of visible HIP devices (0 if none) 
 
 /* ------------------------------------------------------------------------------------------------
  * Graph (host side).  Replaces bdsg::ODGI + NodeInfo[] + the hcfiles sidecars.
- * .og (ODGI/sdsl binary) cannot be parsed without libbdsg: the graph is read from GFA (S and P lines).
+ * The graph is read from GFA (S and P lines) or from an ODGI .og file (detected by its magic number): node ids and
+ * sequences, path names in path-handle order and which paths visit each node -- the layout observed on the reference's
+ * fixture test/reconstructInputSeq/target_graph.og; a file that deviates from it is rejected (VGAN_EIO).  The GBWT is not read.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct vgan_graph vgan_graph; /* opaque */
 
@@ -63,7 +65,7 @@ typedef struct vgan_graph_view {
     const char *children_txt;
 } vgan_graph_view;
 
-/* Load <dir>/graph.gfa (or the path given) and, when present in hcfiles_dir, the sidecars path_supports,
+/* Load the GFA or ODGI file given and, when present in hcfiles_dir, the sidecars path_supports,
  * parsed_pangenome_mapping, mappability.tsv, graph_paths, parents.txt, children.txt (plain or .gz).
  * Missing path_supports => mask derived from the GFA P lines; missing pangenome mapping => running
  * coordinate in node-id order; missing mappability => 1.0. */

@@ -46,6 +46,29 @@ int main(int argc, char **argv) {
     vgan_aln_free(a);
     vgan_graph_free(g);
 
+    { // the ODGI reader on the reference's fixture and on damaged copies of it
+        vgan_graph *og = nullptr;
+        REQUIRE(vgan_graph_load((golden + "/reconstruct/target_graph.og").c_str(), nullptr, &og) == 0);
+        vgan_graph_view ov;
+        REQUIRE(vgan_graph_view_get(og, &ov) == 0 && ov.n_paths == 5 && ov.min_id == 2 && ov.max_id == 29);
+        vgan_graph_free(og);
+        const std::string og_raw = slurp(golden + "/reconstruct/target_graph.og");
+        std::mt19937 r2(3);
+        for (int trial = 0; trial < 300; ++trial) {
+            std::string dmg = og_raw;
+            if (trial % 3 == 0) dmg.resize(4 + r2() % (dmg.size() - 4));
+            else if (trial % 3 == 1)
+                for (int k = 0; k < 4; ++k) dmg[r2() % dmg.size()] = (char)(r2() & 0xff);
+            else {
+                const uint64_t v = ((uint64_t)r2() << 32 | r2()) >> (r2() % 64);
+                memcpy(&dmg[4 + r2() % (dmg.size() - 12)], &v, 8);
+            }
+            std::ofstream(tmp + "/d.og", std::ios::binary).write(dmg.data(), (std::streamsize)dmg.size());
+            vgan_graph *x = nullptr;
+            if (vgan_graph_load((tmp + "/d.og").c_str(), nullptr, &x) == 0) vgan_graph_free(x);
+        }
+    }
+
     // corrupted / truncated GAM payloads
     const std::string raw = slurp(golden + "/alignments/J2a1a1a1.gam");
     std::mt19937 rng(11);

@@ -67,7 +67,7 @@ def test_euka_cli_validation_errors(tmp_path):
                       (("-fq1", "x.fq", "-fq2", "y.fq", "-i"), "expects only one FASTQ file"), (("-fq1", "x.fq"), "giraffe"),
                       (("--minMQ", "61"), "0..60"), (("--iter", "-5"), "must not be negative"), (("--iter", "abc"), "needs an integer"),
                       (("--entropy", "x"), "needs a number"), (("--bogus",), "unrecognized option"), (("--iter",), "needs a value"),
-                      (("--euka_dir", str(tmp_path)), "euka_db.gfa does not exist.")):
+                      (("--euka_dir", str(tmp_path)), "euka_db.og does not exist.")):
         r = run("euka", *args)
         assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
     assert run("euka", "-h").returncode == 0
@@ -99,7 +99,7 @@ def test_soibean_cli_validation_errors(tmp_path):
                       (("--dbprefix", "T", "--deam5p", "x.prof"), "damage profiles do not exist"),
                       (("--dbprefix", "T", "-P", "0"), "must be positive"), (("--dbprefix", "T", "--chains", "x"), "needs an integer"),
                       (("--dbprefix", "T", "--nope"), "unrecognized option"), (("--dbprefix", "T", "--alignment-detail"), "not kept on the GPU path"),
-                      (("--dbprefix", "T", "--soibean_dir", str(tmp_path)), "T.gfa does not exist.")):
+                      (("--dbprefix", "T", "--soibean_dir", str(tmp_path)), "T.og does not exist.")):
         r = run("soibean", *args)
         assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
     assert run("soibean", "-h").returncode == 0

@@ -73,16 +73,63 @@ def test_gam_unmapped_filter_and_roundtrip(tmp_path):
         hc.AlnSet.parse_gam(gamio.gunzip_all(data)[:-7])
 
 
-def test_reconstruction_kats_through_product(golden_dir):
+@pytest.mark.parametrize("graph_file", ["target_graph.gfa", "target_graph.og"])
+def test_reconstruction_kats_through_product(golden_dir, graph_file):
+    """The reference's 10 reconstruction KATs (src/test.cpp:855-994); it runs them on target_graph.og, so does this."""
     d = os.path.join(golden_dir, "reconstruct")
-    g = hc.Graph.load(os.path.join(d, "target_graph.gfa"))
-    assert g.n_paths == 5 and g.path_names == ["seq_1", "seq_2", "seq_3", "seq_4", "seq_5"]
+    g = hc.Graph.load(os.path.join(d, graph_file))
+    assert g.n_paths == 5 and sorted(g.path_names) == ["seq_1", "seq_2", "seq_3", "seq_4", "seq_5"]
     a = hc.AlnSet.read_gam(os.path.join(d, "test_reads.gam"))
     for case in json.load(open(os.path.join(d, "expected.json")))["cases"]:
         gs, rs, sizes = hc.reconstruct(g, a, case["read"])
         assert gs.decode() == case["graph_seq"], case["name"]
         assert rs.decode() == case["read_seq"], case["name"]
         assert sizes == case["mppg_sizes"], case["name"]
+
+
+def test_odgi_graph_equals_its_gfa(golden_dir, tmp_path):
+    """The ODGI reader on the reference's fixture: node ids, sequences, path names and which paths visit each
+    node are those of the GFA of the same graph; damaged files are errors (or, when the damage is in a part the reader skips,
+    the same graph), never a crash."""
+    d = os.path.join(golden_dir, "reconstruct")
+    a = hc.Graph.load(os.path.join(d, "target_graph.gfa"))
+    b = hc.Graph.load(os.path.join(d, "target_graph.og"))
+    assert (a.min_id, a.max_id, a.n_paths) == (b.min_id, b.max_id, b.n_paths) == (2, 29, 5)
+    assert np.array_equal(a.node_seq, b.node_seq) and np.array_equal(a.node_seq_off, b.node_seq_off)
+    assert b.path_names == ["seq_5", "seq_1", "seq_4", "seq_2", "seq_3"]  # odgi's path handle order
+    col = {n: i for i, n in enumerate(a.path_names)}
+    ga, gb = np.asarray(a.pathsgo()), np.asarray(b.pathsgo())
+    for j, n in enumerate(b.path_names):
+        assert np.array_equal(ga[:, col[n]], gb[:, j]), n
+    raw = open(os.path.join(d, "target_graph.og"), "rb").read()
+    import random
+    rng = random.Random(5)
+    n_err = n_same = 0
+    for trial in range(400):
+        data = bytearray(raw)
+        kind = trial % 4
+        if kind == 0:
+            data = data[:rng.randrange(4, len(data))]
+        elif kind == 1:
+            for _ in range(rng.randrange(1, 6)):
+                data[rng.randrange(len(data))] = rng.randrange(256)
+        elif kind == 2:
+            i = rng.randrange(len(data))
+            data[i:i] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 9)))
+        else:
+            i = rng.randrange(4, len(data) - 8)
+            data[i:i + 8] = (rng.getrandbits(64) >> rng.randrange(64)).to_bytes(8, "little")
+        f = tmp_path / "x.og"
+        f.write_bytes(bytes(data))
+        try:
+            c = hc.Graph.load(str(f))
+        except N.NativeError as e:
+            assert e.code == N.VGAN_EIO
+            n_err += 1
+            continue
+        assert c.max_id == 29 and len(c.node_seq) == len(b.node_seq)
+        n_same += 1
+    assert n_err > 200 and n_same > 0
 
 
 def _check_flatten_against_oracle(g, a, batch):

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <sstream>
 #include <thread>
@@ -89,6 +90,7 @@ int load_gfa(const std::string &txt, vgan_graph &g) {
             if (!t3) t3 = e;
             int64_t id;
             if (!parse_i64(t1 + 1, t2, id) || id < 0) return fail(VGAN_EIO, "GFA: non-numeric segment name");
+            if (id >= ((int64_t)1 << 28)) return fail(VGAN_ERANGE, "GFA: segment id %lld is beyond the id-indexed graph layout (2^28)", (long long)id);
             seqs[id].assign(t2 + 1, t3);
         } else if (*b == 'P') {
             const char *t1 = (const char *)memchr(b, '\t', e - b);
@@ -130,6 +132,134 @@ int load_gfa(const std::string &txt, vgan_graph &g) {
     return VGAN_OK;
 }
 
+// ODGI binary graph (.og), as `odgi build` / vg write it and bdsg::ODGI::deserialize reads it (readPathHandleGraph.cpp:14-37
+// opens <dbprefix>.og this way).  odgi's sources are not part of the reference tree, so the layout below is the one observed
+// on the reference's own fixture test/reconstructInputSeq/target_graph.og (every node sequence, path name and path
+// membership checked against the GFA of the same graph, tests/test_host_frontend.py); anything that deviates from it is
+// rejected, not guessed at:
+//   u32 magic ab ad 79 34 | u64 max_rank, min_rank, node_count, edge_count, path_count, path_handle_next, deleted_count,
+//   id_increment (node id = rank + id_increment), one more u64 |
+//   per node in rank order: u32 seq_len, u32 edge_bytes, u32 edge_count, u64 blob_len (= seq_len + edge_bytes), the blob
+//     (sequence, then 2 bytes per edge end), then the packed path steps of the node: u64 n_words, the words, u64 max value,
+//     u64 n_values, u8 bit width, u8 values per word -- five values per step, the first one 2 * (path handle - 1) + strand |
+//   deleted-node bitmap and per-path metadata (skipped) | at the very end the name table: u64 path_count, then per path
+//   u64 name_len, the name, u64 path handle (1-based).
+// Kept: node ids and sequences, path names in handle order, which paths visit each node (not the order of the steps).
+constexpr uint32_t ODGI_MAGIC = 0x3479adabu;
+
+bool is_odgi(const std::string &bytes) {
+    uint32_t m = 0;
+    if (bytes.size() >= 4) memcpy(&m, bytes.data(), 4);
+    return m == ODGI_MAGIC;
+}
+
+int load_odgi(const std::string &bytes, vgan_graph &g) {
+    const unsigned char *d = (const unsigned char *)bytes.data();
+    const size_t n = bytes.size();
+    size_t p = 4;
+    auto u64_at = [&](size_t at, uint64_t &v) {
+        if (at + 8 > n) return false;
+        memcpy(&v, d + at, 8);
+        return true;
+    };
+    uint64_t h[9];
+    for (int i = 0; i < 9; ++i, p += 8)
+        if (!u64_at(p, h[i])) return fail(VGAN_EIO, "ODGI: truncated header");
+    const uint64_t max_rank = h[0], min_rank = h[1], node_count = h[2], path_count = h[4], deleted = h[6], incr = h[7];
+    if (node_count == 0 || node_count > (1ull << 31) || path_count > (1ull << 24) || incr > (1ull << 40) || deleted != 0 || min_rank != 0 ||
+        max_rank + 1 != node_count)
+        return fail(VGAN_EIO, "ODGI: unsupported header (nodes %llu, paths %llu, deleted %llu)", (unsigned long long)node_count,
+                    (unsigned long long)path_count, (unsigned long long)deleted);
+    // nothing is sized by a header field before the records behind it have been seen: a record takes at least 46 bytes
+    if (node_count > (n - p) / 46 || path_count > (n - p) / 17 || incr + node_count > (1ull << 28))
+        return fail(VGAN_EIO, "ODGI: %llu nodes from id %llu do not fit this file / the id-indexed graph layout", (unsigned long long)node_count,
+                    (unsigned long long)incr);
+    std::string all_seq;
+    std::vector<int64_t> rank_off((size_t)node_count + 1, 0);
+    std::vector<std::vector<std::pair<int64_t, bool>>> visits((size_t)path_count);
+    for (uint64_t r = 0; r < node_count; ++r) {
+        const int64_t id = (int64_t)(incr + r);
+        if (p + 20 > n) return fail(VGAN_EIO, "ODGI: truncated node record %llu", (unsigned long long)r);
+        uint32_t seq_len, edge_bytes, edge_count;
+        uint64_t blob_len;
+        memcpy(&seq_len, d + p, 4);
+        memcpy(&edge_bytes, d + p + 4, 4);
+        memcpy(&edge_count, d + p + 8, 4);
+        memcpy(&blob_len, d + p + 12, 8);
+        p += 20;
+        if ((uint64_t)seq_len + edge_bytes != blob_len || edge_bytes != 2 * (uint64_t)edge_count || blob_len > n - p)
+            return fail(VGAN_EIO, "ODGI: node record %llu does not have the known layout", (unsigned long long)r);
+        for (uint32_t i = 0; i < seq_len; ++i) {
+            const unsigned char c = d[p + i];
+            if (c < 'A' || c > 'z' || (c > 'Z' && c < 'a')) return fail(VGAN_EIO, "ODGI: node %lld holds a non-letter", (long long)id);
+        }
+        rank_off[(size_t)r] = (int64_t)all_seq.size();
+        all_seq.append((const char *)d + p, seq_len);
+        p += blob_len;
+        uint64_t n_words, max_value, n_values;
+        if (!u64_at(p, n_words) || n_words > (n - p) / 8) return fail(VGAN_EIO, "ODGI: truncated path steps of node %lld", (long long)id);
+        const size_t words_at = p + 8;
+        p = words_at + 8 * (size_t)n_words;
+        if (!u64_at(p, max_value) || !u64_at(p + 8, n_values) || p + 18 > n) return fail(VGAN_EIO, "ODGI: truncated path steps of node %lld", (long long)id);
+        const unsigned width = d[p + 16], per_word = d[p + 17];
+        p += 18;
+        if (width == 0 || width > 64 || per_word != 64 / width || (width < 64 && max_value != (1ull << width) - 1) || n_values % 5 != 0 ||
+            n_values > n_words * per_word)
+            return fail(VGAN_EIO, "ODGI: path steps of node %lld are not a packed vector of 5-tuples", (long long)id);
+        for (uint64_t s5 = 0; s5 < n_values; s5 += 5) {
+            uint64_t w;
+            memcpy(&w, d + words_at + 8 * (size_t)(s5 / per_word), 8);
+            const uint64_t v = (w >> ((s5 % per_word) * width)) & max_value;
+            const uint64_t handle = v / 2; // 0-based
+            if (handle >= path_count) return fail(VGAN_EIO, "ODGI: node %lld is on path %llu of %llu", (long long)id, (unsigned long long)handle + 1, (unsigned long long)path_count);
+            auto &vs = visits[(size_t)handle];
+            if (vs.empty() || vs.back().first != id) vs.emplace_back(id, (v & 1) != 0);
+        }
+    }
+    rank_off[(size_t)node_count] = (int64_t)all_seq.size();
+    // the name table closes the file: find the offset from which path_count well-formed entries run exactly to the end
+    std::vector<std::string> names((size_t)path_count);
+    bool found = path_count == 0;
+    for (size_t q = n >= 8 ? n - 8 : 0; !found && q >= p && q + 8 <= n; --q) {
+        uint64_t cnt;
+        u64_at(q, cnt);
+        if (cnt == path_count) {
+            size_t x = q + 8;
+            std::vector<std::string> got((size_t)path_count);
+            std::vector<char> seen((size_t)path_count, 0);
+            bool ok = true;
+            for (uint64_t i = 0; i < path_count && ok; ++i) {
+                uint64_t len, handle;
+                ok = u64_at(x, len) && len > 0 && len < 4096 && x + 8 + len + 8 <= n;
+                if (!ok) break;
+                memcpy(&handle, d + x + 8 + len, 8);
+                ok = handle >= 1 && handle <= path_count && !seen[(size_t)handle - 1];
+                if (!ok) break;
+                for (uint64_t k = 0; k < len && ok; ++k) ok = d[x + 8 + k] >= 0x20 && d[x + 8 + k] < 0x7f;
+                seen[(size_t)handle - 1] = 1;
+                got[(size_t)handle - 1].assign((const char *)d + x + 8, (size_t)len);
+                x += 16 + (size_t)len;
+            }
+            if (ok && x == n) {
+                names.swap(got);
+                found = true;
+            }
+        }
+        if (q == 0) break;
+    }
+    if (!found) return fail(VGAN_EIO, "ODGI: no path name table at the end of the file");
+    g.min_id = (int64_t)incr;
+    g.max_id = (int64_t)(incr + node_count - 1);
+    g.node_seq_off.assign((size_t)g.max_id + 2, 0);
+    for (uint64_t r = 0; r <= node_count; ++r) g.node_seq_off[(size_t)(incr + r)] = rank_off[(size_t)r];
+    g.node_seq.swap(all_seq);
+    g.path_names.clear();
+    for (auto &nm : names) g.path_names += nm + "\n";
+    g.n_paths = (uint32_t)path_count;
+    g.path_steps = std::move(visits); // membership in node-id order: enough for the mask, not the walk order of the path
+    return VGAN_OK;
+}
+
 void mask_from_steps(vgan_graph &g) {
     g.mask_words = (g.n_paths + 63) / 64;
     g.mask.assign((size_t)(g.max_id + 1) * g.mask_words, 0);
@@ -140,17 +270,17 @@ void mask_from_steps(vgan_graph &g) {
 
 } // namespace
 
-extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vgan_graph **out) {
+static int graph_load_impl(const char *gfa_path, const char *hcfiles_dir, vgan_graph **out) {
     if (!gfa_path || !out) return fail(VGAN_EINVAL, "vgan_graph_load: null argument");
     PhaseTimer pt("graph_load");
     std::string txt;
     if (!read_file(gfa_path, txt)) return fail(VGAN_EIO, "cannot read %s", gfa_path);
     pt.lap("read gfa");
-    auto g = new vgan_graph();
-    int rc = load_gfa(txt, *g);
+    std::unique_ptr<vgan_graph> holder(new vgan_graph()); // freed on every early return and on exceptions
+    vgan_graph *g = holder.get();
+    int rc = is_odgi(txt) ? load_odgi(txt, *g) : load_gfa(txt, *g);
     pt.lap("parse gfa");
     if (rc) {
-        delete g;
         return rc;
     }
     std::string dir = hcfiles_dir ? hcfiles_dir : "";
@@ -275,8 +405,7 @@ extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vg
             if (!parse_i64(tk[1].first, tk[1].second, s0) || !parse_i64(tk[2].first, tk[2].second, s1)) continue;
             const double v = strtod(std::string(tk[3].first, tk[3].second).c_str(), nullptr);
             if (s1 - s0 > (int64_t)1 << 28 || g->mappability.size() > ((size_t)1 << 30)) { // a corrupt range, not a genome
-                delete g;
-                return fail(VGAN_ERANGE, "mappability.tsv: interval [%lld, %lld) is out of any plausible range", (long long)s0, (long long)s1);
+                        return fail(VGAN_ERANGE, "mappability.tsv: interval [%lld, %lld) is out of any plausible range", (long long)s0, (long long)s1);
             }
             for (int64_t i = s0; i < s1; ++i) g->mappability.push_back(v);
         }
@@ -290,8 +419,18 @@ extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vg
         read_text_maybe_gz(dir + "children.txt", g->children_txt);
     }
     pt.lap("other sidecars");
-    *out = g;
+    *out = holder.release();
     return VGAN_OK;
+}
+
+extern "C" int vgan_graph_load(const char *gfa_path, const char *hcfiles_dir, vgan_graph **out) {
+    try {
+        return graph_load_impl(gfa_path, hcfiles_dir, out);
+    } catch (const std::bad_alloc &) {
+        return fail(VGAN_ENOMEM, "vgan_graph_load: out of memory reading %s", gfa_path ? gfa_path : "(null)");
+    } catch (const std::exception &e) {
+        return fail(VGAN_EIO, "vgan_graph_load: %s", e.what());
+    }
 }
 
 extern "C" int vgan_graph_from_arrays(const vgan_graph_view *v, vgan_graph **out) {

@@ -5,7 +5,8 @@
 //             [-o PREFIX] [--out_dir DIR] [-t N] [--seed N] [--device N]
 //
 // Same flags, defaults, validation and output files as Euka::run.  What differs, and why:
-//   * the graph is read from <dbprefix>.gfa: the ODGI .og / .gbwt pair needs libbdsg and libgbwt;
+//   * the graph is read from <dbprefix>.gfa, or <dbprefix>.og by this build's own ODGI reader (no GBWT: nothing on this path
+//     needs the haplotype index);
 //   * FASTQ input needs vg giraffe in-process (src/map_giraffe.cpp): map with vg and pass the GAM with -g;
 //   * readGAM3's per-alignment lambda runs on the GPU (vgan_euka_*), the abundance MCMC in closed form on the host
 //     (vgan_euka_report); --seed N makes the chain reproducible (default 0 = std::random_device, as the reference).
@@ -164,7 +165,8 @@ int euka_main(int argc, char **argv) {
     if (!fq1.empty() || !fq2.empty())
         die("[euka] FASTQ input needs vg giraffe in-process, which this build does not have; map with vg and pass -g");
     const std::string prefix = euka_dir + dbprefix;
-    for (const char *ext : {".gfa", ".clade", ".bins"}) // Euka.cpp:373-384 (.og / .gbwt there)
+    const std::string graph_ext = is_file(prefix + ".gfa") ? ".gfa" : ".og"; // Euka.cpp:373-384 (.og and .gbwt there)
+    for (const std::string &ext : {graph_ext, std::string(".clade"), std::string(".bins")})
         if (!is_file(prefix + ext)) die(prefix + ext + " does not exist.");
     if (gam.empty()) die("[euka] Error, no input file given (use -g)");
     if (!is_file(gam)) die("[euka] Error, GAM input file " + gam + " does not exist");
@@ -192,7 +194,7 @@ int euka_main(int argc, char **argv) {
     }
     std::cerr << "Reading in variation graph ..." << std::endl;
     Handle<vgan_graph> graph(vgan_graph_free);
-    check(vgan_graph_load((prefix + ".gfa").c_str(), nullptr, &graph.p), "loading graph");
+    check(vgan_graph_load((prefix + graph_ext).c_str(), nullptr, &graph.p), "loading graph");
     pt.lap("tables + graph");
 
     if (vgan_device_count() <= 0) die("[euka] no HIP device is visible: the per-read likelihood pass runs on the GPU only");

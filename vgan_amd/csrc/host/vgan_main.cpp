@@ -4,7 +4,7 @@
 //
 // Mirrors Haplocart::run (reference src/HaploCart.cpp:58-488): same flags, same validation messages, same
 // output lines.  What differs, and why:
-//   * the graph is read from DIR/graph.gfa (+ the hcfiles sidecars): the ODGI .og binary needs libbdsg;
+//   * the graph is read from DIR/graph.gfa or DIR/graph.og (+ the hcfiles sidecars) by this build's own readers;
 //   * FASTQ / FASTA inputs need vg giraffe in-process (src/map_giraffe.cpp), which is not available: map with vg
 //     and pass the sorted GAM with -g (for a consensus FASTA mapped that way add -f NAME to get the reference's
 //     consensus arithmetic);
@@ -125,7 +125,9 @@ int haplocart(int argc, char **argv) {
     } stream;
     check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
     vgan_graph *graph = nullptr;
-    check(vgan_graph_load((hcfiledir + "graph.gfa").c_str(), hcfiledir.c_str(), &graph), "loading graph");
+    // graph.gfa when there is one, else the hcfiles' own graph.og (read natively: node sequences, path names, path membership)
+    const std::string graphfile = hcfiledir + (std::ifstream(hcfiledir + "graph.gfa") ? "graph.gfa" : "graph.og");
+    check(vgan_graph_load(graphfile.c_str(), hcfiledir.c_str(), &graph), "loading graph");
     pt.lap("graph load");
     vgan_graph_view gv;
     check(vgan_graph_view_get(graph, &gv), "graph view");

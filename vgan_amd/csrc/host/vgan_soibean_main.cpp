@@ -4,8 +4,8 @@
 //                [--iter N] [--burnin N] [--chains N] [--no-mcmc] [-P N] [-o PREFIX] [-t N] [--seed N] [--device N]
 //
 // Same flags, defaults, validation and output files as soibean::run.  What differs, and why:
-//   * the graph is read from <soibean_dir>/<dbprefix>.gfa (one path per tree node): the ODGI .og / .gbwt pair needs libbdsg
-//     and libgbwt; FASTQ input needs vg giraffe in-process: map with vg and pass the GAM with -g;
+//   * the graph is read from <soibean_dir>/<dbprefix>.gfa or .og (one embedded path per tree node; the reference takes the
+//     paths from the .gbwt, which this build does not read); FASTQ input needs vg giraffe in-process: map with vg and pass -g;
 //   * analyse_GAM, the initial estimate and every likelihood refresh of the chains run on the GPU (vgan_sb_*); the chain
 //     itself is host control flow (vgan_sb_estimate); --seed N makes it reproducible (0 = std::random_device, as there).
 #include <algorithm>
@@ -164,7 +164,7 @@ int soibean_main(int argc, char **argv) {
             "you taxon of interested by using the make_graph_file.sh script."); // :427-429
     if (iter < burnin) die("The number of iterations must be higher than the burn-in period. Unable to proceed."); // :439-441
     if (treedir.empty()) treedir = sbdir + "tree_dir/";
-    const std::string gfa = sbdir + dbprefix + ".gfa", treename = treedir + dbprefix + ".new.dnd", freqname = sbdir + "soibean_db.baseFreq";
+    const std::string gfa = sbdir + dbprefix + (is_file(sbdir + dbprefix + ".gfa") ? ".gfa" : ".og"), treename = treedir + dbprefix + ".new.dnd", freqname = sbdir + "soibean_db.baseFreq";
     if (!is_file(gfa)) die(gfa + " does not exist.");
     if (!is_file(treename)) die(treename + " does not exist.");
     if (gam.empty()) die("[soibean] Error, no input file given (use -g)");
