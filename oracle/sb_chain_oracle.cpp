@@ -1,8 +1,9 @@
 /*
  * oracle/sb_chain_oracle.cpp -- TEST INFRASTRUCTURE ONLY (see oracle.h).
  *
- * What `vgan soibean` does after analyse_GAM, restated for the CPU with the reference's structures (node pointers, PosTree,
- * MCMCiteration) and loops (paths relative to /root/reference/src):
+ * What `vgan soibean` does after analyse_GAM, restated for the CPU: a pointer-linked tree like the reference's, the same
+ * sequence of random draws, comparisons and floating-point operations (incl. its double / long double mixes and unsigned
+ * arithmetic), written independently of the product's index-based implementation (paths relative to /root/reference/src):
  *   MCMC.cpp:169-470       MCMC::updatePosition
  *   MCMC.cpp:487-520       MCMC::sample_normal
  *   MCMC.cpp:522-1093      MCMC::run_tree_proportion (likelihood through orc_sb_loglike, oracle/sb_oracle.cpp)
@@ -115,271 +116,229 @@ struct Entropy {
     }
 };
 
-typedef struct PosTree {
-    Node *pos;
-    double pos_branch;
-    double theta;
-    double branch_place_anc;
-    double branch_place_der;
-} PosTree;
+// A source's place on the tree (PosTree, MCMC.h:38-44): the branch above `at`, a fraction of the way down it, and its share
+struct Placement {
+    Node *at;
+    double frac;  // pos_branch
+    double share; // theta
+};
 
-typedef struct MCMCiteration {
-    int n_components;
-    vector<double> proportions;
-    vector<double> max_branch_lens;
-    vector<PosTree> positions_tree;
-    double logLike;
-} MCMCiteration;
-
-struct Params {
-    Tree *tr;
-    vector<int> sources;
-    unsigned int maxIter, burn, chains;
-    double logLike;
-    const double *freqs7;
+// One state of the chain (MCMCiteration, MCMC.h:46-52)
+struct State {
+    vector<Placement> src;
+    vector<double> shares; // proportions
+    double loglik;
 };
 
 struct Run {
     const void *h;               /* orc_sb_analyse handle */
-    map<string, int> path_index; /* longname -> path */
+    map<string, int> path_index; /* node label -> graph path */
     Entropy rd;
-    mt19937 rand_engine;   /* rand() */
-    mt19937 theta_engine;  /* sample_normal's static generator */
+    mt19937 rand_engine;  /* stands in for rand() */
+    mt19937 theta_engine; /* sample_normal's function-static generator */
     Run(const void *handle, uint64_t seed) : h(handle), rd(seed), rand_engine(rd()), theta_engine(rd()) {}
+    unsigned pick(unsigned n) { return rand_engine() % n; } /* rand() % n */
 };
-/* stands in for `rand() % n` (the definition of include/vgan_gpu.h: the run's mt19937, full 32-bit output, modulo n) */
-inline unsigned pick(Run &r, unsigned n) { return r.rand_engine() % n; }
 
-inline long double mean(const vector<long double> &v) { return accumulate(v.begin(), v.end(), 0.0) / v.size(); }
-inline long double variance(const vector<long double> &v, long double mean) {
-    long double sum = 0.0;
-    for (const auto &i : v) {
-        long double diff = i - mean;
-        sum += diff * diff;
+/* ---- series statistics (miscfunc.h:12-66): the reference keeps the running sums of mean and autocorrelation in doubles while
+ * the samples are long doubles; the same here ---- */
+long double series_mean(const vector<long double> &x) {
+    double running = 0.0;
+    for (size_t i = 0; i < x.size(); ++i) running = running + x[i];
+    return running / x.size();
+}
+long double series_variance(const vector<long double> &x, long double about) {
+    long double ss = 0.0;
+    for (size_t i = 0; i < x.size(); ++i) ss += (x[i] - about) * (x[i] - about);
+    return ss / (x.size() - 1);
+}
+long double series_autocorr(const vector<long double> &x, int lag) {
+    const long double mu = series_mean(x);
+    const long double var = series_variance(x, mu);
+    double cross = 0.0;
+    const size_t pairs = x.size() - lag;
+    for (size_t i = 0; i < pairs; ++i) cross += ((x[i] - mu) * (x[i + lag] - mu));
+    return cross / (pairs * var);
+}
+double series_ess(const vector<long double> &x) {
+    const int half = x.size() / 2;
+    double a = 1.0, b = series_autocorr(x, 1);
+    double total = a + b;
+    for (int lag = 1; (lag < half - 2) && (a + b > 0); lag += 2) {
+        a = series_autocorr(x, lag + 1);
+        b = series_autocorr(x, lag + 2);
+        total += 2.0 * (a + b);
     }
-    return sum / (v.size() - 1);
+    if (a + b < 0) total -= (a + b);
+    return x.size() / (1 + total);
 }
-inline long double autocorrelation(const vector<long double> &v, int k) {
-    long double m = mean(v);
-    long double denom = variance(v, m);
-    double numer = 0.0;
-    for (size_t i = 0; i < v.size() - k; ++i) numer += ((v[i] - m) * (v[i + k] - m));
-    return numer / ((v.size() - k) * denom);
-}
-inline double effectiveSampleSize(const vector<long double> &v) {
-    int max_lag = v.size() / 2;
-    double rho_hat_even = 1.0;
-    double rho_hat_odd = autocorrelation(v, 1);
-    double rho_hat_tot = rho_hat_even + rho_hat_odd;
-    int t = 1;
-    while ((t < max_lag - 2) && (rho_hat_even + rho_hat_odd > 0)) {
-        rho_hat_even = autocorrelation(v, t + 1);
-        rho_hat_odd = autocorrelation(v, t + 2);
-        rho_hat_tot += 2.0 * (rho_hat_even + rho_hat_odd);
-        t += 2;
-    }
-    if (rho_hat_even + rho_hat_odd < 0) rho_hat_tot -= (rho_hat_even + rho_hat_odd);
-    return v.size() / (1 + rho_hat_tot);
-}
-long double getQuantile2(const vector<long double> &sortedData, double q) {
-    const auto n = sortedData.size();
-    const auto index = (n - 1) * q;
-    const auto lowerIndex = static_cast<size_t>(floor(index));
-    const auto upperIndex = static_cast<size_t>(ceil(index));
-    if (lowerIndex == upperIndex) return sortedData[lowerIndex];
-    const auto frac = index - lowerIndex;
-    return (1.0 - frac) * sortedData[lowerIndex] + frac * sortedData[upperIndex];
+long double sorted_quantile(const vector<long double> &sorted, double q) { /* MCMC.h getQuantile2 */
+    const double where = (sorted.size() - 1) * q;
+    const size_t below = static_cast<size_t>(floor(where)), above = static_cast<size_t>(ceil(where));
+    if (below == above) return sorted[below];
+    const double w = where - below;
+    return (1.0 - w) * sorted[below] + w * sorted[above];
 }
 
-Node *findLCA(Node *node1, Node *node2) {
-    unordered_map<Node *, bool> ancestors;
-    for (Node *c = node1; c != nullptr; c = c->parent) ancestors[c] = true;
-    for (Node *c = node2; c != nullptr; c = c->parent)
-        if (ancestors.find(c) != ancestors.end()) return c;
+/* ---- distance of a placement to the leaves (MCMC.h:528-625).  The reference indexes a #leaves-long vector by node number and
+ * compares it with a vector of ones: only node numbers below #leaves take part ---- */
+double climb(Node *from, Node *until) { /* sum of branch lengths from `from` up to, not including, `until`; -1 if never met */
+    double d = 0.0;
+    Node *n = from;
+    for (; n != nullptr && n != until; n = n->parent) d += (n->dist);
+    return n == until ? d : -1.0;
+}
+Node *meet(Node *a, Node *b) {
+    unordered_map<Node *, bool> above_a;
+    for (Node *n = a; n; n = n->parent) above_a[n] = true;
+    for (Node *n = b; n; n = n->parent)
+        if (above_a.count(n)) return n;
     throw runtime_error("No common ancestor found.");
 }
-double calculateDistanceToAncestor(Node *startNode, Node *ancestor) {
-    double distance = 0.0;
-    Node *current = startNode;
-    while (current != nullptr && current != ancestor) {
-        distance += (current->dist);
-        current = current->parent;
+long double leaf_profile_distance(const Tree &tr, Node *at, int n_leaves, double down_from_top) {
+    vector<double> profile(n_leaves, numeric_limits<double>::max());
+    for (size_t i = 0; i < tr.nodes.size(); ++i) {
+        Node *leaf = tr.nodes[i];
+        if (!leaf->isLeaf()) continue;
+        Node *m = meet(at, leaf);
+        const double mine = climb(at, m) - down_from_top, theirs = climb(leaf, m);
+        if (mine >= 0.0 && theirs >= 0.0 && i < profile.size()) profile[i] = mine + theirs;
     }
-    return current == ancestor ? distance : -1.0;
-}
-/* the reference sizes the result by the number of leaves and indexes it by node number; entries at or beyond that size
- * are never read back (calculateEuclideanDistance stops at the shorter vector), so they are not stored here */
-vector<double> getPatristicDistances(const Tree *tr, Node *node, int numofLeafs, double posonbranch) {
-    vector<double> distances(numofLeafs, numeric_limits<double>::max());
-    for (size_t i = 0; i < tr->nodes.size(); ++i) {
-        Node *leafNode = tr->nodes[i];
-        if (!leafNode->isLeaf()) continue;
-        Node *lca = findLCA(node, leafNode);
-        double distanceToLCAFromNode = calculateDistanceToAncestor(node, lca) - posonbranch;
-        double distanceToLCAFromLeaf = calculateDistanceToAncestor(leafNode, lca);
-        if (distanceToLCAFromNode >= 0.0 && distanceToLCAFromLeaf >= 0.0 && i < distances.size()) distances[i] = distanceToLCAFromNode + distanceToLCAFromLeaf;
+    long double ss = 0.0;
+    for (int i = 0; i < n_leaves; ++i) { /* against initialPatristicDistances = 1.0 everywhere */
+        if (profile[i] == numeric_limits<double>::max()) continue;
+        const double diff = profile[i] - 1.0;
+        ss += diff * diff;
     }
-    return distances;
-}
-long double calculateEuclideanDistance(const vector<double> &vec1, const vector<double> &vec2) {
-    size_t minSize = min(vec1.size(), vec2.size());
-    long double sum = 0.0;
-    for (size_t i = 0; i < minSize; ++i) {
-        if (vec1[i] == numeric_limits<double>::max() || vec2[i] == numeric_limits<double>::max()) continue;
-        double diff = vec1[i] - vec2[i];
-        sum += diff * diff;
-    }
-    return sqrt(sum);
+    return sqrt(ss);
 }
 
-void updatePosition(Run &R, PosTree &current_position, double move_distance, bool move_forward) {
-    if (current_position.pos_branch < 0.0 || current_position.pos_branch > 1.0) throw runtime_error("Error: Initial pos_branch is out of valid range.");
-    if (current_position.pos == nullptr) throw runtime_error("Error: current position pointer is null.");
-    if (move_distance < 0.0) throw runtime_error("Error: move distance cannot be negative.");
-    double move_distance_abs = abs(move_distance);
-    while (move_distance_abs > 0.0) {
-        if (move_forward) {
-            if (current_position.pos_branch + move_distance_abs < 1.0) {
-                current_position.pos_branch += move_distance_abs;
-                move_distance_abs = 0.0;
+/* ---- MCMC::updatePosition (MCMC.cpp:169-470): walk `distance` branch units from a placement, towards the leaves or the root.
+ * Every branch counts as one unit; a leaf turns the walk round, the root sends it down a random child, and on the way up an
+ * inner node may slip sideways into a sibling ---- */
+Node *random_child(Run &R, Node *of) {
+    Node *c = of->children[R.pick(of->nchildren)];
+    if (c->dist < 0.0) throw runtime_error("Error: next branch length cannot be negative.");
+    return c;
+}
+void walk(Run &R, Placement &pl, double distance, bool down) {
+    if (pl.frac < 0.0 || pl.frac > 1.0) throw runtime_error("Error: Initial pos_branch is out of valid range.");
+    if (!pl.at) throw runtime_error("Error: current position pointer is null.");
+    if (distance < 0.0) throw runtime_error("Error: move distance cannot be negative.");
+    double todo = abs(distance);
+    while (todo > 0.0) {
+        if (down) {
+            if (pl.frac + todo < 1.0) { /* stays on this branch */
+                pl.frac += todo;
+                todo = 0.0;
+            } else if (pl.at->children == nullptr) {
+                down = false; /* bounce off the leaf */
             } else {
-                if (current_position.pos->children == nullptr) {
-                    move_forward = false;
-                    continue;
-                }
-                double remaining_distance = move_distance_abs - (1.0 - current_position.pos_branch);
-                if (remaining_distance < 0.0) remaining_distance = 0.0;
-                int num_children = current_position.pos->nchildren;
-                int random_index = pick(R, num_children);
-                current_position.pos = current_position.pos->children[random_index];
-                if (current_position.pos->dist < 0.0) throw runtime_error("Error: next branch length cannot be negative.");
-                if (remaining_distance > 1.0) {
-                    current_position.pos_branch = 1.0;
-                    move_distance_abs = remaining_distance - 1.0;
+                double over = todo - (1.0 - pl.frac);
+                if (over < 0.0) over = 0.0;
+                pl.at = random_child(R, pl.at);
+                if (over > 1.0) {
+                    pl.frac = 1.0;
+                    todo = over - 1.0;
                 } else {
-                    current_position.pos_branch = remaining_distance;
-                    move_distance_abs = 0.0;
+                    pl.frac = over;
+                    todo = 0.0;
                 }
             }
+            continue;
+        }
+        /* upwards */
+        if (pl.frac - todo > 0.0) {
+            pl.frac = pl.frac - todo;
+            todo = 0.0;
+            continue;
+        }
+        Node *up = pl.at->parent;
+        if (up == nullptr) { /* at the root: down again through a random child, nothing consumed */
+            down = true;
+            pl.at = random_child(R, pl.at);
+            continue;
+        }
+        vector<Node *> choice(1, up);
+        if (pl.at->children != nullptr) /* only an inner node considers its siblings */
+            for (int i = 0; i < up->nchildren; ++i)
+                if (up->children[i] != pl.at) choice.push_back(up->children[i]);
+        Node *next = choice[R.pick(choice.size())];
+        if (next == up) {
+            double over = todo - pl.frac;
+            if (over < 0.0) over = 0.0;
+            pl.at = up;
+            if (pl.at->dist < 0.0) throw runtime_error("Error: parent branch length cannot be negative.");
+            if (over > 1.0) {
+                pl.frac = 0.0;
+                todo = over - 1.0;
+            } else {
+                const double f = 1.0 - over;
+                if (f <= 0.0 || f >= 1.0) throw runtime_error("Error: new position branch is not in the valid range.");
+                pl.frac = f;
+                todo = 0.0;
+            }
+            continue;
+        }
+        /* sideways: enter the sibling at its top and carry on downwards */
+        down = true;
+        pl.at = next;
+        const double over = todo - pl.frac;
+        pl.frac = 0.0;
+        if (pl.frac + over < 1.0) {
+            pl.frac = over;
+            if (pl.frac < 0.0 || pl.frac > 1.0) throw runtime_error("Error: pos_branch is out of valid range after increment.");
+            todo = 0.0;
+        } else if (pl.at->children == nullptr) {
+            down = false; /* the sibling is a leaf: turn round there, the distance is kept */
         } else {
-            if (current_position.pos_branch - move_distance_abs > 0.0) {
-                current_position.pos_branch = current_position.pos_branch - move_distance_abs;
-                move_distance_abs = 0.0;
-            } else {
-                vector<Node *> possible_nodes;
-                if (current_position.pos->parent == nullptr) {
-                    move_forward = true;
-                    int num_children = current_position.pos->nchildren;
-                    int random_index = pick(R, num_children);
-                    current_position.pos = current_position.pos->children[random_index];
-                    if (current_position.pos->dist < 0.0) throw runtime_error("Error: next branch length cannot be negative.");
-                    continue;
-                } else {
-                    possible_nodes.push_back(current_position.pos->parent);
-                }
-                if (current_position.pos->children != nullptr) {
-                    for (int i = 0; i < current_position.pos->parent->nchildren; ++i)
-                        if (current_position.pos->parent->children[i] != current_position.pos) possible_nodes.push_back(current_position.pos->parent->children[i]);
-                }
-                Node *chosen_node = possible_nodes[pick(R, possible_nodes.size())];
-                if (chosen_node == current_position.pos->parent) {
-                    double remaining_distance = move_distance_abs - current_position.pos_branch;
-                    if (remaining_distance < 0.0) remaining_distance = 0.0;
-                    current_position.pos = current_position.pos->parent;
-                    if (current_position.pos->dist < 0.0) throw runtime_error("Error: parent branch length cannot be negative.");
-                    if (remaining_distance > 1.0) {
-                        current_position.pos_branch = 0.0;
-                        move_distance_abs = remaining_distance - 1.0;
-                        continue;
-                    } else {
-                        double new_pos_branch = 1.0 - remaining_distance;
-                        if (new_pos_branch <= 0.0 || new_pos_branch >= 1.0) throw runtime_error("Error: new position branch is not in the valid range.");
-                        current_position.pos_branch = new_pos_branch;
-                        move_distance_abs = 0.0;
-                    }
-                } else {
-                    move_forward = true;
-                    current_position.pos = chosen_node;
-                    double remaining_distance = move_distance_abs - current_position.pos_branch;
-                    current_position.pos_branch = 0.0;
-                    if (current_position.pos_branch + remaining_distance < 1.0) {
-                        current_position.pos_branch = remaining_distance;
-                        if (current_position.pos_branch < 0.0 || current_position.pos_branch > 1.0) throw runtime_error("Error: pos_branch is out of valid range after increment.");
-                        move_distance_abs = 0.0;
-                    } else {
-                        if (current_position.pos->children == nullptr) {
-                            move_forward = false;
-                            continue;
-                        }
-                        double remaining_distance = move_distance_abs - (1.0 - current_position.pos_branch);
-                        if (remaining_distance < 0.0) remaining_distance = 0.0;
-                        int num_children = current_position.pos->nchildren;
-                        int random_index = pick(R, num_children);
-                        current_position.pos = current_position.pos->children[random_index];
-                        if (current_position.pos->dist < 0.0) throw runtime_error("Error: next branch length cannot be negative.");
-                        if (remaining_distance > 1.0) {
-                            current_position.pos_branch = 1.0;
-                            move_distance_abs = remaining_distance - 1.0;
-                        }
-                    }
-                }
-            }
+            double deeper = todo - (1.0 - pl.frac);
+            if (deeper < 0.0) deeper = 0.0;
+            pl.at = random_child(R, pl.at);
+            if (deeper > 1.0) {
+                pl.frac = 1.0;
+                todo = deeper - 1.0;
+            } /* otherwise position and distance stay as they are and the loop goes on downwards */
         }
     }
-    if (current_position.pos_branch < 0.0 || current_position.pos_branch > 1.0) throw runtime_error("Error: pos_branch is out of valid range after movement.");
+    if (pl.frac < 0.0 || pl.frac > 1.0) throw runtime_error("Error: pos_branch is out of valid range after movement.");
 }
 
-vector<double> sample_normal(Run &R, vector<double> &x) {
-    vector<double> result;
-    if (x.empty()) throw invalid_argument("vector can't be empty");
-    long double sum = 0.0L;
-    for (size_t i = 0; i < x.size(); ++i) {
-        normal_distribution<double> dist(x[i], 0.1);
-        double sample;
-        do {
-            sample = dist(R.theta_engine);
-        } while (sample < 0.0L || sample > 1.0L);
-        result.emplace_back(sample);
-        sum += sample;
+/* MCMC::sample_normal (MCMC.cpp:487-520): each share redrawn from N(share, 0.1) until it lies in [0, 1], then normalised */
+vector<double> redraw_shares(Run &R, const vector<double> &cur) {
+    if (cur.empty()) throw invalid_argument("vector can't be empty");
+    vector<double> out;
+    long double total = 0.0L;
+    for (size_t i = 0; i < cur.size(); ++i) {
+        normal_distribution<double> around(cur[i], 0.1);
+        double v = around(R.theta_engine);
+        while (v < 0.0L || v > 1.0L) v = around(R.theta_engine);
+        out.push_back(v);
+        total += v;
     }
-    for (size_t i = 0; i < result.size(); ++i) result[i] /= sum;
-    return result;
+    for (size_t i = 0; i < out.size(); ++i) out[i] /= total;
+    return out;
 }
 
-vector<double> generateRandomNumbers(Run &R, int size) { /* MCMC.h:453-465 */
+/* initializeState (MCMC.h:424-505): uniform shares normalised to one from an engine of their own, every source half way
+ * down the branch above its start node */
+State start_state(Run &R, Tree &tr, const vector<int> &start_nodes, double start_loglik) {
     mt19937 gen(R.rd());
-    uniform_real_distribution<> dis(0.0, 1.0);
-    vector<double> random_numbers(size);
+    uniform_real_distribution<> u(0.0, 1.0);
+    vector<double> raw(start_nodes.size());
     double sum = 0.0;
-    for (double &num : random_numbers) {
-        num = dis(gen);
-        sum += num;
+    for (size_t i = 0; i < raw.size(); ++i) {
+        raw[i] = u(gen);
+        sum += raw[i];
     }
-    for (double &num : random_numbers) num /= sum;
-    return random_numbers;
-}
-
-MCMCiteration initializeState(Run &R, Params &params) {
-    MCMCiteration state;
-    state.n_components = params.sources.size();
-    vector<double> random_numbers = generateRandomNumbers(R, state.n_components);
-    vector<PosTree> current_positions(random_numbers.size());
-    int index = 0;
-    for (auto &p : current_positions) {
-        p.pos = params.tr->nodes.at(params.sources[index]);
-        p.pos_branch = 0.5;
-        p.theta = random_numbers[index];
-        p.branch_place_anc = 0.5;
-        p.branch_place_der = 0.5;
-        index++;
+    State st;
+    for (size_t i = 0; i < raw.size(); ++i) {
+        raw[i] /= sum;
+        st.src.push_back(Placement{tr.nodes.at(start_nodes[i]), 0.5, raw[i]});
+        st.shares.push_back(max(0.001, raw[i]));
     }
-    state.positions_tree = current_positions;
-    for (auto &p : state.positions_tree) {
-        state.proportions.emplace_back(max(0.001, p.theta));
-        state.max_branch_lens.emplace_back(p.pos->dist);
-    }
-    state.logLike = params.logLike;
-    return state;
+    st.loglik = start_loglik;
+    return st;
 }
 
 struct GzOut {
@@ -393,188 +352,167 @@ struct GzOut {
     }
 };
 
-vector<MCMCiteration> run_tree_proportion(Run &R, Params params, vector<MCMCiteration> state_t_vec, const string &num, int numPaths, int chainindex, double con) {
-    const unsigned int n_sources = params.sources.size();
-    MCMCiteration state_t_1;
-    double likelihood_t_1;
+struct ChainCfg {
+    unsigned max_iter, burn;
+    double con;
+    const double *freqs7;
+    int n_paths;
+};
+
+double state_loglik(Run &R, const State &st, const ChainCfg &cfg) { /* MCMC.cpp:738-993 through orc_sb_loglike */
+    const int k = (int)st.src.size();
+    vector<int32_t> child(k), parent(k);
+    vector<double> dist(k), pos(k), theta(k);
+    for (int y = 0; y < k; ++y) {
+        Node *n = st.src[y].at;
+        child[y] = R.path_index.at(n->longname);
+        parent[y] = R.path_index.at(n->parent ? n->parent->longname : n->longname);
+        dist[y] = n->dist;
+        pos[y] = st.src[y].frac;
+        theta[y] = st.shares[y];
+    }
+    double ll = 0.0;
+    if (orc_sb_loglike(R.h, k, child.data(), parent.data(), dist.data(), pos.data(), theta.data(), cfg.con, cfg.freqs7, 1, &ll) != 0)
+        throw runtime_error("Problem in the likelihood compuation! Intermediate log likelihood is -nan, -inf or positive.");
+    return ll;
+}
+
+string state_line(const State &st, double loglik, const char *verdict) {
+    ostringstream o;
+    o << setprecision(14);
+    for (const Placement &p : st.src) {
+        o << p.at->longname << '\t' << loglik << '\t' << p.share << '\t' << p.frac << '\t';
+        if (verdict) o << verdict << '\t';
+    }
+    o << endl;
+    return o.str();
+}
+
+/* MCMC::run_tree_proportion (MCMC.cpp:522-1093): returns the states recorded after the burn-in */
+vector<State> run_chain(Run &R, Tree &tr, const vector<int> &start_nodes, double start_loglik, const ChainCfg &cfg, const string &prefix, int chain) {
+    const unsigned k = start_nodes.size();
     mt19937 gen(R.rd());
-    uniform_real_distribution<> dis(0.0, 1.0);
-    vector<PosTree> current_positions(n_sources);
-    MCMCiteration state_t = initializeState(R, params);
-    double proposal_sd;
-    double initSD;
-    if (numPaths <= 30.0) initSD = 3.0;
-    else initSD = numPaths * (3.0 / 30.0);
-    GzOut mcmcout(num + "Result" + to_string(n_sources) + to_string(chainindex) + ".mcmc");
+    uniform_real_distribution<> unit(0.0, 1.0);
+    State cur = start_state(R, tr, start_nodes, start_loglik);
+    const double widest = cfg.n_paths <= 30.0 ? 3.0 : cfg.n_paths * (3.0 / 30.0);
+    const string tag = to_string(k) + to_string(chain);
+    GzOut result(prefix + "Result" + tag + ".mcmc"), trace(prefix + "Trace" + tag + ".detail.mcmc");
     {
-        ostringstream o;
-        for (unsigned sou = 1; sou < n_sources + 1; ++sou) o << "Source_" << sou << '\t' << "Log-likelihood" << '\t' << "proportion" << '\t' << "branch_position_derived" << '\t';
-        o << endl;
-        mcmcout.write(o.str());
+        ostringstream a, b;
+        for (unsigned s = 1; s <= k; ++s) {
+            a << "Source_" << s << '\t' << "Log-likelihood" << '\t' << "proportion" << '\t' << "branch_position_derived" << '\t';
+            b << "Source_" << s << '\t' << "Log-likelihood" << '\t' << "proportion_" << s << '\t' << "branch_position_derived_" << s << '\t' << "Move" << '\t';
+        }
+        a << endl;
+        b << endl;
+        result.write(a.str());
+        trace.write(b.str());
     }
-    GzOut mcmcdetail(num + "Trace" + to_string(n_sources) + to_string(chainindex) + ".detail.mcmc");
-    {
-        ostringstream o;
-        for (unsigned sou = 1; sou < n_sources + 1; ++sou)
-            o << "Source_" << sou << '\t' << "Log-likelihood" << '\t' << "proportion_" << sou << '\t' << "branch_position_derived_" << sou << '\t' << "Move" << '\t';
-        o << endl;
-        mcmcdetail.write(o.str());
+    vector<State> kept;
+    for (unsigned it = 0; it <= cfg.max_iter; it++) {
+        if (cfg.burn >= cfg.max_iter) throw runtime_error("Number of brun in iteration exceedes the number of total iterations. Exiting. ");
+        /* proposal width: linear from `widest` to 0.1 over the burn-in, then from 0.1 towards 1e-5; both denominators are unsigned */
+        const double per_burn = (widest - 0.1) / std::max(static_cast<unsigned int>(1), cfg.burn - 1);
+        const double per_rest = (0.1 - 1e-5) / std::max(static_cast<unsigned int>(1), (cfg.max_iter - cfg.burn) - 1);
+        double width;
+        if (it < cfg.burn) width = std::max(1e-5, widest - it * per_burn);
+        else if (it % 100000 == 0) width = 1;
+        else width = std::max(1e-5, 0.1 - (it - cfg.burn) * per_rest);
+        State prop = cur;
+        if (it != 0)
+            for (size_t i = 0; i < prop.src.size(); i++) {
+                normal_distribution<double> jump(0, width);
+                const double d = jump(gen);
+                if (d < 0.0) walk(R, prop.src[i], -d, false);
+                else walk(R, prop.src[i], d, true);
+            }
+        vector<double> shares;
+        for (const Placement &p : prop.src) shares.push_back(p.share);
+        shares = redraw_shares(R, shares);
+        for (size_t i = 0; i < prop.src.size(); ++i) prop.src[i].share = shares[i];
+        prop.shares = shares;
+        prop.loglik = state_loglik(R, prop, cfg);
+        const double gain = prop.loglik - cur.loglik;
+        const double accept = (gain > 0) ? 1.0 : exp(gain);
+        const double u = unit(gen);
+        const bool take = u <= accept || it == 0;
+        trace.write(state_line(prop, prop.loglik, take ? "accepted" : "rejected"));
+        if (it > cfg.burn) { /* what is recorded is the state the chain is in before the move */
+            result.write(state_line(cur, cur.loglik, nullptr));
+            kept.push_back(cur);
+        }
+        if (take) cur = prop;
     }
-    for (unsigned int iteration = 0; iteration <= params.maxIter; iteration++) {
-        if (params.burn >= params.maxIter) throw runtime_error("Number of brun in iteration exceedes the number of total iterations. Exiting. ");
-        double step = (initSD - 0.1) / std::max(static_cast<unsigned int>(1), params.burn - 1);
-        double step2 = (0.1 - 1e-5) / std::max(static_cast<unsigned int>(1), (params.maxIter - params.burn) - 1);
-        state_t_1 = state_t;
-        if (iteration < params.burn) {
-            proposal_sd = std::max(1e-5, initSD - iteration * step);
-        } else {
-            if (iteration % 100000 == 0) proposal_sd = 1;
-            else proposal_sd = std::max(1e-5, 0.1 - (iteration - params.burn) * step2);
-        }
-        if (iteration != 0) {
-            for (int i = 0; i < state_t_1.n_components; i++) {
-                normal_distribution<double> distribution_bl(0, proposal_sd);
-                double proposed_position = distribution_bl(gen);
-                if (proposed_position < 0.0) updatePosition(R, state_t_1.positions_tree[i], -proposed_position, false);
-                else updatePosition(R, state_t_1.positions_tree[i], proposed_position, true);
-            }
-        }
-        vector<double> tmp_theta;
-        for (auto &p : state_t_1.positions_tree) tmp_theta.emplace_back(p.theta);
-        tmp_theta = sample_normal(R, tmp_theta);
-        for (size_t idx = 0; idx < current_positions.size(); ++idx) state_t_1.positions_tree[idx].theta = tmp_theta[idx];
-        state_t_1.proportions = tmp_theta;
-        vector<string> pathNames, parentpathNames;
-        for (auto &p : state_t_1.positions_tree) {
-            pathNames.emplace_back(p.pos->longname);
-            if (p.pos->parent != nullptr) parentpathNames.emplace_back(p.pos->parent->longname);
-            else parentpathNames.emplace_back(p.pos->longname);
-        }
-        double logLike = 0.0;
-        {
-            const int k = (int)pathNames.size();
-            vector<int32_t> child(k), parent(k);
-            vector<double> dist(k), pos(k), theta(k);
-            for (int y = 0; y < k; ++y) {
-                child[y] = R.path_index.at(pathNames[y]);
-                parent[y] = R.path_index.at(parentpathNames[y]);
-                dist[y] = state_t_1.positions_tree[y].pos->dist;
-                pos[y] = state_t_1.positions_tree[y].pos_branch;
-                theta[y] = state_t_1.proportions[y];
-            }
-            if (orc_sb_loglike(R.h, k, child.data(), parent.data(), dist.data(), pos.data(), theta.data(), con, params.freqs7, 1, &logLike) != 0)
-                throw runtime_error("Problem in the likelihood compuation! Intermediate log likelihood is -nan, -inf or positive.");
-        }
-        likelihood_t_1 = logLike;
-        state_t_1.logLike = likelihood_t_1;
-        double acceptance_prob = (state_t_1.logLike - state_t.logLike > 0) ? 1.0 : exp(state_t_1.logLike - state_t.logLike);
-        double u = dis(gen);
-        if (u <= acceptance_prob || iteration == 0) {
-            ostringstream d;
-            for (auto p : state_t_1.positions_tree) d << std::setprecision(14) << p.pos->longname << "\t" << state_t_1.logLike << '\t' << p.theta << '\t' << p.pos_branch << '\t' << "accepted" << '\t';
-            d << endl;
-            mcmcdetail.write(d.str());
-            if (iteration > params.burn) {
-                ostringstream o;
-                for (auto &p : state_t.positions_tree) o << setprecision(14) << p.pos->longname << '\t' << state_t.logLike << '\t' << p.theta << '\t' << p.pos_branch << '\t';
-                state_t_vec.emplace_back(state_t);
-                o << endl;
-                mcmcout.write(o.str());
-            }
-            state_t = state_t_1;
-        } else {
-            ostringstream d;
-            for (auto p : state_t_1.positions_tree) d << std::setprecision(14) << p.pos->longname << "\t" << state_t_1.logLike << '\t' << p.theta << '\t' << p.pos_branch << '\t' << "rejected" << '\t';
-            d << endl;
-            mcmcdetail.write(d.str());
-            if (iteration > params.burn) {
-                ostringstream o;
-                for (auto &p : state_t.positions_tree) o << setprecision(14) << p.pos->longname << '\t' << state_t.logLike << '\t' << p.theta << '\t' << p.pos_branch << '\t';
-                o << endl;
-                mcmcout.write(o.str());
-                state_t_vec.emplace_back(state_t);
-            }
-        }
-    }
-    return state_t_vec;
+    return kept;
 }
 
-pair<map<string, vector<vector<double>>>, double> processMCMCiterations(const vector<MCMCiteration> &MCMCiterations, int k, const string &num, int chain, const Tree *tr, int numofleafs) {
-    map<string, vector<vector<double>>> branchStatisticsMap;
-    ofstream estimatesFile, branchestimateFile;
-    estimatesFile.open(num + "ProportionEstimates" + to_string(k) + ".txt", ios::app | ios::out);
-    branchestimateFile.open(num + "BranchEstimate" + to_string(k) + ".txt", ios::app | ios::out);
-    estimatesFile << "Source\tChain\tMean Proportion Estimate\t5% CI\tMedian Proportion Estimate\t95% CI\tEffective Sample Size\tAutocorrelation\tVariance\n";
-    branchestimateFile << "Source\tChain\tMean Branch Position\t5% CI\tMedian Branch Position\t95% CI\tEffective Sample Size\tAutocorrelation\tVariance\tEffective Sample Size for the source estimation\n";
-    double chainloglike = MCMCiterations.at(0).logLike;
-    for (int source = 0; source < k; ++source) {
-        vector<double> sourceStatistic = {};
-        vector<long double> proportionVec = {};
-        vector<long double> positionVec = {};
-        string branchName;
-        vector<double> initialPatristicDistances;
-        vector<long double> euc_distances;
-        initialPatristicDistances = vector<double>(numofleafs, 1.0);
-        size_t totalIterations = MCMCiterations.size();
-        for (size_t idx = 0; idx < totalIterations; ++idx) {
-            const auto &iteration = MCMCiterations[idx];
-            if (iteration.logLike > chainloglike) chainloglike = iteration.logLike;
-            branchName = iteration.positions_tree[source].pos->longname;
-            if (branchStatisticsMap.find(branchName) == branchStatisticsMap.end()) branchStatisticsMap[branchName] = vector<vector<double>>();
-            proportionVec.emplace_back(iteration.proportions[source]);
-            positionVec.emplace_back(iteration.positions_tree[source].pos_branch);
-            double t1 = iteration.positions_tree[source].pos->dist * iteration.positions_tree[source].pos_branch;
-            double posonbranch = iteration.positions_tree[source].pos->dist - t1;
-            const vector<double> patristic_distances = getPatristicDistances(tr, iteration.positions_tree[source].pos, numofleafs, posonbranch);
-            long double euc_dist = calculateEuclideanDistance(patristic_distances, initialPatristicDistances);
-            euc_distances.emplace_back(euc_dist);
+/* MCMC::processMCMCiterations (MCMC.cpp:23-150): per source the summaries of share and position over the recorded states, one line
+ * each in the two estimate files; returns {mean share, its variance, mean position, its variance} under the branch the source
+ * ended on, an empty entry for every other branch it visited, and the best log-likelihood */
+struct ChainSummary {
+    map<string, vector<vector<double>>> by_branch;
+    double best;
+};
+ChainSummary summarise(const vector<State> &kept, int k, const string &prefix, int chain, const Tree &tr, int n_leaves) {
+    ofstream shares_out(prefix + "ProportionEstimates" + to_string(k) + ".txt", ios::app | ios::out);
+    ofstream pos_out(prefix + "BranchEstimate" + to_string(k) + ".txt", ios::app | ios::out);
+    shares_out << "Source\tChain\tMean Proportion Estimate\t5% CI\tMedian Proportion Estimate\t95% CI\tEffective Sample Size\tAutocorrelation\tVariance\n";
+    pos_out << "Source\tChain\tMean Branch Position\t5% CI\tMedian Branch Position\t95% CI\tEffective Sample Size\tAutocorrelation\tVariance\tEffective Sample Size for the source estimation\n";
+    ChainSummary out;
+    out.best = kept.at(0).loglik;
+    for (int s = 0; s < k; ++s) {
+        vector<long double> share, pos, spread;
+        string last_branch;
+        for (const State &st : kept) {
+            if (st.loglik > out.best) out.best = st.loglik;
+            const Placement &p = st.src[s];
+            last_branch = p.at->longname;
+            out.by_branch[last_branch]; /* created empty on first sight */
+            share.emplace_back(st.shares[s]);
+            pos.emplace_back(p.frac);
+            const double from_bottom = p.at->dist * p.frac;
+            spread.emplace_back(leaf_profile_distance(tr, p.at, n_leaves, p.at->dist - from_bottom));
         }
-        long double meanTheta = mean(proportionVec);
-        long double meanPos = mean(positionVec);
-        long double Theta_autoc = autocorrelation(proportionVec, 1);
-        long double Theta_ess = effectiveSampleSize(proportionVec);
-        long double Theat_var = variance(proportionVec, meanTheta);
-        long double Pos_autoc = autocorrelation(positionVec, 1);
-        long double Pos_ess = effectiveSampleSize(positionVec);
-        long double dist_ess = effectiveSampleSize(euc_distances);
-        long double Pos_var = variance(positionVec, meanPos);
-        sort(positionVec.begin(), positionVec.end());
-        sort(proportionVec.begin(), proportionVec.end());
-        long double Theta_fq = getQuantile2(proportionVec, 0.05);
-        long double Theta_tq = getQuantile2(proportionVec, 0.95);
-        long double Theta_median = getQuantile2(proportionVec, 0.5);
-        long double Pos_fq = getQuantile2(positionVec, 0.05);
-        long double Pos_median = getQuantile2(positionVec, 0.5);
-        long double Pos_tq = getQuantile2(positionVec, 0.95);
-        estimatesFile << branchName << '\t' << chain << '\t' << meanTheta << '\t' << Theta_fq << '\t' << Theta_median << '\t' << Theta_tq << '\t' << Theta_ess << '\t' << Theta_autoc << '\t' << Theat_var << '\n';
-        branchestimateFile << branchName << '\t' << chain << '\t' << meanPos << '\t' << Pos_fq << '\t' << Pos_median << '\t' << Pos_tq << '\t' << Pos_ess << '\t' << Pos_autoc << '\t' << Pos_var << '\t' << dist_ess << '\n';
-        sourceStatistic.emplace_back(meanTheta);
-        sourceStatistic.emplace_back(Theat_var);
-        sourceStatistic.emplace_back(meanPos);
-        sourceStatistic.emplace_back(Pos_var);
-        branchStatisticsMap[branchName].emplace_back(sourceStatistic);
+        const long double share_mean = series_mean(share), pos_mean = series_mean(pos);
+        const long double share_ac = series_autocorr(share, 1);
+        const long double share_ess = series_ess(share);
+        const long double share_var = series_variance(share, share_mean);
+        const long double pos_ac = series_autocorr(pos, 1);
+        const long double pos_ess = series_ess(pos);
+        const long double spread_ess = series_ess(spread);
+        const long double pos_var = series_variance(pos, pos_mean);
+        sort(pos.begin(), pos.end());
+        sort(share.begin(), share.end());
+        shares_out << last_branch << '\t' << chain << '\t' << share_mean << '\t' << sorted_quantile(share, 0.05) << '\t' << sorted_quantile(share, 0.5) << '\t'
+                   << sorted_quantile(share, 0.95) << '\t' << share_ess << '\t' << share_ac << '\t' << share_var << '\n';
+        pos_out << last_branch << '\t' << chain << '\t' << pos_mean << '\t' << sorted_quantile(pos, 0.05) << '\t' << sorted_quantile(pos, 0.5) << '\t'
+                << sorted_quantile(pos, 0.95) << '\t' << pos_ess << '\t' << pos_ac << '\t' << pos_var << '\t' << spread_ess << '\n';
+        out.by_branch[last_branch].push_back({(double)share_mean, (double)share_var, (double)pos_mean, (double)pos_var});
     }
-    return make_pair(branchStatisticsMap, chainloglike);
+    return out;
 }
 
-vector<int> soibean_generateRandomNumbers(Run &R, const int maxNum, const int k) {
-    vector<int> sigNodes;
+vector<int> random_start_nodes(Run &R, int n_nodes, int k) { /* soibean::generateRandomNumbers (soibean.cpp:157-172) */
     mt19937 gen(R.rd());
-    uniform_int_distribution<> distrib(0, static_cast<int>(maxNum) - 1);
-    for (int i = 0; i < k; ++i) sigNodes.emplace_back(static_cast<int>(distrib(gen)));
-    return sigNodes;
+    uniform_int_distribution<> any(0, n_nodes - 1);
+    vector<int> v;
+    while ((int)v.size() < k) v.push_back(any(gen));
+    return v;
 }
 
-double calculateRhat(const vector<double> &means, const vector<double> &variances, int chainLength) {
-    int numChains = means.size();
-    if (numChains < 2) return -1;
-    double W = accumulate(variances.begin(), variances.end(), 0.0) / numChains;
-    double grandMean = accumulate(means.begin(), means.end(), 0.0) / numChains;
-    double B = 0.0;
-    for (int i = 0; i < numChains; ++i) B += pow(means[i] - grandMean, 2);
-    B *= chainLength / (numChains - 1);
-    double varEstimate = ((chainLength - 1.0) * W + B) / chainLength;
-    return sqrt(varEstimate / W);
+double gelman_rubin(const vector<double> &means, const vector<double> &vars, int chain_len) { /* soibean::calculateRhat (:174-202) */
+    const int m = means.size();
+    if (m < 2) return -1;
+    double within = 0.0, centre = 0.0;
+    for (double v : vars) within += v;
+    within /= m;
+    for (double x : means) centre += x;
+    centre /= m;
+    double between = 0.0;
+    for (int i = 0; i < m; ++i) between += pow(means[i] - centre, 2);
+    between *= chain_len / (m - 1); /* integer quotient */
+    const double pooled = ((chain_len - 1.0) * within + between) / chain_len;
+    return sqrt(pooled / within);
 }
 
 } // namespace
@@ -582,88 +520,55 @@ double calculateRhat(const vector<double> &means, const vector<double> &variance
 extern "C" int orc_sb_estimate(const void *h, const char *newick, const char *path_names, const int32_t *sig_nodes, int32_t n_sig,
                                const orc_sb_estimate_cfg *cfg, const char *prefix) {
     try {
-        Tree taxatree;
-        read_newick(newick, taxatree);
+        Tree tr;
+        read_newick(newick, tr);
         Run R(h, cfg->seed);
         {
-            istringstream ns(path_names);
-            string line;
-            int idx = 0;
-            while (getline(ns, line)) R.path_index[line] = idx++;
+            istringstream names(path_names);
+            string name;
+            for (int idx = 0; getline(names, name); ++idx) R.path_index[name] = idx;
         }
-        int leafcounter = 0;
-        for (Node *n : taxatree.nodes)
-            if (n->isLeaf()) leafcounter++;
-        const int numPaths = (int)R.path_index.size();
-        vector<int> sigNodes(sig_nodes, sig_nodes + n_sig);
-        vector<string> sigPaths;
-        for (int v : sigNodes) sigPaths.emplace_back(taxatree.nodes.at(v)->longname);
-        const string num = prefix;
-        for (size_t i = 0; i < sigNodes.size(); ++i) {
-            vector<int> subVector(sigNodes.begin(), sigNodes.begin() + i + 1);
-            double logLike = 0.0L;
-            double freq = log(1.0 / sigNodes.size());
-            if (sigPaths.size() == 1) {
-                int32_t p = R.path_index.at(sigPaths[i]);
-                logLike = orc_sb_mixture_loglike(h, 1, &p, 0.0);
-            } else {
-                vector<int32_t> ps;
-                for (size_t j = 0; j < subVector.size(); ++j) ps.push_back(R.path_index.at(sigPaths[j]));
-                logLike = orc_sb_mixture_loglike(h, (int32_t)ps.size(), ps.data(), freq);
+        int n_leaves = 0;
+        for (Node *n : tr.nodes) n_leaves += n->isLeaf() ? 1 : 0;
+        ChainCfg cc{cfg->max_iter, cfg->burn, cfg->con, cfg->freqs7, (int)R.path_index.size()};
+        vector<int32_t> sig_paths;
+        for (int32_t i = 0; i < n_sig; ++i) sig_paths.push_back(R.path_index.at(tr.nodes.at(sig_nodes[i])->longname));
+        const string out = prefix;
+        for (int32_t k = 1; k <= n_sig; ++k) { /* soibean.cpp:738-944: the first k starting nodes as sources */
+            /* initial log-likelihood: a lone source is the plain sum, otherwise an equal-weight mixture with weight 1 / #starting nodes */
+            const double start_ll = n_sig == 1 ? orc_sb_mixture_loglike(h, 1, &sig_paths[k - 1], 0.0)
+                                               : orc_sb_mixture_loglike(h, k, sig_paths.data(), log(1.0 / n_sig));
+            if (!cfg->run_mcmc) continue;
+            ofstream diag(out + "Diagnostics" + to_string(k) + "0.txt");
+            diag << "Source\tHighest log-likelihood\tfor chain\tRhat for the proportion estimate\tRhat for the branch position estimate" << endl;
+            map<string, vector<vector<vector<double>>>> seen; /* branch -> chain -> entries (definition: one slot per chain) */
+            vector<double> best_of_chain;
+            vector<int> start(sig_nodes, sig_nodes + k);
+            for (unsigned chain = 0; chain < cfg->chains; ++chain) {
+                if (chain != 0) start = random_start_nodes(R, cc.n_paths, k);
+                const vector<State> kept = run_chain(R, tr, start, start_ll, cc, out, chain);
+                const ChainSummary sum = summarise(kept, k, out, chain, tr, n_leaves);
+                best_of_chain.push_back(sum.best);
+                for (const auto &b : sum.by_branch) {
+                    seen[b.first].resize(cfg->chains);
+                    seen[b.first][chain] = b.second;
+                }
             }
-            Params params;
-            params.tr = &taxatree;
-            params.sources = subVector;
-            params.burn = cfg->burn;
-            params.maxIter = cfg->max_iter;
-            params.chains = cfg->chains;
-            params.logLike = logLike;
-            params.freqs7 = cfg->freqs7;
-            vector<vector<MCMCiteration>> MCMCiterationsVec(cfg->chains);
-            if (cfg->run_mcmc) {
-                ofstream diagnostics;
-                map<string, vector<vector<vector<double>>>> branchStatsMap;
-                unsigned int chainIndex = 0;
-                vector<double> chainLogLikes;
-                diagnostics.open(num + "Diagnostics" + to_string(subVector.size()) + to_string(chainIndex) + ".txt");
-                diagnostics << "Source\tHighest log-likelihood\tfor chain\tRhat for the proportion estimate\tRhat for the branch position estimate" << endl;
-                for (auto &chainVec : MCMCiterationsVec) {
-                    if (chainIndex != 0) params.sources = soibean_generateRandomNumbers(R, numPaths, subVector.size());
-                    vector<MCMCiteration> chainiter = run_tree_proportion(R, params, chainVec, num, numPaths, chainIndex, cfg->con);
-                    auto intermStatsMapPair = processMCMCiterations(chainiter, subVector.size(), num, chainIndex, &taxatree, leafcounter);
-                    chainLogLikes.emplace_back(intermStatsMapPair.second);
-                    for (const auto &branchStat : intermStatsMapPair.first) {
-                        auto &slot = branchStatsMap[branchStat.first];
-                        slot.resize(cfg->chains); /* definition: one slot per chain, empty when the chain did not visit the branch */
-                        slot[chainIndex] = branchStat.second;
-                    }
-                    chainIndex++;
+            const int chain_len = cfg->max_iter - cfg->burn;
+            int winner = 0;
+            for (size_t c = 0; c < best_of_chain.size(); ++c)
+                if (best_of_chain[c] > best_of_chain[winner]) winner = c;
+            for (const auto &b : seen) {
+                vector<double> sm, sv, pm, pv;
+                for (unsigned c = 0; c < cfg->chains; ++c) {
+                    vector<double> row = (b.second[c].empty() || b.second[c][0].size() < 4) ? vector<double>{1.0, 1.0, 1.0, 1.0} : b.second[c][0];
+                    sm.push_back(row[0]);
+                    sv.push_back(row[1]);
+                    pm.push_back(row[2]);
+                    pv.push_back(row[3]);
                 }
-                int numChains = cfg->chains;
-                int chainLength = cfg->max_iter - cfg->burn;
-                for (const auto &branchStat : branchStatsMap) {
-                    const auto &branchName = branchStat.first;
-                    auto allChainStats = branchStat.second;
-                    vector<double> Propmeans(numChains, 1.0), Propvariances(numChains, 1.0), Posmeans(numChains, 1.0), Posvariances(numChains, 1.0);
-                    for (int chain = 0; chain < numChains; ++chain) {
-                        if (allChainStats[chain].empty()) allChainStats[chain] = {{1.0, 1.0, 1.0, 1.0}};
-                        if (allChainStats[chain][0].size() < 4) allChainStats[chain][0].resize(4, 1.0);
-                        Propmeans[chain] = allChainStats[chain][0][0];
-                        Propvariances[chain] = allChainStats[chain][0][1];
-                        Posmeans[chain] = allChainStats[chain][0][2];
-                        Posvariances[chain] = allChainStats[chain][0][3];
-                    }
-                    double maxLogLike = chainLogLikes[0];
-                    int maxIndex = 0;
-                    for (size_t hh = 0; hh < chainLogLikes.size(); ++hh)
-                        if (chainLogLikes[hh] > maxLogLike) {
-                            maxLogLike = chainLogLikes[hh];
-                            maxIndex = hh;
-                        }
-                    double PropRhat = calculateRhat(Propmeans, Propvariances, chainLength);
-                    double PosRhat = calculateRhat(Posmeans, Posvariances, chainLength);
-                    diagnostics << branchName << '\t' << maxLogLike << '\t' << maxIndex << '\t' << PropRhat << '\t' << PosRhat << std::endl;
-                }
+                diag << b.first << '\t' << best_of_chain[winner] << '\t' << winner << '\t' << gelman_rubin(sm, sv, chain_len) << '\t' << gelman_rubin(pm, pv, chain_len)
+                     << std::endl;
             }
         }
         return 0;
