@@ -164,41 +164,48 @@ __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDe
 
 // ---------------------------------------------------------------------------------------------- HKY tables
 // hky[e][which][ref*5+read]: which = 0 child (t2), 1 parent (t1); MCMC.h:111-296 minus the "+ detail.logLikelihood"
-__device__ __forceinline__ double sb_hky_entry(const SbSourceDev &s, uint32_t which, uint32_t j, double con, const double *__restrict__ freqs7) {
-    const int ref = j / 5, rd = j % 5;
-    const double t = which ? s.t1 : s.t2;
+// log of the HKY transition probability ref -> bpo over time t, floored at 1e-8 (MCMC.h:144-233)
+__device__ __forceinline__ double sb_hky_logp(double t, int ref, int bpo, const double *__restrict__ freqs7) {
     const double fR = freqs7[4], fY = freqs7[5], mu = freqs7[6];
     const double kappa = 0.0; // 1/22 in integer arithmetic (MCMC.h:66)
-    double P[4];
-    for (int bpo = 0; bpo < 4; ++bpo) {
-        const double f = freqs7[bpo];
-        const bool pur = bpo == 0 || bpo == 2; // A, G
-        const double grp = pur ? fR : fY;
-        const double Aexp = 1 + grp * (kappa - 1);
-        double v;
-        if (bpo == ref) {
-            const double jut1 = f + f * ((1 / grp) - 1) * exp(-(mu * t));
-            const double jut11 = ((grp - f) / grp) * exp(-(mu * t * Aexp));
-            v = jut1 + jut11;
-        } else if (ref < 4 && (bpo ^ ref) == 2) { // transition partner: A<->G, C<->T
-            const double jut1 = f + f * ((1 / grp) - 1) * exp(-(mu * t));
-            const double jut11 = (f / grp) * exp(-(mu * t * Aexp));
-            v = jut1 > jut11 ? jut1 - jut11 : jut11 - jut1;
-        } else {
-            v = f * (1 - exp(-(mu * t)));
-        }
-        P[bpo] = v < 1e-8 ? 1e-8 : v; // NaN stays NaN and trips the guard downstream
+    const double f = freqs7[bpo];
+    const bool pur = bpo == 0 || bpo == 2; // A, G
+    const double grp = pur ? fR : fY;
+    const double Aexp = 1 + grp * (kappa - 1);
+    double v;
+    if (bpo == ref) {
+        const double jut1 = f + f * ((1 / grp) - 1) * exp(-(mu * t));
+        const double jut11 = ((grp - f) / grp) * exp(-(mu * t * Aexp));
+        v = jut1 + jut11;
+    } else if (ref < 4 && (bpo ^ ref) == 2) { // transition partner: A<->G, C<->T
+        const double jut1 = f + f * ((1 / grp) - 1) * exp(-(mu * t));
+        const double jut11 = (f / grp) * exp(-(mu * t * Aexp));
+        v = jut1 > jut11 ? jut1 - jut11 : jut11 - jut1;
+    } else {
+        v = f * (1 - exp(-(mu * t)));
     }
-    // log-sum-exp over the four post-mutation bases of log P_b + log(b == read ? 1 - con : con/3), folded as the reference does
+    return log(v < 1e-8 ? 1e-8 : v); // NaN stays NaN and trips the guard downstream
+}
+
+// log-sum-exp over the four post-mutation bases of log P_b + log(b == read ? 1 - con : con/3), folded as the reference does
+__device__ __forceinline__ double sb_hky_fold(const double *__restrict__ logp4, int rd, double con) {
     double acc = -INFINITY;
     for (int bpd = 0; bpd < 4; ++bpd) {
-        const double y = log(P[bpd]) + (bpd == rd ? log(1 - con) : log(con / 3));
+        const double y = logp4[bpd] + (bpd == rd ? log(1 - con) : log(con / 3));
         if (acc == 0.0) acc = y; // oplusInitnatl
         else if (acc == -INFINITY) acc = y;
         else acc = fmax(acc, y) + log1p(exp(-fabs(acc - y)));
     }
     if (acc > 1e-8) acc = log(0.999999999);
     return acc;
+}
+
+__device__ __forceinline__ double sb_hky_entry(const SbSourceDev &s, uint32_t which, uint32_t j, double con, const double *__restrict__ freqs7) {
+    const int ref = j / 5, rd = j % 5;
+    const double t = which ? s.t1 : s.t2;
+    double lp[4];
+    for (int bpo = 0; bpo < 4; ++bpo) lp[bpo] = sb_hky_logp(t, ref, bpo, freqs7);
+    return sb_hky_fold(lp, rd, con);
 }
 
 __global__ void sb_hky_kernel(uint32_t n_entries, const SbSourceDev *__restrict__ src, double con,
@@ -309,6 +316,8 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesD
 #pragma unroll
     for (uint32_t y = 0; y < SB_FUSED_MAX_K; ++y)
         if (threadIdx.x == y && y < k) src_s[y] = a.src[y]; // constant indices into the kernel arguments
+    // one lane per table entry (splitting an entry's chain of transcendentals over two steps saved 3 us of prologue but made
+    // the compiler allocate 85 instead of 116 VGPRs and serialise the loads of the main loop: 82 -> 200 us at 1M reads)
     for (uint32_t i = threadIdx.x; i < k * 2 * SB_NCNT; i += SBL_THREADS) {
         const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
         SbSourceDev s;
