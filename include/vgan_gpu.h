@@ -544,6 +544,9 @@ typedef struct vgan_sb_engine {
     int (*mixture)(void *user, uint32_t n, const int32_t *paths, double log_freq, double *loglike);
 } vgan_sb_engine;
 int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out); /* vgan_sb_loglike / vgan_sb_mixture_loglike of the context */
+/* the engine's refresh is one fused kernel plus a fold into pinned host memory; on != 0 brackets it with HIP events so that
+ * vgan_sb_kernel_ms (slot 1) reports it as well -- off by default: the chain is launch bound and two event records cost */
+int vgan_sb_time_engine(vgan_sb_ctx *c, int on);
 
 typedef struct vgan_sb_estimate_cfg {
     uint32_t max_iter;  /* --iter (500000) */

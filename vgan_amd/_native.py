@@ -237,6 +237,7 @@ SYMBOLS = {
     "vgan_tree_view_get": (C.c_int, [vp, C.POINTER(TreeView)]),
     "vgan_tree_free": (None, [vp]),
     "vgan_sb_engine_gpu": (C.c_int, [vp, C.POINTER(SbEngine)]),
+    "vgan_sb_time_engine": (C.c_int, [vp, C.c_int]),
     "vgan_sb_estimate": (C.c_int, [C.POINTER(SbEngine), vp, vp, vp, C.c_uint32, C.POINTER(SbEstimateCfg), C.c_char_p]),
     "vgan_sb_best_paths": (C.c_int, [vp, vp, vp, vp]),
     "vgan_sb_mixture_loglike": (C.c_int, [vp, C.c_uint32, vp, C.c_double, vp]),

@@ -70,6 +70,7 @@ struct vgan_sb_ctx {
     std::vector<char> h_params; // host staging of one refresh's parameters
     // the chain driver's refresh (one state per call, launch bound) is one kernel writing into pinned host memory
     char *pin = nullptr;                 // out double | guard u64
+    bool time_refresh = false;           // HIP events around the engine's refresh too (vgan_sb_time_engine)
     Buf<unsigned long long> ticket;      // guard count of the fused refresh, zero between refreshes
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[2] = {false, false};
@@ -419,7 +420,12 @@ static int refresh_one(vgan_sb_ctx *c, uint32_t k, const vgan_sb_source *src, do
     }
     double *pin_out = reinterpret_cast<double *>(c->pin);
     unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + 8);
-    launch_sb_refresh_fused(c->t, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, c->stream);
+    if (c->time_refresh) {
+        resolve(c, 1);
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    }
+    launch_sb_refresh_fused(c->t, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, c->stream, c->time_refresh ? c->ev[3] : nullptr);
+    if (c->time_refresh) c->pending[1] = true;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = *pin_out;
@@ -433,6 +439,12 @@ static int engine_refresh(void *user, uint32_t k, const vgan_sb_source *src, dou
 }
 static int engine_mixture(void *user, uint32_t n, const int32_t *paths, double log_freq, double *out) {
     return vgan_sb_mixture_loglike((vgan_sb_ctx *)user, n, paths, log_freq, out);
+}
+
+extern "C" int vgan_sb_time_engine(vgan_sb_ctx *c, int on) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_sb_time_engine: null context");
+    c->time_refresh = on != 0;
+    return VGAN_OK;
 }
 
 extern "C" int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out) {

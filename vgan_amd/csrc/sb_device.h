@@ -65,7 +65,8 @@ void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const
 // one state, two launches, no copies: out_host / guard_host are pinned host memory; guard = one zeroed device word (left
 // zeroed); partial: n_blocks doubles.  Bit-identical to launch_sb_hky + launch_sb_loglike for one state.
 void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
-                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st);
+                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st,
+                             hipEvent_t after_main /* recorded between the two kernels when not null */);
 // per-read best path (-1: tie or excluded read), per-path signature counts and the number of usable reads; counters zeroed by the caller
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
                           unsigned long long *n_ok, hipStream_t st);

@@ -437,8 +437,10 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_mixture_kernel(SbTablesDev t, 
 
 // ---------------------------------------------------------------------------------------------- launchers
 void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
-                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st) {
+                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st,
+                             hipEvent_t after_main) {
     hipLaunchKernelGGL(sb_refresh_fused_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, k, a, partial, guard);
+    if (after_main) (void)hipEventRecord(after_main, st); // the timed interval is the fused kernel alone
     hipLaunchKernelGGL(sb_finish_host_kernel, dim3(1), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host);
 }
 

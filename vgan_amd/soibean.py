@@ -81,6 +81,23 @@ class SbContext:
                                         device_out.data_ptr() if device_out is not None else None, guard.ctypes.data))
         return out, guard
 
+    def refresh(self, state, con, freqs7):
+        """One state through the chain driver's engine (fused kernel + fold into pinned host memory): (logLike, guard).
+        state: list of (child, parent, dist, pos, theta)."""
+        if getattr(self, "_engine", None) is None:
+            self._engine = N.SbEngine()
+            N.check(N.lib().vgan_sb_engine_gpu(self._h, C.byref(self._engine)))
+            self._f7 = (C.c_double * 7)()
+            self._out, self._gd = C.c_double(0), C.c_uint64(0)
+        k = len(state)
+        arr = (N.SbSource * k)(*[N.SbSource(*s) for s in state])
+        self._f7[:] = list(freqs7)
+        N.check(self._engine.refresh(self._engine.user, k, C.cast(arr, C.c_void_p), con, self._f7, C.byref(self._out), C.byref(self._gd)))
+        return self._out.value, self._gd.value
+
+    def time_engine(self, on=True):
+        N.check(N.lib().vgan_sb_time_engine(self._h, int(on)))
+
     def best_paths(self):
         """analyse_GAM's mostProbPath: (best[n_reads] with -1 for ties / excluded reads, sig_count[n_paths], n_reads_ok)."""
         best = np.zeros(max(self.n_reads, 1), np.int32)
