@@ -5,8 +5,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
+
+#include <sys/stat.h>
 
 #include "vgan_gpu.h"
 
@@ -36,6 +39,34 @@ inline double parse_double(const std::string &v, const char *flag, const char *t
         die(std::string(tool) + " Error, option " + flag + " needs a number, got '" + v + "'");
     return x;
 }
+
+inline bool is_file(const std::string &p) {
+    struct stat sb;
+    return stat(p.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+}
+
+inline bool ends_with(const std::string &s, const char *suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// the reference's subcommands take FASTQ only (Euka.cpp:213-222, soibean.cpp:286-296)
+inline void reject_fasta(const std::string &f, const char *tool) {
+    for (const char *suf : {".fa", ".fasta", ".fa.gz", ".fasta.gz"})
+        if (ends_with(f, suf)) die(std::string(tool) + " Input file must be FASTQ, not FASTA");
+}
+
+// frees a C-ABI object on every exit path
+template <class T> struct Handle {
+    T *p = nullptr;
+    void (*release)(T *);
+    explicit Handle(void (*r)(T *)) : release(r) {}
+    ~Handle() {
+        if (p) release(p);
+    }
+    Handle(const Handle &) = delete;
+    Handle &operator=(const Handle &) = delete;
+};
 
 // phase times to stderr when VGAN_TIMING is set (developer aid)
 struct PhaseTimer {

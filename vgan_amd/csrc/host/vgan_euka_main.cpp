@@ -17,8 +17,6 @@
 #include <thread>
 #include <vector>
 
-#include <sys/stat.h>
-
 #include "cli_util.h"
 
 using namespace vgan_cli;
@@ -56,32 +54,6 @@ std::string euka_usage() {
            "   --device [INT]    GPU index (default 0)\n";
 }
 
-bool is_file(const std::string &p) {
-    struct stat sb;
-    return stat(p.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
-}
-
-bool ends_with(const std::string &s, const char *suf) {
-    const size_t n = strlen(suf);
-    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
-}
-
-void reject_fasta(const std::string &f) { // Euka.cpp:213-214,221-222
-    for (const char *suf : {".fa", ".fasta", ".fa.gz", ".fasta.gz"})
-        if (ends_with(f, suf)) die("[euka] Input file must be FASTQ, not FASTA");
-}
-
-template <class T> struct Handle { // frees a C-ABI object on every exit path
-    T *p = nullptr;
-    void (*release)(T *);
-    explicit Handle(void (*r)(T *)) : release(r) {}
-    ~Handle() {
-        if (p) release(p);
-    }
-    Handle(const Handle &) = delete;
-    Handle &operator=(const Handle &) = delete;
-};
-
 } // namespace
 
 int euka_main(int argc, char **argv) {
@@ -111,8 +83,8 @@ int euka_main(int argc, char **argv) {
             euka_dir = need("--euka_dir");
             if (euka_dir.empty() || euka_dir.back() != '/') euka_dir += '/';
         } else if (a == "--dbprefix") dbprefix = need("--dbprefix");
-        else if (a == "-fq1") reject_fasta(fq1 = need("-fq1"));
-        else if (a == "-fq2") reject_fasta(fq2 = need("-fq2"));
+        else if (a == "-fq1") reject_fasta(fq1 = need("-fq1"), T);
+        else if (a == "-fq2") reject_fasta(fq2 = need("-fq2"), T);
         else if (a == "-i") {
             interleaved = true;
             if (!fq2.empty()) die("[euka] If interleaved option chosen, Euka expects only one FASTQ file");

@@ -18,8 +18,6 @@
 #include <thread>
 #include <vector>
 
-#include <sys/stat.h>
-
 #include "cli_util.h"
 
 using namespace vgan_cli;
@@ -50,32 +48,6 @@ std::string soibean_usage() {
            "   --seed [INT]         reproducible chains (default 0: std::random_device)\n"
            "   --device [INT]       GPU index (default 0)\n";
 }
-
-bool is_file(const std::string &p) {
-    struct stat sb;
-    return stat(p.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
-}
-
-bool ends_with(const std::string &s, const char *suf) {
-    const size_t n = strlen(suf);
-    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
-}
-
-void reject_fasta(const std::string &f) {
-    for (const char *suf : {".fa", ".fasta", ".fa.gz", ".fasta.gz"})
-        if (ends_with(f, suf)) die("[soibean] Input file must be FASTQ, not FASTA");
-}
-
-template <class T> struct Handle {
-    T *p = nullptr;
-    void (*release)(T *);
-    explicit Handle(void (*r)(T *)) : release(r) {}
-    ~Handle() {
-        if (p) release(p);
-    }
-    Handle(const Handle &) = delete;
-    Handle &operator=(const Handle &) = delete;
-};
 
 std::vector<std::string> lines_of(const char *joined, size_t n) {
     std::vector<std::string> out;
@@ -117,8 +89,8 @@ int soibean_main(int argc, char **argv) {
         } else if (a == "--dbprefix") {
             dbprefix = need("--dbprefix");
             dbprefix_found = true;
-        } else if (a == "-fq1") reject_fasta(fq1 = need("-fq1"));
-        else if (a == "-fq2") reject_fasta(fq2 = need("-fq2"));
+        } else if (a == "-fq1") reject_fasta(fq1 = need("-fq1"), T);
+        else if (a == "-fq2") reject_fasta(fq2 = need("-fq2"), T);
         else if (a == "-i") {
             if (!fq2.empty()) die("[soibean] If interleaved option chosen, soibean expects only one FASTQ file");
         } else if (a == "-g") gam = need("-g");
