@@ -8,6 +8,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 #include <sys/stat.h>
 
@@ -66,6 +67,35 @@ template <class T> struct Handle {
     }
     Handle(const Handle &) = delete;
     Handle &operator=(const Handle &) = delete;
+};
+
+// Decodes a GAM on a thread of its own while the caller loads tables and brings the device up (about 0.2 s of HIP
+// initialisation that would otherwise sit in front of the decode).
+class GamReader {
+  public:
+    void start(const std::string &path, int keep_unmapped) {
+        th_ = std::thread([this, path, keep_unmapped] {
+            rc_ = vgan_aln_read_gam(path.c_str(), keep_unmapped, &aln_);
+            if (rc_ < 0) err_ = vgan_last_error(); // the message is thread local: carry it over
+        });
+    }
+    vgan_alnset *take() { // joins; throws what the reader reported
+        if (th_.joinable()) th_.join();
+        if (rc_ < 0) die("[vgan] reading GAM: " + err_);
+        vgan_alnset *a = aln_;
+        aln_ = nullptr;
+        return a;
+    }
+    ~GamReader() {
+        if (th_.joinable()) th_.join();
+        if (aln_) vgan_aln_free(aln_);
+    }
+
+  private:
+    std::thread th_;
+    vgan_alnset *aln_ = nullptr;
+    int rc_ = 0;
+    std::string err_;
 };
 
 // phase times to stderr when VGAN_TIMING is set (developer aid)

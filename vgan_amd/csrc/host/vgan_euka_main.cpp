@@ -145,6 +145,8 @@ int euka_main(int argc, char **argv) {
     if (run_mcmc && iter - burnin - 1 <= 0) die("[euka] Error, --iter must exceed --burnin + 1");
 
     PhaseTimer pt("euka");
+    GamReader reader; // unmapped reads are kept so that they are counted
+    reader.start(gam, 1);
     Handle<vgan_damage> dmg(vgan_damage_free);
     check(vgan_damage_load(deam5.empty() ? nullptr : deam5.c_str(), deam3.empty() ? nullptr : deam3.c_str(), &dmg.p), "damage profiles");
     std::cerr << "Reading in taxa information ..." << std::endl;
@@ -181,7 +183,7 @@ int euka_main(int argc, char **argv) {
 
     std::cerr << "Estimating clades: Please be patient! Depending on the size of your input file, this process can take some time." << std::endl;
     Handle<vgan_alnset> aln(vgan_aln_free);
-    check(vgan_aln_read_gam(gam.c_str(), 1, &aln.p), "reading GAM"); // unmapped reads are kept so that they are counted
+    aln.p = reader.take();
     vgan_alnset_view av;
     check(vgan_aln_view_get(aln.p, &av), "alignment view");
     pt.lap("GAM decode");

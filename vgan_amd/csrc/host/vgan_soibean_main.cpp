@@ -143,6 +143,8 @@ int soibean_main(int argc, char **argv) {
     if (!is_file(gam)) die("[soibean] Error, GAM input file " + gam + " does not exist");
 
     PhaseTimer pt("soibean");
+    GamReader reader;
+    reader.start(gam, 0);
     Handle<vgan_damage> dmg(vgan_damage_free);
     check(vgan_damage_load(deam5.empty() ? nullptr : deam5.c_str(), deam3.empty() ? nullptr : deam3.c_str(), &dmg.p), "damage profiles");
     std::cerr << "Reading in variation graph ..." << std::endl;
@@ -208,7 +210,7 @@ int soibean_main(int argc, char **argv) {
     Handle<vgan_sb_ctx> ctx(vgan_sb_destroy);
     check(vgan_sb_create(&gv, &dmv, &prm, device, &ctx.p), "creating the device context");
     Handle<vgan_alnset> aln(vgan_aln_free);
-    check(vgan_aln_read_gam(gam.c_str(), 0, &aln.p), "reading GAM");
+    aln.p = reader.take();
     vgan_alnset_view av;
     check(vgan_aln_view_get(aln.p, &av), "alignment view");
     Handle<vgan_sb_host_batch> hb(vgan_sb_host_batch_free);
