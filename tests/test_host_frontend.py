@@ -101,6 +101,17 @@ def test_odgi_graph_equals_its_gfa(golden_dir, tmp_path):
     ga, gb = np.asarray(a.pathsgo()), np.asarray(b.pathsgo())
     for j, n in enumerate(b.path_names):
         assert np.array_equal(ga[:, col[n]], gb[:, j]), n
+    # with a graph_paths sidecar (and no path_supports) the columns follow the sidecar's names, whatever order the .og has
+    import shutil
+    hcdir = tmp_path / "hc"
+    hcdir.mkdir()
+    shutil.copy(os.path.join(d, "target_graph.og"), str(hcdir / "graph.og"))
+    (hcdir / "graph_paths").write_text("seq_3 extra tokens\nseq_1\nseq_2\nseq_5\nseq_4\n")
+    c = hc.Graph.load(str(hcdir / "graph.og"), str(hcdir))
+    assert c.path_names == ["seq_3", "seq_1", "seq_2", "seq_5", "seq_4"]
+    gc = np.asarray(c.pathsgo())
+    for j, n in enumerate(c.path_names):
+        assert np.array_equal(ga[:, col[n]], gc[:, j]), n
     raw = open(os.path.join(d, "target_graph.og"), "rb").read()
     import random
     rng = random.Random(5)

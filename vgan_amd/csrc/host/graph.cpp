@@ -286,6 +286,7 @@ static int graph_load_impl(const char *gfa_path, const char *hcfiles_dir, vgan_g
     std::string dir = hcfiles_dir ? hcfiles_dir : "";
     if (!dir.empty() && dir.back() != '/') dir += '/';
     std::string side;
+    const std::string names_in_graph = g->path_names; // P-line / ODGI handle order: the order of path_steps
     // graph_paths (load.cpp:43-58): first whitespace token of each line
     if (!dir.empty() && read_text_maybe_gz(dir + "graph_paths", side)) {
         g->path_names.clear();
@@ -367,6 +368,30 @@ static int graph_load_impl(const char *gfa_path, const char *hcfiles_dir, vgan_g
         for (unsigned t = 1; t < nth; ++t) first_row[t] = first_row[t - 1] + rows_in[t - 1];
         run([&](unsigned t) { parse(t, first_row[t]); });
     } else {
+        // mask from the graph's own paths.  When graph_paths renamed / reordered the paths (an ODGI file lists its paths in
+        // handle order, not in the order of the sidecar), the steps follow the sidecar's order by name
+        if (g->path_names != names_in_graph && !g->path_steps.empty()) {
+            std::map<std::string, size_t> col;
+            {
+                LineIter it(names_in_graph);
+                const char *b, *e;
+                size_t i = 0;
+                while (it.next(b, e)) col.emplace(std::string(b, e), i++);
+            }
+            std::vector<std::vector<std::pair<int64_t, bool>>> ordered;
+            LineIter it(g->path_names);
+            const char *b, *e;
+            bool all = true;
+            while (it.next(b, e)) {
+                const auto f = col.find(std::string(b, e));
+                if (f == col.end() || f->second >= g->path_steps.size()) {
+                    all = false;
+                    break;
+                }
+                ordered.push_back(g->path_steps[f->second]);
+            }
+            if (all && ordered.size() == g->n_paths) g->path_steps.swap(ordered); // otherwise: positional, as before
+        }
         mask_from_steps(*g);
     }
     pt.lap("path_supports rows");
