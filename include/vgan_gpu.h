@@ -515,7 +515,9 @@ void vgan_sb_destroy(vgan_sb_ctx *c);
  * Where the reference leaves the behaviour open this build defines it:
  *  - randomness: every std::random_device call is replaced by the next output of a splitmix64 stream started at `seed`
  *    (0 = the hardware source, as the reference); libc rand() -- never seeded there -- and the function-local static engine
- *    of sample_normal by one std::mt19937 each per vgan_sb_estimate call, seeded from that stream first;
+ *    of sample_normal by one std::mt19937 each per chain, seeded from that stream when the chain starts (before the chain's
+ *    own engine).  Chains therefore do not share random state: vgan_sb_estimate advances the chains of a source count
+ *    together and evaluates their proposed states in one likelihood call (one launch) per iteration;
  *  - tree nodes are numbered in pre-order of the Newick text (spidir, the reference's tree library, is not in its tree);
  *  - getPatristicDistances indexes a vector of #leaves entries by node index: only indices below #leaves are compared;
  *  - diagnostics rows come in branch-name order (an unordered_map there); a branch a chain did not end on takes the
@@ -542,6 +544,10 @@ typedef struct vgan_sb_engine {
     void *user;
     int (*refresh)(void *user, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7, double *loglike, uint64_t *guard);
     int (*mixture)(void *user, uint32_t n, const int32_t *paths, double log_freq, double *loglike);
+    /* optional (may be NULL): n_states states of k sources each in one call; src[n_states * k], loglike / guard[n_states].
+     * vgan_sb_estimate advances the chains of one source count together and asks for all their states at once. */
+    int (*refresh_many)(void *user, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                        double *loglike, uint64_t *guard);
 } vgan_sb_engine;
 int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out); /* vgan_sb_loglike / vgan_sb_mixture_loglike of the context */
 /* the engine's refresh is one fused kernel plus a fold into pinned host memory; on != 0 brackets it with HIP events so that

@@ -15,7 +15,7 @@
  * estimated source; neither is available here.  spidir (the tree library) is not in the reference tree: the Newick reader
  * below numbers nodes in pre-order of the text.
  * Randomness and undefined behaviour are resolved as include/vgan_gpu.h states for vgan_sb_estimate (seed stream standing in
- * for std::random_device, one mt19937 for rand(), one for sample_normal's static engine; distances beyond #leaves ignored;
+ * for std::random_device, per chain one mt19937 for rand() and one for sample_normal's static engine; distances beyond #leaves ignored;
  * branches in name order with the reference's {1, 1, 1, 1} defaults for chains that did not end on them).
  */
 #include "oracle.h"
@@ -136,7 +136,7 @@ struct Run {
     Entropy rd;
     mt19937 rand_engine;  /* stands in for rand() */
     mt19937 theta_engine; /* sample_normal's function-static generator */
-    Run(const void *handle, uint64_t seed) : h(handle), rd(seed), rand_engine(rd()), theta_engine(rd()) {}
+    Run(const void *handle, uint64_t seed) : h(handle), rd(seed) {} /* both engines are re-seeded from rd when a chain starts */
     unsigned pick(unsigned n) { return rand_engine() % n; } /* rand() % n */
 };
 
@@ -391,7 +391,9 @@ string state_line(const State &st, double loglik, const char *verdict) {
 /* MCMC::run_tree_proportion (MCMC.cpp:522-1093): returns the states recorded after the burn-in */
 vector<State> run_chain(Run &R, Tree &tr, const vector<int> &start_nodes, double start_loglik, const ChainCfg &cfg, const string &prefix, int chain) {
     const unsigned k = start_nodes.size();
-    mt19937 gen(R.rd());
+    R.rand_engine.seed(R.rd()); /* each chain has its own stand-ins for rand() and for sample_normal's static engine ... */
+    R.theta_engine.seed(R.rd());
+    mt19937 gen(R.rd()); /* ... next to the reference's own per-chain engine */
     uniform_real_distribution<> unit(0.0, 1.0);
     State cur = start_state(R, tr, start_nodes, start_loglik);
     const double widest = cfg.n_paths <= 30.0 ? 3.0 : cfg.n_paths * (3.0 / 30.0);

@@ -192,7 +192,7 @@ int main(int argc, char **argv) {
         REQUIRE(vgan_tree_view_get(tr, &tv) == 0 && tv.n_nodes > 10 && tv.n_leaves > 5);
         std::vector<int32_t> node_path(tv.n_nodes);
         for (uint32_t v = 0; v < tv.n_nodes; ++v) node_path[v] = (int32_t)v;
-        vgan_sb_engine eng;
+        vgan_sb_engine eng{}; // refresh_many stays null: the driver asks for one state at a time
         eng.user = nullptr;
         eng.refresh = [](void *, uint32_t k, const vgan_sb_source *src, double, const double *, double *ll, uint64_t *guard) {
             double v = -100.0;

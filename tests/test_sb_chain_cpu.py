@@ -106,11 +106,11 @@ def _setup(n_reads=100, seed=6):
     return g, o, newick, a.n_reads
 
 
-def _engine(o):
+def _engine(o, batched=False):
     def refresh(st, con, f7):
         rc, v = o.loglike(st, con, f7, n_threads=1)
         return v, (1 if rc else 0)
-    return sb.python_engine(refresh, lambda paths, lf: o.mixture_loglike(paths, lf))
+    return sb.python_engine(refresh, lambda paths, lf: o.mixture_loglike(paths, lf), batched=batched)
 
 
 def _files(prefix):
@@ -135,7 +135,9 @@ def test_chain_files_match_the_oracle(tmp_path, seed):
     kw = dict(con=0.004, iters=90, burnin=30, chains=2, seed=seed)
     po, pp = str(tmp_path / "orc_"), str(tmp_path / "prod_")
     o.estimate(newick, g.path_names, sig_nodes, po, FREQS, **kw)
-    sb.estimate(_engine(o), tree, node_path, sig_nodes, pp, g.n_paths, FREQS, **kw)
+    # the product advances its chains together (seed 1: one call per chain and iteration, seed 2: one call for all chains);
+    # the oracle runs them one after the other -- the chains own their generators, so the files are the same
+    sb.estimate(_engine(o, batched=(seed == 2)), tree, node_path, sig_nodes, pp, g.n_paths, FREQS, **kw)
     fo, fp = _files(po), _files(pp)
     k = len(sig_nodes)
     assert sorted(fo) == sorted(fp) and len(fo) == k * (2 * 2 + 3)

@@ -58,4 +58,9 @@ for n in (20000, 1000000):
     sb.estimate(ctx, tree, node_path, [3, 5], d + "/b_", g.n_paths, FREQS, iters=calls, burnin=calls // 10, chains=1, seed=3)
     dt = time.perf_counter() - t
     print("reads %8d: vgan_sb_estimate k=1..2, 1 chain x %d iterations: %.1f us per iteration (summaries included)" % (n, calls, dt / (2 * (calls + 1)) * 1e6))
+    t = time.perf_counter()
+    sb.estimate(ctx, tree, node_path, [3, 5], d + "/c_", g.n_paths, FREQS, iters=calls, burnin=calls // 10, chains=4, seed=3)
+    dt = time.perf_counter() - t
+    print("reads %8d: vgan_sb_estimate k=1..2, 4 chains advanced together x %d iterations: %.1f us per iteration of all four (summaries included)"
+          % (n, calls, dt / (2 * (calls + 1)) * 1e6))
     ctx.close()

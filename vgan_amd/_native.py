@@ -104,8 +104,12 @@ SB_REFRESH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_dou
 SB_MIXTURE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.c_double, C.POINTER(C.c_double))
 
 
+SB_REFRESH_MANY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_double, C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_uint64))
+
+
 class SbEngine(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("refresh", SB_REFRESH_FN), ("mixture", SB_MIXTURE_FN)]
+    _fields_ = [("user", C.c_void_p), ("refresh", SB_REFRESH_FN), ("mixture", SB_MIXTURE_FN), ("refresh_many", SB_REFRESH_MANY_FN)]
 
 
 class SbEstimateCfg(C.Structure):

@@ -9,8 +9,9 @@
 //
 // Definitions where the reference leaves the behaviour open (all documented in include/vgan_gpu.h):
 //  * randomness: every std::random_device call is replaced by the next output of the caller's seed stream (seed 0 = the
-//    hardware source as the reference); libc rand() (unseeded there, so one fixed sequence per process) by one mt19937 of
-//    the run; the function-local static generator of sample_normal by one mt19937 of the run;
+//    hardware source as the reference); libc rand() (unseeded there, so one fixed sequence per process) and the function-local
+//    static generator of sample_normal by one mt19937 each per chain, seeded from that stream when the chain starts -- the
+//    chains are then independent of each other and are advanced together, one likelihood call per iteration for all of them;
 //  * tree node numbering (spidir is not part of the reference tree): pre-order of the Newick text;
 //  * getPatristicDistances writes distances[node index] into a vector of length #leaves: only indices below #leaves
 //    are ever compared (calculateEuclideanDistance stops at the shorter vector), which is what is computed here;
@@ -216,8 +217,7 @@ struct ChainSummary { // processMCMCiterations' return value
 class Estimator {
   public:
     Estimator(const vgan_sb_engine &e, const vgan_tree &t, const int32_t *node_path, const vgan_sb_estimate_cfg &cfg, std::string prefix)
-        : eng_(e), tree_(t), node_path_(node_path), cfg_(cfg), out_(std::move(prefix)), seeds_(cfg.seed), walk_(seeds_.next()),
-          theta_engine_(seeds_.next()) {}
+        : eng_(e), tree_(t), node_path_(node_path), cfg_(cfg), out_(std::move(prefix)), seeds_(cfg.seed) {}
 
     // soibean.cpp:738-944 for one list of starting nodes
     void run(const int32_t *sig_nodes, uint32_t n_sig) {
@@ -238,11 +238,19 @@ class Estimator {
             diag << "Source\tHighest log-likelihood\tfor chain\tRhat for the proportion estimate\tRhat for the branch position estimate" << std::endl;
             std::map<std::string, std::vector<std::vector<std::vector<double>>>> by_branch; // branch -> chain -> entries
             std::vector<double> chain_best;
+            // every chain owns its generators, so the chains are independent of each other and advance together: one
+            // likelihood call per iteration covers all of them (one launch on the GPU)
+            std::vector<std::unique_ptr<Chain>> chains;
             for (uint32_t chain = 0; chain < cfg_.chains; ++chain) {
                 if (chain != 0) sources = random_nodes(k);
-                if (!cfg_.quiet) fprintf(stderr, "Running chain number: %u\n", chain);
-                const std::vector<ChainState> kept = run_chain(sources, ll, chain);
+                chains.push_back(start_chain(sources, ll, chain));
+            }
+            if (!cfg_.quiet) fprintf(stderr, "Running %u chains of %u iterations\n", cfg_.chains, cfg_.max_iter);
+            advance_together(chains, k);
+            for (uint32_t chain = 0; chain < cfg_.chains; ++chain) {
+                const std::vector<ChainState> &kept = chains[chain]->kept;
                 const ChainSummary sum = summarise(kept, (int)k, (int)chain);
+                chains[chain].reset(); // closes its files, frees the recorded states
                 chain_best.push_back(sum.best_log_like);
                 for (const auto &b : sum.per_branch) {
                     auto &slot = by_branch[b.first];
@@ -283,11 +291,11 @@ class Estimator {
         return v;
     }
 
-    uint32_t pick(uint32_t n) { return walk_() % n; } // rand() % n
+    static uint32_t pick(std::mt19937 &walk, uint32_t n) { return walk() % n; } // rand() % n
 
     // MCMC::updatePosition: walk `distance` along the tree from p, forwards (towards the leaves) or backwards.  Positions are
     // fractions of a branch; every branch counts as length 1 for the walk.
-    void move(Position &p, double distance, bool forward) {
+    void move(std::mt19937 &walk, Position &p, double distance, bool forward) const {
         if (p.pos_branch < 0.0 || p.pos_branch > 1.0) throw std::runtime_error("Error: Initial pos_branch is out of valid range.");
         if (distance < 0.0) throw std::runtime_error("Error: move distance cannot be negative.");
         double left = std::abs(distance);
@@ -300,7 +308,7 @@ class Estimator {
                     forward = false; // bounce off the leaf
                 } else {
                     const double rest = std::max(0.0, left - (1.0 - p.pos_branch));
-                    p.node = tree_.child(p.node, (int32_t)pick((uint32_t)tree_.n_children(p.node)));
+                    p.node = tree_.child(p.node, (int32_t)pick(walk, (uint32_t)tree_.n_children(p.node)));
                     check_branch(p.node, "Error: next branch length cannot be negative.");
                     if (rest > 1.0) {
                         p.pos_branch = 1.0;
@@ -320,7 +328,7 @@ class Estimator {
             const int32_t up = tree_.parent[(size_t)p.node];
             if (up < 0) { // the root: turn round into one of its children, position and remaining distance unchanged
                 forward = true;
-                p.node = tree_.child(p.node, (int32_t)pick((uint32_t)tree_.n_children(p.node)));
+                p.node = tree_.child(p.node, (int32_t)pick(walk, (uint32_t)tree_.n_children(p.node)));
                 check_branch(p.node, "Error: next branch length cannot be negative.");
                 continue;
             }
@@ -329,7 +337,7 @@ class Estimator {
             if (!tree_.leaf(p.node))
                 for (int32_t i = 0; i < tree_.n_children(up); ++i)
                     if (tree_.child(up, i) != p.node) options.push_back(tree_.child(up, i));
-            const int32_t chosen = options[pick((uint32_t)options.size())];
+            const int32_t chosen = options[pick(walk, (uint32_t)options.size())];
             if (chosen == up) {
                 const double rest = std::max(0.0, left - p.pos_branch);
                 p.node = up;
@@ -358,7 +366,7 @@ class Estimator {
                 forward = false; // `left` is kept: the walk turns round at the sibling's top
             } else {
                 const double rest2 = std::max(0.0, left - (1.0 - p.pos_branch));
-                p.node = tree_.child(p.node, (int32_t)pick((uint32_t)tree_.n_children(p.node)));
+                p.node = tree_.child(p.node, (int32_t)pick(walk, (uint32_t)tree_.n_children(p.node)));
                 check_branch(p.node, "Error: next branch length cannot be negative.");
                 if (rest2 > 1.0) {
                     p.pos_branch = 1.0;
@@ -373,7 +381,7 @@ class Estimator {
         if (tree_.dist[(size_t)node] < 0.0) throw std::runtime_error(msg);
     }
 
-    std::vector<double> sample_thetas(const std::vector<double> &x) { // MCMC::sample_normal
+    static std::vector<double> sample_thetas(std::mt19937 &theta_engine_, const std::vector<double> &x) { // MCMC::sample_normal
         std::vector<double> r;
         long double sum = 0.0L;
         for (double xi : x) {
@@ -388,10 +396,8 @@ class Estimator {
         return r;
     }
 
-    double refresh(const ChainState &st) {
-        const uint32_t k = (uint32_t)st.at.size();
-        std::vector<vgan_sb_source> src(k);
-        for (uint32_t y = 0; y < k; ++y) {
+    void sources_of(const ChainState &st, vgan_sb_source *src) const {
+        for (size_t y = 0; y < st.at.size(); ++y) {
             const int32_t node = st.at[y].node, up = tree_.parent[(size_t)node];
             src[y].child = path_of(node);
             src[y].parent = path_of(up < 0 ? node : up);
@@ -399,12 +405,25 @@ class Estimator {
             src[y].pos = st.at[y].pos_branch;
             src[y].theta = st.proportions[y];
         }
-        double ll = 0.0;
-        uint64_t guard = 0;
-        if (eng_.refresh(eng_.user, k, src.data(), cfg_.con, cfg_.freqs7, &ll, &guard) != VGAN_OK)
-            throw std::runtime_error(std::string("likelihood refresh: ") + vgan_last_error());
-        if (guard) throw std::runtime_error("Problem in the likelihood compuation! Intermediate log likelihood is -nan, -inf or positive.");
-        return ll;
+    }
+
+    // the log-likelihoods of one proposed state per chain
+    void refresh(std::vector<ChainState> &props, uint32_t k) {
+        const uint32_t n = (uint32_t)props.size();
+        std::vector<vgan_sb_source> src((size_t)n * k);
+        for (uint32_t c = 0; c < n; ++c) sources_of(props[c], src.data() + (size_t)c * k);
+        std::vector<double> ll(n, 0.0);
+        std::vector<uint64_t> guard(n, 0);
+        int rc = VGAN_OK;
+        if (eng_.refresh_many && n > 1) rc = eng_.refresh_many(eng_.user, n, k, src.data(), cfg_.con, cfg_.freqs7, ll.data(), guard.data());
+        else
+            for (uint32_t c = 0; c < n && rc == VGAN_OK; ++c)
+                rc = eng_.refresh(eng_.user, k, src.data() + (size_t)c * k, cfg_.con, cfg_.freqs7, &ll[c], &guard[c]);
+        if (rc != VGAN_OK) throw std::runtime_error(std::string("likelihood refresh: ") + vgan_last_error());
+        for (uint32_t c = 0; c < n; ++c) {
+            if (guard[c]) throw std::runtime_error("Problem in the likelihood compuation! Intermediate log likelihood is -nan, -inf or positive.");
+            props[c].log_like = ll[c];
+        }
     }
 
     static std::string line_of(const vgan_tree &t, const ChainState &s, double ll, const char *verdict) {
@@ -417,13 +436,22 @@ class Estimator {
         return o.str();
     }
 
-    // MCMC::run_tree_proportion
-    std::vector<ChainState> run_chain(const std::vector<int32_t> &sources, double start_ll, uint32_t chain) {
-        const uint32_t k = (uint32_t)sources.size(), burn = cfg_.burn, max_iter = cfg_.max_iter;
-        if (burn >= max_iter) throw std::runtime_error("Number of brun in iteration exceedes the number of total iterations. Exiting. ");
-        std::mt19937 gen(seeds_.next());
-        std::uniform_real_distribution<> unit(0.0, 1.0);
+    // One chain of MCMC::run_tree_proportion: its generators (the proposal / acceptance engine, the one standing in for rand()
+    // in the tree walk, the one standing in for sample_normal's static engine), its state, its two output files
+    struct Chain {
+        std::mt19937 walk, theta, gen;
         ChainState cur;
+        std::unique_ptr<GzLines> result, trace;
+        std::vector<ChainState> kept;
+    };
+
+    std::unique_ptr<Chain> start_chain(const std::vector<int32_t> &sources, double start_ll, uint32_t chain) {
+        const uint32_t k = (uint32_t)sources.size();
+        if (cfg_.burn >= cfg_.max_iter) throw std::runtime_error("Number of brun in iteration exceedes the number of total iterations. Exiting. ");
+        auto c = std::make_unique<Chain>();
+        c->walk.seed(seeds_.next());
+        c->theta.seed(seeds_.next());
+        c->gen.seed(seeds_.next());
         { // initializeState: normalised uniform thetas from an engine of their own, every source in the middle of its branch
             std::mt19937 g0(seeds_.next());
             std::uniform_real_distribution<> u01(0.0, 1.0);
@@ -432,56 +460,68 @@ class Estimator {
             for (double &x : th) sum += (x = u01(g0));
             for (uint32_t i = 0; i < k; ++i) {
                 if (sources[i] < 0 || (uint32_t)sources[i] >= tree_.n()) throw std::runtime_error("source node outside the tree");
-                cur.at.push_back({sources[i], 0.5, th[i] / sum});
-                cur.proportions.push_back(std::max(0.001, th[i] / sum));
+                c->cur.at.push_back({sources[i], 0.5, th[i] / sum});
+                c->cur.proportions.push_back(std::max(0.001, th[i] / sum));
             }
-            cur.log_like = start_ll;
+            c->cur.log_like = start_ll;
         }
+        const std::string tag = std::to_string(k) + std::to_string(chain);
+        c->result = std::make_unique<GzLines>(out_ + "Result" + tag + ".mcmc");
+        c->trace = std::make_unique<GzLines>(out_ + "Trace" + tag + ".detail.mcmc");
+        std::ostringstream h1, h2;
+        for (uint32_t s = 1; s <= k; ++s) {
+            h1 << "Source_" << s << "\tLog-likelihood\tproportion\tbranch_position_derived\t";
+            h2 << "Source_" << s << "\tLog-likelihood\tproportion_" << s << "\tbranch_position_derived_" << s << "\tMove\t";
+        }
+        c->result->put(h1.str() + "\n");
+        c->trace->put(h2.str() + "\n");
+        return c;
+    }
+
+    void advance_together(std::vector<std::unique_ptr<Chain>> &chains, uint32_t k) {
+        const uint32_t burn = cfg_.burn, max_iter = cfg_.max_iter;
         const double init_sd = cfg_.n_paths <= 30 ? 3.0 : cfg_.n_paths * (3.0 / 30.0);
         const double step = (init_sd - 0.1) / std::max(1u, burn - 1u), step2 = (0.1 - 1e-5) / std::max(1u, (max_iter - burn) - 1u);
-        const std::string tag = std::to_string(k) + std::to_string(chain);
-        GzLines result(out_ + "Result" + tag + ".mcmc"), trace(out_ + "Trace" + tag + ".detail.mcmc");
-        {
-            std::ostringstream h1, h2;
-            for (uint32_t s = 1; s <= k; ++s) {
-                h1 << "Source_" << s << "\tLog-likelihood\tproportion\tbranch_position_derived\t";
-                h2 << "Source_" << s << "\tLog-likelihood\tproportion_" << s << "\tbranch_position_derived_" << s << "\tMove\t";
-            }
-            result.put(h1.str() + "\n");
-            trace.put(h2.str() + "\n");
-        }
-        std::vector<ChainState> kept;
+        std::uniform_real_distribution<> unit(0.0, 1.0);
+        std::vector<ChainState> props(chains.size());
         for (uint32_t it = 0; it <= max_iter; ++it) {
-            ChainState prop = cur;
             double sd;
             if (it < burn) sd = std::max(1e-5, init_sd - it * step);
             else if (it % 100000u == 0) sd = 1;
             else sd = std::max(1e-5, 0.1 - (it - burn) * step2);
-            if (it != 0)
-                for (Position &p : prop.at) {
-                    std::normal_distribution<double> jump(0, sd);
-                    const double d = jump(gen);
-                    if (d < 0.0) move(p, -d, false);
-                    else move(p, d, true);
-                }
-            std::vector<double> th;
-            for (const Position &p : prop.at) th.push_back(p.theta);
-            th = sample_thetas(th);
-            for (uint32_t i = 0; i < k; ++i) prop.at[i].theta = th[i];
-            prop.proportions = th;
-            prop.log_like = refresh(prop);
-            const double delta = prop.log_like - cur.log_like;
-            const double accept = delta > 0 ? 1.0 : std::exp(delta);
-            const double u = unit(gen);
-            const bool take = u <= accept || it == 0;
-            trace.put(line_of(tree_, prop, prop.log_like, take ? "accepted" : "rejected"));
-            if (it > burn) { // the state the chain is leaving / staying in is what gets recorded
-                result.put(line_of(tree_, cur, cur.log_like, nullptr));
-                kept.push_back(cur);
+            for (size_t c = 0; c < chains.size(); ++c) {
+                Chain &ch = *chains[c];
+                ChainState &prop = props[c];
+                prop = ch.cur;
+                if (it != 0)
+                    for (Position &p : prop.at) {
+                        std::normal_distribution<double> jump(0, sd);
+                        const double d = jump(ch.gen);
+                        if (d < 0.0) move(ch.walk, p, -d, false);
+                        else move(ch.walk, p, d, true);
+                    }
+                std::vector<double> th;
+                for (const Position &p : prop.at) th.push_back(p.theta);
+                th = sample_thetas(ch.theta, th);
+                for (uint32_t i = 0; i < k; ++i) prop.at[i].theta = th[i];
+                prop.proportions = th;
             }
-            if (take) cur = prop;
+            refresh(props, k);
+            for (size_t c = 0; c < chains.size(); ++c) {
+                Chain &ch = *chains[c];
+                const ChainState &prop = props[c];
+                const double delta = prop.log_like - ch.cur.log_like;
+                const double accept = delta > 0 ? 1.0 : std::exp(delta);
+                const double u = unit(ch.gen);
+                const bool take = u <= accept || it == 0;
+                ch.trace->put(line_of(tree_, prop, prop.log_like, take ? "accepted" : "rejected"));
+                if (it > burn) { // the state the chain is leaving / staying in is what gets recorded
+                    ch.result->put(line_of(tree_, ch.cur, ch.cur.log_like, nullptr));
+                    ch.kept.push_back(ch.cur);
+                }
+                if (take) ch.cur = prop;
+            }
         }
-        return kept;
     }
 
     // distance from `node`, `below_top` down its branch... see getPatristicDistances: to every leaf whose node index is below #leaves
@@ -556,7 +596,6 @@ class Estimator {
     const vgan_sb_estimate_cfg &cfg_;
     std::string out_;
     SeedStream seeds_;
-    std::mt19937 walk_, theta_engine_;
 };
 
 } // namespace

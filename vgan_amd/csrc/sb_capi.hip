@@ -69,9 +69,9 @@ struct vgan_sb_ctx {
     Buf<unsigned long long> sig;
     std::vector<char> h_params; // host staging of one refresh's parameters
     // the chain driver's refresh (one state per call, launch bound) is one kernel writing into pinned host memory
-    char *pin = nullptr;                 // out double | guard u64
+    char *pin = nullptr;                 // out double[16] | guard u64[16]
     bool time_refresh = false;           // HIP events around the engine's refresh too (vgan_sb_time_engine)
-    Buf<unsigned long long> ticket;      // guard count of the fused refresh, zero between refreshes
+    Buf<unsigned long long> ticket;      // guard counts (one per state) of the fused refresh, zero between refreshes
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[2] = {false, false};
     double ms[2] = {0, 0};
@@ -384,14 +384,26 @@ extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, co
     return VGAN_OK;
 }
 
-// One state, results to the host: the per-iteration call of the chain driver -- sb_refresh_fused_kernel with the sources as
-// kernel arguments, then a one-wave fold storing the two results into pinned host memory; bit-identical to vgan_sb_loglike.
-static int refresh_one(vgan_sb_ctx *c, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7, double *out, uint64_t *guard) {
+// n_states states of k sources each, results to the host: the per-iteration call of the chain driver (the chains of one source
+// count advance together) -- sb_refresh_fused_kernel with the sources as kernel arguments, then one wave per state folding
+// the partials into pinned host memory; bit-identical to vgan_sb_loglike.
+constexpr size_t SB_PIN_BYTES = 2 * SB_FUSED_MAX_K * 8;
+
+static int refresh_states(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                          double *out, uint64_t *guard) {
     if (!c || !src || !freqs7 || !out) return fail(VGAN_EINVAL, "vgan_sb_engine refresh: null argument");
-    if (k == 0 || k > SB_FUSED_MAX_K) return vgan_sb_loglike(c, 1, k, src, con, freqs7, out, nullptr, guard);
+    if (n_states == 0 || k == 0) return fail(VGAN_EINVAL, "vgan_sb_engine refresh: need at least one state and one source");
+    const uint32_t ne = n_states * k;
+    if (ne > SB_FUSED_MAX_K) { // beyond the kernel-argument staging: the general path (a launch per call, copies)
+        std::vector<uint64_t> gd(n_states, 0);
+        const int rc = vgan_sb_loglike(c, n_states, k, src, con, freqs7, out, nullptr, gd.data());
+        if (guard)
+            for (uint32_t e = 0; e < n_states; ++e) guard[e] = gd[e];
+        return rc;
+    }
     HIPCHK(hipSetDevice(c->device));
     SbFusedArgs a;
-    for (uint32_t i = 0; i < k; ++i) {
+    for (uint32_t i = 0; i < ne; ++i) {
         if (src[i].child < 0 || src[i].parent < 0 || (uint32_t)src[i].child >= c->P || (uint32_t)src[i].parent >= c->P)
             return fail(VGAN_EINVAL, "vgan_sb_loglike: path index out of range");
         double t = src[i].dist;
@@ -406,36 +418,43 @@ static int refresh_one(vgan_sb_ctx *c, uint32_t k, const vgan_sb_source *src, do
         d.log_1mpos = log((1 - src[i].pos));
         d.log_theta = log(src[i].theta);
     }
-    for (uint32_t i = k; i < SB_FUSED_MAX_K; ++i) a.src[i] = a.src[0];
+    for (uint32_t i = ne; i < SB_FUSED_MAX_K; ++i) a.src[i] = a.src[0];
     memcpy(a.freqs7, freqs7, 7 * 8);
     a.con = con;
     const uint32_t R = c->t.n_reads;
     const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
     int rc;
-    if ((rc = c->partial.reserve(n_blocks))) return rc;
-    if (!c->pin) HIPCHK(hipHostMalloc((void **)&c->pin, 16, hipHostMallocDefault));
+    if ((rc = c->partial.reserve((size_t)n_states * n_blocks))) return rc;
+    if (!c->pin) HIPCHK(hipHostMalloc((void **)&c->pin, SB_PIN_BYTES, hipHostMallocDefault));
     if (!c->ticket.p) {
-        if ((rc = c->ticket.reserve(2))) return rc;
-        HIPCHK(hipMemsetAsync(c->ticket.p, 0, 16, c->stream));
+        if ((rc = c->ticket.reserve(SB_FUSED_MAX_K))) return rc;
+        HIPCHK(hipMemsetAsync(c->ticket.p, 0, SB_FUSED_MAX_K * 8, c->stream));
     }
     double *pin_out = reinterpret_cast<double *>(c->pin);
-    unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + 8);
+    unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + SB_FUSED_MAX_K * 8);
     if (c->time_refresh) {
         resolve(c, 1);
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
     }
-    launch_sb_refresh_fused(c->t, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, c->stream, c->time_refresh ? c->ev[3] : nullptr);
+    launch_sb_refresh_fused(c->t, n_states, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, c->stream,
+                            c->time_refresh ? c->ev[3] : nullptr);
     if (c->time_refresh) c->pending[1] = true;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    *out = *pin_out;
-    if (guard) *guard = *pin_guard;
+    for (uint32_t e = 0; e < n_states; ++e) {
+        out[e] = pin_out[e];
+        if (guard) guard[e] = pin_guard[e];
+    }
     return VGAN_OK;
 }
 
 // the chain driver's view of this context (host/sb_chain.cpp, vgan_sb_estimate)
 static int engine_refresh(void *user, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7, double *out, uint64_t *guard) {
-    return refresh_one((vgan_sb_ctx *)user, k, src, con, freqs7, out, guard);
+    return refresh_states((vgan_sb_ctx *)user, 1, k, src, con, freqs7, out, guard);
+}
+static int engine_refresh_many(void *user, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                               double *out, uint64_t *guard) {
+    return refresh_states((vgan_sb_ctx *)user, n_states, k, src, con, freqs7, out, guard);
 }
 static int engine_mixture(void *user, uint32_t n, const int32_t *paths, double log_freq, double *out) {
     return vgan_sb_mixture_loglike((vgan_sb_ctx *)user, n, paths, log_freq, out);
@@ -452,6 +471,7 @@ extern "C" int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out) {
     out->user = c;
     out->refresh = engine_refresh;
     out->mixture = engine_mixture;
+    out->refresh_many = engine_refresh_many;
     return VGAN_OK;
 }
 

@@ -62,9 +62,10 @@ void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states
 void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky,
                    unsigned long long *guard, uint32_t n_states, hipStream_t st);
 
-// one state, two launches, no copies: out_host / guard_host are pinned host memory; guard = one zeroed device word (left
-// zeroed); partial: n_blocks doubles.  Bit-identical to launch_sb_hky + launch_sb_loglike for one state.
-void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
+// n_states * k <= SB_FUSED_MAX_K sources, two launches, no copies: out_host / guard_host[n_states] are pinned host memory;
+// guard = n_states zeroed device words (left zeroed); partial: n_states * n_blocks doubles.  Bit-identical to launch_sb_hky +
+// launch_sb_loglike.
+void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
                              unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st,
                              hipEvent_t after_main /* recorded between the two kernels when not null */);
 // per-read best path (-1: tie or excluded read), per-path signature counts and the number of usable reads; counters zeroed by the caller

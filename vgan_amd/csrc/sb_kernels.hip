@@ -308,17 +308,18 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(const double *__restrict_
 // guard count straight into pinned host memory.  An MCMC iteration is launch bound at typical read counts (10 us of kernel
 // time at 20k reads): this takes it from five stream operations to two.  (Folding in the last block to finish, behind a
 // device-scope fence and a ticket per block, measured slower at 1024 blocks than the second launch.)
-__global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesDev t, uint32_t k, SbFusedArgs a, double *__restrict__ partial,
-                                                                        unsigned long long *__restrict__ guard) {
+__global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesDev t, uint32_t n_states, uint32_t k, SbFusedArgs a,
+                                                                        double *__restrict__ partial, unsigned long long *__restrict__ guard) {
     __shared__ double hk_s[SB_FUSED_MAX_K * 2 * SB_NCNT];
     __shared__ SbSourceDev src_s[SB_FUSED_MAX_K];
     __shared__ double red_s[SBL_THREADS / 64];
+    const uint32_t ne = n_states * k; // <= SB_FUSED_MAX_K
 #pragma unroll
     for (uint32_t y = 0; y < SB_FUSED_MAX_K; ++y)
-        if (threadIdx.x == y && y < k) src_s[y] = a.src[y]; // constant indices into the kernel arguments
+        if (threadIdx.x == y && y < ne) src_s[y] = a.src[y]; // constant indices into the kernel arguments
     // one lane per table entry (splitting an entry's chain of transcendentals over two steps saved 3 us of prologue but made
     // the compiler allocate 85 instead of 116 VGPRs and serialise the loads of the main loop: 82 -> 200 us at 1M reads)
-    for (uint32_t i = threadIdx.x; i < k * 2 * SB_NCNT; i += SBL_THREADS) {
+    for (uint32_t i = threadIdx.x; i < ne * 2 * SB_NCNT; i += SBL_THREADS) {
         const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
         SbSourceDev s;
         s.t1 = 0.0, s.t2 = 0.0;
@@ -333,33 +334,38 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesD
     __syncthreads();
     const uint32_t R = t.n_reads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double sum = 0.0;
-    unsigned long long bad = 0;
-    for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
-        if (!t.ok[r]) continue;
-        sum += sb_read_term(t, r, k, src_s, hk_s, bad);
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red_s[wave] = sum;
-    if (bad) atomicAdd(guard, bad);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s2 = 0.0;
-        for (int w = 0; w < SBL_THREADS / 64; ++w) s2 += red_s[w];
-        partial[blockIdx.x] = s2;
+    for (uint32_t e = 0; e < n_states; ++e) { // the chains of one source count advance together: one state each
+        double sum = 0.0;
+        unsigned long long bad = 0;
+        for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
+            if (!t.ok[r]) continue;
+            sum += sb_read_term(t, r, k, src_s + (size_t)e * k, hk_s + (size_t)e * k * 2 * SB_NCNT, bad);
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) red_s[wave] = sum;
+        if (bad) atomicAdd(&guard[e], bad);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s2 = 0.0;
+            for (int w = 0; w < SBL_THREADS / 64; ++w) s2 += red_s[w];
+            partial[(size_t)e * gridDim.x + blockIdx.x] = s2;
+        }
+        __syncthreads();
     }
 }
 
+// one wave per state
 __global__ __launch_bounds__(64) void sb_finish_host_kernel(const double *__restrict__ partial, uint32_t n_blocks,
                                                             unsigned long long *__restrict__ guard, double *__restrict__ out_host,
                                                             unsigned long long *__restrict__ guard_host) {
+    const uint32_t e = blockIdx.x;
     double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) s += partial[i];
+    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) s += partial[(size_t)e * n_blocks + i];
     s = wave_sum(s);
     if (threadIdx.x == 0) {
-        *out_host = s;
-        *guard_host = *guard;
-        *guard = 0; // ready for the next refresh (stream ordered)
+        out_host[e] = s;
+        guard_host[e] = guard[e];
+        guard[e] = 0; // ready for the next refresh (stream ordered)
     }
 }
 
@@ -436,12 +442,12 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_mixture_kernel(SbTablesDev t, 
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
+void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
                              unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st,
                              hipEvent_t after_main) {
-    hipLaunchKernelGGL(sb_refresh_fused_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, k, a, partial, guard);
+    hipLaunchKernelGGL(sb_refresh_fused_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, n_states, k, a, partial, guard);
     if (after_main) (void)hipEventRecord(after_main, st); // the timed interval is the fused kernel alone
-    hipLaunchKernelGGL(sb_finish_host_kernel, dim3(1), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host);
+    hipLaunchKernelGGL(sb_finish_host_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host);
 }
 
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,

@@ -193,9 +193,10 @@ class Tree:
             self._h = None
 
 
-def python_engine(refresh, mixture):
+def python_engine(refresh, mixture, batched=False):
     """A vgan_sb_engine from two Python callables (tests drive the chain logic with the oracle's likelihood this way):
-    refresh(list of (child, parent, dist, pos, theta), con, freqs7) -> (loglike, guard); mixture(paths, log_freq) -> loglike."""
+    refresh(list of (child, parent, dist, pos, theta), con, freqs7) -> (loglike, guard); mixture(paths, log_freq) -> loglike.
+    batched=True also provides refresh_many (all chains' states in one call), served by the same callable."""
     def _refresh(user, k, src, con, freqs7, out, guard):
         arr = C.cast(src, C.POINTER(N.SbSource))
         st = [(arr[i].child, arr[i].parent, arr[i].dist, arr[i].pos, arr[i].theta) for i in range(k)]
@@ -214,8 +215,21 @@ def python_engine(refresh, mixture):
             return -1
         return 0
 
-    e = N.SbEngine(None, N.SB_REFRESH_FN(_refresh), N.SB_MIXTURE_FN(_mixture))
-    e._keep = (_refresh, _mixture)
+    def _many(user, n_states, k, src, con, freqs7, out, guard):
+        arr = C.cast(src, C.POINTER(N.SbSource))
+        f7 = [freqs7[i] for i in range(7)]
+        try:
+            for e_ in range(n_states):
+                st = [(arr[e_ * k + i].child, arr[e_ * k + i].parent, arr[e_ * k + i].dist, arr[e_ * k + i].pos, arr[e_ * k + i].theta)
+                      for i in range(k)]
+                out[e_], guard[e_] = refresh(st, con, f7)
+        except Exception:  # noqa: BLE001
+            return -1
+        return 0
+
+    fns = (N.SB_REFRESH_FN(_refresh), N.SB_MIXTURE_FN(_mixture), N.SB_REFRESH_MANY_FN(_many) if batched else N.SB_REFRESH_MANY_FN())
+    e = N.SbEngine(None, *fns)
+    e._keep = fns
     return e
 
 
