@@ -30,6 +30,7 @@
 #include <numeric>
 #include <random>
 #include <sstream>
+#include <thread>
 
 #include <zlib.h>
 
@@ -134,7 +135,8 @@ struct ChainState { // MCMCiteration
 
 class GzLines {
   public:
-    explicit GzLines(const std::string &path) : f_(gzopen(path.c_str(), "wb")), path_(path) {
+    // level 1: the trace holds a line per chain and iteration, and deflate at the default level costs more than the GPU call
+    explicit GzLines(const std::string &path) : f_(gzopen(path.c_str(), "wb1")), path_(path) {
         if (!f_) throw std::runtime_error("cannot write " + path);
     }
     ~GzLines() {
@@ -175,14 +177,40 @@ long double autocorr(const std::vector<long double> &v, int lag) {
     return autocorr(v, lag, m, variance_of(v, m));
 }
 
+// miscfunc.h effectiveSampleSize: 1 + 2 * (sum of autocorrelations, taken in pairs until a pair is no longer positive).  A
+// slowly mixing chain needs thousands of lags of O(n) each -- minutes at the default 425 000 recorded states -- and the lags
+// are independent of each other: they are evaluated a block at a time on several threads and then consumed in order with the
+// reference's stopping rule, so the result is the same number.
 double effective_sample_size(const std::vector<long double> &v) {
     const long double m = mean_of(v), denom = variance_of(v, m);
     const int max_lag = (int)(v.size() / 2);
     double even = 1.0, odd = (double)autocorr(v, 1, m, denom), total = even + odd;
-    for (int t = 1; t < max_lag - 2 && even + odd > 0; t += 2) {
-        even = (double)autocorr(v, t + 1, m, denom);
-        odd = (double)autocorr(v, t + 2, m, denom);
-        total += 2.0 * (even + odd);
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    int t = 1;
+    int block = 8; // lags per round; the first rounds stay small and serial: a well mixed chain stops within a few lags
+    std::vector<double> ac;
+    while (t < max_lag - 2 && even + odd > 0) {
+        const int n_lags = std::min(block, 2 * ((max_lag - 2 - t + 1) / 2)); // whole pairs only: lags t+1 .. t+n_lags
+        if (n_lags <= 0) break;
+        ac.assign((size_t)n_lags, 0.0);
+        const unsigned threads = (size_t)n_lags * v.size() < (1u << 18) ? 1u : std::min<unsigned>(hw, (unsigned)n_lags);
+        auto work = [&](unsigned tid) {
+            for (int j = (int)tid; j < n_lags; j += (int)threads) ac[(size_t)j] = (double)autocorr(v, t + 1 + j, m, denom);
+        };
+        if (threads == 1) work(0);
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned i = 1; i < threads; ++i) pool.emplace_back(work, i);
+            work(0);
+            for (auto &th : pool) th.join();
+        }
+        for (int j = 0; j + 1 < n_lags && t < max_lag - 2 && even + odd > 0; j += 2) {
+            even = ac[(size_t)j];
+            odd = ac[(size_t)j + 1];
+            total += 2.0 * (even + odd);
+            t += 2;
+        }
+        block = std::min(block * 4, 1024);
     }
     if (even + odd < 0) total -= even + odd;
     return v.size() / (1 + total);
@@ -246,7 +274,9 @@ class Estimator {
                 chains.push_back(start_chain(sources, ll, chain));
             }
             if (!cfg_.quiet) fprintf(stderr, "Running %u chains of %u iterations\n", cfg_.chains, cfg_.max_iter);
+            PhaseTimer pt("sb_estimate");
             advance_together(chains, k);
+            pt.lap("chains");
             for (uint32_t chain = 0; chain < cfg_.chains; ++chain) {
                 const std::vector<ChainState> &kept = chains[chain]->kept;
                 const ChainSummary sum = summarise(kept, (int)k, (int)chain);
@@ -258,6 +288,7 @@ class Estimator {
                     slot[chain] = b.second;
                 }
             }
+            pt.lap("summaries");
             const int chain_length = (int)cfg_.max_iter - (int)cfg_.burn;
             size_t best = 0;
             for (size_t h = 0; h < chain_best.size(); ++h)
@@ -426,14 +457,23 @@ class Estimator {
         }
     }
 
+    // "<branch>\t<logLike>\t<theta>\t<pos_branch>\t[<verdict>\t]" per source, numbers as an ostream prints them under
+    // setprecision(14) (= %.14g); formatted by hand because two such lines per chain and iteration are a visible share of
+    // an iteration once the likelihood takes 25 us
     static std::string line_of(const vgan_tree &t, const ChainState &s, double ll, const char *verdict) {
-        std::ostringstream o;
+        std::string o;
+        char num[96];
         for (const Position &p : s.at) {
-            o << std::setprecision(14) << t.name[(size_t)p.node] << '\t' << ll << '\t' << p.theta << '\t' << p.pos_branch << '\t';
-            if (verdict) o << verdict << '\t';
+            o += t.name[(size_t)p.node];
+            const int n = snprintf(num, sizeof num, "\t%.14g\t%.14g\t%.14g\t", ll, p.theta, p.pos_branch);
+            o.append(num, (size_t)n);
+            if (verdict) {
+                o += verdict;
+                o += '\t';
+            }
         }
-        o << '\n';
-        return o.str();
+        o += '\n';
+        return o;
     }
 
     // One chain of MCMC::run_tree_proportion: its generators (the proposal / acceptance engine, the one standing in for rand()
