@@ -287,6 +287,34 @@ def test_cli_end_to_end(tmp_path):
     assert len(fields) // 3 == len(exp)
 
 
+def test_cli_reads_the_reference_odgi_fixture(tmp_path):
+    """`vgan haplocart --hc-files DIR` with only DIR/graph.og (the reference's own layout): the ODGI file of
+    test/reconstructInputSeq gives the same prediction, read count and posterior line as the GFA of the same graph."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "tests", "golden", "reconstruct")
+    outs = {}
+    for kind in ("gfa", "og"):
+        hcdir = tmp_path / kind
+        hcdir.mkdir()
+        shutil.copy(os.path.join(d, "target_graph." + kind), str(hcdir / ("graph." + kind)))
+        # the same path order for both (the .og lists its paths in handle order)
+        (hcdir / "graph_paths").write_text("seq_1\nseq_2\nseq_3\nseq_4\nseq_5\n")
+        out, pf = str(tmp_path / (kind + ".tsv")), str(tmp_path / (kind + ".post"))
+        r = subprocess.run([os.path.join(root, "vgan_amd", "bin", "vgan"), "haplocart", "-g", os.path.join(d, "test_reads.gam"),
+                            "--hc-files", str(hcdir), "-q", "-np", "-o", out, "-pf", pf, "-s", "kat", "-d"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[kind] = (open(out).read(), open(out + ".loglik.tsv").read())
+    assert outs["gfa"][0] == outs["og"][0] and outs["gfa"][0].splitlines()[1].startswith("kat\tseq_")
+
+    def table(txt):
+        return {ln.split("\t")[0]: float(ln.split("\t")[1]) for ln in txt.splitlines()}
+    a, b = table(outs["gfa"][1]), table(outs["og"][1])
+    assert a.keys() == b.keys() and len(a) == 5
+    assert all(b[k] == pytest.approx(a[k], rel=1e-12) for k in a)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
 def test_tiled_kernel_fuzz_against_general_kernel(seed):
     """Random batches that satisfy the tile contract, built by hand over the C-ABI (no flatten step): ragged reads of
