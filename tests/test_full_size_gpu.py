@@ -1,0 +1,129 @@
+"""Parity at BASELINE.json's workload sizes (1M x 150 bp HaploCart, ~1M-read euka shard, 2M-read soibean) through properties
+that do not depend on the size: modes agree, accumulation is additive over any split of the reads, summaries of disjoint
+shards add up, and a random sample of reads matches the oracle.  (The oracle itself finishes only a few hundred reads of
+these workloads in seconds.)"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import util
+from vgan_amd import euka as ek
+from vgan_amd import haplocart as hc
+from vgan_amd import soibean as sb
+from test_euka_cpu import GOLD
+from test_sb_cpu import FREQS
+
+pytestmark = pytest.mark.gpu
+
+
+def _range(a, r0, r1):
+    """The reads [r0, r1) of an alignment set as a set of their own."""
+    drop = np.ones(a.n_reads, np.uint8)
+    drop[r0:r1] = 0
+    return a.without(drop)
+
+
+def test_haplocart_one_million_reads():
+    g = hc.synth_graph(seed=0x76676131)
+    a = hc.synth_reads(g, 1_000_000, seed=0x76676131, read_len=150)
+    whole = hc.HostBatch(g, a)
+    assert whole.n_reads > 999_000 and whole.stats.n_bad == 0
+    ctx = hc.HcContext(g)
+    ctx.accumulate(whole)
+    ref = ctx.finalize()
+    assert np.all(np.isfinite(ref)) and ref.max() < 0
+    # the faithful per-read sweep (mask rows streamed per segment) against the collapsed node-weight form
+    ctx.reset()
+    ctx.set_mode(hc.MODE_PER_READ)
+    ctx.accumulate(whole)
+    assert util.rel_err(ctx.finalize(), ref) < 1e-10
+    # additive over an uneven three-way split, in any order
+    ctx.reset()
+    ctx.set_mode(hc.MODE_NODE_WEIGHTS)
+    cuts = [0, 123_457, 700_001, a.n_reads]
+    for i in (2, 0, 1):
+        ctx.accumulate(hc.HostBatch(g, a, cuts[i], cuts[i + 1]))
+    assert util.rel_err(ctx.finalize(), ref) < 1e-11
+    # every path's total is (sum over reads of S) minus the unsupported penalties: doubling the input doubles it
+    ctx.accumulate(whole)
+    assert util.rel_err(ctx.finalize(), 2 * ref) < 1e-11
+    # a scattered sample of reads against the oracle
+    rng = np.random.default_rng(1)
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    for r0 in rng.integers(0, a.n_reads - 40, 4):
+        _, want, _ = orc.hc_run(og, oa, r0=int(r0), r1=int(r0) + 40, n_threads=8, faithful=False)
+        ctx.reset()
+        ctx.accumulate(hc.HostBatch(g, a, int(r0), int(r0) + 40))
+        assert util.rel_err(ctx.finalize(), want) < 1e-9
+
+
+def test_euka_one_million_reads():
+    d = os.path.join(GOLD, "damageProfiles")
+    texts = (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    dm = ek.Damage.from_text(*texts)
+    g, db, a = ek.synth_euka(1_000_000, dm)
+    ctx = ek.EukaContext(db, dm)
+    whole = ek.EukaHostBatch(g, a)
+    got = ctx.accumulate(whole)
+    fin = ctx.finalize()
+    n, s = ctx.like_sums()
+    assert fin["clade_count"].sum() == got["pass"].sum() > 300_000 and n.sum() == (got["clade"] >= 0).sum()
+    # two shards: counts and baseshift add exactly, coverage and likelihood sums to rounding
+    ctx.reset()
+    half = a.n_reads // 2 + 3
+    parts = [ctx.accumulate(ek.EukaHostBatch(g, a, 0, half)), ctx.accumulate(ek.EukaHostBatch(g, a, half, a.n_reads))]
+    fin2 = ctx.finalize()
+    n2, s2 = ctx.like_sums()
+    assert np.array_equal(fin2["clade_count"], fin["clade_count"]) and np.array_equal(fin2["baseshift"], fin["baseshift"])
+    assert np.allclose(fin2["bin_cov"], fin["bin_cov"], rtol=1e-12, atol=1e-9) and np.array_equal(n2, n)
+    okc = np.isfinite(s)
+    assert np.array_equal(np.isfinite(s2), okc) and util.rel_err(s2[okc], s[okc]) < 1e-12
+    for k in ("clade", "pass"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), got[k])
+    assert np.array_equal(np.concatenate([p["like"] for p in parts]), got["like"])  # per read: the same bits whatever the batch
+    # samples of 300 consecutive reads against the oracle
+    og, odb = util.orc_graph_nodes_only(g), util.orc_euka_db_from_product(db)
+    src = whole.arrays()["read_src"]
+    for r0 in (0, 431_007, a.n_reads - 300):
+        sub = _range(a, r0, r0 + 300)  # stays alive: the oracle's view borrows its arrays
+        ref = orc.euka_run(og, util.orc_alnset_from_product(sub), odb, orc.OrcDamage(*texts), 29, 5)
+        idx = np.nonzero((src >= r0) & (src < r0 + 300))[0]
+        assert np.array_equal(got["clade"][idx], ref["clade"][src[idx] - r0]) and np.array_equal(got["pass"][idx], ref["pass"][src[idx] - r0])
+        ok = got["clade"][idx] >= 0
+        assert ok.sum() > 250 and util.rel_err(got["like"][idx][ok], ref["like"][src[idx] - r0][ok]) < 1e-10
+
+
+def test_soibean_two_million_reads():
+    g = hc.synth_graph(seed=0x76676131, genome_len=16569, n_nodes=11000, n_paths=28)
+    a = hc.synth_reads(g, 2_000_000, seed=9, read_len=65, indel_rate=0.005, softclip_rate=0.01)
+    dm = ek.Damage.from_text("", "")
+    idx = {n: i for i, n in enumerate(g.path_names)}
+    pairs = [(idx[t[0]], idx[t[1]]) for t in (ln.split() for ln in g.parents_txt.splitlines()) if len(t) >= 2]
+    st = [[(pairs[1][0], pairs[1][1], 0.03, 0.35, 0.5), (pairs[7][0], pairs[7][1], 0.011, 0.8, 0.3), (pairs[12][0], pairs[12][1], 0.04, 0.02, 0.2)]]
+    ctx = sb.SbContext(g, dm)
+    ctx.precompute(sb.SbHostBatch(g, a))
+    whole, guard = ctx.loglike(st, 0.01, FREQS)
+    fused, g2 = ctx.refresh(st[0], 0.01, FREQS)
+    assert guard[0] == 0 and g2 == 0 and fused == whole[0]  # the chain driver's fused path: the same bits
+    _, sig, n_ok = ctx.best_paths()
+    mix = ctx.mixture_loglike([3, 9, 20], float(np.log(1 / 3)))
+    # shards: the log-likelihood of a state, the signature counts and the initial mixture are sums over the reads
+    parts, sigs, mixes, oks = 0.0, 0, 0.0, 0
+    cuts = [0, 777_777, a.n_reads]
+    for i in range(2):
+        ctx.precompute(sb.SbHostBatch(g, a, cuts[i], cuts[i + 1]))
+        parts += ctx.loglike(st, 0.01, FREQS)[0][0]
+        _, s_i, n_i = ctx.best_paths()
+        sigs, oks = sigs + s_i, oks + n_i
+        mixes += ctx.mixture_loglike([3, 9, 20], float(np.log(1 / 3)))
+    assert parts == pytest.approx(whole[0], rel=1e-12) and mixes == pytest.approx(mix, rel=1e-12)
+    assert np.array_equal(sigs, sig) and oks == n_ok > 1_990_000
+    # a sample of 200 consecutive reads against the oracle
+    og = util.orc_graph_from_product(g)
+    sub = _range(a, 1_000_000, 1_000_200)  # stays alive: the oracle's view borrows its arrays
+    o = orc.SbOracle(og, util.orc_alnset_from_product(sub), orc.OrcDamage("", ""), penalty=7, path_findable=np.ones(g.n_paths, np.uint8))
+    ctx.precompute(sb.SbHostBatch(g, a, 1_000_000, 1_000_200))
+    rc, ref = o.loglike(st[0], 0.01, FREQS)
+    assert rc == 0 and ctx.loglike(st, 0.01, FREQS)[0][0] == pytest.approx(ref, rel=1e-10)

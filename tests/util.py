@@ -15,7 +15,9 @@ def orc_graph_from_product(g):
 
 
 def orc_alnset_from_product(a):
-    return orc.AlnSet.from_arrays(**a.arrays())
+    oa = orc.AlnSet.from_arrays(**a.arrays())
+    oa._product_owner = a  # the arrays may be views into the product's memory: keep it alive with the view
+    return oa
 
 
 def rel_err(a, b):
