@@ -127,3 +127,30 @@ def test_soibean_two_million_reads():
     ctx.precompute(sb.SbHostBatch(g, a, 1_000_000, 1_000_200))
     rc, ref = o.loglike(st[0], 0.01, FREQS)
     assert rc == 0 and ctx.loglike(st, 0.01, FREQS)[0][0] == pytest.approx(ref, rel=1e-10)
+
+
+def test_empty_inputs_on_every_path(tmp_path):
+    """No reads at all: every entry point returns zeros / empty results instead of failing (an empty GAM is what a sample
+    without a single mapped fragment produces)."""
+    d = os.path.join(GOLD, "damageProfiles")
+    dm = ek.Damage.from_text(open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    g, db, a = ek.synth_euka(50, dm, n_clades=6, nodes_per_clade=120)
+    ectx = ek.EukaContext(db, dm)
+    got = ectx.accumulate(ek.EukaHostBatch(g, a, 0, 0))
+    fin = ectx.finalize()
+    n, s = ectx.like_sums()
+    assert len(got["clade"]) == 0 and not fin["clade_count"].any() and not fin["baseshift"].any() and not n.any() and not s.any()
+    det, est = ek.report(db, fin, n, s, got["clade"], got["pass"], np.zeros(0, np.uint16), str(tmp_path / "none"), min_bins=1, entropy=0.0)
+    assert len(det) == 0 and b"yes" not in open(str(tmp_path / "none_abundance.tsv"), "rb").read()
+    g2 = hc.synth_graph(seed=3, genome_len=900, n_nodes=600, n_paths=12)
+    a2 = hc.synth_reads(g2, 40, seed=1, read_len=60)
+    sctx = sb.SbContext(g2, ek.Damage.from_text("", ""))
+    sctx.precompute(sb.SbHostBatch(g2, a2, 0, 0))
+    ll, guard = sctx.loglike([[(1, 0, 0.01, 0.5, 1.0)]], 0.01, FREQS)
+    best, sig, n_ok = sctx.best_paths()
+    assert ll[0] == 0.0 and guard[0] == 0 and sctx.refresh([(1, 0, 0.01, 0.5, 1.0)], 0.01, FREQS) == (0.0, 0)
+    assert len(best) == 0 and not sig.any() and n_ok == 0 and sctx.mixture_loglike([0, 1], -0.69) == 0.0
+    assert list(sb.signature_paths(sig, n_ok)) == []
+    hctx = hc.HcContext(g2)
+    hctx.accumulate(hc.HostBatch(g2, a2, 0, 0))
+    assert not hctx.finalize().any()
