@@ -154,3 +154,29 @@ def test_empty_inputs_on_every_path(tmp_path):
     hctx = hc.HcContext(g2)
     hctx.accumulate(hc.HostBatch(g2, a2, 0, 0))
     assert not hctx.finalize().any()
+
+
+def test_clis_on_a_gam_without_reads(tmp_path):
+    import shutil
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLD), "..", "vgan_amd", "bin", "vgan")
+    g, db, a = ek.synth_euka(20, None, n_clades=5, nodes_per_clade=120)
+    util.write_euka_db(db, g, tmp_path)
+    gam = str(tmp_path / "none.gam")
+    a.without(np.ones(a.n_reads, np.uint8)).write_gam(gam)
+    r = subprocess.run([exe, "euka", "-g", gam, "--euka_dir", str(tmp_path), "-o", str(tmp_path / "e")], capture_output=True, text=True)
+    assert r.returncode == 0 and "Number of fragments in input file: 0" in r.stderr, r.stderr[-800:]
+    assert open(str(tmp_path / "e_abundance.tsv")).read().count("\tno\t0\t0") == 5
+    hcdir = tmp_path / "hc"
+    hcdir.mkdir()
+    g2 = hc.synth_graph(seed=3, genome_len=900, n_nodes=600, n_paths=12)
+    g2.write(str(hcdir))
+    r = subprocess.run([exe, "haplocart", "-g", gam, "--hc-files", str(hcdir), "-o", str(tmp_path / "h.tsv"), "-np", "-q"], capture_output=True, text=True)
+    assert r.returncode == 0 and open(str(tmp_path / "h.tsv")).read().splitlines()[1].endswith("\t0"), r.stderr[-800:]
+    shutil.copy(str(hcdir / "graph.gfa"), str(tmp_path / "T.gfa"))
+    from test_sb_chain_cpu import _newick_of
+    (tmp_path / "tree_dir").mkdir()
+    (tmp_path / "tree_dir" / "T.new.dnd").write_text(_newick_of(g2))
+    (tmp_path / "soibean_db.baseFreq").write_text("T .3 .2 .2 .3\n")
+    r = subprocess.run([exe, "soibean", "-g", gam, "--soibean_dir", str(tmp_path), "--dbprefix", "T", "-o", str(tmp_path / "s_")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable read" in r.stderr

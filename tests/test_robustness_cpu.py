@@ -185,3 +185,24 @@ def test_table_and_sidecar_loaders_survive_corrupt_files(tmp_path, golden_dir):
     (d / "mappability.tsv").write_text("chrM\t0\t4000000000\t1.0\n")
     with pytest.raises(Exception):
         hc.Graph.load(str(d / "graph.gfa"), str(d))
+
+
+def test_gam_without_reads(tmp_path):
+    """A GAM without reads is the 28-byte BGZF end-of-file block alone (what vg writes for an empty result): every reader
+    returns zero reads (the empty deflate member used to be reported as a corrupt stream)."""
+    g = hc.synth_graph(seed=4, genome_len=900, n_nodes=620, n_paths=30)
+    a = hc.synth_reads(g, 30, seed=1, read_len=80)
+    p = str(tmp_path / "none.gam")
+    a.without(np.ones(a.n_reads, np.uint8)).write_gam(p)
+    raw = open(p, "rb").read()
+    assert raw == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    assert hc.AlnSet.read_gam(p).n_reads == 0 and hc.AlnSet.parse_gam(raw).n_reads == 0 and hc.AlnSet.parse_gam(b"").n_reads == 0
+    assert hc.AlnParts.read_gam(p).n_reads == 0
+    st = hc.GamStream(p)
+    chunks = list(st.chunks(1000))
+    assert sum(c.n_reads for c in chunks) == 0
+    b = hc.HostBatch(g, hc.AlnSet.read_gam(p))
+    assert b.n_reads == 0
+    # the end-of-file block after real data is still just the end
+    a.write_gam(p)
+    assert hc.AlnSet.read_gam(p).n_reads == a.n_reads

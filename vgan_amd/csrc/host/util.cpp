@@ -82,14 +82,16 @@ bool inflate_member(const unsigned char *in, size_t in_size, unsigned char *out,
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;
+    unsigned char scratch[8]; // an empty member (the BGZF end-of-file block; a whole GAM without reads is just that block) still
+                              // needs somewhere to "write": zlib rejects a null next_out and cannot finish with no room at all
     zs.next_in = const_cast<unsigned char *>(in);
     zs.avail_in = (uInt)in_size;
-    zs.next_out = out;
-    zs.avail_out = (uInt)out_size;
+    zs.next_out = out_size ? out : scratch;
+    zs.avail_out = out_size ? (uInt)out_size : (uInt)sizeof scratch;
     const int rc = inflate(&zs, Z_FINISH);
-    const bool ok = rc == Z_STREAM_END && zs.avail_out == 0;
+    const bool ok = rc == Z_STREAM_END && zs.total_out == out_size;
     inflateEnd(&zs);
-    return ok || (rc == Z_STREAM_END && out_size == 0);
+    return ok;
 }
 
 } // namespace
