@@ -325,3 +325,19 @@ def test_vgan_euka_cli_end_to_end_matches_the_oracle(tmp_path, mcmc):
     for k in fo:
         assert fo[k] == fp[k], (k, fo[k][:400], fp[k][:400])
     assert b"yes" in fp["_abundance.tsv"] and ("_%s.prof" % og_name) in fp
+
+
+def test_vgan_euka_reads_its_gam_from_a_pipe(tmp_path):
+    """The reference feeds readGAM3 through a FIFO (Euka.cpp:490-523): `-g /dev/stdin` gives the files of `-g file`."""
+    import subprocess
+    g, db, a = ek.synth_euka(3000, None, seed=4, n_clades=8, nodes_per_clade=150)
+    util.write_euka_db(db, g, tmp_path)
+    gam = str(tmp_path / "r.gam")
+    a.write_gam(gam)
+    exe = os.path.join(os.path.dirname(GOLD), "..", "vgan_amd", "bin", "vgan")
+    common = ["--euka_dir", str(tmp_path), "--entropy", "0", "--minBins", "1", "--seed", "3", "--iter", "300", "--burnin", "30"]
+    r1 = subprocess.run([exe, "euka", "-g", gam, "-o", str(tmp_path / "f")] + common, capture_output=True)
+    r2 = subprocess.run([exe, "euka", "-g", "/dev/stdin", "-o", str(tmp_path / "p")] + common, input=open(gam, "rb").read(), capture_output=True)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-500:], r2.stderr[-500:])
+    a_, b_ = _tree(str(tmp_path / "f")), _tree(str(tmp_path / "p"))
+    assert sorted(a_) == sorted(b_) and len(a_) >= 6 and all(a_[k] == b_[k] for k in a_)

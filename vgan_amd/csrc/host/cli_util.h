@@ -46,6 +46,12 @@ inline bool is_file(const std::string &p) {
     return stat(p.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
 }
 
+// an input the caller may also hand over as a FIFO or /dev/stdin (the reference feeds its own GAM reader through a FIFO)
+inline bool is_readable_input(const std::string &p) {
+    struct stat sb;
+    return stat(p.c_str(), &sb) == 0 && !S_ISDIR(sb.st_mode);
+}
+
 inline bool ends_with(const std::string &s, const char *suf) {
     const size_t n = strlen(suf);
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;

@@ -141,7 +141,7 @@ int euka_main(int argc, char **argv) {
     for (const std::string &ext : {graph_ext, std::string(".clade"), std::string(".bins")})
         if (!is_file(prefix + ext)) die(prefix + ext + " does not exist.");
     if (gam.empty()) die("[euka] Error, no input file given (use -g)");
-    if (!is_file(gam)) die("[euka] Error, GAM input file " + gam + " does not exist");
+    if (!is_readable_input(gam)) die("[euka] Error, GAM input file " + gam + " does not exist");
     if (run_mcmc && iter - burnin - 1 <= 0) die("[euka] Error, --iter must exceed --burnin + 1");
 
     PhaseTimer pt("euka");

@@ -140,7 +140,7 @@ int soibean_main(int argc, char **argv) {
     if (!is_file(gfa)) die(gfa + " does not exist.");
     if (!is_file(treename)) die(treename + " does not exist.");
     if (gam.empty()) die("[soibean] Error, no input file given (use -g)");
-    if (!is_file(gam)) die("[soibean] Error, GAM input file " + gam + " does not exist");
+    if (!is_readable_input(gam)) die("[soibean] Error, GAM input file " + gam + " does not exist");
 
     PhaseTimer pt("soibean");
     GamReader reader;
