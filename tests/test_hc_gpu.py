@@ -494,3 +494,22 @@ def test_batch_validation(tmp_path):
     broken(lambda x: x["seg_start"].__setitem__(1, 0) if x["seg_len"][0] else None, n_tileable=b.n_tileable)  # overlap / order
     broken(lambda x: None, n_tileable=b.n_reads)                                      # the 1500-column reads are not tileable
     broken(lambda x: x["read_col_off"].__setitem__(len(x["read_col_off"]) - 1, 5))    # final offset vs n_cols
+
+
+def test_cli_reads_its_gam_from_a_pipe(tmp_path):
+    """`vgan haplocart -g /dev/stdin`: the streamed reader works on a pipe (the reference hands its reader a FIFO)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = hc.synth_graph(seed=5, genome_len=800, n_nodes=560, n_paths=40)
+    a = hc.synth_reads(g, 5000, seed=1, read_len=100)
+    g.write(str(tmp_path))
+    a.write_gam(str(tmp_path / "r.gam"))
+    exe = os.path.join(root, "vgan_amd", "bin", "vgan")
+    outs = []
+    for src, kw in ((str(tmp_path / "r.gam"), {}), ("/dev/stdin", {"input": open(str(tmp_path / "r.gam"), "rb").read()})):
+        out = str(tmp_path / ("o%d.tsv" % len(outs)))
+        r = subprocess.run([exe, "haplocart", "-g", src, "--hc-files", str(tmp_path), "-q", "-np", "-o", out, "-s", "x", "-t", "-1"],
+                           capture_output=True, **kw)
+        assert r.returncode == 0, r.stderr[-500:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].splitlines()[1].startswith("x\thg")
