@@ -696,6 +696,7 @@ extern "C" int vgan_sb_estimate(const vgan_sb_engine *engine, const vgan_tree *t
     if (!engine || !engine->refresh || !engine->mixture || !tree || !node_path || !sig_nodes || !cfg || !out_prefix)
         return fail(VGAN_EINVAL, "vgan_sb_estimate: null argument");
     if (n_sig == 0) return fail(VGAN_EINVAL, "vgan_sb_estimate: no starting node");
+    if (cfg->n_paths == 0 || cfg->n_paths > tree->n()) return fail(VGAN_EINVAL, "vgan_sb_estimate: n_paths must be 1..%u (the tree's nodes)", tree->n());
     if (cfg->run_mcmc && (cfg->chains == 0 || cfg->burn >= cfg->max_iter))
         return fail(VGAN_EINVAL, "vgan_sb_estimate: The number of iterations must be higher than the burn-in period. Unable to proceed.");
     for (uint32_t i = 0; i < n_sig; ++i)
