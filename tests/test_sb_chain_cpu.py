@@ -72,6 +72,10 @@ def test_newick_errors():
     for bad in ("", "(a:1,b:2)", "(a:1,b:2;", "(a:x,b:1);", "(a:1 b:2);"):
         with pytest.raises(N.NativeError):
             sb.Tree.parse(bad)
+    with pytest.raises(N.NativeError):  # a parser that recurses per level must refuse absurd nesting, not overflow its stack
+        sb.Tree.parse("(" * 200000 + "a" + ")" * 200000 + ";")
+    deep = "(" * 5000 + "a:1" + ",b:1)" * 5000 + ";"
+    assert sb.Tree.parse(deep).n_nodes == 10001
     t = sb.Tree.parse(" ( a:0.5 , (b:1e-3,c)d:2 )r ; ")
     assert t.names == ["r", "a", "d", "b", "c"] and list(t.dist) == [0.0, 0.5, 2.0, 1e-3, 0.0] and t.n_leaves == 3
 

@@ -63,7 +63,15 @@ struct NewickParser {
     void skip_ws() {
         while (p < s.size() && isspace((unsigned char)s[p])) ++p;
     }
+    int depth = 0;
     int32_t node(int32_t up) {
+        struct Level { // the parser recurses per nesting level: a text of a million '(' must not run the stack out
+            int &d;
+            explicit Level(int &x) : d(x) {
+                if (++d > 10000) throw std::runtime_error("Newick: nesting deeper than 10000 levels");
+            }
+            ~Level() { --d; }
+        } level(depth);
         const int32_t id = (int32_t)parent.size();
         parent.push_back(up);
         kids.emplace_back();
