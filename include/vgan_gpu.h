@@ -161,8 +161,8 @@ typedef struct vgan_hc_batch {
     const uint16_t *read_algn_len;/* [n_reads] |algnseq| (= quality window length, update_likelihood.cpp:40) */
     const uint8_t *read_mapq;     /* [n_reads] mapping quality, clamped to 99 */
     const uint32_t *seg_node;     /* [n_segments] node id */
-    const uint16_t *seg_start;    /* [n_segments] */
-    const uint16_t *seg_len;      /* [n_segments] */
+    const uint16_t *seg_start;    /* [n_segments] first column of the mapping within its read (16 bit: see the limit below) */
+    const uint16_t *seg_len;      /* [n_segments] columns it scores */
     const uint8_t *graph_seq;     /* [n_cols] ASCII incl. 'S' softclip and '-' gap marks */
     const uint8_t *algnseq;       /* [n_cols] ASCII path_string with '-' at deletions */
     const uint8_t *qual;          /* [n_qual] raw phred */
@@ -174,6 +174,10 @@ typedef struct vgan_hc_batch {
     const uint32_t *read_src;     /* [n_reads] index of the read in the alignment set, or NULL (not used by the device) */
 } vgan_hc_batch;
 /* Batch contract: read_*_off ascending; the segments of a read ascend in seg_start.
+ * Layout limit (narrower than the reference and the oracle, which have none): a read has at most 65535 alignment
+ * columns, 65535 mappings and 65535 quality bytes -- seg_start / seg_len / read_algn_len are 16 bit and the general
+ * kernel keeps one quality prefix per 64 bytes for 65536 of them.  vgan_hc_flatten* drops and counts reads beyond it
+ * (n_bad); vgan_hc_batch_validate refuses hand-built batches beyond it.  A 16.5 kb consensus read fits four times.
  * Tile contract (reads below n_tileable): at most 1280 columns, 1280 quality bytes and 512 segments; |algnseq| equals the
  * length of the read's graph sequence; the column ranges [seg_start, seg_start+seg_len) of the read do not overlap. */
 
@@ -183,7 +187,7 @@ typedef struct vgan_hc_flatten_stats {
     int64_t n_in, n_out;
     int64_t n_unmapped;   /* identity < 1e-10 (HaploCart.cpp:410) */
     int64_t n_bad;        /* reads on which the reference would std::terminate (unknown node, bad substr, ...), and
-                           * reads beyond the batch layout's 16-bit limits (more than 65535 columns or mappings) */
+                           * reads beyond the batch layout's 16-bit limits (more than 65535 columns, mappings or quality bytes) */
     int64_t n_clamped;    /* mapq >= 100 clamped (reference reads out of bounds) */
     int64_t n_segments;
     int64_t n_cols;
@@ -260,9 +264,12 @@ int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable);  /* also clears the coun
 /* synchronises the stream; ms[i] = summed device time of kernel i, launches[i] = number of launches timed */
 int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[5], uint64_t launches[5]);
 
-/* get_posterior (get_posterior.cpp:87-127) on the device: log-sum-exp over the P paths and over the strict
- * descendants of each ancestor of `predicted`.  clades: '\n'-joined names into clade_buf; conf[i] beside it.
- * Returns the number of records (>= 1) or a negative error. */
+/* get_posterior (get_posterior.cpp:87-127) on the device: log-sum-exp over the P paths and over the descendants of
+ * each ancestor of `predicted`, gathered as get_posterior_of_clade does (:51-76): one child set per recursion level,
+ * so on a children.txt that is not a tree a path reached at two depths is summed twice.  Where the reference is
+ * undefined: an ancestor without path-name descendants sums nothing = 0 (confidence exp(0 - total)), a name absent
+ * from children.txt has no children, a cyclic children.txt is an error.  clades: '\n'-joined names into clade_buf;
+ * conf[i] beside it.  Returns the number of records (>= 1) or a negative error. */
 int vgan_hc_posterior(vgan_hc_ctx *c, const double *final_vec /* host [P] */, const char *predicted,
                       char *clade_buf, int64_t clade_cap, double *conf, int32_t conf_cap);
 /* argmax with the reference's first-maximum tie rule (std::max_element, HaploCart.cpp:423). */

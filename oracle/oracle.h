@@ -100,7 +100,13 @@ int orc_hc_run(const orc_graph_t *g, const orc_alnset_t *a, int64_t r0, int64_t 
 /* a9: get_posterior (src/get_posterior.cpp:36-127). Text inputs use the sidecar formats
  * (graph_paths: one name per line; parents.txt/children.txt: "name tok tok ..." per line).
  * Output: '\t'-joined "clade\tconfidence(%.17g)\tdepth" records separated by '\n' into out (cap bytes);
- * conf[] receives the confidences as double; returns number of records or <0. */
+ * conf[] receives the confidences as double; returns number of records or <0.
+ * Followed literally: one child set per recursion level (:51-76), so a path reachable at two depths of
+ * children.txt is summed twice.  Where the reference is undefined the definition is:
+ *   - an ancestor whose levels contain no path name (sum_log_likelihoods reads v[0] of an empty vector, :78-85):
+ *     the sum of nothing is 0, i.e. confidence = exp(0 - total);
+ *   - a name absent from children.txt (get_children dereferences end(), :41): no children;
+ *   - a cyclic children.txt (unbounded recursion): the walk stops after 100000 levels. */
 int orc_hc_posterior(const long double *final_vec, int32_t n_paths, const char *path_names_txt,
                      const char *parents_txt, const char *children_txt, const char *predicted,
                      char *out, int64_t cap, double *conf, int32_t conf_cap);

@@ -172,7 +172,8 @@ def test_clis_on_a_gam_without_reads(tmp_path):
     g2 = hc.synth_graph(seed=3, genome_len=900, n_nodes=600, n_paths=12)
     g2.write(str(hcdir))
     r = subprocess.run([exe, "haplocart", "-g", gam, "--hc-files", str(hcdir), "-o", str(tmp_path / "h.tsv"), "-np", "-q"], capture_output=True, text=True)
-    assert r.returncode == 0 and open(str(tmp_path / "h.tsv")).read().splitlines()[1].endswith("\t0"), r.stderr[-800:]
+    # HaploCart.cpp:384-385: "[HaploCart] Error, no reads mapped" and a failing exit, no result line
+    assert r.returncode != 0 and "[HaploCart] Error, no reads mapped" in r.stderr and not os.path.exists(str(tmp_path / "h.tsv")), r.stderr[-800:]
     shutil.copy(str(hcdir / "graph.gfa"), str(tmp_path / "T.gfa"))
     from test_sb_chain_cpu import _newick_of
     (tmp_path / "tree_dir").mkdir()

@@ -206,6 +206,43 @@ def test_posterior_matches_oracle():
         assert c1 == pytest.approx(c2, rel=1e-12)
 
 
+def _graph_with_relatives(g, parents_txt, children_txt):
+    return hc.Graph.from_arrays(g.min_id, g.max_id, g.node_seq_off, g.node_seq.tobytes(), g.n_paths, g.mask, g.pangenome_base,
+                                g.mappability, "\n".join(g.path_names) + "\n", parents_txt, children_txt)
+
+
+def test_posterior_on_a_dag_and_on_childless_ancestors():
+    """get_posterior.cpp:51-76 builds a fresh child set per recursion level, so a path reachable at two depths of
+    children.txt enters the clade's sum twice; an ancestor without (path-name) descendants sums nothing, which the
+    oracle header defines as 0 (the reference reads v[0] of an empty vector)."""
+    g0 = hc.synth_graph(seed=5, genome_len=600, n_nodes=400, n_paths=12)
+    n = g0.path_names
+    # n[0] -> n[1], n[2];  n[1] -> n[3];  n[2] -> n[3], n[4];  n[3] -> n[5];  n[4] -> n[5]: n[5] is reached at depth 3 twice
+    # over two parents (one set per level: once) and n[3] at depth 2 over two parents (once); n[6] -> n[1] and n[3]: n[3]
+    # sits at depths 1 and 2 of n[6] (twice), n[5] at depths 2 and 3 (twice)
+    children = "\n".join([
+        "%s %s %s" % (n[0], n[1], n[2]), "%s %s" % (n[1], n[3]), "%s %s %s" % (n[2], n[3], n[4]), "%s %s" % (n[3], n[5]),
+        "%s %s" % (n[4], n[5]), "%s %s %s" % (n[6], n[1], n[3]), "%s notapath [x]" % n[7], "%s" % n[8]]) + "\n"
+    # the predicted path's ancestors: a repeated entry (Q9), a DAG ancestor, a leafless one, one absent from children.txt
+    parents = "%s %s %s %s %s %s %s %s\n" % (n[5], n[3], n[3], n[6], n[0], n[7], n[8], n[9])
+    g = _graph_with_relatives(g0, parents, children)
+    ctx = hc.HcContext(g)
+    rng = np.random.default_rng(3)
+    for fv in (-(rng.random(12) * 30 + 1), np.full(12, -2.5), np.array([0, 0, -1.0, 0, -3, 0, -2, 0, 0, 0, -7, 0.0]), np.zeros(12)):
+        got = ctx.posterior(fv, n[5])
+        ref = orc.hc_posterior(fv.astype(np.longdouble), n, parents, children, n[5])
+        assert [(x[0], x[2]) for x in got] == [(x[0], x[2]) for x in ref]
+        assert [x[0] for x in got] == [n[5], n[3], n[6], n[0], n[7], n[8], n[9]]
+        for (n1, c1, _), (n2, c2, _) in zip(got, ref):
+            assert c1 == pytest.approx(c2, rel=1e-9, abs=1e-300), n1
+    # closed form on flat likelihoods: confidence = (entries of all_top, multiplicity kept) / P
+    got = dict((x[0], x[1]) for x in ctx.posterior(np.full(12, -2.5), n[5]))
+    assert got[n[6]] == pytest.approx(5 / 12, rel=1e-12)  # n1 | n3 n3 | n5 n5
+    assert got[n[0]] == pytest.approx(5 / 12, rel=1e-12)  # n1 n2 | n3 n4 | n5
+    assert got[n[7]] == got[n[8]] == got[n[9]]            # nothing summed: exp(0 - total)
+    assert got[n[7]] == pytest.approx(np.exp(2.5) / 12, rel=1e-12)
+
+
 def test_full_size_graph_properties():
     """hcfiles-shaped graph (11821 nodes / 5179 paths), 20k reads of 150 bp: the three device modes agree, the
     accumulation is linear and order independent, device-resident batches equal host batches, and a read subset

@@ -133,3 +133,26 @@ def test_helpers():
     assert float(L.orc_oplusInitnatl(0.0, -3.0)) == -3.0
     assert float(L.orc_oplusInitnatl(-3.0, 0.0)) == pytest.approx(float(mp.log(mp.e ** -3 + 1)), rel=1e-15)
     assert float(L.orc_oplusnatl(-1000.0, -1001.0)) == pytest.approx(float(-1000 + mp.log1p(mp.e ** -1)), rel=1e-15)
+
+
+def test_posterior_counts_a_path_once_per_level_it_is_reached_at():
+    """get_posterior.cpp:51-76 on a children.txt that is not a tree, closed form on flat likelihoods: the confidence
+    of a clade is (entries of all_top) / P, and all_top gets one entry per recursion level a path's name is in."""
+    n = ["p%d" % i for i in range(10)]
+    children = "\n".join(["p0 p1 p2", "p1 p3", "p2 p3 p4", "p3 p5", "p4 p5", "p6 p1 p3", "p7 nopath [tok]", "p8"]) + "\n"
+    parents = "p5 p3 p3 p6 p0 p7 p8 p9\n"
+    fv = np.full(10, -4.0, np.longdouble)
+    got = orc.hc_posterior(fv, n, parents, children, "p5")
+    assert [x[0] for x in got] == ["p5", "p3", "p6", "p0", "p7", "p8", "p9"]  # Q9: the repeated p3 is emitted once
+    conf = dict((x[0], x[1]) for x in got)
+    assert conf["p5"] == pytest.approx(0.1, rel=1e-15)
+    assert conf["p3"] == pytest.approx(0.1, rel=1e-15)   # p5
+    assert conf["p6"] == pytest.approx(0.5, rel=1e-15)   # p1 p3 | p3 p5 | p5: p3 and p5 twice
+    assert conf["p0"] == pytest.approx(0.5, rel=1e-15)   # p1 p2 | p3 p4 | p5: once per level although two parents list them
+    for k in ("p7", "p8", "p9"):                         # nothing to sum: defined as exp(0 - total)
+        assert conf[k] == pytest.approx(float(mp.e ** 4 / 10), rel=1e-15)
+    # unequal values: a twice-listed path weighs double
+    fv = np.array([-9, -1, -9, -2, -9, -3, -9, -9, -9, -9], np.longdouble)
+    got = dict((x[0], x[1]) for x in orc.hc_posterior(fv, n, parents, children, "p5"))
+    tot = sum(mp.e ** float(v) for v in fv)
+    assert got["p6"] == pytest.approx(float((mp.e ** -1 + 2 * mp.e ** -2 + 2 * mp.e ** -3) / tot), rel=1e-14)

@@ -136,6 +136,32 @@ def test_special_reads():
     run_case(g, a, texts, 7, k1, k3)
 
 
+def test_long_match_edits_count_beyond_255():
+    """One match edit of 300 identical (reference, read) pairs, and a 900-column one: the per-segment 5x5 counts are 16 bit
+    (an 8-bit counter wrapped at 256 and lowered every HKY term of the read)."""
+    rng = np.random.default_rng(11)
+    long_seq = bytes(rng.choice(list(b"ACGT"), 900).tolist())
+    seqs = {1: b"A" * 320, 2: long_seq, 3: b"ACGTACGTACGTACGTACGT"}
+    node_seq = b"".join(seqs[i] for i in (1, 2, 3))
+    off = np.array([0, 0, 320, 1220, 1240], np.int64)
+    mask = np.zeros((4, 1), np.uint64)
+    mask[1, 0] = 0b011
+    mask[2, 0] = 0b110
+    mask[3, 0] = 0b111
+    g = hc.Graph.from_arrays(1, 3, off, node_seq, 3, mask, np.full(4, -1, np.int32), np.ones(1), "p0\np1\np2\n",
+                             "p1 p0\np2 p0\n", "p0 p1 p2\n")
+    alns = [
+        _mk(b"A" * 300, [30 + (i % 11) for i in range(300)], [(1, 5, False, [(300, 300, b"")])]),
+        _mk(long_seq, [25 + (i % 17) for i in range(900)], [(2, 0, False, [(900, 900, b"")])]),
+        _mk(b"A" * 256 + b"ACGTACGTAC", [33] * 266, [(1, 64, False, [(256, 256, b"")]), (3, 0, False, [(10, 10, b"")])]),
+    ]
+    a = hc.AlnSet.parse_gam(gamio.write_gam(alns), keep_unmapped=True)
+    ctx, o = run_case(g, a, ("", ""), 7, [[(1, 0, 0.02, 0.3, 1.0)]], [[(1, 0, 0.02, 0.3, 0.2), (2, 0, 0.05, 0.9, 0.5), (0, 1, 0.01, 0.5, 0.3)]])
+    _, cnt, _ = ctx.read_tables()
+    # A->A pairs on p0: none (read 1 is off p0), 256 + 3 of node 3 (read 2), 300 (read 0); all 900 pairs of read 1 on p1
+    assert sorted(cnt[0, 0, :].tolist()) == [0, 259, 300] and int(cnt[1].sum(axis=0).max()) == 900
+
+
 def _same_tables(a, b, rel):
     """Tab-separated text files field by field: words identical, numbers within rel."""
     la, lb = a.decode().splitlines(), b.decode().splitlines()

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <set>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -97,7 +98,7 @@ struct vgan_hc_ctx {
     std::vector<std::string> path_names;
     std::unordered_map<std::string, uint32_t> path_index;
     std::unordered_map<std::string, std::vector<std::string>> parents, children;
-    DevBuf<uint64_t> sets;
+    DevBuf<uint32_t> lists; // posterior: list offsets, then the path indices
     DevBuf<double> conf;
     // profiling: pairs of events per timed launch, resolved in vgan_hc_profile_read
     bool profiling = false;
@@ -399,7 +400,7 @@ extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
     c->s_u32.release();
     c->s_u16.release();
     c->s_u8.release();
-    c->sets.release();
+    c->lists.release();
     c->conf.release();
     for (auto &t : c->timed) {
         (void)hipEventDestroy(t.a);
@@ -450,6 +451,7 @@ extern "C" int vgan_hc_batch_validate(const vgan_hc_ctx *c, const vgan_hc_batch 
         const uint32_t cols = c1 - c0, ql = b->read_qual_off[r + 1] - b->read_qual_off[r];
         if (b->read_algn_len[r] > cols) return fail(VGAN_EINVAL, "batch: |algnseq| of read %llu exceeds its column region", (unsigned long long)r);
         if (b->read_mapq[r] > 99) return fail(VGAN_EINVAL, "batch: mapping quality of read %llu exceeds 99", (unsigned long long)r);
+        if (cols > 65535 || ql > 65535) return fail(VGAN_EINVAL, "batch: read %llu has more than 65535 columns or quality bytes", (unsigned long long)r);
         const bool tile = r < b->n_tileable;
         if (tile && (cols > HC_TILE_MAX_READ_COLS || ql > HC_TILE_MAX_READ_QUAL || s1 - s0 > HC_TILE_MAX_READ_SEGS))
             return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but exceeds the tile limits", (unsigned long long)r);
@@ -633,42 +635,48 @@ extern "C" int vgan_hc_posterior(vgan_hc_ctx *c, const double *final_vec, const 
     auto pv = c->parents.find(predicted);
     if (pv != c->parents.end()) parent_vec = pv->second;
     std::vector<std::string> clades{predicted};
-    std::vector<std::vector<uint64_t>> sets;
-    sets.emplace_back(c->W, 0);
-    sets[0][pi->second >> 6] |= 1ull << (pi->second & 63);
+    // One index list per record, in the order the reference builds all_top (:51-76): per recursion level the members of
+    // that level's child set in path order; a fresh set per level, so a path reachable at two depths is listed twice.
+    std::unordered_map<std::string, std::vector<uint32_t>> by_name; // graph_paths may repeat a name: every index counts (:60-66)
+    for (uint32_t p = 0; p < c->P; ++p) by_name[c->path_names[p]].push_back(p);
+    std::vector<uint32_t> off{0}, idx{(uint32_t)pi->second};
+    off.push_back(1);
+    constexpr size_t kMaxList = (size_t)1 << 27; // a cyclic children.txt recurses without end in the reference
     for (size_t j = 0; j < parent_vec.size(); ++j) {
-        if (j > 0 && parent_vec[j] == parent_vec[j - 1]) continue; // :110,117 (Q9: j = 0 always emitted)
+        const bool emit = j == 0 || parent_vec[j] != parent_vec[j - 1]; // :110,117 (Q9: j = 0 always emitted)
+        if (!emit) continue; // its all_top is computed and dropped by the reference
         clades.push_back(parent_vec[j]);
-        std::vector<uint64_t> set(c->W, 0);
-        std::unordered_set<std::string> seen;
-        std::deque<std::string> todo{parent_vec[j]};
-        while (!todo.empty()) { // get_children() recursion, :36-76
-            const std::string cur = todo.front();
-            todo.pop_front();
-            auto ch = c->children.find(cur);
-            if (ch == c->children.end()) continue;
-            for (const std::string &k : ch->second) {
-                if (!seen.insert(k).second) continue;
-                auto ki = c->path_index.find(k);
-                if (ki != c->path_index.end()) set[ki->second >> 6] |= 1ull << (ki->second & 63);
-                todo.push_back(k);
+        std::set<std::string> preds{parent_vec[j]};
+        for (int depth = 0; !preds.empty() && depth <= 100000; ++depth) { // get_children(), :36-49
+            std::set<std::string> child_set;
+            for (const std::string &p : preds) {
+                auto ch = c->children.find(p);
+                if (ch == c->children.end()) continue; // the reference dereferences end() here; defined as "no children"
+                child_set.insert(ch->second.begin(), ch->second.end());
             }
+            const size_t level0 = idx.size();
+            for (const std::string &k : child_set) {
+                auto ki = by_name.find(k);
+                if (ki != by_name.end()) idx.insert(idx.end(), ki->second.begin(), ki->second.end());
+            }
+            std::sort(idx.begin() + level0, idx.end()); // path order within the level
+            if (idx.size() > kMaxList) return fail(VGAN_ERANGE, "vgan_hc_posterior: children of '%s' do not end (cycle?)", parent_vec[j].c_str());
+            preds.swap(child_set);
         }
-        sets.push_back(std::move(set));
+        off.push_back((uint32_t)idx.size());
     }
-    const uint32_t ns = (uint32_t)sets.size();
+    const uint32_t ns = (uint32_t)off.size() - 1;
     if ((int32_t)ns > conf_cap) return fail(VGAN_ERANGE, "vgan_hc_posterior: conf_cap too small (%u records)", ns);
     std::string joined;
     for (auto &s : clades) joined += s + "\n";
     if ((int64_t)joined.size() + 1 > clade_cap) return fail(VGAN_ERANGE, "vgan_hc_posterior: clade buffer too small");
     HIPCHK(hipSetDevice(c->device));
     int rc;
-    if ((rc = c->sets.reserve((size_t)ns * c->W)) || (rc = c->conf.reserve(ns))) return rc;
-    std::vector<uint64_t> flat((size_t)ns * c->W);
-    for (uint32_t i = 0; i < ns; ++i) std::copy(sets[i].begin(), sets[i].end(), flat.begin() + (size_t)i * c->W);
-    HIPCHK(hipMemcpyAsync(c->sets.p, flat.data(), flat.size() * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c->lists.reserve(off.size() + idx.size())) || (rc = c->conf.reserve(ns))) return rc;
+    HIPCHK(hipMemcpyAsync(c->lists.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->lists.p + off.size(), idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->final_vec.p, final_vec, (size_t)c->P * 8, hipMemcpyHostToDevice, c->stream));
-    launch_hc_posterior(c->final_vec.p, c->P, c->sets.p, c->W, ns, c->conf.p, c->stream);
+    launch_hc_posterior(c->final_vec.p, c->P, c->lists.p, c->lists.p + off.size(), ns, c->conf.p, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(conf, c->conf.p, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -72,7 +72,7 @@ void launch_hc_finish(const double *totals, const double *acc_seg, const double 
                       hipStream_t st);
 void launch_hc_read_loglik(const HcGraphDev &g, const HcBatchDev &b, const double *segS, const double *segU, double *out,
                            hipStream_t st);
-void launch_hc_posterior(const double *final_vec, uint32_t n_paths, const uint64_t *sets, uint32_t set_words,
-                         uint32_t n_sets, double *conf, hipStream_t st);
+void launch_hc_posterior(const double *final_vec, uint32_t n_paths, const uint32_t *list_off, const uint32_t *list_idx,
+                         uint32_t n_lists, double *conf, hipStream_t st);
 
 } // namespace vgan

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
         const uint32_t seg0 = b.read_seg_off[r], seg1 = b.read_seg_off[r + 1];
         const uint32_t col0 = b.read_col_off[r];
         const uint32_t q0 = b.read_qual_off[r];
-        const uint32_t QL = b.read_qual_off[r + 1] - q0;
+        // (the batch contract bounds a quality string at 65535 bytes; clamped so that a caller's error cannot leave ps_s)
+        const uint32_t QL = min(b.read_qual_off[r + 1] - q0, (uint32_t)SEG_MAXQ * 64u);
         const uint32_t A = b.read_algn_len[r];
         const double pinc = g.incmap[b.read_mapq[r]];
         const bool use_lds = QL <= SEG_MAXQ;
@@ -777,15 +778,16 @@ __global__ void hc_read_loglik_kernel(HcGraphDev g, HcBatchDev b, const double *
 }
 
 // ---------------------------------------------------------------------------------------------- posterior
-// One block per set: conf[set] = exp(LSE(final[p] : p in set) - LSE(final[all])).
+// One block per list: conf[list] = exp(LSE(final[idx[i]] : i in list) - LSE(final[all])).
+// A list is the reference's all_top vector (src/get_posterior.cpp:51-76): the path indices of every recursion level in
+// turn, so a path reachable at two depths of children.txt appears -- and is counted -- twice.
 // libgab's oplusInitnatl treats a running value of exactly 0 as "empty" (SURVEY.md Q11): zeros in front of
-// the first non-zero term are skipped, both here and in the reference's sequential fold.
-__device__ double block_lse(const double *__restrict__ v, const uint64_t *__restrict__ set, uint32_t n, double *sh) {
+// the first non-zero term (in list order) are skipped, both here and in the reference's sequential fold.
+__device__ double block_lse(const double *__restrict__ v, const uint32_t *__restrict__ idx, uint32_t n, double *sh) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     uint32_t first = 0xFFFFFFFFu;
-    for (uint32_t p = tid; p < n; p += blockDim.x) {
-        const bool in = !set || ((set[p >> 6] >> (p & 63)) & 1);
-        if (in && v[p] != 0.0) first = min(first, p);
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        if (v[idx ? idx[i] : i] != 0.0) first = min(first, i);
     }
     first = wave_min_u32(first);
     __shared__ uint32_t shu[16];
@@ -794,12 +796,9 @@ __device__ double block_lse(const double *__restrict__ v, const uint64_t *__rest
     first = 0xFFFFFFFFu;
     for (int w = 0; w < nw; ++w) first = min(first, shu[w]);
     __syncthreads();
-    if (first == 0xFFFFFFFFu) return 0.0; // all members are exactly 0 (or the set is empty)
+    if (first == 0xFFFFFFFFu) return 0.0; // all members are exactly 0, or the list is empty (oracle.h: sum of nothing = 0)
     double mx = -INFINITY;
-    for (uint32_t p = tid; p < n; p += blockDim.x) {
-        const bool in = !set || ((set[p >> 6] >> (p & 63)) & 1);
-        if (in && p >= first) mx = fmax(mx, v[p]);
-    }
+    for (uint32_t i = first + tid; i < n; i += blockDim.x) mx = fmax(mx, v[idx ? idx[i] : i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) sh[wave] = mx;
@@ -808,10 +807,7 @@ __device__ double block_lse(const double *__restrict__ v, const uint64_t *__rest
     for (int w = 0; w < nw; ++w) mx = fmax(mx, sh[w]);
     __syncthreads();
     double s = 0.0;
-    for (uint32_t p = tid; p < n; p += blockDim.x) {
-        const bool in = !set || ((set[p >> 6] >> (p & 63)) & 1);
-        if (in && p >= first) s += exp(v[p] - mx);
-    }
+    for (uint32_t i = first + tid; i < n; i += blockDim.x) s += exp(v[idx ? idx[i] : i] - mx);
     s = wave_sum(s);
     if (lane == 0) sh[wave] = s;
     __syncthreads();
@@ -822,11 +818,13 @@ __device__ double block_lse(const double *__restrict__ v, const uint64_t *__rest
 }
 
 __global__ __launch_bounds__(256) void hc_posterior_kernel(const double *__restrict__ final_vec, uint32_t n_paths,
-                                                            const uint64_t *__restrict__ sets, uint32_t set_words,
+                                                            const uint32_t *__restrict__ list_off,
+                                                            const uint32_t *__restrict__ list_idx,
                                                             double *__restrict__ conf) {
     __shared__ double sh[16];
     const double total = block_lse(final_vec, nullptr, n_paths, sh);
-    const double part = block_lse(final_vec, sets + (size_t)blockIdx.x * set_words, n_paths, sh);
+    const uint32_t o0 = list_off[blockIdx.x], o1 = list_off[blockIdx.x + 1];
+    const double part = block_lse(final_vec, list_idx + o0, o1 - o0, sh);
     if (threadIdx.x == 0) conf[blockIdx.x] = exp(part - total);
 }
 
@@ -949,10 +947,10 @@ void launch_hc_read_loglik(const HcGraphDev &g, const HcBatchDev &b, const doubl
                        segU, out);
 }
 
-void launch_hc_posterior(const double *final_vec, uint32_t n_paths, const uint64_t *sets, uint32_t set_words,
-                         uint32_t n_sets, double *conf, hipStream_t st) {
-    if (n_sets == 0) return;
-    hipLaunchKernelGGL(hc_posterior_kernel, dim3(n_sets), dim3(256), 0, st, final_vec, n_paths, sets, set_words, conf);
+void launch_hc_posterior(const double *final_vec, uint32_t n_paths, const uint32_t *list_off, const uint32_t *list_idx,
+                         uint32_t n_lists, double *conf, hipStream_t st) {
+    if (n_lists == 0) return;
+    hipLaunchKernelGGL(hc_posterior_kernel, dim3(n_lists), dim3(256), 0, st, final_vec, n_paths, list_off, list_idx, conf);
 }
 
 } // namespace vgan

@@ -171,8 +171,10 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         int bad = reconstruct(g, a, r, rc);
         const int64_t nm = a.map_off[r + 1] - a.map_off[r];
         const size_t A = rc.ps.size(), G = rc.gseq.size();
-        if (!bad && (A > 65535 || G > 65535 || nm > 65535)) bad = BAD_RANGE;
         const size_t n_qual_r = (size_t)(a.qual_off[r + 1] - a.qual_off[r]);
+        // 16-bit per-read positions; the quality string is parsed independently of |sequence| (gam.cpp) and the general
+        // kernel keeps one prefix sum per 64 quality bytes for at most 65536 of them
+        if (!bad && (A > 65535 || G > 65535 || nm > 65535 || n_qual_r > 65535)) bad = BAD_RANGE;
         auto &b = (!bad && A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && (size_t)nm <= TILE_MAX_SEGS) ? c.b : c.gen;
         const size_t seg_mark = b.seg_node.size();
         if (!bad) {

@@ -159,7 +159,8 @@ int haplocart(int argc, char **argv) {
         vgan_dedup *d = nullptr;
         ~DedupCloser() { vgan_dedup_free(d); }
     } dedup;
-    if (rmdup && fastafilename.empty()) check(vgan_dedup_create(&dedup.d), "duplicate removal"); // HaploCart.cpp:386-393
+    // HaploCart.cpp:389-390: remove_duplicates_internal runs whatever the input was; only its message depends on -f
+    if (rmdup) check(vgan_dedup_create(&dedup.d), "duplicate removal");
     int64_t n_in = 0, n_dup = 0;
     std::vector<uint8_t> dup;
     vgan_hc_flatten_stats tot{};
@@ -196,15 +197,18 @@ int haplocart(int argc, char **argv) {
         tot.n_unmapped += st.n_unmapped;
         tot.n_out += st.n_out;
     }
+    if (n_in == 0) die("[HaploCart] Error, no reads mapped"); // HaploCart.cpp:384-385
     int64_t n_reads = n_in - n_dup;
     if (!quiet) {
         std::cerr << "Found " << n_in << " reads." << '\n';
-        if (dedup.d) std::cerr << "PCR duplicates removed." << std::endl;
+        if (dedup.d && fastafilename.empty()) std::cerr << "PCR duplicates removed." << std::endl;
         if (!fastafilename.empty()) std::cerr << "Using background error probability of " << background_error_prob << '\n';
         else std::cerr << "Computing haplogroup likelihoods from " << n_reads << " reads." << '\n';
     }
     if (tot.n_bad && !quiet)
         std::cerr << "[HaploCart] warning: " << tot.n_bad << " reads skipped (the reference would terminate on them)\n";
+    if (tot.n_out == 0) // the reference goes on and reports path 0 from an all-zero vector: said aloud, even with -q
+        std::cerr << "[HaploCart] warning: none of the " << n_in << " reads is mapped and usable; the prediction below rests on no evidence\n";
     std::vector<double> final_vec(gv.n_paths);
     check(vgan_hc_finalize(ctx, nullptr, final_vec.data()), "finalize");
     pt.lap("flatten + kernels");

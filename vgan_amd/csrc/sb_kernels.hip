@@ -28,8 +28,8 @@ constexpr double SB_LOG_CLAMP = -1.0000000494736474e-07; // log(0.9999999)
 struct SbSegLds {
     double sup, uns;
     uint32_t node;
-    uint8_t cnt[SB_NCNT];
-    uint8_t pad[3];
+    uint16_t cnt[SB_NCNT]; // a segment has up to 65535 columns (seg_len is 16 bit), e.g. a 300-column homopolymer match edit
+    uint16_t pad;
 };
 
 template <int PP>
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDe
                 const uint32_t node = b.seg_node[s], col = b.seg_col[s], len = b.seg_len[s];
                 const int32_t bix = b.seg_base_ix[s];
                 double sup = 0.0, uns = 0.0;
-                uint8_t c25[SB_NCNT];
+                uint16_t c25[SB_NCNT];
 #pragma unroll
                 for (int j = 0; j < (int)SB_NCNT; ++j) c25[j] = 0;
                 if (len > 0 && (uint32_t)bix >= Lseq) bad = true;
