@@ -38,10 +38,35 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="accepted for old command lines; the parity diff is part of the cpu_baseline leg (--cpu-seconds 0 skips both)")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-read-mode kernel measurement")
     ap.add_argument("--clades", type=int, default=335, help="euka path: number of clades the synthetic reads spread over")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test rigs with fewer GPUs than ranks)")
+    ap.add_argument("--dist-backend", default="auto", help="auto: nccl (= RCCL) when every rank has a GPU of its own, else gloo with ranks sharing GPUs | nccl | gloo")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --reads per GPU (N = 1 is BASELINE configs[1]); strong: --reads-total split over the N GPUs (configs[2])")
+    ap.add_argument("--reads-total", type=int, default=10_000_000, help="strong scaling: reads of the whole job")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the GAM decode / flatten rates")
     ap.add_argument("--path", choices=["haplocart", "euka", "soibean"], default="haplocart",
                     help="haplocart = the BASELINE metric; euka / soibean = configs 4 / 5 as extra lines")
     return ap.parse_args()
+
+
+def pick_device(args):
+    """(rank, world, local device index, torch device, backend) of this process.  --dist-backend auto: RCCL when every
+    rank has a GPU of its own, else gloo with the ranks sharing the GPUs there are (test rigs)."""
+    import torch
+    from vgan_amd import distributed as vd
+    rank, world, local_rank = vd.env_rank()
+    n_dev = torch.cuda.device_count()  # counting does not initialise the GPU
+    if n_dev == 0 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    backend = args.dist_backend
+    if backend == "auto":
+        backend = "nccl" if n_dev >= world else "gloo"
+    if backend == "gloo":
+        local_rank = local_rank % n_dev
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    vd.init(backend=backend, device=dev)
+    return rank, world, local_rank, dev, backend, n_dev
 
 
 def cpu_baseline(graph, alns, budget_s, ctx=None, hc=None):
@@ -124,12 +149,7 @@ def bench_euka(args):
     import torch
     from vgan_amd import distributed as vd
     from vgan_amd import euka as ek
-    rank, world, local_rank = vd.env_rank()
-    if args.dist_backend == "gloo":  # several ranks may share one GPU on a test rig
-        local_rank = min(local_rank, torch.cuda.device_count() - 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    vd.init(backend=args.dist_backend, device=dev)
+    rank, world, local_rank, dev, backend, n_dev = pick_device(args)
     gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
     dm = ek.Damage.load(os.path.join(gold, "dhigh5p.prof"), os.path.join(gold, "dhigh3p.prof"))
     dm_texts = (open(os.path.join(gold, "dhigh5p.prof")).read(), open(os.path.join(gold, "dhigh3p.prof")).read())
@@ -178,7 +198,8 @@ def bench_euka(args):
             "config": {"workload": "euka %d synthetic 75bp aDNA reads per GPU, dhigh damage profiles, 335-clade graph" % args.reads,
                        "reads_per_gpu": hb.n_reads, "passing_reads": int(fin["clade_count"].sum())},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": committed_traffic("round1_v5_euka", "euka_read_kernel", args.reads == 1_000_000 and world == 1),
+                         "traffic": None,
+                         "traffic_from_profile": committed_traffic("round1_v5_euka", "euka_read_kernel", args.reads == 1_000_000 and world == 1),
                          "kernel": "euka_read_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
                          "launches": n, "note": "fp64 VALU bound (SURVEY 8d): one table log + the damage-matrix products per base"}}
         if world == 1 and args.cpu_seconds > 0:
@@ -199,7 +220,8 @@ def committed_traffic(profile, kernel, applies):
         pmc = json.load(open(os.path.join(ROOT, "profiles", profile + "_pmc.json")))
         for kn, v in pmc.items():
             if kernel in kn:
-                return v["fetch_bytes"] + v["write_bytes"]
+                return {"bytes": v["fetch_bytes"] + v["write_bytes"], "profile": "profiles/%s_pmc.json" % profile,
+                        "note": "uncorrected FETCH_SIZE + WRITE_SIZE of a committed rocprofv3 --pmc pass, not measured in this run"}
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -248,12 +270,7 @@ def bench_soibean(args):
     from vgan_amd import euka as ek
     from vgan_amd import haplocart as hc
     from vgan_amd import soibean as sb
-    rank, world, local_rank = vd.env_rank()
-    if args.dist_backend == "gloo":  # several ranks may share one GPU on a test rig
-        local_rank = min(local_rank, torch.cuda.device_count() - 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    vd.init(backend=args.dist_backend, device=dev)
+    rank, world, local_rank, dev, backend, n_dev = pick_device(args)
     g = hc.synth_graph(seed=args.seed, genome_len=16569, n_nodes=11000, n_paths=28)
     alns = hc.synth_reads(g, args.reads, seed=args.seed + 1000003 * rank, read_len=65, indel_rate=0.005, softclip_rate=0.01)
     dm = ek.Damage.from_text("", "")
@@ -337,7 +354,8 @@ def bench_soibean(args):
             "config": {"workload": "soibean k=3, %d synthetic reads per GPU, 28-path tree, host Metropolis loop + GPU refresh per iteration" % args.reads,
                        "reads_per_gpu": R, "precompute_s": t_pre, "accepted": accepted},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": committed_traffic("round1_v5_soibean", "sb_refresh_fused_kernel", R == SB_PROFILED_READS and world == 1)
+                         "traffic": None,
+                         "traffic_from_profile": committed_traffic("round1_v5_soibean", "sb_refresh_fused_kernel", R == SB_PROFILED_READS and world == 1)
                          if fused else None,
                          "kernel": "sb_refresh_fused_kernel" if fused else "sb_loglike_kernel + sb_finish_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
                          "launches": km["refresh"][1]}}
@@ -346,8 +364,115 @@ def bench_soibean(args):
         print(json.dumps(out), flush=True)
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this one, which has not
+    imported torch or touched HIP (a process that has initialised the GPU must not exec), wait for them and leave with
+    the worst exit code.  Rank 0 prints the JSON line on the inherited stdout."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, live, deadline = 0, list(procs), None
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:  # one rank failed: the others would wait in a collective for ever
+                rc = code
+                deadline = time.time() + 15
+        if deadline is not None and live and time.time() > deadline:
+            for q in live:
+                q.kill()  # exactly the processes started above
+            deadline = time.time() + 1e9
+    sys.exit(rc if rc >= 0 else 1)
+
+
+CHUNK_READS = 1_000_000  # reads per device batch (a rank's shard is a list of such batches, all resident in HBM)
+
+
+def collect_traffic(args, kernel_substr):
+    """HBM bytes per launch of the dominant kernel, from the PMC counters of THIS tree on THIS box: two child runs of
+    this very file under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md "rocprofv3
+    PMC slots"), 3 steps each, outside every timed region.  Units are KB per dispatch.  gfx950 corrections per the guide's
+    HBM section: FETCH_SIZE tallies the 128-byte requests of a coalesced stream at 64 B, so it is doubled; WRITE_SIZE is
+    exact for 8/16-byte stores and float atomics; Infinity-Cache hits are counted.  Raw values are kept beside the sum."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    raw = {}
+    tmp = tempfile.mkdtemp(prefix="vgan_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-pmc", "--no-frontend",
+                   "--reads", str(args.reads), "--read-len", str(args.read_len), "--mode", args.mode, "--seed", str(args.seed)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            raw[counter] = sum(vals) / len(vals) * 1024.0
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"fetch_size_bytes_raw": raw["FETCH_SIZE"], "write_size_bytes_raw": raw["WRITE_SIZE"],
+            "bytes": 2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"],
+            "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950: coalesced 128-B read requests are tallied at 64 B)"}
+
+
+def front_end_rates(graph, hc, seed, n=200_000):
+    """SURVEY 8f-1 beside the metric (the timed step starts from a flattened batch in HBM): GAM decode and flatten
+    rates of the host front end on a bounded sample of the same workload."""
+    import tempfile
+    a = hc.synth_reads(graph, n, seed=seed, read_len=150)
+    with tempfile.TemporaryDirectory(prefix="vgan_fe_") as d:
+        p = os.path.join(d, "sample.gam")
+        a.write_gam(p)
+        size = os.path.getsize(p)
+        t0 = time.perf_counter()
+        b = hc.AlnSet.read_gam(p)
+        t_dec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hb = hc.HostBatch(graph, b)
+    t_fl = time.perf_counter() - t0
+    return {"sample_reads": n, "gam_bytes": size, "decode_reads_per_s": n / t_dec, "flatten_reads_per_s": hb.n_reads / t_fl,
+            "threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)  # does not return
     if args.path == "euka":
         return bench_euka(args)
     if args.path == "soibean":
@@ -358,22 +483,30 @@ def main():
     from vgan_amd import distributed as vd
     from vgan_amd import haplocart as hc
 
-    rank, world, local_rank = vd.env_rank()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    if args.dist_backend == "gloo":  # several ranks may share one GPU on a test rig
-        local_rank = min(local_rank, torch.cuda.device_count() - 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    vd.init(backend=args.dist_backend, device=dev)
+    rank, world, local_rank, dev, backend, n_dev = pick_device(args)
 
-    # ---- synthetic workload (same graph on every rank, a different read shard per rank)
+    # ---- synthetic workload: one graph on every rank; the reads are ONE stream defined by the seed (read i depends on
+    # (seed, i) only) and every rank takes a contiguous range of it, so the job's read set does not depend on N.
+    #   weak   : rank r holds reads [r*R, (r+1)*R), R = --reads (N = 1 is BASELINE configs[1]: 1M x 150 bp)
+    #   strong : the --reads-total reads of configs[2] (10M) are split into N contiguous shards
     graph = hc.synth_graph(seed=args.seed)
-    alns = hc.synth_reads(graph, args.reads, seed=args.seed + 1000003 * rank, read_len=args.read_len)
-    hb = hc.HostBatch(graph, alns)
-    db = hc.DeviceBatch(hb, dev)
-    algo = hb.algorithmic_bytes(graph.n_paths)
-    n_reads, n_seg = hb.n_reads, hb.n_segments
+    if args.scaling == "strong":
+        r0, r1 = vd.shard_bounds(args.reads_total, rank, world)
+    else:
+        r0, r1 = rank * args.reads, (rank + 1) * args.reads
+    batches, n_reads, n_seg, algo_nw = [], 0, 0, 0
+    alns0 = None
+    for c0 in range(r0, r1, CHUNK_READS):
+        c1 = min(r1, c0 + CHUNK_READS)
+        alns = hc.synth_reads(graph, c1 - c0, seed=args.seed, read_len=args.read_len, first_read=c0)
+        hb = hc.HostBatch(graph, alns)
+        batches.append(hc.DeviceBatch(hb, dev))
+        n_reads += hb.n_reads
+        n_seg += hb.n_segments
+        algo_nw += hb.algorithmic_bytes(graph.n_paths)["node_weights"]
+        if alns0 is None:
+            alns0 = alns  # the cpu_baseline leg samples the first reads of rank 0
+        del hb
     ctx = hc.HcContext(graph, device=local_rank)
     ctx.use_torch_stream()
     mode = {"node_weights": hc.MODE_NODE_WEIGHTS, "per_read": hc.MODE_PER_READ, "per_read_dense": hc.MODE_PER_READ_DENSE}[args.mode]
@@ -382,7 +515,8 @@ def main():
 
     def step():
         ctx.reset()
-        ctx.accumulate(db)
+        for db in batches:
+            ctx.accumulate(db)
         ctx.finalize_device(final_dev)
         vd.reduce_loglik(final_dev, dst=0)  # RCCL over xGMI when N > 1: 41 KB of per-path sums
 
@@ -404,54 +538,74 @@ def main():
     ctx.profile_enable(False)
     elapsed = vd.all_reduce_max(elapsed, dev)            # MAX over ranks
     total_reads = vd.all_reduce_sum(float(n_reads), dev)  # whole-job reads per step
+    final_host = final_dev.cpu().numpy().copy()           # complete on rank 0
+
+    # ---- per-rank kernel times and the cost of the reduce alone (outside the timed region)
+    my_kernels = {k: v[0] / max(args.steps, 1) for k, v in prof.items()}
+    per_rank, reduce_ms = [my_kernels], None
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "reads": n_reads, "kernel_ms_per_step": my_kernels})
+        per_rank = gathered
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            vd.reduce_loglik(final_dev, dst=0)
+        fence()
+        reduce_ms = vd.all_reduce_max((time.perf_counter() - t0) / 20 * 1e3, dev)
+
+    # ---- a9 (get_posterior.cpp:87-127) on rank 0, timed on its own: host tree walk + upload + one kernel
+    posterior_ms, posterior_top = None, None
+    if rank == 0:
+        pred = graph.path_names[ctx.argmax(final_host)]
+        ctx.posterior(final_host, pred)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            post = ctx.posterior(final_host, pred)
+        posterior_ms = (time.perf_counter() - t0) / 10 * 1e3
+        posterior_top = {"predicted": pred, "confidence": post[0][1], "records": len(post)}
 
     # ---- the reference's loop order (one mask row per segment) measured beside the default mode: the kernel
     # BASELINE.json's north_star puts the >= 30 % HBM-roofline target on.  Outside the timed region.
     per_read = None
     if rank == 0 and mode == hc.MODE_NODE_WEIGHTS and not args.no_extra:
         per_read = {}
+        db0 = batches[0]
         row_bytes = 8 * ((graph.n_paths + 63) // 64) + 4 + 8
         for label, m in (("dense", hc.MODE_PER_READ_DENSE), ("skip_unset_tiles", hc.MODE_PER_READ)):
             ctx.set_mode(m)
             ctx.reset()
-            ctx.accumulate(db)
+            ctx.accumulate(db0)
             ctx.synchronize()
             ctx.profile_enable(True)
             for _ in range(3):
                 ctx.reset()
-                ctx.accumulate(db)
+                ctx.accumulate(db0)
             pr = ctx.profile_read()
             ctx.profile_enable(False)
             ms = pr["sweep_segments"][0] / max(pr["sweep_segments"][1], 1)
-            gbs = n_seg * row_bytes / (ms * 1e-3) / 1e9
+            gbs = db0.n_segments * row_bytes / (ms * 1e-3) / 1e9
             per_read[label] = {"kernel": "hc_sweep_kernel", "avg_launch_ms": ms, "achieved": gbs, "unit": "GB/s",
-                               "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": n_seg * row_bytes,
-                               "reads_per_s_kernel_only": n_reads / (ms * 1e-3)}
+                               "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": db0.n_segments * row_bytes,
+                               "reads_per_s_kernel_only": db0.n_reads / (ms * 1e-3)}
         ctx.set_mode(mode)
 
-    parity = None  # filled by the cpu_baseline leg (the only user of oracle/)
-
     if rank == 0:
-        # dominant kernel and its algorithmic bytes per launch (DESIGN.md "Roofline accounting")
+        # dominant kernel and its algorithmic bytes per launch (DESIGN.md "Roofline accounting"); a rank launches it once
+        # per device batch, so bytes per launch = the rank's bytes / its batches
         if mode == hc.MODE_NODE_WEIGHTS:
-            kname, kbytes = "segment", algo["node_weights"]
+            kname, kbytes = "segment", algo_nw / len(batches)
         else:
-            kname, kbytes = "sweep_segments", n_seg * (8 * ((graph.n_paths + 63) // 64) + 4 + 8)
+            kname, kbytes = "sweep_segments", n_seg * (8 * ((graph.n_paths + 63) // 64) + 4 + 8) / len(batches)
         k_ms, k_n = prof[kname]
         avg_ms = k_ms / max(k_n, 1)
-        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected
-        # in separate runs of this very command, profiles/round1_v4_*_pmc.json); null when no such pass is committed.
+        kernel_name = {"segment": "hc_segment", "sweep_segments": "hc_sweep_kernel"}[kname]
         traffic = None
-        try:
-            tag = {"node_weights": "node", "per_read": "skip", "per_read_dense": "dense"}[args.mode]
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_v4_%s_pmc.json" % tag)))
-            want = "hc_segment_tile_kernel" if kname == "segment" else "hc_sweep_kernel<10, false>"
-            for kn, v in pmc.items():
-                if want in kn and args.reads == 1_000_000 and args.read_len == 150:
-                    traffic = v["fetch_bytes"] + v["write_bytes"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        if world == 1 and not args.no_pmc and args.scaling == "weak":
+            traffic = collect_traffic(args, kernel_name if kname == "segment" else "hc_sweep_kernel<10, false>")
         achieved = kbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        what = ("%d of the %d reads of BASELINE configs[2] per GPU (contiguous shards)" % (n_reads, args.reads_total)
+                if args.scaling == "strong" else "%d synthetic %dbp reads per GPU" % (args.reads, args.read_len))
         out = {
             "metric": "reads/sec (whole node) through HaploCart posterior path, 150bp",
             "value": total_reads * args.steps / elapsed,
@@ -461,28 +615,56 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "HaploCart %d synthetic %dbp reads per GPU vs hcfiles-shaped mtDNA graph (11821 nodes, 5179 paths), posteriors diffed vs CPU"
-                                   % (args.reads, args.read_len),
-                       "reads_per_gpu": n_reads, "segments_per_read": n_seg / max(n_reads, 1), "mode": args.mode,
-                       "sharding": "reads x%d, RCCL reduce of final_vec[5179]" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {"segment": "hc_segment_tile_kernel", "sweep_segments": "hc_sweep_kernel"}[kname],
-                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": avg_ms, "launches": k_n},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
-            "parity": parity,
+            "config": {"workload": "HaploCart %s vs hcfiles-shaped mtDNA graph (11821 nodes, 5179 paths); step = reset + per-read "
+                                   "likelihood kernels over the flattened batch resident in HBM + final_vec%s; GAM decode / flatten "
+                                   "(front_end) and get_posterior (posterior_ms) are timed beside it, not inside" % (
+                                       what, " + RCCL reduce" if world > 1 else ""),
+                       "reads_per_gpu": n_reads, "reads_total": int(total_reads), "segments_per_read": n_seg / max(n_reads, 1),
+                       "mode": args.mode, "device_batches_per_gpu": len(batches),
+                       "sharding": "contiguous read ranges x%d, %s reduce of final_vec[%d] to rank 0" % (world, "RCCL" if backend == "nccl" else "gloo (host staged)", graph.n_paths)
+                                   if world > 1 else "single GPU",
+                       "physical_gpus": min(n_dev, world), "dist_backend": backend if world > 1 else None},
+            # the counters name the limiter (profiles/: VALU issue, SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles); the fraction
+            # BASELINE.json asks for is the HBM one, kept in achieved / peak / frac
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
+                         "kernel": kernel_name, "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": avg_ms, "launches": k_n,
+                         "valu_issue_frac_from_profile": valu_from_profile(kernel_name)},
+            "kernel_ms_per_step": my_kernels,
+            "per_rank": per_rank if world > 1 else None,
+            "reduce_ms": reduce_ms,
+            "posterior_ms": posterior_ms,
+            "posterior": posterior_top,
+            "result_check": {"argmax": int(np.argmax(final_host)), "sum_final_vec": float(final_host.sum())},
+            "parity": None,
             "per_read_kernel": per_read,
         }
+        if world == 1 and not args.no_frontend:
+            out["front_end"] = front_end_rates(graph, hc, args.seed)
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(graph, alns, args.cpu_seconds, ctx, hc)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(graph, alns0, args.cpu_seconds, ctx, hc)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def valu_from_profile(kernel_name):
+    """VALU issue fraction of the dominant kernel from the committed SQ-counter pass (profiles/valu_issue.json, written by
+    tools/summarize_profile.py with the commit it was taken at): a tagged figure of a profile, not a live one."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))
+        for k, v in d.get("kernels", {}).items():
+            if kernel_name in k:
+                return dict(v, profile=d.get("profile"), commit=d.get("commit"))
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 if __name__ == "__main__":

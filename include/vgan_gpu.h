@@ -610,6 +610,8 @@ typedef struct vgan_synth_reads_cfg {
     double softclip_rate;    /* 0.01 reads with a 5-20 bp softclip */
     double low_mapq_rate;    /* 0.1 reads with mapq U{0..59}, else 60 */
     int32_t errors;          /* 1: substitutions with prob 10^(-Q/10) */
+    uint64_t first_read;     /* read i of the set is read first_read + i of the seed's stream: contiguous shards of one
+                              * workload (bench.py's ranks, the sharding tests) are the same reads whatever the shard count */
 } vgan_synth_reads_cfg;
 
 int vgan_synth_hc_graph(const vgan_synth_graph_cfg *cfg, vgan_graph **out);

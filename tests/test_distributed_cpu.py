@@ -1,6 +1,7 @@
 """world_size-2 gloo test of the N>1 path on CPU: reads shard by contiguous ranges, each rank's final_vec is
 summed onto rank 0 with the product's reduce helper.  The per-rank vectors come from the oracle here (no GPU in
-this container); on the GPU box test_hc_gpu.py checks that the device path equals the oracle per shard."""
+this container); tests/test_distributed_gpu.py runs the same two-rank reduce over the product's device vectors, and
+bench.py's own rank launcher, on the GPU box."""
 import os
 import socket
 

@@ -206,3 +206,21 @@ def test_gam_without_reads(tmp_path):
     # the end-of-file block after real data is still just the end
     a.write_gam(p)
     assert hc.AlnSet.read_gam(p).n_reads == a.n_reads
+
+
+def test_oversized_quality_string_is_refused_not_indexed():
+    """The GAM parser takes quality bytes independently of |sequence|; the general segment kernel keeps one quality
+    prefix per 64 bytes for 65536 of them, so a read with a longer quality string must not reach it (it would write
+    past its wave's LDS slice).  Flatten drops and counts it; the boundary value is still accepted."""
+    from test_euka_cpu import _mk
+    g = hc.Graph.from_arrays(1, 1, np.array([0, 0, 20], np.int64), b"ACGTACGTACGTACGTACGT", 1, np.zeros((2, 1), np.uint64),
+                             np.array([-1, 5], np.int32), np.ones(30), "p0\n")
+    ed = [(1, 0, False, [(20, 20, b"")])]
+    alns = [_mk(b"ACGTACGTACGTACGTACGT", [30] * 20, ed), _mk(b"ACGTACGTACGTACGTACGT", [30] * 70000, ed),
+            _mk(b"ACGTACGTACGTACGTACGT", [31] * 65535, ed)]
+    a = hc.AlnSet.parse_gam(gamio.write_gam(alns))
+    assert a.n_reads == 3
+    b = hc.HostBatch(g, a)
+    assert b.n_reads == 2 and b.stats.n_bad == 1 and sorted(b.read_src.tolist()) == [0, 2]
+    ql = np.diff(b.arrays()["read_qual_off"])
+    assert ql.max() == 65535 and b.n_tileable == 1

@@ -148,7 +148,7 @@ class SynthGraphCfg(C.Structure):
 
 class SynthReadsCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("indel_rate", C.c_double),
-                ("softclip_rate", C.c_double), ("low_mapq_rate", C.c_double), ("errors", C.c_int32)]
+                ("softclip_rate", C.c_double), ("low_mapq_rate", C.c_double), ("errors", C.c_int32), ("first_read", C.c_uint64)]
 
 
 # every symbol include/vgan_gpu.h declares: (restype, argtypes)

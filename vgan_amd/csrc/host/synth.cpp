@@ -401,7 +401,7 @@ extern "C" int vgan_synth_hc_reads(const vgan_graph *g, const vgan_synth_reads_c
     std::vector<vgan_alnset> parts((size_t)nt);
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) {
-        const uint64_t b0 = R * t / nt, b1 = R * (t + 1) / nt;
+        const uint64_t b0 = cfg->first_read + R * t / nt, b1 = cfg->first_read + R * (t + 1) / nt;
         if (nt == 1) gen_reads(*g, w, *cfg, b0, b1, parts[t]);
         else th.emplace_back(gen_reads, std::cref(*g), std::cref(w), std::cref(*cfg), b0, b1, std::ref(parts[t]));
     }

@@ -500,8 +500,9 @@ def synth_graph(seed=0x76676131, genome_len=16569, n_nodes=11821, n_paths=5179):
 
 
 def synth_reads(graph, n_reads, seed=0x76676131, read_len=150, indel_rate=0.005, softclip_rate=0.01,
-                low_mapq_rate=0.1, errors=True):
-    cfg = N.SynthReadsCfg(seed, n_reads, read_len, indel_rate, softclip_rate, low_mapq_rate, int(errors))
+                low_mapq_rate=0.1, errors=True, first_read=0):
+    """Reads [first_read, first_read + n_reads) of the stream the seed defines (read i depends on (seed, i) only)."""
+    cfg = N.SynthReadsCfg(seed, n_reads, read_len, indel_rate, softclip_rate, low_mapq_rate, int(errors), first_read)
     h = N.vp()
     N.check(N.lib().vgan_synth_hc_reads(graph._h, C.byref(cfg), C.byref(h)))
     return AlnSet(h)
