@@ -640,7 +640,8 @@ def main():
             "reduce_ms": reduce_ms,
             "posterior_ms": posterior_ms,
             "posterior": posterior_top,
-            "result_check": {"argmax": int(np.argmax(final_host)), "sum_final_vec": float(final_host.sum())},
+            "result_check": {"argmax": int(np.argmax(final_host)), "max_final_vec": float(final_host.max()),
+                             "sum_final_vec": float(final_host.sum())},
             "parity": None,
             "per_read_kernel": per_read,
         }

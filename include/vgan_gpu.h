@@ -233,7 +233,10 @@ enum {
 };
 
 int vgan_hc_create(const vgan_graph_view *graph, const vgan_hc_params *params, int device, vgan_hc_ctx **out);
-int vgan_hc_set_stream(vgan_hc_ctx *c, void *hip_stream); /* NULL = the context's own stream */
+/* hip_stream: a hipStream_t; NULL = the context's own (non-blocking) stream.  The null stream has the handle 0 too: to
+ * run on it -- e.g. beside PyTorch / RCCL work queued on torch's default stream -- pass hipStreamLegacy ((hipStream_t)1).
+ * The same holds for vgan_euka_set_stream and vgan_sb_set_stream. */
+int vgan_hc_set_stream(vgan_hc_ctx *c, void *hip_stream);
 int vgan_hc_set_mode(vgan_hc_ctx *c, int mode);
 int vgan_hc_reset(vgan_hc_ctx *c);                         /* zero the accumulators */
 /* Full check of a batch held in host memory against the contracts above and the context's graph (offsets ascending

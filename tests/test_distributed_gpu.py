@@ -86,7 +86,8 @@ def test_bench_starts_its_own_ranks_weak_and_strong():
     strong = _bench("--gpus", "3", "--dist-backend", "gloo", "--scaling", "strong", "--reads-total", "60000")
     assert strong["n_gpus"] == 3 and strong["scaling"] == "strong" and strong["config"]["reads_total"] == one["config"]["reads_total"]
     for other in (two, strong):  # the same read set whatever the sharding: same result up to the summation order
-        assert other["result_check"]["argmax"] == one["result_check"]["argmax"]
+        # (paths with identical node sets tie exactly in exact arithmetic, so the argmax itself may be any of them)
+        assert other["result_check"]["max_final_vec"] == pytest.approx(one["result_check"]["max_final_vec"], rel=1e-12)
         assert other["result_check"]["sum_final_vec"] == pytest.approx(one["result_check"]["sum_final_vec"], rel=1e-12)
-        assert other["posterior"]["predicted"] == one["posterior"]["predicted"]
+        assert other["posterior"]["confidence"] == pytest.approx(one["posterior"]["confidence"], rel=1e-6)
     assert one["posterior_ms"] > 0 and one["roofline"]["bound"] == "valu" and 0 < one["roofline"]["frac"] < 1

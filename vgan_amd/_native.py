@@ -252,6 +252,17 @@ SYMBOLS = {
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),
 }
 
+HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the null stream by name (a NULL argument selects the context's own stream)
+
+
+def torch_stream_ptr(device):
+    """torch's current stream on `device` as a hipStream_t for the *_set_stream entry points.  torch's default stream is
+    the null stream, whose handle is 0 -- which the C-ABI reads as "the context's own (non-blocking) stream"; the kernels
+    would then race with torch's and RCCL's work on the null stream.  hipStreamLegacy names it explicitly."""
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream or HIP_STREAM_LEGACY
+
+
 _lib = None
 
 

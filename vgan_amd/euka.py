@@ -168,8 +168,7 @@ class EukaContext:
         self.device = device
 
     def use_torch_stream(self):
-        import torch
-        N.check(N.lib().vgan_euka_set_stream(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+        N.check(N.lib().vgan_euka_set_stream(self._h, N.torch_stream_ptr(self.device)))
 
     def reset(self):
         N.check(N.lib().vgan_euka_reset(self._h))

@@ -410,8 +410,7 @@ class HcContext:
         N.check(N.lib().vgan_hc_set_stream(self._h, stream_ptr))
 
     def use_torch_stream(self):
-        import torch
-        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.set_stream(N.torch_stream_ptr(self.device))
 
     def set_mode(self, mode):
         N.check(N.lib().vgan_hc_set_mode(self._h, mode))

@@ -48,8 +48,7 @@ class SbContext:
         self.n_reads = 0
 
     def use_torch_stream(self):
-        import torch
-        N.check(N.lib().vgan_sb_set_stream(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+        N.check(N.lib().vgan_sb_set_stream(self._h, N.torch_stream_ptr(self.device)))
 
     def precompute(self, batch):
         bad = C.c_int64(0)
