@@ -168,8 +168,8 @@ typedef struct vgan_hc_batch {
     const uint8_t *qual;          /* [n_qual] raw phred */
     int32_t on_device;            /* 0: host pointers (copied by accumulate); 1: device pointers (zero copy) */
     /* Reads [0, n_tileable) satisfy the tile contract below and take the LDS-tiled kernel; the others take the
-     * general kernel (any length, overlapping segments).  0 is always valid.  vgan_hc_flatten orders the batch
-     * accordingly (tileable reads first). */
+     * general kernel (any length, overlapping or empty segments).  0 is always valid.  vgan_hc_flatten orders the batch
+     * accordingly (tileable reads first, sorted by node id; read_src tells which read of the input each one is). */
     uint32_t n_tileable;
     const uint32_t *read_src;     /* [n_reads] index of the read in the alignment set, or NULL (not used by the device) */
 } vgan_hc_batch;
@@ -179,7 +179,11 @@ typedef struct vgan_hc_batch {
  * kernel keeps one quality prefix per 64 bytes for 65536 of them.  vgan_hc_flatten* drops and counts reads beyond it
  * (n_bad); vgan_hc_batch_validate refuses hand-built batches beyond it.  A 16.5 kb consensus read fits four times.
  * Tile contract (reads below n_tileable): at most 1280 columns, 1280 quality bytes and 512 segments; |algnseq| equals the
- * length of the read's graph sequence; the column ranges [seg_start, seg_start+seg_len) of the read do not overlap. */
+ * length of the read's graph sequence; every segment has seg_len > 0 and the column ranges [seg_start, seg_start+seg_len)
+ * of the read do not overlap.
+ * Order: any.  vgan_hc_flatten* puts the tileable reads in ascending order of their lowest node id (stable), because
+ * the tiled kernel keeps W[node] of a workgroup's reads in an LDS window of 448 node ids and only reaches into HBM for
+ * segments outside it: a batch in another order gives the same sums, slower. */
 
 typedef struct vgan_hc_host_batch vgan_hc_host_batch; /* opaque owner of a host-side batch */
 

@@ -40,16 +40,18 @@ def test_toy_graph_segments_reads_final(golden_dir):
     ctx = hc.HcContext(g)
     S, U = ctx.segment_scalars(b)
     arr = b.arrays()
-    for r in range(a.n_reads):
+    src = b.read_src.tolist()  # the batch is ordered for the device (tileable reads by node id first), not as the input
+    assert sorted(src) == list(range(a.n_reads))
+    for k, r in enumerate(src):
         rc, So, Uo, node = orc.hc_read_segments(og, oa, r)
         assert rc == 0
-        s0, s1 = arr["read_seg_off"][r], arr["read_seg_off"][r + 1]
+        s0, s1 = arr["read_seg_off"][k], arr["read_seg_off"][k + 1]
         assert util.rel_err(S[s0:s1], So) < 1e-12 and util.rel_err(U[s0:s1], Uo) < 1e-12
     ll = ctx.read_loglik(b)
-    for r in range(a.n_reads):
+    for k, r in enumerate(src):
         rc, ref, _ = orc.hc_read(og, oa, r)  # the literal per-path loops
         assert rc == 0
-        assert util.rel_err(ll[r], ref.astype(np.float64)) < 1e-12, r
+        assert util.rel_err(ll[k], ref.astype(np.float64)) < 1e-12, r
     check_final(ctx, b, og, oa, faithful=True)
 
 
@@ -355,13 +357,14 @@ def test_cli_reads_the_reference_odgi_fixture(tmp_path):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
 def test_tiled_kernel_fuzz_against_general_kernel(seed):
     """Random batches that satisfy the tile contract, built by hand over the C-ABI (no flatten step): ragged reads of
-    1..1280 columns, quality strings shorter / longer than the read or empty, zero-length segments, segments that stop
-    before the read ends, bases outside ACGT, qualities >= 90 and negative.  D_m from the LDS-tiled kernel must equal
+    1..1280 columns, quality strings shorter / longer than the read or empty, segments that stop before the read ends,
+    node ids all over the graph (far outside any LDS window), zero-length segments in the reads behind n_tileable, bases outside ACGT, qualities >= 90 and negative.  D_m from the LDS-tiled kernel must equal
     S_m - U_m from the general kernel (which the other tests hold against the oracle)."""
     rng = np.random.default_rng(seed)
     g = hc.synth_graph(seed=50 + seed, genome_len=1200, n_nodes=700, n_paths=70)
     n_nodes = g.max_id
     R = 3000 + 17 * seed
+    R_tile = R - 250  # the last reads may hold empty segments and take the general kernel in both batches
     seg_off, col_off, qual_off = [0], [0], [0]
     algn_len, mapq, seg_node, seg_start, seg_len = [], [], [], [], []
     gseq, rseq, qual = [], [], []
@@ -390,8 +393,8 @@ def test_tiled_kernel_fuzz_against_general_kernel(seed):
         max_run = int(rng.choice([3, 8, 40, 200]))
         stop_early = rng.random() < 0.2
         while pos < cols and nseg < 512:
-            if rng.random() < 0.05:
-                ln = 0  # a mapping without columns
+            if r >= R_tile and rng.random() < 0.05:
+                ln = 0  # a mapping without columns: such a read is outside the tile contract
             else:
                 ln = int(min(cols - pos, rng.integers(1, max_run + 1)))
             seg_node.append(int(rng.integers(1, n_nodes + 1)))
@@ -416,7 +419,7 @@ def test_tiled_kernel_fuzz_against_general_kernel(seed):
               "read_mapq": mapq, "seg_node": seg_node, "seg_start": seg_start, "seg_len": seg_len,
               "graph_seq": np.concatenate(gseq), "algnseq": np.concatenate(rseq),
               "qual": np.concatenate(qual) if sum(map(len, qual)) else np.zeros(0, np.uint8)}
-    tiled = hc.ArrayBatch(arrays, n_tileable=R)
+    tiled = hc.ArrayBatch(arrays, n_tileable=R_tile)
     general = hc.ArrayBatch(arrays, n_tileable=0)
     for kw in (dict(), dict(background_error_prob=0.02, use_background_error_prob=True),
                dict(background_error_prob=0.01, use_background_error_prob=True, is_consensus_fasta=True)):
@@ -529,6 +532,7 @@ def test_batch_validation(tmp_path):
     broken(lambda x: x["seg_len"].__setitem__(0, 60000))                              # leaves the read
     broken(lambda x: x["read_mapq"].__setitem__(7, 120))
     broken(lambda x: x["seg_start"].__setitem__(1, 0) if x["seg_len"][0] else None, n_tileable=b.n_tileable)  # overlap / order
+    broken(lambda x: x["seg_len"].__setitem__(2, 0), n_tileable=b.n_tileable)         # an empty segment below n_tileable
     broken(lambda x: None, n_tileable=b.n_reads)                                      # the 1500-column reads are not tileable
     broken(lambda x: x["read_col_off"].__setitem__(len(x["read_col_off"]) - 1, 5))    # final offset vs n_cols
 

@@ -148,14 +148,17 @@ def _check_flatten_against_oracle(g, a, batch):
     oa = util.orc_alnset_from_product(a)
     arr = batch.arrays()
     ident = a.arrays()["identity"]
-    k = 0
+    where = {int(r): k for k, r in enumerate(arr["read_src"])}  # the batch is ordered for the device, not as the input
+    n_seen = 0
     for r in range(a.n_reads):
         if ident[r] < 1e-10:
             continue
         rc, gs, rs, sizes = orc.reconstruct(og, oa, r)
         rc2, S, U, node = orc.hc_read_segments(og, oa, r)
         if rc != 0 or rc2 != 0:
+            assert r not in where
             continue  # the reference would terminate: product skips the read
+        k = where[r]
         s0, s1 = arr["read_seg_off"][k], arr["read_seg_off"][k + 1]
         c0 = arr["read_col_off"][k]
         assert arr["read_algn_len"][k] == len(rs)
@@ -169,8 +172,13 @@ def _check_flatten_against_oracle(g, a, batch):
             assert arr["seg_start"][s0 + i] == pos
             assert arr["seg_len"][s0 + i] == min(sizes[i], len(gs) - pos)
             pos += min(sizes[i], len(rs) - pos)
-        k += 1
-    assert k == batch.n_reads
+        n_seen += 1
+    assert n_seen == batch.n_reads
+    # tileable reads come first, in ascending order of their lowest node id (include/vgan_gpu.h "Order")
+    nt = batch.n_tileable
+    low = [int(arr["seg_node"][arr["read_seg_off"][k]:arr["read_seg_off"][k + 1]].min()) for k in range(nt)
+           if arr["read_seg_off"][k + 1] > arr["read_seg_off"][k]]
+    assert low == sorted(low)
 
 
 def test_flatten_matches_oracle_on_fixtures(golden_dir):
@@ -259,8 +267,8 @@ def test_sidecar_loaders_match_oracle(tmp_path):
 
 
 def test_flatten_puts_tileable_reads_first(tmp_path):
-    """vgan_hc_flatten orders a batch as [reads satisfying the tile contract | the others] and reports the split point;
-    read_src maps batch order back to the alignment set."""
+    """vgan_hc_flatten orders a batch as [reads satisfying the tile contract, by lowest node id | the others] and reports
+    the split point; read_src maps batch order back to the alignment set."""
     from vgan_amd import haplocart as hc
     import util
     g = hc.synth_graph(seed=3, genome_len=2000, n_nodes=900, n_paths=64)
@@ -281,10 +289,13 @@ def test_flatten_puts_tileable_reads_first(tmp_path):
             cols = int(co[r + 1] - co[r])
             st = arr["seg_start"][so[r]:so[r + 1]].astype(np.int64)
             ln = arr["seg_len"][so[r]:so[r + 1]].astype(np.int64)
-            ok = (cols <= 1280 and qo[r + 1] - qo[r] <= 1280 and len(st) <= 512 and np.all(st[1:] >= st[:-1] + ln[:-1]))
+            ok = (cols <= 1280 and qo[r + 1] - qo[r] <= 1280 and len(st) <= 512 and np.all(st[1:] >= st[:-1] + ln[:-1])
+                  and np.all(ln > 0))
             assert ok == (r < nt), (r, nt, cols)
-        # within each part the input order is kept
-        assert np.all(np.diff(src[:nt].astype(np.int64)) > 0) and np.all(np.diff(src[nt:].astype(np.int64)) > 0)
+        # the tileable part ascends in the reads' lowest node id, input order kept among equals; the rest keeps the input order
+        low = np.array([arr["seg_node"][so[r]:so[r + 1]].min() for r in range(nt)], np.int64)
+        key = low * (1 << 32) + src[:nt].astype(np.int64)
+        assert np.all(np.diff(key) > 0) and np.all(np.diff(src[nt:].astype(np.int64)) > 0)
 
 
 def test_masked_flatten_equals_flatten_of_filtered_set():

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Developer aid: per-phase cycle split of hc_segment_tile_kernel.
 
-Needs a library built with VGAN_EXTRA_FLAGS=-DVGAN_PHASE_TIMING (python vgan_amd/build.py --force); rebuild without
-the flag afterwards.  Prints the share of wave-0 cycles spent in each phase / barrier wait.
+Needs a library built with the phase marks: VGAN_BUILD_TAG=_pt VGAN_EXTRA_FLAGS=-DVGAN_PHASE_TIMING python vgan_amd/build.py
+(lands beside the product's library), then VGAN_LIB=vgan_amd/lib/libvgan_gpu_pt.so python tools/phase_cycles.py.  Prints the share of wave-0 cycles spent in each phase / barrier wait.
 """
 import ctypes
 import sys
@@ -18,7 +18,7 @@ NAMES = ["top: windows -> LDS", "barrier 1", "B quality prefix", "barrier 2", "C
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-    lib = _native.load()
+    lib = _native.load()  # VGAN_LIB=vgan_amd/lib/libvgan_gpu_pt.so selects the VGAN_BUILD_TAG=_pt build for the whole process
     fn = lib.vgan_hc_debug_phase_cycles
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     g = hc.synth_graph(seed=1)

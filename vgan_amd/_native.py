@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VGAN_GPU_LIB") or os.path.join(HERE, "lib", "libvgan_gpu.so")  # override: developer A/B builds
+LIB_PATH = os.environ.get("VGAN_LIB") or os.environ.get("VGAN_GPU_LIB") or os.path.join(HERE, "lib", "libvgan_gpu.so")  # override: developer A/B builds  # VGAN_LIB: a developer build (vgan_amd/build.py VGAN_BUILD_TAG)
 
 
 class NativeError(RuntimeError):

@@ -9,9 +9,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+TAG = os.environ.get("VGAN_BUILD_TAG", "")  # developer builds beside the product's: lib/libvgan_gpu<TAG>.so, build<TAG>/
 LIBDIR = os.path.join(HERE, "lib")
-OBJDIR = os.path.join(HERE, "build")
-LIB = os.path.join(LIBDIR, "libvgan_gpu.so")
+OBJDIR = os.path.join(HERE, "build" + TAG)
+LIB = os.path.join(LIBDIR, "libvgan_gpu%s.so" % TAG)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -72,7 +73,7 @@ def build(verbose=False, force=False):
     # the vgan CLI (C++ host driver keeping the reference's subcommand surface)
     main_src = os.path.join(CSRC, "host", "vgan_main.cpp")
     main_srcs = sorted(os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host")) if f.endswith("_main.cpp"))
-    if os.path.exists(main_src):
+    if os.path.exists(main_src) and not TAG:
         bindir = os.path.join(HERE, "bin")
         os.makedirs(bindir, exist_ok=True)
         exe = os.path.join(bindir, "vgan")

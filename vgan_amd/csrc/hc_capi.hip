@@ -316,12 +316,19 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         }
     }
     std::vector<HcNodeDev> nt(c->rows);
+    const bool consensus = params->is_consensus_fasta != 0;
     for (uint32_t r = 0; r < c->rows; ++r) {
         const int32_t pb = gv->pangenome_base[r];
-        if (pb >= 0 && (uint64_t)pb < gv->n_mappability) nt[r] = {gv->mappability[pb], match_prob(pb)};
-        else nt[r] = {0.0, 1.0};
+        double mp = 0.0, mt = 1.0;
+        if (pb >= 0 && (uint64_t)pb < gv->n_mappability) {
+            mp = gv->mappability[pb];
+            mt = match_prob(pb);
+        }
+        // log(0) = -inf and 1/0 = inf are meant: the kernel scores such a segment from wbg alone (hc_kernels.hip)
+        const long double mm = (long double)mp * (long double)mt;
+        nt[r] = {(double)logl(consensus ? (long double)mt : mm), (double)(1.0L / mm), mp, mt};
     }
-    std::vector<double> tb(456);
+    std::vector<double> tb(756);
     for (int bte = 0; bte < 256; ++bte) { // src/miscfunc.h:180-188 on int(char)
         const int Q = (int)(int8_t)bte;
         tb[bte] = log(Q > 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25);
@@ -329,10 +336,14 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     for (int Q = 0; Q < 100; ++Q) { // src/miscfunc.h:199-212, src/haplocart_functions.cpp:101-107
         tb[256 + Q] = Q > 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25;
         tb[356 + Q] = pow(10, ((-1 * Q) * 0.1));
+        const double om = 1.0 - tb[356 + Q]; // process_mapping.cpp:41: pcm = (1 - incorrect_mapping_vec[mapq]) * mappability
+        tb[456 + 3 * Q] = om;
+        tb[456 + 3 * Q + 1] = consensus ? (double)logl(1.0L - (long double)params->background_error_prob) : (double)logl((long double)om);
+        tb[456 + 3 * Q + 2] = (double)(1.0L / (long double)om);
     }
     const size_t accn = (size_t)c->W * 64;
     if ((rc = c->umask.reserve(um.size())) || (rc = c->umaskT.reserve(umT.size())) ||
-        (rc = c->tile_word0.reserve(tw0.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(456)) ||
+        (rc = c->tile_word0.reserve(tw0.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(756)) ||
         (rc = c->accum.reserve(((size_t)c->rows + 7) / 8 * 8 + 2 * accn + 8)) || (rc = c->final_vec.reserve(c->P)))
         return bail(rc);
     { // sub-ranges of the accumulator block (sweep kernels read 64-byte aligned blocks of weights: keep 64-byte offsets)
@@ -356,6 +367,7 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     c->g.lq = c->tables.p;
     c->g.qscore = c->tables.p + 256;
     c->g.incmap = c->tables.p + 356;
+    c->g.rdtab = c->tables.p + 456;
     c->g.rows = c->rows;
     c->g.mask_words = c->W;
     c->g.row_entries = row_entries;
@@ -463,7 +475,8 @@ extern "C" int vgan_hc_batch_validate(const vgan_hc_ctx *c, const vgan_hc_batch 
             if (b->seg_node[s] >= c->rows) return fail(VGAN_EINVAL, "batch: segment %u names node %u, beyond the graph", s, b->seg_node[s]);
             if ((uint64_t)st + ln > cols) return fail(VGAN_EINVAL, "batch: segment %u leaves the columns of read %llu", s, (unsigned long long)r);
             if (st < prev_start) return fail(VGAN_EINVAL, "batch: segments of read %llu do not ascend in seg_start", (unsigned long long)r);
-            if (tile && ln && st < prev_end) return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but its segments overlap", (unsigned long long)r);
+            if (tile && ln == 0) return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but has an empty segment", (unsigned long long)r);
+            if (tile && st < prev_end) return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but its segments overlap", (unsigned long long)r);
             prev_start = st;
             if (ln) prev_end = st + ln;
         }
@@ -479,16 +492,17 @@ extern "C" int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *b) {
     HIPCHK(hipSetDevice(c->device));
     HcBatchDev d{};
     if ((rc = stage_batch(c, b, d))) return rc;
-    if ((rc = c->segD.reserve(b->n_segments))) return rc;
-    {
-        ScopedTimer t(c, VGAN_HC_K_SEGMENT);
-        launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, c->segD.p, c->totals.p, c->stream);
-    }
     if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) {
-        ScopedTimer t(c, VGAN_HC_K_NODEACC);
-        if (launch_hc_nodeacc(d.seg_node, c->segD.p, d.n_segments, c->rows, c->nodeW.p, c->stream))
-            return fail(VGAN_ENODEV, "hipFuncSetAttribute(dynamic LDS) failed");
+        // W[node] += D_m inside the segment kernels (LDS window over the node ids of a workgroup's reads): no per-segment
+        // array leaves the chip
+        ScopedTimer t(c, VGAN_HC_K_SEGMENT);
+        launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, nullptr, c->nodeW.p, c->totals.p, c->stream);
     } else {
+        if ((rc = c->segD.reserve(b->n_segments))) return rc;
+        {
+            ScopedTimer t(c, VGAN_HC_K_SEGMENT);
+            launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, c->segD.p, nullptr, c->totals.p, c->stream);
+        }
         ScopedTimer t(c, VGAN_HC_K_SWEEP_SEG);
         launch_hc_sweep(c->g, d.seg_node, c->segD.p, d.n_segments, c->mode == VGAN_HC_MODE_PER_READ, c->acc_seg.p, c->stream);
     }
@@ -505,7 +519,7 @@ extern "C" int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *b, d
     HcBatchDev d{};
     if ((rc = stage_batch(c, b, d))) return rc;
     if ((rc = c->segS.reserve(b->n_segments)) || (rc = c->segU.reserve(b->n_segments))) return rc;
-    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), c->segS.p, c->segU.p, nullptr, nullptr, nullptr, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(S, c->segS.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(U, c->segU.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
@@ -522,7 +536,7 @@ extern "C" int vgan_hc_segment_weights(vgan_hc_ctx *c, const vgan_hc_batch *b, d
     HcBatchDev d{};
     if ((rc = stage_batch(c, b, d))) return rc;
     if ((rc = c->segD.reserve(b->n_segments))) return rc;
-    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, c->segD.p, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, c->segD.p, nullptr, nullptr, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(D, c->segD.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -541,7 +555,7 @@ extern "C" int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *b, doubl
     const size_t n = (size_t)b->n_reads * c->P;
     if ((rc = c->segS.reserve(b->n_segments + 1)) || (rc = c->segU.reserve(b->n_segments + 1)) || (rc = c->dump.reserve(n)))
         return rc;
-    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), c->segS.p, c->segU.p, nullptr, nullptr, c->stream);
+    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), c->segS.p, c->segU.p, nullptr, nullptr, nullptr, c->stream);
     launch_hc_read_loglik(c->g, d, c->segS.p, c->segU.p, c->dump.p, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, c->dump.p, n * 8, hipMemcpyDeviceToHost, c->stream));

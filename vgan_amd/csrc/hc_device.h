@@ -5,7 +5,11 @@
 
 namespace vgan {
 
-struct HcNodeDev {
+struct alignas(32) HcNodeDev {
+    // the tiled kernel's factorised column term (hc_kernels.hip): log and reciprocal of the node's share of
+    // wobs = pcm * match, taken once on the host in long double.  First, so that one 16-byte load fetches both.
+    double ln_w;        // log(mappability * match); log(match) in a consensus-FASTA context
+    double inv_mm;      // 1 / (mappability * match)
     double mappability; // mappabilities[pangenome_base[node]]         (src/process_mapping.cpp:33-35)
     double match;       // pow(1 - 30*mu(pangenome_base[node]), 8)     (src/get_p_obs_base.cpp:44-64)
 };
@@ -19,9 +23,11 @@ struct HcNodeDev {
 //             15 downwards, bit l of each of the tile's words.  One wave-wide 2-byte load (128 B, coalesced) gives
 //             every lane the membership bits of "its" path in all words of the tile.  With tile = blockIdx % 8 each
 //             XCD's L2 sees one eighth of the table (1.5 MB for the hcfiles shape).
-//   node_tab  {mappability, match} per node id: the two per-node scalars the likelihood needs.
+//   node_tab  {ln_w, inv_mm, mappability, match} per node id: the per-node scalars the likelihood needs.
 //   lq        log(p_seq_error((int8)byte)) for every raw quality byte (src/miscfunc.h:180-188, process_mapping.cpp:12)
 //   qscore    qscore_vec[100] (src/miscfunc.h:199-212);  incmap: incorrect_mapping_vec[100]
+//   rdtab     per mapping quality {1 - incmap, log(1 - incmap), 1 / (1 - incmap)}: the read's share of pcm = (1 - p_inc) *
+//             mappability (process_mapping.cpp:41); in a consensus-FASTA context the log is log(1 - background_error_prob)
 struct HcGraphDev {
     const uint64_t *umask;
     const uint16_t *umaskT;
@@ -30,6 +36,7 @@ struct HcGraphDev {
     const double *lq;
     const double *qscore;
     const double *incmap;
+    const double *rdtab; // [100][3]
     uint32_t rows;
     uint32_t mask_words;
     uint32_t row_entries; // n_tiles * 64
@@ -60,12 +67,12 @@ constexpr uint32_t HC_TILE_MAX_READ_COLS = 1280;
 constexpr uint32_t HC_TILE_MAX_READ_QUAL = 1280;
 constexpr uint32_t HC_TILE_MAX_READ_SEGS = 512;
 
-// reads [0, n_tileable) go through the LDS-tiled kernel (D_m only), the rest -- or everything when S_m / U_m are asked
-// for separately -- through the general one
+// reads [0, n_tileable) go through the LDS-tiled kernel, the rest -- or everything when S_m / U_m are asked for
+// separately -- through the general one.  segD (or NULL): D_m = S_m - U_m per segment.  nodeW (or NULL): W[node] += D_m,
+// through a workgroup's LDS window over the node ids of its reads in the tiled kernel.
 void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable,
-                        uint32_t mean_cols_per_read, double *segS, double *segU, double *segD, double *totals, hipStream_t st);
-int launch_hc_nodeacc(const uint32_t *seg_node, const double *segD, uint32_t n_items, uint32_t rows, double *nodeW,
-                      hipStream_t st);
+                        uint32_t mean_cols_per_read, double *segS, double *segU, double *segD, double *nodeW, double *totals,
+                        hipStream_t st);
 void launch_hc_sweep(const HcGraphDev &g, const uint32_t *item_node, const double *D, uint32_t n_items, int skip_zero,
                      double *acc, hipStream_t st);
 void launch_hc_finish(const double *totals, const double *acc_seg, const double *acc_node, uint32_t n_paths, double *out,

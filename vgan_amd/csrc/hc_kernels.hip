@@ -8,12 +8,12 @@
 // do not depend on p.  final[p] = sum_r ll_r[p]                                   (src/HaploCart.cpp:420).
 //
 // Kernels:
-//   hc_segment_tile_kernel   D_m = S_m - U_m per segment.  A 256-thread workgroup takes a tile of up to 8 (24 for short)
+//   hc_segment_tile_kernel   D_m = S_m - U_m per segment and, in NODE_WEIGHTS mode, W[node] += D_m through an LDS
+//                       window over the node ids of the workgroup's reads (the batch is sorted by node id), flushed to
+//                       HBM a few times per launch.  A 256-thread workgroup takes a tile of up to 8 (24 for short)
 //                       reads staged in LDS and works flat over it (phases B..E at the kernel); a tile's data leaves HBM
 //                       one tile ahead.  hc_segment_general_kernel is the same arithmetic for reads that do not fit a
 //                       tile (one wave per read, any length).
-//   hc_nodeacc_kernel   NODE_WEIGHTS mode: W[node] += D_m with a workgroup-private W in LDS (ds_add_f64),
-//                       flushed once per workgroup with coalesced global atomics.
 //   hc_sweep_kernel     the per-path update acc[p] += D for every path NOT supported by the node
 //                       (final[p] = sum_m S_m - acc[p]: no cancellation).  Mask rows are stored bit-transposed
 //                       (hc_device.h): lane l loads ONE 16-bit entry holding its path's bit for each of the tile's
@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_math.h"
 #include "hc_device.h"
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
                                                                              double *__restrict__ segS,
                                                                              double *__restrict__ segU,
                                                                              double *__restrict__ segD,
+                                                                             double *__restrict__ nodeW,
                                                                              double *__restrict__ totals) {
     __shared__ double lq_s[256];
     __shared__ double qs_s[100];
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
                 if (segS) segS[s] = S;
                 if (segU) segU[s] = U;
                 if (segD) segD[s] = S - U;
+                if (nodeW) unsafeAtomicAdd(&nodeW[node], S - U); // the few reads outside the tile contract: W in HBM directly
                 sumS += S;
                 sumU += U;
             }
@@ -147,10 +150,21 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
 //        previous tile's phase D, like the segment records and, a tile earlier still, the read offsets)
 //   B  lane per 5 quality bytes: log p_err prefix sums (thread-local + one DPP wave scan; wave totals folded in by the
 //      consumers), so that U_m is a difference of two prefix values
-//   C  lane per segment: U_m, the segment record {pcm, match, columns, read geometry}; a head bit per first column
-//   D  lane per alignment column: owner segment = nearest head bit at or below the column (the segments of a regular
-//      read tile its columns in order), one table-driven log, LDS fp64 atomic into the segment's sum
-//   E  lane per segment: D_m = S_m - U_m streamed out
+//   C  lane per segment: U_m, the segment record {kappa, lw, column bounds, index shifts}; a head bit at its first column
+//   D  lane per alignment column: owner segment = number of head bits at or below the column - 1 (the segments of a
+//      tile cover ascending column ranges), the column's log term from two table reads and a short log1p series,
+//      LDS fp64 atomic into the segment's sum
+//   E  lane per segment: D_m = S_m - U_m added to W[node] through the workgroup's LDS window over node ids (and / or
+//      streamed out)
+//
+// The column term (process_mapping.cpp:59-77, get_p_obs_base.cpp:67 with tv = ts = 0) is
+//     log(x),  x = wbg * bg(read base) + wobs * om,   om = (graph base == read base) ? 1 - e(Q) : e(Q)
+// with wbg = 1 - pcm, wobs = pcm * match, pcm = (1 - p_inc(mapq)) * mappability(node).  Factorised:
+//     log(x) = log(wobs) + log(om) + log1p(rho),   rho = (wbg / wobs) * bg / om
+// log(wobs) = lw is a sum of a per-read and a per-node table value (both taken on the host), log(om) and 1/om come from a
+// 101 x 2 table built per workgroup, and rho is ~1e-7 for a confidently mapped read, so log1p is a degree-8 series; a
+// column with rho >= 2^-6 (low mapping quality, mismatch at a very high base quality) or a segment with wobs = 0
+// (mapq 0) takes the table-driven log of x itself.  No log, no division per column or segment.
 constexpr int ST_THREADS = 256;
 constexpr int ST_WAVES = ST_THREADS / 64;
 constexpr int ST_READS_LONG = 8;   // reads per tile (at most) for batches of long reads (compare-sum read lookup),
@@ -159,9 +173,11 @@ constexpr int ST_READS_LOG2 = 5; // steps of the segment -> read search (2^5 >= 
 constexpr int ST_COLS = 1280; // LDS capacity per tile: alignment columns,
 constexpr int ST_QUAL = 1280; //                        quality bytes,
 constexpr int ST_SEGS = 512;  //                        segments
+constexpr int ST_WIN = 448;   // node ids covered by the workgroup's W window (what 40 KB of LDS per workgroup leave)
 constexpr int ST_QB = ST_QUAL / ST_THREADS;         // quality bytes per lane in phase B
 constexpr int ST_QW = ST_QB * 64;                   // quality bytes per wave in phase B
 constexpr int ST_SEG_ITERS = ST_SEGS / ST_THREADS;  // segments per lane in phases C and E
+constexpr int ST_FWORDS = ST_COLS / 32;             // head-bit words
 static_assert((ST_SEGS & (ST_SEGS - 1)) == 0, "segment index mask");
 static_assert((1 << ST_READS_LOG2) >= ST_READS_SHORT && ST_READS_SHORT < 64, "read search / header lanes");
 static_assert(HC_TILE_MAX_READ_COLS <= (uint32_t)ST_COLS && HC_TILE_MAX_READ_QUAL <= (uint32_t)ST_QUAL &&
@@ -169,27 +185,32 @@ static_assert(HC_TILE_MAX_READ_COLS <= (uint32_t)ST_COLS && HC_TILE_MAX_READ_QUA
               "a tileable read fits one tile");
 static_assert(ST_QB * ST_THREADS == ST_QUAL && ST_SEG_ITERS * ST_THREADS == ST_SEGS && ST_WAVES == 4,
               "tile shape");
-static_assert(ST_COLS <= 2 * 4 * ST_THREADS - 8 && ST_QUAL <= 2 * 4 * ST_THREADS - 8, "byte windows: two dwords per thread");
+static_assert(ST_COLS + 16 <= 8 * ST_THREADS && ST_QUAL == ST_COLS, "byte windows: one 8-byte word per thread");
+static_assert(ST_FWORDS <= 64, "head words fit one wave");
 
-// x = wbg * bg(read base) + wobs * (1 - eps) per column, with pcm = (1 - incorrect_mapping_vec[mapq]) * mappability[node]
-// (process_mapping.cpp:41) and match = pow(1 - mu(node), 8) (get_p_obs_base.cpp:64):
-struct alignas(16) StSegPm {
-    double wbg;  // 1 - pcm             (0 for a consensus FASTA, process_mapping.cpp:66-70)
-    double wobs; // pcm * match         ((1 - bep) * match for a consensus FASTA)
+// per segment: {kappa = wbg / wobs, lw = log(wobs)}; a segment with wobs = 0: {+inf, wbg}
+struct alignas(16) StSegKL {
+    double kappa, lw;
 };
-// Per-segment column bounds and index shifts, tile-local, so that a column c of the segment needs one compare or add
-// for each: it is scored when c < cend; its read base is rseq_s[c + rshift] while c < aend (Q4: the read bases are
-// taken from the read start, so rshift = read column 0 - segment column 0); its quality is qual_s[c + qshift] while
-// c < qend (Q5: zero beyond the read's quality string).
-struct StSegGeo {
+// Per-segment column bound and index shifts, tile-local, so that a column c of the segment needs one compare or add
+// for each: it is scored when c < cend; its read base is rseq_s[c + rshift] (Q4: the read bases are taken from the
+// read start, so rshift = read column 0 - segment column 0; a tileable read has |algnseq| = its column count, so the
+// index stays inside the read); its quality is qual_s[c + qshift] while c < qend (Q5: zero beyond the read's quality
+// string).
+struct alignas(8) StSegGeo {
     uint16_t cend_bep; // first column past the segment | use_bep << 15
     int16_t rshift;
-    uint16_t aend;
     int16_t qshift;
     uint16_t qend;
-    uint16_t pad;
 };
-static_assert(sizeof(StSegGeo) == 12, "StSegGeo is three dwords");
+struct alignas(16) StLom { // per (error-rate index, base match): log(om), 1 / om
+    double lom, iom;
+};
+struct alignas(32) StRead { // per read of the tile
+    double omp, lp, ip; // 1 - p_inc, its log (log(1 - bep) for a consensus FASTA), its reciprocal
+    uint32_t A, pad;
+};
+constexpr double ST_RHO_MAX = 0.015625; // 2^-6: the series' next term rho^9 / 9 is below 2^-57 relative to log1p's first
 
 __device__ const LogTabEntry hc_log_table[64] = {VGAN_LOG_TABLE};
 
@@ -206,73 +227,85 @@ __device__ unsigned long long hc_phase_cycles[12];
 #endif
 
 struct StTile { // extents of one tile (wave uniform)
-    uint32_t n, seg_base, n_seg, col_base, n_col, q_base, n_q;
+    uint32_t n, seg_base, n_seg, col_base, n_col, q_base, n_q, short_qual;
 };
 
-// a byte window [g0, g0+n) of src as aligned dwords: dword i of the window goes to dword i of the LDS array, so that
-// lds[i + (g0 & 3)] = src[g0 + i].  Every thread moves at most two dwords.
+// a byte window [g0, g0+n) of src as aligned 8-byte words: word i of the window goes to word i of the LDS array, so that
+// lds[i + (g0 & 7)] = src[g0 + i].  One load per thread (162 of the 256 threads for a full tile).
 struct StWindow {
-    uint32_t v0, v1;
+    uint2 v;
 };
 __device__ __forceinline__ StWindow window_request(const uint8_t *__restrict__ src, uint32_t g0, uint32_t n, int tid) {
-    const uint32_t a0 = g0 & ~3u;
-    const uint32_t nd = (g0 + n - a0 + 3u) >> 2;
-    const uint32_t *__restrict__ s32 = reinterpret_cast<const uint32_t *>(src + a0);
+    const uint32_t a0 = g0 & ~7u;
+    const uint32_t nd = (g0 + n - a0 + 7u) >> 3;
+    const uint2 *__restrict__ s64 = reinterpret_cast<const uint2 *>(src + a0);
     StWindow w;
-    w.v0 = (uint32_t)tid < nd ? s32[tid] : 0u;
-    w.v1 = (uint32_t)tid + ST_THREADS < nd ? s32[tid + ST_THREADS] : 0u;
+    w.v = (uint32_t)tid < nd ? s64[tid] : uint2{0u, 0u};
     return w;
 }
 __device__ __forceinline__ void window_store(uint8_t *dst, const StWindow &w, int tid) {
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
-    d32[tid] = w.v0; // dwords past the window carry zeros
-    if (tid + ST_THREADS < (ST_COLS + 8) / 4) d32[tid + ST_THREADS] = w.v1;
+    if (tid < (ST_COLS + 16) / 8) reinterpret_cast<uint2 *>(dst)[tid] = w.v; // words past the window carry zeros
 }
 
 struct StLoads { // one tile's HBM data in flight
     StWindow gseq, rseq, qual;
     uint32_t start[ST_SEG_ITERS], len[ST_SEG_ITERS], node[ST_SEG_ITERS];
-    HcNodeDev nd[ST_SEG_ITERS];
+    double mapp[ST_SEG_ITERS], ln_w[ST_SEG_ITERS], inv_mm[ST_SEG_ITERS]; // of the node (HcNodeDev)
 };
 
+// wave64 inclusive prefix sum of a 32-bit count (DPP, no LDS traffic)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
 template <int ST_READS>
 __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
                                                                       uint32_t n_tileable, uint32_t reads_per_block,
                                                                       double *__restrict__ segD_out,
+                                                                      double *__restrict__ nodeW,
                                                                       double *__restrict__ totals) {
     __shared__ double lq_s[256];
-    __shared__ double qs_s[101];      // qscore_vec, and the background error rate in slot 100
-    __shared__ double bg_s[4];
-    __shared__ double incmap_s[ST_READS <= 8 ? 100 : 1]; // the long-read variant has the LDS to keep incorrect_mapping_vec
-    __shared__ uint8_t code_s[256];   // A C T G -> 0 1 2 3 (bg_s order), anything else 4 (libgab isValidDNA is false)
-    __shared__ LogTabEntry logtab_s[64];
+    __shared__ StLom lom_s[101][2];   // [qscore index, 100 = background error rate][mismatch, match]
+    __shared__ double bg_s[5];
+    __shared__ uint8_t code_s[256];   // A C T G -> 0 8 16 24 (byte offsets into bg_s), anything else 32 (libgab isValidDNA is false)
     __shared__ double ps_s[ST_QUAL + 1]; // wave-local prefix sums of log p_err over the tile's quality bytes
     __shared__ double wsum_s[ST_WAVES];  // each wave's total
     __shared__ double segS_s[ST_SEGS];
-    __shared__ StSegPm segpm_s[ST_SEGS];
+    __shared__ StSegKL segkl_s[ST_SEGS];
     __shared__ StSegGeo seggeo_s[ST_SEGS];
-    __shared__ uint32_t flags_s[ST_COLS / 32]; // bit c: a segment starts at tile column c
-    __shared__ uint16_t colhead_s[ST_COLS];    // ... and which one (valid where the bit is set)
-    __shared__ __attribute__((aligned(16))) uint8_t gseq_s[ST_COLS + 8];
-    __shared__ __attribute__((aligned(16))) uint8_t rseq_s[ST_COLS + 8];
-    __shared__ __attribute__((aligned(16))) uint8_t qual_s[ST_QUAL + 8];
+    __shared__ uint32_t flags_s[ST_FWORDS]; // bit c: a segment starts at tile column c
+    __shared__ __attribute__((aligned(16))) uint8_t gseq_s[ST_COLS + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t rseq_s[ST_COLS + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t qual_s[ST_QUAL + 16];
     // per-read header, double buffered: the next tile's is written while this tile's is in use
     __shared__ uint32_t off_s[2][3][ST_READS + 1];
-    __shared__ uint32_t rdA_s[2][ST_READS];
-    __shared__ double rdpinc_s[2][ST_READS];
+    __shared__ StRead rd_s[2][ST_READS];
     __shared__ uint32_t first90_s[ST_READS];
     __shared__ StTile tile_s[2];
+    __shared__ uint32_t tilebits_s[4]; // [0] bit 0: a segment takes the background error rate on its own; [1] lowest node id
+                                       // (when the window is to be placed); [3] the tile left the window
+    __shared__ double win_s[ST_WIN];   // W[winbase .. winbase + ST_WIN) of this workgroup's reads
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 256; i += ST_THREADS) lq_s[i] = g.lq[i];
-    for (int i = tid; i < 101; i += ST_THREADS) qs_s[i] = i < 100 ? g.qscore[i] : prm.bep;
-    if constexpr (ST_READS <= 8)
-        for (int i = tid; i < 100; i += ST_THREADS) incmap_s[i] = g.incmap[i];
-    for (int i = tid; i < 256; i += ST_THREADS) code_s[i] = is_acgt((uint32_t)i) ? (uint8_t)((i >> 1) & 3) : (uint8_t)4;
-    for (int i = tid; i < 64; i += ST_THREADS) logtab_s[i] = hc_log_table[i];
-    if (tid < 4) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : 0.16644; // A C T G by (c>>1)&3
+    for (int i = tid; i < 202; i += ST_THREADS) {
+        const int qi = i >> 1;
+        const double e = (qi == 100 || prm.use_bep) ? prm.bep : g.qscore[qi];
+        const double om = (i & 1) ? 1.0 - e : e;
+        lom_s[qi][i & 1] = StLom{log_pos(om), 1.0 / om};
+    }
+    for (int i = tid; i < 256; i += ST_THREADS) code_s[i] = is_acgt((uint32_t)i) ? (uint8_t)(((i >> 1) & 3) << 3) : (uint8_t)32;
+    for (int i = tid; i < ST_WIN; i += ST_THREADS) win_s[i] = 0.0;
+    if (tid < 5) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : tid == 3 ? 0.16644 : 0.25; // A C T G by (c>>1)&3
     const double lq0 = g.lq[0];
     double sumT = 0.0, sumU = 0.0; // sum of the column terms (= sum of S_m) and of U_m, each without cancellation
+    uint32_t winbase = 0xFFFFFFFFu; // no window yet (workgroup uniform)
+    bool need_min = true;           // the next tile places the window (workgroup uniform)
 
     const uint32_t rb0 = blockIdx.x * reads_per_block;
     const uint32_t rb1 = min(n_tileable, rb0 + reads_per_block);
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
 
     // header values travel in registers of threads 0..ST_READS until they are published in LDS
     uint32_t h_seg = 0, h_col = 0, h_q = 0, h_A = 0, h_mapq = 0;
-    double h_pinc = 0.0;
+    double h_omp = 0.0, h_lp = 0.0, h_ip = 0.0;
     auto header_request = [&](uint32_t first) {
         if (tid <= ST_READS) {
             const uint32_t r = min(first + tid, rb1);
@@ -292,10 +325,14 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             h_mapq = b.read_mapq[rr];
         }
     };
-    // incorrect_mapping_vec[mapq]: a dependent load, issued a phase after the request so that nothing waits on it
+    // the read's share of pcm by mapping quality: dependent loads, issued a phase after the request so that nothing waits
     auto header_resolve = [&]() {
-        if constexpr (ST_READS > 8)
-            if (tid <= ST_READS) h_pinc = g.incmap[min(h_mapq, 99u)];
+        if (tid <= ST_READS) {
+            const double *t = g.rdtab + 3u * min(h_mapq, 99u);
+            h_omp = t[0];
+            h_lp = t[1];
+            h_ip = t[2];
+        }
     };
     // Wave 0 publishes the header and the tile's extents: reads [first, first+n) with n the largest count whose
     // segments, columns and quality bytes fit the LDS tile (one read always fits: the host selects this kernel only
@@ -309,19 +346,21 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             const bool fits = tid >= 1 && tid <= ST_READS && first + tid <= rb1 && h_seg - sb <= (uint32_t)ST_SEGS &&
                               h_col - cb <= (uint32_t)ST_COLS && h_q - qb <= (uint32_t)ST_QUAL;
             const uint32_t n = max(1u, (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fits)));
+            // a read whose quality string is shorter than its |algnseq| columns needs the column phase's bound check (Q5)
+            const uint32_t ql_next = (uint32_t)__shfl_down((int)h_q, 1, 64) - h_q;
+            const bool shortq = (uint32_t)tid < n && ql_next < h_A;
+            const uint32_t any_short = __builtin_amdgcn_ballot_w64(shortq) != 0 ? 1u : 0u;
             if (tid <= ST_READS) {
                 off_s[buf][0][tid] = h_seg;
                 off_s[buf][1][tid] = h_col;
                 off_s[buf][2][tid] = h_q;
-                if (tid < ST_READS) {
-                    rdA_s[buf][tid] = h_A;
-                    rdpinc_s[buf][tid] = ST_READS <= 8 ? incmap_s[min(h_mapq, 99u)] : h_pinc;
-                }
+                if (tid < ST_READS) rd_s[buf][tid] = StRead{h_omp, h_lp, h_ip, h_A, 0u};
             }
             // clamped: a read that breaks the tile contract (a caller's error) must not index past the LDS arrays
             if ((uint32_t)tid == n)
                 tile_s[buf] = StTile{n, sb, (uint32_t)min(h_seg - sb, (uint32_t)ST_SEGS), cb,
-                                     (uint32_t)min(h_col - cb, (uint32_t)ST_COLS), qb, (uint32_t)min(h_q - qb, (uint32_t)ST_QUAL)};
+                                     (uint32_t)min(h_col - cb, (uint32_t)ST_COLS), qb, (uint32_t)min(h_q - qb, (uint32_t)ST_QUAL),
+                                     any_short};
         }
     };
     auto tile_extents = [&](uint32_t buf) { return tile_s[buf]; };
@@ -343,7 +382,21 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
 #pragma unroll
         for (int it = 0; it < ST_SEG_ITERS; ++it) {
             const uint32_t ls = tid + it * ST_THREADS;
-            L.nd[it] = ls < t.n_seg ? g.node_tab[L.node[it]] : HcNodeDev{0.0, 0.0};
+            const HcNodeDev *nd = g.node_tab + (ls < t.n_seg ? L.node[it] : 0u);
+            const double2 lw_inv = *reinterpret_cast<const double2 *>(&nd->ln_w); // one 16-byte load
+            L.ln_w[it] = lw_inv.x;
+            L.inv_mm[it] = lw_inv.y;
+            L.mapp[it] = nd->mappability;
+        }
+    };
+    // the window's content goes to W in HBM (the slots stay zero otherwise: no atomic for them)
+    auto window_flush = [&]() {
+        for (uint32_t j = tid; j < (uint32_t)ST_WIN; j += ST_THREADS) {
+            const double v = win_s[j];
+            if (v != 0.0) {
+                unsafeAtomicAdd(&nodeW[winbase + j], v);
+                win_s[j] = 0.0;
+            }
         }
     };
 
@@ -366,16 +419,22 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         header_request(r0 + T.n);
         header_resolve();
     }
-
     while (true) {
+        // per-thread addresses are cheap to rebuild and expensive to keep: nothing derived from the thread id is to be
+        // hoisted out of the tile loop (the register allocator would spill it)
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t lanemask = 0xFFFFFFFFu >> (31u - ((uint32_t)tid & 31u)); // head bits at or below this lane's column
         const bool has_next = r0 + T.n < rb1; // wave (and workgroup) uniform
-        const uint32_t cshift = T.col_base & 3u, qshift = T.q_base & 3u;
+        const uint32_t cshift = T.col_base & 7u, qshift = T.q_base & 7u;
         // ---- top: byte windows into LDS, per-tile state reset
         window_store(gseq_s, L.gseq, tid);
         window_store(rseq_s, L.rseq, tid);
         window_store(qual_s, L.qual, tid);
-        if (tid < ST_COLS / 32) flags_s[tid] = 0u;
+        if (tid < ST_FWORDS) flags_s[tid] = 0u;
         if (tid < ST_READS) first90_s[tid] = 0xFFFFFFFFu;
+        if (tid < 3) tilebits_s[tid] = tid == 1 ? 0xFFFFFFFFu : 0u;
         PT_MARK(0);
         __syncthreads();
         PT_MARK(1);
@@ -414,6 +473,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             for (int e = 0; e < ST_QB; ++e) ps_s[i0 + e + 1] = before + loc[e];
             if (lane == 63) wsum_s[wave] = incl;
             if (tid == 0) ps_s[0] = 0.0;
+            need_min = need_min || tilebits_s[3] != 0u;
         }
         if (has_next) header_publish(cur ^ 1u, r0 + T.n); // requested a tile ago
         PT_MARK(2);
@@ -426,17 +486,21 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             uint32_t seg_off_r[ST_READS <= 8 ? ST_READS : 1]; // segment offsets of reads 1.. (wave uniform) for the compare-sum
             if constexpr (ST_READS <= 8) {
 #pragma unroll
-                for (int t = 1; t < ST_READS; ++t) seg_off_r[t] = (uint32_t)t < T.n ? off_s[cur][0][t] : 0xFFFFFFFFu;
+                for (int t = 1; t < ST_READS; ++t)
+                    seg_off_r[t] = (uint32_t)t < T.n ? (uint32_t)__builtin_amdgcn_readfirstlane((int)off_s[cur][0][t]) : 0xFFFFFFFFu;
             }
             const double ws0 = wsum_s[0], ws1 = wsum_s[1], ws2 = wsum_s[2];
+            uint32_t nmin = 0xFFFFFFFFu;
+            bool own_bep = false;
+            if (tid == 0) tilebits_s[3] = 0u;
 #pragma unroll
             for (int it = 0; it < ST_SEG_ITERS; ++it) {
                 const uint32_t ls = tid + it * ST_THREADS;
                 segU[it] = 0.0;
                 if (ls < T.n_seg) {
                     const uint32_t s = T.seg_base + ls;
-                    // read of the segment: the last k < n with off[k] <= s
                     uint32_t k = 0;
+                    // read of the segment: the last k < n with off[k] <= s
                     if constexpr (ST_READS <= 8) { // compare-sum over the (wave uniform) offsets
 #pragma unroll
                         for (int t = 1; t < ST_READS; ++t) k += s >= seg_off_r[t] ? 1u : 0u;
@@ -452,12 +516,11 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                     }
                     const uint32_t colbase = off_s[cur][1][k] - T.col_base;
                     const uint32_t qo = off_s[cur][2][k], QL = off_s[cur][2][k + 1] - qo, qoff = qo - T.q_base;
-                    const uint32_t A = rdA_s[cur][k];
-                    const double pinc = rdpinc_s[cur][k];
+                    const StRead rd = rd_s[cur][k];
+                    const uint32_t A = rd.A;
                     const uint32_t start = L.start[it], len = L.len[it];
                     const uint32_t lo = min(start, QL), hi = min(start + A, QL);
                     const uint32_t ilo = qoff + lo, ihi = qoff + hi;
-                    // P(i) = ps_s[i] + the totals of the waves before the one that wrote slot i
                     double U = ps_s[ihi] - ps_s[ilo];
                     U += (ilo <= 1u * ST_QW && ihi > 1u * ST_QW) ? ws0 : 0.0;
                     U += (ilo <= 2u * ST_QW && ihi > 2u * ST_QW) ? ws1 : 0.0;
@@ -465,26 +528,33 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                     U += (double)(A - (hi - lo)) * lq0; // Q5 zero padding
                     segU[it] = U;
                     sumU += U;
-                    const uint32_t use_bep = (prm.use_bep || first90_s[k] < hi) ? 1u : 0u; // update_likelihood.cpp:42
+                    const bool sticky = first90_s[k] < hi; // update_likelihood.cpp:42
+                    own_bep |= sticky && !prm.use_bep;
+                    const uint32_t use_bep = (prm.use_bep || sticky) ? 1u : 0u;
                     const uint32_t cs = colbase + start;
                     const uint32_t cl = cs < T.n_col ? min(len, T.n_col - cs) : 0u;
-                    const double pcm = (1.0 - pinc) * L.nd[it].mappability;
-                    segpm_s[ls] = prm.consensus ? StSegPm{0.0, (1.0 - prm.bep) * L.nd[it].match}
-                                                : StSegPm{1.0 - pcm, pcm * L.nd[it].match};
-                    seggeo_s[ls] = StSegGeo{(uint16_t)((cs + cl) | (use_bep << 15)), (int16_t)((int)colbase - (int)cs + (int)cshift),
-                                            (uint16_t)(cs + A), (int16_t)((int)qoff - (int)colbase + (int)qshift),
-                                            (uint16_t)(colbase + QL), 0};
-                    segS_s[ls] = 0.0;
-                    if (cl) { // owner marks: the segment's first column, and column 0 of every further 32-column word it covers
-                        atomicOr(&flags_s[cs >> 5], 1u << (cs & 31u));
-                        colhead_s[cs] = (uint16_t)ls;
-                        for (uint32_t bc = (cs | 31u) + 1u; bc < cs + cl; bc += 32u) {
-                            atomicOr(&flags_s[bc >> 5], 1u);
-                            colhead_s[bc] = (uint16_t)ls;
-                        }
+                    // wbg = 1 - pcm, wobs = pcm * match (process_mapping.cpp:41,66-75; a consensus FASTA: 0 and (1 - bep) * match)
+                    const double pcm = rd.omp * L.mapp[it];
+                    const double wbg = prm.consensus ? 0.0 : 1.0 - pcm;
+                    double kappa = prm.consensus ? 0.0 : wbg * (rd.ip * L.inv_mm[it]);
+                    double lw = rd.lp + L.ln_w[it];
+                    if (!(kappa < 1e300)) { // wobs = 0 (mapping quality 0, mappability 0): the column is log(wbg * bg)
+                        kappa = INFINITY;
+                        lw = wbg;
                     }
+                    segkl_s[ls] = StSegKL{kappa, lw};
+                    seggeo_s[ls] = StSegGeo{(uint16_t)((cs + cl) | (use_bep << 15)), (int16_t)((int)colbase - (int)cs + (int)cshift),
+                                            (int16_t)((int)qoff - (int)colbase + (int)qshift), (uint16_t)(colbase + QL)};
+                    segS_s[ls] = 0.0;
+                    if (cl) atomicOr(&flags_s[cs >> 5], 1u << (cs & 31u));
+                    nmin = min(nmin, L.node[it]);
                 }
             }
+            if (nodeW && need_min) { // the window is (re)placed at this tile's lowest node id
+                nmin = wave_min_u32(nmin);
+                if (lane == 0) atomicMin(&tilebits_s[1], nmin);
+            }
+            if (__builtin_amdgcn_ballot_w64(own_bep) != 0 && lane == 0) atomicOr(&tilebits_s[0], 1u);
         }
         PT_MARK(4);
         __syncthreads();
@@ -501,36 +571,63 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         PT_MARK(6);
 
         // ---- D: one lane per alignment column, flat over the tile; everything comes from LDS
-        for (uint32_t c = tid; c < T.n_col; c += ST_THREADS) {
-            // owner = the nearest mark at or below the column within its 32-column word (C marks every word a segment covers)
-            const uint32_t w = c >> 5;
-            const uint32_t fw = flags_s[w] & (0xFFFFFFFFu >> (31u - (c & 31u)));
-            const uint32_t gcode = code_s[gseq_s[c + cshift]];
-            const uint32_t head = (w << 5 | 31u) - (uint32_t)__builtin_clz(fw | 1u);
-            // every LDS read below is unconditional (indices in range, results selected afterwards): the reads of one
-            // column then overlap instead of each waiting behind its own branch
-            const uint32_t ls = (uint32_t)colhead_s[head] & ((uint32_t)ST_SEGS - 1u);
-            const StSegGeo geo = seggeo_s[ls];
-            const StSegPm pm = segpm_s[ls];
-            const uint32_t cend = geo.cend_bep & 0x7FFFu;
-            const bool in_seg = fw != 0u && c < cend; // columns no mapping scores (Q6 tail) have no owner
-            const uint32_t ri = min((uint32_t)((int)c + geo.rshift), (uint32_t)ST_COLS + 7u);
-            const uint32_t qi = min((uint32_t)((int)c + geo.qshift), (uint32_t)ST_QUAL + 7u);
-            const uint32_t rraw = rseq_s[ri];
-            const int qraw = (int)(int8_t)qual_s[qi];
-            const uint32_t rlut = code_s[rraw];
-            const uint32_t rcode = c < geo.aend ? rlut : 4u;
-            int q = c < geo.qend ? qraw : 0;
-            q = q < 0 ? 0 : (q > 99 ? 99 : q);        // qscore_vec's index
-            q = (geo.cend_bep & 0x8000u) ? 100 : q;   // slot 100 holds the background error rate
-            const bool valid = in_seg && (gcode | rcode) < 4u; // process_mapping.cpp:62-63
-            const double e = qs_s[q];
-            const double bgv = bg_s[rlut & 3u];
-            const double om = gcode == rcode ? 1.0 - e : e;    // 1 - eps: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0
-            const double x = pm.wbg * bgv + pm.wobs * om;      // process_mapping.cpp:66-75
-            const double t = log_tab(x, valid, logtab_s);
-            if (valid) unsafeAtomicAdd(&segS_s[ls], t);
+        const uint32_t tb0 = tilebits_s[0], node_lo = tilebits_s[1];
+        // heads in the words below word w, held by lane w: the owner of a column is a popcount away
+        uint32_t wordbase;
+        {
+            const uint32_t pc = lane < ST_FWORDS ? (uint32_t)__builtin_popcount(flags_s[lane]) : 0u;
+            wordbase = wave_incl_scan_u32(pc) - pc - 1u; // (- 1: the owner's index is the head count less one)
         }
+        auto columns = [&](auto general_tag) {
+            constexpr bool GEN = decltype(general_tag)::value;
+            // (whole waves: the owner lookup reads another lane's register, and every index below stays inside its array
+            // for the columns past the tile's end, which no segment claims)
+            for (uint32_t c0 = (uint32_t)wave * 64u; c0 < T.n_col; c0 += ST_THREADS) {
+                const uint32_t c = c0 + (uint32_t)lane;
+                const uint32_t w = c >> 5;
+                const uint32_t fw = flags_s[w] & lanemask;
+                const uint32_t below = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)wordbase);
+                const uint32_t own = (uint32_t)__builtin_popcount(fw) + below; // head bits at or below the column, less one
+                const uint32_t gcode = code_s[gseq_s[c + cshift]];
+                // every LDS read below is unconditional (indices in range, results selected afterwards): the reads of one
+                // column then overlap instead of each waiting behind its own branch
+                const uint32_t ls = own & ((uint32_t)ST_SEGS - 1u);
+                const StSegGeo geo = seggeo_s[ls];
+                const StSegKL kl = segkl_s[ls];
+                const uint32_t cend = geo.cend_bep & 0x7FFFu;
+                const bool in_seg = (int)own >= 0 && c < cend; // columns no mapping scores (Q6 tail) have no owner
+                const uint32_t ri = min((uint32_t)((int)c + geo.rshift), (uint32_t)ST_COLS + 7u);
+                const uint32_t qi = min((uint32_t)((int)c + geo.qshift), (uint32_t)ST_QUAL + 7u);
+                const uint32_t rcode = code_s[rseq_s[ri]];
+                int q = (int)(int8_t)qual_s[qi];
+                if constexpr (GEN) q = c < geo.qend ? q : 0;
+                q = q < 0 ? 0 : (q > 99 ? 99 : q);               // qscore_vec's index
+                if constexpr (GEN) q = (geo.cend_bep & 0x8000u) ? 100 : q; // slot 100 holds the background error rate
+                const bool valid = in_seg && (gcode | rcode) < 32u; // process_mapping.cpp:62-63
+                const uint32_t match = gcode == rcode ? 1u : 0u;   // 1 - eps: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0
+                const StLom lo = lom_s[q][match];
+                const double bgv = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(bg_s) + rcode);
+                const double rho = kl.kappa * bgv * lo.iom;
+                double p = fma(rho, 1.0 / 8.0, -1.0 / 7.0);
+                p = fma(rho, p, 1.0 / 6.0);
+                p = fma(rho, p, -0.2);
+                p = fma(rho, p, 0.25);
+                p = fma(rho, p, -1.0 / 3.0);
+                p = fma(rho, p, 0.5);
+                p = fma(rho, -p, 1.0);
+                double t = fma(rho, p, lo.lom + kl.lw);
+                if (__builtin_expect(valid && !(rho < ST_RHO_MAX), 0)) { // rare: see the head of this section
+                    const double e = (q == 100 || prm.use_bep) ? prm.bep : g.qscore[q];
+                    const double om = match ? 1.0 - e : e;
+                    const bool deg = !(kl.kappa < 1e300); // wobs = 0: {inf, wbg}
+                    const double lx = log_tab(deg ? kl.lw * bgv : fma(kl.kappa, bgv, om), true, hc_log_table);
+                    t = deg ? lx : kl.lw + lx;
+                }
+                if (valid) unsafeAtomicAdd(&segS_s[ls], t);
+            }
+        };
+        if ((tb0 | T.short_qual) != 0u) columns(std::true_type{});
+        else columns(std::false_type{});
         PT_MARK(7);
         if (has_next) {
             tile_gather(Tn, Ln); // the node ids arrived during D,
@@ -541,15 +638,39 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         PT_MARK(9);
 
         // ---- E: one lane per segment
+        if (nodeW && need_min && T.n_seg) {
+            // The window sits at the lowest node id of the workgroup's first tile: the batch is sorted by the reads' lowest
+            // node id (vgan_hc_flatten), so a workgroup's reads stay above it and move through the node ids slowly.  Any
+            // other order is still correct -- a segment outside the window adds to W in HBM directly -- and a tile that
+            // leaves the window with many segments has the next one place it anew.
+            if (winbase != 0xFFFFFFFFu) {
+                window_flush();
+                __syncthreads();
+            }
+            winbase = node_lo;
+            need_min = false;
+        }
+        uint32_t n_outside = 0;
 #pragma unroll
         for (int it = 0; it < ST_SEG_ITERS; ++it) {
             const uint32_t ls = tid + it * ST_THREADS;
             if (ls < T.n_seg) {
                 const double S = segS_s[ls];
                 sumT += S;
-                if (segD_out) segD_out[T.seg_base + ls] = S - segU[it];
+                const double D = S - segU[it];
+                if (segD_out) segD_out[T.seg_base + ls] = D;
+                if (nodeW) {
+                    const uint32_t slot = L.node[it] - winbase;
+                    if (slot < (uint32_t)ST_WIN) {
+                        unsafeAtomicAdd(&win_s[slot], D);
+                    } else {
+                        unsafeAtomicAdd(&nodeW[L.node[it]], D);
+                        n_outside++;
+                    }
+                }
             }
         }
+        if (nodeW && __builtin_popcountll(__builtin_amdgcn_ballot_w64(n_outside > 0)) > 16 && lane == 0) atomicOr(&tilebits_s[3], 1u);
         PT_MARK(10);
         if (!has_next) break;
         // the next tile's barriers order E against its C (E reads segS_s only)
@@ -557,6 +678,10 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         T = Tn;
         L = Ln;
         cur ^= 1u;
+    }
+    if (nodeW && winbase != 0xFFFFFFFFu) {
+        __syncthreads();
+        window_flush();
     }
 #ifdef VGAN_PHASE_TIMING
     if (tid == 0)
@@ -568,43 +693,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         unsafeAtomicAdd(&totals[0], sumT);
         unsafeAtomicAdd(&totals[1], sumU);
     }
-}
-
-// ---------------------------------------------------------------------------------------------- node accumulate
-// W[node] += D_m with a workgroup-private copy of W in LDS.
-__global__ __launch_bounds__(1024) void hc_nodeacc_lds_kernel(const uint32_t *__restrict__ seg_node,
-                                                               const double *__restrict__ segD, uint32_t n_items,
-                                                               uint32_t rows, double *__restrict__ nodeW) {
-    extern __shared__ double w_s[];
-    for (uint32_t j = threadIdx.x; j < rows; j += blockDim.x) w_s[j] = 0.0;
-    __syncthreads();
-    // four independent (node, weight) pairs in flight per lane: the stream is latency bound otherwise
-    const uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr uint32_t NA_UNROLL = 4;
-    for (; (uint64_t)i + (uint64_t)(NA_UNROLL - 1) * stride < n_items; i += NA_UNROLL * stride) {
-        uint32_t nd[NA_UNROLL];
-        double dv[NA_UNROLL];
-#pragma unroll
-        for (uint32_t u = 0; u < NA_UNROLL; ++u) {
-            nd[u] = seg_node[i + u * stride];
-            dv[u] = segD[i + u * stride];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < NA_UNROLL; ++u) unsafeAtomicAdd(&w_s[nd[u]], dv[u]);
-    }
-    for (; i < n_items; i += stride) unsafeAtomicAdd(&w_s[seg_node[i]], segD[i]);
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < rows; j += blockDim.x) {
-        const double v = w_s[j];
-        if (v != 0.0) unsafeAtomicAdd(&nodeW[j], v);
-    }
-}
-
-__global__ void hc_nodeacc_global_kernel(const uint32_t *__restrict__ seg_node, const double *__restrict__ segD,
-                                         uint32_t n_items, double *__restrict__ nodeW) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x)
-        unsafeAtomicAdd(&nodeW[seg_node[i]], segD[i]);
 }
 
 // ---------------------------------------------------------------------------------------------- sweep
@@ -841,49 +929,31 @@ extern "C" int vgan_hc_debug_phase_cycles(unsigned long long *out, int reset) {
 
 // ---------------------------------------------------------------------------------------------- launchers
 void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable,
-                        uint32_t mean_cols_per_read, double *segS, double *segU, double *segD, double *totals, hipStream_t st) {
+                        uint32_t mean_cols_per_read, double *segS, double *segU, double *segD, double *nodeW, double *totals,
+                        hipStream_t st) {
     if (b.n_reads == 0) return;
     uint32_t nt = std::min(n_tileable, b.n_reads);
     if (segS || segU) nt = 0; // the tiled kernel produces D_m only; separate S_m / U_m (debug API) come from the general one
     if (nt) {
         // ~6 workgroups per CU and launch round; contiguous read ranges per workgroup
-        const uint32_t want_blocks = 256u * 6u * 2u;
+        // 16 workgroups per CU: contiguous read ranges (the LDS window wants them), short enough for the dispatcher to even
+        // out the CUs (1024 persistent workgroups: 1.20 ms per 1M x 150 bp; 3072: 1.01; 4096: 1.00; 8192: 1.08)
+        const uint32_t want_blocks = 256u * 16u;
         uint32_t per = (nt + want_blocks - 1) / want_blocks;
         per = std::max(per, (uint32_t)ST_READS_SHORT);
         const uint32_t blocks = (nt + per - 1) / per;
         // short reads: more of them per tile, or the tile's lanes idle (the estimate uses all reads of the batch)
         if (mean_cols_per_read < 110u)
-            hipLaunchKernelGGL(hc_segment_tile_kernel<ST_READS_SHORT>, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, totals);
+            hipLaunchKernelGGL(hc_segment_tile_kernel<ST_READS_SHORT>, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, nodeW, totals);
         else
-            hipLaunchKernelGGL(hc_segment_tile_kernel<ST_READS_LONG>, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, totals);
+            hipLaunchKernelGGL(hc_segment_tile_kernel<ST_READS_LONG>, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, nodeW, totals);
     }
     if (nt < b.n_reads) {
         const uint32_t rest = b.n_reads - nt;
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)rest + SEG_WAVES - 1) / SEG_WAVES, 256u * 8u);
         hipLaunchKernelGGL(hc_segment_general_kernel, dim3(blocks), dim3(SEG_WAVES * 64), 0, st, g, b, prm, nt, segS, segU,
-                           segD, totals);
+                           segD, nodeW, totals);
     }
-}
-
-int launch_hc_nodeacc(const uint32_t *seg_node, const double *segD, uint32_t n_items, uint32_t rows, double *nodeW,
-                      hipStream_t st) {
-    if (n_items == 0) return 0;
-    const size_t lds = (size_t)rows * sizeof(double);
-    if (lds <= 150u * 1024u) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)hc_nodeacc_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return -1;
-            attr_set = true;
-        }
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>(256, ((uint64_t)n_items + 1023) / 1024);
-        hipLaunchKernelGGL(hc_nodeacc_lds_kernel, dim3(blocks), dim3(1024), lds, st, seg_node, segD, n_items, rows, nodeW);
-    } else {
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>(256u * 8u, ((uint64_t)n_items + 255) / 256);
-        hipLaunchKernelGGL(hc_nodeacc_global_kernel, dim3(blocks), dim3(256), 0, st, seg_node, segD, n_items, nodeW);
-    }
-    return 0;
 }
 
 template <int TB>

@@ -138,12 +138,19 @@ constexpr size_t TILE_MAX_COLS = 1280, TILE_MAX_QUAL = 1280, TILE_MAX_SEGS = 512
 struct Chunk {
     vgan_hc_host_batch b;   // reads that satisfy the tile contract
     vgan_hc_host_batch gen; // the others: indels / soft clips (|graph_seq| != |algnseq|, segments may overlap), long reads
+    std::vector<uint32_t> key; // per read of b: its lowest node id (the merged batch is ordered by it)
     vgan_hc_flatten_stats st{};
+};
+
+struct SegTmp {
+    uint32_t node;
+    uint16_t start, len;
 };
 
 void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, const uint8_t *skip, int64_t src_base,
                    Chunk &c) {
     Recon rc;
+    std::vector<SegTmp> seg_tmp;
     { // size the chunk's arrays
         auto &b = c.b; // from the input volume, so that they grow at most once or twice
         const size_t nr = (size_t)(r1 - r0), nm = (size_t)(a.map_off[r1] - a.map_off[r0]);
@@ -175,8 +182,10 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         // 16-bit per-read positions; the quality string is parsed independently of |sequence| (gam.cpp) and the general
         // kernel keeps one prefix sum per 64 quality bytes for at most 65536 of them
         if (!bad && (A > 65535 || G > 65535 || nm > 65535 || n_qual_r > 65535)) bad = BAD_RANGE;
-        auto &b = (!bad && A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && (size_t)nm <= TILE_MAX_SEGS) ? c.b : c.gen;
-        const size_t seg_mark = b.seg_node.size();
+        // segments first (into scratch), then the route: the tile contract also wants every segment to score a column
+        seg_tmp.clear();
+        bool empty_seg = false;
+        uint32_t min_node = 0xFFFFFFFFu;
         if (!bad) {
             size_t pos = 0;
             for (int64_t i = 0; i < nm; ++i) {
@@ -199,19 +208,25 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
                     break;
                 }
                 const size_t n = (size_t)std::max(0, rc.sizes[i]);
-                b.seg_node.push_back((uint32_t)id);
-                b.seg_start.push_back((uint16_t)pos);
-                b.seg_len.push_back((uint16_t)std::min(n, G - pos));
+                const size_t sl = std::min(n, G - pos);
+                seg_tmp.push_back({(uint32_t)id, (uint16_t)pos, (uint16_t)sl});
+                empty_seg |= sl == 0;
+                min_node = std::min(min_node, (uint32_t)id);
                 pos += std::min(n, A - pos);
             }
         }
         if (bad) {
-            b.seg_node.resize(seg_mark);
-            b.seg_start.resize(seg_mark);
-            b.seg_len.resize(seg_mark);
             c.st.n_bad++;
             continue;
         }
+        const bool tile = A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && (size_t)nm <= TILE_MAX_SEGS && !empty_seg;
+        auto &b = tile ? c.b : c.gen;
+        for (const SegTmp &sg : seg_tmp) {
+            b.seg_node.push_back(sg.node);
+            b.seg_start.push_back(sg.start);
+            b.seg_len.push_back(sg.len);
+        }
+        if (tile) c.key.push_back(min_node);
         int32_t mq = a.mapq[r];
         if (mq < 0 || mq > 99) {
             mq = mq < 0 ? 0 : 99;
@@ -242,32 +257,56 @@ template <class T> void append_shifted(std::vector<T> &dst, const std::vector<T>
 } // namespace
 
 namespace {
-// chunks -> one batch: every chunk's tileable reads, then every chunk's other reads (chunks are consumed)
+// chunks -> one batch (chunks are consumed): the tileable reads of all chunks ordered by their lowest node id -- the
+// tiled kernel keeps W[node] of a workgroup's reads in an LDS window, which wants neighbouring reads on neighbouring
+// nodes (a stable counting sort, so reads on the same node keep their input order) -- then every chunk's other reads
 int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
     auto res = new vgan_hc_host_batch();
     vgan_hc_flatten_stats st{};
-    // output order: every chunk's tileable reads, then every chunk's other reads
-    std::vector<vgan_hc_host_batch *> parts;
-    for (auto &c : chunks) parts.push_back(&c.b);
-    for (auto &c : chunks) parts.push_back(&c.gen);
-    uint64_t tot_cols = 0, tot_segs = 0, tot_qual = 0, tot_reads = 0;
+    const size_t nc = chunks.size();
+    // ---- the tileable reads: (chunk, local index) in sorted order
+    std::vector<size_t> rbase(nc + 1, 0);
+    for (size_t i = 0; i < nc; ++i) rbase[i + 1] = rbase[i] + chunks[i].b.read_mapq.size();
+    const size_t nt_reads = rbase[nc];
+    uint32_t kmax = 0;
+    for (auto &c : chunks)
+        for (uint32_t &k : c.key) {
+            if (k == 0xFFFFFFFFu) k = 0; // a read without mappings
+            kmax = std::max(kmax, k);
+        }
+    std::vector<uint32_t> order(nt_reads); // output position -> global tileable index (chunk-major)
+    {
+        std::vector<uint32_t> cnt((size_t)kmax + 2, 0);
+        for (auto &c : chunks)
+            for (uint32_t k : c.key) cnt[(size_t)k + 1]++;
+        for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+        for (size_t i = 0; i < nc; ++i)
+            for (size_t j = 0; j < chunks[i].key.size(); ++j) order[cnt[chunks[i].key[j]]++] = (uint32_t)(rbase[i] + j);
+    }
+    // ---- totals
+    uint64_t t_cols = 0, t_segs = 0, t_qual = 0;
+    for (auto &c : chunks) {
+        t_cols += c.b.graph_seq.size();
+        t_segs += c.b.seg_node.size();
+        t_qual += c.b.qual.size();
+    }
     struct Base {
         size_t r, s, c, q;
     };
-    std::vector<Base> base(parts.size());
-    for (size_t i = 0; i < parts.size(); ++i) {
-        if (i == chunks.size()) res->n_tileable = (uint32_t)tot_reads;
-        base[i] = {(size_t)tot_reads, (size_t)tot_segs, (size_t)tot_cols, (size_t)tot_qual};
-        tot_cols += parts[i]->graph_seq.size();
-        tot_segs += parts[i]->seg_node.size();
-        tot_qual += parts[i]->qual.size();
-        tot_reads += parts[i]->read_mapq.size();
+    std::vector<Base> gbase(nc);
+    uint64_t tot_reads = nt_reads, tot_cols = t_cols, tot_segs = t_segs, tot_qual = t_qual;
+    for (size_t i = 0; i < nc; ++i) {
+        gbase[i] = {(size_t)tot_reads, (size_t)tot_segs, (size_t)tot_cols, (size_t)tot_qual};
+        tot_cols += chunks[i].gen.graph_seq.size();
+        tot_segs += chunks[i].gen.seg_node.size();
+        tot_qual += chunks[i].gen.qual.size();
+        tot_reads += chunks[i].gen.read_mapq.size();
     }
-    if (tot_cols > 0xFFFFFFF0ull || tot_segs > 0xFFFFFFF0ull || tot_qual > 0xFFFFFFF0ull) {
+    if (tot_cols > 0xFFFFFFF0ull || tot_segs > 0xFFFFFFF0ull || tot_qual > 0xFFFFFFF0ull || tot_reads > 0xFFFFFFF0ull) {
         delete res;
         return fail(VGAN_ERANGE, "vgan_hc_flatten: batch exceeds 32-bit offsets; flatten fewer reads per batch");
     }
-    // one allocation per array, then every part is copied (offsets shifted) by its own thread
+    res->n_tileable = (uint32_t)nt_reads;
     res->read_seg_off.resize(tot_reads + 1);
     res->read_col_off.resize(tot_reads + 1);
     res->read_qual_off.resize(tot_reads + 1);
@@ -281,9 +320,43 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
     res->algnseq.resize(tot_cols);
     res->qual.resize(tot_qual);
     res->read_seg_off[0] = res->read_col_off[0] = res->read_qual_off[0] = 0;
-    auto copy_part = [&](size_t i) {
-        auto &cb = *parts[i];
-        const Base &bs = base[i];
+    // ---- offsets of the sorted reads (serial prefix sums over three lengths per read)
+    auto chunk_of = [&](uint32_t gidx) { return (size_t)(std::upper_bound(rbase.begin(), rbase.end(), (size_t)gidx) - rbase.begin()) - 1; };
+    for (size_t o = 0; o < nt_reads; ++o) {
+        const size_t ci = chunk_of(order[o]), j = order[o] - rbase[ci];
+        const auto &cb = chunks[ci].b;
+        res->read_seg_off[o + 1] = res->read_seg_off[o] + (cb.read_seg_off[j + 1] - cb.read_seg_off[j]);
+        res->read_col_off[o + 1] = res->read_col_off[o] + (cb.read_col_off[j + 1] - cb.read_col_off[j]);
+        res->read_qual_off[o + 1] = res->read_qual_off[o] + (cb.read_qual_off[j + 1] - cb.read_qual_off[j]);
+    }
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    // ---- the sorted reads' data, by output range
+    auto copy_sorted = [&](size_t o0, size_t o1) {
+        for (size_t o = o0; o < o1; ++o) {
+            const size_t ci = chunk_of(order[o]), j = order[o] - rbase[ci];
+            const auto &cb = chunks[ci].b;
+            res->read_algn_len[o] = cb.read_algn_len[j];
+            res->read_mapq[o] = cb.read_mapq[j];
+            res->read_src[o] = cb.read_src[j];
+            const size_t s0 = cb.read_seg_off[j], ns = cb.read_seg_off[j + 1] - s0, so = res->read_seg_off[o];
+            if (ns) {
+                memcpy(&res->seg_node[so], &cb.seg_node[s0], ns * sizeof(uint32_t));
+                memcpy(&res->seg_start[so], &cb.seg_start[s0], ns * sizeof(uint16_t));
+                memcpy(&res->seg_len[so], &cb.seg_len[s0], ns * sizeof(uint16_t));
+            }
+            const size_t c0 = cb.read_col_off[j], ncol = cb.read_col_off[j + 1] - c0, co = res->read_col_off[o];
+            if (ncol) {
+                memcpy(&res->graph_seq[co], &cb.graph_seq[c0], ncol);
+                memcpy(&res->algnseq[co], &cb.algnseq[c0], ncol);
+            }
+            const size_t q0 = cb.read_qual_off[j], nq = cb.read_qual_off[j + 1] - q0;
+            if (nq) memcpy(&res->qual[res->read_qual_off[o]], &cb.qual[q0], nq);
+        }
+    };
+    // ---- the other reads: whole parts, offsets shifted
+    auto copy_gen = [&](size_t i) {
+        auto &cb = chunks[i].gen;
+        const Base &bs = gbase[i];
         for (size_t k = 1; k < cb.read_seg_off.size(); ++k) {
             res->read_seg_off[bs.r + k] = cb.read_seg_off[k] + (uint32_t)bs.s;
             res->read_col_off[bs.r + k] = cb.read_col_off[k] + (uint32_t)bs.c;
@@ -301,17 +374,18 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
         cp(res->graph_seq, bs.c, cb.graph_seq);
         cp(res->algnseq, bs.c, cb.algnseq);
         cp(res->qual, bs.q, cb.qual);
-        cb = vgan_hc_host_batch();
     };
     {
-        const size_t nt = std::min<size_t>(parts.size(), std::max(1u, std::thread::hardware_concurrency()));
-        if (chunks.size() == 1 || nt <= 1) {
-            for (size_t i = 0; i < parts.size(); ++i) copy_part(i);
+        const size_t nth = std::max<size_t>(1, std::min<size_t>(hw, (nt_reads + 8191) / 8192));
+        if (nth <= 1) {
+            copy_sorted(0, nt_reads);
+            for (size_t i = 0; i < nc; ++i) copy_gen(i);
         } else {
             std::vector<std::thread> cth;
-            for (size_t t = 0; t < nt; ++t)
+            for (size_t t = 0; t < nth; ++t)
                 cth.emplace_back([&, t] {
-                    for (size_t i = t; i < parts.size(); i += nt) copy_part(i);
+                    copy_sorted(nt_reads * t / nth, nt_reads * (t + 1) / nth);
+                    for (size_t i = t; i < nc; i += nth) copy_gen(i);
                 });
             for (auto &t : cth) t.join();
         }
@@ -322,6 +396,7 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
         st.n_unmapped += c.st.n_unmapped;
         st.n_bad += c.st.n_bad;
         st.n_clamped += c.st.n_clamped;
+        c = Chunk();
     }
     pt.lap("merge");
     st.n_segments = (int64_t)res->seg_node.size();
