@@ -1,4 +1,4 @@
-"""Parity at BASELINE.json's workload sizes (1M x 150 bp HaploCart, ~1M-read euka shard, 2M-read soibean) through properties
+"""Parity at BASELINE.json's workload sizes (1M and 10M x 150 bp HaploCart, 1M and 5M euka reads, 2M-read soibean) through properties
 that do not depend on the size: modes agree, accumulation is additive over any split of the reads, summaries of disjoint
 shards add up, and a random sample of reads matches the oracle.  (The oracle itself finishes only a few hundred reads of
 these workloads in seconds.)"""
@@ -127,6 +127,92 @@ def test_soibean_two_million_reads():
     ctx.precompute(sb.SbHostBatch(g, a, 1_000_000, 1_000_200))
     rc, ref = o.loglike(st[0], 0.01, FREQS)
     assert rc == 0 and ctx.loglike(st, 0.01, FREQS)[0][0] == pytest.approx(ref, rel=1e-10)
+
+
+def test_haplocart_ten_million_reads_in_eight_shards():
+    """BASELINE configs[2]: 10M x 150 bp as 8 contiguous shards of the seeded read stream, each through a context of its
+    own (what 8 ranks do), the eight final vectors summed on the host (what the reduce does) -- against one context that
+    takes the same 10M reads in ten batches, and against the oracle on scattered samples of the stream."""
+    seed, total, world = 0x76676131, 10_000_000, 8
+    g = hc.synth_graph(seed=seed)
+    from vgan_amd import distributed as vd
+    sharded = np.zeros(g.n_paths)
+    n_sharded = 0
+    for rank in range(world):
+        r0, r1 = vd.shard_bounds(total, rank, world)
+        ctx = hc.HcContext(g)
+        a = hc.synth_reads(g, r1 - r0, seed=seed, read_len=150, first_read=r0)
+        b = hc.HostBatch(g, a)
+        n_sharded += b.n_reads
+        ctx.accumulate(b)
+        sharded += ctx.finalize()
+        del ctx, a, b
+    one = hc.HcContext(g)
+    n_one = 0
+    for c0 in range(0, total, 1_000_000):
+        a = hc.synth_reads(g, 1_000_000, seed=seed, read_len=150, first_read=c0)
+        b = hc.HostBatch(g, a)
+        n_one += b.n_reads
+        one.accumulate(b)
+        del a, b
+    whole = one.finalize()
+    assert n_one == n_sharded > 9_990_000
+    assert np.all(np.isfinite(whole)) and whole.max() < 0 and util.rel_err(sharded, whole) < 1e-11
+    # the stream against the oracle, wherever a shard boundary or a batch boundary falls
+    og = util.orc_graph_from_product(g)
+    ctx = hc.HcContext(g)
+    for r0 in (0, 1_249_980, 4_999_990, 9_999_950):
+        a = hc.synth_reads(g, 40, seed=seed, read_len=150, first_read=r0)
+        _, want, _ = orc.hc_run(og, util.orc_alnset_from_product(a), n_threads=8, faithful=False)
+        ctx.reset()
+        ctx.accumulate(hc.HostBatch(g, a))
+        assert util.rel_err(ctx.finalize(), want) < 1e-9
+
+
+def test_euka_five_million_reads_in_eight_shards():
+    """BASELINE configs[3]: 5M synthetic 75 bp aDNA reads with the dhigh damage profiles as 8 shards of 625k, each in a context
+    of its own: per-clade counts and base-shift tables add exactly, coverage and likelihood sums to rounding, against one
+    context taking the eight shards in turn; one shard's head against the oracle."""
+    d = os.path.join(GOLD, "damageProfiles")
+    texts = (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    dm = ek.Damage.from_text(*texts)
+    world, per = 8, 625_000
+    one = None
+    acc = None
+    n_reads = 0
+    for rank in range(world):
+        g, db, a = ek.synth_euka(per, dm, read_seed=1000003 * rank)
+        if one is None:
+            one = ek.EukaContext(db, dm)
+        hb = ek.EukaHostBatch(g, a)
+        n_reads += hb.n_reads
+        ctx = ek.EukaContext(db, dm)
+        got = ctx.accumulate(hb)
+        fin = ctx.finalize()
+        n, s = ctx.like_sums()
+        again = one.accumulate(hb)
+        assert np.array_equal(again["like"], got["like"]) and np.array_equal(again["clade"], got["clade"])  # per read: the same bits
+        part = {"clade_count": fin["clade_count"].astype(np.int64), "baseshift": fin["baseshift"].astype(np.int64),
+                "bin_cov": fin["bin_cov"].astype(np.float64), "n": n.astype(np.int64), "s": np.where(np.isfinite(s), s, 0.0),
+                "inf": ~np.isfinite(s) & (n > 0), "passed": int(got["pass"].sum())}
+        acc = part if acc is None else {k: acc[k] + part[k] for k in part}
+        if rank == 3:  # the head of one shard against the oracle
+            sub = _range(a, 0, 300)
+            ref = orc.euka_run(util.orc_graph_nodes_only(g), util.orc_alnset_from_product(sub), util.orc_euka_db_from_product(db),
+                               orc.OrcDamage(*texts), 29, 5)
+            src = hb.arrays()["read_src"]
+            idx = np.nonzero(src < 300)[0]
+            assert np.array_equal(got["clade"][idx], ref["clade"][src[idx]]) and np.array_equal(got["pass"][idx], ref["pass"][src[idx]])
+            ok = got["clade"][idx] >= 0
+            assert ok.sum() > 250 and util.rel_err(got["like"][idx][ok], ref["like"][src[idx]][ok]) < 1e-10
+        del ctx, g, a, hb
+    fin = one.finalize()
+    n, s = one.like_sums()
+    assert n_reads > 4_900_000 and acc["passed"] == fin["clade_count"].sum() > 1_500_000
+    assert np.array_equal(acc["clade_count"], fin["clade_count"]) and np.array_equal(acc["baseshift"], fin["baseshift"])
+    assert np.array_equal(acc["n"], n) and np.allclose(acc["bin_cov"], fin["bin_cov"], rtol=1e-12, atol=1e-9)
+    okc = np.isfinite(s)
+    assert np.array_equal(~okc & (n > 0), acc["inf"] > 0) and util.rel_err(acc["s"][okc], s[okc]) < 1e-11
 
 
 def test_empty_inputs_on_every_path(tmp_path):
