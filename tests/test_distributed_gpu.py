@@ -91,3 +91,56 @@ def test_bench_starts_its_own_ranks_weak_and_strong():
         assert other["result_check"]["sum_final_vec"] == pytest.approx(one["result_check"]["sum_final_vec"], rel=1e-12)
         assert other["posterior"]["confidence"] == pytest.approx(one["posterior"]["confidence"], rel=1e-6)
     assert one["posterior_ms"] > 0 and one["roofline"]["bound"] == "valu" and 0 < one["roofline"]["frac"] < 1
+
+
+def test_several_contexts_in_one_process_reduce_to_the_single_context_result():
+    """vgan_hc_reduce: the C++ multi-GPU path (one context per GPU, chunks dealt round-robin, one reduce of P doubles).  On a
+    one-GPU box the contexts share the device, so the reduce goes through the host; the collective needs distinct GPUs."""
+    from vgan_amd import haplocart as hc
+    g = hc.synth_graph(seed=21, genome_len=3000, n_nodes=2100, n_paths=200)
+    chunks = [hc.synth_reads(g, 2500, seed=3, read_len=140, first_read=2500 * i) for i in range(6)]
+    one = hc.HcContext(g)
+    for a in chunks:
+        one.accumulate(hc.HostBatch(g, a))
+    want = one.finalize()
+    ctxs = [hc.HcContext(g, device=0) for _ in range(3)]
+    for i, a in enumerate(chunks):
+        ctxs[i % 3].accumulate(hc.HostBatch(g, a))
+    got, used_rccl = hc.reduce_contexts(ctxs)
+    assert not used_rccl  # three contexts on one device
+    assert np.max(np.abs(got - want) / np.abs(want)) < 1e-12
+    # a single context reduces to itself (a finalize sums with atomics: equal to rounding, not to the bit)
+    alone, _ = hc.reduce_contexts([one])
+    assert np.max(np.abs(alone - want) / np.abs(want)) < 1e-13
+
+
+def test_cli_deals_the_reads_to_several_device_contexts(tmp_path):
+    """`vgan haplocart -t N` / `--gpus LIST`: the same result line, log-likelihood table and posteriors from two contexts
+    (here both on GPU 0) as from one."""
+    from vgan_amd import haplocart as hc
+    g = hc.synth_graph(seed=5, genome_len=1500, n_nodes=1050, n_paths=60)
+    a = hc.synth_reads(g, 180_000, seed=1, read_len=100)
+    g.write(str(tmp_path))
+    gam = str(tmp_path / "in.gam")
+    a.write_gam(gam)
+    exe = os.path.join(ROOT, "vgan_amd", "bin", "vgan")
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["--gpus", "0,0"]), ("t4", ["-t", "4"])):
+        out = str(tmp_path / (tag + ".tsv"))
+        r = subprocess.run([exe, "haplocart", "-g", gam, "--hc-files", str(tmp_path), "-o", out, "-pf", out + ".post", "-d", "-s", "x"] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert ("Reduced the log-likelihoods of 2 device contexts (host)" in r.stderr) == (tag == "two")
+        ll = {ln.split("\t")[0]: float(ln.split("\t")[1]) for ln in open(out + ".loglik.tsv").read().splitlines()}
+        outs[tag] = (open(out).read(), ll, open(out + ".post").read())
+    assert outs["one"][0] == outs["two"][0] == outs["t4"][0] and outs["one"][0].splitlines()[1].startswith("x\thg")
+    for other in ("two", "t4"):  # -t 4 on a one-GPU box is one context again
+        assert outs[other][1].keys() == outs["one"][1].keys()
+        assert all(outs[other][1][k] == pytest.approx(v, rel=1e-10) for k, v in outs["one"][1].items())
+        f1, f2 = outs["one"][2].split("\t"), outs[other][2].split("\t")
+        assert len(f1) == len(f2) and f1[0] == f2[0]
+        for x, y in zip(f1[1:], f2[1:]):
+            try:
+                assert float(y) == pytest.approx(float(x), rel=1e-5)
+            except ValueError:
+                assert x == y

@@ -199,6 +199,7 @@ SYMBOLS = {
     "vgan_hc_segment_weights": (C.c_int, [vp, C.POINTER(HcBatch), vp]),
     "vgan_hc_read_loglik": (C.c_int, [vp, C.POINTER(HcBatch), vp]),
     "vgan_hc_finalize": (C.c_int, [vp, vp, vp]),
+    "vgan_hc_reduce": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.POINTER(C.c_int)]),
     "vgan_hc_synchronize": (C.c_int, [vp]),
     "vgan_hc_destroy": (None, [vp]),
     "vgan_hc_profile_enable": (C.c_int, [vp, C.c_int]),

@@ -1,6 +1,8 @@
 // C-ABI of the HaploCart device path (include/vgan_gpu.h): context, uploads, launches.
 // There is no CPU fallback here: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -581,6 +583,89 @@ extern "C" int vgan_hc_finalize(vgan_hc_ctx *c, double *d_out, double *out) {
     if (out) {
         HIPCHK(hipMemcpyAsync(out, c->final_vec.p, (size_t)c->P * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return VGAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- several GPUs, one process
+// RCCL is bound at run time (dlopen) and only on this path: the library carries no link-time dependency on it, and a
+// process that already holds another RCCL (PyTorch ships its own) never sees two.
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    bool ok = false;
+    Rccl() {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return;
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        Reduce = (decltype(Reduce))dlsym(h, "ncclReduce");
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Reduce;
+    }
+};
+Rccl &rccl() {
+    static Rccl r;
+    return r;
+}
+} // namespace
+
+// Sum over contexts of final_vec (src/HaploCart.cpp:419-420, the accumulate the reference does under `omp critical`, here
+// across GPUs): every context finalizes on its own device, then ONE reduce of P doubles onto the first context's device --
+// ncclReduce over the contexts' streams when they sit on distinct devices (xGMI), through the host otherwise (several
+// contexts on one device, RCCL not loadable).  out: host double[P].  *used_rccl (or NULL) tells which way it went.
+extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_rccl) {
+    if (!ctxs || n <= 0 || !out) return fail(VGAN_EINVAL, "vgan_hc_reduce: null argument");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || ctxs[i]->P != ctxs[0]->P) return fail(VGAN_EINVAL, "vgan_hc_reduce: contexts of different graphs");
+    const uint32_t P = ctxs[0]->P;
+    int rc;
+    for (int i = 0; i < n; ++i)
+        if ((rc = vgan_hc_finalize(ctxs[i], nullptr, nullptr))) return rc; // final_vec on every device, asynchronously
+    if (used_rccl) *used_rccl = 0;
+    bool distinct = n > 1;
+    for (int i = 0; i < n && distinct; ++i)
+        for (int j = 0; j < i; ++j) distinct = distinct && ctxs[i]->device != ctxs[j]->device;
+    if (distinct && rccl().ok) {
+        std::vector<int> devs((size_t)n);
+        for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
+        std::vector<ncclComm_t> comms((size_t)n, nullptr);
+        if (rccl().CommInitAll(comms.data(), n, devs.data()) == ncclSuccess) {
+            bool good = rccl().GroupStart() == ncclSuccess;
+            for (int i = 0; i < n && good; ++i) {
+                good = hipSetDevice(ctxs[i]->device) == hipSuccess &&
+                       rccl().Reduce(ctxs[i]->final_vec.p, ctxs[i]->final_vec.p, P, ncclDouble, ncclSum, 0, comms[(size_t)i], ctxs[i]->stream) == ncclSuccess;
+            }
+            good = rccl().GroupEnd() == ncclSuccess && good;
+            for (int i = 0; i < n; ++i) {
+                (void)hipSetDevice(ctxs[i]->device);
+                good = hipStreamSynchronize(ctxs[i]->stream) == hipSuccess && good;
+            }
+            for (auto cm : comms)
+                if (cm) (void)rccl().CommDestroy(cm);
+            if (!good) return fail(VGAN_ENODEV, "vgan_hc_reduce: the RCCL reduce failed");
+            HIPCHK(hipSetDevice(ctxs[0]->device));
+            HIPCHK(hipMemcpy(out, ctxs[0]->final_vec.p, (size_t)P * 8, hipMemcpyDeviceToHost));
+            if (used_rccl) *used_rccl = 1;
+            return VGAN_OK;
+        }
+    }
+    std::vector<double> part(P);
+    for (uint32_t p = 0; p < P; ++p) out[p] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        HIPCHK(hipSetDevice(ctxs[i]->device));
+        HIPCHK(hipMemcpyAsync(part.data(), ctxs[i]->final_vec.p, (size_t)P * 8, hipMemcpyDeviceToHost, ctxs[i]->stream));
+        HIPCHK(hipStreamSynchronize(ctxs[i]->stream));
+        for (uint32_t p = 0; p < P; ++p) out[p] += part[p];
     }
     return VGAN_OK;
 }

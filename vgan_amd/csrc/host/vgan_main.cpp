@@ -54,7 +54,10 @@ std::string haplocart_usage() {
            "   -q               quiet\n"
            "   --keep-duplicates   skip duplicate removal\n"
            "   --per-read       stream the path-membership mask per read (the reference's loop order)\n"
-           "   --device [INT]   GPU index (default 0)\n";
+           "   --device [INT]   GPU index (default 0)\n"
+           "   --gpus [LIST]    GPU indices, comma separated, one device context each (default: -t N takes GPUs 0..N-1 of the\n"
+           "                    visible ones, -t -1 all of them); the reads are dealt to the contexts chunk by chunk and the\n"
+           "                    per-haplogroup log-likelihoods are reduced once at the end (RCCL between distinct GPUs)\n";
 }
 
 int haplocart(int argc, char **argv) {
@@ -63,7 +66,8 @@ int haplocart(int argc, char **argv) {
     std::string gamfilename, fastafilename, fastq1, fastq2, samplename;
     bool invoked_samplename = false;
     double background_error_prob = 0.0001;
-    int n_threads = 1, device = 0;
+    int n_threads = 1, device = 0, gpus_wanted = 1;
+    std::vector<int> gpu_list;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](const char *flag) -> std::string {
@@ -98,7 +102,21 @@ int haplocart(int argc, char **argv) {
             n_threads = parse_int(need("-t"), "-t", "[HaploCart]");
             if (n_threads == 0 || n_threads < -1)
                 die("[HaploCart] Error, invalid number of threads"); // HaploCart.cpp:183-194
+            // the reference's thread count is this build's GPU count too: the OpenMP loop over reads (HaploCart.cpp:408)
+            // runs on min(N, visible GPUs) devices, the host side on N threads
+            gpus_wanted = n_threads;
             if (n_threads == -1) n_threads = 0;                      // all hardware threads
+        } else if (a == "--gpus") {
+            const std::string v = need("--gpus");
+            size_t p0 = 0;
+            while (p0 <= v.size()) {
+                size_t c1 = v.find(',', p0);
+                if (c1 == std::string::npos) c1 = v.size();
+                const int d = parse_int(v.substr(p0, c1 - p0), "--gpus", "[HaploCart]");
+                if (d < 0) die("[HaploCart] Error, --gpus needs non-negative GPU indices");
+                gpu_list.push_back(d);
+                p0 = c1 + 1;
+            }
         } else if (a == "-w") webapp = true;
         else if (a == "-z") (void)need("-z");
         else if (a == "--keep-duplicates") rmdup = false;
@@ -148,13 +166,33 @@ int haplocart(int argc, char **argv) {
     prm.background_error_prob = background_error_prob;
     prm.use_background_error_prob = !fastafilename.empty(); // HaploCart.cpp:397-400
     prm.is_consensus_fasta = !fastafilename.empty();
-    if (vgan_device_count() <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
-    vgan_hc_ctx *ctx = nullptr;
-    check(vgan_hc_create(&gv, &prm, device, &ctx), "creating the device context");
-    check(vgan_hc_set_mode(ctx, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS), "mode");
+    const int n_visible = vgan_device_count();
+    if (n_visible <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
+    if (gpu_list.empty()) {
+        const int k = gpus_wanted == -1 ? n_visible : std::min(gpus_wanted, n_visible);
+        if (k <= 1) gpu_list.push_back(device);
+        else
+            for (int d = 0; d < k; ++d) gpu_list.push_back(d);
+    }
+    struct Contexts { // one device context per entry of the list (an index may repeat: several contexts on one GPU)
+        std::vector<vgan_hc_ctx *> v;
+        ~Contexts() {
+            for (auto c : v) vgan_hc_destroy(c);
+        }
+    } ctxs;
+    for (int d : gpu_list) {
+        vgan_hc_ctx *c = nullptr;
+        check(vgan_hc_create(&gv, &prm, d, &c), "creating the device context");
+        ctxs.v.push_back(c);
+        check(vgan_hc_set_mode(c, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS), "mode");
+    }
+    vgan_hc_ctx *ctx = ctxs.v[0];
     pt.lap("device context");
 
-    const int64_t BATCH = 500000; // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i
+    // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i; with several GPUs the batches
+    // are dealt round-robin (smaller ones, so that a 1M-read input still reaches every GPU)
+    const int64_t BATCH = ctxs.v.size() > 1 ? std::max<int64_t>(50000, 500000 / (int64_t)ctxs.v.size()) : 500000;
+    size_t n_chunks = 0;
     struct DedupCloser {
         vgan_dedup *d = nullptr;
         ~DedupCloser() { vgan_dedup_free(d); }
@@ -190,7 +228,7 @@ int haplocart(int argc, char **argv) {
         check(vgan_hc_host_batch_get(hb, &b), "batch");
         // the copy out of the host batch completes inside the call (pageable memory is staged by the runtime); the
         // kernels run asynchronously while the next chunk is parsed and flattened on the host threads
-        rc = vgan_hc_accumulate(ctx, &b);
+        rc = vgan_hc_accumulate(ctxs.v[n_chunks++ % ctxs.v.size()], &b);
         vgan_hc_host_batch_free(hb);
         check(rc, "accumulate");
         tot.n_bad += st.n_bad;
@@ -210,7 +248,13 @@ int haplocart(int argc, char **argv) {
     if (tot.n_out == 0) // the reference goes on and reports path 0 from an all-zero vector: said aloud, even with -q
         std::cerr << "[HaploCart] warning: none of the " << n_in << " reads is mapped and usable; the prediction below rests on no evidence\n";
     std::vector<double> final_vec(gv.n_paths);
-    check(vgan_hc_finalize(ctx, nullptr, final_vec.data()), "finalize");
+    if (ctxs.v.size() == 1) {
+        check(vgan_hc_finalize(ctx, nullptr, final_vec.data()), "finalize");
+    } else { // HaploCart.cpp:419-420 across GPUs: one reduce of the P sums
+        int used_rccl = 0;
+        check(vgan_hc_reduce(ctxs.v.data(), (int)ctxs.v.size(), final_vec.data(), &used_rccl), "reduce");
+        if (!quiet) std::cerr << "Reduced the log-likelihoods of " << ctxs.v.size() << " device contexts (" << (used_rccl ? "RCCL" : "host") << ")." << '\n';
+    }
     pt.lap("flatten + kernels");
     const int maxh = vgan_hc_argmax(final_vec.data(), gv.n_paths); // HaploCart.cpp:423
     const std::string predicted = path_names[(size_t)maxh];
@@ -250,7 +294,6 @@ int haplocart(int argc, char **argv) {
         if (!quiet) std::cerr << "Writing log likelihoods to " << dbg << std::endl;
     }
     pt.lap("posterior + output");
-    vgan_hc_destroy(ctx);
     // the alignment set (GBs) and the graph are left to process exit: unmapping them page by page first costs ~0.1 s
     pt.lap("teardown");
     return 0;

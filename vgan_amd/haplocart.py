@@ -491,6 +491,16 @@ class HcContext:
         self.close()
 
 
+def reduce_contexts(ctxs):
+    """Sum of the contexts' final_vec through vgan_hc_reduce (RCCL between distinct GPUs, the host otherwise).
+    Returns (final_vec, used_rccl)."""
+    arr = (N.vp * len(ctxs))(*[c._h for c in ctxs])
+    out = np.zeros(ctxs[0].n_paths)
+    used = C.c_int(0)
+    N.check(N.lib().vgan_hc_reduce(arr, len(ctxs), out.ctypes.data, C.byref(used)))
+    return out, bool(used.value)
+
+
 def synth_graph(seed=0x76676131, genome_len=16569, n_nodes=11821, n_paths=5179):
     cfg = N.SynthGraphCfg(seed, genome_len, n_nodes, n_paths)
     h = N.vp()
