@@ -214,6 +214,26 @@ int vgan_reconstruct(const vgan_graph *g, const vgan_alnset *a, int64_t r, char 
                      int32_t *mppg_sizes, int64_t cap, int64_t *lens /* [3] */);
 
 /* ------------------------------------------------------------------------------------------------
+ * GBWT (the reference loads <dbprefix>.gbwt beside the ODGI graph and walks every path with gbwt->extract(),
+ * readOG_Euka.h:36-74).  Reads the file version `vg gbwt -o` of the reference's pinned vg writes (version 4, sdsl
+ * serialisation, with or without vg's "GBWT" type-tag framing); layout pinned on test/reconstructInputSeq/target_graph.gbwt
+ * against the P lines of target_graph.gfa, anything else is refused.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct vgan_gbwt vgan_gbwt; /* opaque */
+int vgan_gbwt_load(const char *path, vgan_gbwt **out);
+void vgan_gbwt_free(vgan_gbwt *g);
+int64_t vgan_gbwt_sequences(const vgan_gbwt *g);   /* threads; a bidirectional index holds 2 per path (forward 2k, reverse 2k+1) */
+int vgan_gbwt_bidirectional(const vgan_gbwt *g);
+/* gbwt::GBWT::extract(sequence): the thread's nodes in GBWT encoding (2 * node id + is_reverse).  Returns the length
+ * (writes at most cap entries; an id beyond the index extracts nothing, as in gbwt) or a negative error. */
+int64_t vgan_gbwt_extract(const vgan_gbwt *g, int64_t sequence, uint64_t *nodes, int64_t cap);
+/* The node x path matrix as readOG_Euka.h:55-73 fills it, quirks kept: extract(path_id) for path_id < n_paths (GBWT
+ * sequence ids, not path ids) and the ENCODED node numbers used as node ids (row = encoding - 1).  matrix: uint8
+ * [n_nodes][n_paths], row major.  The reference never reads the result beyond an emptiness check (the assignment into
+ * NodeInfo::pathsgo at :98 is commented out; soibean takes path membership from the ODGI's own paths, soibean.cpp:476-491). */
+int vgan_gbwt_node_path_matrix(const vgan_gbwt *g, int64_t n_nodes, int64_t n_paths, uint8_t *matrix);
+
+/* ------------------------------------------------------------------------------------------------
  * HaploCart device context.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct vgan_hc_ctx vgan_hc_ctx; /* opaque */

@@ -384,3 +384,70 @@ def test_gam_stream_chunks_equal_the_whole(tmp_path):
     with pytest.raises(Exception):
         for _ in hc.GamStream(bad).chunks(12000):
             pass
+
+
+def test_gbwt_reader_on_the_reference_fixture(golden_dir, tmp_path):
+    """vgan_gbwt_*: the threads of test/reconstructInputSeq/target_graph.gbwt are the P lines of target_graph.gfa (forward
+    at sequence 2k, reverse complement at 2k+1); the node x path matrix follows readOG_Euka.h:55-73 with its quirks; broken
+    files give an error code, never a crash."""
+    import ctypes as C
+    import random
+    L = N.load()
+    d = os.path.join(golden_dir, "reconstruct")
+    raw = open(os.path.join(d, "target_graph.gbwt"), "rb").read()
+    h = N.vp()
+    N.check(L.vgan_gbwt_load(os.path.join(d, "target_graph.gbwt").encode(), C.byref(h)))
+    _, paths = orc.read_gfa(os.path.join(d, "target_graph.gfa"))
+    assert L.vgan_gbwt_sequences(h) == 2 * len(paths) == 10 and L.vgan_gbwt_bidirectional(h) == 1
+
+    def extract(handle, s, cap=64):
+        buf = np.zeros(cap, np.uint64)
+        n = L.vgan_gbwt_extract(handle, s, buf.ctypes.data, cap)
+        assert 0 <= n <= cap
+        return [int(v) for v in buf[:n]]
+
+    for k, (_, steps) in enumerate(paths):
+        assert extract(h, 2 * k) == [2 * nid + int(rev) for nid, rev in steps]
+        assert extract(h, 2 * k + 1) == [2 * nid + 1 - int(rev) for nid, rev in reversed(steps)]
+    assert extract(h, 10) == [] and extract(h, -1) == []       # gbwt::GBWT::extract of an id beyond the index
+    assert L.vgan_gbwt_extract(h, 0, None, 0) == len(paths[0][1])  # length query
+    # readOG_Euka.h:55-73: sequences 0..4 (not paths 0..4), encoded numbers as node ids, row = number - 1
+    n_nodes, n_paths = 28, 5
+    m = np.zeros((n_nodes, n_paths), np.uint8)
+    N.check(L.vgan_gbwt_node_path_matrix(h, n_nodes, n_paths, m.ctypes.data))
+    want = np.zeros_like(m)
+    for p in range(n_paths):
+        for v in extract(h, p):
+            if 0 <= v - 1 < n_nodes:
+                want[v - 1, p] = 1
+    assert np.array_equal(m, want) and m.any() and not m[:, 1].all()
+    assert m[2 * 2 - 1, 0] == 1 and m[2 * 4 - 1, 0] == 1 and m[2 - 1, 0] == 0  # seq_1: 2+,4+,... -> rows 3, 7 (node "4", "8")
+    # the bare payload without vg's type tag reads the same
+    bare = str(tmp_path / "bare.gbwt")
+    open(bare, "wb").write(raw[8:])
+    h2 = N.vp()
+    N.check(L.vgan_gbwt_load(bare.encode(), C.byref(h2)))
+    assert [extract(h2, s) for s in range(10)] == [extract(h, s) for s in range(10)]
+    L.vgan_gbwt_free(h2)
+    L.vgan_gbwt_free(h)
+    # corrupted / truncated files
+    rng = random.Random(5)
+    n_err = 0
+    for trial in range(400):
+        data = bytearray(raw)
+        if trial % 2:
+            data = data[: rng.randrange(1, len(data))]
+        else:
+            for _ in range(rng.randrange(1, 6)):
+                data[rng.randrange(len(data))] = rng.randrange(256)
+        f = str(tmp_path / "bad.gbwt")
+        open(f, "wb").write(bytes(data))
+        hb = N.vp()
+        if L.vgan_gbwt_load(f.encode(), C.byref(hb)) < 0:
+            n_err += 1
+            continue
+        for s in range(10):  # whatever loads must walk to an end or report an error
+            buf = np.zeros(4096, np.uint64)
+            assert L.vgan_gbwt_extract(hb, s, buf.ctypes.data, 4096) <= 4096
+        L.vgan_gbwt_free(hb)
+    assert n_err > 150

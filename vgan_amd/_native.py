@@ -199,6 +199,12 @@ SYMBOLS = {
     "vgan_hc_segment_weights": (C.c_int, [vp, C.POINTER(HcBatch), vp]),
     "vgan_hc_read_loglik": (C.c_int, [vp, C.POINTER(HcBatch), vp]),
     "vgan_hc_finalize": (C.c_int, [vp, vp, vp]),
+    "vgan_gbwt_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "vgan_gbwt_free": (None, [vp]),
+    "vgan_gbwt_sequences": (C.c_int64, [vp]),
+    "vgan_gbwt_bidirectional": (C.c_int, [vp]),
+    "vgan_gbwt_extract": (C.c_int64, [vp, C.c_int64, vp, C.c_int64]),
+    "vgan_gbwt_node_path_matrix": (C.c_int, [vp, C.c_int64, C.c_int64, vp]),
     "vgan_hc_reduce": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.POINTER(C.c_int)]),
     "vgan_hc_synchronize": (C.c_int, [vp]),
     "vgan_hc_destroy": (None, [vp]),

@@ -1,14 +1,17 @@
 // Small helpers shared by the subcommands of the vgan CLI (plain clients of the C-ABI, include/vgan_gpu.h).
 #pragma once
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include <sys/stat.h>
 
@@ -117,5 +120,19 @@ struct PhaseTimer {
         t0 = t1;
     }
 };
+
+// <prefix>.gbwt beside a graph read from <prefix>.og: the reference loads it and walks every path (readOG_Euka.h:36-74) but
+// reads the result only for an emptiness check; an index that is there and cannot be read ends the run, as it does there.
+inline void check_gbwt_beside(const std::string &prefix, int64_t n_nodes, int64_t n_paths, const char *tool) {
+    const std::string f = prefix + ".gbwt";
+    if (!std::ifstream(f)) return;
+    vgan_gbwt *gb = nullptr;
+    if (vgan_gbwt_load(f.c_str(), &gb) < 0) die(std::string(tool) + " Error, cannot read " + f + ": " + vgan_last_error());
+    std::vector<uint8_t> m((size_t)std::max<int64_t>(0, n_nodes) * (size_t)std::max<int64_t>(0, n_paths));
+    const int rc = m.empty() ? 0 : vgan_gbwt_node_path_matrix(gb, n_nodes, n_paths, m.data());
+    vgan_gbwt_free(gb);
+    if (rc < 0) die(std::string(tool) + " Error, cannot walk the paths of " + f + ": " + vgan_last_error());
+    if (n_nodes == 0) die("Error: The node_path_matrix is empty. Unable to proceed."); // soibean.cpp:453-455
+}
 
 } // namespace vgan_cli

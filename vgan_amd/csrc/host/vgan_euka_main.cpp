@@ -5,8 +5,8 @@
 //             [-o PREFIX] [--out_dir DIR] [-t N] [--seed N] [--device N]
 //
 // Same flags, defaults, validation and output files as Euka::run.  What differs, and why:
-//   * the graph is read from <dbprefix>.gfa, or <dbprefix>.og by this build's own ODGI reader (no GBWT: nothing on this path
-//     needs the haplotype index);
+//   * the graph is read from <dbprefix>.gfa, or <dbprefix>.og by this build's own ODGI reader; a <dbprefix>.gbwt beside the
+//     .og is loaded and walked as readOG_Euka.h:36-74 does (its result is not used further there either);
 //   * FASTQ input needs vg giraffe in-process (src/map_giraffe.cpp): map with vg and pass the GAM with -g;
 //   * readGAM3's per-alignment lambda runs on the GPU (vgan_euka_*), the abundance MCMC in closed form on the host
 //     (vgan_euka_report); --seed N makes the chain reproducible (default 0 = std::random_device, as the reference).
@@ -169,6 +169,11 @@ int euka_main(int argc, char **argv) {
     std::cerr << "Reading in variation graph ..." << std::endl;
     Handle<vgan_graph> graph(vgan_graph_free);
     check(vgan_graph_load((prefix + graph_ext).c_str(), nullptr, &graph.p), "loading graph");
+    if (graph_ext == ".og") { // Euka.cpp:372,419: the haplotype index beside the graph
+        vgan_graph_view ggv;
+        check(vgan_graph_view_get(graph.p, &ggv), "graph view");
+        check_gbwt_beside(prefix, ggv.max_id - ggv.min_id + 1, ggv.n_paths, "[euka]");
+    }
     pt.lap("tables + graph");
 
     if (vgan_device_count() <= 0) die("[euka] no HIP device is visible: the per-read likelihood pass runs on the GPU only");

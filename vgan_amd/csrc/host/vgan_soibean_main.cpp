@@ -153,6 +153,8 @@ int soibean_main(int argc, char **argv) {
     vgan_graph_view gv;
     check(vgan_graph_view_get(graph.p, &gv), "graph view");
     if (gv.n_paths == 0) die("Error: The path_names vector is empty. Unable to proceed.");
+    if (gfa.size() > 3 && gfa.compare(gfa.size() - 3, 3, ".og") == 0) // soibean.cpp:446: the haplotype index beside the graph
+        check_gbwt_beside(sbdir + dbprefix, gv.max_id - gv.min_id + 1, gv.n_paths, "[soibean]");
     const std::vector<std::string> path_names = lines_of(gv.path_names, gv.n_paths);
 
     std::cerr << "Loading tree ... " << std::endl;
