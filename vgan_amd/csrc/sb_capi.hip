@@ -58,6 +58,8 @@ struct vgan_sb_ctx {
     Buf<double> sub5p, sub3p, qscore;
     Buf<double> pm;
     Buf<uint16_t> cnt;
+    Buf<double> stage_pm;    // read-major rows of one chunk of reads (sb_transpose_kernel moves them into pm / cnt)
+    Buf<uint16_t> stage_cnt;
     Buf<uint8_t> ok;
     Buf<unsigned long long> n_bad, guard;
     Buf<uint32_t> s32;
@@ -154,6 +156,8 @@ extern "C" void vgan_sb_destroy(vgan_sb_ctx *c) {
     c->qscore.release();
     c->pm.release();
     c->cnt.release();
+    c->stage_pm.release();
+    c->stage_cnt.release();
     c->ok.release();
     c->n_bad.release();
     c->guard.release();
@@ -265,7 +269,11 @@ extern "C" int vgan_sb_precompute(vgan_sb_ctx *c, const vgan_sb_batch *b, int64_
 #undef COPY
     }
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    launch_sb_precompute(c->g, d, c->t, c->n_bad.p, c->stream);
+    {
+        const uint32_t chunk = (uint32_t)std::min<size_t>(std::max<size_t>(R, 1), 65536);
+        if ((rc = c->stage_pm.reserve((size_t)chunk * c->P)) || (rc = c->stage_cnt.reserve((size_t)chunk * c->P * SB_NCNT))) return rc;
+        launch_sb_precompute(c->g, d, c->t, c->stage_pm.p, c->stage_cnt.p, chunk, c->n_bad.p, c->stream);
+    }
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     c->pending[0] = true;
     HIPCHK(hipGetLastError());

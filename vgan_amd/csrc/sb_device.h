@@ -53,8 +53,10 @@ struct SbFusedArgs {
     double con;
 };
 
-void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, unsigned long long *n_bad,
-                          hipStream_t st);
+// stage_pm: chunk_reads * n_paths doubles, stage_cnt: chunk_reads * 25 * n_paths uint16 of scratch (read-major rows of one
+// chunk of reads, transposed into the path-major tables chunk by chunk)
+void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, double *stage_pm, uint16_t *stage_cnt,
+                          uint32_t chunk_reads, unsigned long long *n_bad, hipStream_t st);
 void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states, uint32_t k, const SbSourceDev *src,
                        const double *hky /* [n_states*k][2][25] */, double *partial, uint32_t n_blocks, double *out,
                        double *out2 /* optional second copy of out */, unsigned long long *guard, hipStream_t st);

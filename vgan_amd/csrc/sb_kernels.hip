@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "device_math.h"
 #include "sb_device.h"
 
@@ -33,16 +35,18 @@ struct SbSegLds {
 };
 
 template <int PP>
-__global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDev g, SbBatchDev b, SbTablesDev t,
+__global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDev g, SbBatchDev b, SbTablesDev t, uint32_t r_begin,
+                                                                        uint32_t r_end, double *__restrict__ stage_pm,
+                                                                        uint16_t *__restrict__ stage_cnt,
                                                                         unsigned long long *n_bad) {
     __shared__ double qs_s[100];
     __shared__ SbSegLds seg_s[SBP_WAVES][64];
     for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = g.qscore[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t R = t.n_reads;
+    const uint32_t P = g.n_paths;
 
-    for (uint32_t r = blockIdx.x * SBP_WAVES + wave; r < b.n_reads; r += gridDim.x * SBP_WAVES) {
+    for (uint32_t r = r_begin + blockIdx.x * SBP_WAVES + wave; r < r_end; r += gridDim.x * SBP_WAVES) {
         const uint32_t s0 = b.read_seg_off[r], s1 = b.read_seg_off[r + 1];
         const uint32_t col0 = b.read_col_off[r];
         const uint32_t q0 = b.read_qual_off[r], QL = b.read_qual_off[r + 1] - q0;
@@ -150,14 +154,43 @@ __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDe
             t.ok[r] = bad ? 0 : 1;
             if (bad) atomicAdd(n_bad, 1ull);
         }
+        // Read-major staging rows [read][path] and [read][pair][path]: a lane's stores sit beside its neighbours' (one wave
+        // writes whole 128-byte lines).  Writing the path-major tables from here scattered 2-byte stores R * 50 bytes apart,
+        // which HBM took as one 32-byte write each (13.8x the table's size); sb_transpose_kernel brings the rows into place.
+        const size_t rl = r - r_begin;
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
             const uint32_t p = u * 64 + lane;
-            if (p < g.n_paths) {
-                t.pm[(size_t)p * R + r] = pm[u];
+            if (p < P) {
+                stage_pm[rl * P + p] = pm[u];
 #pragma unroll
-                for (int j = 0; j < (int)SB_NCNT; ++j) t.cnt[((size_t)p * SB_NCNT + j) * R + r] = (uint16_t)min(cnt[u][j], 65535u);
+                for (int j = 0; j < (int)SB_NCNT; ++j) stage_cnt[(rl * SB_NCNT + j) * P + p] = (uint16_t)min(cnt[u][j], 65535u);
             }
+        }
+    }
+}
+
+// out[(f % P) * ncnt + f / P][r_begin + r] = in[r][f] for r < n_r, f < F: the staging rows of a chunk of reads become columns of
+// the path-major tables (ncnt = 1: pm, F = P; ncnt = 25: cnt, F = 25 * P with f = pair * P + path).  64 x 64 tiles through LDS,
+// reads and writes both run along the fast axis of their array.
+template <class T>
+__global__ __launch_bounds__(256) void sb_transpose_kernel(const T *__restrict__ in, T *__restrict__ out, uint32_t n_r, uint32_t F,
+                                                            uint32_t P, uint32_t ncnt, uint32_t r_begin, uint32_t R) {
+    __shared__ T tile[64][64 + (sizeof(T) == 2 ? 2 : 1)];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+#pragma unroll 4
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t rl = wave * 16 + i, f = f0 + lane;
+        if (r0 + rl < n_r && f < F) tile[rl][lane] = in[(size_t)(r0 + rl) * F + f];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t fc = wave * 16 + i, f = f0 + fc;
+        if (f < F && r0 + lane < n_r) {
+            const uint32_t row = (f % P) * ncnt + f / P;
+            out[(size_t)row * R + r_begin + r0 + lane] = tile[lane][fc];
         }
     }
 }
@@ -463,15 +496,21 @@ void launch_sb_mixture(const SbTablesDev &t, uint32_t n, const int32_t *paths, d
     hipLaunchKernelGGL(sb_finish_kernel, dim3(1), dim3(64), 0, st, partial, n_blocks, 1u, out, (double *)nullptr);
 }
 
-void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, unsigned long long *n_bad,
-                          hipStream_t st) {
+void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, double *stage_pm, uint16_t *stage_cnt,
+                          uint32_t chunk_reads, unsigned long long *n_bad, hipStream_t st) {
     if (b.n_reads == 0) return;
-    const uint32_t blocks = min((b.n_reads + SBP_WAVES - 1) / SBP_WAVES, 256u * 8u);
-    const uint32_t pp = (g.n_paths + 63) / 64;
-    if (pp <= 1) hipLaunchKernelGGL(sb_precompute_kernel<1>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
-    else if (pp == 2) hipLaunchKernelGGL(sb_precompute_kernel<2>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
-    else if (pp == 3) hipLaunchKernelGGL(sb_precompute_kernel<3>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
-    else hipLaunchKernelGGL(sb_precompute_kernel<4>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, n_bad);
+    const uint32_t pp = (g.n_paths + 63) / 64, P = g.n_paths;
+    for (uint32_t r0 = 0; r0 < b.n_reads; r0 += chunk_reads) {
+        const uint32_t r1 = std::min(b.n_reads, r0 + chunk_reads), n = r1 - r0;
+        const uint32_t blocks = std::min((n + SBP_WAVES - 1) / SBP_WAVES, 256u * 8u);
+        if (pp <= 1) hipLaunchKernelGGL(sb_precompute_kernel<1>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad);
+        else if (pp == 2) hipLaunchKernelGGL(sb_precompute_kernel<2>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad);
+        else if (pp == 3) hipLaunchKernelGGL(sb_precompute_kernel<3>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad);
+        else hipLaunchKernelGGL(sb_precompute_kernel<4>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad);
+        hipLaunchKernelGGL(sb_transpose_kernel<double>, dim3((n + 63) / 64, (P + 63) / 64), dim3(256), 0, st, stage_pm, t.pm, n, P, P, 1u, r0, t.n_reads);
+        hipLaunchKernelGGL(sb_transpose_kernel<uint16_t>, dim3((n + 63) / 64, (P * SB_NCNT + 63) / 64), dim3(256), 0, st, stage_cnt, t.cnt, n,
+                           P * SB_NCNT, P, SB_NCNT, r0, t.n_reads);
+    }
 }
 
 void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky,
