@@ -245,6 +245,54 @@ def test_posterior_on_a_dag_and_on_childless_ancestors():
     assert got[n[7]] == pytest.approx(np.exp(2.5) / 12, rel=1e-12)
 
 
+def test_oracle_fed_without_any_product_loader(tmp_path):
+    """The loop most parity tests close -- oracle inputs built from the product's parsed arrays -- opened: 12 000 synthetic
+    reads are re-encoded into a GAM by the test-side writer (tests/gamio.py); the oracle reads that file with the test-side
+    decoder and the graph with the test-side GFA reader and its own sidecar loaders, the product reads both with its C++
+    front end.  A mis-parse shared by product and test views would be invisible elsewhere; here it shows."""
+    g0 = hc.synth_graph(seed=77, genome_len=3000, n_nodes=2100, n_paths=400)
+    a0 = hc.synth_reads(g0, 12_000, seed=78, read_len=100, indel_rate=0.05, softclip_rate=0.05, low_mapq_rate=0.3)
+    hcdir = tmp_path / "hcfiles"
+    hcdir.mkdir()
+    g0.write(str(hcdir))
+    gam = str(tmp_path / "reads.gam")
+    open(gam, "wb").write(gamio.write_gam(util.gamio_dicts_from_product(a0), group=300))
+    del a0
+    # oracle side: nothing of the product
+    og, names, parents, children = util.orc_graph_from_hcfiles(str(hcdir))
+    dicts = gamio.read_gam(gam)
+    assert len(dicts) == 12_000
+    oa = orc.AlnSet(dicts)
+    _, ref, n_bad = orc.hc_run(og, oa, n_threads=8, faithful=False)
+    # product side: its own loaders
+    g = hc.Graph.load(str(hcdir / "graph.gfa"), str(hcdir))
+    a = hc.AlnSet.read_gam(gam)
+    b = hc.HostBatch(g, a)
+    assert b.stats.n_bad == n_bad and b.n_reads + b.stats.n_bad + b.stats.n_unmapped == 12_000
+    assert g.path_names == names
+    ctx = hc.HcContext(g)
+    for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ):
+        ctx.reset()
+        ctx.set_mode(mode)
+        ctx.accumulate(b)
+        assert util.rel_err(ctx.finalize(), ref) < RTOL, mode
+    # per-read vectors against the literal per-path loops, and the posterior from the oracle's own relatives text
+    src = b.read_src
+    ll = ctx.read_loglik(hc.HostBatch(g, a, 0, 400))
+    sub = hc.HostBatch(g, a, 0, 400).read_src
+    for k in range(0, len(sub), 9):
+        rc, want, _ = orc.hc_read(og, oa, int(sub[k]))
+        assert rc == 0 and util.rel_err(ll[k], want.astype(np.float64)) < 1e-11, int(sub[k])
+    ctx.set_mode(hc.MODE_NODE_WEIGHTS)
+    fv = ctx.finalize()
+    pred = names[ctx.argmax(fv)]
+    got = ctx.posterior(fv, pred)
+    want = orc.hc_posterior(fv.astype(np.longdouble), names, parents, children, pred)
+    assert [x[0] for x in got] == [x[0] for x in want] and len(src) == b.n_reads
+    for (_, c1, _), (_, c2, _) in zip(got, want):
+        assert c1 == pytest.approx(c2, rel=1e-9, abs=1e-300)
+
+
 def test_full_size_graph_properties():
     """hcfiles-shaped graph (11821 nodes / 5179 paths), 20k reads of 150 bp: the three device modes agree, the
     accumulation is linear and order independent, device-resident batches equal host batches, and a read subset

@@ -83,3 +83,60 @@ def write_euka_db(db, g, directory, prefix="euka_db"):
     shutil.move(os.path.join(tmp, "graph.gfa"), base + ".gfa")
     shutil.rmtree(tmp)
     return base
+
+
+def orc_graph_from_hcfiles(directory):
+    """Oracle graph read from an hcfiles directory WITHOUT any product code: node sequences by the test-side GFA reader,
+    path_supports / parsed_pangenome_mapping / mappability.tsv / graph_paths by the oracle's restated loaders
+    (src/load.cpp:6-58,283-300).  Returns (orc.Graph, path names, parents text, children text)."""
+    import ctypes as C
+    import os
+
+    import gamio
+    L = orc.lib()
+
+    def raw(name):
+        for cand in (name, name + ".gz"):
+            p = os.path.join(directory, cand)
+            if os.path.exists(p):
+                b = open(p, "rb").read()
+                return gamio.gunzip_all(b) if b[:2] == b"\x1f\x8b" else b
+        raise FileNotFoundError(name)
+
+    node_seqs, _ = orc.read_gfa(os.path.join(directory, "graph.gfa"))
+    max_id = max(node_seqs)
+    names = [ln.split()[0] for ln in raw("graph_paths").decode().splitlines() if ln.strip()]
+    P = len(names)
+    rows = np.zeros((max_id + 1, P), np.uint8)
+    n = L.orc_load_path_supports(raw("path_supports"), C.c_int32(P), rows.ctypes.data_as(C.c_void_p), C.c_int64(max_id + 1))
+    assert n == max_id + 1
+    pb = np.full(max_id + 1, -1, np.int32)
+    L.orc_load_pangenome_map(raw("parsed_pangenome_mapping"), pb.ctypes.data_as(C.c_void_p), C.c_int64(max_id + 1))
+    mtxt = raw("mappability.tsv")
+    mp = np.zeros(1 << 16)
+    nm = L.orc_load_mappabilities(mtxt, mp.ctypes.data_as(C.c_void_p), C.c_int64(len(mp)))
+    if nm > len(mp):  # the loader reports the full count: size the table by it
+        mp = np.zeros(nm)
+        nm = L.orc_load_mappabilities(mtxt, mp.ctypes.data_as(C.c_void_p), C.c_int64(len(mp)))
+    assert 0 < nm <= len(mp)
+    return orc.Graph(node_seqs, P, rows, pb, mp[:nm].copy()), names, raw("parents.txt").decode(), raw("children.txt").decode()
+
+
+def gamio_dicts_from_product(a, r0=0, r1=None):
+    """The reads [r0, r1) of a product alignment set as gamio-style dicts (to be re-encoded by the test-side GAM writer)."""
+    arr = a.arrays()
+    r1 = a.n_reads if r1 is None else r1
+    out = []
+    for r in range(r0, r1):
+        maps = []
+        for m in range(arr["map_off"][r], arr["map_off"][r + 1]):
+            edits = [{"from_length": int(arr["e_from"][e]), "to_length": int(arr["e_to"][e]),
+                      "sequence": bytes(arr["e_seq"][arr["e_seq_off"][e]:arr["e_seq_off"][e + 1]])}
+                     for e in range(arr["edit_off"][m], arr["edit_off"][m + 1])]
+            maps.append({"position": {"node_id": int(arr["m_node"][m]), "offset": int(arr["m_offset"][m]), "is_reverse": bool(arr["m_rev"][m])},
+                         "edit": edits, "rank": len(maps) + 1})
+        out.append({"sequence": bytes(arr["seq"][arr["seq_off"][r]:arr["seq_off"][r + 1]]),
+                    "quality": bytes(arr["qual"][arr["qual_off"][r]:arr["qual_off"][r + 1]]),
+                    "mapping_quality": int(arr["mapq"][r]), "identity": float(arr["identity"][r]), "name": b"r%d" % r,
+                    "path": {"name": b"", "mapping": maps}})
+    return out
