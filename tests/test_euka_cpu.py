@@ -130,6 +130,50 @@ def test_oracle_closed_forms():
     assert bs[0, 0] == 1 and bs[1, 1 * 4 + 3] == 1 and bs[2, 2 * 4 + 2] == 1 and bs[9, 3 * 4 + 3] == 1 and bs.sum() == 10
 
 
+def test_oracle_reverse_strand_walks_the_damage_position_backwards():
+    """A fragment on the reverse strand: the graph sequence is the node's reverse complement and the damage position starts
+    at |sequence| - 1 and counts down (readGAM_Euka.h:208-216, 457-461), so column m uses subDeamDiNuc[L][L - 1 - m]: the
+    G>A end of the profile meets the FIRST columns, the C>T end the last ones."""
+    node = b"ACGTACGTACGTACGTACGTAC"
+    rc_node = node[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))  # GTACGTACGTACGTACGTACGT
+    g = _graph([node])
+    db = orc.EukaDb([0.07], [0, 1], [1], [1])
+    dmg = orc.OrcDamage(DHIGH5, DHIGH3)
+    read = bytearray(rc_node)
+    read[0] = ord("A")   # G>A at column 0 (position L-1: the 3' profile's first row)
+    read[21] = ord("T")  # the last column holds a T already; force a C>T two columns earlier instead
+    read[19] = ord("T")  # C>T at column 19 (position 2 from the 5' end)
+    read = bytes(read)
+    q = [35] * 22
+    edits = []
+    for i, (gb, rb) in enumerate(zip(rc_node, read)):
+        edits.append((1, 1, b"" if gb == rb else bytes([rb])))
+    a = orc.AlnSet([_mk(read, q, [(1, 0, True, edits)], mapq=60)])
+    o = orc.euka_run(g, a, db, dmg)
+    assert o["clade"][0] == 0 and o["n_bad"] == 0
+    d, e = mp.mpf("0.07"), mp.mpf(10) ** (-mp.mpf(35) / 10)
+    tT = lambda x, y: mp.mpf(1) if x == y else (mp.mpf("0.95238") if {x, y} in ({"A", "G"}, {"C", "T"}) else mp.mpf("0.02381"))
+    s5 = [mp.mpf(x) for x in ("0.329405", "0.221745", "0.187678", "0.161196", "0.144011")]
+    L_ = 22
+    tot1 = mp.mpf(0)
+    tot2 = mp.mpf(0)
+    for m, (gb, rb) in enumerate(zip(rc_node.decode(), read.decode())):
+        n = L_ - 1 - m
+        c2t5, g2a3 = s5[min(n, 4)], s5[min(L_ - n - 1, 4)]
+        M = {"A": {"A": 1}, "T": {"T": 1}, "C": {"C": 1 - c2t5, "T": c2t5}, "G": {"G": 1 - g2a3, "A": g2a3}}
+        pre = {b: (1 - d if b == gb else d * tT(gb, b)) for b in "ACGT"}
+        post = {b2: sum(pre[b1] * M[b1].get(b2, 0) for b1 in "ACGT") for b2 in "ACGT"}
+        tot1 += mp.log(sum(post[b] * ((1 - e) if b == rb else e / 3) for b in "ACGT"))
+        tot2 += mp.log(1 - mp.mpf("0.25536")) if gb == rb else mp.log(mp.mpf("0.25536"))
+    assert o["in_lik"][0] == pytest.approx(float(tot1), rel=1e-13)
+    assert o["out_lik"][0] == pytest.approx(float(tot2), rel=1e-13)
+    # the same read taken as a forward fragment over the reverse-complemented node differs: the positions run the other way
+    g2 = _graph([rc_node])
+    a2 = orc.AlnSet([_mk(read, q, [(1, 0, False, edits)], mapq=60)])
+    o2 = orc.euka_run(g2, a2, db, dmg)
+    assert o2["out_lik"][0] == pytest.approx(float(tot2), rel=1e-13) and abs(o2["in_lik"][0] - float(tot1)) > 0.1
+
+
 def test_oracle_special_columns():
     """N, gap (insertion + deletion), rare base, softclips, reverse strand walk."""
     g = _graph([b"ACGTNACGTRACGTACGTACGTAAAA", b"CCCC"])

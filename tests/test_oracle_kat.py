@@ -156,3 +156,91 @@ def test_posterior_counts_a_path_once_per_level_it_is_reached_at():
     got = dict((x[0], x[1]) for x in orc.hc_posterior(fv, n, parents, children, "p5"))
     tot = sum(mp.e ** float(v) for v in fv)
     assert got["p6"] == pytest.approx(float((mp.e ** -1 + 2 * mp.e ** -2 + 2 * mp.e ** -3) / tot), rel=1e-14)
+
+
+def _term(read_base, graph_base, q, pcm, match):
+    e = mp.mpf("0.25") if q <= 2 else mp.mpf(10) ** (-mp.mpf(q) / 10)
+    eps = e if read_base == graph_base else 1 - e
+    return mp.log((1 - pcm) * BG[read_base] + pcm * match * (1 - eps))
+
+
+def _lq(q):
+    return mp.log(mp.mpf("0.25") if q <= 2 else mp.mpf(10) ** (-mp.mpf(q) / 10))
+
+
+def test_mixed_supported_and_unsupported_mappings_per_path():
+    """Two mappings on two nodes, three paths: path 0 goes through both nodes, path 1 only through the first, path 2 only
+    through the second.  ll[p] = sum over mappings of (supported ? S_m : U_m) (process_mapping.cpp:54-88) with the Q4 / Q5
+    quirks: the second mapping compares its graph bases with the START of the read and sums its unsupported penalty over
+    a window of |algnseq| qualities starting at ITS offset, zero (Q = 0 -> 0.25) beyond the quality string."""
+    pathsgo = np.zeros((3, 3), np.uint8)
+    pathsgo[1, 0] = pathsgo[2, 0] = 1
+    pathsgo[1, 1] = 1
+    pathsgo[2, 2] = 1
+    g = orc.Graph({1: b"ACG", 2: b"ACT"}, 3, pathsgo, np.array([-1, 4000, 100], np.int32), np.full(17000, 1.0))
+    quals = [30, 31, 32, 33, 34, 35]
+    mappings = [{"position": {"node_id": 1, "offset": 0, "is_reverse": False}, "edit": [{"from_length": 3, "to_length": 3, "sequence": b""}], "rank": 1},
+                {"position": {"node_id": 2, "offset": 0, "is_reverse": False}, "edit": [{"from_length": 3, "to_length": 3, "sequence": b""}], "rank": 2}]
+    a = orc.AlnSet([{"sequence": b"ACGACT", "quality": bytes(quals), "mapping_quality": 50, "identity": 1.0, "name": b"r",
+                     "path": {"name": b"", "mapping": mappings}}])
+    rc, ll, _ = orc.hc_read(g, a, 0)
+    assert rc == 0
+    pcm = 1 - mp.mpf(10) ** -5
+    m1, m2 = mp.mpf(1), (1 - 30 * mp.mpf("1.64273e-7")) ** 8  # coordinate 4000: mu = 0 (Q2); 100: HVS-I
+    S1 = sum(_term(r, gb, q, pcm, m1) for r, gb, q in zip("ACG", "ACG", quals[0:3]))
+    S2 = sum(_term(r, gb, q, pcm, m2) for r, gb, q in zip("ACG", "ACT", quals[3:6]))  # Q4: read bases from the read start
+    U1 = sum(_lq(q) for q in quals)                       # window [0, 6)
+    U2 = sum(_lq(q) for q in quals[3:]) + 3 * _lq(0)      # window [3, 9): three qualities, three zero pads (Q5)
+    assert float(ll[0]) == pytest.approx(float(S1 + S2), rel=1e-13)
+    assert float(ll[1]) == pytest.approx(float(S1 + U2), rel=1e-13)
+    assert float(ll[2]) == pytest.approx(float(U1 + S2), rel=1e-13)
+
+
+def test_reverse_strand_mapping():
+    """A mapping on the reverse strand: the graph sequence is the node's reverse complement (vgan_utils.h:24 through
+    get_sequence of the reversed handle), compared base by base with the read."""
+    g = one_node_graph(b"AACGT", 5000)  # reverse complement ACGTT
+    a = orc.AlnSet([aln(b"ACGTT", [38] * 5, rev=True), aln(b"ACGAT", [38] * 5, rev=True,
+                                                           edits=[{"from_length": 3, "to_length": 3, "sequence": b""},
+                                                                  {"from_length": 1, "to_length": 1, "sequence": b"A"},
+                                                                  {"from_length": 1, "to_length": 1, "sequence": b""}])])
+    rc, ll, _ = orc.hc_read(g, a, 0)
+    pcm = 1 - mp.mpf(10) ** -6
+    assert float(ll[0]) == pytest.approx(float(sum(_term(b, b, 38, pcm, 1) for b in "ACGTT")), rel=1e-13)
+    rc, S, U, node = orc.hc_read_segments(g, a, 1)
+    # Q6: one mapping, three edits -> the mapping scores mppg_sizes[0] = 3 columns (all matches); the substitution is never seen
+    assert len(S) == 1 and S[0] == pytest.approx(float(sum(_term(b, b, 38, pcm, 1) for b in "ACG")), rel=1e-13)
+    assert U[0] == pytest.approx(float(5 * _lq(38)), rel=1e-13)
+
+
+def test_deletion_and_insertion_columns():
+    """Q7 / Q8: an insertion at running offset 0 is a softclip ('S' columns in the graph sequence), elsewhere a gap ('-');
+    a deletion puts '-' into the read string at the running from_length sum.  Columns with a non-ACGT base on either side
+    are skipped (process_mapping.cpp:62-63); the unsupported penalty still runs over the whole quality window."""
+    g = one_node_graph(b"ACGTAC", 4000)
+    # one mapping per edit so that every edit is scored (Q6 indexes the sizes per mapping)
+    def m(off, ed, rank):
+        return {"position": {"node_id": 1, "offset": off, "is_reverse": False}, "edit": [ed], "rank": rank}
+    quals = [30, 30, 30, 30, 30]
+    mappings = [m(0, {"from_length": 2, "to_length": 2, "sequence": b""}, 1),   # AC
+                m(2, {"from_length": 1, "to_length": 0, "sequence": b""}, 2),   # deletion of G
+                m(3, {"from_length": 0, "to_length": 1, "sequence": b"G"}, 3),  # insertion away from offset 0 -> '-'
+                m(3, {"from_length": 2, "to_length": 2, "sequence": b""}, 4)]   # TA
+    a = orc.AlnSet([{"sequence": b"ACGTA", "quality": bytes(quals), "mapping_quality": 60, "identity": 1.0, "name": b"r",
+                     "path": {"name": b"", "mapping": mappings}}])
+    rc, gs, rs, sizes = orc.reconstruct(g, a, 0)
+    assert rc == 0 and gs == b"ACG-TA" and list(sizes) == [2, 1, 1, 2]
+    assert rs == b"AC-GTA"  # Q8: the gap sits at the running sum of from_length (2)
+    rc, S, U, node = orc.hc_read_segments(g, a, 0)
+    pcm = 1 - mp.mpf(10) ** -6
+    t = lambda b: _term(b, b, 30, pcm, 1)
+    # segment 0: columns 0-1 vs read[0:2] = AC; 1: graph G vs read[0] = A (Q4), a mismatch at quality[2];
+    # 2: graph '-' is skipped; 3: graph TA vs read[0:2] = AC (Q4): two mismatches with qualities[4], beyond the string -> Q 0
+    assert S[0] == pytest.approx(float(t("A") + t("C")), rel=1e-13)
+    assert S[1] == pytest.approx(float(_term("A", "G", 30, pcm, 1)), rel=1e-13)
+    assert S[2] == 0.0
+    assert S[3] == pytest.approx(float(_term("A", "T", 30, pcm, 1) + _term("C", "A", 0, pcm, 1)), rel=1e-13)
+    # windows of |algnseq| = 6 qualities from each segment's start over a 5-byte string (Q5)
+    starts = [0, 2, 3, 4]
+    for k, s0 in enumerate(starts):
+        assert U[k] == pytest.approx(float((5 - s0) * _lq(30) + (6 - (5 - s0)) * _lq(0)), rel=1e-13), k

@@ -93,6 +93,18 @@ def test_oracle_closed_forms_forward_read():
     e2 = mp.log(mp.mpf("0.7") * (mp.mpf("0.4") * mp.e ** LL + mp.mpf("0.6") * mp.e ** LLP) +
                 mp.mpf("0.3") * (mp.mpf("0.25") * mp.e ** LLb + mp.mpf("0.75") * mp.e ** LLPb))
     assert ll2 == pytest.approx(float(e2), rel=1e-11)
+    # k = 3 mixture (BASELINE configs[4]): a third source on the same branch as the first with another position and length;
+    # the read's likelihood is sum_y theta_y * (pos_y e^LL_y + (1 - pos_y) e^LLP_y) (MCMC.cpp:868,967-974)
+    rc, ll3 = o.loglike([(0, 1, 0.03, 0.4, 0.5), (1, 0, 0.0, 0.25, 0.3), (0, 1, 0.012, 0.9, 0.2)], 0.01, FREQS)
+    assert rc == 0
+    tc = mp.mpf("0.012")
+    t1c, t2c = mp.mpf("0.9") * tc, tc - mp.mpf("0.9") * tc
+    LLc = mp.mpf(float(pm[0])) + sum(hky_mp(b, b, t2c, mp.mpf("0.01")) for b in refs)
+    LLPc = mp.mpf(float(pm[1])) + sum(hky_mp(b, b, t1c, mp.mpf("0.01")) for b in refs_p)
+    e3 = mp.log(mp.mpf("0.5") * (mp.mpf("0.4") * mp.e ** LL + mp.mpf("0.6") * mp.e ** LLP) +
+                mp.mpf("0.3") * (mp.mpf("0.25") * mp.e ** LLb + mp.mpf("0.75") * mp.e ** LLPb) +
+                mp.mpf("0.2") * (mp.mpf("0.9") * mp.e ** LLc + mp.mpf("0.1") * mp.e ** LLPc))
+    assert ll3 == pytest.approx(float(e3), rel=1e-11)
 
 
 def test_flatten_matches_oracle_slicing():
