@@ -40,7 +40,10 @@ enum {
 
 const char *vgan_last_error(void); /* thread-local message of the last failing call */
 int vgan_abi_version(void);
-int vgan_device_count(void);       /* number of visible HIP devices (0 if none) */
+int vgan_device_count(void);
+/* Brings the HIP runtime and the device up (the first HIP call of a process costs ~0.25 s): call it on a thread of its
+ * own while the graph loads.  Optional. */
+int vgan_device_warmup(int device);       /* number of visible HIP devices (0 if none) */
 
 /* ------------------------------------------------------------------------------------------------
  * Graph (host side).  Replaces bdsg::ODGI + NodeInfo[] + the hcfiles sidecars.

@@ -22,7 +22,7 @@ for ln in open(os.path.join(src, "bench_trace.log")):
 if bench:
     which = ("--mode %s" % bench["config"]["mode"]) if "mode" in bench["config"] else (
         "--path euka" if "euka" in bench["metric"] else "--path soibean --reads %d" % bench["config"].get("reads_per_gpu", 0))
-    lines += ["Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py %s --steps %d --warmup %d --cpu-seconds 0 --no-parity`"
+    lines += ["Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py %s --steps %d --warmup %d --cpu-seconds 0 --no-pmc --no-frontend`"
               % (which, bench["steps"], bench["warmup"]), "",
               "bench.py line under the profiler: value = %.4g %s, ms_per_step = %.4f" % (bench["value"], bench["unit"], bench["ms_per_step"]),
               "roofline (HIP events in bench.py): %s avg %.4f ms/launch, %.1f GB/s algorithmic = %.4f of 8 TB/s" % (

@@ -156,6 +156,7 @@ SYMBOLS = {
     "vgan_last_error": (C.c_char_p, []),
     "vgan_abi_version": (C.c_int, []),
     "vgan_device_count": (C.c_int, []),
+    "vgan_device_warmup": (C.c_int, [C.c_int]),
     "vgan_graph_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp)]),
     "vgan_graph_from_arrays": (C.c_int, [C.POINTER(GraphView), C.POINTER(vp)]),
     "vgan_graph_view_get": (C.c_int, [vp, C.POINTER(GraphView)]),

@@ -245,6 +245,16 @@ extern "C" int vgan_device_count(void) {
     return n;
 }
 
+// The first HIP call of a process loads the runtime and the library's code objects (~0.25 s): a front end calls this on a
+// thread of its own at start-up, while it reads its graph, so that the context creation finds the device ready.
+extern "C" int vgan_device_warmup(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(VGAN_ENODEV, "vgan_device_warmup: no HIP device %d", device);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(nullptr));
+    return VGAN_OK;
+}
+
 extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *params, int device, vgan_hc_ctx **out) {
     if (!gv || !params || !out) return fail(VGAN_EINVAL, "vgan_hc_create: null argument");
     if (gv->n_paths == 0 || gv->max_id < 0 || !gv->mask || !gv->pangenome_base || !gv->mappability)

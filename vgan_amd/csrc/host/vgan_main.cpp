@@ -142,6 +142,14 @@ int haplocart(int argc, char **argv) {
         ~StreamCloser() { vgan_gam_stream_close(s); }
     } stream;
     check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
+    // the HIP runtime comes up on a thread of its own while the graph is read (its failure shows at context creation)
+    struct Warm {
+        std::thread t;
+        ~Warm() {
+            if (t.joinable()) t.join();
+        }
+    } warm;
+    warm.t = std::thread([d = gpu_list.empty() ? device : gpu_list[0]] { (void)vgan_device_warmup(d); });
     vgan_graph *graph = nullptr;
     // graph.gfa when there is one, else the hcfiles' own graph.og (read natively: node sequences, path names, path membership)
     const std::string graphfile = hcfiledir + (std::ifstream(hcfiledir + "graph.gfa") ? "graph.gfa" : "graph.og");
@@ -166,6 +174,7 @@ int haplocart(int argc, char **argv) {
     prm.background_error_prob = background_error_prob;
     prm.use_background_error_prob = !fastafilename.empty(); // HaploCart.cpp:397-400
     prm.is_consensus_fasta = !fastafilename.empty();
+    if (warm.t.joinable()) warm.t.join();
     const int n_visible = vgan_device_count();
     if (n_visible <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
     if (gpu_list.empty()) {
