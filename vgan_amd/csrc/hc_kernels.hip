@@ -620,7 +620,15 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                     const double e = (q == 100 || prm.use_bep) ? prm.bep : g.qscore[q];
                     const double om = match ? 1.0 - e : e;
                     const bool deg = !(kl.kappa < 1e300); // wobs = 0: {inf, wbg}
-                    const double lx = log_tab(deg ? kl.lw * bgv : fma(kl.kappa, bgv, om), true, hc_log_table);
+                    // (the table log by hand: log_tab()'s series for values outside the normal range would park its
+                    // constants in scratch for the whole kernel)
+                    double x = deg ? kl.lw * bgv : fma(kl.kappa, bgv, om);
+                    double adj = 0.0;
+                    if (x < 2.2250738585072014e-308 && x > 0.0) { // subnormal
+                        x *= 18014398509481984.0; // 2^54
+                        adj = -37.429947750237048; // -54 ln 2
+                    }
+                    double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval(x, hc_log_table) + adj : x) : (x == 0.0 ? -INFINITY : __builtin_nan(""));
                     t = deg ? lx : kl.lw + lx;
                 }
                 if (valid) unsafeAtomicAdd(&segS_s[ls], t);
