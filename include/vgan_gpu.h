@@ -406,6 +406,11 @@ void vgan_euka_destroy(vgan_euka_ctx *c);
  * because its `(1/334)` is the integer 0 and log(frac * like) = log(frac) + log(like).  A read with like == 0 (mapq 0, or
  * exp underflow) makes the clade's sum -inf, as it does the reference's. */
 int vgan_euka_like_sums(vgan_euka_ctx *c, int64_t *n_like, double *sum_log_like);
+/* Several contexts (one per GPU, the reads dealt between them): vgan_euka_finalize + vgan_euka_like_sums of every context,
+ * summed -- the integer tables exactly.  Any output may be NULL.  (The per-read outputs of vgan_euka_accumulate are the
+ * caller's to put back in input order: readGAM3 hands them to the abundance chain per read, MCMC.cpp:1192-1193.) */
+int vgan_euka_reduce(vgan_euka_ctx **ctxs, int n, int32_t *clade_count, uint32_t *baseshift, double *bin_cov, int64_t *n_like,
+                     double *sum_log_like, int64_t *n_bad);
 
 /* ------------------------------------------------------------------------------------------------
  * euka downstream of the per-read pass (host only): the detected-clade list at the end of readGAM3

@@ -341,3 +341,33 @@ def test_vgan_euka_reads_its_gam_from_a_pipe(tmp_path):
     assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-500:], r2.stderr[-500:])
     a_, b_ = _tree(str(tmp_path / "f")), _tree(str(tmp_path / "p"))
     assert sorted(a_) == sorted(b_) and len(a_) >= 6 and all(a_[k] == b_[k] for k in a_)
+
+
+def test_vgan_euka_deals_the_fragments_to_several_device_contexts(tmp_path):
+    """`vgan euka --gpus 0,0,0` (three contexts sharing the one GPU of the test rig, a host thread each): the integer tables
+    add exactly and the per-read results go back in input order, so every output file equals the single-context run's (the
+    coverage sums are doubles added in another order: compared as numbers)."""
+    import subprocess
+    from test_sb_gpu import _same_tables
+    d = os.path.join(GOLD, "damageProfiles")
+    p5, p3 = d + "/dhigh5p.prof", d + "/dhigh3p.prof"
+    dm = ek.Damage.load(p5, p3)
+    g, db, a = ek.synth_euka(350_000, dm, seed=31, n_clades=12, nodes_per_clade=180)
+    util.write_euka_db(db, g, tmp_path)
+    gam = str(tmp_path / "reads.gam")
+    a.write_gam(gam)
+    exe = os.path.join(os.path.dirname(GOLD), "..", "vgan_amd", "bin", "vgan")
+    args = ["--entropy", "0", "--minBins", "2", "--minFrag", "40", "--outFrag", "-l", "4", "--no-mcmc", "--minMQ", "20", "-t", "-1"]
+    outs = {}
+    for tag, extra in (("one", []), ("three", ["--gpus", "0,0,0"])):
+        r = subprocess.run([exe, "euka", "-g", gam, "--euka_dir", str(tmp_path), "--deam5p", p5, "--deam3p", p3, "-o", str(tmp_path / tag)] + args + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("Summed the per-clade tables of 3 device contexts" in r.stderr) == (tag == "three")
+        outs[tag] = _tree(str(tmp_path / tag))
+        counts = [ln for ln in r.stderr.splitlines() if ln.startswith("Number of")]
+        outs[tag + "_counts"] = counts
+    assert outs["one_counts"] == outs["three_counts"] and sorted(outs["one"]) == sorted(outs["three"]) and len(outs["one"]) >= 6
+    for k in outs["one"]:
+        if outs["one"][k] != outs["three"][k]:  # only rounding of summed doubles may differ
+            _same_tables(outs["one"][k], outs["three"][k], 1e-9)

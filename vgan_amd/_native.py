@@ -230,6 +230,7 @@ SYMBOLS = {
     "vgan_euka_accumulate": (C.c_int, [vp, C.POINTER(EukaBatch), C.POINTER(EukaReadOut)]),
     "vgan_euka_finalize": (C.c_int, [vp, vp, vp, vp, vp]),
     "vgan_euka_kernel_ms": (C.c_int, [vp, vp, vp]),
+    "vgan_euka_reduce": (C.c_int, [C.POINTER(vp), C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_int64)]),
     "vgan_euka_like_sums": (C.c_int, [vp, vp, vp]),
     "vgan_euka_detect": (C.c_int, [C.POINTER(EukaDbView), vp, vp, C.POINTER(EukaDetectParams), vp, vp]),
     "vgan_euka_abundance_mcmc": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_uint64, vp]),

@@ -388,6 +388,49 @@ extern "C" int vgan_euka_like_sums(vgan_euka_ctx *c, int64_t *n_like, double *su
     return VGAN_OK;
 }
 
+// Several contexts (one per GPU) of one run: the per-clade accumulators of all of them, summed (counts,
+// base-shift tables and likelihood counts are integers and add exactly; bin coverage and log-likelihood sums are doubles).
+// The accumulators are a few hundred KB of five arrays of three types: each context finalizes on its device and the sum
+// is taken on the host (the HaploCart vector, one array of doubles, goes through RCCL in vgan_hc_reduce).
+extern "C" int vgan_euka_reduce(vgan_euka_ctx **ctxs, int n, int32_t *clade_count, uint32_t *baseshift, double *bin_cov,
+                                int64_t *n_like, double *sum_log_like, int64_t *n_bad) {
+    if (!ctxs || n <= 0) return fail(VGAN_EINVAL, "vgan_euka_reduce: null argument");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || ctxs[i]->n_clades != ctxs[0]->n_clades || ctxs[i]->n_bins != ctxs[0]->n_bins || ctxs[i]->ltp != ctxs[0]->ltp)
+            return fail(VGAN_EINVAL, "vgan_euka_reduce: contexts of different databases");
+    const vgan_euka_ctx *c0 = ctxs[0];
+    const size_t C_ = c0->n_clades, NB = c0->n_bins, BS = (size_t)c0->n_clades * 2 * (size_t)std::max(c0->ltp, 0) * 16;
+    std::vector<int32_t> cc(C_);
+    std::vector<uint32_t> bs(BS);
+    std::vector<double> bc(NB), sl(C_);
+    std::vector<int64_t> nl(C_);
+    if (clade_count) std::fill(clade_count, clade_count + C_, 0);
+    if (baseshift) std::fill(baseshift, baseshift + BS, 0u);
+    if (bin_cov) std::fill(bin_cov, bin_cov + NB, 0.0);
+    if (n_like) std::fill(n_like, n_like + C_, (int64_t)0);
+    if (sum_log_like) std::fill(sum_log_like, sum_log_like + C_, 0.0);
+    int64_t bad_total = 0;
+    for (int i = 0; i < n; ++i) {
+        int64_t bad = 0;
+        int rc = vgan_euka_finalize(ctxs[i], cc.data(), BS ? bs.data() : nullptr, NB ? bc.data() : nullptr, &bad);
+        if (rc) return rc;
+        if ((rc = vgan_euka_like_sums(ctxs[i], nl.data(), sl.data()))) return rc;
+        bad_total += bad;
+        for (size_t k = 0; k < C_; ++k) {
+            if (clade_count) clade_count[k] += cc[k];
+            if (n_like) n_like[k] += nl[k];
+            // a clade without reads holds 0 in a context; -inf (a read of likelihood 0) stays -inf in the sum
+            if (sum_log_like) sum_log_like[k] += sl[k];
+        }
+        if (baseshift)
+            for (size_t k = 0; k < BS; ++k) baseshift[k] += bs[k];
+        if (bin_cov)
+            for (size_t k = 0; k < NB; ++k) bin_cov[k] += bc[k];
+    }
+    if (n_bad) *n_bad = bad_total;
+    return VGAN_OK;
+}
+
 extern "C" int vgan_euka_kernel_ms(vgan_euka_ctx *c, double *ms, uint64_t *launches) {
     if (!c) return fail(VGAN_EINVAL, "vgan_euka_kernel_ms: null context");
     HIPCHK(hipSetDevice(c->device));

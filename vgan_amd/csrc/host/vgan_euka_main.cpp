@@ -11,6 +11,7 @@
 //   * readGAM3's per-alignment lambda runs on the GPU (vgan_euka_*), the abundance MCMC in closed form on the host
 //     (vgan_euka_report); --seed N makes the chain reproducible (default 0 = std::random_device, as the reference).
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -51,7 +52,9 @@ std::string euka_usage() {
            " Output options:\n"
            "   --outFrag         write the names of the fragments of every detected taxon\n"
            "   --outGroup [STR]  always write coverage, fragment lengths and profile of this taxon\n"
-           "   --device [INT]    GPU index (default 0)\n";
+           "   --device [INT]    GPU index (default 0)\n"
+           "   --gpus [LIST]     GPU indices, comma separated (default: -t N takes GPUs 0..N-1 of the visible ones, -t -1 all):\n"
+           "                     the fragments are dealt to one device context per entry, the per-clade tables are summed\n";
 }
 
 } // namespace
@@ -62,6 +65,8 @@ int euka_main(int argc, char **argv) {
     std::string deam5, deam3, out_group, out_dir;
     bool interleaved = false, run_mcmc = true, out_frag = false;
     int n_threads = 1, iter = 10000, burnin = 100, ltp = 5, device = 0; // Euka.cpp:171-190
+    int gpus_wanted = 1;
+    std::vector<int> gpu_list;
     int min_bins = 6, min_reads = 10, min_mq = 29, max_bins = 0;
     double entropy = 1.17;
     uint64_t seed = 0;
@@ -116,6 +121,7 @@ int euka_main(int argc, char **argv) {
             n_threads = parse_int(need("-t"), "-t", T);
             if (n_threads < -1 || n_threads == 0) die("[euka] Error, invalid number of threads"); // Euka.cpp:298
             const int hw = (int)std::thread::hardware_concurrency();
+            gpus_wanted = n_threads; // the thread count is this build's GPU count too (min(N, visible GPUs); -1 = all)
             if (n_threads == -1) n_threads = hw;
             else if (n_threads > hw) {
                 std::cerr << "[euka] Warning, specified number of threads is greater than the number available. Using " << hw << " threads\n";
@@ -131,6 +137,17 @@ int euka_main(int argc, char **argv) {
         else if (a == "--device") {
             device = parse_int(need("--device"), "--device", T);
             if (device < 0) die("[euka] Error, --device needs a non-negative GPU index");
+        } else if (a == "--gpus") { // GPU indices, comma separated: one device context (and host thread) each
+            const std::string v = need("--gpus");
+            size_t p0 = 0;
+            while (p0 <= v.size()) {
+                size_t c1 = v.find(',', p0);
+                if (c1 == std::string::npos) c1 = v.size();
+                const int d = parse_int(v.substr(p0, c1 - p0), "--gpus", T);
+                if (d < 0) die("[euka] Error, --gpus needs non-negative GPU indices");
+                gpu_list.push_back(d);
+                p0 = c1 + 1;
+            }
         } else die("[euka] Error, unrecognized option " + a);
     }
     (void)interleaved;
@@ -182,8 +199,24 @@ int euka_main(int argc, char **argv) {
     vgan_euka_params prm;
     prm.min_mapq = (uint32_t)min_mq;
     prm.length_to_prof = ltp;
-    Handle<vgan_euka_ctx> ctx(vgan_euka_destroy);
-    check(vgan_euka_create(&dv, &dmv, &prm, device, &ctx.p), "creating the device context");
+    const int n_visible = vgan_device_count();
+    if (gpu_list.empty()) {
+        const int k = gpus_wanted == -1 ? n_visible : std::min(gpus_wanted, n_visible);
+        if (k <= 1) gpu_list.push_back(device);
+        else
+            for (int d = 0; d < k; ++d) gpu_list.push_back(d);
+    }
+    struct Contexts {
+        std::vector<vgan_euka_ctx *> v;
+        ~Contexts() {
+            for (auto c : v) vgan_euka_destroy(c);
+        }
+    } ctxs;
+    for (int d : gpu_list) {
+        vgan_euka_ctx *c = nullptr;
+        check(vgan_euka_create(&dv, &dmv, &prm, d, &c), "creating the device context");
+        ctxs.v.push_back(c);
+    }
     pt.lap("device context");
 
     std::cerr << "Estimating clades: Please be patient! Depending on the size of your input file, this process can take some time." << std::endl;
@@ -200,44 +233,91 @@ int euka_main(int argc, char **argv) {
     std::vector<int64_t> name_off{0};
     std::string names;
     int64_t n_mapped = 0, n_bad = 0;
-    const int64_t BATCH = 1000000;
-    std::vector<int32_t> o_clade;
-    std::vector<double> o_d;
-    std::vector<uint8_t> o_pass;
-    for (int64_t r0 = 0; r0 < av.n_reads; r0 += BATCH) {
-        const int64_t r1 = std::min(av.n_reads, r0 + BATCH);
-        Handle<vgan_euka_host_batch> hb(vgan_euka_host_batch_free);
-        vgan_euka_flatten_stats st{};
-        check(vgan_euka_flatten(graph.p, aln.p, r0, r1, n_threads, &hb.p, &st), "flattening");
-        n_mapped += st.n_in - st.n_unmapped;
-        n_bad += st.n_bad;
-        vgan_euka_batch b;
-        check(vgan_euka_host_batch_get(hb.p, &b), "batch");
-        if (b.n_reads == 0) continue;
-        const size_t R = b.n_reads;
-        o_clade.resize(R);
-        o_d.resize(4 * R);
-        o_pass.resize(R);
-        vgan_euka_read_out out{o_clade.data(), o_d.data(), o_d.data() + R, o_d.data() + 2 * R, o_d.data() + 3 * R, o_pass.data()};
-        check(vgan_euka_accumulate(ctx.p, &b, &out), "accumulate");
-        for (size_t k = 0; k < R; ++k) {
-            read_clade.push_back(o_clade[k]);
-            read_pass.push_back(o_pass[k]);
-            read_len.push_back(b.read_seq_len[k]);
-            if (out_frag) {
-                const int64_t src = b.read_src[k];
+    // Batches of fragments in input order; with several contexts every context has a host thread of its own taking the
+    // next batch (vgan_euka_accumulate returns the per-read results, so it is synchronous), and the per-read results go
+    // back in batch order: readGAM3 hands them to the abundance chain per read (MCMC.cpp:1192-1193).
+    const size_t K = ctxs.v.size();
+    const int64_t BATCH = K > 1 ? std::max<int64_t>(100000, 1000000 / (int64_t)K) : 1000000;
+    const int64_t n_batches = (av.n_reads + BATCH - 1) / BATCH;
+    struct BatchOut {
+        std::vector<int32_t> clade;
+        std::vector<uint8_t> pass;
+        std::vector<uint16_t> len;
+        std::vector<int64_t> src;
+        int64_t n_mapped = 0, n_bad = 0;
+        std::string err;
+    };
+    std::vector<BatchOut> outs((size_t)n_batches);
+    std::atomic<int64_t> next_batch{0};
+    const int flat_threads = std::max(1, n_threads / (int)K);
+    auto worker = [&](size_t ci) {
+        std::vector<int32_t> o_clade;
+        std::vector<double> o_d;
+        std::vector<uint8_t> o_pass;
+        for (;;) {
+            const int64_t bi = next_batch.fetch_add(1);
+            if (bi >= n_batches) break;
+            BatchOut &o = outs[(size_t)bi];
+            const int64_t r0 = bi * BATCH, r1 = std::min(av.n_reads, r0 + BATCH);
+            vgan_euka_host_batch *hbp = nullptr;
+            vgan_euka_flatten_stats st{};
+            if (vgan_euka_flatten(graph.p, aln.p, r0, r1, flat_threads, &hbp, &st) < 0) {
+                o.err = std::string("flattening: ") + vgan_last_error();
+                break;
+            }
+            Handle<vgan_euka_host_batch> hb(vgan_euka_host_batch_free);
+            hb.p = hbp;
+            o.n_mapped = st.n_in - st.n_unmapped;
+            o.n_bad = st.n_bad;
+            vgan_euka_batch b;
+            if (vgan_euka_host_batch_get(hb.p, &b) < 0) {
+                o.err = std::string("batch: ") + vgan_last_error();
+                break;
+            }
+            if (b.n_reads == 0) continue;
+            const size_t R = b.n_reads;
+            o_clade.resize(R);
+            o_d.resize(4 * R);
+            o_pass.resize(R);
+            vgan_euka_read_out out{o_clade.data(), o_d.data(), o_d.data() + R, o_d.data() + 2 * R, o_d.data() + 3 * R, o_pass.data()};
+            if (vgan_euka_accumulate(ctxs.v[ci], &b, &out) < 0) {
+                o.err = std::string("accumulate: ") + vgan_last_error();
+                break;
+            }
+            o.clade.assign(o_clade.begin(), o_clade.end());
+            o.pass.assign(o_pass.begin(), o_pass.end());
+            o.len.assign(b.read_seq_len, b.read_seq_len + R);
+            if (out_frag) o.src.assign(b.read_src, b.read_src + R);
+        }
+    };
+    if (K == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t ci = 0; ci < K; ++ci) th.emplace_back(worker, ci);
+        for (auto &t : th) t.join();
+    }
+    for (const BatchOut &o : outs) {
+        if (!o.err.empty()) die("[vgan] " + o.err);
+        n_mapped += o.n_mapped;
+        n_bad += o.n_bad;
+        read_clade.insert(read_clade.end(), o.clade.begin(), o.clade.end());
+        read_pass.insert(read_pass.end(), o.pass.begin(), o.pass.end());
+        read_len.insert(read_len.end(), o.len.begin(), o.len.end());
+        if (out_frag)
+            for (int64_t src : o.src) {
                 names.append(av.name + av.name_off[src], (size_t)(av.name_off[src + 1] - av.name_off[src]));
                 name_off.push_back((int64_t)names.size());
             }
-        }
     }
     std::vector<int32_t> clade_count(dv.n_clades);
     std::vector<uint32_t> baseshift((size_t)dv.n_clades * 2 * std::max(ltp, 1) * 16);
     std::vector<double> bin_cov(dv.bin_off[dv.n_clades]), sum_log_like(dv.n_clades);
     std::vector<int64_t> n_like(dv.n_clades);
     int64_t n_bad_dev = 0;
-    check(vgan_euka_finalize(ctx.p, clade_count.data(), baseshift.data(), bin_cov.data(), &n_bad_dev), "finalize");
-    check(vgan_euka_like_sums(ctx.p, n_like.data(), sum_log_like.data()), "likelihood sums");
+    check(vgan_euka_reduce(ctxs.v.data(), (int)K, clade_count.data(), baseshift.data(), bin_cov.data(), n_like.data(), sum_log_like.data(),
+                           &n_bad_dev), "finalize");
+    if (K > 1) std::cerr << "Summed the per-clade tables of " << K << " device contexts." << std::endl;
     pt.lap("flatten + kernels");
     std::cerr << " .. done!" << std::endl;
     int64_t passed = 0;
