@@ -263,6 +263,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
     return v;
 }
+// A C T G -> 0 8 16 24 (byte offsets into the background table), anything else 32
+__device__ __forceinline__ uint32_t base_code8(uint32_t b) {
+    const uint32_t d = b - 65u;
+    const bool ok = d < 20u && ((0x80045u >> d) & 1u);
+    return ok ? ((b << 2) & 24u) : 32u;
+}
+
 template <int ST_READS>
 __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
                                                                       uint32_t n_tileable, uint32_t reads_per_block,
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 const uint32_t fw = flags_s[w] & lanemask;
                 const uint32_t below = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)wordbase);
                 const uint32_t own = (uint32_t)__builtin_popcount(fw) + below; // head bits at or below the column, less one
-                const uint32_t gcode = code_s[gseq_s[c + cshift]];
+                const uint32_t gcode = base_code8(gseq_s[c + cshift]);
                 // every LDS read below is unconditional (indices in range, results selected afterwards): the reads of one
                 // column then overlap instead of each waiting behind its own branch
                 const uint32_t ls = own & ((uint32_t)ST_SEGS - 1u);
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 const bool in_seg = (int)own >= 0 && c < cend; // columns no mapping scores (Q6 tail) have no owner
                 const uint32_t ri = min((uint32_t)((int)c + geo.rshift), (uint32_t)ST_COLS + 7u);
                 const uint32_t qi = min((uint32_t)((int)c + geo.qshift), (uint32_t)ST_QUAL + 7u);
-                const uint32_t rcode = code_s[rseq_s[ri]];
+                const uint32_t rcode = base_code8(rseq_s[ri]);
                 int q = (int)(int8_t)qual_s[qi];
                 if constexpr (GEN) q = c < geo.qend ? q : 0;
                 q = q < 0 ? 0 : (q > 99 ? 99 : q);               // qscore_vec's index
