@@ -451,3 +451,4 @@ def test_gbwt_reader_on_the_reference_fixture(golden_dir, tmp_path):
             assert L.vgan_gbwt_extract(hb, s, buf.ctypes.data, 4096) <= 4096
         L.vgan_gbwt_free(hb)
     assert n_err > 150
+

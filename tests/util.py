@@ -137,6 +137,7 @@ def gamio_dicts_from_product(a, r0=0, r1=None):
                          "edit": edits, "rank": len(maps) + 1})
         out.append({"sequence": bytes(arr["seq"][arr["seq_off"][r]:arr["seq_off"][r + 1]]),
                     "quality": bytes(arr["qual"][arr["qual_off"][r]:arr["qual_off"][r + 1]]),
-                    "mapping_quality": int(arr["mapq"][r]), "identity": float(arr["identity"][r]), "name": b"r%d" % r,
+                    "mapping_quality": int(arr["mapq"][r]), "identity": float(arr["identity"][r]),
+                    "name": bytes(arr["name"][arr["name_off"][r]:arr["name_off"][r + 1]]),
                     "path": {"name": b"", "mapping": maps}})
     return out
