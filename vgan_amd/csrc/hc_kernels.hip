@@ -174,6 +174,7 @@ constexpr int ST_COLS = 1280; // LDS capacity per tile: alignment columns,
 constexpr int ST_QUAL = 1280; //                        quality bytes,
 constexpr int ST_SEGS = 512;  //                        segments
 constexpr int ST_WIN = 448;   // node ids covered by the workgroup's W window (what 40 KB of LDS per workgroup leave)
+constexpr int ST_WIN_SHORT = 288; // ... in the short-read variant
 constexpr int ST_QB = ST_QUAL / ST_THREADS;         // quality bytes per lane in phase B
 constexpr int ST_QW = ST_QB * 64;                   // quality bytes per wave in phase B
 constexpr int ST_SEG_ITERS = ST_SEGS / ST_THREADS;  // segments per lane in phases C and E
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     __shared__ StTile tile_s[2];
     __shared__ uint32_t tilebits_s[4]; // [0] bit 0: a segment takes the background error rate on its own; [1] lowest node id
                                        // (when the window is to be placed); [3] the tile left the window
-    __shared__ double win_s[ST_WIN];   // W[winbase .. winbase + ST_WIN) of this workgroup's reads
+    constexpr int WIN = ST_READS <= 8 ? ST_WIN : ST_WIN_SHORT; // (the 24-read variant holds more header: a smaller window keeps it at 4 workgroups per CU)
+    __shared__ double win_s[WIN];      // W[winbase .. winbase + WIN) of this workgroup's reads
 
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 256; i += ST_THREADS) lq_s[i] = g.lq[i];
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         lom_s[qi][i & 1] = StLom{log_pos(om), 1.0 / om};
     }
     for (int i = tid; i < 256; i += ST_THREADS) code_s[i] = is_acgt((uint32_t)i) ? (uint8_t)(((i >> 1) & 3) << 3) : (uint8_t)32;
-    for (int i = tid; i < ST_WIN; i += ST_THREADS) win_s[i] = 0.0;
+    for (int i = tid; i < WIN; i += ST_THREADS) win_s[i] = 0.0;
     if (tid < 5) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : tid == 3 ? 0.16644 : 0.25; // A C T G by (c>>1)&3
     const double lq0 = g.lq[0];
     double sumT = 0.0, sumU = 0.0; // sum of the column terms (= sum of S_m) and of U_m, each without cancellation
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     };
     // the window's content goes to W in HBM (the slots stay zero otherwise: no atomic for them)
     auto window_flush = [&]() {
-        for (uint32_t j = tid; j < (uint32_t)ST_WIN; j += ST_THREADS) {
+        for (uint32_t j = tid; j < (uint32_t)WIN; j += ST_THREADS) {
             const double v = win_s[j];
             if (v != 0.0) {
                 unsafeAtomicAdd(&nodeW[winbase + j], v);
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 if (segD_out) segD_out[T.seg_base + ls] = D;
                 if (nodeW) {
                     const uint32_t slot = L.node[it] - winbase;
-                    if (slot < (uint32_t)ST_WIN) {
+                    if (slot < (uint32_t)WIN) {
                         unsafeAtomicAdd(&win_s[slot], D);
                     } else {
                         unsafeAtomicAdd(&nodeW[L.node[it]], D);
