@@ -293,6 +293,55 @@ def test_oracle_fed_without_any_product_loader(tmp_path):
         assert c1 == pytest.approx(c2, rel=1e-9, abs=1e-300)
 
 
+def _permuted_batch(arr, order, n_tileable):
+    """The reads of a flattened batch in another order (offsets rebuilt), as a hand-built host batch."""
+    so, co, qo = arr["read_seg_off"], arr["read_col_off"], arr["read_qual_off"]
+    out = {k: [] for k in ("seg_node", "seg_start", "seg_len", "graph_seq", "algnseq", "qual")}
+    nso, nco, nqo = [0], [0], [0]
+    for r in order:
+        for k in ("seg_node", "seg_start", "seg_len"):
+            out[k].append(arr[k][so[r]:so[r + 1]])
+        for k in ("graph_seq", "algnseq"):
+            out[k].append(arr[k][co[r]:co[r + 1]])
+        out["qual"].append(arr["qual"][qo[r]:qo[r + 1]])
+        nso.append(nso[-1] + int(so[r + 1] - so[r]))
+        nco.append(nco[-1] + int(co[r + 1] - co[r]))
+        nqo.append(nqo[-1] + int(qo[r + 1] - qo[r]))
+    arrays = {k: np.concatenate(v) for k, v in out.items()}
+    arrays.update(read_seg_off=nso, read_col_off=nco, read_qual_off=nqo, read_algn_len=arr["read_algn_len"][order], read_mapq=arr["read_mapq"][order])
+    return hc.ArrayBatch(arrays, n_tileable=n_tileable)
+
+
+def test_any_read_order_gives_the_same_sums():
+    """The tiled kernel keeps W[node] of a workgroup's reads in an LDS window placed at the lowest node id of its first tile and
+    expects the batch sorted by node id (vgan_hc_flatten does that).  A batch in any other order -- shuffled, descending, two
+    far-apart regions interleaved (every tile leaves the window: segments go to W in HBM directly and the window is placed
+    anew) -- must give the same final vector."""
+    g = hc.synth_graph(seed=41, genome_len=9000, n_nodes=6400, n_paths=150)
+    a = hc.synth_reads(g, 30_000, seed=2, read_len=150)
+    b = hc.HostBatch(g, a)
+    assert b.n_tileable == b.n_reads
+    arr = {k: np.array(v) for k, v in b.arrays().items() if k != "_owner"}
+    ctx = hc.HcContext(g)
+    ctx.accumulate(b)
+    want = ctx.finalize()
+    n = b.n_reads
+    rng = np.random.default_rng(9)
+    orders = {"shuffled": rng.permutation(n), "descending": np.arange(n)[::-1],
+              "interleaved": np.stack([np.arange(n // 2), np.arange(n // 2) + n // 2], 1).ravel()}
+    for name, order in orders.items():
+        pb = _permuted_batch(arr, order, len(order))
+        ctx.validate(pb)
+        for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ):
+            ctx.reset()
+            ctx.set_mode(mode)
+            ctx.accumulate(pb)
+            got = ctx.finalize()
+            if len(order) == n:
+                assert util.rel_err(got, want) < 1e-11, (name, mode)
+    ctx.set_mode(hc.MODE_NODE_WEIGHTS)
+
+
 def test_full_size_graph_properties():
     """hcfiles-shaped graph (11821 nodes / 5179 paths), 20k reads of 150 bp: the three device modes agree, the
     accumulation is linear and order independent, device-resident batches equal host batches, and a read subset
