@@ -223,6 +223,8 @@ int load(const std::string &raw, vgan_gbwt &g) {
     if (g.alphabet_size <= g.offset || g.alphabet_size - g.offset > ((uint64_t)1 << 32)) return fail(VGAN_EIO, "gbwt: implausible alphabet");
     const uint64_t records = c.get<uint64_t>();
     if (!c.ok || records != g.alphabet_size - g.offset) return fail(VGAN_EIO, "gbwt: record count does not match the alphabet");
+    // the record index spends at least one bit per record: a count the file cannot hold is a corrupt header, not an allocation
+    if (records > (uint64_t)(c.end - c.p) * 8) return fail(VGAN_EIO, "gbwt: %llu records in a file of %zu bytes", (unsigned long long)records, payload.size());
     // sd_vector over the record starts
     const uint64_t sd_size = c.get<uint64_t>();
     const unsigned wl = c.get<uint8_t>();
@@ -274,11 +276,15 @@ extern "C" int vgan_gbwt_load(const char *path, vgan_gbwt **out) {
     if (!path || !out) return fail(VGAN_EINVAL, "vgan_gbwt_load: null argument");
     std::string raw;
     if (!read_file(path, raw)) return fail(VGAN_EIO, "cannot read %s", path);
-    auto g = std::make_unique<vgan_gbwt>();
-    const int rc = load(raw, *g);
-    if (rc) return rc;
-    *out = g.release();
-    return VGAN_OK;
+    try {
+        auto g = std::make_unique<vgan_gbwt>();
+        const int rc = load(raw, *g);
+        if (rc) return rc;
+        *out = g.release();
+        return VGAN_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VGAN_ENOMEM, "gbwt: out of memory reading %s", path);
+    }
 }
 
 extern "C" void vgan_gbwt_free(vgan_gbwt *g) { delete g; }
