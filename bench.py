@@ -419,6 +419,9 @@ def collect_traffic(args, kernel_substr):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    # a run that is itself being profiled (someone else's rocprofv3 around bench.py) does not start a profiler of its own
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     raw = {}
     tmp = tempfile.mkdtemp(prefix="vgan_pmc_")
     try:
@@ -430,7 +433,7 @@ def collect_traffic(args, kernel_substr):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             if r.returncode != 0:
                 return None
             vals = []
