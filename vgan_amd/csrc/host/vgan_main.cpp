@@ -16,11 +16,16 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <mutex>
+#include <deque>
+#include <condition_variable>
 #include <iostream>
 #include <numeric>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <unistd.h>
 
 #include "vgan_gpu.h"
 
@@ -135,6 +140,12 @@ int haplocart(int argc, char **argv) {
     if (!invoked_samplename) samplename = !fastafilename.empty() ? fastafilename : gamfilename;
 
     PhaseTimer pt("haplocart");
+    const auto t_start = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) { // VGAN_TIMING: time since the subcommand started
+        if (getenv("VGAN_TIMING"))
+            fprintf(stderr, "[vgan timing] haplocart @ %.0f ms: %s\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
+    };
     // the GAM is inflated, framed and parsed behind this thread (vgan_gam_stream) while it loads the graph and brings the
     // device up; chunks are then flattened and sent to the device as they become available
     struct StreamCloser {
@@ -155,6 +166,7 @@ int haplocart(int argc, char **argv) {
     const std::string graphfile = hcfiledir + (std::ifstream(hcfiledir + "graph.gfa") ? "graph.gfa" : "graph.og");
     check(vgan_graph_load(graphfile.c_str(), hcfiledir.c_str(), &graph), "loading graph");
     pt.lap("graph load");
+    stamp("graph loaded");
     vgan_graph_view gv;
     check(vgan_graph_view_get(graph, &gv), "graph view");
     std::vector<std::string> path_names;
@@ -189,18 +201,45 @@ int haplocart(int argc, char **argv) {
             for (auto c : v) vgan_hc_destroy(c);
         }
     } ctxs;
-    for (int d : gpu_list) {
-        vgan_hc_ctx *c = nullptr;
-        check(vgan_hc_create(&gv, &prm, d, &c), "creating the device context");
-        ctxs.v.push_back(c);
-        check(vgan_hc_set_mode(c, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS), "mode");
-    }
-    vgan_hc_ctx *ctx = ctxs.v[0];
-    pt.lap("device context");
+    // the contexts come up on a thread of their own (mask transposition, uploads: ~0.2 s) while this one already flattens
+    // the first chunk of reads, which needs the graph only
+    struct Creator {
+        std::thread t;
+        std::string err;
+        ~Creator() {
+            if (t.joinable()) t.join();
+        }
+    } creator;
+    creator.t = std::thread([&] {
+        for (int d : gpu_list) {
+            vgan_hc_ctx *c = nullptr;
+            if (vgan_hc_create(&gv, &prm, d, &c) < 0 ||
+                vgan_hc_set_mode(c, per_read ? VGAN_HC_MODE_PER_READ : VGAN_HC_MODE_NODE_WEIGHTS) < 0) {
+                creator.err = std::string("[vgan] creating the device context: ") + vgan_last_error();
+                if (c) vgan_hc_destroy(c);
+                return;
+            }
+            ctxs.v.push_back(c);
+        }
+    });
+    std::once_flag creator_joined;
+    auto contexts_ready_quiet = [&] { // from any thread
+        std::call_once(creator_joined, [&] {
+            if (creator.t.joinable()) creator.t.join();
+        });
+    };
+    auto contexts_ready = [&] {
+        contexts_ready_quiet();
+        if (!creator.err.empty()) die(creator.err);
+    };
+    const size_t n_ctx = gpu_list.size();
 
     // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i; with several GPUs the batches
     // are dealt round-robin (smaller ones, so that a 1M-read input still reaches every GPU)
-    const int64_t BATCH = ctxs.v.size() > 1 ? std::max<int64_t>(50000, 500000 / (int64_t)ctxs.v.size()) : 500000;
+    // (small enough that flattening runs behind the decoder instead of waiting for half a million reads -- the last chunk's
+    // flatten, not the sum of them, is what follows the end of the decode -- and large enough to keep 32 flatten threads busy:
+    // the parser's slices of 8192 reads are the unit of work)
+    const int64_t BATCH = n_ctx > 1 ? std::max<int64_t>(50000, 500000 / (int64_t)n_ctx) : 262144;
     size_t n_chunks = 0;
     struct DedupCloser {
         vgan_dedup *d = nullptr;
@@ -211,10 +250,66 @@ int haplocart(int argc, char **argv) {
     int64_t n_in = 0, n_dup = 0;
     std::vector<uint8_t> dup;
     vgan_hc_flatten_stats tot{};
+    // flattened chunks -> device, in order, on a thread of its own (at most two chunks wait: the host batches are large)
+    struct Uploader {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<vgan_hc_host_batch *> q;
+        bool closed = false;
+        std::string err;
+        std::thread t;
+        void push(vgan_hc_host_batch *hb) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return q.size() < 2 || !err.empty(); });
+            q.push_back(hb);
+            cv.notify_all();
+        }
+        std::string error() {
+            std::lock_guard<std::mutex> lk(mu);
+            return err;
+        }
+        void close() {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                closed = true;
+            }
+            cv.notify_all();
+            if (t.joinable()) t.join();
+        }
+        ~Uploader() {
+            close();
+            for (auto hb : q) vgan_hc_host_batch_free(hb);
+        }
+    } uploader;
+    uploader.t = std::thread([&] {
+        for (;;) {
+            vgan_hc_host_batch *hb = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(uploader.mu);
+                uploader.cv.wait(lk, [&] { return !uploader.q.empty() || uploader.closed; });
+                if (uploader.q.empty()) return;
+                hb = uploader.q.front();
+            }
+            std::string err;
+            vgan_hc_batch b;
+            if (vgan_hc_host_batch_get(hb, &b) < 0) err = std::string("[vgan] batch: ") + vgan_last_error();
+            if (err.empty()) {
+                contexts_ready_quiet();
+                if (!creator.err.empty()) err = creator.err;
+                else if (vgan_hc_accumulate(ctxs.v[n_chunks++ % ctxs.v.size()], &b) < 0) err = std::string("[vgan] accumulate: ") + vgan_last_error();
+            }
+            vgan_hc_host_batch_free(hb);
+            std::lock_guard<std::mutex> lk(uploader.mu);
+            uploader.q.pop_front();
+            if (!err.empty() && uploader.err.empty()) uploader.err = err;
+            uploader.cv.notify_all();
+        }
+    });
     for (;;) {
         vgan_alnparts *chunk = nullptr;
         check(vgan_gam_stream_next(stream.s, BATCH, &chunk), "reading GAM");
         if (!chunk) break;
+        if (n_in == 0) stamp("first chunk of reads decoded");
         const int64_t nr = vgan_alnparts_n_reads(chunk);
         n_in += nr;
         const uint8_t *skip = nullptr;
@@ -233,17 +328,20 @@ int haplocart(int argc, char **argv) {
         int rc = vgan_hc_flatten_parts(graph, chunk, 0, vgan_alnparts_count(chunk), skip, n_threads, &hb, &st);
         vgan_alnparts_free(chunk);
         check(rc, "flattening");
-        vgan_hc_batch b;
-        check(vgan_hc_host_batch_get(hb, &b), "batch");
-        // the copy out of the host batch completes inside the call (pageable memory is staged by the runtime); the
-        // kernels run asynchronously while the next chunk is parsed and flattened on the host threads
-        rc = vgan_hc_accumulate(ctxs.v[n_chunks++ % ctxs.v.size()], &b);
-        vgan_hc_host_batch_free(hb);
-        check(rc, "accumulate");
+        // the copy out of a (pageable) host batch completes inside vgan_hc_accumulate: the uploader thread makes that call
+        // while this one goes on to flatten the next chunk; the kernels run asynchronously behind both
+        uploader.push(hb);
+        if (!uploader.error().empty()) die(uploader.error());
         tot.n_bad += st.n_bad;
         tot.n_unmapped += st.n_unmapped;
         tot.n_out += st.n_out;
     }
+    stamp("last chunk flattened");
+    uploader.close();
+    if (!uploader.err.empty()) die(uploader.err);
+    stamp("last chunk on the device");
+    contexts_ready();
+    vgan_hc_ctx *ctx = ctxs.v[0];
     if (n_in == 0) die("[HaploCart] Error, no reads mapped"); // HaploCart.cpp:384-385
     int64_t n_reads = n_in - n_dup;
     if (!quiet) {
@@ -303,6 +401,7 @@ int haplocart(int argc, char **argv) {
         if (!quiet) std::cerr << "Writing log likelihoods to " << dbg << std::endl;
     }
     pt.lap("posterior + output");
+    stamp("output written");
     // the alignment set (GBs) and the graph are left to process exit: unmapping them page by page first costs ~0.1 s
     pt.lap("teardown");
     return 0;
@@ -326,9 +425,15 @@ int main(int argc, char **argv) {
             return 1;
         }
         const std::string cmd = argv[1];
-        if (cmd == "haplocart") return haplocart(argc - 1, argv + 1);
-        if (cmd == "euka") return euka_main(argc - 1, argv + 1);
-        if (cmd == "soibean") return soibean_main(argc - 1, argv + 1);
+        if (cmd == "haplocart" || cmd == "euka" || cmd == "soibean") {
+            const int rc = cmd == "haplocart" ? haplocart(argc - 1, argv + 1) : cmd == "euka" ? euka_main(argc - 1, argv + 1) : soibean_main(argc - 1, argv + 1);
+            // every output file is closed by now: leave without running the exit handlers (the HIP runtime's teardown and the
+            // page-by-page release of gigabytes of alignments cost ~0.2 s that no one is waiting for)
+            std::cout.flush();
+            std::cerr.flush();
+            fflush(nullptr);
+            _exit(rc);
+        }
         if (cmd == "version") {
             std::cout << "vgan-mi355x ABI " << vgan_abi_version() << std::endl;
             return 0;
