@@ -2,7 +2,7 @@
 """Developer aid: per-phase cycle split of hc_segment_tile_kernel.
 
 Needs a library built with the phase marks: VGAN_BUILD_TAG=_pt VGAN_EXTRA_FLAGS=-DVGAN_PHASE_TIMING python vgan_amd/build.py
-(lands beside the product's library), then VGAN_LIB=vgan_amd/lib/libvgan_gpu_pt.so python tools/phase_cycles.py.  Prints the share of wave-0 cycles spent in each phase / barrier wait.
+(lands beside the product's library), then VGAN_LIB=vgan_amd/lib/libvgan_gpu_pt.so python tools/phase_cycles.py.  Prints the share of each wave's cycles (lane 0) spent in each phase / barrier wait.
 """
 import ctypes
 import sys
@@ -26,16 +26,18 @@ def main():
     hb = hc.HostBatch(g, a)
     db = hc.DeviceBatch(hb)
     ctx = hc.HcContext(g)
-    out = (ctypes.c_ulonglong * 12)()
+    out = (ctypes.c_ulonglong * 48)()
     for rep in range(3):
         ctx.reset()
         fn(out, 1)
         ctx.accumulate(db)
         ctx.synchronize()
         fn(out, 0)
-    v = np.array(list(out), dtype=np.float64)
-    for name, x in zip(NAMES, v):
-        print("%-28s %6.2f %%  %.3e cycles" % (name, 100 * x / v.sum(), x))
+    v = np.array(list(out), dtype=np.float64).reshape(4, 12)
+    print("%-30s %s" % ("share of each wave's cycles", "   ".join("wave %d" % w for w in range(4))))
+    for i, name in enumerate(NAMES):
+        print("%-30s %s" % (name, "   ".join("%5.2f%%" % (100 * v[w, i] / v[w].sum()) for w in range(4))))
+    print("cycles per wave: " + "  ".join("%.3e" % v[w].sum() for w in range(4)))
 
 
 if __name__ == "__main__":

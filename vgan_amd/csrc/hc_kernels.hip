@@ -216,7 +216,7 @@ constexpr double ST_RHO_MAX = 0.015625; // 2^-6: the series' next term rho^9 / 9
 __device__ const LogTabEntry hc_log_table[64] = {VGAN_LOG_TABLE};
 
 #ifdef VGAN_PHASE_TIMING // developer aid: cycles per phase of the tile kernel (thread 0 of every workgroup)
-__device__ unsigned long long hc_phase_cycles[12];
+__device__ unsigned long long hc_phase_cycles[48]; // [wave][slot]
 #define PT_MARK(slot)                                                  \
     do {                                                               \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -320,12 +320,14 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     const uint32_t rb1 = min(n_tileable, rb0 + reads_per_block);
     if (rb0 >= rb1) return;
 
-    // header values travel in registers of threads 0..ST_READS until they are published in LDS
+    // Header values travel in registers of lanes 0..ST_READS of the LAST wave until they are published in LDS: that wave has
+    // the fewest column chunks in phase D (5 5 5 4 for a full tile) and publishes in the time the others still compute.
+    constexpr int HW = ST_WAVES - 1;
     uint32_t h_seg = 0, h_col = 0, h_q = 0, h_A = 0, h_mapq = 0;
     double h_omp = 0.0, h_lp = 0.0, h_ip = 0.0;
     auto header_request = [&](uint32_t first) {
-        if (tid <= ST_READS) {
-            const uint32_t r = min(first + tid, rb1);
+        if (wave == HW && lane <= ST_READS) {
+            const uint32_t r = min(first + (uint32_t)lane, rb1);
             h_seg = b.read_seg_off[r];
             h_col = b.read_col_off[r];
             h_q = b.read_qual_off[r];
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     };
     // the read's share of pcm by mapping quality: dependent loads, issued a phase after the request so that nothing waits
     auto header_resolve = [&]() {
-        if (tid <= ST_READS) {
+        if (wave == HW && lane <= ST_READS) {
             const double *t = g.rdtab + 3u * min(h_mapq, 99u);
             h_omp = t[0];
             h_lp = t[1];
@@ -348,25 +350,25 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     // for reads within the per-read limits).  The offsets ascend, so "read t-1 still fits" is a prefix property and
     // n is a popcount.
     auto header_publish = [&](uint32_t buf, uint32_t first) {
-        if (wave == 0) {
+        if (wave == HW) {
             const uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_seg);
             const uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_col);
             const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_q);
-            const bool fits = tid >= 1 && tid <= ST_READS && first + tid <= rb1 && h_seg - sb <= (uint32_t)ST_SEGS &&
+            const bool fits = lane >= 1 && lane <= ST_READS && first + (uint32_t)lane <= rb1 && h_seg - sb <= (uint32_t)ST_SEGS &&
                               h_col - cb <= (uint32_t)ST_COLS && h_q - qb <= (uint32_t)ST_QUAL;
             const uint32_t n = max(1u, (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fits)));
             // a read whose quality string is shorter than its |algnseq| columns needs the column phase's bound check (Q5)
             const uint32_t ql_next = (uint32_t)__shfl_down((int)h_q, 1, 64) - h_q;
-            const bool shortq = (uint32_t)tid < n && ql_next < h_A;
+            const bool shortq = (uint32_t)lane < n && ql_next < h_A;
             const uint32_t any_short = __builtin_amdgcn_ballot_w64(shortq) != 0 ? 1u : 0u;
-            if (tid <= ST_READS) {
-                off_s[buf][0][tid] = h_seg;
-                off_s[buf][1][tid] = h_col;
-                off_s[buf][2][tid] = h_q;
-                if (tid < ST_READS) rd_s[buf][tid] = StRead{h_omp, h_lp, h_ip, h_A, 0u};
+            if (lane <= ST_READS) {
+                off_s[buf][0][lane] = h_seg;
+                off_s[buf][1][lane] = h_col;
+                off_s[buf][2][lane] = h_q;
+                if (lane < ST_READS) rd_s[buf][lane] = StRead{h_omp, h_lp, h_ip, h_A, 0u};
             }
             // clamped: a read that breaks the tile contract (a caller's error) must not index past the LDS arrays
-            if ((uint32_t)tid == n)
+            if ((uint32_t)lane == n)
                 tile_s[buf] = StTile{n, sb, (uint32_t)min(h_seg - sb, (uint32_t)ST_SEGS), cb,
                                      (uint32_t)min(h_col - cb, (uint32_t)ST_COLS), qb, (uint32_t)min(h_q - qb, (uint32_t)ST_QUAL),
                                      any_short};
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     if (r0 + T.n < rb1) {
         header_request(r0 + T.n);
         header_resolve();
+        header_publish(cur ^ 1u, r0 + T.n); // (the first tile's barriers come before anyone reads it)
     }
     while (true) {
         // per-thread addresses are cheap to rebuild and expensive to keep: nothing derived from the thread id is to be
@@ -484,7 +487,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             if (tid == 0) ps_s[0] = 0.0;
             need_min = need_min || tilebits_s[3] != 0u;
         }
-        if (has_next) header_publish(cur ^ 1u, r0 + T.n); // requested a tile ago
         PT_MARK(2);
         __syncthreads();
         PT_MARK(3);
@@ -581,42 +583,75 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
 
         // ---- D: one lane per alignment column, flat over the tile; everything comes from LDS
         const uint32_t tb0 = tilebits_s[0], node_lo = tilebits_s[1];
-        // heads in the words below word w, held by lane w: the owner of a column is a popcount away
+        // Lane w keeps head word w and the number of heads in the words below it: a wave's 64 columns lie in two words, so the
+        // owner of a column is four v_readlane and a masked popcount away -- no LDS round trip.
+        const uint32_t flagw = lane < ST_FWORDS ? flags_s[lane] : 0u;
         uint32_t wordbase;
         {
-            const uint32_t pc = lane < ST_FWORDS ? (uint32_t)__builtin_popcount(flags_s[lane]) : 0u;
+            const uint32_t pc = (uint32_t)__builtin_popcount(flagw);
             wordbase = wave_incl_scan_u32(pc) - pc - 1u; // (- 1: the owner's index is the head count less one)
         }
-        auto columns = [&](auto general_tag) {
+        const bool lowhalf = lane < 32;
+        // A chunk of 64 columns per wave, stage by stage (three dependent rounds of LDS reads, then the series).  U > 1 chunks at
+        // a time interleave the chains: measured -1.2 % at U = 2, but only with the series constants in scalar registers, which
+        // alone costs 3.5 % (SGPRs spill to VGPR lanes); with the constants in VGPRs U = 2 spills.  So U = 1.
+        auto column_group = [&](auto general_tag, auto width_tag, const uint32_t c0) {
             constexpr bool GEN = decltype(general_tag)::value;
-            // (whole waves: the owner lookup reads another lane's register, and every index below stays inside its array
-            // for the columns past the tile's end, which no segment claims)
-            for (uint32_t c0 = (uint32_t)wave * 64u; c0 < T.n_col; c0 += ST_THREADS) {
-                const uint32_t c = c0 + (uint32_t)lane;
-                const uint32_t w = c >> 5;
-                const uint32_t fw = flags_s[w] & lanemask;
-                const uint32_t below = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)wordbase);
-                const uint32_t own = (uint32_t)__builtin_popcount(fw) + below; // head bits at or below the column, less one
-                const uint32_t gcode = base_code8(gseq_s[c + cshift]);
-                // every LDS read below is unconditional (indices in range, results selected afterwards): the reads of one
-                // column then overlap instead of each waiting behind its own branch
-                const uint32_t ls = own & ((uint32_t)ST_SEGS - 1u);
-                const StSegGeo geo = seggeo_s[ls];
-                const StSegKL kl = segkl_s[ls];
-                const uint32_t cend = geo.cend_bep & 0x7FFFu;
-                const bool in_seg = (int)own >= 0 && c < cend; // columns no mapping scores (Q6 tail) have no owner
-                const uint32_t ri = min((uint32_t)((int)c + geo.rshift), (uint32_t)ST_COLS + 7u);
-                const uint32_t qi = min((uint32_t)((int)c + geo.qshift), (uint32_t)ST_QUAL + 7u);
-                const uint32_t rcode = base_code8(rseq_s[ri]);
-                int q = (int)(int8_t)qual_s[qi];
-                if constexpr (GEN) q = c < geo.qend ? q : 0;
-                q = q < 0 ? 0 : (q > 99 ? 99 : q);               // qscore_vec's index
-                if constexpr (GEN) q = (geo.cend_bep & 0x8000u) ? 100 : q; // slot 100 holds the background error rate
-                const bool valid = in_seg && (gcode | rcode) < 32u; // process_mapping.cpp:62-63
-                const uint32_t match = gcode == rcode ? 1u : 0u;   // 1 - eps: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0
-                const StLom lo = lom_s[q][match];
-                const double bgv = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(bg_s) + rcode);
-                const double rho = kl.kappa * bgv * lo.iom;
+            constexpr int U = decltype(width_tag)::value;
+            uint32_t c[U], ls[U], gbyte[U];
+            bool owned[U];
+            uint2 geo[U];
+            StSegKL kl[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t cu0 = c0 + (uint32_t)u * ST_THREADS; // wave uniform; below ST_COLS + ST_THREADS
+                const int w0 = (int)(cu0 >> 5);
+                const uint32_t f_lo = (uint32_t)__builtin_amdgcn_readlane((int)flagw, w0);
+                const uint32_t f_hi = (uint32_t)__builtin_amdgcn_readlane((int)flagw, w0 + 1);
+                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readlane((int)wordbase, w0);
+                const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readlane((int)wordbase, w0 + 1);
+                c[u] = cu0 + (uint32_t)lane;
+                const uint32_t own = (uint32_t)__builtin_popcount((lowhalf ? f_lo : f_hi) & lanemask) + (lowhalf ? b_lo : b_hi);
+                owned[u] = (int)own >= 0; // columns no mapping scores (Q6 tail) have no owner
+                ls[u] = own & ((uint32_t)ST_SEGS - 1u);
+                // every LDS read is unconditional (indices in range, results selected afterwards)
+                gbyte[u] = gseq_s[min(c[u] + cshift, (uint32_t)ST_COLS + 15u)];
+                geo[u] = *reinterpret_cast<const uint2 *>(&seggeo_s[ls[u]]);
+                kl[u] = segkl_s[ls[u]];
+            }
+            uint32_t rbyte[U];
+            int q[U];
+            bool in_seg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t cend = geo[u].x & 0x7FFFu;
+                const int rshift = (int)geo[u].x >> 16, qsh = (int)(int16_t)(geo[u].y & 0xFFFFu);
+                in_seg[u] = owned[u] && c[u] < cend;
+                const uint32_t ri = min((uint32_t)((int)c[u] + rshift), (uint32_t)ST_COLS + 7u);
+                const uint32_t qi = min((uint32_t)((int)c[u] + qsh), (uint32_t)ST_QUAL + 7u);
+                rbyte[u] = rseq_s[ri];
+                q[u] = (int)(int8_t)qual_s[qi];
+            }
+            uint32_t match[U];
+            bool valid[U];
+            StLom lo[U];
+            double bgv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t gcode = base_code8(gbyte[u]), rcode = base_code8(rbyte[u]);
+                if constexpr (GEN) q[u] = c[u] < (geo[u].y >> 16) ? q[u] : 0; // Q5: zero beyond the quality string
+                q[u] = q[u] < 0 ? 0 : (q[u] > 99 ? 99 : q[u]);                  // qscore_vec's index
+                if constexpr (GEN) q[u] = (geo[u].x & 0x8000u) ? 100 : q[u];    // slot 100 holds the background error rate
+                valid[u] = in_seg[u] && (gcode | rcode) < 32u; // process_mapping.cpp:62-63
+                match[u] = gcode == rcode ? 1u : 0u;           // 1 - eps: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0
+                lo[u] = lom_s[q[u]][match[u]];
+                bgv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(bg_s) + rcode);
+            }
+            double t[U];
+            bool rare = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double rho = kl[u].kappa * bgv[u] * lo[u].iom;
                 double p = fma(rho, 1.0 / 8.0, -1.0 / 7.0);
                 p = fma(rho, p, 1.0 / 6.0);
                 p = fma(rho, p, -0.2);
@@ -624,31 +659,52 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 p = fma(rho, p, -1.0 / 3.0);
                 p = fma(rho, p, 0.5);
                 p = fma(rho, -p, 1.0);
-                double t = fma(rho, p, lo.lom + kl.lw);
-                if (__builtin_expect(valid && !(rho < ST_RHO_MAX), 0)) { // rare: see the head of this section
-                    const double e = (q == 100 || prm.use_bep) ? prm.bep : g.qscore[q];
-                    const double om = match ? 1.0 - e : e;
-                    const bool deg = !(kl.kappa < 1e300); // wobs = 0: {inf, wbg}
-                    // (the table log by hand: log_tab()'s series for values outside the normal range would park its
-                    // constants in scratch for the whole kernel)
-                    double x = deg ? kl.lw * bgv : fma(kl.kappa, bgv, om);
-                    double adj = 0.0;
-                    if (x < 2.2250738585072014e-308 && x > 0.0) { // subnormal
-                        x *= 18014398509481984.0; // 2^54
-                        adj = -37.429947750237048; // -54 ln 2
-                    }
-                    double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval(x, hc_log_table) + adj : x) : (x == 0.0 ? -INFINITY : __builtin_nan(""));
-                    t = deg ? lx : kl.lw + lx;
-                }
-                if (valid) unsafeAtomicAdd(&segS_s[ls], t);
+                t[u] = fma(rho, p, lo[u].lom + kl[u].lw);
+                rare |= valid[u] && !(rho < ST_RHO_MAX);
             }
+            if (__builtin_expect(rare, 0)) { // see the head of this section
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double rho = kl[u].kappa * bgv[u] * lo[u].iom;
+                    if (valid[u] && !(rho < ST_RHO_MAX)) {
+                        const double e = (q[u] == 100 || prm.use_bep) ? prm.bep : g.qscore[q[u]];
+                        const double om = match[u] ? 1.0 - e : e;
+                        const bool deg = !(kl[u].kappa < 1e300); // wobs = 0: {inf, wbg}
+                        // (the table log by hand: log_tab()'s series for values outside the normal range would park its
+                        // constants in scratch for the whole kernel)
+                        double x = deg ? kl[u].lw * bgv[u] : fma(kl[u].kappa, bgv[u], om);
+                        double adj = 0.0;
+                        if (x < 2.2250738585072014e-308 && x > 0.0) { // subnormal
+                            x *= 18014398509481984.0; // 2^54
+                            adj = -37.429947750237048; // -54 ln 2
+                        }
+                        const double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval(x, hc_log_table) + adj : x)
+                                                  : (x == 0.0 ? -INFINITY : __builtin_nan(""));
+                        t[u] = deg ? lx : kl[u].lw + lx;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (valid[u]) unsafeAtomicAdd(&segS_s[ls[u]], t[u]);
+        };
+        // (whole waves: the owner lookup reads other lanes' registers, and every index stays inside its array for the
+        // columns past the tile's end, which no segment claims)
+        auto columns = [&](auto general_tag) {
+            uint32_t c0 = (uint32_t)wave * 64u;
+            for (; c0 < T.n_col; c0 += ST_THREADS) column_group(general_tag, std::integral_constant<int, 1>{}, c0);
         };
         if ((tb0 | T.short_qual) != 0u) columns(std::true_type{});
         else columns(std::false_type{});
         PT_MARK(7);
         if (has_next) {
             tile_gather(Tn, Ln); // the node ids arrived during D,
-            header_resolve();    // and so did the mapping qualities of the header requested before it
+            // ... and so did the header of the tile after the next, requested before D: it takes this tile's header slots, which
+            // nobody reads after phase C (the last wave gets here first, so its dependent table loads cost nobody a wait)
+            if (r0 + T.n + Tn.n < rb1) {
+                header_resolve();
+                header_publish(cur, r0 + T.n + Tn.n);
+            }
         }
         PT_MARK(8);
         __syncthreads();
@@ -701,8 +757,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         window_flush();
     }
 #ifdef VGAN_PHASE_TIMING
-    if (tid == 0)
-        for (int i = 0; i < 12; ++i) atomicAdd(&hc_phase_cycles[i], pt_acc[i]);
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&hc_phase_cycles[wave * 12 + i], pt_acc[i]);
 #endif
     sumT = wave_sum(sumT);
     sumU = wave_sum(sumU);
@@ -937,7 +993,7 @@ __global__ __launch_bounds__(256) void hc_posterior_kernel(const double *__restr
 extern "C" int vgan_hc_debug_phase_cycles(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hc_phase_cycles), sizeof(hc_phase_cycles)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[48] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(hc_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
