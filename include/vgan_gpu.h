@@ -181,8 +181,8 @@ typedef struct vgan_hc_batch {
  * columns, 65535 mappings and 65535 quality bytes -- seg_start / seg_len / read_algn_len are 16 bit and the general
  * kernel keeps one quality prefix per 64 bytes for 65536 of them.  vgan_hc_flatten* drops and counts reads beyond it
  * (n_bad); vgan_hc_batch_validate refuses hand-built batches beyond it.  A 16.5 kb consensus read fits four times.
- * Tile contract (reads below n_tileable): at most 1280 columns, 1280 quality bytes and 512 segments; |algnseq| equals the
- * length of the read's graph sequence; every segment has seg_len > 0 and the column ranges [seg_start, seg_start+seg_len)
+ * Tile contract (reads below n_tileable): at most 1280 columns, 1280 quality bytes and 512 segments, at least one
+ * segment; |algnseq| equals the length of the read's graph sequence; every segment has seg_len > 0 and the column ranges [seg_start, seg_start+seg_len)
  * of the read do not overlap.
  * Order: any.  vgan_hc_flatten* puts the tileable reads in ascending order of their lowest node id (stable), because
  * the tiled kernel keeps W[node] of a workgroup's reads in an LDS window of 448 node ids and only reaches into HBM for

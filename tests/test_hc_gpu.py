@@ -455,7 +455,7 @@ def test_cli_reads_the_reference_odgi_fixture(tmp_path):
 def test_tiled_kernel_fuzz_against_general_kernel(seed):
     """Random batches that satisfy the tile contract, built by hand over the C-ABI (no flatten step): ragged reads of
     1..1280 columns, quality strings shorter / longer than the read or empty, segments that stop before the read ends,
-    node ids all over the graph (far outside any LDS window), zero-length segments in the reads behind n_tileable, bases outside ACGT, qualities >= 90 and negative.  D_m from the LDS-tiled kernel must equal
+    node ids all over the graph (far outside any LDS window), zero-length segments and reads without any segment behind n_tileable, bases outside ACGT, qualities >= 90 and negative.  D_m from the LDS-tiled kernel must equal
     S_m - U_m from the general kernel (which the other tests hold against the oracle)."""
     rng = np.random.default_rng(seed)
     g = hc.synth_graph(seed=50 + seed, genome_len=1200, n_nodes=700, n_paths=70)
@@ -473,7 +473,7 @@ def test_tiled_kernel_fuzz_against_general_kernel(seed):
             cols = int(rng.integers(1, 257)) if r % 7 else int(rng.choice([1, 2, 255, 256, 700, 1279, 1280]))
         A = cols
         ql = int(rng.choice([cols, cols, cols, max(0, cols - int(rng.integers(1, 9))), min(1280, cols + 5), 0]))
-        if r % 97 == 5:  # degenerate reads: no columns at all, or columns that no mapping covers
+        if r >= R_tile and r % 9 == 5:  # degenerate reads (outside the tile contract): no columns at all, or columns that no mapping covers
             cols = 0 if r % 2 else cols
             A, ql = cols, min(ql, cols)
             seg_off.append(len(seg_node))
@@ -630,6 +630,7 @@ def test_batch_validation(tmp_path):
     broken(lambda x: x["read_mapq"].__setitem__(7, 120))
     broken(lambda x: x["seg_start"].__setitem__(1, 0) if x["seg_len"][0] else None, n_tileable=b.n_tileable)  # overlap / order
     broken(lambda x: x["seg_len"].__setitem__(2, 0), n_tileable=b.n_tileable)         # an empty segment below n_tileable
+    broken(lambda x: x["read_seg_off"].__setitem__(1, x["read_seg_off"][0]), n_tileable=b.n_tileable)  # a read without segments below n_tileable
     broken(lambda x: None, n_tileable=b.n_reads)                                      # the 1500-column reads are not tileable
     broken(lambda x: x["read_col_off"].__setitem__(len(x["read_col_off"]) - 1, 5))    # final offset vs n_cols
 

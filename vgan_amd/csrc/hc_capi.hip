@@ -479,6 +479,7 @@ extern "C" int vgan_hc_batch_validate(const vgan_hc_ctx *c, const vgan_hc_batch 
         const bool tile = r < b->n_tileable;
         if (tile && (cols > HC_TILE_MAX_READ_COLS || ql > HC_TILE_MAX_READ_QUAL || s1 - s0 > HC_TILE_MAX_READ_SEGS))
             return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but exceeds the tile limits", (unsigned long long)r);
+        if (tile && s1 == s0) return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but has no segment", (unsigned long long)r);
         if (tile && b->read_algn_len[r] != cols)
             return fail(VGAN_EINVAL, "batch: read %llu is below n_tileable but |algnseq| differs from its column count", (unsigned long long)r);
         uint32_t prev_end = 0, prev_start = 0;

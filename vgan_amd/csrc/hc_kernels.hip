@@ -187,7 +187,7 @@ static_assert(HC_TILE_MAX_READ_COLS <= (uint32_t)ST_COLS && HC_TILE_MAX_READ_QUA
 static_assert(ST_QB * ST_THREADS == ST_QUAL && ST_SEG_ITERS * ST_THREADS == ST_SEGS && ST_WAVES == 4,
               "tile shape");
 static_assert(ST_COLS + 16 <= 8 * ST_THREADS && ST_QUAL == ST_COLS, "byte windows: one 8-byte word per thread");
-static_assert(ST_FWORDS <= 64, "head words fit one wave");
+static_assert(ST_FWORDS <= 64 && ST_SEGS / 32 <= 64, "head words / read marks fit one wave");
 
 // per segment: {kappa = wbg / wobs, lw = log(wobs)}; a segment with wobs = 0: {+inf, wbg}
 struct alignas(16) StSegKL {
@@ -209,7 +209,8 @@ struct alignas(16) StLom { // per (error-rate index, base match): log(om), 1 / o
 };
 struct alignas(32) StRead { // per read of the tile
     double omp, lp, ip; // 1 - p_inc, its log (log(1 - bep) for a consensus FASTA), its reciprocal
-    uint32_t A, pad;
+    uint32_t a_ql;      // |algnseq| columns | quality string length << 16
+    uint32_t col_q;     // first column | first quality byte << 16, both relative to the tile's
 };
 constexpr double ST_RHO_MAX = 0.015625; // 2^-6: the series' next term rho^9 / 9 is below 2^-57 relative to log1p's first
 
@@ -280,7 +281,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     __shared__ double lq_s[256];
     __shared__ StLom lom_s[101][2];   // [qscore index, 100 = background error rate][mismatch, match]
     __shared__ double bg_s[5];
-    __shared__ uint8_t code_s[256];   // A C T G -> 0 8 16 24 (byte offsets into bg_s), anything else 32 (libgab isValidDNA is false)
     __shared__ double ps_s[ST_QUAL + 1]; // wave-local prefix sums of log p_err over the tile's quality bytes
     __shared__ double wsum_s[ST_WAVES];  // each wave's total
     __shared__ double segS_s[ST_SEGS];
@@ -293,6 +293,9 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     // per-read header, double buffered: the next tile's is written while this tile's is in use
     __shared__ uint32_t off_s[2][3][ST_READS + 1];
     __shared__ StRead rd_s[2][ST_READS];
+    // which read a segment belongs to: .x = marks at the last segment of every read but the tile's last, 32 segments per
+    // word; .y = marks in the words below.  Segment ls is of read  popcount(x & bits below ls) + y.
+    __shared__ uint2 rmark_s[2][ST_SEGS / 32];
     __shared__ uint32_t first90_s[ST_READS];
     __shared__ StTile tile_s[2];
     __shared__ uint32_t tilebits_s[4]; // [0] bit 0: a segment takes the background error rate on its own; [1] lowest node id
@@ -308,7 +311,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         const double om = (i & 1) ? 1.0 - e : e;
         lom_s[qi][i & 1] = StLom{log_pos(om), 1.0 / om};
     }
-    for (int i = tid; i < 256; i += ST_THREADS) code_s[i] = is_acgt((uint32_t)i) ? (uint8_t)(((i >> 1) & 3) << 3) : (uint8_t)32;
     for (int i = tid; i < WIN; i += ST_THREADS) win_s[i] = 0.0;
     if (tid < 5) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : tid == 3 ? 0.16644 : 0.25; // A C T G by (c>>1)&3
     const double lq0 = g.lq[0];
@@ -365,7 +367,20 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 off_s[buf][0][lane] = h_seg;
                 off_s[buf][1][lane] = h_col;
                 off_s[buf][2][lane] = h_q;
-                if (lane < ST_READS) rd_s[buf][lane] = StRead{h_omp, h_lp, h_ip, h_A, 0u};
+                if (lane < ST_READS)
+                    rd_s[buf][lane] = StRead{h_omp, h_lp, h_ip, (uint32_t)(h_A | (min(ql_next, 0xFFFFu) << 16)),
+                                             (uint32_t)(min(h_col - cb, (uint32_t)ST_COLS) | (min(h_q - qb, (uint32_t)ST_QUAL) << 16))};
+            }
+            // the read marks (LDS operations of one wave complete in order: zero, mark, count)
+            if (lane < ST_SEGS / 32) rmark_s[buf][lane].x = 0u;
+            if (lane >= 1 && (uint32_t)lane < n) {
+                const uint32_t pos = min(h_seg - sb, (uint32_t)ST_SEGS) - 1u; // the previous read's last segment
+                if (pos < (uint32_t)ST_SEGS) atomicOr(&rmark_s[buf][pos >> 5].x, 1u << (pos & 31u));
+            }
+            {
+                const uint32_t pc = lane < ST_SEGS / 32 ? (uint32_t)__builtin_popcount(rmark_s[buf][lane & (ST_SEGS / 32 - 1)].x) : 0u;
+                const uint32_t below = wave_incl_scan_u32(pc) - pc;
+                if (lane < ST_SEGS / 32) rmark_s[buf][lane].y = below;
             }
             // clamped: a read that breaks the tile contract (a caller's error) must not index past the LDS arrays
             if ((uint32_t)lane == n)
@@ -494,12 +509,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         // ---- C: one lane per segment
         double segU[ST_SEG_ITERS];
         {
-            uint32_t seg_off_r[ST_READS <= 8 ? ST_READS : 1]; // segment offsets of reads 1.. (wave uniform) for the compare-sum
-            if constexpr (ST_READS <= 8) {
-#pragma unroll
-                for (int t = 1; t < ST_READS; ++t)
-                    seg_off_r[t] = (uint32_t)t < T.n ? (uint32_t)__builtin_amdgcn_readfirstlane((int)off_s[cur][0][t]) : 0xFFFFFFFFu;
-            }
             const double ws0 = wsum_s[0], ws1 = wsum_s[1], ws2 = wsum_s[2];
             uint32_t nmin = 0xFFFFFFFFu;
             bool own_bep = false;
@@ -509,26 +518,12 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 const uint32_t ls = tid + it * ST_THREADS;
                 segU[it] = 0.0;
                 if (ls < T.n_seg) {
-                    const uint32_t s = T.seg_base + ls;
-                    uint32_t k = 0;
-                    // read of the segment: the last k < n with off[k] <= s
-                    if constexpr (ST_READS <= 8) { // compare-sum over the (wave uniform) offsets
-#pragma unroll
-                        for (int t = 1; t < ST_READS; ++t) k += s >= seg_off_r[t] ? 1u : 0u;
-                    } else { // binary search, LDS broadcast reads
-                        uint32_t kend = T.n;
-#pragma unroll
-                        for (int step = 0; step < ST_READS_LOG2; ++step) {
-                            const uint32_t mid = (k + kend) >> 1;
-                            const bool up = mid > k && off_s[cur][0][mid] <= s;
-                            k = up ? mid : k;
-                            kend = up ? kend : (mid > k ? mid : kend);
-                        }
-                    }
-                    const uint32_t colbase = off_s[cur][1][k] - T.col_base;
-                    const uint32_t qo = off_s[cur][2][k], QL = off_s[cur][2][k + 1] - qo, qoff = qo - T.q_base;
+                    // read of the segment: the marks below it
+                    const uint2 mk = rmark_s[cur][ls >> 5];
+                    const uint32_t k = min((uint32_t)__builtin_popcount(mk.x & (lanemask >> 1)) + mk.y, (uint32_t)ST_READS - 1u);
                     const StRead rd = rd_s[cur][k];
-                    const uint32_t A = rd.A;
+                    const uint32_t A = rd.a_ql & 0xFFFFu, QL = rd.a_ql >> 16;
+                    const uint32_t colbase = rd.col_q & 0xFFFFu, qoff = rd.col_q >> 16;
                     const uint32_t start = L.start[it], len = L.len[it];
                     const uint32_t lo = min(start, QL), hi = min(start + A, QL);
                     const uint32_t ilo = qoff + lo, ihi = qoff + hi;

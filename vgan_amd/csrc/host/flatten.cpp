@@ -219,7 +219,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             c.st.n_bad++;
             continue;
         }
-        const bool tile = A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && (size_t)nm <= TILE_MAX_SEGS && !empty_seg;
+        const bool tile = A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && (size_t)nm <= TILE_MAX_SEGS && !empty_seg && !seg_tmp.empty();
         auto &b = tile ? c.b : c.gen;
         for (const SegTmp &sg : seg_tmp) {
             b.seg_node.push_back(sg.node);
