@@ -72,19 +72,20 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return v;
 }
 
-// DPP moves on a double (two 32-bit halves); lanes without a source keep 0.0.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov0(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+// DPP moves on a double (two 32-bit halves); lanes without a source get 0.0 (BOUND: by bound_ctrl, for a move within all
+// rows -- no register to preset; otherwise by presetting the destination, for a move into some rows only).
+template <int CTRL, int ROW_MASK, bool BOUND = false> __device__ __forceinline__ double dpp_mov0(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BOUND);
     return __hiloint2double(hi, lo);
 }
 
 // wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS traffic)
 __device__ __forceinline__ double wave_incl_scan(double v) {
-    v += dpp_mov0<0x111, 0xf>(v); // row_shr:1
-    v += dpp_mov0<0x112, 0xf>(v); // row_shr:2
-    v += dpp_mov0<0x114, 0xf>(v); // row_shr:4
-    v += dpp_mov0<0x118, 0xf>(v); // row_shr:8
+    v += dpp_mov0<0x111, 0xf, true>(v); // row_shr:1
+    v += dpp_mov0<0x112, 0xf, true>(v); // row_shr:2
+    v += dpp_mov0<0x114, 0xf, true>(v); // row_shr:4
+    v += dpp_mov0<0x118, 0xf, true>(v); // row_shr:8
     v += dpp_mov0<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
     v += dpp_mov0<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
     return v;

@@ -304,15 +304,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     __shared__ double win_s[WIN];      // W[winbase .. winbase + WIN) of this workgroup's reads
 
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 256; i += ST_THREADS) lq_s[i] = g.lq[i];
-    for (int i = tid; i < 202; i += ST_THREADS) {
-        const int qi = i >> 1;
-        const double e = (qi == 100 || prm.use_bep) ? prm.bep : g.qscore[qi];
-        const double om = (i & 1) ? 1.0 - e : e;
-        lom_s[qi][i & 1] = StLom{log_pos(om), 1.0 / om};
-    }
-    for (int i = tid; i < WIN; i += ST_THREADS) win_s[i] = 0.0;
-    if (tid < 5) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : tid == 3 ? 0.16644 : 0.25; // A C T G by (c>>1)&3
     const double lq0 = g.lq[0];
     double sumT = 0.0, sumU = 0.0; // sum of the column terms (= sum of S_m) and of U_m, each without cancellation
     uint32_t winbase = 0xFFFFFFFFu; // no window yet (workgroup uniform)
@@ -433,8 +424,18 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     // ---- prologue: the first tile's header and data, the second tile's header
     uint32_t r0 = rb0, cur = 0;
     header_request(r0);
+    // the workgroup's tables, built while the first header is on its way
+    for (int i = tid; i < 256; i += ST_THREADS) lq_s[i] = g.lq[i];
+    for (int i = tid; i < 202; i += ST_THREADS) {
+        const int qi = i >> 1;
+        const double e = (qi == 100 || prm.use_bep) ? prm.bep : g.qscore[qi];
+        const double om = (i & 1) ? 1.0 - e : e;
+        lom_s[qi][i & 1] = StLom{log_pos(om), 1.0 / om};
+    }
+    for (int i = tid; i < WIN; i += ST_THREADS) win_s[i] = 0.0;
+    if (tid < 5) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : tid == 3 ? 0.16644 : 0.25; // A C T G by (c>>1)&3
     header_resolve();
-    __syncthreads(); // the tables above are in place
+    __syncthreads(); // the tables are in place
     header_publish(cur, r0);
     __syncthreads();
     StTile T = tile_extents(cur);
