@@ -272,6 +272,13 @@ __device__ __forceinline__ uint32_t base_code8(uint32_t b) {
     return ok ? ((b << 2) & 24u) : 32u;
 }
 
+// a * b + c as the three-address v_fma_f64: with a constant c the compiler prefers a copy of c + v_fmac_f64 (two instructions)
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int ST_READS>
 __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphDev g, HcBatchDev b, HcParamsDev prm,
                                                                       uint32_t n_tileable, uint32_t reads_per_block,
@@ -587,7 +594,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             const uint32_t pc = (uint32_t)__builtin_popcount(flagw);
             wordbase = wave_incl_scan_u32(pc) - pc - 1u; // (- 1: the owner's index is the head count less one)
         }
-        const bool lowhalf = lane < 32;
         // A chunk of 64 columns per wave, stage by stage (three dependent rounds of LDS reads, then the series).  U > 1 chunks at
         // a time interleave the chains: measured -1.2 % at U = 2, but only with the series constants in scalar registers, which
         // alone costs 3.5 % (SGPRs spill to VGPR lanes); with the constants in VGPRs U = 2 spills.  So U = 1.
@@ -602,12 +608,14 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             for (int u = 0; u < U; ++u) {
                 const uint32_t cu0 = c0 + (uint32_t)u * ST_THREADS; // wave uniform; below ST_COLS + ST_THREADS
                 const int w0 = (int)(cu0 >> 5);
-                const uint32_t f_lo = (uint32_t)__builtin_amdgcn_readlane((int)flagw, w0);
-                const uint32_t f_hi = (uint32_t)__builtin_amdgcn_readlane((int)flagw, w0 + 1);
-                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readlane((int)wordbase, w0);
-                const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readlane((int)wordbase, w0 + 1);
+                // heads at or below lane l of the chunk = head bit 0 + (bits 1..l) = bit 0 + v_mbcnt of the chunk's 64 head
+                // bits shifted down by one; everything but the two v_mbcnt is scalar
+                const uint64_t heads = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)flagw, w0) |
+                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)flagw, w0 + 1) << 32);
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)wordbase, w0) + (uint32_t)(heads & 1u);
+                const uint64_t above0 = heads >> 1;
                 c[u] = cu0 + (uint32_t)lane;
-                const uint32_t own = (uint32_t)__builtin_popcount((lowhalf ? f_lo : f_hi) & lanemask) + (lowhalf ? b_lo : b_hi);
+                const uint32_t own = __builtin_amdgcn_mbcnt_hi((uint32_t)(above0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)above0, base));
                 owned[u] = (int)own >= 0; // columns no mapping scores (Q6 tail) have no owner
                 ls[u] = own & ((uint32_t)ST_SEGS - 1u);
                 // every LDS read is unconditional (indices in range, results selected afterwards)
@@ -648,11 +656,11 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double rho = kl[u].kappa * bgv[u] * lo[u].iom;
-                double p = fma(rho, 1.0 / 8.0, -1.0 / 7.0);
-                p = fma(rho, p, 1.0 / 6.0);
-                p = fma(rho, p, -0.2);
-                p = fma(rho, p, 0.25);
-                p = fma(rho, p, -1.0 / 3.0);
+                double p = fma3(rho, 1.0 / 8.0, -1.0 / 7.0);
+                p = fma3(rho, p, 1.0 / 6.0);
+                p = fma3(rho, p, -0.2);
+                p = fma3(rho, p, 0.25);
+                p = fma3(rho, p, -1.0 / 3.0);
                 p = fma(rho, p, 0.5);
                 p = fma(rho, -p, 1.0);
                 t[u] = fma(rho, p, lo[u].lom + kl[u].lw);
