@@ -579,18 +579,17 @@ extern "C" int vgan_hc_read_loglik(vgan_hc_ctx *c, const vgan_hc_batch *b, doubl
 extern "C" int vgan_hc_finalize(vgan_hc_ctx *c, double *d_out, double *out) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_finalize: null context");
     HIPCHK(hipSetDevice(c->device));
-    // NODE_WEIGHTS accumulations: one pass of the unsupported-path bitmask over the node weights
-    HIPCHK(hipMemsetAsync(c->acc_node.p, 0, (size_t)c->W * 64 * 8, c->stream));
+    // NODE_WEIGHTS accumulations: one pass of the unsupported-path bitmask over the node weights (into acc_node, which every
+    // finalize leaves zero again: calling it twice gives the same vector)
     {
         ScopedTimer t(c, VGAN_HC_K_SWEEP_NODE);
         launch_hc_sweep(c->g, nullptr, c->nodeW.p, c->rows, 1, c->acc_node.p, c->stream);
     }
     {
         ScopedTimer t(c, VGAN_HC_K_FINISH);
-        launch_hc_finish(c->totals.p, c->acc_seg.p, c->acc_node.p, c->P, c->final_vec.p, c->stream);
+        launch_hc_finish(c->totals.p, c->acc_seg.p, c->acc_node.p, c->P, c->W * 64u, c->final_vec.p, d_out, c->stream);
     }
     HIPCHK(hipGetLastError());
-    if (d_out) HIPCHK(hipMemcpyAsync(d_out, c->final_vec.p, (size_t)c->P * 8, hipMemcpyDeviceToDevice, c->stream));
     if (out) {
         HIPCHK(hipMemcpyAsync(out, c->final_vec.p, (size_t)c->P * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));

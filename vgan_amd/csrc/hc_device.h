@@ -75,8 +75,8 @@ void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParams
                         hipStream_t st);
 void launch_hc_sweep(const HcGraphDev &g, const uint32_t *item_node, const double *D, uint32_t n_items, int skip_zero,
                      double *acc, hipStream_t st);
-void launch_hc_finish(const double *totals, const double *acc_seg, const double *acc_node, uint32_t n_paths, double *out,
-                      hipStream_t st);
+void launch_hc_finish(const double *totals, const double *acc_seg, double *acc_node, uint32_t n_paths, uint32_t n_slots,
+                      double *out, double *out2, hipStream_t st);
 void launch_hc_read_loglik(const HcGraphDev &g, const HcBatchDev &b, const double *segS, const double *segU, double *out,
                            hipStream_t st);
 void launch_hc_posterior(const double *final_vec, uint32_t n_paths, const uint32_t *list_off, const uint32_t *list_idx,

@@ -22,7 +22,7 @@
 //                       XCD's L2 holds one eighth of the table.  Used per segment (PER_READ modes) and per node
 //                       (NODE_WEIGHTS mode, D = W[node], once per finalize).
 //   hc_read_loglik_kernel  literal per-read x per-path vectors (debug / parity aid).
-//   hc_finish_kernel    final[p] = Stot - acc[p].
+//   hc_finish_kernel    final[p] = Stot - acc[p]; leaves the node-pass accumulators zero.
 //   hc_posterior_kernel log-sum-exp over path sets (src/get_posterior.cpp:78-127).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -921,10 +921,20 @@ __global__ __launch_bounds__(256) void hc_sweep_kernel(const uint16_t *__restric
 }
 
 // final[p] = Stot - acc[p]
+// (acc_node is scratch of one finalize: the kernel leaves it zero for the next, so finalize needs no memset of its own; out2,
+// when given, receives a second copy -- the caller's device buffer -- instead of a copy engine pass behind the kernel)
 __global__ void hc_finish_kernel(const double *__restrict__ totals, const double *__restrict__ acc_seg,
-                                 const double *__restrict__ acc_node, uint32_t n_paths, double *__restrict__ out) {
+                                 double *__restrict__ acc_node, uint32_t n_paths, uint32_t n_slots, double *__restrict__ out,
+                                 double *__restrict__ out2) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n_paths) out[p] = totals[0] - (acc_seg[p] + acc_node[p]);
+    if (p >= n_slots) return;
+    const double an = acc_node[p];
+    acc_node[p] = 0.0;
+    if (p < n_paths) {
+        const double v = totals[0] - (acc_seg[p] + an);
+        out[p] = v;
+        if (out2) out2[p] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- per-read dump
@@ -1081,10 +1091,10 @@ void launch_hc_sweep(const HcGraphDev &g, const uint32_t *item_node, const doubl
     }
 }
 
-void launch_hc_finish(const double *totals, const double *acc_seg, const double *acc_node, uint32_t n_paths, double *out,
-                      hipStream_t st) {
-    hipLaunchKernelGGL(hc_finish_kernel, dim3((n_paths + 255) / 256), dim3(256), 0, st, totals, acc_seg, acc_node,
-                       n_paths, out);
+void launch_hc_finish(const double *totals, const double *acc_seg, double *acc_node, uint32_t n_paths, uint32_t n_slots,
+                      double *out, double *out2, hipStream_t st) {
+    hipLaunchKernelGGL(hc_finish_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, st, totals, acc_seg, acc_node, n_paths,
+                       n_slots, out, out2);
 }
 
 void launch_hc_read_loglik(const HcGraphDev &g, const HcBatchDev &b, const double *segS, const double *segU, double *out,
