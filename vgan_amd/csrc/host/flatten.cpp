@@ -442,19 +442,31 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
     if (part0 < 0 || part1 > (int64_t)ps->parts.size() || part0 > part1) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: bad slice range");
     if (ps->base + ps->first.back() > 0xFFFFFFF0ll) return fail(VGAN_ERANGE, "vgan_hc_flatten_parts: more than 2^32 reads");
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    const size_t np = (size_t)(part1 - part0);
+    // Work items: sub-ranges of the slices (a slice is 8192 reads: with one item per slice a chunk of 32 slices keeps 32 threads
+    // busy for one slice's time each, whatever the machine)
+    constexpr int64_t SUB = 2048;
+    struct Item {
+        size_t part;
+        int64_t r0, r1;
+    };
+    std::vector<Item> items;
+    for (int64_t pi = part0; pi < part1; ++pi) {
+        const int64_t n = ps->parts[(size_t)pi].n_reads();
+        for (int64_t r0 = 0; r0 < n; r0 += SUB) items.push_back({(size_t)pi, r0, std::min(n, r0 + SUB)});
+    }
+    const size_t np = items.size();
     n_threads = std::min(n_threads, 40); // as in vgan_hc_flatten_masked
     n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, np));
     PhaseTimer pt("hc_flatten_parts");
-    std::vector<Chunk> chunks(np); // one per slice, in order
+    std::vector<Chunk> chunks(np); // one per item, in input order
     std::atomic<size_t> next{0};
     auto work = [&]() {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= np) break;
-            const size_t pi = (size_t)part0 + i;
-            const vgan_alnset &a = ps->parts[pi];
-            flatten_range(*g, a, 0, a.n_reads(), skip ? skip + ps->first[pi] : nullptr, ps->base + ps->first[pi], chunks[i]);
+            const Item &it = items[i];
+            const vgan_alnset &a = ps->parts[it.part];
+            flatten_range(*g, a, it.r0, it.r1, skip ? skip + ps->first[it.part] : nullptr, ps->base + ps->first[it.part], chunks[i]);
         }
     };
     if (n_threads == 1) {
