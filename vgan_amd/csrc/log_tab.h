@@ -26,6 +26,14 @@ struct alignas(16) LogTabEntry {
 
 VGAN_HD bool log_tab_in_domain(double x) { return x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308; }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double log_tab_fma3(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#endif
+
 VGAN_HD double log_tab_eval(double x, const LogTabEntry *tab) {
     uint64_t bits;
     memcpy(&bits, &x, 8);
@@ -39,10 +47,11 @@ VGAN_HD double log_tab_eval(double x, const LogTabEntry *tab) {
     const LogTabEntry e = tab[idx];
 #if defined(__HIP_DEVICE_COMPILE__)
     const double r = __builtin_fma(m, e.rcp, -1.0);
-    double q = __builtin_fma(r, 1.0 / 7.0, -1.0 / 6.0);
-    q = __builtin_fma(r, q, 0.2);
-    q = __builtin_fma(r, q, -0.25);
-    q = __builtin_fma(r, q, 1.0 / 3.0);
+    // (three-address v_fma_f64 spelled out: with a constant addend the compiler emits a copy of it + v_fmac_f64)
+    double q = log_tab_fma3(r, 1.0 / 7.0, -1.0 / 6.0);
+    q = log_tab_fma3(r, q, 0.2);
+    q = log_tab_fma3(r, q, -0.25);
+    q = log_tab_fma3(r, q, 1.0 / 3.0);
     q = __builtin_fma(r, q, -0.5);
     const double p = __builtin_fma(r * r, q, r);
     const double dk = (double)k;
