@@ -40,6 +40,10 @@ enum {
 
 const char *vgan_last_error(void); /* thread-local message of the last failing call */
 int vgan_abi_version(void);
+/* The host front end (GAM parser, flatten step, host batches) recycles its large arrays instead of returning them to the
+ * system (every munmap interrupts all the cores the process runs on).  This hands the idle ones back, on n_threads threads;
+ * a long-lived caller may use it between inputs, the CLI uses it on its way out. */
+void vgan_host_release_memory(int n_threads);
 int vgan_device_count(void);
 /* Brings the HIP runtime and the device up (the first HIP call of a process costs ~0.25 s): call it on a thread of its
  * own while the graph loads.  Optional. */

@@ -155,6 +155,7 @@ class SynthReadsCfg(C.Structure):
 SYMBOLS = {
     "vgan_last_error": (C.c_char_p, []),
     "vgan_abi_version": (C.c_int, []),
+    "vgan_host_release_memory": (None, [C.c_int]),
     "vgan_device_count": (C.c_int, []),
     "vgan_device_warmup": (C.c_int, [C.c_int]),
     "vgan_graph_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp)]),

@@ -35,18 +35,21 @@ bool read_bytes_maybe_gz(const std::string &path, ByteBuf &out); // the same for
 // Allocator for the front end's large arrays: default-initialises (resize() does not write, so the pages of a merged
 // array are first touched by the threads that fill it, not zeroed serially by the caller) and asks for transparent
 // huge pages on big blocks (512x fewer page faults where THP is in madvise mode).
+void big_free_bytes(void *p, size_t bytes);
 template <class T> struct BigAlloc {
     using value_type = T;
     BigAlloc() = default;
     template <class U> BigAlloc(const BigAlloc<U> &) {}
     T *allocate(size_t n);
-    void deallocate(T *p, size_t) { free(p); }
+    void deallocate(T *p, size_t n) { big_free_bytes(p, n * sizeof(T)); }
     template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new ((void *)p) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
     template <class U> bool operator==(const BigAlloc<U> &) const { return true; }
     template <class U> bool operator!=(const BigAlloc<U> &) const { return false; }
 };
-void *big_alloc_bytes(size_t bytes); // util.cpp; throws std::bad_alloc
+void *big_alloc_bytes(size_t bytes);         // util.cpp; throws std::bad_alloc
+void big_free_bytes(void *p, size_t bytes); // with the size given to big_alloc_bytes (blocks of 64 KB and more are recycled)
+void big_pool_release(int n_threads);       // the recycled blocks back to the system
 template <class T> T *BigAlloc<T>::allocate(size_t n) { return static_cast<T *>(big_alloc_bytes(n * sizeof(T))); }
 template <class T> using BigVec = std::vector<T, BigAlloc<T>>;
 struct ByteBuf : BigVec<char> { // the few std::string operations the front end uses on byte arrays

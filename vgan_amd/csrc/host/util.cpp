@@ -324,7 +324,36 @@ bool read_file(const std::string &path, std::string &out, bool inflate_if_gzip) 
     return true;
 }
 
-void *big_alloc_bytes(size_t bytes) {
+// Large blocks are recycled, not returned: every munmap interrupts all the cores the process runs on and every fresh mapping
+// is faulted in page by page, and the front end allocates a few hundred large arrays per chunk of reads from up to 128 threads
+// (freeing one parsed chunk of 262k reads cost 55-110 ms on the 256-core box; freeing it on a thread of its own, beside the
+// flatten threads' page faults, made a run take anything from 0.7 to 4 s).  Size classes 2^k and 1.5 * 2^k from 64 KB up;
+// a freed block waits in its class for the next request, up to a cap, beyond which it goes back to the system.
+namespace {
+constexpr size_t POOL_MIN = 64u << 10;
+constexpr size_t POOL_MAX = 256u << 20; // larger blocks (a whole inflated input) are one of a kind: not kept
+constexpr size_t POOL_CAP = (size_t)12 << 30;
+struct BlockPool {
+    std::mutex mu;
+    std::vector<void *> free_blocks[2 * 48];
+    size_t held = 0;
+};
+BlockPool &block_pool() {
+    static BlockPool *p = new BlockPool; // never destroyed: blocks are handed back during static destruction too
+    return *p;
+}
+// smallest class >= bytes: index 2k for 2^k, 2k + 1 for 1.5 * 2^k
+inline size_t pool_class(size_t bytes, size_t *cls_bytes) {
+    size_t k = 16;
+    while (((size_t)1 << k) < bytes && k < 47) ++k;
+    if (k > 16 && ((size_t)3 << (k - 2)) >= bytes) { // 1.5 * 2^(k-1)
+        *cls_bytes = (size_t)3 << (k - 2);
+        return 2 * (k - 1) + 1;
+    }
+    *cls_bytes = (size_t)1 << k;
+    return 2 * k;
+}
+void *raw_big_alloc(size_t bytes) {
     constexpr size_t HUGE = 2u << 20;
     void *p = nullptr;
     if (bytes >= HUGE) {
@@ -334,8 +363,74 @@ void *big_alloc_bytes(size_t bytes) {
     } else {
         p = malloc(bytes ? bytes : 1);
     }
+    return p;
+}
+} // namespace
+
+void *big_alloc_bytes(size_t bytes) {
+    void *p = nullptr;
+    if (bytes >= POOL_MIN && bytes <= POOL_MAX) {
+        size_t cb;
+        const size_t c = pool_class(bytes, &cb);
+        BlockPool &bp = block_pool();
+        {
+            std::lock_guard<std::mutex> lk(bp.mu);
+            auto &v = bp.free_blocks[c];
+            if (!v.empty()) {
+                p = v.back();
+                v.pop_back();
+                bp.held -= cb;
+            }
+        }
+        if (!p) p = raw_big_alloc(cb);
+    } else {
+        p = raw_big_alloc(bytes);
+    }
     if (!p) throw std::bad_alloc();
     return p;
+}
+
+// every recycled block back to the system, on n_threads threads (the kernel unmaps disjoint ranges in parallel)
+void big_pool_release(int n_threads) {
+    std::vector<void *> all;
+    {
+        BlockPool &bp = block_pool();
+        std::lock_guard<std::mutex> lk(bp.mu);
+        for (auto &v : bp.free_blocks) {
+            all.insert(all.end(), v.begin(), v.end());
+            v.clear();
+        }
+        bp.held = 0;
+    }
+    n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_threads), all.size()));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= all.size()) break;
+            free(all[i]);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+void big_free_bytes(void *p, size_t bytes) {
+    if (!p) return;
+    if (bytes >= POOL_MIN && bytes <= POOL_MAX) {
+        size_t cb;
+        const size_t c = pool_class(bytes, &cb);
+        BlockPool &bp = block_pool();
+        std::lock_guard<std::mutex> lk(bp.mu);
+        if (bp.held + cb <= POOL_CAP) {
+            bp.free_blocks[c].push_back(p);
+            bp.held += cb;
+            return;
+        }
+    }
+    free(p);
 }
 
 MappedFile::~MappedFile() {
@@ -396,3 +491,4 @@ bool read_text_maybe_gz(const std::string &path, std::string &out) {
 
 extern "C" const char *vgan_last_error(void) { return vgan::last_error(); }
 extern "C" int vgan_abi_version(void) { return VGAN_ABI_VERSION; }
+extern "C" void vgan_host_release_memory(int n_threads) { vgan::big_pool_release(n_threads > 0 ? n_threads : 16); }
