@@ -328,11 +328,19 @@ bool read_file(const std::string &path, std::string &out, bool inflate_if_gzip) 
 // is faulted in page by page, and the front end allocates a few hundred large arrays per chunk of reads from up to 128 threads
 // (freeing one parsed chunk of 262k reads cost 55-110 ms on the 256-core box; freeing it on a thread of its own, beside the
 // flatten threads' page faults, made a run take anything from 0.7 to 4 s).  Size classes 2^k and 1.5 * 2^k from 64 KB up;
-// a freed block waits in its class for the next request, up to a cap, beyond which it goes back to the system.
+// a freed block waits in its class for the next request, up to a cap (pool_cap), beyond which it goes back to the system.
 namespace {
 constexpr size_t POOL_MIN = 64u << 10;
 constexpr size_t POOL_MAX = 256u << 20; // larger blocks (a whole inflated input) are one of a kind: not kept
-constexpr size_t POOL_CAP = (size_t)12 << 30;
+// at most 12 GB and an eighth of the machine's memory wait in the pool
+static size_t pool_cap() {
+    static const size_t cap = [] {
+        const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+        const size_t ram = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz : (size_t)64 << 30;
+        return std::min((size_t)12 << 30, ram / 8);
+    }();
+    return cap;
+}
 struct BlockPool {
     std::mutex mu;
     std::vector<void *> free_blocks[2 * 48];
@@ -424,7 +432,7 @@ void big_free_bytes(void *p, size_t bytes) {
         const size_t c = pool_class(bytes, &cb);
         BlockPool &bp = block_pool();
         std::lock_guard<std::mutex> lk(bp.mu);
-        if (bp.held + cb <= POOL_CAP) {
+        if (bp.held + cb <= pool_cap()) {
             bp.free_blocks[c].push_back(p);
             bp.held += cb;
             return;
