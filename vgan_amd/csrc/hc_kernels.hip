@@ -285,11 +285,13 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                                                                       double *__restrict__ segD_out,
                                                                       double *__restrict__ nodeW,
                                                                       double *__restrict__ totals) {
-    __shared__ double lq_s[256];
     __shared__ StLom lom_s[101][2];   // [qscore index, 100 = background error rate][mismatch, match]
     __shared__ double bg_s[5];
-    __shared__ double ps_s[ST_QUAL + 1]; // wave-local prefix sums of log p_err over the tile's quality bytes
-    __shared__ double wsum_s[ST_WAVES];  // each wave's total
+    // log p_err of a quality byte is log(10^(-Q/10)) = -Q ln(10)/10 for Q > 2 and log(0.25) otherwise (src/miscfunc.h:180-188 on
+    // int(char)): its prefix sums are kept as INTEGERS, sum of the Q above 2 in bits 11.. and the count of the others in bits
+    // 0..10 (1280 bytes of at most 127: 18 + 11 bits), wave-local; U_m is one multiply-add per segment on exact differences.
+    __shared__ uint32_t ps_s[ST_QUAL + 1];
+    __shared__ uint32_t wsum_s[ST_WAVES]; // each wave's total
     __shared__ double segS_s[ST_SEGS];
     __shared__ StSegKL segkl_s[ST_SEGS];
     __shared__ StSegGeo seggeo_s[ST_SEGS];
@@ -311,7 +313,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     __shared__ double win_s[WIN];      // W[winbase .. winbase + WIN) of this workgroup's reads
 
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double lq0 = g.lq[0];
     double sumT = 0.0, sumU = 0.0; // sum of the column terms (= sum of S_m) and of U_m, each without cancellation
     uint32_t winbase = 0xFFFFFFFFu; // no window yet (workgroup uniform)
     bool need_min = true;           // the next tile places the window (workgroup uniform)
@@ -432,7 +433,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     uint32_t r0 = rb0, cur = 0;
     header_request(r0);
     // the workgroup's tables, built while the first header is on its way
-    for (int i = tid; i < 256; i += ST_THREADS) lq_s[i] = g.lq[i];
     for (int i = tid; i < 202; i += ST_THREADS) {
         const int qi = i >> 1;
         const double e = (qi == 100 || prm.use_bep) ? prm.bep : g.qscore[qi];
@@ -495,19 +495,20 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                     }
                 }
             }
-            double loc[ST_QB];
-            double run = 0.0;
+            uint32_t loc[ST_QB];
+            uint32_t run = 0u;
 #pragma unroll
             for (int e = 0; e < ST_QB; ++e) {
-                run += lq_s[qb[e]];
+                const int Q = (int)(int8_t)qb[e];
+                run += Q > 2 ? (uint32_t)Q << 11 : 1u;
                 loc[e] = run;
             }
-            const double incl = wave_incl_scan(run);
-            const double before = incl - run;
+            const uint32_t incl = wave_incl_scan_u32(run);
+            const uint32_t before = incl - run;
 #pragma unroll
             for (int e = 0; e < ST_QB; ++e) ps_s[i0 + e + 1] = before + loc[e];
             if (lane == 63) wsum_s[wave] = incl;
-            if (tid == 0) ps_s[0] = 0.0;
+            if (tid == 0) ps_s[0] = 0u;
             need_min = need_min || tilebits_s[3] != 0u;
         }
         PT_MARK(2);
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         // ---- C: one lane per segment
         double segU[ST_SEG_ITERS];
         {
-            const double ws0 = wsum_s[0], ws1 = wsum_s[1], ws2 = wsum_s[2];
+            const uint32_t ws0 = wsum_s[0], ws1 = wsum_s[1], ws2 = wsum_s[2];
             uint32_t nmin = 0xFFFFFFFFu;
             bool own_bep = false;
             if (tid == 0) tilebits_s[3] = 0u;
@@ -535,11 +536,13 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                     const uint32_t start = L.start[it], len = L.len[it];
                     const uint32_t lo = min(start, QL), hi = min(start + A, QL);
                     const uint32_t ilo = qoff + lo, ihi = qoff + hi;
-                    double U = ps_s[ihi] - ps_s[ilo];
-                    U += (ilo <= 1u * ST_QW && ihi > 1u * ST_QW) ? ws0 : 0.0;
-                    U += (ilo <= 2u * ST_QW && ihi > 2u * ST_QW) ? ws1 : 0.0;
-                    U += (ilo <= 3u * ST_QW && ihi > 3u * ST_QW) ? ws2 : 0.0;
-                    U += (double)(A - (hi - lo)) * lq0; // Q5 zero padding
+                    uint32_t pk = ps_s[ihi] - ps_s[ilo]; // (wave-local sums: whole waves in between are added back)
+                    pk += (ilo <= 1u * ST_QW && ihi > 1u * ST_QW) ? ws0 : 0u;
+                    pk += (ilo <= 2u * ST_QW && ihi > 2u * ST_QW) ? ws1 : 0u;
+                    pk += (ilo <= 3u * ST_QW && ihi > 3u * ST_QW) ? ws2 : 0u;
+                    // Q5: the bytes beyond the quality string count as Q = 0, i.e. among the "others"
+                    const uint32_t n_low = (pk & 2047u) + (A - (hi - lo));
+                    const double U = fma((double)(pk >> 11), -0.23025850929940457 /* ln(10) / 10 */, (double)n_low * -1.3862943611198906 /* log(0.25) */);
                     segU[it] = U;
                     sumU += U;
                     const bool sticky = first90_s[k] < hi; // update_likelihood.cpp:42
