@@ -480,10 +480,16 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
             const uint32_t i0 = tid * ST_QB;
             uint32_t qb[ST_QB];
             bool hot = false;
+            { // the lane's 5 bytes lie in two consecutive dwords: one LDS read instead of five
+                static_assert(ST_QB == 5, "two dwords hold the lane's bytes");
+                const uint32_t o = qshift + i0;
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(qual_s + (o & ~3u)); // (ds_read2_b32)
+                const uint64_t bytes = (((uint64_t)w[1] << 32) | w[0]) >> (8u * (o & 3u));
 #pragma unroll
-            for (int e = 0; e < ST_QB; ++e) { // all byte reads first, one rare branch for the lot
-                qb[e] = qual_s[qshift + i0 + e];
-                hot |= (int)(int8_t)qb[e] >= 90;
+                for (int e = 0; e < ST_QB; ++e) { // one rare branch for the lot
+                    qb[e] = (uint32_t)(bytes >> (8 * e)) & 0xFFu;
+                    hot |= (int)(int8_t)qb[e] >= 90;
+                }
             }
             if (hot) { // rare: Q >= 90 switches the read to the background error rate
                 for (int e = 0; e < ST_QB; ++e) {
