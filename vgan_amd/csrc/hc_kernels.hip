@@ -308,7 +308,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     __shared__ uint32_t first90_s[ST_READS];
     __shared__ StTile tile_s[2];
     __shared__ uint32_t tilebits_s[4]; // [0] bit 0: a segment takes the background error rate on its own; [1] lowest node id
-                                       // (when the window is to be placed); [3] the tile left the window
+                                       // (when the window is to be placed); [2] a quality byte >= 90 in the tile;
+                                       // [3] the tile left the window
     constexpr int WIN = ST_READS <= 8 ? ST_WIN : ST_WIN_SHORT; // (the 24-read variant holds more header: a smaller window keeps it at 4 workgroups per CU)
     __shared__ double win_s[WIN];      // W[winbase .. winbase + WIN) of this workgroup's reads
 
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                 }
             }
             if (hot) { // rare: Q >= 90 switches the read to the background error rate
+                tilebits_s[2] = 1u; // (phase C looks at first90_s only then)
                 for (int e = 0; e < ST_QB; ++e) {
                     const uint32_t i = i0 + e, gq = T.q_base + i;
                     if ((int)(int8_t)qb[e] >= 90 && i < T.n_q) {
@@ -525,6 +527,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
         double segU[ST_SEG_ITERS];
         {
             const uint32_t ws0 = wsum_s[0], ws1 = wsum_s[1], ws2 = wsum_s[2];
+            const bool any_hot = __builtin_amdgcn_readfirstlane((int)tilebits_s[2]) != 0; // a quality >= 90 somewhere in the tile
             uint32_t nmin = 0xFFFFFFFFu;
             bool own_bep = false;
             if (tid == 0) tilebits_s[3] = 0u;
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                     const double U = fma((double)(pk >> 11), -0.23025850929940457 /* ln(10) / 10 */, (double)n_low * -1.3862943611198906 /* log(0.25) */);
                     segU[it] = U;
                     sumU += U;
-                    const bool sticky = first90_s[k] < hi; // update_likelihood.cpp:42
+                    const bool sticky = any_hot && first90_s[k] < hi; // update_likelihood.cpp:42
                     own_bep |= sticky && !prm.use_bep;
                     const uint32_t use_bep = (prm.use_bep || sticky) ? 1u : 0u;
                     const uint32_t cs = colbase + start;
