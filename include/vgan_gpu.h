@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGAN_ABI_VERSION 2
+#define VGAN_ABI_VERSION 3
 
 enum {
     VGAN_OK = 0,
@@ -179,6 +179,9 @@ typedef struct vgan_hc_batch {
      * accordingly (tileable reads first, sorted by node id; read_src tells which read of the input each one is). */
     uint32_t n_tileable;
     const uint32_t *read_src;     /* [n_reads] index of the read in the alignment set, or NULL (not used by the device) */
+    /* (ABI 3) The device-resident companion of the tileable reads in the layout the segment kernel streams, from
+     * vgan_hc_pack, or NULL: vgan_hc_accumulate then runs the layout pass itself, into the context's scratch, every call. */
+    const struct vgan_hc_packed *packed;
 } vgan_hc_batch;
 /* Batch contract: read_*_off ascending; the segments of a read ascend in seg_start.
  * Layout limit (narrower than the reference and the oracle, which have none): a read has at most 65535 alignment
@@ -275,6 +278,15 @@ int vgan_hc_reset(vgan_hc_ctx *c);                         /* zero the accumulat
  * n_tileable reads).  vgan_hc_accumulate only checks for null arrays: batches from vgan_hc_flatten* hold by
  * construction, hand-built ones should be validated once (O(reads + segments) on the host). */
 int vgan_hc_batch_validate(const vgan_hc_ctx *c, const vgan_hc_batch *batch);
+/* The layout pass on its own, for a batch that stays resident in HBM and is accumulated more than once: the tileable reads
+ * go, once, into the layout the segment kernel streams -- a 32-bit record per alignment column {graph byte, read byte as
+ * update_likelihood.cpp:46 pairs them, quality byte, first-column-of-a-mapping bit}, an 8-byte record per mapping, a
+ * 16-byte header per read.  Bytes are moved, nothing is compared, clamped or looked up.  The result belongs to the
+ * context's device, is independent of the batch's own arrays afterwards (the reads beyond n_tileable still use them) and is
+ * handed back through vgan_hc_batch.packed.  Synchronises the context's stream. */
+typedef struct vgan_hc_packed vgan_hc_packed; /* opaque */
+int vgan_hc_pack(vgan_hc_ctx *c, const vgan_hc_batch *batch, vgan_hc_packed **out);
+void vgan_hc_packed_free(vgan_hc_packed *p);
 /* Asynchronous on the context's stream: adds the batch's reads into the device accumulators. */
 int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *batch);
 /* Per-segment scalars of a batch (test / debug aid): S_m, U_m as the kernel computes them. Host outputs. */
@@ -297,8 +309,9 @@ int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_rccl);
 void vgan_hc_destroy(vgan_hc_ctx *c);
 
 /* Per-kernel device timing with HIP events on the context's stream (bench.py's roofline figure).
- * Slots: 0 segment kernel, 1 per-segment mask sweep, 2 per-node mask sweep, 3 finish, 4 node-weight accumulate. */
-enum { VGAN_HC_K_SEGMENT = 0, VGAN_HC_K_SWEEP_SEG = 1, VGAN_HC_K_SWEEP_NODE = 2, VGAN_HC_K_FINISH = 3, VGAN_HC_K_NODEACC = 4,
+ * Slots: 0 segment kernel, 1 per-segment mask sweep, 2 per-node mask sweep, 3 finish, 4 the layout pass when vgan_hc_accumulate
+ * has to run it (a batch without .packed). */
+enum { VGAN_HC_K_SEGMENT = 0, VGAN_HC_K_SWEEP_SEG = 1, VGAN_HC_K_SWEEP_NODE = 2, VGAN_HC_K_FINISH = 3, VGAN_HC_K_PACK = 4,
        VGAN_HC_K_COUNT = 5 };
 int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable);  /* also clears the counters */
 /* synchronises the stream; ms[i] = summed device time of kernel i, launches[i] = number of launches timed */

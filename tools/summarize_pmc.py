@@ -12,7 +12,7 @@ d = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0]
+        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         if "vgan::" in k:
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}

@@ -35,7 +35,7 @@ class HcBatch(C.Structure):
                 ("read_seg_off", vp), ("read_col_off", vp), ("read_qual_off", vp), ("read_algn_len", vp),
                 ("read_mapq", vp), ("seg_node", vp), ("seg_start", vp), ("seg_len", vp), ("graph_seq", vp),
                 ("algnseq", vp), ("qual", vp), ("on_device", C.c_int32), ("n_tileable", C.c_uint32),
-                ("read_src", vp)]
+                ("read_src", vp), ("packed", vp)]
 
 
 class FlattenStats(C.Structure):
@@ -195,6 +195,8 @@ SYMBOLS = {
     "vgan_hc_set_stream": (C.c_int, [vp, vp]),
     "vgan_hc_set_mode": (C.c_int, [vp, C.c_int]),
     "vgan_hc_reset": (C.c_int, [vp]),
+    "vgan_hc_pack": (C.c_int, [vp, C.POINTER(HcBatch), C.POINTER(vp)]),
+    "vgan_hc_packed_free": (None, [vp]),
     "vgan_hc_accumulate": (C.c_int, [vp, C.POINTER(HcBatch)]),
     "vgan_hc_segment_scalars": (C.c_int, [vp, C.POINTER(HcBatch), vp, vp]),
     "vgan_hc_batch_validate": (C.c_int, [vp, C.POINTER(HcBatch)]),
@@ -262,6 +264,8 @@ SYMBOLS = {
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),
 }
 
+ABI_VERSION = 3  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
+
 HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the null stream by name (a NULL argument selects the context's own stream)
 
 
@@ -297,6 +301,9 @@ def load(path=None):
         f = getattr(L, name)  # AttributeError if the symbol is not exported
         f.restype = res
         f.argtypes = args
+    if L.vgan_abi_version() != ABI_VERSION:
+        raise ImportError("vgan_amd: %s speaks ABI %d, this binding ABI %d -- rebuild with `python -m vgan_amd.build`"
+                          % (p, L.vgan_abi_version(), ABI_VERSION))
     if path is None:
         _lib = L
     return L

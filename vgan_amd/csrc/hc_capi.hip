@@ -76,6 +76,24 @@ double match_prob(int pangenome_base) {
 
 } // namespace
 
+// the tileable reads of one batch in the wave kernel's layout (hc_device.h: HcPackedDev), device resident
+struct vgan_hc_packed {
+    int device = 0;
+    DevBuf<uint4> rhdr;
+    DevBuf<uint2> srec;
+    DevBuf<uint32_t> crec;
+    DevBuf<uint8_t> qualp;
+    DevBuf<uint32_t> maxima;
+    HcPackedDev d{};
+    void release() {
+        rhdr.release();
+        srec.release();
+        crec.release();
+        qualp.release();
+        maxima.release();
+    }
+};
+
 struct vgan_hc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -96,6 +114,7 @@ struct vgan_hc_ctx {
     DevBuf<uint32_t> s_u32;
     DevBuf<uint16_t> s_u16;
     DevBuf<uint8_t> s_u8;
+    vgan_hc_packed scratch_pack; // layout pass output of batches that come without a packed companion
     // posterior
     std::vector<std::string> path_names;
     std::unordered_map<std::string, uint32_t> path_index;
@@ -234,6 +253,89 @@ int check_batch(const vgan_hc_batch *b) {
     if (b->n_segments && (!b->seg_node || !b->seg_start || !b->seg_len)) return fail(VGAN_EINVAL, "batch: null per-segment array");
     if (b->n_cols && (!b->graph_seq || !b->algnseq)) return fail(VGAN_EINVAL, "batch: null sequence array");
     if (b->n_qual && !b->qual) return fail(VGAN_EINVAL, "batch: null quality array");
+    return VGAN_OK;
+}
+
+// VGAN_HC_KERNEL=tile keeps the tileable reads on the LDS-tiled kernel (developer aid: A/B runs of the two data paths)
+bool wave_kernel_enabled() {
+    const char *e = getenv("VGAN_HC_KERNEL"); // (read per call: a test flips it between two accumulates)
+    return !(e && strcmp(e, "tile") == 0);
+}
+
+// The layout pass over reads [0, nt) of the staged batch d into P (hc_device.h: HcPackedDev).  max_segs / max_qual: the
+// largest per-read counts when the caller knows them (host arrays); otherwise (readback) they are taken from the device,
+// which synchronises the stream.
+int pack_into(vgan_hc_ctx *c, const vgan_hc_batch *b, const HcBatchDev &d, uint32_t nt, vgan_hc_packed &P, bool readback,
+              uint32_t max_segs, uint32_t max_qual, uint32_t max_cols) {
+    int rc;
+    P.device = c->device;
+    if ((rc = P.rhdr.reserve((size_t)nt + 1)) || (rc = P.srec.reserve(std::max<size_t>(1, b->n_segments))) ||
+        (rc = P.crec.reserve(std::max<size_t>(1, b->n_cols))) || (rc = P.qualp.reserve((size_t)b->n_qual + 32)) ||
+        (rc = P.maxima.reserve(4)))
+        return rc;
+    launch_hc_pack(d, nt, b->n_cols, b->n_qual, P.rhdr.p, P.srec.p, P.crec.p, P.qualp.p, readback ? P.maxima.p : nullptr, c->stream);
+    HIPCHK(hipGetLastError());
+    if (readback) {
+        uint32_t mx[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(mx, P.maxima.p, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        max_segs = mx[0];
+        max_qual = mx[1];
+        max_cols = mx[2];
+    }
+    P.d.rhdr = P.rhdr.p;
+    P.d.srec = P.srec.p;
+    P.d.crec = P.crec.p;
+    P.d.qualp = P.qualp.p;
+    P.d.n_reads = nt;
+    P.d.n_segments = b->n_segments;
+    P.d.n_cols = b->n_cols;
+    P.d.n_qual = b->n_qual;
+    P.d.max_read_segs = max_segs;
+    P.d.max_read_qual = max_qual;
+    P.d.max_read_cols = max_cols;
+    return VGAN_OK;
+}
+
+// D_m per segment (segD) and / or W[node] += D_m (nodeW) and the totals for every read of the batch: the tileable reads
+// through the wave kernel on their packed form (the batch's companion, or the context's scratch filled here), the others
+// through the general kernel.  `staged`: d holds the batch's arrays on the device already.
+int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *nodeW, double *totals, HcBatchDev *staged = nullptr) {
+    int rc;
+    const uint32_t nt = std::min(b->n_tileable, b->n_reads);
+    const uint32_t mean_cols = (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads));
+    const vgan_hc_packed *pk = nullptr;
+    if (nt && b->packed) {
+        if (b->packed->device != c->device || b->packed->d.n_reads != nt || b->packed->d.n_segments != b->n_segments)
+            return fail(VGAN_EINVAL, "batch: the packed companion belongs to another batch or device");
+        if (hc_wave_kernel_fits(b->packed->d.max_read_segs, b->packed->d.max_read_qual, b->packed->d.max_read_cols)) pk = b->packed;
+    }
+    HcBatchDev d{};
+    const bool need_arrays = staged || !pk || nt < b->n_reads || !wave_kernel_enabled();
+    if (need_arrays && (rc = stage_batch(c, b, d))) return rc;
+    if (staged) *staged = d;
+    if (nt && !pk && !b->on_device && wave_kernel_enabled()) {
+        // host arrays: the per-read maxima that select the kernel variant cost one pass over the offsets here
+        uint32_t ms = 0, mq = 0, mc = 0;
+        for (uint32_t r = 0; r < nt; ++r) {
+            ms = std::max(ms, b->read_seg_off[r + 1] - b->read_seg_off[r]);
+            mq = std::max(mq, b->read_qual_off[r + 1] - b->read_qual_off[r]);
+            mc = std::max(mc, b->read_col_off[r + 1] - b->read_col_off[r]);
+        }
+        if (hc_wave_kernel_fits(ms, mq, mc)) {
+            ScopedTimer t(c, VGAN_HC_K_PACK);
+            if ((rc = pack_into(c, b, d, nt, c->scratch_pack, false, ms, mq, mc))) return rc;
+            pk = &c->scratch_pack;
+        }
+    }
+    ScopedTimer t(c, VGAN_HC_K_SEGMENT);
+    if (pk && wave_kernel_enabled()) {
+        launch_hc_segments_wave(c->g, pk->d, c->prm, segD, nodeW, totals, c->stream);
+        launch_hc_segments_general(c->g, d, c->prm, nt, nullptr, nullptr, segD, nodeW, totals, c->stream);
+    } else {
+        // (a device batch without a companion, reads beyond every variant of the wave kernel)
+        launch_hc_segments(c->g, d, c->prm, nt, mean_cols, nullptr, nullptr, segD, nodeW, totals, c->stream);
+    }
     return VGAN_OK;
 }
 
@@ -424,6 +526,7 @@ extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
     c->s_u32.release();
     c->s_u16.release();
     c->s_u8.release();
+    c->scratch_pack.release();
     c->lists.release();
     c->conf.release();
     for (auto &t : c->timed) {
@@ -497,27 +600,52 @@ extern "C" int vgan_hc_batch_validate(const vgan_hc_ctx *c, const vgan_hc_batch 
     return VGAN_OK;
 }
 
+extern "C" int vgan_hc_pack(vgan_hc_ctx *c, const vgan_hc_batch *b, vgan_hc_packed **out) {
+    if (!c || !out) return fail(VGAN_EINVAL, "vgan_hc_pack: null argument");
+    *out = nullptr;
+    int rc = check_batch(b);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    auto P = new vgan_hc_packed();
+    const uint32_t nt = std::min(b->n_tileable, b->n_reads);
+    HcBatchDev d{};
+    if (nt) {
+        if ((rc = stage_batch(c, b, d)) || (rc = pack_into(c, b, d, nt, *P, true, 0, 0, 0))) {
+            P->release();
+            delete P;
+            return rc;
+        }
+    } else {
+        P->device = c->device;
+        P->d.n_segments = b->n_segments;
+    }
+    *out = P;
+    return VGAN_OK;
+}
+
+extern "C" void vgan_hc_packed_free(vgan_hc_packed *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    p->release();
+    delete p;
+}
+
 extern "C" int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *b) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_accumulate: null context");
     int rc = check_batch(b);
     if (rc) return rc;
     if (b->n_reads == 0) return VGAN_OK;
     HIPCHK(hipSetDevice(c->device));
-    HcBatchDev d{};
-    if ((rc = stage_batch(c, b, d))) return rc;
     if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) {
-        // W[node] += D_m inside the segment kernels (LDS window over the node ids of a workgroup's reads): no per-segment
+        // W[node] += D_m inside the segment kernels (LDS window over the node ids of a wave's reads): no per-segment
         // array leaves the chip
-        ScopedTimer t(c, VGAN_HC_K_SEGMENT);
-        launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, nullptr, c->nodeW.p, c->totals.p, c->stream);
+        if ((rc = run_segments(c, b, nullptr, c->nodeW.p, c->totals.p))) return rc;
     } else {
         if ((rc = c->segD.reserve(b->n_segments))) return rc;
-        {
-            ScopedTimer t(c, VGAN_HC_K_SEGMENT);
-            launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, c->segD.p, nullptr, c->totals.p, c->stream);
-        }
+        HcBatchDev d{}; // (the sweep reads the node ids from the batch's own arrays)
+        if ((rc = run_segments(c, b, c->segD.p, nullptr, c->totals.p, &d))) return rc;
         ScopedTimer t(c, VGAN_HC_K_SWEEP_SEG);
-        launch_hc_sweep(c->g, d.seg_node, c->segD.p, d.n_segments, c->mode == VGAN_HC_MODE_PER_READ, c->acc_seg.p, c->stream);
+        launch_hc_sweep(c->g, d.seg_node, c->segD.p, b->n_segments, c->mode == VGAN_HC_MODE_PER_READ, c->acc_seg.p, c->stream);
     }
     HIPCHK(hipGetLastError());
     return VGAN_OK;
@@ -546,10 +674,8 @@ extern "C" int vgan_hc_segment_weights(vgan_hc_ctx *c, const vgan_hc_batch *b, d
     if (rc) return rc;
     if (b->n_reads == 0 || b->n_segments == 0) return VGAN_OK;
     HIPCHK(hipSetDevice(c->device));
-    HcBatchDev d{};
-    if ((rc = stage_batch(c, b, d))) return rc;
     if ((rc = c->segD.reserve(b->n_segments))) return rc;
-    launch_hc_segments(c->g, d, c->prm, b->n_tileable, (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads)), nullptr, nullptr, c->segD.p, nullptr, nullptr, c->stream);
+    if ((rc = run_segments(c, b, c->segD.p, nullptr, nullptr))) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(D, c->segD.p, (size_t)b->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

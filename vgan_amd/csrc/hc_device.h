@@ -55,6 +55,29 @@ struct HcBatchDev {
     const uint8_t *graph_seq, *algnseq, *qual;
 };
 
+// The tileable reads of a batch in the layout the wave kernel streams (hc_wave_kernels.hip), written once per batch by
+// the layout pass launch_hc_pack -- byte moves only: no comparison, clamp or table lookup happens there.
+//   rhdr   uint4 [n_reads + 1]   {seg_off, qual_off, col_off, |algnseq| | mapq << 16}; entry n_reads holds the end offsets
+//   srec   uint2 [segments]      {node id, seg_start | (read index & 0xFFFF) << 16}
+//   crec   uint32 [columns]      one record per alignment column of the read, at the column's own position col_off + c:
+//                                byte 0 graph_seq[col_off + c], byte 1 algnseq[col_off + c - seg_start] (the read bases are
+//                                taken from the read start: update_likelihood.cpp:46), byte 2 qual[qual_off + c] (0 beyond the
+//                                quality string), bit 31 set on the first column of a segment; columns no segment scores are 0
+//   qualp  uint8 [quality bytes + 32]  the quality strings, zero padded so that any aligned 8-byte word can be read whole
+struct HcPackedDev {
+    const uint4 *rhdr;
+    const uint2 *srec;
+    const uint32_t *crec;
+    const uint8_t *qualp;
+    uint32_t n_reads;       // tileable reads packed
+    uint32_t n_segments;    // upper bounds of the three streams (the batch's totals)
+    uint64_t n_cols;
+    uint64_t n_qual;
+    uint32_t max_read_segs; // over the packed reads: select the kernel variant
+    uint32_t max_read_qual;
+    uint32_t max_read_cols;
+};
+
 struct HcParamsDev {
     double bep;
     int use_bep;
@@ -73,6 +96,18 @@ constexpr uint32_t HC_TILE_MAX_READ_SEGS = 512;
 void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t n_tileable,
                         uint32_t mean_cols_per_read, double *segS, double *segU, double *segD, double *nodeW, double *totals,
                         hipStream_t st);
+// layout pass: packs reads [0, n_tileable) of b into the caller's buffers (sized from the batch totals: n_tileable + 1
+// headers, n_segments records, n_cols column records -- zeroed here --, n_qual + 32 quality bytes).  maxima (device, 3 words,
+// or NULL) receives max segments / quality bytes / columns per packed read.
+void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint2 *srec,
+                    uint32_t *crec, uint8_t *qualp, uint32_t *maxima, hipStream_t st);
+// true when the wave kernel has a variant for reads of that size (otherwise the LDS-tiled kernel takes the batch)
+bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_t max_read_cols);
+void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *segD, double *nodeW,
+                             double *totals, hipStream_t st);
+// reads [r_begin, n_reads) through the general kernel (one wave per read, any length)
+void launch_hc_segments_general(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t r_begin, double *segS,
+                                double *segU, double *segD, double *nodeW, double *totals, hipStream_t st);
 void launch_hc_sweep(const HcGraphDev &g, const uint32_t *item_node, const double *D, uint32_t n_items, int skip_zero,
                      double *acc, hipStream_t st);
 void launch_hc_finish(const double *totals, const double *acc_seg, double *acc_node, uint32_t n_paths, uint32_t n_slots,

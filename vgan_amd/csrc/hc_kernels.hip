@@ -1047,12 +1047,16 @@ void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParams
         else
             hipLaunchKernelGGL(hc_segment_tile_kernel<ST_READS_LONG>, dim3(blocks), dim3(ST_THREADS), 0, st, g, b, prm, nt, per, segD, nodeW, totals);
     }
-    if (nt < b.n_reads) {
-        const uint32_t rest = b.n_reads - nt;
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)rest + SEG_WAVES - 1) / SEG_WAVES, 256u * 8u);
-        hipLaunchKernelGGL(hc_segment_general_kernel, dim3(blocks), dim3(SEG_WAVES * 64), 0, st, g, b, prm, nt, segS, segU,
-                           segD, nodeW, totals);
-    }
+    launch_hc_segments_general(g, b, prm, nt, segS, segU, segD, nodeW, totals, st);
+}
+
+void launch_hc_segments_general(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t r_begin, double *segS,
+                                double *segU, double *segD, double *nodeW, double *totals, hipStream_t st) {
+    if (r_begin >= b.n_reads) return;
+    const uint32_t rest = b.n_reads - r_begin;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)rest + SEG_WAVES - 1) / SEG_WAVES, 256u * 8u);
+    hipLaunchKernelGGL(hc_segment_general_kernel, dim3(blocks), dim3(SEG_WAVES * 64), 0, st, g, b, prm, r_begin, segS, segU, segD,
+                       nodeW, totals);
 }
 
 template <int TB>

@@ -1,0 +1,599 @@
+// HaploCart segment kernel, wave-owned form (gfx950, wave64): S_m, U_m and W[node] += S_m - U_m for the tileable reads
+// of a batch.  Same arithmetic as hc_segment_tile_kernel (hc_kernels.hip; reference: src/process_mapping.cpp:4-91,
+// src/update_likelihood.cpp:19-53, src/get_p_obs_base.cpp:3-69), different data path:
+//
+//   * the batch is read in the packed layout of HcPackedDev (hc_device.h): one 32-bit record per alignment column
+//     {graph byte, read byte, quality byte, head-of-segment bit}, loaded by the column's own lane straight into a register
+//     (256 coalesced bytes per wave and chunk) -- no byte windows in LDS, no index arithmetic per column;
+//   * a WAVE owns its reads: a tile of up to WV_NR consecutive reads (as many as fit CAPS segments / CAPQ quality bytes of
+//     wave-private LDS) is taken through  quality prefix sums -> lane per segment -> lane per column -> lane per segment
+//     by the one wave, so nothing in the tile loop needs a workgroup barrier (LDS operations of a wave execute in order);
+//     the waves of a workgroup share only the read-only tables built before the single __syncthreads();
+//   * W[node] is kept in a wave-private LDS window over the node ids of the wave's reads (the batch is sorted by node id).
+//
+// Per tile:
+//   Q  lane per 8 quality bytes: integer prefix sums (sum of Q above 2, count of the others: log p_err is -Q ln10/10 or
+//      log 0.25, src/miscfunc.h:180-188), one DPP wave scan per 512 bytes
+//   C  lane per segment: U_m from two prefix values, {kappa, lw} of the factorised column term into LDS
+//   D  lane per column: owner segment = running count of head bits (ballot + v_mbcnt), the column's term
+//      log(wobs) + log(om) + log1p(kappa * bg / om) from two table reads and a short series, LDS fp64 add into S_m
+//   E  lane per segment: D_m = S_m - U_m into the window (or straight to HBM outside it), or streamed out
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "device_math.h"
+#include "hc_device.h"
+
+namespace vgan {
+namespace wv {
+
+#ifndef WV_CAPS
+#define WV_CAPS 160 // segments per tile of the small variant (two 150 bp reads on the hcfiles graph: 121 on average)
+#endif
+#ifndef WV_OCC
+#define WV_OCC 4 // workgroups per CU the small variant is compiled for (waves per SIMD: registers)
+#endif
+constexpr int WV_THREADS = 256;
+constexpr int WV_WAVES = WV_THREADS / 64;
+constexpr int WV_NR = 8;    // reads per tile at most (their headers travel in lanes 0..WV_NR of the wave)
+constexpr int WV_WIN = 160; // node ids covered by a wave's W window
+constexpr uint32_t WV_BUF_FLAGS = 0x00020000u; // raw buffer descriptor, 32-bit data format (gfx9)
+constexpr double WV_RHO_MAX = 0.015625; // 2^-6: the series' next term rho^9 / 9 is below 2^-57 relative to log1p's first
+
+struct alignas(16) WvKL { // per segment: kappa = wbg / wobs, lw = log(wobs); a segment with wobs = 0: {+inf, wbg}
+    double kappa, lw;     // (sign of kappa set: the segment takes the background error rate, update_likelihood.cpp:42)
+};
+struct alignas(16) WvLom { // per (error-rate index, base match): log(om), 1 / om
+    double lom, iom;
+};
+struct alignas(32) WvRead { // per read of the tile
+    double omp, lp, ip; // 1 - p_inc, its log (log(1 - bep) for a consensus FASTA), its reciprocal
+    uint32_t a_ql;      // |algnseq| | quality string length << 16
+    uint32_t qoff;      // first quality byte, relative to the tile's quality window
+};
+
+template <int CAPS, int CAPQ> struct WvSlice { // one wave's LDS
+    WvKL kl[CAPS];
+    double S[CAPS];
+    uint32_t ps[CAPQ + 16]; // ps[4 + i]: prefix through byte i of the quality window (ps[3] = 0: the empty prefix)
+    WvRead rd[WV_NR];
+    uint32_t first90[WV_NR];
+    double win[WV_WIN];
+};
+
+__device__ const LogTabEntry wv_log_table[64] = {VGAN_LOG_TABLE};
+
+__device__ __forceinline__ double wv_fma3(double a, double b, double c) { // three-address v_fma_f64 (see hc_kernels.hip)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t wv_scan_u32(uint32_t v) { // wave64 inclusive prefix sum (DPP)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t wv_readlane(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ uint32_t wv_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+using wv_rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ wv_rsrc wv_make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, (int)WV_BUF_FLAGS);
+}
+__device__ __forceinline__ uint32_t wv_load1(wv_rsrc r, uint32_t off) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ uint2 wv_load2(wv_rsrc r, uint32_t off) {
+    using v2 = __attribute__((__vector_size__(2 * sizeof(int)))) int;
+    const v2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    return uint2{(uint32_t)v[0], (uint32_t)v[1]};
+}
+__device__ __forceinline__ uint4 wv_load4(wv_rsrc r, uint32_t off) {
+    using v4 = __attribute__((__vector_size__(4 * sizeof(int)))) int;
+    const v4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+}
+__device__ __forceinline__ double wv_dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+
+// The column term beyond the series' range (rho >= 2^-6: very low mapping quality, low mappability, a mismatch at a very high
+// base quality; wobs = 0): the table-driven log of x = wbg * bg + wobs * om itself.  Out of line: a few percent of the
+// chunks come here, and its constants stay out of the column loop's registers.
+__device__ __attribute__((noinline)) double wv_rare_term(double kappa, double lw, double bgv, double om) {
+    const bool deg = !(kappa < 1e300); // wobs = 0: {inf, wbg}
+    double x = deg ? lw * bgv : fma(kappa, bgv, om);
+    double adj = 0.0;
+    if (x < 2.2250738585072014e-308 && x > 0.0) { // subnormal
+        x *= 18014398509481984.0;                   // 2^54
+        adj = -37.429947750237048;                  // -54 ln 2
+    }
+    const double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval(x, wv_log_table) + adj : x)
+                              : (x == 0.0 ? -INFINITY : __builtin_nan(""));
+    return deg ? lx : lw + lx;
+}
+
+// Q >= 90 switches the rest of the read to the background error rate (update_likelihood.cpp:40-44): first90[k] = index of the
+// first such byte in read k's quality string.  Out of line (real data holds no such quality).  qv: the lane's 8 window bytes
+// at window position pos0; reads: rd / first90 of the tile's n reads; the tile's bytes are window positions [lo, hi).
+__device__ __attribute__((noinline)) void wv_first90(uint2 qv, uint32_t pos0, uint32_t lo, uint32_t hi, uint32_t n, const WvRead *rd,
+                                                     uint32_t *first90) {
+#pragma nounroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t w = e < 4 ? qv.x : qv.y;
+        const int Q = (int)(int8_t)(w >> (8 * (e & 3)));
+        const uint32_t pos = pos0 + (uint32_t)e;
+        if (Q >= 90 && pos >= lo && pos < hi) {
+            uint32_t kk = 0;
+            for (uint32_t t = 1; t < n; ++t) kk += pos >= rd[t].qoff ? 1u : 0u;
+            atomicMin(&first90[kk], pos - rd[kk].qoff);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ the kernel
+struct WvArgs { // only what the kernel reads (every pointer costs two scalar registers for the whole launch)
+    const uint4 *rhdr;
+    const uint2 *srec;
+    const uint32_t *crec;
+    const uint8_t *qualp;
+    const HcNodeDev *node_tab;
+    const double *qscore;
+    const double *rdtab;
+    double *segD_out;
+    double *nodeW;
+    double *totals;
+    double bep;
+    uint32_t n_reads, rows, reads_per_wave;
+    uint32_t qual_bytes; // readable bytes of qualp
+    uint32_t use_bep, consensus;
+};
+
+struct WvTile { // one tile's extents (wave uniform)
+    uint32_t r, n, s_base, n_seg, q_base, n_q, c_base, n_col;
+};
+struct alignas(32) WvRdTab { // rdtab row of a mapping quality: 1 - p_inc, its log, its reciprocal
+    double omp, lp, ip, pad;
+};
+template <int SPASS, int QCH, int NCH> struct WvData { // one tile's HBM data, in flight or arrived
+    uint2 qv[QCH];
+    uint2 sr[SPASS];
+    uint32_t rec[NCH];
+};
+
+// A tile holds at most CAPS segments, CAPQ quality bytes and CAPC alignment columns: everything a tile reads from HBM is
+// requested as a fixed set of loads (bounded by the buffer descriptors: what lies beyond the tile comes back as zeros) one
+// tile ahead.  No load in the tile loop is conditional -- s_waitcnt vmcnt counts in order, and the compiler can only wait for
+// exactly the loads it needs when it knows how many were issued after them.
+template <int CAPS, int CAPQ, int CAPC>
+__global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_segment_wave_kernel(WvArgs a) {
+    constexpr int SPASS = (CAPS + 63) / 64;     // segment passes per tile at most
+    constexpr int QCH = (CAPQ + 8 + 511) / 512; // quality chunks (512 bytes: 8 per lane) per tile at most
+    constexpr int NCH = CAPC / 64;              // column chunks per tile at most
+    static_assert(CAPS >= 64 && CAPC % 64 == 0, "whole chunks");
+    using Slice = WvSlice<CAPS, CAPQ>;
+    using Data = WvData<SPASS, QCH, NCH>;
+    __shared__ WvLom lom_s[101][2]; // [qscore index, 100 = background error rate][mismatch, match]
+    __shared__ double bg_s[8];      // A C T G by (base >> 1) & 3
+    __shared__ WvRdTab rdtab_s[100]; // the read's share of pcm by mapping quality (process_mapping.cpp:41)
+    __shared__ Slice slice_s[WV_WAVES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 202; i += WV_THREADS) {
+        const int qi = i >> 1;
+        const double e = (qi == 100 || a.use_bep) ? a.bep : a.qscore[qi];
+        const double om = (i & 1) ? 1.0 - e : e;
+        lom_s[qi][i & 1] = WvLom{log_pos(om), 1.0 / om};
+    }
+    if (tid < 8) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : tid == 3 ? 0.16644 : 0.25;
+    if (tid < 100) rdtab_s[tid] = WvRdTab{a.rdtab[3 * tid], a.rdtab[3 * tid + 1], a.rdtab[3 * tid + 2], 0.0};
+    Slice &L = slice_s[wave];
+    for (int i = lane; i < WV_WIN; i += 64) L.win[i] = 0.0;
+    if (lane < 4) L.ps[lane] = 0u;
+    __syncthreads(); // the only one: from here on every wave is on its own
+
+    const uint32_t w0 = (blockIdx.x * WV_WAVES + (uint32_t)wave) * a.reads_per_wave;
+    const uint32_t w1 = min(a.n_reads, w0 + a.reads_per_wave);
+    if (w0 >= w1) return;
+
+    const wv_rsrc rs_hdr = wv_make_rsrc(a.rhdr, (a.n_reads + 1u) * 16u);
+    const wv_rsrc rs_node = wv_make_rsrc(a.node_tab, a.rows * 32u);
+    const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u;
+
+    // a tile's header: lane t holds rhdr[first + t] for t = 0..WV_NR (the entry behind the last read gives its end)
+    auto header_load = [&](uint32_t first) {
+        const uint32_t rr = min(first + min((uint32_t)lane, (uint32_t)WV_NR), w1);
+        return wv_load4(rs_hdr, rr * 16u);
+    };
+    // reads [r, r + n), n the largest count whose segments and quality bytes fit the wave's LDS (the offsets ascend, so
+    // "read t still fits" is a prefix property and n is a popcount); one read always fits (the launcher's choice of variant)
+    auto tile_form = [&](const uint4 &h, uint32_t r) {
+        const uint32_t hs0 = wv_first(h.x), hq0 = wv_first(h.y), hc0 = wv_first(h.z);
+        const bool fits = lane >= 1 && lane <= WV_NR && r + (uint32_t)lane <= w1 && h.x - hs0 <= (uint32_t)CAPS && h.y - hq0 <= (uint32_t)CAPQ &&
+                          h.z - hc0 <= (uint32_t)CAPC;
+        const uint32_t n = max(1u, (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fits)));
+        // (clamped: a caller's contract violation must not index past the LDS arrays)
+        const uint32_t n_seg = min(wv_readlane(h.x, n) - hs0, (uint32_t)CAPS), n_q = min(wv_readlane(h.y, n) - hq0, (uint32_t)CAPQ);
+        const uint32_t n_col = min(wv_readlane(h.z, n) - hc0, (uint32_t)CAPC);
+        return WvTile{r, n, hs0, n_seg, hq0, n_q, hc0, n_col};
+    };
+    // every load of a tile, unconditionally (`live` false: descriptors of length zero, nothing is fetched)
+    auto tile_request = [&](const WvTile &t, bool live, Data &d) {
+        const uint32_t a0 = t.q_base & ~7u; // the quality window: aligned 8-byte words
+        const wv_rsrc rs_q = wv_make_rsrc(a.qualp + a0, live ? t.n_q + (t.q_base & 7u) + 8u : 0u); // (whole words: qualp is padded)
+        const wv_rsrc rs_s = wv_make_rsrc(a.srec + t.s_base, live ? t.n_seg * 8u : 0u);
+        const wv_rsrc rs_c = wv_make_rsrc(a.crec + t.c_base, live ? t.n_col * 4u : 0u);
+#pragma unroll
+        for (int k = 0; k < QCH; ++k) d.qv[k] = wv_load2(rs_q, lane8 + (uint32_t)k * 512u);
+#pragma unroll
+        for (int k = 0; k < SPASS; ++k) d.sr[k] = wv_load2(rs_s, lane8 + (uint32_t)k * 512u);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) d.rec[k] = wv_load1(rs_c, lane4 + (uint32_t)k * 256u);
+    };
+    // the nodes' scalars (dependent on the segment records; a lane without a segment reads node 0)
+    auto node_gather = [&](const Data &d, double (&nd_lw)[SPASS], double (&nd_inv)[SPASS], double (&nd_mapp)[SPASS]) {
+#pragma unroll
+        for (int k = 0; k < SPASS; ++k) {
+            const uint32_t o = min(d.sr[k].x, a.rows - 1u) << 5;
+            const uint4 v = wv_load4(rs_node, o);
+            const uint2 m = wv_load2(rs_node, o + 16u);
+            nd_lw[k] = wv_dbl(v.x, v.y);
+            nd_inv[k] = wv_dbl(v.z, v.w);
+            nd_mapp[k] = wv_dbl(m.x, m.y);
+        }
+    };
+    auto window_flush = [&](uint32_t winbase) {
+        for (uint32_t j = lane; j < (uint32_t)WV_WIN; j += 64) {
+            const double v = L.win[j];
+            if (v != 0.0) {
+                unsafeAtomicAdd(&a.nodeW[winbase + j], v);
+                L.win[j] = 0.0;
+            }
+        }
+    };
+
+    double sumT = 0.0, sumU = 0.0;  // sum of S_m and of U_m, each without cancellation
+    uint32_t winbase = 0xFFFFFFFFu; // no window yet (wave uniform)
+    bool need_place = true;
+
+    // ---- prologue: the first tile's header and data, the second tile's header.  In the loop a tile's data was requested a
+    // whole tile earlier and its header two tiles earlier, so nothing in it waits for HBM.
+    uint4 Hn = header_load(w0);
+    WvTile T = tile_form(Hn, w0);
+    uint32_t h_q = Hn.y, h_am = Hn.w; // of the tile's reads (lane t: read r + t): first quality byte, |algnseq| | mapq << 16
+    Hn = header_load(T.r + T.n); // (clamped to the wave's last read: a header nobody uses then)
+    Data D;
+    tile_request(T, true, D);
+
+    while (true) {
+        // the nodes' scalars: the segment records arrived during the tile before, these land during Q
+        double nd_lw[SPASS], nd_inv[SPASS], nd_mapp[SPASS];
+        node_gather(D, nd_lw, nd_inv, nd_mapp);
+        // ---- the next tile: formed from its header (here since the tile before), the header after it requested
+        const bool has_next = T.r + T.n < w1;
+        const WvTile Tn = tile_form(Hn, min(T.r + T.n, w1)); // (meaningless behind the last tile, and unused)
+        const uint32_t hn_q = Hn.y, hn_am = Hn.w;
+        Hn = header_load(Tn.r + Tn.n);
+        const uint32_t a0 = T.q_base & ~7u, qshift = T.q_base & 7u, n_qw = T.n_q + qshift;
+
+        // ---- the tile's reads: one record each
+        {
+            const uint32_t q_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_q, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+            if ((uint32_t)lane < T.n) {
+                const uint32_t A = h_am & 0xFFFFu, QL = min(q_next - h_q, 0xFFFFu);
+                const WvRdTab rt = rdtab_s[min(h_am >> 16, 99u)];
+                L.rd[lane] = WvRead{rt.omp, rt.lp, rt.ip, A | (QL << 16), h_q - a0};
+                L.first90[lane] = 0xFFFFFFFFu;
+            }
+        }
+
+        // ---- Q: prefix sums over the quality window.  Slots past the tile's bytes receive sums nobody reads.
+        bool hot = false;
+        {
+            uint32_t carry = 0u;
+#pragma unroll
+            for (int k = 0; k < QCH; ++k) {
+                if ((uint32_t)k * 512u < n_qw) {
+                    uint32_t loc[8], run = 0u;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t w = e < 4 ? D.qv[k].x : D.qv[k].y;
+                        const int Q = (int)(int8_t)(w >> (8 * (e & 3)));
+                        run += Q > 2 ? (uint32_t)Q << 11 : 1u;
+                        loc[e] = run;
+                        hot |= Q >= 90;
+                    }
+                    const uint32_t incl = wv_scan_u32(run);
+                    const uint32_t before = incl - run + carry;
+                    carry += wv_readlane(incl, 63);
+                    uint4 *dst = reinterpret_cast<uint4 *>(&L.ps[4 + k * 512 + lane * 8]);
+                    if (k * 512 + lane * 8 < CAPQ + 8) { // (the window holds at most CAPQ + 7 bytes)
+                        dst[0] = uint4{before + loc[0], before + loc[1], before + loc[2], before + loc[3]};
+                        dst[1] = uint4{before + loc[4], before + loc[5], before + loc[6], before + loc[7]};
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool tile_hot = __builtin_amdgcn_ballot_w64(hot) != 0; // a quality byte >= 90 in (or just beside) the window
+        if (__builtin_expect(tile_hot, 0)) {
+            // rare: Q >= 90 switches the rest of the read to the background error rate (update_likelihood.cpp:40-44);
+            // first90[k] = index of the first such byte in read k's quality string
+#pragma unroll
+            for (int k = 0; k < QCH; ++k) wv_first90(D.qv[k], (uint32_t)k * 512u + lane8, qshift, n_qw, T.n, L.rd, L.first90);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+
+        // the next tile's data leaves HBM now and has this tile's C, D and E to arrive
+        Data Dn;
+        tile_request(Tn, has_next, Dn);
+
+        // ---- C: one lane per segment
+        double segU[SPASS];
+        uint32_t segnode[SPASS];
+        bool tile_bep = false; // a segment of the tile takes the background error rate on its own (wave uniform)
+#pragma unroll
+        for (int k = 0; k < SPASS; ++k) {
+            segU[k] = 0.0;
+            segnode[k] = 0u;
+            if ((uint32_t)k * 64u < T.n_seg) {
+                const uint32_t ls = (uint32_t)k * 64u + (uint32_t)lane;
+                const bool on = ls < T.n_seg;
+                const uint32_t start = D.sr[k].y & 0xFFFFu;
+                const uint32_t kr = min(((D.sr[k].y >> 16) - T.r) & 0xFFFFu, (uint32_t)WV_NR - 1u);
+                const WvRead rd = L.rd[kr];
+                const uint32_t A = rd.a_ql & 0xFFFFu, QL = rd.a_ql >> 16;
+                const uint32_t lo = min(start, QL), hi = min(start + A, QL);
+                const uint32_t ilo = min(rd.qoff + lo, (uint32_t)CAPQ + 8u), ihi = min(rd.qoff + hi, (uint32_t)CAPQ + 8u);
+                const uint32_t pkd = L.ps[ihi + 3u] - L.ps[ilo + 3u];
+                // Q5: the bytes beyond the quality string count as Q = 0, i.e. among the "others"
+                const uint32_t n_low = (pkd & 2047u) + (A - (hi - lo));
+                const double U = fma((double)(pkd >> 11), -0.23025850929940457 /* ln(10) / 10 */,
+                                     (double)n_low * -1.3862943611198906 /* log(0.25) */);
+                segU[k] = U;
+                segnode[k] = D.sr[k].x;
+                if (on) sumU += U;
+                // wbg = 1 - pcm, wobs = pcm * match (process_mapping.cpp:41,66-75; a consensus FASTA: 0 and (1 - bep) * match)
+                const double pcm = rd.omp * nd_mapp[k];
+                const double wbg = a.consensus ? 0.0 : 1.0 - pcm;
+                double kappa = a.consensus ? 0.0 : wbg * (rd.ip * nd_inv[k]);
+                double lw = rd.lp + nd_lw[k];
+                if (!(kappa < 1e300)) { // wobs = 0 (mapping quality 0, mappability 0): the column is log(wbg * bg)
+                    kappa = INFINITY;
+                    lw = wbg;
+                }
+                if (__builtin_expect(tile_hot, 0)) {
+                    const bool sticky = on && !a.use_bep && L.first90[kr] < hi; // update_likelihood.cpp:42
+                    if (sticky) kappa = -kappa;
+                    tile_bep = tile_bep || __builtin_amdgcn_ballot_w64(sticky) != 0;
+                }
+                if (CAPS % 64 == 0 || on) { // (the last pass of a capacity that is not whole passes)
+                    L.kl[ls] = WvKL{kappa, lw};
+                    L.S[ls] = 0.0;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- D: one lane per alignment column, 64 columns per step
+        {
+            uint32_t segs_before = 0u; // heads in the chunks before this one (scalar)
+            auto chunk = [&](const uint32_t rec) {
+                const uint64_t heads = __builtin_amdgcn_ballot_w64((int32_t)rec < 0);
+                // owner = heads at or below the lane - 1 = (head bit 0 + heads before the chunk - 1: scalar) + (bits 1..l:
+                // v_mbcnt over the head bits shifted down by one); the scalar part goes into the LDS address
+                const WvKL *kl_base = L.kl + (segs_before + (uint32_t)(heads & 1u) - 1u);
+                double *S_base = L.S + (segs_before + (uint32_t)(heads & 1u) - 1u);
+                const uint64_t above0 = heads >> 1;
+                const uint32_t own = __builtin_amdgcn_mbcnt_hi((uint32_t)(above0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)above0, 0u));
+                segs_before += (uint32_t)__builtin_popcountll(heads);
+                const WvKL kl = kl_base[own];
+                // bases: code (b >> 1) & 3 = A C T G -> 0 1 2 3; a byte is one of the four iff it equals its code's letter
+                const uint32_t gb = rec & 0xFFu, rb = (rec >> 8) & 0xFFu;
+                const uint32_t gc8 = (rec << 2) & 0x18u, rc8 = (rec >> 6) & 0x18u;
+                const uint32_t letters = 0x47544341u; // "ACTG"
+                const bool valid = __builtin_amdgcn_ubfe(letters, gc8, 8u) == gb && __builtin_amdgcn_ubfe(letters, rc8, 8u) == rb; // process_mapping.cpp:62-63
+                int q = __builtin_amdgcn_sbfe((int)rec, 16u, 8u);
+                q = q < 0 ? 0 : (q > 99 ? 99 : q); // qscore_vec's index
+                // table row 2 q + (graph base == read base): the compare writes VCC, the add takes it as carry
+                // (1 - eps on a match: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0)
+                uint32_t row;
+                asm("v_cmp_eq_u32_sdwa vcc, %1, %1 src0_sel:BYTE_0 src1_sel:BYTE_1\n\tv_addc_co_u32 %0, vcc, %2, %2, vcc"
+                    : "=v"(row)
+                    : "v"(rec), "v"(q)
+                    : "vcc");
+                if (__builtin_expect(tile_bep, 0)) { // a segment behind a quality >= 90: row 100 holds the background error rate
+                    if (__double2hiint(kl.kappa) < 0) row = 200u + (row & 1u);
+                }
+                const double kappa = fabs(kl.kappa);
+                const WvLom lo = *reinterpret_cast<const WvLom *>(reinterpret_cast<const uint8_t *>(lom_s) + (row << 4));
+                const double bgv = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(bg_s) + rc8);
+                const double rho = kappa * bgv * lo.iom;
+                // log1p(rho): three terms while rho < 2^-13 (the next, rho^4 / 4, is below 6e-17 absolute) ...
+                double p = fma(rho, -1.0 / 3.0, 0.5);
+                p = fma(rho, -p, 1.0);
+                const double l0 = lo.lom + kl.lw;
+                double t = fma(rho, p, l0);
+                if (__builtin_amdgcn_ballot_w64(valid && !(rho < 0.0001220703125)) != 0) {
+                    // ... eight up to 2^-6 (a read of low mapping quality, a mismatch at a high base quality) ...
+                    double p8 = wv_fma3(rho, 1.0 / 8.0, -1.0 / 7.0);
+                    p8 = wv_fma3(rho, p8, 1.0 / 6.0);
+                    p8 = wv_fma3(rho, p8, -0.2);
+                    p8 = wv_fma3(rho, p8, 0.25);
+                    p8 = wv_fma3(rho, p8, -1.0 / 3.0);
+                    p8 = fma(rho, p8, 0.5);
+                    p8 = fma(rho, -p8, 1.0);
+                    t = fma(rho, p8, l0);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(valid && !(rho < WV_RHO_MAX)) != 0, 0)) {
+                        // ... and beyond (very low mapping quality, low mappability, wobs = 0) the table-driven log of x itself
+                        if (valid && !(rho < WV_RHO_MAX)) {
+                            const uint32_t qi = row >> 1;
+                            const double e = (qi == 100u || a.use_bep) ? a.bep : a.qscore[qi];
+                            t = wv_rare_term(kappa, kl.lw, bgv, (row & 1u) ? 1.0 - e : e);
+                        }
+                    }
+                }
+                if (valid) unsafeAtomicAdd(&S_base[own], t);
+            };
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if ((uint32_t)k * 64u < T.n_col) chunk(D.rec[k]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- E: one lane per segment
+        if (a.nodeW && need_place) {
+            // The window sits at the lowest node id of the tile: the batch is sorted by the reads' lowest node id
+            // (vgan_hc_flatten), so the wave's reads stay above it and move through the node ids slowly.  Any other order is
+            // still correct -- a segment outside the window adds to W in HBM directly -- and a tile that leaves the window
+            // with many segments has the next one place it anew.
+            uint32_t nmin = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < SPASS; ++k)
+                if ((uint32_t)k * 64u + (uint32_t)lane < T.n_seg) nmin = min(nmin, segnode[k]);
+            nmin = wave_min_u32(nmin);
+            if (winbase != 0xFFFFFFFFu) window_flush(winbase);
+            winbase = wv_first(nmin);
+            need_place = false;
+        }
+#pragma unroll
+        for (int k = 0; k < SPASS; ++k) {
+            if ((uint32_t)k * 64u < T.n_seg) {
+                const uint32_t ls = (uint32_t)k * 64u + (uint32_t)lane;
+                const bool on = ls < T.n_seg;
+                const double S = L.S[ls];
+                const double Dm = S - segU[k];
+                bool outside = false;
+                if (on) {
+                    sumT += S;
+                    if (a.segD_out) a.segD_out[T.s_base + ls] = Dm;
+                    if (a.nodeW) {
+                        const uint32_t slot = segnode[k] - winbase;
+                        if (slot < (uint32_t)WV_WIN) {
+                            unsafeAtomicAdd(&L.win[slot], Dm);
+                        } else {
+                            unsafeAtomicAdd(&a.nodeW[segnode[k]], Dm);
+                            outside = true;
+                        }
+                    }
+                }
+                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(outside)) > 16) need_place = true;
+            }
+        }
+        if (!has_next) break;
+        T = Tn;
+        h_q = hn_q;
+        h_am = hn_am;
+        D = Dn;
+    }
+    if (a.nodeW && winbase != 0xFFFFFFFFu) window_flush(winbase);
+    sumT = wave_sum(sumT);
+    sumU = wave_sum(sumU);
+    if (lane == 0 && a.totals) {
+        unsafeAtomicAdd(&a.totals[0], sumT);
+        unsafeAtomicAdd(&a.totals[1], sumU);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ layout pass
+// One wave per read: headers, segment records, the column records of every segment at the columns' own positions.
+__global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_pack, uint4 *__restrict__ rhdr,
+                                                      uint2 *__restrict__ srec, uint32_t *__restrict__ crec,
+                                                      uint32_t *__restrict__ maxima) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r > n_pack) return;
+    if (r == n_pack) { // the end offsets
+        if (lane == 0) rhdr[r] = uint4{b.read_seg_off[r], b.read_qual_off[r], b.read_col_off[r], 0u};
+        return;
+    }
+    const uint32_t s0 = b.read_seg_off[r], s1 = b.read_seg_off[r + 1];
+    const uint32_t c0 = b.read_col_off[r], c1 = b.read_col_off[r + 1];
+    const uint32_t q0 = b.read_qual_off[r], q1 = b.read_qual_off[r + 1];
+    const uint32_t A = b.read_algn_len[r];
+    if (lane == 0) {
+        rhdr[r] = uint4{s0, q0, c0, A | ((uint32_t)b.read_mapq[r] << 16)};
+        if (maxima) {
+            atomicMax(&maxima[0], s1 - s0);
+            atomicMax(&maxima[1], q1 - q0);
+            atomicMax(&maxima[2], c1 - c0);
+        }
+    }
+    const uint32_t cols = c1 - c0, QL = q1 - q0;
+    for (uint32_t s = s0 + lane; s < s1; s += 64u) {
+        const uint32_t start = b.seg_start[s], len = b.seg_len[s];
+        srec[s] = uint2{b.seg_node[s], start | ((r & 0xFFFFu) << 16)};
+        const uint32_t cl = start < cols ? min(len, cols - start) : 0u;
+        for (uint32_t j = 0; j < cl; ++j) {
+            const uint32_t c = start + j;
+            const uint32_t gb = b.graph_seq[c0 + c];
+            const uint32_t rb = j < A ? b.algnseq[c0 + j] : 0u; // read bases from the read start (update_likelihood.cpp:46)
+            const uint32_t qb = c < QL ? b.qual[q0 + c] : 0u;   // zero beyond the quality string
+            crec[c0 + c] = gb | (rb << 8) | (qb << 16) | (j == 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+} // namespace wv
+using namespace wv;
+
+bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_t max_read_cols) {
+    return max_read_segs <= 512u && max_read_qual <= 1280u && max_read_cols <= 1280u;
+}
+
+void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint2 *srec,
+                    uint32_t *crec, uint8_t *qualp, uint32_t *maxima, hipStream_t st) {
+    const uint32_t n = std::min(n_tileable, b.n_reads);
+    if (maxima) (void)hipMemsetAsync(maxima, 0, 12, st);
+    if (n_cols) (void)hipMemsetAsync(crec, 0, n_cols * 4, st);
+    if (n_qual) (void)hipMemcpyAsync(qualp, b.qual, n_qual, hipMemcpyDeviceToDevice, st);
+    (void)hipMemsetAsync(qualp + n_qual, 0, 32, st);
+    hipLaunchKernelGGL(hc_pack_kernel, dim3((n + 1 + 3) / 4), dim3(256), 0, st, b, n, rhdr, srec, crec, maxima);
+}
+
+void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *segD, double *nodeW,
+                             double *totals, hipStream_t st) {
+    if (pk.n_reads == 0) return;
+    // contiguous read ranges per wave (the W window wants them), ~16 workgroups per CU so that the dispatcher evens out the CUs
+    const uint32_t want_waves = 256u * 16u * (uint32_t)WV_WAVES;
+    uint32_t per = (pk.n_reads + want_waves - 1) / want_waves;
+    per = std::max(per, 8u);
+    const uint32_t waves = (pk.n_reads + per - 1) / per;
+    const uint32_t blocks = (waves + WV_WAVES - 1) / WV_WAVES;
+    WvArgs a{};
+    a.rhdr = pk.rhdr;
+    a.srec = pk.srec;
+    a.crec = pk.crec;
+    a.qualp = pk.qualp;
+    a.node_tab = g.node_tab;
+    a.qscore = g.qscore;
+    a.rdtab = g.rdtab;
+    a.segD_out = segD;
+    a.nodeW = nodeW;
+    a.totals = totals;
+    a.bep = prm.bep;
+    a.n_reads = pk.n_reads;
+    a.rows = g.rows;
+    a.reads_per_wave = per;
+    a.qual_bytes = (uint32_t)std::min<uint64_t>(0xFFFFFFF0u, pk.n_qual + 32u);
+    a.use_bep = prm.use_bep ? 1u : 0u;
+    a.consensus = prm.consensus ? 1u : 0u;
+    if (pk.max_read_segs <= (uint32_t)WV_CAPS && pk.max_read_qual <= 384u && pk.max_read_cols <= 384u)
+        hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, 384, 384>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((hc_segment_wave_kernel<512, 1280, 1280>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
+}
+
+} // namespace vgan

@@ -368,9 +368,11 @@ class ArrayBatch:
 
 
 class DeviceBatch:
-    """The same SoA resident in HBM as torch tensors (zero-copy hand-over to vgan_hc_accumulate)."""
+    """The same SoA resident in HBM as torch tensors (zero-copy hand-over to vgan_hc_accumulate).  With `ctx`, the
+    tileable reads are also put -- once -- into the packed layout the segment kernel streams (vgan_hc_pack), so that
+    every accumulate of the resident batch is the kernel alone; without it the batch takes the LDS-tiled kernel."""
 
-    def __init__(self, host_batch, device="cuda:0"):
+    def __init__(self, host_batch, device="cuda:0", ctx=None):
         import torch
         self.t = {}
         arrs = host_batch.arrays()
@@ -390,8 +392,29 @@ class DeviceBatch:
         c.on_device = 1
         c.n_tileable = host_batch.c.n_tileable
         c.read_src = None  # host-side bookkeeping only
+        c.packed = None
         self.c = c
         self.n_reads, self.n_segments = c.n_reads, c.n_segments
+        self._packed = N.vp()
+        self.pack_ms = None
+        if ctx is not None:
+            self.pack(ctx)
+
+    def pack(self, ctx):
+        """The layout pass (vgan_hc_pack) on ctx's device; returns its wall time in ms (synchronous)."""
+        import time
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        N.check(N.lib().vgan_hc_pack(ctx._h, C.byref(self.c), C.byref(self._packed)))
+        self.pack_ms = (time.perf_counter() - t0) * 1e3
+        self.c.packed = self._packed
+        return self.pack_ms
+
+    def __del__(self):
+        if getattr(self, "_packed", None) and N is not None:
+            N.lib().vgan_hc_packed_free(self._packed)
+            self._packed = None
 
 
 class HcContext:
@@ -460,7 +483,7 @@ class HcContext:
         ms = np.zeros(5)
         n = np.zeros(5, np.uint64)
         N.check(N.lib().vgan_hc_profile_read(self._h, ms.ctypes.data, n.ctypes.data))
-        names = ("segment", "sweep_segments", "sweep_nodes", "finish", "node_accumulate")
+        names = ("segment", "sweep_segments", "sweep_nodes", "finish", "pack")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def synchronize(self):
