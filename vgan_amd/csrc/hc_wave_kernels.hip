@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "device_math.h"
@@ -33,6 +34,9 @@ namespace wv {
 #ifndef WV_CAPS
 #define WV_CAPS 160 // segments per tile of the small variant (two 150 bp reads on the hcfiles graph: 121 on average)
 #endif
+#ifndef WV_GROUP
+#define WV_GROUP 2 // column chunks whose LDS reads are issued together
+#endif
 #ifndef WV_OCC
 #define WV_OCC 4 // workgroups per CU the small variant is compiled for (waves per SIMD: registers)
 #endif
@@ -41,7 +45,7 @@ constexpr int WV_WAVES = WV_THREADS / 64;
 constexpr int WV_NR = 8;    // reads per tile at most (their headers travel in lanes 0..WV_NR of the wave)
 constexpr int WV_WIN = 160; // node ids covered by a wave's W window
 constexpr uint32_t WV_BUF_FLAGS = 0x00020000u; // raw buffer descriptor, 32-bit data format (gfx9)
-constexpr double WV_RHO_MAX = 0.015625; // 2^-6: the series' next term rho^9 / 9 is below 2^-57 relative to log1p's first
+
 
 struct alignas(16) WvKL { // per segment: kappa = wbg / wobs, lw = log(wobs); a segment with wobs = 0: {+inf, wbg}
     double kappa, lw;     // (sign of kappa set: the segment takes the background error rate, update_likelihood.cpp:42)
@@ -65,6 +69,16 @@ template <int CAPS, int CAPQ> struct WvSlice { // one wave's LDS
 };
 
 __device__ const LogTabEntry wv_log_table[64] = {VGAN_LOG_TABLE};
+
+#ifdef WV_STATS // developer aid: how often the column loop leaves its short path (one count per wave and event)
+__device__ unsigned long long wv_stats[8]; // tiles, reads, chunk groups, far groups, rare groups, segment passes, bep tiles, windows placed
+#define WV_COUNT(slot, n)                                     \
+    do {                                                      \
+        if (lane == 0) atomicAdd(&wv_stats[slot], (unsigned long long)(n)); \
+    } while (0)
+#else
+#define WV_COUNT(slot, n)
+#endif
 
 __device__ __forceinline__ double wv_fma3(double a, double b, double c) { // three-address v_fma_f64 (see hc_kernels.hip)
     double r;
@@ -103,22 +117,6 @@ __device__ __forceinline__ uint4 wv_load4(wv_rsrc r, uint32_t off) {
     return uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
 }
 __device__ __forceinline__ double wv_dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
-
-// The column term beyond the series' range (rho >= 2^-6: very low mapping quality, low mappability, a mismatch at a very high
-// base quality; wobs = 0): the table-driven log of x = wbg * bg + wobs * om itself.  Out of line: a few percent of the
-// chunks come here, and its constants stay out of the column loop's registers.
-__device__ __attribute__((noinline)) double wv_rare_term(double kappa, double lw, double bgv, double om) {
-    const bool deg = !(kappa < 1e300); // wobs = 0: {inf, wbg}
-    double x = deg ? lw * bgv : fma(kappa, bgv, om);
-    double adj = 0.0;
-    if (x < 2.2250738585072014e-308 && x > 0.0) { // subnormal
-        x *= 18014398509481984.0;                   // 2^54
-        adj = -37.429947750237048;                  // -54 ln 2
-    }
-    const double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval(x, wv_log_table) + adj : x)
-                              : (x == 0.0 ? -INFINITY : __builtin_nan(""));
-    return deg ? lx : lw + lx;
-}
 
 // Q >= 90 switches the rest of the read to the background error rate (update_likelihood.cpp:40-44): first90[k] = index of the
 // first such byte in read k's quality string.  Out of line (real data holds no such quality).  qv: the lane's 8 window bytes
@@ -183,6 +181,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     __shared__ WvLom lom_s[101][2]; // [qscore index, 100 = background error rate][mismatch, match]
     __shared__ double bg_s[8];      // A C T G by (base >> 1) & 3
     __shared__ WvRdTab rdtab_s[100]; // the read's share of pcm by mapping quality (process_mapping.cpp:41)
+    __shared__ LogTabEntry logtab_s[64]; // log_tab.h
     __shared__ Slice slice_s[WV_WAVES];
 
     const int tid = threadIdx.x;
@@ -195,6 +194,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         lom_s[qi][i & 1] = WvLom{log_pos(om), 1.0 / om};
     }
     if (tid < 8) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : tid == 3 ? 0.16644 : 0.25;
+    if (tid < 64) logtab_s[tid] = wv_log_table[tid];
     if (tid < 100) rdtab_s[tid] = WvRdTab{a.rdtab[3 * tid], a.rdtab[3 * tid + 1], a.rdtab[3 * tid + 2], 0.0};
     Slice &L = slice_s[wave];
     for (int i = lane; i < WV_WIN; i += 64) L.win[i] = 0.0;
@@ -226,19 +226,21 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         const uint32_t n_col = min(wv_readlane(h.z, n) - hc0, (uint32_t)CAPC);
         return WvTile{r, n, hs0, n_seg, hq0, n_q, hc0, n_col};
     };
-    // every load of a tile, unconditionally (`live` false: descriptors of length zero, nothing is fetched)
-    auto tile_request = [&](const WvTile &t, bool live, Data &d) {
+    // Every load of a tile is issued unconditionally (`live` false: descriptors of length zero, nothing is fetched), each
+    // into the register the same tile position was just consumed from: a slot is refilled for the NEXT tile right behind its
+    // last use, so no second set of registers and no copy between the sets exists.
+    auto request_qual = [&](const WvTile &t, bool live, Data &d) {
         const uint32_t a0 = t.q_base & ~7u; // the quality window: aligned 8-byte words
         const wv_rsrc rs_q = wv_make_rsrc(a.qualp + a0, live ? t.n_q + (t.q_base & 7u) + 8u : 0u); // (whole words: qualp is padded)
-        const wv_rsrc rs_s = wv_make_rsrc(a.srec + t.s_base, live ? t.n_seg * 8u : 0u);
-        const wv_rsrc rs_c = wv_make_rsrc(a.crec + t.c_base, live ? t.n_col * 4u : 0u);
 #pragma unroll
         for (int k = 0; k < QCH; ++k) d.qv[k] = wv_load2(rs_q, lane8 + (uint32_t)k * 512u);
+    };
+    auto request_segs = [&](const WvTile &t, bool live, Data &d) {
+        const wv_rsrc rs_s = wv_make_rsrc(a.srec + t.s_base, live ? t.n_seg * 8u : 0u);
 #pragma unroll
         for (int k = 0; k < SPASS; ++k) d.sr[k] = wv_load2(rs_s, lane8 + (uint32_t)k * 512u);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) d.rec[k] = wv_load1(rs_c, lane4 + (uint32_t)k * 256u);
     };
+    auto rsrc_cols = [&](const WvTile &t, bool live) { return wv_make_rsrc(a.crec + t.c_base, live ? t.n_col * 4u : 0u); };
     // the nodes' scalars (dependent on the segment records; a lane without a segment reads node 0)
     auto node_gather = [&](const Data &d, double (&nd_lw)[SPASS], double (&nd_inv)[SPASS], double (&nd_mapp)[SPASS]) {
 #pragma unroll
@@ -255,7 +257,9 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         for (uint32_t j = lane; j < (uint32_t)WV_WIN; j += 64) {
             const double v = L.win[j];
             if (v != 0.0) {
+#ifndef WV_NOFLUSH // (developer aid: what the flush's global atomics cost)
                 unsafeAtomicAdd(&a.nodeW[winbase + j], v);
+#endif
                 L.win[j] = 0.0;
             }
         }
@@ -272,7 +276,13 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     uint32_t h_q = Hn.y, h_am = Hn.w; // of the tile's reads (lane t: read r + t): first quality byte, |algnseq| | mapq << 16
     Hn = header_load(T.r + T.n); // (clamped to the wave's last read: a header nobody uses then)
     Data D;
-    tile_request(T, true, D);
+    request_qual(T, true, D);
+    request_segs(T, true, D);
+    {
+        const wv_rsrc rs_c = rsrc_cols(T, true);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) D.rec[k] = wv_load1(rs_c, lane4 + (uint32_t)k * 256u);
+    }
 
     while (true) {
         // the nodes' scalars: the segment records arrived during the tile before, these land during Q
@@ -284,6 +294,9 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         const uint32_t hn_q = Hn.y, hn_am = Hn.w;
         Hn = header_load(Tn.r + Tn.n);
         const uint32_t a0 = T.q_base & ~7u, qshift = T.q_base & 7u, n_qw = T.n_q + qshift;
+        WV_COUNT(0, 1);
+        WV_COUNT(1, T.n);
+        WV_COUNT(5, (T.n_seg + 63u) / 64u);
 
         // ---- the tile's reads: one record each
         {
@@ -335,9 +348,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
-        // the next tile's data leaves HBM now and has this tile's C, D and E to arrive
-        Data Dn;
-        tile_request(Tn, has_next, Dn);
+        request_qual(Tn, has_next, D); // the next tile's quality bytes take the registers: a whole tile to arrive
 
         // ---- C: one lane per segment
         double segU[SPASS];
@@ -384,72 +395,119 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                 }
             }
         }
+        request_segs(Tn, has_next, D); // (the node ids this tile's E needs are in segnode)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // ---- D: one lane per alignment column, 64 columns per step
         {
             uint32_t segs_before = 0u; // heads in the chunks before this one (scalar)
-            auto chunk = [&](const uint32_t rec) {
-                const uint64_t heads = __builtin_amdgcn_ballot_w64((int32_t)rec < 0);
-                // owner = heads at or below the lane - 1 = (head bit 0 + heads before the chunk - 1: scalar) + (bits 1..l:
-                // v_mbcnt over the head bits shifted down by one); the scalar part goes into the LDS address
-                const WvKL *kl_base = L.kl + (segs_before + (uint32_t)(heads & 1u) - 1u);
-                double *S_base = L.S + (segs_before + (uint32_t)(heads & 1u) - 1u);
-                const uint64_t above0 = heads >> 1;
-                const uint32_t own = __builtin_amdgcn_mbcnt_hi((uint32_t)(above0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)above0, 0u));
-                segs_before += (uint32_t)__builtin_popcountll(heads);
-                const WvKL kl = kl_base[own];
-                // bases: code (b >> 1) & 3 = A C T G -> 0 1 2 3; a byte is one of the four iff it equals its code's letter
-                const uint32_t gb = rec & 0xFFu, rb = (rec >> 8) & 0xFFu;
-                const uint32_t gc8 = (rec << 2) & 0x18u, rc8 = (rec >> 6) & 0x18u;
-                const uint32_t letters = 0x47544341u; // "ACTG"
-                const bool valid = __builtin_amdgcn_ubfe(letters, gc8, 8u) == gb && __builtin_amdgcn_ubfe(letters, rc8, 8u) == rb; // process_mapping.cpp:62-63
-                int q = __builtin_amdgcn_sbfe((int)rec, 16u, 8u);
-                q = q < 0 ? 0 : (q > 99 ? 99 : q); // qscore_vec's index
-                // table row 2 q + (graph base == read base): the compare writes VCC, the add takes it as carry
-                // (1 - eps on a match: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0)
-                uint32_t row;
-                asm("v_cmp_eq_u32_sdwa vcc, %1, %1 src0_sel:BYTE_0 src1_sel:BYTE_1\n\tv_addc_co_u32 %0, vcc, %2, %2, vcc"
-                    : "=v"(row)
-                    : "v"(rec), "v"(q)
-                    : "vcc");
-                if (__builtin_expect(tile_bep, 0)) { // a segment behind a quality >= 90: row 100 holds the background error rate
-                    if (__double2hiint(kl.kappa) < 0) row = 200u + (row & 1u);
+            // N chunks at a time: every LDS read of the group is issued before the first result is used, so the group pays one
+            // LDS round trip (the chains of the chunks interleave); a group shares the branches to the longer series
+            auto chunks = [&](auto n_tag, const uint32_t *recs) {
+                constexpr int N = decltype(n_tag)::value;
+                const WvKL *klp[N];
+                double *Sp[N];
+                uint32_t own[N], row[N], rc8[N];
+                bool valid[N];
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    const uint32_t rec = recs[u];
+                    const uint64_t heads = __builtin_amdgcn_ballot_w64((int32_t)rec < 0);
+                    // owner = heads at or below the lane - 1 = (head bit 0 + heads before the chunk - 1: scalar) + (bits 1..l:
+                    // v_mbcnt over the head bits shifted down by one); the scalar part goes into the LDS address
+                    klp[u] = L.kl + (segs_before + (uint32_t)(heads & 1u) - 1u);
+                    Sp[u] = L.S + (segs_before + (uint32_t)(heads & 1u) - 1u);
+                    const uint64_t above0 = heads >> 1;
+                    own[u] = __builtin_amdgcn_mbcnt_hi((uint32_t)(above0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)above0, 0u));
+                    segs_before += (uint32_t)__builtin_popcountll(heads);
+                    // bases: code (b >> 1) & 3 = A C T G -> 0 1 2 3; a byte is one of the four iff it equals its code's letter
+                    const uint32_t gb = rec & 0xFFu, rb = (rec >> 8) & 0xFFu;
+                    const uint32_t gc8 = (rec << 2) & 0x18u;
+                    rc8[u] = (rec >> 6) & 0x18u;
+                    const uint32_t letters = 0x47544341u; // "ACTG"
+                    valid[u] = __builtin_amdgcn_ubfe(letters, gc8, 8u) == gb && __builtin_amdgcn_ubfe(letters, rc8[u], 8u) == rb; // process_mapping.cpp:62-63
+                    int q = __builtin_amdgcn_sbfe((int)rec, 16u, 8u);
+                    q = q < 0 ? 0 : (q > 99 ? 99 : q); // qscore_vec's index
+                    // table row 2 q + (graph base == read base): the compare writes VCC, the add takes it as carry
+                    // (1 - eps on a match: get_p_obs_base.cpp:3-27, :67 with tv = ts = 0)
+                    asm("v_cmp_eq_u32_sdwa vcc, %1, %1 src0_sel:BYTE_0 src1_sel:BYTE_1\n\tv_addc_co_u32 %0, vcc, %2, %2, vcc"
+                        : "=v"(row[u])
+                        : "v"(rec), "v"(q)
+                        : "vcc");
                 }
-                const double kappa = fabs(kl.kappa);
-                const WvLom lo = *reinterpret_cast<const WvLom *>(reinterpret_cast<const uint8_t *>(lom_s) + (row << 4));
-                const double bgv = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(bg_s) + rc8);
-                const double rho = kappa * bgv * lo.iom;
-                // log1p(rho): three terms while rho < 2^-13 (the next, rho^4 / 4, is below 6e-17 absolute) ...
-                double p = fma(rho, -1.0 / 3.0, 0.5);
-                p = fma(rho, -p, 1.0);
-                const double l0 = lo.lom + kl.lw;
-                double t = fma(rho, p, l0);
-                if (__builtin_amdgcn_ballot_w64(valid && !(rho < 0.0001220703125)) != 0) {
-                    // ... eight up to 2^-6 (a read of low mapping quality, a mismatch at a high base quality) ...
-                    double p8 = wv_fma3(rho, 1.0 / 8.0, -1.0 / 7.0);
-                    p8 = wv_fma3(rho, p8, 1.0 / 6.0);
-                    p8 = wv_fma3(rho, p8, -0.2);
-                    p8 = wv_fma3(rho, p8, 0.25);
-                    p8 = wv_fma3(rho, p8, -1.0 / 3.0);
-                    p8 = fma(rho, p8, 0.5);
-                    p8 = fma(rho, -p8, 1.0);
-                    t = fma(rho, p8, l0);
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(valid && !(rho < WV_RHO_MAX)) != 0, 0)) {
-                        // ... and beyond (very low mapping quality, low mappability, wobs = 0) the table-driven log of x itself
-                        if (valid && !(rho < WV_RHO_MAX)) {
-                            const uint32_t qi = row >> 1;
-                            const double e = (qi == 100u || a.use_bep) ? a.bep : a.qscore[qi];
-                            t = wv_rare_term(kappa, kl.lw, bgv, (row & 1u) ? 1.0 - e : e);
+                WvKL kl[N];
+#pragma unroll
+                for (int u = 0; u < N; ++u) kl[u] = klp[u][own[u]];
+                if (__builtin_expect(tile_bep, 0)) { // a segment behind a quality >= 90: row 100 holds the background error rate
+#pragma unroll
+                    for (int u = 0; u < N; ++u)
+                        if (__double2hiint(kl[u].kappa) < 0) row[u] = 200u + (row[u] & 1u);
+                }
+                WvLom lo[N];
+                double bgv[N], rho[N], l0[N], t[N];
+                bool far = false;
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    lo[u] = *reinterpret_cast<const WvLom *>(reinterpret_cast<const uint8_t *>(lom_s) + (row[u] << 4));
+                    bgv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(bg_s) + rc8[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    rho[u] = fabs(kl[u].kappa) * bgv[u] * lo[u].iom;
+                    // log1p(rho) by six terms below 2^-8 (the next, rho^7 / 7, is under 2e-18 there).  On HaploCart's own
+                    // pairing of graph and read bases (update_likelihood.cpp:46) two columns in three are mismatches, i.e.
+                    // rho = kappa * bg / e(Q) ~ 1e-3 for a confidently mapped read: this IS the common case.
+                    double p = wv_fma3(rho[u], 1.0 / 6.0, -0.2);
+                    p = wv_fma3(rho[u], p, 0.25);
+                    p = wv_fma3(rho[u], p, -1.0 / 3.0);
+                    p = fma(rho[u], p, 0.5);
+                    p = fma(rho[u], -p, 1.0);
+                    l0[u] = lo[u].lom + kl[u].lw;
+                    t[u] = fma(rho[u], p, l0[u]);
+                    far |= valid[u] && !(rho[u] < 0.00390625);
+                }
+                WV_COUNT(2, 1);
+                if (__builtin_amdgcn_ballot_w64(far) != 0) {
+                    // Beyond (mapping quality below ~50, low mappability): log1p(rho) = log(u) + (rho - (u - 1)) / u with
+                    // u = 1 + rho rounded, the log from the table in LDS (log_tab.h); a segment with wobs = 0 ({inf, wbg}:
+                    // mapping quality 0) scores log(wbg * bg)
+                    WV_COUNT(3, 1);
+#pragma unroll
+                    for (int u = 0; u < N; ++u) {
+                        if (valid[u] && !(rho[u] < 0.00390625)) {
+                            const bool deg = !(fabs(kl[u].kappa) < 1e300);
+                            double x = deg ? kl[u].lw * bgv[u] : 1.0 + rho[u];
+                            const double corr = deg ? 0.0 : (rho[u] - (x - 1.0)) * __builtin_amdgcn_rcp(x);
+                            double adj = 0.0;
+                            if (x < 2.2250738585072014e-308 && x > 0.0) { // subnormal
+                                x *= 18014398509481984.0;                   // 2^54
+                                adj = -37.429947750237048;                  // -54 ln 2
+                            }
+                            const double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval(x, logtab_s) + adj : x)
+                                                      : (x == 0.0 ? -INFINITY : __builtin_nan(""));
+                            t[u] = deg ? lx : l0[u] + (lx + corr);
                         }
                     }
                 }
-                if (valid) unsafeAtomicAdd(&S_base[own], t);
-            };
 #pragma unroll
-            for (int k = 0; k < NCH; ++k)
-                if ((uint32_t)k * 64u < T.n_col) chunk(D.rec[k]);
+                for (int u = 0; u < N; ++u)
+                    if (valid[u]) unsafeAtomicAdd(&Sp[u][own[u]], t[u]);
+            };
+            static_assert(NCH % WV_GROUP == 0, "whole groups");
+            const wv_rsrc rs_cn = rsrc_cols(Tn, has_next);
+#pragma unroll
+            for (int k = 0; k < NCH; k += WV_GROUP) {
+                if constexpr (WV_GROUP == 2) {
+                    if (((uint32_t)k + 1u) * 64u < T.n_col) chunks(std::integral_constant<int, 2>{}, &D.rec[k]);
+                    else if ((uint32_t)k * 64u < T.n_col) chunks(std::integral_constant<int, 1>{}, &D.rec[k]);
+                } else {
+                    if ((uint32_t)k * 64u < T.n_col) chunks(std::integral_constant<int, 1>{}, &D.rec[k]);
+                }
+                // the slots just used take the next tile's columns
+#pragma unroll
+                for (int u = 0; u < WV_GROUP; ++u) D.rec[k + u] = wv_load1(rs_cn, lane4 + (uint32_t)(k + u) * 256u);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -467,6 +525,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
             if (winbase != 0xFFFFFFFFu) window_flush(winbase);
             winbase = wv_first(nmin);
             need_place = false;
+            WV_COUNT(7, 1);
         }
 #pragma unroll
         for (int k = 0; k < SPASS; ++k) {
@@ -496,7 +555,6 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         T = Tn;
         h_q = hn_q;
         h_am = hn_am;
-        D = Dn;
     }
     if (a.nodeW && winbase != 0xFFFFFFFFu) window_flush(winbase);
     sumT = wave_sum(sumT);
@@ -549,6 +607,17 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
 } // namespace wv
 using namespace wv;
 
+#ifdef WV_STATS
+extern "C" int vgan_hc_debug_wave_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(wv_stats), sizeof(wv_stats)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wv_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_t max_read_cols) {
     return max_read_segs <= 512u && max_read_qual <= 1280u && max_read_cols <= 1280u;
 }
@@ -567,7 +636,9 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
                              double *totals, hipStream_t st) {
     if (pk.n_reads == 0) return;
     // contiguous read ranges per wave (the W window wants them), ~16 workgroups per CU so that the dispatcher evens out the CUs
-    const uint32_t want_waves = 256u * 16u * (uint32_t)WV_WAVES;
+    uint32_t wg_per_cu = 16u;
+    if (const char *e = getenv("VGAN_WV_WG_PER_CU")) wg_per_cu = (uint32_t)std::max(1, atoi(e)); // developer aid
+    const uint32_t want_waves = 256u * wg_per_cu * (uint32_t)WV_WAVES;
     uint32_t per = (pk.n_reads + want_waves - 1) / want_waves;
     per = std::max(per, 8u);
     const uint32_t waves = (pk.n_reads + per - 1) / per;
