@@ -458,7 +458,7 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     const size_t accn = (size_t)c->W * 64;
     if ((rc = c->umask.reserve(um.size())) || (rc = c->umaskT.reserve(umT.size())) ||
         (rc = c->tile_word0.reserve(tw0.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(756)) ||
-        (rc = c->accum.reserve(((size_t)c->rows + 7) / 8 * 8 + 2 * accn + 8)) || (rc = c->final_vec.reserve(c->P)))
+        (rc = c->accum.reserve(((size_t)c->rows + 7) / 8 * 8 + 2 * accn + HC_TOTAL_SLOTS * HC_TOTAL_STRIDE)) || (rc = c->final_vec.reserve(c->P)))
         return bail(rc);
     { // sub-ranges of the accumulator block (sweep kernels read 64-byte aligned blocks of weights: keep 64-byte offsets)
         const size_t nW = ((size_t)c->rows + 7) / 8 * 8;
@@ -466,7 +466,7 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         c->acc_seg.p = c->accum.p + nW;
         c->acc_node.p = c->acc_seg.p + accn;
         c->totals.p = c->acc_node.p + accn;
-        c->accum_n = nW + 2 * accn + 8;
+        c->accum_n = nW + 2 * accn + HC_TOTAL_SLOTS * HC_TOTAL_STRIDE;
     }
     if (hipMemcpy(c->umask.p, um.data(), um.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->umaskT.p, umT.data(), umT.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||

@@ -84,6 +84,12 @@ struct HcParamsDev {
     int consensus;
 };
 
+// totals: sum of S_m (and of U_m) over everything accumulated, kept in HC_TOTAL_SLOTS partial sums 128 bytes apart -- every
+// wave of a segment kernel ends with one add, and tens of thousands of adds to ONE address serialise in the L2 (~14 ns each,
+// measured: 65 536 of them set the length of a 0.6 ms launch to 0.9 ms).  Slot s at totals[s * HC_TOTAL_STRIDE + {0, 1}].
+constexpr uint32_t HC_TOTAL_SLOTS = 64;
+constexpr uint32_t HC_TOTAL_STRIDE = 16; // doubles
+
 // per-read limits of the LDS-tiled segment kernel (the tile contract of include/vgan_gpu.h; flatten.cpp applies them)
 // (a read has to fit one LDS tile; every phase of the kernel is flat over the tile, so there is no smaller per-read bound)
 constexpr uint32_t HC_TILE_MAX_READ_COLS = 1280;

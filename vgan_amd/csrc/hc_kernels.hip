@@ -139,8 +139,9 @@ __global__ __launch_bounds__(SEG_WAVES * 64) void hc_segment_general_kernel(HcGr
     sumS = wave_sum(sumS);
     sumU = wave_sum(sumU);
     if (lane == 0 && totals) {
-        unsafeAtomicAdd(&totals[0], sumS);
-        unsafeAtomicAdd(&totals[1], sumU);
+        double *t = totals + ((blockIdx.x * SEG_WAVES + wave) % HC_TOTAL_SLOTS) * HC_TOTAL_STRIDE;
+        unsafeAtomicAdd(&t[0], sumS);
+        unsafeAtomicAdd(&t[1], sumU);
     }
 }
 
@@ -779,8 +780,9 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     sumT = wave_sum(sumT);
     sumU = wave_sum(sumU);
     if (lane == 0 && totals) {
-        unsafeAtomicAdd(&totals[0], sumT);
-        unsafeAtomicAdd(&totals[1], sumU);
+        double *t = totals + ((blockIdx.x * ST_WAVES + wave) % HC_TOTAL_SLOTS) * HC_TOTAL_STRIDE;
+        unsafeAtomicAdd(&t[0], sumT);
+        unsafeAtomicAdd(&t[1], sumU);
     }
 }
 
@@ -943,7 +945,9 @@ __global__ void hc_finish_kernel(const double *__restrict__ totals, const double
     const double an = acc_node[p];
     acc_node[p] = 0.0;
     if (p < n_paths) {
-        const double v = totals[0] - (acc_seg[p] + an);
+        double stot = 0.0; // (the partial sums of hc_device.h, in slot order: the same value in every thread)
+        for (uint32_t s = 0; s < HC_TOTAL_SLOTS; ++s) stot += totals[s * HC_TOTAL_STRIDE];
+        const double v = stot - (acc_seg[p] + an);
         out[p] = v;
         if (out2) out2[p] = v;
     }

@@ -560,8 +560,9 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     sumT = wave_sum(sumT);
     sumU = wave_sum(sumU);
     if (lane == 0 && a.totals) {
-        unsafeAtomicAdd(&a.totals[0], sumT);
-        unsafeAtomicAdd(&a.totals[1], sumU);
+        double *t = a.totals + ((blockIdx.x * WV_WAVES + (uint32_t)wave) % HC_TOTAL_SLOTS) * HC_TOTAL_STRIDE;
+        unsafeAtomicAdd(&t[0], sumT);
+        unsafeAtomicAdd(&t[1], sumU);
     }
 }
 
