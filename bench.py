@@ -433,19 +433,30 @@ def collect_traffic(args, kernel_substr):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
-            if r.returncode != 0:
-                return None
+            # its own session: on a timeout the whole group goes (the profiled python is a grandchild of ours and would
+            # otherwise keep running on the GPU beside the legs that follow)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=180)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, 9)
+                except OSError:
+                    pass
+                pr.wait()
+                return {"bytes": None, "failed": "%s pass timed out" % counter}
+            if rc != 0:
+                return {"bytes": None, "failed": "%s pass exited with %d" % (counter, rc)}
             vals = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
                         vals.append(float(row["Counter_Value"]))
             if not vals:
-                return None
+                return {"bytes": None, "failed": "no %s row for a kernel named *%s*" % (counter, kernel_substr)}
             raw[counter] = sum(vals) / len(vals) * 1024.0
-    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-        return None
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+        return {"bytes": None, "failed": repr(e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return {"fetch_size_bytes_raw": raw["FETCH_SIZE"], "write_size_bytes_raw": raw["WRITE_SIZE"],
@@ -497,23 +508,27 @@ def main():
         r0, r1 = vd.shard_bounds(args.reads_total, rank, world)
     else:
         r0, r1 = rank * args.reads, (rank + 1) * args.reads
-    batches, n_reads, n_seg, algo_nw = [], 0, 0, 0
+    ctx = hc.HcContext(graph, device=local_rank)
+    ctx.use_torch_stream()
+    mode = {"node_weights": hc.MODE_NODE_WEIGHTS, "per_read": hc.MODE_PER_READ, "per_read_dense": hc.MODE_PER_READ_DENSE}[args.mode]
+    ctx.set_mode(mode)
+    batches, n_reads, n_seg, algo_nw, pack_ms = [], 0, 0, 0, 0.0
     alns0 = None
     for c0 in range(r0, r1, CHUNK_READS):
         c1 = min(r1, c0 + CHUNK_READS)
         alns = hc.synth_reads(graph, c1 - c0, seed=args.seed, read_len=args.read_len, first_read=c0)
         hb = hc.HostBatch(graph, alns)
-        batches.append(hc.DeviceBatch(hb, dev))
+        # resident in HBM in the layout the segment kernel streams: the upload's layout pass (vgan_hc_pack: byte moves, no
+        # arithmetic) runs once here, as the flatten does, and its time is reported beside the step
+        db = hc.DeviceBatch(hb, dev, ctx=ctx)
+        pack_ms += db.pack_ms
+        batches.append(db)
         n_reads += hb.n_reads
         n_seg += hb.n_segments
         algo_nw += hb.algorithmic_bytes(graph.n_paths)["node_weights"]
         if alns0 is None:
             alns0 = alns  # the cpu_baseline leg samples the first reads of rank 0
         del hb
-    ctx = hc.HcContext(graph, device=local_rank)
-    ctx.use_torch_stream()
-    mode = {"node_weights": hc.MODE_NODE_WEIGHTS, "per_read": hc.MODE_PER_READ, "per_read_dense": hc.MODE_PER_READ_DENSE}[args.mode]
-    ctx.set_mode(mode)
     final_dev = torch.zeros(graph.n_paths, dtype=torch.float64, device=dev)
 
     def step():
@@ -623,7 +638,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "HaploCart %s vs hcfiles-shaped mtDNA graph (11821 nodes, 5179 paths); step = reset + per-read "
-                                   "likelihood kernels over the flattened batch resident in HBM + final_vec%s; GAM decode / flatten "
+                                   "likelihood kernels over the flattened batch resident in HBM (packed per-column layout, written "
+                                   "once by the upload's layout pass: layout_pass_ms) + final_vec%s; GAM decode / flatten "
                                    "(front_end) and get_posterior (posterior_ms) are timed beside it, not inside" % (
                                        what, " + RCCL reduce" if world > 1 else ""),
                        "reads_per_gpu": n_reads, "reads_total": int(total_reads), "segments_per_read": n_seg / max(n_reads, 1),
@@ -631,13 +647,14 @@ def main():
                        "sharding": "contiguous read ranges x%d, %s reduce of final_vec[%d] to rank 0" % (world, "RCCL" if backend == "nccl" else "gloo (host staged)", graph.n_paths)
                                    if world > 1 else "single GPU",
                        "physical_gpus": min(n_dev, world), "dist_backend": backend if world > 1 else None},
-            # the counters name the limiter (profiles/: VALU issue, SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles); the fraction
-            # BASELINE.json asks for is the HBM one, kept in achieved / peak / frac
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
+            # bound / achieved / peak / frac are the HBM figures BASELINE.json asks for (algorithmic bytes over the kernel's
+            # time against the 8 TB/s peak); what actually limits the launch is named beside them, from a committed profile
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic.get("bytes") if traffic else None, "traffic_detail": traffic,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": avg_ms, "launches": k_n,
-                         "valu_issue_frac_from_profile": valu_from_profile(kernel_name)},
+                         "limiter": valu_from_profile(kernel_name)},
+            "layout_pass_ms": pack_ms,
             "kernel_ms_per_step": my_kernels,
             "per_rank": per_rank if world > 1 else None,
             "reduce_ms": reduce_ms,
@@ -659,13 +676,13 @@ def main():
 
 
 def valu_from_profile(kernel_name):
-    """VALU issue fraction of the dominant kernel from the committed SQ-counter pass (profiles/valu_issue.json, written by
-    tools/summarize_profile.py with the commit it was taken at): a tagged figure of a profile, not a live one."""
+    """What limits the dominant kernel, from the committed SQ-counter pass (profiles/valu_issue.json, written by
+    tools/summarize_pmc.py with the commit it was taken at): a tagged figure of a profile, not a live one."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))
         for k, v in d.get("kernels", {}).items():
             if kernel_name in k:
-                return dict(v, profile=d.get("profile"), commit=d.get("commit"))
+                return dict(v, kind="valu issue + LDS", source="profiles/valu_issue.json", profile=d.get("profile"), commit=d.get("commit"))
     except (OSError, ValueError):
         pass
     return None

@@ -103,7 +103,7 @@ void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParams
                         uint32_t mean_cols_per_read, double *segS, double *segU, double *segD, double *nodeW, double *totals,
                         hipStream_t st);
 // layout pass: packs reads [0, n_tileable) of b into the caller's buffers (sized from the batch totals: n_tileable + 1
-// headers, n_segments records, n_cols column records -- zeroed here --, n_qual + 32 quality bytes).  maxima (device, 3 words,
+// headers, n_segments records, n_cols column records, n_qual + 32 quality bytes).  maxima (device, 3 words,
 // or NULL) receives max segments / quality bytes / columns per packed read.
 void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint2 *srec,
                     uint32_t *crec, uint8_t *qualp, uint32_t *maxima, hipStream_t st);

@@ -31,6 +31,12 @@
 namespace vgan {
 namespace wv {
 
+#ifndef WV_CAPQ
+#define WV_CAPQ 384 // quality bytes and
+#endif
+#ifndef WV_CAPC
+#define WV_CAPC 384 // alignment columns per tile of the small variant
+#endif
 #ifndef WV_CAPS
 #define WV_CAPS 160 // segments per tile of the small variant (two 150 bp reads on the hcfiles graph: 121 on average)
 #endif
@@ -43,7 +49,10 @@ namespace wv {
 constexpr int WV_THREADS = 256;
 constexpr int WV_WAVES = WV_THREADS / 64;
 constexpr int WV_NR = 8;    // reads per tile at most (their headers travel in lanes 0..WV_NR of the wave)
-constexpr int WV_WIN = 160; // node ids covered by a wave's W window
+#ifndef WV_WIN_SLOTS
+#define WV_WIN_SLOTS 160
+#endif
+constexpr int WV_WIN = WV_WIN_SLOTS; // node ids covered by a wave's W window
 constexpr uint32_t WV_BUF_FLAGS = 0x00020000u; // raw buffer descriptor, 32-bit data format (gfx9)
 
 
@@ -567,12 +576,15 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
 }
 
 // ------------------------------------------------------------------------------------------------------------ layout pass
-// One wave per read: headers, segment records, the column records of every segment at the columns' own positions.
+// One wave per read.  Lanes over its segments: the segment records, and for every column a segment scores its seg_start + 1
+// in LDS; then lanes over its columns: the column records, read and written in coalesced runs.
+constexpr int PK_COLS = 1280; // a tileable read's columns at most (hc_device.h: HC_TILE_MAX_READ_COLS)
 __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_pack, uint4 *__restrict__ rhdr,
                                                       uint2 *__restrict__ srec, uint32_t *__restrict__ crec,
                                                       uint32_t *__restrict__ maxima) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    __shared__ uint16_t own_s[4][PK_COLS];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * 4u + wave;
     if (r > n_pack) return;
     if (r == n_pack) { // the end offsets
         if (lane == 0) rhdr[r] = uint4{b.read_seg_off[r], b.read_qual_off[r], b.read_col_off[r], 0u};
@@ -590,18 +602,29 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
             atomicMax(&maxima[2], c1 - c0);
         }
     }
-    const uint32_t cols = c1 - c0, QL = q1 - q0;
+    const uint32_t cols = min(c1 - c0, (uint32_t)PK_COLS), QL = q1 - q0; // (a read beyond the tile contract: a caller's error)
+    uint16_t *own = own_s[wave];
+    for (uint32_t c = lane; c < cols; c += 64u) own[c] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     for (uint32_t s = s0 + lane; s < s1; s += 64u) {
         const uint32_t start = b.seg_start[s], len = b.seg_len[s];
         srec[s] = uint2{b.seg_node[s], start | ((r & 0xFFFFu) << 16)};
         const uint32_t cl = start < cols ? min(len, cols - start) : 0u;
-        for (uint32_t j = 0; j < cl; ++j) {
-            const uint32_t c = start + j;
+        for (uint32_t j = 0; j < cl; ++j) own[start + j] = (uint16_t)(start + 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t c = lane; c < cols; c += 64u) {
+        const uint32_t o = own[c];
+        uint32_t rec = 0u; // a column no segment scores
+        if (o) {
+            const uint32_t j = c - (o - 1u);
             const uint32_t gb = b.graph_seq[c0 + c];
             const uint32_t rb = j < A ? b.algnseq[c0 + j] : 0u; // read bases from the read start (update_likelihood.cpp:46)
             const uint32_t qb = c < QL ? b.qual[q0 + c] : 0u;   // zero beyond the quality string
-            crec[c0 + c] = gb | (rb << 8) | (qb << 16) | (j == 0 ? 0x80000000u : 0u);
+            rec = gb | (rb << 8) | (qb << 16) | (j == 0 ? 0x80000000u : 0u);
         }
+        crec[c0 + c] = rec;
     }
 }
 
@@ -627,7 +650,6 @@ void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, u
                     uint32_t *crec, uint8_t *qualp, uint32_t *maxima, hipStream_t st) {
     const uint32_t n = std::min(n_tileable, b.n_reads);
     if (maxima) (void)hipMemsetAsync(maxima, 0, 12, st);
-    if (n_cols) (void)hipMemsetAsync(crec, 0, n_cols * 4, st);
     if (n_qual) (void)hipMemcpyAsync(qualp, b.qual, n_qual, hipMemcpyDeviceToDevice, st);
     (void)hipMemsetAsync(qualp + n_qual, 0, 32, st);
     hipLaunchKernelGGL(hc_pack_kernel, dim3((n + 1 + 3) / 4), dim3(256), 0, st, b, n, rhdr, srec, crec, maxima);
@@ -662,8 +684,8 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
     a.qual_bytes = (uint32_t)std::min<uint64_t>(0xFFFFFFF0u, pk.n_qual + 32u);
     a.use_bep = prm.use_bep ? 1u : 0u;
     a.consensus = prm.consensus ? 1u : 0u;
-    if (pk.max_read_segs <= (uint32_t)WV_CAPS && pk.max_read_qual <= 384u && pk.max_read_cols <= 384u)
-        hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, 384, 384>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
+    if (pk.max_read_segs <= (uint32_t)WV_CAPS && pk.max_read_qual <= (uint32_t)WV_CAPQ && pk.max_read_cols <= (uint32_t)WV_CAPC)
+        hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
     else
         hipLaunchKernelGGL((hc_segment_wave_kernel<512, 1280, 1280>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
 }
