@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def kernel_switch():
-    """VGAN_HC_KERNEL=tile keeps the tileable reads on the LDS-tiled kernel (read per call by the library)."""
+    """VGAN_HC_KERNEL=tile keeps the tileable reads on the LDS-tiled kernel, =wave sends them to the wave kernel whatever
+    their shape (read per call by the library)."""
     old = os.environ.get("VGAN_HC_KERNEL")
 
     def use(which):
@@ -55,8 +56,10 @@ def test_wave_kernel_against_tile_kernel_and_general_kernel_per_segment(kernel_s
 
 
 @pytest.mark.parametrize("read_len", [40, 75, 150, 300, 500])
-def test_both_variants_of_the_wave_kernel_against_the_oracle(read_len):
-    """Reads of 40..300 columns take the small variant (several reads per tile), 500-column reads the large one."""
+def test_both_variants_of_the_wave_kernel_against_the_oracle(read_len, kernel_switch):
+    """Reads of 40..300 columns take the small variant (several reads per tile), 500-column reads the large one.  (Left to
+    itself the library sends the shapes the LDS-tiled kernel is faster on to that kernel: VGAN_HC_KERNEL=wave overrides.)"""
+    kernel_switch("wave")
     g = hc.synth_graph(seed=21, genome_len=3000, n_nodes=2000, n_paths=200)
     a = hc.synth_reads(g, 1500, seed=22 + read_len, read_len=read_len, indel_rate=0.05, softclip_rate=0.1, low_mapq_rate=0.3)
     b = hc.HostBatch(g, a)

@@ -115,6 +115,8 @@ struct vgan_hc_ctx {
     DevBuf<uint16_t> s_u16;
     DevBuf<uint8_t> s_u8;
     vgan_hc_packed scratch_pack; // layout pass output of batches that come without a packed companion
+    DevBuf<uint32_t> work_ctr;   // the segment kernel's work queue (hc_wave_kernels.hip)
+    uint32_t work_base = 0;
     // posterior
     std::vector<std::string> path_names;
     std::unordered_map<std::string, uint32_t> path_index;
@@ -304,11 +306,13 @@ int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *n
     int rc;
     const uint32_t nt = std::min(b->n_tileable, b->n_reads);
     const uint32_t mean_cols = (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads));
+    const uint32_t mean_segs = b->n_segments / std::max<uint32_t>(1, b->n_reads);
     const vgan_hc_packed *pk = nullptr;
     if (nt && b->packed) {
         if (b->packed->device != c->device || b->packed->d.n_reads != nt || b->packed->d.n_segments != b->n_segments)
             return fail(VGAN_EINVAL, "batch: the packed companion belongs to another batch or device");
-        if (hc_wave_kernel_fits(b->packed->d.max_read_segs, b->packed->d.max_read_qual, b->packed->d.max_read_cols)) pk = b->packed;
+        if (hc_wave_kernel_fits(b->packed->d.max_read_segs, b->packed->d.max_read_qual, b->packed->d.max_read_cols, mean_segs, mean_cols))
+            pk = b->packed;
     }
     HcBatchDev d{};
     const bool need_arrays = staged || !pk || nt < b->n_reads || !wave_kernel_enabled();
@@ -322,7 +326,7 @@ int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *n
             mq = std::max(mq, b->read_qual_off[r + 1] - b->read_qual_off[r]);
             mc = std::max(mc, b->read_col_off[r + 1] - b->read_col_off[r]);
         }
-        if (hc_wave_kernel_fits(ms, mq, mc)) {
+        if (hc_wave_kernel_fits(ms, mq, mc, mean_segs, mean_cols)) {
             ScopedTimer t(c, VGAN_HC_K_PACK);
             if ((rc = pack_into(c, b, d, nt, c->scratch_pack, false, ms, mq, mc))) return rc;
             pk = &c->scratch_pack;
@@ -330,7 +334,12 @@ int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *n
     }
     ScopedTimer t(c, VGAN_HC_K_SEGMENT);
     if (pk && wave_kernel_enabled()) {
-        launch_hc_segments_wave(c->g, pk->d, c->prm, segD, nodeW, totals, c->stream);
+        if (!c->work_ctr.p) {
+            if ((rc = c->work_ctr.reserve(16))) return rc;
+            HIPCHK(hipMemsetAsync(c->work_ctr.p, 0, 64, c->stream));
+            c->work_base = 0;
+        }
+        launch_hc_segments_wave(c->g, pk->d, c->prm, segD, nodeW, totals, c->work_ctr.p, &c->work_base, c->stream);
         launch_hc_segments_general(c->g, d, c->prm, nt, nullptr, nullptr, segD, nodeW, totals, c->stream);
     } else {
         // (a device batch without a companion, reads beyond every variant of the wave kernel)
@@ -527,6 +536,7 @@ extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
     c->s_u16.release();
     c->s_u8.release();
     c->scratch_pack.release();
+    c->work_ctr.release();
     c->lists.release();
     c->conf.release();
     for (auto &t : c->timed) {

@@ -107,10 +107,13 @@ void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParams
 // or NULL) receives max segments / quality bytes / columns per packed read.
 void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint2 *srec,
                     uint32_t *crec, uint8_t *qualp, uint32_t *maxima, hipStream_t st);
-// true when the wave kernel has a variant for reads of that size (otherwise the LDS-tiled kernel takes the batch)
-bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_t max_read_cols);
+// true when the wave kernel is the faster route for reads of that shape (otherwise the LDS-tiled kernel takes the batch)
+bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_t max_read_cols, uint32_t mean_read_segs,
+                         uint32_t mean_read_cols);
+// work_ctr: one device word, zero when first used, that only this context's launches touch; *work_base: its value when the
+// next launch starts (kept by the caller between launches on the one stream)
 void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *segD, double *nodeW,
-                             double *totals, hipStream_t st);
+                             double *totals, uint32_t *work_ctr, uint32_t *work_base, hipStream_t st);
 // reads [r_begin, n_reads) through the general kernel (one wave per read, any length)
 void launch_hc_segments_general(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t r_begin, double *segS,
                                 double *segU, double *segD, double *nodeW, double *totals, hipStream_t st);

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "device_math.h"
@@ -32,16 +33,16 @@ namespace vgan {
 namespace wv {
 
 #ifndef WV_CAPQ
-#define WV_CAPQ 384 // quality bytes and
+#define WV_CAPQ 480 // quality bytes and
 #endif
 #ifndef WV_CAPC
-#define WV_CAPC 384 // alignment columns per tile of the small variant
+#define WV_CAPC 512 // alignment columns per tile of the small variant
 #endif
 #ifndef WV_CAPS
-#define WV_CAPS 160 // segments per tile of the small variant (two 150 bp reads on the hcfiles graph: 121 on average)
+#define WV_CAPS 192 // segments per tile of the small variant (three 150 bp reads on the hcfiles graph: 182 on average)
 #endif
 #ifndef WV_GROUP
-#define WV_GROUP 2 // column chunks whose LDS reads are issued together
+#define WV_GROUP 1 // column chunks whose LDS reads are issued together (2: measured 3 % slower)
 #endif
 #ifndef WV_OCC
 #define WV_OCC 4 // workgroups per CU the small variant is compiled for (waves per SIMD: registers)
@@ -50,7 +51,7 @@ constexpr int WV_THREADS = 256;
 constexpr int WV_WAVES = WV_THREADS / 64;
 constexpr int WV_NR = 8;    // reads per tile at most (their headers travel in lanes 0..WV_NR of the wave)
 #ifndef WV_WIN_SLOTS
-#define WV_WIN_SLOTS 160
+#define WV_WIN_SLOTS 128
 #endif
 constexpr int WV_WIN = WV_WIN_SLOTS; // node ids covered by a wave's W window
 constexpr uint32_t WV_BUF_FLAGS = 0x00020000u; // raw buffer descriptor, 32-bit data format (gfx9)
@@ -158,13 +159,16 @@ struct WvArgs { // only what the kernel reads (every pointer costs two scalar re
     double *nodeW;
     double *totals;
     double bep;
-    uint32_t n_reads, rows, reads_per_wave;
+    uint32_t *work;          // ticket counter of the launch's work queue (scalar atomic)
+    uint32_t work_base;      // its value when the launch starts
+    uint32_t n_reads, rows, unit_reads; // reads per work unit
     uint32_t qual_bytes; // readable bytes of qualp
     uint32_t use_bep, consensus;
 };
 
 struct WvTile { // one tile's extents (wave uniform)
     uint32_t r, n, s_base, n_seg, q_base, n_q, c_base, n_col;
+    uint32_t w1; // end of the work unit the tile lies in
 };
 struct alignas(32) WvRdTab { // rdtab row of a mapping quality: 1 - p_inc, its log, its reciprocal
     double omp, lp, ip, pad;
@@ -210,22 +214,31 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     if (lane < 4) L.ps[lane] = 0u;
     __syncthreads(); // the only one: from here on every wave is on its own
 
-    const uint32_t w0 = (blockIdx.x * WV_WAVES + (uint32_t)wave) * a.reads_per_wave;
-    const uint32_t w1 = min(a.n_reads, w0 + a.reads_per_wave);
-    if (w0 >= w1) return;
-
+    // Work comes in units of a.unit_reads consecutive reads, handed out by a ticket counter: a wave that finishes early takes
+    // more (CUs do not run at one speed, reads do not cost the same), and the launch ends when the last unit does instead of
+    // when the slowest of a fixed set of ranges does.  The ticket is a SCALAR atomic: it returns into a scalar register and
+    // counts in lgkmcnt, so the vector-memory pipeline of the tile loop (counted s_waitcnt vmcnt) never sees it.
+    const uint32_t n_units = (a.n_reads + a.unit_reads - 1u) / a.unit_reads;
+    auto grab_unit = [&]() {
+        uint32_t t = 1u;
+        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(a.work) : "memory");
+        return t - a.work_base; // >= n_units: the queue is empty (every wave with work draws exactly one such ticket)
+    };
+    // (a wave's first unit is its own number: thousands of tickets drawn in the launch's first microsecond would queue)
+    uint32_t unit = blockIdx.x * WV_WAVES + (uint32_t)wave;
+    if (unit >= n_units) return;
     const wv_rsrc rs_hdr = wv_make_rsrc(a.rhdr, (a.n_reads + 1u) * 16u);
     const wv_rsrc rs_node = wv_make_rsrc(a.node_tab, a.rows * 32u);
     const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u;
 
     // a tile's header: lane t holds rhdr[first + t] for t = 0..WV_NR (the entry behind the last read gives its end)
-    auto header_load = [&](uint32_t first) {
+    auto header_load = [&](uint32_t first, uint32_t w1) {
         const uint32_t rr = min(first + min((uint32_t)lane, (uint32_t)WV_NR), w1);
         return wv_load4(rs_hdr, rr * 16u);
     };
     // reads [r, r + n), n the largest count whose segments and quality bytes fit the wave's LDS (the offsets ascend, so
     // "read t still fits" is a prefix property and n is a popcount); one read always fits (the launcher's choice of variant)
-    auto tile_form = [&](const uint4 &h, uint32_t r) {
+    auto tile_form = [&](const uint4 &h, uint32_t r, uint32_t w1) {
         const uint32_t hs0 = wv_first(h.x), hq0 = wv_first(h.y), hc0 = wv_first(h.z);
         const bool fits = lane >= 1 && lane <= WV_NR && r + (uint32_t)lane <= w1 && h.x - hs0 <= (uint32_t)CAPS && h.y - hq0 <= (uint32_t)CAPQ &&
                           h.z - hc0 <= (uint32_t)CAPC;
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         // (clamped: a caller's contract violation must not index past the LDS arrays)
         const uint32_t n_seg = min(wv_readlane(h.x, n) - hs0, (uint32_t)CAPS), n_q = min(wv_readlane(h.y, n) - hq0, (uint32_t)CAPQ);
         const uint32_t n_col = min(wv_readlane(h.z, n) - hc0, (uint32_t)CAPC);
-        return WvTile{r, n, hs0, n_seg, hq0, n_q, hc0, n_col};
+        return WvTile{r, n, hs0, n_seg, hq0, n_q, hc0, n_col, w1};
     };
     // Every load of a tile is issued unconditionally (`live` false: descriptors of length zero, nothing is fetched), each
     // into the register the same tile position was just consumed from: a slot is refilled for the NEXT tile right behind its
@@ -278,12 +291,34 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     uint32_t winbase = 0xFFFFFFFFu; // no window yet (wave uniform)
     bool need_place = true;
 
+    // the tile behind `t`: in the same unit, or at the head of the next unit drawn from the queue (first = w1 = n_reads when
+    // the queue is empty: no such tile)
+    auto next_first = [&](const WvTile &t, uint32_t &first, uint32_t &w1, bool &fresh) {
+        first = t.r + t.n;
+        w1 = t.w1;
+        fresh = false;
+        if (first >= t.w1) {
+            unit = a.work ? grab_unit() : n_units; // (no queue: one unit per wave, the fixed partition)
+#ifdef WV_SAMEUNIT // (developer aid: every unit re-reads the first units' data -- what the launch costs without HBM latency)
+            first = unit < n_units ? (unit % 64u) * a.unit_reads : a.n_reads;
+#else
+            first = unit < n_units ? unit * a.unit_reads : a.n_reads;
+#endif
+            w1 = min(a.n_reads, first + a.unit_reads);
+            fresh = true;
+        }
+    };
+
     // ---- prologue: the first tile's header and data, the second tile's header.  In the loop a tile's data was requested a
     // whole tile earlier and its header two tiles earlier, so nothing in it waits for HBM.
-    uint4 Hn = header_load(w0);
-    WvTile T = tile_form(Hn, w0);
+    const uint32_t u0 = unit * a.unit_reads, u1 = min(a.n_reads, u0 + a.unit_reads);
+    uint4 Hn = header_load(u0, u1);
+    WvTile T = tile_form(Hn, u0, u1);
     uint32_t h_q = Hn.y, h_am = Hn.w; // of the tile's reads (lane t: read r + t): first quality byte, |algnseq| | mapq << 16
-    Hn = header_load(T.r + T.n); // (clamped to the wave's last read: a header nobody uses then)
+    uint32_t fn, wn;       // where the next tile starts and its unit ends
+    bool fresh_n, fresh = true; // the (next) tile opens a unit: the W window is placed anew
+    next_first(T, fn, wn, fresh_n);
+    Hn = header_load(fn, wn); // (behind the last tile: the entry at n_reads, a header nobody uses)
     Data D;
     request_qual(T, true, D);
     request_segs(T, true, D);
@@ -298,10 +333,14 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         double nd_lw[SPASS], nd_inv[SPASS], nd_mapp[SPASS];
         node_gather(D, nd_lw, nd_inv, nd_mapp);
         // ---- the next tile: formed from its header (here since the tile before), the header after it requested
-        const bool has_next = T.r + T.n < w1;
-        const WvTile Tn = tile_form(Hn, min(T.r + T.n, w1)); // (meaningless behind the last tile, and unused)
+        const bool has_next = fn < a.n_reads;
+        const WvTile Tn = tile_form(Hn, fn, wn); // (meaningless behind the last tile, and unused)
         const uint32_t hn_q = Hn.y, hn_am = Hn.w;
-        Hn = header_load(Tn.r + Tn.n);
+        uint32_t f2 = a.n_reads, w2 = a.n_reads;
+        bool fresh_2 = false;
+        if (has_next) next_first(Tn, f2, w2, fresh_2);
+        Hn = header_load(f2, w2);
+        if (fresh) need_place = true;
         const uint32_t a0 = T.q_base & ~7u, qshift = T.q_base & 7u, n_qw = T.n_q + qshift;
         WV_COUNT(0, 1);
         WV_COUNT(1, T.n);
@@ -564,6 +603,10 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         T = Tn;
         h_q = hn_q;
         h_am = hn_am;
+        fn = f2;
+        wn = w2;
+        fresh = fresh_n;
+        fresh_n = fresh_2;
     }
     if (a.nodeW && winbase != 0xFFFFFFFFu) window_flush(winbase);
     sumT = wave_sum(sumT);
@@ -642,8 +685,19 @@ extern "C" int vgan_hc_debug_wave_stats(unsigned long long *out, int reset) {
 }
 #endif
 
-bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_t max_read_cols) {
-    return max_read_segs <= 512u && max_read_qual <= 1280u && max_read_cols <= 1280u;
+// Which reads the wave kernel takes.  Its tile holds WV_CAPS segments / WV_CAPQ quality bytes / WV_CAPC columns of at most
+// WV_NR reads: the kernel is built for tiles of several reads (150 bp: three, 75 bp: six).  A batch whose reads are so long
+// that a tile holds one (300 bp) or so short that WV_NR of them leave the tile half empty (40 bp) runs faster on the LDS-tiled
+// kernel (measured, 1M reads: 300 bp 1.18 against 0.87 ms, 40 bp 0.39 against 0.29 ms; 150 bp 0.57 against 0.89, 75 bp 0.40
+// against 0.48), and so does one holding a read beyond the tile's capacity.  VGAN_HC_KERNEL=wave takes the kernel whenever a
+// variant of it can hold the batch's reads (developer aid; the tests use it to force the large variant).
+bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_t max_read_cols, uint32_t mean_read_segs,
+                         uint32_t mean_read_cols) {
+    if (max_read_segs > 512u || max_read_qual > 1280u || max_read_cols > 1280u) return false;
+    const char *e = getenv("VGAN_HC_KERNEL");
+    if (e && strcmp(e, "wave") == 0) return true;
+    if (max_read_segs > (uint32_t)WV_CAPS || max_read_qual > (uint32_t)WV_CAPQ || max_read_cols > (uint32_t)WV_CAPC) return false;
+    return 2u * mean_read_segs <= (uint32_t)WV_CAPS && 2u * mean_read_cols <= (uint32_t)WV_CAPC && mean_read_cols * (uint32_t)WV_NR >= 384u;
 }
 
 void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint2 *srec,
@@ -656,16 +710,40 @@ void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, u
 }
 
 void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *segD, double *nodeW,
-                             double *totals, hipStream_t st) {
+                             double *totals, uint32_t *work_ctr, uint32_t *work_base, hipStream_t st) {
     if (pk.n_reads == 0) return;
-    // contiguous read ranges per wave (the W window wants them), ~16 workgroups per CU so that the dispatcher evens out the CUs
-    uint32_t wg_per_cu = 16u;
-    if (const char *e = getenv("VGAN_WV_WG_PER_CU")) wg_per_cu = (uint32_t)std::max(1, atoi(e)); // developer aid
-    const uint32_t want_waves = 256u * wg_per_cu * (uint32_t)WV_WAVES;
-    uint32_t per = (pk.n_reads + want_waves - 1) / want_waves;
-    per = std::max(per, 8u);
-    const uint32_t waves = (pk.n_reads + per - 1) / per;
-    const uint32_t blocks = (waves + WV_WAVES - 1) / WV_WAVES;
+    const bool small = pk.max_read_segs <= (uint32_t)WV_CAPS && pk.max_read_qual <= (uint32_t)WV_CAPQ && pk.max_read_cols <= (uint32_t)WV_CAPC;
+    // a persistent grid: as many workgroups as the chip holds at once, fed by the work queue
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    static const int occ_small = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC>, WV_THREADS, 0) != hipSuccess || n <= 0) n = WV_OCC;
+        return n;
+    }();
+    static const int occ_large = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hc_segment_wave_kernel<512, 1280, 1280>, WV_THREADS, 0) != hipSuccess || n <= 0) n = 1;
+        return n;
+    }();
+    uint32_t unit = small ? 32u : 8u; // reads per work unit: ~16 tiles -- the price of a ticket against the length of the launch's tail
+    if (const char *e = getenv("VGAN_WV_UNIT")) unit = (uint32_t)std::max(1, atoi(e)); // developer aid
+    uint32_t blocks = (uint32_t)(n_cu * (small ? occ_small : occ_large));
+    if (const char *e = getenv("VGAN_WV_WG_PER_CU")) { // developer aid: the fixed partition into that many workgroups per CU, no queue
+        blocks = (uint32_t)(n_cu * std::max(1, atoi(e)));
+        unit = std::max(8u, (pk.n_reads + blocks * WV_WAVES - 1) / (blocks * WV_WAVES));
+        work_ctr = nullptr;
+    }
+    const uint32_t n_units = (pk.n_reads + unit - 1) / unit;
+    blocks = std::min(blocks, (n_units + WV_WAVES - 1) / WV_WAVES);
+    const uint32_t n_waves = blocks * WV_WAVES;
+    if (work_ctr && *work_base > 0xC0000000u) { // (the counter runs on from launch to launch; long before it wraps it starts over)
+        (void)hipMemsetAsync(work_ctr, 0, 4, st);
+        *work_base = 0;
+    }
     WvArgs a{};
     a.rhdr = pk.rhdr;
     a.srec = pk.srec;
@@ -678,13 +756,18 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
     a.nodeW = nodeW;
     a.totals = totals;
     a.bep = prm.bep;
+    a.work = work_ctr;
+    // tickets: the first n_waves units are the waves' own, every further unit is one ticket, and every wave draws one more to
+    // learn that the queue is empty (the grid never has more waves than units)
+    a.work_base = *work_base - n_waves;
+    if (work_ctr) *work_base += n_units;
     a.n_reads = pk.n_reads;
     a.rows = g.rows;
-    a.reads_per_wave = per;
+    a.unit_reads = unit;
     a.qual_bytes = (uint32_t)std::min<uint64_t>(0xFFFFFFF0u, pk.n_qual + 32u);
     a.use_bep = prm.use_bep ? 1u : 0u;
     a.consensus = prm.consensus ? 1u : 0u;
-    if (pk.max_read_segs <= (uint32_t)WV_CAPS && pk.max_read_qual <= (uint32_t)WV_CAPQ && pk.max_read_cols <= (uint32_t)WV_CAPC)
+    if (small)
         hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
     else
         hipLaunchKernelGGL((hc_segment_wave_kernel<512, 1280, 1280>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
