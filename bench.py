@@ -39,8 +39,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the per-read-mode kernel measurement")
     ap.add_argument("--clades", type=int, default=335, help="euka path: number of clades the synthetic reads spread over")
     ap.add_argument("--dist-backend", default="auto", help="auto: nccl (= RCCL) when every rank has a GPU of its own, else gloo with ranks sharing GPUs | nccl | gloo")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --reads per GPU (N = 1 is BASELINE configs[1]); strong: --reads-total split over the N GPUs (configs[2])")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="weak: --reads per GPU (the default at N = 1: BASELINE configs[1]); strong: --reads-total split over the N "
+                         "GPUs (the default at N > 1: BASELINE configs[2], 10M reads; the weak figure is measured beside it)")
     ap.add_argument("--reads-total", type=int, default=10_000_000, help="strong scaling: reads of the whole job")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--no-frontend", action="store_true", help="skip the GAM decode / flatten rates")
@@ -485,6 +486,8 @@ def front_end_rates(graph, hc, seed, n=200_000):
 
 def main():
     args = parse()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)  # does not return
     if args.path == "euka":
@@ -572,6 +575,41 @@ def main():
         fence()
         reduce_ms = vd.all_reduce_max((time.perf_counter() - t0) / 20 * 1e3, dev)
 
+    # ---- N > 1: who took part (is RCCL really running over N ranks on N devices?), and, beside the strong figure, the weak one
+    # (the first 1M-read device batch of every rank: configs[1] per GPU)
+    dist_info, weak_beside = None, None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "device_name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        rccl_version = None
+        if backend == "nccl":
+            try:
+                rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001 -- a version string must not end a benchmark
+                rccl_version = "unknown (%r)" % (e,)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl_version,
+                     "distinct_devices": len({(d["device_index"], d["pci_bus_id"], d["uuid"]) for d in everyone}), "ranks": everyone}
+        if args.scaling == "strong":
+            def weak_step():
+                ctx.reset()
+                ctx.accumulate(batches[0])
+                ctx.finalize_device(final_dev)
+                vd.reduce_loglik(final_dev, dst=0)
+            for _ in range(args.warmup):
+                weak_step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                weak_step()
+            fence()
+            w_el = vd.all_reduce_max(time.perf_counter() - t0, dev)
+            w_reads = vd.all_reduce_sum(float(batches[0].n_reads), dev)
+            weak_beside = {"scaling": "weak", "reads_per_gpu": batches[0].n_reads, "value": w_reads * args.steps / w_el,
+                           "unit": "reads/s", "ms_per_step": w_el / args.steps * 1e3}
+
     # ---- a9 (get_posterior.cpp:87-127) on rank 0, timed on its own: host tree walk + upload + one kernel
     posterior_ms, posterior_top = None, None
     if rank == 0:
@@ -657,6 +695,8 @@ def main():
             "layout_pass_ms": pack_ms,
             "kernel_ms_per_step": my_kernels,
             "per_rank": per_rank if world > 1 else None,
+            "dist": dist_info,
+            "weak_beside": weak_beside,
             "reduce_ms": reduce_ms,
             "posterior_ms": posterior_ms,
             "posterior": posterior_top,

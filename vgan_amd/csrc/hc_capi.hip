@@ -7,7 +7,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <chrono>
 #include <deque>
+#include <map>
+#include <mutex>
 #include <set>
 #include <sstream>
 #include <string>
@@ -117,6 +120,7 @@ struct vgan_hc_ctx {
     vgan_hc_packed scratch_pack; // layout pass output of batches that come without a packed companion
     DevBuf<uint32_t> work_ctr;   // the segment kernel's work queue (hc_wave_kernels.hip)
     uint32_t work_base = 0;
+    bool touched = false;        // something was accumulated since the last reset (vgan_hc_reduce leaves the others out)
     // posterior
     std::vector<std::string> path_names;
     std::unordered_map<std::string, uint32_t> path_index;
@@ -305,6 +309,7 @@ int pack_into(vgan_hc_ctx *c, const vgan_hc_batch *b, const HcBatchDev &d, uint3
 int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *nodeW, double *totals, HcBatchDev *staged = nullptr) {
     int rc;
     const uint32_t nt = std::min(b->n_tileable, b->n_reads);
+    if (nodeW || totals) c->touched = true;
     const uint32_t mean_cols = (uint32_t)(b->n_cols / std::max<uint32_t>(1, b->n_reads));
     const uint32_t mean_segs = b->n_segments / std::max<uint32_t>(1, b->n_reads);
     const vgan_hc_packed *pk = nullptr;
@@ -566,6 +571,7 @@ extern "C" int vgan_hc_reset(vgan_hc_ctx *c) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_reset: null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->accum.p, 0, c->accum_n * 8, c->stream));
+    c->touched = false;
     return VGAN_OK;
 }
 
@@ -763,6 +769,17 @@ Rccl &rccl() {
     static Rccl r;
     return r;
 }
+// one communicator per set of devices, for the life of the process (never destroyed: RCCL tears down with the runtime)
+struct CommCache {
+    std::mutex mu;
+    std::map<std::vector<int>, std::vector<ncclComm_t>> m;
+    double last_setup_ms = 0.0;
+    int n_setups = 0;
+};
+CommCache &comm_cache() {
+    static CommCache c;
+    return c;
+}
 } // namespace
 
 // Sum over contexts of final_vec (src/HaploCart.cpp:419-420, the accumulate the reference does under `omp critical`, here
@@ -775,29 +792,58 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
         if (!ctxs[i] || ctxs[i]->P != ctxs[0]->P) return fail(VGAN_EINVAL, "vgan_hc_reduce: contexts of different graphs");
     const uint32_t P = ctxs[0]->P;
     int rc;
+    if (used_rccl) *used_rccl = 0;
+    // contexts nothing was accumulated into add nothing: a short input that reached one GPU only is that context's finalize,
+    // whatever the number of contexts standing by
+    std::vector<vgan_hc_ctx *> live;
+    for (int i = 0; i < n; ++i)
+        if (ctxs[i]->touched) live.push_back(ctxs[i]);
+    if (live.size() <= 1) return vgan_hc_finalize(live.empty() ? ctxs[0] : live[0], nullptr, out);
+    const bool partial = (int)live.size() < n; // (a communicator is per device set: a partial set goes through the host)
+    if (partial) {
+        ctxs = live.data();
+        n = (int)live.size();
+    }
     for (int i = 0; i < n; ++i)
         if ((rc = vgan_hc_finalize(ctxs[i], nullptr, nullptr))) return rc; // final_vec on every device, asynchronously
-    if (used_rccl) *used_rccl = 0;
-    bool distinct = n > 1;
+    bool distinct = n > 1 && !partial;
     for (int i = 0; i < n && distinct; ++i)
         for (int j = 0; j < i; ++j) distinct = distinct && ctxs[i]->device != ctxs[j]->device;
+    // 41 KB per context: ONE reduce is cheapest through the host (a few D2H copies; setting a communicator up costs orders of
+    // magnitude more than it saves).  RCCL over xGMI is for a device set that reduces again and again: it is taken when a
+    // communicator for exactly these devices is already cached, or when VGAN_HC_REDUCE=rccl asks for one -- created once per
+    // device set and kept for the life of the process.
     if (distinct && rccl().ok) {
         std::vector<int> devs((size_t)n);
         for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
-        std::vector<ncclComm_t> comms((size_t)n, nullptr);
-        if (rccl().CommInitAll(comms.data(), n, devs.data()) == ncclSuccess) {
+        const char *want = getenv("VGAN_HC_REDUCE");
+        std::vector<ncclComm_t> *comms = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(comm_cache().mu);
+            auto it = comm_cache().m.find(devs);
+            if (it != comm_cache().m.end()) {
+                comms = &it->second;
+            } else if (want && strcmp(want, "rccl") == 0) {
+                std::vector<ncclComm_t> fresh((size_t)n, nullptr);
+                const auto t0 = std::chrono::steady_clock::now();
+                if (rccl().CommInitAll(fresh.data(), n, devs.data()) == ncclSuccess) {
+                    comm_cache().last_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    comm_cache().n_setups += 1;
+                    comms = &(comm_cache().m[devs] = std::move(fresh));
+                }
+            }
+        }
+        if (comms) {
             bool good = rccl().GroupStart() == ncclSuccess;
             for (int i = 0; i < n && good; ++i) {
                 good = hipSetDevice(ctxs[i]->device) == hipSuccess &&
-                       rccl().Reduce(ctxs[i]->final_vec.p, ctxs[i]->final_vec.p, P, ncclDouble, ncclSum, 0, comms[(size_t)i], ctxs[i]->stream) == ncclSuccess;
+                       rccl().Reduce(ctxs[i]->final_vec.p, ctxs[i]->final_vec.p, P, ncclDouble, ncclSum, 0, (*comms)[(size_t)i], ctxs[i]->stream) == ncclSuccess;
             }
             good = rccl().GroupEnd() == ncclSuccess && good;
             for (int i = 0; i < n; ++i) {
                 (void)hipSetDevice(ctxs[i]->device);
                 good = hipStreamSynchronize(ctxs[i]->stream) == hipSuccess && good;
             }
-            for (auto cm : comms)
-                if (cm) (void)rccl().CommDestroy(cm);
             if (!good) return fail(VGAN_ENODEV, "vgan_hc_reduce: the RCCL reduce failed");
             HIPCHK(hipSetDevice(ctxs[0]->device));
             HIPCHK(hipMemcpy(out, ctxs[0]->final_vec.p, (size_t)P * 8, hipMemcpyDeviceToHost));
@@ -813,6 +859,13 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
         HIPCHK(hipStreamSynchronize(ctxs[i]->stream));
         for (uint32_t p = 0; p < P; ++p) out[p] += part[p];
     }
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_reduce_info(double *last_setup_ms, int *n_setups) {
+    std::lock_guard<std::mutex> lk(comm_cache().mu);
+    if (last_setup_ms) *last_setup_ms = comm_cache().last_setup_ms;
+    if (n_setups) *n_setups = comm_cache().n_setups;
     return VGAN_OK;
 }
 

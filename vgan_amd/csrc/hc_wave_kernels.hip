@@ -627,47 +627,48 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
                                                       uint32_t *__restrict__ maxima) {
     __shared__ uint16_t own_s[4][PK_COLS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t r = blockIdx.x * 4u + wave;
-    if (r > n_pack) return;
-    if (r == n_pack) { // the end offsets
-        if (lane == 0) rhdr[r] = uint4{b.read_seg_off[r], b.read_qual_off[r], b.read_col_off[r], 0u};
-        return;
-    }
-    const uint32_t s0 = b.read_seg_off[r], s1 = b.read_seg_off[r + 1];
-    const uint32_t c0 = b.read_col_off[r], c1 = b.read_col_off[r + 1];
-    const uint32_t q0 = b.read_qual_off[r], q1 = b.read_qual_off[r + 1];
-    const uint32_t A = b.read_algn_len[r];
-    if (lane == 0) {
-        rhdr[r] = uint4{s0, q0, c0, A | ((uint32_t)b.read_mapq[r] << 16)};
-        if (maxima) {
-            atomicMax(&maxima[0], s1 - s0);
-            atomicMax(&maxima[1], q1 - q0);
-            atomicMax(&maxima[2], c1 - c0);
-        }
-    }
-    const uint32_t cols = min(c1 - c0, (uint32_t)PK_COLS), QL = q1 - q0; // (a read beyond the tile contract: a caller's error)
     uint16_t *own = own_s[wave];
-    for (uint32_t c = lane; c < cols; c += 64u) own[c] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (uint32_t s = s0 + lane; s < s1; s += 64u) {
-        const uint32_t start = b.seg_start[s], len = b.seg_len[s];
-        srec[s] = uint2{b.seg_node[s], start | ((r & 0xFFFFu) << 16)};
-        const uint32_t cl = start < cols ? min(len, cols - start) : 0u;
-        for (uint32_t j = 0; j < cl; ++j) own[start + j] = (uint16_t)(start + 1u);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (uint32_t c = lane; c < cols; c += 64u) {
-        const uint32_t o = own[c];
-        uint32_t rec = 0u; // a column no segment scores
-        if (o) {
-            const uint32_t j = c - (o - 1u);
-            const uint32_t gb = b.graph_seq[c0 + c];
-            const uint32_t rb = j < A ? b.algnseq[c0 + j] : 0u; // read bases from the read start (update_likelihood.cpp:46)
-            const uint32_t qb = c < QL ? b.qual[q0 + c] : 0u;   // zero beyond the quality string
-            rec = gb | (rb << 8) | (qb << 16) | (j == 0 ? 0x80000000u : 0u);
+    for (uint32_t r = blockIdx.x * 4u + wave; r <= n_pack; r += gridDim.x * 4u) { // (a wave per read would be a million waves)
+        if (r == n_pack) { // the end offsets
+            if (lane == 0) rhdr[r] = uint4{b.read_seg_off[r], b.read_qual_off[r], b.read_col_off[r], 0u};
+            break;
         }
-        crec[c0 + c] = rec;
+        const uint32_t s0 = b.read_seg_off[r], s1 = b.read_seg_off[r + 1];
+        const uint32_t c0 = b.read_col_off[r], c1 = b.read_col_off[r + 1];
+        const uint32_t q0 = b.read_qual_off[r], q1 = b.read_qual_off[r + 1];
+        const uint32_t A = b.read_algn_len[r];
+        if (lane == 0) {
+            rhdr[r] = uint4{s0, q0, c0, A | ((uint32_t)b.read_mapq[r] << 16)};
+            if (maxima) {
+                atomicMax(&maxima[0], s1 - s0);
+                atomicMax(&maxima[1], q1 - q0);
+                atomicMax(&maxima[2], c1 - c0);
+            }
+        }
+        const uint32_t cols = min(c1 - c0, (uint32_t)PK_COLS), QL = q1 - q0; // (a read beyond the tile contract: a caller's error)
+        for (uint32_t c = lane; c < cols; c += 64u) own[c] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (uint32_t s = s0 + lane; s < s1; s += 64u) {
+            const uint32_t start = b.seg_start[s], len = b.seg_len[s];
+            srec[s] = uint2{b.seg_node[s], start | ((r & 0xFFFFu) << 16)};
+            const uint32_t cl = start < cols ? min(len, cols - start) : 0u;
+            for (uint32_t j = 0; j < cl; ++j) own[start + j] = (uint16_t)(start + 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t c = lane; c < cols; c += 64u) {
+            const uint32_t o = own[c];
+            uint32_t rec = 0u; // a column no segment scores
+            if (o) {
+                const uint32_t j = c - (o - 1u);
+                const uint32_t gb = b.graph_seq[c0 + c];
+                const uint32_t rb = j < A ? b.algnseq[c0 + j] : 0u; // read bases from the read start (update_likelihood.cpp:46)
+                const uint32_t qb = c < QL ? b.qual[q0 + c] : 0u;   // zero beyond the quality string
+                rec = gb | (rb << 8) | (qb << 16) | (j == 0 ? 0x80000000u : 0u);
+            }
+            crec[c0 + c] = rec;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the next read's marks come after these reads of own[])
     }
 }
 
@@ -706,7 +707,7 @@ void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, u
     if (maxima) (void)hipMemsetAsync(maxima, 0, 12, st);
     if (n_qual) (void)hipMemcpyAsync(qualp, b.qual, n_qual, hipMemcpyDeviceToDevice, st);
     (void)hipMemsetAsync(qualp + n_qual, 0, 32, st);
-    hipLaunchKernelGGL(hc_pack_kernel, dim3((n + 1 + 3) / 4), dim3(256), 0, st, b, n, rhdr, srec, crec, maxima);
+    hipLaunchKernelGGL(hc_pack_kernel, dim3(std::min<uint32_t>((n + 1 + 3) / 4, 8192u)), dim3(256), 0, st, b, n, rhdr, srec, crec, maxima);
 }
 
 void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *segD, double *nodeW,

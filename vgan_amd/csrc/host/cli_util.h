@@ -128,8 +128,19 @@ inline void check_gbwt_beside(const std::string &prefix, int64_t n_nodes, int64_
     if (!std::ifstream(f)) return;
     vgan_gbwt *gb = nullptr;
     if (vgan_gbwt_load(f.c_str(), &gb) < 0) die(std::string(tool) + " Error, cannot read " + f + ": " + vgan_last_error());
-    std::vector<uint8_t> m((size_t)std::max<int64_t>(0, n_nodes) * (size_t)std::max<int64_t>(0, n_paths));
-    const int rc = m.empty() ? 0 : vgan_gbwt_node_path_matrix(gb, n_nodes, n_paths, m.data());
+    // The reference fills a nodes x paths matrix here and never reads it (the assignment into NodeInfo::pathsgo is commented
+    // out): the walk is what can fail, so the walk is what is repeated -- one thread at a time into a buffer that grows with
+    // the longest thread, not a dense matrix (a node count times a path count of bytes: tens of GB on a large graph).
+    const int64_t n_seq = std::min<int64_t>(vgan_gbwt_sequences(gb), std::max<int64_t>(0, n_paths));
+    std::vector<uint64_t> nodes(1 << 16);
+    int64_t rc = 0;
+    for (int64_t s = 0; s < n_seq && rc >= 0; ++s) {
+        rc = vgan_gbwt_extract(gb, s, nodes.data(), (int64_t)nodes.size());
+        if (rc > (int64_t)nodes.size()) { // the thread is longer than the buffer: once more with room for it
+            nodes.resize((size_t)rc);
+            rc = vgan_gbwt_extract(gb, s, nodes.data(), (int64_t)nodes.size());
+        }
+    }
     vgan_gbwt_free(gb);
     if (rc < 0) die(std::string(tool) + " Error, cannot walk the paths of " + f + ": " + vgan_last_error());
     if (n_nodes == 0) die("Error: The node_path_matrix is empty. Unable to proceed."); // soibean.cpp:453-455

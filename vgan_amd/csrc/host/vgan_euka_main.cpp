@@ -53,7 +53,7 @@ std::string euka_usage() {
            "   --outFrag         write the names of the fragments of every detected taxon\n"
            "   --outGroup [STR]  always write coverage, fragment lengths and profile of this taxon\n"
            "   --device [INT]    GPU index (default 0)\n"
-           "   --gpus [LIST]     GPU indices, comma separated (default: -t N takes GPUs 0..N-1 of the visible ones, -t -1 all):\n"
+           "   --gpus [LIST]     GPU indices, comma separated (default: the one of --device; VGAN_GPUS in the environment: a list or `all`):\n"
            "                     the fragments are dealt to one device context per entry, the per-clade tables are summed\n";
 }
 
@@ -65,7 +65,6 @@ int euka_main(int argc, char **argv) {
     std::string deam5, deam3, out_group, out_dir;
     bool interleaved = false, run_mcmc = true, out_frag = false;
     int n_threads = 1, iter = 10000, burnin = 100, ltp = 5, device = 0; // Euka.cpp:171-190
-    int gpus_wanted = 1;
     std::vector<int> gpu_list;
     int min_bins = 6, min_reads = 10, min_mq = 29, max_bins = 0;
     double entropy = 1.17;
@@ -121,8 +120,7 @@ int euka_main(int argc, char **argv) {
             n_threads = parse_int(need("-t"), "-t", T);
             if (n_threads < -1 || n_threads == 0) die("[euka] Error, invalid number of threads"); // Euka.cpp:298
             const int hw = (int)std::thread::hardware_concurrency();
-            gpus_wanted = n_threads; // the thread count is this build's GPU count too (min(N, visible GPUs); -1 = all)
-            if (n_threads == -1) n_threads = hw;
+            if (n_threads == -1) n_threads = hw; // (host threads only, as in the reference: GPUs are asked for with --gpus)
             else if (n_threads > hw) {
                 std::cerr << "[euka] Warning, specified number of threads is greater than the number available. Using " << hw << " threads\n";
                 n_threads = hw;
@@ -201,10 +199,22 @@ int euka_main(int argc, char **argv) {
     prm.length_to_prof = ltp;
     const int n_visible = vgan_device_count();
     if (gpu_list.empty()) {
-        const int k = gpus_wanted == -1 ? n_visible : std::min(gpus_wanted, n_visible);
-        if (k <= 1) gpu_list.push_back(device);
-        else
-            for (int d = 0; d < k; ++d) gpu_list.push_back(d);
+        const char *e = getenv("VGAN_GPUS"); // `all` or a comma separated list, as --gpus
+        if (e && std::string(e) == "all") {
+            for (int d = 0; d < n_visible; ++d) gpu_list.push_back(d);
+        } else if (e && *e) {
+            const std::string v = e;
+            size_t p0 = 0;
+            while (p0 <= v.size()) {
+                size_t c1 = v.find(',', p0);
+                if (c1 == std::string::npos) c1 = v.size();
+                const int d = parse_int(v.substr(p0, c1 - p0), "VGAN_GPUS", T);
+                if (d < 0) die("[euka] Error, VGAN_GPUS needs non-negative GPU indices");
+                gpu_list.push_back(d);
+                p0 = c1 + 1;
+            }
+        }
+        if (gpu_list.empty()) gpu_list.push_back(device);
     }
     struct Contexts {
         std::vector<vgan_euka_ctx *> v;

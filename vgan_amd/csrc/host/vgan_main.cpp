@@ -60,9 +60,9 @@ std::string haplocart_usage() {
            "   --keep-duplicates   skip duplicate removal\n"
            "   --per-read       stream the path-membership mask per read (the reference's loop order)\n"
            "   --device [INT]   GPU index (default 0)\n"
-           "   --gpus [LIST]    GPU indices, comma separated, one device context each (default: -t N takes GPUs 0..N-1 of the\n"
-           "                    visible ones, -t -1 all of them); the reads are dealt to the contexts chunk by chunk and the\n"
-           "                    per-haplogroup log-likelihoods are reduced once at the end (RCCL between distinct GPUs)\n";
+           "   --gpus [LIST]    GPU indices, comma separated, or `all`: one device context each (default: the one of --device;\n"
+           "                    the environment's VGAN_GPUS is read the same way); the reads are dealt to the contexts chunk by\n"
+           "                    chunk and the per-haplogroup log-likelihoods are reduced once at the end\n";
 }
 
 int haplocart(int argc, char **argv) {
@@ -71,7 +71,8 @@ int haplocart(int argc, char **argv) {
     std::string gamfilename, fastafilename, fastq1, fastq2, samplename;
     bool invoked_samplename = false;
     double background_error_prob = 0.0001;
-    int n_threads = 1, device = 0, gpus_wanted = 1;
+    int n_threads = 1, device = 0;
+    std::string gpu_spec;
     std::vector<int> gpu_list;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -107,21 +108,11 @@ int haplocart(int argc, char **argv) {
             n_threads = parse_int(need("-t"), "-t", "[HaploCart]");
             if (n_threads == 0 || n_threads < -1)
                 die("[HaploCart] Error, invalid number of threads"); // HaploCart.cpp:183-194
-            // the reference's thread count is this build's GPU count too: the OpenMP loop over reads (HaploCart.cpp:408)
-            // runs on min(N, visible GPUs) devices, the host side on N threads
-            gpus_wanted = n_threads;
+            // host threads only, as in the reference: a command line written for the CPU build (`-t 32`) must not grab
+            // every GPU of a shared node -- several GPUs are asked for by name (--gpus, or VGAN_GPUS in the environment)
             if (n_threads == -1) n_threads = 0;                      // all hardware threads
         } else if (a == "--gpus") {
-            const std::string v = need("--gpus");
-            size_t p0 = 0;
-            while (p0 <= v.size()) {
-                size_t c1 = v.find(',', p0);
-                if (c1 == std::string::npos) c1 = v.size();
-                const int d = parse_int(v.substr(p0, c1 - p0), "--gpus", "[HaploCart]");
-                if (d < 0) die("[HaploCart] Error, --gpus needs non-negative GPU indices");
-                gpu_list.push_back(d);
-                p0 = c1 + 1;
-            }
+            gpu_spec = need("--gpus");
         } else if (a == "-w") webapp = true;
         else if (a == "-z") (void)need("-z");
         else if (a == "--keep-duplicates") rmdup = false;
@@ -189,12 +180,22 @@ int haplocart(int argc, char **argv) {
     if (warm.t.joinable()) warm.t.join();
     const int n_visible = vgan_device_count();
     if (n_visible <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
-    if (gpu_list.empty()) {
-        const int k = gpus_wanted == -1 ? n_visible : std::min(gpus_wanted, n_visible);
-        if (k <= 1) gpu_list.push_back(device);
-        else
-            for (int d = 0; d < k; ++d) gpu_list.push_back(d);
+    if (gpu_spec.empty())
+        if (const char *e = getenv("VGAN_GPUS")) gpu_spec = e;
+    if (gpu_spec == "all") {
+        for (int d = 0; d < n_visible; ++d) gpu_list.push_back(d);
+    } else if (!gpu_spec.empty()) {
+        size_t p0 = 0;
+        while (p0 <= gpu_spec.size()) {
+            size_t c1 = gpu_spec.find(',', p0);
+            if (c1 == std::string::npos) c1 = gpu_spec.size();
+            const int d = parse_int(gpu_spec.substr(p0, c1 - p0), "--gpus", "[HaploCart]");
+            if (d < 0) die("[HaploCart] Error, --gpus needs non-negative GPU indices");
+            gpu_list.push_back(d);
+            p0 = c1 + 1;
+        }
     }
+    if (gpu_list.empty()) gpu_list.push_back(device);
     struct Contexts { // one device context per entry of the list (an index may repeat: several contexts on one GPU)
         std::vector<vgan_hc_ctx *> v;
         ~Contexts() {
@@ -357,10 +358,16 @@ int haplocart(int argc, char **argv) {
     std::vector<double> final_vec(gv.n_paths);
     if (ctxs.v.size() == 1) {
         check(vgan_hc_finalize(ctx, nullptr, final_vec.data()), "finalize");
-    } else { // HaploCart.cpp:419-420 across GPUs: one reduce of the P sums
+    } else { // HaploCart.cpp:419-420 across GPUs: one reduce of the P sums (contexts no chunk reached are left out of it)
         int used_rccl = 0;
         check(vgan_hc_reduce(ctxs.v.data(), (int)ctxs.v.size(), final_vec.data(), &used_rccl), "reduce");
-        if (!quiet) std::cerr << "Reduced the log-likelihoods of " << ctxs.v.size() << " device contexts (" << (used_rccl ? "RCCL" : "host") << ")." << '\n';
+        if (!quiet) {
+            std::cerr << "Reduced the log-likelihoods of " << ctxs.v.size() << " device contexts (" << (used_rccl ? "RCCL" : "host") << ")." << '\n';
+            double setup_ms = 0;
+            int n_setups = 0;
+            if (used_rccl && vgan_hc_reduce_info(&setup_ms, &n_setups) == 0 && n_setups)
+                std::cerr << "RCCL communicator over " << ctxs.v.size() << " devices set up in " << setup_ms << " ms." << '\n';
+        }
     }
     pt.lap("flatten + kernels");
     const int maxh = vgan_hc_argmax(final_vec.data(), gv.n_paths); // HaploCart.cpp:423

@@ -514,9 +514,16 @@ class HcContext:
         self.close()
 
 
+def reduce_info():
+    """(wall ms of the last RCCL communicator set-up of vgan_hc_reduce, number of set-ups in this process)."""
+    ms, n = C.c_double(0.0), C.c_int(0)
+    N.check(N.lib().vgan_hc_reduce_info(C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
 def reduce_contexts(ctxs):
-    """Sum of the contexts' final_vec through vgan_hc_reduce (RCCL between distinct GPUs, the host otherwise).
-    Returns (final_vec, used_rccl)."""
+    """Sum of the contexts' final_vec through vgan_hc_reduce (through the host; RCCL between distinct GPUs once a
+    communicator for them is cached or VGAN_HC_REDUCE=rccl asks for one).  Returns (final_vec, used_rccl)."""
     arr = (N.vp * len(ctxs))(*[c._h for c in ctxs])
     out = np.zeros(ctxs[0].n_paths)
     used = C.c_int(0)
