@@ -116,6 +116,10 @@ int vgan_aln_read_gam(const char *path, int keep_unmapped, vgan_alnset **out);
 int vgan_aln_parse_gam(const void *bytes, size_t n, int keep_unmapped, vgan_alnset **out);
 int vgan_aln_from_arrays(const vgan_alnset_view *v, vgan_alnset **out);
 int vgan_aln_write_gam(const vgan_alnset *a, const char *path, int group_size);
+/* `vgan haplocart -j -jf FILE` (readGAM.h:37-38, HaploCart.cpp:146-152,231): every Alignment of the GAM as one line of JSON
+ * in protobuf's JSON mapping as vg's pb2json configures it -- proto field names, declaration order, absent fields left out,
+ * 64-bit integers as strings, bytes as base64.  *n_alignments (or NULL): how many were written. */
+int vgan_gam_dump_json(const char *gam_path, const char *json_path, int64_t *n_alignments);
 int vgan_aln_view_get(const vgan_alnset *a, vgan_alnset_view *out);
 /* Dup_Remover::remove_duplicates_internal (rmdup.cpp:68-110), single-end rule: is_dup[r] = 1 when an earlier read
  * has the same (node id, offset) in its first mapping.  O(n) instead of the reference's O(n^2); same marks. */

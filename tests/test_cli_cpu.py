@@ -155,3 +155,52 @@ def test_duplicate_marks_match_the_quadratic_rule():
     k = kept.arrays()
     assert [bytes(k["name"][k["name_off"][i]:k["name_off"][i + 1]]) for i in range(3)] == \
         [bytes(arr["name"][arr["name_off"][i]:arr["name_off"][i + 1]]) for i in np.flatnonzero(~ref)[:3]]
+
+
+def test_json_dump_of_the_alignments(tmp_path, golden_dir):
+    """-j / -jf (HaploCart.cpp:146-152,231; readGAM.h:37-38): every Alignment as a line of JSON in protobuf's mapping -- held
+    against the test-side GAM decoder on the reference's own fixture and on a re-encoded set with every edit kind."""
+    import base64
+    import ctypes as C
+    import json
+
+    import gamio
+    from vgan_amd import _native as N
+
+    r = run("haplocart", "-j", "-g", "/dev/null")
+    assert r.returncode != 0 and "cannot invoke -j without -jf" in r.stderr
+    src = os.path.join(golden_dir, "reconstruct", "test_reads.gam")
+    alns = gamio.read_gam(src)
+    # a second file from the test-side encoder: negative offsets cannot occur, but reverse strands, insertions, deletions,
+    # substitutions, an empty quality string and a name that needs escaping do
+    extra = [dict(a) for a in alns]
+    extra[0]["name"] = b'q"uote\\back<tag>\ttab'
+    extra[1]["quality"] = b""
+    second = str(tmp_path / "second.gam")
+    open(second, "wb").write(gamio.write_gam(extra, group=3))
+    for path, want in ((src, alns), (second, extra)):
+        out = str(tmp_path / "dump.json")
+        n = C.c_int64(0)
+        N.check(N.lib().vgan_gam_dump_json(path.encode(), out.encode(), C.byref(n)))
+        lines = open(out).read().splitlines()
+        assert n.value == len(want) == len(lines)
+        for ln, a in zip(lines, want):
+            d = json.loads(ln)
+            assert list(d.keys()) == [k for k in ("sequence", "path", "name", "quality", "mapping_quality", "score", "identity", "time_used") if k in d]
+            assert d.get("sequence", "").encode() == a["sequence"] and d.get("name", "").encode() == a["name"]
+            assert base64.b64decode(d.get("quality", "")) == a["quality"]
+            assert d.get("mapping_quality", 0) == a["mapping_quality"] and d.get("score", 0) == a["score"]
+            assert float(d.get("identity", 0.0)) == a["identity"]  # the shortest text that reads back
+            maps = d.get("path", {}).get("mapping", [])
+            assert len(maps) == len(a["path"]["mapping"])
+            for jm, m in zip(maps, a["path"]["mapping"]):
+                pos = jm.get("position", {})
+                assert int(pos.get("node_id", "0")) == m["position"]["node_id"] and isinstance(pos.get("node_id", "0"), str)
+                assert int(pos.get("offset", "0")) == m["position"]["offset"] and bool(pos.get("is_reverse", False)) == bool(m["position"]["is_reverse"])
+                assert [(e.get("from_length", 0), e.get("to_length", 0), e.get("sequence", "").encode()) for e in jm.get("edit", [])] == \
+                       [(e["from_length"], e["to_length"], e["sequence"]) for e in m["edit"]]
+    # a truncated file is an error, not a shorter dump
+    bad = str(tmp_path / "bad.gam")
+    raw = gamio.gunzip_all(open(src, "rb").read())
+    open(bad, "wb").write(raw[:len(raw) - 7])
+    assert N.lib().vgan_gam_dump_json(bad.encode(), str(tmp_path / "bad.json").encode(), None) < 0

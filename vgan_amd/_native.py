@@ -167,6 +167,7 @@ SYMBOLS = {
     "vgan_aln_parse_gam": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(vp)]),
     "vgan_aln_from_arrays": (C.c_int, [C.POINTER(AlnSetView), C.POINTER(vp)]),
     "vgan_aln_write_gam": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "vgan_gam_dump_json": (C.c_int, [C.c_char_p, C.c_char_p, vp]),
     "vgan_aln_view_get": (C.c_int, [vp, C.POINTER(AlnSetView)]),
     "vgan_aln_mark_duplicates": (C.c_int, [vp, vp, vp]),
     "vgan_aln_filter": (C.c_int, [vp, vp, C.POINTER(vp)]),

@@ -127,6 +127,11 @@ struct vgan_hc_ctx {
     std::unordered_map<std::string, std::vector<std::string>> parents, children;
     DevBuf<uint32_t> lists; // posterior: list offsets, then the path indices
     DevBuf<double> conf;
+    // posterior: name -> path indices (built at the first call), and the lists of the last predicted haplotype as they sit on
+    // the device (a caller asks about the same prediction again and again: the walk and its upload are done once)
+    std::unordered_map<std::string, std::vector<uint32_t>> by_name;
+    std::string post_predicted, post_clades;
+    uint32_t post_n_off = 0, post_ns = 0;
     // profiling: pairs of events per timed launch, resolved in vgan_hc_profile_read
     bool profiling = false;
     struct Timed {
@@ -928,56 +933,66 @@ extern "C" int vgan_hc_posterior(vgan_hc_ctx *c, const double *final_vec, const 
     if (c->path_names.size() != c->P) return fail(VGAN_ESTATE, "vgan_hc_posterior: graph has %zu path names for %u paths", c->path_names.size(), c->P);
     auto pi = c->path_index.find(predicted);
     if (pi == c->path_index.end()) return fail(VGAN_EINVAL, "vgan_hc_posterior: '%s' is not a path name", predicted);
-    // src/get_posterior.cpp:94-123: the predicted haplotype, then each ancestor with its strict descendants
-    std::vector<std::string> parent_vec;
-    auto pv = c->parents.find(predicted);
-    if (pv != c->parents.end()) parent_vec = pv->second;
-    std::vector<std::string> clades{predicted};
-    // One index list per record, in the order the reference builds all_top (:51-76): per recursion level the members of
-    // that level's child set in path order; a fresh set per level, so a path reachable at two depths is listed twice.
-    std::unordered_map<std::string, std::vector<uint32_t>> by_name; // graph_paths may repeat a name: every index counts (:60-66)
-    for (uint32_t p = 0; p < c->P; ++p) by_name[c->path_names[p]].push_back(p);
-    std::vector<uint32_t> off{0}, idx{(uint32_t)pi->second};
-    off.push_back(1);
-    constexpr size_t kMaxList = (size_t)1 << 27; // a cyclic children.txt recurses without end in the reference
-    for (size_t j = 0; j < parent_vec.size(); ++j) {
-        const bool emit = j == 0 || parent_vec[j] != parent_vec[j - 1]; // :110,117 (Q9: j = 0 always emitted)
-        if (!emit) continue; // its all_top is computed and dropped by the reference
-        clades.push_back(parent_vec[j]);
-        std::set<std::string> preds{parent_vec[j]};
-        for (int depth = 0; !preds.empty() && depth <= 100000; ++depth) { // get_children(), :36-49
-            std::set<std::string> child_set;
-            for (const std::string &p : preds) {
-                auto ch = c->children.find(p);
-                if (ch == c->children.end()) continue; // the reference dereferences end() here; defined as "no children"
-                child_set.insert(ch->second.begin(), ch->second.end());
-            }
-            const size_t level0 = idx.size();
-            for (const std::string &k : child_set) {
-                auto ki = by_name.find(k);
-                if (ki != by_name.end()) idx.insert(idx.end(), ki->second.begin(), ki->second.end());
-            }
-            std::sort(idx.begin() + level0, idx.end()); // path order within the level
-            if (idx.size() > kMaxList) return fail(VGAN_ERANGE, "vgan_hc_posterior: children of '%s' do not end (cycle?)", parent_vec[j].c_str());
-            preds.swap(child_set);
-        }
-        off.push_back((uint32_t)idx.size());
-    }
-    const uint32_t ns = (uint32_t)off.size() - 1;
-    if ((int32_t)ns > conf_cap) return fail(VGAN_ERANGE, "vgan_hc_posterior: conf_cap too small (%u records)", ns);
-    std::string joined;
-    for (auto &s : clades) joined += s + "\n";
-    if ((int64_t)joined.size() + 1 > clade_cap) return fail(VGAN_ERANGE, "vgan_hc_posterior: clade buffer too small");
     HIPCHK(hipSetDevice(c->device));
     int rc;
-    if ((rc = c->lists.reserve(off.size() + idx.size())) || (rc = c->conf.reserve(ns))) return rc;
-    HIPCHK(hipMemcpyAsync(c->lists.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->lists.p + off.size(), idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (c->post_predicted != predicted || c->post_ns == 0) {
+        // src/get_posterior.cpp:94-123: the predicted haplotype, then each ancestor with its strict descendants
+        std::vector<std::string> parent_vec;
+        auto pv = c->parents.find(predicted);
+        if (pv != c->parents.end()) parent_vec = pv->second;
+        std::vector<std::string> clades{predicted};
+        // One index list per record, in the order the reference builds all_top (:51-76): per recursion level the members of
+        // that level's child set in path order; a fresh set per level, so a path reachable at two depths is listed twice.
+        if (c->by_name.empty()) // graph_paths may repeat a name: every index counts (:60-66)
+            for (uint32_t p = 0; p < c->P; ++p) c->by_name[c->path_names[p]].push_back(p);
+        const auto &by_name = c->by_name;
+        std::vector<uint32_t> off{0}, idx{(uint32_t)pi->second};
+        off.push_back(1);
+        constexpr size_t kMaxList = (size_t)1 << 27; // a cyclic children.txt recurses without end in the reference
+        for (size_t j = 0; j < parent_vec.size(); ++j) {
+            const bool emit = j == 0 || parent_vec[j] != parent_vec[j - 1]; // :110,117 (Q9: j = 0 always emitted)
+            if (!emit) continue; // its all_top is computed and dropped by the reference
+            clades.push_back(parent_vec[j]);
+            std::set<std::string> preds{parent_vec[j]};
+            for (int depth = 0; !preds.empty() && depth <= 100000; ++depth) { // get_children(), :36-49
+                std::set<std::string> child_set;
+                for (const std::string &p : preds) {
+                    auto ch = c->children.find(p);
+                    if (ch == c->children.end()) continue; // the reference dereferences end() here; defined as "no children"
+                    child_set.insert(ch->second.begin(), ch->second.end());
+                }
+                const size_t level0 = idx.size();
+                for (const std::string &k : child_set) {
+                    auto ki = by_name.find(k);
+                    if (ki != by_name.end()) idx.insert(idx.end(), ki->second.begin(), ki->second.end());
+                }
+                std::sort(idx.begin() + level0, idx.end()); // path order within the level
+                if (idx.size() > kMaxList) return fail(VGAN_ERANGE, "vgan_hc_posterior: children of '%s' do not end (cycle?)", parent_vec[j].c_str());
+                preds.swap(child_set);
+            }
+            off.push_back((uint32_t)idx.size());
+        }
+        c->post_ns = 0; // (nothing is cached while the device copy is being replaced)
+        if ((rc = c->lists.reserve(off.size() + idx.size()))) return rc;
+        HIPCHK(hipMemcpyAsync(c->lists.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->lists.p + off.size(), idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream)); // (off / idx are locals)
+        c->post_clades.clear();
+        for (auto &s : clades) c->post_clades += s + "\n";
+        c->post_predicted = predicted;
+        c->post_n_off = (uint32_t)off.size();
+        c->post_ns = (uint32_t)off.size() - 1;
+    }
+    const uint32_t ns = c->post_ns;
+    if ((int32_t)ns > conf_cap) return fail(VGAN_ERANGE, "vgan_hc_posterior: conf_cap too small (%u records)", ns);
+    if ((int64_t)c->post_clades.size() + 1 > clade_cap) return fail(VGAN_ERANGE, "vgan_hc_posterior: clade buffer too small");
+    if ((rc = c->conf.reserve(ns))) return rc;
+    // (the vector the caller holds may be a reduce over several contexts: it is sent, not assumed to be this context's own)
     HIPCHK(hipMemcpyAsync(c->final_vec.p, final_vec, (size_t)c->P * 8, hipMemcpyHostToDevice, c->stream));
-    launch_hc_posterior(c->final_vec.p, c->P, c->lists.p, c->lists.p + off.size(), ns, c->conf.p, c->stream);
+    launch_hc_posterior(c->final_vec.p, c->P, c->lists.p, c->lists.p + c->post_n_off, ns, c->conf.p, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(conf, c->conf.p, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    memcpy(clade_buf, joined.c_str(), joined.size() + 1);
+    memcpy(clade_buf, c->post_clades.c_str(), c->post_clades.size() + 1);
     return (int)ns;
 }

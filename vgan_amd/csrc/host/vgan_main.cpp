@@ -68,7 +68,8 @@ std::string haplocart_usage() {
 int haplocart(int argc, char **argv) {
     bool debug = false, quiet = false, compute_posteriors = true, rmdup = true, per_read = false, webapp = false;
     std::string posteriorfilename = "/dev/stdout", outputfilename = "/dev/stdout", hcfiledir = "../share/vgan/hcfiles/";
-    std::string gamfilename, fastafilename, fastq1, fastq2, samplename;
+    std::string gamfilename, fastafilename, fastq1, fastq2, samplename, jsonfilename;
+    bool dump_json = false;
     bool invoked_samplename = false;
     double background_error_prob = 0.0001;
     int n_threads = 1, device = 0;
@@ -96,7 +97,8 @@ int haplocart(int argc, char **argv) {
         else if (a == "-fq1") fastq1 = need("-fq1");
         else if (a == "-fq2") fastq2 = need("-fq2");
         else if (a == "-i") die("[HaploCart] interleaved FASTQ input needs vg giraffe; map with vg and pass -g");
-        else if (a == "-j" || a == "-jf") die("[HaploCart] JSON dump is not part of the GPU path");
+        else if (a == "-j") dump_json = true;           // HaploCart.cpp:146-149
+        else if (a == "-jf") jsonfilename = need("-jf"); // HaploCart.cpp:151-154
         else if (a == "-o") outputfilename = need("-o");
         else if (a == "-np") compute_posteriors = false;
         else if (a == "-pf") posteriorfilename = need("-pf");
@@ -126,6 +128,7 @@ int haplocart(int argc, char **argv) {
     if (webapp) die("[HaploCart] webapp mode is not part of the GPU path");
     if (!fastq1.empty() || !fastq2.empty())
         die("[HaploCart] FASTQ input needs vg giraffe in-process, which this build does not have; map with vg and pass -g");
+    if (dump_json && jsonfilename.empty()) die("[HaploCart] Error, cannot invoke -j without -jf"); // HaploCart.cpp:231
     if (gamfilename.empty()) die("[HaploCart] Error, no input file given (use -g)");
     if (!std::ifstream(gamfilename)) die("[HaploCart] Error, GAM input file " + gamfilename + " does not exist");
     if (!invoked_samplename) samplename = !fastafilename.empty() ? fastafilename : gamfilename;
@@ -144,6 +147,24 @@ int haplocart(int argc, char **argv) {
         ~StreamCloser() { vgan_gam_stream_close(s); }
     } stream;
     check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
+    // -j -jf FILE: every alignment of the GAM as a line of JSON (readGAM.h:37-38 writes them while it reads; here a pass of
+    // its own, on a thread beside the run).  The reference opens -jf FILE even without -j (and leaves it empty).
+    struct JsonDump {
+        std::thread t;
+        int rc = 0;
+        std::string err;
+        ~JsonDump() {
+            if (t.joinable()) t.join();
+        }
+    } json;
+    if (dump_json) {
+        json.t = std::thread([&] {
+            json.rc = vgan_gam_dump_json(gamfilename.c_str(), jsonfilename.c_str(), nullptr);
+            if (json.rc < 0) json.err = vgan_last_error();
+        });
+    } else if (!jsonfilename.empty()) {
+        std::ofstream touch(jsonfilename);
+    }
     // the HIP runtime comes up on a thread of its own while the graph is read (its failure shows at context creation)
     struct Warm {
         std::thread t;
@@ -418,6 +439,8 @@ int haplocart(int argc, char **argv) {
             fclose(f);
         }
     }
+    if (json.t.joinable()) json.t.join();
+    if (json.rc < 0) die("[HaploCart] writing " + jsonfilename + ": " + json.err);
     // Every output is written and closed: leave from here.  Returning runs this function's destructors first -- the stream's
     // inflated bytes (1.6 GB per million reads), the recycled arrays, the graph, the device contexts: hundreds of munmap calls,
     // each interrupting every core the process ran on -- which cost 0.2-0.3 s that no one is waiting for; the kernel takes
