@@ -189,6 +189,7 @@ def bench_euka(args):
             dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
             fin[k] = t.cpu().numpy()
     if rank == 0:
+        euka_traffic = collect_traffic(args, "euka_read_kernel") if world == 1 and not args.no_pmc else None
         kb = hb.algorithmic_bytes()
         avg = ms / max(n, 1)
         gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
@@ -198,11 +199,12 @@ def bench_euka(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "euka %d synthetic 75bp aDNA reads per GPU, dhigh damage profiles, 335-clade graph" % args.reads,
                        "reads_per_gpu": hb.n_reads, "passing_reads": int(fin["clade_count"].sum())},
+            # (HBM figures as one coherent record; the kernel's limiter is fp64 VALU issue: one table log + the damage-matrix
+            # products per base, SURVEY 8d.  traffic: in-run rocprofv3 --pmc passes, as on the HaploCart line)
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "traffic_from_profile": committed_traffic("round1_v5_euka", "euka_read_kernel", args.reads == 1_000_000 and world == 1),
+                         "traffic": euka_traffic.get("bytes") if euka_traffic else None, "traffic_detail": euka_traffic,
                          "kernel": "euka_read_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
-                         "launches": n, "note": "fp64 VALU bound (SURVEY 8d): one table log + the damage-matrix products per base"}}
+                         "launches": n, "limiter": dict(valu_from_profile("euka_read_kernel") or {}, kind="valu (fp64) issue")}}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline_euka(g, db, alns, dm_texts, ctx, ek, args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -344,6 +346,7 @@ def bench_soibean(args):
     km = ctx.kernel_ms()
     if rank == 0:
         R = hb.n_reads
+        sb_traffic = collect_traffic(args, "sb_refresh_fused_kernel" if fused else "sb_loglike_kernel") if world == 1 and not args.no_pmc else None
         avg = km["refresh"][0] / max(km["refresh"][1], 1)
         kb = R * 3 * 2 * (8 + 25 * 2) + R  # 2k path rows of pm (8 B) + cnt (25 x 2 B) + ok flags
         gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
@@ -355,9 +358,7 @@ def bench_soibean(args):
             "config": {"workload": "soibean k=3, %d synthetic reads per GPU, 28-path tree, host Metropolis loop + GPU refresh per iteration" % args.reads,
                        "reads_per_gpu": R, "precompute_s": t_pre, "accepted": accepted},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "traffic_from_profile": committed_traffic("round1_v5_soibean", "sb_refresh_fused_kernel", R == SB_PROFILED_READS and world == 1)
-                         if fused else None,
+                         "traffic": sb_traffic.get("bytes") if sb_traffic else None, "traffic_detail": sb_traffic,
                          "kernel": "sb_refresh_fused_kernel" if fused else "sb_loglike_kernel + sb_finish_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
                          "launches": km["refresh"][1]}}
         if world == 1 and args.cpu_seconds > 0:
@@ -430,7 +431,8 @@ def collect_traffic(args, kernel_substr):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-pmc", "--no-frontend",
-                   "--reads", str(args.reads), "--read-len", str(args.read_len), "--mode", args.mode, "--seed", str(args.seed)]
+                   "--reads", str(args.reads), "--read-len", str(args.read_len), "--mode", args.mode, "--seed", str(args.seed),
+                   "--path", args.path, "--clades", str(args.clades)]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)

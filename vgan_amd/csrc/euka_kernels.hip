@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "device_math.h"
 #include "euka_device.h"
 
@@ -39,6 +41,18 @@ constexpr int EK_GROUP = 16;                              // lanes per read: a D
 constexpr int EK_READS_PER_WAVE = 64 / EK_GROUP;          // 4 reads per wave,
 constexpr int EK_READS_PER_BLOCK = EK_WAVES * EK_READS_PER_WAVE; // 16 per workgroup
 constexpr uint32_t EK_DMG_LDS_PAIRS = 64;                 // (5' row, 3' row) pairs kept in LDS (10 KB)
+constexpr int EK_ACC_LTP = 8;                             // lengthToProf up to which a wave keeps the base shifts in LDS,
+constexpr int EK_ACC_BINS = 32;                           // bins per clade up to which it keeps the coverage there
+
+// A wave's accumulators for ONE clade (the batch is sorted by node id, clades own contiguous node ranges: a wave's reads
+// are of one clade for long stretches).  Flushed to the global tables when the clade changes and when the wave ends.
+struct EkAcc {
+    uint32_t shift[2 * EK_ACC_LTP * 16];
+    double cov[EK_ACC_BINS];
+    double logsum;
+    uint32_t n_like;
+    int32_t count;
+};
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
 __device__ __forceinline__ double row_sum16(double v) {
@@ -63,6 +77,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     // the order it tests them (readGAM_Euka.h:236-280): 0 'N', 1 '-', 2 rare IUPAC code, 3 'S', 4 none
     __shared__ uint8_t cls_s[256];
     __shared__ double bfl_s[16]; // base_freq log of the read base by its low nibble; 0 unless A C G T / 'N' (slot 9)
+    __shared__ EkAcc acc_s[EK_WAVES];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         const int ai = acgt_index((uint32_t)i);
         const int rank = i == 'N' ? 0 : i == '-' ? 1 : is_rare((uint32_t)i) ? 2 : i == 'S' ? 3 : 4;
@@ -76,9 +91,15 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     for (int i = threadIdx.x; i < 64; i += blockDim.x) logtab_s[i] = euka_log_table[i];
     if (DMG_LDS)
         for (uint32_t i = threadIdx.x; i < d.n5 * d.n3 * 20u; i += blockDim.x) dmg_s[i] = d.dmg_pair[i];
+    {
+        uint32_t *z = reinterpret_cast<uint32_t *>(acc_s);
+        for (uint32_t i = threadIdx.x; i < sizeof(acc_s) / 4; i += blockDim.x) z[i] = 0u;
+    }
     __syncthreads();
     const double *const dmg = DMG_LDS ? dmg_s : d.dmg_pair;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    EkAcc &acc = acc_s[wave];
+    const bool shift_in_lds = d.ltp <= EK_ACC_LTP;
     const uint32_t sub = lane & 15u, gshift = lane & 48u, grp = (uint32_t)lane >> 4;
     const uint32_t below = (1u << sub) - 1u;
     auto row_bits = [&](bool p) { return (uint32_t)(__builtin_amdgcn_ballot_w64(p) >> gshift) & 0xFFFFu; };
@@ -94,8 +115,48 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     uint32_t *const baseshift = o.baseshift + (size_t)rep * d.n_clades * 2 * (d.ltp > 0 ? d.ltp : 1) * 16;
     double *const bin_cov = o.bin_cov + (size_t)rep * o.n_bins;
 
-    for (uint32_t rbase = (blockIdx.x * EK_WAVES + wave) * EK_READS_PER_WAVE; rbase < b.n_reads;
-         rbase += gridDim.x * EK_READS_PER_BLOCK) {
+    // the wave's accumulators go to the global tables (replica of this workgroup): a few hundred atomics per clade and wave
+    // instead of ~15 per read
+    int32_t cur = -1; // the clade the accumulators hold (wave uniform)
+    auto flush = [&]() {
+        if (cur < 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (shift_in_lds) {
+            for (int i = lane; i < 2 * d.ltp * 16; i += 64) {
+                const uint32_t v = acc.shift[i];
+                if (v) {
+                    atomicAdd(&baseshift[(size_t)cur * 2 * d.ltp * 16 + i], v);
+                    acc.shift[i] = 0u;
+                }
+            }
+        }
+        const uint32_t b0 = d.bin_off[cur], nb = min(d.bin_off[cur + 1] - b0, (uint32_t)EK_ACC_BINS);
+        if ((uint32_t)lane < nb) {
+            const double v = acc.cov[lane];
+            if (v != 0.0) {
+                unsafeAtomicAdd(&bin_cov[b0 + lane], v);
+                acc.cov[lane] = 0.0;
+            }
+        }
+        if (lane == 0) {
+            if (acc.count) atomicAdd(&clade_count[cur], acc.count);
+            if (acc.n_like) {
+                atomicAdd(&like_n[cur], acc.n_like);
+                unsafeAtomicAdd(&like_logsum[cur], acc.logsum);
+            }
+            acc.count = 0;
+            acc.n_like = 0u;
+            acc.logsum = 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // contiguous reads per wave (whole steps of four)
+    const uint32_t n_waves = gridDim.x * EK_WAVES;
+    const uint32_t per_wave = ((b.n_reads + n_waves - 1) / n_waves + EK_READS_PER_WAVE - 1) / EK_READS_PER_WAVE * EK_READS_PER_WAVE;
+    const uint32_t w_begin = (blockIdx.x * EK_WAVES + wave) * per_wave, w_end = min(b.n_reads, w_begin + per_wave);
+    for (uint32_t rbase = w_begin; rbase < w_end; rbase += EK_READS_PER_WAVE) {
         const bool have = rbase + grp < b.n_reads; // this row has a read
         const uint32_t r = min(rbase + grp, b.n_reads - 1u);
         const uint32_t col0 = b.read_col_off[r];
@@ -125,6 +186,14 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             }
         }
         const double pair_dist = d.clade_dist[c_n];
+        {   // the step's first read names the wave's clade; a row of another clade (a boundary step) adds to the global tables
+            const int32_t c_first = __builtin_amdgcn_readfirstlane(c_n);
+            if (c_first != cur) {
+                flush();
+                cur = c_first;
+            }
+        }
+        const bool in_acc = c_n == cur;
 
         double lik = 0.0, lik2 = 0.0;
         uint32_t carry_n = 0, carry_sc = 0;
@@ -217,7 +286,10 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 gb = (gb >= 'a' && gb <= 'z') ? gb - 32u : gb;
                 rb = (rb >= 'a' && rb <= 'z') ? rb - 32u : rb;
                 const int g4 = acgt_index(gb), r4 = acgt_index(rb);
-                if (g4 >= 0 && r4 >= 0) atomicAdd(&baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4 * 4 + r4], 1u);
+                if (g4 >= 0 && r4 >= 0) {
+                    if (in_acc && shift_in_lds) atomicAdd(&acc.shift[p * 16 + g4 * 4 + r4], 1u);
+                    else atomicAdd(&baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4 * 4 + r4], 1u);
+                }
             }
         }
         // clade_like / clade_not_like (:485-492)
@@ -236,11 +308,17 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             o.like[r] = like;
             o.not_like[r] = 1.0 - like;
             o.pass[r] = pass ? 1 : 0;
-            if (pass) atomicAdd(&clade_count[c_n], 1);
             // the abundance MCMC only ever uses sum_k log(frac * clade_like[k]) per clade (MCMC.cpp:1175-1215, (1/334) == 0):
             // keep the count and the sum of logs; a read with like == 0 (mapq 0, or exp underflow) makes the sum -inf as there
-            atomicAdd(&like_n[c_n], 1u);
-            unsafeAtomicAdd(&like_logsum[c_n], log(like));
+            if (in_acc) {
+                if (pass) atomicAdd(&acc.count, 1);
+                atomicAdd(&acc.n_like, 1u);
+                unsafeAtomicAdd(&acc.logsum, log(like));
+            } else {
+                if (pass) atomicAdd(&clade_count[c_n], 1);
+                atomicAdd(&like_n[c_n], 1u);
+                unsafeAtomicAdd(&like_logsum[c_n], log(like));
+            }
         }
         // bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546).  Lane j of a
         // row owns the clade's bin jb + j and counts the read's mappings that fall into it (16 nodes per step, handed
@@ -263,10 +341,44 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                         cnt += (nd >= my_lo && nd <= my_hi && nd >= 0) ? 1u : 0u; // ... whatever its bounds
                     }
                 }
-                if (cnt) unsafeAtomicAdd(&bin_cov[b0 + jb + sub], (double)cnt * inv);
+                if (cnt) {
+                    if (in_acc && jb + sub < (uint32_t)EK_ACC_BINS) unsafeAtomicAdd(&acc.cov[jb + sub], (double)cnt * inv);
+                    else unsafeAtomicAdd(&bin_cov[b0 + jb + sub], (double)cnt * inv);
+                }
             }
         }
     }
+    // The end of the workgroup: its four waves took consecutive ranges of the sorted reads, so they mostly end on one
+    // clade -- their accumulators are added up in LDS and leave the chip once.
+    __shared__ int32_t cur_s[EK_WAVES];
+    if (lane == 0) cur_s[wave] = cur;
+    __syncthreads();
+    const int32_t cur0 = cur_s[0];
+    if (wave > 0) {
+        if (cur == cur0 && cur >= 0) {
+            EkAcc &a0 = acc_s[0];
+            if (shift_in_lds)
+                for (int i = lane; i < 2 * d.ltp * 16; i += 64) {
+                    const uint32_t v = acc.shift[i];
+                    if (v) atomicAdd(&a0.shift[i], v);
+                }
+            if (lane < EK_ACC_BINS) {
+                const double v = acc.cov[lane];
+                if (v != 0.0) unsafeAtomicAdd(&a0.cov[lane], v);
+            }
+            if (lane == 0) {
+                if (acc.count) atomicAdd(&a0.count, acc.count);
+                if (acc.n_like) {
+                    atomicAdd(&a0.n_like, acc.n_like);
+                    unsafeAtomicAdd(&a0.logsum, acc.logsum);
+                }
+            }
+        } else {
+            flush();
+        }
+    }
+    __syncthreads();
+    if (wave == 0) flush();
 }
 
 // replica r > 0 added onto replica 0, replicas cleared: fixed order, so the sums do not depend on scheduling
@@ -316,8 +428,12 @@ void launch_euka_reduce(const EukaOutDev &o, uint32_t n_clades, int32_t ltp, hip
 
 void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev &o, hipStream_t st) {
     if (b.n_reads == 0) return;
+    // each wave a contiguous range of the (sorted) reads; a workgroup's waves flush together at the end, so the number of
+    // workgroups (not waves) sets the flush traffic: 4096 of them even out the CUs (1024: 0.96 ms, 4096: 0.89 ms per 1M reads)
     uint32_t blocks = (b.n_reads + EK_READS_PER_BLOCK - 1) / EK_READS_PER_BLOCK;
-    blocks = blocks < 256u * 8u ? blocks : 256u * 8u;
+    uint32_t cap = 256u * 16u;
+    if (const char *e = getenv("VGAN_EUKA_BLOCKS")) cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap; // developer aid
+    blocks = blocks < cap ? blocks : cap;
     if (d.n5 * d.n3 <= EK_DMG_LDS_PAIRS)
         hipLaunchKernelGGL(euka_read_kernel<true>, dim3(blocks), dim3(EK_WAVES * 64), 0, st, d, b, o);
     else

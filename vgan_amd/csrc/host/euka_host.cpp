@@ -321,6 +321,69 @@ extern "C" int vgan_euka_flatten(const vgan_graph *g, const vgan_alnset *a, int6
         st.n_bad += c.st.n_bad;
         c.b = vgan_euka_host_batch();
     }
+    // The reads go to the device in ascending order of their first mapping's node id (stable; read_src says which read of
+    // the input each one is): clades own contiguous node ranges, so a wave of the read kernel sees one clade for long
+    // stretches and keeps that clade's counters in LDS instead of adding to the global tables read by read.
+    {
+        const size_t R = res->read_mapq.size();
+        std::vector<uint32_t> order(R);
+        for (size_t i = 0; i < R; ++i) order[i] = (uint32_t)i;
+        auto key = [&](uint32_t i) { return res->read_map_off[i] < res->read_map_off[i + 1] ? res->map_node[res->read_map_off[i]] : 0u; };
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+        bool sorted = true;
+        for (size_t i = 0; i < R && sorted; ++i) sorted = order[i] == i;
+        if (!sorted) {
+            auto srt = new vgan_euka_host_batch();
+            srt->read_col_off.assign(R + 1, 0);
+            srt->read_qual_off.assign(R + 1, 0);
+            srt->read_map_off.assign(R + 1, 0);
+            for (size_t i = 0; i < R; ++i) {
+                const uint32_t o = order[i];
+                srt->read_col_off[i + 1] = srt->read_col_off[i] + (res->read_col_off[o + 1] - res->read_col_off[o]);
+                srt->read_qual_off[i + 1] = srt->read_qual_off[i] + (res->read_qual_off[o + 1] - res->read_qual_off[o]);
+                srt->read_map_off[i + 1] = srt->read_map_off[i] + (res->read_map_off[o + 1] - res->read_map_off[o]);
+            }
+            srt->read_gseq_len.resize(R);
+            srt->read_rseq_len.resize(R);
+            srt->read_seq_len.resize(R);
+            srt->read_mapq.resize(R);
+            srt->read_rev.resize(R);
+            srt->read_src.resize(R);
+            srt->map_node.resize(res->map_node.size());
+            srt->graph_seq.resize(res->graph_seq.size());
+            srt->read_seq.resize(res->read_seq.size());
+            srt->qual.resize(res->qual.size());
+            auto move_range = [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; ++i) {
+                    const uint32_t o = order[i];
+                    srt->read_gseq_len[i] = res->read_gseq_len[o];
+                    srt->read_rseq_len[i] = res->read_rseq_len[o];
+                    srt->read_seq_len[i] = res->read_seq_len[o];
+                    srt->read_mapq[i] = res->read_mapq[o];
+                    srt->read_rev[i] = res->read_rev[o];
+                    srt->read_src[i] = res->read_src[o];
+                    const size_t nc = res->read_col_off[o + 1] - res->read_col_off[o], nq = res->read_qual_off[o + 1] - res->read_qual_off[o],
+                                 nm = res->read_map_off[o + 1] - res->read_map_off[o];
+                    if (nc) {
+                        memcpy(&srt->graph_seq[srt->read_col_off[i]], &res->graph_seq[res->read_col_off[o]], nc);
+                        memcpy(&srt->read_seq[srt->read_col_off[i]], &res->read_seq[res->read_col_off[o]], nc);
+                    }
+                    if (nq) memcpy(&srt->qual[srt->read_qual_off[i]], &res->qual[res->read_qual_off[o]], nq);
+                    if (nm) memcpy(&srt->map_node[srt->read_map_off[i]], &res->map_node[res->read_map_off[o]], nm * sizeof(uint32_t));
+                }
+            };
+            const size_t nth = (size_t)std::max(1, std::min<int>(n_threads, (int)((R + 16383) / 16384)));
+            if (nth <= 1) {
+                move_range(0, R);
+            } else {
+                std::vector<std::thread> mv;
+                for (size_t t = 0; t < nth; ++t) mv.emplace_back(move_range, R * t / nth, R * (t + 1) / nth);
+                for (auto &t : mv) t.join();
+            }
+            delete res;
+            res = srt;
+        }
+    }
     if (stats) *stats = st;
     *out = res;
     return VGAN_OK;

@@ -294,10 +294,20 @@ int euka_main(int argc, char **argv) {
                 o.err = std::string("accumulate: ") + vgan_last_error();
                 break;
             }
-            o.clade.assign(o_clade.begin(), o_clade.end());
-            o.pass.assign(o_pass.begin(), o_pass.end());
-            o.len.assign(b.read_seq_len, b.read_seq_len + R);
-            if (out_frag) o.src.assign(b.read_src, b.read_src + R);
+            // the batch is in node order (vgan_euka_flatten): the per-read lists go on in input order, as the reference's do
+            std::vector<int64_t> pos((size_t)(r1 - r0), -1);
+            for (size_t i = 0; i < R; ++i) pos[(size_t)((int64_t)b.read_src[i] - r0)] = (int64_t)i;
+            o.clade.clear();
+            o.pass.clear();
+            o.len.clear();
+            o.src.clear();
+            for (int64_t i : pos) {
+                if (i < 0) continue;
+                o.clade.push_back(o_clade[(size_t)i]);
+                o.pass.push_back(o_pass[(size_t)i]);
+                o.len.push_back(b.read_seq_len[i]);
+                if (out_frag) o.src.push_back(b.read_src[i]);
+            }
         }
     };
     if (K == 1) {
