@@ -1,0 +1,48 @@
+"""The HIP path against the committed fixture of the independent Python + mpmath restatement (tools/pyref_hc.py,
+tests/golden/hc_pyref/): no oracle/ in this file -- liboracle.so is neither loaded nor needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from vgan_amd import haplocart as hc
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hc_pyref")
+
+
+@pytest.mark.parametrize("key, kw", [("default", {}), ("background", dict(background_error_prob=0.02, use_background_error_prob=True))])
+def test_final_vector_per_read_vectors_and_posteriors_against_the_python_restatement(key, kw):
+    want = json.load(open(os.path.join(FIX, "hc_pyref.json")))[key]
+    g = hc.Graph.load(os.path.join(FIX, "graph.gfa"), FIX)
+    a = hc.AlnSet.read_gam(os.path.join(FIX, "reads.gam"))
+    assert a.n_reads == want["n_alignments"]
+    # the reads the restatement refuses as undefined in the reference (the product defines them: include/vgan_gpu.h) are left out
+    drop = np.zeros(a.n_reads, np.uint8)
+    for u in want["undefined_reads"]:
+        drop[u["read"]] = 1
+    a = a.without(drop)
+    b = hc.HostBatch(g, a)
+    assert b.n_reads == want["n_used"] and b.stats.n_bad == 0
+    fv = np.array([float(x) for x in want["final_vec"]])
+    ctx = hc.HcContext(g, **kw)
+    for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ, hc.MODE_PER_READ_DENSE):
+        ctx.reset()
+        ctx.set_mode(mode)
+        ctx.accumulate(b)
+        got = ctx.finalize()
+        assert np.max(np.abs(got - fv) / np.abs(fv)) < 1e-9, (key, mode)
+    assert g.path_names[ctx.argmax(got)] == want["predicted"]
+    post = ctx.posterior(got, want["predicted"])
+    assert [c for c, _, _ in post] == [x["clade"] for x in want["posterior"]]
+    for (_, c1, _), x in zip(post, want["posterior"]):
+        assert c1 == pytest.approx(float(x["confidence"]), rel=1e-9, abs=1e-300)
+    # per-read vectors (the value Haplocart::update returns) of the first reads
+    kept = [r for r in range(want["n_alignments"]) if not drop[r]]
+    src = list(b.read_src)
+    ll = ctx.read_loglik(b)
+    for rec in want["first_reads"]:
+        k = src.index(kept.index(rec["read"]))
+        ref = np.array([float(x) for x in rec["loglik"]])
+        assert np.max(np.abs(ll[k] - ref) / np.abs(ref)) < 1e-11, rec["read"]

@@ -1,0 +1,465 @@
+#!/usr/bin/env python3
+"""A second, independent restatement of HaploCart's per-read likelihood path -- Python + mpmath (40 digits), written from the
+reference's sources, NOT from oracle/ (the C++ long double restatement the test-suite otherwise leans on).  It exists so
+that the numbers every parity test is held against do not rest on one author path alone: two restatements in two languages
+with two arithmetics agreeing to 1e-15 is a far smaller common-mode risk than one.
+
+What it follows, line by line (paths under /root/reference/src/):
+    vgan_utils.h:6-79             reconstruct_graph_sequence (with vg's path_string / edit_is_* semantics, see below)
+    update_likelihood.cpp:19-53   the loop over mappings, the quality window, the sticky Q >= 90 switch
+    process_mapping.cpp:4-91      supported / unsupported sums per path
+    get_p_obs_base.cpp:3-69       epsilon per base, the per-region mutation rate (its integer divisions kept)
+    miscfunc.h:180-216            get_p_seq_error, get_qscore_vec
+    haplocart_functions.cpp:81-107 background frequencies, incorrect_mapping_vec
+    HaploCart.cpp:408-424         the accumulate over reads (identity < 1e-10 skipped), argmax
+    get_posterior.cpp:36-127      clade posteriors (libgab's oplusInitnatl restated from its published behaviour)
+    load.cpp:6-58,283-345         mappability.tsv, parsed_pangenome_mapping (+1), graph_paths, path_supports, parents / children
+
+Third-party pieces that are not in the reference tree (vg: path_string, edit_is_match / _sub / _insertion / _deletion,
+get_sequence of a reversed handle; libgab: oplusInitnatl, isValidDNA) are restated from their published semantics; the
+reconstruction is pinned on the reference's own 10 known-answer cases (tests/golden/reconstruct/expected.json, src/test.cpp:855-994)
+by `--check-kats`.
+
+Where the reference is undefined the run stops being a restatement; this script does NOT guess: a read that indexes a string
+past its end inside substr / insert, names an unknown node, has more mappings than edits or a mapping quality >= 100 is
+reported in "undefined_reads" and left out (the product counts the same reads as n_bad / clamps them).  ONE definition is
+shared with the build because every multi-mapping read needs it (include/vgan_gpu.h): a quality index at or past
+the end of the quality string reads as 0.  The out-of-bounds parent_vec[j-1] at j = 0 (get_posterior.cpp:110,117) is read as
+"different" (SURVEY Q9).
+
+Usage (in the build container; the GPU box only loads the JSON):
+    python tools/pyref_hc.py --make tests/golden/hc_pyref        # writes the inputs (GFA, sidecars, GAM) and hc_pyref.json
+    python tools/pyref_hc.py --run DIR [--out FILE]              # recomputes the JSON from the files in DIR
+    python tools/pyref_hc.py --check-kats                        # the reconstruction against the reference's KATs
+"""
+import argparse
+import gzip
+import json
+import os
+import sys
+
+import mpmath as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import gamio  # noqa: E402  (the test-side GAM decoder / encoder: no product code)
+
+mp.mp.dps = 40
+
+
+class Undefined(Exception):
+    """The reference's behaviour on this read is undefined (out-of-range access, uncaught throw in a noexcept function)."""
+
+
+# ----------------------------------------------------------------------------------------------------------------- inputs
+def _open(path):
+    if os.path.exists(path):
+        return open(path, "rt")
+    if os.path.exists(path + ".gz"):
+        return gzip.open(path + ".gz", "rt")
+    raise FileNotFoundError(path)
+
+
+def load_gfa(path):
+    seqs = {}
+    for ln in open(path):
+        t = ln.rstrip("\n").split("\t")
+        if t and t[0] == "S":
+            seqs[int(t[1])] = t[2]
+    return seqs
+
+
+def load_hcfiles(d):
+    """load.cpp:6-58,283-345"""
+    mappabilities = []
+    for ln in _open(os.path.join(d, "mappability.tsv")):
+        t = ln.split()
+        if len(t) < 4:
+            continue
+        for _ in range(int(t[1]), int(t[2])):  # load.cpp:18-20
+            mappabilities.append(float(t[3]))
+    pangenome_map = {}
+    for ln in _open(os.path.join(d, "parsed_pangenome_mapping")):
+        t = ln.split()
+        if len(t) >= 2 and t[0] not in pangenome_map:  # map::insert keeps the first
+            pangenome_map[t[0]] = int(t[1]) + 1  # load.cpp:37
+    path_names = [ln.split()[0] for ln in _open(os.path.join(d, "graph_paths")) if ln.split()]  # whole first token
+    supports = []
+    for ln in _open(os.path.join(d, "path_supports")):
+        supports.append([c == "1" for c in ln.rstrip("\n")])  # row index = line number = node id (load.cpp:283-300)
+
+    def relatives(name):
+        rel = {}
+        for ln in _open(os.path.join(d, name)):
+            t = ln.split()
+            if not t:
+                continue
+            if t[0] not in rel:
+                rel[t[0]] = [x for x in t[1:] if "[" not in x]
+        return rel
+    return {"mappabilities": mappabilities, "pangenome_map": pangenome_map, "path_names": path_names, "supports": supports,
+            "parents": relatives("parents.txt"), "children": relatives("children.txt")}
+
+
+# -------------------------------------------------------------------------------------- vg / libgab semantics (published)
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+
+
+def node_sequence(seqs, node_id, is_reverse):
+    """bdsg::ODGI::get_sequence(get_handle(id, is_reverse)): the reverse complement on the reverse strand."""
+    if node_id not in seqs:
+        raise Undefined("unknown node %d" % node_id)
+    s = seqs[node_id]
+    return "".join(_COMP.get(c, c) for c in reversed(s)) if is_reverse else s
+
+
+def edit_is_match(e):
+    return e["from_length"] == e["to_length"] and len(e["sequence"]) == 0
+
+
+def edit_is_sub(e):
+    return e["from_length"] == e["to_length"] and len(e["sequence"]) > 0
+
+
+def edit_is_insertion(e):
+    return e["from_length"] == 0 and e["to_length"] > 0 and len(e["sequence"]) > 0
+
+
+def edit_is_deletion(e):
+    return e["from_length"] > 0 and e["to_length"] == 0
+
+
+def path_string(seqs, path):
+    """vg::algorithms::path_string: the sequence the path spells -- graph bases under matches, the edit's own sequence otherwise."""
+    out = []
+    for m in path["mapping"]:
+        pos = m["position"]
+        ns = node_sequence(seqs, pos["node_id"], pos["is_reverse"])
+        off = pos["offset"]
+        for e in m["edit"]:
+            if edit_is_match(e):
+                out.append(ns[off:off + e["from_length"]])
+            else:
+                out.append(e["sequence"].decode())
+            off += e["from_length"]
+    return "".join(out)
+
+
+def is_valid_dna(c):  # libgab
+    return c in "ACGT"
+
+
+def oplus_init(x, y):
+    """libgab oplusInitnatl: log(exp(x) + exp(y)), with a running value of exactly 0 standing for "nothing yet"."""
+    if x == 0:
+        return y
+    big, small = (x, y) if x > y else (y, x)
+    return big + mp.log1p(mp.exp(small - big))
+
+
+# ------------------------------------------------------------------------------------------------- vgan_utils.h:6-79
+def substr(s, pos, n):
+    if pos > len(s):
+        raise Undefined("substr: pos %d beyond a string of %d" % (pos, len(s)))  # std::out_of_range inside noexcept
+    return s[pos:pos + n]
+
+
+def reconstruct_graph_sequence(seqs, path):
+    graph_seq = ""
+    mppg_sizes = []
+    mppg_counter = 0  # :12, never incremented
+    ps = path_string(seqs, path)  # :18
+    mppgs = path["mapping"]
+    f = 0
+    for mppg in mppgs:
+        pos = mppg["position"]
+        node_seq = node_sequence(seqs, pos["node_id"], pos["is_reverse"])  # :24
+        aligned_length = 0  # :26
+        ed = mppg["edit"]
+        edit_counter = 0  # :28, never incremented
+        offset = pos["offset"]
+        for edit in ed:
+            to_length, from_length = edit["to_length"], edit["from_length"]
+            softclip = ((mppg_counter == 0 and offset == 0 and edit_counter == 0 and from_length == 0 and to_length > 0 and edit_is_insertion(edit)) or
+                        (mppg_counter == len(mppgs) - 1 and offset == 0 and edit_counter == len(ed) and from_length == 0 and to_length > 0 and
+                         edit_is_insertion(edit)))  # :38-39
+            if edit_is_match(edit) or edit_is_sub(edit):  # :41-47
+                piece = substr(node_seq, offset, from_length)
+                graph_seq += piece
+                aligned_length = len(piece)
+            elif edit_is_insertion(edit):  # :49-64
+                graph_seq += ("S" if softclip else "-") * to_length
+                aligned_length = to_length
+            elif edit_is_deletion(edit):  # :66-70
+                piece = substr(node_seq, offset, from_length)
+                graph_seq += piece
+                aligned_length = len(piece)
+                if f > len(ps):
+                    raise Undefined("insert: index %d beyond a string of %d" % (f, len(ps)))
+                ps = ps[:f] + "-" * from_length + ps[f:]
+            offset += from_length  # :71
+            f += from_length
+            mppg_sizes.append(aligned_length)  # :74: one entry per EDIT
+    return graph_seq, ps, mppg_sizes
+
+
+# ------------------------------------------------------------------------------------------ tables (miscfunc.h, haplocart_functions.cpp)
+def get_p_seq_error(Q):  # miscfunc.h:180-188; pow(10, (-1 * Q) * 0.1) with the exponent formed in double
+    return mp.mpf(10) ** mp.mpf(float((-1 * Q) * 0.1)) if Q > 2 else mp.mpf("0.25")
+
+
+# miscfunc.h:199-212: Q >= 2 takes get_p_seq_error (which answers 0.25 up to 2), the others 0.25
+QSCORE_VEC = [get_p_seq_error(Q) if Q >= 2 else mp.mpf("0.25") for Q in range(100)]
+# the tables are vector<double>: every entry is rounded to double when stored
+QSCORE_VEC = [mp.mpf(float(x)) for x in QSCORE_VEC]
+INCORRECT_MAPPING_VEC = [mp.mpf(float(mp.mpf(10) ** mp.mpf(float((-1 * Q) * 0.1)))) for Q in range(100)]  # haplocart_functions.cpp:101-107
+BACKGROUND = {"A": mp.mpf(0.27532), "C": mp.mpf(0.30044), "G": mp.mpf(0.16644), "T": mp.mpf(0.25780)}  # :81-98 (doubles)
+
+
+def get_background_freq(c):
+    return BACKGROUND.get(c, mp.mpf(0.25))
+
+
+def _in(lo, hi, x):
+    return lo <= x <= hi
+
+
+def get_p_obs_base(pangenome_base, epsilon, generations=8):
+    """get_p_obs_base.cpp:38-69.  (22/23), (1/46), (2/3) and (1/3) are integer divisions in the reference: 0."""
+    b = pangenome_base & 0xFFFFFFFF  # inRange takes unsigned
+    if _in(57, 372, b):
+        mu = 1.64273e-7
+    elif _in(1, 56, b) or _in(373, 576, b):
+        mu = 2.29640e-8
+    elif _in(16384, 16569, b):
+        mu = 1.54555e-8
+    elif (_in(3307, 4262, b) or _in(4470, 5511, b) or _in(5904, 7445, b) or _in(7586, 8269, b) or _in(8366, 9990, b) or _in(10059, 10403, b) or
+          _in(10470, 12137, b) or _in(12337, 14673, b) or _in(14747, 15886, b)):
+        mu = 8.87640e-9 * (2 // 3) * 1.92596e-8 * (1 // 3)
+    elif (_in(577, 647, b) or _in(1602, 1670, b) or _in(3230, 3304, b) or _in(4263, 4400, b) or _in(4402, 4469, b) or _in(5512, 5579, b) or
+          _in(5587, 5654, b) or _in(5657, 5728, b) or _in(5761, 5891, b) or _in(7446, 7514, b) or _in(7518, 7585, b) or _in(8295, 8364, b) or
+          _in(15888, 15953, b) or _in(15956, 16023, b)):
+        mu = 6.91285e-9
+    elif _in(648, 1601, b) or _in(1671, 3229, b):
+        mu = 6.91285e-9
+    else:
+        mu = 2.48537e-8
+    mu *= 30  # a double
+    # const double match = pow(1 - mu, generations): evaluated exactly, then rounded to the double the reference holds
+    match = mp.mpf(float(mp.mpf(1 - mu) ** generations))
+    tv = (1 - match) * (22 // 23)
+    ts = (1 - match) * (1 // 46)
+    return match * (1 - epsilon) + epsilon * (2 * tv + ts)  # long double in the reference
+
+
+# ------------------------------------------------------------------------------------- update_likelihood.cpp / process_mapping.cpp
+def signed_char(b):
+    return b - 256 if b >= 128 else b
+
+
+def read_loglik(seqs, hc, aln, background_error_prob, use_background_error_prob, is_consensus_fasta):
+    """Haplocart::update for one read: the vector over paths (mpf).  Raises Undefined where the reference does not define one."""
+    n_paths = len(hc["path_names"])
+    path = aln["path"]
+    graph_full, algnseq, mppg_sizes = reconstruct_graph_sequence(seqs, path)
+    quality = aln["quality"]
+    mapq = aln["mapping_quality"]
+    if mapq >= 100 or mapq < 0:
+        raise Undefined("mapping quality %d indexes incorrect_mapping_vec out of range" % mapq)
+    ll = [mp.mpf(0)] * n_paths
+    position_in_read = 0
+    use_bep = use_background_error_prob  # a by-value parameter of update_likelihood, sticky across the read's mappings (:42)
+    for i, mppg in enumerate(path["mapping"]):
+        if i >= len(mppg_sizes):
+            raise Undefined("mapping %d has no entry in mppg_sizes (%d edits)" % (i, len(mppg_sizes)))
+        graph_seq = substr(graph_full, position_in_read, mppg_sizes[i])  # :36
+        read_seq = substr(algnseq, position_in_read, mppg_sizes[i])      # :37
+        quality_scores = []
+        for j in range(position_in_read, position_in_read + len(algnseq)):  # :40-44
+            q = signed_char(quality[j]) if j < len(quality) else 0  # past the end: 0 (the build's definition)
+            if q >= 90:
+                use_bep = True
+            quality_scores.append(q)
+        position_in_read += len(read_seq)  # :45
+        # ---- process_mapping (:46): mapping_seq is the WHOLE algnseq
+        mapping_seq = algnseq
+        node_id = mppg["position"]["node_id"]
+        key = str(node_id)
+        if key not in hc["pangenome_map"]:
+            raise Undefined("node %d is not in parsed_pangenome_mapping (map::at throws)" % node_id)
+        pangenome_base = hc["pangenome_map"][key]
+        if not (0 <= pangenome_base < len(hc["mappabilities"])):
+            raise Undefined("mappabilities[%d] is out of range" % pangenome_base)
+        mappability = mp.mpf(hc["mappabilities"][pangenome_base])
+        p_correctly_mapped = (1 - INCORRECT_MAPPING_VEC[mapq]) * mappability  # :41 (long double)
+        # get_p_no_seq_error_mapping (get_p_obs_base.cpp:3-27)
+        p_no_seq_error = []
+        for k in range(len(graph_seq)):
+            if k >= len(mapping_seq):
+                raise Undefined("mapping_seq[%d] beyond its end" % k)
+            same = graph_seq[k] == mapping_seq[k]
+            if use_bep:
+                p_no_seq_error.append(mp.mpf(background_error_prob) if same else 1 - mp.mpf(background_error_prob))
+            else:
+                q = quality_scores[k] if k < len(quality_scores) else None
+                if q is None or not (0 <= q < 100):
+                    raise Undefined("qscore_vec[%r] is out of range" % (q,))
+                p_no_seq_error.append(QSCORE_VEC[q] if same else 1 - QSCORE_VEC[q])
+        # supported paths (:57-80)
+        log_lik_if_mapped = mp.mpf(0)
+        for j in range(len(graph_seq)):
+            g, r = graph_seq[j], mapping_seq[j]
+            if g == "N" or r == "N":
+                continue
+            if not is_valid_dna(g) or not is_valid_dna(r):
+                continue
+            p_obs_base = get_p_obs_base(pangenome_base, p_no_seq_error[j], 8)
+            if not is_consensus_fasta:
+                x = (1 - p_correctly_mapped) * get_background_freq(r) + p_correctly_mapped * p_obs_base
+            else:
+                x = (1 - mp.mpf(background_error_prob)) * p_obs_base
+            log_lik_if_mapped += mp.log(x) if x > 0 else mp.mpf("-inf")
+        # unsupported paths: get_log_lik_if_unsupported (:4-24) -- `counter % 4 == 4` never holds, every entry is a "mismatch"
+        log_lik_if_unsupported = mp.mpf(0)
+        for Q in quality_scores:
+            log_lik_if_unsupported += mp.log(get_p_seq_error(Q))
+        row = node_id  # nodevector.at(node_id - minid)->pathsgo: path_supports row = node id (load.cpp:283-300)
+        if not (0 <= row < len(hc["supports"])):
+            raise Undefined("node %d has no path_supports row" % node_id)
+        sup = hc["supports"][row]
+        ll = [ll[p] + (log_lik_if_mapped if (p < len(sup) and sup[p]) else log_lik_if_unsupported) for p in range(n_paths)]
+    return ll
+
+
+def get_posterior(final_vec, hc, predicted):
+    """get_posterior.cpp:87-127 with get_posterior_of_clade :51-76 and get_children :36-49."""
+    path_names, parents, children = hc["path_names"], hc["parents"], hc["children"]
+
+    def sum_ll(v):
+        ret = v[0]
+        for x in v[1:]:
+            ret = oplus_init(ret, x)
+        return ret
+
+    def get_children(preds):
+        out = set()
+        for p in preds:
+            out.update(children.get(p, []))  # (find()->second on a missing key is undefined: read as "no children")
+        return out
+
+    def clade(all_top, preds, depth=0):
+        if depth > 10000:
+            raise Undefined("children.txt does not end (cycle)")
+        child_set = get_children(preds)
+        for idx, name in enumerate(path_names):
+            if name in child_set:
+                all_top.append(final_vec[idx])
+        if child_set:
+            clade(all_top, child_set, depth + 1)
+        return all_top
+    total = sum_ll(final_vec)
+    parent_vec = parents.get(predicted, [])
+    clades = [predicted]
+    conf = [mp.exp(sum_ll([final_vec[path_names.index(predicted)]]) - total)]
+    for j, par in enumerate(parent_vec):
+        differs = j == 0 or parent_vec[j] != parent_vec[j - 1]  # (j = 0 reads parent_vec[-1]: taken as "different")
+        all_top = clade([], {par})
+        if differs:
+            clades.append(par)
+            conf.append(mp.exp(sum_ll(all_top) - total) if all_top else mp.exp(mp.mpf(0) - total))  # (an empty sum: the build's 0)
+    return clades, conf
+
+
+def run(d, background_error_prob=0.0001, use_background_error_prob=False, is_consensus_fasta=False):
+    seqs = load_gfa(os.path.join(d, "graph.gfa"))
+    hc = load_hcfiles(d)
+    alns = gamio.read_gam(os.path.join(d, "reads.gam"))
+    n_paths = len(hc["path_names"])
+    final_vec = [mp.mpf(0)] * n_paths
+    undefined, used, per_read = [], 0, []
+    for r, a in enumerate(alns):
+        if a["identity"] < 1e-10:  # HaploCart.cpp:410
+            continue
+        try:
+            ll = read_loglik(seqs, hc, a, background_error_prob, use_background_error_prob, is_consensus_fasta)
+        except Undefined as e:
+            undefined.append({"read": r, "why": str(e)})
+            continue
+        used += 1
+        final_vec = [x + y for x, y in zip(final_vec, ll)]
+        if len(per_read) < 12:
+            per_read.append({"read": r, "loglik": [mp.nstr(x, 25) for x in ll]})
+    best = max(range(n_paths), key=lambda p: (final_vec[p], -p))  # std::max_element: the first maximum
+    clades, conf = get_posterior(final_vec, hc, hc["path_names"][best])
+    return {"n_alignments": len(alns), "n_used": used, "undefined_reads": undefined,
+            "params": {"background_error_prob": background_error_prob, "use_background_error_prob": use_background_error_prob,
+                       "is_consensus_fasta": is_consensus_fasta},
+            "final_vec": [mp.nstr(x, 25) for x in final_vec], "predicted": hc["path_names"][best],
+            "posterior": [{"clade": c, "confidence": mp.nstr(v, 25)} for c, v in zip(clades, conf)],
+            "first_reads": per_read}
+
+
+# ---------------------------------------------------------------------------------------------------------- fixture writer
+def make(d):
+    """Inputs from the product's synthetic generator (host code, no GPU), then edited through the test-side GAM codec so that the
+    cases the generator does not draw are there too: qualities >= 90 and >= 128, mapping quality 0, a short quality string."""
+    from vgan_amd import haplocart as hc
+    os.makedirs(d, exist_ok=True)
+    g = hc.synth_graph(seed=77, genome_len=700, n_nodes=300, n_paths=64)
+    g.write(d)
+    if os.path.exists(os.path.join(d, "path_supports.gz")):  # committed as plain text
+        txt = gzip.open(os.path.join(d, "path_supports.gz"), "rt").read()
+        open(os.path.join(d, "path_supports"), "w").write(txt)
+        os.remove(os.path.join(d, "path_supports.gz"))
+    a = hc.synth_reads(g, 240, seed=78, read_len=120, indel_rate=0.15, softclip_rate=0.1, low_mapq_rate=0.3)
+    tmp = os.path.join(d, "reads.gam")
+    a.write_gam(tmp)
+    alns = gamio.read_gam(tmp)
+    for r, al in enumerate(alns):
+        q = bytearray(al["quality"])
+        if r % 23 == 5 and len(q) > 40:
+            q[37] = 93  # the sticky switch, mid read
+        if r % 31 == 7 and len(q) > 10:
+            q[3] = 200  # a negative quality (signed char)
+        if r % 41 == 11:
+            q = q[:max(0, len(q) - 9)]  # a quality string shorter than the read
+        al["quality"] = bytes(q)
+        if r % 17 == 3:
+            al["mapping_quality"] = 0
+    open(tmp, "wb").write(gamio.write_gam(alns, group=64))
+    out = {"_what": "tools/pyref_hc.py: an independent Python + mpmath (40 digits) restatement of HaploCart's likelihood path on the "
+                    "inputs beside this file; NOT generated by oracle/ or by the product",
+           "default": run(d), "background": run(d, background_error_prob=0.02, use_background_error_prob=True)}
+    json.dump(out, open(os.path.join(d, "hc_pyref.json"), "w"), indent=0)
+    print("wrote", d, "used", out["default"]["n_used"], "undefined", len(out["default"]["undefined_reads"]))
+
+
+def check_kats():
+    d = os.path.join(ROOT, "tests", "golden", "reconstruct")
+    seqs = load_gfa(os.path.join(d, "target_graph.gfa"))
+    alns = gamio.read_gam(os.path.join(d, "test_reads.gam"))
+    exp = json.load(open(os.path.join(d, "expected.json")))["cases"]
+    for c in exp:
+        gs, ps, sizes = reconstruct_graph_sequence(seqs, alns[c["read"]]["path"])
+        assert gs == c["graph_seq"] and ps == c["read_seq"], (c["name"], gs, ps)
+        if "mppg_sizes" in c:
+            assert sizes == c["mppg_sizes"], (c["name"], sizes)
+    print("reconstruction: %d of the reference's known-answer cases reproduced" % len(exp))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--make")
+    ap.add_argument("--run")
+    ap.add_argument("--out")
+    ap.add_argument("--check-kats", action="store_true")
+    args = ap.parse_args()
+    if args.check_kats:
+        check_kats()
+    if args.make:
+        make(args.make)
+    if args.run:
+        res = run(args.run)
+        txt = json.dumps(res, indent=0)
+        open(args.out, "w").write(txt) if args.out else print(txt[:2000])
