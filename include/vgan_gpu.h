@@ -148,6 +148,12 @@ typedef struct vgan_gam_stream vgan_gam_stream;
 int vgan_gam_stream_open(const char *path, int keep_unmapped, vgan_gam_stream **out);
 int vgan_gam_stream_next(vgan_gam_stream *s, int64_t min_reads, vgan_alnparts **out);
 void vgan_gam_stream_close(vgan_gam_stream *s);
+/* The processors the host front end sizes its thread pools from: the smaller of the affinity mask and the cgroup CPU quota. */
+int vgan_host_cpus(void);
+/* Diagnostics of the BGZF decode pipeline, summed over the process: out[0] segments decoded, out[1] segments whose own
+ * framing was taken from the group it started in, out[2] from a later group, out[3] framed by the serial walk alone,
+ * out[4] messages joined in a buffer of their own (longer than a segment buffer's headroom). */
+void vgan_gam_decode_counts(int64_t out[5]);
 int64_t vgan_alnparts_base(const vgan_alnparts *p);
 /* keep-first duplicate marking across chunks (the state holds the keys seen so far; rmdup.cpp:68-110 semantics) */
 typedef struct vgan_dedup vgan_dedup;

@@ -12,12 +12,14 @@ def test_host_sources_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "host_san")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vgan_amd/csrc"),
-           os.path.join(ROOT, "tests/native/host_sanitizer_driver.cpp")] + srcs + ["-o", exe, "-lz", "-lpthread"]
+           os.path.join(ROOT, "tests/native/host_sanitizer_driver.cpp")] + srcs + ["-o", exe, "-lz", "-lpthread", "-ldl"]
     subprocess.check_call(cmd)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    r = subprocess.run([exe, os.path.join(ROOT, "tests/golden"), str(tmp_path)], capture_output=True, text=True, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "host sanitizer driver: ok" in r.stdout
+    # once with the decoder's own segment size, once with segments of two BGZF blocks (groups and messages across every boundary)
+    for extra in ({}, {"VGAN_GAM_SEG_BLOCKS": "2", "VGAN_GAM_THREADS": "5"}):
+        r = subprocess.run([exe, os.path.join(ROOT, "tests/golden"), str(tmp_path)], capture_output=True, text=True, env=dict(env, **extra))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert "host sanitizer driver: ok" in r.stdout
 
 
 def test_host_sources_under_tsan(tmp_path):
@@ -28,11 +30,12 @@ def test_host_sources_under_tsan(tmp_path):
     exe = str(tmp_path / "host_tsan")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vgan_amd/csrc"),
-           os.path.join(ROOT, "tests/native/host_sanitizer_driver.cpp")] + srcs + ["-o", exe, "-lz", "-lpthread"]
+           os.path.join(ROOT, "tests/native/host_sanitizer_driver.cpp")] + srcs + ["-o", exe, "-lz", "-lpthread", "-ldl"]
     subprocess.check_call(cmd)
     out = tmp_path / "o"
     out.mkdir()
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
-    r = subprocess.run([exe, os.path.join(ROOT, "tests/golden"), str(out), "40000"], capture_output=True, text=True, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
-    assert "host sanitizer driver: ok" in r.stdout and "ThreadSanitizer" not in r.stderr
+    for extra in ({}, {"VGAN_GAM_SEG_BLOCKS": "2", "VGAN_GAM_THREADS": "6"}):
+        r = subprocess.run([exe, os.path.join(ROOT, "tests/golden"), str(out), "40000"], capture_output=True, text=True, env=dict(env, **extra))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+        assert "host sanitizer driver: ok" in r.stdout and "ThreadSanitizer" not in r.stderr

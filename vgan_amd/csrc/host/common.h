@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <new>
+#include <functional>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -101,6 +102,14 @@ struct MappedFile {
     bool open_path(const std::string &path);
 };
 
+// BGZF (SAM spec 4.1): the members of a buffer with their places in the inflated stream; false when the buffer is anything
+// else.  inflate_member: one gzip member into exactly out_size bytes.
+struct BgzfBlock {
+    size_t in_off, in_size, out_off, out_size;
+};
+bool bgzf_index(const unsigned char *p, size_t n, std::vector<BgzfBlock> &blocks);
+bool inflate_member(const unsigned char *in, size_t in_size, unsigned char *out, size_t out_size);
+
 // Block-parallel BGZF inflate that hands out the prefix inflated so far: the consumer (GAM framing) starts while later
 // blocks are still being inflated (util.cpp).  start() returns false for anything that is not a BGZF stream.
 struct AsyncInflate {
@@ -117,6 +126,21 @@ struct AsyncInflate {
     struct Impl;
     Impl *impl;
 };
+
+// The processors this process may keep busy: the smaller of its affinity mask and its cgroup's CPU quota (cpu.max; a
+// container given 16 CPUs of a 256-thread host is throttled for the rest of every 100 ms period once a hundred threads have
+// spent the quota in the first 15 ms of it -- the stages then stall in turn, and the work per read, not the thread count, is
+// what the throughput follows).  Thread pools are sized from this, not from hardware_concurrency().
+unsigned usable_cpus();
+// For a job that ends within a period or two of the quota (a few hundred thousand reads): up to four times as many, the
+// unspent quota of the idle time before it is what such a burst runs on.
+unsigned burst_cpus();
+
+// fn(0..n-1) on n threads: the caller runs fn(0), the others come from a pool of persistent workers (util.cpp).  A thread
+// that is created and destroyed maps and unmaps its stack -- write locks on the address space, which every page fault of
+// every other thread waits behind: the chunk loop's ~80 short-lived threads per 65k reads capped the flatten stage at 2 M reads/s
+// whatever ran beside it.  Calls may come from several threads at once.
+void parallel_run(int n, const std::function<void(int)> &fn);
 
 // Phase timing of the host front end to stderr when VGAN_TIMING is set in the environment (developer aid).
 struct PhaseTimer {

@@ -278,7 +278,7 @@ extern "C" int vgan_euka_flatten(const vgan_graph *g, const vgan_alnset *a, int6
                                  vgan_euka_host_batch **out, vgan_euka_flatten_stats *stats) {
     if (!g || !a || !out) return fail(VGAN_EINVAL, "vgan_euka_flatten: null argument");
     if (r0 < 0 || r1 > a->n_reads() || r0 > r1) return fail(VGAN_EINVAL, "vgan_euka_flatten: bad read range");
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = (int)usable_cpus();
     const int64_t n = r1 - r0;
     n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (n + 4095) / 4096));
     std::vector<EChunk> chunks((size_t)n_threads);

@@ -329,7 +329,7 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
         res->read_col_off[o + 1] = res->read_col_off[o] + (cb.read_col_off[j + 1] - cb.read_col_off[j]);
         res->read_qual_off[o + 1] = res->read_qual_off[o] + (cb.read_qual_off[j + 1] - cb.read_qual_off[j]);
     }
-    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t hw = nt_reads <= 300000 ? burst_cpus() : usable_cpus();
     // ---- the sorted reads' data, by output range
     auto copy_sorted = [&](size_t o0, size_t o1) {
         for (size_t o = o0; o < o1; ++o) {
@@ -381,13 +381,11 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
             copy_sorted(0, nt_reads);
             for (size_t i = 0; i < nc; ++i) copy_gen(i);
         } else {
-            std::vector<std::thread> cth;
-            for (size_t t = 0; t < nth; ++t)
-                cth.emplace_back([&, t] {
-                    copy_sorted(nt_reads * t / nth, nt_reads * (t + 1) / nth);
-                    for (size_t i = t; i < nc; i += nth) copy_gen(i);
-                });
-            for (auto &t : cth) t.join();
+            parallel_run((int)nth, [&](int ti) {
+                const size_t t = (size_t)ti;
+                copy_sorted(nt_reads * t / nth, nt_reads * (t + 1) / nth);
+                for (size_t i = t; i < nc; i += nth) copy_gen(i);
+            });
         }
     }
     for (auto &c : chunks) {
@@ -416,7 +414,7 @@ extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a,
                                       int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
     if (!g || !a || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten: null argument");
     if (r0 < 0 || r1 > a->n_reads() || r0 > r1) return fail(VGAN_EINVAL, "vgan_hc_flatten: bad read range");
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = (int)(r1 - r0 <= 300000 ? burst_cpus() : usable_cpus());
     const int64_t n = r1 - r0;
     // every chunk allocates a dozen arrays of a few hundred KB (one mmap each in glibc) and faults them in: beyond ~32
     // threads the address-space lock, not the cores, sets the pace (1M reads on 256 cores: 8 threads 0.34 s, 32: 0.08 s,
@@ -441,7 +439,7 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
     if (!g || !ps || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: null argument");
     if (part0 < 0 || part1 > (int64_t)ps->parts.size() || part0 > part1) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: bad slice range");
     if (ps->base + ps->first.back() > 0xFFFFFFF0ll) return fail(VGAN_ERANGE, "vgan_hc_flatten_parts: more than 2^32 reads");
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = (int)usable_cpus();
     // Work items: sub-ranges of the slices (a slice is 8192 reads: with one item per slice a chunk of 32 slices keeps 32 threads
     // busy for one slice's time each, whatever the machine)
     constexpr int64_t SUB = 2048;
@@ -469,13 +467,7 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
             flatten_range(*g, a, it.r0, it.r1, skip ? skip + ps->first[it.part] : nullptr, ps->base + ps->first[it.part], chunks[i]);
         }
     };
-    if (n_threads == 1) {
-        work();
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_threads; ++t) th.emplace_back(work);
-        for (auto &t : th) t.join();
-    }
+    parallel_run(n_threads, [&](int) { work(); });
     pt.lap("chunks");
     return merge_chunks(chunks, pt, out, stats);
 }

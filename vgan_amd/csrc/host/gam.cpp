@@ -10,6 +10,7 @@
 #include <deque>
 #include <mutex>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -287,30 +288,565 @@ void vgan::merge_alnsets(std::vector<vgan_alnset> &parts, vgan_alnset &o) {
         cp(o.e_seq, bs.eseq, p.e_seq);
         p = vgan_alnset();
     };
-    const size_t nt = std::min<size_t>(parts.size(), std::max(1u, std::thread::hardware_concurrency()));
+    const size_t nt = std::min<size_t>(parts.size(), burst_cpus());
     if (nt <= 1) {
         for (size_t i = 0; i < parts.size(); ++i) copy_part(i);
     } else {
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; ++t)
-            th.emplace_back([&, t] {
-                for (size_t i = t; i < parts.size(); i += nt) copy_part(i);
-            });
-        for (auto &t : th) t.join();
+        parallel_run((int)nt, [&](int t) {
+            for (size_t i = (size_t)t; i < parts.size(); i += nt) copy_part(i);
+        });
     }
 }
 
-// GAM bytes -> slices of ~SLICE reads in input order, as a pipeline that runs behind the caller: block-parallel
-// inflate (BGZF) hands its finished prefix to the serial framing pass, which hands slices of messages to the wire
-// parser pool; take() returns the next parsed slices as soon as they exist.
+// ---- BGZF input (what vg writes): the segment pipeline ---------------------------------------------------------------
+// The compressed file is cut into segments of a few dozen BGZF blocks.  A pool of workers takes them in file order; each
+// inflates its segment into a recycled buffer, FRAMES it speculatively (a walk from the first group header it can
+// recognise: the item "GAM" that opens every group vg writes) and parses the messages it framed.  One serial thread, the
+// stitcher, carries the true state of the framing across the segments: it walks from where the previous segment ended
+// until it stands on a group header the segment's own walk started from or passed -- from there on the two walks are the
+// same deterministic function of the same bytes, so the segment's result is taken whole -- and hands the few messages it
+// framed itself (half a group per segment, and the message that straddles the boundary, which it joins in the headroom in
+// front of the next buffer) to the pool.  A stream without tags, or a walk that never meets the true one, is framed by the
+// stitcher alone and still parsed by the pool: the result is the serial walk's in every case.
+// Memory is bounded: the buffers form a ring (a segment's buffer returns when its messages are parsed and the stitcher
+// has passed it), and no segment is started more than `ahead` segments beyond the last one the caller has taken.
+namespace {
+
+std::atomic<int64_t> g_decode_counts[5];
+
+struct WalkState {
+    bool in_group = false; // false: a group header (the item count) comes next
+    bool first = false;    // the next item is the first of its group: it may be the type tag
+    uint64_t rem = 0;      // items left in the group
+};
+
+// 1: read, q is past it; 0: the bytes end inside it; -1: longer than ten bytes
+inline int get_varint(const uint8_t *p, const uint8_t *e, uint64_t &v, const uint8_t *&q) {
+    v = 0;
+    for (int shift = 0; shift <= 63; shift += 7) {
+        if (p >= e) return 0;
+        const uint8_t b = *p++;
+        v |= (uint64_t)(b & 0x7f) << shift;
+        if (!(b & 0x80)) {
+            q = p;
+            return 1;
+        }
+    }
+    return -1;
+}
+
+enum { WALK_MORE = 0, WALK_BAD = -1, WALK_STOP = 1 };
+
+// The framing of readGAM's stream (libvgio's groups: {count, count x (length, bytes)}, the first item of a group possibly
+// the tag "GAM") from state st at p, over [p, e).  WALK_MORE: the item at p does not end inside the bytes (need = its size
+// when the length could be read, else 0); WALK_BAD: a malformed varint at p; WALK_STOP: at_header(p) said so.
+template <class Emit, class AtHeader>
+int walk(WalkState &st, const uint8_t *&p, const uint8_t *e, uint64_t &need, Emit &&emit, AtHeader &&at_header) {
+    need = 0;
+    for (;;) {
+        uint64_t v;
+        const uint8_t *q;
+        if (!st.in_group) {
+            if (at_header(p)) return WALK_STOP;
+            const int r = get_varint(p, e, v, q);
+            if (r <= 0) return r;
+            st.rem = v;
+            st.first = true;
+            st.in_group = v != 0;
+            p = q;
+            continue;
+        }
+        const int r = get_varint(p, e, v, q);
+        if (r <= 0) return r;
+        if (v > (uint64_t)(e - q)) {
+            need = v > UINT64_MAX - 16 ? UINT64_MAX : v + (uint64_t)(q - p);
+            return WALK_MORE;
+        }
+        if (!(st.first && v == 3 && memcmp(q, "GAM", 3) == 0)) emit(q, q + v);
+        st.first = false;
+        p = q + v;
+        if (--st.rem == 0) st.in_group = false;
+    }
+}
+
+void reserve_for(vgan_alnset &a, size_t nbytes, size_t nr) { // ~1 mapping per 20 bytes, ~1 edit per 16
+    a.seq_off.reserve(nr + 1);
+    a.qual_off.reserve(nr + 1);
+    a.name_off.reserve(nr + 1);
+    a.map_off.reserve(nr + 1);
+    a.mapq.reserve(nr);
+    a.identity.reserve(nr);
+    a.seq.reserve(nbytes / 6);
+    a.qual.reserve(nbytes / 6);
+    a.name.reserve(nr * 16);
+    a.m_node.reserve(nbytes / 18);
+    a.m_offset.reserve(nbytes / 18);
+    a.m_rev.reserve(nbytes / 18);
+    a.edit_off.reserve(nbytes / 18);
+    a.e_from.reserve(nbytes / 14);
+    a.e_to.reserve(nbytes / 14);
+    a.e_seq_off.reserve(nbytes / 14);
+}
+
+struct SegPipe {
+    using Msg = std::pair<const uint8_t *, const uint8_t *>;
+    struct Hdr {
+        uint32_t off, msg; // a group header the segment's walk stood on: its offset, and the messages framed before it
+    };
+    struct Seg {
+        size_t b0 = 0, b1 = 0, out_off = 0, size = 0;
+        uint8_t *buf = nullptr; // data at buf + head; the bytes before it take the tail of the previous segment
+        size_t cap = 0, head = 0;
+        bool special = false; // a buffer of its own (a message larger than the headroom)
+        std::atomic<int> refs{0};
+        bool ready = false; // under mu
+        bool inflate_ok = true;
+        bool anchored = false, closed = false; // closed: the walk saw the end of the group it started in
+        size_t anchor_tag = 0;
+        uint32_t n_first = 0;
+        std::vector<Hdr> hdrs;
+        std::vector<std::pair<uint32_t, uint32_t>> msgs; // (offset, length) of the framed messages
+        WalkState end;
+        size_t end_off = 0;
+        vgan_alnset parsed;
+        bool parse_ok = true;
+        uint8_t *data() const { return buf + head; }
+    };
+    struct Entry { // what take() hands out, in input order
+        vgan_alnset a;
+        std::vector<Msg> msgs; // to be parsed by the pool (empty: `a` came parsed with its segment)
+        Seg *seg = nullptr;
+        size_t k = 0;
+        bool parsed = false;
+    };
+
+    const uint8_t *in = nullptr;
+    std::vector<BgzfBlock> blocks;
+    int keep_unmapped = 0;
+    size_t total_out = 0, seg_blocks = 0, buf_bytes = 0, ring = 0, ahead = 0;
+    std::vector<Seg> segs;
+    std::deque<Entry> entries;
+    std::deque<size_t> head_tasks;
+    std::vector<uint8_t *> free_bufs, all_bufs;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_seg, cv_done;
+    size_t next_seg = 0, stitched = 0, delivered = 0;
+    int64_t delivered_reads = 0;
+    bool stop = false, stitch_done = false, bad_inflate = false, bad_frame = false;
+    std::thread stitcher;
+    std::vector<std::thread> workers;
+    PhaseTimer pt{"parse_gam"};
+
+    ~SegPipe() {
+        join();
+        for (Seg &s : segs)
+            if (s.buf && s.special) big_free_bytes(s.buf, s.cap);
+        for (uint8_t *b : all_bufs) big_free_bytes(b, buf_bytes);
+    }
+
+    void join() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        cv_seg.notify_all();
+        if (stitcher.joinable()) stitcher.join();
+        for (auto &t : workers)
+            if (t.joinable()) t.join();
+        workers.clear();
+    }
+
+    bool start(const void *bytes, size_t n, int keep) {
+        in = (const uint8_t *)bytes;
+        if (!bgzf_index(in, n, blocks) || blocks.empty()) return false;
+        keep_unmapped = keep;
+        total_out = blocks.back().out_off + blocks.back().out_size;
+        // a short input is a burst; a long one runs at the quota (twice as many workers as processors: they wait on each other)
+        unsigned nt = std::min(blocks.size() <= 8192 ? burst_cpus() : 2 * usable_cpus(), 64u);
+        // segments of 2-8 MB of inflated bytes: several per worker on a small input, and long against a group (vg: up to
+        // 1000 messages) on a large one -- the part of a segment before its first group header is framed serially
+        seg_blocks = std::min<size_t>(128, std::max<size_t>(32, blocks.size() / (4 * (size_t)nt)));
+        if (const char *e = getenv("VGAN_GAM_SEG_BLOCKS")) { // tests: segments of a block or two, so that every way a group
+            const long v = atol(e);                          // or a message can lie across a boundary occurs in a small file
+            if (v >= 1) seg_blocks = (size_t)std::min<long>(v, 1024);
+        }
+        if (const char *e = getenv("VGAN_GAM_THREADS")) {
+            const long v = atol(e);
+            if (v >= 1) nt = (unsigned)std::min<long>(v, 256);
+        }
+        const size_t nseg = (blocks.size() + seg_blocks - 1) / seg_blocks;
+        nt = (unsigned)std::min<size_t>(nt, nseg);
+        buf_bytes = seg_blocks * 65536 * 3 / 2; // a size class of the block pool; the half in front is the headroom
+        ring = nt + 8;
+        size_t ahead_blocks = 4096; // ~0.25 GB of inflated input (160k short reads) parsed ahead of the caller
+        if (const char *e = getenv("VGAN_GAM_AHEAD_BLOCKS")) ahead_blocks = (size_t)std::max<long>(1, atol(e));
+        ahead = std::max<size_t>(nt + 8, ahead_blocks / seg_blocks);
+        segs = std::vector<Seg>(nseg);
+        for (size_t k = 0; k < nseg; ++k) {
+            Seg &s = segs[k];
+            s.b0 = k * seg_blocks;
+            s.b1 = std::min(blocks.size(), s.b0 + seg_blocks);
+            s.out_off = blocks[s.b0].out_off;
+            s.size = blocks[s.b1 - 1].out_off + blocks[s.b1 - 1].out_size - s.out_off;
+        }
+        pt.lap("inflate started");
+        for (unsigned t = 0; t < nt; ++t) workers.emplace_back([this] { work(); });
+        stitcher = std::thread([this] { stitch(); });
+        return true;
+    }
+
+    void release(Seg &s) {
+        if (s.refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+        uint8_t *b = s.buf;
+        s.buf = nullptr;
+        if (s.special) {
+            big_free_bytes(b, s.cap);
+            s.special = false;
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_bufs.push_back(b);
+        }
+        cv_work.notify_one();
+    }
+
+    size_t taken() const { return delivered < entries.size() ? entries[delivered].k : stitched; } // under mu
+
+    bool parse_msgs(const Msg *m, size_t n, vgan_alnset &a) const {
+        if (!n) return true;
+        reserve_for(a, (size_t)(m[n - 1].second - m[0].first), n);
+        for (size_t i = 0; i < n; ++i)
+            if (!parse_alignment(Cur{m[i].first, m[i].second, true}, a, keep_unmapped)) return false;
+        return true;
+    }
+
+    // the segment's own walk: from the first "GAM" item whose group it can follow
+    void frame_segment(Seg &s) const {
+        const uint8_t *d = s.data(), *e = d + s.size;
+        static const uint8_t TAG[4] = {3, 'G', 'A', 'M'};
+        const uint8_t *t = s.size >= 5 ? (const uint8_t *)memmem(d + 1, s.size - 1, TAG, 4) : nullptr; // its count before it
+        if (!t) return;
+        s.anchored = true;
+        s.anchor_tag = (size_t)(t - d);
+        // the group of the anchor: its count lies before the tag and cannot be told from the previous message's last
+        // bytes, so its end is recognised instead (a count followed by the tag; no message starts with field number 0)
+        const uint8_t *p = t + 4;
+        for (;;) {
+            uint64_t v;
+            const uint8_t *q;
+            if (get_varint(p, e, v, q) <= 0 || e - q < 4) break;
+            if (memcmp(q, TAG, 4) == 0) {
+                s.closed = true;
+                break;
+            }
+            if (v > (uint64_t)(e - q)) break;
+            s.msgs.emplace_back((uint32_t)(q - d), (uint32_t)v);
+            p = q + v;
+        }
+        s.n_first = (uint32_t)s.msgs.size();
+        s.end_off = (size_t)(p - d);
+        if (!s.closed) return; // the stitcher knows the count and resumes at end_off
+        uint64_t need;
+        walk(s.end, p, e, need, [&](const uint8_t *a, const uint8_t *b) { s.msgs.emplace_back((uint32_t)(a - d), (uint32_t)(b - a)); },
+             [&](const uint8_t *h) {
+                 s.hdrs.push_back({(uint32_t)(h - d), (uint32_t)s.msgs.size()});
+                 return false;
+             });
+        s.end_off = (size_t)(p - d); // WALK_MORE and WALK_BAD alike: the stitcher walks the item at end_off itself
+    }
+
+    void do_segment(Seg &s) {
+        for (size_t b = s.b0; b < s.b1; ++b) {
+            const BgzfBlock &bl = blocks[b];
+            if (!inflate_member(in + bl.in_off, bl.in_size, s.data() + (bl.out_off - s.out_off), bl.out_size)) {
+                s.inflate_ok = false;
+                return;
+            }
+        }
+        frame_segment(s);
+        if (s.msgs.empty()) return;
+        const uint8_t *d = s.data();
+        reserve_for(s.parsed, (size_t)s.msgs.back().first + s.msgs.back().second - s.msgs.front().first, s.msgs.size());
+        for (const auto &m : s.msgs)
+            if (!parse_alignment(Cur{d + m.first, d + m.first + m.second, true}, s.parsed, keep_unmapped)) {
+                s.parse_ok = false;
+                return;
+            }
+    }
+
+    void work() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] {
+                return stop || !head_tasks.empty() || (next_seg >= segs.size() && stitch_done) ||
+                       (next_seg < segs.size() && next_seg < taken() + ahead && (!free_bufs.empty() || all_bufs.size() < ring));
+            });
+            if (stop) return;
+            if (!head_tasks.empty()) {
+                Entry *en = &entries[head_tasks.front()]; // element addresses are stable while entries are appended
+                head_tasks.pop_front();
+                lk.unlock();
+                const bool good = parse_msgs(en->msgs.data(), en->msgs.size(), en->a);
+                std::vector<Msg>().swap(en->msgs);
+                release(*en->seg);
+                lk.lock();
+                en->parsed = true;
+                if (!good) bad_frame = stop = true;
+                cv_done.notify_all();
+                if (!good) cv_work.notify_all(), cv_seg.notify_all();
+                continue;
+            }
+            if (next_seg < segs.size() && next_seg < taken() + ahead && (!free_bufs.empty() || all_bufs.size() < ring)) {
+                Seg &s = segs[next_seg++];
+                if (!free_bufs.empty()) {
+                    s.buf = free_bufs.back();
+                    free_bufs.pop_back();
+                } else {
+                    s.buf = (uint8_t *)big_alloc_bytes(buf_bytes);
+                    all_bufs.push_back(s.buf);
+                }
+                s.cap = buf_bytes;
+                s.head = buf_bytes - seg_blocks * 65536;
+                s.refs.store(1, std::memory_order_relaxed); // the stitcher's
+                lk.unlock();
+                do_segment(s);
+                lk.lock();
+                s.ready = true;
+                cv_seg.notify_all();
+                continue;
+            }
+            if (next_seg >= segs.size() && stitch_done) return;
+        }
+    }
+
+    // (stitcher) messages framed serially, in buffer k: an entry the pool parses
+    void hand_over(std::vector<Msg> &cur, size_t k) {
+        if (cur.empty()) return;
+        segs[k].refs.fetch_add(1, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            entries.emplace_back();
+            Entry &en = entries.back();
+            en.msgs.swap(cur);
+            en.seg = &segs[k];
+            en.k = k;
+            head_tasks.push_back(entries.size() - 1);
+        }
+        cv_work.notify_one();
+        cur.clear();
+        cur.reserve(1024);
+    }
+
+    bool wait_ready(size_t k) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_seg.wait(lk, [&] { return stop || segs[k].ready; });
+        return !stop;
+    }
+
+    void stitch() {
+        constexpr size_t HEAD_SLICE = 2048;
+        WalkState st;
+        std::vector<Msg> cur;
+        bool frame_ok = true, inflate_ok = true;
+        const uint8_t *pos = nullptr;
+        for (size_t k = 0; k < segs.size();) {
+            Seg &s = segs[k];
+            if (k == 0) {
+                if (!wait_ready(0)) return;
+                pos = s.data();
+            }
+            if (!s.inflate_ok) {
+                inflate_ok = false;
+                break;
+            }
+            const uint8_t *const data = s.data(), *const end = data + s.size;
+            size_t hi = 0;
+            uint32_t from_msg = 0;
+            uint64_t anchor_count = 0;
+            bool at_anchor = false, met = !s.anchored, own = false;
+            uint64_t need = 0;
+            int r;
+            for (;;) {
+                r = walk(st, pos, end, need,
+                         [&](const uint8_t *a, const uint8_t *b) {
+                             cur.emplace_back(a, b);
+                             if (cur.size() == HEAD_SLICE) hand_over(cur, k);
+                         },
+                         [&](const uint8_t *h) {
+                             if (met || h < data) return false;
+                             const size_t x = (size_t)(h - data);
+                             while (hi < s.hdrs.size() && s.hdrs[hi].off < x) ++hi;
+                             if (hi < s.hdrs.size() && s.hdrs[hi].off == x) {
+                                 from_msg = s.hdrs[hi].msg;
+                                 return true;
+                             }
+                             if (x < s.anchor_tag && s.anchor_tag - x <= 10) {
+                                 uint64_t c;
+                                 const uint8_t *q;
+                                 if (get_varint(h, data + s.anchor_tag, c, q) == 1 && q == data + s.anchor_tag && c >= 1 &&
+                                     (s.closed ? c - 1 == s.n_first : c - 1 >= s.n_first)) {
+                                     at_anchor = true;
+                                     anchor_count = c;
+                                     return true;
+                                 }
+                             }
+                             return false;
+                         });
+                if (r != WALK_STOP) break;
+                // the true walk stands where the segment's own walk stood: the rest of the segment is that walk's
+                met = own = true;
+                g_decode_counts[at_anchor ? 1 : 2].fetch_add(1, std::memory_order_relaxed);
+                hand_over(cur, k);
+                if (at_anchor || from_msg == 0) {
+                    if (!s.parse_ok) {
+                        frame_ok = false;
+                        break;
+                    }
+                    if (s.parsed.n_reads() > 0) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        entries.emplace_back();
+                        Entry &en = entries.back();
+                        en.a = std::move(s.parsed);
+                        en.k = k;
+                        en.parsed = true;
+                    }
+                    cv_done.notify_all();
+                } else { // met at a later group: the messages before it are not the stream's
+                    for (size_t i = from_msg; i < s.msgs.size(); ++i) {
+                        cur.emplace_back(data + s.msgs[i].first, data + s.msgs[i].first + s.msgs[i].second);
+                        if (cur.size() == HEAD_SLICE) hand_over(cur, k);
+                    }
+                    hand_over(cur, k);
+                }
+                if (at_anchor && !s.closed) {
+                    st.rem = anchor_count - 1 - s.n_first;
+                    st.in_group = st.rem != 0;
+                    st.first = false;
+                } else {
+                    st = s.end;
+                }
+                pos = data + s.end_off;
+            }
+            g_decode_counts[0].fetch_add(1, std::memory_order_relaxed);
+            if (!own) g_decode_counts[3].fetch_add(1, std::memory_order_relaxed);
+            s.parsed = vgan_alnset();
+            std::vector<Hdr>().swap(s.hdrs);
+            std::vector<std::pair<uint32_t, uint32_t>>().swap(s.msgs);
+            if (!frame_ok || r == WALK_BAD) {
+                frame_ok = false;
+                break;
+            }
+            hand_over(cur, k);
+            const size_t left = (size_t)(end - pos);
+            if (k + 1 == segs.size()) {
+                frame_ok = left == 0 && !st.in_group;
+                break;
+            }
+            if (need && need - left > total_out - (s.out_off + s.size)) { // longer than the rest of the stream
+                frame_ok = false;
+                break;
+            }
+            if (!wait_ready(k + 1)) return;
+            Seg &nx = segs[k + 1];
+            if (!nx.inflate_ok) {
+                inflate_ok = false;
+                break;
+            }
+            if (left > nx.head) { // a message longer than the headroom: a buffer of its own for the two pieces
+                g_decode_counts[4].fetch_add(1, std::memory_order_relaxed);
+                const size_t cap = left + nx.size + 64;
+                uint8_t *nb = (uint8_t *)big_alloc_bytes(cap);
+                memcpy(nb + left, nx.data(), nx.size);
+                uint8_t *old = nx.buf;
+                const bool was_special = nx.special;
+                const size_t old_cap = nx.cap;
+                nx.buf = nb;
+                nx.cap = cap;
+                nx.head = left;
+                nx.special = true;
+                if (was_special) {
+                    big_free_bytes(old, old_cap);
+                } else {
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        free_bufs.push_back(old);
+                    }
+                    cv_work.notify_one();
+                }
+            }
+            if (left) memcpy(nx.data() - left, pos, left);
+            pos = nx.data() - left;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stitched = k + 1;
+            }
+            release(s);
+            ++k;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stitched = segs.size();
+            stitch_done = true;
+            if (!inflate_ok) bad_inflate = true;
+            if (!frame_ok) bad_frame = true;
+            if (!inflate_ok || !frame_ok) stop = true;
+        }
+        pt.lap("framing");
+        cv_work.notify_all();
+        cv_done.notify_all();
+    }
+
+    int take(int64_t min_reads, std::vector<vgan_alnset> &out, int64_t *first_read) {
+        out.clear();
+        std::unique_lock<std::mutex> lk(mu);
+        if (first_read) *first_read = delivered_reads;
+        int64_t got = 0;
+        bool moved = false;
+        auto ready = [&] { return bad_inflate || bad_frame || (delivered < entries.size() && entries[delivered].parsed) || (stitch_done && delivered >= entries.size()); };
+        for (;;) {
+            if (!ready()) {
+                if (moved) cv_work.notify_all(); // the workers may run further ahead
+                moved = false;
+                cv_done.wait(lk, ready);
+            }
+            if (bad_inflate || bad_frame) break;
+            if (delivered >= entries.size()) break; // end of the stream
+            Entry &en = entries[delivered];
+            const int64_t nr = en.a.n_reads();
+            if (nr > 0) {
+                out.emplace_back(std::move(en.a));
+                got += nr;
+            }
+            en.a = vgan_alnset();
+            ++delivered;
+            moved = true;
+            if (got >= min_reads) break;
+        }
+        delivered_reads += got;
+        const bool bi = bad_inflate, bf = bad_frame;
+        lk.unlock();
+        if (moved) cv_work.notify_all();
+        if (bi) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
+        if (bf) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
+        return VGAN_OK;
+    }
+};
+
+} // namespace
+
+// GAM bytes -> slices of reads in input order, as a pipeline that runs behind the caller; take() returns the next parsed
+// slices as soon as they exist.  BGZF input goes through the segment pipeline above; anything else (plain bytes, a gzip
+// stream that is not BGZF: inflated whole first) through a serial framing pass that hands slices of ~SLICE messages to a
+// parser pool.
 struct vgan_gam_stream {
     using Msg = std::pair<const uint8_t *, const uint8_t *>;
     static constexpr size_t SLICE = 8192;
     MappedFile file;
     int keep_unmapped = 0;
     ByteBuf inflated;
-    AsyncInflate bg; // BGZF (what vg writes): framing runs on the prefix inflated so far
-    bool streaming = false;
+    std::unique_ptr<SegPipe> seg;
     const uint8_t *p = nullptr;
     size_t n = 0;
     std::deque<std::vector<Msg>> slices; // grown by the framing thread only, under mu
@@ -320,7 +856,7 @@ struct vgan_gam_stream {
     std::condition_variable cv_work, cv_done;
     size_t next_slice = 0, delivered = 0;
     int64_t delivered_reads = 0;
-    bool framing_done = false, framed = true, inflate_ok = true;
+    bool framing_done = false, framed = true;
     std::atomic<bool> ok{true};
     std::thread framer;
     std::vector<std::thread> workers;
@@ -329,11 +865,11 @@ struct vgan_gam_stream {
     ~vgan_gam_stream() { join(); }
 
     void join() {
+        if (seg) seg->join();
         if (framer.joinable()) framer.join();
         for (auto &t : workers)
             if (t.joinable()) t.join();
         workers.clear();
-        (void)bg.finish();
     }
 
     int start(const void *bytes, size_t nbytes, int keep) {
@@ -342,18 +878,15 @@ struct vgan_gam_stream {
         p = (const uint8_t *)bytes;
         n = nbytes;
         if (n >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
-            if (bg.start(bytes, n)) {
-                streaming = true;
-                p = (const uint8_t *)bg.out.data();
-                n = bg.out.size();
-            } else {
-                if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
-                p = (const uint8_t *)inflated.data();
-                n = inflated.size();
-            }
+            seg.reset(new SegPipe());
+            if (seg->start(bytes, n, keep)) return VGAN_OK;
+            seg.reset();
+            if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
+            p = (const uint8_t *)inflated.data();
+            n = inflated.size();
+            pt.lap("inflate");
         }
-        pt.lap(streaming ? "inflate started" : "inflate");
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned hw = usable_cpus();
         const unsigned nt = (unsigned)std::min<size_t>(std::min(hw, 64u), std::max<size_t>(1, n / (4u << 20)));
         for (unsigned t = 0; t < nt; ++t) workers.emplace_back([this] { work(); });
         framer = std::thread([this] { frame(); });
@@ -362,24 +895,7 @@ struct vgan_gam_stream {
 
     void parse_slice(const std::vector<Msg> &ms, vgan_alnset &a) {
         if (ms.empty()) return;
-        // reserve from the byte volume of the slice: ~1 mapping per 20 bytes, ~1 edit per 16
-        const size_t nbytes = (size_t)(ms.back().second - ms.front().first), nr = ms.size();
-        a.seq_off.reserve(nr + 1);
-        a.qual_off.reserve(nr + 1);
-        a.name_off.reserve(nr + 1);
-        a.map_off.reserve(nr + 1);
-        a.mapq.reserve(nr);
-        a.identity.reserve(nr);
-        a.seq.reserve(nbytes / 6);
-        a.qual.reserve(nbytes / 6);
-        a.name.reserve(nr * 16);
-        a.m_node.reserve(nbytes / 18);
-        a.m_offset.reserve(nbytes / 18);
-        a.m_rev.reserve(nbytes / 18);
-        a.edit_off.reserve(nbytes / 18);
-        a.e_from.reserve(nbytes / 14);
-        a.e_to.reserve(nbytes / 14);
-        a.e_seq_off.reserve(nbytes / 14);
+        reserve_for(a, (size_t)(ms.back().second - ms.front().first), ms.size());
         for (const Msg &m : ms) {
             if (!parse_alignment(Cur{m.first, m.second, true}, a, keep_unmapped)) {
                 ok = false;
@@ -411,11 +927,7 @@ struct vgan_gam_stream {
         }
     }
 
-    void frame() { // serial: groups of {count, count x (len, bytes)}, the first item of a group possibly the tag "GAM"
-        const uint8_t *const base = p;
-        auto need = [&](const uint8_t *upto) { // bytes [0, upto) must be final before they are read
-            if (streaming && inflate_ok) inflate_ok = bg.wait_for((size_t)(upto - base));
-        };
+    void frame() { // serial: the same walk as the segment pipeline's, over the whole buffer
         auto open_slice = [&]() {
             std::lock_guard<std::mutex> lk(mu);
             slices.emplace_back();
@@ -425,37 +937,22 @@ struct vgan_gam_stream {
         };
         open_slice();
         std::vector<Msg> *cur = &slices.back();
-        Cur c{p, p + n, true};
-        while (!c.done() && inflate_ok) {
-            need(c.p + 10); // a varint
-            const uint64_t count = c.varint();
-            if (!c.ok) break;
-            bool first = true;
-            for (uint64_t i = 0; i < count && c.ok && inflate_ok; ++i) {
-                need(c.p + 10);
-                Cur item = c.sub(); // the length only: the payload is not touched here
-                if (!c.ok) break;
-                if (first) {
-                    first = false;
-                    if (item.e - item.p == 3) {
-                        need(item.e);
-                        if (memcmp(item.p, "GAM", 3) == 0) continue;
-                    }
-                }
-                cur->emplace_back(item.p, item.e);
-                if (cur->size() == SLICE) {
-                    need(item.e); // the parsers read the payloads
-                    open_slice();
-                    cur = &slices.back();
-                    cv_work.notify_one();
-                }
-            }
-            if (!c.ok) break;
-        }
-        need(p + n);
+        WalkState st;
+        const uint8_t *at = p;
+        uint64_t need = 0;
+        const int r = walk(st, at, p + n, need,
+                           [&](const uint8_t *a, const uint8_t *b) {
+                               cur->emplace_back(a, b);
+                               if (cur->size() == SLICE) {
+                                   open_slice();
+                                   cur = &slices.back();
+                                   cv_work.notify_one();
+                               }
+                           },
+                           [](const uint8_t *) { return false; });
         {
             std::lock_guard<std::mutex> lk(mu);
-            framed = c.ok && inflate_ok;
+            framed = r == WALK_MORE && at == p + n && !st.in_group;
             framing_done = true;
         }
         pt.lap("framing");
@@ -465,6 +962,7 @@ struct vgan_gam_stream {
 
     // The next parsed slices in input order holding at least min_reads reads (fewer at the end); empty at the end.
     int take(int64_t min_reads, std::vector<vgan_alnset> &out, int64_t *first_read) {
+        if (seg) return seg->take(min_reads, out, first_read);
         out.clear();
         std::unique_lock<std::mutex> lk(mu);
         if (first_read) *first_read = delivered_reads;
@@ -486,9 +984,8 @@ struct vgan_gam_stream {
             if (got >= min_reads) break;
         }
         delivered_reads += got;
-        const bool bad_frame = framing_done && !framed, bad_inflate = framing_done && !inflate_ok;
+        const bool bad_frame = framing_done && !framed;
         lk.unlock();
-        if (bad_inflate) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
         if (bad_frame || !ok) return fail(VGAN_EIO, "GAM: malformed group or Alignment message");
         return VGAN_OK;
     }
@@ -502,7 +999,6 @@ static int parse_gam_parts(const void *bytes, size_t n, int keep_unmapped, std::
     rc = st.take(INT64_MAX, parts, nullptr);
     st.join();
     if (rc) return rc;
-    if (!st.bg.finish()) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");
     st.pt.lap("parse");
     return VGAN_OK;
 }
@@ -570,6 +1066,11 @@ extern "C" int vgan_gam_stream_next(vgan_gam_stream *st, int64_t min_reads, vgan
 }
 
 extern "C" void vgan_gam_stream_close(vgan_gam_stream *st) { delete st; }
+
+extern "C" void vgan_gam_decode_counts(int64_t out[5]) {
+    if (!out) return;
+    for (int i = 0; i < 5; ++i) out[i] = g_decode_counts[i].load(std::memory_order_relaxed);
+}
 
 extern "C" int64_t vgan_alnparts_base(const vgan_alnparts *p) { return p ? p->base : 0; }
 

@@ -318,7 +318,7 @@ static int graph_load_impl(const char *gfa_path, const char *hcfiles_dir, vgan_g
         // boundary and knowing its first row from a count of the newlines before it
         const char *base = ps_bytes.data();
         const size_t nbytes = ps_bytes.size();
-        const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), nbytes / (1u << 20) + 1}));
+        const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)usable_cpus(), nbytes / (1u << 20) + 1}));
         std::vector<size_t> cut(nth + 1, nbytes);
         cut[0] = 0;
         for (unsigned t = 1; t < nth; ++t) {

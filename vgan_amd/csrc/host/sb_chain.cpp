@@ -193,7 +193,7 @@ double effective_sample_size(const std::vector<long double> &v) {
     const long double m = mean_of(v), denom = variance_of(v, m);
     const int max_lag = (int)(v.size() / 2);
     double even = 1.0, odd = (double)autocorr(v, 1, m, denom), total = even + odd;
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(16u, usable_cpus()));
     int t = 1;
     int block = 8; // lags per round; the first rounds stay small and serial: a well mixed chain stops within a few lags
     std::vector<double> ac;

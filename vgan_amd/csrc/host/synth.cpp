@@ -396,7 +396,7 @@ extern "C" int vgan_synth_hc_reads(const vgan_graph *g, const vgan_synth_reads_c
             if (w.site_node[(size_t)p * w.n_sites + s] == 0)
                 return fail(VGAN_EINVAL, "vgan_synth_hc_reads: path %u has no node at site %u (not a synthetic hc graph?)", p, s);
     const uint64_t R = cfg->n_reads;
-    int nt = (int)std::max(1u, std::thread::hardware_concurrency());
+    int nt = (int)usable_cpus();
     nt = (int)std::max<uint64_t>(1, std::min<uint64_t>(nt, (R + 8191) / 8192));
     std::vector<vgan_alnset> parts((size_t)nt);
     std::vector<std::thread> th;

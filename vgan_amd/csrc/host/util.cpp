@@ -1,7 +1,9 @@
 // Error reporting, file and gzip helpers of the host front end.
 #include "common.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -12,6 +14,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
+#include <deque>
 #include <mutex>
 #include <memory>
 #include <condition_variable>
@@ -47,12 +51,6 @@ bool file_exists(const std::string &path) {
     return stat(path.c_str(), &st) == 0 && !S_ISDIR(st.st_mode);
 }
 
-namespace {
-
-struct BgzfBlock {
-    size_t in_off, in_size, out_off, out_size;
-};
-
 // BGZF = gzip members with an extra subfield 'B','C' holding the member size - 1 (SAM spec 4.1).  Returns true and the
 // block list when the whole buffer is a sequence of such members.
 bool bgzf_index(const unsigned char *p, size_t n, std::vector<BgzfBlock> &blocks) {
@@ -78,12 +76,51 @@ bool bgzf_index(const unsigned char *p, size_t n, std::vector<BgzfBlock> &blocks
     return true;
 }
 
+// libdeflate (what htslib inflates BGZF with: 2-3x zlib's rate on these 64 KB members), when the system has its shared
+// object: loaded at run time, by its four stable entry points; zlib does the work otherwise, with the same results.
+namespace {
+struct FastInflate {
+    void *(*alloc)() = nullptr;
+    int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    FastInflate() {
+        if (getenv("VGAN_NO_LIBDEFLATE")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        gunzip = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_gzip_decompress");
+        release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !gunzip || !release) alloc = nullptr;
+    }
+};
+const FastInflate &fast_inflate() {
+    static const FastInflate f;
+    return f;
+}
+struct ThreadDecompressor {
+    void *d = nullptr;
+    ~ThreadDecompressor() {
+        if (d) fast_inflate().release(d);
+    }
+};
+} // namespace
+
 bool inflate_member(const unsigned char *in, size_t in_size, unsigned char *out, size_t out_size) {
+    unsigned char scratch[8]; // an empty member (the BGZF end-of-file block; a whole GAM without reads is just that block) still
+                              // needs somewhere to "write": zlib rejects a null next_out and cannot finish with no room at all
+    const FastInflate &f = fast_inflate();
+    if (f.alloc) {
+        static thread_local ThreadDecompressor td;
+        if (!td.d) td.d = f.alloc();
+        if (td.d) {
+            size_t got = 0;
+            const int rc = f.gunzip(td.d, in, in_size, out_size ? out : scratch, out_size ? out_size : sizeof scratch, &got);
+            return rc == 0 && got == out_size;
+        }
+    }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;
-    unsigned char scratch[8]; // an empty member (the BGZF end-of-file block; a whole GAM without reads is just that block) still
-                              // needs somewhere to "write": zlib rejects a null next_out and cannot finish with no room at all
     zs.next_in = const_cast<unsigned char *>(in);
     zs.avail_in = (uInt)in_size;
     zs.next_out = out_size ? out : scratch;
@@ -94,8 +131,6 @@ bool inflate_member(const unsigned char *in, size_t in_size, unsigned char *out,
     return ok;
 }
 
-} // namespace
-
 // Inflates a concatenation of gzip members.  BGZF input (what vg writes) is inflated block-parallel straight into its
 // final position; other gzip streams sequentially.
 bool gunzip_members(const void *data, size_t n, ByteBuf &out) {
@@ -105,7 +140,7 @@ bool gunzip_members(const void *data, size_t n, ByteBuf &out) {
     if (bgzf_index(p, n, blocks)) {
         const size_t total = blocks.empty() ? 0 : blocks.back().out_off + blocks.back().out_size;
         out.resize(total);
-        unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+        unsigned nt = usable_cpus();
         nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, blocks.size() / 64));
         std::atomic<bool> ok{true};
         auto work = [&](size_t b0, size_t b1) {
@@ -180,7 +215,7 @@ bool AsyncInflate::start(const void *data, size_t n) {
     out.resize(m.blocks.back().out_off + m.blocks.back().out_size);
     m.done.reset(new std::atomic<uint8_t>[m.blocks.size()]);
     for (size_t i = 0; i < m.blocks.size(); ++i) m.done[i].store(0, std::memory_order_relaxed);
-    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = usable_cpus();
     nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, m.blocks.size() / 64));
     auto work = [this]() {
         Impl &m = *impl;
@@ -279,7 +314,7 @@ bool gzip_bytes(const std::string &in, std::string &out) {
             o.append((const char *)tail, 8);
         }
     };
-    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = usable_cpus();
     nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, nb / 16));
     if (nt <= 1) {
         work(0, nb);
@@ -322,6 +357,104 @@ bool read_file(const std::string &path, std::string &out, bool inflate_if_gzip) 
     }
     out.swap(raw);
     return true;
+}
+
+unsigned usable_cpus() {
+    static const unsigned n = [] {
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min(hw, (unsigned)std::max(1, CPU_COUNT(&set)));
+        double quota = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "max 100000" or "<quota> <period>"
+            char q[64];
+            long period = 0;
+            if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / (double)period;
+            fclose(f);
+        } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // cgroup v1
+            long q = -1, period = 0;
+            if (fscanf(f1, "%ld", &q) != 1) q = -1;
+            fclose(f1);
+            if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(f2, "%ld", &period) != 1) period = 0;
+                fclose(f2);
+            }
+            if (q > 0 && period > 0) quota = (double)q / (double)period;
+        }
+        if (quota > 0) hw = std::min(hw, (unsigned)std::max(1.0, quota + 0.5));
+        if (const char *e = getenv("VGAN_CPUS")) hw = (unsigned)std::max(1, atoi(e));
+        return hw;
+    }();
+    return n;
+}
+
+unsigned burst_cpus() {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min(hw, (unsigned)std::max(1, CPU_COUNT(&set)));
+    if (getenv("VGAN_CPUS")) return usable_cpus();
+    return std::min(hw, 4 * usable_cpus());
+}
+
+} // namespace vgan
+extern "C" int vgan_host_cpus(void) { return (int)vgan::usable_cpus(); }
+namespace vgan {
+
+namespace {
+struct WorkerPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    size_t n_threads = 0, idle = 0;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            ++idle;
+            cv.wait(lk, [&] { return !q.empty(); });
+            --idle;
+            std::function<void()> f = std::move(q.front());
+            q.pop_front();
+            lk.unlock();
+            f();
+            lk.lock();
+        }
+    }
+    void submit(std::function<void()> f) {
+        std::lock_guard<std::mutex> lk(mu);
+        q.push_back(std::move(f));
+        if (idle < q.size() && n_threads < 512) { // one more worker: they stay for the life of the process
+            ++n_threads;
+            std::thread([this] { worker(); }).detach();
+        }
+        cv.notify_one();
+    }
+};
+WorkerPool &worker_pool() {
+    static WorkerPool *p = new WorkerPool; // never destroyed: its threads outlive static destruction
+    return *p;
+}
+} // namespace
+
+void parallel_run(int n, const std::function<void(int)> &fn) {
+    if (n <= 1) {
+        fn(0);
+        return;
+    }
+    struct Job {
+        std::mutex mu;
+        std::condition_variable cv;
+        int left;
+    } job;
+    job.left = n - 1;
+    WorkerPool &wp = worker_pool();
+    for (int t = 1; t < n; ++t)
+        wp.submit([&job, &fn, t] {
+            fn(t);
+            std::lock_guard<std::mutex> lk(job.mu); // held while notifying: the waiter cannot leave (and destroy job) before
+            if (--job.left == 0) job.cv.notify_one();
+        });
+    fn(0);
+    std::unique_lock<std::mutex> lk(job.mu);
+    job.cv.wait(lk, [&] { return job.left == 0; });
 }
 
 // Large blocks are recycled, not returned: every munmap interrupts all the cores the process runs on and every fresh mapping

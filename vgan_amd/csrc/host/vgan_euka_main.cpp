@@ -119,7 +119,7 @@ int euka_main(int argc, char **argv) {
         else if (a == "-t") {
             n_threads = parse_int(need("-t"), "-t", T);
             if (n_threads < -1 || n_threads == 0) die("[euka] Error, invalid number of threads"); // Euka.cpp:298
-            const int hw = (int)std::thread::hardware_concurrency();
+            const int hw = (int)vgan_host_cpus();
             if (n_threads == -1) n_threads = hw; // (host threads only, as in the reference: GPUs are asked for with --gpus)
             else if (n_threads > hw) {
                 std::cerr << "[euka] Warning, specified number of threads is greater than the number available. Using " << hw << " threads\n";

@@ -198,12 +198,14 @@ int haplocart(int argc, char **argv) {
     prm.background_error_prob = background_error_prob;
     prm.use_background_error_prob = !fastafilename.empty(); // HaploCart.cpp:397-400
     prm.is_consensus_fasta = !fastafilename.empty();
-    if (warm.t.joinable()) warm.t.join();
-    const int n_visible = vgan_device_count();
-    if (n_visible <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
+    // (the HIP runtime is still coming up: only "--gpus all" has to wait for it here, to know how many contexts there will
+    // be; otherwise the first chunks are decoded and flattened beside it and the context thread below is the one that waits)
     if (gpu_spec.empty())
         if (const char *e = getenv("VGAN_GPUS")) gpu_spec = e;
     if (gpu_spec == "all") {
+        if (warm.t.joinable()) warm.t.join();
+        const int n_visible = vgan_device_count();
+        if (n_visible <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
         for (int d = 0; d < n_visible; ++d) gpu_list.push_back(d);
     } else if (!gpu_spec.empty()) {
         size_t p0 = 0;
@@ -233,6 +235,12 @@ int haplocart(int argc, char **argv) {
         }
     } creator;
     creator.t = std::thread([&] {
+        if (warm.t.joinable()) warm.t.join();
+        stamp("HIP runtime up");
+        if (vgan_device_count() <= 0) {
+            creator.err = "[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only";
+            return;
+        }
         for (int d : gpu_list) {
             vgan_hc_ctx *c = nullptr;
             if (vgan_hc_create(&gv, &prm, d, &c) < 0 ||
@@ -243,6 +251,7 @@ int haplocart(int argc, char **argv) {
             }
             ctxs.v.push_back(c);
         }
+        stamp("device contexts ready");
     });
     std::once_flag creator_joined;
     auto contexts_ready_quiet = [&] { // from any thread
@@ -256,12 +265,12 @@ int haplocart(int argc, char **argv) {
     };
     const size_t n_ctx = gpu_list.size();
 
-    // reads per device batch: host flattening of batch i+1 overlaps the kernels of batch i; with several GPUs the batches
-    // are dealt round-robin (smaller ones, so that a 1M-read input still reaches every GPU)
-    // (small enough that flattening runs behind the decoder instead of waiting for half a million reads -- the last chunk's
-    // flatten, not the sum of them, is what follows the end of the decode -- and large enough to keep 32 flatten threads busy:
-    // the parser's slices of 8192 reads are the unit of work)
-    const int64_t BATCH = n_ctx > 1 ? std::max<int64_t>(50000, 500000 / (int64_t)n_ctx) : 262144;
+    // reads per device batch: small enough that the first one is decoded ~30 ms after the start and every array of the loop
+    // is recycled a few chunks later (the resident set, which the kernel takes apart at ~80 ms per GB when the process ends,
+    // follows the chunk size), large enough for one work item of 2048 reads per flatten thread (65536 reads: ~8 ms on 32
+    // threads) and a full grid on the device.  With several GPUs the batches are dealt round-robin.
+    int64_t BATCH = n_ctx > 1 ? std::max<int64_t>(50000, 500000 / (int64_t)n_ctx) : 65536;
+    if (const char *e = getenv("VGAN_HC_BATCH")) BATCH = std::max<int64_t>(1024, atoll(e)); // developer aid
     size_t n_chunks = 0;
     struct DedupCloser {
         vgan_dedup *d = nullptr;
@@ -270,20 +279,34 @@ int haplocart(int argc, char **argv) {
     // HaploCart.cpp:389-390: remove_duplicates_internal runs whatever the input was; only its message depends on -f
     if (rmdup) check(vgan_dedup_create(&dedup.d), "duplicate removal");
     int64_t n_in = 0, n_dup = 0;
-    std::vector<uint8_t> dup;
     vgan_hc_flatten_stats tot{};
-    // flattened chunks -> device, in order, on a thread of its own (at most two chunks wait: the host batches are large)
+    // flattened chunks -> device, in order, on a thread of its own.  The device contexts are ready 0.3-0.45 s after the start
+    // (the HIP runtime comes up beside a hundred busy threads); until then the flattened chunks wait here -- up to `depth`
+    // of them (~85 MB each), after which the loop, and behind it the decoder, wait too.
     struct Uploader {
         std::mutex mu;
         std::condition_variable cv;
         std::deque<vgan_hc_host_batch *> q;
+        size_t depth = 16;
         bool closed = false;
         std::string err;
         std::thread t;
-        void push(vgan_hc_host_batch *hb) {
+        int64_t next = 0; // batches enter in input order, whichever lane made them
+        void push(int64_t seq, vgan_hc_host_batch *hb) {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return q.size() < 2 || !err.empty(); });
+            cv.wait(lk, [&] { return (seq == next && q.size() < depth) || !err.empty(); });
+            if (!err.empty()) {
+                lk.unlock();
+                vgan_hc_host_batch_free(hb);
+                return;
+            }
             q.push_back(hb);
+            ++next;
+            cv.notify_all();
+        }
+        void fail(const std::string &why) { // a lane that failed: the others must not wait for its turn
+            std::unique_lock<std::mutex> lk(mu);
+            if (err.empty()) err = why;
             cv.notify_all();
         }
         std::string error() {
@@ -303,6 +326,7 @@ int haplocart(int argc, char **argv) {
             for (auto hb : q) vgan_hc_host_batch_free(hb);
         }
     } uploader;
+    if (const char *e = getenv("VGAN_HC_QUEUE")) uploader.depth = (size_t)std::max(1, atoi(e)); // developer aid
     uploader.t = std::thread([&] {
         for (;;) {
             vgan_hc_host_batch *hb = nullptr;
@@ -319,6 +343,7 @@ int haplocart(int argc, char **argv) {
                 contexts_ready_quiet();
                 if (!creator.err.empty()) err = creator.err;
                 else if (vgan_hc_accumulate(ctxs.v[n_chunks++ % ctxs.v.size()], &b) < 0) err = std::string("[vgan] accumulate: ") + vgan_last_error();
+                if (n_chunks <= 3) stamp("chunk handed to the device");
             }
             vgan_hc_host_batch_free(hb);
             std::lock_guard<std::mutex> lk(uploader.mu);
@@ -327,38 +352,95 @@ int haplocart(int argc, char **argv) {
             uploader.cv.notify_all();
         }
     });
-    for (;;) {
-        vgan_alnparts *chunk = nullptr;
-        check(vgan_gam_stream_next(stream.s, BATCH, &chunk), "reading GAM");
-        if (!chunk) break;
-        if (n_in == 0) stamp("first chunk of reads decoded");
-        const int64_t nr = vgan_alnparts_n_reads(chunk);
-        n_in += nr;
-        const uint8_t *skip = nullptr;
-        if (dedup.d) {
-            dup.resize((size_t)nr);
-            int64_t nd = 0;
-            if (vgan_dedup_mark(dedup.d, chunk, dup.data(), &nd) < 0) {
+    // The loop: next chunk of decoded reads -> duplicate marks -> flatten -> device queue.  Taking a chunk and marking its
+    // duplicates is serial (input order); the flattening of several chunks runs side by side on `lanes` threads (each call
+    // spreads over its own share of the host threads), and the queue takes the batches back in input order.
+    double t_wait_decode = 0, t_flatten = 0, t_wait_device = 0, t_free = 0; // VGAN_TIMING: where the lanes' time went
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const int want_threads = n_threads > 0 ? n_threads : (int)vgan_host_cpus();
+    int lanes = std::max(1, std::min(4, want_threads / 64)); // one lane unless the machine is large and all ours
+    if (const char *e = getenv("VGAN_HC_LANES")) lanes = std::max(1, std::min(16, atoi(e))); // developer aid
+    const int lane_threads = std::max(1, std::min(40, want_threads / lanes));
+    std::mutex take_mu, stat_mu;
+    int64_t next_seq = 0;
+    bool at_end = false;
+    std::string lane_err;
+    auto lane = [&] {
+        try {
+            std::vector<uint8_t> dup;
+            for (;;) {
+                vgan_alnparts *chunk = nullptr;
+                int64_t seq = 0;
+                const uint8_t *skip = nullptr;
+                auto t0 = std::chrono::steady_clock::now();
+                double waited = 0;
+                {
+                    std::lock_guard<std::mutex> lk(take_mu);
+                    if (at_end) return;
+                    check(vgan_gam_stream_next(stream.s, BATCH, &chunk), "reading GAM");
+                    waited = since(t0);
+                    if (!chunk) {
+                        at_end = true;
+                        return;
+                    }
+                    if (n_in == 0) stamp("first chunk of reads decoded");
+                    seq = next_seq++;
+                    const int64_t nr = vgan_alnparts_n_reads(chunk);
+                    n_in += nr;
+                    if (dedup.d) {
+                        dup.resize((size_t)nr);
+                        int64_t nd = 0;
+                        if (vgan_dedup_mark(dedup.d, chunk, dup.data(), &nd) < 0) {
+                            vgan_alnparts_free(chunk);
+                            check(-1, "duplicate removal");
+                        }
+                        n_dup += nd;
+                        skip = dup.data();
+                    }
+                }
+                vgan_hc_host_batch *hb = nullptr;
+                vgan_hc_flatten_stats st{};
+                t0 = std::chrono::steady_clock::now();
+                const int rc = vgan_hc_flatten_parts(graph, chunk, 0, vgan_alnparts_count(chunk), skip, lane_threads, &hb, &st);
+                const double fl = since(t0);
+                t0 = std::chrono::steady_clock::now();
                 vgan_alnparts_free(chunk);
-                check(-1, "duplicate removal");
+                const double fr = since(t0);
+                check(rc, "flattening");
+                // the copy out of a (pageable) host batch completes inside vgan_hc_accumulate: the uploader thread makes that
+                // call while the lanes go on; the kernels run asynchronously behind both
+                t0 = std::chrono::steady_clock::now();
+                uploader.push(seq, hb);
+                const double wd = since(t0);
+                std::lock_guard<std::mutex> lk(stat_mu);
+                t_wait_decode += waited;
+                t_flatten += fl;
+                t_free += fr;
+                t_wait_device += wd;
+                tot.n_bad += st.n_bad;
+                tot.n_unmapped += st.n_unmapped;
+                tot.n_out += st.n_out;
+                if (!uploader.error().empty()) die(uploader.error());
             }
-            n_dup += nd;
-            skip = dup.data();
+        } catch (const std::exception &e) {
+            uploader.fail(e.what());
+            std::lock_guard<std::mutex> lk(stat_mu);
+            if (lane_err.empty()) lane_err = e.what();
+            std::lock_guard<std::mutex> lk2(take_mu);
+            at_end = true;
         }
-        vgan_hc_host_batch *hb = nullptr;
-        vgan_hc_flatten_stats st{};
-        int rc = vgan_hc_flatten_parts(graph, chunk, 0, vgan_alnparts_count(chunk), skip, n_threads, &hb, &st);
-        vgan_alnparts_free(chunk);
-        check(rc, "flattening");
-        // the copy out of a (pageable) host batch completes inside vgan_hc_accumulate: the uploader thread makes that call
-        // while this one goes on to flatten the next chunk; the kernels run asynchronously behind both
-        uploader.push(hb);
-        if (!uploader.error().empty()) die(uploader.error());
-        tot.n_bad += st.n_bad;
-        tot.n_unmapped += st.n_unmapped;
-        tot.n_out += st.n_out;
+    };
+    {
+        std::vector<std::thread> lane_threads_v;
+        for (int l = 1; l < lanes; ++l) lane_threads_v.emplace_back(lane);
+        lane();
+        for (auto &t : lane_threads_v) t.join();
     }
+    if (!lane_err.empty()) die(lane_err);
     stamp("last chunk flattened");
+    if (getenv("VGAN_TIMING"))
+        fprintf(stderr, "[vgan timing] haplocart loop (%d lanes x %d threads, summed over the lanes): waiting for decoded reads %.0f ms, flattening %.0f ms, freeing chunks %.0f ms, waiting for the device queue %.0f ms\n",
+                lanes, lane_threads, t_wait_decode, t_flatten, t_free, t_wait_device);
     uploader.close();
     if (!uploader.err.empty()) die(uploader.err);
     stamp("last chunk on the device");
@@ -431,6 +513,12 @@ int haplocart(int argc, char **argv) {
     pt.lap("posterior + output");
     stamp("output written");
     if (getenv("VGAN_TIMING")) { // resident anonymous memory the kernel has to take apart when the process ends
+        if (FILE *f = fopen("/proc/self/status", "r")) {
+            char line[256];
+            while (fgets(line, sizeof line, f))
+                if (!strncmp(line, "VmHWM:", 6)) fprintf(stderr, "[vgan timing] haplocart memory: %s", line);
+            fclose(f);
+        }
         if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {
             char line[256];
             while (fgets(line, sizeof line, f))
@@ -447,6 +535,9 @@ int haplocart(int argc, char **argv) {
     // the address space apart in one pass either way (0.3-0.4 s for the ~6 GB a million reads leave resident; handing the
     // recycled arrays back on 32 threads first took 0.25 s and saved 0.15 s of it).  (VGAN_KEEP_TEARDOWN=1: return normally, for leak checkers.)
     if (!getenv("VGAN_KEEP_TEARDOWN")) {
+        if (getenv("VGAN_TIMING"))
+            fprintf(stderr, "[vgan timing] wall clock at exit: %.6f\n",
+                    std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
         std::cout.flush();
         std::cerr.flush();
         fflush(nullptr);
@@ -468,6 +559,8 @@ std::string usage() {
 } // namespace
 
 int main(int argc, char **argv) {
+    if (getenv("VGAN_TIMING"))
+        fprintf(stderr, "[vgan timing] wall clock at main: %.6f\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
     try {
         if (argc < 2) {
             std::cerr << usage();

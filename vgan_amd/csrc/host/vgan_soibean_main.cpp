@@ -98,7 +98,7 @@ int soibean_main(int argc, char **argv) {
         else if (a == "-t") {
             n_threads = parse_int(need("-t"), "-t", T);
             if (n_threads < -1 || n_threads == 0) die("[soibean] Error, invalid number of threads");
-            const int hw = (int)std::thread::hardware_concurrency();
+            const int hw = (int)vgan_host_cpus();
             if (n_threads == -1 || n_threads > hw) n_threads = hw;
         } else if (a == "--no-mcmc") run_mcmc = false;
         else if (a == "--iter" || a == "--iterations") iter = non_negative("--iter");
