@@ -482,8 +482,12 @@ def front_end_rates(graph, hc, seed, n=200_000):
     t0 = time.perf_counter()
     hb = hc.HostBatch(graph, b)
     t_fl = time.perf_counter() - t0
+    from vgan_amd import _native as N
     return {"sample_reads": n, "gam_bytes": size, "decode_reads_per_s": n / t_dec, "flatten_reads_per_s": hb.n_reads / t_fl,
-            "threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)}
+            "threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1),
+            # what the container may keep busy (affinity mask and cgroup CPU quota): a sample this size is a burst on the
+            # quota's slack; a long input runs at ~7 us of CPU per read on this many processors
+            "cpu_quota": int(N.lib().vgan_host_cpus())}
 
 
 def main():
