@@ -95,6 +95,12 @@ __device__ __forceinline__ double wv_fma3(double a, double b, double c) { // thr
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// the same with the addend in a scalar register pair: a series' constants need no vector registers and no copies into them
+__device__ __forceinline__ double wv_fma3s(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t wv_scan_u32(uint32_t v) { // wave64 inclusive prefix sum (DPP)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
@@ -287,6 +293,8 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         }
     };
 
+    double c6 = 1.0 / 6.0; // the series' leading coefficient, kept in a vector register pair for the whole launch (an
+    asm volatile("" : "+v"(c6)); // instruction takes one scalar operand; the other coefficients travel as scalars)
     double sumT = 0.0, sumU = 0.0;  // sum of S_m and of U_m, each without cancellation
     uint32_t winbase = 0xFFFFFFFFu; // no window yet (wave uniform)
     bool need_place = true;
@@ -457,24 +465,29 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                 const WvKL *klp[N];
                 double *Sp[N];
                 uint32_t own[N], row[N], rc8[N];
-                bool valid[N];
+                uint64_t valid[N], farm[N]; // lane masks (kept as masks: they only ever gate branches)
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
                     const uint32_t rec = recs[u];
                     const uint64_t heads = __builtin_amdgcn_ballot_w64((int32_t)rec < 0);
                     // owner = heads at or below the lane - 1 = (head bit 0 + heads before the chunk - 1: scalar) + (bits 1..l:
                     // v_mbcnt over the head bits shifted down by one); the scalar part goes into the LDS address
-                    klp[u] = L.kl + (segs_before + (uint32_t)(heads & 1u) - 1u);
-                    Sp[u] = L.S + (segs_before + (uint32_t)(heads & 1u) - 1u);
+                    uint32_t sbase = segs_before + (uint32_t)(heads & 1u) - 1u;
+                    asm volatile("" : "+s"(sbase)); // (kept whole: the -1 otherwise travels into a vector add per chunk)
+                    klp[u] = L.kl + sbase;
+                    Sp[u] = L.S + sbase;
                     const uint64_t above0 = heads >> 1;
                     own[u] = __builtin_amdgcn_mbcnt_hi((uint32_t)(above0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)above0, 0u));
                     segs_before += (uint32_t)__builtin_popcountll(heads);
-                    // bases: code (b >> 1) & 3 = A C T G -> 0 1 2 3; a byte is one of the four iff it equals its code's letter
-                    const uint32_t gb = rec & 0xFFu, rb = (rec >> 8) & 0xFFu;
-                    const uint32_t gc8 = (rec << 2) & 0x18u;
+                    // bases: code (b >> 1) & 3 = A C T G -> 0 1 2 3; a byte is one of the four iff it equals its code's letter.
+                    // Both bytes at once: the two codes select their letters out of "ACTG" (v_perm_b32), and the pair of
+                    // letters is compared with the pair of bytes (process_mapping.cpp:62-63)
                     rc8[u] = (rec >> 6) & 0x18u;
                     const uint32_t letters = 0x47544341u; // "ACTG"
-                    valid[u] = __builtin_amdgcn_ubfe(letters, gc8, 8u) == gb && __builtin_amdgcn_ubfe(letters, rc8[u], 8u) == rb; // process_mapping.cpp:62-63
+                    const uint32_t want = __builtin_amdgcn_perm(letters, letters, (rec >> 1) & 0x0303u);
+                    uint64_t vmask; // (the compiler has no 16-bit compare of two registers' low halves; SDWA does it in one)
+                    asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0" : "=s"(vmask) : "v"(want), "v"(rec));
+                    valid[u] = vmask;
                     int q = __builtin_amdgcn_sbfe((int)rec, 16u, 8u);
                     q = q < 0 ? 0 : (q > 99 ? 99 : q); // qscore_vec's index
                     // table row 2 q + (graph base == read base): the compare writes VCC, the add takes it as carry
@@ -506,24 +519,25 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                     // log1p(rho) by six terms below 2^-8 (the next, rho^7 / 7, is under 2e-18 there).  On HaploCart's own
                     // pairing of graph and read bases (update_likelihood.cpp:46) two columns in three are mismatches, i.e.
                     // rho = kappa * bg / e(Q) ~ 1e-3 for a confidently mapped read: this IS the common case.
-                    double p = wv_fma3(rho[u], 1.0 / 6.0, -0.2);
-                    p = wv_fma3(rho[u], p, 0.25);
-                    p = wv_fma3(rho[u], p, -1.0 / 3.0);
+                    double p = wv_fma3s(rho[u], c6, -0.2);
+                    p = wv_fma3s(rho[u], p, 0.25);
+                    p = wv_fma3s(rho[u], p, -1.0 / 3.0);
                     p = fma(rho[u], p, 0.5);
                     p = fma(rho[u], -p, 1.0);
                     l0[u] = lo[u].lom + kl[u].lw;
                     t[u] = fma(rho[u], p, l0[u]);
-                    far |= valid[u] && !(rho[u] < 0.00390625);
+                    farm[u] = valid[u] & __builtin_amdgcn_ballot_w64(!(rho[u] < 0.00390625));
+                    far |= farm[u] != 0;
                 }
                 WV_COUNT(2, 1);
-                if (__builtin_amdgcn_ballot_w64(far) != 0) {
+                if (far) {
                     // Beyond (mapping quality below ~50, low mappability): log1p(rho) = log(u) + (rho - (u - 1)) / u with
                     // u = 1 + rho rounded, the log from the table in LDS (log_tab.h); a segment with wobs = 0 ({inf, wbg}:
                     // mapping quality 0) scores log(wbg * bg)
                     WV_COUNT(3, 1);
 #pragma unroll
                     for (int u = 0; u < N; ++u) {
-                        if (valid[u] && !(rho[u] < 0.00390625)) {
+                        if (__builtin_amdgcn_inverse_ballot_w64(farm[u])) {
                             const bool deg = !(fabs(kl[u].kappa) < 1e300);
                             double x = deg ? kl[u].lw * bgv[u] : 1.0 + rho[u];
                             const double corr = deg ? 0.0 : (rho[u] - (x - 1.0)) * __builtin_amdgcn_rcp(x);
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                 }
 #pragma unroll
                 for (int u = 0; u < N; ++u)
-                    if (valid[u]) unsafeAtomicAdd(&Sp[u][own[u]], t[u]);
+                    if (__builtin_amdgcn_inverse_ballot_w64(valid[u])) unsafeAtomicAdd(&Sp[u][own[u]], t[u]);
             };
             static_assert(NCH % WV_GROUP == 0, "whole groups");
             const wv_rsrc rs_cn = rsrc_cols(Tn, has_next);
