@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x76676131)
     ap.add_argument("--no-parity", action="store_true", help="accepted for old command lines; the parity diff is part of the cpu_baseline leg (--cpu-seconds 0 skips both)")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-read-mode kernel measurement")
+    ap.add_argument("--sb-paths", type=int, default=28, help="soibean path: paths of the synthetic tree (28: BASELINE config 5's shape; 210: the size of soibean_db.clade)")
     ap.add_argument("--clades", type=int, default=335, help="euka path: number of clades the synthetic reads spread over")
     ap.add_argument("--dist-backend", default="auto", help="auto: nccl (= RCCL) when every rank has a GPU of its own, else gloo with ranks sharing GPUs | nccl | gloo")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
@@ -274,7 +275,7 @@ def bench_soibean(args):
     from vgan_amd import haplocart as hc
     from vgan_amd import soibean as sb
     rank, world, local_rank, dev, backend, n_dev = pick_device(args)
-    g = hc.synth_graph(seed=args.seed, genome_len=16569, n_nodes=11000, n_paths=28)
+    g = hc.synth_graph(seed=args.seed, genome_len=16569, n_nodes=11000, n_paths=args.sb_paths)
     alns = hc.synth_reads(g, args.reads, seed=args.seed + 1000003 * rank, read_len=65, indel_rate=0.005, softclip_rate=0.01)
     dm = ek.Damage.from_text("", "")
     hb = sb.SbHostBatch(g, alns)
@@ -355,7 +356,7 @@ def bench_soibean(args):
             "unit": "reads*iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "soibean k=3, %d synthetic reads per GPU, 28-path tree, host Metropolis loop + GPU refresh per iteration" % args.reads,
+            "config": {"workload": "soibean k=3, %d synthetic reads per GPU, %d-path tree, host Metropolis loop + GPU refresh per iteration" % (args.reads, args.sb_paths),
                        "reads_per_gpu": R, "precompute_s": t_pre, "accepted": accepted},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": sb_traffic.get("bytes") if sb_traffic else None, "traffic_detail": sb_traffic,

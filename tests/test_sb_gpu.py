@@ -273,3 +273,32 @@ def test_vgan_soibean_cli_end_to_end(tmp_path):
     r = subprocess.run([exe, "soibean", "-g", gam, "--soibean_dir", str(db), "--dbprefix", "Synth", "--no-mcmc", "-o", str(tmp_path / "nm_")],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "Identified signature paths" in r.stderr and r.stderr.count("Initial log-likelihood") >= 1
+
+
+def test_column_kernel_equals_segment_kernel_bit_for_bit():
+    """sb_precompute_cols_kernel (a lane per column) against sb_precompute_kernel (a lane per segment): the same arithmetic
+    in the same order per value, so the tables are identical; reads beyond the column kernel's capacities (here: 300-column
+    reads among 60-column ones) are left to the segment kernel inside the same call."""
+    old = os.environ.get("VGAN_SB_PRECOMPUTE")
+    d = os.path.join(GOLD, "damageProfiles")
+    texts = (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    try:
+        for n_paths, read_len, seed in ((28, 60, 3), (28, 300, 4), (130, 80, 5), (64, 120, 6)):
+            g = hc.synth_graph(seed=seed, genome_len=5000, n_nodes=3300, n_paths=n_paths)
+            a = hc.synth_reads(g, 3000, seed=seed + 1, read_len=read_len, indel_rate=0.05, softclip_rate=0.05)
+            hb = sb.SbHostBatch(g, a)
+            tabs = {}
+            for which in ("segments", "columns"):
+                os.environ["VGAN_SB_PRECOMPUTE"] = which
+                ctx = sb.SbContext(g, ek.Damage.from_text(*texts), penalty=7)
+                bad = ctx.precompute(hb)
+                tabs[which] = ctx.read_tables() + (bad,)
+            for x, y in zip(tabs["segments"][:3], tabs["columns"][:3]):
+                assert x.dtype == y.dtype and np.array_equal(x.view(np.uint8), y.view(np.uint8)), (n_paths, read_len)
+            assert tabs["segments"][3] == tabs["columns"][3]
+            assert set(np.unique(tabs["columns"][2])) <= {0, 1}
+    finally:
+        if old is None:
+            os.environ.pop("VGAN_SB_PRECOMPUTE", None)
+        else:
+            os.environ["VGAN_SB_PRECOMPUTE"] = old

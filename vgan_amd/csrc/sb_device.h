@@ -6,6 +6,7 @@
 namespace vgan {
 
 constexpr uint32_t SB_MAX_PATHS = 256;
+constexpr uint8_t SB_OK_DEFERRED = 2; // (while the tables are built: a read the column kernel left to the segment kernel)
 constexpr uint32_t SB_NCNT = 25; // (reference base, read base) in {A, C, G, T, other}^2
 
 struct SbGraphDev {

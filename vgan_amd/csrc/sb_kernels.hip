@@ -14,6 +14,8 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "device_math.h"
 #include "sb_device.h"
@@ -38,7 +40,7 @@ template <int PP>
 __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDev g, SbBatchDev b, SbTablesDev t, uint32_t r_begin,
                                                                         uint32_t r_end, double *__restrict__ stage_pm,
                                                                         uint16_t *__restrict__ stage_cnt,
-                                                                        unsigned long long *n_bad) {
+                                                                        unsigned long long *n_bad, bool only_deferred) {
     __shared__ double qs_s[100];
     __shared__ SbSegLds seg_s[SBP_WAVES][64];
     for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = g.qscore[i];
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDe
     const uint32_t P = g.n_paths;
 
     for (uint32_t r = r_begin + blockIdx.x * SBP_WAVES + wave; r < r_end; r += gridDim.x * SBP_WAVES) {
+        if (only_deferred && t.ok[r] != SB_OK_DEFERRED) continue; // (the column kernel left this read to this one)
         const uint32_t s0 = b.read_seg_off[r], s1 = b.read_seg_off[r + 1];
         const uint32_t col0 = b.read_col_off[r];
         const uint32_t q0 = b.read_qual_off[r], QL = b.read_qual_off[r + 1] - q0;
@@ -166,6 +169,252 @@ __global__ __launch_bounds__(SBP_WAVES * 64) void sb_precompute_kernel(SbGraphDe
 #pragma unroll
                 for (int j = 0; j < (int)SB_NCNT; ++j) stage_cnt[(rl * SB_NCNT + j) * P + p] = (uint16_t)min(cnt[u][j], 65535u);
             }
+        }
+    }
+}
+
+// ---- the same tables, one lane per alignment column ----------------------------------------------------------------------
+// sb_precompute_kernel gives a lane to every edit-level SEGMENT and lets it walk its columns: the walk is as long as the
+// wave's longest segment while the average one has 1.4 columns, and the per-path pass adds all 25 pair counters of every
+// segment on P of 64 lanes.  Here a wave still owns a read, but
+//   A  lanes over the segments: their column ranges become SLOTS (slot = (segment, k), off_m = prefix sum of the lengths: the
+//      ranges of a reverse read step backwards and may overlap, slots do not), the damage row sums, the nodes' path masks;
+//   B  lanes over the slots: the column's supported / unsupported log terms (one log: the unsupported term is one of two
+//      table values per quality) and its pair index; the running read position of the penalty pattern is the segment's base
+//      index plus a rank difference (ballot + mbcnt over "read base is not a gap");
+//   C  lanes over the segments again: sup_m / uns_m summed in column order (a few adds per segment);
+//   D  lanes over the paths: pm[p] in segment order;
+//   E  lanes over (slot, path) pairs: one LDS counter add per supported regular column and path -- the 5x5 counts as a
+//      histogram instead of 25 adds per segment and path.
+// Same arithmetic in the same order per value as the segment kernel (bit-identical tables).  A read beyond the capacities
+// (SBC_CAPS segments, SBC_CAPT slots) is marked SB_OK_DEFERRED and taken by the segment kernel in a second launch.
+constexpr int SBC_WAVES = 4;
+constexpr int SBC_CAPS = 96, SBC_CAPT = 160;
+constexpr int SBC_DMG_POS = 40; // positions of the two damage profiles kept in LDS (beyond: read from HBM)
+struct SbcSeg {
+    uint32_t node;
+    uint16_t col, len;
+    int32_t bix;
+    uint16_t off, pad; // first slot
+};
+template <int MW> struct alignas(16) SbcSlice { // MW: 32-bit words of a node's path mask
+    union {
+        double rowsum[SBC_CAPS][4]; // phases A, B
+        struct {
+            double sup[SBC_CAPS], uns[SBC_CAPS]; // phases C, D
+        } su;
+    };
+    SbcSeg seg[SBC_CAPS];
+    uint32_t smask[SBC_CAPS][MW];
+    uint16_t slot[SBC_CAPT]; // owner segment | pair index << 8 (pair index SB_NCNT: no pair)
+    // behind it, sized by the launcher: {ls[CAPT], lu[CAPT], rank[CAPT]} (phases B, C), then the pair histogram in their place (E)
+};
+constexpr size_t SBC_TAIL_MIN = (size_t)SBC_CAPT * (8 + 8 + 2);
+inline size_t sbc_slice_bytes(size_t fixed, uint32_t hist_n) { return (fixed + std::max(SBC_TAIL_MIN, (size_t)hist_n * 4) + 15) & ~(size_t)15; }
+
+__device__ __forceinline__ uint32_t sbc_scan_incl(uint32_t v, int lane) { // wave64 inclusive prefix sum
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+template <int MWT>
+__global__ __launch_bounds__(SBC_WAVES * 64) void sb_precompute_cols_kernel(SbGraphDev g, SbBatchDev b, SbTablesDev t, uint32_t r_begin,
+                                                                            uint32_t r_end, double *__restrict__ stage_pm,
+                                                                            uint16_t *__restrict__ stage_cnt, unsigned long long *n_bad,
+                                                                            uint32_t ppad_log2, uint32_t pen_magic) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sbc_smem[];
+    __shared__ double qs_s[100], l1m_s[100], lq3_s[100]; // eps(Q), log(1 - eps), log(eps / 3)
+    __shared__ uint32_t fw_s[8];                            // findable paths, as mask words
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t P = g.n_paths, MW = g.mask_words;
+    const uint32_t ppad = 1u << ppad_log2, hist_n = SB_NCNT << ppad_log2;
+    using Slice = SbcSlice<MWT>;
+    const size_t tail_bytes = SBC_TAIL_MIN > (size_t)hist_n * 4 ? SBC_TAIL_MIN : (size_t)hist_n * 4;
+    const size_t slice_bytes = (sizeof(Slice) + tail_bytes + 15) & ~(size_t)15;
+    Slice &L = *reinterpret_cast<Slice *>(sbc_smem + (size_t)wave * slice_bytes);
+    uint8_t *tail = sbc_smem + (size_t)wave * slice_bytes + sizeof(Slice);
+    double *const ls_s = reinterpret_cast<double *>(tail), *const lu_s = ls_s + SBC_CAPT;
+    uint16_t *const rank_s = reinterpret_cast<uint16_t *>(lu_s + SBC_CAPT);
+    uint32_t *const hist = reinterpret_cast<uint32_t *>(tail); // [pair][ppad], once ls / lu / rank are dead
+    for (int i = threadIdx.x; i < 100; i += blockDim.x) {
+        const double e = g.qscore[i];
+        qs_s[i] = e;
+        l1m_s[i] = log_pos(1.0 - e);
+        lq3_s[i] = log_pos(e / 3.0);
+    }
+    if (threadIdx.x < 8) {
+        uint32_t w = 0;
+        for (uint32_t p = threadIdx.x * 32u; p < min(P, threadIdx.x * 32u + 32u); ++p) w |= (uint32_t)(g.findable[p] != 0) << (p & 31u);
+        fw_s[threadIdx.x] = w;
+    }
+    // per position of either profile and per row o: the row's diagonal element and its sum (what a segment needs of the two
+    // matrices at its base: damage.cpp:18-36 picks the row by the diagonals, getLCAfromGAM.h:338-348 needs the row's sum)
+    __shared__ double dg_s[SBC_DMG_POS][4], rs_s[SBC_DMG_POS][4];
+    const uint32_t n5 = g.n5, n3 = g.n3;
+    const bool dmg_lds = n5 + n3 <= (uint32_t)SBC_DMG_POS;
+    if (dmg_lds) {
+        for (uint32_t i = threadIdx.x; i < (n5 + n3) * 4u; i += blockDim.x) {
+            const uint32_t pos = i >> 2, o = i & 3u;
+            const double *row = (pos < n5 ? g.sub5p + 16u * pos : g.sub3p + 16u * (pos - n5)) + 4u * o;
+            dg_s[pos][o] = row[o];
+            rs_s[pos][o] = ((row[0] + row[1]) + row[2]) + row[3];
+        }
+    }
+    __syncthreads();
+    const uint32_t pen = (uint32_t)g.penalty;
+
+    for (uint32_t r = r_begin + blockIdx.x * SBC_WAVES + wave; r < r_end; r += gridDim.x * SBC_WAVES) {
+        const uint32_t s0 = b.read_seg_off[r], M = b.read_seg_off[r + 1] - s0;
+        const uint32_t col0 = b.read_col_off[r];
+        const uint32_t q0 = b.read_qual_off[r], QL = b.read_qual_off[r + 1] - q0;
+        const uint32_t Lseq = b.read_gseq_len[r], A = b.read_rseq_len[r];
+        const int dir = b.read_rev[r] != 0 ? -1 : 1;
+        const size_t rl = r - r_begin;
+        // ---- A: segments -> slots
+        bool bad = false;
+        uint32_t T = 0; // slots so far
+        if (M <= (uint32_t)SBC_CAPS) {
+            for (uint32_t m0 = 0; m0 < M; m0 += 64) {
+                const uint32_t m = m0 + lane;
+                const bool on = m < M;
+                const uint32_t len = on ? b.seg_len[s0 + m] : 0u;
+                const uint32_t incl = sbc_scan_incl(len, lane);
+                const uint32_t off = T + incl - len;
+                T += (uint32_t)__shfl((int)incl, 63, 64);
+                if (on && off + len <= (uint32_t)SBC_CAPT) {
+                    const uint32_t node = b.seg_node[s0 + m], col = b.seg_col[s0 + m];
+                    const int32_t bix = b.seg_base_ix[s0 + m];
+                    if (len > 0 && (uint32_t)bix >= Lseq) bad = true;
+                    const uint32_t nn = min((uint32_t)bix, Lseq - 1u);
+                    const uint32_t i5 = min(nn, n5 - 1u), i3 = min(Lseq - 1u - nn, n3 - 1u);
+                    if (dmg_lds) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) L.rowsum[m][o] = dg_s[i5][o] <= dg_s[n5 + i3][o] ? rs_s[i5][o] : rs_s[n5 + i3][o];
+                    } else {
+                        const double *m5 = g.sub5p + 16u * i5, *m3 = g.sub3p + 16u * i3;
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) { // sum_b post[b] = sum_o pre[o] * rowsum(M[o]) (getLCAfromGAM.h:338-348)
+                            const double *row5 = m5 + 4 * o, *row3 = m3 + 4 * o;
+                            const double *row = row5[o] <= row3[o] ? row5 : row3; // damage.cpp:18-36
+                            L.rowsum[m][o] = ((row[0] + row[1]) + row[2]) + row[3];
+                        }
+                    }
+                    L.seg[m] = SbcSeg{node, (uint16_t)col, (uint16_t)len, bix, (uint16_t)off, 0};
+                    const bool known = node != 0u && node < g.rows;
+                    const uint32_t *mrow = reinterpret_cast<const uint32_t *>(g.mask + (size_t)node * MW);
+#pragma unroll
+                    for (uint32_t w = 0; w < (uint32_t)MWT; ++w) L.smask[m][w] = (known && w < 2u * MW) ? (mrow[w] & fw_s[w]) : 0u;
+                    for (uint32_t k = 0; k < len; ++k) L.slot[off + k] = (uint16_t)m;
+                }
+            }
+        }
+        if (M > (uint32_t)SBC_CAPS || T > (uint32_t)SBC_CAPT) { // wave uniform: the segment kernel takes this read
+            if (lane == 0) t.ok[r] = SB_OK_DEFERRED;
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- B: slots
+        uint32_t rank_base = 0;
+        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+            const uint32_t sl = t0 + lane;
+            const bool on = sl < T;
+            const uint32_t m = on ? L.slot[sl] : 0u;
+            const SbcSeg sg = L.seg[m];
+            const uint32_t k = sl - sg.off, c = (uint32_t)sg.col + k;
+            const uint32_t gc = on ? b.graph_seq[col0 + c] : 0u;
+            const uint32_t rc = (on && c < A) ? b.read_seq[col0 + c] : 0u;
+            int q = (on && k < QL) ? (int)(int8_t)b.qual[q0 + k] : 0; // Q12: within-segment index
+            const uint64_t ng = __builtin_amdgcn_ballot_w64(on && rc != '-');
+            const uint32_t rank = rank_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(ng >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ng, 0u));
+            rank_base += (uint32_t)__builtin_popcountll(ng);
+            if (on) rank_s[sl] = (uint16_t)rank;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (on) {
+                const uint32_t before = rank - (uint32_t)rank_s[sg.off]; // read bases (not gaps) of the segment before this column
+                const int32_t bo = sg.bix + dir * (int32_t)before;     // baseOnRead of the unsupported walk (:515-519)
+                q = q < 0 ? 0 : (q > 99 ? 99 : q);
+                const double qs = qs_s[q];
+                double ls, lu;
+                uint32_t j = SB_NCNT; // no pair
+                if (gc == 'N' || rc == 'N') {
+                    ls = lu = SB_LOG_025;
+                } else if (gc == 'S' || rc == 'S') {
+                    ls = lu = lq3_s[q];
+                } else if (gc == '-' || rc == '-') {
+                    ls = lu = SB_LOG_002;
+                } else {
+                    const int gi = acgt5(gc);
+                    double p = 0.0;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) p += (o == gi ? 1.0 - qs : qs / 3.0) * L.rowsum[m][o];
+                    ls = log_pos(p);
+                    if (ls > SB_LOG_CLAMP) ls = SB_LOG_CLAMP; // :349-351
+                    const uint32_t ab = (uint32_t)(bo < 0 ? -bo : bo);
+                    // ab % PENALTY (:473-512) by the launcher's reciprocal (exact for ab < 2^16: |bo| <= base index + columns)
+                    const uint32_t quo = pen == 1u ? ab : (ab < 65536u ? __umulhi(ab, pen_magic) : ab / pen);
+                    lu = (ab - quo * pen == 0u) ? l1m_s[q] : lq3_s[q];
+                    j = (uint32_t)(gi * 5 + acgt5(rc));
+                }
+                ls_s[sl] = ls;
+                lu_s[sl] = lu;
+                L.slot[sl] = (uint16_t)(m | (j << 8));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- C: per segment, in column order (rowsum is dead: sup / uns take its place)
+        for (uint32_t m0 = 0; m0 < M; m0 += 64) {
+            const uint32_t m = m0 + lane;
+            double sup = 0.0, uns = 0.0;
+            if (m < M) {
+                const SbcSeg sg = L.seg[m];
+                for (uint32_t k = 0; k < sg.len; ++k) {
+                    sup += ls_s[sg.off + k];
+                    uns += lu_s[sg.off + k];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (every lane of the pass has read its rowsum-free inputs)
+            if (m < M) {
+                L.su.sup[m] = sup;
+                L.su.uns[m] = uns;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = lane; i < hist_n; i += 64) hist[i] = 0u; // (ls / lu / rank are dead)
+        // ---- D: per path, in segment order
+        for (uint32_t p = lane; p < P; p += 64) {
+            double pm = 0.0;
+            const uint32_t w = MWT == 1 ? 0u : p >> 5, bit = p & 31u;
+            for (uint32_t m = 0; m < M; ++m) pm += ((L.smask[m][w] >> bit) & 1u) ? L.su.sup[m] : L.su.uns[m];
+            stage_pm[rl * P + p] = pm;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- E: (slot, path) pairs
+        const uint32_t n_pairs = T << ppad_log2;
+        for (uint32_t i = lane; i < n_pairs; i += 64) {
+            const uint32_t sl = i >> ppad_log2, p = i & (ppad - 1u);
+            const uint32_t rec = L.slot[sl], j = rec >> 8;
+            if (j < SB_NCNT && ((L.smask[rec & 0xFFu][MWT == 1 ? 0u : p >> 5] >> (p & 31u)) & 1u)) atomicAdd(&hist[(j << ppad_log2) + p], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // read-major staging rows (see sb_precompute_kernel): [read][pair][path]
+        for (uint32_t h = lane; h < hist_n; h += 64) {
+            const uint32_t j = h >> ppad_log2, p = h & (ppad - 1u);
+            if (p < P) stage_cnt[(rl * SB_NCNT + j) * P + p] = (uint16_t)min(hist[h], 65535u);
+        }
+        bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) {
+            t.ok[r] = bad ? 0 : 1;
+            if (bad) atomicAdd(n_bad, 1ull);
         }
     }
 }
@@ -500,13 +749,32 @@ void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTabl
                           uint32_t chunk_reads, unsigned long long *n_bad, hipStream_t st) {
     if (b.n_reads == 0) return;
     const uint32_t pp = (g.n_paths + 63) / 64, P = g.n_paths;
+    uint32_t ppad_log2 = 0;
+    while ((1u << ppad_log2) < P) ++ppad_log2;
+    const int mw32 = P <= 32 ? 1 : 2; // 32-bit words of a node's path mask the column kernel keeps
+    const size_t slice = sbc_slice_bytes(mw32 == 1 ? sizeof(SbcSlice<1>) : sizeof(SbcSlice<2>), SB_NCNT << ppad_log2);
+    const uint32_t pen = (uint32_t)std::max(1, g.penalty);
+    const uint32_t pen_magic = pen == 1 ? 0xFFFFFFFFu : (uint32_t)((0x100000000ull + pen - 1) / pen); // floor(x / pen) = mulhi(x, magic), x < 2^16
+    const char *force = getenv("VGAN_SB_PRECOMPUTE"); // developer aid / tests: "segments" keeps every read on the segment kernel
+    // up to 64 paths: the pair histogram is 25 x 64 counters and a (slot, path) sweep at most one step per column.  Beyond
+    // (210 paths measured: 32.4 ms per 500k reads against the segment kernel's 29.8) the segment kernel keeps the reads.
+    const bool cols = !(force && !strcmp(force, "segments")) && P <= 64u && slice * SBC_WAVES <= 60u * 1024u;
     for (uint32_t r0 = 0; r0 < b.n_reads; r0 += chunk_reads) {
         const uint32_t r1 = std::min(b.n_reads, r0 + chunk_reads), n = r1 - r0;
+        if (cols) { // a lane per column; the reads beyond its capacities are left marked for the kernel below
+            const uint32_t cblocks = std::min((n + SBC_WAVES - 1) / SBC_WAVES, 256u * 16u);
+            if (mw32 == 1)
+                hipLaunchKernelGGL(sb_precompute_cols_kernel<1>, dim3(cblocks), dim3(SBC_WAVES * 64), slice * SBC_WAVES, st, g, b, t, r0, r1, stage_pm,
+                                   stage_cnt, n_bad, ppad_log2, pen_magic);
+            else
+                hipLaunchKernelGGL(sb_precompute_cols_kernel<2>, dim3(cblocks), dim3(SBC_WAVES * 64), slice * SBC_WAVES, st, g, b, t, r0, r1, stage_pm,
+                                   stage_cnt, n_bad, ppad_log2, pen_magic);
+        }
         const uint32_t blocks = std::min((n + SBP_WAVES - 1) / SBP_WAVES, 256u * 8u);
-        if (pp <= 1) hipLaunchKernelGGL(sb_precompute_kernel<1>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad);
-        else if (pp == 2) hipLaunchKernelGGL(sb_precompute_kernel<2>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad);
-        else if (pp == 3) hipLaunchKernelGGL(sb_precompute_kernel<3>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad);
-        else hipLaunchKernelGGL(sb_precompute_kernel<4>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad);
+        if (pp <= 1) hipLaunchKernelGGL(sb_precompute_kernel<1>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad, cols);
+        else if (pp == 2) hipLaunchKernelGGL(sb_precompute_kernel<2>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad, cols);
+        else if (pp == 3) hipLaunchKernelGGL(sb_precompute_kernel<3>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad, cols);
+        else hipLaunchKernelGGL(sb_precompute_kernel<4>, dim3(blocks), dim3(SBP_WAVES * 64), 0, st, g, b, t, r0, r1, stage_pm, stage_cnt, n_bad, cols);
         hipLaunchKernelGGL(sb_transpose_kernel<double>, dim3((n + 63) / 64, (P + 63) / 64), dim3(256), 0, st, stage_pm, t.pm, n, P, P, 1u, r0, t.n_reads);
         hipLaunchKernelGGL(sb_transpose_kernel<uint16_t>, dim3((n + 63) / 64, (P * SB_NCNT + 63) / 64), dim3(256), 0, st, stage_cnt, t.cnt, n,
                            P * SB_NCNT, P, SB_NCNT, r0, t.n_reads);
