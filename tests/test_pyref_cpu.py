@@ -63,3 +63,106 @@ def test_the_cpp_oracle_agrees_with_the_python_restatement():
         for rec in want["first_reads"]:
             rc, vec, _ = orc.hc_read(og, oa, kept.index(rec["read"]), **kw)
             assert rc == 0 and util.rel_err(vec.astype(np.float64), np.array([float(x) for x in rec["loglik"]])) < 1e-13
+
+
+# ------------------------------------------------------------------------------------------------------------------- euka
+EFIX = os.path.join(HERE, "golden", "euka_pyref")
+
+
+def _euka_inputs():
+    from vgan_amd import euka as ek
+    from vgan_amd import haplocart as hc
+    g = hc.Graph.load(os.path.join(EFIX, "graph.gfa"))
+    db = ek.EukaDb.load(os.path.join(EFIX, "euka_db.clade"), os.path.join(EFIX, "euka_db.bins"))
+    a = hc.AlnSet.read_gam(os.path.join(EFIX, "reads.gam"), keep_unmapped=True)
+    texts = (open(os.path.join(EFIX, "damage5p.prof")).read(), open(os.path.join(EFIX, "damage3p.prof")).read())
+    return g, db, a, texts
+
+
+def check_euka_against_fixture(got, fin, want, read_index, tol):
+    """got: per-read arrays indexed by k, read_index[k] = alignment number; fin: the sums; want: the fixture of one run."""
+    recs = {x["read"]: x for x in want["reads"]}
+    assert not want["undefined_reads"] and len(recs) == len(read_index)
+    for k, r in enumerate(read_index):
+        x = recs[int(r)]
+        assert int(got["clade"][k]) == x["clade"] and bool(got["pass"][k]) == x["pass"], r
+        for key in ("in_lik", "out_lik", "like"):
+            ref = float(x[key])
+            assert abs(got[key][k] - ref) <= tol * max(abs(ref), 1e-300), (r, key)
+        assert abs(got["not_like"][k] - float(x["not_like"])) <= 1e-12
+    assert list(fin["clade_count"]) == want["clade_count"]
+    assert np.array_equal(np.asarray(fin["baseshift"]), np.array(want["baseshift"], np.uint32))
+    flat = np.array([float(v) for b in want["bin_cov"] for v in b])
+    assert np.allclose(np.asarray(fin["bin_cov"]), flat, rtol=1e-12, atol=1e-12)
+
+
+def test_euka_restatement_recomputes_its_fixture_on_a_sample():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pyref_euka as pe
+    fix = json.load(open(os.path.join(EFIX, "euka_pyref.json")))["default"]
+    seqs = pe.load_gfa(os.path.join(EFIX, "graph.gfa"))
+    clades, chunks = pe.load_clades(os.path.join(EFIX, "euka_db.clade")), pe.load_bins(os.path.join(EFIX, "euka_db.bins"))
+    dmg = pe.DamageModel(open(os.path.join(EFIX, "damage5p.prof")).read(), open(os.path.join(EFIX, "damage3p.prof")).read())
+    alns = gamio.read_gam(os.path.join(EFIX, "reads.gam"))
+    for rec in fix["reads"][:6]:
+        a = alns[rec["read"]]
+        c_n = pe.clade_of(chunks, a["path"]["mapping"][0]["position"]["node_id"])
+        gs, rs, _ = pe.reconstruct_graph_sequence(seqs, a["path"])
+        i, o = pe.read_models(a, gs, rs, clades[c_n]["dist"], dmg)
+        assert c_n == rec["clade"] and pe.mp.nstr(i, 25) == rec["in_lik"] and pe.mp.nstr(o, 25) == rec["out_lik"]
+
+
+def test_the_cpp_euka_oracle_agrees_with_the_python_restatement():
+    fix = json.load(open(os.path.join(EFIX, "euka_pyref.json")))
+    g, db, a, texts = _euka_inputs()
+    og = util.orc_graph_nodes_only(g)
+    oa = util.orc_alnset_from_product(a)
+    for key, (mq, ltp) in (("default", (29, 5)), ("other_thresholds", (0, 3))):
+        ref = orc.euka_run(og, oa, util.orc_euka_db_from_product(db), orc.OrcDamage(*texts), mq, ltp)
+        assert ref["n_bad"] == 0
+        idx = [x["read"] for x in fix[key]["reads"]]
+        got = {k: ref[k][idx] for k in ("clade", "in_lik", "out_lik", "like", "not_like", "pass")}
+        check_euka_against_fixture(got, ref, fix[key], idx, 1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------------------- soibean
+SFIX = os.path.join(HERE, "golden", "sb_pyref")
+
+
+def _sb_inputs():
+    from vgan_amd import haplocart as hc
+    g = hc.Graph.load(os.path.join(SFIX, "graph.gfa"), SFIX)
+    a = hc.AlnSet.read_gam(os.path.join(SFIX, "reads.gam"), keep_unmapped=True)
+    texts = (open(os.path.join(SFIX, "damage5p.prof")).read(), open(os.path.join(SFIX, "damage3p.prof")).read())
+    return g, a, texts
+
+
+def test_soibean_restatement_recomputes_its_fixture_on_a_sample():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pyref_sb as ps
+    fix = json.load(open(os.path.join(SFIX, "sb_pyref.json")))["default"]
+    seqs, names, node_paths, dmg = ps.load_inputs(SFIX)
+    alns = gamio.read_gam(os.path.join(SFIX, "reads.gam"))
+    for rec in fix["reads"][:3]:
+        pm, _ = ps.analyse_read(seqs, node_paths, names, alns[rec["read"]], dmg, 7)
+        assert [ps.mp.nstr(x, 25) for x in pm] == rec["pm"]
+
+
+def test_the_cpp_soibean_oracle_agrees_with_the_python_restatement():
+    fix = json.load(open(os.path.join(SFIX, "sb_pyref.json")))["default"]
+    g, a, texts = _sb_inputs()
+    og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
+    findable = np.array([len(n) <= 101 for n in g.path_names], np.uint8)
+    o = orc.SbOracle(og, oa, orc.OrcDamage(*texts), penalty=fix["params"]["penalty"], path_findable=findable)
+    assert o.n_bad == 0 and not fix["undefined_reads"]
+    for rec in fix["reads"]:
+        r = rec["read"]
+        assert o.ok(r)
+        assert util.rel_err(o.pathmap(r), np.array([float(x) for x in rec["pm"]])) < 1e-13, r
+        for p in range(g.n_paths):
+            c, _ = o.counts(r, p)
+            assert list(c) == rec["cnt"][p], (r, p)
+    assert sum(o.ok(r) for r in range(a.n_reads)) == len(fix["reads"])
+    for st in fix["states"]:
+        rc, ll = o.loglike([tuple(s) for s in st["sources"]], st["con"], fix["params"]["freqs"])
+        assert rc == 0 and abs(ll - float(st["loglike"])) <= 1e-12 * abs(float(st["loglike"]))

@@ -46,3 +46,45 @@ def test_final_vector_per_read_vectors_and_posteriors_against_the_python_restate
         k = src.index(kept.index(rec["read"]))
         ref = np.array([float(x) for x in rec["loglik"]])
         assert np.max(np.abs(ll[k] - ref) / np.abs(ref)) < 1e-11, rec["read"]
+
+
+def test_euka_per_read_models_and_sums_against_the_python_restatement():
+    """tools/pyref_euka.py's fixture (tests/golden/euka_pyref/): clade, model 1 / model 2 log-likelihoods, clade_like, the
+    detection rule per read; counts, base-shift table and bin coverage per clade."""
+    from test_pyref_cpu import _euka_inputs, check_euka_against_fixture, EFIX
+    from vgan_amd import euka as ek
+    fix = json.load(open(os.path.join(EFIX, "euka_pyref.json")))
+    g, db, a, texts = _euka_inputs()
+    for key, (mq, ltp) in (("default", (29, 5)), ("other_thresholds", (0, 3))):
+        hb = ek.EukaHostBatch(g, a)
+        assert hb.stats.n_bad == 0
+        ctx = ek.EukaContext(db, ek.Damage.from_text(*texts), min_mapq=mq, length_to_prof=ltp)
+        got = ctx.accumulate(hb)
+        fin = ctx.finalize()
+        assert fin["n_bad"] == 0
+        check_euka_against_fixture(got, fin, fix[key], list(hb.arrays()["read_src"]), 1e-9)
+
+
+def test_soibean_tables_and_state_likelihoods_against_the_python_restatement():
+    """tools/pyref_sb.py's fixture (tests/golden/sb_pyref/): pathMap and the (reference, read) pair counts per read and path,
+    and the log-likelihood of k = 1 and k = 3 states computed by the restatement from the per-base records themselves."""
+    from test_pyref_cpu import _sb_inputs, SFIX
+    from vgan_amd import euka as ek
+    from vgan_amd import soibean as sb
+    fix = json.load(open(os.path.join(SFIX, "sb_pyref.json")))["default"]
+    g, a, texts = _sb_inputs()
+    hb = sb.SbHostBatch(g, a)
+    assert hb.stats.n_bad == 0 and hb.n_reads == len(fix["reads"])
+    ctx = sb.SbContext(g, ek.Damage.from_text(*texts), penalty=fix["params"]["penalty"])
+    assert ctx.precompute(hb) == 0
+    pm, cnt, ok = ctx.read_tables()
+    assert ok.all()
+    recs = {x["read"]: x for x in fix["reads"]}
+    for k, r in enumerate(hb.arrays()["read_src"]):
+        x = recs[int(r)]
+        ref = np.array([float(v) for v in x["pm"]])
+        assert np.max(np.abs(pm[:, k] - ref) / np.abs(ref)) < 1e-9, r
+        assert np.array_equal(cnt[:, :, k].astype(np.int64), np.array(x["cnt"])), r
+    for st in fix["states"]:
+        got, guard = ctx.loglike([[tuple(s) for s in st["sources"]]], st["con"], fix["params"]["freqs"])
+        assert guard[0] == 0 and got[0] == pytest.approx(float(st["loglike"]), rel=1e-9)

@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""A second, independent restatement of soibean's per-read path -- Python + mpmath (40 digits), written from the reference's
+sources, NOT from oracle/ (see tools/pyref_hc.py for why; the alignment reconstruction and the readers are shared with it,
+the damage matrices with tools/pyref_euka.py).
+
+What it follows (paths under /root/reference/src/):
+    getLCAfromGAM.h:92-560     analyse_GAM: the edit-level segments of a read (mppg_sizes; those beyond the mappings are
+                               "No_support"), the slice of the reconstructed sequences a segment takes on either strand, and
+                               per path the supported walk (N / soft clip / gap constants, else the damage-marginalised
+                               probability of the graph base at the SEGMENT's base index, clamped at log(0.9999999)) or the
+                               unsupported walk (log(1 - e) on every PENALTY-th read position, log(e / 3) elsewhere) -- the
+                               read's pathMap and its per-base records (reference base, read base, pathSupport)
+    getLCAfromGAM.h:80-88      path names cut at 101 characters: a longer name is never found among a node's paths
+    MCMC.h:66,108-296          computeBaseLogLike: HKY with kappa = 1 / 22 = 0 (integer division), floors at 1e-8, the
+                               marginal over the read base with the error rate `con`, the cap log(0.999999999)
+    MCMC.h:298-312             calculateLogWeightedAverage
+    MCMC.cpp:738-993           the likelihood of a state: per read child and parent sums over the per-base records, mixed over the
+                               branch position (k = 1) or over branch position and sources (k > 1)
+    Euka.cpp:38-52             qscore_vec
+    damage.cpp                 tools/pyref_euka.py
+
+The outputs are the factorised form the product keeps: pm[path] = pathMap, cnt[path][5 x 5] = the
+(reference, read) pairs of the records with pathSupport -- and the state log-likelihoods computed from the per-base records
+themselves, as the reference does.
+
+Undefined in the reference, refused here ("undefined_reads"): a quality index past the quality string or a quality >= 100,
+a fragment whose |graph_seq| is below 15 or above 1000, a base index at or past it on a supported regular column, substr
+past the end, a node without path list.
+
+Usage (build container only):
+    python tools/pyref_sb.py --make tests/golden/sb_pyref
+    python tools/pyref_sb.py --run DIR [--out FILE]
+"""
+import argparse
+import json
+import os
+import sys
+
+import mpmath as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+import gamio  # noqa: E402
+from pyref_hc import Undefined, load_gfa, reconstruct_graph_sequence, signed_char, substr  # noqa: E402
+from pyref_euka import DamageModel, qscore, MINLENGTHFRAGMENT, MAXLENGTHFRAGMENT  # noqa: E402
+
+mp.mp.dps = 40
+
+
+def D(x):
+    """A literal of the C++ source: the double it is there, not the decimal it is written as (log(0.9999999) differs from the
+    log of the decimal by 1e-9 relative)."""
+    return mp.mpf(float(x))
+ACGT = "ACGT"
+NEG_INF = mp.mpf("-inf")
+
+
+def oplus(x, y):  # libgab oplusnatl
+    hi, lo = (x, y) if x > y else (y, x)
+    if lo == NEG_INF:
+        return hi
+    return hi + mp.log1p(mp.exp(lo - hi))
+
+
+def oplus_init(x, y):  # libgab oplusInitnatl
+    return y if x == 0 else oplus(x, y)
+
+
+def pair_class(c):
+    return ACGT.index(c) if c in ACGT else 4
+
+
+# ---------------------------------------------------------------------------------------------------------- analyse_GAM
+def analyse_read(seqs, node_paths, path_names, aln, dmg, penalty):
+    """pathMap[p] and records[p] = list of (reference base, read base, pathSupport, logLikelihood) in the reference's order."""
+    maps = aln["path"]["mapping"]
+    if not maps:
+        raise Undefined("no mapping")
+    qual = aln["quality"]
+    rev = maps[0]["position"]["is_reverse"]
+    graph_seq, read_seq, sizes = reconstruct_graph_sequence(seqs, aln["path"])
+    base_ix = len(aln["sequence"]) - 1 if rev else 0  # :107
+    Lseq = len(graph_seq)
+    names = [n[:101] for n in path_names]  # :80-88 (pathNames is resized in place)
+    P = len(names)
+    path_map = [mp.mpf(0)] * P
+    records = [[] for _ in range(P)]
+
+    def quality(s):
+        if s > len(qual):
+            raise Undefined("quality index %d past a string of %d" % (s, len(qual)))
+        q = signed_char(qual[s]) if s < len(qual) else 0
+        if q < 0 or q >= 100:
+            raise Undefined("qscore_vec[%d]" % q)
+        return qscore(q)
+
+    for i, size in enumerate(sizes):
+        if len(sizes) != len(maps) and i >= len(maps):  # :156-160
+            prob_paths = ["No_support"]
+        else:
+            nid = maps[i]["position"]["node_id"]
+            if nid not in node_paths:
+                raise Undefined("nodepaths.at(%d)" % nid)
+            prob_paths = node_paths[nid]
+        if rev:  # :179-186
+            start = base_ix - size - 1 if base_ix - size - 1 >= 0 else 0
+        else:
+            start = base_ix
+        node_seq, part = substr(graph_seq, start, size), substr(read_seq, start, size)
+        if len(part) + 1 < len(node_seq):
+            raise Undefined("partReadSeq[%d] past a string of %d" % (len(part) + 1, len(part)))
+        for m in range(P):
+            on_read = base_ix
+            if names[m] in prob_paths:
+                for s in range(len(node_seq)):
+                    g = node_seq[s]
+                    r = part[s] if s < len(part) else "\0"
+                    e = quality(s)
+                    if g == "N" or r == "N":
+                        ll, sup = mp.log(D(0.25)), False
+                    elif g == "S" or r == "S":
+                        ll, sup = mp.log(e / 3), False
+                    elif g == "-" or r == "-":
+                        ll, sup = mp.log(D(0.02)), False
+                    else:
+                        pre = [(1 - e) if ACGT[o] == g else e / 3 for o in range(4)]
+                        if Lseq < MINLENGTHFRAGMENT or Lseq > MAXLENGTHFRAGMENT or base_ix < 0 or base_ix >= Lseq:
+                            raise Undefined("subDeamDiNuc[%d][%d]" % (Lseq, base_ix))
+                        post = [mp.mpf(0)] * 4
+                        for d in range(4):
+                            for o in range(4):
+                                post[d] += pre[o] * dmg.row(Lseq, base_ix, o)[d]
+                        ll = NEG_INF
+                        for d in range(4):
+                            ll = oplus_init(ll, mp.log(post[d]))
+                        if ll > mp.log(D(0.9999999)):
+                            ll = mp.log(D(0.9999999))
+                        sup = True
+                    path_map[m] += ll
+                    records[m].append((g, r, sup, ll))
+            else:
+                for s in range(len(node_seq)):
+                    g = node_seq[s]
+                    r = part[s] if s < len(part) else "\0"
+                    e = quality(s)
+                    if g == "N" or r == "N":
+                        ll = mp.log(D(0.25))
+                    elif g == "S" or r == "S":
+                        ll = mp.log(e / 3)
+                    elif g == "-" or r == "-":
+                        ll = mp.log(D(0.02))
+                    elif abs(on_read) % penalty == 0:
+                        ll = mp.log(1 - e)
+                    else:
+                        ll = mp.log(e / 3)
+                    path_map[m] += ll
+                    records[m].append((g, "-", False, ll))
+                    if r != "-":
+                        on_read += -1 if rev else 1
+        if rev:  # :537-544
+            base_ix = start
+        else:
+            base_ix += size
+    return path_map, records
+
+
+# -------------------------------------------------------------------------------------------------------- the likelihood
+def hky_log(ref, read, t, con, freqs):
+    """computeBaseLogLike without the record's own logLikelihood (MCMC.h:108-290)."""
+    fA, fC, fG, fT, fR, fY, mu = freqs
+    F = {"A": fA, "C": fC, "G": fG, "T": fT}
+    kappa = mp.mpf(0)  # MCMC.h:66: 1 / 22 in integers
+    prob = []
+    for rb in ACGT:
+        grp = fR if rb in "AG" else fY
+        A = 1 + grp * (kappa - 1)
+        if rb == ref:
+            p = F[rb] + F[rb] * ((1 / grp) - 1) * mp.exp(-(mu * t)) + ((grp - F[rb]) / grp) * mp.exp(-(mu * t * A))
+        elif {rb, ref} in ({"A", "G"}, {"C", "T"}):
+            j1 = F[rb] + F[rb] * ((1 / grp) - 1) * mp.exp(-(mu * t))
+            j11 = (F[rb] / grp) * mp.exp(-(mu * t * A))
+            p = j1 - j11 if j1 > j11 else j11 - j1
+        else:
+            p = F[rb] * (1 - mp.exp(-(mu * t)))
+        if p < D(1e-8):
+            p = D(1e-8)
+        prob.append(p)
+    ll = NEG_INF
+    for d in range(4):
+        ll = oplus_init(ll, mp.log(prob[d]) + (mp.log(1 - con) if ACGT[d] == read else mp.log(con / 3)))
+    if ll > D(1e-8):
+        ll = mp.log(D(0.999999999))
+    return ll
+
+
+def read_sum(recs, t, con, freqs):
+    tot = mp.mpf(0)
+    for g, r, sup, ll in recs:
+        tot += (hky_log(g, r, t, con, freqs) + ll) if sup else ll
+    return tot
+
+
+def state_loglike(all_records, state, con, freqs):
+    """MCMC.cpp:738-993; state: list of (child, parent, dist, pos_branch, theta)."""
+    total = mp.mpf(0)
+    for records in all_records:
+        if len(state) == 1:
+            c, p, dist, pos, _ = state[0]
+            t = dist if dist != 0 else D(0.00001)
+            t1 = pos * t
+            t2 = t - t1
+            ll, llp = read_sum(records[c], t2, con, freqs), read_sum(records[p], t1, con, freqs)
+            a, b = ll + mp.log(pos), llp + mp.log(1 - pos)  # calculateLogWeightedAverage
+            hi = max(a, b)
+            total += hi + mp.log(mp.exp(a - hi) + mp.exp(b - hi)) - mp.log(pos + (1 - pos))
+        else:
+            inter = NEG_INF
+            for c, p, dist, pos, theta in state:
+                t = dist if dist != 0 else D(0.00001)
+                t1 = pos * t
+                t2 = t - t1
+                ll, llp = read_sum(records[c], t2, con, freqs), read_sum(records[p], t1, con, freqs)
+                inter2 = oplus(mp.log(pos) + ll, mp.log(1 - pos) + llp)
+                inter = oplus_init(inter, inter2 + mp.log(theta))
+            total += inter
+    return total
+
+
+# ------------------------------------------------------------------------------------------------------------------ runs
+FREQS = ["0.31", "0.27", "0.13", "0.29", "0.44", "0.56", "0.0012"]  # A C G T R Y M
+
+
+def load_inputs(d):
+    seqs = load_gfa(os.path.join(d, "graph.gfa"))
+    path_names = [ln.split()[0] for ln in open(os.path.join(d, "graph_paths")) if ln.split()]
+    node_paths = {}
+    for nid, ln in enumerate(open(os.path.join(d, "path_supports"))):  # row = node id (soibean.cpp:476-491 asks the graph itself)
+        if nid in seqs:
+            node_paths[nid] = [path_names[p] for p, c in enumerate(ln.rstrip("\n")) if c == "1" and p < len(path_names)]
+
+    def text(name):
+        p = os.path.join(d, name)
+        return open(p).read() if os.path.exists(p) else ""
+    return seqs, path_names, node_paths, DamageModel(text("damage5p.prof"), text("damage3p.prof"))
+
+
+def run(d, penalty=7):
+    seqs, path_names, node_paths, dmg = load_inputs(d)
+    states = json.load(open(os.path.join(d, "states.json")))
+    alns = gamio.read_gam(os.path.join(d, "reads.gam"))
+    reads, undefined, all_records = [], [], []
+    for r, a in enumerate(alns):
+        if a["identity"] == 0:  # :101
+            continue
+        try:
+            pm, recs = analyse_read(seqs, node_paths, path_names, a, dmg, penalty)
+        except Undefined as e:
+            undefined.append({"read": r, "why": str(e)})
+            continue
+        except KeyError as e:
+            undefined.append({"read": r, "why": "node %s" % e})
+            continue
+        cnt = []
+        for p in range(len(path_names)):
+            c = [0] * 25
+            for g, rb, sup, _ in recs[p]:
+                if sup:
+                    c[pair_class(g) * 5 + pair_class(rb)] += 1
+            cnt.append(c)
+        all_records.append(recs)
+        reads.append({"read": r, "pm": [mp.nstr(x, 25) for x in pm], "cnt": cnt})
+    freqs = [D(x) for x in FREQS]
+    lls = []
+    for st in states:
+        s = [(c, p, mp.mpf(repr(dist)), mp.mpf(repr(pos)), mp.mpf(repr(theta))) for c, p, dist, pos, theta in st["sources"]]
+        lls.append({"sources": st["sources"], "con": st["con"], "loglike": mp.nstr(state_loglike(all_records, s, mp.mpf(repr(st["con"])), freqs), 25)})
+    return {"n_alignments": len(alns), "params": {"penalty": penalty, "freqs": [float(x) for x in FREQS]}, "undefined_reads": undefined,
+            "reads": reads, "states": lls}
+
+
+def make(d):
+    """Inputs from the product's synthetic generator (host code, no GPU): a 12-path tree, reads of both strands with indels and
+    soft clips, one over-long path name; the reads the reference leaves undefined are taken out."""
+    from vgan_amd import haplocart as hc
+    os.makedirs(d, exist_ok=True)
+    gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
+    open(os.path.join(d, "damage5p.prof"), "w").write(open(gold + "/dhigh5p.prof").read())
+    open(os.path.join(d, "damage3p.prof"), "w").write(open(gold + "/dhigh3p.prof").read())
+    g0 = hc.synth_graph(seed=61, genome_len=900, n_nodes=500, n_paths=12)
+    names = g0.path_names
+    names[7] = "L" * 110  # never "found" among a node's paths
+    g = hc.Graph.from_arrays(g0.min_id, g0.max_id, g0.node_seq_off, g0.node_seq.tobytes(), 12, g0.mask, g0.pangenome_base,
+                             g0.mappability, "\n".join(names) + "\n", g0.parents_txt, g0.children_txt)
+    g.write(d)
+    import gzip
+    for f in ("path_supports",):
+        if os.path.exists(os.path.join(d, f + ".gz")):
+            open(os.path.join(d, f), "w").write(gzip.open(os.path.join(d, f + ".gz"), "rt").read())
+            os.remove(os.path.join(d, f + ".gz"))
+    a = hc.synth_reads(g0, 120, seed=62, read_len=50, indel_rate=0.1, softclip_rate=0.1)
+    tmp = os.path.join(d, "reads.gam")
+    a.write_gam(tmp)
+    alns = gamio.read_gam(tmp)
+    idx = {n: i for i, n in enumerate(g0.path_names)}
+    pairs = [(idx[t[0]], idx[t[1]]) for t in (ln.split() for ln in g0.parents_txt.splitlines()) if len(t) >= 2 and 7 not in (idx[t[0]], idx[t[1]])]
+    states = [{"sources": [[pairs[0][0], pairs[0][1], 0.03, 0.4, 1.0]], "con": 0.01},
+              {"sources": [[pairs[3][0], pairs[3][1], 0.0, 0.5, 1.0]], "con": 0.01},
+              {"sources": [[pairs[1][0], pairs[1][1], 0.03, 0.35, 0.5], [pairs[4][0], pairs[4][1], 0.011, 0.8, 0.3],
+                           [pairs[6][0], pairs[6][1], 0.04, 0.02, 0.2]], "con": 0.02}]
+    json.dump(states, open(os.path.join(d, "states.json"), "w"))
+    for _ in range(3):
+        und = {u["read"] for u in run(d)["undefined_reads"]}
+        if not und:
+            break
+        alns = [al for r, al in enumerate(alns) if r not in und]
+        open(tmp, "wb").write(gamio.write_gam(alns, group=40))
+    out = {"_what": "tools/pyref_sb.py: an independent Python + mpmath (40 digits) restatement of soibean's analyse_GAM tables and "
+                    "state likelihood on the inputs beside this file; NOT generated by oracle/ or by the product",
+           "default": run(d)}
+    json.dump(out, open(os.path.join(d, "sb_pyref.json"), "w"), indent=0)
+    print("wrote", d, "reads", len(out["default"]["reads"]), "undefined", len(out["default"]["undefined_reads"]),
+          [s["loglike"] for s in out["default"]["states"]])
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--make")
+    ap.add_argument("--run")
+    ap.add_argument("--out")
+    args = ap.parse_args()
+    if args.make:
+        make(args.make)
+    elif args.run:
+        json.dump(run(args.run), open(args.out, "w") if args.out else sys.stdout, indent=0)
