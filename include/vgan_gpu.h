@@ -150,6 +150,9 @@ int vgan_gam_stream_next(vgan_gam_stream *s, int64_t min_reads, vgan_alnparts **
 void vgan_gam_stream_close(vgan_gam_stream *s);
 /* The processors the host front end sizes its thread pools from: the smaller of the affinity mask and the cgroup CPU quota. */
 int vgan_host_cpus(void);
+/* Diagnostics (filled while VGAN_TIMING is set): CPU microseconds the front end's threads spent in inflate, frame + parse,
+ * flatten, and the caller's part of the batch merge, summed over the process. */
+void vgan_host_cpu_account(int64_t out[4]);
 /* Diagnostics of the BGZF decode pipeline, summed over the process: out[0] segments decoded, out[1] segments whose own
  * framing was taken from the group it started in, out[2] from a later group, out[3] framed by the serial walk alone,
  * out[4] messages joined in a buffer of their own (longer than a segment buffer's headroom). */

@@ -186,6 +186,7 @@ SYMBOLS = {
     "vgan_gam_stream_close": (None, [vp]),
     "vgan_gam_decode_counts": (None, [C.POINTER(C.c_int64)]),
     "vgan_host_cpus": (C.c_int, []),
+    "vgan_host_cpu_account": (None, [C.POINTER(C.c_int64)]),
     "vgan_dedup_create": (C.c_int, [C.POINTER(vp)]),
     "vgan_dedup_mark": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int64)]),
     "vgan_dedup_free": (None, [vp]),

@@ -3,7 +3,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <new>
@@ -155,6 +157,18 @@ struct PhaseTimer {
         t0 = t1;
     }
 };
+
+// CPU time of the calling thread, for the per-stage accounts VGAN_TIMING prints (the container's CPU quota makes the sum of
+// these, not any one stage's wall time, what a long input's throughput follows).
+inline double thread_cpu_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+struct CpuAccount { // process-wide sums, in microseconds
+    std::atomic<int64_t> inflate{0}, frame_parse{0}, flatten{0}, merge{0};
+};
+CpuAccount &cpu_account();
 
 } // namespace vgan
 

@@ -467,9 +467,16 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
             flatten_range(*g, a, it.r0, it.r1, skip ? skip + ps->first[it.part] : nullptr, ps->base + ps->first[it.part], chunks[i]);
         }
     };
-    parallel_run(n_threads, [&](int) { work(); });
+    parallel_run(n_threads, [&](int) {
+        const double c0 = pt.on ? thread_cpu_ms() : 0;
+        work();
+        if (pt.on) cpu_account().flatten += (int64_t)((thread_cpu_ms() - c0) * 1e3);
+    });
     pt.lap("chunks");
-    return merge_chunks(chunks, pt, out, stats);
+    const double m0 = pt.on ? thread_cpu_ms() : 0;
+    const int rc = merge_chunks(chunks, pt, out, stats);
+    if (pt.on) cpu_account().merge += (int64_t)((thread_cpu_ms() - m0) * 1e3); // (the calling thread's share: the serial part)
+    return rc;
 }
 
 extern "C" int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out) {

@@ -558,6 +558,18 @@ struct SegPipe {
     }
 
     void do_segment(Seg &s) {
+        const bool acct = pt.on;
+        const double c0 = acct ? thread_cpu_ms() : 0;
+        struct Acct {
+            bool on;
+            double c0, c1 = 0;
+            ~Acct() {
+                if (!on) return;
+                const double c2 = thread_cpu_ms();
+                cpu_account().inflate += (int64_t)(((c1 ? c1 : c2) - c0) * 1e3);
+                if (c1) cpu_account().frame_parse += (int64_t)((c2 - c1) * 1e3);
+            }
+        } ac{acct, c0};
         for (size_t b = s.b0; b < s.b1; ++b) {
             const BgzfBlock &bl = blocks[b];
             if (!inflate_member(in + bl.in_off, bl.in_size, s.data() + (bl.out_off - s.out_off), bl.out_size)) {
@@ -565,6 +577,7 @@ struct SegPipe {
                 return;
             }
         }
+        if (acct) ac.c1 = thread_cpu_ms();
         frame_segment(s);
         if (s.msgs.empty()) return;
         const uint8_t *d = s.data();
@@ -588,7 +601,9 @@ struct SegPipe {
                 Entry *en = &entries[head_tasks.front()]; // element addresses are stable while entries are appended
                 head_tasks.pop_front();
                 lk.unlock();
+                const double hc0 = pt.on ? thread_cpu_ms() : 0;
                 const bool good = parse_msgs(en->msgs.data(), en->msgs.size(), en->a);
+                if (pt.on) cpu_account().frame_parse += (int64_t)((thread_cpu_ms() - hc0) * 1e3);
                 std::vector<Msg>().swap(en->msgs);
                 release(*en->seg);
                 lk.lock();

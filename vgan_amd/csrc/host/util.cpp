@@ -359,6 +359,11 @@ bool read_file(const std::string &path, std::string &out, bool inflate_if_gzip) 
     return true;
 }
 
+CpuAccount &cpu_account() {
+    static CpuAccount a;
+    return a;
+}
+
 unsigned usable_cpus() {
     static const unsigned n = [] {
         unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -397,6 +402,14 @@ unsigned burst_cpus() {
 
 } // namespace vgan
 extern "C" int vgan_host_cpus(void) { return (int)vgan::usable_cpus(); }
+extern "C" void vgan_host_cpu_account(int64_t out[4]) {
+    if (!out) return;
+    vgan::CpuAccount &a = vgan::cpu_account();
+    out[0] = a.inflate;
+    out[1] = a.frame_parse;
+    out[2] = a.flatten;
+    out[3] = a.merge;
+}
 namespace vgan {
 
 namespace {

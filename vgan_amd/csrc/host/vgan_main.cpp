@@ -512,6 +512,14 @@ int haplocart(int argc, char **argv) {
     }
     pt.lap("posterior + output");
     stamp("output written");
+    if (getenv("VGAN_TIMING")) {
+        int64_t acc[4] = {0, 0, 0, 0};
+        vgan_host_cpu_account(acc);
+        timespec pts;
+        clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &pts);
+        fprintf(stderr, "[vgan timing] haplocart CPU: inflate %.0f ms, frame + parse %.0f ms, flatten %.0f ms, merge (caller) %.0f ms; the process %.0f ms; %d processors usable\n",
+                acc[0] * 1e-3, acc[1] * 1e-3, acc[2] * 1e-3, acc[3] * 1e-3, pts.tv_sec * 1e3 + pts.tv_nsec * 1e-6, vgan_host_cpus());
+    }
     if (getenv("VGAN_TIMING")) { // resident anonymous memory the kernel has to take apart when the process ends
         if (FILE *f = fopen("/proc/self/status", "r")) {
             char line[256];
