@@ -80,9 +80,25 @@ def test_euka_one_million_reads():
     assert np.allclose(fin2["bin_cov"], fin["bin_cov"], rtol=1e-12, atol=1e-9) and np.array_equal(n2, n)
     okc = np.isfinite(s)
     assert np.array_equal(np.isfinite(s2), okc) and util.rel_err(s2[okc], s[okc]) < 1e-12
-    for k in ("clade", "pass"):
-        assert np.array_equal(np.concatenate([p[k] for p in parts]), got[k])
-    assert np.array_equal(np.concatenate([p["like"] for p in parts]), got["like"])  # per read: the same bits whatever the batch
+    # per read, by its index in the input (a batch holds its reads ordered by their first node, not in input order)
+    def by_read(res, batch):
+        src = batch.arrays()["read_src"]
+        out = {k: np.zeros(a.n_reads, res[k].dtype) for k in ("clade", "pass", "like")}
+        for k in out:
+            out[k][src] = res[k]
+        held = np.zeros(a.n_reads, bool)
+        held[src] = True
+        return out, held
+    w, w_held = by_read(got, whole)
+    shard_batches = [ek.EukaHostBatch(g, a, 0, half), ek.EukaHostBatch(g, a, half, a.n_reads)]
+    seen = np.zeros(a.n_reads, bool)
+    for res, hb in zip(parts, shard_batches):
+        sub, sel = by_read(res, hb)
+        assert not (sel & seen).any() and w_held[sel].all()
+        seen |= sel
+        for k in ("clade", "pass", "like"):  # like: the same bits whatever the batch
+            assert np.array_equal(sub[k][sel], w[k][sel]), k
+    assert np.array_equal(seen, w_held)
     # samples of 300 consecutive reads against the oracle
     og, odb = util.orc_graph_nodes_only(g), util.orc_euka_db_from_product(db)
     src = whole.arrays()["read_src"]
