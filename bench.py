@@ -101,7 +101,7 @@ def cpu_baseline(graph, alns, budget_s, ctx=None, hc=None):
     hoisted = n_h / (time.perf_counter() - t0)
     out = {"value": faithful, "unit": "reads/s", "cores": cores, "kind": "port",
            "sample": "first %d of the workload's reads, literal reference loops (oracle, long double, OpenMP x%d)" % (done, cores),
-           "hoisted_variant_reads_per_s": hoisted}
+           "hoisted_variant_reads_per_s": hoisted, "cpu_quota": host_cpu_quota()}
     parity = None
     if ctx is not None and ref is not None:  # the device on the same sample
         sub = hc.HostBatch(graph, alns, 0, done)
@@ -259,7 +259,7 @@ def cpu_baseline_soibean(g, alns, dm, sb, state_fn, freqs, budget_s):
     ctx.precompute(hb)
     got = float(ctx.loglike([st], 0.01, freqs)[0][0])
     err = abs(got - ref) / max(abs(ref), 1e-300)
-    return ({"value": rate, "unit": "reads*iterations/s", "cores": cores, "kind": "port",
+    return ({"value": rate, "unit": "reads*iterations/s", "cores": cores, "kind": "port", "cpu_quota": host_cpu_quota(),
              "sample": "refresh over the first %d reads, %d repetitions (oracle, long double, OpenMP x%d)" % (n, reps, cores)},
             {"reads": int(n), "max_rel_err_vs_oracle": float(err), "tolerance": 1e-6})
 
@@ -466,6 +466,13 @@ def collect_traffic(args, kernel_substr):
     return {"fetch_size_bytes_raw": raw["FETCH_SIZE"], "write_size_bytes_raw": raw["WRITE_SIZE"],
             "bytes": 2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"],
             "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950: coalesced 128-B read requests are tallied at 64 B)"}
+
+
+def host_cpu_quota():
+    """Processors the container may keep busy (affinity mask and cgroup CPU quota, as the product's host code reads them): the
+    OpenMP threads of a cpu_baseline leg share this many, however many were started."""
+    from vgan_amd import _native as N
+    return int(N.lib().vgan_host_cpus())
 
 
 def front_end_rates(graph, hc, seed, n=200_000):
