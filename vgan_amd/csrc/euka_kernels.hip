@@ -70,7 +70,8 @@ __device__ __forceinline__ double row_sum16(double v) {
 // outputs, base shifts, bin coverage) runs for the wave's four reads at once.
 template <bool DMG_LDS>
 __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, EukaBatchDev b, EukaOutDev o) {
-    __shared__ double qs_s[100];
+    __shared__ double2 qs_s[100]; // {eps(Q), eps(Q) / 3}: the quotient from a table -- an fp64 division is eleven instructions, one of
+                                  // them the quarter-rate reciprocal, per column
     __shared__ LogTabEntry logtab_s[64];
     __shared__ double dmg_s[DMG_LDS ? EK_DMG_LDS_PAIRS * 20 : 1];
     // byte -> class: low nibble = ACGT index 0..3, else 8; high nibble = the rank of the lambda's special cases in
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         const int t = threadIdx.x;
         bfl_s[t] = base_freq_log(t == 0 ? 'A' : t == 1 ? 'C' : t == 2 ? 'G' : t == 3 ? 'T' : t == 9 ? 'N' : 0u);
     }
-    for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = d.qscore[i];
+    for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = double2{d.qscore[i], d.qscore[i] / 3.0};
     for (int i = threadIdx.x; i < 64; i += blockDim.x) logtab_s[i] = euka_log_table[i];
     if (DMG_LDS)
         for (uint32_t i = threadIdx.x; i < d.n5 * d.n3 * 20u; i += blockDim.x) dmg_s[i] = d.dmg_pair[i];
@@ -215,15 +216,17 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             const uint32_t kind = min(gcl >> 4, rcl >> 4);                // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
             int q = (m < QL && QL > 0u) ? q_raw : 0; // Q15
             q = q < 0 ? 0 : (q > 99 ? 99 : q);
-            const double qs = qs_s[q];
+            const double2 qe = qs_s[q];
+            const double qs = qe.x;
             // the regular column (:283-400), evaluated for every lane: p = sum_o pre[o] * sum_b M[o][b] * w[b] with
             // w = w_miss except w[read base] = w_hit, i.e. per original base o: w_miss * rowsum[o] + (w_hit - w_miss) * M[o][rb],
             // and pre = 1 - dist at the graph base g, dist * 0.95238 at its transition partner g^2, dist * 0.02381 at the
             // other two (:312-318, Euka.cpp:453-468).  Pair table layout: euka_device.h.
             const uint32_t gi = gcl & 15u, ri = rcl & 15u; // 0..3, or 8 / 9 outside ACGT
             const uint32_t nn = min(n, Lseq - 1u);
-            const double *e = dmg + 20u * (min(nn, d.n5 - 1u) * d.n3 + min(Lseq - 1u - nn, d.n3 - 1u));
-            const double w_hit = 1.0 - qs, w_miss = qs / 3.0;
+            // (24-bit multiplies: positions and table sizes are below 2^24, and the full 32-bit multiply is a quarter-rate instruction)
+            const double *e = dmg + __umul24(20u, __umul24(min(nn, d.n5 - 1u), d.n3) + min(Lseq - 1u - nn, d.n3 - 1u));
+            const double w_hit = 1.0 - qs, w_miss = qe.y;
             const double dw = ri < 4u ? w_hit - w_miss : 0.0; // a read base outside ACGT matches no column
             const double *mcol = e + 4u * (ri & 3u);        // M[.][read base]
             const uint32_t o0 = gi & 3u, o1 = o0 ^ 1u, o2 = o0 ^ 2u, o3 = o0 ^ 3u;

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(SBC_WAVES * 64) void sb_precompute_cols_kernel(SbGr
                                                                             uint16_t *__restrict__ stage_cnt, unsigned long long *n_bad,
                                                                             uint32_t ppad_log2, uint32_t pen_magic) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sbc_smem[];
-    __shared__ double qs_s[100], l1m_s[100], lq3_s[100]; // eps(Q), log(1 - eps), log(eps / 3)
+    __shared__ double qs_s[100], q3_s[100], l1m_s[100], lq3_s[100]; // eps(Q), eps / 3, log(1 - eps), log(eps / 3)
     __shared__ uint32_t fw_s[8];                            // findable paths, as mask words
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t P = g.n_paths, MW = g.mask_words;
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(SBC_WAVES * 64) void sb_precompute_cols_kernel(SbGr
     for (int i = threadIdx.x; i < 100; i += blockDim.x) {
         const double e = g.qscore[i];
         qs_s[i] = e;
+        q3_s[i] = e / 3.0; // (the quotient the segment kernel forms per column: the same bits, one division per table entry)
         l1m_s[i] = log_pos(1.0 - e);
         lq3_s[i] = log_pos(e / 3.0);
     }
@@ -351,8 +352,9 @@ __global__ __launch_bounds__(SBC_WAVES * 64) void sb_precompute_cols_kernel(SbGr
                 } else {
                     const int gi = acgt5(gc);
                     double p = 0.0;
+                    const double e3 = q3_s[q];
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) p += (o == gi ? 1.0 - qs : qs / 3.0) * L.rowsum[m][o];
+                    for (int o = 0; o < 4; ++o) p += (o == gi ? 1.0 - qs : e3) * L.rowsum[m][o];
                     ls = log_pos(p);
                     if (ls > SB_LOG_CLAMP) ls = SB_LOG_CLAMP; // :349-351
                     const uint32_t ab = (uint32_t)(bo < 0 ? -bo : bo);
