@@ -225,7 +225,10 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             const uint32_t gi = gcl & 15u, ri = rcl & 15u; // 0..3, or 8 / 9 outside ACGT
             const uint32_t nn = min(n, Lseq - 1u);
             // (24-bit multiplies: positions and table sizes are below 2^24, and the full 32-bit multiply is a quarter-rate instruction)
-            const double *e = dmg + __umul24(20u, __umul24(min(nn, d.n5 - 1u), d.n3) + min(Lseq - 1u - nn, d.n3 - 1u));
+            uint32_t pair_ix, e_ix; // (spelled out: the compiler forms a quarter-rate 64-bit multiply-add for the same expression)
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair_ix) : "v"(min(nn, d.n5 - 1u)), "s"(d.n3), "v"(min(Lseq - 1u - nn, d.n3 - 1u)));
+            asm("v_mul_u32_u24 %0, 20, %1" : "=v"(e_ix) : "v"(pair_ix));
+            const double *e = dmg + e_ix;
             const double w_hit = 1.0 - qs, w_miss = qe.y;
             const double dw = ri < 4u ? w_hit - w_miss : 0.0; // a read base outside ACGT matches no column
             const double *mcol = e + 4u * (ri & 3u);        // M[.][read base]
