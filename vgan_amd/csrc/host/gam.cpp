@@ -491,9 +491,25 @@ struct SegPipe {
             s.size = blocks[s.b1 - 1].out_off + blocks[s.b1 - 1].out_size - s.out_off;
         }
         pt.lap("inflate started");
-        for (unsigned t = 0; t < nt; ++t) workers.emplace_back([this] { work(); });
-        stitcher = std::thread([this] { stitch(); });
+        for (unsigned t = 0; t < nt; ++t) workers.emplace_back([this] { guarded([this] { work(); }); });
+        stitcher = std::thread([this] { guarded([this] { stitch(); }); });
         return true;
+    }
+
+    // a thread of the pipeline that runs out of memory (or throws anything else) ends the stream with an error instead of
+    // the process: take() reports it as a malformed stream would be
+    template <class F> void guarded(F &&f) {
+        try {
+            f();
+        } catch (...) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                bad_frame = stop = true;
+            }
+            cv_work.notify_all();
+            cv_seg.notify_all();
+            cv_done.notify_all();
+        }
     }
 
     void release(Seg &s) {
