@@ -282,108 +282,104 @@ extern "C" int vgan_euka_flatten(const vgan_graph *g, const vgan_alnset *a, int6
     const int64_t n = r1 - r0;
     n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (n + 4095) / 4096));
     std::vector<EChunk> chunks((size_t)n_threads);
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t) {
+    PhaseTimer pt("euka_flatten");
+    parallel_run(n_threads, [&](int t) {
         const int64_t b0 = r0 + n * t / n_threads, b1 = r0 + n * (t + 1) / n_threads;
-        if (n_threads == 1) euka_flatten_range(*g, *a, b0, b1, chunks[(size_t)t]);
-        else th.emplace_back(euka_flatten_range, std::cref(*g), std::cref(*a), b0, b1, std::ref(chunks[(size_t)t]));
-    }
-    for (auto &t : th) t.join();
+        euka_flatten_range(*g, *a, b0, b1, chunks[(size_t)t]);
+    });
+    pt.lap("chunks");
     auto res = new vgan_euka_host_batch();
     vgan_euka_flatten_stats st{};
     uint64_t tc = 0, tq = 0, tm = 0;
+    size_t R = 0;
     for (auto &c : chunks) {
         tc += c.b.graph_seq.size();
         tq += c.b.qual.size();
         tm += c.b.map_node.size();
+        R += c.b.read_mapq.size();
+        st.n_in += c.st.n_in;
+        st.n_out += c.st.n_out;
+        st.n_unmapped += c.st.n_unmapped;
+        st.n_bad += c.st.n_bad;
     }
     if (tc > 0xFFFFFFF0ull || tq > 0xFFFFFFF0ull || tm > 0xFFFFFFF0ull) {
         delete res;
         return fail(VGAN_ERANGE, "vgan_euka_flatten: batch exceeds 32-bit offsets; flatten fewer reads per batch");
     }
-    for (auto &c : chunks) {
-        cat_shift(res->read_col_off, c.b.read_col_off, (uint32_t)res->graph_seq.size());
-        cat_shift(res->read_qual_off, c.b.read_qual_off, (uint32_t)res->qual.size());
-        cat_shift(res->read_map_off, c.b.read_map_off, (uint32_t)res->map_node.size());
-        cat(res->read_gseq_len, c.b.read_gseq_len);
-        cat(res->read_rseq_len, c.b.read_rseq_len);
-        cat(res->read_seq_len, c.b.read_seq_len);
-        cat(res->read_mapq, c.b.read_mapq);
-        cat(res->read_rev, c.b.read_rev);
-        cat(res->read_src, c.b.read_src);
-        cat(res->map_node, c.b.map_node);
-        cat(res->graph_seq, c.b.graph_seq);
-        cat(res->read_seq, c.b.read_seq);
-        cat(res->qual, c.b.qual);
-        st.n_in += c.st.n_in;
-        st.n_out += c.st.n_out;
-        st.n_unmapped += c.st.n_unmapped;
-        st.n_bad += c.st.n_bad;
-        c.b = vgan_euka_host_batch();
-    }
     // The reads go to the device in ascending order of their first mapping's node id (stable; read_src says which read of
     // the input each one is): clades own contiguous node ranges, so a wave of the read kernel sees one clade for long
     // stretches and keeps that clade's counters in LDS instead of adding to the global tables read by read.
+    // Straight from the threads' chunks into the ordered batch: keys gathered once, two stable 16-bit counting passes (a
+    // comparison sort whose comparator chases two arrays per key took 0.2-0.3 s per million reads on one thread), the
+    // destination offsets by one prefix pass, the bytes moved in parallel -- no concatenated copy in between.
+    std::vector<uint32_t> keys(R), order(R), tmp(R), chunk_of(R), local_of(R);
     {
-        const size_t R = res->read_mapq.size();
-        std::vector<uint32_t> order(R);
-        for (size_t i = 0; i < R; ++i) order[i] = (uint32_t)i;
-        auto key = [&](uint32_t i) { return res->read_map_off[i] < res->read_map_off[i + 1] ? res->map_node[res->read_map_off[i]] : 0u; };
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
-        bool sorted = true;
-        for (size_t i = 0; i < R && sorted; ++i) sorted = order[i] == i;
-        if (!sorted) {
-            auto srt = new vgan_euka_host_batch();
-            srt->read_col_off.assign(R + 1, 0);
-            srt->read_qual_off.assign(R + 1, 0);
-            srt->read_map_off.assign(R + 1, 0);
-            for (size_t i = 0; i < R; ++i) {
-                const uint32_t o = order[i];
-                srt->read_col_off[i + 1] = srt->read_col_off[i] + (res->read_col_off[o + 1] - res->read_col_off[o]);
-                srt->read_qual_off[i + 1] = srt->read_qual_off[i] + (res->read_qual_off[o + 1] - res->read_qual_off[o]);
-                srt->read_map_off[i + 1] = srt->read_map_off[i] + (res->read_map_off[o + 1] - res->read_map_off[o]);
+        size_t i = 0;
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            const auto &cb = chunks[c].b;
+            for (size_t j = 0; j < cb.read_mapq.size(); ++j, ++i) {
+                keys[i] = cb.read_map_off[j] < cb.read_map_off[j + 1] ? cb.map_node[cb.read_map_off[j]] : 0u;
+                chunk_of[i] = (uint32_t)c;
+                local_of[i] = (uint32_t)j;
             }
-            srt->read_gseq_len.resize(R);
-            srt->read_rseq_len.resize(R);
-            srt->read_seq_len.resize(R);
-            srt->read_mapq.resize(R);
-            srt->read_rev.resize(R);
-            srt->read_src.resize(R);
-            srt->map_node.resize(res->map_node.size());
-            srt->graph_seq.resize(res->graph_seq.size());
-            srt->read_seq.resize(res->read_seq.size());
-            srt->qual.resize(res->qual.size());
-            auto move_range = [&](size_t i0, size_t i1) {
-                for (size_t i = i0; i < i1; ++i) {
-                    const uint32_t o = order[i];
-                    srt->read_gseq_len[i] = res->read_gseq_len[o];
-                    srt->read_rseq_len[i] = res->read_rseq_len[o];
-                    srt->read_seq_len[i] = res->read_seq_len[o];
-                    srt->read_mapq[i] = res->read_mapq[o];
-                    srt->read_rev[i] = res->read_rev[o];
-                    srt->read_src[i] = res->read_src[o];
-                    const size_t nc = res->read_col_off[o + 1] - res->read_col_off[o], nq = res->read_qual_off[o + 1] - res->read_qual_off[o],
-                                 nm = res->read_map_off[o + 1] - res->read_map_off[o];
-                    if (nc) {
-                        memcpy(&srt->graph_seq[srt->read_col_off[i]], &res->graph_seq[res->read_col_off[o]], nc);
-                        memcpy(&srt->read_seq[srt->read_col_off[i]], &res->read_seq[res->read_col_off[o]], nc);
-                    }
-                    if (nq) memcpy(&srt->qual[srt->read_qual_off[i]], &res->qual[res->read_qual_off[o]], nq);
-                    if (nm) memcpy(&srt->map_node[srt->read_map_off[i]], &res->map_node[res->read_map_off[o]], nm * sizeof(uint32_t));
-                }
-            };
-            const size_t nth = (size_t)std::max(1, std::min<int>(n_threads, (int)((R + 16383) / 16384)));
-            if (nth <= 1) {
-                move_range(0, R);
+        }
+        std::vector<uint32_t> cnt(65537);
+        for (int pass = 0; pass < 2; ++pass) {
+            const int sh = 16 * pass;
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (size_t k = 0; k < R; ++k) cnt[((keys[k] >> sh) & 0xFFFFu) + 1u]++;
+            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+            if (pass == 0) {
+                for (size_t k = 0; k < R; ++k) tmp[cnt[keys[k] & 0xFFFFu]++] = (uint32_t)k;
             } else {
-                std::vector<std::thread> mv;
-                for (size_t t = 0; t < nth; ++t) mv.emplace_back(move_range, R * t / nth, R * (t + 1) / nth);
-                for (auto &t : mv) t.join();
+                for (size_t k = 0; k < R; ++k) order[cnt[(keys[tmp[k]] >> 16) & 0xFFFFu]++] = tmp[k];
             }
-            delete res;
-            res = srt;
         }
     }
+    pt.lap("order");
+    res->read_col_off.assign(R + 1, 0);
+    res->read_qual_off.assign(R + 1, 0);
+    res->read_map_off.assign(R + 1, 0);
+    for (size_t i = 0; i < R; ++i) {
+        const auto &cb = chunks[chunk_of[order[i]]].b;
+        const uint32_t j = local_of[order[i]];
+        res->read_col_off[i + 1] = res->read_col_off[i] + (cb.read_col_off[j + 1] - cb.read_col_off[j]);
+        res->read_qual_off[i + 1] = res->read_qual_off[i] + (cb.read_qual_off[j + 1] - cb.read_qual_off[j]);
+        res->read_map_off[i + 1] = res->read_map_off[i] + (cb.read_map_off[j + 1] - cb.read_map_off[j]);
+    }
+    res->read_gseq_len.resize(R);
+    res->read_rseq_len.resize(R);
+    res->read_seq_len.resize(R);
+    res->read_mapq.resize(R);
+    res->read_rev.resize(R);
+    res->read_src.resize(R);
+    res->map_node.resize((size_t)tm);
+    res->graph_seq.resize((size_t)tc);
+    res->read_seq.resize((size_t)tc);
+    res->qual.resize((size_t)tq);
+    auto move_range = [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            const auto &cb = chunks[chunk_of[order[i]]].b;
+            const uint32_t j = local_of[order[i]];
+            res->read_gseq_len[i] = cb.read_gseq_len[j];
+            res->read_rseq_len[i] = cb.read_rseq_len[j];
+            res->read_seq_len[i] = cb.read_seq_len[j];
+            res->read_mapq[i] = cb.read_mapq[j];
+            res->read_rev[i] = cb.read_rev[j];
+            res->read_src[i] = cb.read_src[j];
+            const size_t nc = cb.read_col_off[j + 1] - cb.read_col_off[j], nq = cb.read_qual_off[j + 1] - cb.read_qual_off[j],
+                         nm = cb.read_map_off[j + 1] - cb.read_map_off[j];
+            if (nc) {
+                memcpy(&res->graph_seq[res->read_col_off[i]], &cb.graph_seq[cb.read_col_off[j]], nc);
+                memcpy(&res->read_seq[res->read_col_off[i]], &cb.read_seq[cb.read_col_off[j]], nc);
+            }
+            if (nq) memcpy(&res->qual[res->read_qual_off[i]], &cb.qual[cb.read_qual_off[j]], nq);
+            if (nm) memcpy(&res->map_node[res->read_map_off[i]], &cb.map_node[cb.read_map_off[j]], nm * sizeof(uint32_t));
+        }
+    };
+    const int nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)burst_cpus(), (R + 16383) / 16384));
+    parallel_run(nth, [&](int t) { move_range(R * (size_t)t / (size_t)nth, R * ((size_t)t + 1) / (size_t)nth); });
+    pt.lap("reorder");
     if (stats) *stats = st;
     *out = res;
     return VGAN_OK;
