@@ -110,13 +110,10 @@ extern "C" int vgan_sb_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
     const int64_t n = r1 - r0;
     n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (n + 4095) / 4096));
     std::vector<SChunk> chunks((size_t)n_threads);
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t) {
+    parallel_run(n_threads, [&](int t) {
         const int64_t b0 = r0 + n * t / n_threads, b1 = r0 + n * (t + 1) / n_threads;
-        if (n_threads == 1) sb_flatten_range(*g, *a, b0, b1, chunks[(size_t)t]);
-        else th.emplace_back(sb_flatten_range, std::cref(*g), std::cref(*a), b0, b1, std::ref(chunks[(size_t)t]));
-    }
-    for (auto &t : th) t.join();
+        sb_flatten_range(*g, *a, b0, b1, chunks[(size_t)t]);
+    });
     auto res = new vgan_sb_host_batch();
     vgan_sb_flatten_stats st{};
     uint64_t tc = 0, tq = 0, ts = 0;
@@ -129,27 +126,60 @@ extern "C" int vgan_sb_flatten(const vgan_graph *g, const vgan_alnset *a, int64_
         delete res;
         return fail(VGAN_ERANGE, "vgan_sb_flatten: batch exceeds 32-bit offsets; flatten fewer reads per batch");
     }
-    for (auto &c : chunks) {
-        cat_shift(res->read_seg_off, c.b.read_seg_off, (uint32_t)res->seg_node.size());
-        cat_shift(res->read_col_off, c.b.read_col_off, (uint32_t)res->graph_seq.size());
-        cat_shift(res->read_qual_off, c.b.read_qual_off, (uint32_t)res->qual.size());
-        cat(res->read_gseq_len, c.b.read_gseq_len);
-        cat(res->read_rseq_len, c.b.read_rseq_len);
-        cat(res->read_rev, c.b.read_rev);
-        cat(res->read_src, c.b.read_src);
-        cat(res->seg_node, c.b.seg_node);
-        cat(res->seg_col, c.b.seg_col);
-        cat(res->seg_len, c.b.seg_len);
-        cat(res->seg_base_ix, c.b.seg_base_ix);
-        cat(res->graph_seq, c.b.graph_seq);
-        cat(res->read_seq, c.b.read_seq);
-        cat(res->qual, c.b.qual);
-        st.n_in += c.st.n_in;
-        st.n_out += c.st.n_out;
-        st.n_unmapped += c.st.n_unmapped;
-        st.n_bad += c.st.n_bad;
-        c.b = vgan_sb_host_batch();
+    // every array sized once, the chunks copied into their places side by side (appending them one after the other on one
+    // thread, with the arrays growing under it, cost as much as flattening them)
+    struct Base {
+        size_t r, s, c, q;
+    };
+    std::vector<Base> base(chunks.size() + 1, Base{0, 0, 0, 0});
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        const auto &cb = chunks[i].b;
+        base[i + 1] = Base{base[i].r + cb.read_rev.size(), base[i].s + cb.seg_node.size(), base[i].c + cb.graph_seq.size(), base[i].q + cb.qual.size()};
+        st.n_in += chunks[i].st.n_in;
+        st.n_out += chunks[i].st.n_out;
+        st.n_unmapped += chunks[i].st.n_unmapped;
+        st.n_bad += chunks[i].st.n_bad;
     }
+    const Base tot = base.back();
+    res->read_seg_off.resize(tot.r + 1);
+    res->read_col_off.resize(tot.r + 1);
+    res->read_qual_off.resize(tot.r + 1);
+    res->read_gseq_len.resize(tot.r);
+    res->read_rseq_len.resize(tot.r);
+    res->read_rev.resize(tot.r);
+    res->read_src.resize(tot.r);
+    res->seg_node.resize(tot.s);
+    res->seg_col.resize(tot.s);
+    res->seg_len.resize(tot.s);
+    res->seg_base_ix.resize(tot.s);
+    res->graph_seq.resize(tot.c);
+    res->read_seq.resize(tot.c);
+    res->qual.resize(tot.q);
+    res->read_seg_off[0] = res->read_col_off[0] = res->read_qual_off[0] = 0;
+    parallel_run((int)chunks.size(), [&](int ti) {
+        auto &cb = chunks[(size_t)ti].b;
+        const Base &bs = base[(size_t)ti];
+        for (size_t j = 1; j < cb.read_seg_off.size(); ++j) {
+            res->read_seg_off[bs.r + j] = cb.read_seg_off[j] + (uint32_t)bs.s;
+            res->read_col_off[bs.r + j] = cb.read_col_off[j] + (uint32_t)bs.c;
+            res->read_qual_off[bs.r + j] = cb.read_qual_off[j] + (uint32_t)bs.q;
+        }
+        auto cp = [](auto &dst, size_t at, const auto &src) {
+            if (!src.empty()) memcpy(&dst[at], src.data(), src.size() * sizeof(src[0]));
+        };
+        cp(res->read_gseq_len, bs.r, cb.read_gseq_len);
+        cp(res->read_rseq_len, bs.r, cb.read_rseq_len);
+        cp(res->read_rev, bs.r, cb.read_rev);
+        cp(res->read_src, bs.r, cb.read_src);
+        cp(res->seg_node, bs.s, cb.seg_node);
+        cp(res->seg_col, bs.s, cb.seg_col);
+        cp(res->seg_len, bs.s, cb.seg_len);
+        cp(res->seg_base_ix, bs.s, cb.seg_base_ix);
+        cp(res->graph_seq, bs.c, cb.graph_seq);
+        cp(res->read_seq, bs.c, cb.read_seq);
+        cp(res->qual, bs.q, cb.qual);
+        cb = vgan_sb_host_batch();
+    });
     if (stats) *stats = st;
     *out = res;
     return VGAN_OK;
