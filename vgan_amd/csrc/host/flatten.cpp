@@ -77,11 +77,71 @@ inline bool append_node(const vgan_graph &g, int64_t id, bool rev, int64_t off, 
 } // namespace
 
 // a1, shared by the HaploCart / euka / soibean front halves.  Returns 0 or a BAD_* code.
+namespace {
+// The common read: every edit a match or a substitution (from_length == to_length).  Then path_string and graph_seq grow
+// side by side and nothing is ever inserted into path_string, so one walk over the mappings writes both through plain
+// pointers into strings sized once.  Anything else -- an indel, an edit of unequal lengths, an offset past its node, an unknown
+// node -- returns false and the general walk below decides (and reports) as before.
+bool reconstruct_matches_only(const vgan_graph &g, const vgan_alnset &a, int64_t m0, int64_t m1, Recon &o) {
+    const int64_t e0 = a.edit_off[m0], e1 = a.edit_off[m1];
+    int64_t tot_from = 0, tot_ps = 0;
+    for (int64_t e = e0; e < e1; ++e) {
+        const int32_t from = a.e_from[e];
+        if (from != a.e_to[e] || from < 0) return false;
+        const int64_t sl = a.e_seq_off[e + 1] - a.e_seq_off[e];
+        tot_from += from;
+        tot_ps += sl > 0 ? sl : from;
+    }
+    o.gseq.resize((size_t)tot_from);
+    o.ps.resize((size_t)tot_ps);
+    o.sizes.resize((size_t)(e1 - e0));
+    char *gq = &o.gseq[0], *pq = &o.ps[0];
+    int32_t *sz = o.sizes.data();
+    for (int64_t m = m0; m < m1; ++m) {
+        const int64_t id = a.m_node[m];
+        if (!g.has_node(id)) return false;
+        const int64_t len = g.seq_len(id);
+        const char *ns = g.seq_ptr(id);
+        const bool rev = a.m_rev[m];
+        int64_t off = a.m_offset[m];
+        if (off != (int64_t)(int32_t)off) return false; // (the two walks of the general form read the offset through different types)
+        for (int64_t e = a.edit_off[m]; e < a.edit_off[m + 1]; ++e) {
+            const int64_t from = a.e_from[e];
+            const int64_t sl = a.e_seq_off[e + 1] - a.e_seq_off[e];
+            if (off > len || off < 0) return false;
+            const int64_t n = std::min(from, len - off);
+            // (a node of this graph holds one or two bases: byte loops, not calls)
+            if (!rev) {
+                const char *src = ns + off;
+                for (int64_t k = 0; k < n; ++k) gq[k] = src[k];
+            } else {
+                for (int64_t k = 0; k < n; ++k) gq[k] = comp(ns[len - 1 - (off + k)]);
+            }
+            if (sl > 0) {
+                const char *src = a.e_seq.data() + a.e_seq_off[e];
+                for (int64_t k = 0; k < sl; ++k) pq[k] = src[k];
+                pq += sl;
+            } else {
+                for (int64_t k = 0; k < n; ++k) pq[k] = gq[k];
+                pq += n;
+            }
+            gq += n;
+            *sz++ = (int32_t)n;
+            off += from;
+        }
+    }
+    o.gseq.resize((size_t)(gq - o.gseq.data()));
+    o.ps.resize((size_t)(pq - o.ps.data()));
+    return true;
+}
+} // namespace
+
 int vgan::reconstruct(const vgan_graph &g, const vgan_alnset &a, int64_t r, Recon &o) {
+    const int64_t m0 = a.map_off[r], m1 = a.map_off[r + 1];
+    if (m1 > m0 && reconstruct_matches_only(g, a, m0, m1, o)) return 0;
     o.gseq.clear();
     o.ps.clear();
     o.sizes.clear();
-    const int64_t m0 = a.map_off[r], m1 = a.map_off[r + 1];
     // path_string: node bases for matches, edit.sequence for substitutions/insertions
     for (int64_t m = m0; m < m1; ++m) {
         const int64_t id = a.m_node[m];

@@ -44,6 +44,7 @@ struct Cur {
     bool ok = true;
     bool done() const { return p >= e; }
     uint64_t varint() {
+        if (p < e && !(*p & 0x80)) return *p++; // one byte: field keys, lengths, node offsets, edit lengths
         uint64_t v = 0;
         int shift = 0;
         while (p < e) {
@@ -369,7 +370,7 @@ int walk(WalkState &st, const uint8_t *&p, const uint8_t *e, uint64_t &need, Emi
     }
 }
 
-void reserve_for(vgan_alnset &a, size_t nbytes, size_t nr) { // ~1 mapping per 20 bytes, ~1 edit per 16
+void reserve_for(vgan_alnset &a, size_t nbytes, size_t nr) { // a mapping with one edit is 13-16 bytes on the wire
     a.seq_off.reserve(nr + 1);
     a.qual_off.reserve(nr + 1);
     a.name_off.reserve(nr + 1);
@@ -379,13 +380,13 @@ void reserve_for(vgan_alnset &a, size_t nbytes, size_t nr) { // ~1 mapping per 2
     a.seq.reserve(nbytes / 6);
     a.qual.reserve(nbytes / 6);
     a.name.reserve(nr * 16);
-    a.m_node.reserve(nbytes / 18);
-    a.m_offset.reserve(nbytes / 18);
-    a.m_rev.reserve(nbytes / 18);
-    a.edit_off.reserve(nbytes / 18);
-    a.e_from.reserve(nbytes / 14);
-    a.e_to.reserve(nbytes / 14);
-    a.e_seq_off.reserve(nbytes / 14);
+    a.m_node.reserve(nbytes / 12 + 16);
+    a.m_offset.reserve(nbytes / 12 + 16);
+    a.m_rev.reserve(nbytes / 12 + 16);
+    a.edit_off.reserve(nbytes / 12 + 16);
+    a.e_from.reserve(nbytes / 12 + 16);
+    a.e_to.reserve(nbytes / 12 + 16);
+    a.e_seq_off.reserve(nbytes / 12 + 16);
 }
 
 struct SegPipe {
