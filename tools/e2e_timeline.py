@@ -35,10 +35,30 @@ for extra, i in [(e, i) for e in variants for i in range(reps)]:
     t = time.time()
     p = subprocess.Popen([exe, "haplocart", "-g", d + "/r.gam", "--hc-files", d, "-q", "-t", "-1", "--keep-duplicates", "-o", d + "/out%d.tsv" % i,
                           "-np"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, VGAN_TIMING="1", **extra))
+    peak = {}
+
+    def poll():  # the child's resident set while it runs (anonymous / file-backed / shared), sampled every 20 ms
+        while p.poll() is None:
+            try:
+                for ln in open("/proc/%d/status" % p.pid):
+                    k = ln.split(":")[0]
+                    if k in ("VmRSS", "RssAnon", "RssFile", "RssShmem"):
+                        v = int(ln.split()[1])
+                        if v > peak.get(k, (0, 0))[0]:
+                            peak[k] = (v, time.time() - t)
+            except OSError:
+                pass
+            time.sleep(0.02)
+    import threading
+    th = threading.Thread(target=poll)
+    th.start()
     _, err = p.communicate()
     dt = time.time() - t
-    ru = resource.getrusage(resource.RUSAGE_CHILDREN)
-    print("run %d: rc=%d wall %.3f s = %.2f M reads/s, peak RSS of the children so far %.2f GB" % (i, p.returncode, dt, n / dt / 1e6, ru.ru_maxrss / 1e6), flush=True)
+    th.join()
+    if peak:
+        print("        sampled peaks: " + ", ".join("%s %.2f GB at %.2f s" % (k, v / 1e6, at) for k, (v, at) in sorted(peak.items())), flush=True)
+    # (ru_maxrss of the child is of no use here: it starts as a copy of this process, which holds the synthetic reads)
+    print("run %d: rc=%d wall %.3f s = %.2f M reads/s" % (i, p.returncode, dt, n / dt / 1e6), flush=True)
     clk = {l.split()[5].rstrip(":"): float(l.split()[-1]) for l in err.splitlines() if "wall clock at" in l}
     if "main" in clk and "exit" in clk:
         print("        spawn -> main %.0f ms, main -> _exit %.0f ms, _exit -> reaped %.0f ms" % (

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <thread>
 
+#include <sys/mman.h>
+
 using namespace vgan;
 
 void vgan_alnset::fill_view(vgan_alnset_view *v) const {
@@ -422,6 +424,8 @@ struct SegPipe {
     };
 
     const uint8_t *in = nullptr;
+    bool in_is_file_mapping = false; // the compressed bytes are a private read-only mapping of the file: pages behind the
+    size_t in_released = 0;          // stitcher are dropped from the resident set (they stay in the page cache)
     std::vector<BgzfBlock> blocks;
     int keep_unmapped = 0;
     size_t total_out = 0, seg_blocks = 0, buf_bytes = 0, ring = 0, ahead = 0;
@@ -679,6 +683,15 @@ struct SegPipe {
 
     void stitch() {
         constexpr size_t HEAD_SLICE = 2048;
+        if (in_is_file_mapping) {
+            // indexing the blocks touched a page or two of each, and the kernel mapped their neighbours with them: the whole
+            // file counts as resident 0.1 s after the start.  What lies beyond the workers' first reach is let go again (the
+            // pages stay in the page cache and come back as the workers get there)
+            const size_t page = 4096, far_block = std::min(blocks.size() - 1, (ahead + 2) * seg_blocks);
+            const size_t from = (blocks[far_block].in_off + page - 1) / page * page;
+            const size_t end = blocks.back().in_off + blocks.back().in_size;
+            if ((uintptr_t)in % page == 0 && end > from) (void)madvise((void *)((uintptr_t)in + from), end - from, MADV_DONTNEED);
+        }
         WalkState st;
         std::vector<Msg> cur;
         bool frame_ok = true, inflate_ok = true;
@@ -810,6 +823,13 @@ struct SegPipe {
             }
             if (left) memcpy(nx.data() - left, pos, left);
             pos = nx.data() - left;
+            if (in_is_file_mapping && (k & 63u) == 63u) { // every 64 segments: the compressed input the workers are done with
+                const size_t page = 4096, upto = blocks[s.b1 - 1].in_off / page * page; // (segments up to k are inflated: k + 1 is ready)
+                const size_t from = (in_released + page - 1) / page * page;
+                const uintptr_t base = (uintptr_t)in;
+                if (upto > from && base % page == 0) (void)madvise((void *)(base + from), upto - from, MADV_DONTNEED);
+                in_released = upto;
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 stitched = k + 1;
@@ -911,6 +931,7 @@ struct vgan_gam_stream {
         n = nbytes;
         if (n >= 2 && p[0] == 0x1f && p[1] == 0x8b) {
             seg.reset(new SegPipe());
+            seg->in_is_file_mapping = file.mapped && bytes == file.p;
             if (seg->start(bytes, n, keep)) return VGAN_OK;
             seg.reset();
             if (!gunzip_members(bytes, n, inflated)) return fail(VGAN_EIO, "GAM: gzip stream is corrupt");

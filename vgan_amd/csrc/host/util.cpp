@@ -483,6 +483,7 @@ static size_t pool_cap() {
     static const size_t cap = [] {
         const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
         const size_t ram = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz : (size_t)64 << 30;
+        if (const char *e = getenv("VGAN_POOL_CAP_MB")) return (size_t)std::max(64L, atol(e)) << 20; // developer aid
         return std::min((size_t)12 << 30, ram / 8);
     }();
     return cap;

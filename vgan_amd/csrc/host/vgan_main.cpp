@@ -524,7 +524,8 @@ int haplocart(int argc, char **argv) {
         if (FILE *f = fopen("/proc/self/status", "r")) {
             char line[256];
             while (fgets(line, sizeof line, f))
-                if (!strncmp(line, "VmHWM:", 6)) fprintf(stderr, "[vgan timing] haplocart memory: %s", line);
+                if (!strncmp(line, "VmHWM:", 6) || !strncmp(line, "RssAnon:", 8) || !strncmp(line, "RssFile:", 8) || !strncmp(line, "RssShmem:", 9))
+                    fprintf(stderr, "[vgan timing] haplocart memory: %s", line);
             fclose(f);
         }
         if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {
