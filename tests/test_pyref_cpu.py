@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 import gamio
 import orc
@@ -166,3 +167,35 @@ def test_the_cpp_soibean_oracle_agrees_with_the_python_restatement():
     for st in fix["states"]:
         rc, ll = o.loglike([tuple(s) for s in st["sources"]], st["con"], fix["params"]["freqs"])
         assert rc == 0 and abs(ll - float(st["loglike"])) <= 1e-12 * abs(float(st["loglike"]))
+
+
+def test_product_reconstruction_equals_the_python_restatement_on_thousands_of_reads(tmp_path):
+    """a1 of every path (vgan_utils.h:6-79) through the product's own GAM reader and `reconstruct` (csrc/host/flatten.cpp: the
+    one-walk form for match / substitution reads and the general two-walk form) against tools/pyref_hc.py reading the same file
+    with the test-side decoder: graph_seq, the aligned read string and the per-edit sizes, read by read -- and the reads the
+    restatement refuses as undefined in the reference are the ones the product reports as such."""
+    from vgan_amd import _native as N
+    from vgan_amd import haplocart as hc
+    p = _pyref()
+    g = hc.synth_graph(seed=123, genome_len=2500, n_nodes=1700, n_paths=40)
+    a = hc.synth_reads(g, 4000, seed=124, read_len=90, indel_rate=0.3, softclip_rate=0.2)
+    f = str(tmp_path / "r.gam")
+    a.write_gam(f)
+    b = hc.AlnSet.read_gam(f, keep_unmapped=True)
+    dicts = gamio.read_gam(f)
+    assert b.n_reads == len(dicts) == 4000
+    off, seq = g.node_seq_off, g.node_seq
+    seqs = {i: bytes(seq[off[i]:off[i + 1]]).decode() for i in range(g.min_id, g.max_id + 1) if off[i + 1] > off[i]}
+    n_general = n_undefined = 0
+    for r, d in enumerate(dicts):
+        try:
+            gs, rs, sizes = p.reconstruct_graph_sequence(seqs, d["path"])
+        except (p.Undefined, KeyError):
+            n_undefined += 1
+            with pytest.raises(N.NativeError):
+                hc.reconstruct(g, b, r)
+            continue
+        got_g, got_r, got_s = hc.reconstruct(g, b, r)
+        assert got_g == gs.encode() and got_r == rs.encode() and list(got_s) == sizes, r
+        n_general += any(e["from_length"] != e["to_length"] for m in d["path"]["mapping"] for e in m["edit"])
+    assert n_general > 800 and 4000 - n_general - n_undefined > 1500  # both walks of the product were exercised
