@@ -90,6 +90,18 @@ __device__ unsigned long long wv_stats[8]; // tiles, reads, chunk groups, far gr
 #define WV_COUNT(slot, n)
 #endif
 
+#ifdef WV_PHASES // developer aid: where a wave's time goes (shader clock between the phases of the tile loop, summed over the waves)
+__device__ unsigned long long wv_phase_cycles[8]; // gather issue, next tile + header, reads, Q, C, D, E, tiles
+#define WV_MARK(i)                                                   \
+    do {                                                             \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        ph_acc[i] += now_ - ph_t;                                    \
+        ph_t = now_;                                                 \
+    } while (0)
+#else
+#define WV_MARK(i)
+#endif
+
 __device__ __forceinline__ double wv_fma3(double a, double b, double c) { // three-address v_fma_f64 (see hc_kernels.hip)
     double r;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -336,10 +348,14 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         for (int k = 0; k < NCH; ++k) D.rec[k] = wv_load1(rs_c, lane4 + (uint32_t)k * 256u);
     }
 
+#ifdef WV_PHASES
+    unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+#endif
     while (true) {
         // the nodes' scalars: the segment records arrived during the tile before, these land during Q
         double nd_lw[SPASS], nd_inv[SPASS], nd_mapp[SPASS];
         node_gather(D, nd_lw, nd_inv, nd_mapp);
+        WV_MARK(0);
         // ---- the next tile: formed from its header (here since the tile before), the header after it requested
         const bool has_next = fn < a.n_reads;
         const WvTile Tn = tile_form(Hn, fn, wn); // (meaningless behind the last tile, and unused)
@@ -354,6 +370,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         WV_COUNT(1, T.n);
         WV_COUNT(5, (T.n_seg + 63u) / 64u);
 
+        WV_MARK(1);
         // ---- the tile's reads: one record each
         {
             const uint32_t q_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_q, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
@@ -365,6 +382,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
             }
         }
 
+        WV_MARK(2);
         // ---- Q: prefix sums over the quality window.  Slots past the tile's bytes receive sums nobody reads.
         bool hot = false;
         {
@@ -404,6 +422,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
+        WV_MARK(3);
         request_qual(Tn, has_next, D); // the next tile's quality bytes take the registers: a whole tile to arrive
 
         // ---- C: one lane per segment
@@ -455,6 +474,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        WV_MARK(4);
         // ---- D: one lane per alignment column, 64 columns per step
         {
             uint32_t segs_before = 0u; // heads in the chunks before this one (scalar)
@@ -573,6 +593,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        WV_MARK(5);
         // ---- E: one lane per segment
         if (a.nodeW && need_place) {
             // The window sits at the lowest node id of the tile: the batch is sorted by the reads' lowest node id
@@ -613,6 +634,10 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                 if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(outside)) > 16) need_place = true;
             }
         }
+        WV_MARK(6);
+#ifdef WV_PHASES
+        ph_acc[7] += 1;
+#endif
         if (!has_next) break;
         T = Tn;
         h_q = hn_q;
@@ -623,6 +648,10 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         fresh_n = fresh_2;
     }
     if (a.nodeW && winbase != 0xFFFFFFFFu) window_flush(winbase);
+#ifdef WV_PHASES
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&wv_phase_cycles[i], ph_acc[i]);
+#endif
     sumT = wave_sum(sumT);
     sumU = wave_sum(sumU);
     if (lane == 0 && a.totals) {
@@ -692,6 +721,17 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
 
 } // namespace wv
 using namespace wv;
+
+#ifdef WV_PHASES
+extern "C" int vgan_hc_debug_wave_phases(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(wv_phase_cycles), sizeof(wv_phase_cycles)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wv_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 #ifdef WV_STATS
 extern "C" int vgan_hc_debug_wave_stats(unsigned long long *out, int reset) {
