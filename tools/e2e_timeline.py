@@ -29,12 +29,13 @@ with open(d + "/r.gam", "wb") as out:  # gzip members concatenate
 print("GAM: %d reads, %.1f MB" % (n, os.path.getsize(d + "/r.gam") / 1e6), flush=True)
 exe = os.path.join(ROOT, "vgan_amd/bin/vgan")
 variants = [{}] + [dict(kv.split("=", 1) for kv in v.split(",")) for v in sys.argv[3:]]
-for extra, i in [(e, i) for e in variants for i in range(reps)]:
+for extra, i in [(dict(e), i) for e in variants for i in range(reps)]:
     if i == 0 and extra:
         print("with", extra, flush=True)
     t = time.time()
-    p = subprocess.Popen([exe, "haplocart", "-g", d + "/r.gam", "--hc-files", d, "-q", "-t", "-1", "--keep-duplicates", "-o", d + "/out%d.tsv" % i,
-                          "-np"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, VGAN_TIMING="1", **extra))
+    dedup = extra.pop("DEDUP", None)  # DEDUP=1: the reference's default (duplicates removed); else --keep-duplicates
+    p = subprocess.Popen([exe, "haplocart", "-g", d + "/r.gam", "--hc-files", d, "-q", "-t", "-1"] + ([] if dedup else ["--keep-duplicates"]) +
+                         ["-o", d + "/out%d.tsv" % i, "-np"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, VGAN_TIMING="1", **extra))
     peak = {}
 
     def poll():  # the child's resident set while it runs (anonymous / file-backed / shared), sampled every 20 ms
