@@ -652,3 +652,30 @@ def test_cli_reads_its_gam_from_a_pipe(tmp_path):
         assert r.returncode == 0, r.stderr[-500:]
         outs.append(open(out).read())
     assert outs[0] == outs[1] and outs[0].splitlines()[1].startswith("x\thg")
+
+
+def test_cli_chunk_loop_lanes_and_small_batches_give_the_same_log_likelihoods(tmp_path):
+    """The chunk loop of `vgan haplocart` (csrc/host/vgan_main.cpp): chunks taken and marked for duplicates in input order,
+    flattened on several lanes side by side, queued for the device in order again.  Many small chunks on three lanes, with
+    duplicate removal, against one lane and one chunk: the same reads kept, the same per-haplotype log-likelihoods (-d writes
+    them) to rounding."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = hc.synth_graph(seed=15, genome_len=5000, n_nodes=3400, n_paths=60)
+    a = hc.synth_reads(g, 30000, seed=3, read_len=100, indel_rate=0.05, softclip_rate=0.05, low_mapq_rate=0.2)
+    g.write(str(tmp_path))
+    a.write_gam(str(tmp_path / "r.gam"))
+    res = {}
+    for tag, env in (("one", {"VGAN_HC_LANES": "1", "VGAN_HC_BATCH": "1000000"}),
+                     ("lanes", {"VGAN_HC_LANES": "3", "VGAN_HC_BATCH": "1024", "VGAN_HC_QUEUE": "3", "VGAN_GAM_SEG_BLOCKS": "4"})):
+        out = str(tmp_path / (tag + ".tsv"))
+        r = subprocess.run([os.path.join(root, "vgan_amd", "bin", "vgan"), "haplocart", "-g", str(tmp_path / "r.gam"), "--hc-files",
+                            str(tmp_path), "-q", "-np", "-d", "-o", out, "-s", "s", "-t", "6"],
+                           capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        ll = dict((ln.split("\t")[0], float(ln.split("\t")[1])) for ln in open(out + ".loglik.tsv").read().splitlines())
+        res[tag] = (open(out).read().splitlines()[1], ll)
+    assert res["one"][0] == res["lanes"][0]  # sample, predicted haplogroup, reads kept
+    assert res["one"][1].keys() == res["lanes"][1].keys() and len(res["one"][1]) == 60
+    for k, v in res["one"][1].items():
+        assert res["lanes"][1][k] == pytest.approx(v, rel=1e-9)
