@@ -204,3 +204,53 @@ def test_json_dump_of_the_alignments(tmp_path, golden_dir):
     raw = gamio.gunzip_all(open(src, "rb").read())
     open(bad, "wb").write(raw[:len(raw) - 7])
     assert N.lib().vgan_gam_dump_json(bad.encode(), str(tmp_path / "bad.json").encode(), None) < 0
+
+
+def test_the_working_process_and_its_early_leaving_parent(tmp_path):
+    """cli_util.h EarlyLeave: the subcommand runs in a child, the parent leaves with the child's code as soon as the outputs are
+    flushed.  Exit codes and messages are those of the run in one process (VGAN_NO_FORK=1); a working process that is killed
+    takes its parent with it by the same signal; nothing stays behind holding the caller's pipes."""
+    import signal
+    import time
+    for args in (["haplocart", "-e", "1.5"], ["haplocart", "-g", str(tmp_path / "missing.gam")], ["euka", "-t", "0"], ["soibean", "--iter", "x"]):
+        a = subprocess.run([VGAN] + args, capture_output=True, text=True)
+        b = subprocess.run([VGAN] + args, capture_output=True, text=True, env=dict(os.environ, VGAN_NO_FORK="1"))
+        assert a.returncode == b.returncode != 0 and a.stderr == b.stderr and a.stdout == b.stdout, args
+    # a working process blocked on its input (a FIFO nobody writes to) is killed: the parent ends by the same signal
+    fifo = str(tmp_path / "never.gam")
+    os.mkfifo(fifo)
+    g = hc.synth_graph(seed=5, genome_len=400, n_nodes=280, n_paths=8)
+    g.write(str(tmp_path))
+    p = subprocess.Popen([VGAN, "haplocart", "-g", fifo, "--hc-files", str(tmp_path), "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    kids = []
+    for _ in range(100):  # the child appears
+        time.sleep(0.02)
+        try:
+            kids = [int(x) for x in open("/proc/%d/task/%d/children" % (p.pid, p.pid)).read().split()]
+        except OSError:
+            kids = []
+        if kids:
+            break
+    assert len(kids) == 1
+    os.kill(kids[0], signal.SIGTERM)
+    p.communicate(timeout=20)
+    assert p.returncode == -signal.SIGTERM
+    # and the other way round: the parent is killed, the working process does not outlive it
+    p = subprocess.Popen([VGAN, "haplocart", "-g", fifo, "--hc-files", str(tmp_path), "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    for _ in range(100):
+        time.sleep(0.02)
+        try:
+            kids = [int(x) for x in open("/proc/%d/task/%d/children" % (p.pid, p.pid)).read().split()]
+        except OSError:
+            kids = []
+        if kids:
+            break
+    assert len(kids) == 1
+    p.kill()
+    p.communicate(timeout=20)
+    for _ in range(100):
+        if not os.path.exists("/proc/%d" % kids[0]) or open("/proc/%d/stat" % kids[0]).read().split()[2] == "Z":
+            break
+        time.sleep(0.05)
+    else:
+        raise AssertionError("the working process outlived its parent")

@@ -9,6 +9,12 @@
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/prctl.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <iostream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,6 +26,78 @@
 namespace vgan_cli {
 
 [[noreturn]] inline void die(const std::string &msg) { throw std::runtime_error(msg); }
+
+// ---- leaving without waiting for the teardown ------------------------------------------------------------------------
+// A run leaves gigabytes resident and a GPU context behind; the kernel takes them apart inside the process's exit
+// (0.2-0.6 s for the 3-4 GB of a million reads), after every output has been written.  So the work runs in a CHILD process
+// (forked before anything touches the GPU or starts a thread); when its outputs are flushed it sends its exit code through a
+// pipe, lets go of stdin / stdout / stderr and exits -- and the parent, which did nothing but wait for that byte, leaves with
+// the code at once while the child's exit is still freeing memory.  (mold, the linker, returns the same way.)  A child that
+// dies without a result is waited for and its fate passed on; a parent that dies takes the child with it (PR_SET_PDEATHSIG)
+// until the result is out.  Not done when VGAN_NO_FORK is set, nor under tools that preload into the process (a profiler's
+// library has initialised the GPU before main: such a process must not fork).
+struct EarlyLeave {
+    int fd = -1; // write end of the result pipe (in the child)
+    static EarlyLeave &get() {
+        static EarlyLeave e;
+        return e;
+    }
+    // In the parent: does not return (leaves with the child's code).  In the child, or when forking is off: returns.
+    void start() {
+        if (getenv("VGAN_NO_FORK") || getenv("VGAN_KEEP_TEARDOWN") || getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIB") || getenv("ROCPROFILER_LIBRARY_PATH"))
+            return;
+        if (const char *pre = getenv("LD_PRELOAD")) // a profiler's tool library in the process: the GPU is up before main
+            if (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "rocprofiler")) return;
+        int pfd[2];
+        if (pipe2(pfd, O_CLOEXEC) != 0) return;
+        fflush(nullptr);
+        const pid_t pid = fork();
+        if (pid < 0) {
+            close(pfd[0]);
+            close(pfd[1]);
+            return;
+        }
+        if (pid == 0) {
+            close(pfd[0]);
+            (void)prctl(PR_SET_PDEATHSIG, SIGKILL);
+            if (getppid() == 1) _exit(1); // the parent is gone already
+            fd = pfd[1];
+            return;
+        }
+        close(pfd[1]);
+        unsigned char code = 0;
+        ssize_t k;
+        do k = read(pfd[0], &code, 1);
+        while (k < 0 && errno == EINTR);
+        if (k == 1) _exit(code);
+        int st = 0; // no result: the child was killed or crashed
+        while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {
+        }
+        if (WIFSIGNALED(st)) {
+            signal(WTERMSIG(st), SIG_DFL);
+            raise(WTERMSIG(st));
+        }
+        _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);
+    }
+    // Every output is written: flush, hand the code over, leave.
+    [[noreturn]] void finish(int code) {
+        std::cout.flush();
+        std::cerr.flush();
+        fflush(nullptr);
+        if (fd >= 0) {
+            (void)prctl(PR_SET_PDEATHSIG, 0);
+            const unsigned char b = (unsigned char)code;
+            ssize_t k;
+            do k = write(fd, &b, 1);
+            while (k < 0 && errno == EINTR);
+            close(fd);
+            close(0);
+            close(1);
+            close(2);
+        }
+        _exit(code);
+    }
+};
 
 inline void check(int rc, const char *what) {
     if (rc < 0) die(std::string("[vgan] ") + what + ": " + vgan_last_error());

@@ -547,10 +547,7 @@ int haplocart(int argc, char **argv) {
         if (getenv("VGAN_TIMING"))
             fprintf(stderr, "[vgan timing] wall clock at exit: %.6f\n",
                     std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
-        std::cout.flush();
-        std::cerr.flush();
-        fflush(nullptr);
-        _exit(0);
+        EarlyLeave::get().finish(0);
     }
     pt.lap("teardown");
     return 0;
@@ -577,13 +574,17 @@ int main(int argc, char **argv) {
         }
         const std::string cmd = argv[1];
         if (cmd == "haplocart" || cmd == "euka" || cmd == "soibean") {
-            const int rc = cmd == "haplocart" ? haplocart(argc - 1, argv + 1) : cmd == "euka" ? euka_main(argc - 1, argv + 1) : soibean_main(argc - 1, argv + 1);
+            EarlyLeave::get().start(); // (the parent of the working process leaves from inside this call: cli_util.h)
+            int rc;
+            try {
+                rc = cmd == "haplocart" ? haplocart(argc - 1, argv + 1) : cmd == "euka" ? euka_main(argc - 1, argv + 1) : soibean_main(argc - 1, argv + 1);
+            } catch (const std::exception &e) {
+                std::cerr << e.what() << std::endl;
+                rc = 1;
+            }
             // every output file is closed by now: leave without running the exit handlers (the HIP runtime's teardown and the
             // page-by-page release of gigabytes of alignments cost ~0.2 s that no one is waiting for)
-            std::cout.flush();
-            std::cerr.flush();
-            fflush(nullptr);
-            _exit(rc);
+            EarlyLeave::get().finish(rc);
         }
         if (cmd == "version") {
             std::cout << "vgan-mi355x ABI " << vgan_abi_version() << std::endl;
