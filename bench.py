@@ -80,7 +80,10 @@ def cpu_baseline(graph, alns, budget_s, ctx=None, hc=None):
     import orc
     import util
     og, oa = util.orc_graph_from_product(graph), util.orc_alnset_from_product(alns)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # as many OpenMP threads as the container may keep busy (affinity mask and cgroup CPU quota): threads beyond the quota are
+    # time-sliced on the same processors and only slow the loop down
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(affinity, host_cpu_quota()))
     done, t_used = 0, 0.0
     chunk = cores
     ref = None
@@ -101,10 +104,10 @@ def cpu_baseline(graph, alns, budget_s, ctx=None, hc=None):
     hoisted = n_h / (time.perf_counter() - t0)
     out = {"value": faithful, "unit": "reads/s", "cores": cores, "kind": "port",
            "sample": "first %d of the workload's reads, literal reference loops (oracle, long double, OpenMP x%d)" % (done, cores),
-           "hoisted_variant_reads_per_s": hoisted, "cpu_quota": host_cpu_quota()}
+           "hoisted_variant_reads_per_s": hoisted, "cpu_quota": host_cpu_quota(), "affinity_cpus": affinity}
     parity = None
     if ctx is not None and ref is not None:  # the device on the same sample
-        sub = hc.HostBatch(graph, alns, 0, done)
+        sub = hc.HostBatch(graph, alns, 0, done, packed=True)
         ctx.reset()
         ctx.accumulate(sub)
         got = ctx.finalize()
@@ -238,7 +241,8 @@ def cpu_baseline_soibean(g, alns, dm, sb, state_fn, freqs, budget_s):
     import numpy as np
     import orc
     import util
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(affinity, host_cpu_quota()))  # (threads beyond the container's CPU quota only time-slice)
     n = min(alns.n_reads, 20000)
     drop = np.ones(alns.n_reads, np.uint8)
     drop[:n] = 0
@@ -259,7 +263,7 @@ def cpu_baseline_soibean(g, alns, dm, sb, state_fn, freqs, budget_s):
     ctx.precompute(hb)
     got = float(ctx.loglike([st], 0.01, freqs)[0][0])
     err = abs(got - ref) / max(abs(ref), 1e-300)
-    return ({"value": rate, "unit": "reads*iterations/s", "cores": cores, "kind": "port", "cpu_quota": host_cpu_quota(),
+    return ({"value": rate, "unit": "reads*iterations/s", "cores": cores, "kind": "port", "cpu_quota": host_cpu_quota(), "affinity_cpus": affinity,
              "sample": "refresh over the first %d reads, %d repetitions (oracle, long double, OpenMP x%d)" % (n, reps, cores)},
             {"reads": int(n), "max_rel_err_vs_oracle": float(err), "tolerance": 1e-6})
 
@@ -488,7 +492,7 @@ def front_end_rates(graph, hc, seed, n=200_000):
         b = hc.AlnSet.read_gam(p)
         t_dec = time.perf_counter() - t0
     t0 = time.perf_counter()
-    hb = hc.HostBatch(graph, b)
+    hb = hc.HostBatch(graph, b, packed=True)
     t_fl = time.perf_counter() - t0
     from vgan_amd import _native as N
     return {"sample_reads": n, "gam_bytes": size, "decode_reads_per_s": n / t_dec, "flatten_reads_per_s": hb.n_reads / t_fl,
@@ -534,11 +538,10 @@ def main():
     for c0 in range(r0, r1, CHUNK_READS):
         c1 = min(r1, c0 + CHUNK_READS)
         alns = hc.synth_reads(graph, c1 - c0, seed=args.seed, read_len=args.read_len, first_read=c0)
-        hb = hc.HostBatch(graph, alns)
-        # resident in HBM in the layout the segment kernel streams: the upload's layout pass (vgan_hc_pack: byte moves, no
-        # arithmetic) runs once here, as the flatten does, and its time is reported beside the step
-        db = hc.DeviceBatch(hb, dev, ctx=ctx)
-        pack_ms += db.pack_ms
+        # the batch as the front half hands it over: vgan_hc_flatten*_packed writes the layout the segment kernel streams
+        # (byte moves, no arithmetic), the upload copies it as it is -- one copy in HBM, no layout pass on the device
+        hb = hc.HostBatch(graph, alns, packed=True)
+        db = hc.DeviceBatch(hb, dev)
         batches.append(db)
         n_reads += hb.n_reads
         n_seg += hb.n_segments
@@ -690,9 +693,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "HaploCart %s vs hcfiles-shaped mtDNA graph (11821 nodes, 5179 paths); step = reset + per-read "
-                                   "likelihood kernels over the flattened batch resident in HBM (packed per-column layout, written "
-                                   "once by the upload's layout pass: layout_pass_ms) + final_vec%s; GAM decode / flatten "
-                                   "(front_end) and get_posterior (posterior_ms) are timed beside it, not inside" % (
+                                   "likelihood kernels over the flattened batch resident in HBM in the layout the host flatten step "
+                                   "writes (vgan_hc_flatten_packed: one copy, no device-side layout pass) + final_vec%s; GAM decode / "
+                                   "flatten (front_end) and get_posterior (posterior_ms) are timed beside it, not inside" % (
                                        what, " + RCCL reduce" if world > 1 else ""),
                        "reads_per_gpu": n_reads, "reads_total": int(total_reads), "segments_per_read": n_seg / max(n_reads, 1),
                        "mode": args.mode, "device_batches_per_gpu": len(batches),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGAN_ABI_VERSION 3
+#define VGAN_ABI_VERSION 4
 
 enum {
     VGAN_OK = 0,
@@ -232,6 +232,42 @@ int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p, int64_t p
                           int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
 int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out);
 void vgan_hc_host_batch_free(vgan_hc_host_batch *b);
+
+/* (ABI 4) The packed batch: the reads that satisfy the tile contract, in the layout the segment kernel streams -- what the
+ * front half hands to the device for every read the kernel can take whole (HaploCart touches each read once,
+ * HaploCart.cpp:408-421: the layout is written once, by the flatten step, and nothing on the device re-arranges it).
+ * Bytes are moved and nothing else: no comparison, clamp or table lookup happens before the kernel.
+ *   rhdr   uint32 [4 * (n_reads + 1)]  per read {first segment, first quality byte, first column, |algnseq| | mapq << 16};
+ *                                      entry n_reads holds the three end offsets
+ *   srec   uint32 [2 * n_segments]     per mapping {node id, seg_start | (read index & 0xFFFF) << 16}
+ *   crec   uint32 [n_cols]             per alignment column, at the column's own position: byte 0 graph_seq[c], byte 1
+ *                                      algnseq[c - seg_start] (the read bases are taken from the READ start,
+ *                                      update_likelihood.cpp:46), byte 2 qual[c] (0 past the quality string), bit 31 set on
+ *                                      the first column of a mapping; a column no mapping scores is 0
+ *   qualp  uint8 [n_qual + 32]         the quality strings, followed by 32 zero bytes (aligned 8-byte words are read whole)
+ * Reads in ascending order of their lowest node id (any order gives the same sums, slower).  The per-read maxima select the
+ * kernel variant.  on_device: the four arrays are device pointers (a batch resident in HBM, zero copy). */
+typedef struct vgan_hc_packed_view {
+    uint32_t n_reads;
+    uint32_t n_segments;
+    uint64_t n_cols;
+    uint64_t n_qual;
+    const uint32_t *rhdr;
+    const uint32_t *srec;
+    const uint32_t *crec;
+    const uint8_t *qualp;
+    uint32_t max_read_segs, max_read_qual, max_read_cols; /* over the reads: <= 512 / 1280 / 1280 (the tile contract) */
+    int32_t on_device;
+    const uint32_t *read_src; /* [n_reads] index of each read in the alignment set (host; not used by the device), or NULL */
+} vgan_hc_packed_view;
+/* As vgan_hc_flatten_masked / vgan_hc_flatten_parts, but the reads that satisfy the tile contract leave in the packed layout
+ * (vgan_hc_host_batch_get_packed) and vgan_hc_host_batch_get returns the OTHER reads alone, as a batch of its own
+ * (n_tileable = 0, offsets from 0).  A job hands both to the context: vgan_hc_accumulate_packed + vgan_hc_accumulate. */
+int vgan_hc_flatten_packed(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip, int n_threads,
+                           vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
+int vgan_hc_flatten_parts_packed(const vgan_graph *g, const vgan_alnparts *p, int64_t part0, int64_t part1, const uint8_t *skip,
+                                 int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats);
+int vgan_hc_host_batch_get_packed(const vgan_hc_host_batch *b, vgan_hc_packed_view *out);
 /* a1 on its own, for the reconstruction KATs: strings are NUL terminated into caller buffers of cap bytes. */
 int vgan_reconstruct(const vgan_graph *g, const vgan_alnset *a, int64_t r, char *graph_seq, char *read_seq,
                      int32_t *mppg_sizes, int64_t cap, int64_t *lens /* [3] */);
@@ -300,8 +336,18 @@ int vgan_hc_batch_validate(const vgan_hc_ctx *c, const vgan_hc_batch *batch);
 typedef struct vgan_hc_packed vgan_hc_packed; /* opaque */
 int vgan_hc_pack(vgan_hc_ctx *c, const vgan_hc_batch *batch, vgan_hc_packed **out);
 void vgan_hc_packed_free(vgan_hc_packed *p);
+/* What the layout pass wrote, copied to host arrays sized as in vgan_hc_packed_view (test aid: the host flatten's packed
+ * layout is held against it word for word).  n[4] receives reads, segments, columns, quality bytes; any array may be NULL. */
+int vgan_hc_packed_download(const vgan_hc_packed *p, uint64_t n[4], uint32_t *rhdr, uint32_t *srec, uint32_t *crec, uint8_t *qualp);
 /* Asynchronous on the context's stream: adds the batch's reads into the device accumulators. */
 int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *batch);
+/* (ABI 4) The same for a packed batch: host arrays are copied to the device as they are (one copy of the batch in HBM, no
+ * layout pass), device arrays are read in place.  All three modes. */
+int vgan_hc_accumulate_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
+/* Host check of a packed batch against the layout above and the context's graph (offsets, node ids, head bits, maxima). */
+int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
+/* D_m = S_m - U_m per segment of a packed batch (test / debug aid). Host output [n_segments]. */
+int vgan_hc_segment_weights_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *batch, double *D);
 /* Per-segment scalars of a batch (test / debug aid): S_m, U_m as the kernel computes them. Host outputs. */
 int vgan_hc_segment_scalars(vgan_hc_ctx *c, const vgan_hc_batch *batch, double *S, double *U);
 /* D_m = S_m - U_m per segment as vgan_hc_accumulate computes it, i.e. through the LDS-tiled kernel for the batch's

@@ -207,21 +207,35 @@ def test_json_dump_of_the_alignments(tmp_path, golden_dir):
 
 
 def test_the_working_process_and_its_early_leaving_parent(tmp_path):
-    """cli_util.h EarlyLeave: the subcommand runs in a child, the parent leaves with the child's code as soon as the outputs are
-    flushed.  Exit codes and messages are those of the run in one process (VGAN_NO_FORK=1); a working process that is killed
-    takes its parent with it by the same signal; nothing stays behind holding the caller's pipes."""
+    """cli_util.h EarlyLeave (opt-in: VGAN_EARLY_LEAVE=1): the subcommand runs in a child, the parent leaves with the child's
+    code as soon as the outputs are flushed.  Exit codes and messages are those of the run in one process (the default); a
+    working process that is killed takes its parent with it by the same signal; nothing stays behind holding the caller's
+    pipes; vgan as pid 1 of a pid namespace (`docker run image vgan ...`) works the same."""
+    import shutil
     import signal
     import time
+    early = dict(os.environ, VGAN_EARLY_LEAVE="1")
     for args in (["haplocart", "-e", "1.5"], ["haplocart", "-g", str(tmp_path / "missing.gam")], ["euka", "-t", "0"], ["soibean", "--iter", "x"]):
-        a = subprocess.run([VGAN] + args, capture_output=True, text=True)
-        b = subprocess.run([VGAN] + args, capture_output=True, text=True, env=dict(os.environ, VGAN_NO_FORK="1"))
+        a = subprocess.run([VGAN] + args, capture_output=True, text=True, env=early)
+        b = subprocess.run([VGAN] + args, capture_output=True, text=True)
         assert a.returncode == b.returncode != 0 and a.stderr == b.stderr and a.stdout == b.stdout, args
+    # as pid 1: the working child's parent legitimately has pid 1
+    for ns in (["unshare", "-p", "-f"], ["unshare", "-p", "-f", "-r"]):  # (a new pid namespace needs privilege or a user namespace)
+        if not shutil.which("unshare") or subprocess.run(ns + [VGAN, "haplocart", "-h"], capture_output=True).returncode in (1, 126, 127) and \
+                subprocess.run(ns + ["true"], capture_output=True).returncode != 0:
+            continue
+        b = subprocess.run([VGAN, "haplocart", "-h"], capture_output=True, text=True)
+        a = subprocess.run(ns + [VGAN, "haplocart", "-h"], capture_output=True, text=True, env=early)
+        if a.returncode == 126:  # the binary cannot be executed from inside that namespace (path permissions)
+            continue
+        assert a.returncode == b.returncode and a.stdout == b.stdout and a.stderr == b.stderr
+        break
     # a working process blocked on its input (a FIFO nobody writes to) is killed: the parent ends by the same signal
     fifo = str(tmp_path / "never.gam")
     os.mkfifo(fifo)
     g = hc.synth_graph(seed=5, genome_len=400, n_nodes=280, n_paths=8)
     g.write(str(tmp_path))
-    p = subprocess.Popen([VGAN, "haplocart", "-g", fifo, "--hc-files", str(tmp_path), "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = subprocess.Popen([VGAN, "haplocart", "-g", fifo, "--hc-files", str(tmp_path), "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=early)
     kids = []
     for _ in range(100):  # the child appears
         time.sleep(0.02)
@@ -236,7 +250,7 @@ def test_the_working_process_and_its_early_leaving_parent(tmp_path):
     p.communicate(timeout=20)
     assert p.returncode == -signal.SIGTERM
     # and the other way round: the parent is killed, the working process does not outlive it
-    p = subprocess.Popen([VGAN, "haplocart", "-g", fifo, "--hc-files", str(tmp_path), "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = subprocess.Popen([VGAN, "haplocart", "-g", fifo, "--hc-files", str(tmp_path), "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=early)
     for _ in range(100):
         time.sleep(0.02)
         try:

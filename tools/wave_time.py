@@ -14,9 +14,9 @@ rl = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 g = hc.synth_graph(seed=1)
 a = hc.synth_reads(g, n, seed=2, read_len=rl)
-hb = hc.HostBatch(g, a)
+hb = hc.HostBatch(g, a, packed=True)
 ctx = hc.HcContext(g)
-db = hc.DeviceBatch(hb, ctx=ctx)
+db = hc.DeviceBatch(hb)
 for _ in range(3):
     ctx.accumulate(db)
 ctx.reset()

@@ -38,6 +38,12 @@ class HcBatch(C.Structure):
                 ("read_src", vp), ("packed", vp)]
 
 
+class HcPackedView(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_segments", C.c_uint32), ("n_cols", C.c_uint64), ("n_qual", C.c_uint64),
+                ("rhdr", vp), ("srec", vp), ("crec", vp), ("qualp", vp), ("max_read_segs", C.c_uint32),
+                ("max_read_qual", C.c_uint32), ("max_read_cols", C.c_uint32), ("on_device", C.c_int32), ("read_src", vp)]
+
+
 class FlattenStats(C.Structure):
     _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64), ("n_unmapped", C.c_int64), ("n_bad", C.c_int64),
                 ("n_clamped", C.c_int64), ("n_segments", C.c_int64), ("n_cols", C.c_int64)]
@@ -193,6 +199,13 @@ SYMBOLS = {
     "vgan_hc_flatten_parts": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
     "vgan_hc_flatten_masked": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
     "vgan_hc_host_batch_get": (C.c_int, [vp, C.POINTER(HcBatch)]),
+    "vgan_hc_flatten_packed": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
+    "vgan_hc_flatten_parts_packed": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int, C.POINTER(vp), C.POINTER(FlattenStats)]),
+    "vgan_hc_host_batch_get_packed": (C.c_int, [vp, C.POINTER(HcPackedView)]),
+    "vgan_hc_accumulate_packed": (C.c_int, [vp, C.POINTER(HcPackedView)]),
+    "vgan_hc_packed_validate": (C.c_int, [vp, C.POINTER(HcPackedView)]),
+    "vgan_hc_segment_weights_packed": (C.c_int, [vp, C.POINTER(HcPackedView), vp]),
+    "vgan_hc_packed_download": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "vgan_hc_host_batch_free": (None, [vp]),
     "vgan_reconstruct": (C.c_int, [vp, vp, C.c_int64, C.c_char_p, C.c_char_p, vp, C.c_int64, vp]),
     "vgan_hc_create": (C.c_int, [C.POINTER(GraphView), C.POINTER(HcParams), C.c_int, C.POINTER(vp)]),
@@ -269,7 +282,7 @@ SYMBOLS = {
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),
 }
 
-ABI_VERSION = 3  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
+ABI_VERSION = 4  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
 
 HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the null stream by name (a NULL argument selects the context's own stream)
 

@@ -120,6 +120,7 @@ struct vgan_hc_ctx {
     vgan_hc_packed scratch_pack; // layout pass output of batches that come without a packed companion
     DevBuf<uint32_t> work_ctr;   // the segment kernel's work queue (hc_wave_kernels.hip)
     uint32_t work_base = 0;
+    bool work_dirty = false;     // a launch failed or the stream changed: counter and mirror start over
     bool touched = false;        // something was accumulated since the last reset (vgan_hc_reduce leaves the others out)
     // posterior
     std::vector<std::string> path_names;
@@ -308,6 +309,8 @@ int pack_into(vgan_hc_ctx *c, const vgan_hc_batch *b, const HcBatchDev &d, uint3
     return VGAN_OK;
 }
 
+int ensure_work_queue(vgan_hc_ctx *c);
+
 // D_m per segment (segD) and / or W[node] += D_m (nodeW) and the totals for every read of the batch: the tileable reads
 // through the wave kernel on their packed form (the batch's companion, or the context's scratch filled here), the others
 // through the general kernel.  `staged`: d holds the batch's arrays on the device already.
@@ -344,16 +347,81 @@ int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *n
     }
     ScopedTimer t(c, VGAN_HC_K_SEGMENT);
     if (pk && wave_kernel_enabled()) {
-        if (!c->work_ctr.p) {
-            if ((rc = c->work_ctr.reserve(16))) return rc;
-            HIPCHK(hipMemsetAsync(c->work_ctr.p, 0, 64, c->stream));
-            c->work_base = 0;
-        }
+        if ((rc = ensure_work_queue(c))) return rc;
         launch_hc_segments_wave(c->g, pk->d, c->prm, segD, nodeW, totals, c->work_ctr.p, &c->work_base, c->stream);
+        if (hipPeekAtLastError() != hipSuccess) c->work_dirty = true;
         launch_hc_segments_general(c->g, d, c->prm, nt, nullptr, nullptr, segD, nodeW, totals, c->stream);
     } else {
         // (a device batch without a companion, reads beyond every variant of the wave kernel)
         launch_hc_segments(c->g, d, c->prm, nt, mean_cols, nullptr, nullptr, segD, nodeW, totals, c->stream);
+    }
+    return VGAN_OK;
+}
+
+// A packed batch on the device: in place when it is there already, else copied as it is into the context's scratch
+// (the one copy of the batch HBM holds; no layout pass).
+int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d) {
+    if (!v) return fail(VGAN_EINVAL, "null packed batch");
+    d = HcPackedDev{};
+    d.n_reads = v->n_reads;
+    d.n_segments = v->n_segments;
+    d.n_cols = v->n_cols;
+    d.n_qual = v->n_qual;
+    d.max_read_segs = v->max_read_segs;
+    d.max_read_qual = v->max_read_qual;
+    d.max_read_cols = v->max_read_cols;
+    if (v->n_reads == 0) return VGAN_OK;
+    if (!v->rhdr || !v->srec || !v->crec || !v->qualp) return fail(VGAN_EINVAL, "packed batch: null array");
+    if (v->max_read_segs > HC_TILE_MAX_READ_SEGS || v->max_read_qual > HC_TILE_MAX_READ_QUAL || v->max_read_cols > HC_TILE_MAX_READ_COLS ||
+        v->max_read_segs == 0)
+        return fail(VGAN_EINVAL, "packed batch: per-read maxima missing or beyond the tile contract (512 segments / 1280 quality bytes / 1280 columns)");
+    if (v->n_cols > 0xFFFFFFF0ull || v->n_qual > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "packed batch: more than 2^32 columns or quality bytes");
+    if (v->on_device) {
+        d.rhdr = reinterpret_cast<const uint4 *>(v->rhdr);
+        d.srec = reinterpret_cast<const uint2 *>(v->srec);
+        d.crec = v->crec;
+        d.qualp = v->qualp;
+        return VGAN_OK;
+    }
+    int rc;
+    vgan_hc_packed &P = c->scratch_pack;
+    P.device = c->device;
+    if ((rc = P.rhdr.reserve((size_t)v->n_reads + 1)) || (rc = P.srec.reserve(std::max<size_t>(1, v->n_segments))) ||
+        (rc = P.crec.reserve(std::max<size_t>(1, v->n_cols))) || (rc = P.qualp.reserve((size_t)v->n_qual + 32)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(P.rhdr.p, v->rhdr, ((size_t)v->n_reads + 1) * 16, hipMemcpyHostToDevice, c->stream));
+    if (v->n_segments) HIPCHK(hipMemcpyAsync(P.srec.p, v->srec, (size_t)v->n_segments * 8, hipMemcpyHostToDevice, c->stream));
+    if (v->n_cols) HIPCHK(hipMemcpyAsync(P.crec.p, v->crec, (size_t)v->n_cols * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(P.qualp.p, v->qualp, (size_t)v->n_qual + 32, hipMemcpyHostToDevice, c->stream));
+    d.rhdr = P.rhdr.p;
+    d.srec = P.srec.p;
+    d.crec = P.crec.p;
+    d.qualp = P.qualp.p;
+    return VGAN_OK;
+}
+
+int ensure_work_queue(vgan_hc_ctx *c) {
+    int rc;
+    if (!c->work_ctr.p || c->work_dirty) {
+        if (!c->work_ctr.p && (rc = c->work_ctr.reserve(16))) return rc;
+        HIPCHK(hipMemsetAsync(c->work_ctr.p, 0, 64, c->stream));
+        c->work_base = 0;
+        c->work_dirty = false;
+    }
+    return VGAN_OK;
+}
+
+// the wave kernel over a packed batch on the device: D_m per segment and / or W[node] += D_m, and the totals
+int run_packed(vgan_hc_ctx *c, const HcPackedDev &d, double *segD, double *nodeW, double *totals) {
+    int rc;
+    if (d.n_reads == 0) return VGAN_OK;
+    if (nodeW || totals) c->touched = true;
+    if ((rc = ensure_work_queue(c))) return rc;
+    ScopedTimer t(c, VGAN_HC_K_SEGMENT);
+    launch_hc_segments_wave(c->g, d, c->prm, segD, nodeW, totals, c->work_ctr.p, &c->work_base, c->stream);
+    if (hipGetLastError() != hipSuccess) {
+        c->work_dirty = true; // (the host's mirror of the ticket counter no longer holds: the next launch starts it over)
+        return fail(VGAN_ENODEV, "the segment kernel could not be launched");
     }
     return VGAN_OK;
 }
@@ -560,7 +628,11 @@ extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
 
 extern "C" int vgan_hc_set_stream(vgan_hc_ctx *c, void *hip_stream) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_set_stream: null context");
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    // (what is queued on the stream left behind is not waited for: a caller that changes streams between two accumulates
+    // orders them itself -- include/vgan_gpu.h; the work queue's counter starts over on the new stream)
+    const hipStream_t ns = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (ns != c->stream) c->work_dirty = true;
+    c->stream = ns;
     return VGAN_OK;
 }
 
@@ -669,6 +741,97 @@ extern "C" int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *b) {
         launch_hc_sweep(c->g, d.seg_node, c->segD.p, b->n_segments, c->mode == VGAN_HC_MODE_PER_READ, c->acc_seg.p, c->stream);
     }
     HIPCHK(hipGetLastError());
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_accumulate_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_hc_accumulate_packed: null context");
+    if (!v) return fail(VGAN_EINVAL, "vgan_hc_accumulate_packed: null batch");
+    if (v->n_reads == 0) return VGAN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    HcPackedDev d{};
+    if ((rc = stage_packed(c, v, d))) return rc;
+    if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) return run_packed(c, d, nullptr, c->nodeW.p, c->totals.p);
+    // the reference's loop order: D_m per segment, then every segment's mask row over the P accumulators
+    if ((rc = c->segD.reserve(v->n_segments)) || (rc = c->s_u32.reserve(v->n_segments))) return rc;
+    if ((rc = run_packed(c, d, c->segD.p, nullptr, c->totals.p))) return rc;
+    launch_hc_srec_nodes(d.srec, v->n_segments, c->s_u32.p, c->stream);
+    ScopedTimer t(c, VGAN_HC_K_SWEEP_SEG);
+    launch_hc_sweep(c->g, c->s_u32.p, c->segD.p, v->n_segments, c->mode == VGAN_HC_MODE_PER_READ, c->acc_seg.p, c->stream);
+    HIPCHK(hipGetLastError());
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_segment_weights_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, double *D) {
+    if (!c || !v || !D) return fail(VGAN_EINVAL, "vgan_hc_segment_weights_packed: null argument");
+    if (v->n_reads == 0 || v->n_segments == 0) return VGAN_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    HcPackedDev d{};
+    if ((rc = stage_packed(c, v, d)) || (rc = c->segD.reserve(v->n_segments))) return rc;
+    if ((rc = run_packed(c, d, c->segD.p, nullptr, nullptr))) return rc;
+    HIPCHK(hipMemcpyAsync(D, c->segD.p, (size_t)v->n_segments * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packed_view *v) {
+    if (!c || !v) return fail(VGAN_EINVAL, "vgan_hc_packed_validate: null argument");
+    if (v->on_device) return fail(VGAN_EINVAL, "vgan_hc_packed_validate: the batch must be in host memory");
+    const uint64_t R = v->n_reads, S = v->n_segments;
+    if (R == 0) return VGAN_OK;
+    if (!v->rhdr || !v->srec || !v->crec || !v->qualp) return fail(VGAN_EINVAL, "packed batch: null array");
+    const uint32_t *h = v->rhdr;
+    if (h[0] != 0 || h[1] != 0 || h[2] != 0) return fail(VGAN_EINVAL, "packed batch: offsets do not start at 0");
+    if (h[4 * R] != S || h[4 * R + 1] != v->n_qual || h[4 * R + 2] != v->n_cols)
+        return fail(VGAN_EINVAL, "packed batch: final offsets do not match n_segments / n_qual / n_cols");
+    uint32_t ms = 0, mq = 0, mc = 0;
+    for (uint64_t r = 0; r < R; ++r) {
+        const uint32_t *a = h + 4 * r, *b = a + 4;
+        if (b[0] < a[0] || b[1] < a[1] || b[2] < a[2]) return fail(VGAN_EINVAL, "packed batch: offsets of read %llu descend", (unsigned long long)r);
+        const uint32_t ns = b[0] - a[0], nq = b[1] - a[1], ncol = b[2] - a[2], A = a[3] & 0xFFFFu, mapq = a[3] >> 16;
+        if (ns == 0 || ns > HC_TILE_MAX_READ_SEGS || nq > HC_TILE_MAX_READ_QUAL || ncol > HC_TILE_MAX_READ_COLS)
+            return fail(VGAN_EINVAL, "packed batch: read %llu is outside the tile contract", (unsigned long long)r);
+        if (A != ncol) return fail(VGAN_EINVAL, "packed batch: |algnseq| of read %llu differs from its column count", (unsigned long long)r);
+        if (mapq > 99) return fail(VGAN_EINVAL, "packed batch: mapping quality of read %llu exceeds 99", (unsigned long long)r);
+        ms = std::max(ms, ns);
+        mq = std::max(mq, nq);
+        mc = std::max(mc, ncol);
+        uint32_t prev_end = 0;
+        for (uint32_t s = a[0]; s < b[0]; ++s) {
+            const uint32_t node = v->srec[2 * (size_t)s], w = v->srec[2 * (size_t)s + 1], st = w & 0xFFFFu;
+            if (node >= c->rows) return fail(VGAN_EINVAL, "packed batch: segment %u names node %u, beyond the graph", s, node);
+            if ((w >> 16) != ((uint32_t)r & 0xFFFFu)) return fail(VGAN_EINVAL, "packed batch: segment %u does not carry its read's index", s);
+            if (st < prev_end || st >= ncol) return fail(VGAN_EINVAL, "packed batch: segments of read %llu overlap, descend or leave its columns", (unsigned long long)r);
+            if (!(v->crec[(size_t)a[2] + st] & 0x80000000u)) return fail(VGAN_EINVAL, "packed batch: segment %u has no head bit at its first column", s);
+            prev_end = st + 1;
+        }
+        uint32_t heads = 0;
+        for (uint32_t col = 0; col < ncol; ++col) heads += v->crec[(size_t)a[2] + col] >> 31;
+        if (heads != ns) return fail(VGAN_EINVAL, "packed batch: read %llu has %u head bits for %u segments", (unsigned long long)r, heads, ns);
+    }
+    if (ms > v->max_read_segs || mq > v->max_read_qual || mc > v->max_read_cols)
+        return fail(VGAN_EINVAL, "packed batch: a read exceeds the stated per-read maxima");
+    for (int i = 0; i < 32; ++i)
+        if (v->qualp[v->n_qual + i] != 0) return fail(VGAN_EINVAL, "packed batch: the quality array is not followed by 32 zero bytes");
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_packed_download(const vgan_hc_packed *p, uint64_t n[4], uint32_t *rhdr, uint32_t *srec, uint32_t *crec, uint8_t *qualp) {
+    if (!p) return fail(VGAN_EINVAL, "vgan_hc_packed_download: null argument");
+    HIPCHK(hipSetDevice(p->device));
+    if (n) {
+        n[0] = p->d.n_reads;
+        n[1] = p->d.n_segments;
+        n[2] = p->d.n_cols;
+        n[3] = p->d.n_qual;
+    }
+    if (p->d.n_reads == 0) return VGAN_OK;
+    if (rhdr) HIPCHK(hipMemcpy(rhdr, p->d.rhdr, ((size_t)p->d.n_reads + 1) * 16, hipMemcpyDeviceToHost));
+    if (srec && p->d.n_segments) HIPCHK(hipMemcpy(srec, p->d.srec, (size_t)p->d.n_segments * 8, hipMemcpyDeviceToHost));
+    if (crec && p->d.n_cols) HIPCHK(hipMemcpy(crec, p->d.crec, (size_t)p->d.n_cols * 4, hipMemcpyDeviceToHost));
+    if (qualp) HIPCHK(hipMemcpy(qualp, p->d.qualp, (size_t)p->d.n_qual + 32, hipMemcpyDeviceToHost));
     return VGAN_OK;
 }
 

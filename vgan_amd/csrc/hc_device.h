@@ -114,6 +114,8 @@ bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_
 // next launch starts (kept by the caller between launches on the one stream)
 void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *segD, double *nodeW,
                              double *totals, uint32_t *work_ctr, uint32_t *work_base, hipStream_t st);
+// node ids of the packed segment records into a plain array (the per-segment mask sweep reads them eight at a time)
+void launch_hc_srec_nodes(const uint2 *srec, uint32_t n_segments, uint32_t *out, hipStream_t st);
 // reads [r_begin, n_reads) through the general kernel (one wave per read, any length)
 void launch_hc_segments_general(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t r_begin, double *segS,
                                 double *segU, double *segD, double *nodeW, double *totals, hipStream_t st);

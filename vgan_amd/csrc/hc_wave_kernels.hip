@@ -45,9 +45,15 @@ namespace wv {
 #define WV_GROUP 1 // column chunks whose LDS reads are issued together (2: measured 3 % slower)
 #endif
 #ifndef WV_OCC
-#define WV_OCC 4 // workgroups per CU the small variant is compiled for (waves per SIMD: registers)
+#define WV_OCC 4 // waves per SIMD the small variant is compiled for (registers; LDS: WV_OCC * 4 waves' slices + tables per CU)
 #endif
-constexpr int WV_THREADS = 256;
+#ifndef WV_WG_THREADS
+#define WV_WG_THREADS 256 // a workgroup shares nothing but the read-only tables: its size only sets how often they are built
+#endif
+#ifndef WV_SUB
+#define WV_SUB 1 // accumulator sub-slots per window entry (lane parity picks one: halves the same-address LDS adds of a segment)
+#endif
+constexpr int WV_THREADS = WV_WG_THREADS;
 constexpr int WV_WAVES = WV_THREADS / 64;
 constexpr int WV_NR = 8;    // reads per tile at most (their headers travel in lanes 0..WV_NR of the wave)
 #ifndef WV_WIN_SLOTS
@@ -69,13 +75,17 @@ struct alignas(32) WvRead { // per read of the tile
     uint32_t qoff;      // first quality byte, relative to the tile's quality window
 };
 
-template <int CAPS, int CAPQ> struct WvSlice { // one wave's LDS
+// DIRECT (node-weights accumulation only): a column's term goes straight into the W window slot of its mapping's node --
+// no per-segment sum S, no pass over the segments behind the column loop.  slot[]: the segment's byte offset into win[], or
+// 0x80000000 | node id for a node outside the window.
+template <int CAPS, int CAPQ, bool DIRECT> struct WvSlice { // one wave's LDS
     WvKL kl[CAPS];
-    double S[CAPS];
+    double S[DIRECT ? 1 : CAPS];
+    uint32_t slot[DIRECT ? CAPS : 1];
     uint32_t ps[CAPQ + 16]; // ps[4 + i]: prefix through byte i of the quality window (ps[3] = 0: the empty prefix)
     WvRead rd[WV_NR];
     uint32_t first90[WV_NR];
-    double win[WV_WIN];
+    double win[WV_WIN * (DIRECT ? WV_SUB : 1)];
 };
 
 __device__ const LogTabEntry wv_log_table[64] = {VGAN_LOG_TABLE};
@@ -201,13 +211,14 @@ template <int SPASS, int QCH, int NCH> struct WvData { // one tile's HBM data, i
 // requested as a fixed set of loads (bounded by the buffer descriptors: what lies beyond the tile comes back as zeros) one
 // tile ahead.  No load in the tile loop is conditional -- s_waitcnt vmcnt counts in order, and the compiler can only wait for
 // exactly the loads it needs when it knows how many were issued after them.
-template <int CAPS, int CAPQ, int CAPC>
+template <int CAPS, int CAPQ, int CAPC, bool DIRECT>
 __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_segment_wave_kernel(WvArgs a) {
     constexpr int SPASS = (CAPS + 63) / 64;     // segment passes per tile at most
     constexpr int QCH = (CAPQ + 8 + 511) / 512; // quality chunks (512 bytes: 8 per lane) per tile at most
     constexpr int NCH = CAPC / 64;              // column chunks per tile at most
     static_assert(CAPS >= 64 && CAPC % 64 == 0, "whole chunks");
-    using Slice = WvSlice<CAPS, CAPQ>;
+    using Slice = WvSlice<CAPS, CAPQ, DIRECT>;
+    constexpr int SUB = DIRECT ? WV_SUB : 1;
     using Data = WvData<SPASS, QCH, NCH>;
     __shared__ WvLom lom_s[101][2]; // [qscore index, 100 = background error rate][mismatch, match]
     __shared__ double bg_s[8];      // A C T G by (base >> 1) & 3
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     if (tid < 64) logtab_s[tid] = wv_log_table[tid];
     if (tid < 100) rdtab_s[tid] = WvRdTab{a.rdtab[3 * tid], a.rdtab[3 * tid + 1], a.rdtab[3 * tid + 2], 0.0};
     Slice &L = slice_s[wave];
-    for (int i = lane; i < WV_WIN; i += 64) L.win[i] = 0.0;
+    for (int i = lane; i < WV_WIN * SUB; i += 64) L.win[i] = 0.0;
     if (lane < 4) L.ps[lane] = 0u;
     __syncthreads(); // the only one: from here on every wave is on its own
 
@@ -295,16 +306,33 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     };
     auto window_flush = [&](uint32_t winbase) {
         for (uint32_t j = lane; j < (uint32_t)WV_WIN; j += 64) {
-            const double v = L.win[j];
+            double v = L.win[j * SUB];
+            if constexpr (SUB == 2) v += L.win[j * SUB + 1];
             if (v != 0.0) {
 #ifndef WV_NOFLUSH // (developer aid: what the flush's global atomics cost)
                 unsafeAtomicAdd(&a.nodeW[winbase + j], v);
 #endif
-                L.win[j] = 0.0;
+                L.win[j * SUB] = 0.0;
+                if constexpr (SUB == 2) L.win[j * SUB + 1] = 0.0;
             }
         }
     };
+    // The window sits at the lowest node id of the tile: the batch is sorted by the reads' lowest node id (vgan_hc_flatten), so
+    // the wave's reads stay above it and move through the node ids slowly.  Any other order is still correct -- a segment
+    // outside the window adds to W in HBM directly -- and a tile that leaves the window with many segments has the next one
+    // place it anew.
+    auto window_place = [&](const uint32_t (&nodes)[SPASS], const WvTile &t, uint32_t &winbase) {
+        uint32_t nmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < SPASS; ++k)
+            if ((uint32_t)k * 64u + (uint32_t)lane < t.n_seg) nmin = min(nmin, nodes[k]);
+        nmin = wave_min_u32(nmin);
+        if (winbase != 0xFFFFFFFFu) window_flush(winbase);
+        winbase = wv_first(nmin);
+        WV_COUNT(7, 1);
+    };
 
+    const uint32_t sub8 = SUB == 2 ? ((uint32_t)lane & 1u) * 8u : 0u; // the lane's accumulator sub-slot
     double c6 = 1.0 / 6.0; // the series' leading coefficient, kept in a vector register pair for the whole launch (an
     asm volatile("" : "+v"(c6)); // instruction takes one scalar operand; the other coefficients travel as scalars)
     double sumT = 0.0, sumU = 0.0;  // sum of S_m and of U_m, each without cancellation
@@ -429,6 +457,15 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         double segU[SPASS];
         uint32_t segnode[SPASS];
         bool tile_bep = false; // a segment of the tile takes the background error rate on its own (wave uniform)
+        bool tile_out = false; // DIRECT: a segment of the tile lies outside the W window (wave uniform)
+        if constexpr (DIRECT) {
+            if (need_place) {
+#pragma unroll
+                for (int k = 0; k < SPASS; ++k) segnode[k] = D.sr[k].x;
+                window_place(segnode, T, winbase);
+                need_place = false;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < SPASS; ++k) {
             segU[k] = 0.0;
@@ -466,7 +503,20 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                 }
                 if (CAPS % 64 == 0 || on) { // (the last pass of a capacity that is not whole passes)
                     L.kl[ls] = WvKL{kappa, lw};
-                    L.S[ls] = 0.0;
+                    if constexpr (!DIRECT) L.S[ls] = 0.0;
+                }
+                if constexpr (DIRECT) {
+                    // -U_m goes to the node's slot here, the columns' terms follow in D
+                    const uint32_t node = D.sr[k].x, sl = node - winbase;
+                    const bool inside = sl < (uint32_t)WV_WIN;
+                    if (CAPS % 64 == 0 || on) L.slot[ls] = inside ? sl * (8u * SUB) : (0x80000000u | node);
+                    if (on) {
+                        if (inside) unsafeAtomicAdd(&L.win[sl * SUB], -U);
+                        else unsafeAtomicAdd(&a.nodeW[node], -U);
+                    }
+                    const uint32_t n_out = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(on && !inside));
+                    tile_out = tile_out || n_out != 0;
+                    if (n_out > 16) need_place = true; // (the next tile places the window anew)
                 }
             }
         }
@@ -483,6 +533,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
             auto chunks = [&](auto n_tag, const uint32_t *recs) {
                 constexpr int N = decltype(n_tag)::value;
                 const WvKL *klp[N];
+                const uint32_t *slp[N];
                 double *Sp[N];
                 uint32_t own[N], row[N], rc8[N];
                 uint64_t valid[N], farm[N]; // lane masks (kept as masks: they only ever gate branches)
@@ -495,7 +546,8 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                     uint32_t sbase = segs_before + (uint32_t)(heads & 1u) - 1u;
                     asm volatile("" : "+s"(sbase)); // (kept whole: the -1 otherwise travels into a vector add per chunk)
                     klp[u] = L.kl + sbase;
-                    Sp[u] = L.S + sbase;
+                    slp[u] = L.slot + (DIRECT ? sbase : 0u);
+                    Sp[u] = L.S + (DIRECT ? 0u : sbase);
                     const uint64_t above0 = heads >> 1;
                     own[u] = __builtin_amdgcn_mbcnt_hi((uint32_t)(above0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)above0, 0u));
                     segs_before += (uint32_t)__builtin_popcountll(heads);
@@ -518,8 +570,12 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                         : "vcc");
                 }
                 WvKL kl[N];
+                uint32_t slv[N];
 #pragma unroll
-                for (int u = 0; u < N; ++u) kl[u] = klp[u][own[u]];
+                for (int u = 0; u < N; ++u) {
+                    kl[u] = klp[u][own[u]];
+                    if constexpr (DIRECT) slv[u] = slp[u][own[u]];
+                }
                 if (__builtin_expect(tile_bep, 0)) { // a segment behind a quality >= 90: row 100 holds the background error rate
 #pragma unroll
                     for (int u = 0; u < N; ++u)
@@ -573,8 +629,22 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < N; ++u)
-                    if (__builtin_amdgcn_inverse_ballot_w64(valid[u])) unsafeAtomicAdd(&Sp[u][own[u]], t[u]);
+                for (int u = 0; u < N; ++u) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(valid[u])) {
+                        if constexpr (DIRECT) {
+                            sumT += t[u];
+                            double *dst = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(L.win) + (slv[u] & 0x7FFFFFFFu) + sub8);
+                            if (__builtin_expect(tile_out, 0)) {
+                                if ((int32_t)slv[u] < 0) unsafeAtomicAdd(&a.nodeW[slv[u] & 0x7FFFFFFFu], t[u]);
+                                else unsafeAtomicAdd(dst, t[u]);
+                            } else {
+                                unsafeAtomicAdd(dst, t[u]);
+                            }
+                        } else {
+                            unsafeAtomicAdd(&Sp[u][own[u]], t[u]);
+                        }
+                    }
+                }
             };
             static_assert(NCH % WV_GROUP == 0, "whole groups");
             const wv_rsrc rs_cn = rsrc_cols(Tn, has_next);
@@ -594,24 +664,13 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         WV_MARK(5);
-        // ---- E: one lane per segment
-        if (a.nodeW && need_place) {
-            // The window sits at the lowest node id of the tile: the batch is sorted by the reads' lowest node id
-            // (vgan_hc_flatten), so the wave's reads stay above it and move through the node ids slowly.  Any other order is
-            // still correct -- a segment outside the window adds to W in HBM directly -- and a tile that leaves the window
-            // with many segments has the next one place it anew.
-            uint32_t nmin = 0xFFFFFFFFu;
-#pragma unroll
-            for (int k = 0; k < SPASS; ++k)
-                if ((uint32_t)k * 64u + (uint32_t)lane < T.n_seg) nmin = min(nmin, segnode[k]);
-            nmin = wave_min_u32(nmin);
-            if (winbase != 0xFFFFFFFFu) window_flush(winbase);
-            winbase = wv_first(nmin);
+        // ---- E: one lane per segment (DIRECT: nothing is left to do)
+        if (!DIRECT && a.nodeW && need_place) {
+            window_place(segnode, T, winbase);
             need_place = false;
-            WV_COUNT(7, 1);
         }
 #pragma unroll
-        for (int k = 0; k < SPASS; ++k) {
+        for (int k = 0; k < (DIRECT ? 0 : SPASS); ++k) {
             if ((uint32_t)k * 64u < T.n_seg) {
                 const uint32_t ls = (uint32_t)k * 64u + (uint32_t)lane;
                 const bool on = ls < T.n_seg;
@@ -647,7 +706,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         fresh = fresh_n;
         fresh_n = fresh_2;
     }
-    if (a.nodeW && winbase != 0xFFFFFFFFu) window_flush(winbase);
+    if ((DIRECT || a.nodeW) && winbase != 0xFFFFFFFFu) window_flush(winbase);
 #ifdef WV_PHASES
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&wv_phase_cycles[i], ph_acc[i]);
@@ -719,6 +778,10 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
     }
 }
 
+__global__ __launch_bounds__(256) void hc_srec_nodes_kernel(const uint2 *__restrict__ srec, uint32_t n, uint32_t *__restrict__ out) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = srec[i].x;
+}
+
 } // namespace wv
 using namespace wv;
 
@@ -768,24 +831,34 @@ void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, u
     hipLaunchKernelGGL(hc_pack_kernel, dim3(std::min<uint32_t>((n + 1 + 3) / 4, 8192u)), dim3(256), 0, st, b, n, rhdr, srec, crec, maxima);
 }
 
+void launch_hc_srec_nodes(const uint2 *srec, uint32_t n_segments, uint32_t *out, hipStream_t st) {
+    if (n_segments == 0) return;
+    hipLaunchKernelGGL(hc_srec_nodes_kernel, dim3(std::min<uint32_t>((n_segments + 255u) / 256u, 4096u)), dim3(256), 0, st, srec, n_segments, out);
+}
+
 void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *segD, double *nodeW,
                              double *totals, uint32_t *work_ctr, uint32_t *work_base, hipStream_t st) {
     if (pk.n_reads == 0) return;
     const bool small = pk.max_read_segs <= (uint32_t)WV_CAPS && pk.max_read_qual <= (uint32_t)WV_CAPQ && pk.max_read_cols <= (uint32_t)WV_CAPC;
     // a persistent grid: as many workgroups as the chip holds at once, fed by the work queue
-    static const int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    // (keyed on the device the launch goes to: contexts of one process may sit on different GPUs)
+    static int n_cu_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (n_cu_dev[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        n_cu_dev[dev] = n;
+    }
+    const int n_cu = n_cu_dev[dev];
     static const int occ_small = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC>, WV_THREADS, 0) != hipSuccess || n <= 0) n = WV_OCC;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC, true>, WV_THREADS, 0) != hipSuccess || n <= 0) n = WV_OCC * 4 / WV_WAVES;
         return n;
     }();
     static const int occ_large = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hc_segment_wave_kernel<512, 1280, 1280>, WV_THREADS, 0) != hipSuccess || n <= 0) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hc_segment_wave_kernel<512, 1280, 1280, false>, WV_THREADS, 0) != hipSuccess || n <= 0) n = 1;
         return n;
     }();
     uint32_t unit = small ? 32u : 8u; // reads per work unit: ~16 tiles -- the price of a ticket against the length of the launch's tail
@@ -826,10 +899,17 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
     a.qual_bytes = (uint32_t)std::min<uint64_t>(0xFFFFFFF0u, pk.n_qual + 32u);
     a.use_bep = prm.use_bep ? 1u : 0u;
     a.consensus = prm.consensus ? 1u : 0u;
-    if (small)
-        hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
+    // node-weights accumulation alone: the columns add straight into the W window (no per-segment sums); D_m streamed out
+    // (the per-read modes, the test aids): the per-segment form
+    const bool direct = nodeW && !segD && !getenv("VGAN_WV_NO_DIRECT");
+    if (small && direct)
+        hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC, true>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
+    else if (small)
+        hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC, false>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
+    else if (direct)
+        hipLaunchKernelGGL((hc_segment_wave_kernel<512, 1280, 1280, true>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((hc_segment_wave_kernel<512, 1280, 1280>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
+        hipLaunchKernelGGL((hc_segment_wave_kernel<512, 1280, 1280, false>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
 }
 
 } // namespace vgan

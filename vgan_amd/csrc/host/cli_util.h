@@ -34,8 +34,10 @@ namespace vgan_cli {
 // pipe, lets go of stdin / stdout / stderr and exits -- and the parent, which did nothing but wait for that byte, leaves with
 // the code at once while the child's exit is still freeing memory.  (mold, the linker, returns the same way.)  A child that
 // dies without a result is waited for and its fate passed on; a parent that dies takes the child with it (PR_SET_PDEATHSIG)
-// until the result is out.  Not done when VGAN_NO_FORK is set, nor under tools that preload into the process (a profiler's
-// library has initialised the GPU before main: such a process must not fork).
+// until the result is out.  OPT-IN (VGAN_EARLY_LEAVE=1): by default the subcommand runs in the calling process, so that the
+// exit code arrives when the memory and the GPU context are released and `time` / wait4 account for the worker itself.
+// Never done under tools that preload into the process (a profiler's library has initialised the GPU before main: such a
+// process must not fork).
 struct EarlyLeave {
     int fd = -1; // write end of the result pipe (in the child)
     static EarlyLeave &get() {
@@ -44,6 +46,8 @@ struct EarlyLeave {
     }
     // In the parent: does not return (leaves with the child's code).  In the child, or when forking is off: returns.
     void start() {
+        const char *want = getenv("VGAN_EARLY_LEAVE");
+        if (!want || !*want || strcmp(want, "0") == 0) return;
         if (getenv("VGAN_NO_FORK") || getenv("VGAN_KEEP_TEARDOWN") || getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIB") || getenv("ROCPROFILER_LIBRARY_PATH"))
             return;
         if (const char *pre = getenv("LD_PRELOAD")) // a profiler's tool library in the process: the GPU is up before main
@@ -51,6 +55,7 @@ struct EarlyLeave {
         int pfd[2];
         if (pipe2(pfd, O_CLOEXEC) != 0) return;
         fflush(nullptr);
+        const pid_t parent = getpid(); // (vgan itself may be pid 1 -- `docker run image vgan ...` -- or sit under a sub-reaper)
         const pid_t pid = fork();
         if (pid < 0) {
             close(pfd[0]);
@@ -60,7 +65,7 @@ struct EarlyLeave {
         if (pid == 0) {
             close(pfd[0]);
             (void)prctl(PR_SET_PDEATHSIG, SIGKILL);
-            if (getppid() == 1) _exit(1); // the parent is gone already
+            if (getppid() != parent) _exit(1); // the parent is gone already
             fd = pfd[1];
             return;
         }

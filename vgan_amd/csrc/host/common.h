@@ -225,5 +225,12 @@ struct vgan_hc_host_batch {
     vgan::BigVec<uint8_t> graph_seq, algnseq, qual;
     vgan::BigVec<uint32_t> read_src; // index of each batch read in the alignment set
     uint32_t n_tileable = 0;        // reads [0, n_tileable) satisfy the tile contract (include/vgan_gpu.h)
+    // vgan_hc_flatten*_packed: the reads that satisfy the tile contract in the segment kernel's own layout
+    // (vgan_hc_packed_view); the SoA arrays above then hold the other reads alone
+    bool is_packed = false;
+    vgan::BigVec<uint32_t> pk_rhdr, pk_srec, pk_crec, pk_src;
+    vgan::BigVec<uint8_t> pk_qualp;
+    uint32_t pk_reads = 0, pk_segments = 0, pk_max_segs = 0, pk_max_qual = 0, pk_max_cols = 0;
+    uint64_t pk_cols = 0, pk_qual = 0;
     void fill(vgan_hc_batch *b) const;
 };

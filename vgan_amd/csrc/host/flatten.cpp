@@ -195,8 +195,20 @@ namespace {
 // per-read limits of the device's LDS-tiled kernel (hc_device.h keeps the same numbers)
 constexpr size_t TILE_MAX_COLS = 1280, TILE_MAX_QUAL = 1280, TILE_MAX_SEGS = 512;
 
+// the tileable reads of a chunk in the layout the segment kernel streams (include/vgan_gpu.h: vgan_hc_packed_view), offsets
+// local to the chunk, the read index of the segment records still open (the merge knows a read's place in the batch)
+struct PkChunk {
+    BigVec<uint32_t> seg_off{0}, col_off{0}, qual_off{0};
+    BigVec<uint32_t> am;   // |algnseq| | mapq << 16
+    BigVec<uint32_t> src;
+    BigVec<uint32_t> srec; // {node, start} pairs
+    BigVec<uint32_t> crec;
+    BigVec<uint8_t> qual;
+};
+
 struct Chunk {
     vgan_hc_host_batch b;   // reads that satisfy the tile contract
+    PkChunk pk;             // ... or, for a packed batch, the same reads in the kernel's own layout
     vgan_hc_host_batch gen; // the others: indels / soft clips (|graph_seq| != |algnseq|, segments may overlap), long reads
     std::vector<uint32_t> key; // per read of b: its lowest node id (the merged batch is ordered by it)
     vgan_hc_flatten_stats st{};
@@ -208,10 +220,22 @@ struct SegTmp {
 };
 
 void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_t r1, const uint8_t *skip, int64_t src_base,
-                   Chunk &c) {
+                   bool packed, Chunk &c) {
     Recon rc;
     std::vector<SegTmp> seg_tmp;
-    { // size the chunk's arrays
+    if (packed) { // size the chunk's arrays
+        auto &k = c.pk;
+        const size_t nr = (size_t)(r1 - r0), nm = (size_t)(a.map_off[r1] - a.map_off[r0]);
+        const size_t nb = (size_t)(a.seq_off[r1] - a.seq_off[r0]), nq = (size_t)(a.qual_off[r1] - a.qual_off[r0]);
+        k.seg_off.reserve(nr + 1);
+        k.col_off.reserve(nr + 1);
+        k.qual_off.reserve(nr + 1);
+        k.am.reserve(nr);
+        k.src.reserve(nr);
+        k.srec.reserve(2 * nm);
+        k.crec.reserve(nb + nb / 16 + 64);
+        k.qual.reserve(nq);
+    } else {
         auto &b = c.b; // from the input volume, so that they grow at most once or twice
         const size_t nr = (size_t)(r1 - r0), nm = (size_t)(a.map_off[r1] - a.map_off[r0]);
         const size_t nb = (size_t)(a.seq_off[r1] - a.seq_off[r0]), nq = (size_t)(a.qual_off[r1] - a.qual_off[r0]);
@@ -280,6 +304,43 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             continue;
         }
         const bool tile = A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && (size_t)nm <= TILE_MAX_SEGS && !empty_seg && !seg_tmp.empty();
+        int32_t mq = a.mapq[r];
+        if (mq < 0 || mq > 99) {
+            mq = mq < 0 ? 0 : 99;
+            c.st.n_clamped++;
+        }
+        if (tile && packed) {
+            // The kernel's own layout, written here once (bytes are moved, nothing is compared, clamped or looked up): a record
+            // per alignment column {graph byte, the read byte update_likelihood.cpp:46 pairs it with -- algnseq from the READ
+            // start --, quality byte by column (0 past the string), bit 31 on a mapping's first column}; a column no mapping
+            // scores is 0
+            auto &k = c.pk;
+            const size_t c0 = k.crec.size();
+            k.crec.resize(c0 + A);
+            uint32_t *cr = k.crec.data() + c0;
+            memset(cr, 0, A * sizeof(uint32_t));
+            const uint8_t *gs = reinterpret_cast<const uint8_t *>(rc.gseq.data()), *rs = reinterpret_cast<const uint8_t *>(rc.ps.data());
+            const uint8_t *q = reinterpret_cast<const uint8_t *>(a.qual.data() + a.qual_off[r]);
+            for (const SegTmp &sg : seg_tmp) {
+                k.srec.push_back(sg.node);
+                k.srec.push_back(sg.start);
+                const size_t st = sg.start, ln = sg.len;
+                for (size_t j = 0; j < ln; ++j) {
+                    const size_t col = st + j;
+                    cr[col] = (uint32_t)gs[col] | ((uint32_t)rs[j] << 8) | ((col < n_qual_r ? (uint32_t)q[col] : 0u) << 16);
+                }
+                cr[st] |= 0x80000000u;
+            }
+            k.qual.insert(k.qual.end(), q, q + n_qual_r);
+            k.am.push_back((uint32_t)A | ((uint32_t)mq << 16));
+            k.src.push_back((uint32_t)(r + src_base));
+            k.seg_off.push_back((uint32_t)(k.srec.size() / 2));
+            k.col_off.push_back((uint32_t)k.crec.size());
+            k.qual_off.push_back((uint32_t)k.qual.size());
+            c.key.push_back(min_node);
+            c.st.n_out++;
+            continue;
+        }
         auto &b = tile ? c.b : c.gen;
         for (const SegTmp &sg : seg_tmp) {
             b.seg_node.push_back(sg.node);
@@ -287,11 +348,6 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             b.seg_len.push_back(sg.len);
         }
         if (tile) c.key.push_back(min_node);
-        int32_t mq = a.mapq[r];
-        if (mq < 0 || mq > 99) {
-            mq = mq < 0 ? 0 : 99;
-            c.st.n_clamped++;
-        }
         const size_t region = std::max(A, G);
         b.graph_seq.insert(b.graph_seq.end(), rc.gseq.begin(), rc.gseq.end());
         b.graph_seq.insert(b.graph_seq.end(), region - G, 0);
@@ -318,15 +374,17 @@ template <class T> void append_shifted(std::vector<T> &dst, const std::vector<T>
 
 namespace {
 // chunks -> one batch (chunks are consumed): the tileable reads of all chunks ordered by their lowest node id -- the
-// tiled kernel keeps W[node] of a workgroup's reads in an LDS window, which wants neighbouring reads on neighbouring
-// nodes (a stable counting sort, so reads on the same node keep their input order) -- then every chunk's other reads
-int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+// segment kernels keep W[node] of a wave's (workgroup's) reads in an LDS window, which wants neighbouring reads on
+// neighbouring nodes (a stable counting sort, so reads on the same node keep their input order) -- then every chunk's other
+// reads.  `packed`: the tileable reads arrive, and leave, in the segment kernel's own layout (res->pk_*), and the SoA arrays
+// hold the other reads alone (a batch of its own, offsets from 0).
+int merge_chunks(std::vector<Chunk> &chunks, bool packed, PhaseTimer &pt, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
     auto res = new vgan_hc_host_batch();
     vgan_hc_flatten_stats st{};
     const size_t nc = chunks.size();
     // ---- the tileable reads: (chunk, local index) in sorted order
     std::vector<size_t> rbase(nc + 1, 0);
-    for (size_t i = 0; i < nc; ++i) rbase[i + 1] = rbase[i] + chunks[i].b.read_mapq.size();
+    for (size_t i = 0; i < nc; ++i) rbase[i + 1] = rbase[i] + chunks[i].key.size();
     const size_t nt_reads = rbase[nc];
     uint32_t kmax = 0;
     for (auto &c : chunks)
@@ -346,15 +404,16 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
     // ---- totals
     uint64_t t_cols = 0, t_segs = 0, t_qual = 0;
     for (auto &c : chunks) {
-        t_cols += c.b.graph_seq.size();
-        t_segs += c.b.seg_node.size();
-        t_qual += c.b.qual.size();
+        t_cols += packed ? c.pk.crec.size() : c.b.graph_seq.size();
+        t_segs += packed ? c.pk.srec.size() / 2 : c.b.seg_node.size();
+        t_qual += packed ? c.pk.qual.size() : c.b.qual.size();
     }
     struct Base {
         size_t r, s, c, q;
     };
     std::vector<Base> gbase(nc);
-    uint64_t tot_reads = nt_reads, tot_cols = t_cols, tot_segs = t_segs, tot_qual = t_qual;
+    // (a packed batch keeps its SoA arrays for the other reads alone)
+    uint64_t tot_reads = packed ? 0 : nt_reads, tot_cols = packed ? 0 : t_cols, tot_segs = packed ? 0 : t_segs, tot_qual = packed ? 0 : t_qual;
     for (size_t i = 0; i < nc; ++i) {
         gbase[i] = {(size_t)tot_reads, (size_t)tot_segs, (size_t)tot_cols, (size_t)tot_qual};
         tot_cols += chunks[i].gen.graph_seq.size();
@@ -362,11 +421,12 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
         tot_qual += chunks[i].gen.qual.size();
         tot_reads += chunks[i].gen.read_mapq.size();
     }
-    if (tot_cols > 0xFFFFFFF0ull || tot_segs > 0xFFFFFFF0ull || tot_qual > 0xFFFFFFF0ull || tot_reads > 0xFFFFFFF0ull) {
+    if (tot_cols > 0xFFFFFFF0ull || tot_segs > 0xFFFFFFF0ull || tot_qual > 0xFFFFFFF0ull || tot_reads > 0xFFFFFFF0ull ||
+        t_cols > 0xFFFFFFF0ull || t_segs > 0xFFFFFFF0ull || t_qual > 0xFFFFFFF0ull) {
         delete res;
         return fail(VGAN_ERANGE, "vgan_hc_flatten: batch exceeds 32-bit offsets; flatten fewer reads per batch");
     }
-    res->n_tileable = (uint32_t)nt_reads;
+    res->n_tileable = packed ? 0 : (uint32_t)nt_reads;
     res->read_seg_off.resize(tot_reads + 1);
     res->read_col_off.resize(tot_reads + 1);
     res->read_qual_off.resize(tot_reads + 1);
@@ -380,14 +440,53 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
     res->algnseq.resize(tot_cols);
     res->qual.resize(tot_qual);
     res->read_seg_off[0] = res->read_col_off[0] = res->read_qual_off[0] = 0;
-    // ---- offsets of the sorted reads (serial prefix sums over three lengths per read)
     auto chunk_of = [&](uint32_t gidx) { return (size_t)(std::upper_bound(rbase.begin(), rbase.end(), (size_t)gidx) - rbase.begin()) - 1; };
-    for (size_t o = 0; o < nt_reads; ++o) {
-        const size_t ci = chunk_of(order[o]), j = order[o] - rbase[ci];
-        const auto &cb = chunks[ci].b;
-        res->read_seg_off[o + 1] = res->read_seg_off[o] + (cb.read_seg_off[j + 1] - cb.read_seg_off[j]);
-        res->read_col_off[o + 1] = res->read_col_off[o] + (cb.read_col_off[j + 1] - cb.read_col_off[j]);
-        res->read_qual_off[o + 1] = res->read_qual_off[o] + (cb.read_qual_off[j + 1] - cb.read_qual_off[j]);
+    // ---- offsets of the sorted reads (serial prefix sums over three lengths per read)
+    std::vector<uint32_t> pseg, pcol, pqual; // (packed: the sorted reads' offsets)
+    if (packed) {
+        res->is_packed = true;
+        res->pk_reads = (uint32_t)nt_reads;
+        res->pk_segments = (uint32_t)t_segs;
+        res->pk_cols = t_cols;
+        res->pk_qual = t_qual;
+        res->pk_rhdr.resize(4 * (nt_reads + 1));
+        res->pk_srec.resize(2 * t_segs);
+        res->pk_crec.resize(t_cols);
+        res->pk_qualp.resize(t_qual + 32);
+        res->pk_src.resize(nt_reads);
+        pseg.resize(nt_reads + 1);
+        pcol.resize(nt_reads + 1);
+        pqual.resize(nt_reads + 1);
+        pseg[0] = pcol[0] = pqual[0] = 0;
+        uint32_t ms = 0, mq = 0, mc = 0;
+        for (size_t o = 0; o < nt_reads; ++o) {
+            const size_t ci = chunk_of(order[o]), j = order[o] - rbase[ci];
+            const auto &k = chunks[ci].pk;
+            const uint32_t ns = k.seg_off[j + 1] - k.seg_off[j], ncl = k.col_off[j + 1] - k.col_off[j], nq = k.qual_off[j + 1] - k.qual_off[j];
+            pseg[o + 1] = pseg[o] + ns;
+            pcol[o + 1] = pcol[o] + ncl;
+            pqual[o + 1] = pqual[o] + nq;
+            ms = std::max(ms, ns);
+            mq = std::max(mq, nq);
+            mc = std::max(mc, ncl);
+        }
+        res->pk_max_segs = ms;
+        res->pk_max_qual = mq;
+        res->pk_max_cols = mc;
+        uint32_t *h = res->pk_rhdr.data() + 4 * nt_reads; // the end offsets
+        h[0] = (uint32_t)t_segs;
+        h[1] = (uint32_t)t_qual;
+        h[2] = (uint32_t)t_cols;
+        h[3] = 0;
+        memset(res->pk_qualp.data() + t_qual, 0, 32);
+    } else {
+        for (size_t o = 0; o < nt_reads; ++o) {
+            const size_t ci = chunk_of(order[o]), j = order[o] - rbase[ci];
+            const auto &cb = chunks[ci].b;
+            res->read_seg_off[o + 1] = res->read_seg_off[o] + (cb.read_seg_off[j + 1] - cb.read_seg_off[j]);
+            res->read_col_off[o + 1] = res->read_col_off[o] + (cb.read_col_off[j + 1] - cb.read_col_off[j]);
+            res->read_qual_off[o + 1] = res->read_qual_off[o] + (cb.read_qual_off[j + 1] - cb.read_qual_off[j]);
+        }
     }
     const size_t hw = nt_reads <= 300000 ? burst_cpus() : usable_cpus();
     // ---- the sorted reads' data, by output range
@@ -411,6 +510,30 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
             }
             const size_t q0 = cb.read_qual_off[j], nq = cb.read_qual_off[j + 1] - q0;
             if (nq) memcpy(&res->qual[res->read_qual_off[o]], &cb.qual[q0], nq);
+        }
+    };
+    auto copy_sorted_packed = [&](size_t o0, size_t o1) {
+        for (size_t o = o0; o < o1; ++o) {
+            const size_t ci = chunk_of(order[o]), j = order[o] - rbase[ci];
+            const auto &k = chunks[ci].pk;
+            uint32_t *h = res->pk_rhdr.data() + 4 * o;
+            h[0] = pseg[o];
+            h[1] = pqual[o];
+            h[2] = pcol[o];
+            h[3] = k.am[j];
+            res->pk_src[o] = k.src[j];
+            const size_t s0 = k.seg_off[j], ns = k.seg_off[j + 1] - s0;
+            const uint32_t rtag = ((uint32_t)o & 0xFFFFu) << 16; // the segment's read, as the kernel finds it within a tile
+            const uint32_t *sp = k.srec.data() + 2 * s0;
+            uint32_t *sd = res->pk_srec.data() + 2 * (size_t)pseg[o];
+            for (size_t t = 0; t < ns; ++t) {
+                sd[2 * t] = sp[2 * t];
+                sd[2 * t + 1] = sp[2 * t + 1] | rtag;
+            }
+            const size_t c0 = k.col_off[j], ncol = k.col_off[j + 1] - c0;
+            if (ncol) memcpy(res->pk_crec.data() + pcol[o], k.crec.data() + c0, ncol * sizeof(uint32_t));
+            const size_t q0 = k.qual_off[j], nq = k.qual_off[j + 1] - q0;
+            if (nq) memcpy(res->pk_qualp.data() + pqual[o], k.qual.data() + q0, nq);
         }
     };
     // ---- the other reads: whole parts, offsets shifted
@@ -437,13 +560,17 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
     };
     {
         const size_t nth = std::max<size_t>(1, std::min<size_t>(hw, (nt_reads + 8191) / 8192));
+        auto sorted = [&](size_t o0, size_t o1) {
+            if (packed) copy_sorted_packed(o0, o1);
+            else copy_sorted(o0, o1);
+        };
         if (nth <= 1) {
-            copy_sorted(0, nt_reads);
+            sorted(0, nt_reads);
             for (size_t i = 0; i < nc; ++i) copy_gen(i);
         } else {
             parallel_run((int)nth, [&](int ti) {
                 const size_t t = (size_t)ti;
-                copy_sorted(nt_reads * t / nth, nt_reads * (t + 1) / nth);
+                sorted(nt_reads * t / nth, nt_reads * (t + 1) / nth);
                 for (size_t i = t; i < nc; i += nth) copy_gen(i);
             });
         }
@@ -457,21 +584,15 @@ int merge_chunks(std::vector<Chunk> &chunks, PhaseTimer &pt, vgan_hc_host_batch 
         c = Chunk();
     }
     pt.lap("merge");
-    st.n_segments = (int64_t)res->seg_node.size();
-    st.n_cols = (int64_t)res->graph_seq.size();
+    st.n_segments = (int64_t)res->seg_node.size() + (int64_t)res->pk_segments;
+    st.n_cols = (int64_t)res->graph_seq.size() + (int64_t)res->pk_cols;
     if (stats) *stats = st;
     *out = res;
     return VGAN_OK;
 }
-} // namespace
 
-extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
-                               vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
-    return vgan_hc_flatten_masked(g, a, r0, r1, nullptr, n_threads, out, stats);
-}
-
-extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
-                                      int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+int flatten_set(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip, int n_threads, bool packed,
+                vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
     if (!g || !a || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten: null argument");
     if (r0 < 0 || r1 > a->n_reads() || r0 > r1) return fail(VGAN_EINVAL, "vgan_hc_flatten: bad read range");
     if (n_threads <= 0) n_threads = (int)(r1 - r0 <= 300000 ? burst_cpus() : usable_cpus());
@@ -486,16 +607,16 @@ extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a,
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t) {
         const int64_t b0 = r0 + n * t / n_threads, b1 = r0 + n * (t + 1) / n_threads;
-        if (n_threads == 1) flatten_range(*g, *a, b0, b1, skip, 0, chunks[t]);
-        else th.emplace_back(flatten_range, std::cref(*g), std::cref(*a), b0, b1, skip, (int64_t)0, std::ref(chunks[t]));
+        if (n_threads == 1) flatten_range(*g, *a, b0, b1, skip, 0, packed, chunks[t]);
+        else th.emplace_back(flatten_range, std::cref(*g), std::cref(*a), b0, b1, skip, (int64_t)0, packed, std::ref(chunks[t]));
     }
     for (auto &t : th) t.join();
     pt.lap("chunks");
-    return merge_chunks(chunks, pt, out, stats);
+    return merge_chunks(chunks, packed, pt, out, stats);
 }
 
-extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *ps, int64_t part0, int64_t part1, const uint8_t *skip,
-                                     int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+int flatten_parts(const vgan_graph *g, const vgan_alnparts *ps, int64_t part0, int64_t part1, const uint8_t *skip, int n_threads,
+                  bool packed, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
     if (!g || !ps || !out) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: null argument");
     if (part0 < 0 || part1 > (int64_t)ps->parts.size() || part0 > part1) return fail(VGAN_EINVAL, "vgan_hc_flatten_parts: bad slice range");
     if (ps->base + ps->first.back() > 0xFFFFFFF0ll) return fail(VGAN_ERANGE, "vgan_hc_flatten_parts: more than 2^32 reads");
@@ -513,7 +634,7 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
         for (int64_t r0 = 0; r0 < n; r0 += SUB) items.push_back({(size_t)pi, r0, std::min(n, r0 + SUB)});
     }
     const size_t np = items.size();
-    n_threads = std::min(n_threads, 40); // as in vgan_hc_flatten_masked
+    n_threads = std::min(n_threads, 40); // as in flatten_set
     n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, np));
     PhaseTimer pt("hc_flatten_parts");
     std::vector<Chunk> chunks(np); // one per item, in input order
@@ -524,7 +645,7 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
             if (i >= np) break;
             const Item &it = items[i];
             const vgan_alnset &a = ps->parts[it.part];
-            flatten_range(*g, a, it.r0, it.r1, skip ? skip + ps->first[it.part] : nullptr, ps->base + ps->first[it.part], chunks[i]);
+            flatten_range(*g, a, it.r0, it.r1, skip ? skip + ps->first[it.part] : nullptr, ps->base + ps->first[it.part], packed, chunks[i]);
         }
     };
     parallel_run(n_threads, [&](int) {
@@ -534,9 +655,55 @@ extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *p
     });
     pt.lap("chunks");
     const double m0 = pt.on ? thread_cpu_ms() : 0;
-    const int rc = merge_chunks(chunks, pt, out, stats);
+    const int rc = merge_chunks(chunks, packed, pt, out, stats);
     if (pt.on) cpu_account().merge += (int64_t)((thread_cpu_ms() - m0) * 1e3); // (the calling thread's share: the serial part)
     return rc;
+}
+} // namespace
+
+extern "C" int vgan_hc_flatten(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, int n_threads,
+                               vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    return flatten_set(g, a, r0, r1, nullptr, n_threads, false, out, stats);
+}
+
+extern "C" int vgan_hc_flatten_masked(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
+                                      int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    return flatten_set(g, a, r0, r1, skip, n_threads, false, out, stats);
+}
+
+extern "C" int vgan_hc_flatten_parts(const vgan_graph *g, const vgan_alnparts *ps, int64_t part0, int64_t part1, const uint8_t *skip,
+                                     int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    return flatten_parts(g, ps, part0, part1, skip, n_threads, false, out, stats);
+}
+
+extern "C" int vgan_hc_flatten_packed(const vgan_graph *g, const vgan_alnset *a, int64_t r0, int64_t r1, const uint8_t *skip,
+                                      int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    return flatten_set(g, a, r0, r1, skip, n_threads, true, out, stats);
+}
+
+extern "C" int vgan_hc_flatten_parts_packed(const vgan_graph *g, const vgan_alnparts *ps, int64_t part0, int64_t part1,
+                                            const uint8_t *skip, int n_threads, vgan_hc_host_batch **out, vgan_hc_flatten_stats *stats) {
+    return flatten_parts(g, ps, part0, part1, skip, n_threads, true, out, stats);
+}
+
+extern "C" int vgan_hc_host_batch_get_packed(const vgan_hc_host_batch *b, vgan_hc_packed_view *out) {
+    if (!b || !out) return fail(VGAN_EINVAL, "vgan_hc_host_batch_get_packed: null argument");
+    memset(out, 0, sizeof *out);
+    if (!b->is_packed) return fail(VGAN_ESTATE, "vgan_hc_host_batch_get_packed: the batch was not flattened into the packed layout");
+    out->n_reads = b->pk_reads;
+    out->n_segments = b->pk_segments;
+    out->n_cols = b->pk_cols;
+    out->n_qual = b->pk_qual;
+    out->rhdr = b->pk_rhdr.data();
+    out->srec = b->pk_srec.data();
+    out->crec = b->pk_crec.data();
+    out->qualp = b->pk_qualp.data();
+    out->max_read_segs = b->pk_max_segs;
+    out->max_read_qual = b->pk_max_qual;
+    out->max_read_cols = b->pk_max_cols;
+    out->on_device = 0;
+    out->read_src = b->pk_src.data();
+    return VGAN_OK;
 }
 
 extern "C" int vgan_hc_host_batch_get(const vgan_hc_host_batch *b, vgan_hc_batch *out) {

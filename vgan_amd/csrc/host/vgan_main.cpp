@@ -337,12 +337,15 @@ int haplocart(int argc, char **argv) {
                 hb = uploader.q.front();
             }
             std::string err;
-            vgan_hc_batch b;
-            if (vgan_hc_host_batch_get(hb, &b) < 0) err = std::string("[vgan] batch: ") + vgan_last_error();
+            vgan_hc_batch b;              // the reads outside the tile contract (long reads, ...): the general kernel
+            vgan_hc_packed_view pk;       // everything else, in the segment kernel's own layout as the flatten step wrote it
+            if (vgan_hc_host_batch_get(hb, &b) < 0 || vgan_hc_host_batch_get_packed(hb, &pk) < 0) err = std::string("[vgan] batch: ") + vgan_last_error();
             if (err.empty()) {
                 contexts_ready_quiet();
-                if (!creator.err.empty()) err = creator.err;
-                else if (vgan_hc_accumulate(ctxs.v[n_chunks++ % ctxs.v.size()], &b) < 0) err = std::string("[vgan] accumulate: ") + vgan_last_error();
+                vgan_hc_ctx *cx = creator.err.empty() ? ctxs.v[n_chunks++ % ctxs.v.size()] : nullptr;
+                if (!cx) err = creator.err;
+                else if (vgan_hc_accumulate_packed(cx, &pk) < 0 || (b.n_reads && vgan_hc_accumulate(cx, &b) < 0))
+                    err = std::string("[vgan] accumulate: ") + vgan_last_error();
                 if (n_chunks <= 3) stamp("chunk handed to the device");
             }
             vgan_hc_host_batch_free(hb);
@@ -401,7 +404,7 @@ int haplocart(int argc, char **argv) {
                 vgan_hc_host_batch *hb = nullptr;
                 vgan_hc_flatten_stats st{};
                 t0 = std::chrono::steady_clock::now();
-                const int rc = vgan_hc_flatten_parts(graph, chunk, 0, vgan_alnparts_count(chunk), skip, lane_threads, &hb, &st);
+                const int rc = vgan_hc_flatten_parts_packed(graph, chunk, 0, vgan_alnparts_count(chunk), skip, lane_threads, &hb, &st);
                 const double fl = since(t0);
                 t0 = std::chrono::steady_clock::now();
                 vgan_alnparts_free(chunk);

@@ -286,36 +286,53 @@ _BATCH_FIELDS = (("read_seg_off", np.uint32, "R1"), ("read_col_off", np.uint32, 
                  ("algnseq", np.uint8, "C"), ("qual", np.uint8, "Q"))
 
 
-class HostBatch:
-    """Flattened HaploCart batch in host memory (vgan_hc_flatten)."""
+_PACKED_FIELDS = (("rhdr", np.uint32, lambda k: 4 * (k.n_reads + 1)), ("srec", np.uint32, lambda k: 2 * k.n_segments),
+                  ("crec", np.uint32, lambda k: k.n_cols), ("qualp", np.uint8, lambda k: k.n_qual + 32))
 
-    def __init__(self, graph, alns, r0=0, r1=None, n_threads=0, skip=None):
+
+class HostBatch:
+    """Flattened HaploCart batch in host memory (vgan_hc_flatten).  packed=True (vgan_hc_flatten*_packed): the reads that
+    satisfy the tile contract leave in the segment kernel's own layout (`pk`, a vgan_hc_packed_view; packed_arrays()), and
+    `c` / arrays() hold the OTHER reads alone; n_reads / n_segments count both parts."""
+
+    def __init__(self, graph, alns, r0=0, r1=None, n_threads=0, skip=None, packed=False):
         """skip: optional bool/uint8 mask over the alignment set (e.g. AlnSet.mark_duplicates()): reads left out.
         alns may be an AlnParts: r0 / r1 then count slices."""
         self._h = N.vp()
         self.stats = N.FlattenStats()
+        self.pk = None
         sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
         assert sk is None or len(sk) == alns.n_reads
+        skp = None if sk is None else sk.ctypes.data
+        L = N.lib()
         if isinstance(alns, AlnParts):
             r1 = alns.n_parts if r1 is None else r1
-            N.check(N.lib().vgan_hc_flatten_parts(graph._h, alns._h, r0, r1, None if sk is None else sk.ctypes.data, n_threads,
-                                                  C.byref(self._h), C.byref(self.stats)))
-            self.c = N.HcBatch()
-            N.check(N.lib().vgan_hc_host_batch_get(self._h, C.byref(self.c)))
-            return
-        r1 = alns.n_reads if r1 is None else r1
-        N.check(N.lib().vgan_hc_flatten_masked(graph._h, alns._h, r0, r1, None if sk is None else sk.ctypes.data, n_threads,
-                                               C.byref(self._h), C.byref(self.stats)))
+            fn = L.vgan_hc_flatten_parts_packed if packed else L.vgan_hc_flatten_parts
+        else:
+            r1 = alns.n_reads if r1 is None else r1
+            fn = L.vgan_hc_flatten_packed if packed else L.vgan_hc_flatten_masked
+        N.check(fn(graph._h, alns._h, r0, r1, skp, n_threads, C.byref(self._h), C.byref(self.stats)))
         self.c = N.HcBatch()
-        N.check(N.lib().vgan_hc_host_batch_get(self._h, C.byref(self.c)))
+        N.check(L.vgan_hc_host_batch_get(self._h, C.byref(self.c)))
+        if packed:
+            self.pk = N.HcPackedView()
+            N.check(L.vgan_hc_host_batch_get_packed(self._h, C.byref(self.pk)))
 
     @property
     def n_reads(self):
-        return self.c.n_reads
+        return self.c.n_reads + (self.pk.n_reads if self.pk is not None else 0)
 
     @property
     def n_segments(self):
-        return self.c.n_segments
+        return self.c.n_segments + (self.pk.n_segments if self.pk is not None else 0)
+
+    def packed_arrays(self):
+        """numpy views of the packed part (rhdr [4(R+1)], srec [2S], crec [C], qualp [Q+32], read_src [R])."""
+        k = self.pk
+        out = {name: _np_view(getattr(k, name), size(k), dt) for name, dt, size in _PACKED_FIELDS}
+        out["read_src"] = _np_view(k.read_src, k.n_reads, np.uint32)
+        out["_owner"] = self
+        return out
 
     def arrays(self):
         c = self.c
@@ -332,14 +349,18 @@ class HostBatch:
 
     @property
     def read_src(self):
-        """Index in the alignment set of each batch read (the batch is not in input order)."""
-        return np.array(self.arrays()["read_src"])
+        """Index in the alignment set of each batch read (the batch is not in input order): the packed reads, then the others."""
+        rest = np.array(self.arrays()["read_src"])
+        return rest if self.pk is None else np.concatenate([np.array(self.packed_arrays()["read_src"]), rest])
 
     def algorithmic_bytes(self, n_paths):
-        """bases + quals + segment descriptors (+ one mask row per segment in PER_READ mode)."""
-        c = self.c
-        io = 2 * c.n_cols + c.n_qual + 8 * c.n_segments + 15 * c.n_reads
-        return {"node_weights": io, "per_read": io + c.n_segments * (8 * ((n_paths + 63) // 64) + 8)}
+        """bases + quals + segment descriptors (+ one mask row per segment in PER_READ mode).  The same
+        figure for both layouts: the input bytes of the SoA form (two byte streams per column, the quality string, an
+        8-byte record per segment, 15 bytes of per-read header) -- the packed layout is fatter, which lowers the fraction."""
+        c, k = self.c, self.pk
+        cols, qual = c.n_cols + (k.n_cols if k is not None else 0), c.n_qual + (k.n_qual if k is not None else 0)
+        io = 2 * cols + qual + 8 * self.n_segments + 15 * self.n_reads
+        return {"node_weights": io, "per_read": io + self.n_segments * (8 * ((n_paths + 63) // 64) + 8)}
 
     def __del__(self):
         if getattr(self, "_h", None) and N is not None:
@@ -375,6 +396,21 @@ class DeviceBatch:
     def __init__(self, host_batch, device="cuda:0", ctx=None):
         import torch
         self.t = {}
+        self.pk = None
+        if getattr(host_batch, "pk", None) is not None:
+            # a packed batch: its four arrays go to HBM as they are (one copy, no layout pass on the device)
+            pa, hk = host_batch.packed_arrays(), host_batch.pk
+            k = N.HcPackedView()
+            for f in ("n_reads", "n_segments", "n_cols", "n_qual", "max_read_segs", "max_read_qual", "max_read_cols"):
+                setattr(k, f, getattr(hk, f))
+            for name, dt, _ in _PACKED_FIELDS:
+                a = pa[name].view(np.int32) if dt == np.uint32 else pa[name]
+                self.t["pk_" + name] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+                setattr(k, name, self.t["pk_" + name].data_ptr())
+            k.on_device = 1
+            k.read_src = None
+            self.pk = k
+            ctx = None  # (nothing left for the layout pass: the other reads take the general kernel)
         arrs = host_batch.arrays()
         for name, dt, _ in _BATCH_FIELDS:
             a = arrs[name]
@@ -394,7 +430,7 @@ class DeviceBatch:
         c.read_src = None  # host-side bookkeeping only
         c.packed = None
         self.c = c
-        self.n_reads, self.n_segments = c.n_reads, c.n_segments
+        self.n_reads, self.n_segments = host_batch.n_reads, host_batch.n_segments
         self._packed = N.vp()
         self.pack_ms = None
         if ctx is not None:
@@ -410,6 +446,17 @@ class DeviceBatch:
         self.pack_ms = (time.perf_counter() - t0) * 1e3
         self.c.packed = self._packed
         return self.pack_ms
+
+    def download_packed(self):
+        """What the layout pass (vgan_hc_pack) wrote, as host arrays named as in vgan_hc_packed_view (test aid)."""
+        n = np.zeros(4, np.uint64)
+        N.check(N.lib().vgan_hc_packed_download(self._packed, n.ctypes.data, None, None, None, None))
+        R, S, Cn, Q = (int(x) for x in n)
+        out = {"rhdr": np.zeros(4 * (R + 1), np.uint32), "srec": np.zeros(2 * S, np.uint32), "crec": np.zeros(Cn, np.uint32),
+               "qualp": np.zeros(Q + 32, np.uint8)}
+        N.check(N.lib().vgan_hc_packed_download(self._packed, n.ctypes.data, out["rhdr"].ctypes.data, out["srec"].ctypes.data,
+                                                out["crec"].ctypes.data, out["qualp"].ctypes.data))
+        return out
 
     def __del__(self):
         if getattr(self, "_packed", None) and N is not None:
@@ -442,7 +489,22 @@ class HcContext:
         N.check(N.lib().vgan_hc_reset(self._h))
 
     def accumulate(self, batch):
+        """A packed batch (HostBatch(packed=True) or its DeviceBatch): the packed reads, then the others."""
+        pk = getattr(batch, "pk", None)
+        if pk is not None:
+            N.check(N.lib().vgan_hc_accumulate_packed(self._h, C.byref(pk)))
+            if batch.c.n_reads == 0:
+                return
         N.check(N.lib().vgan_hc_accumulate(self._h, C.byref(batch.c)))
+
+    def validate_packed(self, batch):
+        N.check(N.lib().vgan_hc_packed_validate(self._h, C.byref(batch.pk)))
+
+    def segment_weights_packed(self, batch):
+        """D_m per segment of the packed part, in the packed batch's segment order."""
+        D = np.zeros(batch.pk.n_segments)
+        N.check(N.lib().vgan_hc_segment_weights_packed(self._h, C.byref(batch.pk), D.ctypes.data))
+        return D
 
     def segment_scalars(self, batch):
         S = np.zeros(batch.n_segments)
