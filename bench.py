@@ -280,7 +280,9 @@ def bench_soibean(args):
     from vgan_amd import soibean as sb
     rank, world, local_rank, dev, backend, n_dev = pick_device(args)
     g = hc.synth_graph(seed=args.seed, genome_len=16569, n_nodes=11000, n_paths=args.sb_paths)
-    alns = hc.synth_reads(g, args.reads, seed=args.seed + 1000003 * rank, read_len=65, indel_rate=0.005, softclip_rate=0.01)
+    # the job's reads are ONE seeded stream (read i depends on (seed, i) only); rank r holds reads [r * R, (r + 1) * R): the split
+    # MCMC.cpp:739 makes over OpenMP threads (`reduction(+:logLike)`), made over GPUs
+    alns = hc.synth_reads(g, args.reads, seed=args.seed, read_len=65, indel_rate=0.005, softclip_rate=0.01, first_read=rank * args.reads)
     dm = ek.Damage.from_text("", "")
     hb = sb.SbHostBatch(g, alns)
     ctx = sb.SbContext(g, dm, device=local_rank)
@@ -326,15 +328,22 @@ def bench_soibean(args):
                 cur = ll
                 accepted += 1
             return
-        ctx.loglike(st, 0.01, freqs, device_out=d_out)
-        if world > 1:  # one scalar per iteration over RCCL
-            if dist.get_backend() == "gloo":
-                h = d_out.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM)
-                d_out.copy_(h)
-            else:
-                dist.all_reduce(d_out, op=dist.ReduceOp.SUM)
-        ll = float(d_out.item())
+        # N > 1: every rank refreshes its share, then ONE all-reduce of the state's sum per iteration.  The sums are fixed point
+        # (vgan_sb_sum: two 64-bit integers and a double for what does not fit), so the total -- and with it every accept /
+        # reject -- is the same bits whatever the number of ranks
+        sums, _ = ctx.loglike_sums(st, 0.01, freqs)
+        hi, lo, nf = sums[0]
+        ti = torch.tensor([hi, lo - (1 << 64) if lo >= (1 << 63) else lo], dtype=torch.int64)
+        tf = torch.tensor([nf], dtype=torch.float64)
+        if dist.get_backend() == "gloo":
+            dist.all_reduce(ti, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tf, op=dist.ReduceOp.SUM)
+        else:  # RCCL over xGMI
+            ti, tf = ti.to(dev), tf.to(dev)
+            dist.all_reduce(ti, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tf, op=dist.ReduceOp.SUM)
+            ti, tf = ti.cpu(), tf.cpu()
+        ll = sb.sum_value([(int(ti[0]), int(ti[1]) & ((1 << 64) - 1), float(tf[0]))])
         if cur is None or logu < ll - cur:
             cur = ll
             accepted += 1
@@ -361,7 +370,9 @@ def bench_soibean(args):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "soibean k=3, %d synthetic reads per GPU, %d-path tree, host Metropolis loop + GPU refresh per iteration" % (args.reads, args.sb_paths),
-                       "reads_per_gpu": R, "precompute_s": t_pre, "accepted": accepted},
+                       "reads_per_gpu": R, "precompute_s": t_pre, "accepted": accepted,
+                       "sharding": "contiguous read ranges x%d, one all-reduce (%s) of the state's fixed-point sum per iteration" % (world, backend) if world > 1 else "single GPU"},
+            "result_check": {"last_loglike": cur, "accepted": accepted},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": sb_traffic.get("bytes") if sb_traffic else None, "traffic_detail": sb_traffic,
                          "kernel": "sb_refresh_fused_kernel" if fused else "sb_loglike_kernel + sb_finish_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,

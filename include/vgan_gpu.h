@@ -619,6 +619,22 @@ int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, double *pm, ui
  * of the reference's runtime_error guards would fire. */
 int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
                     double *out, double *d_out, uint64_t *guard);
+/* (ABI 4) Every sum over reads of this path (a refresh, the initial mixture) is taken in fixed point, in integers: units of
+ * 2^-44, value = (hi * 2^32 + lo) * 2^-44 + nf, a term that is not finite or 2^18 and beyond in magnitude going into the plain
+ * double nf.  Integer sums do not depend on the order of their terms, so a log-likelihood is the same bits however the reads
+ * are dealt to lanes, workgroups, contexts or GPUs -- an MCMC accept / reject does not depend on the number of devices.  A
+ * caller holding the reads in several contexts adds the contexts' sums (vgan_sb_sum_add) and converts once
+ * (vgan_sb_sum_value); vgan_sb_group_* below does that for the chain driver. */
+typedef struct vgan_sb_sum {
+    int64_t hi;
+    uint64_t lo;
+    double nf;
+} vgan_sb_sum;
+double vgan_sb_sum_value(const vgan_sb_sum *s);
+void vgan_sb_sum_add(vgan_sb_sum *acc, const vgan_sb_sum *x);
+/* vgan_sb_loglike / vgan_sb_mixture_loglike returning the sums themselves (host, synchronises) */
+int vgan_sb_loglike_sums(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                         vgan_sb_sum *sums, uint64_t *guard);
 /* analyse_GAM's per-read mostProbPath (getLCAfromGAM.h:563-579) over the resident reads: best[r] (host, n_reads of the
  * batch, may be NULL) = the path holding the read's highest pathMap value when exactly one path does, -1 on a tie or for a
  * read excluded on the device; sig_count[n_paths] = reads per uniquely best path, the "signature" frequencies of
@@ -628,6 +644,7 @@ int vgan_sb_best_paths(vgan_sb_ctx *c, int32_t *best, int64_t *sig_count, int64_
 /* the initial log-likelihood of soibean.cpp:737-756 over the resident reads: sum_r (+)_j (log_freq + pathMap_r[paths[j]])
  * with oplusInitnatl as (+); one source and log_freq = 0 gives the plain sum of :744-747 */
 int vgan_sb_mixture_loglike(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double log_freq, double *out);
+int vgan_sb_mixture_sums(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double log_freq, vgan_sb_sum *sum);
 /* host: the initial sources of soibean.cpp:669-712 from the signature counts: paths with at least 1 % of the reads, by
  * descending count (equal counts: ascending path index; the reference's order among them is that of an unordered_map),
  * cut to cutk when cutk > 0; every path with a count when none reaches the threshold.  paths[] capacity n_paths */
@@ -679,6 +696,16 @@ typedef struct vgan_sb_engine {
                         double *loglike, uint64_t *guard);
 } vgan_sb_engine;
 int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out); /* vgan_sb_loglike / vgan_sb_mixture_loglike of the context */
+/* (ABI 4) The reads of one job dealt to several contexts -- one per GPU; MCMC.cpp:739 is an OpenMP loop over the reads with
+ * `reduction(+:logLike)`, here the loop runs over devices -- as ONE engine: a refresh is launched on every context before any
+ * is waited for, the contexts' sums (vgan_sb_sum: integers) are added on the host and converted once.  The chain files are
+ * those of one context holding all the reads, byte for byte.  The contexts stay the caller's (the group only refers to them). */
+typedef struct vgan_sb_group vgan_sb_group;
+int vgan_sb_group_create(vgan_sb_ctx **ctxs, int n, vgan_sb_group **out);
+void vgan_sb_group_free(vgan_sb_group *g);
+int vgan_sb_engine_group(vgan_sb_group *g, vgan_sb_engine *out);
+/* vgan_sb_best_paths' signature counts and usable-read count summed over the group's contexts */
+int vgan_sb_group_best_paths(vgan_sb_group *g, int64_t *sig_count, int64_t *n_reads_ok);
 /* the engine's refresh is one fused kernel plus a fold into pinned host memory; on != 0 brackets it with HIP events so that
  * vgan_sb_kernel_ms (slot 1) reports it as well -- off by default: the chain is launch bound and two event records cost */
 int vgan_sb_time_engine(vgan_sb_ctx *c, int on);

@@ -95,7 +95,19 @@ def test_bench_starts_its_own_ranks_weak_and_strong():
         assert other["posterior"]["confidence"] == pytest.approx(one["posterior"]["confidence"], rel=1e-6)
     # (bound / achieved / peak / frac are one coherent HBM record; what limits the kernel is named beside it)
     assert one["posterior_ms"] > 0 and one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
-    assert one["layout_pass_ms"] > 0 and "limiter" in one["roofline"]
+    # (the batch arrives in the kernel's layout from the host flatten: no layout pass on the device, inside the step or beside it)
+    assert one["layout_pass_ms"] == 0 and one["kernel_ms_per_step"]["pack"] == 0 and "limiter" in one["roofline"]
+
+
+def test_soibean_bench_over_two_ranks_gives_the_one_rank_chain():
+    """bench.py --path soibean: two ranks holding reads [0, R) and [R, 2R) of the job's stream all-reduce the state's
+    fixed-point sum every iteration; the chain -- every log-likelihood, every accept -- is the one rank's over [0, 2R)."""
+    one = _bench("--path", "soibean", "--reads", "40000", "--steps", "12", "--warmup", "3")
+    two = _bench("--path", "soibean", "--gpus", "2", "--dist-backend", "gloo", "--reads", "20000", "--steps", "12", "--warmup", "3")
+    assert two["n_gpus"] == 2 and "all-reduce" in two["config"]["sharding"]
+    assert two["result_check"]["accepted"] == one["result_check"]["accepted"]
+    # (a read needs its neighbours for nothing, so the halves' reads are the whole's reads; unusable reads are dropped per share)
+    assert two["result_check"]["last_loglike"] == one["result_check"]["last_loglike"]
 
 
 def test_several_contexts_in_one_process_reduce_to_the_single_context_result():

@@ -90,9 +90,11 @@ def test_a_broken_packed_batch_is_refused():
     ctx.validate_packed(hb)
     ctx.accumulate(hb)
     assert np.all(np.isfinite(ctx.finalize()))
-    # an empty packed part (every read beyond the tile contract) is fine
-    long_only = hc.HostBatch(g, hc.synth_reads(g, 5, seed=93, read_len=1900), packed=True)
-    assert long_only.pk.n_reads == 0 and long_only.c.n_reads == 5
-    ctx.reset()
-    ctx.accumulate(long_only)
-    assert np.all(np.isfinite(ctx.finalize()))
+    # long reads stay outside the packed part (the general kernel takes them); an empty batch is fine
+    g2 = hc.synth_graph(seed=94, genome_len=9000, n_nodes=6000, n_paths=40)
+    long_reads = hc.HostBatch(g2, hc.synth_reads(g2, 5, seed=93, read_len=3000, softclip_rate=0.0, indel_rate=0.0), packed=True)
+    assert long_reads.c.n_reads >= 3 and long_reads.n_reads == 5
+    ctx2 = hc.HcContext(g2)
+    ctx2.accumulate(long_reads)
+    ctx2.accumulate(hc.HostBatch(g2, hc.synth_reads(g2, 5, seed=95, read_len=100), 0, 0, packed=True))
+    assert np.all(np.isfinite(ctx2.finalize()))

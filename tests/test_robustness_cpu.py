@@ -224,3 +224,31 @@ def test_oversized_quality_string_is_refused_not_indexed():
     assert b.n_reads == 2 and b.stats.n_bad == 1 and sorted(b.read_src.tolist()) == [0, 2]
     ql = np.diff(b.arrays()["read_qual_off"])
     assert ql.max() == 65535 and b.n_tileable == 1
+
+
+def test_the_worker_pool_survives_a_fork():
+    """csrc/host/util.cpp parallel_run: a child of fork() (Python's multiprocessing default) inherits the pool's counters and
+    none of its threads; it must start a pool of its own instead of waiting for workers that do not exist."""
+    import os
+    from vgan_amd import haplocart as hc
+    g = hc.synth_graph(seed=3, genome_len=1200, n_nodes=800, n_paths=50)
+    a = hc.synth_reads(g, 20000, seed=4, read_len=100)
+    hb = hc.HostBatch(g, a, n_threads=4)  # the pool has threads now
+    pid = os.fork()
+    if pid == 0:
+        try:
+            signal_ok = hc.HostBatch(g, a, n_threads=4).n_reads == hb.n_reads
+        except BaseException:  # noqa: BLE001 -- the child must not fall back into pytest
+            signal_ok = False
+        os._exit(0 if signal_ok else 3)
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        done, st = os.waitpid(pid, os.WNOHANG)
+        if done:
+            assert os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0
+            return
+        time.sleep(0.05)
+    os.kill(pid, 9)
+    os.waitpid(pid, 0)
+    raise AssertionError("the forked child hung in parallel_run")

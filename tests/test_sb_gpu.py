@@ -302,3 +302,104 @@ def test_column_kernel_equals_segment_kernel_bit_for_bit():
             os.environ.pop("VGAN_SB_PRECOMPUTE", None)
         else:
             os.environ["VGAN_SB_PRECOMPUTE"] = old
+
+
+def _group_case(tmp_path, n_reads=900, shares=(0.0, 0.37, 0.5, 1.0)):
+    """One context holding every read, and a group of contexts holding contiguous shares of them."""
+    g, a, profs, newick = _soibean_case(n_reads=n_reads)
+    texts = tuple(open(p).read() for p in profs)
+    dm = ek.Damage.from_text(*texts)
+    one = sb.SbContext(g, dm, penalty=7)
+    one.precompute(sb.SbHostBatch(g, a))
+    parts = []
+    for f0, f1 in zip(shares[:-1], shares[1:]):
+        c = sb.SbContext(g, dm, penalty=7)
+        c.precompute(sb.SbHostBatch(g, a, int(a.n_reads * f0), int(a.n_reads * f1)))
+        parts.append(c)
+    return g, a, profs, newick, one, parts
+
+
+def test_sums_over_reads_do_not_depend_on_how_the_reads_are_dealt(tmp_path):
+    """Every sum over reads is taken in fixed point (vgan_sb_sum): the contexts' sums added up are the one context's sum,
+    integer for integer, and the log-likelihood is the same double -- refresh, batched refresh and the initial mixture."""
+    g, a, profs, newick, one, parts = _group_case(tmp_path)
+    grp = sb.SbGroup(parts)
+    states = [[(1, 0, 0.02, 0.3, 1.0)], [(3, 2, 0.01, 0.7, 1.0)], [(5, 4, 0.0, 0.5, 1.0)]]
+    k3 = [[(1, 0, 0.02, 0.3, 0.5), (3, 2, 0.01, 0.7, 0.3), (6, 5, 0.03, 0.2, 0.2)]]
+    for sts in (states, k3):
+        whole, gw = one.loglike_sums(sts, 0.01, FREQS)
+        split = [c.loglike_sums(sts, 0.01, FREQS) for c in parts]
+        for e in range(len(sts)):
+            hi = sum(s[0][e][0] for s in split)
+            lo = sum(s[0][e][1] for s in split)
+            assert (hi, lo) == whole[e][:2] and whole[e][2] == 0.0
+            assert sb.sum_value([s[0][e] for s in split]) == sb.sum_value([whole[e]])
+        v, _ = one.loglike(sts, 0.01, FREQS)
+        assert [sb.sum_value([w]) for w in whole] == list(v)
+        for e, st in enumerate(sts):
+            assert grp.refresh(st, 0.01, FREQS)[0] == v[e] == one.refresh(st, 0.01, FREQS)[0]
+    paths = [0, 3, 5]
+    lf = float(np.log(1 / 3))
+    assert grp.mixture_loglike(paths, lf) == one.mixture_loglike(paths, lf)
+    assert sb.sum_value([c.mixture_sums(paths, lf) for c in parts]) == one.mixture_loglike(paths, lf)
+    _, sig1, n1 = one.best_paths()
+    sigg, ng = grp.best_paths()
+    assert np.array_equal(sig1, sigg) and n1 == ng
+    # and against the oracle (long double, its own order): the fixed-point unit is 2^-44 per read
+    texts = tuple(open(p).read() for p in profs)
+    o = orc.SbOracle(util.orc_graph_from_product(g), util.orc_alnset_from_product(a), orc.OrcDamage(*texts), penalty=7,
+                     path_findable=np.ones(g.n_paths, np.uint8))
+    rc, ref = o.loglike(k3[0], 0.01, FREQS)
+    assert rc == 0 and abs(grp.refresh(k3[0], 0.01, FREQS)[0] - ref) <= 1e-10 * abs(ref)
+
+
+def test_chains_over_a_group_of_contexts_write_the_files_of_one_context(tmp_path):
+    """vgan_sb_estimate over vgan_sb_engine_group (three contexts on this GPU, uneven shares) against the same chains over one
+    context: every output file byte for byte."""
+    g, a, profs, newick, one, parts = _group_case(tmp_path)
+    tree = sb.Tree.parse(newick)
+    node_path = tree.node_paths(g.path_names)
+    _, sig, n_ok = one.best_paths()
+    paths = sb.signature_paths(sig, n_ok, cutk=2)
+    inv = {int(p): v for v, p in enumerate(node_path)}
+    sig_nodes = [inv[int(p)] for p in paths]
+    kw = dict(con=0.004, iters=150, burnin=30, chains=3, seed=11)
+    sb.estimate(one, tree, node_path, sig_nodes, str(tmp_path / "one_"), g.n_paths, FREQS, **kw)
+    sb.estimate(sb.SbGroup(parts), tree, node_path, sig_nodes, str(tmp_path / "grp_"), g.n_paths, FREQS, **kw)
+    f1, fg = _chain_files(str(tmp_path / "one_")), _chain_files(str(tmp_path / "grp_"))
+    assert sorted(f1) == sorted(fg) and len(f1) >= 7
+    for name in f1:
+        assert f1[name] == fg[name], name
+
+
+def test_vgan_soibean_deals_the_reads_to_several_device_contexts(tmp_path):
+    """`vgan soibean --gpus 0,0,0` (three contexts on the one GPU of the test rig) writes the files of `--gpus 0`."""
+    import shutil
+    import subprocess
+    g, a, profs, newick = _soibean_case(n_reads=700)
+    db = tmp_path / "db"
+    (db / "tree_dir").mkdir(parents=True)
+    g.write(str(db))
+    shutil.move(str(db / "graph.gfa"), str(db / "Synth.gfa"))
+    (db / "tree_dir" / "Synth.new.dnd").write_text(newick + "\n")
+    (db / "soibean_db.baseFreq").write_text("Other .25 .25 .25 .25\nSynth .31 .25 .15 .29\n")
+    gam = str(tmp_path / "reads.gam")
+    a.write_gam(gam)
+    exe = os.path.join(os.path.dirname(GOLD), "..", "vgan_amd", "bin", "vgan")
+    outs = {}
+    for tag, gpus in (("one", "0"), ("three", "0,0,0")):
+        out = str(tmp_path / (tag + "_"))
+        r = subprocess.run([exe, "soibean", "-g", gam, "--soibean_dir", str(db), "--dbprefix", "Synth", "--deam5p", profs[0], "--deam3p", profs[1],
+                            "--iter", "120", "--burnin", "20", "--chains", "2", "--seed", "7", "-o", out, "--gpus", gpus],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert ("3 device contexts" in r.stderr) == (tag == "three")
+        outs[tag] = (_chain_files(out), [l for l in r.stderr.splitlines() if "log-likelihood" in l or "signature" in l])
+    assert sorted(outs["one"][0]) == sorted(outs["three"][0]) and len(outs["one"][0]) >= 7
+    for name in outs["one"][0]:
+        assert outs["one"][0][name] == outs["three"][0][name], name
+    assert outs["one"][1] == outs["three"][1]
+    env = dict(os.environ, VGAN_GPUS="0,0")
+    r = subprocess.run([exe, "soibean", "-g", gam, "--soibean_dir", str(db), "--dbprefix", "Synth", "--no-mcmc", "-o", str(tmp_path / "env_")],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "2 device contexts" in r.stderr

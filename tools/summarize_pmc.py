@@ -34,8 +34,10 @@ for k, cs in out.items():
 if issue and len(sys.argv) > 2:  # summarize_pmc.py <dir> <profile name>: the committed figure bench.py quotes as *_from_profile
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    try:
-        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
-    except Exception:
-        commit = None
+    commit = os.environ.get("VGAN_COMMIT")  # (the GPU box holds a snapshot without .git: the caller names the tree)
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            commit = None
     json.dump({"profile": sys.argv[2], "commit": commit, "kernels": issue}, open(os.path.join(root, "profiles", "valu_issue.json"), "w"), indent=1)

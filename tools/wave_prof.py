@@ -15,9 +15,9 @@ def main():
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     g = hc.synth_graph(seed=1)
     a = hc.synth_reads(g, n, seed=2, read_len=rl)
-    hb = hc.HostBatch(g, a)
+    hb = hc.HostBatch(g, a, packed=True)
     ctx = hc.HcContext(g)
-    db = hc.DeviceBatch(hb, ctx=ctx)
+    db = hc.DeviceBatch(hb)
     ctx.profile_enable(True)
     for _ in range(reps):
         ctx.accumulate(db)

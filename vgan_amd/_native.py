@@ -44,6 +44,10 @@ class HcPackedView(C.Structure):
                 ("max_read_qual", C.c_uint32), ("max_read_cols", C.c_uint32), ("on_device", C.c_int32), ("read_src", vp)]
 
 
+class SbSum(C.Structure):
+    _fields_ = [("hi", C.c_int64), ("lo", C.c_uint64), ("nf", C.c_double)]
+
+
 class FlattenStats(C.Structure):
     _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64), ("n_unmapped", C.c_int64), ("n_bad", C.c_int64),
                 ("n_clamped", C.c_int64), ("n_segments", C.c_int64), ("n_cols", C.c_int64)]
@@ -277,6 +281,14 @@ SYMBOLS = {
     "vgan_sb_mixture_loglike": (C.c_int, [vp, C.c_uint32, vp, C.c_double, vp]),
     "vgan_sb_signature_paths": (C.c_int, [vp, C.c_uint32, C.c_int64, C.c_int32, vp, vp]),
     "vgan_sb_destroy": (None, [vp]),
+    "vgan_sb_sum_value": (C.c_double, [vp]),
+    "vgan_sb_sum_add": (None, [vp, vp]),
+    "vgan_sb_loglike_sums": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_double, vp, vp, vp]),
+    "vgan_sb_mixture_sums": (C.c_int, [vp, C.c_uint32, vp, C.c_double, vp]),
+    "vgan_sb_group_create": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "vgan_sb_group_free": (None, [vp]),
+    "vgan_sb_engine_group": (C.c_int, [vp, C.POINTER(SbEngine)]),
+    "vgan_sb_group_best_paths": (C.c_int, [vp, vp, vp]),
     "vgan_synth_euka": (C.c_int, [C.POINTER(SynthEukaCfg), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "vgan_synth_hc_graph": (C.c_int, [C.POINTER(SynthGraphCfg), C.POINTER(vp)]),
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),

@@ -51,13 +51,18 @@ namespace wv {
 #define WV_WG_THREADS 256 // a workgroup shares nothing but the read-only tables: its size only sets how often they are built
 #endif
 #ifndef WV_SUB
-#define WV_SUB 1 // accumulator sub-slots per window entry (lane parity picks one: halves the same-address LDS adds of a segment)
+#define WV_SUB 2 // accumulator sub-slots per window entry (lane parity picks one: halves the same-address LDS adds of a segment)
 #endif
-constexpr int WV_THREADS = WV_WG_THREADS;
-constexpr int WV_WAVES = WV_THREADS / 64;
+constexpr int WV_THREADS_SMALL = WV_WG_THREADS; // workgroup of the small variant (several reads per tile)
+constexpr int WV_THREADS_LARGE = 256;           // ... of the large one (a tile of one long read, a wave per SIMD)
+#ifdef WV_MAX_VGPR
+#define WV_VGPR_ATTR __attribute__((amdgpu_num_vgpr(WV_MAX_VGPR)))
+#else
+#define WV_VGPR_ATTR
+#endif
 constexpr int WV_NR = 8;    // reads per tile at most (their headers travel in lanes 0..WV_NR of the wave)
 #ifndef WV_WIN_SLOTS
-#define WV_WIN_SLOTS 128
+#define WV_WIN_SLOTS 160 // (a 150 bp read spans 106 node ids on the hcfiles graph, 140 at most: three sorted reads fit)
 #endif
 constexpr int WV_WIN = WV_WIN_SLOTS; // node ids covered by a wave's W window
 constexpr uint32_t WV_BUF_FLAGS = 0x00020000u; // raw buffer descriptor, 32-bit data format (gfx9)
@@ -77,11 +82,11 @@ struct alignas(32) WvRead { // per read of the tile
 
 // DIRECT (node-weights accumulation only): a column's term goes straight into the W window slot of its mapping's node --
 // no per-segment sum S, no pass over the segments behind the column loop.  slot[]: the segment's byte offset into win[], or
-// 0x80000000 | node id for a node outside the window.
+// 0xFFFF for a node outside the window (its id is then read from the segment record in HBM: the rare path).
 template <int CAPS, int CAPQ, bool DIRECT> struct WvSlice { // one wave's LDS
     WvKL kl[CAPS];
     double S[DIRECT ? 1 : CAPS];
-    uint32_t slot[DIRECT ? CAPS : 1];
+    uint16_t slot[DIRECT ? CAPS : 2];
     uint32_t ps[CAPQ + 16]; // ps[4 + i]: prefix through byte i of the quality window (ps[3] = 0: the empty prefix)
     WvRead rd[WV_NR];
     uint32_t first90[WV_NR];
@@ -154,6 +159,10 @@ __device__ __forceinline__ uint4 wv_load4(wv_rsrc r, uint32_t off) {
     const v4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
     return uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
 }
+// fp64 add into LDS through a pointer the compiler KNOWS is LDS (a select between an LDS and a global destination otherwise
+// ends as one flat atomic: out of order, counted in vmcnt and lgkmcnt both)
+using wv_lds_dptr = __attribute__((address_space(3))) double *;
+__device__ __forceinline__ void wv_lds_add(double *p, double v) { __builtin_amdgcn_ds_atomic_fadd_f64((wv_lds_dptr)p, v); }
 __device__ __forceinline__ double wv_dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
 // Q >= 90 switches the rest of the read to the background error rate (update_likelihood.cpp:40-44): first90[k] = index of the
@@ -198,8 +207,8 @@ struct WvTile { // one tile's extents (wave uniform)
     uint32_t r, n, s_base, n_seg, q_base, n_q, c_base, n_col;
     uint32_t w1; // end of the work unit the tile lies in
 };
-struct alignas(32) WvRdTab { // rdtab row of a mapping quality: 1 - p_inc, its log, its reciprocal
-    double omp, lp, ip, pad;
+struct WvRdTab { // rdtab row of a mapping quality: 1 - p_inc, its log, its reciprocal
+    double omp, lp, ip;
 };
 template <int SPASS, int QCH, int NCH> struct WvData { // one tile's HBM data, in flight or arrived
     uint2 qv[QCH];
@@ -211,8 +220,9 @@ template <int SPASS, int QCH, int NCH> struct WvData { // one tile's HBM data, i
 // requested as a fixed set of loads (bounded by the buffer descriptors: what lies beyond the tile comes back as zeros) one
 // tile ahead.  No load in the tile loop is conditional -- s_waitcnt vmcnt counts in order, and the compiler can only wait for
 // exactly the loads it needs when it knows how many were issued after them.
-template <int CAPS, int CAPQ, int CAPC, bool DIRECT>
-__global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_segment_wave_kernel(WvArgs a) {
+template <int CAPS, int CAPQ, int CAPC, bool DIRECT, int WV_THREADS, int OCC>
+__global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_kernel(WvArgs a) {
+    constexpr int WV_WAVES = WV_THREADS / 64;
     constexpr int SPASS = (CAPS + 63) / 64;     // segment passes per tile at most
     constexpr int QCH = (CAPQ + 8 + 511) / 512; // quality chunks (512 bytes: 8 per lane) per tile at most
     constexpr int NCH = CAPC / 64;              // column chunks per tile at most
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     constexpr int SUB = DIRECT ? WV_SUB : 1;
     using Data = WvData<SPASS, QCH, NCH>;
     __shared__ WvLom lom_s[101][2]; // [qscore index, 100 = background error rate][mismatch, match]
-    __shared__ double bg_s[8];      // A C T G by (base >> 1) & 3
+    __shared__ double2 bg_s[4];     // A C T G by (base >> 1) & 3: {frequency, frequency / 6} (the series' leading coefficient rides along)
     __shared__ WvRdTab rdtab_s[100]; // the read's share of pcm by mapping quality (process_mapping.cpp:41)
     __shared__ LogTabEntry logtab_s[64]; // log_tab.h
     __shared__ Slice slice_s[WV_WAVES];
@@ -235,9 +245,12 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
         const double om = (i & 1) ? 1.0 - e : e;
         lom_s[qi][i & 1] = WvLom{log_pos(om), 1.0 / om};
     }
-    if (tid < 8) bg_s[tid] = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : tid == 3 ? 0.16644 : 0.25;
+    if (tid < 4) {
+        const double f = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : 0.16644;
+        bg_s[tid] = double2{f, f * (1.0 / 6.0)};
+    }
     if (tid < 64) logtab_s[tid] = wv_log_table[tid];
-    if (tid < 100) rdtab_s[tid] = WvRdTab{a.rdtab[3 * tid], a.rdtab[3 * tid + 1], a.rdtab[3 * tid + 2], 0.0};
+    if (tid < 100) rdtab_s[tid] = WvRdTab{a.rdtab[3 * tid], a.rdtab[3 * tid + 1], a.rdtab[3 * tid + 2]};
     Slice &L = slice_s[wave];
     for (int i = lane; i < WV_WIN * SUB; i += 64) L.win[i] = 0.0;
     if (lane < 4) L.ps[lane] = 0u;
@@ -333,8 +346,6 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
     };
 
     const uint32_t sub8 = SUB == 2 ? ((uint32_t)lane & 1u) * 8u : 0u; // the lane's accumulator sub-slot
-    double c6 = 1.0 / 6.0; // the series' leading coefficient, kept in a vector register pair for the whole launch (an
-    asm volatile("" : "+v"(c6)); // instruction takes one scalar operand; the other coefficients travel as scalars)
     double sumT = 0.0, sumU = 0.0;  // sum of S_m and of U_m, each without cancellation
     uint32_t winbase = 0xFFFFFFFFu; // no window yet (wave uniform)
     bool need_place = true;
@@ -509,9 +520,9 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                     // -U_m goes to the node's slot here, the columns' terms follow in D
                     const uint32_t node = D.sr[k].x, sl = node - winbase;
                     const bool inside = sl < (uint32_t)WV_WIN;
-                    if (CAPS % 64 == 0 || on) L.slot[ls] = inside ? sl * (8u * SUB) : (0x80000000u | node);
+                    if (CAPS % 64 == 0 || on) L.slot[ls] = (uint16_t)(inside ? sl * (8u * SUB) : 0xFFFFu);
                     if (on) {
-                        if (inside) unsafeAtomicAdd(&L.win[sl * SUB], -U);
+                        if (inside) wv_lds_add(&L.win[sl * SUB], -U);
                         else unsafeAtomicAdd(&a.nodeW[node], -U);
                     }
                     const uint32_t n_out = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(on && !inside));
@@ -533,7 +544,8 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
             auto chunks = [&](auto n_tag, const uint32_t *recs) {
                 constexpr int N = decltype(n_tag)::value;
                 const WvKL *klp[N];
-                const uint32_t *slp[N];
+                const uint16_t *slp[N];
+                uint32_t sgl[N]; // (the chunk's first segment, as an index into the batch's segment records: the rare path)
                 double *Sp[N];
                 uint32_t own[N], row[N], rc8[N];
                 uint64_t valid[N], farm[N]; // lane masks (kept as masks: they only ever gate branches)
@@ -547,6 +559,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                     asm volatile("" : "+s"(sbase)); // (kept whole: the -1 otherwise travels into a vector add per chunk)
                     klp[u] = L.kl + sbase;
                     slp[u] = L.slot + (DIRECT ? sbase : 0u);
+                    sgl[u] = T.s_base + sbase;
                     Sp[u] = L.S + (DIRECT ? 0u : sbase);
                     const uint64_t above0 = heads >> 1;
                     own[u] = __builtin_amdgcn_mbcnt_hi((uint32_t)(above0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)above0, 0u));
@@ -554,7 +567,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                     // bases: code (b >> 1) & 3 = A C T G -> 0 1 2 3; a byte is one of the four iff it equals its code's letter.
                     // Both bytes at once: the two codes select their letters out of "ACTG" (v_perm_b32), and the pair of
                     // letters is compared with the pair of bytes (process_mapping.cpp:62-63)
-                    rc8[u] = (rec >> 6) & 0x18u;
+                    rc8[u] = (rec >> 5) & 0x30u;
                     const uint32_t letters = 0x47544341u; // "ACTG"
                     const uint32_t want = __builtin_amdgcn_perm(letters, letters, (rec >> 1) & 0x0303u);
                     uint64_t vmask; // (the compiler has no 16-bit compare of two registers' low halves; SDWA does it in one)
@@ -582,20 +595,23 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                         if (__double2hiint(kl[u].kappa) < 0) row[u] = 200u + (row[u] & 1u);
                 }
                 WvLom lo[N];
-                double bgv[N], rho[N], l0[N], t[N];
+                double bgv[N], bg6[N], rho[N], l0[N], t[N];
                 bool far = false;
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
                     lo[u] = *reinterpret_cast<const WvLom *>(reinterpret_cast<const uint8_t *>(lom_s) + (row[u] << 4));
-                    bgv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(bg_s) + rc8[u]);
+                    const double2 b2 = *reinterpret_cast<const double2 *>(reinterpret_cast<const uint8_t *>(bg_s) + rc8[u]);
+                    bgv[u] = b2.x;
+                    bg6[u] = b2.y;
                 }
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
-                    rho[u] = fabs(kl[u].kappa) * bgv[u] * lo[u].iom;
+                    const double ki = fabs(kl[u].kappa) * lo[u].iom;
+                    rho[u] = ki * bgv[u];
                     // log1p(rho) by six terms below 2^-8 (the next, rho^7 / 7, is under 2e-18 there).  On HaploCart's own
                     // pairing of graph and read bases (update_likelihood.cpp:46) two columns in three are mismatches, i.e.
                     // rho = kappa * bg / e(Q) ~ 1e-3 for a confidently mapped read: this IS the common case.
-                    double p = wv_fma3s(rho[u], c6, -0.2);
+                    double p = wv_fma3s(ki, bg6[u], -0.2); // rho / 6 - 1 / 5
                     p = wv_fma3s(rho[u], p, 0.25);
                     p = wv_fma3s(rho[u], p, -1.0 / 3.0);
                     p = fma(rho[u], p, 0.5);
@@ -622,7 +638,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                                 x *= 18014398509481984.0;                   // 2^54
                                 adj = -37.429947750237048;                  // -54 ln 2
                             }
-                            const double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval(x, logtab_s) + adj : x)
+                            const double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval_s(x, logtab_s) + adj : x)
                                                       : (x == 0.0 ? -INFINITY : __builtin_nan(""));
                             t[u] = deg ? lx : l0[u] + (lx + corr);
                         }
@@ -633,15 +649,15 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                     if (__builtin_amdgcn_inverse_ballot_w64(valid[u])) {
                         if constexpr (DIRECT) {
                             sumT += t[u];
-                            double *dst = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(L.win) + (slv[u] & 0x7FFFFFFFu) + sub8);
+                            double *dst = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(L.win) + slv[u] + sub8);
                             if (__builtin_expect(tile_out, 0)) {
-                                if ((int32_t)slv[u] < 0) unsafeAtomicAdd(&a.nodeW[slv[u] & 0x7FFFFFFFu], t[u]);
-                                else unsafeAtomicAdd(dst, t[u]);
+                                if (slv[u] == 0xFFFFu) unsafeAtomicAdd(&a.nodeW[min(a.srec[sgl[u] + own[u]].x, a.rows - 1u)], t[u]);
+                                else wv_lds_add(dst, t[u]);
                             } else {
-                                unsafeAtomicAdd(dst, t[u]);
+                                wv_lds_add(dst, t[u]);
                             }
                         } else {
-                            unsafeAtomicAdd(&Sp[u][own[u]], t[u]);
+                            wv_lds_add(&Sp[u][own[u]], t[u]);
                         }
                     }
                 }
@@ -683,7 +699,7 @@ __global__ __launch_bounds__(WV_THREADS, (CAPS <= 192 ? WV_OCC : 1)) void hc_seg
                     if (a.nodeW) {
                         const uint32_t slot = segnode[k] - winbase;
                         if (slot < (uint32_t)WV_WIN) {
-                            unsafeAtomicAdd(&L.win[slot], Dm);
+                            wv_lds_add(&L.win[slot], Dm);
                         } else {
                             unsafeAtomicAdd(&a.nodeW[segnode[k]], Dm);
                             outside = true;
@@ -851,16 +867,30 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
         n_cu_dev[dev] = n;
     }
     const int n_cu = n_cu_dev[dev];
-    static const int occ_small = [] {
+    constexpr int OCC_S = WV_OCC, TS = WV_THREADS_SMALL, TL = WV_THREADS_LARGE;
+    using KS = void (*)(WvArgs);
+    const KS k_small_direct = hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC, true, TS, OCC_S>;
+    const KS k_small = hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC, false, TS, OCC_S>;
+    const KS k_large_direct = hc_segment_wave_kernel<512, 1280, 1280, true, TL, 1>;
+    const KS k_large = hc_segment_wave_kernel<512, 1280, 1280, false, TL, 1>;
+    // Workgroups a CU really holds at once.  The occupancy API overstates it on gfx950: LDS is handed out in granules of
+    // 1280 bytes (128 per CU), so five workgroups fit only at 32 000 bytes each and below, four at 40 960 (measured with
+    // tools/dev/census.hip: 32 256 bytes per workgroup run four to a CU where the API says five).
+    auto resident = [](KS kern, int threads, int fallback) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC, true>, WV_THREADS, 0) != hipSuccess || n <= 0) n = WV_OCC * 4 / WV_WAVES;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, 0) != hipSuccess || n <= 0) n = fallback;
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess && fa.sharedSizeBytes > 0)
+            n = std::min<int>(n, 128 / (int)((fa.sharedSizeBytes + 1279) / 1280));
+        return std::max(1, n);
+    };
+    static const int occ_small = [&] {
+        int n = resident(k_small_direct, TS, OCC_S * 256 / TS);
+        if (const char *e = getenv("VGAN_WV_BLOCKS_PER_CU")) n = std::max(1, atoi(e)); // developer aid
         return n;
     }();
-    static const int occ_large = [] {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hc_segment_wave_kernel<512, 1280, 1280, false>, WV_THREADS, 0) != hipSuccess || n <= 0) n = 1;
-        return n;
-    }();
+    static const int occ_large = [&] { return resident(k_large, TL, 1); }();
+    const int WV_WAVES = (small ? TS : TL) / 64;
     uint32_t unit = small ? 32u : 8u; // reads per work unit: ~16 tiles -- the price of a ticket against the length of the launch's tail
     if (const char *e = getenv("VGAN_WV_UNIT")) unit = (uint32_t)std::max(1, atoi(e)); // developer aid
     uint32_t blocks = (uint32_t)(n_cu * (small ? occ_small : occ_large));
@@ -902,14 +932,8 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
     // node-weights accumulation alone: the columns add straight into the W window (no per-segment sums); D_m streamed out
     // (the per-read modes, the test aids): the per-segment form
     const bool direct = nodeW && !segD && !getenv("VGAN_WV_NO_DIRECT");
-    if (small && direct)
-        hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC, true>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
-    else if (small)
-        hipLaunchKernelGGL((hc_segment_wave_kernel<WV_CAPS, WV_CAPQ, WV_CAPC, false>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
-    else if (direct)
-        hipLaunchKernelGGL((hc_segment_wave_kernel<512, 1280, 1280, true>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
-    else
-        hipLaunchKernelGGL((hc_segment_wave_kernel<512, 1280, 1280, false>), dim3(blocks), dim3(WV_THREADS), 0, st, a);
+    const KS kern = small ? (direct ? k_small_direct : k_small) : (direct ? k_large_direct : k_large);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(small ? TS : TL), 0, st, a);
 }
 
 } // namespace vgan

@@ -104,6 +104,20 @@ struct EarlyLeave {
     }
 };
 
+inline int parse_int(const std::string &v, const char *flag, const char *tool);
+// "0,1,3" -> GPU indices appended to out (--gpus / VGAN_GPUS)
+inline void parse_gpu_list(const std::string &v, const char *flag, const char *tool, std::vector<int> &out) {
+    size_t p0 = 0;
+    while (p0 <= v.size()) {
+        size_t c1 = v.find(',', p0);
+        if (c1 == std::string::npos) c1 = v.size();
+        const int d = parse_int(v.substr(p0, c1 - p0), flag, tool);
+        if (d < 0) die(std::string(tool) + " Error, " + flag + " needs non-negative GPU indices");
+        out.push_back(d);
+        p0 = c1 + 1;
+    }
+}
+
 inline void check(int rc, const char *what) {
     if (rc < 0) die(std::string("[vgan] ") + what + ": " + vgan_last_error());
 }

@@ -12,7 +12,10 @@
 
 #include <zlib.h>
 
+#include <pthread.h>
+
 #include <algorithm>
+#include <exception>
 #include <atomic>
 #include <functional>
 #include <deque>
@@ -441,9 +444,18 @@ struct WorkerPool {
         cv.notify_one();
     }
 };
+WorkerPool *g_pool = nullptr;
+// A child of fork() inherits the pool's counters and none of its threads (Python's multiprocessing forks by default): it
+// starts with a pool of its own -- the parent's object is left as it is, its mutex may be held by a thread that is not there.
+void pool_after_fork_in_child() { g_pool = new WorkerPool; }
 WorkerPool &worker_pool() {
-    static WorkerPool *p = new WorkerPool; // never destroyed: its threads outlive static destruction
-    return *p;
+    static const bool once = [] {
+        g_pool = new WorkerPool; // never destroyed: its threads outlive static destruction
+        (void)pthread_atfork(nullptr, nullptr, pool_after_fork_in_child);
+        return true;
+    }();
+    (void)once;
+    return *g_pool;
 }
 } // namespace
 
@@ -456,18 +468,32 @@ void parallel_run(int n, const std::function<void(int)> &fn) {
         std::mutex mu;
         std::condition_variable cv;
         int left;
+        std::exception_ptr err; // the first exception of any share: rethrown on the caller once every share has ended
     } job;
     job.left = n - 1;
     WorkerPool &wp = worker_pool();
     for (int t = 1; t < n; ++t)
         wp.submit([&job, &fn, t] {
-            fn(t);
+            std::exception_ptr e;
+            try {
+                fn(t);
+            } catch (...) {
+                e = std::current_exception();
+            }
             std::lock_guard<std::mutex> lk(job.mu); // held while notifying: the waiter cannot leave (and destroy job) before
+            if (e && !job.err) job.err = e;
             if (--job.left == 0) job.cv.notify_one();
         });
-    fn(0);
-    std::unique_lock<std::mutex> lk(job.mu);
+    std::exception_ptr mine;
+    try {
+        fn(0);
+    } catch (...) {
+        mine = std::current_exception();
+    }
+    std::unique_lock<std::mutex> lk(job.mu); // (always: the workers hold references to job and fn)
     job.cv.wait(lk, [&] { return job.left == 0; });
+    if (mine) std::rethrow_exception(mine);
+    if (job.err) std::rethrow_exception(job.err);
 }
 
 // Large blocks are recycled, not returned: every munmap interrupts all the cores the process runs on and every fresh mapping

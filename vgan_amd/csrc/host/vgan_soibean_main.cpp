@@ -46,7 +46,11 @@ std::string soibean_usage() {
            "   -k [INT]             number of sources, random start (default: estimated)\n"
            "   -P [INT]             mismatch penalty period for unsupported bases (default: 7)\n"
            "   --seed [INT]         reproducible chains (default 0: std::random_device)\n"
-           "   --device [INT]       GPU index (default 0)\n";
+           "   --device [INT]       GPU index (default 0)\n"
+           "   --gpus [LIST]        GPU indices, comma separated (default: the one of --device; VGAN_GPUS in the environment: a list or\n"
+           "                        `all`): the reads are dealt once to one device context per GPU, every likelihood refresh runs\n"
+           "                        on all of them and their sums are added (MCMC.cpp:739's reduction over the reads); the chain\n"
+           "                        files are those of one GPU, byte for byte\n";
 }
 
 std::vector<std::string> lines_of(const char *joined, size_t n) {
@@ -65,6 +69,7 @@ int soibean_main(int argc, char **argv) {
     std::string sbdir = "../share/vgan/soibean_dir/", treedir, dbprefix = "soibean_db", gam, fq1, fq2, out_prefix = "beanOut", deam5, deam3;
     bool run_mcmc = true, dbprefix_found = false, rand_start = false, specified_k = false, specified_deam = false;
     int n_threads = 1, iter = 500000, burnin = 75000, chains = 4, k = 1, penalty = 7, device = 0; // soibean.cpp:209-240
+    std::vector<int> gpu_list;
     uint64_t seed = 0;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -126,6 +131,8 @@ int soibean_main(int argc, char **argv) {
         else if (a == "--device") {
             device = parse_int(need("--device"), "--device", T);
             if (device < 0) die("[soibean] Error, --device needs a non-negative GPU index");
+        } else if (a == "--gpus") {
+            parse_gpu_list(need("--gpus"), "--gpus", T, gpu_list);
         } else die("[soibean] Error, unrecognized option " + a);
     }
     if (!fq1.empty() || !fq2.empty())
@@ -209,22 +216,58 @@ int soibean_main(int argc, char **argv) {
     vgan_damage_view dmv;
     check(vgan_damage_view_get(dmg.p, &dmv), "damage view");
     vgan_sb_params prm{penalty, 0};
-    Handle<vgan_sb_ctx> ctx(vgan_sb_destroy);
-    check(vgan_sb_create(&gv, &dmv, &prm, device, &ctx.p), "creating the device context");
+    // one device context per GPU (--gpus / VGAN_GPUS; a GPU may be named twice: two contexts on it), the reads dealt to them
+    // once in contiguous shares: MCMC.cpp:739 runs its loop over the reads in parallel with `reduction(+:logLike)`, here the
+    // reduction runs over devices -- in integers (vgan_sb_sum), so the number of devices does not change a bit of the result
+    if (gpu_list.empty()) {
+        if (const char *e = getenv("VGAN_GPUS")) {
+            if (std::string(e) == "all")
+                for (int d = 0; d < vgan_device_count(); ++d) gpu_list.push_back(d);
+            else if (*e) parse_gpu_list(e, "VGAN_GPUS", T, gpu_list);
+        }
+        if (gpu_list.empty()) gpu_list.push_back(device);
+    }
+    struct Contexts {
+        std::vector<vgan_sb_ctx *> v;
+        vgan_sb_group *group = nullptr;
+        ~Contexts() {
+            vgan_sb_group_free(group);
+            for (auto c : v) vgan_sb_destroy(c);
+        }
+    } ctxs;
+    for (int d : gpu_list) {
+        if (d >= vgan_device_count()) die("[soibean] Error, GPU " + std::to_string(d) + " asked for, " + std::to_string(vgan_device_count()) + " visible");
+        vgan_sb_ctx *c = nullptr;
+        check(vgan_sb_create(&gv, &dmv, &prm, d, &c), "creating the device context");
+        ctxs.v.push_back(c);
+    }
+    check(vgan_sb_group_create(ctxs.v.data(), (int)ctxs.v.size(), &ctxs.group), "grouping the device contexts");
     Handle<vgan_alnset> aln(vgan_aln_free);
     aln.p = reader.take();
     vgan_alnset_view av;
     check(vgan_aln_view_get(aln.p, &av), "alignment view");
-    Handle<vgan_sb_host_batch> hb(vgan_sb_host_batch_free);
     vgan_sb_flatten_stats st{};
-    check(vgan_sb_flatten(graph.p, aln.p, 0, av.n_reads, n_threads, &hb.p, &st), "flattening");
-    vgan_sb_batch b;
-    check(vgan_sb_host_batch_get(hb.p, &b), "batch");
     int64_t dev_bad = 0;
-    check(vgan_sb_precompute(ctx.p, &b, &dev_bad), "analyse_GAM");
+    const int64_t n_ctx = (int64_t)ctxs.v.size();
+    for (int64_t i = 0; i < n_ctx; ++i) {
+        const int64_t r0 = av.n_reads * i / n_ctx, r1 = av.n_reads * (i + 1) / n_ctx;
+        Handle<vgan_sb_host_batch> hb(vgan_sb_host_batch_free);
+        vgan_sb_flatten_stats sti{};
+        check(vgan_sb_flatten(graph.p, aln.p, r0, r1, n_threads, &hb.p, &sti), "flattening");
+        st.n_in += sti.n_in;
+        st.n_out += sti.n_out;
+        st.n_unmapped += sti.n_unmapped;
+        st.n_bad += sti.n_bad;
+        vgan_sb_batch b;
+        check(vgan_sb_host_batch_get(hb.p, &b), "batch");
+        int64_t bad_i = 0;
+        check(vgan_sb_precompute(ctxs.v[(size_t)i], &b, &bad_i), "analyse_GAM");
+        dev_bad += bad_i;
+    }
     std::vector<int64_t> sig(gv.n_paths);
     int64_t n_ok = 0;
-    check(vgan_sb_best_paths(ctx.p, nullptr, sig.data(), &n_ok), "signature counts");
+    check(vgan_sb_group_best_paths(ctxs.group, sig.data(), &n_ok), "signature counts");
+    if (n_ctx > 1) std::cerr << "[soibean] " << n_ctx << " device contexts, the reads dealt in contiguous shares" << std::endl;
     pt.lap("GAM + analyse_GAM");
     std::cerr << "Number of paths: " << gv.n_paths << std::endl << "Number of reads: " << n_ok << std::endl;
     if (st.n_bad + dev_bad) std::cerr << "[soibean] warning: " << st.n_bad + dev_bad << " reads skipped (the reference would index out of bounds on them)\n";
@@ -280,7 +323,7 @@ int soibean_main(int argc, char **argv) {
     cfg.run_mcmc = run_mcmc;
     cfg.quiet = 0;
     vgan_sb_engine engine;
-    check(vgan_sb_engine_gpu(ctx.p, &engine), "engine");
+    check(vgan_sb_engine_group(ctxs.group, &engine), "engine");
     check(vgan_sb_estimate(&engine, tree.p, node_path.data(), sig_nodes.data(), (uint32_t)sig_nodes.size(), &cfg, out_prefix.c_str()), "estimation");
     pt.lap("chains");
     return 0;

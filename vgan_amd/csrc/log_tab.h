@@ -34,6 +34,42 @@ __device__ __forceinline__ double log_tab_fma3(double a, double b, double c) {
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// the same with every constant addend in a scalar register pair (an instruction takes one scalar operand): a kernel short of
+// vector registers keeps none of the series' constants in them (hc_wave_kernels.hip at five waves per SIMD)
+__device__ __forceinline__ double log_tab_fma3s(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double log_tab_eval_s(double x, const LogTabEntry *tab) {
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    const uint32_t lx = (uint32_t)bits;
+    const uint32_t h = (uint32_t)(bits >> 32) + (0x3FF00000u - VGAN_LOG_OFF);
+    const int k = (int)(h >> 20) - 1023;
+    const uint32_t idx = (h >> 14) & 63u;
+    const uint64_t mbits = ((uint64_t)((h & 0x000FFFFFu) + VGAN_LOG_OFF) << 32) | lx;
+    double m;
+    memcpy(&m, &mbits, 8);
+    const LogTabEntry e = tab[idx];
+    const double r = __builtin_fma(m, e.rcp, -1.0);
+    // Horner from the top with one scalar constant per instruction: q = r / 7 - 1 / 6 costs a multiply and an add
+    double t = r * (1.0 / 7.0);
+    t = t + (-1.0 / 6.0);
+    t = log_tab_fma3s(r, t, 0.2);
+    t = log_tab_fma3s(r, t, -0.25);
+    t = log_tab_fma3s(r, t, 1.0 / 3.0);
+    t = __builtin_fma(r, t, -0.5);
+    const double p = __builtin_fma(r * r, t, r);
+    const double dk = (double)k;
+    return __builtin_fma(dk, 6.93147180369123816490e-01, e.logc) + __builtin_fma(dk, 1.90821492927058770002e-10, p);
+}
+#else
+VGAN_HD double log_tab_eval(double x, const LogTabEntry *tab);
+inline double log_tab_eval_s(double x, const LogTabEntry *tab) { return log_tab_eval(x, tab); } // (host pass of a .hip file)
+#endif
+
 VGAN_HD double log_tab_eval(double x, const LogTabEntry *tab) {
     uint64_t bits;
     memcpy(&bits, &x, 8);

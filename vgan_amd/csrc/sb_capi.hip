@@ -66,12 +66,13 @@ struct vgan_sb_ctx {
     Buf<uint16_t> s16;
     Buf<uint8_t> s8;
     Buf<SbSourceDev> src;
-    Buf<double> hky, partial, out, freqs;
+    Buf<double> hky, out, freqs;
+    Buf<SbFix> partial, out_fix; // per-workgroup sums of a refresh; the folded sums themselves (vgan_sb_*_sums)
     Buf<int32_t> best, mix_paths;
     Buf<unsigned long long> sig;
     std::vector<char> h_params; // host staging of one refresh's parameters
     // the chain driver's refresh (one state per call, launch bound) is one kernel writing into pinned host memory
-    char *pin = nullptr;                 // out double[16] | guard u64[16]
+    char *pin = nullptr;                 // out double[16] | guard u64[16] | sums SbFix[16]
     bool time_refresh = false;           // HIP events around the engine's refresh too (vgan_sb_time_engine)
     Buf<unsigned long long> ticket;      // guard counts (one per state) of the fused refresh, zero between refreshes
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -167,6 +168,7 @@ extern "C" void vgan_sb_destroy(vgan_sb_ctx *c) {
     c->src.release();
     c->hky.release();
     c->partial.release();
+    c->out_fix.release();
     c->out.release();
     c->freqs.release();
     c->best.release();
@@ -321,8 +323,31 @@ extern "C" int vgan_sb_best_paths(vgan_sb_ctx *c, int32_t *best, int64_t *sig_co
     return VGAN_OK;
 }
 
+static_assert(sizeof(vgan_sb_sum) == sizeof(SbFix) && offsetof(vgan_sb_sum, lo) == offsetof(SbFix, lo) && offsetof(vgan_sb_sum, nf) == offsetof(SbFix, nf),
+              "vgan_sb_sum is the device's SbFix");
+
+extern "C" double vgan_sb_sum_value(const vgan_sb_sum *s) {
+    if (!s) return 0.0;
+    return sb_fix_value(SbFix{(long long)s->hi, (unsigned long long)s->lo, s->nf});
+}
+extern "C" void vgan_sb_sum_add(vgan_sb_sum *acc, const vgan_sb_sum *x) {
+    if (!acc || !x) return;
+    acc->hi += x->hi;
+    acc->lo += x->lo;
+    acc->nf += x->nf;
+}
+
+static int mixture_impl(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double log_freq, double *out, vgan_sb_sum *sum);
 extern "C" int vgan_sb_mixture_loglike(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double log_freq, double *out) {
-    if (!c || !paths || !out) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: null argument");
+    if (!out) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: null argument");
+    return mixture_impl(c, n, paths, log_freq, out, nullptr);
+}
+extern "C" int vgan_sb_mixture_sums(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double log_freq, vgan_sb_sum *sum) {
+    if (!sum) return fail(VGAN_EINVAL, "vgan_sb_mixture_sums: null argument");
+    return mixture_impl(c, n, paths, log_freq, nullptr, sum);
+}
+static int mixture_impl(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double log_freq, double *out, vgan_sb_sum *sum) {
+    if (!c || !paths) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: null argument");
     if (n == 0 || n > SB_MAX_PATHS) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: 1..%u sources, got %u", SB_MAX_PATHS, n);
     for (uint32_t i = 0; i < n; ++i)
         if (paths[i] < 0 || (uint32_t)paths[i] >= c->P) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: path index out of range");
@@ -330,17 +355,29 @@ extern "C" int vgan_sb_mixture_loglike(vgan_sb_ctx *c, uint32_t n, const int32_t
     const uint32_t R = c->t.n_reads;
     const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
     int rc;
-    if ((rc = c->mix_paths.reserve(n)) || (rc = c->partial.reserve(n_blocks)) || (rc = c->out.reserve(1))) return rc;
+    if ((rc = c->mix_paths.reserve(n)) || (rc = c->partial.reserve(n_blocks)) || (rc = c->out.reserve(1)) || (rc = c->out_fix.reserve(1))) return rc;
     HIPCHK(hipMemcpyAsync(c->mix_paths.p, paths, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    launch_sb_mixture(c->t, n, c->mix_paths.p, log_freq, c->partial.p, n_blocks, c->out.p, c->stream);
+    launch_sb_mixture(c->t, n, c->mix_paths.p, log_freq, c->partial.p, n_blocks, c->out.p, c->out_fix.p, c->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, c->out.p, 8, hipMemcpyDeviceToHost, c->stream));
+    if (out) HIPCHK(hipMemcpyAsync(out, c->out.p, 8, hipMemcpyDeviceToHost, c->stream));
+    if (sum) HIPCHK(hipMemcpyAsync(sum, c->out_fix.p, sizeof(SbFix), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return VGAN_OK;
 }
 
+static int loglike_impl(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                        double *out, double *d_out, uint64_t *guard, vgan_sb_sum *sums);
 extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con,
                                const double *freqs7, double *out, double *d_out, uint64_t *guard) {
+    return loglike_impl(c, n_states, k, src, con, freqs7, out, d_out, guard, nullptr);
+}
+extern "C" int vgan_sb_loglike_sums(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con,
+                                    const double *freqs7, vgan_sb_sum *sums, uint64_t *guard) {
+    if (!sums) return fail(VGAN_EINVAL, "vgan_sb_loglike_sums: null argument");
+    return loglike_impl(c, n_states, k, src, con, freqs7, nullptr, nullptr, guard, sums);
+}
+static int loglike_impl(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                        double *out, double *d_out, uint64_t *guard, vgan_sb_sum *sums) {
     if (!c || !src || !freqs7) return fail(VGAN_EINVAL, "vgan_sb_loglike: null argument");
     if (n_states == 0 || k == 0) return fail(VGAN_EINVAL, "vgan_sb_loglike: need at least one state and one source");
     if ((size_t)n_states * k * 2 * SB_NCNT * 8 > 60000) return fail(VGAN_ERANGE, "vgan_sb_loglike: n_states*k too large for one launch (<= 150)");
@@ -366,7 +403,7 @@ extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, co
     const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
     int rc;
     if ((rc = c->src.reserve(ne + 2)) || (rc = c->hky.reserve((size_t)ne * 2 * SB_NCNT)) || (rc = c->partial.reserve((size_t)n_states * n_blocks)) ||
-        (rc = c->out.reserve(n_states)) || (rc = c->guard.reserve(n_states)))
+        (rc = c->out.reserve(n_states)) || (rc = c->out_fix.reserve(n_states)) || (rc = c->guard.reserve(n_states)))
         return rc;
     // the sources and the seven frequencies travel in one copy: [SbSourceDev x ne][double x 7]
     static_assert(sizeof(SbSourceDev) % 8 == 0, "freqs follow the sources at an 8-byte offset");
@@ -377,13 +414,14 @@ extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, co
     const double *d_freqs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(c->src.p) + ne * sizeof(SbSourceDev));
     launch_sb_hky(ne, c->src.p, con, d_freqs, c->hky.p, c->guard.p, n_states, c->stream);
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    launch_sb_loglike(c->t, c->P, n_states, k, c->src.p, c->hky.p, c->partial.p, n_blocks, c->out.p, d_out, c->guard.p, c->stream);
+    launch_sb_loglike(c->t, c->P, n_states, k, c->src.p, c->hky.p, c->partial.p, n_blocks, c->out.p, d_out, c->out_fix.p, c->guard.p, c->stream);
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     c->pending[1] = true;
     HIPCHK(hipGetLastError());
-    if (out || guard) {
+    if (out || guard || sums) {
         std::vector<unsigned long long> gd(n_states);
         if (out) HIPCHK(hipMemcpyAsync(out, c->out.p, (size_t)n_states * 8, hipMemcpyDeviceToHost, c->stream));
+        if (sums) HIPCHK(hipMemcpyAsync(sums, c->out_fix.p, (size_t)n_states * sizeof(SbFix), hipMemcpyDeviceToHost, c->stream));
         if (guard) HIPCHK(hipMemcpyAsync(gd.data(), c->guard.p, (size_t)n_states * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (guard)
@@ -395,18 +433,27 @@ extern "C" int vgan_sb_loglike(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, co
 // n_states states of k sources each, results to the host: the per-iteration call of the chain driver (the chains of one source
 // count advance together) -- sb_refresh_fused_kernel with the sources as kernel arguments, then one wave per state folding
 // the partials into pinned host memory; bit-identical to vgan_sb_loglike.
-constexpr size_t SB_PIN_BYTES = 2 * SB_FUSED_MAX_K * 8;
+constexpr size_t SB_PIN_BYTES = 2 * SB_FUSED_MAX_K * 8 + SB_FUSED_MAX_K * sizeof(SbFix);
 
-static int refresh_states(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
-                          double *out, uint64_t *guard) {
-    if (!c || !src || !freqs7 || !out) return fail(VGAN_EINVAL, "vgan_sb_engine refresh: null argument");
+// launch half: everything is queued on the context's stream, nothing is waited for.  *general: the states did not fit the
+// kernel-argument staging and went through vgan_sb_loglike (already complete: results in gen_*).
+struct SbPending {
+    bool general = false;
+    std::vector<double> gen_out;
+    std::vector<vgan_sb_sum> gen_sum;
+    std::vector<uint64_t> gen_guard;
+};
+static int refresh_launch(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                          SbPending &pd) {
+    if (!c || !src || !freqs7) return fail(VGAN_EINVAL, "vgan_sb_engine refresh: null argument");
     if (n_states == 0 || k == 0) return fail(VGAN_EINVAL, "vgan_sb_engine refresh: need at least one state and one source");
     const uint32_t ne = n_states * k;
-    if (ne > SB_FUSED_MAX_K) { // beyond the kernel-argument staging: the general path (a launch per call, copies)
-        std::vector<uint64_t> gd(n_states, 0);
-        const int rc = vgan_sb_loglike(c, n_states, k, src, con, freqs7, out, nullptr, gd.data());
-        if (guard)
-            for (uint32_t e = 0; e < n_states; ++e) guard[e] = gd[e];
+    pd.general = ne > SB_FUSED_MAX_K;
+    if (pd.general) { // beyond the kernel-argument staging: the general path (a launch per call, copies)
+        pd.gen_out.assign(n_states, 0.0);
+        pd.gen_sum.assign(n_states, vgan_sb_sum{0, 0, 0.0});
+        pd.gen_guard.assign(n_states, 0);
+        int rc = loglike_impl(c, n_states, k, src, con, freqs7, pd.gen_out.data(), nullptr, pd.gen_guard.data(), pd.gen_sum.data());
         return rc;
     }
     HIPCHK(hipSetDevice(c->device));
@@ -440,20 +487,46 @@ static int refresh_states(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const v
     }
     double *pin_out = reinterpret_cast<double *>(c->pin);
     unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + SB_FUSED_MAX_K * 8);
+    SbFix *pin_fix = reinterpret_cast<SbFix *>(c->pin + 2 * SB_FUSED_MAX_K * 8);
     if (c->time_refresh) {
         resolve(c, 1);
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
     }
-    launch_sb_refresh_fused(c->t, n_states, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, c->stream,
+    launch_sb_refresh_fused(c->t, n_states, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, pin_fix, c->stream,
                             c->time_refresh ? c->ev[3] : nullptr);
     if (c->time_refresh) c->pending[1] = true;
     HIPCHK(hipGetLastError());
+    return VGAN_OK;
+}
+// collect half: waits for the context's stream; out / sums / guard (each may be NULL) receive n_states entries
+static int refresh_collect(vgan_sb_ctx *c, uint32_t n_states, const SbPending &pd, double *out, vgan_sb_sum *sums, uint64_t *guard) {
+    if (pd.general) {
+        for (uint32_t e = 0; e < n_states; ++e) {
+            if (out) out[e] = pd.gen_out[e];
+            if (sums) sums[e] = pd.gen_sum[e];
+            if (guard) guard[e] = pd.gen_guard[e];
+        }
+        return VGAN_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const double *pin_out = reinterpret_cast<const double *>(c->pin);
+    const unsigned long long *pin_guard = reinterpret_cast<const unsigned long long *>(c->pin + SB_FUSED_MAX_K * 8);
+    const SbFix *pin_fix = reinterpret_cast<const SbFix *>(c->pin + 2 * SB_FUSED_MAX_K * 8);
     for (uint32_t e = 0; e < n_states; ++e) {
-        out[e] = pin_out[e];
+        if (out) out[e] = pin_out[e];
+        if (sums) sums[e] = vgan_sb_sum{(int64_t)pin_fix[e].hi, (uint64_t)pin_fix[e].lo, pin_fix[e].nf};
         if (guard) guard[e] = pin_guard[e];
     }
     return VGAN_OK;
+}
+static int refresh_states(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                          double *out, uint64_t *guard) {
+    if (!out) return fail(VGAN_EINVAL, "vgan_sb_engine refresh: null argument");
+    SbPending pd;
+    int rc = refresh_launch(c, n_states, k, src, con, freqs7, pd);
+    if (rc) return rc;
+    return refresh_collect(c, n_states, pd, out, nullptr, guard);
 }
 
 // the chain driver's view of this context (host/sb_chain.cpp, vgan_sb_estimate)
@@ -480,6 +553,92 @@ extern "C" int vgan_sb_engine_gpu(vgan_sb_ctx *c, vgan_sb_engine *out) {
     out->refresh = engine_refresh;
     out->mixture = engine_mixture;
     out->refresh_many = engine_refresh_many;
+    return VGAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- several contexts, one engine
+// The reads of one job dealt to several contexts (one per GPU: MCMC.cpp:739 is `#pragma omp parallel for ... reduction(+:
+// logLike)` over the reads, here over devices): a refresh is launched on every context, then the per-context sums -- integers,
+// see SbFix -- are added on the host and turned into the log-likelihood once.  Same bits as one context holding all the reads.
+struct vgan_sb_group {
+    std::vector<vgan_sb_ctx *> ctxs;
+};
+
+extern "C" int vgan_sb_group_create(vgan_sb_ctx **ctxs, int n, vgan_sb_group **out) {
+    if (!ctxs || n <= 0 || !out) return fail(VGAN_EINVAL, "vgan_sb_group_create: null argument");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || ctxs[i]->P != ctxs[0]->P) return fail(VGAN_EINVAL, "vgan_sb_group_create: contexts of different graphs");
+    auto g = new vgan_sb_group();
+    g->ctxs.assign(ctxs, ctxs + n);
+    *out = g;
+    return VGAN_OK;
+}
+extern "C" void vgan_sb_group_free(vgan_sb_group *g) { delete g; }
+
+static int group_refresh_many(void *user, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
+                              double *out, uint64_t *guard) {
+    auto g = (vgan_sb_group *)user;
+    if (!g || !out) return fail(VGAN_EINVAL, "vgan_sb_group refresh: null argument");
+    const size_t nc = g->ctxs.size();
+    std::vector<SbPending> pd(nc);
+    int rc;
+    for (size_t i = 0; i < nc; ++i) // every device starts before any is waited for
+        if (g->ctxs[i]->t.n_reads && (rc = refresh_launch(g->ctxs[i], n_states, k, src, con, freqs7, pd[i]))) return rc;
+    std::vector<vgan_sb_sum> tot(n_states, vgan_sb_sum{0, 0, 0.0}), part(n_states);
+    std::vector<uint64_t> gd(n_states), gtot(n_states, 0);
+    for (size_t i = 0; i < nc; ++i) {
+        if (!g->ctxs[i]->t.n_reads) continue;
+        if ((rc = refresh_collect(g->ctxs[i], n_states, pd[i], nullptr, part.data(), gd.data()))) return rc;
+        for (uint32_t e = 0; e < n_states; ++e) {
+            vgan_sb_sum_add(&tot[e], &part[e]);
+            gtot[e] += gd[e];
+        }
+    }
+    for (uint32_t e = 0; e < n_states; ++e) {
+        out[e] = vgan_sb_sum_value(&tot[e]);
+        if (guard) guard[e] = gtot[e];
+    }
+    return VGAN_OK;
+}
+static int group_refresh(void *user, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7, double *out, uint64_t *guard) {
+    return group_refresh_many(user, 1, k, src, con, freqs7, out, guard);
+}
+static int group_mixture(void *user, uint32_t n, const int32_t *paths, double log_freq, double *out) {
+    auto g = (vgan_sb_group *)user;
+    if (!g || !out) return fail(VGAN_EINVAL, "vgan_sb_group mixture: null argument");
+    vgan_sb_sum tot{0, 0, 0.0}, part;
+    int rc;
+    for (auto c : g->ctxs) {
+        if (!c->t.n_reads) continue;
+        if ((rc = vgan_sb_mixture_sums(c, n, paths, log_freq, &part))) return rc;
+        vgan_sb_sum_add(&tot, &part);
+    }
+    *out = vgan_sb_sum_value(&tot);
+    return VGAN_OK;
+}
+extern "C" int vgan_sb_engine_group(vgan_sb_group *g, vgan_sb_engine *out) {
+    if (!g || !out) return fail(VGAN_EINVAL, "vgan_sb_engine_group: null argument");
+    out->user = g;
+    out->refresh = group_refresh;
+    out->mixture = group_mixture;
+    out->refresh_many = group_refresh_many;
+    return VGAN_OK;
+}
+// the per-path signature counts and the number of usable reads over all the group's contexts (vgan_sb_best_paths, summed)
+extern "C" int vgan_sb_group_best_paths(vgan_sb_group *g, int64_t *sig_count, int64_t *n_reads_ok) {
+    if (!g || !sig_count || !n_reads_ok) return fail(VGAN_EINVAL, "vgan_sb_group_best_paths: null argument");
+    const uint32_t P = g->ctxs[0]->P;
+    std::vector<int64_t> part(P);
+    for (uint32_t p = 0; p < P; ++p) sig_count[p] = 0;
+    *n_reads_ok = 0;
+    int rc;
+    for (auto c : g->ctxs) {
+        if (!c->t.n_reads) continue;
+        int64_t ok = 0;
+        if ((rc = vgan_sb_best_paths(c, nullptr, part.data(), &ok))) return rc;
+        for (uint32_t p = 0; p < P; ++p) sig_count[p] += part[p];
+        *n_reads_ok += ok;
+    }
     return VGAN_OK;
 }
 

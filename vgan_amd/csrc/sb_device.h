@@ -40,6 +40,23 @@ struct SbTablesDev {
     uint32_t n_reads;
 };
 
+// Sums over reads are taken in fixed point, in integers (units of 2^-44): the result does not depend on how the reads are
+// dealt to lanes, waves, workgroups, contexts or GPUs -- an MCMC accept / reject must not depend on the number of devices.
+// A term that does not fit (not finite, or 2^18 and beyond in magnitude) goes into a plain double beside the integers.
+// value = (hi * 2^32 + lo) * 2^-44 + nf (the layout of vgan_sb_sum, include/vgan_gpu.h)
+struct SbFix {
+    long long hi;
+    unsigned long long lo;
+    double nf;
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline double sb_fix_value(const SbFix &f) {
+    // (both products are exact -- powers of two --, so a fused multiply-add here gives the same bits as two operations)
+    return ((double)f.hi * 0x1p-12 + (double)f.lo * 0x1p-44) + f.nf;
+}
+
 struct SbSourceDev {
     int32_t child, parent;
     double t1, t2;      // pos*t, t - t1
@@ -59,23 +76,25 @@ struct SbFusedArgs {
 void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, double *stage_pm, uint16_t *stage_cnt,
                           uint32_t chunk_reads, unsigned long long *n_bad, hipStream_t st);
 void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states, uint32_t k, const SbSourceDev *src,
-                       const double *hky /* [n_states*k][2][25] */, double *partial, uint32_t n_blocks, double *out,
-                       double *out2 /* optional second copy of out */, unsigned long long *guard, hipStream_t st);
+                       const double *hky /* [n_states*k][2][25] */, SbFix *partial, uint32_t n_blocks, double *out,
+                       double *out2 /* optional second copy of out */, SbFix *out_fix /* optional: the sums themselves */,
+                       unsigned long long *guard, hipStream_t st);
 // also zeroes guard[0..n_states)
 void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky,
                    unsigned long long *guard, uint32_t n_states, hipStream_t st);
 
 // n_states * k <= SB_FUSED_MAX_K sources, two launches, no copies: out_host / guard_host[n_states] are pinned host memory;
-// guard = n_states zeroed device words (left zeroed); partial: n_states * n_blocks doubles.  Bit-identical to launch_sb_hky +
+// fix_host[n_states] likewise (the sums themselves: a caller adding over several contexts takes these);
+// guard = n_states zeroed device words (left zeroed); partial: n_states * n_blocks entries.  Bit-identical to launch_sb_hky +
 // launch_sb_loglike.
-void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
-                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st,
+void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, SbFix *partial, uint32_t n_blocks,
+                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host, hipStream_t st,
                              hipEvent_t after_main /* recorded between the two kernels when not null */);
 // per-read best path (-1: tie or excluded read), per-path signature counts and the number of usable reads; counters zeroed by the caller
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
                           unsigned long long *n_ok, hipStream_t st);
-// out[0] = sum over reads of (+)_j (log_freq + pm[paths[j]]); partial: n_blocks doubles of scratch
-void launch_sb_mixture(const SbTablesDev &t, uint32_t n, const int32_t *paths, double log_freq, double *partial, uint32_t n_blocks,
-                       double *out, hipStream_t st);
+// out[0] = sum over reads of (+)_j (log_freq + pm[paths[j]]); partial: n_blocks entries of scratch; out_fix (or NULL): the sum itself
+void launch_sb_mixture(const SbTablesDev &t, uint32_t n, const int32_t *paths, double log_freq, SbFix *partial, uint32_t n_blocks,
+                       double *out, SbFix *out_fix, hipStream_t st);
 
 } // namespace vgan

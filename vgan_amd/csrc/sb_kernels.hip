@@ -539,50 +539,90 @@ __device__ __forceinline__ double sb_read_term(const SbTablesDev &t, uint32_t r,
     return inter;
 }
 
+// ---- fixed-point sums over reads (sb_device.h: SbFix)
+__device__ __forceinline__ void sb_fix_add(SbFix &f, double x) {
+    if (fabs(x) < 0x1p18) { // (a NaN fails the comparison)
+        // x * 2^44 = h * 2^32 + l with h = floor(x * 2^12) (an int32) and 0 <= l < 2^32, l rounded to an integer: a function of x
+        // alone, so the sum of the (h, l) pairs is the same in any order
+        const double h = floor(x * 0x1p12);
+        const double l = rint(fma(-h, 0x1p32, x * 0x1p44));
+        const bool carry = l >= 0x1p32; // (rounded up to the next unit of hi)
+        f.hi += (long long)(int)h + (carry ? 1 : 0);
+        f.lo += carry ? 0ull : (unsigned long long)(unsigned int)l;
+    } else {
+        f.nf += x;
+    }
+}
+__device__ __forceinline__ SbFix sb_fix_wave_sum(SbFix f) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        f.hi += __shfl_xor(f.hi, o, 64);
+        f.lo += __shfl_xor(f.lo, o, 64);
+        f.nf += __shfl_xor(f.nf, o, 64);
+    }
+    return f;
+}
+// the workgroup's sum into partial[slot] (thread 0 writes it); red_s: one entry per wave.  Ends with a barrier.
+__device__ __forceinline__ void sb_fix_block_store(SbFix f, SbFix *red_s, SbFix *dst) {
+    f = sb_fix_wave_sum(f);
+    if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SbFix s2{0, 0, 0.0};
+        for (int w = 0; w < SBL_THREADS / 64; ++w) {
+            s2.hi += red_s[w].hi;
+            s2.lo += red_s[w].lo;
+            s2.nf += red_s[w].nf;
+        }
+        *dst = s2;
+    }
+    __syncthreads();
+}
+// one wave: the sum of n entries (lane l takes l, l + 64, ...)
+__device__ __forceinline__ SbFix sb_fix_fold(const SbFix *p, uint32_t n) {
+    SbFix s{0, 0, 0.0};
+    for (uint32_t i = threadIdx.x; i < n; i += 64) {
+        s.hi += p[i].hi;
+        s.lo += p[i].lo;
+        s.nf += p[i].nf;
+    }
+    return sb_fix_wave_sum(s);
+}
+
 __global__ __launch_bounds__(SBL_THREADS) void sb_loglike_kernel(SbTablesDev t, uint32_t n_states, uint32_t k,
                                                                   const SbSourceDev *__restrict__ src,
-                                                                  const double *__restrict__ hky, double *__restrict__ partial,
+                                                                  const double *__restrict__ hky, SbFix *__restrict__ partial,
                                                                   unsigned long long *__restrict__ guard) {
     extern __shared__ double hk_s[]; // [n_states*k][2][25]
-    __shared__ double red_s[SBL_THREADS / 64];
+    __shared__ SbFix red_s[SBL_THREADS / 64];
     const uint32_t n_tab = n_states * k * 2 * SB_NCNT;
     for (uint32_t i = threadIdx.x; i < n_tab; i += SBL_THREADS) hk_s[i] = hky[i];
     __syncthreads();
     const uint32_t R = t.n_reads;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t e = 0; e < n_states; ++e) {
-        double sum = 0.0;
+        SbFix sum{0, 0, 0.0};
         unsigned long long bad = 0;
         for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
             if (!t.ok[r]) continue;
-            const double inter = sb_read_term(t, r, k, src + (size_t)e * k, hk_s + (size_t)e * k * 2 * SB_NCNT, bad);
-            sum += inter;
-        }
-        sum = wave_sum(sum);
-        if (lane == 0) red_s[wave] = sum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s2 = 0.0;
-            for (int w = 0; w < SBL_THREADS / 64; ++w) s2 += red_s[w];
-            partial[(size_t)e * gridDim.x + blockIdx.x] = s2;
+            sb_fix_add(sum, sb_read_term(t, r, k, src + (size_t)e * k, hk_s + (size_t)e * k * 2 * SB_NCNT, bad));
         }
         if (bad) atomicAdd(&guard[e], bad);
-        __syncthreads();
+        sb_fix_block_store(sum, red_s, &partial[(size_t)e * gridDim.x + blockIdx.x]);
     }
 }
 
-// One wave per state: lane l adds partials l, l+64, ... in order, then a shuffle tree -- a fixed order, so the sum is
-// reproducible (the first version walked all partials on one thread: 79 us of dependent loads per refresh).
-__global__ __launch_bounds__(64) void sb_finish_kernel(const double *__restrict__ partial, uint32_t n_blocks, uint32_t n_states,
-                                                       double *__restrict__ out, double *__restrict__ out2) {
+// One wave per state folds the workgroups' sums (integers: any order gives the same bits; the first version walked all
+// partials on one thread: 79 us of dependent loads per refresh).
+__global__ __launch_bounds__(64) void sb_finish_kernel(const SbFix *__restrict__ partial, uint32_t n_blocks, uint32_t n_states,
+                                                       double *__restrict__ out, double *__restrict__ out2, SbFix *__restrict__ out_fix) {
     const uint32_t e = blockIdx.x;
     if (e >= n_states) return;
-    double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) s += partial[(size_t)e * n_blocks + i];
-    s = wave_sum(s);
+    const SbFix s = sb_fix_fold(partial + (size_t)e * n_blocks, n_blocks);
     if (threadIdx.x == 0) {
-        out[e] = s;
-        if (out2) out2[e] = s; // the caller's device buffer (handed to RCCL)
+        const double v = sb_fix_value(s);
+        out[e] = v;
+        if (out2) out2[e] = v; // the caller's device buffer (handed to RCCL)
+        if (out_fix) out_fix[e] = s;
     }
 }
 
@@ -593,10 +633,10 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(const double *__restrict_
 // time at 20k reads): this takes it from five stream operations to two.  (Folding in the last block to finish, behind a
 // device-scope fence and a ticket per block, measured slower at 1024 blocks than the second launch.)
 __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesDev t, uint32_t n_states, uint32_t k, SbFusedArgs a,
-                                                                        double *__restrict__ partial, unsigned long long *__restrict__ guard) {
+                                                                        SbFix *__restrict__ partial, unsigned long long *__restrict__ guard) {
     __shared__ double hk_s[SB_FUSED_MAX_K * 2 * SB_NCNT];
     __shared__ SbSourceDev src_s[SB_FUSED_MAX_K];
-    __shared__ double red_s[SBL_THREADS / 64];
+    __shared__ SbFix red_s[SBL_THREADS / 64];
     const uint32_t ne = n_states * k; // <= SB_FUSED_MAX_K
 #pragma unroll
     for (uint32_t y = 0; y < SB_FUSED_MAX_K; ++y)
@@ -617,37 +657,27 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesD
     }
     __syncthreads();
     const uint32_t R = t.n_reads;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t e = 0; e < n_states; ++e) { // the chains of one source count advance together: one state each
-        double sum = 0.0;
+        SbFix sum{0, 0, 0.0};
         unsigned long long bad = 0;
         for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
             if (!t.ok[r]) continue;
-            sum += sb_read_term(t, r, k, src_s + (size_t)e * k, hk_s + (size_t)e * k * 2 * SB_NCNT, bad);
+            sb_fix_add(sum, sb_read_term(t, r, k, src_s + (size_t)e * k, hk_s + (size_t)e * k * 2 * SB_NCNT, bad));
         }
-        sum = wave_sum(sum);
-        if (lane == 0) red_s[wave] = sum;
         if (bad) atomicAdd(&guard[e], bad);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s2 = 0.0;
-            for (int w = 0; w < SBL_THREADS / 64; ++w) s2 += red_s[w];
-            partial[(size_t)e * gridDim.x + blockIdx.x] = s2;
-        }
-        __syncthreads();
+        sb_fix_block_store(sum, red_s, &partial[(size_t)e * gridDim.x + blockIdx.x]);
     }
 }
 
 // one wave per state
-__global__ __launch_bounds__(64) void sb_finish_host_kernel(const double *__restrict__ partial, uint32_t n_blocks,
+__global__ __launch_bounds__(64) void sb_finish_host_kernel(const SbFix *__restrict__ partial, uint32_t n_blocks,
                                                             unsigned long long *__restrict__ guard, double *__restrict__ out_host,
-                                                            unsigned long long *__restrict__ guard_host) {
+                                                            unsigned long long *__restrict__ guard_host, SbFix *__restrict__ fix_host) {
     const uint32_t e = blockIdx.x;
-    double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_blocks; i += 64) s += partial[(size_t)e * n_blocks + i];
-    s = wave_sum(s);
+    const SbFix s = sb_fix_fold(partial + (size_t)e * n_blocks, n_blocks);
     if (threadIdx.x == 0) {
-        out_host[e] = s;
+        out_host[e] = sb_fix_value(s);
+        if (fix_host) fix_host[e] = s;
         guard_host[e] = guard[e];
         guard[e] = 0; // ready for the next refresh (stream ordered)
     }
@@ -698,13 +728,13 @@ __global__ __launch_bounds__(256) void sb_best_path_kernel(SbTablesDev t, uint32
 // soibean.cpp:737-756: per read inter = log_freq + pathMap[paths[0]], then inter = oplusInitnatl(inter, log_freq +
 // pathMap[paths[j]]) for the further sources; block partials in a fixed order as the refresh kernel's
 __global__ __launch_bounds__(SBL_THREADS) void sb_mixture_kernel(SbTablesDev t, uint32_t n, const int32_t *__restrict__ paths,
-                                                                  double log_freq, double *__restrict__ partial) {
-    __shared__ double red_s[SBL_THREADS / 64];
+                                                                  double log_freq, SbFix *__restrict__ partial) {
+    __shared__ SbFix red_s[SBL_THREADS / 64];
     __shared__ int32_t path_s[SB_MAX_PATHS];
     for (uint32_t i = threadIdx.x; i < n; i += SBL_THREADS) path_s[i] = paths[i];
     __syncthreads();
     const uint32_t R = t.n_reads;
-    double sum = 0.0;
+    SbFix sum{0, 0, 0.0};
     for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
         if (!t.ok[r]) continue;
         double inter = log_freq + t.pm[(size_t)path_s[0] * R + r];
@@ -713,25 +743,18 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_mixture_kernel(SbTablesDev t, 
             if (inter == 0.0) inter = y; // oplusInitnatl: a running value of 0 means "empty" 
             else inter = fmax(inter, y) + log1p(exp(-fabs(inter - y)));
         }
-        sum += inter;
+        sb_fix_add(sum, inter);
     }
-    sum = wave_sum(sum);
-    if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s2 = 0.0;
-        for (int w = 0; w < SBL_THREADS / 64; ++w) s2 += red_s[w];
-        partial[blockIdx.x] = s2;
-    }
+    sb_fix_block_store(sum, red_s, &partial[blockIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, double *partial, uint32_t n_blocks,
-                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, hipStream_t st,
+void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, SbFix *partial, uint32_t n_blocks,
+                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host, hipStream_t st,
                              hipEvent_t after_main) {
     hipLaunchKernelGGL(sb_refresh_fused_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, n_states, k, a, partial, guard);
     if (after_main) (void)hipEventRecord(after_main, st); // the timed interval is the fused kernel alone
-    hipLaunchKernelGGL(sb_finish_host_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host);
+    hipLaunchKernelGGL(sb_finish_host_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host, fix_host);
 }
 
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
@@ -741,10 +764,10 @@ void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best,
     hipLaunchKernelGGL(sb_best_path_kernel, dim3(blocks), dim3(256), 0, st, t, n_paths, best, sig_count, n_ok);
 }
 
-void launch_sb_mixture(const SbTablesDev &t, uint32_t n, const int32_t *paths, double log_freq, double *partial, uint32_t n_blocks,
-                       double *out, hipStream_t st) {
+void launch_sb_mixture(const SbTablesDev &t, uint32_t n, const int32_t *paths, double log_freq, SbFix *partial, uint32_t n_blocks,
+                       double *out, SbFix *out_fix, hipStream_t st) {
     hipLaunchKernelGGL(sb_mixture_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, n, paths, log_freq, partial);
-    hipLaunchKernelGGL(sb_finish_kernel, dim3(1), dim3(64), 0, st, partial, n_blocks, 1u, out, (double *)nullptr);
+    hipLaunchKernelGGL(sb_finish_kernel, dim3(1), dim3(64), 0, st, partial, n_blocks, 1u, out, (double *)nullptr, out_fix);
 }
 
 void launch_sb_precompute(const SbGraphDev &g, const SbBatchDev &b, const SbTablesDev &t, double *stage_pm, uint16_t *stage_cnt,
@@ -790,12 +813,12 @@ void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const
 }
 
 void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states, uint32_t k, const SbSourceDev *src,
-                       const double *hky, double *partial, uint32_t n_blocks, double *out, double *out2,
+                       const double *hky, SbFix *partial, uint32_t n_blocks, double *out, double *out2, SbFix *out_fix,
                        unsigned long long *guard, hipStream_t st) {
     (void)n_paths;
     const size_t lds = (size_t)n_states * k * 2 * SB_NCNT * sizeof(double);
     hipLaunchKernelGGL(sb_loglike_kernel, dim3(n_blocks), dim3(SBL_THREADS), lds, st, t, n_states, k, src, hky, partial, guard);
-    hipLaunchKernelGGL(sb_finish_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, n_states, out, out2);
+    hipLaunchKernelGGL(sb_finish_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, n_states, out, out2, out_fix);
 }
 
 } // namespace vgan

@@ -80,6 +80,26 @@ class SbContext:
                                         device_out.data_ptr() if device_out is not None else None, guard.ctypes.data))
         return out, guard
 
+    def loglike_sums(self, states, con, freqs7):
+        """vgan_sb_loglike_sums: per state the fixed-point sum itself as (hi, lo, nf) -- what a caller holding the reads in several
+        contexts adds up (integers: the order does not matter) before converting once with sum_value()."""
+        k = len(states[0])
+        arr = (N.SbSource * (len(states) * k))()
+        for e, st in enumerate(states):
+            for y, (c, p, d, pos, th) in enumerate(st):
+                arr[e * k + y] = N.SbSource(c, p, d, pos, th)
+        f = np.ascontiguousarray(freqs7, np.float64)
+        sums = (N.SbSum * len(states))()
+        guard = np.zeros(len(states), np.uint64)
+        N.check(N.lib().vgan_sb_loglike_sums(self._h, len(states), k, arr, con, f.ctypes.data, sums, guard.ctypes.data))
+        return [(s.hi, s.lo, s.nf) for s in sums], guard
+
+    def mixture_sums(self, paths, log_freq):
+        p = np.ascontiguousarray(paths, np.int32)
+        s = N.SbSum()
+        N.check(N.lib().vgan_sb_mixture_sums(self._h, len(p), p.ctypes.data, log_freq, C.byref(s)))
+        return (s.hi, s.lo, s.nf)
+
     def refresh(self, state, con, freqs7):
         """One state through the chain driver's engine (fused kernel + fold into pinned host memory): (logLike, guard).
         state: list of (child, parent, dist, pos, theta)."""
@@ -121,6 +141,60 @@ class SbContext:
     def close(self):
         if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_sb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def sum_value(parts):
+    """The log-likelihood of fixed-point sums added over contexts: parts = [(hi, lo, nf), ...] (vgan_sb_sum_add / _value)."""
+    acc = N.SbSum(0, 0, 0.0)
+    for hi, lo, nf in parts:
+        x = N.SbSum(hi, lo, nf)
+        N.lib().vgan_sb_sum_add(C.byref(acc), C.byref(x))
+    return N.lib().vgan_sb_sum_value(C.byref(acc))
+
+
+class SbGroup:
+    """Several contexts holding shares of one job's reads, as one likelihood engine (vgan_sb_group): MCMC.cpp:739's reduction
+    over the reads, run over devices.  The contexts stay the caller's."""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+        self._h = N.vp()
+        arr = (N.vp * len(self.ctxs))(*[c._h for c in self.ctxs])
+        N.check(N.lib().vgan_sb_group_create(arr, len(self.ctxs), C.byref(self._h)))
+        self._engine = N.SbEngine()
+        N.check(N.lib().vgan_sb_engine_group(self._h, C.byref(self._engine)))
+        self.n_paths = self.ctxs[0].n_paths
+
+    def engine(self):
+        return self._engine
+
+    def refresh(self, state, con, freqs7):
+        k = len(state)
+        arr = (N.SbSource * k)(*[N.SbSource(*s) for s in state])
+        f7 = (C.c_double * 7)(*list(freqs7))
+        out, gd = C.c_double(0), C.c_uint64(0)
+        N.check(self._engine.refresh(self._engine.user, k, C.cast(arr, C.c_void_p), con, f7, C.byref(out), C.byref(gd)))
+        return out.value, gd.value
+
+    def mixture_loglike(self, paths, log_freq):
+        p = np.ascontiguousarray(paths, np.int32)
+        out = C.c_double(0)
+        N.check(self._engine.mixture(self._engine.user, len(p), p.ctypes.data_as(C.POINTER(C.c_int32)), log_freq, C.byref(out)))
+        return out.value
+
+    def best_paths(self):
+        sig = np.zeros(self.n_paths, np.int64)
+        n = C.c_int64(0)
+        N.check(N.lib().vgan_sb_group_best_paths(self._h, sig.ctypes.data, C.addressof(n)))
+        return sig, n.value
+
+    def close(self):
+        if getattr(self, "_h", None) and N is not None:
+            N.lib().vgan_sb_group_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -234,10 +308,12 @@ def python_engine(refresh, mixture, batched=False):
 
 def estimate(engine, tree, node_path, sig_nodes, prefix, n_paths, freqs7, con=0.01, iters=500000, burnin=75000, chains=4, seed=1,
              run_mcmc=True, quiet=True):
-    """soibean.cpp:738-944 (vgan_sb_estimate).  engine: an SbContext (GPU) or a python_engine()."""
+    """soibean.cpp:738-944 (vgan_sb_estimate).  engine: an SbContext (GPU), an SbGroup (several) or a python_engine()."""
     if isinstance(engine, SbContext):
         e = N.SbEngine()
         N.check(N.lib().vgan_sb_engine_gpu(engine._h, C.byref(e)))
+    elif isinstance(engine, SbGroup):
+        e = engine.engine()
     else:
         e = engine
     cfg = N.SbEstimateCfg(iters, burnin, chains, n_paths, seed, con, (C.c_double * 7)(*freqs7), int(run_mcmc), int(quiet))
