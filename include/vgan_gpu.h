@@ -339,11 +339,28 @@ void vgan_hc_packed_free(vgan_hc_packed *p);
 /* What the layout pass wrote, copied to host arrays sized as in vgan_hc_packed_view (test aid: the host flatten's packed
  * layout is held against it word for word).  n[4] receives reads, segments, columns, quality bytes; any array may be NULL. */
 int vgan_hc_packed_download(const vgan_hc_packed *p, uint64_t n[4], uint32_t *rhdr, uint32_t *srec, uint32_t *crec, uint8_t *qualp);
+/* the arrays of a packed view (host or device: the current device must be the view's) copied to host arrays sized as the view
+ * says (test aid; any array may be NULL) */
+int vgan_hc_packed_view_download(const vgan_hc_packed_view *v, uint32_t *rhdr, uint32_t *srec, uint32_t *crec, uint8_t *qualp);
 /* Asynchronous on the context's stream: adds the batch's reads into the device accumulators. */
 int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *batch);
 /* (ABI 4) The same for a packed batch: host arrays are copied to the device as they are (one copy of the batch in HBM, no
  * layout pass), device arrays are read in place.  All three modes. */
 int vgan_hc_accumulate_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
+/* (ABI 4) a1 on the device: reconstruct_graph_sequence (vgan_utils.h:6-79), the slicing of update_likelihood.cpp:28-45 and the
+ * packed layout in one pass over a chunk of the parser's arrays, for the reads whose edits are all matches or substitutions
+ * on known nodes and which satisfy the tile contract -- what it writes is vgan_hc_flatten_parts_packed's packed batch of those
+ * reads, word for word, resident in HBM.  Every other read (indels, soft clips, long reads, reads the reference would
+ * terminate on) is left to the host: host_mask[r] = 1 (r indexes the chunk's reads; caller array of vgan_alnparts_n_reads
+ * bytes), to be flattened with vgan_hc_flatten_parts_packed(skip = the complement of host_mask, joined with the caller's own
+ * skip marks).  skip (or NULL): reads to leave out altogether, indexed like host_mask.  out: a device view (on_device = 1)
+ * valid until the next run on this object; out->read_src is a host array.  stats: n_in / n_out / n_unmapped / n_clamped /
+ * n_segments / n_cols of the reads taken here.  Synchronises the context's stream. */
+typedef struct vgan_hc_devflat vgan_hc_devflat;
+int vgan_hc_devflat_create(vgan_hc_ctx *c, const vgan_graph *graph, vgan_hc_devflat **out);
+int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chunk, const uint8_t *skip, vgan_hc_packed_view *out,
+                        uint8_t *host_mask, vgan_hc_flatten_stats *stats);
+void vgan_hc_devflat_free(vgan_hc_devflat *f);
 /* Host check of a packed batch against the layout above and the context's graph (offsets, node ids, head bits, maxima). */
 int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
 /* D_m = S_m - U_m per segment of a packed batch (test / debug aid). Host output [n_segments]. */

@@ -210,6 +210,10 @@ SYMBOLS = {
     "vgan_hc_packed_validate": (C.c_int, [vp, C.POINTER(HcPackedView)]),
     "vgan_hc_segment_weights_packed": (C.c_int, [vp, C.POINTER(HcPackedView), vp]),
     "vgan_hc_packed_download": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+    "vgan_hc_packed_view_download": (C.c_int, [C.POINTER(HcPackedView), vp, vp, vp, vp]),
+    "vgan_hc_devflat_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "vgan_hc_devflat_run": (C.c_int, [vp, vp, vp, C.POINTER(HcPackedView), vp, C.POINTER(FlattenStats)]),
+    "vgan_hc_devflat_free": (None, [vp]),
     "vgan_hc_host_batch_free": (None, [vp]),
     "vgan_reconstruct": (C.c_int, [vp, vp, C.c_int64, C.c_char_p, C.c_char_p, vp, C.c_int64, vp]),
     "vgan_hc_create": (C.c_int, [C.POINTER(GraphView), C.POINTER(HcParams), C.c_int, C.POINTER(vp)]),

@@ -145,6 +145,8 @@ struct vgan_hc_ctx {
     uint64_t prof_n[VGAN_HC_K_COUNT] = {0, 0, 0, 0, 0};
 };
 
+vgan::HcCtxInfo vgan::hc_ctx_info(const vgan_hc_ctx *c) { return HcCtxInfo{c->device, c->stream, c->rows}; }
+
 namespace {
 struct ScopedTimer {
     vgan_hc_ctx *c;
@@ -815,6 +817,17 @@ extern "C" int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packe
         return fail(VGAN_EINVAL, "packed batch: a read exceeds the stated per-read maxima");
     for (int i = 0; i < 32; ++i)
         if (v->qualp[v->n_qual + i] != 0) return fail(VGAN_EINVAL, "packed batch: the quality array is not followed by 32 zero bytes");
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_packed_view_download(const vgan_hc_packed_view *v, uint32_t *rhdr, uint32_t *srec, uint32_t *crec, uint8_t *qualp) {
+    if (!v) return fail(VGAN_EINVAL, "vgan_hc_packed_view_download: null argument");
+    if (v->n_reads == 0) return VGAN_OK;
+    const hipMemcpyKind k = v->on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
+    if (rhdr) HIPCHK(hipMemcpy(rhdr, v->rhdr, ((size_t)v->n_reads + 1) * 16, k));
+    if (srec && v->n_segments) HIPCHK(hipMemcpy(srec, v->srec, (size_t)v->n_segments * 8, k));
+    if (crec && v->n_cols) HIPCHK(hipMemcpy(crec, v->crec, (size_t)v->n_cols * 4, k));
+    if (qualp) HIPCHK(hipMemcpy(qualp, v->qualp, (size_t)v->n_qual + 32, k));
     return VGAN_OK;
 }
 

@@ -78,6 +78,17 @@ struct HcPackedDev {
     uint32_t max_read_cols;
 };
 
+// what another translation unit needs of a context (hc_flatten_kernels.hip)
+struct HcCtxInfo {
+    int device;
+    hipStream_t stream;
+    uint32_t rows;
+};
+} // namespace vgan
+struct vgan_hc_ctx;
+namespace vgan {
+HcCtxInfo hc_ctx_info(const vgan_hc_ctx *c);
+
 struct HcParamsDev {
     double bep;
     int use_bep;

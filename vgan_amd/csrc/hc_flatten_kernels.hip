@@ -1,0 +1,560 @@
+// a1 on the device: reconstruct_graph_sequence + the slicing of update_likelihood + the packed layout, in one pass over the
+// parser's arrays (reference: src/vgan_utils.h:6-79, src/update_likelihood.cpp:28-45, src/HaploCart.cpp:410).  The host keeps
+// the general walk (csrc/host/flatten.cpp): this path takes the reads whose edits are all matches or substitutions
+// (from_length == to_length) on known nodes and which satisfy the tile contract -- the common read -- and leaves every
+// other read, flagged, to the host.  What it writes is the host flatten's packed batch of the same reads, word for word
+// (tests/test_devflat_gpu.py): integer and byte work only.
+//
+//   hc_df_classify_kernel   a thread per read: the walk over mappings and edits without moving a byte -- may the device take
+//                           it, how many columns / segments / quality bytes, its lowest node id
+//   (hipcub)                stable radix sort of the taken reads by lowest node id, exclusive sums of the three sizes
+//   hc_df_write_kernel      a wave per read: node bases (reverse complement for reverse mappings) and read bases into LDS,
+//                           lanes over mappings; segment records, lanes over segments; column records, lanes over columns
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "hc_device.h"
+#include "host/common.h"
+#include "vgan_gpu.h"
+
+using namespace vgan;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(VGAN_ENODEV, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace vgan {
+namespace df {
+
+constexpr uint32_t DF_COLS = HC_TILE_MAX_READ_COLS, DF_QUAL = HC_TILE_MAX_READ_QUAL, DF_SEGS = HC_TILE_MAX_READ_SEGS;
+enum : uint8_t { DF_DEVICE = 0, DF_HOST = 1, DF_SKIP = 2, DF_UNMAPPED = 3 };
+
+struct DfSlice { // one parser slice's arrays on the device
+    const int64_t *map_off, *qual_off, *edit_off, *e_seq_off, *m_node, *m_offset;
+    const int32_t *mapq, *e_from, *e_to;
+    const double *identity;
+    const uint8_t *m_rev, *e_seq, *qual, *skip; // skip: NULL or per read of the slice
+    uint32_t n_reads, read0;                    // read0: the slice's first read within the chunk
+};
+struct DfGraph {
+    const int64_t *node_seq_off;
+    const uint8_t *node_seq;
+    const int32_t *pangenome_base;
+    int64_t min_id, max_id;
+    uint64_t n_mapp;
+};
+struct DfCounters { // zeroed per chunk
+    unsigned int n_dev, n_in, n_unmapped, n_clamped, max_segs, max_qual, max_cols, pad;
+};
+
+__device__ __forceinline__ uint8_t df_comp(uint8_t c) { // csrc/host/flatten.cpp: comp()
+    switch (c) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    case 'a': return 't';
+    case 'c': return 'g';
+    case 'g': return 'c';
+    case 't': return 'a';
+    default: return 'N';
+    }
+}
+
+// A thread per read of the slice.  Mirrors reconstruct_matches_only() + the route of flatten_range() (csrc/host/flatten.cpp):
+// anything the one-walk form does not cover is the host's.
+__global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph g, uint8_t *__restrict__ flag, uint32_t *__restrict__ key,
+                                                             uint4 *__restrict__ info, DfCounters *__restrict__ ctr) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= s.n_reads) return;
+    const uint32_t gr = s.read0 + r;
+    uint8_t f = DF_HOST;
+    uint32_t A = 0, G = 0, kmin = 0xFFFFFFFFu, nm = 0, nq = 0;
+    if (s.skip && s.skip[r]) {
+        f = DF_SKIP;
+    } else if (s.identity[r] < 1e-10) { // HaploCart.cpp:410
+        f = DF_UNMAPPED;
+    } else {
+        const int64_t m0 = s.map_off[r], m1 = s.map_off[r + 1];
+        const int64_t e0 = m1 > m0 ? s.edit_off[m0] : 0, e1 = m1 > m0 ? s.edit_off[m1] : 0;
+        const int64_t q_len = s.qual_off[r + 1] - s.qual_off[r];
+        bool ok = m1 > m0 && m1 - m0 <= (int64_t)DF_SEGS && q_len <= (int64_t)DF_QUAL && e1 - e0 >= m1 - m0;
+        nm = (uint32_t)(m1 - m0);
+        nq = (uint32_t)q_len;
+        int64_t a_len = 0, g_len = 0, pos = 0; // pos: where the next segment starts (saturating at A, which equals G here)
+        bool empty_seg = false;
+        for (int64_t m = m0; ok && m < m1; ++m) {
+            const int64_t id = s.m_node[m];
+            if (id < g.min_id || id > g.max_id) {
+                ok = false;
+                break;
+            }
+            const int32_t pb = g.pangenome_base[id];
+            if (pb < 0 || (uint64_t)pb >= g.n_mapp) {
+                ok = false;
+                break;
+            }
+            kmin = min(kmin, (uint32_t)id);
+            const int64_t len = g.node_seq_off[id + 1] - g.node_seq_off[id];
+            int64_t off = s.m_offset[m];
+            if (off != (int64_t)(int32_t)off) {
+                ok = false;
+                break;
+            }
+            for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
+                const int64_t from = s.e_from[e];
+                if (from != (int64_t)s.e_to[e] || from < 0 || off > len || off < 0) {
+                    ok = false;
+                    break;
+                }
+                const int64_t sl = s.e_seq_off[e + 1] - s.e_seq_off[e];
+                const int64_t n = min(from, len - off);
+                g_len += n;
+                a_len += sl > 0 ? sl : n;
+                off += from;
+            }
+        }
+        ok = ok && a_len == g_len && a_len <= (int64_t)DF_COLS && a_len > 0;
+        if (ok) {
+            // segment i = mapping i with the size of the read's i-th EDIT: start = min(A, sum of the sizes before), length
+            // min(size, A - start); a segment without a column sends the read to the general kernel (the host's business)
+            int64_t idx = 0;
+            for (int64_t m = m0; m < m1 && idx < m1 - m0; ++m) {
+                const int64_t id = s.m_node[m];
+                const int64_t len = g.node_seq_off[id + 1] - g.node_seq_off[id];
+                int64_t off = s.m_offset[m];
+                for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1] && idx < m1 - m0; ++e, ++idx) {
+                    const int64_t from = s.e_from[e];
+                    const int64_t n = min(from, len - off);
+                    const int64_t sl = min(n, a_len - pos);
+                    empty_seg = empty_seg || sl <= 0;
+                    pos += min(n, a_len - pos);
+                    off += from;
+                }
+            }
+            ok = !empty_seg;
+        }
+        if (ok) {
+            f = DF_DEVICE;
+            A = (uint32_t)a_len;
+            G = (uint32_t)g_len;
+        }
+    }
+    flag[gr] = f;
+    key[gr] = f == DF_DEVICE ? kmin : 0xFFFFFFFFu;
+    info[gr] = uint4{G, nm, nq, A};
+    if (f != DF_SKIP) atomicAdd(&ctr->n_in, 1u);
+    if (f == DF_UNMAPPED) atomicAdd(&ctr->n_unmapped, 1u);
+    if (f == DF_DEVICE) {
+        atomicAdd(&ctr->n_dev, 1u);
+        atomicMax(&ctr->max_segs, nm);
+        atomicMax(&ctr->max_qual, nq);
+        atomicMax(&ctr->max_cols, A);
+        const int32_t mq = s.mapq[r];
+        if (mq < 0 || mq > 99) atomicAdd(&ctr->n_clamped, 1u);
+    }
+}
+
+// sizes of the taken reads in sorted order (the sort's values are chunk read indices; taken reads come first)
+__global__ __launch_bounds__(256) void hc_df_gather_kernel(const uint32_t *__restrict__ order, const uint4 *__restrict__ info, uint32_t n_dev,
+                                                           uint32_t *__restrict__ segs, uint32_t *__restrict__ quals, uint32_t *__restrict__ cols) {
+    const uint32_t o = blockIdx.x * 256u + threadIdx.x;
+    if (o > n_dev) return;
+    if (o == n_dev) { // (the scans' last input: their output there is the total)
+        segs[o] = quals[o] = cols[o] = 0;
+        return;
+    }
+    const uint4 v = info[order[o]];
+    segs[o] = v.y;
+    quals[o] = v.z;
+    cols[o] = v.w;
+}
+
+struct DfOut {
+    uint4 *rhdr;
+    uint2 *srec;
+    uint32_t *crec;
+    uint8_t *qualp;
+    uint32_t *read_src;
+};
+
+// A wave per taken read, in sorted order.
+__global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restrict__ slices, uint32_t n_slices, DfGraph g,
+                                                          const uint32_t *__restrict__ order, const uint32_t *__restrict__ soff,
+                                                          const uint32_t *__restrict__ qoff, const uint32_t *__restrict__ coff, uint32_t n_dev,
+                                                          uint32_t src_base, DfOut out) {
+    __shared__ uint8_t gs_s[4][DF_COLS], ps_s[4][DF_COLS];
+    __shared__ uint16_t own_s[4][DF_COLS], sz_s[4][DF_SEGS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint8_t *gs = gs_s[wave], *ps = ps_s[wave];
+    uint16_t *own = own_s[wave], *sz = sz_s[wave];
+    for (uint32_t o = blockIdx.x * 4u + wave; o <= n_dev; o += gridDim.x * 4u) {
+        if (o == n_dev) { // the end offsets, and the zero bytes behind the quality strings
+            if (lane == 0) out.rhdr[o] = uint4{soff[o], qoff[o], coff[o], 0u};
+            if (lane < 32) out.qualp[qoff[o] + lane] = 0;
+            break;
+        }
+        const uint32_t gr = order[o];
+        uint32_t si = 0;
+        while (si + 1 < n_slices && slices[si + 1].read0 <= gr) ++si;
+        const DfSlice s = slices[si];
+        const uint32_t r = gr - s.read0;
+        const int64_t m0 = s.map_off[r], m1 = s.map_off[r + 1];
+        const uint32_t nm = (uint32_t)(m1 - m0);
+        const uint32_t s0 = soff[o], q0 = qoff[o], c0 = coff[o], A = coff[o + 1] - c0, nq = qoff[o + 1] - q0;
+        int32_t mq = s.mapq[r];
+        mq = mq < 0 ? 0 : (mq > 99 ? 99 : mq);
+        if (lane == 0) {
+            out.rhdr[o] = uint4{s0, q0, c0, A | ((uint32_t)mq << 16)};
+            out.read_src[o] = src_base + gr;
+        }
+        for (uint32_t c = lane; c < A; c += 64u) own[c] = 0;
+        // ---- lanes over mappings: where each one's bases go (wave scans of the per-mapping totals), then the bytes.  Node bases
+        // land at the running |graph_seq|, read bases at the running |path_string| (an edit's sequence where it has one, its
+        // node bases otherwise): the two agree in total for a read that got here, not necessarily edit by edit
+        uint32_t g_base = 0, a_base = 0, e_base = 0; // columns (graph / read side) and edits of the mappings before this pass
+        for (uint32_t mb = 0; mb < nm; mb += 64u) {
+            const uint32_t mi = mb + lane;
+            const bool on = mi < nm;
+            uint32_t gn = 0, an = 0, ne = 0;
+            int64_t id = 0, len = 0, off0 = 0;
+            bool rev = false;
+            if (on) {
+                const int64_t m = m0 + mi;
+                id = s.m_node[m];
+                len = g.node_seq_off[id + 1] - g.node_seq_off[id];
+                off0 = s.m_offset[m];
+                rev = s.m_rev[m] != 0;
+                int64_t off = off0;
+                for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
+                    const int64_t from = s.e_from[e], sl = s.e_seq_off[e + 1] - s.e_seq_off[e];
+                    const uint32_t n = (uint32_t)min(from, len - off);
+                    gn += n;
+                    an += sl > 0 ? (uint32_t)sl : n;
+                    off += from;
+                    ++ne;
+                }
+            }
+            uint32_t gp = gn, ap = an, ep = ne; // inclusive prefix sums over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t x = __shfl_up(gp, d, 64), y = __shfl_up(ap, d, 64), z = __shfl_up(ep, d, 64);
+                if ((int)lane >= d) {
+                    gp += x;
+                    ap += y;
+                    ep += z;
+                }
+            }
+            const uint32_t g_tot = __shfl(gp, 63, 64), a_tot = __shfl(ap, 63, 64), e_tot = __shfl(ep, 63, 64);
+            uint32_t gq = g_base + gp - gn, aq = a_base + ap - an, eq = e_base + ep - ne; // this mapping's first places
+            if (on) {
+                const int64_t m = m0 + mi;
+                const uint8_t *ns = g.node_seq + g.node_seq_off[id];
+                int64_t off = off0;
+                for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e, ++eq) {
+                    const int64_t from = s.e_from[e], sl = s.e_seq_off[e + 1] - s.e_seq_off[e];
+                    const uint32_t n = (uint32_t)min(from, len - off);
+                    for (uint32_t k = 0; k < n && gq + k < A; ++k) {
+                        const uint8_t b = rev ? df_comp(ns[len - 1 - (off + k)]) : ns[off + k];
+                        gs[gq + k] = b;
+                        if (sl <= 0 && aq + k < A) ps[aq + k] = b;
+                    }
+                    if (sl > 0) {
+                        const uint8_t *es = s.e_seq + s.e_seq_off[e];
+                        for (int64_t k = 0; k < sl && aq + k < A; ++k) ps[aq + k] = es[k];
+                    }
+                    if (eq < nm) sz[eq] = (uint16_t)n;
+                    gq += n;
+                    aq += sl > 0 ? (uint32_t)sl : n;
+                    off += from;
+                }
+            }
+            g_base += g_tot;
+            a_base += a_tot;
+            e_base += e_tot;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- lanes over segments: segment i = mapping i with the size of the read's i-th edit (update_likelihood.cpp:33-45, Q6)
+        {
+            uint32_t p_base = 0;
+            for (uint32_t sb = 0; sb < nm; sb += 64u) {
+                const uint32_t i = sb + lane;
+                const bool on = i < nm;
+                const uint32_t n = on ? sz[i] : 0u;
+                uint32_t pp = n;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t a = __shfl_up(pp, d, 64);
+                    if ((int)lane >= d) pp += a;
+                }
+                const uint32_t p_tot = __shfl(pp, 63, 64);
+                if (on) {
+                    const uint32_t start = min(A, p_base + pp - n), sl = min(n, A - start);
+                    out.srec[s0 + i] = uint2{(uint32_t)s.m_node[m0 + i], start | ((o & 0xFFFFu) << 16)};
+                    for (uint32_t j = 0; j < sl; ++j) own[start + j] = (uint16_t)(start + 1u);
+                }
+                p_base += p_tot;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- lanes over columns and over quality bytes
+        const uint8_t *q = s.qual + s.qual_off[r];
+        for (uint32_t c = lane; c < A; c += 64u) {
+            const uint32_t ow = own[c];
+            uint32_t rec = 0u;
+            if (ow) {
+                const uint32_t j = c - (ow - 1u);
+                rec = (uint32_t)gs[c] | ((uint32_t)ps[j] << 8) | ((c < nq ? (uint32_t)q[c] : 0u) << 16) | (j == 0 ? 0x80000000u : 0u);
+            }
+            out.crec[c0 + c] = rec;
+        }
+        for (uint32_t i = lane; i < nq; i += 64u) out.qualp[q0 + i] = q[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the next read's marks come after these reads of the wave's LDS)
+    }
+}
+
+} // namespace df
+} // namespace vgan
+
+using namespace vgan::df;
+
+// ------------------------------------------------------------------------------------------------------------ the C-ABI
+namespace {
+template <class T> struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap && p) return VGAN_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 4 + 256;
+        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return VGAN_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+} // namespace
+
+struct vgan_hc_devflat {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t rows = 0;
+    DfGraph g{};
+    DBuf<int64_t> node_seq_off;
+    DBuf<uint8_t> node_seq;
+    DBuf<int32_t> pangenome_base;
+    // one chunk's parser arrays (all slices, one after the other) and what the kernels make of them
+    DBuf<uint8_t> stage;
+    DBuf<DfSlice> slices;
+    DBuf<uint8_t> flag;
+    DBuf<uint32_t> key, key_out, val, val_out, segs, quals, cols, soff, qoff, coff, read_src;
+    DBuf<uint4> info, rhdr;
+    DBuf<uint2> srec;
+    DBuf<uint32_t> crec;
+    DBuf<uint8_t> qualp;
+    DBuf<DfCounters> ctr;
+    DBuf<uint8_t> cub_tmp;
+    std::vector<uint32_t> h_src;
+    void release() {
+        node_seq_off.release();
+        node_seq.release();
+        pangenome_base.release();
+        stage.release();
+        slices.release();
+        flag.release();
+        for (auto *b : {&key, &key_out, &val, &val_out, &segs, &quals, &cols, &soff, &qoff, &coff, &read_src, &crec}) b->release();
+        info.release();
+        rhdr.release();
+        srec.release();
+        qualp.release();
+        ctr.release();
+        cub_tmp.release();
+    }
+};
+
+extern "C" int vgan_hc_devflat_create(vgan_hc_ctx *c, const vgan_graph *graph, vgan_hc_devflat **out) {
+    if (!c || !graph || !out) return fail(VGAN_EINVAL, "vgan_hc_devflat_create: null argument");
+    const HcCtxInfo ci = hc_ctx_info(c);
+    HIPCHK(hipSetDevice(ci.device));
+    auto f = new vgan_hc_devflat();
+    f->device = ci.device;
+    f->stream = ci.stream;
+    f->rows = ci.rows;
+    int rc;
+    auto bail = [&](int code) {
+        f->release();
+        delete f;
+        return code;
+    };
+    const size_t n_off = graph->node_seq_off.size(), n_seq = graph->node_seq.size(), n_pb = graph->pangenome_base.size();
+    if ((rc = f->node_seq_off.reserve(n_off)) || (rc = f->node_seq.reserve(n_seq + 1)) || (rc = f->pangenome_base.reserve(n_pb + 1)) ||
+        (rc = f->ctr.reserve(1)))
+        return bail(rc);
+    if (hipMemcpy(f->node_seq_off.p, graph->node_seq_off.data(), n_off * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        (n_seq && hipMemcpy(f->node_seq.p, graph->node_seq.data(), n_seq, hipMemcpyHostToDevice) != hipSuccess) ||
+        (n_pb && hipMemcpy(f->pangenome_base.p, graph->pangenome_base.data(), n_pb * 4, hipMemcpyHostToDevice) != hipSuccess))
+        return bail(fail(VGAN_ENODEV, "vgan_hc_devflat_create: upload failed"));
+    f->g.node_seq_off = f->node_seq_off.p;
+    f->g.node_seq = f->node_seq.p;
+    f->g.pangenome_base = f->pangenome_base.p;
+    f->g.min_id = graph->min_id;
+    f->g.max_id = std::min<int64_t>(graph->max_id, (int64_t)n_pb - 1);
+    f->g.n_mapp = graph->mappability.size();
+    *out = f;
+    return VGAN_OK;
+}
+
+extern "C" void vgan_hc_devflat_free(vgan_hc_devflat *f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
+    f->release();
+    delete f;
+}
+
+extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chunk, const uint8_t *skip, vgan_hc_packed_view *out,
+                                   uint8_t *host_mask, vgan_hc_flatten_stats *stats) {
+    if (!f || !chunk || !out || !host_mask) return fail(VGAN_EINVAL, "vgan_hc_devflat_run: null argument");
+    memset(out, 0, sizeof *out);
+    if (stats) memset(stats, 0, sizeof *stats);
+    const size_t np = chunk->parts.size();
+    const int64_t n_reads = chunk->first.back();
+    if (n_reads == 0) return VGAN_OK;
+    if (n_reads > 0x7FFFFFF0ll || chunk->base + n_reads > 0xFFFFFFF0ll) return fail(VGAN_ERANGE, "vgan_hc_devflat_run: too many reads in one chunk");
+    HIPCHK(hipSetDevice(f->device));
+    hipStream_t st = f->stream;
+    int rc;
+    // ---- the slices' arrays, one after the other in one staging block (8-byte aligned pieces)
+    auto up8 = [](size_t n) { return (n + 7) & ~(size_t)7; };
+    size_t total = 0;
+    for (const vgan_alnset &a : chunk->parts) {
+        const size_t R = (size_t)a.n_reads(), M = a.m_node.size(), E = a.e_from.size();
+        total += up8((R + 1) * 8) * 2 + up8((M + 1) * 8) + up8((E + 1) * 8) + up8(M * 8) * 2 + up8(R * 4) + up8(E * 4) * 2 + up8(R * 8) +
+                 up8(M) + up8(a.e_seq.size()) + up8(a.qual.size()) + up8(R);
+    }
+    const uint32_t R_all = (uint32_t)n_reads;
+    if ((rc = f->stage.reserve(total)) || (rc = f->slices.reserve(np)) || (rc = f->flag.reserve(R_all)) || (rc = f->key.reserve(R_all)) ||
+        (rc = f->key_out.reserve(R_all)) || (rc = f->val.reserve(R_all)) || (rc = f->val_out.reserve(R_all)) || (rc = f->info.reserve(R_all)) ||
+        (rc = f->segs.reserve(R_all + 1)) || (rc = f->quals.reserve(R_all + 1)) || (rc = f->cols.reserve(R_all + 1)) ||
+        (rc = f->soff.reserve(R_all + 1)) || (rc = f->qoff.reserve(R_all + 1)) || (rc = f->coff.reserve(R_all + 1)))
+        return rc;
+    HIPCHK(hipMemsetAsync(f->ctr.p, 0, sizeof(DfCounters), st));
+    std::vector<DfSlice> hs(np);
+    uint8_t *cur = f->stage.p;
+    auto put = [&](const void *src, size_t bytes) -> const void * {
+        uint8_t *dst = cur;
+        cur += up8(bytes);
+        if (bytes) (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+        return dst;
+    };
+    for (size_t i = 0; i < np; ++i) {
+        const vgan_alnset &a = chunk->parts[i];
+        const size_t R = (size_t)a.n_reads(), M = a.m_node.size(), E = a.e_from.size();
+        DfSlice &s = hs[i];
+        s.n_reads = (uint32_t)R;
+        s.read0 = (uint32_t)chunk->first[i];
+        s.map_off = (const int64_t *)put(a.map_off.data(), (R + 1) * 8);
+        s.qual_off = (const int64_t *)put(a.qual_off.data(), (R + 1) * 8);
+        s.edit_off = (const int64_t *)put(a.edit_off.data(), (M + 1) * 8);
+        s.e_seq_off = (const int64_t *)put(a.e_seq_off.data(), (E + 1) * 8);
+        s.m_node = (const int64_t *)put(a.m_node.data(), M * 8);
+        s.m_offset = (const int64_t *)put(a.m_offset.data(), M * 8);
+        s.mapq = (const int32_t *)put(a.mapq.data(), R * 4);
+        s.e_from = (const int32_t *)put(a.e_from.data(), E * 4);
+        s.e_to = (const int32_t *)put(a.e_to.data(), E * 4);
+        s.identity = (const double *)put(a.identity.data(), R * 8);
+        s.m_rev = (const uint8_t *)put(a.m_rev.data(), M);
+        s.e_seq = (const uint8_t *)put(a.e_seq.data(), a.e_seq.size());
+        s.qual = (const uint8_t *)put(a.qual.data(), a.qual.size());
+        s.skip = skip ? (const uint8_t *)put(skip + chunk->first[i], R) : nullptr;
+        if (R) hipLaunchKernelGGL(hc_df_classify_kernel, dim3((uint32_t)((R + 255) / 256)), dim3(256), 0, st, s, f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(f->slices.p, hs.data(), np * sizeof(DfSlice), hipMemcpyHostToDevice, st));
+    // ---- the taken reads in ascending order of their lowest node id, input order kept among equals (the others' key is 2^32 - 1)
+    {
+        std::vector<uint32_t> iota(R_all);
+        for (uint32_t i = 0; i < R_all; ++i) iota[i] = i;
+        HIPCHK(hipMemcpyAsync(f->val.p, iota.data(), (size_t)R_all * 4, hipMemcpyHostToDevice, st));
+        size_t tmp = 0;
+        if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, f->key.p, f->key_out.p, f->val.p, f->val_out.p, (int)R_all, 0, 32, st) != hipSuccess)
+            return fail(VGAN_ENODEV, "vgan_hc_devflat_run: sort sizing failed");
+        if ((rc = f->cub_tmp.reserve(tmp))) return rc;
+        if (hipcub::DeviceRadixSort::SortPairs(f->cub_tmp.p, tmp, f->key.p, f->key_out.p, f->val.p, f->val_out.p, (int)R_all, 0, 32, st) != hipSuccess)
+            return fail(VGAN_ENODEV, "vgan_hc_devflat_run: sort failed");
+        HIPCHK(hipStreamSynchronize(st)); // (iota is a local)
+    }
+    DfCounters hc{};
+    HIPCHK(hipMemcpyAsync(&hc, f->ctr.p, sizeof hc, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(host_mask, f->flag.p, R_all, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < R_all; ++i) host_mask[i] = host_mask[i] == DF_HOST ? 1 : 0;
+    const uint32_t n_dev = hc.n_dev;
+    if (stats) {
+        stats->n_in = hc.n_in;
+        stats->n_unmapped = hc.n_unmapped;
+        stats->n_clamped = hc.n_clamped;
+        stats->n_out = n_dev;
+    }
+    if (n_dev == 0) return VGAN_OK;
+    // ---- offsets of the sorted reads: exclusive sums of their three sizes (entry n_dev: the totals)
+    hipLaunchKernelGGL(hc_df_gather_kernel, dim3((n_dev + 1 + 255) / 256), dim3(256), 0, st, f->val_out.p, f->info.p, n_dev, f->segs.p, f->quals.p, f->cols.p);
+    {
+        size_t tmp = 0;
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, f->segs.p, f->soff.p, (int)(n_dev + 1), st) != hipSuccess)
+            return fail(VGAN_ENODEV, "vgan_hc_devflat_run: scan sizing failed");
+        if ((rc = f->cub_tmp.reserve(tmp))) return rc;
+        if (hipcub::DeviceScan::ExclusiveSum(f->cub_tmp.p, tmp, f->segs.p, f->soff.p, (int)(n_dev + 1), st) != hipSuccess ||
+            hipcub::DeviceScan::ExclusiveSum(f->cub_tmp.p, tmp, f->quals.p, f->qoff.p, (int)(n_dev + 1), st) != hipSuccess ||
+            hipcub::DeviceScan::ExclusiveSum(f->cub_tmp.p, tmp, f->cols.p, f->coff.p, (int)(n_dev + 1), st) != hipSuccess)
+            return fail(VGAN_ENODEV, "vgan_hc_devflat_run: scan failed");
+    }
+    uint32_t tot[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(&tot[0], f->soff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&tot[1], f->qoff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&tot[2], f->coff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = f->rhdr.reserve((size_t)n_dev + 1)) || (rc = f->srec.reserve(tot[0] + 1)) || (rc = f->crec.reserve(tot[2] + 1)) ||
+        (rc = f->qualp.reserve((size_t)tot[1] + 32)) || (rc = f->read_src.reserve(n_dev)))
+        return rc;
+    DfOut o{f->rhdr.p, f->srec.p, f->crec.p, f->qualp.p, f->read_src.p};
+    hipLaunchKernelGGL(hc_df_write_kernel, dim3(std::min<uint32_t>((n_dev + 1 + 3) / 4, 16384u)), dim3(256), 0, st, f->slices.p, (uint32_t)np, f->g,
+                       f->val_out.p, f->soff.p, f->qoff.p, f->coff.p, n_dev, (uint32_t)chunk->base, o);
+    HIPCHK(hipGetLastError());
+    f->h_src.resize(n_dev);
+    HIPCHK(hipMemcpyAsync(f->h_src.data(), f->read_src.p, (size_t)n_dev * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st)); // (the staging block is reused by the next call; the caller's arrays may go)
+    out->n_reads = n_dev;
+    out->n_segments = tot[0];
+    out->n_qual = tot[1];
+    out->n_cols = tot[2];
+    out->rhdr = reinterpret_cast<const uint32_t *>(f->rhdr.p);
+    out->srec = reinterpret_cast<const uint32_t *>(f->srec.p);
+    out->crec = f->crec.p;
+    out->qualp = f->qualp.p;
+    out->max_read_segs = hc.max_segs;
+    out->max_read_qual = hc.max_qual;
+    out->max_read_cols = hc.max_cols;
+    out->on_device = 1;
+    out->read_src = f->h_src.data();
+    if (stats) {
+        stats->n_segments = tot[0];
+        stats->n_cols = tot[2];
+    }
+    return VGAN_OK;
+}

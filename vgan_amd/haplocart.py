@@ -464,6 +464,52 @@ class DeviceBatch:
             self._packed = None
 
 
+class DeviceFlatten:
+    """a1 on the device (vgan_hc_devflat): a chunk of parsed alignments (AlnParts) -> the packed batch of the reads the
+    device can take, resident in HBM, and the mask of the reads left to the host flatten."""
+
+    class Result:
+        """pk: the device view (valid until the next run); host_mask[r] = 1: read r of the chunk is the host's; c: no SoA part."""
+
+        def __init__(self, pk, host_mask, stats):
+            self.pk, self.host_mask, self.stats = pk, host_mask, stats
+            self.c = N.HcBatch()  # (an empty SoA part: HcContext.accumulate takes the packed view alone)
+            self.n_reads, self.n_segments = pk.n_reads, pk.n_segments
+
+        def download(self):
+            k = self.pk
+            out = {"rhdr": np.zeros(4 * (k.n_reads + 1), np.uint32), "srec": np.zeros(2 * k.n_segments, np.uint32),
+                   "crec": np.zeros(k.n_cols, np.uint32), "qualp": np.zeros(k.n_qual + 32, np.uint8)}
+            if k.n_reads:
+                N.check(N.lib().vgan_hc_packed_view_download(C.byref(k), out["rhdr"].ctypes.data, out["srec"].ctypes.data,
+                                                             out["crec"].ctypes.data, out["qualp"].ctypes.data))
+                out["read_src"] = np.array(_np_view(k.read_src, k.n_reads, np.uint32))
+            else:
+                out["read_src"] = np.zeros(0, np.uint32)
+            return out
+
+    def __init__(self, ctx, graph):
+        self._h = N.vp()
+        self._keep = (ctx, graph)
+        N.check(N.lib().vgan_hc_devflat_create(ctx._h, graph._h, C.byref(self._h)))
+
+    def run(self, parts, skip=None):
+        assert isinstance(parts, AlnParts)
+        sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+        mask = np.zeros(max(parts.n_reads, 1), np.uint8)
+        pk, st = N.HcPackedView(), N.FlattenStats()
+        N.check(N.lib().vgan_hc_devflat_run(self._h, parts._h, None if sk is None else sk.ctypes.data, C.byref(pk), mask.ctypes.data, C.byref(st)))
+        return DeviceFlatten.Result(pk, mask[:parts.n_reads], st)
+
+    def close(self):
+        if getattr(self, "_h", None) and N is not None:
+            N.lib().vgan_hc_devflat_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 class HcContext:
     """One HaploCart device context (vgan_hc_ctx) on one GPU."""
 
