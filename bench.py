@@ -196,6 +196,7 @@ def bench_euka(args):
         euka_traffic = collect_traffic(args, "euka_read_kernel") if world == 1 and not args.no_pmc else None
         kb = hb.algorithmic_bytes()
         avg = ms / max(n, 1)
+        euka_issue = collect_issue(args, "euka_read_kernel", avg) if world == 1 and not args.no_pmc else None
         gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
         out = {
             "metric": "reads/sec through euka per-read two-model likelihood (readGAM3), 75bp aDNA", "value": n_total * args.steps / elapsed,
@@ -208,7 +209,9 @@ def bench_euka(args):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": euka_traffic.get("bytes") if euka_traffic else None, "traffic_detail": euka_traffic,
                          "kernel": "euka_read_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
-                         "launches": n, "limiter": dict(valu_from_profile("euka_read_kernel") or {}, kind="valu (fp64) issue")}}
+                         "launches": n,
+                         # this kernel is fp64-VALU bound -- the ALU-side fraction (vector instruction issue) beside the HBM one
+                         "alu": euka_issue, "limiter": dict(euka_issue or {}, kind="valu (fp64) issue")}}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline_euka(g, db, alns, dm_texts, ctx, ek, args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -362,6 +365,7 @@ def bench_soibean(args):
         R = hb.n_reads
         sb_traffic = collect_traffic(args, "sb_refresh_fused_kernel" if fused else "sb_loglike_kernel") if world == 1 and not args.no_pmc else None
         avg = km["refresh"][0] / max(km["refresh"][1], 1)
+        sb_issue = collect_issue(args, "sb_refresh_fused_kernel" if fused else "sb_loglike_kernel", avg) if world == 1 and not args.no_pmc else None
         kb = R * 3 * 2 * (8 + 25 * 2) + R  # 2k path rows of pm (8 B) + cnt (25 x 2 B) + ok flags
         gbs = kb / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
         out = {
@@ -376,7 +380,7 @@ def bench_soibean(args):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": sb_traffic.get("bytes") if sb_traffic else None, "traffic_detail": sb_traffic,
                          "kernel": "sb_refresh_fused_kernel" if fused else "sb_loglike_kernel + sb_finish_kernel", "algorithmic_bytes_per_launch": kb, "avg_launch_ms": avg,
-                         "launches": km["refresh"][1]}}
+                         "launches": km["refresh"][1], "alu": sb_issue}}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline_soibean(g, alns, dm, sb, state, freqs, args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -423,12 +427,10 @@ def spawn_ranks(n):
 CHUNK_READS = 1_000_000  # reads per device batch (a rank's shard is a list of such batches, all resident in HBM)
 
 
-def collect_traffic(args, kernel_substr):
-    """HBM bytes per launch of the dominant kernel, from the PMC counters of THIS tree on THIS box: two child runs of
-    this very file under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md "rocprofv3
-    PMC slots"), 3 steps each, outside every timed region.  Units are KB per dispatch.  gfx950 corrections per the guide's
-    HBM section: FETCH_SIZE tallies the 128-byte requests of a coalesced stream at 64 B, so it is doubled; WRITE_SIZE is
-    exact for 8/16-byte stores and float atomics; Infinity-Cache hits are counted.  Raw values are kept beside the sum."""
+def pmc_pass(args, kernel_substr, counters):
+    """Mean per-dispatch values of `counters` (one rocprofv3 --pmc pass: they must fit the block's slots) for the kernels whose
+    name holds kernel_substr: a child run of this very file, 3 steps, outside every timed region.  {counter: value} or
+    {"failed": why}; None where no profiler exists or this run is itself being profiled."""
     import csv
     import glob
     import shutil
@@ -440,47 +442,87 @@ def collect_traffic(args, kernel_substr):
     # a run that is itself being profiled (someone else's rocprofv3 around bench.py) does not start a profiler of its own
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None
-    raw = {}
     tmp = tempfile.mkdtemp(prefix="vgan_pmc_")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-pmc", "--no-frontend",
-                   "--reads", str(args.reads), "--read-len", str(args.read_len), "--mode", args.mode, "--seed", str(args.seed),
-                   "--path", args.path, "--clades", str(args.clades)]
-            env = dict(os.environ, TMPDIR="/tmp")
-            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-                env.pop(k, None)
-            # its own session: on a timeout the whole group goes (the profiled python is a grandchild of ours and would
-            # otherwise keep running on the GPU beside the legs that follow)
-            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        out = os.path.join(tmp, "pass")
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-pmc", "--no-frontend",
+               "--reads", str(args.reads), "--read-len", str(args.read_len), "--mode", args.mode, "--seed", str(args.seed),
+               "--path", args.path, "--clades", str(args.clades)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        # its own session: on a timeout the whole group goes (the profiled python is a grandchild of ours and would
+        # otherwise keep running on the GPU beside the legs that follow)
+        pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = pr.wait(timeout=180)
+        except subprocess.TimeoutExpired:
             try:
-                rc = pr.wait(timeout=180)
-            except subprocess.TimeoutExpired:
-                try:
-                    os.killpg(pr.pid, 9)
-                except OSError:
-                    pass
-                pr.wait()
-                return {"bytes": None, "failed": "%s pass timed out" % counter}
-            if rc != 0:
-                return {"bytes": None, "failed": "%s pass exited with %d" % (counter, rc)}
-            vals = []
-            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
-                return {"bytes": None, "failed": "no %s row for a kernel named *%s*" % (counter, kernel_substr)}
-            raw[counter] = sum(vals) / len(vals) * 1024.0
+                os.killpg(pr.pid, 9)
+            except OSError:
+                pass
+            pr.wait()
+            return {"failed": "%s pass timed out" % "+".join(counters)}
+        if rc != 0:
+            return {"failed": "%s pass exited with %d" % ("+".join(counters), rc)}
+        vals = {c: [] for c in counters}
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] in vals:
+                    vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if not all(vals.values()):
+            return {"failed": "no %s row for a kernel named *%s*" % ("+".join(c for c in counters if not vals[c]), kernel_substr)}
+        return {c: sum(v) / len(v) for c, v in vals.items()}
     except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
-        return {"bytes": None, "failed": repr(e)}
+        return {"failed": repr(e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def collect_traffic(args, kernel_substr):
+    """HBM bytes per launch of the dominant kernel, from the PMC counters of THIS tree on THIS box: two child runs under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").  Units are
+    KB per dispatch.  gfx950 corrections per the guide's HBM section: FETCH_SIZE tallies the 128-byte requests of a coalesced
+    stream at 64 B, so it is doubled; WRITE_SIZE is exact for 8/16-byte stores and float atomics; Infinity-Cache hits are
+    counted.  Raw values are kept beside the sum."""
+    raw = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        got = pmc_pass(args, kernel_substr, [counter])
+        if got is None:
+            return None
+        if "failed" in got:
+            return {"bytes": None, "failed": got["failed"]}
+        raw[counter] = got[counter] * 1024.0
     return {"fetch_size_bytes_raw": raw["FETCH_SIZE"], "write_size_bytes_raw": raw["WRITE_SIZE"],
             "bytes": 2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"],
             "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950: coalesced 128-B read requests are tallied at 64 B)"}
+
+
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4  # wave-instructions/s: 1024 SIMDs, one vector instruction of a wave per 4 cycles, 2.4 GHz
+
+
+def collect_issue(args, kernel_substr, avg_launch_ms):
+    """What the dominant kernel does to the chip's instruction issue, from one SQ pass of THIS tree on THIS box (a child run
+    under rocprofv3 --pmc, beside the timed region): the ALU-side roofline SURVEY 8d asks for beside the HBM one.  alu_frac =
+    VALU wave-instructions per launch / the launch's time / the chip's VALU issue peak (1024 SIMDs x clock / 4: every vector
+    instruction of a wave occupies its SIMD for four cycles, measured: SQ_ACTIVE_INST_VALU x 4 / SQ_INSTS_VALU = 4.0)."""
+    got = pmc_pass(args, kernel_substr, ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE",
+                                         "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"])
+    if got is None:
+        return None
+    if "failed" in got:
+        return {"alu_frac": None, "failed": got["failed"]}
+    cyc = got["GRBM_GUI_ACTIVE"] / 8.0  # (summed over the 8 XCDs)
+    rate = got["SQ_INSTS_VALU"] / (avg_launch_ms * 1e-3) if avg_launch_ms > 0 else 0.0
+    return {"bound": "valu issue", "achieved": rate / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
+            "alu_frac": rate / VALU_ISSUE_PEAK,
+            "valu_insts": got["SQ_INSTS_VALU"], "salu_insts": got["SQ_INSTS_SALU"], "lds_insts": got["SQ_INSTS_LDS"],
+            # the same launch under the profiler: busy fractions of the SIMDs' vector issue and of the CUs' LDS
+            "valu_issue_frac_profiled": got["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * 1024.0) if cyc > 0 else None,
+            "lds_busy_frac_profiled": got["SQ_LDS_IDX_ACTIVE"] / (cyc * 256.0) if cyc > 0 else None,
+            "lds_bank_conflict_share": got["SQ_LDS_BANK_CONFLICT"] / max(got["SQ_LDS_IDX_ACTIVE"], 1.0),
+            "source": "in-run rocprofv3 --pmc pass of this tree (3 steps, beside the timed region)"}
 
 
 def host_cpu_quota():
@@ -490,7 +532,7 @@ def host_cpu_quota():
     return int(N.lib().vgan_host_cpus())
 
 
-def front_end_rates(graph, hc, seed, n=200_000):
+def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
     """SURVEY 8f-1 beside the metric (the timed step starts from a flattened batch in HBM): GAM decode and flatten
     rates of the host front end on a bounded sample of the same workload."""
     import tempfile
@@ -505,8 +547,24 @@ def front_end_rates(graph, hc, seed, n=200_000):
     t0 = time.perf_counter()
     hb = hc.HostBatch(graph, b, packed=True)
     t_fl = time.perf_counter() - t0
+    # a1 on the device (vgan_hc_devflat): the parser's arrays go up as they are (PCIe inside the figure), reconstruct + slicing +
+    # layout run as kernels; what `vgan haplocart` does for every chunk of a long input once the device contexts are up
+    dev = None
+    if ctx is not None:
+        with tempfile.TemporaryDirectory(prefix="vgan_fe_") as d:
+            p = os.path.join(d, "sample.gam")
+            a.write_gam(p)
+            parts = hc.AlnParts.read_gam(p)
+        df = hc.DeviceFlatten(ctx, graph)
+        df.run(parts)  # (buffers, pinned staging)
+        t0 = time.perf_counter()
+        res = df.run(parts)
+        t_df = time.perf_counter() - t0
+        dev = {"reads_per_s": parts.n_reads / t_df, "reads_taken": int(res.pk.n_reads), "reads_left_to_the_host": int(res.host_mask.sum())}
+        df.close()
     from vgan_amd import _native as N
     return {"sample_reads": n, "gam_bytes": size, "decode_reads_per_s": n / t_dec, "flatten_reads_per_s": hb.n_reads / t_fl,
+            "device_flatten": dev,
             "threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1),
             # what the container may keep busy (affinity mask and cgroup CPU quota): a sample this size is a burst on the
             # quota's slack; a long input runs at ~7 us of CPU per read on this many processors
@@ -684,9 +742,11 @@ def main():
         k_ms, k_n = prof[kname]
         avg_ms = k_ms / max(k_n, 1)
         kernel_name = {"segment": "hc_segment", "sweep_segments": "hc_sweep_kernel"}[kname]
-        traffic = None
+        traffic, issue = None, None
         if world == 1 and not args.no_pmc and args.scaling == "weak":
-            traffic = collect_traffic(args, kernel_name if kname == "segment" else "hc_sweep_kernel<10, false>")
+            ksub = kernel_name if kname == "segment" else "hc_sweep_kernel<10, false>"
+            traffic = collect_traffic(args, ksub)
+            issue = collect_issue(args, ksub, avg_ms)
         achieved = kbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         what = ("%d of the %d reads of BASELINE configs[2] per GPU (contiguous shards)" % (n_reads, args.reads_total)
                 if args.scaling == "strong" else "%d synthetic %dbp reads per GPU" % (args.reads, args.read_len))
@@ -719,7 +779,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic.get("bytes") if traffic else None, "traffic_detail": traffic,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": avg_ms, "launches": k_n,
-                         "limiter": valu_from_profile(kernel_name)},
+                         # what limits the launch: vector-instruction issue and LDS, from an in-run SQ pass
+                         "alu": issue, "limiter": issue},
             "layout_pass_ms": pack_ms,
             "kernel_ms_per_step": my_kernels,
             "per_rank": per_rank if world > 1 else None,
@@ -734,26 +795,13 @@ def main():
             "per_read_kernel": per_read,
         }
         if world == 1 and not args.no_frontend:
-            out["front_end"] = front_end_rates(graph, hc, args.seed)
+            out["front_end"] = front_end_rates(graph, hc, args.seed, ctx=ctx)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(graph, alns0, args.cpu_seconds, ctx, hc)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def valu_from_profile(kernel_name):
-    """What limits the dominant kernel, from the committed SQ-counter pass (profiles/valu_issue.json, written by
-    tools/summarize_pmc.py with the commit it was taken at): a tagged figure of a profile, not a live one."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))
-        for k, v in d.get("kernels", {}).items():
-            if kernel_name in k:
-                return dict(v, kind="valu issue + LDS", source="profiles/valu_issue.json", profile=d.get("profile"), commit=d.get("commit"))
-    except (OSError, ValueError):
-        pass
-    return None
 
 
 if __name__ == "__main__":

@@ -378,15 +378,17 @@ int vgan_hc_finalize(vgan_hc_ctx *c, double *d_out, double *out);
 int vgan_hc_synchronize(vgan_hc_ctx *c);
 /* Several GPUs in one process (the reference's OpenMP loop with its critical-section accumulate, HaploCart.cpp:408-421, one
  * context per GPU instead of one thread per core): every context finalizes, then ONE reduce of the P doubles onto the
- * first context.  41 KB per context: through the host by default (a communicator costs orders of magnitude more to set
- * up than one such reduce); ncclReduce over xGMI when the contexts sit on distinct devices AND a communicator for exactly
- * that device set exists already or VGAN_HC_REDUCE=rccl is set in the environment -- it is then created once, cached for
- * the life of the process and reused by every later reduce over the same devices (RCCL is loaded at run time, the library
- * does not link it).  out: host double[P] = the sum of what all the contexts accumulated.  *used_rccl (or NULL): 1 if the
- * collective ran. */
+ * first context -- ncclReduce over xGMI when the contexts sit on distinct devices (the communicator is created once per
+ * device set, cached for the life of the process and reused by every later reduce over the same devices; RCCL is loaded at
+ * run time, the library does not link it), through the host when contexts share a device, when RCCL cannot be loaded or
+ * initialised, or when VGAN_HC_REDUCE=host is set in the environment (for a single reduce of 41 KB per context the cheaper
+ * way: vgan_hc_reduce_info / _last report what the collective's set-up and the reduce cost).  out: host double[P] = the sum of
+ * what all the contexts accumulated.  *used_rccl (or NULL): 1 if the collective ran. */
 int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_rccl);
 /* wall time of the last communicator set-up (ncclCommInitAll) and how many there were in this process; either may be NULL */
 int vgan_hc_reduce_info(double *last_setup_ms, int *n_setups);
+/* wall time of the last vgan_hc_reduce (a communicator set-up made inside it included) and which way it went; either may be NULL */
+int vgan_hc_reduce_last(double *reduce_ms, int *was_rccl);
 void vgan_hc_destroy(vgan_hc_ctx *c);
 
 /* Per-kernel device timing with HIP events on the context's stream (bench.py's roofline figure).

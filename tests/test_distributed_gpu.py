@@ -182,16 +182,16 @@ def test_rccl_reduce_between_two_distinct_gpus(tmp_path, monkeypatch):
     ctxs = [hc.HcContext(g, device=d) for d in (0, 1)]
     for i, a in enumerate(chunks):
         ctxs[i % 2].accumulate(hc.HostBatch(g, a))
-    got, used = hc.reduce_contexts(ctxs)  # no communicator yet, none asked for: through the host
+    monkeypatch.setenv("VGAN_HC_REDUCE", "host")
+    got, used = hc.reduce_contexts(ctxs)  # asked to stay on the host
     assert not used and np.max(np.abs(got - want) / np.abs(want)) < 1e-12
-    monkeypatch.setenv("VGAN_HC_REDUCE", "rccl")
+    monkeypatch.delenv("VGAN_HC_REDUCE")
     n0 = hc.reduce_info()[1]
-    got, used = hc.reduce_contexts(ctxs)
+    got, used = hc.reduce_contexts(ctxs)  # distinct devices: the collective, its communicator made here
     assert used and np.max(np.abs(got - want) / np.abs(want)) < 1e-12
     ms, n1 = hc.reduce_info()
     assert n1 == n0 + 1 and ms > 0
-    monkeypatch.delenv("VGAN_HC_REDUCE")
-    got, used = hc.reduce_contexts(ctxs)  # the cached communicator is taken without being asked for
+    got, used = hc.reduce_contexts(ctxs)  # the cached communicator again
     assert used and hc.reduce_info()[1] == n1 and np.max(np.abs(got - want) / np.abs(want)) < 1e-12
     # the CLI on the two GPUs
     a = hc.synth_reads(g, 120_000, seed=9, read_len=100)
@@ -200,7 +200,7 @@ def test_rccl_reduce_between_two_distinct_gpus(tmp_path, monkeypatch):
     a.write_gam(gam)
     exe = os.path.join(ROOT, "vgan_amd", "bin", "vgan")
     lls = {}
-    for tag, extra, env in (("one", [], {}), ("host", ["--gpus", "0,1"], {}), ("rccl", ["--gpus", "0,1"], {"VGAN_HC_REDUCE": "rccl"})):
+    for tag, extra, env in (("one", [], {}), ("host", ["--gpus", "0,1"], {"VGAN_HC_REDUCE": "host"}), ("rccl", ["--gpus", "0,1"], {})):
         out = str(tmp_path / (tag + ".tsv"))
         r = subprocess.run([exe, "haplocart", "-g", gam, "--hc-files", str(tmp_path), "-o", out, "-np", "-d", "-s", "x"] + extra,
                            capture_output=True, text=True, env=dict(os.environ, **env))

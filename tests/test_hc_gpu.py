@@ -666,16 +666,25 @@ def test_cli_chunk_loop_lanes_and_small_batches_give_the_same_log_likelihoods(tm
     g.write(str(tmp_path))
     a.write_gam(str(tmp_path / "r.gam"))
     res = {}
-    for tag, env in (("one", {"VGAN_HC_LANES": "1", "VGAN_HC_BATCH": "1000000"}),
-                     ("lanes", {"VGAN_HC_LANES": "3", "VGAN_HC_BATCH": "1024", "VGAN_HC_QUEUE": "3", "VGAN_GAM_SEG_BLOCKS": "4"})):
+    # (the default route flattens on the device and leaves the reads with indels / soft clips to the host; VGAN_HC_HOST_FLATTEN=1
+    # sends every read through the host flatten, on `lanes` threads)
+    for tag, env in (("one", {"VGAN_HC_LANES": "1", "VGAN_HC_BATCH": "1000000", "VGAN_HC_HOST_FLATTEN": "1"}),
+                     ("lanes", {"VGAN_HC_LANES": "3", "VGAN_HC_BATCH": "1024", "VGAN_HC_QUEUE": "3", "VGAN_GAM_SEG_BLOCKS": "4", "VGAN_HC_HOST_FLATTEN": "1"}),
+                     ("device", {"VGAN_HC_BATCH": "1000000", "VGAN_HC_DEVICE_AFTER": "0"}),
+                     ("device_small", {"VGAN_HC_BATCH": "1024", "VGAN_HC_QUEUE": "3", "VGAN_GAM_SEG_BLOCKS": "4", "VGAN_TIMING": "1", "VGAN_HC_DEVICE_AFTER": "2"})):
         out = str(tmp_path / (tag + ".tsv"))
         r = subprocess.run([os.path.join(root, "vgan_amd", "bin", "vgan"), "haplocart", "-g", str(tmp_path / "r.gam"), "--hc-files",
                             str(tmp_path), "-q", "-np", "-d", "-o", out, "-s", "s", "-t", "6"],
                            capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr
+        if tag == "device_small":  # some reads were the device's, some the host's
+            line = [ln for ln in r.stderr.splitlines() if "device flatten" in ln][0]
+            n_host = int(line.split("host flatten of the ")[1].split()[0])
+            assert 0 < n_host < 30000, line
         ll = dict((ln.split("\t")[0], float(ln.split("\t")[1])) for ln in open(out + ".loglik.tsv").read().splitlines())
         res[tag] = (open(out).read().splitlines()[1], ll)
-    assert res["one"][0] == res["lanes"][0]  # sample, predicted haplogroup, reads kept
-    assert res["one"][1].keys() == res["lanes"][1].keys() and len(res["one"][1]) == 60
-    for k, v in res["one"][1].items():
-        assert res["lanes"][1][k] == pytest.approx(v, rel=1e-9)
+    for other in ("lanes", "device", "device_small"):
+        assert res["one"][0] == res[other][0]  # sample, predicted haplogroup, reads kept
+        assert res["one"][1].keys() == res[other][1].keys() and len(res["one"][1]) == 60
+        for k, v in res["one"][1].items():
+            assert res[other][1][k] == pytest.approx(v, rel=1e-9)

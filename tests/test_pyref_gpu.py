@@ -9,11 +9,16 @@ import pytest
 from vgan_amd import haplocart as hc
 
 pytestmark = pytest.mark.gpu
-FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hc_pyref")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(params=["hc_pyref", "hc_pyref_j2"], ids=["simulated", "J2a1a1a1"])
+def FIX(request):
+    return os.path.join(GOLD, request.param)
 
 
 @pytest.mark.parametrize("key, kw", [("default", {}), ("background", dict(background_error_prob=0.02, use_background_error_prob=True))])
-def test_final_vector_per_read_vectors_and_posteriors_against_the_python_restatement(key, kw):
+def test_final_vector_per_read_vectors_and_posteriors_against_the_python_restatement(key, kw, FIX):
     want = json.load(open(os.path.join(FIX, "hc_pyref.json")))[key]
     g = hc.Graph.load(os.path.join(FIX, "graph.gfa"), FIX)
     a = hc.AlnSet.read_gam(os.path.join(FIX, "reads.gam"))

@@ -41,7 +41,6 @@ import mpmath as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-sys.path.insert(0, ROOT)
 import gamio  # noqa: E402
 from pyref_hc import Undefined, load_gfa, reconstruct_graph_sequence, signed_char  # noqa: E402
 
@@ -297,50 +296,62 @@ def run(d, min_mapq=29, ltp=5):
 
 # ---------------------------------------------------------------------------------------------------------- fixture writer
 def make(d):
-    """Inputs from the product's synthetic generator (host code, no GPU), rewritten through the test-side GAM codec with the cases
-    the generator does not draw: soft clips counted in threes, an N and a rare base in the graph, mapping qualities around the
-    threshold, a reverse-strand read set."""
-    import numpy as np
-    from vgan_amd import euka as ek
+    """Inputs built by tools/pyref_inputs.py (plain seeded Python, no product code): six clades, each a small variation graph of
+    its own over a contiguous range of node ids, with the clade and bin tables euka loads (load.cpp:70-158); reads of both strands
+    with substitutions, indels and soft clips, rewritten with the cases a plain simulator does not draw: an N and a rare base
+    in the graph, mapping qualities around the threshold and 0, qualities below Q2."""
+    import random
+    import pyref_inputs as pi
     os.makedirs(d, exist_ok=True)
     gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
     t5, t3 = open(gold + "/dhigh5p.prof").read(), open(gold + "/dhigh3p.prof").read()
     open(os.path.join(d, "damage5p.prof"), "w").write(t5)
     open(os.path.join(d, "damage3p.prof"), "w").write(t3)
-    dm = ek.Damage.from_text(t5, t3)
-    g, db, a = ek.synth_euka(260, dm, seed=91, n_clades=6, nodes_per_clade=60, read_len_mean=60)
-    seq, off = g.node_seq, g.node_seq_off
+    rng = random.Random(91)
+    seqs, clades, bins, alns = {}, [], [], []
+    first = 1
+    for c in range(6):
+        g = pi.variation_graph(seed=910 + c, genome_len=150, n_paths=4, first_id=first)
+        ids = sorted(g["seqs"])
+        lo, hi = ids[0], ids[-1]
+        seqs.update(g["seqs"])
+        clades.append((c, "clade%03d" % c, rng.uniform(0.05, 0.2), lo, hi))
+        width = max(3, (hi - lo + 1) // 9)
+        row = []
+        for j in range(10):
+            b0 = lo + j * (hi - lo + 1) // 10
+            row.append((b0, min(hi, b0 + width), rng.uniform(1.1, 1.35)))
+        bins.append(row)
+        alns += pi.simulate_reads(920 + c, g, 44, read_len=60, sub_rate=0.03, indel_rate=0.12, softclip_rate=0.15, reverse_rate=0.5,
+                                  low_mapq_rate=0.2, name="c%d_" % c)
+        first = hi + 1
+    some = sorted(seqs)
+    seqs[some[7]] = "N" + seqs[some[7]][1:]       # an unresolved base
+    seqs[some[31]] = seqs[some[31]][:-1] + "R"    # a base outside ACGTN
+    rng.shuffle(alns)
     with open(os.path.join(d, "graph.gfa"), "w") as f:
         f.write("H\tVN:Z:1.0\n")
-        for nid in range(g.min_id, g.max_id + 1):
-            s = bytes(seq[off[nid]:off[nid + 1]]).decode()
-            if s:
-                f.write("S\t%d\t%s\n" % (nid, s))
-    names = db.clade_names
+        for nid in sorted(seqs):
+            f.write("S\t%d\t%s\n" % (nid, seqs[nid]))
     with open(os.path.join(d, "euka_db.clade"), "w") as f:
-        for c in range(db.n_clades):
-            lo = int(db.bin_lo[db.bin_off[c]]) if db.bin_off[c + 1] > db.bin_off[c] else 0
-            hi = int(db.bin_hi[db.bin_off[c + 1] - 1]) if db.bin_off[c + 1] > db.bin_off[c] else 0
-            f.write("%d %s %.17g 1 %d %d\n" % (int(db.clade_id[c]) if db.view.clade_id else c, names[c], float(db.clade_dist[c]), lo, hi))
+        for c, name, dist, lo, hi in clades:
+            f.write("%d %s %.17g 1 %d %d\n" % (c, name, dist, lo, hi))
     with open(os.path.join(d, "euka_db.bins"), "w") as f:
-        for c in range(db.n_clades):
-            t = [names[c]]
-            for j in range(int(db.bin_off[c]), int(db.bin_off[c + 1])):
-                t += [str(int(db.bin_lo[j])), str(int(db.bin_hi[j])), "%.17g" % float(db.bin_entropy[j])]
+        for (c, name, _, _, _), row in zip(clades, bins):
+            t = [name]
+            for lo, hi, e in row:
+                t += [str(lo), str(hi), "%.17g" % e]
             f.write(" ".join(t) + "\n")
-    tmp = os.path.join(d, "reads.gam")
-    a.write_gam(tmp)
-    alns = gamio.read_gam(tmp)
-    rng = np.random.default_rng(5)
     for r, al in enumerate(alns):
         if r % 9 == 2:
-            al["mapping_quality"] = int(rng.integers(27, 33))
+            al["mapping_quality"] = rng.randint(27, 32)
         if r % 13 == 4:
             al["mapping_quality"] = 0
         if r % 11 == 6 and len(al["quality"]) > 20:
             q = bytearray(al["quality"])
             q[7], q[8] = 0, 1  # below Q2: 0.25
             al["quality"] = bytes(q)
+    tmp = os.path.join(d, "reads.gam")
     open(tmp, "wb").write(gamio.write_gam(alns, group=50))
     for _ in range(3):  # the reads whose treatment the reference leaves undefined are taken out: the sums below must not depend on them
         und = {u["read"] for u in run(d)["undefined_reads"]} | {u["read"] for u in run(d, min_mapq=0, ltp=3)["undefined_reads"]}
@@ -349,7 +360,7 @@ def make(d):
         alns = [al for r, al in enumerate(alns) if r not in und]
         open(tmp, "wb").write(gamio.write_gam(alns, group=50))
     out = {"_what": "tools/pyref_euka.py: an independent Python + mpmath (40 digits) restatement of euka's per-read path on the inputs "
-                    "beside this file; NOT generated by oracle/ or by the product",
+                    "beside this file (tools/pyref_inputs.py: plain seeded Python); NOT generated by oracle/ or by the product",
            "default": run(d), "other_thresholds": run(d, min_mapq=0, ltp=3)}
     json.dump(out, open(os.path.join(d, "euka_pyref.json"), "w"), indent=0)
     print("wrote", d, "reads", len(out["default"]["reads"]), "undefined", len(out["default"]["undefined_reads"]),

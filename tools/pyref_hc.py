@@ -33,6 +33,7 @@ Usage (in the build container; the GPU box only loads the JSON):
     python tools/pyref_hc.py --check-kats                        # the reconstruction against the reference's KATs
 """
 import argparse
+import math
 import gzip
 import json
 import os
@@ -42,7 +43,7 @@ import mpmath as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gamio  # noqa: E402  (the test-side GAM decoder / encoder: no product code)
 
 mp.mp.dps = 40
@@ -103,7 +104,7 @@ def load_hcfiles(d):
 
 
 # -------------------------------------------------------------------------------------- vg / libgab semantics (published)
-_COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "a": "t", "c": "g", "g": "c", "t": "a"}
 
 
 def node_sequence(seqs, node_id, is_reverse):
@@ -111,7 +112,9 @@ def node_sequence(seqs, node_id, is_reverse):
     if node_id not in seqs:
         raise Undefined("unknown node %d" % node_id)
     s = seqs[node_id]
-    return "".join(_COMP.get(c, c) for c in reversed(s)) if is_reverse else s
+    # (libbdsg / vg reverse_complement(char): A<->T, C<->G in either case, and every other character -- N, IUPAC codes -- 'N';
+    # restated from the published sources of the pinned dependency, which is not in the reference's tree)
+    return "".join(_COMP.get(c, "N") for c in reversed(s)) if is_reverse else s
 
 
 def edit_is_match(e):
@@ -205,15 +208,17 @@ def reconstruct_graph_sequence(seqs, path):
 
 
 # ------------------------------------------------------------------------------------------ tables (miscfunc.h, haplocart_functions.cpp)
-def get_p_seq_error(Q):  # miscfunc.h:180-188; pow(10, (-1 * Q) * 0.1) with the exponent formed in double
-    return mp.mpf(10) ** mp.mpf(float((-1 * Q) * 0.1)) if Q > 2 else mp.mpf("0.25")
+# Types are the reference's: what it computes in `double` is computed here in Python floats through libm (math.pow / math.log are
+# the C library's pow / log the reference calls), what it keeps in `long double` in mpmath at 40 digits.  The difference shows:
+# `1 - qscore_vec[Q]` is a double, and get_p_obs_base's `1 - epsilon` then gives back 1 - (1 - e), not e -- 1e-10 relative at Q = 60
+# (the reference's bundled J2a1a1a1.gam holds such qualities; a simulator drawing Q <= 41 never sees it).
+def get_p_seq_error(Q):  # miscfunc.h:180-188: const double, pow(10, (-1 * Q) * 0.1) in double
+    return math.pow(10, ((-1 * Q) * 0.1)) if Q > 2 else 0.25
 
 
-# miscfunc.h:199-212: Q >= 2 takes get_p_seq_error (which answers 0.25 up to 2), the others 0.25
-QSCORE_VEC = [get_p_seq_error(Q) if Q >= 2 else mp.mpf("0.25") for Q in range(100)]
-# the tables are vector<double>: every entry is rounded to double when stored
-QSCORE_VEC = [mp.mpf(float(x)) for x in QSCORE_VEC]
-INCORRECT_MAPPING_VEC = [mp.mpf(float(mp.mpf(10) ** mp.mpf(float((-1 * Q) * 0.1)))) for Q in range(100)]  # haplocart_functions.cpp:101-107
+# miscfunc.h:199-212 (vector<double>): Q >= 2 takes get_p_seq_error (which answers 0.25 up to 2), the others 0.25
+QSCORE_VEC = [get_p_seq_error(Q) if Q >= 2 else 0.25 for Q in range(100)]
+INCORRECT_MAPPING_VEC = [math.pow(10, ((-1 * Q) * 0.1)) for Q in range(100)]  # haplocart_functions.cpp:101-107 (vector<double>)
 BACKGROUND = {"A": mp.mpf(0.27532), "C": mp.mpf(0.30044), "G": mp.mpf(0.16644), "T": mp.mpf(0.25780)}  # :81-98 (doubles)
 
 
@@ -246,11 +251,11 @@ def get_p_obs_base(pangenome_base, epsilon, generations=8):
     else:
         mu = 2.48537e-8
     mu *= 30  # a double
-    # const double match = pow(1 - mu, generations): evaluated exactly, then rounded to the double the reference holds
-    match = mp.mpf(float(mp.mpf(1 - mu) ** generations))
-    tv = (1 - match) * (22 // 23)
-    ts = (1 - match) * (1 // 46)
-    return match * (1 - epsilon) + epsilon * (2 * tv + ts)  # long double in the reference
+    match = math.pow((1 - mu), generations)  # const double
+    tv = (1 - math.pow((1 - mu), generations)) * (22 // 23)
+    ts = (1 - math.pow((1 - mu), generations)) * (1 // 46)
+    epsilon = float(epsilon)  # the parameter is `const double epsilon`
+    return mp.mpf(match * (1 - epsilon) + (epsilon * (2 * tv + ts)))  # evaluated in double, then stored in a long double (:67)
 
 
 # ------------------------------------------------------------------------------------- update_likelihood.cpp / process_mapping.cpp
@@ -291,21 +296,21 @@ def read_loglik(seqs, hc, aln, background_error_prob, use_background_error_prob,
         pangenome_base = hc["pangenome_map"][key]
         if not (0 <= pangenome_base < len(hc["mappabilities"])):
             raise Undefined("mappabilities[%d] is out of range" % pangenome_base)
-        mappability = mp.mpf(hc["mappabilities"][pangenome_base])
-        p_correctly_mapped = (1 - INCORRECT_MAPPING_VEC[mapq]) * mappability  # :41 (long double)
+        mappability = float(hc["mappabilities"][pangenome_base])  # const double
+        p_correctly_mapped = mp.mpf((1 - INCORRECT_MAPPING_VEC[mapq]) * mappability)  # :41: a product of doubles, kept in a long double
         # get_p_no_seq_error_mapping (get_p_obs_base.cpp:3-27)
         p_no_seq_error = []
         for k in range(len(graph_seq)):
             if k >= len(mapping_seq):
                 raise Undefined("mapping_seq[%d] beyond its end" % k)
             same = graph_seq[k] == mapping_seq[k]
-            if use_bep:
-                p_no_seq_error.append(mp.mpf(background_error_prob) if same else 1 - mp.mpf(background_error_prob))
+            if use_bep:  # (the vector is of long double, the values pushed into it are doubles: `1 - background_error_prob` too)
+                p_no_seq_error.append(float(background_error_prob) if same else 1 - float(background_error_prob))
             else:
                 q = quality_scores[k] if k < len(quality_scores) else None
                 if q is None or not (0 <= q < 100):
                     raise Undefined("qscore_vec[%r] is out of range" % (q,))
-                p_no_seq_error.append(QSCORE_VEC[q] if same else 1 - QSCORE_VEC[q])
+                p_no_seq_error.append(QSCORE_VEC[q] if same else 1 - QSCORE_VEC[q])  # doubles
         # supported paths (:57-80)
         log_lik_if_mapped = mp.mpf(0)
         for j in range(len(graph_seq)):
@@ -318,12 +323,13 @@ def read_loglik(seqs, hc, aln, background_error_prob, use_background_error_prob,
             if not is_consensus_fasta:
                 x = (1 - p_correctly_mapped) * get_background_freq(r) + p_correctly_mapped * p_obs_base
             else:
-                x = (1 - mp.mpf(background_error_prob)) * p_obs_base
+                x = mp.mpf(1 - float(background_error_prob)) * p_obs_base  # (1 - background_error_prob) is a double
             log_lik_if_mapped += mp.log(x) if x > 0 else mp.mpf("-inf")
         # unsupported paths: get_log_lik_if_unsupported (:4-24) -- `counter % 4 == 4` never holds, every entry is a "mismatch"
-        log_lik_if_unsupported = mp.mpf(0)
+        log_lik_if_unsupported = 0.0  # `double ret`, log of a double: all of it in double
         for Q in quality_scores:
-            log_lik_if_unsupported += mp.log(get_p_seq_error(Q))
+            log_lik_if_unsupported += math.log(get_p_seq_error(Q))
+        log_lik_if_unsupported = mp.mpf(log_lik_if_unsupported)
         row = node_id  # nodevector.at(node_id - minid)->pathsgo: path_supports row = node id (load.cpp:283-300)
         if not (0 <= row < len(hc["supports"])):
             raise Undefined("node %d has no path_supports row" % node_id)
@@ -402,20 +408,15 @@ def run(d, background_error_prob=0.0001, use_background_error_prob=False, is_con
 
 # ---------------------------------------------------------------------------------------------------------- fixture writer
 def make(d):
-    """Inputs from the product's synthetic generator (host code, no GPU), then edited through the test-side GAM codec so that the
-    cases the generator does not draw are there too: qualities >= 90 and >= 128, mapping quality 0, a short quality string."""
-    from vgan_amd import haplocart as hc
+    """Inputs built by tools/pyref_inputs.py (plain seeded Python: no product code on this side at all), then edited so that the
+    cases a plain simulator does not draw are there too: qualities >= 90 and >= 128, mapping quality 0, a short quality string.
+    A second fixture beside it (<d>_j2): the reference's own bundled alignments (test/input_files/J2a1a1a1.gam: 81 giraffe
+    alignments, 43.9 mappings per read) on a graph built to cover their node ids."""
+    import pyref_inputs as pi
     os.makedirs(d, exist_ok=True)
-    g = hc.synth_graph(seed=77, genome_len=700, n_nodes=300, n_paths=64)
-    g.write(d)
-    if os.path.exists(os.path.join(d, "path_supports.gz")):  # committed as plain text
-        txt = gzip.open(os.path.join(d, "path_supports.gz"), "rt").read()
-        open(os.path.join(d, "path_supports"), "w").write(txt)
-        os.remove(os.path.join(d, "path_supports.gz"))
-    a = hc.synth_reads(g, 240, seed=78, read_len=120, indel_rate=0.15, softclip_rate=0.1, low_mapq_rate=0.3)
-    tmp = os.path.join(d, "reads.gam")
-    a.write_gam(tmp)
-    alns = gamio.read_gam(tmp)
+    g = pi.variation_graph(seed=77, genome_len=700, n_paths=64)
+    pi.write_hcfiles(d, g, mappability=[(0, 200, 1.0), (200, 260, 0.5), (260, 480, 1.0), (480, 500, 0.25), (500, g["genome_len"] + 2, 1.0)])
+    alns = pi.simulate_reads(78, g, 240, read_len=120, indel_rate=0.15, softclip_rate=0.1, low_mapq_rate=0.3)
     for r, al in enumerate(alns):
         q = bytearray(al["quality"])
         if r % 23 == 5 and len(q) > 40:
@@ -427,12 +428,26 @@ def make(d):
         al["quality"] = bytes(q)
         if r % 17 == 3:
             al["mapping_quality"] = 0
-    open(tmp, "wb").write(gamio.write_gam(alns, group=64))
+    open(os.path.join(d, "reads.gam"), "wb").write(gamio.write_gam(alns, group=64))
     out = {"_what": "tools/pyref_hc.py: an independent Python + mpmath (40 digits) restatement of HaploCart's likelihood path on the "
-                    "inputs beside this file; NOT generated by oracle/ or by the product",
+                    "inputs beside this file (tools/pyref_inputs.py: plain seeded Python); NOT generated by oracle/ or by the product",
            "default": run(d), "background": run(d, background_error_prob=0.02, use_background_error_prob=True)}
     json.dump(out, open(os.path.join(d, "hc_pyref.json"), "w"), indent=0)
     print("wrote", d, "used", out["default"]["n_used"], "undefined", len(out["default"]["undefined_reads"]))
+    # ---- the reference's bundled alignments on a covering graph
+    d2 = d.rstrip("/") + "_j2"
+    os.makedirs(d2, exist_ok=True)
+    src = os.path.join(ROOT, "tests", "golden", "alignments", "J2a1a1a1.gam")
+    real = gamio.read_gam(src)
+    g2 = pi.covering_graph(79, real, n_paths=24)
+    pi.write_hcfiles(d2, g2, mappability=[(0, g2["genome_len"] // 3, 1.0), (g2["genome_len"] // 3, g2["genome_len"] // 2, 0.5),
+                                          (g2["genome_len"] // 2, g2["genome_len"] + 2, 1.0)])
+    open(os.path.join(d2, "reads.gam"), "wb").write(open(src, "rb").read())
+    out2 = {"_what": "tools/pyref_hc.py on the reference's test/input_files/J2a1a1a1.gam (copied beside this file) and a graph covering its "
+                     "node ids (tools/pyref_inputs.py covering_graph)",
+            "default": run(d2), "background": run(d2, background_error_prob=0.02, use_background_error_prob=True)}
+    json.dump(out2, open(os.path.join(d2, "hc_pyref.json"), "w"), indent=0)
+    print("wrote", d2, "used", out2["default"]["n_used"], "undefined", len(out2["default"]["undefined_reads"]))
 
 
 def check_kats():

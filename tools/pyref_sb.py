@@ -41,7 +41,6 @@ import mpmath as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-sys.path.insert(0, ROOT)
 import gamio  # noqa: E402
 from pyref_hc import Undefined, load_gfa, reconstruct_graph_sequence, signed_char, substr  # noqa: E402
 from pyref_euka import DamageModel, qscore, MINLENGTHFRAGMENT, MAXLENGTHFRAGMENT  # noqa: E402
@@ -281,30 +280,22 @@ def run(d, penalty=7):
 
 
 def make(d):
-    """Inputs from the product's synthetic generator (host code, no GPU): a 12-path tree, reads of both strands with indels and
-    soft clips, one over-long path name; the reads the reference leaves undefined are taken out."""
-    from vgan_amd import haplocart as hc
+    """Inputs built by tools/pyref_inputs.py (plain seeded Python, no product code): a 12-path tree, reads of both strands with
+    substitutions, indels and soft clips, one over-long path name; the reads the reference leaves undefined are taken out."""
+    import pyref_inputs as pi
     os.makedirs(d, exist_ok=True)
     gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
     open(os.path.join(d, "damage5p.prof"), "w").write(open(gold + "/dhigh5p.prof").read())
     open(os.path.join(d, "damage3p.prof"), "w").write(open(gold + "/dhigh3p.prof").read())
-    g0 = hc.synth_graph(seed=61, genome_len=900, n_nodes=500, n_paths=12)
-    names = g0.path_names
-    names[7] = "L" * 110  # never "found" among a node's paths
-    g = hc.Graph.from_arrays(g0.min_id, g0.max_id, g0.node_seq_off, g0.node_seq.tobytes(), 12, g0.mask, g0.pangenome_base,
-                             g0.mappability, "\n".join(names) + "\n", g0.parents_txt, g0.children_txt)
-    g.write(d)
-    import gzip
-    for f in ("path_supports",):
-        if os.path.exists(os.path.join(d, f + ".gz")):
-            open(os.path.join(d, f), "w").write(gzip.open(os.path.join(d, f + ".gz"), "rt").read())
-            os.remove(os.path.join(d, f + ".gz"))
-    a = hc.synth_reads(g0, 120, seed=62, read_len=50, indel_rate=0.1, softclip_rate=0.1)
+    g = pi.variation_graph(seed=61, genome_len=900, n_paths=12)
+    real_names = list(g["names"])
+    g["names"][7] = "L" * 110  # never "found" among a node's paths (getLCAfromGAM.h:80-88)
+    pi.write_hcfiles(d, g)
+    alns = pi.simulate_reads(62, g, 120, read_len=50, sub_rate=0.03, indel_rate=0.1, softclip_rate=0.1, reverse_rate=0.5, low_mapq_rate=0.1)
     tmp = os.path.join(d, "reads.gam")
-    a.write_gam(tmp)
-    alns = gamio.read_gam(tmp)
-    idx = {n: i for i, n in enumerate(g0.path_names)}
-    pairs = [(idx[t[0]], idx[t[1]]) for t in (ln.split() for ln in g0.parents_txt.splitlines()) if len(t) >= 2 and 7 not in (idx[t[0]], idx[t[1]])]
+    open(tmp, "wb").write(gamio.write_gam(alns, group=40))
+    pairs = [(q, par) for q, par in enumerate(g["parent"]) if par >= 0 and 7 not in (q, par)]
+    assert len(pairs) >= 7, real_names
     states = [{"sources": [[pairs[0][0], pairs[0][1], 0.03, 0.4, 1.0]], "con": 0.01},
               {"sources": [[pairs[3][0], pairs[3][1], 0.0, 0.5, 1.0]], "con": 0.01},
               {"sources": [[pairs[1][0], pairs[1][1], 0.03, 0.35, 0.5], [pairs[4][0], pairs[4][1], 0.011, 0.8, 0.3],
@@ -317,7 +308,8 @@ def make(d):
         alns = [al for r, al in enumerate(alns) if r not in und]
         open(tmp, "wb").write(gamio.write_gam(alns, group=40))
     out = {"_what": "tools/pyref_sb.py: an independent Python + mpmath (40 digits) restatement of soibean's analyse_GAM tables and "
-                    "state likelihood on the inputs beside this file; NOT generated by oracle/ or by the product",
+                    "state likelihood on the inputs beside this file (tools/pyref_inputs.py: plain seeded Python); NOT generated by "
+                    "oracle/ or by the product",
            "default": run(d)}
     json.dump(out, open(os.path.join(d, "sb_pyref.json"), "w"), indent=0)
     print("wrote", d, "reads", len(out["default"]["reads"]), "undefined", len(out["default"]["undefined_reads"]),

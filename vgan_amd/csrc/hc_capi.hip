@@ -954,8 +954,8 @@ Rccl &rccl() {
 struct CommCache {
     std::mutex mu;
     std::map<std::vector<int>, std::vector<ncclComm_t>> m;
-    double last_setup_ms = 0.0;
-    int n_setups = 0;
+    double last_setup_ms = 0.0, last_reduce_ms = 0.0; // (the reduce's wall time includes a set-up made inside it)
+    int n_setups = 0, last_was_rccl = 0;
 };
 CommCache &comm_cache() {
     static CommCache c;
@@ -990,21 +990,23 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
     bool distinct = n > 1 && !partial;
     for (int i = 0; i < n && distinct; ++i)
         for (int j = 0; j < i; ++j) distinct = distinct && ctxs[i]->device != ctxs[j]->device;
-    // 41 KB per context: ONE reduce is cheapest through the host (a few D2H copies; setting a communicator up costs orders of
-    // magnitude more than it saves).  RCCL over xGMI is for a device set that reduces again and again: it is taken when a
-    // communicator for exactly these devices is already cached, or when VGAN_HC_REDUCE=rccl asks for one -- created once per
-    // device set and kept for the life of the process.
-    if (distinct && rccl().ok) {
+    // Contexts on distinct devices reduce with ncclReduce over xGMI (BASELINE.json's north_star: reads shard across GPUs, one RCCL
+    // reduce of the per-path vector): the communicator is created once per device set and kept for the life of the process
+    // (its set-up time is reported: vgan_hc_reduce_info).  VGAN_HC_REDUCE=host keeps the sum on the host -- for ONE reduce of
+    // 41 KB per context that is the cheaper way, a communicator costs more to set up than it saves --, contexts sharing a
+    // device always take it, and so does a set for which RCCL cannot be loaded or initialised.
+    const auto t_red0 = std::chrono::steady_clock::now();
+    const char *how = getenv("VGAN_HC_REDUCE");
+    if (distinct && rccl().ok && !(how && strcmp(how, "host") == 0)) {
         std::vector<int> devs((size_t)n);
         for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
-        const char *want = getenv("VGAN_HC_REDUCE");
         std::vector<ncclComm_t> *comms = nullptr;
         {
             std::lock_guard<std::mutex> lk(comm_cache().mu);
             auto it = comm_cache().m.find(devs);
             if (it != comm_cache().m.end()) {
                 comms = &it->second;
-            } else if (want && strcmp(want, "rccl") == 0) {
+            } else {
                 std::vector<ncclComm_t> fresh((size_t)n, nullptr);
                 const auto t0 = std::chrono::steady_clock::now();
                 if (rccl().CommInitAll(fresh.data(), n, devs.data()) == ncclSuccess) {
@@ -1029,6 +1031,9 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
             HIPCHK(hipSetDevice(ctxs[0]->device));
             HIPCHK(hipMemcpy(out, ctxs[0]->final_vec.p, (size_t)P * 8, hipMemcpyDeviceToHost));
             if (used_rccl) *used_rccl = 1;
+            std::lock_guard<std::mutex> lk(comm_cache().mu);
+            comm_cache().last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_red0).count();
+            comm_cache().last_was_rccl = 1;
             return VGAN_OK;
         }
     }
@@ -1040,6 +1045,18 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
         HIPCHK(hipStreamSynchronize(ctxs[i]->stream));
         for (uint32_t p = 0; p < P; ++p) out[p] += part[p];
     }
+    {
+        std::lock_guard<std::mutex> lk(comm_cache().mu);
+        comm_cache().last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_red0).count();
+        comm_cache().last_was_rccl = 0;
+    }
+    return VGAN_OK;
+}
+
+extern "C" int vgan_hc_reduce_last(double *reduce_ms, int *was_rccl) {
+    std::lock_guard<std::mutex> lk(comm_cache().mu);
+    if (reduce_ms) *reduce_ms = comm_cache().last_reduce_ms;
+    if (was_rccl) *was_rccl = comm_cache().last_was_rccl;
     return VGAN_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <vector>
 
@@ -370,6 +371,13 @@ struct vgan_hc_devflat {
     DBuf<DfCounters> ctr;
     DBuf<uint8_t> cub_tmp;
     std::vector<uint32_t> h_src;
+    // the parser's arrays reach the device through pinned staging: the pieces are copied into it on several host threads (a
+    // pageable hipMemcpy is ONE thread's memcpy into the runtime's own staging: 12.6 ms per 65 536 reads, the whole stage's
+    // time), then one DMA takes the block
+    uint8_t *pin = nullptr;
+    size_t pin_cap = 0;
+    uint32_t *pin_iota = nullptr; // 0, 1, 2, ...: the sort's values, uploaded once per size class
+    size_t iota_cap = 0, iota_on_dev = 0;
     void release() {
         node_seq_off.release();
         node_seq.release();
@@ -378,6 +386,9 @@ struct vgan_hc_devflat {
         slices.release();
         flag.release();
         for (auto *b : {&key, &key_out, &val, &val_out, &segs, &quals, &cols, &soff, &qoff, &coff, &read_src, &crec}) b->release();
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr;
+        pin_cap = 0;
         info.release();
         rhdr.release();
         srec.release();
@@ -449,18 +460,33 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
     }
     const uint32_t R_all = (uint32_t)n_reads;
     if ((rc = f->stage.reserve(total)) || (rc = f->slices.reserve(np)) || (rc = f->flag.reserve(R_all)) || (rc = f->key.reserve(R_all)) ||
-        (rc = f->key_out.reserve(R_all)) || (rc = f->val.reserve(R_all)) || (rc = f->val_out.reserve(R_all)) || (rc = f->info.reserve(R_all)) ||
+        (rc = f->key_out.reserve(R_all)) || (rc = f->val_out.reserve(R_all)) || (rc = f->info.reserve(R_all)) ||
         (rc = f->segs.reserve(R_all + 1)) || (rc = f->quals.reserve(R_all + 1)) || (rc = f->cols.reserve(R_all + 1)) ||
         (rc = f->soff.reserve(R_all + 1)) || (rc = f->qoff.reserve(R_all + 1)) || (rc = f->coff.reserve(R_all + 1)))
         return rc;
     HIPCHK(hipMemsetAsync(f->ctr.p, 0, sizeof(DfCounters), st));
+    PhaseTimer pt("hc_devflat");
+    const bool pageable = getenv("VGAN_DF_PAGEABLE") != nullptr; // developer aid: the runtime's own staging instead of ours
+    if (!pageable && total > f->pin_cap) {
+        if (f->pin) (void)hipHostFree(f->pin);
+        f->pin = nullptr;
+        f->pin_cap = 0;
+        const size_t want = total + total / 4 + (1u << 20);
+        HIPCHK(hipHostMalloc((void **)&f->pin, want, hipHostMallocDefault));
+        f->pin_cap = want;
+    }
     std::vector<DfSlice> hs(np);
-    uint8_t *cur = f->stage.p;
+    struct Piece {
+        const void *src;
+        size_t off, bytes;
+    };
+    std::vector<Piece> pieces;
+    size_t cur = 0;
     auto put = [&](const void *src, size_t bytes) -> const void * {
-        uint8_t *dst = cur;
+        const size_t off = cur;
         cur += up8(bytes);
-        if (bytes) (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-        return dst;
+        if (bytes) pieces.push_back({src, off, bytes});
+        return f->stage.p + off;
     };
     for (size_t i = 0; i < np; ++i) {
         const vgan_alnset &a = chunk->parts[i];
@@ -482,27 +508,57 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
         s.e_seq = (const uint8_t *)put(a.e_seq.data(), a.e_seq.size());
         s.qual = (const uint8_t *)put(a.qual.data(), a.qual.size());
         s.skip = skip ? (const uint8_t *)put(skip + chunk->first[i], R) : nullptr;
-        if (R) hipLaunchKernelGGL(hc_df_classify_kernel, dim3((uint32_t)((R + 255) / 256)), dim3(256), 0, st, s, f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
     }
+    if (pageable) {
+        for (const Piece &pc : pieces) HIPCHK(hipMemcpyAsync(f->stage.p + pc.off, pc.src, pc.bytes, hipMemcpyHostToDevice, st));
+    } else { // host copies into the pinned block, split into ~1 MB jobs over the host threads, then one DMA
+        struct Job {
+            const uint8_t *src;
+            uint8_t *dst;
+            size_t n;
+        };
+        std::vector<Job> jobs;
+        for (const Piece &pc : pieces)
+            for (size_t o = 0; o < pc.bytes; o += (1u << 20)) jobs.push_back({(const uint8_t *)pc.src + o, f->pin + pc.off + o, std::min<size_t>(1u << 20, pc.bytes - o)});
+        const int nth = (int)std::max<size_t>(1, std::min<size_t>({(size_t)usable_cpus(), (size_t)8, jobs.size() / 4 + 1}));
+        std::atomic<size_t> next{0};
+        parallel_run(nth, [&](int) {
+            for (;;) {
+                const size_t j = next.fetch_add(1);
+                if (j >= jobs.size()) break;
+                memcpy(jobs[j].dst, jobs[j].src, jobs[j].n);
+            }
+        });
+        pt.lap("staging copy");
+        if (cur) HIPCHK(hipMemcpyAsync(f->stage.p, f->pin, cur, hipMemcpyHostToDevice, st));
+    }
+    for (size_t i = 0; i < np; ++i)
+        if (hs[i].n_reads)
+            hipLaunchKernelGGL(hc_df_classify_kernel, dim3((hs[i].n_reads + 255) / 256), dim3(256), 0, st, hs[i], f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(f->slices.p, hs.data(), np * sizeof(DfSlice), hipMemcpyHostToDevice, st));
     // ---- the taken reads in ascending order of their lowest node id, input order kept among equals (the others' key is 2^32 - 1)
     {
-        std::vector<uint32_t> iota(R_all);
-        for (uint32_t i = 0; i < R_all; ++i) iota[i] = i;
-        HIPCHK(hipMemcpyAsync(f->val.p, iota.data(), (size_t)R_all * 4, hipMemcpyHostToDevice, st));
+        if (f->iota_on_dev < R_all) { // 0, 1, 2, ...: on the device once, a prefix of it serves every smaller chunk
+            const size_t want = (size_t)R_all + R_all / 4 + 1024;
+            std::vector<uint32_t> iota(want);
+            for (size_t i = 0; i < want; ++i) iota[i] = (uint32_t)i;
+            if ((rc = f->val.reserve(want))) return rc;
+            HIPCHK(hipMemcpy(f->val.p, iota.data(), want * 4, hipMemcpyHostToDevice));
+            f->iota_on_dev = want;
+        }
         size_t tmp = 0;
         if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, f->key.p, f->key_out.p, f->val.p, f->val_out.p, (int)R_all, 0, 32, st) != hipSuccess)
             return fail(VGAN_ENODEV, "vgan_hc_devflat_run: sort sizing failed");
         if ((rc = f->cub_tmp.reserve(tmp))) return rc;
         if (hipcub::DeviceRadixSort::SortPairs(f->cub_tmp.p, tmp, f->key.p, f->key_out.p, f->val.p, f->val_out.p, (int)R_all, 0, 32, st) != hipSuccess)
             return fail(VGAN_ENODEV, "vgan_hc_devflat_run: sort failed");
-        HIPCHK(hipStreamSynchronize(st)); // (iota is a local)
     }
     DfCounters hc{};
     HIPCHK(hipMemcpyAsync(&hc, f->ctr.p, sizeof hc, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(host_mask, f->flag.p, R_all, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    pt.lap("upload + classify + sort");
     for (uint32_t i = 0; i < R_all; ++i) host_mask[i] = host_mask[i] == DF_HOST ? 1 : 0;
     const uint32_t n_dev = hc.n_dev;
     if (stats) {
@@ -539,6 +595,7 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
     f->h_src.resize(n_dev);
     HIPCHK(hipMemcpyAsync(f->h_src.data(), f->read_src.p, (size_t)n_dev * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st)); // (the staging block is reused by the next call; the caller's arrays may go)
+    pt.lap("offsets + write");
     out->n_reads = n_dev;
     out->n_segments = tot[0];
     out->n_qual = tot[1];

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
     for (int i = tid; i < 202; i += ST_THREADS) {
         const int qi = i >> 1;
         const double e = (qi == 100 || prm.use_bep) ? prm.bep : g.qscore[qi];
-        const double om = (i & 1) ? 1.0 - e : e;
+        const double om = (i & 1) ? 1.0 - e : 1.0 - (1.0 - e); // (a mismatch: 1 - (1 - e) in double, get_p_obs_base.cpp:21,67)
         lom_s[qi][i & 1] = StLom{log_pos(om), 1.0 / om};
     }
     for (int i = tid; i < WIN; i += ST_THREADS) win_s[i] = 0.0;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void hc_segment_tile_kernel(HcGraphD
                     const double rho = kl[u].kappa * bgv[u] * lo[u].iom;
                     if (valid[u] && !(rho < ST_RHO_MAX)) {
                         const double e = (q[u] == 100 || prm.use_bep) ? prm.bep : g.qscore[q[u]];
-                        const double om = match[u] ? 1.0 - e : e;
+                        const double om = match[u] ? 1.0 - e : 1.0 - (1.0 - e);
                         const bool deg = !(kl[u].kappa < 1e300); // wobs = 0: {inf, wbg}
                         // (the table log by hand: log_tab()'s series for values outside the normal range would park its
                         // constants in scratch for the whole kernel)

@@ -242,7 +242,9 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
     for (int i = tid; i < 202; i += WV_THREADS) {
         const int qi = i >> 1;
         const double e = (qi == 100 || a.use_bep) ? a.bep : a.qscore[qi];
-        const double om = (i & 1) ? 1.0 - e : e;
+        // (a mismatch: the reference pushes 1 - e into a vector as a double and get_p_obs_base takes 1 - that: 1 - (1 - e), which is e
+        // only to the double's rounding of 1 - e -- 1e-10 relative at Q = 60; get_p_obs_base.cpp:21,67)
+        const double om = (i & 1) ? 1.0 - e : 1.0 - (1.0 - e);
         lom_s[qi][i & 1] = WvLom{log_pos(om), 1.0 / om};
     }
     if (tid < 4) {

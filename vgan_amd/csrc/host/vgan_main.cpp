@@ -10,6 +10,7 @@
 //     consensus arithmetic);
 //   * the likelihood loop runs on the GPU through the C-ABI (include/vgan_gpu.h); -t only sizes the host front end.
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdint>
 #include <cstdlib>
@@ -227,6 +228,7 @@ int haplocart(int argc, char **argv) {
     } ctxs;
     // the contexts come up on a thread of their own (mask transposition, uploads: ~0.2 s) while this one already flattens
     // the first chunk of reads, which needs the graph only
+    std::atomic<bool> contexts_up{false}; // (the lanes flatten on the host until the device can: see the chunk loop)
     struct Creator {
         std::thread t;
         std::string err;
@@ -252,6 +254,7 @@ int haplocart(int argc, char **argv) {
             ctxs.v.push_back(c);
         }
         stamp("device contexts ready");
+        contexts_up.store(true);
     });
     std::once_flag creator_joined;
     auto contexts_ready_quiet = [&] { // from any thread
@@ -280,27 +283,47 @@ int haplocart(int argc, char **argv) {
     if (rmdup) check(vgan_dedup_create(&dedup.d), "duplicate removal");
     int64_t n_in = 0, n_dup = 0;
     vgan_hc_flatten_stats tot{};
-    // flattened chunks -> device, in order, on a thread of its own.  The device contexts are ready 0.3-0.45 s after the start
-    // (the HIP runtime comes up beside a hundred busy threads); until then the flattened chunks wait here -- up to `depth`
-    // of them (~85 MB each), after which the loop, and behind it the decoder, wait too.
+    // decoded chunks -> device, in order, on a thread of its own.  The front half of the hot path -- reconstruct_graph_sequence,
+    // the slicing into mappings, the segment kernel's layout -- runs ON THE DEVICE for every read whose edits are matches or
+    // substitutions (vgan_hc_devflat: the parser's arrays go up as they are); only the reads it flags (indels, soft clips,
+    // reads beyond the tile contract, reads the reference would terminate on) pass through the host flatten.
+    // VGAN_HC_HOST_FLATTEN=1: every read through the host flatten (the lanes then flatten, as before).
+    // The device contexts are ready 0.3-0.45 s after the start (the HIP runtime comes up beside a hundred busy threads); until
+    // then the chunks wait here -- up to `depth` of them, after which the loop, and behind it the decoder, wait too.
+    const bool host_flatten = getenv("VGAN_HC_HOST_FLATTEN") != nullptr;
+    int64_t device_after = 32; // chunks (2M reads) flattened on the host before the device takes over
+    if (const char *e = getenv("VGAN_HC_DEVICE_AFTER")) device_after = std::max<int64_t>(0, atoll(e)); // developer aid / tests
+    struct Item {
+        vgan_alnparts *chunk = nullptr;   // device flatten: the decoded chunk itself
+        std::vector<uint8_t> dup;         // ... and its duplicate marks (empty: none)
+        vgan_hc_host_batch *hb = nullptr; // host flatten: the flattened chunk
+    };
     struct Uploader {
         std::mutex mu;
         std::condition_variable cv;
-        std::deque<vgan_hc_host_batch *> q;
+        std::deque<Item> q;
         size_t depth = 16;
         bool closed = false;
         std::string err;
         std::thread t;
         int64_t next = 0; // batches enter in input order, whichever lane made them
-        void push(int64_t seq, vgan_hc_host_batch *hb) {
+        static void drop(Item &it) {
+            if (it.chunk) vgan_alnparts_free(it.chunk);
+            if (it.hb) vgan_hc_host_batch_free(it.hb);
+            it.chunk = nullptr;
+            it.hb = nullptr;
+        }
+        void push(int64_t seq, Item &&it) {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return (seq == next && q.size() < depth) || !err.empty(); });
+            // (a decoded chunk holds ~2.7 KB of parser arrays per read, a flattened one 1.25 KB: fewer of the former may wait)
+            const size_t room = it.chunk ? std::max<size_t>(2, depth / 4) : depth;
+            cv.wait(lk, [&] { return (seq == next && q.size() < room) || !err.empty(); });
             if (!err.empty()) {
                 lk.unlock();
-                vgan_hc_host_batch_free(hb);
+                drop(it);
                 return;
             }
-            q.push_back(hb);
+            q.push_back(std::move(it));
             ++next;
             cv.notify_all();
         }
@@ -323,48 +346,100 @@ int haplocart(int argc, char **argv) {
         }
         ~Uploader() {
             close();
-            for (auto hb : q) vgan_hc_host_batch_free(hb);
+            for (auto &it : q) drop(it);
         }
     } uploader;
     if (const char *e = getenv("VGAN_HC_QUEUE")) uploader.depth = (size_t)std::max(1, atoi(e)); // developer aid
+    std::mutex stat_mu;
+    struct DevFlats {
+        std::vector<vgan_hc_devflat *> v;
+        ~DevFlats() {
+            for (auto f : v) vgan_hc_devflat_free(f);
+        }
+    } devflats;
+    double t_devflat = 0, t_hostflat_rest = 0;
+    int64_t n_host_reads = 0;
+    auto since_ms = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    // one chunk on the device: packed part + the other reads of a host batch
+    auto hand_over = [&](vgan_hc_ctx *cx, vgan_hc_host_batch *hb) -> std::string {
+        vgan_hc_batch b;        // the reads outside the tile contract (long reads, ...): the general kernel
+        vgan_hc_packed_view pk; // everything else, in the segment kernel's own layout as the flatten step wrote it
+        if (vgan_hc_host_batch_get(hb, &b) < 0 || vgan_hc_host_batch_get_packed(hb, &pk) < 0) return std::string("[vgan] batch: ") + vgan_last_error();
+        if (vgan_hc_accumulate_packed(cx, &pk) < 0 || (b.n_reads && vgan_hc_accumulate(cx, &b) < 0)) return std::string("[vgan] accumulate: ") + vgan_last_error();
+        return std::string();
+    };
     uploader.t = std::thread([&] {
+        std::vector<uint8_t> mask, skip2;
         for (;;) {
-            vgan_hc_host_batch *hb = nullptr;
+            Item it;
             {
                 std::unique_lock<std::mutex> lk(uploader.mu);
                 uploader.cv.wait(lk, [&] { return !uploader.q.empty() || uploader.closed; });
                 if (uploader.q.empty()) return;
-                hb = uploader.q.front();
+                it = std::move(uploader.q.front());
+                uploader.q.front() = Item();
             }
             std::string err;
-            vgan_hc_batch b;              // the reads outside the tile contract (long reads, ...): the general kernel
-            vgan_hc_packed_view pk;       // everything else, in the segment kernel's own layout as the flatten step wrote it
-            if (vgan_hc_host_batch_get(hb, &b) < 0 || vgan_hc_host_batch_get_packed(hb, &pk) < 0) err = std::string("[vgan] batch: ") + vgan_last_error();
-            if (err.empty()) {
-                contexts_ready_quiet();
-                vgan_hc_ctx *cx = creator.err.empty() ? ctxs.v[n_chunks++ % ctxs.v.size()] : nullptr;
-                if (!cx) err = creator.err;
-                else if (vgan_hc_accumulate_packed(cx, &pk) < 0 || (b.n_reads && vgan_hc_accumulate(cx, &b) < 0))
-                    err = std::string("[vgan] accumulate: ") + vgan_last_error();
-                if (n_chunks <= 3) stamp("chunk handed to the device");
+            contexts_ready_quiet();
+            const size_t which = n_chunks++ % std::max<size_t>(1, ctxs.v.size());
+            vgan_hc_ctx *cx = creator.err.empty() && !ctxs.v.empty() ? ctxs.v[which] : nullptr;
+            if (!cx) {
+                err = creator.err.empty() ? "[vgan] no device context" : creator.err;
+            } else if (it.hb) {
+                err = hand_over(cx, it.hb);
+            } else {
+                if (devflats.v.size() < ctxs.v.size()) devflats.v.resize(ctxs.v.size(), nullptr);
+                if (!devflats.v[which] && vgan_hc_devflat_create(cx, graph, &devflats.v[which]) < 0) err = std::string("[vgan] device flatten: ") + vgan_last_error();
+                const int64_t nr = vgan_alnparts_n_reads(it.chunk);
+                mask.assign((size_t)std::max<int64_t>(1, nr), 0);
+                vgan_hc_packed_view pk;
+                vgan_hc_flatten_stats st{};
+                auto t0 = std::chrono::steady_clock::now();
+                if (err.empty() && vgan_hc_devflat_run(devflats.v[which], it.chunk, it.dup.empty() ? nullptr : it.dup.data(), &pk, mask.data(), &st) < 0)
+                    err = std::string("[vgan] device flatten: ") + vgan_last_error();
+                if (err.empty() && vgan_hc_accumulate_packed(cx, &pk) < 0) err = std::string("[vgan] accumulate: ") + vgan_last_error();
+                const double td = since_ms(t0);
+                int64_t n_host = 0;
+                for (int64_t r = 0; r < nr; ++r) n_host += mask[(size_t)r];
+                vgan_hc_flatten_stats sh{};
+                double th = 0;
+                if (err.empty() && n_host) { // the reads the device left: the host's general walk, then both of its parts
+                    t0 = std::chrono::steady_clock::now();
+                    skip2.resize((size_t)nr);
+                    for (int64_t r = 0; r < nr; ++r) skip2[(size_t)r] = mask[(size_t)r] ? 0 : 1; // (a skipped read is not flagged)
+                    vgan_hc_host_batch *hb = nullptr;
+                    if (vgan_hc_flatten_parts_packed(graph, it.chunk, 0, vgan_alnparts_count(it.chunk), skip2.data(), 0, &hb, &sh) < 0)
+                        err = std::string("[vgan] flattening: ") + vgan_last_error();
+                    else err = hand_over(cx, hb);
+                    if (hb) vgan_hc_host_batch_free(hb);
+                    th = since_ms(t0);
+                }
+                std::lock_guard<std::mutex> lk(stat_mu);
+                tot.n_bad += sh.n_bad;
+                tot.n_unmapped += st.n_unmapped;
+                tot.n_out += st.n_out + sh.n_out;
+                t_devflat += td;
+                t_hostflat_rest += th;
+                n_host_reads += n_host;
             }
-            vgan_hc_host_batch_free(hb);
+            if (n_chunks <= 3) stamp("chunk handed to the device");
+            Uploader::drop(it);
             std::lock_guard<std::mutex> lk(uploader.mu);
             uploader.q.pop_front();
             if (!err.empty() && uploader.err.empty()) uploader.err = err;
             uploader.cv.notify_all();
         }
     });
-    // The loop: next chunk of decoded reads -> duplicate marks -> flatten -> device queue.  Taking a chunk and marking its
-    // duplicates is serial (input order); the flattening of several chunks runs side by side on `lanes` threads (each call
-    // spreads over its own share of the host threads), and the queue takes the batches back in input order.
+    // The loop: next chunk of decoded reads -> duplicate marks -> (host flatten ->) device queue.  Taking a chunk and marking
+    // its duplicates is serial (input order); with the host flatten the flattening of several chunks runs side by side on `lanes`
+    // threads (each call spreads over its own share of the host threads), and the queue takes the batches back in input order.
     double t_wait_decode = 0, t_flatten = 0, t_wait_device = 0, t_free = 0; // VGAN_TIMING: where the lanes' time went
-    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    auto since = since_ms;
     const int want_threads = n_threads > 0 ? n_threads : (int)vgan_host_cpus();
     int lanes = std::max(1, std::min(4, want_threads / 64)); // one lane unless the machine is large and all ours
     if (const char *e = getenv("VGAN_HC_LANES")) lanes = std::max(1, std::min(16, atoi(e))); // developer aid
     const int lane_threads = std::max(1, std::min(40, want_threads / lanes));
-    std::mutex take_mu, stat_mu;
+    std::mutex take_mu;
     int64_t next_seq = 0;
     bool at_end = false;
     std::string lane_err;
@@ -390,6 +465,7 @@ int haplocart(int argc, char **argv) {
                     seq = next_seq++;
                     const int64_t nr = vgan_alnparts_n_reads(chunk);
                     n_in += nr;
+                    dup.clear();
                     if (dedup.d) {
                         dup.resize((size_t)nr);
                         int64_t nd = 0;
@@ -401,19 +477,28 @@ int haplocart(int argc, char **argv) {
                         skip = dup.data();
                     }
                 }
-                vgan_hc_host_batch *hb = nullptr;
+                Item it;
+                double fl = 0, fr = 0;
                 vgan_hc_flatten_stats st{};
+                // Until the device contexts are up (the HIP runtime takes ~0.3 s to come up) the chunks are flattened here, on the
+                // host's threads, as they come: a short input is done by then, a long one switches to the device flatten
+                // (the device route costs a few tenths of a second once -- pinned staging, device buffers, their release when the
+                // process ends -- and so starts behind the first `device_after` chunks: a 1M-read input never gets there)
+                if (host_flatten || !contexts_up.load() || seq < device_after) {
+                    t0 = std::chrono::steady_clock::now();
+                    const int rc = vgan_hc_flatten_parts_packed(graph, chunk, 0, vgan_alnparts_count(chunk), skip, lane_threads, &it.hb, &st);
+                    fl = since(t0);
+                    t0 = std::chrono::steady_clock::now();
+                    vgan_alnparts_free(chunk);
+                    fr = since(t0);
+                    check(rc, "flattening");
+                } else {
+                    it.chunk = chunk; // (freed by the uploader once the device has taken it)
+                    it.dup = dup;
+                }
+                // the copy out of (pageable) host memory completes inside the uploader's calls; the kernels run asynchronously
                 t0 = std::chrono::steady_clock::now();
-                const int rc = vgan_hc_flatten_parts_packed(graph, chunk, 0, vgan_alnparts_count(chunk), skip, lane_threads, &hb, &st);
-                const double fl = since(t0);
-                t0 = std::chrono::steady_clock::now();
-                vgan_alnparts_free(chunk);
-                const double fr = since(t0);
-                check(rc, "flattening");
-                // the copy out of a (pageable) host batch completes inside vgan_hc_accumulate: the uploader thread makes that
-                // call while the lanes go on; the kernels run asynchronously behind both
-                t0 = std::chrono::steady_clock::now();
-                uploader.push(seq, hb);
+                uploader.push(seq, std::move(it));
                 const double wd = since(t0);
                 std::lock_guard<std::mutex> lk(stat_mu);
                 t_wait_decode += waited;
@@ -442,8 +527,8 @@ int haplocart(int argc, char **argv) {
     if (!lane_err.empty()) die(lane_err);
     stamp("last chunk flattened");
     if (getenv("VGAN_TIMING"))
-        fprintf(stderr, "[vgan timing] haplocart loop (%d lanes x %d threads, summed over the lanes): waiting for decoded reads %.0f ms, flattening %.0f ms, freeing chunks %.0f ms, waiting for the device queue %.0f ms\n",
-                lanes, lane_threads, t_wait_decode, t_flatten, t_free, t_wait_device);
+        fprintf(stderr, "[vgan timing] haplocart loop (%d lanes x %d threads, summed over the lanes): waiting for decoded reads %.0f ms, flattening %.0f ms, freeing chunks %.0f ms, waiting for the device queue %.0f ms; device flatten + hand-over %.0f ms, host flatten of the %lld reads it left %.0f ms\n",
+                lanes, lane_threads, t_wait_decode, t_flatten, t_free, t_wait_device, t_devflat, (long long)n_host_reads, t_hostflat_rest);
     uploader.close();
     if (!uploader.err.empty()) die(uploader.err);
     stamp("last chunk on the device");
@@ -469,10 +554,12 @@ int haplocart(int argc, char **argv) {
         check(vgan_hc_reduce(ctxs.v.data(), (int)ctxs.v.size(), final_vec.data(), &used_rccl), "reduce");
         if (!quiet) {
             std::cerr << "Reduced the log-likelihoods of " << ctxs.v.size() << " device contexts (" << (used_rccl ? "RCCL" : "host") << ")." << '\n';
-            double setup_ms = 0;
+            double setup_ms = 0, reduce_ms = 0;
             int n_setups = 0;
+            (void)vgan_hc_reduce_last(&reduce_ms, nullptr);
             if (used_rccl && vgan_hc_reduce_info(&setup_ms, &n_setups) == 0 && n_setups)
-                std::cerr << "RCCL communicator over " << ctxs.v.size() << " devices set up in " << setup_ms << " ms." << '\n';
+                std::cerr << "RCCL communicator over " << ctxs.v.size() << " devices set up in " << setup_ms << " ms; the reduce took " << reduce_ms
+                          << " ms in all (VGAN_HC_REDUCE=host sums on the host instead)." << '\n';
         }
     }
     pt.lap("flatten + kernels");

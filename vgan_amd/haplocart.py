@@ -630,8 +630,8 @@ def reduce_info():
 
 
 def reduce_contexts(ctxs):
-    """Sum of the contexts' final_vec through vgan_hc_reduce (through the host; RCCL between distinct GPUs once a
-    communicator for them is cached or VGAN_HC_REDUCE=rccl asks for one).  Returns (final_vec, used_rccl)."""
+    """Sum of the contexts' final_vec through vgan_hc_reduce (RCCL between distinct GPUs, through the host for contexts sharing
+    a device or with VGAN_HC_REDUCE=host).  Returns (final_vec, used_rccl)."""
     arr = (N.vp * len(ctxs))(*[c._h for c in ctxs])
     out = np.zeros(ctxs[0].n_paths)
     used = C.c_int(0)
