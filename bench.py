@@ -544,9 +544,9 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
         t0 = time.perf_counter()
         b = hc.AlnSet.read_gam(p)
         t_dec = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     hb = hc.HostBatch(graph, b, packed=True)
-    t_fl = time.perf_counter() - t0
+    t_fl, cpu_fl = time.perf_counter() - t0, time.process_time() - c0
     # a1 on the device (vgan_hc_devflat): the parser's arrays go up as they are (PCIe inside the figure), reconstruct + slicing +
     # layout run as kernels; what `vgan haplocart` does for every chunk of a long input once the device contexts are up
     dev = None
@@ -557,14 +557,17 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
             parts = hc.AlnParts.read_gam(p)
         df = hc.DeviceFlatten(ctx, graph)
         df.run(parts)  # (buffers, pinned staging)
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         res = df.run(parts)
-        t_df = time.perf_counter() - t0
-        dev = {"reads_per_s": parts.n_reads / t_df, "reads_taken": int(res.pk.n_reads), "reads_left_to_the_host": int(res.host_mask.sum())}
+        t_df, cpu_df = time.perf_counter() - t0, time.process_time() - c0
+        # (wall: PCIe transfer of the parser's arrays included; host_cpu_us_per_read: what the stage costs the host's processors --
+        # on a CPU quota that, not the wall time of one stage, is what a long input's throughput follows)
+        dev = {"reads_per_s": parts.n_reads / t_df, "host_cpu_us_per_read": cpu_df / parts.n_reads * 1e6, "reads_taken": int(res.pk.n_reads),
+               "reads_left_to_the_host": int(res.host_mask.sum())}
         df.close()
     from vgan_amd import _native as N
     return {"sample_reads": n, "gam_bytes": size, "decode_reads_per_s": n / t_dec, "flatten_reads_per_s": hb.n_reads / t_fl,
-            "device_flatten": dev,
+            "flatten_host_cpu_us_per_read": cpu_fl / max(hb.n_reads, 1) * 1e6, "device_flatten": dev,
             "threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1),
             # what the container may keep busy (affinity mask and cgroup CPU quota): a sample this size is a burst on the
             # quota's slack; a long input runs at ~7 us of CPU per read on this many processors

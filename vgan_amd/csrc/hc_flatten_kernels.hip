@@ -37,12 +37,16 @@ namespace df {
 constexpr uint32_t DF_COLS = HC_TILE_MAX_READ_COLS, DF_QUAL = HC_TILE_MAX_READ_QUAL, DF_SEGS = HC_TILE_MAX_READ_SEGS;
 enum : uint8_t { DF_DEVICE = 0, DF_HOST = 1, DF_SKIP = 2, DF_UNMAPPED = 3 };
 
-struct DfSlice { // one parser slice's arrays on the device
-    const int64_t *map_off, *qual_off, *edit_off, *e_seq_off, *m_node, *m_offset;
-    const int32_t *mapq, *e_from, *e_to;
-    const double *identity;
-    const uint8_t *m_rev, *e_seq, *qual, *skip; // skip: NULL or per read of the slice
-    uint32_t n_reads, read0;                    // read0: the slice's first read within the chunk
+// One parser slice's arrays on the device, narrowed on their way into the staging block (the parser keeps 64-bit offsets and ids:
+// 2.7 KB per read; what the kernels need of them is 1.4 KB): offsets within the slice and node ids as 32 bits (an id that does
+// not fit is no node of the graph: 0xFFFFFFFF), the mapping's offset as int32 (INT32_MIN: does not fit -- the host's read), an
+// edit as its length when it is a match or a substitution (from_length == to_length >= 0) and -1 otherwise, the identity as
+// the one bit HaploCart.cpp:410 asks of it.
+struct DfSlice {
+    const uint32_t *map_off, *qual_off, *edit_off, *e_seq_off, *m_node;
+    const int32_t *m_offset, *mapq, *e_len;
+    const uint8_t *unmapped, *m_rev, *e_seq, *qual, *skip; // skip: NULL or per read of the slice
+    uint32_t n_reads, read0;                               // read0: the slice's first read within the chunk
 };
 struct DfGraph {
     const int64_t *node_seq_off;
@@ -69,85 +73,131 @@ __device__ __forceinline__ uint8_t df_comp(uint8_t c) { // csrc/host/flatten.cpp
     }
 }
 
-// A thread per read of the slice.  Mirrors reconstruct_matches_only() + the route of flatten_range() (csrc/host/flatten.cpp):
-// anything the one-walk form does not cover is the host's.
+// A wave per read of the slice, lanes over its mappings.  Mirrors reconstruct_matches_only() + the route of flatten_range()
+// (csrc/host/flatten.cpp): anything the one-walk form does not cover is the host's.  (A thread per read walked its ~60 mappings
+// one dependent load after the other: 5 ms per 65 536 reads, half of the whole stage.)
 __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph g, uint8_t *__restrict__ flag, uint32_t *__restrict__ key,
                                                              uint4 *__restrict__ info, DfCounters *__restrict__ ctr) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (r >= s.n_reads) return;
     const uint32_t gr = s.read0 + r;
     uint8_t f = DF_HOST;
     uint32_t A = 0, G = 0, kmin = 0xFFFFFFFFu, nm = 0, nq = 0;
     if (s.skip && s.skip[r]) {
         f = DF_SKIP;
-    } else if (s.identity[r] < 1e-10) { // HaploCart.cpp:410
+    } else if (s.unmapped[r]) { // identity < 1e-10, HaploCart.cpp:410
         f = DF_UNMAPPED;
     } else {
         const int64_t m0 = s.map_off[r], m1 = s.map_off[r + 1];
         const int64_t e0 = m1 > m0 ? s.edit_off[m0] : 0, e1 = m1 > m0 ? s.edit_off[m1] : 0;
-        const int64_t q_len = s.qual_off[r + 1] - s.qual_off[r];
+        const int64_t q_len = (int64_t)s.qual_off[r + 1] - (int64_t)s.qual_off[r];
         bool ok = m1 > m0 && m1 - m0 <= (int64_t)DF_SEGS && q_len <= (int64_t)DF_QUAL && e1 - e0 >= m1 - m0;
         nm = (uint32_t)(m1 - m0);
         nq = (uint32_t)q_len;
-        int64_t a_len = 0, g_len = 0, pos = 0; // pos: where the next segment starts (saturating at A, which equals G here)
-        bool empty_seg = false;
-        for (int64_t m = m0; ok && m < m1; ++m) {
-            const int64_t id = s.m_node[m];
-            if (id < g.min_id || id > g.max_id) {
-                ok = false;
-                break;
-            }
-            const int32_t pb = g.pangenome_base[id];
-            if (pb < 0 || (uint64_t)pb >= g.n_mapp) {
-                ok = false;
-                break;
-            }
-            kmin = min(kmin, (uint32_t)id);
-            const int64_t len = g.node_seq_off[id + 1] - g.node_seq_off[id];
-            int64_t off = s.m_offset[m];
-            if (off != (int64_t)(int32_t)off) {
-                ok = false;
-                break;
-            }
-            for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
-                const int64_t from = s.e_from[e];
-                if (from != (int64_t)s.e_to[e] || from < 0 || off > len || off < 0) {
-                    ok = false;
-                    break;
-                }
-                const int64_t sl = s.e_seq_off[e + 1] - s.e_seq_off[e];
-                const int64_t n = min(from, len - off);
-                g_len += n;
-                a_len += sl > 0 ? sl : n;
-                off += from;
-            }
-        }
-        ok = ok && a_len == g_len && a_len <= (int64_t)DF_COLS && a_len > 0;
-        if (ok) {
-            // segment i = mapping i with the size of the read's i-th EDIT: start = min(A, sum of the sizes before), length
-            // min(size, A - start); a segment without a column sends the read to the general kernel (the host's business)
-            int64_t idx = 0;
-            for (int64_t m = m0; m < m1 && idx < m1 - m0; ++m) {
+        uint32_t a_len = 0, g_len = 0;
+        if (ok) { // ---- pass 1: every mapping on known ground, the read's lengths
+            bool bad = false;
+            uint32_t gn = 0, an = 0;
+            for (uint32_t mi = lane; mi < nm; mi += 64u) {
+                const int64_t m = m0 + mi;
                 const int64_t id = s.m_node[m];
+                if (id < g.min_id || id > g.max_id) {
+                    bad = true;
+                    continue;
+                }
+                const int32_t pb = g.pangenome_base[id];
+                if (pb < 0 || (uint64_t)pb >= g.n_mapp) {
+                    bad = true;
+                    continue;
+                }
+                kmin = min(kmin, (uint32_t)id);
                 const int64_t len = g.node_seq_off[id + 1] - g.node_seq_off[id];
                 int64_t off = s.m_offset[m];
-                for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1] && idx < m1 - m0; ++e, ++idx) {
-                    const int64_t from = s.e_from[e];
+                if (off == (int64_t)INT32_MIN) { // (the offset did not fit 32 bits: the two walks of the general form disagree on such a read)
+                    bad = true;
+                    continue;
+                }
+                for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
+                    const int64_t from = s.e_len[e];
+                    if (from < 0 || off > len || off < 0) { // (an edit that is not a match or a substitution: -1)
+                        bad = true;
+                        break;
+                    }
+                    const int64_t sl = (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
                     const int64_t n = min(from, len - off);
-                    const int64_t sl = min(n, a_len - pos);
-                    empty_seg = empty_seg || sl <= 0;
-                    pos += min(n, a_len - pos);
+                    gn += (uint32_t)n;
+                    an += (uint32_t)(sl > 0 ? sl : n);
                     off += from;
                 }
             }
-            ok = !empty_seg;
+            ok = __builtin_amdgcn_ballot_w64(bad) == 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                gn += __shfl_xor(gn, o, 64);
+                an += __shfl_xor(an, o, 64);
+                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+            }
+            g_len = gn;
+            a_len = an;
+            ok = ok && a_len == g_len && a_len <= DF_COLS && a_len > 0;
+        }
+        if (ok) {
+            // ---- pass 2: segment i = mapping i with the size of the read's i-th EDIT: start = min(A, sum of the sizes before), length
+            // min(size, A - start); a segment without a column sends the read to the general kernel (the host's business)
+            bool empty_seg = false;
+            uint32_t g_base = 0, e_base = 0;
+            for (uint32_t mb = 0; mb < nm && e_base < nm; mb += 64u) {
+                const uint32_t mi = mb + lane;
+                const bool on = mi < nm;
+                uint32_t gn = 0, ne = 0;
+                int64_t len = 0, off0 = 0;
+                if (on) {
+                    const int64_t m = m0 + mi, id = s.m_node[m];
+                    len = g.node_seq_off[id + 1] - g.node_seq_off[id];
+                    off0 = s.m_offset[m];
+                    int64_t off = off0;
+                    for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
+                        const int64_t from = s.e_len[e];
+                        gn += (uint32_t)min(from, len - off);
+                        off += from;
+                        ++ne;
+                    }
+                }
+                uint32_t gp = gn, ep = ne;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t x = __shfl_up(gp, d, 64), z = __shfl_up(ep, d, 64);
+                    if ((int)lane >= d) {
+                        gp += x;
+                        ep += z;
+                    }
+                }
+                const uint32_t g_tot = __shfl(gp, 63, 64), e_tot = __shfl(ep, 63, 64);
+                if (on) {
+                    uint32_t before = g_base + gp - gn, eq = e_base + ep - ne; // sizes of the edits before this mapping's first; its index
+                    int64_t off = off0;
+                    for (int64_t e = s.edit_off[m0 + mi]; e < s.edit_off[m0 + mi + 1] && eq < nm; ++e, ++eq) {
+                        const int64_t from = s.e_len[e];
+                        const uint32_t n = (uint32_t)min(from, len - off);
+                        const uint32_t start = min(a_len, before);
+                        empty_seg = empty_seg || min(n, a_len - start) == 0;
+                        before += n;
+                        off += from;
+                    }
+                }
+                g_base += g_tot;
+                e_base += e_tot;
+            }
+            ok = __builtin_amdgcn_ballot_w64(empty_seg) == 0;
         }
         if (ok) {
             f = DF_DEVICE;
-            A = (uint32_t)a_len;
-            G = (uint32_t)g_len;
+            A = a_len;
+            G = g_len;
         }
     }
+    if (lane != 0) return;
     flag[gr] = f;
     key[gr] = f == DF_DEVICE ? kmin : 0xFFFFFFFFu;
     info[gr] = uint4{G, nm, nq, A};
@@ -235,7 +285,7 @@ __global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restr
                 rev = s.m_rev[m] != 0;
                 int64_t off = off0;
                 for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
-                    const int64_t from = s.e_from[e], sl = s.e_seq_off[e + 1] - s.e_seq_off[e];
+                    const int64_t from = s.e_len[e], sl = (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
                     const uint32_t n = (uint32_t)min(from, len - off);
                     gn += n;
                     an += sl > 0 ? (uint32_t)sl : n;
@@ -260,7 +310,7 @@ __global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restr
                 const uint8_t *ns = g.node_seq + g.node_seq_off[id];
                 int64_t off = off0;
                 for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e, ++eq) {
-                    const int64_t from = s.e_from[e], sl = s.e_seq_off[e + 1] - s.e_seq_off[e];
+                    const int64_t from = s.e_len[e], sl = (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
                     const uint32_t n = (uint32_t)min(from, len - off);
                     for (uint32_t k = 0; k < n && gq + k < A; ++k) {
                         const uint8_t b = rev ? df_comp(ns[len - 1 - (off + k)]) : ns[off + k];
@@ -450,13 +500,15 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
     HIPCHK(hipSetDevice(f->device));
     hipStream_t st = f->stream;
     int rc;
-    // ---- the slices' arrays, one after the other in one staging block (8-byte aligned pieces)
+    // ---- the slices' arrays, narrowed (DfSlice), one after the other in one staging block (8-byte aligned pieces)
     auto up8 = [](size_t n) { return (n + 7) & ~(size_t)7; };
     size_t total = 0;
     for (const vgan_alnset &a : chunk->parts) {
         const size_t R = (size_t)a.n_reads(), M = a.m_node.size(), E = a.e_from.size();
-        total += up8((R + 1) * 8) * 2 + up8((M + 1) * 8) + up8((E + 1) * 8) + up8(M * 8) * 2 + up8(R * 4) + up8(E * 4) * 2 + up8(R * 8) +
-                 up8(M) + up8(a.e_seq.size()) + up8(a.qual.size()) + up8(R);
+        total += up8((R + 1) * 4) * 2 + up8((M + 1) * 4) + up8((E + 1) * 4) + up8(M * 4) * 2 + up8(R * 4) + up8(E * 4) + up8(R) + up8(M) +
+                 up8(a.e_seq.size()) + up8(a.qual.size()) + up8(R);
+        if (a.seq_off.size() && (a.qual.size() > 0xFFFFFFF0ull || a.e_seq.size() > 0xFFFFFFF0ull || M > 0xFFFFFFF0ull || E > 0xFFFFFFF0ull))
+            return fail(VGAN_ERANGE, "vgan_hc_devflat_run: a parser slice beyond 32-bit offsets");
     }
     const uint32_t R_all = (uint32_t)n_reads;
     if ((rc = f->stage.reserve(total)) || (rc = f->slices.reserve(np)) || (rc = f->flag.reserve(R_all)) || (rc = f->key.reserve(R_all)) ||
@@ -466,8 +518,7 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
         return rc;
     HIPCHK(hipMemsetAsync(f->ctr.p, 0, sizeof(DfCounters), st));
     PhaseTimer pt("hc_devflat");
-    const bool pageable = getenv("VGAN_DF_PAGEABLE") != nullptr; // developer aid: the runtime's own staging instead of ours
-    if (!pageable && total > f->pin_cap) {
+    if (total > f->pin_cap) {
         if (f->pin) (void)hipHostFree(f->pin);
         f->pin = nullptr;
         f->pin_cap = 0;
@@ -476,16 +527,19 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
         f->pin_cap = want;
     }
     std::vector<DfSlice> hs(np);
+    // what a piece is made of: bytes as they are, or a narrowing of the parser's wider array
+    enum Kind { K_BYTES, K_OFF64, K_NODE64, K_MOFF64, K_EDIT, K_UNMAPPED };
     struct Piece {
-        const void *src;
-        size_t off, bytes;
+        Kind kind;
+        const void *src, *src2;
+        size_t off, n; // destination offset in the block; elements (bytes for K_BYTES)
     };
     std::vector<Piece> pieces;
     size_t cur = 0;
-    auto put = [&](const void *src, size_t bytes) -> const void * {
+    auto put = [&](Kind k, const void *src, const void *src2, size_t n, size_t elem) -> const void * {
         const size_t off = cur;
-        cur += up8(bytes);
-        if (bytes) pieces.push_back({src, off, bytes});
+        cur += up8(n * elem);
+        if (n) pieces.push_back({k, src, src2, off, n});
         return f->stage.p + off;
     };
     for (size_t i = 0; i < np; ++i) {
@@ -494,47 +548,78 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
         DfSlice &s = hs[i];
         s.n_reads = (uint32_t)R;
         s.read0 = (uint32_t)chunk->first[i];
-        s.map_off = (const int64_t *)put(a.map_off.data(), (R + 1) * 8);
-        s.qual_off = (const int64_t *)put(a.qual_off.data(), (R + 1) * 8);
-        s.edit_off = (const int64_t *)put(a.edit_off.data(), (M + 1) * 8);
-        s.e_seq_off = (const int64_t *)put(a.e_seq_off.data(), (E + 1) * 8);
-        s.m_node = (const int64_t *)put(a.m_node.data(), M * 8);
-        s.m_offset = (const int64_t *)put(a.m_offset.data(), M * 8);
-        s.mapq = (const int32_t *)put(a.mapq.data(), R * 4);
-        s.e_from = (const int32_t *)put(a.e_from.data(), E * 4);
-        s.e_to = (const int32_t *)put(a.e_to.data(), E * 4);
-        s.identity = (const double *)put(a.identity.data(), R * 8);
-        s.m_rev = (const uint8_t *)put(a.m_rev.data(), M);
-        s.e_seq = (const uint8_t *)put(a.e_seq.data(), a.e_seq.size());
-        s.qual = (const uint8_t *)put(a.qual.data(), a.qual.size());
-        s.skip = skip ? (const uint8_t *)put(skip + chunk->first[i], R) : nullptr;
+        s.map_off = (const uint32_t *)put(K_OFF64, a.map_off.data(), nullptr, R + 1, 4);
+        s.qual_off = (const uint32_t *)put(K_OFF64, a.qual_off.data(), nullptr, R + 1, 4);
+        s.edit_off = (const uint32_t *)put(K_OFF64, a.edit_off.data(), nullptr, M + 1, 4);
+        s.e_seq_off = (const uint32_t *)put(K_OFF64, a.e_seq_off.data(), nullptr, E + 1, 4);
+        s.m_node = (const uint32_t *)put(K_NODE64, a.m_node.data(), nullptr, M, 4);
+        s.m_offset = (const int32_t *)put(K_MOFF64, a.m_offset.data(), nullptr, M, 4);
+        s.mapq = (const int32_t *)put(K_BYTES, a.mapq.data(), nullptr, R * 4, 1);
+        s.e_len = (const int32_t *)put(K_EDIT, a.e_from.data(), a.e_to.data(), E, 4);
+        s.unmapped = (const uint8_t *)put(K_UNMAPPED, a.identity.data(), nullptr, R, 1);
+        s.m_rev = (const uint8_t *)put(K_BYTES, a.m_rev.data(), nullptr, M, 1);
+        s.e_seq = (const uint8_t *)put(K_BYTES, a.e_seq.data(), nullptr, a.e_seq.size(), 1);
+        s.qual = (const uint8_t *)put(K_BYTES, a.qual.data(), nullptr, a.qual.size(), 1);
+        s.skip = skip ? (const uint8_t *)put(K_BYTES, skip + chunk->first[i], nullptr, R, 1) : nullptr;
     }
-    if (pageable) {
-        for (const Piece &pc : pieces) HIPCHK(hipMemcpyAsync(f->stage.p + pc.off, pc.src, pc.bytes, hipMemcpyHostToDevice, st));
-    } else { // host copies into the pinned block, split into ~1 MB jobs over the host threads, then one DMA
+    { // host copies / narrowings into the pinned block, in jobs of ~256k elements over the host threads, then one DMA
         struct Job {
-            const uint8_t *src;
-            uint8_t *dst;
-            size_t n;
+            const Piece *pc;
+            size_t e0, e1;
         };
         std::vector<Job> jobs;
+        constexpr size_t STEP = 1u << 18;
         for (const Piece &pc : pieces)
-            for (size_t o = 0; o < pc.bytes; o += (1u << 20)) jobs.push_back({(const uint8_t *)pc.src + o, f->pin + pc.off + o, std::min<size_t>(1u << 20, pc.bytes - o)});
+            for (size_t o = 0; o < pc.n; o += STEP) jobs.push_back({&pc, o, std::min(pc.n, o + STEP)});
         const int nth = (int)std::max<size_t>(1, std::min<size_t>({(size_t)usable_cpus(), (size_t)8, jobs.size() / 4 + 1}));
         std::atomic<size_t> next{0};
         parallel_run(nth, [&](int) {
             for (;;) {
                 const size_t j = next.fetch_add(1);
                 if (j >= jobs.size()) break;
-                memcpy(jobs[j].dst, jobs[j].src, jobs[j].n);
+                const Piece &pc = *jobs[j].pc;
+                const size_t e0 = jobs[j].e0, e1 = jobs[j].e1;
+                uint8_t *dst = f->pin + pc.off;
+                switch (pc.kind) {
+                case K_BYTES: memcpy(dst + e0, (const uint8_t *)pc.src + e0, e1 - e0); break;
+                case K_OFF64: {
+                    const int64_t *src = (const int64_t *)pc.src;
+                    uint32_t *d = (uint32_t *)dst;
+                    for (size_t e = e0; e < e1; ++e) d[e] = (uint32_t)src[e];
+                    break;
+                }
+                case K_NODE64: {
+                    const int64_t *src = (const int64_t *)pc.src;
+                    uint32_t *d = (uint32_t *)dst;
+                    for (size_t e = e0; e < e1; ++e) d[e] = src[e] < 0 || src[e] > 0xFFFFFFFEll ? 0xFFFFFFFFu : (uint32_t)src[e];
+                    break;
+                }
+                case K_MOFF64: {
+                    const int64_t *src = (const int64_t *)pc.src;
+                    int32_t *d = (int32_t *)dst;
+                    for (size_t e = e0; e < e1; ++e) d[e] = src[e] != (int64_t)(int32_t)src[e] || (int32_t)src[e] == INT32_MIN ? INT32_MIN : (int32_t)src[e];
+                    break;
+                }
+                case K_EDIT: {
+                    const int32_t *from = (const int32_t *)pc.src, *to = (const int32_t *)pc.src2;
+                    int32_t *d = (int32_t *)dst;
+                    for (size_t e = e0; e < e1; ++e) d[e] = from[e] == to[e] && from[e] >= 0 ? from[e] : -1;
+                    break;
+                }
+                case K_UNMAPPED: {
+                    const double *src = (const double *)pc.src;
+                    for (size_t e = e0; e < e1; ++e) dst[e] = src[e] < 1e-10 ? 1 : 0;
+                    break;
+                }
+                }
             }
         });
-        pt.lap("staging copy");
+        pt.lap("staging (narrowing copy)");
         if (cur) HIPCHK(hipMemcpyAsync(f->stage.p, f->pin, cur, hipMemcpyHostToDevice, st));
     }
     for (size_t i = 0; i < np; ++i)
         if (hs[i].n_reads)
-            hipLaunchKernelGGL(hc_df_classify_kernel, dim3((hs[i].n_reads + 255) / 256), dim3(256), 0, st, hs[i], f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
+            hipLaunchKernelGGL(hc_df_classify_kernel, dim3((hs[i].n_reads + 3) / 4), dim3(256), 0, st, hs[i], f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(f->slices.p, hs.data(), np * sizeof(DfSlice), hipMemcpyHostToDevice, st));
     // ---- the taken reads in ascending order of their lowest node id, input order kept among equals (the others' key is 2^32 - 1)

@@ -57,13 +57,16 @@ std::string haplocart_usage() {
            "   -pf [STR]        posterior output file (default: stdout)\n"
            "   -t  [INT]        host threads (-1 for all available)\n"
            "   -d               write per-haplogroup log-likelihoods to <out>.loglik.tsv\n"
+           "   -j -jf [STR]     write every alignment as a line of JSON to the file (protobuf's JSON mapping as vg's pb2json\n"
+           "                    configures it: the same fields and values, not verified byte for byte against vg's output)\n"
            "   -q               quiet\n"
            "   --keep-duplicates   skip duplicate removal\n"
            "   --per-read       stream the path-membership mask per read (the reference's loop order)\n"
            "   --device [INT]   GPU index (default 0)\n"
            "   --gpus [LIST]    GPU indices, comma separated, or `all`: one device context each (default: the one of --device;\n"
            "                    the environment's VGAN_GPUS is read the same way); the reads are dealt to the contexts chunk by\n"
-           "                    chunk and the per-haplogroup log-likelihoods are reduced once at the end\n";
+           "                    chunk and the per-haplogroup log-likelihoods are reduced once at the end (RCCL between distinct\n"
+           "                    GPUs; VGAN_HC_REDUCE=host sums on the host)\n";
 }
 
 int haplocart(int argc, char **argv) {
