@@ -257,6 +257,8 @@ typedef struct vgan_hc_packed_view {
     const uint32_t *crec;
     const uint8_t *qualp;
     uint32_t max_read_segs, max_read_qual, max_read_cols; /* over the reads: <= 512 / 1280 / 1280 (the tile contract) */
+    uint32_t max_read_node_span; /* largest (highest - lowest node id) of a read, or 0 when not known: the kernel that adds columns
+                                  * straight into its window of W[node] is taken when the reads fit that window */
     int32_t on_device;
     const uint32_t *read_src; /* [n_reads] index of each read in the alignment set (host; not used by the device), or NULL */
 } vgan_hc_packed_view;

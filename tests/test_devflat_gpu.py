@@ -24,7 +24,8 @@ def compare(g, parts, ctx, df, skip=None, want_host=None):
     assert host.pk.n_reads == res.pk.n_reads and host.pk.n_segments == res.pk.n_segments
     assert (host.pk.n_cols, host.pk.n_qual) == (res.pk.n_cols, res.pk.n_qual)
     if res.pk.n_reads:
-        assert (host.pk.max_read_segs, host.pk.max_read_qual, host.pk.max_read_cols) == (res.pk.max_read_segs, res.pk.max_read_qual, res.pk.max_read_cols)
+        assert (host.pk.max_read_segs, host.pk.max_read_qual, host.pk.max_read_cols, host.pk.max_read_node_span) == \
+            (res.pk.max_read_segs, res.pk.max_read_qual, res.pk.max_read_cols, res.pk.max_read_node_span)
         got, want = res.download(), host.packed_arrays()
         for name in ("rhdr", "srec", "crec", "qualp", "read_src"):
             assert np.array_equal(got[name], want[name]), name

@@ -51,6 +51,8 @@ def check(g, a, n_threads=3, **kw):
         so, co, qo = arr["read_seg_off"], arr["read_col_off"], arr["read_qual_off"]
         assert k.max_read_segs == np.diff(so[:nt + 1]).max() and k.max_read_cols == np.diff(co[:nt + 1]).max()
         assert k.max_read_qual == np.diff(qo[:nt + 1]).max()
+        sn = arr["seg_node"].astype(np.int64)
+        assert k.max_read_node_span == max(int(sn[so[r]:so[r + 1]].max() - sn[so[r]:so[r + 1]].min()) for r in range(nt))
     assert np.array_equal(got["read_src"], arr["read_src"][:nt])
     # the other reads: a SoA batch of their own, same data, offsets from 0
     rest = pk.arrays()

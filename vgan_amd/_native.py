@@ -41,7 +41,8 @@ class HcBatch(C.Structure):
 class HcPackedView(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("n_segments", C.c_uint32), ("n_cols", C.c_uint64), ("n_qual", C.c_uint64),
                 ("rhdr", vp), ("srec", vp), ("crec", vp), ("qualp", vp), ("max_read_segs", C.c_uint32),
-                ("max_read_qual", C.c_uint32), ("max_read_cols", C.c_uint32), ("on_device", C.c_int32), ("read_src", vp)]
+                ("max_read_qual", C.c_uint32), ("max_read_cols", C.c_uint32), ("max_read_node_span", C.c_uint32), ("on_device", C.c_int32),
+                ("read_src", vp)]
 
 
 class SbSum(C.Structure):

@@ -372,6 +372,7 @@ int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d) {
     d.max_read_segs = v->max_read_segs;
     d.max_read_qual = v->max_read_qual;
     d.max_read_cols = v->max_read_cols;
+    d.max_read_node_span = v->max_read_node_span;
     if (v->n_reads == 0) return VGAN_OK;
     if (!v->rhdr || !v->srec || !v->crec || !v->qualp) return fail(VGAN_EINVAL, "packed batch: null array");
     if (v->max_read_segs > HC_TILE_MAX_READ_SEGS || v->max_read_qual > HC_TILE_MAX_READ_QUAL || v->max_read_cols > HC_TILE_MAX_READ_COLS ||

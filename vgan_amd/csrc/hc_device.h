@@ -76,6 +76,7 @@ struct HcPackedDev {
     uint32_t max_read_segs; // over the packed reads: select the kernel variant
     uint32_t max_read_qual;
     uint32_t max_read_cols;
+    uint32_t max_read_node_span; // 0: not known
 };
 
 // what another translation unit needs of a context (hc_flatten_kernels.hip)

@@ -56,7 +56,7 @@ struct DfGraph {
     uint64_t n_mapp;
 };
 struct DfCounters { // zeroed per chunk
-    unsigned int n_dev, n_in, n_unmapped, n_clamped, max_segs, max_qual, max_cols, pad;
+    unsigned int n_dev, n_in, n_unmapped, n_clamped, max_segs, max_qual, max_cols, max_span;
 };
 
 __device__ __forceinline__ uint8_t df_comp(uint8_t c) { // csrc/host/flatten.cpp: comp()
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
     if (r >= s.n_reads) return;
     const uint32_t gr = s.read0 + r;
     uint8_t f = DF_HOST;
-    uint32_t A = 0, G = 0, kmin = 0xFFFFFFFFu, nm = 0, nq = 0;
+    uint32_t A = 0, G = 0, kmin = 0xFFFFFFFFu, kmax = 0u, nm = 0, nq = 0;
     if (s.skip && s.skip[r]) {
         f = DF_SKIP;
     } else if (s.unmapped[r]) { // identity < 1e-10, HaploCart.cpp:410
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
                     continue;
                 }
                 kmin = min(kmin, (uint32_t)id);
+                kmax = max(kmax, (uint32_t)id);
                 const int64_t len = g.node_seq_off[id + 1] - g.node_seq_off[id];
                 int64_t off = s.m_offset[m];
                 if (off == (int64_t)INT32_MIN) { // (the offset did not fit 32 bits: the two walks of the general form disagree on such a read)
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
                 gn += __shfl_xor(gn, o, 64);
                 an += __shfl_xor(an, o, 64);
                 kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
             }
             g_len = gn;
             a_len = an;
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
         atomicMax(&ctr->max_segs, nm);
         atomicMax(&ctr->max_qual, nq);
         atomicMax(&ctr->max_cols, A);
+        atomicMax(&ctr->max_span, kmax - kmin);
         const int32_t mq = s.mapq[r];
         if (mq < 0 || mq > 99) atomicAdd(&ctr->n_clamped, 1u);
     }
@@ -692,6 +695,7 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
     out->max_read_segs = hc.max_segs;
     out->max_read_qual = hc.max_qual;
     out->max_read_cols = hc.max_cols;
+    out->max_read_node_span = hc.max_span;
     out->on_device = 1;
     out->read_src = f->h_src.data();
     if (stats) {

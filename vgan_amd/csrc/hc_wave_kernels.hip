@@ -60,7 +60,10 @@ constexpr int WV_THREADS_LARGE = 256;           // ... of the large one (a tile 
 #else
 #define WV_VGPR_ATTR
 #endif
-constexpr int WV_NR = 8;    // reads per tile at most (their headers travel in lanes 0..WV_NR of the wave)
+#ifndef WV_NR_MAX
+#define WV_NR_MAX 8
+#endif
+constexpr int WV_NR = WV_NR_MAX;    // reads per tile at most (their headers travel in lanes 0..WV_NR of the wave)
 #ifndef WV_WIN_SLOTS
 #define WV_WIN_SLOTS 160 // (a 150 bp read spans 106 node ids on the hcfiles graph, 140 at most: three sorted reads fit)
 #endif
@@ -933,7 +936,11 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
     a.consensus = prm.consensus ? 1u : 0u;
     // node-weights accumulation alone: the columns add straight into the W window (no per-segment sums); D_m streamed out
     // (the per-read modes, the test aids): the per-segment form
-    const bool direct = nodeW && !segD && !getenv("VGAN_WV_NO_DIRECT");
+    // ... when the reads fit the W window (a read spanning more node ids than the window has slots sends its outlying
+    // segments' COLUMNS to HBM one by one there; the per-segment form sends one sum per outlying segment: 300 bp reads, 212 ids:
+    // 3.4 against 1.2 ms per 500 k).  The span as the flatten step measured it, else judged by the mean read length.
+    const uint32_t span = pk.max_read_node_span ? pk.max_read_node_span : (uint32_t)(pk.n_cols / std::max<uint32_t>(1, pk.n_reads)) * 3u / 4u;
+    const bool direct = nodeW && !segD && span < (uint32_t)WV_WIN && !getenv("VGAN_WV_NO_DIRECT");
     const KS kern = small ? (direct ? k_small_direct : k_small) : (direct ? k_large_direct : k_large);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(small ? TS : TL), 0, st, a);
 }

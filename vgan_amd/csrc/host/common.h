@@ -230,7 +230,7 @@ struct vgan_hc_host_batch {
     bool is_packed = false;
     vgan::BigVec<uint32_t> pk_rhdr, pk_srec, pk_crec, pk_src;
     vgan::BigVec<uint8_t> pk_qualp;
-    uint32_t pk_reads = 0, pk_segments = 0, pk_max_segs = 0, pk_max_qual = 0, pk_max_cols = 0;
+    uint32_t pk_reads = 0, pk_segments = 0, pk_max_segs = 0, pk_max_qual = 0, pk_max_cols = 0, pk_max_span = 0;
     uint64_t pk_cols = 0, pk_qual = 0;
     void fill(vgan_hc_batch *b) const;
 };

@@ -211,6 +211,7 @@ struct Chunk {
     PkChunk pk;             // ... or, for a packed batch, the same reads in the kernel's own layout
     vgan_hc_host_batch gen; // the others: indels / soft clips (|graph_seq| != |algnseq|, segments may overlap), long reads
     std::vector<uint32_t> key; // per read of b: its lowest node id (the merged batch is ordered by it)
+    uint32_t max_span = 0;     // largest (highest - lowest node id) of a tileable read
     vgan_hc_flatten_stats st{};
 };
 
@@ -269,7 +270,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         // segments first (into scratch), then the route: the tile contract also wants every segment to score a column
         seg_tmp.clear();
         bool empty_seg = false;
-        uint32_t min_node = 0xFFFFFFFFu;
+        uint32_t min_node = 0xFFFFFFFFu, max_node = 0u;
         if (!bad) {
             size_t pos = 0;
             for (int64_t i = 0; i < nm; ++i) {
@@ -296,6 +297,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
                 seg_tmp.push_back({(uint32_t)id, (uint16_t)pos, (uint16_t)sl});
                 empty_seg |= sl == 0;
                 min_node = std::min(min_node, (uint32_t)id);
+                max_node = std::max(max_node, (uint32_t)id);
                 pos += std::min(n, A - pos);
             }
         }
@@ -309,6 +311,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             mq = mq < 0 ? 0 : 99;
             c.st.n_clamped++;
         }
+        if (tile) c.max_span = std::max(c.max_span, max_node - min_node);
         if (tile && packed) {
             // The kernel's own layout, written here once (bytes are moved, nothing is compared, clamped or looked up): a record
             // per alignment column {graph byte, the read byte update_likelihood.cpp:46 pairs it with -- algnseq from the READ
@@ -473,6 +476,7 @@ int merge_chunks(std::vector<Chunk> &chunks, bool packed, PhaseTimer &pt, vgan_h
         res->pk_max_segs = ms;
         res->pk_max_qual = mq;
         res->pk_max_cols = mc;
+        for (auto &c : chunks) res->pk_max_span = std::max(res->pk_max_span, c.max_span);
         uint32_t *h = res->pk_rhdr.data() + 4 * nt_reads; // the end offsets
         h[0] = (uint32_t)t_segs;
         h[1] = (uint32_t)t_qual;
@@ -701,6 +705,7 @@ extern "C" int vgan_hc_host_batch_get_packed(const vgan_hc_host_batch *b, vgan_h
     out->max_read_segs = b->pk_max_segs;
     out->max_read_qual = b->pk_max_qual;
     out->max_read_cols = b->pk_max_cols;
+    out->max_read_node_span = b->pk_max_span;
     out->on_device = 0;
     out->read_src = b->pk_src.data();
     return VGAN_OK;

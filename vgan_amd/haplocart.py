@@ -401,7 +401,7 @@ class DeviceBatch:
             # a packed batch: its four arrays go to HBM as they are (one copy, no layout pass on the device)
             pa, hk = host_batch.packed_arrays(), host_batch.pk
             k = N.HcPackedView()
-            for f in ("n_reads", "n_segments", "n_cols", "n_qual", "max_read_segs", "max_read_qual", "max_read_cols"):
+            for f in ("n_reads", "n_segments", "n_cols", "n_qual", "max_read_segs", "max_read_qual", "max_read_cols", "max_read_node_span"):
                 setattr(k, f, getattr(hk, f))
             for name, dt, _ in _PACKED_FIELDS:
                 a = pa[name].view(np.int32) if dt == np.uint32 else pa[name]
