@@ -15,7 +15,7 @@ fn = _native.load().vgan_hc_debug_wave_stats
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 g = hc.synth_graph(seed=1)
 a = hc.synth_reads(g, n, seed=2, read_len=rl)
-hb = hc.HostBatch(g, a)
+hb = hc.HostBatch(g, a, packed=True)
 ctx = hc.HcContext(g)
 db = hc.DeviceBatch(hb, ctx=ctx)
 out = (ctypes.c_ulonglong * 8)()
