@@ -30,3 +30,4 @@ tot = sum(out[:7])
 for k, v in zip(names, out[:7]):
     print("%-66s %6.2f %%   %8.0f clocks per tile" % (k, 100.0 * v / tot, v / max(out[7], 1)))
 print("tiles %d, clocks per tile %.0f (shader clock, 100 MHz reference on gfx9: s_memtime)" % (out[7], tot / max(out[7], 1)))
+

@@ -108,6 +108,9 @@ __device__ unsigned long long wv_stats[8]; // tiles, reads, chunk groups, far gr
 #define WV_COUNT(slot, n)
 #endif
 
+#ifdef WV_SPANS // developer aid: the launch's timeline wave by wave (tools/wave_spans.py)
+__device__ unsigned long long wv_wave_span[4 * 16384]; // per wave: when it started / left (100 MHz clock), tiles, when it took its last unit
+#endif
 #ifdef WV_PHASES // developer aid: where a wave's time goes (shader clock between the phases of the tile loop, summed over the waves)
 __device__ unsigned long long wv_phase_cycles[8]; // gather issue, next tile + header, reads, Q, C, D, E, tiles
 #define WV_MARK(i)                                                   \
@@ -395,6 +398,10 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
 #ifdef WV_PHASES
     unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
 #endif
+#ifdef WV_SPANS
+    const unsigned long long span_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long span_last = span_t0, span_tiles = 0;
+#endif
     while (true) {
         // the nodes' scalars: the segment records arrived during the tile before, these land during Q
         double nd_lw[SPASS], nd_inv[SPASS], nd_mapp[SPASS];
@@ -409,6 +416,10 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
         if (has_next) next_first(Tn, f2, w2, fresh_2);
         Hn = header_load(f2, w2);
         if (fresh) need_place = true;
+#ifdef WV_SPANS
+        span_tiles += 1;
+        if (fresh_2) span_last = __builtin_amdgcn_s_memrealtime();
+#endif
         const uint32_t a0 = T.q_base & ~7u, qshift = T.q_base & 7u, n_qw = T.n_q + qshift;
         WV_COUNT(0, 1);
         WV_COUNT(1, T.n);
@@ -634,18 +645,28 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
                     WV_COUNT(3, 1);
 #pragma unroll
                     for (int u = 0; u < N; ++u) {
-                        if (__builtin_amdgcn_inverse_ballot_w64(farm[u])) {
-                            const bool deg = !(fabs(kl[u].kappa) < 1e300);
-                            double x = deg ? kl[u].lw * bgv[u] : 1.0 + rho[u];
-                            const double corr = deg ? 0.0 : (rho[u] - (x - 1.0)) * __builtin_amdgcn_rcp(x);
-                            double adj = 0.0;
-                            if (x < 2.2250738585072014e-308 && x > 0.0) { // subnormal
-                                x *= 18014398509481984.0;                   // 2^54
-                                adj = -37.429947750237048;                  // -54 ln 2
+                        // (the lanes of a segment with wobs = 0, or whose rho left the doubles' range, apart: the branch around
+                        // their special cases is taken by whole chunks, almost always)
+                        const uint64_t odd = farm[u] & __builtin_amdgcn_ballot_w64(!(rho[u] < 1e290));
+                        if (__builtin_amdgcn_inverse_ballot_w64(farm[u] & ~odd)) {
+                            const double x = 1.0 + rho[u];
+                            const double corr = (rho[u] - (x - 1.0)) * __builtin_amdgcn_rcp(x);
+                            t[u] = l0[u] + (log_tab_eval_s(x, logtab_s) + corr);
+                        }
+                        if (odd != 0) {
+                            if (__builtin_amdgcn_inverse_ballot_w64(odd)) {
+                                const bool deg = !(fabs(kl[u].kappa) < 1e300);
+                                double x = deg ? kl[u].lw * bgv[u] : 1.0 + rho[u];
+                                const double corr = deg ? 0.0 : (rho[u] - (x - 1.0)) * __builtin_amdgcn_rcp(x);
+                                double adj = 0.0;
+                                if (x < 2.2250738585072014e-308 && x > 0.0) { // subnormal
+                                    x *= 18014398509481984.0;                   // 2^54
+                                    adj = -37.429947750237048;                  // -54 ln 2
+                                }
+                                const double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval_s(x, logtab_s) + adj : x)
+                                                          : (x == 0.0 ? -INFINITY : __builtin_nan(""));
+                                t[u] = deg ? lx : l0[u] + (lx + corr);
                             }
-                            const double lx = x > 0.0 ? (x <= 1.7976931348623157e308 ? log_tab_eval_s(x, logtab_s) + adj : x)
-                                                      : (x == 0.0 ? -INFINITY : __builtin_nan(""));
-                            t[u] = deg ? lx : l0[u] + (lx + corr);
                         }
                     }
                 }
@@ -732,6 +753,15 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&wv_phase_cycles[i], ph_acc[i]);
 #endif
+#ifdef WV_SPANS
+    if (lane == 0) {
+        const uint32_t gw = (blockIdx.x * WV_WAVES + (uint32_t)wave) & 16383u;
+        wv_wave_span[4 * gw] = span_t0;
+        wv_wave_span[4 * gw + 1] = __builtin_amdgcn_s_memrealtime();
+        wv_wave_span[4 * gw + 2] = span_tiles;
+        wv_wave_span[4 * gw + 3] = span_last;
+    }
+#endif
     sumT = wave_sum(sumT);
     sumU = wave_sum(sumU);
     if (lane == 0 && a.totals) {
@@ -806,6 +836,11 @@ __global__ __launch_bounds__(256) void hc_srec_nodes_kernel(const uint2 *__restr
 } // namespace wv
 using namespace wv;
 
+#ifdef WV_SPANS
+extern "C" int vgan_hc_debug_wave_spans(unsigned long long *out /* 4 * 16384 */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(wv_wave_span), sizeof(wv_wave_span)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef WV_PHASES
 extern "C" int vgan_hc_debug_wave_phases(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(wv_phase_cycles), sizeof(wv_phase_cycles)) != hipSuccess) return -1;
