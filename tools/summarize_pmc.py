@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Mean per-dispatch value of every counter in the rocprofv3 --pmc passes under a directory, per kernel (vgan:: kernels
-only).  Writes <dir>/summary.json and prints a table.  usage: summarize_pmc.py <dir>"""
+only).  Writes <dir>/summary.json and prints a table; with a profile name also profiles/<name>.json and the kernels' issue
+figures into profiles/valu_issue.json.  usage: summarize_pmc.py <dir> [<profile name>]"""
 import collections
 import csv
 import glob
@@ -16,7 +17,10 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
         if "vgan::" in k:
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
-json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1, sort_keys=True)
+if not out and os.path.exists(os.path.join(d, "summary.json")):  # (the passes' CSVs were summarised on the GPU box and removed)
+    out = json.load(open(os.path.join(d, "summary.json")))
+else:
+    json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1, sort_keys=True)
 issue = {}
 for k, cs in out.items():
     print("==", k)
@@ -40,4 +44,15 @@ if issue and len(sys.argv) > 2:  # summarize_pmc.py <dir> <profile name>: the co
             commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
         except Exception:
             commit = None
-    json.dump({"profile": sys.argv[2], "commit": commit, "kernels": issue}, open(os.path.join(root, "profiles", "valu_issue.json"), "w"), indent=1)
+    # the counters themselves under profiles/<name>.json; valu_issue.json keeps the kernels of earlier profiles of the SAME tree
+    json.dump(out, open(os.path.join(root, "profiles", sys.argv[2] + ".json"), "w"), indent=1, sort_keys=True)
+    vi = os.path.join(root, "profiles", "valu_issue.json")
+    names, kernels = [sys.argv[2]], dict(issue)
+    try:
+        old = json.load(open(vi))
+        if old.get("commit") == commit and old.get("profile") != sys.argv[2]:
+            names = [n for n in old["profile"].split(" + ") if n != sys.argv[2]] + names
+            kernels = {**old.get("kernels", {}), **issue}
+    except Exception:
+        pass
+    json.dump({"profile": " + ".join(names), "commit": commit, "kernels": kernels}, open(vi, "w"), indent=1)
