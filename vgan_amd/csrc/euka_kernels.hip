@@ -54,6 +54,14 @@ struct EkAcc {
     int32_t count;
 };
 
+// A wave's block of 64 reads between the stages of the kernel (a lane per read / a row of 16 lanes per read)
+struct EkBlk {
+    uint32_t col0[64], ga[64], lq[64], q0[64], m0[64], nm[64]; // ga: |graph| | |read columns| << 16; lq: |sequence| | |quality| << 16
+    uint32_t flags[64];                                         // 1 reverse strand, 2 a column beyond the damage tables, 4 passed
+    int32_t mapq[64], cn[64];
+    double pd[64], in[64], out[64];
+};
+
 // sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
 __device__ __forceinline__ double row_sum16(double v) {
     v += dpp_mov0<0x128, 0xf>(v);
@@ -79,6 +87,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     __shared__ uint8_t cls_s[256];
     __shared__ double bfl_s[16]; // base_freq log of the read base by its low nibble; 0 unless A C G T / 'N' (slot 9)
     __shared__ EkAcc acc_s[EK_WAVES];
+    __shared__ EkBlk blk_s[EK_WAVES];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         const int ai = acgt_index((uint32_t)i);
         const int rank = i == 'N' ? 0 : i == '-' ? 1 : is_rare((uint32_t)i) ? 2 : i == 'S' ? 3 : 4;
@@ -153,206 +162,266 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // contiguous reads per wave (whole steps of four)
+    // Contiguous reads per wave, taken in blocks of 64 through four stages -- what is per READ (its offsets and lengths, its
+    // clade, the closing log-sum-exp and the outputs) runs with a lane per read, 64 reads per instruction; only the column
+    // loop and what needs a read's columns or mappings runs with a row of 16 lanes per read, 4 reads per instruction.  (In
+    // the first form of this kernel every stage ran per group of four reads: half of its vector instructions were the
+    // per-read work done sixteen lanes wide, the libm calls of the epilogue first.)
+    EkBlk &blk = blk_s[wave];
     const uint32_t n_waves = gridDim.x * EK_WAVES;
     const uint32_t per_wave = ((b.n_reads + n_waves - 1) / n_waves + EK_READS_PER_WAVE - 1) / EK_READS_PER_WAVE * EK_READS_PER_WAVE;
     const uint32_t w_begin = (blockIdx.x * EK_WAVES + wave) * per_wave, w_end = min(b.n_reads, w_begin + per_wave);
-    for (uint32_t rbase = w_begin; rbase < w_end; rbase += EK_READS_PER_WAVE) {
-        const bool have = rbase + grp < b.n_reads; // this row has a read
-        const uint32_t r = min(rbase + grp, b.n_reads - 1u);
-        const uint32_t col0 = b.read_col_off[r];
-        const uint32_t G = have ? b.read_gseq_len[r] : 0u, A = b.read_rseq_len[r];
-        const uint32_t q0 = b.read_qual_off[r], QL = b.read_qual_off[r + 1] - q0;
-        const uint32_t Lseq = b.read_seq_len[r];
-        const int32_t mapq = b.read_mapq[r];
-        const bool rev = b.read_rev[r] != 0;
-        const uint32_t m0 = b.read_map_off[r], m1 = b.read_map_off[r + 1];
-        // clade of the first mapping's node: last (clade, bin) containing it, else clade 0 (readGAM_Euka.h:99-140)
-        int32_t c_n = 0;
+    for (uint32_t bstart = w_begin; bstart < w_end; bstart += 64u) {
+        const uint32_t nb = min(64u, w_end - bstart);
+        // ---- A: a lane per read: what the row of the read will need, and its clade
         {
-            const uint32_t node = b.map_node[m0];
-            if (d.n_node_clade) {
-                c_n = d.node_clade[min(node, d.n_node_clade - 1u)];
-            } else {
-                uint32_t lo = 0, hi = d.n_bp; // first breakpoint > node
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (d.bp[mid] <= node) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (lo > 0) {
-                    const int32_t c = d.bp_clade[lo - 1];
-                    if (c >= 0) c_n = c;
+            const uint32_t r = bstart + min((uint32_t)lane, nb - 1u);
+            const uint32_t q0 = b.read_qual_off[r], m0 = b.read_map_off[r];
+            // clade of the first mapping's node: last (clade, bin) containing it, else clade 0 (readGAM_Euka.h:99-140)
+            int32_t c_n = 0;
+            {
+                const uint32_t node = b.map_node[m0];
+                if (d.n_node_clade) {
+                    c_n = d.node_clade[min(node, d.n_node_clade - 1u)];
+                } else {
+                    uint32_t lo = 0, hi = d.n_bp; // first breakpoint > node
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (d.bp[mid] <= node) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    if (lo > 0) {
+                        const int32_t c = d.bp_clade[lo - 1];
+                        if (c >= 0) c_n = c;
+                    }
                 }
             }
-        }
-        const double pair_dist = d.clade_dist[c_n];
-        {   // the step's first read names the wave's clade; a row of another clade (a boundary step) adds to the global tables
+            blk.col0[lane] = b.read_col_off[r];
+            blk.ga[lane] = (uint32_t)b.read_gseq_len[r] | ((uint32_t)b.read_rseq_len[r] << 16);
+            blk.lq[lane] = (uint32_t)b.read_seq_len[r] | (min(b.read_qual_off[r + 1] - q0, 0xFFFFu) << 16); // (columns are below 2^16)
+            blk.q0[lane] = q0;
+            blk.m0[lane] = m0;
+            blk.nm[lane] = b.read_map_off[r + 1] - m0;
+            blk.flags[lane] = b.read_rev[r] != 0 ? 1u : 0u;
+            blk.mapq[lane] = b.read_mapq[r];
+            blk.cn[lane] = c_n;
+            blk.pd[lane] = d.clade_dist[c_n];
+            // the block's first read names the wave's clade; a read of another clade (a boundary block) adds to the global tables
             const int32_t c_first = __builtin_amdgcn_readfirstlane(c_n);
             if (c_first != cur) {
                 flush();
                 cur = c_first;
             }
         }
-        const bool in_acc = c_n == cur;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- B: a row per read, four reads per step
+        for (uint32_t g4 = 0; g4 < nb; g4 += EK_READS_PER_WAVE) {
+            const bool have = g4 + grp < nb; // this row has a read
+            const uint32_t i = min(g4 + grp, nb - 1u);
+            const uint32_t col0 = blk.col0[i], ga = blk.ga[i], lq = blk.lq[i], q0 = blk.q0[i];
+            const uint32_t G = have ? (ga & 0xFFFFu) : 0u, A = ga >> 16, Lseq = lq & 0xFFFFu, QL = lq >> 16;
+            const bool rev = (blk.flags[i] & 1u) != 0;
+            const int32_t c_n = blk.cn[i];
+            const double pair_dist = blk.pd[i];
+            const bool in_acc = c_n == cur;
 
-        double lik = 0.0, lik2 = 0.0;
-        uint32_t carry_n = 0, carry_sc = 0;
-        bool bad = false;
-        const uint32_t maxG = wave_max4(G);
-        for (uint32_t base = 0; base < maxG; base += EK_GROUP) {
-            const uint32_t m = base + sub;
-            const bool active = m < G;
-            // unconditional loads at clamped addresses, selected afterwards: the loads of a column overlap
-            const uint32_t mc = min(m, max(G, 1u) - 1u);
-            const uint32_t gc_raw = b.graph_seq[col0 + mc], rc_raw = b.read_seq[col0 + mc];
-            const int q_raw = (int)(int8_t)b.qual[q0 + min(m, max(QL, 1u) - 1u)];
-            const uint32_t gc = active ? gc_raw : 0u;
-            const uint32_t rc = (active && m < A) ? rc_raw : 0u;
-            const uint32_t gcl = cls_s[gc], rcl = cls_s[rc];
-            const uint32_t nongap = row_bits(active && rc != '-');
-            const uint32_t n_before = carry_n + (uint32_t)__builtin_popcount(nongap & below);
-            const uint32_t n = rev ? (Lseq - 1u - n_before) : n_before; // unsigned wrap as in the reference
-            const uint32_t kind = min(gcl >> 4, rcl >> 4);                // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
-            int q = (m < QL && QL > 0u) ? q_raw : 0; // Q15
-            q = q < 0 ? 0 : (q > 99 ? 99 : q);
-            const double2 qe = qs_s[q];
-            const double qs = qe.x;
-            // the regular column (:283-400), evaluated for every lane: p = sum_o pre[o] * sum_b M[o][b] * w[b] with
-            // w = w_miss except w[read base] = w_hit, i.e. per original base o: w_miss * rowsum[o] + (w_hit - w_miss) * M[o][rb],
-            // and pre = 1 - dist at the graph base g, dist * 0.95238 at its transition partner g^2, dist * 0.02381 at the
-            // other two (:312-318, Euka.cpp:453-468).  Pair table layout: euka_device.h.
-            const uint32_t gi = gcl & 15u, ri = rcl & 15u; // 0..3, or 8 / 9 outside ACGT
-            const uint32_t nn = min(n, Lseq - 1u);
-            // (24-bit multiplies: positions and table sizes are below 2^24, and the full 32-bit multiply is a quarter-rate instruction)
-            uint32_t pair_ix, e_ix; // (spelled out: the compiler forms a quarter-rate 64-bit multiply-add for the same expression)
-            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair_ix) : "v"(min(nn, d.n5 - 1u)), "s"(d.n3), "v"(min(Lseq - 1u - nn, d.n3 - 1u)));
-            asm("v_mul_u32_u24 %0, 20, %1" : "=v"(e_ix) : "v"(pair_ix));
-            const double *e = dmg + e_ix;
-            const double w_hit = 1.0 - qs, w_miss = qe.y;
-            const double dw = ri < 4u ? w_hit - w_miss : 0.0; // a read base outside ACGT matches no column
-            const double *mcol = e + 4u * (ri & 3u);        // M[.][read base]
-            const uint32_t o0 = gi & 3u, o1 = o0 ^ 1u, o2 = o0 ^ 2u, o3 = o0 ^ 3u;
-            const double d0 = w_miss * e[16 + o0] + dw * mcol[o0];
-            const double d2 = w_miss * e[16 + o2] + dw * mcol[o2];
-            const double d1 = w_miss * e[16 + o1] + dw * mcol[o1];
-            const double d3 = w_miss * e[16 + o3] + dw * mcol[o3];
-            double p = (1.0 - pair_dist) * d0 + pair_dist * (0.95238 * d2 + 0.02381 * (d1 + d3));
-            p = gi < 4u ? p : 0.0; // a graph base outside ACGT has no t_T_ratio entry
-            // model 1 = c1 + log(a1), model 2 = l2; the cases only pick a1 / c1 / l2, so one log serves all of them
-            if (kind == 4u && active && n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
-            double a1 = kind == 4u ? p : 1.0, c1 = 0.0;
-            double l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
-            // N / gap / rare / softclip columns are a few per thousand: the whole wave skips their selects unless it has one
-            if (__builtin_amdgcn_ballot_w64(active && kind != 4u)) {
-                const uint32_t scb = row_bits(active && kind == 3u);
-                const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
-                carry_sc += (uint32_t)__builtin_popcount(scb);
-                const double bfl = bfl_s[rcl & 15u];
-                if (kind == 3u) { // :263-280
-                    a1 = (sc_index % 3u == 0u) ? w_hit : w_miss;
-                    l2 = -1.3862943611198906; // log(0.25)
+            double lik = 0.0, lik2 = 0.0;
+            uint32_t carry_n = 0, carry_sc = 0;
+            bool bad = false;
+            const uint32_t maxG = wave_max4(G);
+            for (uint32_t base = 0; base < maxG; base += EK_GROUP) {
+                const uint32_t m = base + sub;
+                const bool active = m < G;
+                // unconditional loads at clamped addresses, selected afterwards: the loads of a column overlap
+                const uint32_t mc = min(m, max(G, 1u) - 1u);
+                const uint32_t gc_raw = b.graph_seq[col0 + mc], rc_raw = b.read_seq[col0 + mc];
+                const int q_raw = (int)(int8_t)b.qual[q0 + min(m, max(QL, 1u) - 1u)];
+                const uint32_t gc = active ? gc_raw : 0u;
+                const uint32_t rc = (active && m < A) ? rc_raw : 0u;
+                const uint32_t gcl = cls_s[gc], rcl = cls_s[rc];
+                const uint32_t nongap = row_bits(active && rc != '-');
+                const uint32_t n_before = carry_n + (uint32_t)__builtin_popcount(nongap & below);
+                const uint32_t n = rev ? (Lseq - 1u - n_before) : n_before; // unsigned wrap as in the reference
+                const uint32_t kind = min(gcl >> 4, rcl >> 4);                // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
+                int q = (m < QL && QL > 0u) ? q_raw : 0; // Q15
+                q = q < 0 ? 0 : (q > 99 ? 99 : q);
+                const double2 qe = qs_s[q];
+                const double qs = qe.x;
+                // the regular column (:283-400), evaluated for every lane: p = sum_o pre[o] * sum_b M[o][b] * w[b] with
+                // w = w_miss except w[read base] = w_hit, i.e. per original base o: w_miss * rowsum[o] + (w_hit - w_miss) * M[o][rb],
+                // and pre = 1 - dist at the graph base g, dist * 0.95238 at its transition partner g^2, dist * 0.02381 at the
+                // other two (:312-318, Euka.cpp:453-468).  Pair table layout: euka_device.h.
+                const uint32_t gi = gcl & 15u, ri = rcl & 15u; // 0..3, or 8 / 9 outside ACGT
+                const uint32_t nn = min(n, Lseq - 1u);
+                // (24-bit multiplies: positions and table sizes are below 2^24, and the full 32-bit multiply is a quarter-rate instruction)
+                uint32_t pair_ix, e_ix; // (spelled out: the compiler forms a quarter-rate 64-bit multiply-add for the same expression)
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair_ix) : "v"(min(nn, d.n5 - 1u)), "s"(d.n3), "v"(min(Lseq - 1u - nn, d.n3 - 1u)));
+                asm("v_mul_u32_u24 %0, 20, %1" : "=v"(e_ix) : "v"(pair_ix));
+                const double *e = dmg + e_ix;
+                const double w_hit = 1.0 - qs, w_miss = qe.y;
+                const double dw = ri < 4u ? w_hit - w_miss : 0.0; // a read base outside ACGT matches no column
+                const double *mcol = e + 4u * (ri & 3u);        // M[.][read base]
+                const uint32_t o0 = gi & 3u, o1 = o0 ^ 1u, o2 = o0 ^ 2u, o3 = o0 ^ 3u;
+                const double d0 = w_miss * e[16 + o0] + dw * mcol[o0];
+                const double d2 = w_miss * e[16 + o2] + dw * mcol[o2];
+                const double d1 = w_miss * e[16 + o1] + dw * mcol[o1];
+                const double d3 = w_miss * e[16 + o3] + dw * mcol[o3];
+                double p = (1.0 - pair_dist) * d0 + pair_dist * (0.95238 * d2 + 0.02381 * (d1 + d3));
+                p = gi < 4u ? p : 0.0; // a graph base outside ACGT has no t_T_ratio entry
+                // model 1 = c1 + log(a1), model 2 = l2; the cases only pick a1 / c1 / l2, so one log serves all of them
+                if (kind == 4u && active && n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
+                double a1 = kind == 4u ? p : 1.0, c1 = 0.0;
+                double l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
+                // N / gap / rare / softclip columns are a few per thousand: the whole wave skips their selects unless it has one
+                if (__builtin_amdgcn_ballot_w64(active && kind != 4u)) {
+                    const uint32_t scb = row_bits(active && kind == 3u);
+                    const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
+                    carry_sc += (uint32_t)__builtin_popcount(scb);
+                    const double bfl = bfl_s[rcl & 15u];
+                    if (kind == 3u) { // :263-280
+                        a1 = (sc_index % 3u == 0u) ? w_hit : w_miss;
+                        l2 = -1.3862943611198906; // log(0.25)
+                    }
+                    if (kind == 2u) { // :252-257
+                        a1 = (1.0 - pair_dist) * 0.001;
+                        l2 = -6.907755278982137; // log(0.001)
+                    }
+                    if (kind == 1u) { // :244-249
+                        c1 = -6.214608098422191;  // log(0.002)
+                        l2 = -1.6094379124341003; // log(0.2)
+                    }
+                    if (kind == 0u) c1 = l2 = bfl; // :236-241
                 }
-                if (kind == 2u) { // :252-257
-                    a1 = (1.0 - pair_dist) * 0.001;
-                    l2 = -6.907755278982137; // log(0.001)
+                if (!active) {
+                    a1 = 1.0;
+                    c1 = l2 = 0.0;
                 }
-                if (kind == 1u) { // :244-249
-                    c1 = -6.214608098422191;  // log(0.002)
-                    l2 = -1.6094379124341003; // log(0.2)
-                }
-                if (kind == 0u) c1 = l2 = bfl; // :236-241
+                const double l1 = c1 + log_tab(a1, true, logtab_s); // log(1) == 0 exactly
+                lik += l1;
+                lik2 += l2;
+                carry_n += (uint32_t)__builtin_popcount(nongap);
             }
-            if (!active) {
-                a1 = 1.0;
-                c1 = l2 = 0.0;
-            }
-            const double l1 = c1 + log_tab(a1, true, logtab_s); // log(1) == 0 exactly
-            lik += l1;
-            lik2 += l2;
-            carry_n += (uint32_t)__builtin_popcount(nongap);
-        }
-        const double in = row_sum16(lik), out = row_sum16(lik2);
-        bad = row_bits(bad) != 0u;
-        if (bad) {
+            const double in = row_sum16(lik), out = row_sum16(lik2);
+            bad = row_bits(bad) != 0u;
             if (sub == 0 && have) {
+                blk.in[i] = in;
+                blk.out[i] = out;
+                if (bad) blk.flags[i] |= 2u;
+            }
+            const bool live = have && !bad;
+            // Baseshift::baseshift_calc: first / last lengthToProf columns (baseshift.cpp:57-88)
+            for (int p = (int)sub; p < 2 * d.ltp; p += EK_GROUP) {
+                const int64_t gi = p < d.ltp ? p : (int64_t)G - 2 * d.ltp + p;
+                const int64_t ri = p < d.ltp ? p : (int64_t)A - 2 * d.ltp + p;
+                if (live && gi >= 0 && ri >= 0 && gi < (int64_t)G && ri < (int64_t)A) {
+                    uint32_t gb = b.graph_seq[col0 + gi], rb = b.read_seq[col0 + ri];
+                    gb = (gb >= 'a' && gb <= 'z') ? gb - 32u : gb;
+                    rb = (rb >= 'a' && rb <= 'z') ? rb - 32u : rb;
+                    const int g4i = acgt_index(gb), r4i = acgt_index(rb);
+                    if (g4i >= 0 && r4i >= 0) {
+                        if (in_acc && shift_in_lds) atomicAdd(&acc.shift[p * 16 + g4i * 4 + r4i], 1u);
+                        else atomicAdd(&baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4i * 4 + r4i], 1u);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- C: a lane per read: clade_like / clade_not_like (:485-492), the outputs, the clade's sums
+        bool any_pass;
+        {
+            const bool mine = (uint32_t)lane < nb;
+            const uint32_t r = bstart + min((uint32_t)lane, nb - 1u);
+            const uint32_t fl = blk.flags[lane];
+            const bool bad = mine && (fl & 2u) != 0;
+            const bool live = mine && !bad;
+            const double in = blk.in[lane], out = blk.out[lane];
+            const int32_t mapq = blk.mapq[lane], c_n = blk.cn[lane];
+            const bool in_acc = c_n == cur;
+            if (bad) {
                 o.clade[r] = -1;
                 o.in_lik[r] = o.out_lik[r] = o.like[r] = o.not_like[r] = 0.0;
                 o.pass[r] = 0;
-                atomicAdd(o.n_bad, 1ull);
             }
-        }
-        const bool live = have && !bad;
-        // Baseshift::baseshift_calc: first / last lengthToProf columns (baseshift.cpp:57-88)
-        for (int p = (int)sub; p < 2 * d.ltp; p += EK_GROUP) {
-            const int64_t gi = p < d.ltp ? p : (int64_t)G - 2 * d.ltp + p;
-            const int64_t ri = p < d.ltp ? p : (int64_t)A - 2 * d.ltp + p;
-            if (live && gi >= 0 && ri >= 0 && gi < (int64_t)G && ri < (int64_t)A) {
-                uint32_t gb = b.graph_seq[col0 + gi], rb = b.read_seq[col0 + ri];
-                gb = (gb >= 'a' && gb <= 'z') ? gb - 32u : gb;
-                rb = (rb >= 'a' && rb <= 'z') ? rb - 32u : rb;
-                const int g4 = acgt_index(gb), r4 = acgt_index(rb);
-                if (g4 >= 0 && r4 >= 0) {
-                    if (in_acc && shift_in_lds) atomicAdd(&acc.shift[p * 16 + g4 * 4 + r4], 1u);
-                    else atomicAdd(&baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4 * 4 + r4], 1u);
-                }
+            const uint64_t bad_m = __builtin_amdgcn_ballot_w64(bad);
+            if (bad_m && lane == 0) atomicAdd(o.n_bad, (unsigned long long)__builtin_popcountll(bad_m));
+            // 1 - 10^(-mapq/10): table for 0..255; beyond it the subtrahend is below 1 ulp of 1 (negative mapq cannot be encoded
+            // by a well-formed GAM, it is evaluated with exp for completeness)
+            const double map_q = mapq >= 256 ? 1.0 : (mapq >= 0 ? d.mapq_ok[mapq] : 1.0 - exp(-0.1 * mapq * 2.302585092994046));
+            double lse;
+            if (in == 0.0) lse = out; // oplusInitnatl: a running value of 0 means "empty"
+            else lse = fmax(in, out) + log1p(exp(-fabs(in - out)));
+            const double like = map_q * exp(in - lse);
+            const bool pass = live && (in - out > 1.0) && ((uint32_t)mapq > d.min_mapq); // :504-510 (unsigned compare)
+            if (live) {
+                o.clade[r] = c_n;
+                o.in_lik[r] = in;
+                o.out_lik[r] = out;
+                o.like[r] = like;
+                o.not_like[r] = 1.0 - like;
+                o.pass[r] = pass ? 1 : 0;
             }
-        }
-        // clade_like / clade_not_like (:485-492)
-        // 1 - 10^(-mapq/10): table for 0..255; beyond it the subtrahend is below 1 ulp of 1 (negative mapq cannot be encoded
-        // by a well-formed GAM, it is evaluated with exp for completeness)
-        const double map_q = mapq >= 256 ? 1.0 : (mapq >= 0 ? d.mapq_ok[mapq] : 1.0 - exp(-0.1 * mapq * 2.302585092994046));
-        double lse;
-        if (in == 0.0) lse = out; // oplusInitnatl: a running value of 0 means "empty"
-        else lse = fmax(in, out) + log1p(exp(-fabs(in - out)));
-        const double like = map_q * exp(in - lse);
-        const bool pass = live && (in - out > 1.0) && ((uint32_t)mapq > d.min_mapq); // :504-510 (unsigned compare)
-        if (sub == 0 && live) {
-            o.clade[r] = c_n;
-            o.in_lik[r] = in;
-            o.out_lik[r] = out;
-            o.like[r] = like;
-            o.not_like[r] = 1.0 - like;
-            o.pass[r] = pass ? 1 : 0;
+            if (pass) blk.flags[lane] = fl | 4u;
             // the abundance MCMC only ever uses sum_k log(frac * clade_like[k]) per clade (MCMC.cpp:1175-1215, (1/334) == 0):
             // keep the count and the sum of logs; a read with like == 0 (mapq 0, or exp underflow) makes the sum -inf as there
-            if (in_acc) {
-                if (pass) atomicAdd(&acc.count, 1);
-                atomicAdd(&acc.n_like, 1u);
-                unsafeAtomicAdd(&acc.logsum, log(like));
-            } else {
+            const double ll = log(like);
+            const uint64_t acc_m = __builtin_amdgcn_ballot_w64(live && in_acc);
+            if (acc_m) { // the reads of the wave's clade: one sum, one count
+                const double s = wave_sum(live && in_acc ? ll : 0.0);
+                const uint32_t n_pass = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pass && in_acc));
+                if (lane == 0) {
+                    acc.count += (int32_t)n_pass;
+                    acc.n_like += (uint32_t)__builtin_popcountll(acc_m);
+                    acc.logsum += s;
+                }
+            }
+            if (live && !in_acc) {
                 if (pass) atomicAdd(&clade_count[c_n], 1);
                 atomicAdd(&like_n[c_n], 1u);
-                unsafeAtomicAdd(&like_logsum[c_n], log(like));
+                unsafeAtomicAdd(&like_logsum[c_n], ll);
             }
+            any_pass = __builtin_amdgcn_ballot_w64(pass) != 0;
         }
-        // bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546).  Lane j of a
-        // row owns the clade's bin jb + j and counts the read's mappings that fall into it (16 nodes per step, handed
-        // round the row), then adds count / #mappings once.
-        if (__builtin_amdgcn_ballot_w64(pass)) {
-            const uint32_t b0 = d.bin_off[c_n], nb = pass ? d.bin_off[c_n + 1] - b0 : 0u;
-            const uint32_t nm = pass ? m1 - m0 : 0u;
-            const double inv = 1.0 / (double)(m1 - m0);
-            const uint32_t max_nb = wave_max4(nb), max_nm = wave_max4(nm);
-            for (uint32_t jb = 0; jb < max_nb; jb += EK_GROUP) {
-                const bool mine = jb + sub < nb;
-                const int32_t my_lo = mine ? d.bin_lo[b0 + jb + sub] : 1;
-                const int32_t my_hi = mine ? d.bin_hi[b0 + jb + sub] : 0;
-                uint32_t cnt = 0;
-                for (uint32_t mb = 0; mb < max_nm; mb += EK_GROUP) {
-                    const int32_t node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1; // no bin holds -1 ...
-                    const uint32_t in = min((uint32_t)EK_GROUP, max_nm - mb);
-                    for (uint32_t i = 0; i < in; ++i) {
-                        const int32_t nd = __shfl(node, (int)(gshift + i), 64);
-                        cnt += (nd >= my_lo && nd <= my_hi && nd >= 0) ? 1u : 0u; // ... whatever its bounds
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- D: bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546).  A row per
+        // read again: lane j of a row owns the clade's bin jb + j and counts the read's mappings that fall into it (16 nodes per
+        // step, handed round the row), then adds count / #mappings once.
+        if (any_pass) {
+            for (uint32_t g4 = 0; g4 < nb; g4 += EK_READS_PER_WAVE) {
+                const uint32_t i = min(g4 + grp, nb - 1u);
+                const bool pass = g4 + grp < nb && (blk.flags[i] & 4u) != 0;
+                if (!__builtin_amdgcn_ballot_w64(pass)) continue;
+                const int32_t c_n = blk.cn[i];
+                const bool in_acc = c_n == cur;
+                const uint32_t m0 = blk.m0[i], nm_all = blk.nm[i];
+                const uint32_t b0 = d.bin_off[c_n], nbin = pass ? d.bin_off[c_n + 1] - b0 : 0u;
+                const uint32_t nm = pass ? nm_all : 0u;
+                const double inv = 1.0 / (double)nm_all;
+                const uint32_t max_nb = wave_max4(nbin), max_nm = wave_max4(nm);
+                for (uint32_t jb = 0; jb < max_nb; jb += EK_GROUP) {
+                    const bool mine = jb + sub < nbin;
+                    const int32_t my_lo = mine ? d.bin_lo[b0 + jb + sub] : 1;
+                    const int32_t my_hi = mine ? d.bin_hi[b0 + jb + sub] : 0;
+                    uint32_t cnt = 0;
+                    for (uint32_t mb = 0; mb < max_nm; mb += EK_GROUP) {
+                        const int32_t node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1; // no bin holds -1 ...
+                        const uint32_t inn = min((uint32_t)EK_GROUP, max_nm - mb);
+                        for (uint32_t k = 0; k < inn; ++k) {
+                            const int32_t nd = __shfl(node, (int)(gshift + k), 64);
+                            cnt += (nd >= my_lo && nd <= my_hi && nd >= 0) ? 1u : 0u; // ... whatever its bounds
+                        }
+                    }
+                    if (cnt) {
+                        if (in_acc && jb + sub < (uint32_t)EK_ACC_BINS) unsafeAtomicAdd(&acc.cov[jb + sub], (double)cnt * inv);
+                        else unsafeAtomicAdd(&bin_cov[b0 + jb + sub], (double)cnt * inv);
                     }
                 }
-                if (cnt) {
-                    if (in_acc && jb + sub < (uint32_t)EK_ACC_BINS) unsafeAtomicAdd(&acc.cov[jb + sub], (double)cnt * inv);
-                    else unsafeAtomicAdd(&bin_cov[b0 + jb + sub], (double)cnt * inv);
-                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // The end of the workgroup: its four waves took consecutive ranges of the sorted reads, so they mostly end on one
     // clade -- their accumulators are added up in LDS and leave the chip once.
