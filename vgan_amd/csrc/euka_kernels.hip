@@ -226,8 +226,11 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             const double pair_dist = blk.pd[i];
             const bool in_acc = c_n == cur;
 
-            double lik = 0.0, lik2 = 0.0;
-            uint32_t carry_n = 0, carry_sc = 0;
+            // model 1 of a column is c1 + log(a1): the a1 of a lane's columns are multiplied up and the log is taken once per eight
+            // of them (a1 is a probability of a base under the damage and error model, 1e-12 at the very least: eight fit a
+            // double with room to spare; a1 = 0 -- a graph byte outside ACGT in a regular column -- gives log 0 = -inf either way)
+            double lik = 0.0, lik2 = 0.0, prod = 1.0;
+            uint32_t carry_n = 0, carry_sc = 0, step = 0;
             bool bad = false;
             const uint32_t maxG = wave_max4(G);
             for (uint32_t base = 0; base < maxG; base += EK_GROUP) {
@@ -297,11 +300,16 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                     a1 = 1.0;
                     c1 = l2 = 0.0;
                 }
-                const double l1 = c1 + log_tab(a1, true, logtab_s); // log(1) == 0 exactly
-                lik += l1;
+                prod *= a1;
+                lik += c1;
+                if ((++step & 7u) == 0u) {
+                    lik += log_tab(prod, true, logtab_s); // log(1) == 0 exactly
+                    prod = 1.0;
+                }
                 lik2 += l2;
                 carry_n += (uint32_t)__builtin_popcount(nongap);
             }
+            if (step & 7u) lik += log_tab(prod, true, logtab_s);
             const double in = row_sum16(lik), out = row_sum16(lik2);
             bad = row_bits(bad) != 0u;
             if (sub == 0 && have) {
