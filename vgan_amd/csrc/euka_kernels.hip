@@ -86,12 +86,15 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     // the order it tests them (readGAM_Euka.h:236-280): 0 'N', 1 '-', 2 rare IUPAC code, 3 'S', 4 none
     __shared__ uint8_t cls_s[256];
     __shared__ double bfl_s[16]; // base_freq log of the read base by its low nibble; 0 unless A C G T / 'N' (slot 9)
+    __shared__ uint8_t up4_s[256]; // byte -> ACGT index of its upper-case form, else 0x80 (Baseshift::baseshift_calc folds the case)
     __shared__ EkAcc acc_s[EK_WAVES];
     __shared__ EkBlk blk_s[EK_WAVES];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         const int ai = acgt_index((uint32_t)i);
         const int rank = i == 'N' ? 0 : i == '-' ? 1 : is_rare((uint32_t)i) ? 2 : i == 'S' ? 3 : 4;
         cls_s[i] = (uint8_t)((ai >= 0 ? ai : (i == 'N' ? 9 : 8)) | (rank << 4));
+        const int au = acgt_index((uint32_t)((i >= 'a' && i <= 'z') ? i - 32 : i));
+        up4_s[i] = (uint8_t)(au >= 0 ? au : 0x80);
     }
     if (threadIdx.x < 16) {
         const int t = threadIdx.x;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             // of them (a1 is a probability of a base under the damage and error model, 1e-12 at the very least: eight fit a
             // double with room to spare; a1 = 0 -- a graph byte outside ACGT in a regular column -- gives log 0 = -inf either way)
             double lik = 0.0, lik2 = 0.0, prod = 1.0;
-            uint32_t carry_n = 0, carry_sc = 0, step = 0;
+            uint32_t carry_n = 0, carry_sc = 0, step = 0, n_reg = 0, n_same = 0;
             bool bad = false;
             const uint32_t maxG = wave_max4(G);
             for (uint32_t base = 0; base < maxG; base += EK_GROUP) {
@@ -271,45 +274,49 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 const double d1 = w_miss * e[16 + o1] + dw * mcol[o1];
                 const double d3 = w_miss * e[16 + o3] + dw * mcol[o3];
                 double p = (1.0 - pair_dist) * d0 + pair_dist * (0.95238 * d2 + 0.02381 * (d1 + d3));
-                p = gi < 4u ? p : 0.0; // a graph base outside ACGT has no t_T_ratio entry
-                // model 1 = c1 + log(a1), model 2 = l2; the cases only pick a1 / c1 / l2, so one log serves all of them
+                // model 1 = c1 + log(a1), model 2 = l2.  A regular column of two ACGT bytes -- all but a few per thousand -- has
+                // a1 = p, c1 = 0 and l2 one of two constants, which are counted instead of added; everything else (an inactive
+                // lane included) starts from a1 = 1, c1 = l2 = 0 and the cases below pick what differs
+                const bool regular = active && kind == 4u && gi < 4u;
                 if (kind == 4u && active && n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
-                double a1 = kind == 4u ? p : 1.0, c1 = 0.0;
-                double l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
+                double a1 = regular ? p : 1.0, c1 = 0.0, l2 = 0.0;
+                n_same += (regular && gc == rc) ? 1u : 0u;
+                n_reg += regular ? 1u : 0u;
                 // N / gap / rare / softclip columns are a few per thousand: the whole wave skips their selects unless it has one
-                if (__builtin_amdgcn_ballot_w64(active && kind != 4u)) {
+                if (__builtin_amdgcn_ballot_w64(active && !regular)) {
                     const uint32_t scb = row_bits(active && kind == 3u);
                     const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
                     carry_sc += (uint32_t)__builtin_popcount(scb);
                     const double bfl = bfl_s[rcl & 15u];
-                    if (kind == 3u) { // :263-280
+                    if (active && kind == 4u && !regular) { // a graph base outside ACGT has no t_T_ratio entry: p = 0
+                        a1 = 0.0;
+                        l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
+                    }
+                    if (active && kind == 3u) { // :263-280
                         a1 = (sc_index % 3u == 0u) ? w_hit : w_miss;
                         l2 = -1.3862943611198906; // log(0.25)
                     }
-                    if (kind == 2u) { // :252-257
+                    if (active && kind == 2u) { // :252-257
                         a1 = (1.0 - pair_dist) * 0.001;
                         l2 = -6.907755278982137; // log(0.001)
                     }
-                    if (kind == 1u) { // :244-249
+                    if (active && kind == 1u) { // :244-249
                         c1 = -6.214608098422191;  // log(0.002)
                         l2 = -1.6094379124341003; // log(0.2)
                     }
-                    if (kind == 0u) c1 = l2 = bfl; // :236-241
-                }
-                if (!active) {
-                    a1 = 1.0;
-                    c1 = l2 = 0.0;
+                    if (active && kind == 0u) c1 = l2 = bfl; // :236-241
+                    lik += c1;
+                    lik2 += l2;
                 }
                 prod *= a1;
-                lik += c1;
                 if ((++step & 7u) == 0u) {
                     lik += log_tab(prod, true, logtab_s); // log(1) == 0 exactly
                     prod = 1.0;
                 }
-                lik2 += l2;
                 carry_n += (uint32_t)__builtin_popcount(nongap);
             }
             if (step & 7u) lik += log_tab(prod, true, logtab_s);
+            lik2 += (double)n_same * -0.2948543988682102 /* log(1-0.25536) */ + (double)(n_reg - n_same) * -1.3650809647206932 /* log(0.25536) */;
             const double in = row_sum16(lik), out = row_sum16(lik2);
             bad = row_bits(bad) != 0u;
             if (sub == 0 && have) {
@@ -320,14 +327,11 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             const bool live = have && !bad;
             // Baseshift::baseshift_calc: first / last lengthToProf columns (baseshift.cpp:57-88)
             for (int p = (int)sub; p < 2 * d.ltp; p += EK_GROUP) {
-                const int64_t gi = p < d.ltp ? p : (int64_t)G - 2 * d.ltp + p;
-                const int64_t ri = p < d.ltp ? p : (int64_t)A - 2 * d.ltp + p;
-                if (live && gi >= 0 && ri >= 0 && gi < (int64_t)G && ri < (int64_t)A) {
-                    uint32_t gb = b.graph_seq[col0 + gi], rb = b.read_seq[col0 + ri];
-                    gb = (gb >= 'a' && gb <= 'z') ? gb - 32u : gb;
-                    rb = (rb >= 'a' && rb <= 'z') ? rb - 32u : rb;
-                    const int g4i = acgt_index(gb), r4i = acgt_index(rb);
-                    if (g4i >= 0 && r4i >= 0) {
+                const int gp = p < d.ltp ? p : (int)G - 2 * d.ltp + p; // (lengths are below 2^16)
+                const int rp = p < d.ltp ? p : (int)A - 2 * d.ltp + p;
+                if (live && gp >= 0 && rp >= 0 && gp < (int)G && rp < (int)A) {
+                    const uint32_t g4i = up4_s[b.graph_seq[col0 + (uint32_t)gp]], r4i = up4_s[b.read_seq[col0 + (uint32_t)rp]];
+                    if ((g4i | r4i) < 4u) {
                         if (in_acc && shift_in_lds) atomicAdd(&acc.shift[p * 16 + g4i * 4 + r4i], 1u);
                         else atomicAdd(&baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4i * 4 + r4i], 1u);
                     }
