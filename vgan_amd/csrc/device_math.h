@@ -51,12 +51,16 @@ __device__ __forceinline__ double log_pos(double x) {
     return dk * 6.93147180369123816490e-01 - ((hfsq - fma(sq, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
 }
 
+// the same out of line: for branches no lane takes in practice (inlined there, the series' constants are hoisted out of the
+// caller's loops and held -- or spilled -- for the whole kernel)
+__device__ __attribute__((noinline)) double log_pos_cold(double x) { return log_pos(x); }
+
 // log(x) through the table staged in LDS (log_tab.h).  Lanes with `wanted` false may hold anything and get anything
 // back; a wanted x outside the normal positive range takes the series above (a branch no lane takes in practice).
 __device__ __forceinline__ double log_tab(double x, bool wanted, const LogTabEntry *tab_lds) {
     const bool ok = ((uint32_t)__double2hiint(x) - 0x00100000u) < 0x7FE00000u; // positive, normal, finite
     double r = log_tab_eval(x, tab_lds);
-    if (__builtin_expect(wanted && !ok, 0)) r = log_pos(x);
+    if (__builtin_expect(wanted && !ok, 0)) r = log_pos_cold(x);
     return r;
 }
 

@@ -54,6 +54,21 @@ struct EkAcc {
     int32_t count;
 };
 
+// clade_like and its log for one read (readGAM_Euka.h:485-492).  Out of line: inlined, libm's constants are hoisted out of
+// the kernel's loops and held in registers -- or spilled -- through the column loop.
+struct EkLike {
+    double like, log_like;
+};
+__device__ __attribute__((noinline)) EkLike ek_clade_like(double in, double out, double map_q) {
+    double lse;
+    if (in == 0.0) lse = out; // oplusInitnatl: a running value of 0 means "empty"
+    else lse = fmax(in, out) + log1p(exp(-fabs(in - out)));
+    const double like = map_q * exp(in - lse);
+    return EkLike{like, log(like)};
+}
+// 1 - 10^(-mapq/10) for a negative mapq (cannot be encoded by a well-formed GAM; evaluated for completeness)
+__device__ __attribute__((noinline)) double ek_map_q_cold(int32_t mapq) { return 1.0 - exp(-0.1 * mapq * 2.302585092994046); }
+
 // A wave's block of 64 reads between the stages of the kernel (a lane per read / a row of 16 lanes per read)
 struct EkBlk {
     uint32_t col0[64], ga[64], lq[64], q0[64], m0[64], nm[64]; // ga: |graph| | |read columns| << 16; lq: |sequence| | |quality| << 16
@@ -360,11 +375,10 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             if (bad_m && lane == 0) atomicAdd(o.n_bad, (unsigned long long)__builtin_popcountll(bad_m));
             // 1 - 10^(-mapq/10): table for 0..255; beyond it the subtrahend is below 1 ulp of 1 (negative mapq cannot be encoded
             // by a well-formed GAM, it is evaluated with exp for completeness)
-            const double map_q = mapq >= 256 ? 1.0 : (mapq >= 0 ? d.mapq_ok[mapq] : 1.0 - exp(-0.1 * mapq * 2.302585092994046));
-            double lse;
-            if (in == 0.0) lse = out; // oplusInitnatl: a running value of 0 means "empty"
-            else lse = fmax(in, out) + log1p(exp(-fabs(in - out)));
-            const double like = map_q * exp(in - lse);
+            double map_q = mapq >= 256 ? 1.0 : d.mapq_ok[max(mapq, 0)];
+            if (__builtin_expect(mapq < 0, 0)) map_q = ek_map_q_cold(mapq);
+            const EkLike cl = ek_clade_like(in, out, map_q);
+            const double like = cl.like;
             const bool pass = live && (in - out > 1.0) && ((uint32_t)mapq > d.min_mapq); // :504-510 (unsigned compare)
             if (live) {
                 o.clade[r] = c_n;
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             if (pass) blk.flags[lane] = fl | 4u;
             // the abundance MCMC only ever uses sum_k log(frac * clade_like[k]) per clade (MCMC.cpp:1175-1215, (1/334) == 0):
             // keep the count and the sum of logs; a read with like == 0 (mapq 0, or exp underflow) makes the sum -inf as there
-            const double ll = log(like);
+            const double ll = cl.log_like;
             const uint64_t acc_m = __builtin_amdgcn_ballot_w64(live && in_acc);
             if (acc_m) { // the reads of the wave's clade: one sum, one count
                 const double s = wave_sum(live && in_acc ? ll : 0.0);
