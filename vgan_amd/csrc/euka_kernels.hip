@@ -234,6 +234,18 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- B: a row per read, four reads per step
+        // (a group's first three bytes per lane are requested while the group in front is closed: see the column loop)
+        uint32_t gc_next, rc_next;
+        int q_next;
+        auto first_bytes = [&](uint32_t g4n) {
+            const uint32_t i = min(g4n + grp, nb - 1u);
+            const uint32_t col0 = blk.col0[i], q0 = blk.q0[i];
+            const uint32_t g_last = max(blk.ga[i] & 0xFFFFu, 1u) - 1u, q_last = max(blk.lq[i] >> 16, 1u) - 1u;
+            gc_next = b.graph_seq[col0 + min(sub, g_last)];
+            rc_next = b.read_seq[col0 + min(sub, g_last)];
+            q_next = (int)(int8_t)b.qual[q0 + min(sub, q_last)];
+        };
+        first_bytes(0);
         for (uint32_t g4 = 0; g4 < nb; g4 += EK_READS_PER_WAVE) {
             const bool have = g4 + grp < nb; // this row has a read
             const uint32_t i = min(g4 + grp, nb - 1u);
@@ -251,13 +263,20 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             uint32_t carry_n = 0, carry_sc = 0, step = 0, n_reg = 0, n_same = 0;
             bool bad = false;
             const uint32_t maxG = wave_max4(G);
+            // a step's three bytes are loaded a step ahead (unconditional loads at clamped addresses, selected afterwards):
+            // their latency lies behind the step in front instead of in front of their own
+            const uint32_t g_last = max(ga & 0xFFFFu, 1u) - 1u, q_last = max(QL, 1u) - 1u;
             for (uint32_t base = 0; base < maxG; base += EK_GROUP) {
                 const uint32_t m = base + sub;
                 const bool active = m < G;
-                // unconditional loads at clamped addresses, selected afterwards: the loads of a column overlap
-                const uint32_t mc = min(m, max(G, 1u) - 1u);
-                const uint32_t gc_raw = b.graph_seq[col0 + mc], rc_raw = b.read_seq[col0 + mc];
-                const int q_raw = (int)(int8_t)b.qual[q0 + min(m, max(QL, 1u) - 1u)];
+                const uint32_t gc_raw = gc_next, rc_raw = rc_next;
+                const int q_raw = q_next;
+                {
+                    const uint32_t m2 = m + EK_GROUP;
+                    gc_next = b.graph_seq[col0 + min(m2, g_last)];
+                    rc_next = b.read_seq[col0 + min(m2, g_last)];
+                    q_next = (int)(int8_t)b.qual[q0 + min(m2, q_last)];
+                }
                 const uint32_t gc = active ? gc_raw : 0u;
                 const uint32_t rc = (active && m < A) ? rc_raw : 0u;
                 const uint32_t gcl = cls_s[gc], rcl = cls_s[rc];
@@ -330,6 +349,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 }
                 carry_n += (uint32_t)__builtin_popcount(nongap);
             }
+            if (g4 + EK_READS_PER_WAVE < nb) first_bytes(g4 + EK_READS_PER_WAVE);
             if (step & 7u) lik += log_tab(prod, true, logtab_s);
             lik2 += (double)n_same * -0.2948543988682102 /* log(1-0.25536) */ + (double)(n_reg - n_same) * -1.3650809647206932 /* log(0.25536) */;
             const double in = row_sum16(lik), out = row_sum16(lik2);
