@@ -74,6 +74,7 @@ struct vgan_sb_ctx {
     // the chain driver's refresh (one state per call, launch bound) is one kernel writing into pinned host memory
     char *pin = nullptr;                 // out double[16] | guard u64[16] | sums SbFix[16]
     bool time_refresh = false;           // HIP events around the engine's refresh too (vgan_sb_time_engine)
+    uint64_t refresh_seq = 0;            // refreshes launched so far (the finishing kernel leaves the number in the pinned block)
     Buf<unsigned long long> ticket;      // guard counts (one per state) of the fused refresh, zero between refreshes
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[2] = {false, false};
@@ -433,12 +434,14 @@ static int loglike_impl(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vga
 // n_states states of k sources each, results to the host: the per-iteration call of the chain driver (the chains of one source
 // count advance together) -- sb_refresh_fused_kernel with the sources as kernel arguments, then one wave per state folding
 // the partials into pinned host memory; bit-identical to vgan_sb_loglike.
-constexpr size_t SB_PIN_BYTES = 2 * SB_FUSED_MAX_K * 8 + SB_FUSED_MAX_K * sizeof(SbFix);
+constexpr size_t SB_PIN_SEQ_OFF = 2 * SB_FUSED_MAX_K * 8 + SB_FUSED_MAX_K * sizeof(SbFix); // u64[16]: the refresh that wrote the entry
+constexpr size_t SB_PIN_BYTES = SB_PIN_SEQ_OFF + SB_FUSED_MAX_K * 8;
 
 // launch half: everything is queued on the context's stream, nothing is waited for.  *general: the states did not fit the
 // kernel-argument staging and went through vgan_sb_loglike (already complete: results in gen_*).
 struct SbPending {
     bool general = false;
+    uint64_t seq = 0; // the refresh's number: what the finishing kernel leaves in the pinned block behind its results
     std::vector<double> gen_out;
     std::vector<vgan_sb_sum> gen_sum;
     std::vector<uint64_t> gen_guard;
@@ -480,7 +483,10 @@ static int refresh_launch(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const v
     const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
     int rc;
     if ((rc = c->partial.reserve((size_t)n_states * n_blocks))) return rc;
-    if (!c->pin) HIPCHK(hipHostMalloc((void **)&c->pin, SB_PIN_BYTES, hipHostMallocDefault));
+    if (!c->pin) {
+        HIPCHK(hipHostMalloc((void **)&c->pin, SB_PIN_BYTES, hipHostMallocDefault));
+        memset(c->pin, 0, SB_PIN_BYTES);
+    }
     if (!c->ticket.p) {
         if ((rc = c->ticket.reserve(SB_FUSED_MAX_K))) return rc;
         HIPCHK(hipMemsetAsync(c->ticket.p, 0, SB_FUSED_MAX_K * 8, c->stream));
@@ -492,7 +498,9 @@ static int refresh_launch(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const v
         resolve(c, 1);
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
     }
-    launch_sb_refresh_fused(c->t, n_states, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, pin_fix, c->stream,
+    pd.seq = ++c->refresh_seq;
+    launch_sb_refresh_fused(c->t, n_states, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, pin_fix,
+                            reinterpret_cast<unsigned long long *>(c->pin + SB_PIN_SEQ_OFF), pd.seq, c->stream,
                             c->time_refresh ? c->ev[3] : nullptr);
     if (c->time_refresh) c->pending[1] = true;
     HIPCHK(hipGetLastError());
@@ -509,7 +517,24 @@ static int refresh_collect(vgan_sb_ctx *c, uint32_t n_states, const SbPending &p
         return VGAN_OK;
     }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // The finishing kernel writes the refresh's number behind each state's results (system-scope fence in between): the host
+    // watches those words instead of sleeping in hipStreamSynchronize -- an MCMC iteration is one such wait, and the wake-up
+    // was a tenth of it.  The stream is asked now and then so that a failed launch ends the wait.
+    {
+        const volatile uint64_t *seq = reinterpret_cast<const volatile uint64_t *>(c->pin + SB_PIN_SEQ_OFF);
+        for (uint32_t spins = 0;; ++spins) {
+            bool all = true;
+            for (uint32_t e = 0; e < n_states; ++e) all = all && seq[e] == pd.seq;
+            if (all) break;
+            if ((spins & 0xFFFu) == 0xFFFu) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) break; // (everything queued has run: the words are there)
+                if (q != hipErrorNotReady) return fail(VGAN_ENODEV, "vgan_sb_engine refresh: the stream failed");
+            }
+            __builtin_ia32_pause();
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     const double *pin_out = reinterpret_cast<const double *>(c->pin);
     const unsigned long long *pin_guard = reinterpret_cast<const unsigned long long *>(c->pin + SB_FUSED_MAX_K * 8);
     const SbFix *pin_fix = reinterpret_cast<const SbFix *>(c->pin + 2 * SB_FUSED_MAX_K * 8);

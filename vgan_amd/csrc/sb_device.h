@@ -88,8 +88,8 @@ void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const
 // guard = n_states zeroed device words (left zeroed); partial: n_states * n_blocks entries.  Bit-identical to launch_sb_hky +
 // launch_sb_loglike.
 void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, SbFix *partial, uint32_t n_blocks,
-                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host, hipStream_t st,
-                             hipEvent_t after_main /* recorded between the two kernels when not null */);
+                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host,
+                             unsigned long long *seq_host, unsigned long long seq, hipStream_t st, hipEvent_t after_main);
 // per-read best path (-1: tie or excluded read), per-path signature counts and the number of usable reads; counters zeroed by the caller
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
                           unsigned long long *n_ok, hipStream_t st);

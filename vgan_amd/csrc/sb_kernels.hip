@@ -672,7 +672,8 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesD
 // one wave per state
 __global__ __launch_bounds__(64) void sb_finish_host_kernel(const SbFix *__restrict__ partial, uint32_t n_blocks,
                                                             unsigned long long *__restrict__ guard, double *__restrict__ out_host,
-                                                            unsigned long long *__restrict__ guard_host, SbFix *__restrict__ fix_host) {
+                                                            unsigned long long *__restrict__ guard_host, SbFix *__restrict__ fix_host,
+                                                            unsigned long long *__restrict__ seq_host, unsigned long long seq) {
     const uint32_t e = blockIdx.x;
     const SbFix s = sb_fix_fold(partial + (size_t)e * n_blocks, n_blocks);
     if (threadIdx.x == 0) {
@@ -680,6 +681,10 @@ __global__ __launch_bounds__(64) void sb_finish_host_kernel(const SbFix *__restr
         if (fix_host) fix_host[e] = s;
         guard_host[e] = guard[e];
         guard[e] = 0; // ready for the next refresh (stream ordered)
+        if (seq_host) { // the host may be watching this word instead of waiting for the stream: results first, then the number
+            __threadfence_system();
+            __hip_atomic_store(&seq_host[e], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -750,11 +755,12 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_mixture_kernel(SbTablesDev t, 
 
 // ---------------------------------------------------------------------------------------------- launchers
 void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, SbFix *partial, uint32_t n_blocks,
-                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host, hipStream_t st,
-                             hipEvent_t after_main) {
+                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host,
+                             unsigned long long *seq_host, unsigned long long seq, hipStream_t st, hipEvent_t after_main) {
     hipLaunchKernelGGL(sb_refresh_fused_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, n_states, k, a, partial, guard);
     if (after_main) (void)hipEventRecord(after_main, st); // the timed interval is the fused kernel alone
-    hipLaunchKernelGGL(sb_finish_host_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host, fix_host);
+    hipLaunchKernelGGL(sb_finish_host_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host, fix_host,
+                       seq_host, seq);
 }
 
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
