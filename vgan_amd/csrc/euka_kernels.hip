@@ -93,10 +93,14 @@ __device__ __forceinline__ double row_sum16(double v) {
 // outputs, base shifts, bin coverage) runs for the wave's four reads at once.
 template <bool DMG_LDS>
 __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, EukaBatchDev b, EukaOutDev o) {
-    __shared__ double2 qs_s[100]; // {eps(Q), eps(Q) / 3}: the quotient from a table -- an fp64 division is eleven instructions, one of
-                                  // them the quarter-rate reciprocal, per column
+    // {w_miss, w_hit - w_miss} = {eps(Q) / 3, (1 - eps(Q)) - eps(Q) / 3}: from a table -- an fp64 division is eleven instructions,
+    // one of them the quarter-rate reciprocal, per column (w_hit itself is only needed on a softclip column: 1 - d.qscore[q] there)
+    __shared__ double2 qs_s[100];
     __shared__ LogTabEntry logtab_s[64];
-    __shared__ double dmg_s[DMG_LDS ? EK_DMG_LDS_PAIRS * 20 : 1];
+    // per (5' row, 3' row) pair, read base rb and original base o: {M[o][rb], rowsum[o]} -- what a column needs for one original
+    // base in ONE 16-byte read, and the four original bases of a column (o, o ^ 1, o ^ 2, o ^ 3) at addresses that differ by an
+    // exclusive-or of the 16-byte index (256 bytes per pair; the global table of euka_device.h keeps its 160)
+    __shared__ double2 dmg_s[DMG_LDS ? EK_DMG_LDS_PAIRS * 16 : 1];
     // byte -> class: low nibble = ACGT index 0..3, else 8; high nibble = the rank of the lambda's special cases in
     // the order it tests them (readGAM_Euka.h:236-280): 0 'N', 1 '-', 2 rare IUPAC code, 3 'S', 4 none
     __shared__ uint8_t cls_s[256];
@@ -115,16 +119,21 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         const int t = threadIdx.x;
         bfl_s[t] = base_freq_log(t == 0 ? 'A' : t == 1 ? 'C' : t == 2 ? 'G' : t == 3 ? 'T' : t == 9 ? 'N' : 0u);
     }
-    for (int i = threadIdx.x; i < 100; i += blockDim.x) qs_s[i] = double2{d.qscore[i], d.qscore[i] / 3.0};
+    for (int i = threadIdx.x; i < 100; i += blockDim.x) {
+        const double qs = d.qscore[i], w_miss = qs / 3.0;
+        qs_s[i] = double2{w_miss, (1.0 - qs) - w_miss};
+    }
     for (int i = threadIdx.x; i < 64; i += blockDim.x) logtab_s[i] = euka_log_table[i];
     if (DMG_LDS)
-        for (uint32_t i = threadIdx.x; i < d.n5 * d.n3 * 20u; i += blockDim.x) dmg_s[i] = d.dmg_pair[i];
+        for (uint32_t i = threadIdx.x; i < d.n5 * d.n3 * 16u; i += blockDim.x) {
+            const uint32_t pair = i >> 4, rb = (i >> 2) & 3u, o = i & 3u;
+            dmg_s[i] = double2{d.dmg_pair[pair * 20u + 4u * rb + o], d.dmg_pair[pair * 20u + 16u + o]};
+        }
     {
         uint32_t *z = reinterpret_cast<uint32_t *>(acc_s);
         for (uint32_t i = threadIdx.x; i < sizeof(acc_s) / 4; i += blockDim.x) z[i] = 0u;
     }
     __syncthreads();
-    const double *const dmg = DMG_LDS ? dmg_s : d.dmg_pair;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     EkAcc &acc = acc_s[wave];
     const bool shift_in_lds = d.ltp <= EK_ACC_LTP;
@@ -287,26 +296,37 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 int q = (m < QL && QL > 0u) ? q_raw : 0; // Q15
                 q = q < 0 ? 0 : (q > 99 ? 99 : q);
                 const double2 qe = qs_s[q];
-                const double qs = qe.x;
                 // the regular column (:283-400), evaluated for every lane: p = sum_o pre[o] * sum_b M[o][b] * w[b] with
                 // w = w_miss except w[read base] = w_hit, i.e. per original base o: w_miss * rowsum[o] + (w_hit - w_miss) * M[o][rb],
                 // and pre = 1 - dist at the graph base g, dist * 0.95238 at its transition partner g^2, dist * 0.02381 at the
-                // other two (:312-318, Euka.cpp:453-468).  Pair table layout: euka_device.h.
+                // other two (:312-318, Euka.cpp:453-468).
                 const uint32_t gi = gcl & 15u, ri = rcl & 15u; // 0..3, or 8 / 9 outside ACGT
                 const uint32_t nn = min(n, Lseq - 1u);
                 // (24-bit multiplies: positions and table sizes are below 2^24, and the full 32-bit multiply is a quarter-rate instruction)
-                uint32_t pair_ix, e_ix; // (spelled out: the compiler forms a quarter-rate 64-bit multiply-add for the same expression)
+                uint32_t pair_ix; // (spelled out: the compiler forms a quarter-rate 64-bit multiply-add for the same expression)
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair_ix) : "v"(min(nn, d.n5 - 1u)), "s"(d.n3), "v"(min(Lseq - 1u - nn, d.n3 - 1u)));
-                asm("v_mul_u32_u24 %0, 20, %1" : "=v"(e_ix) : "v"(pair_ix));
-                const double *e = dmg + e_ix;
-                const double w_hit = 1.0 - qs, w_miss = qe.y;
-                const double dw = ri < 4u ? w_hit - w_miss : 0.0; // a read base outside ACGT matches no column
-                const double *mcol = e + 4u * (ri & 3u);        // M[.][read base]
-                const uint32_t o0 = gi & 3u, o1 = o0 ^ 1u, o2 = o0 ^ 2u, o3 = o0 ^ 3u;
-                const double d0 = w_miss * e[16 + o0] + dw * mcol[o0];
-                const double d2 = w_miss * e[16 + o2] + dw * mcol[o2];
-                const double d1 = w_miss * e[16 + o1] + dw * mcol[o1];
-                const double d3 = w_miss * e[16 + o3] + dw * mcol[o3];
+                const double w_miss = qe.x;
+                const double dw = ri < 4u ? qe.y : 0.0; // a read base outside ACGT matches no column
+                const uint32_t o0 = gi & 3u;
+                double d0, d1, d2, d3;
+                if constexpr (DMG_LDS) {
+                    const uint32_t ix = (pair_ix << 4) | ((ri & 3u) << 2) | o0; // entry {M[o0][rb], rowsum[o0]}
+                    const double2 e0 = dmg_s[ix], e1 = dmg_s[ix ^ 1u], e2 = dmg_s[ix ^ 2u], e3 = dmg_s[ix ^ 3u];
+                    d0 = w_miss * e0.y + dw * e0.x;
+                    d2 = w_miss * e2.y + dw * e2.x;
+                    d1 = w_miss * e1.y + dw * e1.x;
+                    d3 = w_miss * e3.y + dw * e3.x;
+                } else {
+                    uint32_t e_ix;
+                    asm("v_mul_u32_u24 %0, 20, %1" : "=v"(e_ix) : "v"(pair_ix));
+                    const double *e = d.dmg_pair + e_ix; // pair table layout: euka_device.h
+                    const double *mcol = e + 4u * (ri & 3u); // M[.][read base]
+                    const uint32_t o1 = o0 ^ 1u, o2 = o0 ^ 2u, o3 = o0 ^ 3u;
+                    d0 = w_miss * e[16 + o0] + dw * mcol[o0];
+                    d2 = w_miss * e[16 + o2] + dw * mcol[o2];
+                    d1 = w_miss * e[16 + o1] + dw * mcol[o1];
+                    d3 = w_miss * e[16 + o3] + dw * mcol[o3];
+                }
                 double p = (1.0 - pair_dist) * d0 + pair_dist * (0.95238 * d2 + 0.02381 * (d1 + d3));
                 // model 1 = c1 + log(a1), model 2 = l2.  A regular column of two ACGT bytes -- all but a few per thousand -- has
                 // a1 = p, c1 = 0 and l2 one of two constants, which are counted instead of added; everything else (an inactive
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                         l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
                     }
                     if (active && kind == 3u) { // :263-280
-                        a1 = (sc_index % 3u == 0u) ? w_hit : w_miss;
+                        a1 = (sc_index % 3u == 0u) ? 1.0 - d.qscore[q] : w_miss; // w_hit
                         l2 = -1.3862943611198906; // log(0.25)
                     }
                     if (active && kind == 2u) { // :252-257
