@@ -50,6 +50,21 @@ def test_synthetic_clades_with_damage():
     compare(g, db, a, ("", ""), min_mapq=0, ltp=3)
 
 
+@pytest.mark.parametrize("blocks", ["3", "11"])
+def test_full_blocks_of_reads_per_wave(monkeypatch, blocks):
+    """The kernel takes a wave's reads in blocks of 64 (a lane per read around the column loop): few workgroups give every wave
+    several full blocks and a ragged last one, with clade boundaries inside blocks (VGAN_EUKA_BLOCKS caps the grid; a launch of
+    the default size gives a wave of a small batch four reads)."""
+    monkeypatch.setenv("VGAN_EUKA_BLOCKS", blocks)
+    d = os.path.join(GOLD, "damageProfiles")
+    texts = (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read())
+    dm = ek.Damage.from_text(*texts)
+    g, db, a = ek.synth_euka(5003, dm, seed=17, n_clades=12, nodes_per_clade=200)
+    got, fin, ref = compare(g, db, a, texts)
+    assert got["pass"].sum() > 1500
+    compare(g, db, a, ("", ""), min_mapq=0, ltp=12)  # base shifts beyond the LDS accumulators' length
+
+
 def test_special_columns_and_filters():
     seqs = [b"ACGTNACGTRACGTACGTACGTAAAA", b"CCCCGGGGTTTTAAAACCCCGGGGTTTT", b"ACGTACGTACGTACGTACGT"]
     node_seq = b"".join(seqs)
