@@ -275,10 +275,18 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             // a step's three bytes are loaded a step ahead (unconditional loads at clamped addresses, selected afterwards):
             // their latency lies behind the step in front instead of in front of their own
             const uint32_t g_last = max(ga & 0xFFFFu, 1u) - 1u, q_last = max(QL, 1u) - 1u;
+            const uint32_t n_sign = rev ? 0xFFFFFFFFu : 1u, n_base = rev ? Lseq - 1u : 0u; // the damage position from the non-gap count
             for (uint32_t base = 0; base < maxG; base += EK_GROUP) {
                 const uint32_t m = base + sub;
-                const bool active = m < G;
-                const uint32_t gc_raw = gc_next, rc_raw = rc_next;
+                // lane masks are kept as what the compares write -- a pair of scalar registers -- and combined there: as a bool a
+                // condition that is the AND of two compares goes through a register and a second compare before a ballot
+                uint64_t act_m, in_a_m, in_q_m;
+                asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(act_m) : "v"(m), "v"(G));
+                asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(in_a_m) : "v"(m), "v"(A));
+                asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(in_q_m) : "v"(m), "v"(QL));
+                const bool active = __builtin_amdgcn_inverse_ballot_w64(act_m);
+                const uint32_t gc = gc_next; // (an inactive lane holds the row's last column: everything it feeds is masked)
+                const uint32_t rc = __builtin_amdgcn_inverse_ballot_w64(act_m & in_a_m) ? rc_next : 0u;
                 const int q_raw = q_next;
                 {
                     const uint32_t m2 = m + EK_GROUP;
@@ -286,14 +294,16 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                     rc_next = b.read_seq[col0 + min(m2, g_last)];
                     q_next = (int)(int8_t)b.qual[q0 + min(m2, q_last)];
                 }
-                const uint32_t gc = active ? gc_raw : 0u;
-                const uint32_t rc = (active && m < A) ? rc_raw : 0u;
                 const uint32_t gcl = cls_s[gc], rcl = cls_s[rc];
-                const uint32_t nongap = row_bits(active && rc != '-');
+                uint64_t nongap_m;
+                asm("v_cmp_ne_u32 %0, 45, %1" : "=s"(nongap_m) : "v"(rc)); // '-'
+                nongap_m &= act_m;
+                const uint32_t nongap = (uint32_t)(nongap_m >> gshift) & 0xFFFFu;
                 const uint32_t n_before = carry_n + (uint32_t)__builtin_popcount(nongap & below);
-                const uint32_t n = rev ? (Lseq - 1u - n_before) : n_before; // unsigned wrap as in the reference
-                const uint32_t kind = min(gcl >> 4, rcl >> 4);                // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
-                int q = (m < QL && QL > 0u) ? q_raw : 0; // Q15
+                // forward: n_before; reverse strand: Lseq - 1 - n_before (unsigned wrap as in the reference)
+                uint32_t n;
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(n) : "v"(n_before), "v"(n_sign), "v"(n_base));
+                int q = __builtin_amdgcn_inverse_ballot_w64(in_q_m) ? q_raw : 0; // Q15 (m < QL is false for an empty string)
                 q = q < 0 ? 0 : (q > 99 ? 99 : q);
                 const double2 qe = qs_s[q];
                 // the regular column (:283-400), evaluated for every lane: p = sum_o pre[o] * sum_b M[o][b] * w[b] with
@@ -331,13 +341,24 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 // model 1 = c1 + log(a1), model 2 = l2.  A regular column of two ACGT bytes -- all but a few per thousand -- has
                 // a1 = p, c1 = 0 and l2 one of two constants, which are counted instead of added; everything else (an inactive
                 // lane included) starts from a1 = 1, c1 = l2 = 0 and the cases below pick what differs
-                const bool regular = active && kind == 4u && gi < 4u;
-                if (kind == 4u && active && n >= Lseq) bad = true; // subDeamDiNuc[Lseq][n] out of range in the reference
+                // regular: both bytes' ranks are 4 (no special case) and the graph byte is one of ACGT -- one compare of the two class
+                // bytes side by side (class byte: index in the low nibble, 8 / 9 outside ACGT; rank in the high one)
+                const uint32_t cls2 = gcl | (rcl << 8);
+                uint64_t regular_m, same_m, past_m;
+                asm("v_cmp_eq_u32 %0, %1, %2" : "=s"(regular_m) : "v"(cls2 & 0xF0FCu), "v"(0x4040u));
+                regular_m &= act_m;
+                asm("v_cmp_eq_u32 %0, %1, %2" : "=s"(same_m) : "v"(gc), "v"(rc));
+                asm("v_cmp_ge_u32 %0, %1, %2" : "=s"(past_m) : "v"(n), "v"(Lseq));
+                const bool regular = __builtin_amdgcn_inverse_ballot_w64(regular_m);
+                if (__builtin_expect((past_m & act_m) != 0, 0)) { // subDeamDiNuc[Lseq][n] out of range in the reference
+                    if (active && n >= Lseq && min(gcl >> 4, rcl >> 4) == 4u) bad = true;
+                }
                 double a1 = regular ? p : 1.0, c1 = 0.0, l2 = 0.0;
-                n_same += (regular && gc == rc) ? 1u : 0u;
+                n_same += __builtin_amdgcn_inverse_ballot_w64(regular_m & same_m) ? 1u : 0u;
                 n_reg += regular ? 1u : 0u;
                 // N / gap / rare / softclip columns are a few per thousand: the whole wave skips their selects unless it has one
-                if (__builtin_amdgcn_ballot_w64(active && !regular)) {
+                if ((act_m & ~regular_m) != 0) {
+                    const uint32_t kind = min(gcl >> 4, rcl >> 4); // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
                     const uint32_t scb = row_bits(active && kind == 3u);
                     const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
                     carry_sc += (uint32_t)__builtin_popcount(scb);
