@@ -316,17 +316,23 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 uint32_t pair_ix; // (spelled out: the compiler forms a quarter-rate 64-bit multiply-add for the same expression)
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pair_ix) : "v"(min(nn, d.n5 - 1u)), "s"(d.n3), "v"(min(Lseq - 1u - nn, d.n3 - 1u)));
                 const double w_miss = qe.x;
-                const double dw = ri < 4u ? qe.y : 0.0; // a read base outside ACGT matches no column
+                // (a read byte outside ACGT matches no column: dw = 0 there -- a case for the branch of the odd columns below)
+                double dw = qe.y;
                 const uint32_t o0 = gi & 3u;
                 double d0, d1, d2, d3;
                 if constexpr (DMG_LDS) {
-                    const uint32_t ix = (pair_ix << 4) | ((ri & 3u) << 2) | o0; // entry {M[o0][rb], rowsum[o0]}
-                    const double2 e0 = dmg_s[ix], e1 = dmg_s[ix ^ 1u], e2 = dmg_s[ix ^ 2u], e3 = dmg_s[ix ^ 3u];
+                    // byte offset of entry {M[o0][rb], rowsum[o0]}: pair * 256 + rb * 64 + o0 * 16; the other three original bases
+                    // differ in the o bits by an exclusive-or
+                    const uint32_t a0 = ((pair_ix << 8) | ((rcl << 6) & 0xC0u)) | ((gcl << 4) & 0x30u);
+                    const uint8_t *tab = reinterpret_cast<const uint8_t *>(dmg_s);
+                    const double2 e0 = *reinterpret_cast<const double2 *>(tab + a0), e1 = *reinterpret_cast<const double2 *>(tab + (a0 ^ 16u)),
+                                  e2 = *reinterpret_cast<const double2 *>(tab + (a0 ^ 32u)), e3 = *reinterpret_cast<const double2 *>(tab + (a0 ^ 48u));
                     d0 = w_miss * e0.y + dw * e0.x;
                     d2 = w_miss * e2.y + dw * e2.x;
                     d1 = w_miss * e1.y + dw * e1.x;
                     d3 = w_miss * e3.y + dw * e3.x;
                 } else {
+                    dw = ri < 4u ? dw : 0.0;
                     uint32_t e_ix;
                     asm("v_mul_u32_u24 %0, 20, %1" : "=v"(e_ix) : "v"(pair_ix));
                     const double *e = d.dmg_pair + e_ix; // pair table layout: euka_device.h
@@ -341,11 +347,11 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 // model 1 = c1 + log(a1), model 2 = l2.  A regular column of two ACGT bytes -- all but a few per thousand -- has
                 // a1 = p, c1 = 0 and l2 one of two constants, which are counted instead of added; everything else (an inactive
                 // lane included) starts from a1 = 1, c1 = l2 = 0 and the cases below pick what differs
-                // regular: both bytes' ranks are 4 (no special case) and the graph byte is one of ACGT -- one compare of the two class
-                // bytes side by side (class byte: index in the low nibble, 8 / 9 outside ACGT; rank in the high one)
+                // regular: both bytes' ranks are 4 (no special case) and both are ACGT -- one compare of the two class bytes side by
+                // side (class byte: index in the low nibble, 8 / 9 outside ACGT; rank in the high one)
                 const uint32_t cls2 = gcl | (rcl << 8);
                 uint64_t regular_m, same_m, past_m;
-                asm("v_cmp_eq_u32 %0, %1, %2" : "=s"(regular_m) : "v"(cls2 & 0xF0FCu), "v"(0x4040u));
+                asm("v_cmp_eq_u32 %0, %1, %2" : "=s"(regular_m) : "v"(cls2 & 0xFCFCu), "v"(0x4040u));
                 regular_m &= act_m;
                 asm("v_cmp_eq_u32 %0, %1, %2" : "=s"(same_m) : "v"(gc), "v"(rc));
                 asm("v_cmp_ge_u32 %0, %1, %2" : "=s"(past_m) : "v"(n), "v"(Lseq));
@@ -354,8 +360,11 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                     if (active && n >= Lseq && min(gcl >> 4, rcl >> 4) == 4u) bad = true;
                 }
                 double a1 = regular ? p : 1.0, c1 = 0.0, l2 = 0.0;
-                n_same += __builtin_amdgcn_inverse_ballot_w64(regular_m & same_m) ? 1u : 0u;
-                n_reg += regular ? 1u : 0u;
+                { // the counters take the masks as carries: an add each
+                    uint64_t co;
+                    asm("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(n_same), "=s"(co) : "s"(regular_m & same_m));
+                    asm("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(n_reg), "=s"(co) : "s"(regular_m));
+                }
                 // N / gap / rare / softclip columns are a few per thousand: the whole wave skips their selects unless it has one
                 if ((act_m & ~regular_m) != 0) {
                     const uint32_t kind = min(gcl >> 4, rcl >> 4); // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
@@ -363,8 +372,20 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                     const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
                     carry_sc += (uint32_t)__builtin_popcount(scb);
                     const double bfl = bfl_s[rcl & 15u];
-                    if (active && kind == 4u && !regular) { // a graph base outside ACGT has no t_T_ratio entry: p = 0
+                    if (active && kind == 4u && !regular) {
+                        // a graph byte outside ACGT has no t_T_ratio entry: p = 0; a read byte outside ACGT matches no column of the
+                        // damage matrix: the column's p with dw = 0 (the same expression: d = w_miss * rowsum + 0 * M exactly)
                         a1 = 0.0;
+                        if (gi < 4u) {
+                            if constexpr (DMG_LDS) {
+                                const uint32_t ix = (pair_ix << 4) | o0; // (any read base: only the row sums are used)
+                                const double z0 = w_miss * dmg_s[ix].y, z1 = w_miss * dmg_s[ix ^ 1u].y, z2 = w_miss * dmg_s[ix ^ 2u].y,
+                                             z3 = w_miss * dmg_s[ix ^ 3u].y;
+                                a1 = (1.0 - pair_dist) * z0 + pair_dist * (0.95238 * z2 + 0.02381 * (z1 + z3));
+                            } else {
+                                a1 = p; // (dw was selected above)
+                            }
+                        }
                         l2 = gc == rc ? -0.2948543988682102 /* log(1-0.25536) */ : -1.3650809647206932 /* log(0.25536) */;
                     }
                     if (active && kind == 3u) { // :263-280
