@@ -510,15 +510,22 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 const uint32_t max_nb = wave_max4(nbin), max_nm = wave_max4(nm);
                 for (uint32_t jb = 0; jb < max_nb; jb += EK_GROUP) {
                     const bool mine = jb + sub < nbin;
-                    const int32_t my_lo = mine ? d.bin_lo[b0 + jb + sub] : 1;
-                    const int32_t my_hi = mine ? d.bin_hi[b0 + jb + sub] : 0;
+                    // node in [lo, hi] as ONE unsigned compare: node - lo <= hi - lo; a lane without a bin (and a bin whose bounds
+                    // are the wrong way round) takes lo = INT_MIN, width 0: no node id -- they are below 2^31, the filler is -1 --
+                    // passes
+                    const int32_t b_lo = mine ? max(d.bin_lo[b0 + jb + sub], 0) : 1, b_hi = mine ? d.bin_hi[b0 + jb + sub] : 0; // (node ids are >= 0)
+                    const uint32_t my_lo = b_hi >= b_lo ? (uint32_t)b_lo : 0x80000000u, my_w = b_hi >= b_lo ? (uint32_t)(b_hi - b_lo) : 0u;
                     uint32_t cnt = 0;
                     for (uint32_t mb = 0; mb < max_nm; mb += EK_GROUP) {
-                        const int32_t node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1; // no bin holds -1 ...
+                        const int32_t node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1;
                         const uint32_t inn = min((uint32_t)EK_GROUP, max_nm - mb);
-                        for (uint32_t k = 0; k < inn; ++k) {
-                            const int32_t nd = __shfl(node, (int)(gshift + k), 64);
-                            cnt += (nd >= my_lo && nd <= my_hi && nd >= 0) ? 1u : 0u; // ... whatever its bounds
+                        // four nodes of the row per step: the four lane exchanges are in flight together (one at a time, each
+                        // step waited for its own)
+                        for (uint32_t k = 0; k < inn; k += 4u) {
+                            const int32_t n0 = __shfl(node, (int)(gshift + k), 64), n1 = __shfl(node, (int)(gshift + k + 1u), 64),
+                                          n2 = __shfl(node, (int)(gshift + k + 2u), 64), n3 = __shfl(node, (int)(gshift + k + 3u), 64);
+                            cnt += ((uint32_t)n0 - my_lo <= my_w ? 1u : 0u) + ((uint32_t)n1 - my_lo <= my_w ? 1u : 0u) +
+                                   ((uint32_t)n2 - my_lo <= my_w ? 1u : 0u) + ((uint32_t)n3 - my_lo <= my_w ? 1u : 0u);
                         }
                     }
                     if (cnt) {
