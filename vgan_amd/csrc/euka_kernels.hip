@@ -271,6 +271,20 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             double lik = 0.0, lik2 = 0.0, prod = 1.0;
             uint32_t carry_n = 0, carry_sc = 0, step = 0, n_reg = 0, n_same = 0;
             bool bad = false;
+            // the base-shift columns of the read's ends (Baseshift::baseshift_calc: the first / last lengthToProf columns): a lane's
+            // first one is loaded here, behind the column loop it would be a load waited for on the spot
+            uint32_t bs_g = 0u, bs_r = 0u;
+            bool bs_ok = false;
+            if ((int)sub < 2 * d.ltp) {
+                const int p = (int)sub;
+                const int gp = p < d.ltp ? p : (int)G - 2 * d.ltp + p; // (lengths are below 2^16)
+                const int rp = p < d.ltp ? p : (int)A - 2 * d.ltp + p;
+                bs_ok = have && gp >= 0 && rp >= 0 && gp < (int)G && rp < (int)A;
+                if (bs_ok) {
+                    bs_g = b.graph_seq[col0 + (uint32_t)gp];
+                    bs_r = b.read_seq[col0 + (uint32_t)rp];
+                }
+            }
             const uint32_t maxG = wave_max4(G);
             // a step's three bytes are loaded a step ahead (unconditional loads at clamped addresses, selected afterwards):
             // their latency lies behind the step in front instead of in front of their own
@@ -424,10 +438,19 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             const bool live = have && !bad;
             // Baseshift::baseshift_calc: first / last lengthToProf columns (baseshift.cpp:57-88)
             for (int p = (int)sub; p < 2 * d.ltp; p += EK_GROUP) {
-                const int gp = p < d.ltp ? p : (int)G - 2 * d.ltp + p; // (lengths are below 2^16)
-                const int rp = p < d.ltp ? p : (int)A - 2 * d.ltp + p;
-                if (live && gp >= 0 && rp >= 0 && gp < (int)G && rp < (int)A) {
-                    const uint32_t g4i = up4_s[b.graph_seq[col0 + (uint32_t)gp]], r4i = up4_s[b.read_seq[col0 + (uint32_t)rp]];
+                uint32_t gb = bs_g, rb = bs_r;
+                bool ok = bs_ok;
+                if (p >= EK_GROUP) { // (lengthToProf above 8: the further columns are loaded here)
+                    const int gp = p < d.ltp ? p : (int)G - 2 * d.ltp + p;
+                    const int rp = p < d.ltp ? p : (int)A - 2 * d.ltp + p;
+                    ok = have && gp >= 0 && rp >= 0 && gp < (int)G && rp < (int)A;
+                    if (ok) {
+                        gb = b.graph_seq[col0 + (uint32_t)gp];
+                        rb = b.read_seq[col0 + (uint32_t)rp];
+                    }
+                }
+                if (live && ok) {
+                    const uint32_t g4i = up4_s[gb], r4i = up4_s[rb];
                     if ((g4i | r4i) < 4u) {
                         if (in_acc && shift_in_lds) atomicAdd(&acc.shift[p * 16 + g4i * 4 + r4i], 1u);
                         else atomicAdd(&baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4i * 4 + r4i], 1u);
