@@ -71,8 +71,9 @@ __device__ __attribute__((noinline)) double ek_map_q_cold(int32_t mapq) { return
 
 // A wave's block of 64 reads between the stages of the kernel (a lane per read / a row of 16 lanes per read)
 struct EkBlk {
-    uint32_t col0[64], ga[64], lq[64], q0[64], m0[64], nm[64]; // ga: |graph| | |read columns| << 16; lq: |sequence| | |quality| << 16
-    uint32_t flags[64];                                         // 1 reverse strand, 2 a column beyond the damage tables, 4 passed
+    uint32_t col0[64], ga[64], lq[64], q0[64], m0[64]; // ga: |graph| | |read columns| << 16; lq: |sequence| | |quality| << 16
+    uint32_t bins[64];  // the clade's first bin (24 bits) | its number of bins << 24
+    uint32_t flags[64]; // 1 reverse strand, 2 a column beyond the damage tables, 4 passed; the read's mappings << 16
     int32_t mapq[64], cn[64];
     double pd[64], in[64], out[64];
 };
@@ -228,8 +229,11 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             blk.lq[lane] = (uint32_t)b.read_seq_len[r] | (min(b.read_qual_off[r + 1] - q0, 0xFFFFu) << 16); // (columns are below 2^16)
             blk.q0[lane] = q0;
             blk.m0[lane] = m0;
-            blk.nm[lane] = b.read_map_off[r + 1] - m0;
-            blk.flags[lane] = b.read_rev[r] != 0 ? 1u : 0u;
+            blk.flags[lane] = (b.read_rev[r] != 0 ? 1u : 0u) | (min(b.read_map_off[r + 1] - m0, 0xFFFFu) << 16);
+            {
+                const uint32_t b0 = d.bin_off[c_n];
+                blk.bins[lane] = (b0 & 0xFFFFFFu) | (min(d.bin_off[c_n + 1] - b0, 255u) << 24);
+            }
             blk.mapq[lane] = b.read_mapq[r];
             blk.cn[lane] = c_n;
             blk.pd[lane] = d.clade_dist[c_n];
@@ -519,15 +523,36 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         // ---- D: bin coverage: every mapping's node adds 1/#mappings to each bin of the clade holding it (:520-546).  A row per
         // read again: lane j of a row owns the clade's bin jb + j and counts the read's mappings that fall into it (16 nodes per
         // step, handed round the row), then adds count / #mappings once.
+        // A group's loads -- its lane's bin bounds, the first 32 of the row's mappings -- are requested while the group in front is
+        // counted (the clade's bin range was looked up in stage A): behind each other they were three round trips per group.
         if (any_pass) {
-            for (uint32_t g4 = 0; g4 < nb; g4 += EK_READS_PER_WAVE) {
+            struct EkCovIn {
+                int32_t lo, hi, n0, n1;
+            };
+            auto cov_request = [&](uint32_t g4, EkCovIn &q) {
                 const uint32_t i = min(g4 + grp, nb - 1u);
-                const bool pass = g4 + grp < nb && (blk.flags[i] & 4u) != 0;
+                const uint32_t fl = blk.flags[i], bins = blk.bins[i];
+                const bool pass = g4 + grp < nb && (fl & 4u) != 0;
+                const uint32_t b0 = bins & 0xFFFFFFu, nbin = pass ? bins >> 24 : 0u, m0 = blk.m0[i], nm = pass ? fl >> 16 : 0u;
+                q.lo = sub < nbin ? d.bin_lo[b0 + sub] : 1;
+                q.hi = sub < nbin ? d.bin_hi[b0 + sub] : 0;
+                q.n0 = sub < nm ? (int32_t)b.map_node[m0 + sub] : -1; // no bin holds -1
+                q.n1 = sub + EK_GROUP < nm ? (int32_t)b.map_node[m0 + sub + EK_GROUP] : -1;
+            };
+            EkCovIn cin, cnext;
+            cov_request(0u, cin);
+            for (uint32_t g4 = 0; g4 < nb; g4 += EK_READS_PER_WAVE) {
+                if (g4 + EK_READS_PER_WAVE < nb) cov_request(g4 + EK_READS_PER_WAVE, cnext);
+                const EkCovIn here = cin;
+                cin = cnext;
+                const uint32_t i = min(g4 + grp, nb - 1u);
+                const uint32_t fl = blk.flags[i], bins = blk.bins[i];
+                const bool pass = g4 + grp < nb && (fl & 4u) != 0;
                 if (!__builtin_amdgcn_ballot_w64(pass)) continue;
                 const int32_t c_n = blk.cn[i];
                 const bool in_acc = c_n == cur;
-                const uint32_t m0 = blk.m0[i], nm_all = blk.nm[i];
-                const uint32_t b0 = d.bin_off[c_n], nbin = pass ? d.bin_off[c_n + 1] - b0 : 0u;
+                const uint32_t m0 = blk.m0[i], nm_all = fl >> 16;
+                const uint32_t b0 = bins & 0xFFFFFFu, nbin = pass ? bins >> 24 : 0u;
                 const uint32_t nm = pass ? nm_all : 0u;
                 const double inv = 1.0 / (double)nm_all;
                 const uint32_t max_nb = wave_max4(nbin), max_nm = wave_max4(nm);
@@ -536,11 +561,17 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                     // node in [lo, hi] as ONE unsigned compare: node - lo <= hi - lo; a lane without a bin (and a bin whose bounds
                     // are the wrong way round) takes lo = INT_MIN, width 0: no node id -- they are below 2^31, the filler is -1 --
                     // passes
-                    const int32_t b_lo = mine ? max(d.bin_lo[b0 + jb + sub], 0) : 1, b_hi = mine ? d.bin_hi[b0 + jb + sub] : 0; // (node ids are >= 0)
+                    int32_t b_lo = here.lo, b_hi = here.hi;
+                    if (jb) { // (a clade with more than 16 bins)
+                        b_lo = mine ? d.bin_lo[b0 + jb + sub] : 1;
+                        b_hi = mine ? d.bin_hi[b0 + jb + sub] : 0;
+                    }
+                    b_lo = max(b_lo, 0); // (node ids are >= 0)
                     const uint32_t my_lo = b_hi >= b_lo ? (uint32_t)b_lo : 0x80000000u, my_w = b_hi >= b_lo ? (uint32_t)(b_hi - b_lo) : 0u;
                     uint32_t cnt = 0;
                     for (uint32_t mb = 0; mb < max_nm; mb += EK_GROUP) {
-                        const int32_t node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1;
+                        int32_t node = mb == 0u ? here.n0 : here.n1;
+                        if (mb >= 2u * EK_GROUP) node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1; // (beyond 32 mappings)
                         const uint32_t inn = min((uint32_t)EK_GROUP, max_nm - mb);
                         // four nodes of the row per step: the four lane exchanges are in flight together (one at a time, each
                         // step waited for its own)
