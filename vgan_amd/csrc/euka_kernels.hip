@@ -76,6 +76,7 @@ struct EkBlk {
     uint32_t flags[64]; // 1 reverse strand, 2 a column beyond the damage tables, 4 passed; the read's mappings << 16
     int32_t mapq[64], cn[64];
     double pd[64], in[64], out[64];
+    uint8_t passed[64]; // the block's reads that passed, in order (stage D takes them four at a time)
 };
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- C: a lane per read: clade_like / clade_not_like (:485-492), the outputs, the clade's sums
         bool any_pass;
+        uint32_t n_pass_blk = 0u;
         {
             const bool mine = (uint32_t)lane < nb;
             const uint32_t r = bstart + min((uint32_t)lane, nb - 1u);
@@ -498,6 +500,9 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 o.pass[r] = pass ? 1 : 0;
             }
             if (pass) blk.flags[lane] = fl | 4u;
+            const uint64_t pass_m = __builtin_amdgcn_ballot_w64(pass);
+            if (pass) blk.passed[__builtin_popcountll(pass_m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+            n_pass_blk = (uint32_t)__builtin_popcountll(pass_m);
             // the abundance MCMC only ever uses sum_k log(frac * clade_like[k]) per clade (MCMC.cpp:1175-1215, (1/334) == 0):
             // keep the count and the sum of logs; a read with like == 0 (mapq 0, or exp underflow) makes the sum -inf as there
             const double ll = cl.log_like;
@@ -530,9 +535,9 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
                 int32_t lo, hi, n0, n1;
             };
             auto cov_request = [&](uint32_t g4, EkCovIn &q) {
-                const uint32_t i = min(g4 + grp, nb - 1u);
+                const bool pass = g4 + grp < n_pass_blk; // (the rows take the reads that passed, four at a time)
+                const uint32_t i = blk.passed[min(g4 + grp, n_pass_blk - 1u)];
                 const uint32_t fl = blk.flags[i], bins = blk.bins[i];
-                const bool pass = g4 + grp < nb && (fl & 4u) != 0;
                 const uint32_t b0 = bins & 0xFFFFFFu, nbin = pass ? bins >> 24 : 0u, m0 = blk.m0[i], nm = pass ? fl >> 16 : 0u;
                 q.lo = sub < nbin ? d.bin_lo[b0 + sub] : 1;
                 q.hi = sub < nbin ? d.bin_hi[b0 + sub] : 0;
@@ -541,14 +546,13 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
             };
             EkCovIn cin, cnext;
             cov_request(0u, cin);
-            for (uint32_t g4 = 0; g4 < nb; g4 += EK_READS_PER_WAVE) {
-                if (g4 + EK_READS_PER_WAVE < nb) cov_request(g4 + EK_READS_PER_WAVE, cnext);
+            for (uint32_t g4 = 0; g4 < n_pass_blk; g4 += EK_READS_PER_WAVE) {
+                if (g4 + EK_READS_PER_WAVE < n_pass_blk) cov_request(g4 + EK_READS_PER_WAVE, cnext);
                 const EkCovIn here = cin;
                 cin = cnext;
-                const uint32_t i = min(g4 + grp, nb - 1u);
+                const bool pass = g4 + grp < n_pass_blk;
+                const uint32_t i = blk.passed[min(g4 + grp, n_pass_blk - 1u)];
                 const uint32_t fl = blk.flags[i], bins = blk.bins[i];
-                const bool pass = g4 + grp < nb && (fl & 4u) != 0;
-                if (!__builtin_amdgcn_ballot_w64(pass)) continue;
                 const int32_t c_n = blk.cn[i];
                 const bool in_acc = c_n == cur;
                 const uint32_t m0 = blk.m0[i], nm_all = fl >> 16;
