@@ -194,7 +194,7 @@ extern "C" int vgan_sb_precompute(vgan_sb_ctx *c, const vgan_sb_batch *b, int64_
     const size_t R = b->n_reads, S = b->n_segments;
     int rc;
     if ((rc = c->pm.reserve((size_t)c->P * std::max<size_t>(R, 1))) ||
-        (rc = c->cnt.reserve((size_t)c->P * SB_NCNT * std::max<size_t>(R, 1))) || (rc = c->ok.reserve(std::max<size_t>(R, 1))))
+        (rc = c->cnt.reserve((size_t)c->P * SB_NCNT * 64u * std::max<size_t>(sb_cnt_tiles((uint32_t)R), 1))) || (rc = c->ok.reserve(std::max<size_t>(R, 1))))
         return rc;
     c->t.pm = c->pm.p;
     c->t.cnt = c->cnt.p;
@@ -293,15 +293,25 @@ extern "C" int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, dou
     HIPCHK(hipSetDevice(c->device));
     const size_t n = r1 - r0, R = c->t.n_reads;
     if (n == 0) return VGAN_OK;
+    // (the counts lie tiled by 64 reads on the device: the tiles covering [r0, r1) come over per path and are laid out
+    // [path][pair][read] for the caller here)
+    const uint32_t n_tiles = sb_cnt_tiles((uint32_t)R), t0 = r0 / 64u, t1 = (r1 + 63u) / 64u;
+    std::vector<uint16_t> tiles;
+    if (cnt) tiles.resize((size_t)c->P * (t1 - t0) * SB_NCNT * 64u);
     for (uint32_t p = 0; p < c->P; ++p) {
         if (pm) HIPCHK(hipMemcpyAsync(pm + (size_t)p * n, c->t.pm + (size_t)p * R + r0, n * 8, hipMemcpyDeviceToHost, c->stream));
         if (cnt)
-            for (uint32_t j = 0; j < SB_NCNT; ++j)
-                HIPCHK(hipMemcpyAsync(cnt + ((size_t)p * SB_NCNT + j) * n, c->t.cnt + ((size_t)p * SB_NCNT + j) * R + r0, n * 2,
-                                      hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(tiles.data() + (size_t)p * (t1 - t0) * SB_NCNT * 64u, c->t.cnt + sb_cnt_index(p, t0 * 64u, n_tiles),
+                                  (size_t)(t1 - t0) * SB_NCNT * 64u * 2u, hipMemcpyDeviceToHost, c->stream));
     }
     if (ok) HIPCHK(hipMemcpyAsync(ok, c->t.ok + r0, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (cnt)
+        for (uint32_t p = 0; p < c->P; ++p)
+            for (uint32_t j = 0; j < SB_NCNT; ++j)
+                for (uint32_t r = r0; r < r1; ++r)
+                    cnt[((size_t)p * SB_NCNT + j) * n + (r - r0)] =
+                        tiles[(((size_t)p * (t1 - t0) + (r / 64u - t0)) * SB_NCNT + j) * 64u + r % 64u];
     return VGAN_OK;
 }
 

@@ -31,14 +31,26 @@ struct SbBatchDev {
 
 // Factorised result of analyse_GAM, HBM resident: the 2k paths one MCMC iteration touches are whole rows.
 //   pm  double [n_paths][R]          sum of per-base log-likelihoods (pathMap)
-//   cnt uint16 [n_paths][25][R]      counts of (reference, read) pairs over path-supported bases
+//   cnt uint16 [n_paths][R / 64][25][64]  counts of (reference, read) pairs over path-supported bases, tiled by 64 reads
 //   ok  uint8  [R]
 struct SbTablesDev {
-    double *pm;
-    uint16_t *cnt;
+    double *pm;    // [path][read]
+    uint16_t *cnt; // [path][read / 64][pair (25)][read % 64]: the 25 counts of a wave's 64 reads on one path are 3200 contiguous
+                   // bytes -- the refresh streams them (one row per pair, n_reads apart, was 25 pages per path and wave)
     uint8_t *ok;
     uint32_t n_reads;
 };
+// where (path, read)'s count of pair 0 lies (pair j: + j * 64); n_tiles = sb_cnt_tiles(n_reads)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t sb_cnt_tiles(uint32_t n_reads) { return (n_reads + 63u) / 64u; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t sb_cnt_index(uint32_t path, uint32_t read, uint32_t n_tiles) {
+    return (((size_t)path * n_tiles + read / 64u) * 25u) * 64u + read % 64u;
+}
 
 // Sums over reads are taken in fixed point, in integers (units of 2^-44): the result does not depend on how the reads are
 // dealt to lanes, waves, workgroups, contexts or GPUs -- an MCMC accept / reject must not depend on the number of devices.

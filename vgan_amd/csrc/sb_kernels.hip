@@ -421,8 +421,8 @@ __global__ __launch_bounds__(SBC_WAVES * 64) void sb_precompute_cols_kernel(SbGr
     }
 }
 
-// out[(f % P) * ncnt + f / P][r_begin + r] = in[r][f] for r < n_r, f < F: the staging rows of a chunk of reads become columns of
-// the path-major tables (ncnt = 1: pm, F = P; ncnt = 25: cnt, F = 25 * P with f = pair * P + path).  64 x 64 tiles through LDS,
+// in[r][f] for r < n_r, f < F: the staging rows of a chunk of reads become columns of the path-major tables (ncnt = 1: pm[f][read],
+// F = P; ncnt = 25: cnt, F = 25 * P with f = pair * P + path, into the tiled layout of sb_device.h).  64 x 64 tiles through LDS,
 // reads and writes both run along the fast axis of their array.
 template <class T>
 __global__ __launch_bounds__(256) void sb_transpose_kernel(const T *__restrict__ in, T *__restrict__ out, uint32_t n_r, uint32_t F,
@@ -440,8 +440,11 @@ __global__ __launch_bounds__(256) void sb_transpose_kernel(const T *__restrict__
     for (uint32_t i = 0; i < 16; ++i) {
         const uint32_t fc = wave * 16 + i, f = f0 + fc;
         if (f < F && r0 + lane < n_r) {
-            const uint32_t row = (f % P) * ncnt + f / P;
-            out[(size_t)row * R + r_begin + r0 + lane] = tile[lane][fc];
+            if (ncnt == 1u) {
+                out[(size_t)(f % P) * R + r_begin + r0 + lane] = tile[lane][fc];
+            } else { // the counts: tiled by 64 reads (sb_device.h)
+                out[sb_cnt_index(f % P, r_begin + r0 + lane, sb_cnt_tiles(R)) + (size_t)(f / P) * 64u] = tile[lane][fc];
+            }
         }
     }
 }
@@ -514,12 +517,21 @@ __device__ __forceinline__ double sb_read_term(const SbTablesDev &t, uint32_t r,
         const SbSourceDev s = src[y];
         const double *hc = hk_s + (size_t)y * 2 * SB_NCNT, *hp = hc + SB_NCNT;
         double LL = t.pm[(size_t)s.child * R + r], LLP = t.pm[(size_t)s.parent * R + r];
-        const uint16_t *cc = t.cnt + (size_t)s.child * SB_NCNT * R + r;
-        const uint16_t *cp = t.cnt + (size_t)s.parent * SB_NCNT * R + r;
+        const uint32_t n_tiles = sb_cnt_tiles(R);
+        const uint16_t *cc = t.cnt + sb_cnt_index((uint32_t)s.child, r, n_tiles);
+        const uint16_t *cp = t.cnt + sb_cnt_index((uint32_t)s.parent, r, n_tiles);
+        // all fifty counts are requested before the first is used (left to itself the compiler orders this loop load, wait, use)
+        uint32_t cv[SB_NCNT], pv[SB_NCNT];
 #pragma unroll
         for (int j = 0; j < (int)SB_NCNT; ++j) {
-            LL += (double)cc[(size_t)j * R] * hc[j];
-            LLP += (double)cp[(size_t)j * R] * hp[j];
+            cv[j] = cc[j * 64];
+            pv[j] = cp[j * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < (int)SB_NCNT; ++j) {
+            LL += (double)cv[j] * hc[j];
+            LLP += (double)pv[j] * hp[j];
         }
         if (!(LL <= 0.0) || !(LLP <= 0.0) || isinf(LL) || isinf(LLP)) bad++; // MCMC.cpp:857-862,953-958
         if (k == 1) { // calculateLogWeightedAverage (MCMC.h:299-315)
