@@ -40,6 +40,18 @@ template <int KIND> __global__ void k(double *out, int iters, unsigned long long
                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");)
         } else if constexpr (KIND == 6) { // 64 x (32-bit VALU add)
             REP64(asm volatile("v_add_u32 %0, %0, %1" : "+v"(s0) : "v"(s1));)
+        } else if constexpr (KIND == 7) { // 64 independent conversions u32 -> fp64
+            REP8(asm volatile("v_cvt_f64_u32 %0, %8\n v_cvt_f64_u32 %1, %8\n v_cvt_f64_u32 %2, %8\n v_cvt_f64_u32 %3, %8\n"
+                              "v_cvt_f64_u32 %4, %8\n v_cvt_f64_u32 %5, %8\n v_cvt_f64_u32 %6, %8\n v_cvt_f64_u32 %7, %8"
+                              : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7) : "v"(s1));)
+        } else if constexpr (KIND == 8) { // 64 independent fp64 reciprocals (a transcendental)
+            REP8(asm volatile("v_rcp_f64 %0, %8\n v_rcp_f64 %1, %8\n v_rcp_f64 %2, %8\n v_rcp_f64 %3, %8\n"
+                              "v_rcp_f64 %4, %8\n v_rcp_f64 %5, %8\n v_rcp_f64 %6, %8\n v_rcp_f64 %7, %8"
+                              : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7) : "v"(m));)
+        } else if constexpr (KIND == 9) { // 64 independent 32-bit multiplies (v_mul_lo_u32)
+            REP8(asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4\n"
+                              "v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4"
+                              : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3) : "v"(3u));)
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -81,5 +93,8 @@ int main() {
     run<4>("fp64 FMA + SALU add alternating (128)", 128);
     run<5>("SALU add alone", 64);
     run<6>("v_add_u32 dependent chain", 64);
+    run<7>("v_cvt_f64_u32, independent", 64);
+    run<8>("v_rcp_f64, independent", 64);
+    run<9>("v_mul_lo_u32, 4 chains", 64);
     return 0;
 }
