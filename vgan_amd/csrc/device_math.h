@@ -51,6 +51,54 @@ __device__ __forceinline__ double log_pos(double x) {
     return dk * 6.93147180369123816490e-01 - ((hfsq - fma(sq, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
 }
 
+// log(1 + exp(-x)) for x >= 0 -- the second term of log-sum-exp -- cheaper than libm's exp and log1p one after the other (which
+// also carry every special case of their full domains): exp(-x) = 2^k exp(r), |r| <= ln 2 / 2, by its series to r^13 (the next
+// term is below 2e-17 relative); then with u = 1 + t rounded, log1p(t) = log(u) + (t - (u - 1)) / u, log(u) for u in [1, 2] by the
+// series of log_pos without its domain checks.  Error ~2 ulp of a value <= ln 2.  x = +inf -> 0, NaN -> NaN.
+__device__ __forceinline__ double softplus_neg(double x) {
+    const double kd = rint(x * -1.4426950408889634); // k = round(-x / ln 2) <= 0
+    double r = fma(kd, -6.93147180369123816490e-01, -x);
+    r = fma(kd, -1.90821492927058770002e-10, r);
+    double p = fma(r, 1.6059043836821613e-10, 2.08767569878681e-09); // 1/13!, 1/12!
+    p = fma(r, p, 2.505210838544172e-08);                            // 1/11!
+    p = fma(r, p, 2.755731922398589e-07);                            // 1/10!
+    p = fma(r, p, 2.7557319223985893e-06);                           // 1/9!
+    p = fma(r, p, 2.48015873015873e-05);                             // 1/8!
+    p = fma(r, p, 1.984126984126984e-04);                            // 1/7!
+    p = fma(r, p, 1.388888888888889e-03);                            // 1/6!
+    p = fma(r, p, 8.333333333333333e-03);                            // 1/5!
+    p = fma(r, p, 4.1666666666666664e-02);                           // 1/4!
+    p = fma(r, p, 1.6666666666666666e-01);                           // 1/3!
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    double t = __builtin_amdgcn_ldexp(p, (int)kd); // exp(-x); underflows through the subnormals to 0
+    t = x > 800.0 ? 0.0 : t;                       // (k beyond the exponent range, +inf)
+    // log1p(t), t in [0, 1]
+    const double u = 1.0 + t;
+    const bool hi = u > 1.4142135623730951; // m = u / 2 in [0.707, 1], k = 1; else m = u, k = 0
+    const double m = hi ? 0.5 * u : u;
+    const double f = m - 1.0;
+    const double den = 2.0 + f;
+    double q = __builtin_amdgcn_rcp(den);
+    q = fma(fma(-den, q, 1.0), q, q);
+    q = fma(fma(-den, q, 1.0), q, q);
+    double sq = f * q;
+    sq = fma(fma(-den, sq, f), q, sq); // s = f / (2 + f) to within an ulp
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = hi ? 1.0 : 0.0;
+    const double lg = dk * 6.93147180369123816490e-01 - ((hfsq - fma(sq, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+    // (1 + t was rounded: the part of t that u lost, over u; 1 / u from the reciprocal above when m = u, else refined anew)
+    double ru = __builtin_amdgcn_rcp(u);
+    ru = fma(fma(-u, ru, 1.0), ru, ru);
+    return lg + (t - (u - 1.0)) * ru;
+}
+
 // the same out of line: for branches no lane takes in practice (inlined there, the series' constants are hoisted out of the
 // caller's loops and held -- or spilled -- for the whole kernel)
 __device__ __attribute__((noinline)) double log_pos_cold(double x) { return log_pos(x); }

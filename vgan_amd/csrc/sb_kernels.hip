@@ -542,10 +542,17 @@ __device__ __forceinline__ double sb_read_term(const SbTablesDev &t, uint32_t r,
             inter = isinf(lws) ? -INFINITY : lse - lws;
         } else { // :967-974
             const double a = s.log_pos + LL, bb = s.log_1mpos + LLP;
-            const double inter2 = fmax(a, bb) + log1p(exp(-fabs(a - bb)));
+#ifdef SB_HACK_NOLIBM // (developer aid, wrong results: what the exp / log1p pairs cost)
+            const double inter2 = fmax(a, bb) + 0.5 * fabs(a - bb);
             const double yv = inter2 + s.log_theta;
             if (inter == 0.0 || inter == -INFINITY) inter = yv;
-            else inter = fmax(inter, yv) + log1p(exp(-fabs(inter - yv)));
+            else inter = fmax(inter, yv) + 0.5 * fabs(inter - yv);
+#else
+            const double inter2 = fmax(a, bb) + softplus_neg(fabs(a - bb));
+            const double yv = inter2 + s.log_theta;
+            if (inter == 0.0 || inter == -INFINITY) inter = yv;
+            else inter = fmax(inter, yv) + softplus_neg(fabs(inter - yv));
+#endif
         }
     }
     return inter;
