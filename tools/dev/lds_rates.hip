@@ -25,6 +25,14 @@ template <int KIND> __global__ __launch_bounds__(256) void k(double *out, int it
             REP64(asm volatile("ds_read_u16 v10, %0\n s_waitcnt lgkmcnt(8)" ::"v"(a2) : "v10", "memory");)
         } else if constexpr (KIND == 3) {
             REP64(asm volatile("ds_write_b128 %0, v[10:13]\n s_waitcnt lgkmcnt(8)" ::"v"(a16) : "memory");)
+        } else if constexpr (KIND == 7) {
+            REP64(asm volatile("ds_write_b64 %0, v[10:11]\n s_waitcnt lgkmcnt(8)" ::"v"(a8) : "memory");)
+        } else if constexpr (KIND == 8) {
+            REP64(asm volatile("ds_write_b32 %0, v10\n s_waitcnt lgkmcnt(8)" ::"v"(a8) : "memory");)
+        } else if constexpr (KIND == 9) {
+            REP64(asm volatile("ds_write2_b64 %0, v[10:11], v[12:13] offset1:1\n s_waitcnt lgkmcnt(8)" ::"v"(a16) : "memory");)
+        } else if constexpr (KIND == 10) {
+            REP64(asm volatile("ds_read2_b64 v[10:13], %0 offset1:1\n s_waitcnt lgkmcnt(8)" ::"v"(a16) : "v10", "v11", "v12", "v13", "memory");)
         } else if constexpr (KIND == 4) {
             REP64(asm volatile("ds_add_f64 %0, %1\n s_waitcnt lgkmcnt(8)" ::"v"(a8), "v"(v) : "memory");)
         } else if constexpr (KIND == 5) {
@@ -60,6 +68,10 @@ int main() {
     run<1>("ds_read_b64, lane-linear");
     run<2>("ds_read_u16, lane-linear");
     run<3>("ds_write_b128, lane-linear");
+    run<7>("ds_write_b64, lane-linear");
+    run<8>("ds_write_b32, 8-byte stride");
+    run<9>("ds_write2_b64 (16 bytes per lane)");
+    run<10>("ds_read2_b64 (16 bytes per lane)");
     run<4>("ds_add_f64, an address per lane");
     run<5>("ds_add_f64, two lanes per address");
     run<6>("ds_add_f64, all lanes one address");
