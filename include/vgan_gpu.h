@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGAN_ABI_VERSION 4
+#define VGAN_ABI_VERSION 5
 
 enum {
     VGAN_OK = 0,
@@ -242,11 +242,21 @@ void vgan_hc_host_batch_free(vgan_hc_host_batch *b);
  *   srec   uint32 [2 * n_segments]     per mapping {node id, seg_start | (read index & 0xFFFF) << 16}
  *   crec   uint32 [n_cols]             per alignment column, at the column's own position: byte 0 graph_seq[c], byte 1
  *                                      algnseq[c - seg_start] (the read bases are taken from the READ start,
- *                                      update_likelihood.cpp:46), byte 2 qual[c] (0 past the quality string), bit 31 set on
- *                                      the first column of a mapping; a column no mapping scores is 0
- *   qualp  uint8 [n_qual + 32]         the quality strings, followed by 32 zero bytes (aligned 8-byte words are read whole)
- * Reads in ascending order of their lowest node id (any order gives the same sums, slower).  The per-read maxima select the
- * kernel variant.  on_device: the four arrays are device pointers (a batch resident in HBM, zero copy). */
+ *                                      update_likelihood.cpp:46), byte 2 qual[c] (0 past the quality string; (ABI 5) on EVERY
+ *                                      column, scored or not: the kernel takes the quality prefix sums of
+ *                                      get_log_lik_if_unsupported, process_mapping.cpp:4-24, from the column records it holds
+ *                                      anyway), byte 3 = VGAN_HC_CREC_HEAD >> 24 on the first column of a mapping and 0
+ *                                      elsewhere; bytes 0 and 1 of a column no mapping scores are 0
+ *   qualp  uint8 [n_qual + 32]         the quality strings, followed by 32 zero bytes (aligned 8-byte words are read whole;
+ *                                      read by the per-segment kernel forms only)
+ * (ABI 5) The tile contract also asks for a quality string no longer than the read's columns (|quality| <= |algnseq|: the
+ * parser takes the two lengths independently); a read that breaks it stays with the SoA batch.
+ * Reads in ascending order of their lowest node id, those of mapping quality VGAN_HC_MAPQ_MAJOR first and the others behind
+ * them (any order gives the same sums, slower: the kernel keeps W[node] of a wave's reads in a window over neighbouring node
+ * ids, and takes whole tiles of reads that share the one mapping quality through a table of column terms).  The per-read
+ * maxima select the kernel variant.  on_device: the four arrays are device pointers (a batch resident in HBM, zero copy). */
+#define VGAN_HC_CREC_HEAD 0x04000000u /* (ABI 5; was bit 31) a column's running count of these IS its mapping's index * 4 */
+#define VGAN_HC_MAPQ_MAJOR 60         /* vg giraffe's cap: the mapping quality of (nearly) every uniquely placed read */
 typedef struct vgan_hc_packed_view {
     uint32_t n_reads;
     uint32_t n_segments;

@@ -174,10 +174,11 @@ def _check_flatten_against_oracle(g, a, batch):
             pos += min(sizes[i], len(rs) - pos)
         n_seen += 1
     assert n_seen == batch.n_reads
-    # tileable reads come first, in ascending order of their lowest node id (include/vgan_gpu.h "Order")
+    # tileable reads come first: those of mapping quality VGAN_HC_MAPQ_MAJOR (60) in ascending order of their lowest node id,
+    # then the others in theirs (include/vgan_gpu.h "Order", ABI 5)
     nt = batch.n_tileable
-    low = [int(arr["seg_node"][arr["read_seg_off"][k]:arr["read_seg_off"][k + 1]].min()) for k in range(nt)
-           if arr["read_seg_off"][k + 1] > arr["read_seg_off"][k]]
+    low = [(int(arr["read_mapq"][k]) != 60, int(arr["seg_node"][arr["read_seg_off"][k]:arr["read_seg_off"][k + 1]].min()))
+           for k in range(nt) if arr["read_seg_off"][k + 1] > arr["read_seg_off"][k]]
     assert low == sorted(low)
 
 
@@ -293,7 +294,9 @@ def test_flatten_puts_tileable_reads_first(tmp_path):
                   and np.all(ln > 0))
             assert ok == (r < nt), (r, nt, cols)
         # the tileable part ascends in the reads' lowest node id, input order kept among equals; the rest keeps the input order
+        # ((ABI 5) the reads of mapping quality 60 first, the others behind them)
         low = np.array([arr["seg_node"][so[r]:so[r + 1]].min() for r in range(nt)], np.int64)
+        low = low + (arr["read_mapq"][:nt] != 60).astype(np.int64) * (1 << 30)
         key = low * (1 << 32) + src[:nt].astype(np.int64)
         assert np.all(np.diff(key) > 0) and np.all(np.diff(src[nt:].astype(np.int64)) > 0)
 

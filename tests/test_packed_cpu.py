@@ -27,9 +27,15 @@ def pack_of_soa(arr, nt):
     c_in_read = col - co[cr]
     qlen = (qo[1:nt + 1] - qo[:nt])[cr]
     qb = np.where(c_in_read < qlen, arr["qual"][np.minimum(qo[cr] + c_in_read, max(len(arr["qual"]) - 1, 0))], 0).astype(np.uint32)
-    crec = np.zeros(Cn, np.uint32)
-    crec[col] = arr["graph_seq"][col].astype(np.uint32) | (arr["algnseq"][co[cr] + j].astype(np.uint32) << 8) | (qb << 16) | \
-        np.where(j == 0, np.uint32(0x80000000), np.uint32(0))
+    # (ABI 5) the quality byte sits on EVERY column below the string's length, scored or not; the head flag is byte 3 = 4
+    allc = np.arange(Cn, dtype=np.int64)
+    rd_of = np.repeat(np.arange(nt, dtype=np.int64), np.diff(co[:nt + 1]))
+    cin = allc - co[rd_of]
+    ql_all = (qo[1:nt + 1] - qo[:nt])[rd_of]
+    crec = (np.where(cin < ql_all, arr["qual"][np.minimum(qo[rd_of] + cin, max(len(arr["qual"]) - 1, 0))], 0).astype(np.uint32) << 16)
+    crec[col] |= arr["graph_seq"][col].astype(np.uint32) | (arr["algnseq"][co[cr] + j].astype(np.uint32) << 8) | \
+        np.where(j == 0, np.uint32(0x04000000), np.uint32(0))
+    assert np.array_equal(crec[col] >> 16 & 0xFF, qb)
     qualp = np.zeros(Q + 32, np.uint8)
     qualp[:Q] = arr["qual"][:Q]
     return {"rhdr": rhdr.ravel(), "srec": srec.ravel(), "crec": crec, "qualp": qualp}

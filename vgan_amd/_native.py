@@ -300,7 +300,7 @@ SYMBOLS = {
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),
 }
 
-ABI_VERSION = 4  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
+ABI_VERSION = 5  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
 
 HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the null stream by name (a NULL argument selects the context's own stream)
 

@@ -807,7 +807,7 @@ extern "C" int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packe
             if (node >= c->rows) return fail(VGAN_EINVAL, "packed batch: segment %u names node %u, beyond the graph", s, node);
             if ((w >> 16) != ((uint32_t)r & 0xFFFFu)) return fail(VGAN_EINVAL, "packed batch: segment %u does not carry its read's index", s);
             if (st < prev_end || st >= ncol) return fail(VGAN_EINVAL, "packed batch: segments of read %llu overlap, descend or leave its columns", (unsigned long long)r);
-            if (!(v->crec[(size_t)a[2] + st] & 0x80000000u)) return fail(VGAN_EINVAL, "packed batch: segment %u has no head bit at its first column", s);
+            if (!(v->crec[(size_t)a[2] + st] & VGAN_HC_CREC_HEAD)) return fail(VGAN_EINVAL, "packed batch: segment %u has no head bit at its first column", s);
             prev_end = st + 1;
         }
         uint32_t heads = 0;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "vgan_gpu.h" // the packed layout's constants (VGAN_HC_CREC_HEAD, VGAN_HC_MAPQ_MAJOR)
+
 namespace vgan {
 
 struct alignas(32) HcNodeDev {

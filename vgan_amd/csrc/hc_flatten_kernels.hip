@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
             }
             g_len = gn;
             a_len = an;
-            ok = ok && a_len == g_len && a_len <= DF_COLS && a_len > 0;
+            ok = ok && a_len == g_len && a_len <= DF_COLS && a_len > 0 && nq <= a_len; // (|quality| <= |algnseq|: flatten.cpp's tile contract)
         }
         if (ok) {
             // ---- pass 2: segment i = mapping i with the size of the read's i-th EDIT: start = min(A, sum of the sizes before), length
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
     }
     if (lane != 0) return;
     flag[gr] = f;
-    key[gr] = f == DF_DEVICE ? kmin : 0xFFFFFFFFu;
+    // (csrc/host/flatten.cpp: sort_key() -- the reads of mapping quality VGAN_HC_MAPQ_MAJOR first, the others behind them)
+    key[gr] = f == DF_DEVICE ? (min(kmin, 0x3FFFFFFFu) | (s.mapq[r] == VGAN_HC_MAPQ_MAJOR ? 0u : 0x40000000u)) : 0xFFFFFFFFu;
     info[gr] = uint4{G, nm, nq, A};
     if (f != DF_SKIP) atomicAdd(&ctr->n_in, 1u);
     if (f == DF_UNMAPPED) atomicAdd(&ctr->n_unmapped, 1u);
@@ -364,10 +365,10 @@ __global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restr
         const uint8_t *q = s.qual + s.qual_off[r];
         for (uint32_t c = lane; c < A; c += 64u) {
             const uint32_t ow = own[c];
-            uint32_t rec = 0u;
+            uint32_t rec = (c < nq ? (uint32_t)q[c] : 0u) << 16; // (the quality byte on every column, scored or not)
             if (ow) {
                 const uint32_t j = c - (ow - 1u);
-                rec = (uint32_t)gs[c] | ((uint32_t)ps[j] << 8) | ((c < nq ? (uint32_t)q[c] : 0u) << 16) | (j == 0 ? 0x80000000u : 0u);
+                rec |= (uint32_t)gs[c] | ((uint32_t)ps[j] << 8) | (j == 0 ? VGAN_HC_CREC_HEAD : 0u);
             }
             out.crec[c0 + c] = rec;
         }

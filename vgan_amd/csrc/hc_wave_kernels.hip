@@ -568,7 +568,7 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
                     const uint32_t rec = recs[u];
-                    const uint64_t heads = __builtin_amdgcn_ballot_w64((int32_t)rec < 0);
+                    const uint64_t heads = __builtin_amdgcn_ballot_w64(rec >= VGAN_HC_CREC_HEAD); // (byte 3 holds nothing else)
                     // owner = heads at or below the lane - 1 = (head bit 0 + heads before the chunk - 1: scalar) + (bits 1..l:
                     // v_mbcnt over the head bits shifted down by one); the scalar part goes into the LDS address
                     uint32_t sbase = segs_before + (uint32_t)(heads & 1u) - 1u;
@@ -810,13 +810,12 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (uint32_t c = lane; c < cols; c += 64u) {
             const uint32_t o = own[c];
-            uint32_t rec = 0u; // a column no segment scores
-            if (o) {
+            uint32_t rec = (c < QL ? (uint32_t)b.qual[q0 + c] : 0u) << 16; // the quality byte on every column (zero beyond the string)
+            if (o) { // (a column no segment scores keeps that byte alone)
                 const uint32_t j = c - (o - 1u);
                 const uint32_t gb = b.graph_seq[c0 + c];
                 const uint32_t rb = j < A ? b.algnseq[c0 + j] : 0u; // read bases from the read start (update_likelihood.cpp:46)
-                const uint32_t qb = c < QL ? b.qual[q0 + c] : 0u;   // zero beyond the quality string
-                rec = gb | (rb << 8) | (qb << 16) | (j == 0 ? 0x80000000u : 0u);
+                rec |= gb | (rb << 8) | (j == 0 ? VGAN_HC_CREC_HEAD : 0u);
             }
             crec[c0 + c] = rec;
         }

@@ -215,6 +215,15 @@ struct Chunk {
     vgan_hc_flatten_stats st{};
 };
 
+// Order of the tileable reads in a batch: the reads of mapping quality VGAN_HC_MAPQ_MAJOR by their lowest node id, then the
+// others by theirs (include/vgan_gpu.h: a tile of the segment kernel whose reads share that mapping quality takes its column
+// terms from a table).  A read without mappings (no lowest node) sorts first.
+constexpr uint32_t KEY_MINOR = 0x40000000u;
+inline uint32_t sort_key(uint32_t min_node, int32_t mapq) {
+    const uint32_t n = min_node == 0xFFFFFFFFu ? 0u : std::min(min_node, KEY_MINOR - 1u);
+    return n | (mapq == VGAN_HC_MAPQ_MAJOR ? 0u : KEY_MINOR);
+}
+
 struct SegTmp {
     uint32_t node;
     uint16_t start, len;
@@ -305,7 +314,9 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             c.st.n_bad++;
             continue;
         }
-        const bool tile = A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && (size_t)nm <= TILE_MAX_SEGS && !empty_seg && !seg_tmp.empty();
+        // (|quality| <= |algnseq|: the packed layout carries the quality string in the column records, include/vgan_gpu.h)
+        const bool tile = A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && n_qual_r <= A && (size_t)nm <= TILE_MAX_SEGS && !empty_seg &&
+                          !seg_tmp.empty();
         int32_t mq = a.mapq[r];
         if (mq < 0 || mq > 99) {
             mq = mq < 0 ? 0 : 99;
@@ -315,24 +326,21 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
         if (tile && packed) {
             // The kernel's own layout, written here once (bytes are moved, nothing is compared, clamped or looked up): a record
             // per alignment column {graph byte, the read byte update_likelihood.cpp:46 pairs it with -- algnseq from the READ
-            // start --, quality byte by column (0 past the string), bit 31 on a mapping's first column}; a column no mapping
-            // scores is 0
+            // start --, quality byte by column (0 past the string), VGAN_HC_CREC_HEAD on a mapping's first column}; a column no
+            // mapping scores keeps its quality byte alone
             auto &k = c.pk;
             const size_t c0 = k.crec.size();
             k.crec.resize(c0 + A);
             uint32_t *cr = k.crec.data() + c0;
-            memset(cr, 0, A * sizeof(uint32_t));
             const uint8_t *gs = reinterpret_cast<const uint8_t *>(rc.gseq.data()), *rs = reinterpret_cast<const uint8_t *>(rc.ps.data());
             const uint8_t *q = reinterpret_cast<const uint8_t *>(a.qual.data() + a.qual_off[r]);
+            for (size_t col = 0; col < A; ++col) cr[col] = (col < n_qual_r ? (uint32_t)q[col] : 0u) << 16;
             for (const SegTmp &sg : seg_tmp) {
                 k.srec.push_back(sg.node);
                 k.srec.push_back(sg.start);
                 const size_t st = sg.start, ln = sg.len;
-                for (size_t j = 0; j < ln; ++j) {
-                    const size_t col = st + j;
-                    cr[col] = (uint32_t)gs[col] | ((uint32_t)rs[j] << 8) | ((col < n_qual_r ? (uint32_t)q[col] : 0u) << 16);
-                }
-                cr[st] |= 0x80000000u;
+                for (size_t j = 0; j < ln; ++j) cr[st + j] |= (uint32_t)gs[st + j] | ((uint32_t)rs[j] << 8);
+                cr[st] |= VGAN_HC_CREC_HEAD;
             }
             k.qual.insert(k.qual.end(), q, q + n_qual_r);
             k.am.push_back((uint32_t)A | ((uint32_t)mq << 16));
@@ -340,7 +348,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             k.seg_off.push_back((uint32_t)(k.srec.size() / 2));
             k.col_off.push_back((uint32_t)k.crec.size());
             k.qual_off.push_back((uint32_t)k.qual.size());
-            c.key.push_back(min_node);
+            c.key.push_back(sort_key(min_node, mq));
             c.st.n_out++;
             continue;
         }
@@ -350,7 +358,7 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             b.seg_start.push_back(sg.start);
             b.seg_len.push_back(sg.len);
         }
-        if (tile) c.key.push_back(min_node);
+        if (tile) c.key.push_back(sort_key(min_node, mq));
         const size_t region = std::max(A, G);
         b.graph_seq.insert(b.graph_seq.end(), rc.gseq.begin(), rc.gseq.end());
         b.graph_seq.insert(b.graph_seq.end(), region - G, 0);
@@ -389,20 +397,18 @@ int merge_chunks(std::vector<Chunk> &chunks, bool packed, PhaseTimer &pt, vgan_h
     std::vector<size_t> rbase(nc + 1, 0);
     for (size_t i = 0; i < nc; ++i) rbase[i + 1] = rbase[i] + chunks[i].key.size();
     const size_t nt_reads = rbase[nc];
-    uint32_t kmax = 0;
+    uint32_t kmax = 0; // (the keys' node part; the counting sort's bins: the major reads' nodes, then the others')
     for (auto &c : chunks)
-        for (uint32_t &k : c.key) {
-            if (k == 0xFFFFFFFFu) k = 0; // a read without mappings
-            kmax = std::max(kmax, k);
-        }
+        for (uint32_t k : c.key) kmax = std::max(kmax, k & (KEY_MINOR - 1u));
+    auto bin = [kmax](uint32_t k) { return (size_t)(k & (KEY_MINOR - 1u)) + ((k & KEY_MINOR) ? (size_t)kmax + 1 : 0); };
     std::vector<uint32_t> order(nt_reads); // output position -> global tileable index (chunk-major)
     {
-        std::vector<uint32_t> cnt((size_t)kmax + 2, 0);
+        std::vector<uint32_t> cnt(2 * ((size_t)kmax + 1) + 1, 0);
         for (auto &c : chunks)
-            for (uint32_t k : c.key) cnt[(size_t)k + 1]++;
+            for (uint32_t k : c.key) cnt[bin(k) + 1]++;
         for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
         for (size_t i = 0; i < nc; ++i)
-            for (size_t j = 0; j < chunks[i].key.size(); ++j) order[cnt[chunks[i].key[j]]++] = (uint32_t)(rbase[i] + j);
+            for (size_t j = 0; j < chunks[i].key.size(); ++j) order[cnt[bin(chunks[i].key[j])]++] = (uint32_t)(rbase[i] + j);
     }
     // ---- totals
     uint64_t t_cols = 0, t_segs = 0, t_qual = 0;
