@@ -106,8 +106,10 @@ struct vgan_hc_ctx {
     HcParamsDev prm{};
     DevBuf<uint64_t> umask;
     DevBuf<uint16_t> umaskT, tile_word0;
-    DevBuf<HcNodeDev> node_tab;
+    DevBuf<HcNodeDev> node_tab, cls_tab;
+    DevBuf<uint16_t> node_hi;
     DevBuf<double> tables; // lq[256] qscore[100] incmap[100]
+    DevBuf<double> col_memo; // hc_col8_kernels.hip: the table of column terms
     DevBuf<double> accum;                                    // one block: nodeW | acc_seg | acc_node | totals (one memset)
     struct View { double *p = nullptr; } nodeW, acc_seg, acc_node, totals;
     size_t accum_n = 0;
@@ -350,7 +352,8 @@ int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *n
     ScopedTimer t(c, VGAN_HC_K_SEGMENT);
     if (pk && wave_kernel_enabled()) {
         if ((rc = ensure_work_queue(c))) return rc;
-        launch_hc_segments_wave(c->g, pk->d, c->prm, segD, nodeW, totals, c->work_ctr.p, &c->work_base, c->stream);
+        if (nodeW && !segD && hc_col8_kernel_fits(c->g, pk->d)) launch_hc_segments_col8(c->g, pk->d, c->prm, nodeW, totals, c->stream);
+        else launch_hc_segments_wave(c->g, pk->d, c->prm, segD, nodeW, totals, c->work_ctr.p, &c->work_base, c->stream);
         if (hipPeekAtLastError() != hipSuccess) c->work_dirty = true;
         launch_hc_segments_general(c->g, d, c->prm, nt, nullptr, nullptr, segD, nodeW, totals, c->stream);
     } else {
@@ -421,7 +424,9 @@ int run_packed(vgan_hc_ctx *c, const HcPackedDev &d, double *segD, double *nodeW
     if (nodeW || totals) c->touched = true;
     if ((rc = ensure_work_queue(c))) return rc;
     ScopedTimer t(c, VGAN_HC_K_SEGMENT);
-    launch_hc_segments_wave(c->g, d, c->prm, segD, nodeW, totals, c->work_ctr.p, &c->work_base, c->stream);
+    // node-weights accumulation alone: eight columns to a lane and the table of column terms, where the batch and the graph fit
+    if (nodeW && !segD && hc_col8_kernel_fits(c->g, d)) launch_hc_segments_col8(c->g, d, c->prm, nodeW, totals, c->stream);
+    else launch_hc_segments_wave(c->g, d, c->prm, segD, nodeW, totals, c->work_ctr.p, &c->work_base, c->stream);
     if (hipGetLastError() != hipSuccess) {
         c->work_dirty = true; // (the host's mirror of the ticket counter no longer holds: the next launch starts it over)
         return fail(VGAN_ENODEV, "the segment kernel could not be launched");
@@ -532,6 +537,46 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         const long double mm = (long double)mp * (long double)mt;
         nt[r] = {(double)logl(consensus ? (long double)mt : mm), (double)(1.0L / mm), mp, mt};
     }
+    // node classes: the distinct {ln_w, inv_mm, mappability} triples, most frequent first (hc_col8_kernels.hip keeps a table of
+    // column terms for the first HC_MEMO_CLASSES of them; a graph with more than HC_MAX_NODE_CLASSES takes the older kernels)
+    std::vector<HcNodeDev> cls;
+    std::vector<uint16_t> nhi(c->rows, 0);
+    {
+        auto same = [](const HcNodeDev &x, const HcNodeDev &y) { return memcmp(&x, &y, 3 * sizeof(double)) == 0; };
+        std::vector<uint32_t> of(c->rows), cnt;
+        bool many = false;
+        for (uint32_t r = 0; r < c->rows && !many; ++r) {
+            uint32_t k = 0;
+            while (k < cls.size() && !same(cls[k], nt[r])) ++k;
+            if (k == cls.size()) {
+                if (cls.size() == HC_MAX_NODE_CLASSES) {
+                    many = true;
+                    break;
+                }
+                cls.push_back(nt[r]);
+                cnt.push_back(0);
+            }
+            of[r] = k;
+            cnt[k]++;
+        }
+        if (many) {
+            cls.clear();
+        } else {
+            std::vector<uint32_t> ord(cls.size()), rank(cls.size());
+            for (uint32_t k = 0; k < ord.size(); ++k) ord[k] = k;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return cnt[x] > cnt[y]; });
+            std::vector<HcNodeDev> sorted(cls.size());
+            for (uint32_t i = 0; i < ord.size(); ++i) {
+                rank[ord[i]] = i;
+                sorted[i] = cls[ord[i]];
+            }
+            cls.swap(sorted);
+            for (uint32_t r = 0; r < c->rows; ++r) {
+                const uint32_t k = rank[of[r]];
+                nhi[r] = (uint16_t)(k < HC_MEMO_CLASSES ? k * HC_MEMO_CLASS_BYTES : 0xE000u | k);
+            }
+        }
+    }
     std::vector<double> tb(756);
     for (int bte = 0; bte < 256; ++bte) { // src/miscfunc.h:180-188 on int(char)
         const int Q = (int)(int8_t)bte;
@@ -548,6 +593,7 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     const size_t accn = (size_t)c->W * 64;
     if ((rc = c->umask.reserve(um.size())) || (rc = c->umaskT.reserve(umT.size())) ||
         (rc = c->tile_word0.reserve(tw0.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(756)) ||
+        (rc = c->node_hi.reserve(nhi.size())) || (rc = c->cls_tab.reserve(std::max<size_t>(1, cls.size()))) ||
         (rc = c->accum.reserve(((size_t)c->rows + 7) / 8 * 8 + 2 * accn + HC_TOTAL_SLOTS * HC_TOTAL_STRIDE)) || (rc = c->final_vec.reserve(c->P)))
         return bail(rc);
     { // sub-ranges of the accumulator block (sweep kernels read 64-byte aligned blocks of weights: keep 64-byte offsets)
@@ -562,7 +608,9 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         hipMemcpy(c->umaskT.p, umT.data(), umT.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->tile_word0.p, tw0.data(), tw0.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->node_tab.p, nt.data(), nt.size() * sizeof(HcNodeDev), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->tables.p, tb.data(), tb.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(c->tables.p, tb.data(), tb.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->node_hi.p, nhi.data(), nhi.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        (!cls.empty() && hipMemcpy(c->cls_tab.p, cls.data(), cls.size() * sizeof(HcNodeDev), hipMemcpyHostToDevice) != hipSuccess))
         return bail(fail(VGAN_ENODEV, "vgan_hc_create: upload failed"));
     c->g.umask = c->umask.p;
     c->g.umaskT = c->umaskT.p;
@@ -572,6 +620,16 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     c->g.qscore = c->tables.p + 256;
     c->g.incmap = c->tables.p + 356;
     c->g.rdtab = c->tables.p + 456;
+    c->g.node_hi = c->node_hi.p;
+    c->g.cls_tab = c->cls_tab.p;
+    c->g.n_cls = (uint32_t)cls.size();
+    c->g.col_memo = nullptr;
+    if (c->g.n_cls) { // the table of column terms (a pure function of the graph's node classes and the error-rate parameters)
+        if ((rc = c->col_memo.reserve(hc_col8_memo_doubles()))) return bail(rc);
+        launch_hc_col8_memo(c->g, c->prm, c->col_memo.p, c->stream);
+        if (hipGetLastError() != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: the table of column terms could not be built"));
+        c->g.col_memo = c->col_memo.p;
+    }
     c->g.rows = c->rows;
     c->g.mask_words = c->W;
     c->g.row_entries = row_entries;
@@ -606,6 +664,9 @@ extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
     c->umaskT.release();
     c->tile_word0.release();
     c->node_tab.release();
+    c->cls_tab.release();
+    c->col_memo.release();
+    c->node_hi.release();
     c->tables.release();
     c->accum.release();
     c->final_vec.release();
@@ -796,6 +857,7 @@ extern "C" int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packe
         const uint32_t ns = b[0] - a[0], nq = b[1] - a[1], ncol = b[2] - a[2], A = a[3] & 0xFFFFu, mapq = a[3] >> 16;
         if (ns == 0 || ns > HC_TILE_MAX_READ_SEGS || nq > HC_TILE_MAX_READ_QUAL || ncol > HC_TILE_MAX_READ_COLS)
             return fail(VGAN_EINVAL, "packed batch: read %llu is outside the tile contract", (unsigned long long)r);
+        if (nq > ncol) return fail(VGAN_EINVAL, "packed batch: the quality string of read %llu is longer than its columns", (unsigned long long)r);
         if (A != ncol) return fail(VGAN_EINVAL, "packed batch: |algnseq| of read %llu differs from its column count", (unsigned long long)r);
         if (mapq > 99) return fail(VGAN_EINVAL, "packed batch: mapping quality of read %llu exceeds 99", (unsigned long long)r);
         ms = std::max(ms, ns);
@@ -811,7 +873,7 @@ extern "C" int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packe
             prev_end = st + 1;
         }
         uint32_t heads = 0;
-        for (uint32_t col = 0; col < ncol; ++col) heads += v->crec[(size_t)a[2] + col] >> 31;
+        for (uint32_t col = 0; col < ncol; ++col) heads += v->crec[(size_t)a[2] + col] >= VGAN_HC_CREC_HEAD ? 1u : 0u;
         if (heads != ns) return fail(VGAN_EINVAL, "packed batch: read %llu has %u head bits for %u segments", (unsigned long long)r, heads, ns);
     }
     if (ms > v->max_read_segs || mq > v->max_read_qual || mc > v->max_read_cols)

@@ -39,6 +39,12 @@ struct HcGraphDev {
     const double *qscore;
     const double *incmap;
     const double *rdtab; // [100][3]
+    // node classes (hc_col8_kernels.hip): the distinct {ln_w, inv_mm, mappability} triples of node_tab, most frequent first
+    const uint16_t *node_hi;  // [rows] class * (bytes of a class in the kernel's table of column terms) for the classes the table
+                              // covers, 0xE000 | class for the others
+    const HcNodeDev *cls_tab; // [n_cls]
+    uint32_t n_cls;           // 0: more than HC_MAX_NODE_CLASSES classes (the kernel is not taken)
+    const double *col_memo;   // the context's table of column terms (hc_col8_memo_kernel), or NULL
     uint32_t rows;
     uint32_t mask_words;
     uint32_t row_entries; // n_tiles * 64
@@ -104,6 +110,10 @@ struct HcParamsDev {
 constexpr uint32_t HC_TOTAL_SLOTS = 64;
 constexpr uint32_t HC_TOTAL_STRIDE = 16; // doubles
 
+constexpr uint32_t HC_MAX_NODE_CLASSES = 32;   // node classes hc_segment_col8_kernel keeps the scalars of
+constexpr uint32_t HC_MEMO_CLASSES = 16;       // ... of which its table of column terms covers the most frequent (C8_NMEMO)
+constexpr uint32_t HC_MEMO_CLASS_BYTES = 3072; // a class's part of that table (C8_CLS_BYTES)
+
 // per-read limits of the LDS-tiled segment kernel (the tile contract of include/vgan_gpu.h; flatten.cpp applies them)
 // (a read has to fit one LDS tile; every phase of the kernel is flat over the tile, so there is no smaller per-read bound)
 constexpr uint32_t HC_TILE_MAX_READ_COLS = 1280;
@@ -128,6 +138,12 @@ bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_
 // next launch starts (kept by the caller between launches on the one stream)
 void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *segD, double *nodeW,
                              double *totals, uint32_t *work_ctr, uint32_t *work_base, hipStream_t st);
+// the same for node-weights accumulation alone (W[node] += D_m and the totals), eight columns to a lane with a table of column
+// terms (hc_col8_kernels.hip); hc_col8_kernel_fits: the batches and graphs it takes
+bool hc_col8_kernel_fits(const HcGraphDev &g, const HcPackedDev &pk);
+size_t hc_col8_memo_doubles(); // the context's table of column terms: its size, and the launch that fills it (after the graph side is up)
+void launch_hc_col8_memo(const HcGraphDev &g, const HcParamsDev &prm, double *out, hipStream_t st);
+void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *nodeW, double *totals, hipStream_t st);
 // node ids of the packed segment records into a plain array (the per-segment mask sweep reads them eight at a time)
 void launch_hc_srec_nodes(const uint2 *srec, uint32_t n_segments, uint32_t *out, hipStream_t st);
 // reads [r_begin, n_reads) through the general kernel (one wave per read, any length)
