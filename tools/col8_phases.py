@@ -18,7 +18,7 @@ hb = hc.HostBatch(g, a, packed=True)
 ctx = hc.HcContext(g)
 db = hc.DeviceBatch(hb)
 fn = _native.load().vgan_hc_debug_col8_phases
-out = np.zeros(8, np.uint64)
+out = np.zeros(12, np.uint64)
 ctx.accumulate(db)
 ctx.synchronize()
 fn(C.c_void_p(out.ctypes.data), 1)
@@ -26,11 +26,12 @@ ctx.reset()
 ctx.accumulate(db)
 ctx.synchronize()
 fn(C.c_void_p(out.ctypes.data), 1)
-names = ("top", "reads+Q", "C", "C2(general)", "D fast", "D general")
+names = ("top", "reads+Q", "C", "C2(general)", "D fast", "D not fast", "end (next classes)")
+idx = (0, 1, 2, 3, 4, 5, 8)
 tiles, gen = int(out[6]), int(out[7])
-tot = float(out[:6].sum())
-print("tiles %d general %d; cycles per tile %.0f" % (tiles, gen, tot / max(tiles, 1)))
-for k, v in zip(names, out[:6]):
+tot = float(sum(out[i] for i in idx))
+print("tiles %d not fast %d (of them through the context's table %d); cycles per tile %.0f" % (tiles, gen, int(out[9]), tot / max(tiles, 1)))
+for k, v in zip(names, [out[i] for i in idx]):
     print("%-12s %6.1f %%  %8.0f cycles per tile" % (k, 100.0 * float(v) / tot, float(v) / max(tiles, 1)))
 if gen:
     print("D general per general tile %.0f, C2 per general tile %.0f, D fast per fast tile %.0f" % (float(out[5]) / gen, float(out[3]) / gen, float(out[4]) / max(tiles - gen, 1)))

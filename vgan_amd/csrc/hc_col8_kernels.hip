@@ -117,6 +117,15 @@ __device__ __forceinline__ uint32_t c8_scan_u32(uint32_t v) { // wave64 inclusiv
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return v;
 }
+__device__ __forceinline__ uint32_t c8_wave_min(uint32_t v) { // wave64 minimum, in every lane's hands through lane 63 (DPP: no LDS round trips)
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t c8_readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint32_t c8_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -201,6 +210,7 @@ struct C8Args {
     double *totals;
     double bep;
     uint32_t n_reads, rows, n_cls;
+    uint64_t n_cols4, n_segs8; // bytes of crec / srec
     uint32_t use_bep, consensus;
 };
 
@@ -210,7 +220,7 @@ struct C8Tile { // one tile's extents (wave uniform)
 };
 
 #ifdef C8_PHASES // developer aid: where a wave's time goes (shader clock between the phases of the tile loop, summed over the waves)
-__device__ unsigned long long c8_phase_cycles[8]; // top, reads + Q, C, general C2, D fast, D general, tiles, general tiles
+__device__ unsigned long long c8_phase_cycles[12]; // top, reads + Q, C, general C2, D fast, D general, tiles, not-fast tiles, end (classes of the next tile), gfast tiles
 #define C8_MARK(i)                                                    \
     do {                                                              \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
     };
 
     double sumT = 0.0;                      // sum of the column terms (the W window's fp64 part passes through here at a flush)
-    unsigned long long accQ = 0, accN = 0;  // sum over the segments of {sum of Q above 2, count of the others}
+    unsigned long long accQ = 0, accN = 0;  // sum over the segments of {sum of Q above 2, count of the others} (taken at the window's flush)
     uint32_t winbase = 0xFFFFFFFFu;         // no window yet (wave uniform)
     bool need_place = true;
     auto window_flush = [&](uint32_t wb) {
@@ -334,6 +344,8 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
             const unsigned long long u = L.win_i[j];
             if (d != 0.0 || u != 0ull) {
                 sumT += d;
+                accQ += u >> 32;
+                accN += (uint32_t)u;
                 // - U_m = ln(10)/10 * (sum of Q above 2) + log(4) * (count of the others): miscfunc.h:180-188
                 const double mu = fma((double)(uint32_t)(u >> 32), 0.23025850929940457, (double)(uint32_t)u * 1.3862943611198906);
                 unsafeAtomicAdd(&a.nodeW[wb + j], d + mu);
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
     request_classes(sr, nhi);
 
 #ifdef C8_PHASES
-    unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter(), ph_gf = 0;
+    unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
 #endif
     while (true) {
         // ---- the next tile: formed from its header; its segment and column records, its reads' scalars and the header after it requested
@@ -388,6 +400,19 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
         request_segs(Tn, has_next, srN);
         request_cols(Tn, has_next, nl, nh4);
         Hn = header_load(f2, w2);
+#ifdef C8_L2_PREFETCH // (measured: 0.437 against 0.361 ms -- more requests in flight make every one of them slower; kept for A/B runs)
+        // the tile after the next one: its records' cache lines are touched now (one dword a line, the value is not used), so that
+        // the loads a tile from now find them on the chip -- a wave's tile is shorter than a trip to HBM under this kernel's load
+        uint32_t pf_touch;
+        {
+            const uint64_t c2 = (uint64_t)Tn.c_base + Tn.n_col, s2 = (uint64_t)Tn.s_base + Tn.n_seg;
+            const uint8_t *pc = reinterpret_cast<const uint8_t *>(a.crec + c2) + (uint32_t)lane * 128u;
+            const uint8_t *ps2 = reinterpret_cast<const uint8_t *>(a.srec + s2) + ((uint32_t)lane - 16u) * 128u;
+            const uint8_t *pp = lane < 16 ? pc : ps2;
+            const bool onp = has_next && (lane < 16 ? c2 * 4u + (uint32_t)lane * 128u < a.n_cols4 : (lane < 28 && s2 * 8u + ((uint32_t)lane - 16u) * 128u < a.n_segs8));
+            pf_touch = onp ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pp)) : 0u;
+        }
+#endif
         if (fresh) need_place = true;
         C8_COUNT(0, 1);
         C8_COUNT(1, T.n);
@@ -454,7 +479,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
 #pragma unroll
             for (int k = 0; k < C8_SPASS; ++k)
                 if ((uint32_t)k * 64u + (uint32_t)lane < T.n_seg) nmin = min(nmin, sr[k].x);
-            nmin = wave_min_u32(nmin);
+            nmin = c8_wave_min(nmin);
             if (winbase != 0xFFFFFFFFu) window_flush(winbase);
             winbase = c8_first(nmin);
             need_place = false;
@@ -469,7 +494,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
         {
             // (the three passes side by side, stage by stage: their LDS round trips overlap; a pass beyond the tile's segments works
             // on zero records and changes nothing)
-            uint32_t kr[C8_SPASS], hi[C8_SPASS], gap[C8_SPASS], p_lo[C8_SPASS], p_hi[C8_SPASS];
+            uint32_t kr[C8_SPASS], hi[C8_SPASS], gap[C8_SPASS], p_lo[C8_SPASS], p_hi[C8_SPASS], seg_flags = 0u;
             uint2 rd[C8_SPASS];
 #pragma unroll
             for (int k = 0; k < C8_SPASS; ++k) {
@@ -498,23 +523,30 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
 
                 L.info[ls + 1u] = (inside ? sl * 8u : C8_OUTSIDE) | ((nhi[k] + memo_base) << 16);
                 if (on) {
-                    accQ += sq;
-                    accN += n_low;
-                    if (inside) lds_iadd(wini_base + sl * 8u, ((unsigned long long)sq << 32) | n_low);
-                    else unsafeAtomicAdd(&a.nodeW[min(node, a.rows - 1u)], fma((double)sq, 0.23025850929940457, (double)n_low * 1.3862943611198906));
+                    if (inside) {
+                        lds_iadd(wini_base + sl * 8u, ((unsigned long long)sq << 32) | n_low);
+                    } else { // (rare: the sums that otherwise pass through the window's flush)
+                        accQ += sq;
+                        accN += n_low;
+                        unsafeAtomicAdd(&a.nodeW[min(node, a.rows - 1u)], fma((double)sq, 0.23025850929940457, (double)n_low * 1.3862943611198906));
+                    }
                 }
                 if (__builtin_expect(tile_hot, 0)) {
                     const bool sticky = on && !a.use_bep && L.first90[kr[k]] < hi[k]; // update_likelihood.cpp:42
                     sticky_m[k] = __builtin_amdgcn_ballot_w64(sticky);
                     tile_bep = tile_bep || sticky_m[k] != 0;
                 }
-                all_cls = all_cls && __builtin_amdgcn_ballot_w64(on && nhi[k] >= 0xE000u) == 0;
-                all_major = all_major && __builtin_amdgcn_ballot_w64(on && (rd[k].y & 0x800000u) == 0u) == 0;
+                // per lane, counted over its (up to three) mappings: those outside the window (bits 0-1), on a node class outside the
+                // tables (bits 8-9), of a read of another mapping quality (bits 16-17) -- three ballots a tile instead of three a pass
+                const uint32_t bits = (inside ? 0u : 1u) + (nhi[k] >= 0xE000u ? 0x100u : 0u) + ((rd[k].y & 0x800000u) ? 0u : 0x10000u);
+                seg_flags += on ? bits : 0u;
                 seg_rb[k] = ((rd[k].y >> 16) & 0x7Fu) * (uint32_t)(C8_NMEMO * C8_CLS_BYTES);
-                const uint32_t n_out = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(on && !inside));
-                tile_out = tile_out || n_out != 0;
-                if (n_out > 16) need_place = true; // (the next tile places the window anew)
             }
+            all_cls = __builtin_amdgcn_ballot_w64((seg_flags & 0x300u) != 0u) == 0;
+            all_major = __builtin_amdgcn_ballot_w64((seg_flags & 0x30000u) != 0u) == 0;
+            const uint32_t n_out = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((seg_flags & 3u) != 0u));
+            tile_out = n_out != 0;
+            if (n_out > 8) need_place = true; // (the next tile places the window anew)
         }
         // fast: every column term comes from the workgroup's table; gfast: from the context's (a read of another mapping quality)
         const bool tabled = all_cls && !tile_out && q_plain, fast = tabled && all_major, gfast = tabled && !all_major;
@@ -638,10 +670,14 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
         C8_MARK(fast ? 4 : 5);
         ph_acc[6] += 1;
         ph_acc[7] += fast ? 0 : 1;
-        ph_gf += gfast ? 1 : 0;
+        ph_acc[9] += gfast ? 1 : 0;
 #endif
         if (!has_next) break;
         request_classes(srN, nhiN); // (the next tile's segment records have been on their way for a whole tile; these land during its Q)
+#ifdef C8_L2_PREFETCH
+        asm volatile("" ::"v"(pf_touch)); // (the touch's register is its own until here)
+#endif
+        C8_MARK(8);
         T = Tn;
 #pragma unroll
         for (int k = 0; k < C8_SPASS; ++k) {
@@ -662,7 +698,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
     if (winbase != 0xFFFFFFFFu) window_flush(winbase);
 #ifdef C8_PHASES
     if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&c8_phase_cycles[i], ph_acc[i]);
+        for (int i = 0; i < 12; ++i) atomicAdd(&c8_phase_cycles[i], ph_acc[i]);
 #endif
     sumT = wave_sum(sumT);
 #pragma unroll
@@ -728,7 +764,7 @@ void launch_hc_col8_memo(const HcGraphDev &g, const HcParamsDev &prm, double *ou
 extern "C" int vgan_hc_debug_col8_phases(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(c8_phase_cycles), sizeof(c8_phase_cycles)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[8] = {};
+        unsigned long long z[12] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(c8_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
@@ -785,6 +821,8 @@ void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const H
     a.n_reads = pk.n_reads;
     a.rows = g.rows;
     a.n_cls = g.n_cls;
+    a.n_cols4 = pk.n_cols * 4u;
+    a.n_segs8 = (uint64_t)pk.n_segments * 8u;
     a.use_bep = prm.use_bep ? 1u : 0u;
     a.consensus = prm.consensus ? 1u : 0u;
     hipLaunchKernelGGL(hc_segment_col8_kernel, dim3(blocks), dim3(C8_THREADS), 0, st, a);
