@@ -239,7 +239,9 @@ void vgan_hc_host_batch_free(vgan_hc_host_batch *b);
  * Bytes are moved and nothing else: no comparison, clamp or table lookup happens before the kernel.
  *   rhdr   uint32 [4 * (n_reads + 1)]  per read {first segment, first quality byte, first column, |algnseq| | mapq << 16};
  *                                      entry n_reads holds the three end offsets
- *   srec   uint32 [2 * n_segments]     per mapping {node id, seg_start | (read index & 0xFFFF) << 16}
+ *   srec   uint32 [n_segments]         per mapping VGAN_HC_SREC(node id, seg_start, read index): node id in bits 0-17,
+ *                                      seg_start in bits 18-28, the read's index & 7 in bits 29-31 ((ABI 5) one word a mapping;
+ *                                      a graph with node ids beyond VGAN_HC_SREC_MAX_NODE hands every read over in the SoA form)
  *   crec   uint32 [n_cols]             per alignment column, at the column's own position: byte 0 graph_seq[c], byte 1
  *                                      algnseq[c - seg_start] (the read bases are taken from the READ start,
  *                                      update_likelihood.cpp:46), byte 2 qual[c] (0 past the quality string; (ABI 5) on EVERY
@@ -255,6 +257,8 @@ void vgan_hc_host_batch_free(vgan_hc_host_batch *b);
  * them (any order gives the same sums, slower: the kernel keeps W[node] of a wave's reads in a window over neighbouring node
  * ids, and takes whole tiles of reads that share the one mapping quality through a table of column terms).  The per-read
  * maxima select the kernel variant.  on_device: the four arrays are device pointers (a batch resident in HBM, zero copy). */
+#define VGAN_HC_SREC_MAX_NODE 0x3FFFFu
+#define VGAN_HC_SREC(node, start, read) ((uint32_t)(node) | (uint32_t)(start) << 18 | ((uint32_t)(read) & 7u) << 29)
 #define VGAN_HC_CREC_HEAD 0x04000000u /* (ABI 5; was bit 31) a column's running count of these IS its mapping's index * 4 */
 #define VGAN_HC_MAPQ_MAJOR 60         /* vg giraffe's cap: the mapping quality of (nearly) every uniquely placed read */
 typedef struct vgan_hc_packed_view {

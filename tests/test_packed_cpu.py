@@ -15,9 +15,8 @@ def pack_of_soa(arr, nt):
     rhdr[:, 0], rhdr[:, 1], rhdr[:, 2] = so[:nt + 1], qo[:nt + 1], co[:nt + 1]
     rhdr[:nt, 3] = arr["read_algn_len"][:nt].astype(np.uint32) | (arr["read_mapq"][:nt].astype(np.uint32) << 16)
     ridx = np.repeat(np.arange(nt, dtype=np.uint32), np.diff(so[:nt + 1]))
-    srec = np.zeros((S, 2), np.uint32)
-    srec[:, 0] = arr["seg_node"][:S]
-    srec[:, 1] = arr["seg_start"][:S].astype(np.uint32) | ((ridx & 0xFFFF) << 16)
+    # (ABI 5) one word a mapping: node id | seg_start << 18 | (read index & 7) << 29
+    srec = arr["seg_node"][:S].astype(np.uint32) | (arr["seg_start"][:S].astype(np.uint32) << 18) | ((ridx & 7) << 29)
     # per column: the segment that scores it (tileable reads: ranges do not overlap)
     seg_first = co[ridx] + arr["seg_start"][:S].astype(np.int64)
     ln = arr["seg_len"][:S].astype(np.int64)
@@ -124,3 +123,21 @@ def test_packed_flatten_of_a_sliced_alignment_set(tmp_path):
     got = pk.packed_arrays()
     for name in ("rhdr", "srec", "crec", "qualp", "read_src"):
         assert np.array_equal(got[name], whole[name]), name
+
+
+def test_a_graph_beyond_the_segment_records_node_field_stays_in_the_soa_form():
+    """(ABI 5) VGAN_HC_SREC keeps a node id in 18 bits: a read that touches a node beyond them is not packed -- it leaves with
+    the other reads of the batch, for the general kernel."""
+    g = hc.synth_graph(seed=5, genome_len=640000, n_nodes=280000, n_paths=8)
+    a = hc.synth_reads(g, 3000, seed=6, read_len=100)
+    soa = hc.HostBatch(g, a, n_threads=3)
+    pk = hc.HostBatch(g, a, n_threads=3, packed=True)
+    assert pk.n_reads == soa.n_reads and 0 < pk.pk.n_reads < soa.n_tileable
+    nodes = pk.packed_arrays()["srec"] & 0x3FFFF
+    arr = pk.arrays()
+    assert nodes.max() <= 0x3FFFF and arr["seg_node"].max() > 0x3FFFF
+    # every read whose nodes fit the field was packed
+    so = arr["read_seg_off"]
+    top = np.array([arr["seg_node"][so[r]:so[r + 1]].max() for r in range(pk.c.n_reads)])
+    tileable_left = sum(1 for r in range(pk.c.n_reads) if top[r] <= 0x3FFFF)
+    assert soa.n_tileable - pk.pk.n_reads >= pk.c.n_reads - (soa.n_reads - soa.n_tileable) - tileable_left

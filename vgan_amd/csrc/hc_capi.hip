@@ -83,7 +83,7 @@ double match_prob(int pangenome_base) {
 struct vgan_hc_packed {
     int device = 0;
     DevBuf<uint4> rhdr;
-    DevBuf<uint2> srec;
+    DevBuf<uint32_t> srec;
     DevBuf<uint32_t> crec;
     DevBuf<uint8_t> qualp;
     DevBuf<uint32_t> maxima;
@@ -384,7 +384,7 @@ int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d) {
     if (v->n_cols > 0xFFFFFFF0ull || v->n_qual > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "packed batch: more than 2^32 columns or quality bytes");
     if (v->on_device) {
         d.rhdr = reinterpret_cast<const uint4 *>(v->rhdr);
-        d.srec = reinterpret_cast<const uint2 *>(v->srec);
+        d.srec = v->srec;
         d.crec = v->crec;
         d.qualp = v->qualp;
         return VGAN_OK;
@@ -396,7 +396,7 @@ int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d) {
         (rc = P.crec.reserve(std::max<size_t>(1, v->n_cols))) || (rc = P.qualp.reserve((size_t)v->n_qual + 32)))
         return rc;
     HIPCHK(hipMemcpyAsync(P.rhdr.p, v->rhdr, ((size_t)v->n_reads + 1) * 16, hipMemcpyHostToDevice, c->stream));
-    if (v->n_segments) HIPCHK(hipMemcpyAsync(P.srec.p, v->srec, (size_t)v->n_segments * 8, hipMemcpyHostToDevice, c->stream));
+    if (v->n_segments) HIPCHK(hipMemcpyAsync(P.srec.p, v->srec, (size_t)v->n_segments * 4, hipMemcpyHostToDevice, c->stream));
     if (v->n_cols) HIPCHK(hipMemcpyAsync(P.crec.p, v->crec, (size_t)v->n_cols * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(P.qualp.p, v->qualp, (size_t)v->n_qual + 32, hipMemcpyHostToDevice, c->stream));
     d.rhdr = P.rhdr.p;
@@ -865,9 +865,9 @@ extern "C" int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packe
         mc = std::max(mc, ncol);
         uint32_t prev_end = 0;
         for (uint32_t s = a[0]; s < b[0]; ++s) {
-            const uint32_t node = v->srec[2 * (size_t)s], w = v->srec[2 * (size_t)s + 1], st = w & 0xFFFFu;
+            const uint32_t w = v->srec[s], node = w & VGAN_HC_SREC_MAX_NODE, st = (w >> 18) & 0x7FFu;
             if (node >= c->rows) return fail(VGAN_EINVAL, "packed batch: segment %u names node %u, beyond the graph", s, node);
-            if ((w >> 16) != ((uint32_t)r & 0xFFFFu)) return fail(VGAN_EINVAL, "packed batch: segment %u does not carry its read's index", s);
+            if ((w >> 29) != ((uint32_t)r & 7u)) return fail(VGAN_EINVAL, "packed batch: segment %u does not carry its read's index", s);
             if (st < prev_end || st >= ncol) return fail(VGAN_EINVAL, "packed batch: segments of read %llu overlap, descend or leave its columns", (unsigned long long)r);
             if (!(v->crec[(size_t)a[2] + st] & VGAN_HC_CREC_HEAD)) return fail(VGAN_EINVAL, "packed batch: segment %u has no head bit at its first column", s);
             prev_end = st + 1;
@@ -888,7 +888,7 @@ extern "C" int vgan_hc_packed_view_download(const vgan_hc_packed_view *v, uint32
     if (v->n_reads == 0) return VGAN_OK;
     const hipMemcpyKind k = v->on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
     if (rhdr) HIPCHK(hipMemcpy(rhdr, v->rhdr, ((size_t)v->n_reads + 1) * 16, k));
-    if (srec && v->n_segments) HIPCHK(hipMemcpy(srec, v->srec, (size_t)v->n_segments * 8, k));
+    if (srec && v->n_segments) HIPCHK(hipMemcpy(srec, v->srec, (size_t)v->n_segments * 4, k));
     if (crec && v->n_cols) HIPCHK(hipMemcpy(crec, v->crec, (size_t)v->n_cols * 4, k));
     if (qualp) HIPCHK(hipMemcpy(qualp, v->qualp, (size_t)v->n_qual + 32, k));
     return VGAN_OK;
@@ -905,7 +905,7 @@ extern "C" int vgan_hc_packed_download(const vgan_hc_packed *p, uint64_t n[4], u
     }
     if (p->d.n_reads == 0) return VGAN_OK;
     if (rhdr) HIPCHK(hipMemcpy(rhdr, p->d.rhdr, ((size_t)p->d.n_reads + 1) * 16, hipMemcpyDeviceToHost));
-    if (srec && p->d.n_segments) HIPCHK(hipMemcpy(srec, p->d.srec, (size_t)p->d.n_segments * 8, hipMemcpyDeviceToHost));
+    if (srec && p->d.n_segments) HIPCHK(hipMemcpy(srec, p->d.srec, (size_t)p->d.n_segments * 4, hipMemcpyDeviceToHost));
     if (crec && p->d.n_cols) HIPCHK(hipMemcpy(crec, p->d.crec, (size_t)p->d.n_cols * 4, hipMemcpyDeviceToHost));
     if (qualp) HIPCHK(hipMemcpy(qualp, p->d.qualp, (size_t)p->d.n_qual + 32, hipMemcpyDeviceToHost));
     return VGAN_OK;

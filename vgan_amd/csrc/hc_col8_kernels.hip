@@ -43,7 +43,7 @@ constexpr int C8_THREADS = 1024, C8_WAVES = 16;
 constexpr int C8_CPL = 8;               // columns per lane
 constexpr int C8_CAPC = 64 * C8_CPL;    // columns,
 constexpr int C8_CAPS = 192;            // segments and
-constexpr int C8_NR = 8;                // reads per tile at most
+constexpr int C8_NR = 8;                // reads per tile at most (the segment records carry the read's index & 7)
 constexpr int C8_SPASS = C8_CAPS / 64;
 constexpr int C8_WIN = 160;             // node ids covered by a wave's W window (hc_wave_kernels.hip: WV_WIN_SLOTS)
 constexpr int C8_QMAX = 48;             // quality values the table of column terms covers: [0, C8_QMAX)
@@ -134,6 +134,7 @@ __device__ __forceinline__ c8_rsrc c8_make_rsrc(const void *p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, (int)C8_BUF_FLAGS);
 }
 __device__ __forceinline__ uint32_t c8_load_u16(c8_rsrc r, uint32_t off) { return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0); }
+__device__ __forceinline__ uint32_t c8_load1(c8_rsrc r, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); }
 __device__ __forceinline__ uint2 c8_load2(c8_rsrc r, uint32_t off) {
     using v2 = __attribute__((__vector_size__(2 * sizeof(int)))) int;
     const v2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
@@ -199,7 +200,7 @@ __device__ __forceinline__ C8KL c8_seg_kl(double omp, double lp, double ip, cons
 
 struct C8Args {
     const uint4 *rhdr;
-    const uint2 *srec;
+    const uint32_t *srec;
     const uint32_t *crec;
     const uint16_t *node_hi;  // per node: its class's byte offset in the table, or 0xE000 | class for a class outside it
     const HcNodeDev *cls_tab; // per node class: {ln_w, inv_mm, mappability, match}
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
     };
     const c8_rsrc rs_hdr = c8_make_rsrc(a.rhdr, (a.n_reads + 1u) * 16u);
     const c8_rsrc rs_nhi = c8_make_rsrc(a.node_hi, a.rows * 2u);
-    const uint32_t lane8 = (uint32_t)lane * 8u, lane32 = (uint32_t)lane * 32u;
+    const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u, lane32 = (uint32_t)lane * 32u;
     const uint32_t memo_base = lds_addr(&S.memo[0]);
     const uint32_t info_base = lds_addr(&L.info[0]), wind_base = lds_addr(&L.win_d[0]), wini_base = lds_addr(&L.win_i[0]);
 
@@ -328,10 +329,10 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
         lo = c8_load4(rs_c, lane32);
         hi = c8_load4(rs_c, lane32 + 16u);
     };
-    auto request_segs = [&](const C8Tile &t, bool live, uint2 (&sr)[C8_SPASS]) {
-        const c8_rsrc rs_s = c8_make_rsrc(a.srec + t.s_base, live ? t.n_seg * 8u : 0u);
+    auto request_segs = [&](const C8Tile &t, bool live, uint32_t (&sr)[C8_SPASS]) { // (VGAN_HC_SREC: node | seg_start << 18 | read index & 7 << 29)
+        const c8_rsrc rs_s = c8_make_rsrc(a.srec + t.s_base, live ? t.n_seg * 4u : 0u);
 #pragma unroll
-        for (int k = 0; k < C8_SPASS; ++k) sr[k] = c8_load2(rs_s, lane8 + (uint32_t)k * 512u);
+        for (int k = 0; k < C8_SPASS; ++k) sr[k] = c8_load1(rs_s, lane4 + (uint32_t)k * 256u);
     };
 
     double sumT = 0.0;                      // sum of the column terms (the W window's fp64 part passes through here at a flush)
@@ -366,9 +367,9 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
 
     // ---- prologue.  In the loop everything a tile reads was requested a whole tile earlier (its header two tiles earlier): a
     // fast tile is ~2.5 us of a wave's time, about one trip to HBM under load.
-    auto request_classes = [&](const uint2 (&srx)[C8_SPASS], uint32_t (&nh)[C8_SPASS]) { // (a lane without a segment reads node 0)
+    auto request_classes = [&](const uint32_t (&srx)[C8_SPASS], uint32_t (&nh)[C8_SPASS]) { // (a lane without a segment reads node 0)
 #pragma unroll
-        for (int k = 0; k < C8_SPASS; ++k) nh[k] = c8_load_u16(rs_nhi, min(srx[k].x, a.rows - 1u) * 2u);
+        for (int k = 0; k < C8_SPASS; ++k) nh[k] = c8_load_u16(rs_nhi, min(srx[k] & VGAN_HC_SREC_MAX_NODE, a.rows - 1u) * 2u);
     };
     uint32_t u0, u1;
     if (!unit_of((uint32_t)wave, u0, u1)) return;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
     next_first(T, fn, wn, fresh_n);
     Hn = header_load(fn, wn);
     uint4 rl, rh, nl, nh4; // the tile's column records (lane's columns 0..3, 4..7), the next tile's
-    uint2 sr[C8_SPASS], srN[C8_SPASS];
+    uint32_t sr[C8_SPASS], srN[C8_SPASS];
     uint32_t nhi[C8_SPASS], nhiN[C8_SPASS]; // the mappings' node classes
     request_segs(T, true, sr);
     request_cols(T, true, rl, rh);
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
             uint32_t nmin = 0xFFFFFFFFu;
 #pragma unroll
             for (int k = 0; k < C8_SPASS; ++k)
-                if ((uint32_t)k * 64u + (uint32_t)lane < T.n_seg) nmin = min(nmin, sr[k].x);
+                if ((uint32_t)k * 64u + (uint32_t)lane < T.n_seg) nmin = min(nmin, sr[k] & VGAN_HC_SREC_MAX_NODE);
             nmin = c8_wave_min(nmin);
             if (winbase != 0xFFFFFFFFu) window_flush(winbase);
             winbase = c8_first(nmin);
@@ -498,12 +499,12 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
             uint2 rd[C8_SPASS];
 #pragma unroll
             for (int k = 0; k < C8_SPASS; ++k) {
-                kr[k] = min(((sr[k].y >> 16) - T.r) & 0xFFFFu, (uint32_t)C8_NR - 1u);
+                kr[k] = ((sr[k] >> 29) - T.r) & 7u;
                 rd[k] = L.rdA[kr[k]];
             }
 #pragma unroll
             for (int k = 0; k < C8_SPASS; ++k) {
-                const uint32_t start = sr[k].y & 0xFFFFu;
+                const uint32_t start = (sr[k] >> 18) & 0x7FFu;
                 const uint32_t A = rd[k].x & 0xFFFFu, QL = rd[k].x >> 16, coff = rd[k].y & 0xFFFFu;
                 const uint32_t lo = min(start, QL);
                 hi[k] = min(start + A, QL);
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
                 const bool on = ls < T.n_seg;
                 const uint32_t pkd = p_hi[k] - p_lo[k];
                 const uint32_t n_low = (pkd & 2047u) + gap[k], sq = pkd >> 11;
-                const uint32_t node = sr[k].x, sl = node - winbase;
+                const uint32_t node = sr[k] & VGAN_HC_SREC_MAX_NODE, sl = node - winbase;
                 const bool inside = sl < (uint32_t)C8_WIN;
 
                 L.info[ls + 1u] = (inside ? sl * 8u : C8_OUTSIDE) | ((nhi[k] + memo_base) << 16);
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
             for (int k = 0; k < C8_SPASS; ++k) {
                 if ((uint32_t)k * 64u < T.n_seg) {
                     const uint32_t ls = (uint32_t)k * 64u + (uint32_t)lane;
-                    const uint32_t kr = min(((sr[k].y >> 16) - T.r) & 0xFFFFu, (uint32_t)C8_NR - 1u);
+                    const uint32_t kr = ((sr[k] >> 29) - T.r) & 7u;
                     const uint32_t cls = nhi[k] < 0xE000u ? nhi[k] / C8_CLS_BYTES : min(nhi[k] - 0xE000u, (uint32_t)HC_MAX_NODE_CLASSES - 1u);
                     C8KL kl = c8_seg_kl(L.rdB[kr][0], L.rdB[kr][1], L.rdB[kr][2], S.cls[cls], a.consensus != 0);
                     if ((sticky_m[k] >> lane) & 1ull) kl.kappa = -kl.kappa;
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
                         const uint32_t so = inf[e] & 0xFFFFu;
                         if (so == C8_OUTSIDE) {
                             sumT += tt;
-                            unsafeAtomicAdd(&a.nodeW[min(a.srec[T.s_base + (own_seg4 >> 2) - 1u].x, a.rows - 1u)], tt);
+                            unsafeAtomicAdd(&a.nodeW[min(a.srec[T.s_base + (own_seg4 >> 2) - 1u] & VGAN_HC_SREC_MAX_NODE, a.rows - 1u)], tt);
                         } else {
                             lds_fadd(wind_base + so, tt);
                         }
@@ -822,7 +823,7 @@ void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const H
     a.rows = g.rows;
     a.n_cls = g.n_cls;
     a.n_cols4 = pk.n_cols * 4u;
-    a.n_segs8 = (uint64_t)pk.n_segments * 8u;
+    a.n_segs8 = (uint64_t)pk.n_segments * 4u;
     a.use_bep = prm.use_bep ? 1u : 0u;
     a.consensus = prm.consensus ? 1u : 0u;
     hipLaunchKernelGGL(hc_segment_col8_kernel, dim3(blocks), dim3(C8_THREADS), 0, st, a);

@@ -66,7 +66,7 @@ struct HcBatchDev {
 // The tileable reads of a batch in the layout the wave kernel streams (hc_wave_kernels.hip), written once per batch by
 // the layout pass launch_hc_pack -- byte moves only: no comparison, clamp or table lookup happens there.
 //   rhdr   uint4 [n_reads + 1]   {seg_off, qual_off, col_off, |algnseq| | mapq << 16}; entry n_reads holds the end offsets
-//   srec   uint2 [segments]      {node id, seg_start | (read index & 0xFFFF) << 16}
+//   srec   uint32 [segments]     VGAN_HC_SREC(node id, seg_start, read index): bits 0-17, 18-28, 29-31 (the index & 7)
 //   crec   uint32 [columns]      one record per alignment column of the read, at the column's own position col_off + c:
 //                                byte 0 graph_seq[col_off + c], byte 1 algnseq[col_off + c - seg_start] (the read bases are
 //                                taken from the read start: update_likelihood.cpp:46), byte 2 qual[qual_off + c] (0 beyond the
@@ -74,7 +74,7 @@ struct HcBatchDev {
 //   qualp  uint8 [quality bytes + 32]  the quality strings, zero padded so that any aligned 8-byte word can be read whole
 struct HcPackedDev {
     const uint4 *rhdr;
-    const uint2 *srec;
+    const uint32_t *srec;
     const uint32_t *crec;
     const uint8_t *qualp;
     uint32_t n_reads;       // tileable reads packed
@@ -129,7 +129,7 @@ void launch_hc_segments(const HcGraphDev &g, const HcBatchDev &b, const HcParams
 // layout pass: packs reads [0, n_tileable) of b into the caller's buffers (sized from the batch totals: n_tileable + 1
 // headers, n_segments records, n_cols column records, n_qual + 32 quality bytes).  maxima (device, 3 words,
 // or NULL) receives max segments / quality bytes / columns per packed read.
-void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint2 *srec,
+void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint32_t *srec,
                     uint32_t *crec, uint8_t *qualp, uint32_t *maxima, hipStream_t st);
 // true when the wave kernel is the faster route for reads of that shape (otherwise the LDS-tiled kernel takes the batch)
 bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_t max_read_cols, uint32_t mean_read_segs,
@@ -145,7 +145,7 @@ size_t hc_col8_memo_doubles(); // the context's table of column terms: its size,
 void launch_hc_col8_memo(const HcGraphDev &g, const HcParamsDev &prm, double *out, hipStream_t st);
 void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *nodeW, double *totals, hipStream_t st);
 // node ids of the packed segment records into a plain array (the per-segment mask sweep reads them eight at a time)
-void launch_hc_srec_nodes(const uint2 *srec, uint32_t n_segments, uint32_t *out, hipStream_t st);
+void launch_hc_srec_nodes(const uint32_t *srec, uint32_t n_segments, uint32_t *out, hipStream_t st);
 // reads [r_begin, n_reads) through the general kernel (one wave per read, any length)
 void launch_hc_segments_general(const HcGraphDev &g, const HcBatchDev &b, const HcParamsDev &prm, uint32_t r_begin, double *segS,
                                 double *segU, double *segD, double *nodeW, double *totals, hipStream_t st);

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
             }
             g_len = gn;
             a_len = an;
-            ok = ok && a_len == g_len && a_len <= DF_COLS && a_len > 0 && nq <= a_len; // (|quality| <= |algnseq|: flatten.cpp's tile contract)
+            // (|quality| <= |algnseq| and node ids within VGAN_HC_SREC's 18 bits: flatten.cpp's tile contract of a packed batch)
+            ok = ok && a_len == g_len && a_len <= DF_COLS && a_len > 0 && nq <= a_len && kmax <= VGAN_HC_SREC_MAX_NODE;
         }
         if (ok) {
             // ---- pass 2: segment i = mapping i with the size of the read's i-th EDIT: start = min(A, sum of the sizes before), length
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void hc_df_gather_kernel(const uint32_t *__res
 
 struct DfOut {
     uint4 *rhdr;
-    uint2 *srec;
+    uint32_t *srec;
     uint32_t *crec;
     uint8_t *qualp;
     uint32_t *read_src;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restr
                 const uint32_t p_tot = __shfl(pp, 63, 64);
                 if (on) {
                     const uint32_t start = min(A, p_base + pp - n), sl = min(n, A - start);
-                    out.srec[s0 + i] = uint2{(uint32_t)s.m_node[m0 + i], start | ((o & 0xFFFFu) << 16)};
+                    out.srec[s0 + i] = VGAN_HC_SREC(s.m_node[m0 + i], start, o);
                     for (uint32_t j = 0; j < sl; ++j) own[start + j] = (uint16_t)(start + 1u);
                 }
                 p_base += p_tot;
@@ -419,7 +420,7 @@ struct vgan_hc_devflat {
     DBuf<uint8_t> flag;
     DBuf<uint32_t> key, key_out, val, val_out, segs, quals, cols, soff, qoff, coff, read_src;
     DBuf<uint4> info, rhdr;
-    DBuf<uint2> srec;
+    DBuf<uint32_t> srec;
     DBuf<uint32_t> crec;
     DBuf<uint8_t> qualp;
     DBuf<DfCounters> ctr;
@@ -690,7 +691,7 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
     out->n_qual = tot[1];
     out->n_cols = tot[2];
     out->rhdr = reinterpret_cast<const uint32_t *>(f->rhdr.p);
-    out->srec = reinterpret_cast<const uint32_t *>(f->srec.p);
+    out->srec = f->srec.p;
     out->crec = f->crec.p;
     out->qualp = f->qualp.p;
     out->max_read_segs = hc.max_segs;

@@ -192,7 +192,7 @@ __device__ __attribute__((noinline)) void wv_first90(uint2 qv, uint32_t pos0, ui
 // ------------------------------------------------------------------------------------------------------------ the kernel
 struct WvArgs { // only what the kernel reads (every pointer costs two scalar registers for the whole launch)
     const uint4 *rhdr;
-    const uint2 *srec;
+    const uint32_t *srec;
     const uint32_t *crec;
     const uint8_t *qualp;
     const HcNodeDev *node_tab;
@@ -218,7 +218,7 @@ struct WvRdTab { // rdtab row of a mapping quality: 1 - p_inc, its log, its reci
 };
 template <int SPASS, int QCH, int NCH> struct WvData { // one tile's HBM data, in flight or arrived
     uint2 qv[QCH];
-    uint2 sr[SPASS];
+    uint32_t sr[SPASS]; // VGAN_HC_SREC: node | seg_start << 18 | read index & 7 << 29
     uint32_t rec[NCH];
 };
 
@@ -308,16 +308,16 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
         for (int k = 0; k < QCH; ++k) d.qv[k] = wv_load2(rs_q, lane8 + (uint32_t)k * 512u);
     };
     auto request_segs = [&](const WvTile &t, bool live, Data &d) {
-        const wv_rsrc rs_s = wv_make_rsrc(a.srec + t.s_base, live ? t.n_seg * 8u : 0u);
+        const wv_rsrc rs_s = wv_make_rsrc(a.srec + t.s_base, live ? t.n_seg * 4u : 0u);
 #pragma unroll
-        for (int k = 0; k < SPASS; ++k) d.sr[k] = wv_load2(rs_s, lane8 + (uint32_t)k * 512u);
+        for (int k = 0; k < SPASS; ++k) d.sr[k] = wv_load1(rs_s, lane4 + (uint32_t)k * 256u); // (VGAN_HC_SREC words, taken apart where they are used)
     };
     auto rsrc_cols = [&](const WvTile &t, bool live) { return wv_make_rsrc(a.crec + t.c_base, live ? t.n_col * 4u : 0u); };
     // the nodes' scalars (dependent on the segment records; a lane without a segment reads node 0)
     auto node_gather = [&](const Data &d, double (&nd_lw)[SPASS], double (&nd_inv)[SPASS], double (&nd_mapp)[SPASS]) {
 #pragma unroll
         for (int k = 0; k < SPASS; ++k) {
-            const uint32_t o = min(d.sr[k].x, a.rows - 1u) << 5;
+            const uint32_t o = min(d.sr[k] & VGAN_HC_SREC_MAX_NODE, a.rows - 1u) << 5;
             const uint4 v = wv_load4(rs_node, o);
             const uint2 m = wv_load2(rs_node, o + 16u);
             nd_lw[k] = wv_dbl(v.x, v.y);
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
         if constexpr (DIRECT) {
             if (need_place) {
 #pragma unroll
-                for (int k = 0; k < SPASS; ++k) segnode[k] = D.sr[k].x;
+                for (int k = 0; k < SPASS; ++k) segnode[k] = D.sr[k] & VGAN_HC_SREC_MAX_NODE;
                 window_place(segnode, T, winbase);
                 need_place = false;
             }
@@ -500,8 +500,9 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
             if ((uint32_t)k * 64u < T.n_seg) {
                 const uint32_t ls = (uint32_t)k * 64u + (uint32_t)lane;
                 const bool on = ls < T.n_seg;
-                const uint32_t start = D.sr[k].y & 0xFFFFu;
-                const uint32_t kr = min(((D.sr[k].y >> 16) - T.r) & 0xFFFFu, (uint32_t)WV_NR - 1u);
+                const uint32_t start = (D.sr[k] >> 18) & 0x7FFu;
+                const uint32_t kr = ((D.sr[k] >> 29) - T.r) & 7u;
+                static_assert(WV_NR == 8, "the segment records carry the read's index & 7");
                 const WvRead rd = L.rd[kr];
                 const uint32_t A = rd.a_ql & 0xFFFFu, QL = rd.a_ql >> 16;
                 const uint32_t lo = min(start, QL), hi = min(start + A, QL);
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
                 const double U = fma((double)(pkd >> 11), -0.23025850929940457 /* ln(10) / 10 */,
                                      (double)n_low * -1.3862943611198906 /* log(0.25) */);
                 segU[k] = U;
-                segnode[k] = D.sr[k].x;
+                segnode[k] = D.sr[k] & VGAN_HC_SREC_MAX_NODE;
                 if (on) sumU += U;
                 // wbg = 1 - pcm, wobs = pcm * match (process_mapping.cpp:41,66-75; a consensus FASTA: 0 and (1 - bep) * match)
                 const double pcm = rd.omp * nd_mapp[k];
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
                 }
                 if constexpr (DIRECT) {
                     // -U_m goes to the node's slot here, the columns' terms follow in D
-                    const uint32_t node = D.sr[k].x, sl = node - winbase;
+                    const uint32_t node = D.sr[k] & VGAN_HC_SREC_MAX_NODE, sl = node - winbase;
                     const bool inside = sl < (uint32_t)WV_WIN;
                     if (CAPS % 64 == 0 || on) L.slot[ls] = (uint16_t)(inside ? sl * (8u * SUB) : 0xFFFFu);
                     if (on) {
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
                             sumT += t[u];
                             double *dst = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(L.win) + slv[u] + sub8);
                             if (__builtin_expect(tile_out, 0)) {
-                                if (slv[u] == 0xFFFFu) unsafeAtomicAdd(&a.nodeW[min(a.srec[sgl[u] + own[u]].x, a.rows - 1u)], t[u]);
+                                if (slv[u] == 0xFFFFu) unsafeAtomicAdd(&a.nodeW[min(a.srec[sgl[u] + own[u]] & VGAN_HC_SREC_MAX_NODE, a.rows - 1u)], t[u]);
                                 else wv_lds_add(dst, t[u]);
                             } else {
                                 wv_lds_add(dst, t[u]);
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(WV_THREADS, OCC) WV_VGPR_ATTR void hc_segment_wave_
 // in LDS; then lanes over its columns: the column records, read and written in coalesced runs.
 constexpr int PK_COLS = 1280; // a tileable read's columns at most (hc_device.h: HC_TILE_MAX_READ_COLS)
 __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_pack, uint4 *__restrict__ rhdr,
-                                                      uint2 *__restrict__ srec, uint32_t *__restrict__ crec,
+                                                      uint32_t *__restrict__ srec, uint32_t *__restrict__ crec,
                                                       uint32_t *__restrict__ maxima) {
     __shared__ uint16_t own_s[4][PK_COLS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         for (uint32_t s = s0 + lane; s < s1; s += 64u) {
             const uint32_t start = b.seg_start[s], len = b.seg_len[s];
-            srec[s] = uint2{b.seg_node[s], start | ((r & 0xFFFFu) << 16)};
+            srec[s] = VGAN_HC_SREC(b.seg_node[s], start, r);
             const uint32_t cl = start < cols ? min(len, cols - start) : 0u;
             for (uint32_t j = 0; j < cl; ++j) own[start + j] = (uint16_t)(start + 1u);
         }
@@ -828,8 +829,8 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
     }
 }
 
-__global__ __launch_bounds__(256) void hc_srec_nodes_kernel(const uint2 *__restrict__ srec, uint32_t n, uint32_t *__restrict__ out) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = srec[i].x;
+__global__ __launch_bounds__(256) void hc_srec_nodes_kernel(const uint32_t *__restrict__ srec, uint32_t n, uint32_t *__restrict__ out) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = srec[i] & VGAN_HC_SREC_MAX_NODE;
 }
 
 } // namespace wv
@@ -877,7 +878,7 @@ bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_
     return 2u * mean_read_segs <= (uint32_t)WV_CAPS && 2u * mean_read_cols <= (uint32_t)WV_CAPC && mean_read_cols * (uint32_t)WV_NR >= 384u;
 }
 
-void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint2 *srec,
+void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint32_t *srec,
                     uint32_t *crec, uint8_t *qualp, uint32_t *maxima, hipStream_t st) {
     const uint32_t n = std::min(n_tileable, b.n_reads);
     if (maxima) (void)hipMemsetAsync(maxima, 0, 12, st);
@@ -886,7 +887,7 @@ void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, u
     hipLaunchKernelGGL(hc_pack_kernel, dim3(std::min<uint32_t>((n + 1 + 3) / 4, 8192u)), dim3(256), 0, st, b, n, rhdr, srec, crec, maxima);
 }
 
-void launch_hc_srec_nodes(const uint2 *srec, uint32_t n_segments, uint32_t *out, hipStream_t st) {
+void launch_hc_srec_nodes(const uint32_t *srec, uint32_t n_segments, uint32_t *out, hipStream_t st) {
     if (n_segments == 0) return;
     hipLaunchKernelGGL(hc_srec_nodes_kernel, dim3(std::min<uint32_t>((n_segments + 255u) / 256u, 4096u)), dim3(256), 0, st, srec, n_segments, out);
 }

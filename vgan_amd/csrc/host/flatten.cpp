@@ -315,8 +315,10 @@ void flatten_range(const vgan_graph &g, const vgan_alnset &a, int64_t r0, int64_
             continue;
         }
         // (|quality| <= |algnseq|: the packed layout carries the quality string in the column records, include/vgan_gpu.h)
+        // (a packed batch: one word a mapping, include/vgan_gpu.h VGAN_HC_SREC -- a graph with node ids beyond its 18 bits hands every
+        // read over in the SoA form)
         const bool tile = A == G && A <= TILE_MAX_COLS && n_qual_r <= TILE_MAX_QUAL && n_qual_r <= A && (size_t)nm <= TILE_MAX_SEGS && !empty_seg &&
-                          !seg_tmp.empty();
+                          !seg_tmp.empty() && (!packed || max_node <= VGAN_HC_SREC_MAX_NODE);
         int32_t mq = a.mapq[r];
         if (mq < 0 || mq > 99) {
             mq = mq < 0 ? 0 : 99;
@@ -459,7 +461,7 @@ int merge_chunks(std::vector<Chunk> &chunks, bool packed, PhaseTimer &pt, vgan_h
         res->pk_cols = t_cols;
         res->pk_qual = t_qual;
         res->pk_rhdr.resize(4 * (nt_reads + 1));
-        res->pk_srec.resize(2 * t_segs);
+        res->pk_srec.resize(t_segs);
         res->pk_crec.resize(t_cols);
         res->pk_qualp.resize(t_qual + 32);
         res->pk_src.resize(nt_reads);
@@ -533,13 +535,9 @@ int merge_chunks(std::vector<Chunk> &chunks, bool packed, PhaseTimer &pt, vgan_h
             h[3] = k.am[j];
             res->pk_src[o] = k.src[j];
             const size_t s0 = k.seg_off[j], ns = k.seg_off[j + 1] - s0;
-            const uint32_t rtag = ((uint32_t)o & 0xFFFFu) << 16; // the segment's read, as the kernel finds it within a tile
             const uint32_t *sp = k.srec.data() + 2 * s0;
-            uint32_t *sd = res->pk_srec.data() + 2 * (size_t)pseg[o];
-            for (size_t t = 0; t < ns; ++t) {
-                sd[2 * t] = sp[2 * t];
-                sd[2 * t + 1] = sp[2 * t + 1] | rtag;
-            }
+            uint32_t *sd = res->pk_srec.data() + (size_t)pseg[o];
+            for (size_t t = 0; t < ns; ++t) sd[t] = VGAN_HC_SREC(sp[2 * t], sp[2 * t + 1], o); // (the read's index & 7: as the kernel finds it within a tile)
             const size_t c0 = k.col_off[j], ncol = k.col_off[j + 1] - c0;
             if (ncol) memcpy(res->pk_crec.data() + pcol[o], k.crec.data() + c0, ncol * sizeof(uint32_t));
             const size_t q0 = k.qual_off[j], nq = k.qual_off[j + 1] - q0;

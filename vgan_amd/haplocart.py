@@ -286,7 +286,7 @@ _BATCH_FIELDS = (("read_seg_off", np.uint32, "R1"), ("read_col_off", np.uint32, 
                  ("algnseq", np.uint8, "C"), ("qual", np.uint8, "Q"))
 
 
-_PACKED_FIELDS = (("rhdr", np.uint32, lambda k: 4 * (k.n_reads + 1)), ("srec", np.uint32, lambda k: 2 * k.n_segments),
+_PACKED_FIELDS = (("rhdr", np.uint32, lambda k: 4 * (k.n_reads + 1)), ("srec", np.uint32, lambda k: k.n_segments),
                   ("crec", np.uint32, lambda k: k.n_cols), ("qualp", np.uint8, lambda k: k.n_qual + 32))
 
 
@@ -327,7 +327,7 @@ class HostBatch:
         return self.c.n_segments + (self.pk.n_segments if self.pk is not None else 0)
 
     def packed_arrays(self):
-        """numpy views of the packed part (rhdr [4(R+1)], srec [2S], crec [C], qualp [Q+32], read_src [R])."""
+        """numpy views of the packed part (rhdr [4(R+1)], srec [S], crec [C], qualp [Q+32], read_src [R])."""
         k = self.pk
         out = {name: _np_view(getattr(k, name), size(k), dt) for name, dt, size in _PACKED_FIELDS}
         out["read_src"] = _np_view(k.read_src, k.n_reads, np.uint32)
@@ -452,7 +452,7 @@ class DeviceBatch:
         n = np.zeros(4, np.uint64)
         N.check(N.lib().vgan_hc_packed_download(self._packed, n.ctypes.data, None, None, None, None))
         R, S, Cn, Q = (int(x) for x in n)
-        out = {"rhdr": np.zeros(4 * (R + 1), np.uint32), "srec": np.zeros(2 * S, np.uint32), "crec": np.zeros(Cn, np.uint32),
+        out = {"rhdr": np.zeros(4 * (R + 1), np.uint32), "srec": np.zeros(S, np.uint32), "crec": np.zeros(Cn, np.uint32),
                "qualp": np.zeros(Q + 32, np.uint8)}
         N.check(N.lib().vgan_hc_packed_download(self._packed, n.ctypes.data, out["rhdr"].ctypes.data, out["srec"].ctypes.data,
                                                 out["crec"].ctypes.data, out["qualp"].ctypes.data))
@@ -478,7 +478,7 @@ class DeviceFlatten:
 
         def download(self):
             k = self.pk
-            out = {"rhdr": np.zeros(4 * (k.n_reads + 1), np.uint32), "srec": np.zeros(2 * k.n_segments, np.uint32),
+            out = {"rhdr": np.zeros(4 * (k.n_reads + 1), np.uint32), "srec": np.zeros(k.n_segments, np.uint32),
                    "crec": np.zeros(k.n_cols, np.uint32), "qualp": np.zeros(k.n_qual + 32, np.uint8)}
             if k.n_reads:
                 N.check(N.lib().vgan_hc_packed_view_download(C.byref(k), out["rhdr"].ctypes.data, out["srec"].ctypes.data,
