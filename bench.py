@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--reads-total", type=int, default=10_000_000, help="strong scaling: reads of the whole job")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--no-frontend", action="store_true", help="skip the GAM decode / flatten rates")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the host-to-device / streamed single-pass figures")
     ap.add_argument("--path", choices=["haplocart", "euka", "soibean"], default="haplocart",
                     help="haplocart = the BASELINE metric; euka / soibean = configs 4 / 5 as extra lines")
     return ap.parse_args()
@@ -446,7 +447,7 @@ def pmc_pass(args, kernel_substr, counters):
     try:
         out = os.path.join(tmp, "pass")
         cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-pmc", "--no-frontend",
+               "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extra", "--no-pmc", "--no-frontend", "--no-ingest",
                "--reads", str(args.reads), "--read-len", str(args.read_len), "--mode", args.mode, "--seed", str(args.seed),
                "--path", args.path, "--clades", str(args.clades)]
         env = dict(os.environ, TMPDIR="/tmp")
@@ -574,6 +575,85 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
             "cpu_quota": int(N.lib().vgan_host_cpus())}
 
 
+def ingest_rates(graph, hc, ctx, dev, args, n_batches=3, passes=8):
+    """What it costs to get a batch to the kernel (the timed step replays a batch that is already in HBM; HaploCart touches each
+    read once, HaploCart.cpp:408-421): (a) the packed batch over the link from pinned host memory, alone; (b) a streamed SINGLE
+    PASS -- fresh batches, every read uploaded and accumulated exactly once: a copy stream fills one of two device buffers while
+    the kernels of the batch before run on the compute stream (events order buffer reuse).  What crosses the link is what
+    vgan_hc_accumulate_packed sends: rhdr + srec + crec (the kernel reads the quality bytes from the column records)."""
+    import numpy as np
+    import torch
+    from vgan_amd import _native as N
+    import ctypes as C
+    host = []
+    for b in range(n_batches):
+        alns = hc.synth_reads(graph, args.reads, seed=args.seed, read_len=args.read_len, first_read=(b + 1) * args.reads)
+        hb = hc.HostBatch(graph, alns, packed=True)
+        if hb.c.n_reads:  # (reads outside the tile contract would take the general kernel: not this figure's business)
+            return {"skipped": "the sample holds %d reads outside the packed layout" % hb.c.n_reads}
+        pa, k = hb.packed_arrays(), hb.pk
+        pinned = {n: torch.from_numpy(np.ascontiguousarray(pa[n].view(np.int32))).pin_memory() for n in ("rhdr", "srec", "crec")}
+        meta = {f: getattr(k, f) for f in ("n_reads", "n_segments", "n_cols", "n_qual", "max_read_segs", "max_read_qual", "max_read_cols", "max_read_node_span")}
+        host.append((pinned, meta))
+        del hb, pa, alns
+    cap = {n: max(h[0][n].numel() for h in host) for n in ("rhdr", "srec", "crec")}
+    bufs = [{n: torch.empty(cap[n], dtype=torch.int32, device=dev) for n in cap} for _ in range(2)]
+    n_bytes = sum(h[0][n].numel() * 4 for h in host for n in cap) / len(host)
+    compute, copy = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+
+    def view(buf, meta):
+        v = N.HcPackedView()
+        for f, x in meta.items():
+            setattr(v, f, x)
+        v.rhdr, v.srec, v.crec, v.qualp = buf["rhdr"].data_ptr(), buf["srec"].data_ptr(), buf["crec"].data_ptr(), None
+        v.on_device, v.read_src = 1, None
+        return v
+
+    # (a) the link alone
+    with torch.cuda.stream(copy):
+        for n in cap:
+            bufs[0][n][:host[0][0][n].numel()].copy_(host[0][0][n], non_blocking=True)
+        copy.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for n in cap:
+                bufs[0][n][:host[0][0][n].numel()].copy_(host[0][0][n], non_blocking=True)
+        copy.synchronize()
+        h2d_s = (time.perf_counter() - t0) / 3
+    # (b) the streamed single pass
+    def run(n_pass):
+        copied = [torch.cuda.Event() for _ in range(2)]
+        done = [torch.cuda.Event() for _ in range(2)]
+        reads = 0
+        for i in range(n_pass):
+            b = i & 1
+            pinned, meta = host[i % len(host)]
+            with torch.cuda.stream(copy):
+                if i >= 2:
+                    copy.wait_event(done[b])  # (the kernels that read this buffer two batches ago)
+                for n in cap:
+                    bufs[b][n][:pinned[n].numel()].copy_(pinned[n], non_blocking=True)
+                copied[b].record(copy)
+            compute.wait_event(copied[b])
+            N.check(N.lib().vgan_hc_accumulate_packed(ctx._h, C.byref(view(bufs[b], meta))))
+            done[b].record(compute)
+            reads += meta["n_reads"]
+        return reads
+    ctx.reset()
+    run(2)
+    torch.cuda.synchronize()
+    ctx.reset()
+    t0 = time.perf_counter()
+    reads = run(passes)
+    ctx.finalize()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"link_bytes_per_read": n_bytes / args.reads, "h2d_GBps_pinned": n_bytes / h2d_s / 1e9, "h2d_ms_per_1M_reads": h2d_s * 1e3 * 1e6 / args.reads,
+            "single_pass_reads_per_s": reads / el, "single_pass_batches": passes, "single_pass_reads": reads,
+            "what": "fresh %d-read packed batches from pinned host memory, double-buffered: hipMemcpyAsync on a copy stream beside the "
+                    "kernels of the batch before; every read crosses the link and is accumulated exactly once; final_vec at the end" % args.reads}
+
+
 def main():
     args = parse()
     if args.scaling is None:
@@ -605,7 +685,7 @@ def main():
     ctx.use_torch_stream()
     mode = {"node_weights": hc.MODE_NODE_WEIGHTS, "per_read": hc.MODE_PER_READ, "per_read_dense": hc.MODE_PER_READ_DENSE}[args.mode]
     ctx.set_mode(mode)
-    batches, n_reads, n_seg, algo_nw, pack_ms = [], 0, 0, 0, 0.0
+    batches, n_reads, n_seg, n_cols, algo_nw = [], 0, 0, 0, 0
     alns0 = None
     for c0 in range(r0, r1, CHUNK_READS):
         c1 = min(r1, c0 + CHUNK_READS)
@@ -617,6 +697,7 @@ def main():
         batches.append(db)
         n_reads += hb.n_reads
         n_seg += hb.n_segments
+        n_cols += hb.c.n_cols + (hb.pk.n_cols if hb.pk is not None else 0)
         algo_nw += hb.algorithmic_bytes(graph.n_paths)["node_weights"]
         if alns0 is None:
             alns0 = alns  # the cpu_baseline leg samples the first reads of rank 0
@@ -730,7 +811,8 @@ def main():
             ctx.profile_enable(False)
             ms = pr["sweep_segments"][0] / max(pr["sweep_segments"][1], 1)
             gbs = db0.n_segments * row_bytes / (ms * 1e-3) / 1e9
-            per_read[label] = {"kernel": "hc_sweep_kernel", "avg_launch_ms": ms, "achieved": gbs, "unit": "GB/s",
+            per_read[label] = {"kernel": "hc_sweep_kernel", "debug": label == "dense",  # (dense: every tile swept, a debug variant -- DESIGN.md 4.3)
+                               "avg_launch_ms": ms, "achieved": gbs, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": db0.n_segments * row_bytes,
                                "reads_per_s_kernel_only": db0.n_reads / (ms * 1e-3)}
         ctx.set_mode(mode)
@@ -751,6 +833,9 @@ def main():
             traffic = collect_traffic(args, ksub)
             issue = collect_issue(args, ksub, avg_ms)
         achieved = kbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # the same launch on SURVEY 8d's literal formula for the collapsed form, B_read' = 2 L + 16 M (L columns, M mappings per read)
+        survey_bytes = (2.0 * n_cols + 16.0 * n_seg) / len(batches)
+        survey_gbs = survey_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         what = ("%d of the %d reads of BASELINE configs[2] per GPU (contiguous shards)" % (n_reads, args.reads_total)
                 if args.scaling == "strong" else "%d synthetic %dbp reads per GPU" % (args.reads, args.read_len))
         out = {
@@ -782,9 +867,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic.get("bytes") if traffic else None, "traffic_detail": traffic,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": avg_ms, "launches": k_n,
+                         # both byte bases, so that no reader has to recompute: `frac` is on the stricter one (the input bytes of the
+                         # SoA form: 2 per column + the quality string + 8 per mapping + 15 per read)
+                         "byte_bases": {"input_bytes_per_read": kbytes * len(batches) / max(n_reads, 1), "frac_on_input_bytes": achieved / HBM_PEAK_GBS,
+                                        "survey_8d_2L_16M_bytes_per_read": survey_bytes * len(batches) / max(n_reads, 1),
+                                        "frac_on_survey_8d": survey_gbs / HBM_PEAK_GBS} if mode == hc.MODE_NODE_WEIGHTS else None,
                          # what limits the launch: vector-instruction issue and LDS, from an in-run SQ pass
                          "alu": issue, "limiter": issue},
-            "layout_pass_ms": pack_ms,
             "kernel_ms_per_step": my_kernels,
             "per_rank": per_rank if world > 1 else None,
             "dist": dist_info,
@@ -799,6 +888,9 @@ def main():
         }
         if world == 1 and not args.no_frontend:
             out["front_end"] = front_end_rates(graph, hc, args.seed, ctx=ctx)
+        if world == 1 and not args.no_ingest and mode == hc.MODE_NODE_WEIGHTS:
+            batches.clear()  # (the resident batch's HBM is not needed any more)
+            out["ingest"] = ingest_rates(graph, hc, ctx, dev, args)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(graph, alns0, args.cpu_seconds, ctx, hc)
         print(json.dumps(out), flush=True)

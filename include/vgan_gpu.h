@@ -249,8 +249,10 @@ void vgan_hc_host_batch_free(vgan_hc_host_batch *b);
  *                                      get_log_lik_if_unsupported, process_mapping.cpp:4-24, from the column records it holds
  *                                      anyway), byte 3 = VGAN_HC_CREC_HEAD >> 24 on the first column of a mapping and 0
  *                                      elsewhere; bytes 0 and 1 of a column no mapping scores are 0
- *   qualp  uint8 [n_qual + 32]         the quality strings, followed by 32 zero bytes (aligned 8-byte words are read whole;
- *                                      read by the per-segment kernel forms only)
+ *   qualp  uint8 [n_qual + 32]         the quality strings, followed by 32 zero bytes (aligned 8-byte words are read whole).
+ *                                      Read by the per-segment kernel forms only: vgan_hc_accumulate_packed in the node-weights
+ *                                      mode neither uploads nor reads it when the kernel that takes the batch finds the quality
+ *                                      bytes in the column records, and accepts NULL here then (VGAN_EINVAL otherwise)
  * (ABI 5) The tile contract also asks for a quality string no longer than the read's columns (|quality| <= |algnseq|: the
  * parser takes the two lengths independently); a read that breaks it stays with the SoA batch.
  * Reads in ascending order of their lowest node id, those of mapping quality VGAN_HC_MAPQ_MAJOR first and the others behind

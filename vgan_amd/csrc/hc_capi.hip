@@ -365,7 +365,9 @@ int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *n
 
 // A packed batch on the device: in place when it is there already, else copied as it is into the context's scratch
 // (the one copy of the batch HBM holds; no layout pass).
-int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d) {
+// want_qual false: the kernel that takes the batch reads the quality bytes from the column records (hc_col8_kernels.hip), and
+// the second copy of the quality strings is neither asked for nor sent.
+int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d, bool want_qual = true) {
     if (!v) return fail(VGAN_EINVAL, "null packed batch");
     d = HcPackedDev{};
     d.n_reads = v->n_reads;
@@ -377,7 +379,7 @@ int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d) {
     d.max_read_cols = v->max_read_cols;
     d.max_read_node_span = v->max_read_node_span;
     if (v->n_reads == 0) return VGAN_OK;
-    if (!v->rhdr || !v->srec || !v->crec || !v->qualp) return fail(VGAN_EINVAL, "packed batch: null array");
+    if (!v->rhdr || !v->srec || !v->crec || (want_qual && !v->qualp)) return fail(VGAN_EINVAL, "packed batch: null array");
     if (v->max_read_segs > HC_TILE_MAX_READ_SEGS || v->max_read_qual > HC_TILE_MAX_READ_QUAL || v->max_read_cols > HC_TILE_MAX_READ_COLS ||
         v->max_read_segs == 0)
         return fail(VGAN_EINVAL, "packed batch: per-read maxima missing or beyond the tile contract (512 segments / 1280 quality bytes / 1280 columns)");
@@ -393,16 +395,16 @@ int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d) {
     vgan_hc_packed &P = c->scratch_pack;
     P.device = c->device;
     if ((rc = P.rhdr.reserve((size_t)v->n_reads + 1)) || (rc = P.srec.reserve(std::max<size_t>(1, v->n_segments))) ||
-        (rc = P.crec.reserve(std::max<size_t>(1, v->n_cols))) || (rc = P.qualp.reserve((size_t)v->n_qual + 32)))
+        (rc = P.crec.reserve(std::max<size_t>(1, v->n_cols))) || (want_qual && (rc = P.qualp.reserve((size_t)v->n_qual + 32))))
         return rc;
     HIPCHK(hipMemcpyAsync(P.rhdr.p, v->rhdr, ((size_t)v->n_reads + 1) * 16, hipMemcpyHostToDevice, c->stream));
     if (v->n_segments) HIPCHK(hipMemcpyAsync(P.srec.p, v->srec, (size_t)v->n_segments * 4, hipMemcpyHostToDevice, c->stream));
     if (v->n_cols) HIPCHK(hipMemcpyAsync(P.crec.p, v->crec, (size_t)v->n_cols * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(P.qualp.p, v->qualp, (size_t)v->n_qual + 32, hipMemcpyHostToDevice, c->stream));
+    if (want_qual) HIPCHK(hipMemcpyAsync(P.qualp.p, v->qualp, (size_t)v->n_qual + 32, hipMemcpyHostToDevice, c->stream));
     d.rhdr = P.rhdr.p;
     d.srec = P.srec.p;
     d.crec = P.crec.p;
-    d.qualp = P.qualp.p;
+    d.qualp = want_qual ? P.qualp.p : nullptr;
     return VGAN_OK;
 }
 
@@ -426,6 +428,7 @@ int run_packed(vgan_hc_ctx *c, const HcPackedDev &d, double *segD, double *nodeW
     ScopedTimer t(c, VGAN_HC_K_SEGMENT);
     // node-weights accumulation alone: eight columns to a lane and the table of column terms, where the batch and the graph fit
     if (nodeW && !segD && hc_col8_kernel_fits(c->g, d)) launch_hc_segments_col8(c->g, d, c->prm, nodeW, totals, c->stream);
+    else if (!d.qualp) return fail(VGAN_EINVAL, "packed batch: this batch takes a kernel that reads the quality strings' own copy (qualp), which the view does not carry");
     else launch_hc_segments_wave(c->g, d, c->prm, segD, nodeW, totals, c->work_ctr.p, &c->work_base, c->stream);
     if (hipGetLastError() != hipSuccess) {
         c->work_dirty = true; // (the host's mirror of the ticket counter no longer holds: the next launch starts it over)
@@ -815,7 +818,21 @@ extern "C" int vgan_hc_accumulate_packed(vgan_hc_ctx *c, const vgan_hc_packed_vi
     HIPCHK(hipSetDevice(c->device));
     int rc;
     HcPackedDev d{};
-    if ((rc = stage_packed(c, v, d))) return rc;
+    // (node-weights accumulation through hc_segment_col8_kernel: the quality bytes are read from the column records, their second
+    // copy stays where it is -- 150 of a 150 bp read's 1006 bytes that do not cross the link)
+    bool want_qual = true;
+    if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) {
+        HcPackedDev probe{};
+        probe.n_reads = v->n_reads;
+        probe.n_segments = v->n_segments;
+        probe.n_cols = v->n_cols;
+        probe.max_read_segs = v->max_read_segs;
+        probe.max_read_qual = v->max_read_qual;
+        probe.max_read_cols = v->max_read_cols;
+        probe.max_read_node_span = v->max_read_node_span;
+        want_qual = !hc_col8_kernel_fits(c->g, probe);
+    }
+    if ((rc = stage_packed(c, v, d, want_qual))) return rc;
     if (c->mode == VGAN_HC_MODE_NODE_WEIGHTS) return run_packed(c, d, nullptr, c->nodeW.p, c->totals.p);
     // the reference's loop order: D_m per segment, then every segment's mask row over the P accumulators
     if ((rc = c->segD.reserve(v->n_segments)) || (rc = c->s_u32.reserve(v->n_segments))) return rc;
