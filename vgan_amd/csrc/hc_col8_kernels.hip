@@ -39,13 +39,16 @@
 namespace vgan {
 namespace c8 {
 
-constexpr int C8_THREADS = 1024, C8_WAVES = 16;
-constexpr int C8_CPL = 8;               // columns per lane
-constexpr int C8_CAPC = 64 * C8_CPL;    // columns,
-constexpr int C8_CAPS = 192;            // segments and
+// A variant of the kernel: columns per lane (a multiple of 8: the tile holds 64 * CPL columns), segments per tile (whole passes
+// of 64), node ids covered by a wave's W window, waves of the one workgroup a CU holds (what its LDS can carry).
+template <int CPL_, int CAPS_, int WIN_, int WAVES_> struct C8Cfg {
+    static constexpr int CPL = CPL_, CAPC = 64 * CPL_, CAPS = CAPS_, SPASS = CAPS_ / 64, WIN = WIN_, WAVES = WAVES_, THREADS = 64 * WAVES_;
+    static_assert(CPL_ % 8 == 0 && CAPS_ % 64 == 0, "whole groups and passes");
+};
+using C8Short = C8Cfg<8, 192, 160, 16>;  // three 150 bp reads to a tile (a read spans 106 node ids on the hcfiles graph, 140 at most)
+using C8Mid = C8Cfg<16, 384, 256, 8>;    // three 300 bp reads (212 node ids)
+using C8Long = C8Cfg<24, 512, 512, 4>;   // two 600 bp reads (424 node ids); a read up to the tile contract's 1280 columns / 512 segments
 constexpr int C8_NR = 8;                // reads per tile at most (the segment records carry the read's index & 7)
-constexpr int C8_SPASS = C8_CAPS / 64;
-constexpr int C8_WIN = 160;             // node ids covered by a wave's W window (hc_wave_kernels.hip: WV_WIN_SLOTS)
 constexpr int C8_QMAX = 48;             // quality values the table of column terms covers: [0, C8_QMAX)
 constexpr int C8_NMEMO = 16;            // node classes it covers (the most frequent ones)
 constexpr uint32_t C8_CLS_BYTES = C8_QMAX * 64u; // a class's part of the table: [quality][match][read base] doubles
@@ -61,7 +64,8 @@ struct alignas(16) C8Lom { // per (error-rate index, base match): log(om), 1 / o
     double lom, iom;
 };
 
-struct C8Slice { // one wave's LDS
+template <class K> struct C8Slice { // one wave's LDS
+    static constexpr int C8_CAPC = K::CAPC, C8_CAPS = K::CAPS, C8_WIN = K::WIN;
     union {
         uint32_t ps[C8_CAPC + 8]; // ps[4 + j]: prefix through tile column j (ps[3] = 0: the empty prefix); dead behind phase C
         C8KL kl[C8_CAPS];         // a general tile's {kappa, lw} per segment (written behind phase C)
@@ -74,7 +78,7 @@ struct C8Slice { // one wave's LDS
     unsigned long long win_i[C8_WIN]; // {count of Q <= 2 (low word), sum of Q above 2 (high word)} per window slot
 };
 
-struct C8Lds {
+template <class K> struct C8Lds {
     double memo[C8_NMEMO * C8_QMAX * 8]; // first: its byte offsets fit the 16 bits info[] gives them
     C8Lom lom[101][2];                   // [qscore index, 100 = background error rate][mismatch, match]
     double2 bg[4];                       // A C T G by (base >> 1) & 3: {frequency, frequency / 6}
@@ -82,9 +86,9 @@ struct C8Lds {
     HcNodeDev cls[HC_MAX_NODE_CLASSES];  // the node classes' scalars
     uint32_t ticket;                     // the workgroup's work queue: the next ticket
     uint32_t pad_[3];
-    C8Slice slice[C8_WAVES];
+    C8Slice<K> slice[K::WAVES];
 };
-static_assert(sizeof(C8Lds) <= 163840, "one workgroup per CU: all of its LDS");
+static_assert(sizeof(C8Lds<C8Short>) <= 163840 && sizeof(C8Lds<C8Mid>) <= 163840 && sizeof(C8Lds<C8Long>) <= 163840, "one workgroup per CU: all of its LDS");
 
 __device__ const LogTabEntry c8_log_table[64] = {VGAN_LOG_TABLE};
 
@@ -241,8 +245,11 @@ __device__ unsigned long long c8_stats[8];
 #define C8_COUNT(slot, n)
 #endif
 
-__global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
-    __shared__ C8Lds S;
+template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8_kernel(C8Args a) {
+    constexpr int C8_CPL = K::CPL, C8_CAPC = K::CAPC, C8_CAPS = K::CAPS, C8_SPASS = K::SPASS, C8_WIN = K::WIN, C8_WAVES = K::WAVES, C8_THREADS = K::THREADS;
+    constexpr int C8_NG = C8_CPL / 4; // 16-byte groups of column records per lane
+    using C8Slice = c8::C8Slice<K>;
+    __shared__ C8Lds<K> S;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
     };
     const c8_rsrc rs_hdr = c8_make_rsrc(a.rhdr, (a.n_reads + 1u) * 16u);
     const c8_rsrc rs_nhi = c8_make_rsrc(a.node_hi, a.rows * 2u);
-    const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u, lane32 = (uint32_t)lane * 32u;
+    const uint32_t lane4 = (uint32_t)lane * 4u, laneC = (uint32_t)lane * (uint32_t)C8_CPL, laneC4 = laneC * 4u;
     const uint32_t memo_base = lds_addr(&S.memo[0]);
     const uint32_t info_base = lds_addr(&L.info[0]), wind_base = lds_addr(&L.win_d[0]), wini_base = lds_addr(&L.win_i[0]);
 
@@ -324,10 +331,10 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
         return C8Tile{r, n, hs0, n_seg, hc0, n_col, w1};
     };
     // a tile's loads are issued unconditionally (`live` false: descriptors of length zero, nothing is fetched)
-    auto request_cols = [&](const C8Tile &t, bool live, uint4 &lo, uint4 &hi) {
+    auto request_cols = [&](const C8Tile &t, bool live, uint4 (&rq)[C8_NG]) { // the lane's C8_CPL consecutive columns
         const c8_rsrc rs_c = c8_make_rsrc(a.crec + t.c_base, live ? t.n_col * 4u : 0u);
-        lo = c8_load4(rs_c, lane32);
-        hi = c8_load4(rs_c, lane32 + 16u);
+#pragma unroll
+        for (int g = 0; g < C8_NG; ++g) rq[g] = c8_load4(rs_c, laneC4 + (uint32_t)g * 16u);
     };
     auto request_segs = [&](const C8Tile &t, bool live, uint32_t (&sr)[C8_SPASS]) { // (VGAN_HC_SREC: node | seg_start << 18 | read index & 7 << 29)
         const c8_rsrc rs_s = c8_make_rsrc(a.srec + t.s_base, live ? t.n_seg * 4u : 0u);
@@ -380,11 +387,11 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
     bool fresh_n, fresh = true;
     next_first(T, fn, wn, fresh_n);
     Hn = header_load(fn, wn);
-    uint4 rl, rh, nl, nh4; // the tile's column records (lane's columns 0..3, 4..7), the next tile's
+    uint4 rq[C8_NG], rqN[C8_NG]; // the tile's column records (the lane's columns, four to a register group), the next tile's
     uint32_t sr[C8_SPASS], srN[C8_SPASS];
     uint32_t nhi[C8_SPASS], nhiN[C8_SPASS]; // the mappings' node classes
     request_segs(T, true, sr);
-    request_cols(T, true, rl, rh);
+    request_cols(T, true, rq);
     request_classes(sr, nhi);
 
 #ifdef C8_PHASES
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
         bool fresh_2 = false;
         if (has_next) next_first(Tn, f2, w2, fresh_2);
         request_segs(Tn, has_next, srN);
-        request_cols(Tn, has_next, nl, nh4);
+        request_cols(Tn, has_next, rqN);
         Hn = header_load(f2, w2);
 #ifdef C8_L2_PREFETCH // (measured: 0.437 against 0.361 ms -- more requests in flight make every one of them slower; kept for A/B runs)
         // the tile after the next one: its records' cache lines are touched now (one dword a line, the value is not used), so that
@@ -428,15 +435,22 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
                 L.rdA[lane] = uint2{A | (QL << 16), min(h_c - T.c_base, (uint32_t)C8_CAPC) | (mq << 16) | major};
             }
         }
-        const uint32_t rec[8] = {rl.x, rl.y, rl.z, rl.w, rh.x, rh.y, rh.z, rh.w};
+        uint32_t rec[C8_CPL];
+#pragma unroll
+        for (int g = 0; g < C8_NG; ++g) {
+            rec[4 * g] = rq[g].x;
+            rec[4 * g + 1] = rq[g].y;
+            rec[4 * g + 2] = rq[g].z;
+            rec[4 * g + 3] = rq[g].w;
+        }
 
         // ---- Q: prefix sums of {Q above 2: Q << 11, else 1} over the tile's columns, from byte 2 of the records
         bool q_plain, tile_hot; // every quality byte of the tile in [0, C8_QMAX); one at 90 or above (bytes are signed, as the reference reads them)
         {
-            uint32_t loc[8], run = 0u;
+            uint32_t loc[C8_CPL], run = 0u;
             int mn = 127, mx = -128;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < C8_CPL; ++e) {
                 const int Q = __builtin_amdgcn_sbfe((int)rec[e], 16u, 8u);
                 run += Q > 2 ? (uint32_t)Q << 11 : 1u;
                 loc[e] = run;
@@ -445,9 +459,9 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
             }
             const uint32_t incl = c8_scan_u32(run);
             const uint32_t before = incl - run;
-            uint4 *dst = reinterpret_cast<uint4 *>(&L.ps[4 + lane * 8]);
-            dst[0] = uint4{before + loc[0], before + loc[1], before + loc[2], before + loc[3]};
-            dst[1] = uint4{before + loc[4], before + loc[5], before + loc[6], before + loc[7]};
+            uint4 *dst = reinterpret_cast<uint4 *>(&L.ps[4 + lane * C8_CPL]);
+#pragma unroll
+            for (int g = 0; g < C8_NG; ++g) dst[g] = uint4{before + loc[4 * g], before + loc[4 * g + 1], before + loc[4 * g + 2], before + loc[4 * g + 3]};
             // (columns past the tile's come back as zero records: quality 0)
             q_plain = __builtin_amdgcn_ballot_w64(mn < 0 || mx >= C8_QMAX) == 0;
             tile_hot = __builtin_amdgcn_ballot_w64(mx >= 90) != 0; // switches the rest of a read to the background error rate (update_likelihood.cpp:40-44)
@@ -459,9 +473,9 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma nounroll
-            for (int e = 0; e < 8; ++e) { // first90[k] = index of the first such byte in read k's quality string
+            for (int e = 0; e < C8_CPL; ++e) { // first90[k] = index of the first such byte in read k's quality string
                 const int Q = __builtin_amdgcn_sbfe((int)rec[e], 16u, 8u);
-                const uint32_t col = lane8 + (uint32_t)e;
+                const uint32_t col = laneC + (uint32_t)e;
                 if (Q >= 90 && col < T.n_col) {
                     uint32_t kk = 0;
                     for (uint32_t t = 1; t < T.n; ++t) kk += col >= (L.rdA[t].y & 0xFFFFu) ? 1u : 0u;
@@ -584,42 +598,42 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         C8_MARK(3);
 
-        // ---- D: a lane's eight columns.  Index of a column's mapping * 4 = running sum of the head flags (byte 3 = 4).
+        // ---- D: the lane's columns, eight at a time.  Index of a column's mapping * 4 = running sum of the head flags (byte 3 = 4).
         {
-            uint32_t own[8];
+            uint32_t own[C8_CPL];
             own[0] = rec[0] >> 24;
 #pragma unroll
-            for (int e = 1; e < 8; ++e)
+            for (int e = 1; e < C8_CPL; ++e)
                 asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(own[e]) : "v"(rec[e]), "v"(own[e - 1]));
-            const uint32_t incl = c8_scan_u32(own[7]);
-            const uint32_t ibase = incl - own[7] + info_base; // (info[0] stands for "no mapping yet")
-            uint32_t inf[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) inf[e] = lds_ld32(ibase + own[e]);
+            const uint32_t incl = c8_scan_u32(own[C8_CPL - 1]);
+            const uint32_t excl = incl - own[C8_CPL - 1];
+            const uint32_t ibase = excl + info_base; // (info[0] stands for "no mapping yet")
             if (__builtin_expect(tabled, 1)) {
-                auto steps = [&](auto from_global) {
+                auto steps = [&](auto from_global, const uint32_t *rec8, const uint32_t *own8) {
                     constexpr bool G = decltype(from_global)::value;
                     double t[8];
                     uint64_t valid[8];
-                    uint32_t rbo[8];
+                    uint32_t inf[8], rbo[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) inf[e] = lds_ld32(ibase + own8[e]);
                     if constexpr (G) {
                         // the read's part of the context's table, less the LDS address info[] carries (the "no mapping yet" slot reads ps[3] = 0)
                         const uint32_t rbase = ibase + (lds_addr(&L.ps[3]) - info_base);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) rbo[e] = lds_ld32(rbase + own[e]) - memo_base;
+                        for (int e = 0; e < 8; ++e) rbo[e] = lds_ld32(rbase + own8[e]) - memo_base;
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         // both bases among A C G T (process_mapping.cpp:62-63): the codes (b >> 1) & 3 select their letters out of
                         // "A.C.T.G." and the pair of letters is compared with the pair of bytes
                         uint32_t sel, want;
-                        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(rec[e]), "s"(0x0606u), "v"(0x0C0C0000u)); // (one scalar operand an instruction)
+                        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(rec8[e]), "s"(0x0606u), "v"(0x0C0C0000u)); // (one scalar operand an instruction)
                         want = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, sel);
-                        asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0" : "=s"(valid[e]) : "v"(want), "v"(rec[e]));
-                        const uint32_t q = __builtin_amdgcn_ubfe(rec[e], 16u, 8u);
+                        asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0" : "=s"(valid[e]) : "v"(want), "v"(rec8[e]));
+                        const uint32_t q = __builtin_amdgcn_ubfe(rec8[e], 16u, 8u);
                         uint32_t row; // 2 q + (graph base == read base): the compare writes VCC, the add takes it as carry
-                        asm("v_cmp_eq_u32_sdwa vcc, %1, %1 src0_sel:BYTE_0 src1_sel:BYTE_1\n\tv_addc_co_u32 %0, vcc, %2, %2, vcc" : "=v"(row) : "v"(rec[e]), "v"(q) : "vcc");
-                        const uint32_t rc = __builtin_amdgcn_ubfe(rec[e], 9u, 2u);
+                        asm("v_cmp_eq_u32_sdwa vcc, %1, %1 src0_sel:BYTE_0 src1_sel:BYTE_1\n\tv_addc_co_u32 %0, vcc, %2, %2, vcc" : "=v"(row) : "v"(rec8[e]), "v"(q) : "vcc");
+                        const uint32_t rc = __builtin_amdgcn_ubfe(rec8[e], 9u, 2u);
                         const uint32_t ad = (rc << 3) + ((row << 5) + (inf[e] >> 16));
                         if constexpr (G) t[e] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(a.gmemo) + (ad + rbo[e]));
                         else t[e] = lds_ld64(ad);
@@ -631,32 +645,41 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
                         if (__builtin_amdgcn_inverse_ballot_w64(valid[e])) lds_fadd(sa, t[e]);
                     }
                 };
-                if (gfast) steps(std::true_type{});
-                else steps(std::false_type{});
+#pragma unroll
+                for (int g8 = 0; g8 < C8_CPL; g8 += 8) {
+                    if (gfast) steps(std::true_type{}, &rec[g8], &own[g8]);
+                    else steps(std::false_type{}, &rec[g8], &own[g8]);
+                }
             } else {
                 const uint32_t klbase = lds_addr(&L.kl[0]) - 4u * 4u; // (own counts from 4: segment 0)
+#pragma unroll
+                for (int g8 = 0; g8 < C8_CPL; g8 += 8) {
+                    uint32_t inf[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) inf[e] = lds_ld32(ibase + own[g8 + e]);
 #pragma unroll 1
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t r_ = rec[e];
-                    const uint32_t want = __builtin_amdgcn_perm(0x47544341u, 0x47544341u, (r_ >> 1) & 0x0303u);
-                    const bool valid = (want & 0xFFFFu) == (r_ & 0xFFFFu);
-                    int q = __builtin_amdgcn_sbfe((int)r_, 16u, 8u);
-                    q = q < 0 ? 0 : (q > 99 ? 99 : q); // qscore_vec's index
-                    uint32_t row = 2u * (uint32_t)q + ((r_ & 0xFFu) == ((r_ >> 8) & 0xFFu) ? 1u : 0u);
-                    const uint32_t own_seg4 = incl - own[7] + own[e]; // (index + 1) * 4
-                    const c8_v2d klv = *(lds_v2dp)(size_t)(klbase + own_seg4 * 4u);
-                    const C8KL kl{klv.x, klv.y};
-                    if (tile_bep && __double2hiint(kl.kappa) < 0) row = 200u + (row & 1u);
-                    const C8Lom lo = *reinterpret_cast<const C8Lom *>(reinterpret_cast<const uint8_t *>(S.lom) + (row << 4));
-                    const double2 bg = S.bg[(r_ >> 9) & 3u];
-                    const double tt = c8_col_term(kl.kappa, kl.lw, lo, bg, S.logtab);
-                    if (valid && own_seg4 != 0u) {
-                        const uint32_t so = inf[e] & 0xFFFFu;
-                        if (so == C8_OUTSIDE) {
-                            sumT += tt;
-                            unsafeAtomicAdd(&a.nodeW[min(a.srec[T.s_base + (own_seg4 >> 2) - 1u] & VGAN_HC_SREC_MAX_NODE, a.rows - 1u)], tt);
-                        } else {
-                            lds_fadd(wind_base + so, tt);
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t r_ = rec[g8 + e];
+                        const uint32_t want = __builtin_amdgcn_perm(0x47544341u, 0x47544341u, (r_ >> 1) & 0x0303u);
+                        const bool valid = (want & 0xFFFFu) == (r_ & 0xFFFFu);
+                        int q = __builtin_amdgcn_sbfe((int)r_, 16u, 8u);
+                        q = q < 0 ? 0 : (q > 99 ? 99 : q); // qscore_vec's index
+                        uint32_t row = 2u * (uint32_t)q + ((r_ & 0xFFu) == ((r_ >> 8) & 0xFFu) ? 1u : 0u);
+                        const uint32_t own_seg4 = excl + own[g8 + e]; // (index + 1) * 4
+                        const c8_v2d klv = *(lds_v2dp)(size_t)(klbase + own_seg4 * 4u);
+                        const C8KL kl{klv.x, klv.y};
+                        if (tile_bep && __double2hiint(kl.kappa) < 0) row = 200u + (row & 1u);
+                        const C8Lom lo = *reinterpret_cast<const C8Lom *>(reinterpret_cast<const uint8_t *>(S.lom) + (row << 4));
+                        const double2 bg = S.bg[(r_ >> 9) & 3u];
+                        const double tt = c8_col_term(kl.kappa, kl.lw, lo, bg, S.logtab);
+                        if (valid && own_seg4 != 0u) {
+                            const uint32_t so = inf[e] & 0xFFFFu;
+                            if (so == C8_OUTSIDE) {
+                                sumT += tt;
+                                unsafeAtomicAdd(&a.nodeW[min(a.srec[T.s_base + (own_seg4 >> 2) - 1u] & VGAN_HC_SREC_MAX_NODE, a.rows - 1u)], tt);
+                            } else {
+                                lds_fadd(wind_base + so, tt);
+                            }
                         }
                     }
                 }
@@ -693,8 +716,8 @@ __global__ __launch_bounds__(C8_THREADS) void hc_segment_col8_kernel(C8Args a) {
         wn = w2;
         fresh = fresh_n;
         fresh_n = fresh_2;
-        rl = nl;
-        rh = nh4;
+#pragma unroll
+        for (int g = 0; g < C8_NG; ++g) rq[g] = rqN[g];
     }
     if (winbase != 0xFFFFFFFFu) window_flush(winbase);
 #ifdef C8_PHASES
@@ -782,18 +805,28 @@ extern "C" int vgan_hc_debug_col8_stats(unsigned long long *out, int reset) {
 }
 #endif
 
-// Which batches the kernel takes: node-weights accumulation of reads that fit its tile (several to a tile) and its W window, on a
-// graph whose nodes fall into at most HC_MAX_NODE_CLASSES classes.  VGAN_HC_KERNEL=wave / tile keep the older kernels (A/B runs).
-bool hc_col8_kernel_fits(const HcGraphDev &g, const HcPackedDev &pk) {
-    const char *e = getenv("VGAN_HC_KERNEL");
-    if (e && (strcmp(e, "wave") == 0 || strcmp(e, "tile") == 0)) return false;
-    if (g.n_cls == 0 || !g.node_hi || !g.cls_tab || !g.col_memo || pk.n_reads == 0) return false;
-    if (pk.max_read_segs > (uint32_t)C8_CAPS || pk.max_read_cols > (uint32_t)C8_CAPC || pk.max_read_qual > pk.max_read_cols) return false;
-    const uint32_t mean_segs = pk.n_segments / pk.n_reads, mean_cols = (uint32_t)(pk.n_cols / pk.n_reads);
-    if (2u * mean_segs > (uint32_t)C8_CAPS || 2u * mean_cols > (uint32_t)C8_CAPC) return false; // (a read to a tile: the wave kernel's large variant)
-    const uint32_t span = pk.max_read_node_span ? pk.max_read_node_span : mean_cols * 3u / 4u;
-    return span < (uint32_t)C8_WIN;
+// Which batches the kernel takes: node-weights accumulation of reads that fit one of its variants' tiles and W window, on a graph
+// whose nodes fall into at most HC_MAX_NODE_CLASSES classes.  VGAN_HC_KERNEL=wave / tile keep the older kernels (A/B runs).
+namespace {
+template <class K> bool c8_variant_holds(const HcPackedDev &pk, uint32_t span) {
+    return pk.max_read_segs <= (uint32_t)K::CAPS && pk.max_read_cols <= (uint32_t)K::CAPC && span < (uint32_t)K::WIN;
 }
+// 0 none, 1 short, 2 mid, 3 long: the smallest variant that holds every read and, where a larger one is needed for that, the larger
+int c8_variant(const HcGraphDev &g, const HcPackedDev &pk) {
+    const char *e = getenv("VGAN_HC_KERNEL");
+    if (e && (strcmp(e, "wave") == 0 || strcmp(e, "tile") == 0)) return 0;
+    if (g.n_cls == 0 || !g.node_hi || !g.cls_tab || !g.col_memo || pk.n_reads == 0) return 0;
+    if (pk.max_read_qual > pk.max_read_cols) return 0;
+    const uint32_t mean_segs = pk.n_segments / pk.n_reads, mean_cols = (uint32_t)(pk.n_cols / pk.n_reads);
+    const uint32_t span = pk.max_read_node_span ? pk.max_read_node_span : mean_cols * 3u / 4u;
+    // (at least two mean reads to a tile where a variant offers that: a lone read leaves half of a tile's lanes idle)
+    if (c8_variant_holds<C8Short>(pk, span) && (2u * mean_segs <= (uint32_t)C8Short::CAPS && 2u * mean_cols <= (uint32_t)C8Short::CAPC)) return 1;
+    if (c8_variant_holds<C8Mid>(pk, span) && (2u * mean_segs <= (uint32_t)C8Mid::CAPS && 2u * mean_cols <= (uint32_t)C8Mid::CAPC)) return 2;
+    if (c8_variant_holds<C8Long>(pk, span)) return 3;
+    return 0;
+}
+} // namespace
+bool hc_col8_kernel_fits(const HcGraphDev &g, const HcPackedDev &pk) { return c8_variant(g, pk) != 0; }
 
 void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *nodeW, double *totals, hipStream_t st) {
     if (pk.n_reads == 0) return;
@@ -805,8 +838,10 @@ void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const H
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         n_cu_dev[dev] = n;
     }
+    const int variant = c8_variant(g, pk);
+    const uint32_t waves = variant == 1 ? C8Short::WAVES : variant == 2 ? C8Mid::WAVES : C8Long::WAVES;
     const uint32_t n_blocks = (pk.n_reads + C8_BLOCK - 1u) / C8_BLOCK;
-    const uint32_t blocks = std::min<uint32_t>((uint32_t)n_cu_dev[dev], (n_blocks + C8_WAVES - 1) / C8_WAVES); // (a workgroup per CU: all of its LDS)
+    const uint32_t blocks = std::min<uint32_t>((uint32_t)n_cu_dev[dev], (n_blocks + waves - 1) / waves); // (a workgroup per CU: all of its LDS)
     C8Args a{};
     a.rhdr = pk.rhdr;
     a.srec = pk.srec;
@@ -826,7 +861,9 @@ void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const H
     a.n_segs8 = (uint64_t)pk.n_segments * 4u;
     a.use_bep = prm.use_bep ? 1u : 0u;
     a.consensus = prm.consensus ? 1u : 0u;
-    hipLaunchKernelGGL(hc_segment_col8_kernel, dim3(blocks), dim3(C8_THREADS), 0, st, a);
+    if (variant == 1) hipLaunchKernelGGL(hc_segment_col8_kernel<C8Short>, dim3(blocks), dim3(C8Short::THREADS), 0, st, a);
+    else if (variant == 2) hipLaunchKernelGGL(hc_segment_col8_kernel<C8Mid>, dim3(blocks), dim3(C8Mid::THREADS), 0, st, a);
+    else if (variant == 3) hipLaunchKernelGGL(hc_segment_col8_kernel<C8Long>, dim3(blocks), dim3(C8Long::THREADS), 0, st, a);
 }
 
 } // namespace vgan
