@@ -282,7 +282,7 @@ bool wave_kernel_enabled() {
 // largest per-read counts when the caller knows them (host arrays); otherwise (readback) they are taken from the device,
 // which synchronises the stream.
 int pack_into(vgan_hc_ctx *c, const vgan_hc_batch *b, const HcBatchDev &d, uint32_t nt, vgan_hc_packed &P, bool readback,
-              uint32_t max_segs, uint32_t max_qual, uint32_t max_cols) {
+              uint32_t max_segs, uint32_t max_qual, uint32_t max_cols, uint32_t qual_excess = 0) {
     int rc;
     P.device = c->device;
     if ((rc = P.rhdr.reserve((size_t)nt + 1)) || (rc = P.srec.reserve(std::max<size_t>(1, b->n_segments))) ||
@@ -292,12 +292,13 @@ int pack_into(vgan_hc_ctx *c, const vgan_hc_batch *b, const HcBatchDev &d, uint3
     launch_hc_pack(d, nt, b->n_cols, b->n_qual, P.rhdr.p, P.srec.p, P.crec.p, P.qualp.p, readback ? P.maxima.p : nullptr, c->stream);
     HIPCHK(hipGetLastError());
     if (readback) {
-        uint32_t mx[3] = {0, 0, 0};
-        HIPCHK(hipMemcpyAsync(mx, P.maxima.p, 12, hipMemcpyDeviceToHost, c->stream));
+        uint32_t mx[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(mx, P.maxima.p, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         max_segs = mx[0];
         max_qual = mx[1];
         max_cols = mx[2];
+        qual_excess = mx[3];
     }
     P.d.rhdr = P.rhdr.p;
     P.d.srec = P.srec.p;
@@ -310,6 +311,7 @@ int pack_into(vgan_hc_ctx *c, const vgan_hc_batch *b, const HcBatchDev &d, uint3
     P.d.max_read_segs = max_segs;
     P.d.max_read_qual = max_qual;
     P.d.max_read_cols = max_cols;
+    P.d.qual_excess = qual_excess;
     return VGAN_OK;
 }
 
@@ -337,15 +339,17 @@ int run_segments(vgan_hc_ctx *c, const vgan_hc_batch *b, double *segD, double *n
     if (staged) *staged = d;
     if (nt && !pk && !b->on_device && wave_kernel_enabled()) {
         // host arrays: the per-read maxima that select the kernel variant cost one pass over the offsets here
-        uint32_t ms = 0, mq = 0, mc = 0;
+        uint32_t ms = 0, mq = 0, mc = 0, mx = 0;
         for (uint32_t r = 0; r < nt; ++r) {
+            const uint32_t q = b->read_qual_off[r + 1] - b->read_qual_off[r], cl = b->read_col_off[r + 1] - b->read_col_off[r];
             ms = std::max(ms, b->read_seg_off[r + 1] - b->read_seg_off[r]);
-            mq = std::max(mq, b->read_qual_off[r + 1] - b->read_qual_off[r]);
-            mc = std::max(mc, b->read_col_off[r + 1] - b->read_col_off[r]);
+            mq = std::max(mq, q);
+            mc = std::max(mc, cl);
+            mx = std::max(mx, q > cl ? q - cl : 0u);
         }
         if (hc_wave_kernel_fits(ms, mq, mc, mean_segs, mean_cols)) {
             ScopedTimer t(c, VGAN_HC_K_PACK);
-            if ((rc = pack_into(c, b, d, nt, c->scratch_pack, false, ms, mq, mc))) return rc;
+            if ((rc = pack_into(c, b, d, nt, c->scratch_pack, false, ms, mq, mc, mx))) return rc;
             pk = &c->scratch_pack;
         }
     }

@@ -551,15 +551,17 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                     sticky_m[k] = __builtin_amdgcn_ballot_w64(sticky);
                     tile_bep = tile_bep || sticky_m[k] != 0;
                 }
-                // per lane, counted over its (up to three) mappings: those outside the window (bits 0-1), on a node class outside the
-                // tables (bits 8-9), of a read of another mapping quality (bits 16-17) -- three ballots a tile instead of three a pass
+                // per lane, counted over its mappings (one a pass, eight passes at most): those outside the window (bits 0-7), on a node
+                // class outside the tables (bits 8-15), of a read of another mapping quality (bits 16-23) -- three ballots a tile
+                // instead of three a pass
                 const uint32_t bits = (inside ? 0u : 1u) + (nhi[k] >= 0xE000u ? 0x100u : 0u) + ((rd[k].y & 0x800000u) ? 0u : 0x10000u);
                 seg_flags += on ? bits : 0u;
                 seg_rb[k] = ((rd[k].y >> 16) & 0x7Fu) * (uint32_t)(C8_NMEMO * C8_CLS_BYTES);
             }
-            all_cls = __builtin_amdgcn_ballot_w64((seg_flags & 0x300u) != 0u) == 0;
-            all_major = __builtin_amdgcn_ballot_w64((seg_flags & 0x30000u) != 0u) == 0;
-            const uint32_t n_out = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((seg_flags & 3u) != 0u));
+            static_assert(C8_SPASS <= 255, "the counts' fields");
+            all_cls = __builtin_amdgcn_ballot_w64((seg_flags & 0xFF00u) != 0u) == 0;
+            all_major = __builtin_amdgcn_ballot_w64((seg_flags & 0xFF0000u) != 0u) == 0;
+            const uint32_t n_out = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((seg_flags & 0xFFu) != 0u));
             tile_out = n_out != 0;
             if (n_out > 8) need_place = true; // (the next tile places the window anew)
         }
@@ -816,7 +818,7 @@ int c8_variant(const HcGraphDev &g, const HcPackedDev &pk) {
     const char *e = getenv("VGAN_HC_KERNEL");
     if (e && (strcmp(e, "wave") == 0 || strcmp(e, "tile") == 0)) return 0;
     if (g.n_cls == 0 || !g.node_hi || !g.cls_tab || !g.col_memo || pk.n_reads == 0) return 0;
-    if (pk.max_read_qual > pk.max_read_cols) return 0;
+    if (pk.max_read_qual > pk.max_read_cols || pk.qual_excess) return 0; // (a quality string that outruns its read's columns: not in the records)
     const uint32_t mean_segs = pk.n_segments / pk.n_reads, mean_cols = (uint32_t)(pk.n_cols / pk.n_reads);
     const uint32_t span = pk.max_read_node_span ? pk.max_read_node_span : mean_cols * 3u / 4u;
     // (at least two mean reads to a tile where a variant offers that: a lone read leaves half of a tile's lanes idle)

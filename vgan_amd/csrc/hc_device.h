@@ -85,6 +85,9 @@ struct HcPackedDev {
     uint32_t max_read_qual;
     uint32_t max_read_cols;
     uint32_t max_read_node_span; // 0: not known
+    uint32_t qual_excess;        // largest (quality length - columns) of a read, 0 when no quality string outruns its read's columns
+                                 // (the contract of a packed VIEW; a batch packed from SoA arrays may break it: such a batch
+                                 // keeps to the kernels that read qualp)
 };
 
 // what another translation unit needs of a context (hc_flatten_kernels.hip)

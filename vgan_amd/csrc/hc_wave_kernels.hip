@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
     uint16_t *own = own_s[wave];
     // the batch's maxima: kept per wave and sent once (an atomic per read on the same three words serialises the whole launch:
     // 3 M same-address atomics at ~14 ns were 34 of the pass's 35 ms)
-    uint32_t mx_s = 0u, mx_q = 0u, mx_c = 0u;
+    uint32_t mx_s = 0u, mx_q = 0u, mx_c = 0u, mx_x = 0u;
     for (uint32_t r = blockIdx.x * 4u + wave; r <= n_pack; r += gridDim.x * 4u) { // (a wave per read would be a million waves)
         if (r == n_pack) { // the end offsets
             if (lane == 0) rhdr[r] = uint4{b.read_seg_off[r], b.read_qual_off[r], b.read_col_off[r], 0u};
@@ -798,6 +798,7 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
         mx_s = max(mx_s, s1 - s0);
         mx_q = max(mx_q, q1 - q0);
         mx_c = max(mx_c, c1 - c0);
+        mx_x = max(mx_x, (q1 - q0) > (c1 - c0) ? (q1 - q0) - (c1 - c0) : 0u);
         const uint32_t cols = min(c1 - c0, (uint32_t)PK_COLS), QL = q1 - q0; // (a read beyond the tile contract: a caller's error)
         for (uint32_t c = lane; c < cols; c += 64u) own[c] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -826,6 +827,7 @@ __global__ __launch_bounds__(256) void hc_pack_kernel(HcBatchDev b, uint32_t n_p
         if (mx_s) atomicMax(&maxima[0], mx_s);
         if (mx_q) atomicMax(&maxima[1], mx_q);
         if (mx_c) atomicMax(&maxima[2], mx_c);
+        if (mx_x) atomicMax(&maxima[3], mx_x);
     }
 }
 
@@ -881,7 +883,7 @@ bool hc_wave_kernel_fits(uint32_t max_read_segs, uint32_t max_read_qual, uint32_
 void launch_hc_pack(const HcBatchDev &b, uint32_t n_tileable, uint64_t n_cols, uint64_t n_qual, uint4 *rhdr, uint32_t *srec,
                     uint32_t *crec, uint8_t *qualp, uint32_t *maxima, hipStream_t st) {
     const uint32_t n = std::min(n_tileable, b.n_reads);
-    if (maxima) (void)hipMemsetAsync(maxima, 0, 12, st);
+    if (maxima) (void)hipMemsetAsync(maxima, 0, 16, st);
     if (n_qual) (void)hipMemcpyAsync(qualp, b.qual, n_qual, hipMemcpyDeviceToDevice, st);
     (void)hipMemsetAsync(qualp + n_qual, 0, 32, st);
     hipLaunchKernelGGL(hc_pack_kernel, dim3(std::min<uint32_t>((n + 1 + 3) / 4, 8192u)), dim3(256), 0, st, b, n, rhdr, srec, crec, maxima);
