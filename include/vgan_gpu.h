@@ -407,6 +407,10 @@ int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_rccl);
 int vgan_hc_reduce_info(double *last_setup_ms, int *n_setups);
 /* wall time of the last vgan_hc_reduce (a communicator set-up made inside it included) and which way it went; either may be NULL */
 int vgan_hc_reduce_last(double *reduce_ms, int *was_rccl);
+/* (ABI 5) Which way the last vgan_hc_reduce went, in words: returns 1 when it was an RCCL reduce (buf = ""), 0 when the vectors were
+ * summed on the host, with the reason in buf (contexts sharing a device, VGAN_HC_REDUCE=host, librccl missing, ncclCommInitAll's
+ * error string).  The two ways add the contexts' vectors in different orders: the sums may differ in their last bits. */
+int vgan_hc_reduce_why(char *buf, int64_t cap);
 void vgan_hc_destroy(vgan_hc_ctx *c);
 
 /* Per-kernel device timing with HIP events on the context's stream (bench.py's roofline figure).

@@ -85,6 +85,12 @@ extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_v
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(VGAN_ENODEV, "vgan_euka_create: no HIP device is visible (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(VGAN_EINVAL, "vgan_euka_create: device %d out of range", device);
+    // the read kernel packs a clade's bins as {first bin: 24 bits, count: 8 bits} (euka_kernels.hip: EkBlk)
+    if (db->bin_off[db->n_clades] >= (1u << 24))
+        return fail(VGAN_ERANGE, "vgan_euka_create: %u coverage bins in all (the kernel addresses 2^24)", db->bin_off[db->n_clades]);
+    for (uint32_t cl = 0; cl < db->n_clades; ++cl)
+        if (db->bin_off[cl + 1] - db->bin_off[cl] > 255u)
+            return fail(VGAN_ERANGE, "vgan_euka_create: clade %u has %u coverage bins (the kernel keeps at most 255 per clade)", cl, db->bin_off[cl + 1] - db->bin_off[cl]);
     HIPCHK(hipSetDevice(device));
     auto c = new vgan_euka_ctx();
     c->device = device;
@@ -273,6 +279,10 @@ extern "C" int vgan_euka_accumulate(vgan_euka_ctx *c, const vgan_euka_batch *b, 
         o.not_like = out->not_like;
         o.pass = out->pass;
     } else {
+        // (the read kernel keeps a read's mapping count and quality length in 16 bits each: EkBlk)
+        for (size_t r = 0; r < R; ++r)
+            if (b->read_map_off[r + 1] - b->read_map_off[r] > 0xFFFFu || b->read_qual_off[r + 1] - b->read_qual_off[r] > 0xFFFFu)
+                return fail(VGAN_ERANGE, "vgan_euka_accumulate: read %zu has more than 65535 mappings or quality bytes", r);
         auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
         if ((rc = c->s32.reserve(3 * up(R + 1) + up(b->n_maps))) || (rc = c->s16.reserve(3 * up(R))) ||
             (rc = c->s8.reserve(up(R) + 2 * up(b->n_cols) + up(b->n_qual))) || (rc = c->smq.reserve(up(R))) ||

@@ -395,6 +395,11 @@ int stage_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *v, HcPackedDev &d, b
         d.qualp = v->qualp;
         return VGAN_OK;
     }
+    { // host arrays: the end offsets must be the stated totals (the kernels bound their loads by them; the full check is vgan_hc_packed_validate)
+        const uint32_t *e = v->rhdr + 4 * (size_t)v->n_reads;
+        if (v->rhdr[0] != 0 || v->rhdr[2] != 0 || e[0] != v->n_segments || e[2] != v->n_cols || e[1] != v->n_qual)
+            return fail(VGAN_EINVAL, "packed batch: the headers' first / last offsets do not match n_segments / n_qual / n_cols");
+    }
     int rc;
     vgan_hc_packed &P = c->scratch_pack;
     P.device = c->device;
@@ -428,6 +433,8 @@ int run_packed(vgan_hc_ctx *c, const HcPackedDev &d, double *segD, double *nodeW
     int rc;
     if (d.n_reads == 0) return VGAN_OK;
     if (nodeW || totals) c->touched = true;
+    if (!wave_kernel_enabled())
+        return fail(VGAN_EINVAL, "VGAN_HC_KERNEL=tile asks for the LDS-tiled kernel, which reads SoA batches: a packed batch has no such form");
     if ((rc = ensure_work_queue(c))) return rc;
     ScopedTimer t(c, VGAN_HC_K_SEGMENT);
     // node-weights accumulation alone: eight columns to a lane and the table of column terms, where the batch and the graph fit
@@ -1015,19 +1022,27 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why_not; // (not ok: what was missing)
     Rccl() {
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (h) break;
         }
-        if (!h) return;
+        if (!h) {
+            const char *e = dlerror();
+            why_not = std::string("librccl could not be loaded") + (e ? std::string(": ") + e : std::string());
+            return;
+        }
         CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
         GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
         Reduce = (decltype(Reduce))dlsym(h, "ncclReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
         ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Reduce;
+        if (!ok) why_not = "librccl lacks one of ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclReduce";
     }
 };
 Rccl &rccl() {
@@ -1040,6 +1055,7 @@ struct CommCache {
     std::map<std::vector<int>, std::vector<ncclComm_t>> m;
     double last_setup_ms = 0.0, last_reduce_ms = 0.0; // (the reduce's wall time includes a set-up made inside it)
     int n_setups = 0, last_was_rccl = 0;
+    std::string last_why; // why the last reduce was summed on the host ("" when it went through RCCL)
 };
 CommCache &comm_cache() {
     static CommCache c;
@@ -1081,6 +1097,10 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
     // device always take it, and so does a set for which RCCL cannot be loaded or initialised.
     const auto t_red0 = std::chrono::steady_clock::now();
     const char *how = getenv("VGAN_HC_REDUCE");
+    std::string why; // the host sum is never taken silently: vgan_hc_reduce_why() says what sent the reduce there
+    if (!distinct) why = partial ? "a chunk reached only some of the contexts (a communicator is per device set)" : "contexts share a device";
+    else if (how && strcmp(how, "host") == 0) why = "VGAN_HC_REDUCE=host";
+    else if (!rccl().ok) why = rccl().why_not;
     if (distinct && rccl().ok && !(how && strcmp(how, "host") == 0)) {
         std::vector<int> devs((size_t)n);
         for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
@@ -1093,10 +1113,13 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
             } else {
                 std::vector<ncclComm_t> fresh((size_t)n, nullptr);
                 const auto t0 = std::chrono::steady_clock::now();
-                if (rccl().CommInitAll(fresh.data(), n, devs.data()) == ncclSuccess) {
+                const ncclResult_t ir = rccl().CommInitAll(fresh.data(), n, devs.data());
+                if (ir == ncclSuccess) {
                     comm_cache().last_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                     comm_cache().n_setups += 1;
                     comms = &(comm_cache().m[devs] = std::move(fresh));
+                } else {
+                    why = std::string("ncclCommInitAll failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(ir) : "unknown error");
                 }
             }
         }
@@ -1118,6 +1141,7 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
             std::lock_guard<std::mutex> lk(comm_cache().mu);
             comm_cache().last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_red0).count();
             comm_cache().last_was_rccl = 1;
+            comm_cache().last_why.clear();
             return VGAN_OK;
         }
     }
@@ -1133,8 +1157,15 @@ extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_
         std::lock_guard<std::mutex> lk(comm_cache().mu);
         comm_cache().last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_red0).count();
         comm_cache().last_was_rccl = 0;
+        comm_cache().last_why = why;
     }
     return VGAN_OK;
+}
+
+extern "C" int vgan_hc_reduce_why(char *buf, int64_t cap) {
+    std::lock_guard<std::mutex> lk(comm_cache().mu);
+    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", comm_cache().last_why.c_str());
+    return comm_cache().last_was_rccl;
 }
 
 extern "C" int vgan_hc_reduce_last(double *reduce_ms, int *was_rccl) {

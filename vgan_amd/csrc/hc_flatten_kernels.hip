@@ -408,6 +408,7 @@ template <class T> struct DBuf {
 
 struct vgan_hc_devflat {
     int device = 0;
+    const vgan_hc_ctx *ctx = nullptr; // (its stream is asked for at every run: vgan_hc_set_stream may have changed it)
     hipStream_t stream = nullptr;
     uint32_t rows = 0;
     DfGraph g{};
@@ -459,6 +460,7 @@ extern "C" int vgan_hc_devflat_create(vgan_hc_ctx *c, const vgan_graph *graph, v
     HIPCHK(hipSetDevice(ci.device));
     auto f = new vgan_hc_devflat();
     f->device = ci.device;
+    f->ctx = c;
     f->stream = ci.stream;
     f->rows = ci.rows;
     int rc;
@@ -503,6 +505,15 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
     if (n_reads == 0) return VGAN_OK;
     if (n_reads > 0x7FFFFFF0ll || chunk->base + n_reads > 0xFFFFFFF0ll) return fail(VGAN_ERANGE, "vgan_hc_devflat_run: too many reads in one chunk");
     HIPCHK(hipSetDevice(f->device));
+    // the context's stream as it is NOW: the segment kernel reads this object's output on it, and this run overwrites (or
+    // re-allocates) that output -- the two must sit on one stream.  A change of streams: what the old one still holds is waited for.
+    {
+        const hipStream_t now = hc_ctx_info(f->ctx).stream;
+        if (now != f->stream) {
+            if (f->stream) HIPCHK(hipStreamSynchronize(f->stream));
+            f->stream = now;
+        }
+    }
     hipStream_t st = f->stream;
     int rc;
     // ---- the slices' arrays, narrowed (DfSlice), one after the other in one staging block (8-byte aligned pieces)

@@ -556,7 +556,10 @@ int haplocart(int argc, char **argv) {
         int used_rccl = 0;
         check(vgan_hc_reduce(ctxs.v.data(), (int)ctxs.v.size(), final_vec.data(), &used_rccl), "reduce");
         if (!quiet) {
-            std::cerr << "Reduced the log-likelihoods of " << ctxs.v.size() << " device contexts (" << (used_rccl ? "RCCL" : "host") << ")." << '\n';
+            char why[256] = "";
+            (void)vgan_hc_reduce_why(why, sizeof why);
+            std::cerr << "Reduced the log-likelihoods of " << ctxs.v.size() << " device contexts (" << (used_rccl ? "RCCL" : "host") << (why[0] ? ": " : "")
+                      << why << ")." << '\n';
             double setup_ms = 0, reduce_ms = 0;
             int n_setups = 0;
             (void)vgan_hc_reduce_last(&reduce_ms, nullptr);

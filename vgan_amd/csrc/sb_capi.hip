@@ -1,6 +1,8 @@
 // C-ABI of the soibean device path (include/vgan_gpu.h).  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <thread>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -541,7 +543,15 @@ static int refresh_collect(vgan_sb_ctx *c, uint32_t n_states, const SbPending &p
                 if (q == hipSuccess) break; // (everything queued has run: the words are there)
                 if (q != hipErrorNotReady) return fail(VGAN_ENODEV, "vgan_sb_engine refresh: the stream failed");
             }
+            if (spins >= 0x20000u) { // (~50 us of spinning did not see the words: a long refresh -- sleep on the stream instead of a core)
+                if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(VGAN_ENODEV, "vgan_sb_engine refresh: the stream failed");
+                break;
+            }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
