@@ -67,7 +67,7 @@ def test_two_ranks_on_one_gpu_reduce_product_vectors(tmp_path):
 
 def _bench(*extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extra",
-           "--no-pmc", "--no-frontend"] + list(extra)
+           "--no-pmc", "--no-frontend", "--no-ingest"] + list(extra)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -96,7 +96,10 @@ def test_bench_starts_its_own_ranks_weak_and_strong():
     # (bound / achieved / peak / frac are one coherent HBM record; what limits the kernel is named beside it)
     assert one["posterior_ms"] > 0 and one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
     # (the batch arrives in the kernel's layout from the host flatten: no layout pass on the device, inside the step or beside it)
-    assert one["layout_pass_ms"] == 0 and one["kernel_ms_per_step"]["pack"] == 0 and "limiter" in one["roofline"]
+    assert one["kernel_ms_per_step"]["pack"] == 0 and "limiter" in one["roofline"]
+    # (both byte bases of the roofline fraction are printed; the stricter one is `frac`)
+    bb = one["roofline"]["byte_bases"]
+    assert bb["frac_on_input_bytes"] == pytest.approx(one["roofline"]["frac"]) and bb["frac_on_survey_8d"] > bb["frac_on_input_bytes"]
 
 
 def test_soibean_bench_over_two_ranks_gives_the_one_rank_chain():
