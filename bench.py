@@ -23,6 +23,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PREFLIGHT = None  # N > 1: what vgan_amd.distributed.preflight() found (part of the line's `dist` record)
 
 
 def parse():
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--reads-total", type=int, default=10_000_000, help="strong scaling: reads of the whole job")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--no-frontend", action="store_true", help="skip the GAM decode / flatten rates")
+    ap.add_argument("--preflight", action="store_true", help="N > 1: initialise the process group, run the collectives' self-test, print its record and leave")
+    ap.add_argument("--preflight-timeout", type=float, default=60.0, help="seconds a rank may spend inside the self-test's collectives")
     ap.add_argument("--no-ingest", action="store_true", help="skip the host-to-device / streamed single-pass figures")
     ap.add_argument("--path", choices=["haplocart", "euka", "soibean"], default="haplocart",
                     help="haplocart = the BASELINE metric; euka / soibean = configs 4 / 5 as extra lines")
@@ -69,6 +72,21 @@ def pick_device(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     vd.init(backend=backend, device=dev)
+    # N > 1: the group is exercised before anything is built on it (one int64 and one float64 all-reduce and a reduce to rank 0 on
+    # the tensors the job uses, under a watchdog: a rank stuck in a collective leaves with exit code 3 and a reason within
+    # --preflight-timeout seconds).  --preflight: that, the record on rank 0's stdout, and out.
+    global PREFLIGHT
+    PREFLIGHT = vd.preflight(dev, timeout_s=args.preflight_timeout) if world > 1 else None
+    if args.preflight:
+        if rank == 0:
+            import torch.distributed as dist
+            print(json.dumps({"preflight": PREFLIGHT or {"world_size": 1, "ok": True}, "backend": backend if world > 1 else None, "n_gpus": world,
+                              "visible_devices": n_dev}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(0)
     return rank, world, local_rank, dev, backend, n_dev
 
 
@@ -337,17 +355,12 @@ def bench_soibean(args):
         # reject -- is the same bits whatever the number of ranks
         sums, _ = ctx.loglike_sums(st, 0.01, freqs)
         hi, lo, nf = sums[0]
-        ti = torch.tensor([hi, lo - (1 << 64) if lo >= (1 << 63) else lo], dtype=torch.int64)
-        tf = torch.tensor([nf], dtype=torch.float64)
-        if dist.get_backend() == "gloo":
-            dist.all_reduce(ti, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tf, op=dist.ReduceOp.SUM)
-        else:  # RCCL over xGMI
-            ti, tf = ti.to(dev), tf.to(dev)
-            dist.all_reduce(ti, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tf, op=dist.ReduceOp.SUM)
-            ti, tf = ti.cpu(), tf.cpu()
-        ll = sb.sum_value([(int(ti[0]), int(ti[1]) & ((1 << 64) - 1), float(tf[0]))])
+        # ONE collective per iteration: the three words of every rank's sum (the double as its bit pattern) gathered on every rank
+        # (RCCL over xGMI on device tensors, gloo on host ones), then added in rank order -- sb.sum_value adds the fixed-point
+        # parts exactly, so the total does not depend on the number of ranks
+        import struct
+        parts = vd.all_gather_words([hi, lo, struct.unpack("<q", struct.pack("<d", nf))[0]], dev)
+        ll = sb.sum_value([(h - (1 << 64) if h >= (1 << 63) else h, l, struct.unpack("<d", struct.pack("<Q", f))[0]) for h, l, f in parts])
         if cur is None or logu < ll - cur:
             cur = ll
             accepted += 1
@@ -760,7 +773,7 @@ def main():
                 rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
             except Exception as e:  # noqa: BLE001 -- a version string must not end a benchmark
                 rccl_version = "unknown (%r)" % (e,)
-        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl_version,
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl_version, "preflight": PREFLIGHT,
                      "distinct_devices": len({(d["device_index"], d["pci_bus_id"], d["uuid"]) for d in everyone}), "ranks": everyone}
         if args.scaling == "strong":
             def weak_step():

@@ -102,6 +102,15 @@ def test_bench_starts_its_own_ranks_weak_and_strong():
     assert bb["frac_on_input_bytes"] == pytest.approx(one["roofline"]["frac"]) and bb["frac_on_survey_8d"] > bb["frac_on_input_bytes"]
 
 
+def test_bench_preflight_over_two_ranks():
+    """bench.py --gpus N --preflight: the process group comes up, the collectives' self-test runs on the tensors the job would use,
+    rank 0 prints its record, everyone leaves with 0 (and the same self-test opens every N > 1 run: the `dist` record carries it)."""
+    pre = _bench("--gpus", "2", "--dist-backend", "gloo", "--preflight")
+    assert pre["n_gpus"] == 2 and pre["preflight"]["ok"] and pre["preflight"]["world_size"] == 2 and pre["preflight"]["backend"] == "gloo"
+    two = _bench("--gpus", "2", "--dist-backend", "gloo", "--scaling", "weak", "--reads", "20000")
+    assert two["dist"]["preflight"]["ok"] and two["dist"]["preflight"]["int64_sum"] == [3, 3 << 40]
+
+
 def test_soibean_bench_over_two_ranks_gives_the_one_rank_chain():
     """bench.py --path soibean: two ranks holding reads [0, R) and [R, 2R) of the job's stream all-reduce the state's
     fixed-point sum every iteration; the chain -- every log-likelihood, every accept -- is the one rank's over [0, 2R)."""
