@@ -15,10 +15,12 @@ import util
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-FIXES = [os.path.join(HERE, "golden", "hc_pyref"), os.path.join(HERE, "golden", "hc_pyref_j2")]  # simulated reads; the reference's J2a1a1a1.gam
+# simulated reads; the reference's four bundled alignment files (test/input_files/*.gam) on graphs covering their node ids
+FIX_NAMES = ["hc_pyref", "hc_pyref_j2", "hc_pyref_two_unique", "hc_pyref_all_the_same", "hc_pyref_all_the_same_reverse"]
+FIXES = [os.path.join(HERE, "golden", n) for n in FIX_NAMES]
 
 
-@pytest.fixture(params=FIXES, ids=["simulated", "J2a1a1a1"])
+@pytest.fixture(params=FIXES, ids=["simulated", "J2a1a1a1", "two_unique", "all_the_same", "all_the_same_reverse"])
 def FIX(request):
     return request.param
 
@@ -78,6 +80,56 @@ def test_the_cpp_oracle_agrees_with_the_python_restatement(FIX):
         for rec in want["first_reads"]:
             rc, vec, _ = orc.hc_read(og, oa, kept.index(rec["read"]), **kw)
             assert rc == 0 and util.rel_err(vec.astype(np.float64), np.array([float(x) for x in rec["loglik"]])) < 1e-13
+
+
+# ---- the fixture at the reference's shape: 5 179 paths (81 mask words), 11 820 nodes, 1 200 reads of ~150 bases
+FULL = os.path.join(HERE, "golden", "hc_pyref_full")
+
+
+def test_full_shape_fixture_is_what_the_script_computes_on_a_sample():
+    """tools/pyref_hc.py --make-full: per-mapping sums in mpmath, the sum over a read's mappings through the path_supports rows in
+    numpy long double, read_loglik's literal loop over the paths beside it on 50 reads (asserted when the fixture is made).  Here:
+    the sampled entries of the first reads' vectors are recomputed from the committed inputs."""
+    p = _pyref()
+    fix = json.load(open(os.path.join(FULL, "hc_pyref.json")))
+    assert fix["default"]["literal_reads_checked"] == 50 and len(fix["default"]["final_vec"]) == 5179
+    seqs = p.load_gfa(os.path.join(FULL, "graph.gfa"))
+    hcf = p.load_hcfiles(FULL, supports_as_numpy=True, supports_lists=False)
+    alns = gamio.read_gam(os.path.join(FULL, "reads.gam"))
+    sup = hcf["supports_np"]
+    for rec in fix["default"]["first_reads"][:3]:
+        segs = p.segment_sums(seqs, hcf, alns[rec["read"]], 0.0001, False, False)
+        for path, want in list(zip(rec["paths"], rec["loglik"]))[:16]:
+            ll = sum((m_ if sup[node, path] else u_) for node, m_, u_ in segs)
+            assert abs(ll - p.mp.mpf(want)) <= abs(p.mp.mpf(want)) * p.mp.mpf("1e-22"), (rec["read"], path)
+
+
+def test_the_cpp_oracle_agrees_with_the_python_restatement_at_the_reference_shape():
+    fix = json.load(open(os.path.join(FULL, "hc_pyref.json")))
+    og, names, parents, children = util.orc_graph_from_hcfiles(FULL)
+    assert len(names) == 5179
+    dicts = gamio.read_gam(os.path.join(FULL, "reads.gam"))
+    for key, kw in (("default", {}), ("background", dict(params=orc.hc_params(background_error_prob=0.02, use_background_error_prob=True)))):
+        want = fix[key]
+        undefined = {u["read"] for u in want["undefined_reads"]}
+        oa = orc.AlnSet([d for r, d in enumerate(dicts) if r not in undefined])
+        # (the hoisted entry: S_m / U_m once per mapping -- bit-identical sums to the literal loops, which take minutes at 5 179 paths;
+        # the literal loops run on the first reads below)
+        _, ref, n_bad = orc.hc_run(og, oa, n_threads=8, faithful=False, **kw)
+        assert n_bad == 0
+        fv = np.array([float(x) for x in want["final_vec"]])
+        assert util.rel_err(np.asarray(ref, np.float64), fv) < 1e-13, key
+        pred = names[int(np.argmax(np.asarray(ref, np.float64)))]
+        assert pred == want["predicted"]
+        post = orc.hc_posterior(np.asarray(ref, np.longdouble), names, parents, children, pred)
+        assert [c for c, _, _ in post] == [x["clade"] for x in want["posterior"]]
+        for (_, c1, _), x in zip(post, want["posterior"]):
+            assert abs(c1 - float(x["confidence"])) <= 1e-12 * max(abs(float(x["confidence"])), 1e-300)
+        kept = [r for r in range(len(dicts)) if r not in undefined]
+        for rec in want["first_reads"][:4]:  # the literal per-path loops of the oracle, read by read
+            rc, vec, _ = orc.hc_read(og, oa, kept.index(rec["read"]), **kw)
+            got = vec.astype(np.float64)[rec["paths"]]
+            assert rc == 0 and util.rel_err(got, np.array([float(x) for x in rec["loglik"]])) < 1e-13
 
 
 # ------------------------------------------------------------------------------------------------------------------- euka

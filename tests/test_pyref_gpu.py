@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(params=["hc_pyref", "hc_pyref_j2"], ids=["simulated", "J2a1a1a1"])
+@pytest.fixture(params=["hc_pyref", "hc_pyref_j2", "hc_pyref_two_unique", "hc_pyref_all_the_same", "hc_pyref_all_the_same_reverse"],
+                ids=["simulated", "J2a1a1a1", "two_unique", "all_the_same", "all_the_same_reverse"])
 def FIX(request):
     return os.path.join(GOLD, request.param)
 
@@ -51,6 +52,46 @@ def test_final_vector_per_read_vectors_and_posteriors_against_the_python_restate
         k = src.index(kept.index(rec["read"]))
         ref = np.array([float(x) for x in rec["loglik"]])
         assert np.max(np.abs(ll[k] - ref) / np.abs(ref)) < 1e-11, rec["read"]
+
+
+@pytest.mark.parametrize("key, kw", [("default", {}), ("background", dict(background_error_prob=0.02, use_background_error_prob=True))])
+def test_the_reference_shape_against_the_python_restatement(key, kw):
+    """tests/golden/hc_pyref_full (tools/pyref_hc.py --make-full): 5 179 paths / 81 mask words, 11 820 nodes, 1 200 reads of ~150
+    bases -- the shape BASELINE.json's configs are quoted on -- through every mode, the packed route included."""
+    FULL = os.path.join(GOLD, "hc_pyref_full")
+    want = json.load(open(os.path.join(FULL, "hc_pyref.json")))[key]
+    g = hc.Graph.load(os.path.join(FULL, "graph.gfa"), FULL)
+    assert g.n_paths == 5179
+    a = hc.AlnSet.read_gam(os.path.join(FULL, "reads.gam"))
+    drop = np.zeros(a.n_reads, np.uint8)
+    for u in want["undefined_reads"]:
+        drop[u["read"]] = 1
+    a = a.without(drop)
+    fv = np.array([float(x) for x in want["final_vec"]])
+    ctx = hc.HcContext(g, **kw)
+    for packed in (False, True):
+        b = hc.HostBatch(g, a, packed=packed)
+        assert b.n_reads == want["n_used"] and b.stats.n_bad == 0
+        for mode in (hc.MODE_NODE_WEIGHTS, hc.MODE_PER_READ, hc.MODE_PER_READ_DENSE):
+            ctx.reset()
+            ctx.set_mode(mode)
+            ctx.accumulate(b)
+            got = ctx.finalize()
+            assert np.max(np.abs(got - fv) / np.abs(fv)) < 1e-9, (key, mode, packed)
+    ctx.set_mode(hc.MODE_NODE_WEIGHTS)
+    assert g.path_names[ctx.argmax(got)] == want["predicted"]
+    post = ctx.posterior(got, want["predicted"])
+    assert [c for c, _, _ in post] == [x["clade"] for x in want["posterior"]]
+    for (_, c1, _), x in zip(post, want["posterior"]):
+        assert c1 == pytest.approx(float(x["confidence"]), rel=1e-9, abs=1e-300)
+    kept = [r for r in range(want["n_alignments"]) if not drop[r]]
+    b = hc.HostBatch(g, a)
+    src = list(b.read_src)
+    ll = ctx.read_loglik(b)
+    for rec in want["first_reads"]:
+        k = src.index(kept.index(rec["read"]))
+        ref = np.array([float(x) for x in rec["loglik"]])
+        assert np.max(np.abs(ll[k][rec["paths"]] - ref) / np.abs(ref)) < 1e-11, rec["read"]
 
 
 def test_euka_per_read_models_and_sums_against_the_python_restatement():

@@ -71,7 +71,7 @@ def load_gfa(path):
     return seqs
 
 
-def load_hcfiles(d):
+def load_hcfiles(d, supports_as_numpy=False, supports_lists=True):
     """load.cpp:6-58,283-345"""
     mappabilities = []
     for ln in _open(os.path.join(d, "mappability.tsv")):
@@ -86,9 +86,12 @@ def load_hcfiles(d):
         if len(t) >= 2 and t[0] not in pangenome_map:  # map::insert keeps the first
             pangenome_map[t[0]] = int(t[1]) + 1  # load.cpp:37
     path_names = [ln.split()[0] for ln in _open(os.path.join(d, "graph_paths")) if ln.split()]  # whole first token
-    supports = []
+    supports, rows_np = [], []
     for ln in _open(os.path.join(d, "path_supports")):
-        supports.append([c == "1" for c in ln.rstrip("\n")])  # row index = line number = node id (load.cpp:283-300)
+        supports.append([c == "1" for c in ln.rstrip("\n")] if supports_lists else None)  # row index = line number = node id (load.cpp:283-300)
+        if supports_as_numpy:
+            import numpy as np
+            rows_np.append(np.frombuffer(ln.rstrip("\n").encode(), np.uint8) == ord("1"))
 
     def relatives(name):
         rel = {}
@@ -99,8 +102,13 @@ def load_hcfiles(d):
             if t[0] not in rel:
                 rel[t[0]] = [x for x in t[1:] if "[" not in x]
         return rel
-    return {"mappabilities": mappabilities, "pangenome_map": pangenome_map, "path_names": path_names, "supports": supports,
-            "parents": relatives("parents.txt"), "children": relatives("children.txt")}
+    out = {"mappabilities": mappabilities, "pangenome_map": pangenome_map, "path_names": path_names, "supports": supports,
+           "n_support_rows": len(supports), "parents": relatives("parents.txt"), "children": relatives("children.txt")}
+    if supports_as_numpy:
+        import numpy as np
+        width = max(len(x) for x in rows_np)
+        out["supports_np"] = np.stack([np.pad(x, (0, width - len(x))) for x in rows_np])
+    return out
 
 
 # -------------------------------------------------------------------------------------- vg / libgab semantics (published)
@@ -450,6 +458,183 @@ def make(d):
     print("wrote", d2, "used", out2["default"]["n_used"], "undefined", len(out2["default"]["undefined_reads"]))
 
 
+def segment_sums(seqs, hc, aln, background_error_prob, use_background_error_prob, is_consensus_fasta):
+    """read_loglik's two numbers per mapping -- (node id, log_lik_if_mapped, log_lik_if_unsupported) -- without the loop over the
+    paths: the SAME statements as read_loglik above, in the same order (kept side by side on purpose; run_full() holds the two
+    against each other on a subset of the reads, path by path)."""
+    path = aln["path"]
+    graph_full, algnseq, mppg_sizes = reconstruct_graph_sequence(seqs, path)
+    quality = aln["quality"]
+    mapq = aln["mapping_quality"]
+    if mapq >= 100 or mapq < 0:
+        raise Undefined("mapping quality %d indexes incorrect_mapping_vec out of range" % mapq)
+    out = []
+    position_in_read = 0
+    use_bep = use_background_error_prob
+    for i, mppg in enumerate(path["mapping"]):
+        if i >= len(mppg_sizes):
+            raise Undefined("mapping %d has no entry in mppg_sizes (%d edits)" % (i, len(mppg_sizes)))
+        graph_seq = substr(graph_full, position_in_read, mppg_sizes[i])
+        read_seq = substr(algnseq, position_in_read, mppg_sizes[i])
+        quality_scores = []
+        for j in range(position_in_read, position_in_read + len(algnseq)):
+            q = signed_char(quality[j]) if j < len(quality) else 0
+            if q >= 90:
+                use_bep = True
+            quality_scores.append(q)
+        position_in_read += len(read_seq)
+        mapping_seq = algnseq
+        node_id = mppg["position"]["node_id"]
+        key = str(node_id)
+        if key not in hc["pangenome_map"]:
+            raise Undefined("node %d is not in parsed_pangenome_mapping (map::at throws)" % node_id)
+        pangenome_base = hc["pangenome_map"][key]
+        if not (0 <= pangenome_base < len(hc["mappabilities"])):
+            raise Undefined("mappabilities[%d] is out of range" % pangenome_base)
+        mappability = float(hc["mappabilities"][pangenome_base])
+        p_correctly_mapped = mp.mpf((1 - INCORRECT_MAPPING_VEC[mapq]) * mappability)
+        p_no_seq_error = []
+        for k in range(len(graph_seq)):
+            if k >= len(mapping_seq):
+                raise Undefined("mapping_seq[%d] beyond its end" % k)
+            same = graph_seq[k] == mapping_seq[k]
+            if use_bep:
+                p_no_seq_error.append(float(background_error_prob) if same else 1 - float(background_error_prob))
+            else:
+                q = quality_scores[k] if k < len(quality_scores) else None
+                if q is None or not (0 <= q < 100):
+                    raise Undefined("qscore_vec[%r] is out of range" % (q,))
+                p_no_seq_error.append(QSCORE_VEC[q] if same else 1 - QSCORE_VEC[q])
+        log_lik_if_mapped = mp.mpf(0)
+        for j in range(len(graph_seq)):
+            g, r = graph_seq[j], mapping_seq[j]
+            if g == "N" or r == "N":
+                continue
+            if not is_valid_dna(g) or not is_valid_dna(r):
+                continue
+            p_obs_base = get_p_obs_base(pangenome_base, p_no_seq_error[j], 8)
+            if not is_consensus_fasta:
+                x = (1 - p_correctly_mapped) * get_background_freq(r) + p_correctly_mapped * p_obs_base
+            else:
+                x = mp.mpf(1 - float(background_error_prob)) * p_obs_base
+            log_lik_if_mapped += mp.log(x) if x > 0 else mp.mpf("-inf")
+        log_lik_if_unsupported = 0.0
+        for Q in quality_scores:
+            log_lik_if_unsupported += math.log(get_p_seq_error(Q))
+        if not (0 <= node_id < hc["n_support_rows"]):
+            raise Undefined("node %d has no path_supports row" % node_id)
+        out.append((node_id, log_lik_if_mapped, mp.mpf(log_lik_if_unsupported)))
+    return out
+
+
+def run_full(d, background_error_prob=0.0001, use_background_error_prob=False, is_consensus_fasta=False, literal_reads=50, sample_paths=64):
+    """run() at the reference's real shape (thousands of paths): the per-mapping sums in mpmath as everywhere in this file, the sum
+    over a read's mappings THROUGH the path_supports rows in numpy long double (x87: 64-bit mantissa) over all paths at once -- the
+    literal statement `ll[p] += supported ? mapped : unsupported` for every p -- and, for the first `literal_reads` usable reads,
+    read_loglik's own loop over the paths in mpmath beside it, which must give the same vector."""
+    import numpy as np
+    seqs = load_gfa(os.path.join(d, "graph.gfa"))
+    hc = load_hcfiles(d, supports_as_numpy=True)
+    alns = gamio.read_gam(os.path.join(d, "reads.gam"))
+    sup = hc["supports_np"]
+    n_paths = len(hc["path_names"])
+    final = np.zeros(n_paths, np.longdouble)
+    undefined, used, per_read = [], 0, []
+    pick = sorted(random_sample(n_paths, sample_paths))
+    for r, a in enumerate(alns):
+        if a["identity"] < 1e-10:
+            continue
+        try:
+            segs = segment_sums(seqs, hc, a, background_error_prob, use_background_error_prob, is_consensus_fasta)
+        except Undefined as e:
+            undefined.append({"read": r, "why": str(e)})
+            continue
+        ll = np.zeros(n_paths, np.longdouble)
+        for node, m_, u_ in segs:
+            row = sup[node, :n_paths]
+            ll += np.where(row, np.longdouble(mp.nstr(m_, 30)), np.longdouble(mp.nstr(u_, 30)))
+        if used < literal_reads:  # the loop over the paths as the reference has it, in mpmath, on the plain lists
+            lit = read_loglik(seqs, hc, a, background_error_prob, use_background_error_prob, is_consensus_fasta)
+            worst = max(abs(mp.mpf(str(ll[p_])) - lit[p_]) / abs(lit[p_]) for p_ in range(n_paths) if lit[p_] != 0)
+            assert worst < mp.mpf("1e-17"), (r, worst)
+            if len(per_read) < 8:
+                per_read.append({"read": r, "paths": pick, "loglik": [mp.nstr(lit[p_], 25) for p_ in pick]})
+        used += 1
+        final += ll
+    fv = [mp.mpf(np.format_float_positional(x, unique=True, trim="-")) for x in final]  # (long double -> mpmath, every digit)
+    best = max(range(n_paths), key=lambda p_: (fv[p_], -p_))
+    clades, conf = get_posterior(fv, hc, hc["path_names"][best])
+    return {"n_alignments": len(alns), "n_used": used, "undefined_reads": undefined,
+            "params": {"background_error_prob": background_error_prob, "use_background_error_prob": use_background_error_prob,
+                       "is_consensus_fasta": is_consensus_fasta},
+            "final_vec": [mp.nstr(x, 22) for x in fv], "predicted": hc["path_names"][best],
+            "posterior": [{"clade": c, "confidence": mp.nstr(v, 22)} for c, v in zip(clades, conf)],
+            "first_reads": per_read, "literal_reads_checked": min(used, literal_reads)}
+
+
+def make_bundled(base):
+    """The reference's other bundled alignments (test/input_files/{two_unique, all_the_same, all_the_same_reverse}.gam, copied under
+    tests/golden/alignments/ as data) on graphs built to cover their node ids, like <base>_j2 for J2a1a1a1.gam."""
+    import pyref_inputs as pi
+    for k, name in enumerate(("two_unique", "all_the_same", "all_the_same_reverse")):
+        d = "%s_%s" % (base.rstrip("/"), name)
+        os.makedirs(d, exist_ok=True)
+        src = os.path.join(ROOT, "tests", "golden", "alignments", name + ".gam")
+        real = gamio.read_gam(src)
+        g = pi.covering_graph(83 + k, real, n_paths=24)
+        L = g["genome_len"]
+        pi.write_hcfiles(d, g, mappability=[(0, L // 4, 1.0), (L // 4, L // 3, 0.75), (L // 3, L + 2, 1.0)], gfa_paths=False)
+        raw = open(os.path.join(d, "path_supports"), "rb").read()
+        with gzip.GzipFile(os.path.join(d, "path_supports.gz"), "wb", mtime=0) as f:
+            f.write(raw)
+        os.remove(os.path.join(d, "path_supports"))
+        open(os.path.join(d, "reads.gam"), "wb").write(open(src, "rb").read())
+        out = {"_what": "tools/pyref_hc.py --make-bundled on the reference's test/input_files/%s.gam (copied beside this file) and a graph "
+                        "covering its node ids (tools/pyref_inputs.py covering_graph)" % name,
+               "default": run(d), "background": run(d, background_error_prob=0.02, use_background_error_prob=True)}
+        json.dump(out, open(os.path.join(d, "hc_pyref.json"), "w"), indent=0)
+        print("wrote", d, "alignments", out["default"]["n_alignments"], "used", out["default"]["n_used"], "undefined", len(out["default"]["undefined_reads"]))
+
+
+def random_sample(n, k):
+    import random
+    return random.Random(4242).sample(range(n), min(k, n))
+
+
+def make_full(d):
+    """The fixture at the reference's shape: 11 820 nodes, 5 179 paths (81 mask words), 16 569 reference bases; 1 200 reads of
+    ~150 bases (tools/pyref_inputs.py: plain seeded Python).  The path sidecars are gzipped (the loaders read them so)."""
+    import pyref_inputs as pi
+    os.makedirs(d, exist_ok=True)
+    g = pi.variation_graph(seed=179, genome_len=16569, n_paths=5179, site_rate=0.425)
+    L = g["genome_len"]
+    pi.write_hcfiles(d, g, mappability=[(0, 3000, 1.0), (3000, 3050, 0.5), (3050, 9000, 1.0), (9000, 9100, 0.8125), (9100, 14000, 1.0),
+                                        (14000, 14040, 0.25), (14040, L + 2, 1.0)], gfa_paths=False)
+    for name in ("path_supports", "parents.txt", "children.txt"):
+        raw = open(os.path.join(d, name), "rb").read()
+        with gzip.GzipFile(os.path.join(d, name + ".gz"), "wb", mtime=0) as f:
+            f.write(raw)
+        os.remove(os.path.join(d, name))
+    alns = pi.simulate_reads(180, g, 1200, read_len=150, indel_rate=0.04, softclip_rate=0.04, low_mapq_rate=0.1)
+    for r, al in enumerate(alns):
+        q = bytearray(al["quality"])
+        if r % 97 == 5 and len(q) > 60:
+            q[57] = 93
+        if r % 131 == 7 and len(q) > 10:
+            q[3] = 200
+        if r % 151 == 11:
+            q = q[:max(0, len(q) - 9)]
+        al["quality"] = bytes(q)
+        if r % 89 == 3:
+            al["mapping_quality"] = 0
+    open(os.path.join(d, "reads.gam"), "wb").write(gamio.write_gam(alns, group=256))
+    out = {"_what": "tools/pyref_hc.py --make-full: the independent Python + mpmath restatement at the reference's shape (5 179 paths, "
+                    "11 820 nodes, ~150-base reads); inputs by tools/pyref_inputs.py; NOT generated by oracle/ or by the product",
+           "default": run_full(d), "background": run_full(d, background_error_prob=0.02, use_background_error_prob=True, literal_reads=10)}
+    json.dump(out, open(os.path.join(d, "hc_pyref.json"), "w"), indent=0)
+    print("wrote", d, "used", out["default"]["n_used"], "undefined", len(out["default"]["undefined_reads"]))
+
+
 def check_kats():
     d = os.path.join(ROOT, "tests", "golden", "reconstruct")
     seqs = load_gfa(os.path.join(d, "target_graph.gfa"))
@@ -466,6 +651,8 @@ def check_kats():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--make")
+    ap.add_argument("--make-full", help="the fixture at the reference's shape (5 179 paths): tests/golden/hc_pyref_full")
+    ap.add_argument("--make-bundled", help="fixtures of the reference's other three bundled GAMs: <arg>_two_unique, _all_the_same, _all_the_same_reverse")
     ap.add_argument("--run")
     ap.add_argument("--out")
     ap.add_argument("--check-kats", action="store_true")
@@ -474,6 +661,10 @@ if __name__ == "__main__":
         check_kats()
     if args.make:
         make(args.make)
+    if args.make_full:
+        make_full(args.make_full)
+    if args.make_bundled:
+        make_bundled(args.make_bundled)
     if args.run:
         res = run(args.run)
         txt = json.dumps(res, indent=0)

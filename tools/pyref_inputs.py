@@ -76,7 +76,9 @@ def variation_graph(seed, genome_len=700, n_paths=64, site_rate=0.16, indel_shar
     return {"seqs": seqs, "paths": paths, "names": [name_fmt % q for q in range(n_paths)], "pos": pos, "parent": parent, "genome_len": genome_len}
 
 
-def write_gfa(path, g):
+def write_gfa(path, g, with_paths=True):
+    """with_paths False: no P lines (thousands of paths of thousands of steps: the hcfiles sidecars graph_paths / path_supports say
+    which node lies on which path, as they do for the reference, load.cpp:43-58,283-300)."""
     with open(path, "w") as f:
         f.write("H\tVN:Z:1.0\n")
         for nid in sorted(g["seqs"]):
@@ -86,15 +88,16 @@ def write_gfa(path, g):
             links.update(zip(walk[:-1], walk[1:]))
         for a, b in sorted(links):
             f.write("L\t%d\t+\t%d\t+\t0M\n" % (a, b))
-        for name, walk in zip(g["names"], g["paths"]):
-            f.write("P\t%s\t%s\t*\n" % (name, ",".join("%d+" % v for v in walk)))
+        if with_paths:
+            for name, walk in zip(g["names"], g["paths"]):
+                f.write("P\t%s\t%s\t*\n" % (name, ",".join("%d+" % v for v in walk)))
 
 
-def write_hcfiles(d, g, mappability=None):
+def write_hcfiles(d, g, mappability=None, gfa_paths=True):
     """The files HaploCart's loaders read (load.cpp), beside graph.gfa."""
     import os
     os.makedirs(d, exist_ok=True)
-    write_gfa(os.path.join(d, "graph.gfa"), g)
+    write_gfa(os.path.join(d, "graph.gfa"), g, with_paths=gfa_paths)
     P = len(g["paths"])
     with open(os.path.join(d, "graph_paths"), "w") as f:
         for n in g["names"]:
