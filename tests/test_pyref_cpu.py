@@ -136,13 +136,17 @@ def test_the_cpp_oracle_agrees_with_the_python_restatement_at_the_reference_shap
 EFIX = os.path.join(HERE, "golden", "euka_pyref")
 
 
-def _euka_inputs():
+EFIX_FULL = os.path.join(HERE, "golden", "euka_pyref_full")  # the SHIPPED 335-clade tables (tools/pyref_euka.py --make-full)
+
+
+def _euka_inputs(d=None):
     from vgan_amd import euka as ek
     from vgan_amd import haplocart as hc
-    g = hc.Graph.load(os.path.join(EFIX, "graph.gfa"))
-    db = ek.EukaDb.load(os.path.join(EFIX, "euka_db.clade"), os.path.join(EFIX, "euka_db.bins"))
-    a = hc.AlnSet.read_gam(os.path.join(EFIX, "reads.gam"), keep_unmapped=True)
-    texts = (open(os.path.join(EFIX, "damage5p.prof")).read(), open(os.path.join(EFIX, "damage3p.prof")).read())
+    d = d or EFIX
+    g = hc.Graph.load(os.path.join(d, "graph.gfa"))
+    db = ek.EukaDb.load(os.path.join(d, "euka_db.clade"), os.path.join(d, "euka_db.bins"))
+    a = hc.AlnSet.read_gam(os.path.join(d, "reads.gam"), keep_unmapped=True)
+    texts = (open(os.path.join(d, "damage5p.prof")).read(), open(os.path.join(d, "damage3p.prof")).read())
     return g, db, a, texts
 
 
@@ -190,6 +194,20 @@ def test_the_cpp_euka_oracle_agrees_with_the_python_restatement():
         idx = [x["read"] for x in fix[key]["reads"]]
         got = {k: ref[k][idx] for k in ("clade", "in_lik", "out_lik", "like", "not_like", "pass")}
         check_euka_against_fixture(got, ref, fix[key], idx, 1e-13)
+
+
+def test_the_cpp_euka_oracle_agrees_with_the_python_restatement_on_the_shipped_tables():
+    """335 clades, the shipped euka_db.clade / euka_db.bins (node ids up to 6.9 million, written as "1836.0": std::stoi reads the
+    integer prefix, load.cpp:70-95)."""
+    fix = json.load(open(os.path.join(EFIX_FULL, "euka_pyref.json")))["default"]
+    g, db, a, texts = _euka_inputs(EFIX_FULL)
+    assert len(fix["clade_count"]) == 335
+    ref = orc.euka_run(util.orc_graph_nodes_only(g), util.orc_alnset_from_product(a), util.orc_euka_db_from_product(db), orc.OrcDamage(*texts), 29, 5)
+    assert ref["n_bad"] == 0
+    idx = [x["read"] for x in fix["reads"]]
+    got = {k: ref[k][idx] for k in ("clade", "in_lik", "out_lik", "like", "not_like", "pass")}
+    # (`like` is exp(a difference of two log-likelihoods of ~ -50): the doubles' 1e-16 on those is 1e-13 on it)
+    check_euka_against_fixture(got, ref, fix, idx, 1e-12)
 
 
 # ---------------------------------------------------------------------------------------------------------------- soibean

@@ -111,6 +111,21 @@ def test_euka_per_read_models_and_sums_against_the_python_restatement():
         check_euka_against_fixture(got, fin, fix[key], list(hb.arrays()["read_src"]), 1e-9)
 
 
+def test_euka_on_the_shipped_335_clade_tables_against_the_python_restatement():
+    """tests/golden/euka_pyref_full: the shipped euka_db.clade / euka_db.bins, 631 reads over 335 clades' node-id ranges."""
+    from test_pyref_cpu import _euka_inputs, check_euka_against_fixture, EFIX_FULL
+    from vgan_amd import euka as ek
+    fix = json.load(open(os.path.join(EFIX_FULL, "euka_pyref.json")))["default"]
+    g, db, a, texts = _euka_inputs(EFIX_FULL)
+    hb = ek.EukaHostBatch(g, a)
+    assert hb.stats.n_bad == 0
+    ctx = ek.EukaContext(db, ek.Damage.from_text(*texts), min_mapq=29, length_to_prof=5)
+    got = ctx.accumulate(hb)
+    fin = ctx.finalize()
+    assert fin["n_bad"] == 0 and len(fin["clade_count"]) == 335
+    check_euka_against_fixture(got, fin, fix, list(hb.arrays()["read_src"]), 1e-9)
+
+
 def test_soibean_tables_and_state_likelihoods_against_the_python_restatement():
     """tools/pyref_sb.py's fixture (tests/golden/sb_pyref/): pathMap and the (reference, read) pair counts per read and path,
     and the log-likelihood of k = 1 and k = 3 states computed by the restatement from the per-base records themselves."""

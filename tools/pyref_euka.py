@@ -74,8 +74,16 @@ def load_bins(path):  # load.cpp:70-95
         if not ln.strip():
             chunks.append([])
             continue
-        chunks.append([(int(t[j]), int(t[j + 1]), float(t[j + 2])) for j in range(1, len(t) - 2, 3)])
+        chunks.append([(stoi(t[j]), stoi(t[j + 1]), float(t[j + 2])) for j in range(1, len(t) - 2, 3)])
     return chunks
+
+
+def stoi(s):  # std::stoi: the longest integer prefix ("1836.0" -> 1836: the shipped euka_db.bins writes its node ids so)
+    import re
+    m = re.match(r"\s*[+-]?\d+", s)
+    if not m:
+        raise ValueError("stoi: no conversion: %r" % s)
+    return int(m.group(0))
 
 
 def read_rates(text):  # miscfunc.h:84-136: header, then 12 rates per line
@@ -367,14 +375,69 @@ def make(d):
           "passed", sum(x["pass"] for x in out["default"]["reads"]))
 
 
+def make_full(d):
+    """The fixture with the SHIPPED tables (share/vgan/euka_dir/euka_db.{clade,bins}, copied under tests/golden/euka_dir/ as data):
+    335 clades over node ids up to 6.9 million.  The euka graph itself is not shipped, so every clade gets a small variation graph of
+    its own (tools/pyref_inputs.py) placed at the first node id of one of ITS coverage bins, and two reads drawn from it."""
+    import random
+    import shutil
+    import pyref_inputs as pi
+    os.makedirs(d, exist_ok=True)
+    gold = os.path.join(ROOT, "tests", "golden")
+    for name in ("euka_db.clade", "euka_db.bins"):
+        shutil.copyfile(os.path.join(gold, "euka_dir", name), os.path.join(d, name))
+    t5, t3 = open(gold + "/damageProfiles/dhigh5p.prof").read(), open(gold + "/damageProfiles/dhigh3p.prof").read()
+    open(os.path.join(d, "damage5p.prof"), "w").write(t5)
+    open(os.path.join(d, "damage3p.prof"), "w").write(t3)
+    clades = load_clades(os.path.join(d, "euka_db.clade"))
+    chunks = load_bins(os.path.join(d, "euka_db.bins"))
+    assert len(clades) == 335 and len(chunks) == 335
+    rng = random.Random(191)
+    seqs, alns = {}, []
+    for c, bins in enumerate(chunks):
+        j = rng.randrange(len(bins))
+        first = bins[j][0]
+        g = pi.variation_graph(seed=1910 + c, genome_len=110, n_paths=3, first_id=max(first, 1))
+        seqs.update(g["seqs"])
+        alns += pi.simulate_reads(2920 + c, g, 2, read_len=64, sub_rate=0.03, indel_rate=0.12, softclip_rate=0.15, reverse_rate=0.5,
+                                  low_mapq_rate=0.2, name="c%d_" % c)
+    rng.shuffle(alns)
+    with open(os.path.join(d, "graph.gfa"), "w") as f:
+        f.write("H\tVN:Z:1.0\n")
+        for nid in sorted(seqs):
+            f.write("S\t%d\t%s\n" % (nid, seqs[nid]))
+    for r, al in enumerate(alns):
+        if r % 9 == 2:
+            al["mapping_quality"] = rng.randint(27, 32)
+        if r % 13 == 4:
+            al["mapping_quality"] = 0
+    tmp = os.path.join(d, "reads.gam")
+    open(tmp, "wb").write(gamio.write_gam(alns, group=100))
+    for _ in range(3):
+        und = {u["read"] for u in run(d)["undefined_reads"]}
+        if not und:
+            break
+        alns = [al for r, al in enumerate(alns) if r not in und]
+        open(tmp, "wb").write(gamio.write_gam(alns, group=100))
+    out = {"_what": "tools/pyref_euka.py --make-full: the independent Python + mpmath restatement of euka's per-read path with the SHIPPED "
+                    "clade and bin tables (335 clades); graph and reads by tools/pyref_inputs.py; NOT generated by oracle/ or by the product",
+           "default": run(d)}
+    json.dump(out, open(os.path.join(d, "euka_pyref.json"), "w"), indent=0)
+    print("wrote", d, "reads", len(out["default"]["reads"]), "undefined", len(out["default"]["undefined_reads"]),
+          "passed", sum(x["pass"] for x in out["default"]["reads"]), "clades hit", sum(1 for x in out["default"]["clade_count"] if x))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--make")
+    ap.add_argument("--make-full", help="the fixture with the shipped 335-clade tables: tests/golden/euka_pyref_full")
     ap.add_argument("--run")
     ap.add_argument("--out")
     args = ap.parse_args()
     if args.make:
         make(args.make)
+    elif args.make_full:
+        make_full(args.make_full)
     elif args.run:
         res = run(args.run)
         json.dump(res, open(args.out, "w") if args.out else sys.stdout, indent=0)
