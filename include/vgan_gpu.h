@@ -365,6 +365,10 @@ int vgan_hc_accumulate(vgan_hc_ctx *c, const vgan_hc_batch *batch);
 /* (ABI 4) The same for a packed batch: host arrays are copied to the device as they are (one copy of the batch in HBM, no
  * layout pass), device arrays are read in place.  All three modes. */
 int vgan_hc_accumulate_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
+/* (ABI 5) The GAM front end on the device (csrc/gam_kernels.hip; reference: src/readGAM.h:20-68).  Test / developer entry of its
+ * first stage: a BGZF file's bytes are inflated on the device (a lane per BGZF member) and copied back; out = NULL asks for the
+ * inflated size alone.  kernel_ms (or NULL): the inflate kernel's device time. */
+int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *out, uint64_t out_cap, uint64_t *out_size, double *kernel_ms);
 /* (ABI 4) a1 on the device: reconstruct_graph_sequence (vgan_utils.h:6-79), the slicing of update_likelihood.cpp:28-45 and the
  * packed layout in one pass over a chunk of the parser's arrays, for the reads whose edits are all matches or substitutions
  * on known nodes and which satisfy the tile contract -- what it writes is vgan_hc_flatten_parts_packed's packed batch of those

@@ -224,6 +224,7 @@ SYMBOLS = {
     "vgan_hc_reduce_info": (C.c_int, [vp, vp]),
     "vgan_hc_reduce_last": (C.c_int, [vp, vp]),
     "vgan_hc_reduce_why": (C.c_int, [C.c_char_p, C.c_int64]),
+    "vgan_gamdev_inflate_bytes": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
     "vgan_hc_pack": (C.c_int, [vp, C.POINTER(HcBatch), C.POINTER(vp)]),
     "vgan_hc_packed_free": (None, [vp]),
     "vgan_hc_accumulate": (C.c_int, [vp, C.POINTER(HcBatch)]),
