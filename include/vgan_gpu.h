@@ -369,6 +369,23 @@ int vgan_hc_accumulate_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
  * first stage: a BGZF file's bytes are inflated on the device (a lane per BGZF member) and copied back; out = NULL asks for the
  * inflated size alone.  kernel_ms (or NULL): the inflate kernel's device time. */
 int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *out, uint64_t out_cap, uint64_t *out_size, double *kernel_ms);
+/* (ABI 5) The whole front end: a BGZF GAM file's bytes -> the parser's arrays on the device, as kernels: inflate (a lane per BGZF
+ * member), framing of libvgio's groups (a lane per 1 MiB segment, from the first group tag "GAM" it finds to the next segment's: the
+ * walks must meet, or the call fails with VGAN_EIO and the caller takes the host pipeline), protobuf wire walk of vg.Alignment (a lane
+ * per message: sizes, exclusive sums, fill).  What it leaves on the device is, bit for bit, what vgan_gam_stream's parser and the
+ * narrowing of vgan_hc_devflat_run make of the same file: 32-bit offsets, node ids, mapping offsets, edit lengths (-1: not a match
+ * or substitution), quality and substitution bytes, the identity as HaploCart.cpp:410's one bit, and the first mapping's
+ * (node id, offset) per read for the duplicate marks (src/rmdup.cpp).  keep_unmapped = 0 drops identity == 0 (readGAM.h:47).
+ * hip_stream NULL: a stream of the object's own. */
+typedef struct vgan_gamdev vgan_gamdev;
+int vgan_gamdev_create(int device, void *hip_stream, vgan_gamdev **out);
+void vgan_gamdev_free(vgan_gamdev *g);
+int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, int keep_unmapped);
+/* sizes[8]: inflated bytes, messages, reads, mappings, edits, edit-sequence bytes, quality bytes, 0; ms[4]: upload, inflate, framing,
+ * parsing (wall, synchronous) */
+int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double ms[4]);
+/* test aid: array `which` of the last parse copied to the host (the list is beside the definition, csrc/gam_kernels.hip) */
+int vgan_gamdev_download(const vgan_gamdev *g, int which, void *dst);
 /* (ABI 4) a1 on the device: reconstruct_graph_sequence (vgan_utils.h:6-79), the slicing of update_likelihood.cpp:28-45 and the
  * packed layout in one pass over a chunk of the parser's arrays, for the reads whose edits are all matches or substitutions
  * on known nodes and which satisfy the tile contract -- what it writes is vgan_hc_flatten_parts_packed's packed batch of those

@@ -92,3 +92,104 @@ def test_a_damaged_member_is_refused(tmp_path):
         assert rc != 0 or out[:int(size.value)].tobytes() != want
         n_bad += rc != 0
     assert n_bad >= 1
+
+
+# ---------------------------------------------------------------------------------------------- framing + parsing on the device
+_DT = {0: np.uint32, 1: np.uint32, 2: np.uint32, 3: np.uint32, 4: np.uint32, 5: np.int32, 6: np.int32, 7: np.int32, 8: np.uint8, 9: np.uint8,
+       10: np.uint8, 11: np.uint8, 12: np.int64, 13: np.int64, 14: np.uint8, 15: np.uint64, 16: np.uint32}
+
+
+class GamDev:
+    def __init__(self):
+        self._h = N.vp()
+        N.check(N.lib().vgan_gamdev_create(0, None, C.byref(self._h)))
+
+    def parse(self, data, keep_unmapped=False):
+        buf = np.frombuffer(data, np.uint8)
+        N.check(N.lib().vgan_gamdev_parse(self._h, buf.ctypes.data, len(data), int(keep_unmapped)))
+        sizes = np.zeros(8, np.uint64)
+        ms = np.zeros(4)
+        N.check(N.lib().vgan_gamdev_sizes(self._h, sizes.ctypes.data, ms.ctypes.data))
+        self.sizes = dict(zip(("inflated", "messages", "R", "M", "E", "S", "Q"), (int(x) for x in sizes[:7])))
+        self.ms = dict(zip(("upload", "inflate", "frame", "parse"), ms))
+        return self
+
+    def array(self, which):
+        z = self.sizes
+        n = {0: z["R"] + 1, 1: z["R"] + 1, 2: z["M"] + 1, 3: z["E"] + 1, 4: z["M"], 5: z["M"], 6: z["R"], 7: z["E"], 8: z["R"], 9: z["M"], 10: z["S"], 11: z["Q"],
+             12: z["R"], 13: z["R"], 14: z["inflated"], 15: z["messages"], 16: z["messages"]}[which]
+        out = np.zeros(max(n, 1), _DT[which])
+        N.check(N.lib().vgan_gamdev_download(self._h, which, out.ctypes.data))
+        return out[:n]
+
+    def close(self):
+        if self._h:
+            N.lib().vgan_gamdev_free(self._h)
+            self._h = None
+
+
+def host_slice(a):
+    """What vgan_hc_devflat_run's narrowing makes of a host-parsed alignment set (csrc/hc_flatten_kernels.hip: DfSlice)."""
+    x = a.arrays()
+    node = x["m_node"]
+    off = x["m_offset"]
+    return {0: x["map_off"].astype(np.uint32), 1: x["qual_off"].astype(np.uint32), 2: x["edit_off"].astype(np.uint32), 3: x["e_seq_off"].astype(np.uint32),
+            4: np.where((node < 0) | (node > 0xFFFFFFFE), 0xFFFFFFFF, node).astype(np.uint32),
+            5: np.where((off != off.astype(np.int32)) | (off.astype(np.int32) == -2**31), -2**31, off).astype(np.int32),
+            6: x["mapq"].astype(np.int32), 7: np.where((x["e_from"] == x["e_to"]) & (x["e_from"] >= 0), x["e_from"], -1).astype(np.int32),
+            8: (x["identity"] < 1e-10).astype(np.uint8), 9: x["m_rev"].astype(np.uint8), 10: np.array(x["e_seq"]), 11: np.array(x["qual"]),
+            12: np.array([node[x["map_off"][r]] if x["map_off"][r + 1] > x["map_off"][r] else -1 for r in range(x["n_reads"])], np.int64),
+            13: np.array([off[x["map_off"][r]] if x["map_off"][r + 1] > x["map_off"][r] else 0 for r in range(x["n_reads"])], np.int64)}
+
+
+def check_against_host(gd, data, keep_unmapped):
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".gam") as f:
+        f.write(data)
+        f.flush()
+        a = hc.AlnSet.read_gam(f.name, keep_unmapped=keep_unmapped)
+    gd.parse(data, keep_unmapped)
+    want = host_slice(a)
+    assert gd.sizes["R"] == a.n_reads
+    for which, w in want.items():
+        got = gd.array(which)
+        assert got.shape == w.shape and np.array_equal(got, w), which
+    return a.n_reads
+
+
+@pytest.mark.parametrize("name", ["alignments/J2a1a1a1.gam", "alignments/two_unique.gam", "alignments/all_the_same.gam",
+                                  "alignments/all_the_same_reverse.gam", "reconstruct/test_reads.gam"])
+def test_device_framing_and_parsing_of_the_reference_gams(name):
+    data = open(os.path.join(GOLD, name), "rb").read()
+    gd = GamDev()
+    for keep in (False, True):
+        assert check_against_host(gd, data, keep) > 0
+    gd.close()
+
+
+def test_device_front_end_on_synthetic_files(tmp_path):
+    """Files of several segments (the walks must meet on the groups' tags), groups of odd sizes, reads with indels and soft clips
+    (edits that are neither match nor substitution), unmapped reads."""
+    g = hc.synth_graph(seed=5, genome_len=3000, n_nodes=2000, n_paths=50)
+    gd = GamDev()
+    for n, rl, group in ((40000, 150, 512), (3000, 600, 7), (9000, 75, 1000)):
+        a = hc.synth_reads(g, n, seed=6 + n, read_len=rl, indel_rate=0.1, softclip_rate=0.1)
+        p = str(tmp_path / ("s%d.gam" % n))
+        a.write_gam(p, group_size=group)
+        data = open(p, "rb").read()
+        assert a.n_reads - 5 <= check_against_host(gd, data, False) <= a.n_reads  # (a read without a single matching base has identity 0: dropped)
+        assert check_against_host(gd, data, True) == a.n_reads
+        print("device front end %d reads: %s" % (n, {k: round(v, 2) for k, v in gd.ms.items()}))
+    # the message list itself: offsets ascend, lengths add up with the framing bytes to the inflated size
+    off, ln = gd.array(15), gd.array(16)
+    assert np.all(off[1:] > off[:-1]) and int(off[-1] + ln[-1]) == gd.sizes["inflated"]
+    gd.close()
+
+
+def test_an_empty_file_and_a_stream_without_tags(tmp_path):
+    import gamio
+    gd = GamDev()
+    empty = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00"  # the BGZF end-of-file member
+    gd.parse(empty)
+    assert gd.sizes["R"] == 0 and gd.sizes["messages"] == 0
+    gd.close()

@@ -225,6 +225,11 @@ SYMBOLS = {
     "vgan_hc_reduce_last": (C.c_int, [vp, vp]),
     "vgan_hc_reduce_why": (C.c_int, [C.c_char_p, C.c_int64]),
     "vgan_gamdev_inflate_bytes": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
+    "vgan_gamdev_create": (C.c_int, [C.c_int, vp, vp]),
+    "vgan_gamdev_free": (None, [vp]),
+    "vgan_gamdev_parse": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
+    "vgan_gamdev_sizes": (C.c_int, [vp, vp, vp]),
+    "vgan_gamdev_download": (C.c_int, [vp, C.c_int, vp]),
     "vgan_hc_pack": (C.c_int, [vp, C.POINTER(HcBatch), C.POINTER(vp)]),
     "vgan_hc_packed_free": (None, [vp]),
     "vgan_hc_accumulate": (C.c_int, [vp, C.POINTER(HcBatch)]),

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -332,6 +333,385 @@ __global__ __launch_bounds__(64) void gd_inflate_kernel(const uint8_t *__restric
     status[b] = err;
 }
 
+// ------------------------------------------------------------------------------------------------------------------ framing
+// libvgio's stream: groups {count, count x (length, bytes)}; the first item of every group vg writes is the tag "GAM".
+constexpr uint32_t GD_TAG = 0x4D414703u; // the bytes 03 'G' 'A' 'M' as they sit in memory
+constexpr uint64_t GD_NO_ANCHOR = ~0ull;
+enum : uint32_t { GF_OK = 0, GF_BAD_VARINT = 1, GF_MISSED = 2, GF_TRUNCATED = 3, GF_BAD_MESSAGE = 4 };
+
+__device__ __forceinline__ uint32_t gd_u32_at(const uint8_t *u, uint64_t n, uint64_t p) { // four bytes at any offset (zeros beyond n)
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v |= (p + k < n ? (uint32_t)u[p + k] : 0u) << (8 * k);
+    return v;
+}
+// 1: read (q is past it); 0: the bytes end inside it; -1: longer than ten bytes   (csrc/host/gam.cpp: get_varint)
+__device__ __forceinline__ int gd_varint(const uint8_t *u, uint64_t e, uint64_t p, uint64_t &v, uint64_t &q) {
+    v = 0;
+    for (int shift = 0; shift <= 63; shift += 7) {
+        if (p >= e) return 0;
+        const uint8_t b = u[p++];
+        v |= (uint64_t)(b & 0x7f) << shift;
+        if (!(b & 0x80)) {
+            q = p;
+            return 1;
+        }
+    }
+    return -1;
+}
+
+// One WAVE per segment: the first tag in [seg start (or 1), seg end); a match may begin in the segment and end beyond it.
+__global__ __launch_bounds__(256) void gd_anchor_kernel(const uint8_t *__restrict__ u, uint64_t n, uint64_t seg_bytes, uint32_t n_segs,
+                                                        uint64_t *__restrict__ anchor) {
+    const uint32_t lane = threadIdx.x & 63u, seg = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (seg >= n_segs) return;
+    const uint64_t s0 = (uint64_t)seg * seg_bytes, s1 = min(n, s0 + seg_bytes);
+    uint64_t found = GD_NO_ANCHOR;
+    if (seg == 0) { // the stream's own start: the walk begins in header state at offset 0, no tag is looked for
+        if (lane == 0) anchor[0] = 0;
+        return;
+    }
+    for (uint64_t base = s0 & ~15ull; base < s1; base += 64u * 16u) {
+        const uint64_t at = base + (uint64_t)lane * 16u;
+        uint32_t w[5] = {0, 0, 0, 0, 0};
+        if (at + 20 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(u + at);
+            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+            w[4] = *reinterpret_cast<const uint32_t *>(u + at + 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) w[k] = gd_u32_at(u, n, at + 4u * k);
+        }
+        uint32_t hit = 16;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            const uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
+            const uint32_t win = (i & 3) ? (uint32_t)(((uint64_t)hi << 32 | lo) >> (8 * (i & 3))) : lo;
+            const uint64_t pos = at + (uint64_t)i;
+            if (win == GD_TAG && pos >= s0 && pos < s1 && pos >= 1) hit = (uint32_t)i;
+        }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(hit < 16);
+        if (m) {
+            const uint32_t l0 = (uint32_t)__builtin_ctzll(m);
+            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hit, (int)l0);
+            found = base + (uint64_t)l0 * 16u + h0;
+            break;
+        }
+    }
+    if (lane == 0) anchor[seg] = found;
+}
+
+// One LANE per anchored segment: the walk from its tag to the next anchored segment's tag (or the stream's end).  emit = false:
+// count the messages; true: write {offset, length} from msg_base[seg].
+struct GdWalkOut {
+    uint32_t n_msg, status;
+};
+template <bool EMIT>
+__device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t start, bool at_tag, uint64_t stop_tag, uint64_t *msg_off, uint32_t *msg_len,
+                                     uint64_t out_base) {
+    uint64_t p = start, cnt = 0;
+    uint64_t rem = 0;
+    bool in_group = false, first = false;
+    if (at_tag) {
+        // the anchor's own group: its count lies before the tag and cannot be told from the previous message's last bytes, so its end
+        // is recognised instead -- a count followed by the tag (no message starts with field number 0)   (gam.cpp: frame_segment)
+        p = start + 4;
+        for (;;) {
+            uint64_t v, q;
+            if (p >= n) return GdWalkOut{(uint32_t)cnt, stop_tag == n && p == n ? GF_OK : GF_TRUNCATED};
+            const int r = gd_varint(u, n, p, v, q);
+            if (r <= 0) return GdWalkOut{(uint32_t)cnt, r < 0 ? GF_BAD_VARINT : GF_TRUNCATED};
+            if (gd_u32_at(u, n, q) == GD_TAG && q + 4 <= n) { // p is a group header
+                if (q == stop_tag) return GdWalkOut{(uint32_t)cnt, GF_OK};
+                if (q > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
+                rem = v;
+                first = true;
+                in_group = v != 0;
+                p = q;
+                break;
+            }
+            if (v > n - q) return GdWalkOut{(uint32_t)cnt, GF_TRUNCATED};
+            if (q + v > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED}; // (the next anchor lies inside this item: one of the two tags is no tag)
+            if (EMIT) {
+                msg_off[out_base + cnt] = q;
+                msg_len[out_base + cnt] = (uint32_t)v;
+            }
+            if (v > 0xFFFFFFFFull) return GdWalkOut{(uint32_t)cnt, GF_BAD_MESSAGE};
+            cnt += 1;
+            p = q + v;
+        }
+    }
+    for (;;) { // the walk proper (gam.cpp: walk)
+        uint64_t v, q;
+        if (!in_group) {
+            if (p == n) return GdWalkOut{(uint32_t)cnt, stop_tag == n ? GF_OK : GF_MISSED};
+            const int r = gd_varint(u, n, p, v, q);
+            if (r <= 0) return GdWalkOut{(uint32_t)cnt, r < 0 ? GF_BAD_VARINT : GF_TRUNCATED};
+            rem = v;
+            first = true;
+            in_group = v != 0;
+            p = q;
+            if (in_group && p == stop_tag) return GdWalkOut{(uint32_t)cnt, GF_OK}; // the next anchored segment starts on this group's tag
+            if (p > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
+            continue;
+        }
+        const int r = gd_varint(u, n, p, v, q);
+        if (r <= 0) return GdWalkOut{(uint32_t)cnt, r < 0 ? GF_BAD_VARINT : GF_TRUNCATED};
+        if (v > n - q) return GdWalkOut{(uint32_t)cnt, GF_TRUNCATED};
+        const bool tag = first && v == 3 && u[q] == 'G' && u[q + 1] == 'A' && u[q + 2] == 'M';
+        if (!tag) {
+            if (v > 0xFFFFFFFFull) return GdWalkOut{(uint32_t)cnt, GF_BAD_MESSAGE};
+            if (EMIT) {
+                msg_off[out_base + cnt] = q;
+                msg_len[out_base + cnt] = (uint32_t)v;
+            }
+            cnt += 1;
+        }
+        first = false;
+        p = q + v;
+        if (p > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
+        if (--rem == 0) in_group = false;
+    }
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void gd_frame_kernel(const uint8_t *__restrict__ u, uint64_t n, uint32_t n_segs, const uint64_t *__restrict__ anchor,
+                                                      const uint64_t *__restrict__ next_anchor, uint32_t *__restrict__ seg_msgs,
+                                                      const uint64_t *__restrict__ msg_base, uint64_t *__restrict__ msg_off, uint32_t *__restrict__ msg_len,
+                                                      uint32_t *__restrict__ seg_status) {
+    const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
+    if (seg >= n_segs) return;
+    const uint64_t a = anchor[seg];
+    if (a == GD_NO_ANCHOR) { // (its bytes are walked from the anchored segment before it)
+        if (!EMIT) {
+            seg_msgs[seg] = 0;
+            seg_status[seg] = GF_OK;
+        }
+        return;
+    }
+    const GdWalkOut w = gd_walk_segment<EMIT>(u, n, a, seg != 0, next_anchor[seg], msg_off, msg_len, EMIT ? msg_base[seg] : 0);
+    if (!EMIT) {
+        seg_msgs[seg] = w.n_msg;
+        seg_status[seg] = w.status;
+    }
+}
+
+// next_anchor[seg] = the tag position of the first anchored segment behind seg, or n (one thread: a few thousand segments)
+__global__ void gd_next_anchor_kernel(const uint64_t *__restrict__ anchor, uint32_t n_segs, uint64_t n, uint64_t *__restrict__ next_anchor) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t nxt = n;
+    for (uint32_t s = n_segs; s-- > 0;) {
+        next_anchor[s] = nxt;
+        if (anchor[s] != GD_NO_ANCHOR) nxt = anchor[s];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ parsing
+// protobuf wire walk of vg.Alignment, statement for statement csrc/host/gam.cpp (Cur, parse_alignment, parse_mapping, parse_edit):
+// which occurrence of a repeated scalar wins, which fields are appended, what is skipped and what makes a message malformed.
+struct GdCur {
+    const uint8_t *p, *e;
+    bool ok;
+};
+__device__ __forceinline__ bool gc_done(const GdCur &c) { return c.p >= c.e; }
+__device__ __forceinline__ uint64_t gc_varint(GdCur &c) {
+    if (c.p < c.e && !(*c.p & 0x80)) return *c.p++;
+    uint64_t v = 0;
+    int shift = 0;
+    while (c.p < c.e) {
+        const uint8_t b = *c.p++;
+        v |= (uint64_t)(b & 0x7f) << shift;
+        if (!(b & 0x80)) return v;
+        shift += 7;
+        if (shift > 63) break;
+    }
+    c.ok = false;
+    return 0;
+}
+__device__ __forceinline__ GdCur gc_sub(GdCur &c) {
+    const uint64_t n = gc_varint(c);
+    if (!c.ok || n > (uint64_t)(c.e - c.p)) {
+        c.ok = false;
+        return GdCur{c.p, c.p, false};
+    }
+    GdCur s{c.p, c.p + n, true};
+    c.p += n;
+    return s;
+}
+__device__ __forceinline__ void gc_skip(GdCur &c, int wt) {
+    switch (wt) {
+    case 0: (void)gc_varint(c); break;
+    case 1:
+        if (c.e - c.p >= 8) c.p += 8;
+        else c.ok = false;
+        break;
+    case 2: (void)gc_sub(c); break;
+    case 5:
+        if (c.e - c.p >= 4) c.p += 4;
+        else c.ok = false;
+        break;
+    default: c.ok = false;
+    }
+}
+
+struct GdSizes { // per message
+    uint32_t n_map, n_edit, eseq, qual;
+};
+struct GdOut { // the arrays of one DfSlice (hc_flatten_kernels.hip) and what the host's duplicate marks need
+    uint32_t *map_off, *qual_off, *edit_off, *e_seq_off, *m_node;
+    int32_t *m_offset, *mapq, *e_len;
+    uint8_t *unmapped, *m_rev, *e_seq, *qual;
+    int64_t *first_node, *first_offset; // of the read's first mapping (-1, 0: no mapping): src/rmdup.cpp's key
+};
+
+// FILL false: the message's sizes, its keep flag (identity != 0 or keep_unmapped) and whether it parses; true: its arrays, written at
+// the places the exclusive sums give it.
+template <bool FILL>
+__device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, double &identity, int32_t &mapq, const GdOut &o, uint32_t m0, uint32_t e0,
+                                 uint32_t s0, uint32_t q0, int64_t &first_node, int64_t &first_off) {
+    GdCur c{mp, mp + mlen, true};
+    sz = GdSizes{0, 0, 0, 0};
+    identity = 0.0;
+    mapq = 0;
+    first_node = -1;
+    first_off = 0;
+    while (!gc_done(c) && c.ok) {
+        const uint64_t key = gc_varint(c);
+        const int f = (int)(key >> 3), wt = (int)(key & 7);
+        if (f == 2 && wt == 2) {
+            GdCur path = gc_sub(c);
+            while (!gc_done(path) && path.ok) {
+                const uint64_t k2 = gc_varint(path);
+                const int f2 = (int)(k2 >> 3), w2 = (int)(k2 & 7);
+                if (f2 == 2 && w2 == 2) { // a mapping
+                    GdCur mc = gc_sub(path);
+                    if (!path.ok) return false;
+                    int64_t node = 0, off = 0;
+                    uint8_t rev = 0;
+                    while (!gc_done(mc) && mc.ok) {
+                        const uint64_t k3 = gc_varint(mc);
+                        const int f3 = (int)(k3 >> 3), w3 = (int)(k3 & 7);
+                        if (f3 == 1 && w3 == 2) { // position
+                            GdCur pc = gc_sub(mc);
+                            while (!gc_done(pc) && pc.ok) {
+                                const uint64_t k4 = gc_varint(pc);
+                                const int f4 = (int)(k4 >> 3), w4 = (int)(k4 & 7);
+                                if (f4 == 1 && w4 == 0) node = (int64_t)gc_varint(pc);
+                                else if (f4 == 2 && w4 == 0) off = (int64_t)gc_varint(pc);
+                                else if (f4 == 4 && w4 == 0) rev = gc_varint(pc) != 0;
+                                else gc_skip(pc, w4);
+                            }
+                            if (!pc.ok) return false;
+                        } else if (f3 == 2 && w3 == 2) { // an edit
+                            GdCur ec = gc_sub(mc);
+                            if (!mc.ok) return false;
+                            int32_t from = 0, to = 0;
+                            const uint8_t *sb = nullptr, *se = nullptr;
+                            while (!gc_done(ec) && ec.ok) {
+                                const uint64_t k4 = gc_varint(ec);
+                                const int f4 = (int)(k4 >> 3), w4 = (int)(k4 & 7);
+                                if (f4 == 1 && w4 == 0) from = (int32_t)gc_varint(ec);
+                                else if (f4 == 2 && w4 == 0) to = (int32_t)gc_varint(ec);
+                                else if (f4 == 3 && w4 == 2) {
+                                    GdCur sc = gc_sub(ec);
+                                    sb = sc.p;
+                                    se = sc.e;
+                                } else gc_skip(ec, w4);
+                            }
+                            if (!ec.ok) return false;
+                            const uint32_t nb = sb ? (uint32_t)(se - sb) : 0u;
+                            if (FILL) {
+                                o.e_len[e0 + sz.n_edit] = from == to && from >= 0 ? from : -1;
+                                for (uint32_t k = 0; k < nb; ++k) o.e_seq[s0 + sz.eseq + k] = sb[k];
+                                o.e_seq_off[e0 + sz.n_edit + 1] = s0 + sz.eseq + nb;
+                            }
+                            sz.n_edit += 1;
+                            sz.eseq += nb;
+                        } else gc_skip(mc, w3);
+                    }
+                    if (!mc.ok) return false;
+                    if (sz.n_map == 0) {
+                        first_node = node;
+                        first_off = off;
+                    }
+                    if (FILL) {
+                        o.m_node[m0 + sz.n_map] = node < 0 || node > 0xFFFFFFFEll ? 0xFFFFFFFFu : (uint32_t)node;
+                        o.m_offset[m0 + sz.n_map] = off != (int64_t)(int32_t)off || (int32_t)off == INT32_MIN ? INT32_MIN : (int32_t)off;
+                        o.m_rev[m0 + sz.n_map] = rev;
+                        o.edit_off[m0 + sz.n_map + 1] = e0 + sz.n_edit;
+                    }
+                    sz.n_map += 1;
+                } else gc_skip(path, w2);
+            }
+            if (!path.ok) return false;
+        } else if (f == 4 && wt == 2) {
+            GdCur sc = gc_sub(c);
+            const uint32_t nb = (uint32_t)(sc.e - sc.p);
+            if (FILL && sc.ok)
+                for (uint32_t k = 0; k < nb; ++k) o.qual[q0 + sz.qual + k] = sc.p[k];
+            sz.qual += sc.ok ? nb : 0u;
+        } else if (f == 5 && wt == 0) {
+            mapq = (int32_t)gc_varint(c);
+        } else if (f == 16 && wt == 1) {
+            if (c.e - c.p < 8) return false;
+            uint64_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bits |= (uint64_t)c.p[k] << (8 * k);
+            identity = __longlong_as_double((long long)bits);
+            c.p += 8;
+        } else if ((f == 1 || f == 3) && wt == 2) { // sequence, name: not needed on the device
+            (void)gc_sub(c);
+        } else gc_skip(c, wt);
+    }
+    return c.ok;
+}
+
+__global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict__ u, const uint64_t *__restrict__ msg_off, const uint32_t *__restrict__ msg_len,
+                                                       uint32_t n_msg, int keep_unmapped, uint32_t *__restrict__ keep, uint32_t *__restrict__ n_map,
+                                                       uint32_t *__restrict__ n_edit, uint32_t *__restrict__ n_eseq, uint32_t *__restrict__ n_qual,
+                                                       uint32_t *__restrict__ bad) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_msg) return;
+    GdSizes sz;
+    double identity;
+    int32_t mapq;
+    int64_t fn, fo;
+    const bool ok = gd_parse_message<false>(u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, 0, 0, 0, 0, fn, fo);
+    if (!ok) atomicAdd(bad, 1u);
+    const bool kp = ok && (keep_unmapped || identity != 0.0); // readGAM.h:47: "Discard unmapped reads"
+    keep[i] = kp ? 1u : 0u;
+    n_map[i] = kp ? sz.n_map : 0u;
+    n_edit[i] = kp ? sz.n_edit : 0u;
+    n_eseq[i] = kp ? sz.eseq : 0u;
+    n_qual[i] = kp ? sz.qual : 0u;
+}
+
+__global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict__ u, const uint64_t *__restrict__ msg_off, const uint32_t *__restrict__ msg_len,
+                                                      uint32_t n_msg, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ r_at,
+                                                      const uint32_t *__restrict__ m_at, const uint32_t *__restrict__ e_at, const uint32_t *__restrict__ s_at,
+                                                      const uint32_t *__restrict__ q_at, GdOut o) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) { // the offsets' leading zeros
+        o.map_off[0] = 0;
+        o.qual_off[0] = 0;
+        o.edit_off[0] = 0;
+        o.e_seq_off[0] = 0;
+    }
+    if (i >= n_msg || !keep[i]) return;
+    GdSizes sz;
+    double identity;
+    int32_t mapq;
+    int64_t fn, fo;
+    const uint32_t r = r_at[i];
+    (void)gd_parse_message<true>(u + msg_off[i], msg_len[i], sz, identity, mapq, o, m_at[i], e_at[i], s_at[i], q_at[i], fn, fo);
+    o.map_off[r + 1] = m_at[i] + sz.n_map;
+    o.qual_off[r + 1] = q_at[i] + sz.qual;
+    o.mapq[r] = mapq;
+    o.unmapped[r] = identity < 1e-10 ? 1 : 0; // HaploCart.cpp:410
+    o.first_node[r] = fn;
+    o.first_offset[r] = fo;
+}
+
 } // namespace gd
 } // namespace vgan
 
@@ -414,4 +794,266 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
 #undef GDCHK
     cleanup();
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------ the C-ABI object
+namespace {
+template <class T> struct GBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap && p) return VGAN_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 8 + 64;
+        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return VGAN_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+} // namespace
+
+struct vgan_gamdev {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    GBuf<uint8_t> in, infl, cub_tmp;
+    GBuf<GdBlock> blocks;
+    GBuf<uint32_t> status, seg_msgs, seg_status, msg_len, keep, n_map, n_edit, n_eseq, n_qual, r_at, m_at, e_at, s_at, q_at, bad;
+    GBuf<uint64_t> anchor, next_anchor, msg_base, msg_off;
+    // one DfSlice's arrays (hc_flatten_kernels.hip) of the file's reads
+    GBuf<uint32_t> map_off, qual_off, edit_off, e_seq_off, m_node;
+    GBuf<int32_t> m_offset, mapq, e_len;
+    GBuf<uint8_t> unmapped, m_rev, e_seq, qual;
+    GBuf<int64_t> first_node, first_offset;
+    uint64_t n_inflated = 0, n_messages = 0, R = 0, M = 0, E = 0, S = 0, Q = 0;
+    double ms_inflate = 0, ms_frame = 0, ms_parse = 0, ms_upload = 0;
+    void release_all() {
+        in.release(), infl.release(), cub_tmp.release(), blocks.release();
+        for (auto *b : {&status, &seg_msgs, &seg_status, &msg_len, &keep, &n_map, &n_edit, &n_eseq, &n_qual, &r_at, &m_at, &e_at, &s_at, &q_at, &bad, &map_off,
+                        &qual_off, &edit_off, &e_seq_off, &m_node})
+            b->release();
+        for (auto *b : {&anchor, &next_anchor, &msg_base, &msg_off}) b->release();
+        for (auto *b : {&m_offset, &mapq, &e_len}) b->release();
+        for (auto *b : {&unmapped, &m_rev, &e_seq, &qual}) b->release();
+        first_node.release(), first_offset.release();
+    }
+};
+
+extern "C" int vgan_gamdev_create(int device, void *hip_stream, vgan_gamdev **out) {
+    if (!out) return fail(VGAN_EINVAL, "vgan_gamdev_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(VGAN_ENODEV, "vgan_gamdev_create: no HIP device is visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(VGAN_EINVAL, "vgan_gamdev_create: device %d out of range", device);
+    HIPCHK(hipSetDevice(device));
+    auto g = new vgan_gamdev();
+    g->device = device;
+    if (hip_stream) {
+        g->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete g;
+            return fail(VGAN_ENODEV, "vgan_gamdev_create: hipStreamCreate failed");
+        }
+        g->own_stream = true;
+    }
+    *out = g;
+    return VGAN_OK;
+}
+
+extern "C" void vgan_gamdev_free(vgan_gamdev *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    g->release_all();
+    if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+namespace {
+int exclusive_sum(vgan_gamdev *g, const uint32_t *in, uint32_t *out, size_t n) {
+    size_t tmp = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n, g->stream) != hipSuccess) return fail(VGAN_ENODEV, "vgan_gamdev_parse: scan sizing failed");
+    int rc;
+    if ((rc = g->cub_tmp.reserve(tmp + 16))) return rc;
+    if (hipcub::DeviceScan::ExclusiveSum(g->cub_tmp.p, tmp, in, out, (int)n, g->stream) != hipSuccess) return fail(VGAN_ENODEV, "vgan_gamdev_parse: scan failed");
+    return VGAN_OK;
+}
+double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+} // namespace
+
+// A BGZF GAM file's bytes -> the parser's arrays on the device (what vgan_gam_stream + the narrowing of vgan_hc_devflat_run make of the
+// same file on the host).  VGAN_EIO: not BGZF, a member that does not inflate, a stream the segment walks cannot frame consistently
+// (the caller takes the host pipeline), a malformed message.
+extern "C" int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, int keep_unmapped) {
+    if (!g || (!bytes && n)) return fail(VGAN_EINVAL, "vgan_gamdev_parse: null argument");
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    g->n_inflated = g->n_messages = g->R = g->M = g->E = g->S = g->Q = 0;
+    std::vector<BgzfBlock> blocks;
+    if (!bgzf_index((const unsigned char *)bytes, (size_t)n, blocks)) return fail(VGAN_EIO, "vgan_gamdev_parse: not a BGZF stream");
+    std::vector<GdBlock> gb;
+    uint64_t total = 0;
+    for (const BgzfBlock &b : blocks) {
+        const unsigned char *p = (const unsigned char *)bytes + b.in_off;
+        const size_t xlen = p[10] | (p[11] << 8), hdr = 12 + xlen;
+        if (b.out_size == 0) continue; // (the end-of-file member, empty members: nothing to write)
+        gb.push_back(GdBlock{(uint64_t)(b.in_off + hdr), (uint64_t)b.out_off, (uint32_t)(b.in_size - hdr - 8), (uint32_t)b.out_size});
+        total = b.out_off + b.out_size;
+    }
+    if (!blocks.empty()) total = blocks.back().out_off + blocks.back().out_size;
+    g->n_inflated = total;
+    int rc;
+    auto t0 = std::chrono::steady_clock::now();
+    if ((rc = g->in.reserve(n + 64)) || (rc = g->infl.reserve(total + 64)) || (rc = g->blocks.reserve(gb.size() + 1)) || (rc = g->status.reserve(gb.size() + 1))) return rc;
+    HIPCHK(hipMemcpyAsync(g->in.p, bytes, n, hipMemcpyHostToDevice, st));
+    if (!gb.empty()) HIPCHK(hipMemcpyAsync(g->blocks.p, gb.data(), gb.size() * sizeof(GdBlock), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    g->ms_upload = ms_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    if ((rc = gamdev_inflate(g->in.p, g->blocks.p, (uint32_t)gb.size(), g->infl.p, g->status.p, st))) return rc;
+    {
+        std::vector<uint32_t> stt(gb.size());
+        if (!gb.empty()) HIPCHK(hipMemcpyAsync(stt.data(), g->status.p, gb.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t i = 0; i < stt.size(); ++i)
+            if (stt[i] != GD_OK) return fail(VGAN_EIO, "vgan_gamdev_parse: BGZF member %zu does not inflate (code %u)", i, stt[i]);
+    }
+    g->ms_inflate = ms_since(t0);
+    if (total == 0) return VGAN_OK;
+    // ---- framing
+    t0 = std::chrono::steady_clock::now();
+    const uint64_t seg_bytes = 1u << 20;
+    const uint32_t n_segs = (uint32_t)((total + seg_bytes - 1) / seg_bytes);
+    if ((rc = g->anchor.reserve(n_segs)) || (rc = g->next_anchor.reserve(n_segs)) || (rc = g->seg_msgs.reserve(n_segs)) || (rc = g->seg_status.reserve(n_segs)) ||
+        (rc = g->msg_base.reserve(n_segs)))
+        return rc;
+    hipLaunchKernelGGL(gd_anchor_kernel, dim3((n_segs + 3) / 4), dim3(256), 0, st, g->infl.p, total, seg_bytes, n_segs, g->anchor.p);
+    hipLaunchKernelGGL(gd_next_anchor_kernel, dim3(1), dim3(1), 0, st, g->anchor.p, n_segs, total, g->next_anchor.p);
+    hipLaunchKernelGGL(gd_frame_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, g->infl.p, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
+                       (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, g->seg_status.p);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> seg_n(n_segs), seg_st(n_segs);
+    HIPCHK(hipMemcpyAsync(seg_n.data(), g->seg_msgs.p, n_segs * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(seg_st.data(), g->seg_status.p, n_segs * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint64_t> base(n_segs);
+    uint64_t n_msg = 0;
+    for (uint32_t s = 0; s < n_segs; ++s) {
+        if (seg_st[s] != GF_OK)
+            return fail(VGAN_EIO, "vgan_gamdev_parse: the stream cannot be framed from segment %u (code %u: %s)", s, seg_st[s],
+                        seg_st[s] == GF_MISSED ? "a segment's walk does not meet the next one's group tag" : "malformed or truncated");
+        base[s] = n_msg;
+        n_msg += seg_n[s];
+    }
+    if (n_msg > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "vgan_gamdev_parse: more than 2^32 messages");
+    g->n_messages = n_msg;
+    if (n_msg == 0) {
+        g->ms_frame = ms_since(t0);
+        return VGAN_OK;
+    }
+    if ((rc = g->msg_off.reserve(n_msg)) || (rc = g->msg_len.reserve(n_msg))) return rc;
+    HIPCHK(hipMemcpyAsync(g->msg_base.p, base.data(), n_segs * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gd_frame_kernel<true>, dim3((n_segs + 63) / 64), dim3(64), 0, st, g->infl.p, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
+                       g->msg_base.p, g->msg_off.p, g->msg_len.p, g->seg_status.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    g->ms_frame = ms_since(t0);
+    // ---- parsing
+    t0 = std::chrono::steady_clock::now();
+    const uint32_t NM = (uint32_t)n_msg;
+    for (auto *b : {&g->keep, &g->n_map, &g->n_edit, &g->n_eseq, &g->n_qual, &g->r_at, &g->m_at, &g->e_at, &g->s_at, &g->q_at})
+        if ((rc = b->reserve((size_t)NM + 1))) return rc;
+    if ((rc = g->bad.reserve(4))) return rc;
+    HIPCHK(hipMemsetAsync(g->bad.p, 0, 4, st));
+    hipLaunchKernelGGL(gd_count_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, NM, keep_unmapped, g->keep.p, g->n_map.p,
+                       g->n_edit.p, g->n_eseq.p, g->n_qual.p, g->bad.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = exclusive_sum(g, g->keep.p, g->r_at.p, NM)) || (rc = exclusive_sum(g, g->n_map.p, g->m_at.p, NM)) || (rc = exclusive_sum(g, g->n_edit.p, g->e_at.p, NM)) ||
+        (rc = exclusive_sum(g, g->n_eseq.p, g->s_at.p, NM)) || (rc = exclusive_sum(g, g->n_qual.p, g->q_at.p, NM)))
+        return rc;
+    uint32_t last[10], bad = 0;
+    {
+        const uint32_t *srcs[10] = {g->keep.p, g->n_map.p, g->n_edit.p, g->n_eseq.p, g->n_qual.p, g->r_at.p, g->m_at.p, g->e_at.p, g->s_at.p, g->q_at.p};
+        for (int k = 0; k < 10; ++k) HIPCHK(hipMemcpyAsync(&last[k], srcs[k] + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&bad, g->bad.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    if (bad) return fail(VGAN_EIO, "vgan_gamdev_parse: %u malformed alignment messages", bad);
+    g->R = (uint64_t)last[0] + last[5];
+    g->M = (uint64_t)last[1] + last[6];
+    g->E = (uint64_t)last[2] + last[7];
+    g->S = (uint64_t)last[3] + last[8];
+    g->Q = (uint64_t)last[4] + last[9];
+    // (the sums are 32-bit: a total that does not fit shows as a sum below one of its terms -- checked through 64-bit sizes of the
+    // inflated bytes: every array is a subset of them)
+    if (total > 0xFFFFFFF0ull && (g->S > total || g->Q > total)) return fail(VGAN_ERANGE, "vgan_gamdev_parse: a chunk beyond 32-bit offsets; parse fewer bytes at a time");
+    if ((rc = g->map_off.reserve(g->R + 1)) || (rc = g->qual_off.reserve(g->R + 1)) || (rc = g->edit_off.reserve(g->M + 1)) || (rc = g->e_seq_off.reserve(g->E + 1)) ||
+        (rc = g->m_node.reserve(g->M + 1)) || (rc = g->m_offset.reserve(g->M + 1)) || (rc = g->mapq.reserve(g->R + 1)) || (rc = g->e_len.reserve(g->E + 1)) ||
+        (rc = g->unmapped.reserve(g->R + 1)) || (rc = g->m_rev.reserve(g->M + 1)) || (rc = g->e_seq.reserve(g->S + 1)) || (rc = g->qual.reserve(g->Q + 1)) ||
+        (rc = g->first_node.reserve(g->R + 1)) || (rc = g->first_offset.reserve(g->R + 1)))
+        return rc;
+    GdOut o{g->map_off.p, g->qual_off.p, g->edit_off.p, g->e_seq_off.p, g->m_node.p, g->m_offset.p, g->mapq.p, g->e_len.p, g->unmapped.p, g->m_rev.p, g->e_seq.p,
+            g->qual.p, g->first_node.p, g->first_offset.p};
+    hipLaunchKernelGGL(gd_fill_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, NM, g->keep.p, g->r_at.p, g->m_at.p, g->e_at.p,
+                       g->s_at.p, g->q_at.p, o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    g->ms_parse = ms_since(t0);
+    return VGAN_OK;
+}
+
+// sizes[8]: inflated bytes, messages, reads, mappings, edits, edit-sequence bytes, quality bytes, 0;  ms[4]: upload, inflate, framing, parsing (wall)
+extern "C" int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double ms[4]) {
+    if (!g) return fail(VGAN_EINVAL, "vgan_gamdev_sizes: null argument");
+    if (sizes) {
+        const uint64_t v[8] = {g->n_inflated, g->n_messages, g->R, g->M, g->E, g->S, g->Q, 0};
+        memcpy(sizes, v, sizeof v);
+    }
+    if (ms) {
+        ms[0] = g->ms_upload, ms[1] = g->ms_inflate, ms[2] = g->ms_frame, ms[3] = g->ms_parse;
+    }
+    return VGAN_OK;
+}
+
+// Copies one of the arrays of the last parse to the host (test aid).  which: 0 map_off[R+1] 1 qual_off[R+1] 2 edit_off[M+1] 3 e_seq_off[E+1]
+// 4 m_node[M] 5 m_offset[M] 6 mapq[R] 7 e_len[E] 8 unmapped[R] 9 m_rev[M] 10 e_seq[S] 11 qual[Q] 12 first_node[R] 13 first_offset[R]
+// 14 the inflated bytes 15 msg_off[messages] (uint64) 16 msg_len[messages]
+extern "C" int vgan_gamdev_download(const vgan_gamdev *g, int which, void *dst) {
+    if (!g || !dst) return fail(VGAN_EINVAL, "vgan_gamdev_download: null argument");
+    HIPCHK(hipSetDevice(g->device));
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+    case 0: src = g->map_off.p, bytes = (g->R + 1) * 4; break;
+    case 1: src = g->qual_off.p, bytes = (g->R + 1) * 4; break;
+    case 2: src = g->edit_off.p, bytes = (g->M + 1) * 4; break;
+    case 3: src = g->e_seq_off.p, bytes = (g->E + 1) * 4; break;
+    case 4: src = g->m_node.p, bytes = g->M * 4; break;
+    case 5: src = g->m_offset.p, bytes = g->M * 4; break;
+    case 6: src = g->mapq.p, bytes = g->R * 4; break;
+    case 7: src = g->e_len.p, bytes = g->E * 4; break;
+    case 8: src = g->unmapped.p, bytes = g->R; break;
+    case 9: src = g->m_rev.p, bytes = g->M; break;
+    case 10: src = g->e_seq.p, bytes = g->S; break;
+    case 11: src = g->qual.p, bytes = g->Q; break;
+    case 12: src = g->first_node.p, bytes = g->R * 8; break;
+    case 13: src = g->first_offset.p, bytes = g->R * 8; break;
+    case 14: src = g->infl.p, bytes = g->n_inflated; break;
+    case 15: src = g->msg_off.p, bytes = g->n_messages * 8; break;
+    case 16: src = g->msg_len.p, bytes = g->n_messages * 4; break;
+    default: return fail(VGAN_EINVAL, "vgan_gamdev_download: no array %d", which);
+    }
+    if (g->R == 0 && which <= 3) { // (an empty parse: the offsets' leading zero)
+        memset(dst, 0, 4);
+        return VGAN_OK;
+    }
+    if (bytes && src) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return VGAN_OK;
 }
