@@ -400,6 +400,12 @@ int vgan_hc_devflat_create(vgan_hc_ctx *c, const vgan_graph *graph, vgan_hc_devf
 int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chunk, const uint8_t *skip, vgan_hc_packed_view *out,
                         uint8_t *host_mask, vgan_hc_flatten_stats *stats);
 void vgan_hc_devflat_free(vgan_hc_devflat *f);
+/* (ABI 5) The same over the arrays a vgan_gamdev_parse left on the device (declared below): nothing crosses the link but the duplicate
+ * marks (skip: per read of the parse, host memory or -- skip_on_device -- device memory; NULL: none) and the mask of the reads left to
+ * the host.  base: index of the parse's first read in the whole input (read_src = base + index). */
+struct vgan_gamdev;
+int vgan_hc_devflat_run_gamdev(vgan_hc_devflat *f, const struct vgan_gamdev *gd, const uint8_t *skip, int skip_on_device, uint32_t base,
+                               vgan_hc_packed_view *out, uint8_t *host_mask, vgan_hc_flatten_stats *stats);
 /* Host check of a packed batch against the layout above and the context's graph (offsets, node ids, head bits, maxima). */
 int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
 /* D_m = S_m - U_m per segment of a packed batch (test / debug aid). Host output [n_segments]. */

@@ -193,3 +193,42 @@ def test_an_empty_file_and_a_stream_without_tags(tmp_path):
     gd.parse(empty)
     assert gd.sizes["R"] == 0 and gd.sizes["messages"] == 0
     gd.close()
+
+
+def test_device_parse_feeds_the_device_flatten_like_the_host_parser(tmp_path):
+    """file bytes -> vgan_gamdev_parse -> vgan_hc_devflat_run_gamdev must give, word for word, the packed batch (and the mask of
+    the reads left to the host) that host parse -> vgan_hc_devflat_run gives; and the same final vector."""
+    g = hc.synth_graph(seed=15, genome_len=4000, n_nodes=2600, n_paths=80)
+    a = hc.synth_reads(g, 30000, seed=16, read_len=150, indel_rate=0.05, softclip_rate=0.05)
+    p = str(tmp_path / "x.gam")
+    a.write_gam(p)
+    data = open(p, "rb").read()
+    ctx = hc.HcContext(g)
+    df = hc.DeviceFlatten(ctx, g)
+    parts = hc.AlnParts.read_gam(p)
+    want = df.run(parts)
+    w = want.download()
+    w_mask = np.array(want.host_mask)
+    ctx.accumulate(want)
+    f_host = ctx.finalize()
+    gdev = hc.GamDevice().parse(data)
+    assert gdev.sizes["reads"] == parts.n_reads
+    got = df.run_gamdev(gdev)
+    gg = got.download()
+    for name in ("rhdr", "srec", "crec", "qualp", "read_src"):
+        assert np.array_equal(gg[name], w[name]), name
+    assert np.array_equal(np.array(got.host_mask), w_mask) and 0 < w_mask.sum() < parts.n_reads
+    for f in ("n_in", "n_out", "n_unmapped", "n_segments", "n_cols"):
+        assert getattr(got.stats, f) == getattr(want.stats, f), f
+    ctx.reset()
+    ctx.accumulate(got)
+    f_dev = ctx.finalize()  # (the same words in, the same kernels: equal up to the order of the window flushes' fp64 atomics)
+    assert np.max(np.abs(f_dev - f_host) / np.abs(f_host)) < 1e-13
+    # with duplicate marks
+    dup = parts.mark_duplicates()
+    w2 = df.run(parts, skip=dup).download()
+    g2 = df.run_gamdev(gdev, skip=dup).download()
+    for name in ("rhdr", "srec", "crec", "read_src"):
+        assert np.array_equal(g2[name], w2[name]), name
+    df.close()
+    gdev.close()

@@ -14,3 +14,16 @@ struct GdBlock { // one BGZF member: its DEFLATE payload within the file's bytes
 int gamdev_inflate(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_status, hipStream_t st);
 
 } // namespace vgan
+struct vgan_gamdev;
+namespace vgan {
+// the arrays of the last vgan_gamdev_parse, as hc_flatten_kernels.hip's DfSlice wants them (device pointers)
+struct GamdevSlice {
+    const uint32_t *map_off, *qual_off, *edit_off, *e_seq_off, *m_node;
+    const int32_t *m_offset, *mapq, *e_len;
+    const uint8_t *unmapped, *m_rev, *e_seq, *qual;
+    const int64_t *first_node, *first_offset;
+    uint64_t n_reads;
+    int device;
+};
+bool gamdev_slice(const vgan_gamdev *g, GamdevSlice *out);
+} // namespace vgan

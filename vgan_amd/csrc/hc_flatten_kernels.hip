@@ -19,6 +19,7 @@
 #include <cstring>
 #include <vector>
 
+#include "gam_device.h"
 #include "hc_device.h"
 #include "host/common.h"
 #include "vgan_gpu.h"
@@ -495,6 +496,10 @@ extern "C" void vgan_hc_devflat_free(vgan_hc_devflat *f) {
     delete f;
 }
 
+static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uint32_t R_all, uint32_t base, vgan_hc_packed_view *out, uint8_t *host_mask,
+                         vgan_hc_flatten_stats *stats, PhaseTimer &pt);
+static int df_prepare(vgan_hc_devflat *f, uint32_t R_all, size_t n_slices);
+
 extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chunk, const uint8_t *skip, vgan_hc_packed_view *out,
                                    uint8_t *host_mask, vgan_hc_flatten_stats *stats) {
     if (!f || !chunk || !out || !host_mask) return fail(VGAN_EINVAL, "vgan_hc_devflat_run: null argument");
@@ -527,12 +532,7 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
             return fail(VGAN_ERANGE, "vgan_hc_devflat_run: a parser slice beyond 32-bit offsets");
     }
     const uint32_t R_all = (uint32_t)n_reads;
-    if ((rc = f->stage.reserve(total)) || (rc = f->slices.reserve(np)) || (rc = f->flag.reserve(R_all)) || (rc = f->key.reserve(R_all)) ||
-        (rc = f->key_out.reserve(R_all)) || (rc = f->val_out.reserve(R_all)) || (rc = f->info.reserve(R_all)) ||
-        (rc = f->segs.reserve(R_all + 1)) || (rc = f->quals.reserve(R_all + 1)) || (rc = f->cols.reserve(R_all + 1)) ||
-        (rc = f->soff.reserve(R_all + 1)) || (rc = f->qoff.reserve(R_all + 1)) || (rc = f->coff.reserve(R_all + 1)))
-        return rc;
-    HIPCHK(hipMemsetAsync(f->ctr.p, 0, sizeof(DfCounters), st));
+    if ((rc = f->stage.reserve(total)) || (rc = df_prepare(f, R_all, np))) return rc;
     PhaseTimer pt("hc_devflat");
     if (total > f->pin_cap) {
         if (f->pin) (void)hipHostFree(f->pin);
@@ -633,6 +633,16 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
         pt.lap("staging (narrowing copy)");
         if (cur) HIPCHK(hipMemcpyAsync(f->stage.p, f->pin, cur, hipMemcpyHostToDevice, st));
     }
+    return df_run_slices(f, hs, R_all, (uint32_t)chunk->base, out, host_mask, stats, pt);
+}
+
+// classify -> sort -> offsets -> write over slices whose arrays are on the device (uploaded above, or left there by the GAM front
+// end on the device: gam_kernels.hip)
+static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uint32_t R_all, uint32_t base, vgan_hc_packed_view *out, uint8_t *host_mask,
+                         vgan_hc_flatten_stats *stats, PhaseTimer &pt) {
+    hipStream_t st = f->stream;
+    const size_t np = hs.size();
+    int rc;
     for (size_t i = 0; i < np; ++i)
         if (hs[i].n_reads)
             hipLaunchKernelGGL(hc_df_classify_kernel, dim3((hs[i].n_reads + 3) / 4), dim3(256), 0, st, hs[i], f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
@@ -691,7 +701,7 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
         return rc;
     DfOut o{f->rhdr.p, f->srec.p, f->crec.p, f->qualp.p, f->read_src.p};
     hipLaunchKernelGGL(hc_df_write_kernel, dim3(std::min<uint32_t>((n_dev + 1 + 3) / 4, 16384u)), dim3(256), 0, st, f->slices.p, (uint32_t)np, f->g,
-                       f->val_out.p, f->soff.p, f->qoff.p, f->coff.p, n_dev, (uint32_t)chunk->base, o);
+                       f->val_out.p, f->soff.p, f->qoff.p, f->coff.p, n_dev, base, o);
     HIPCHK(hipGetLastError());
     f->h_src.resize(n_dev);
     HIPCHK(hipMemcpyAsync(f->h_src.data(), f->read_src.p, (size_t)n_dev * 4, hipMemcpyDeviceToHost, st));
@@ -716,4 +726,55 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
         stats->n_cols = tot[2];
     }
     return VGAN_OK;
+}
+
+static int df_prepare(vgan_hc_devflat *f, uint32_t R_all, size_t n_slices) {
+    int rc;
+    if ((rc = f->slices.reserve(n_slices)) || (rc = f->flag.reserve(R_all)) || (rc = f->key.reserve(R_all)) || (rc = f->key_out.reserve(R_all)) ||
+        (rc = f->val_out.reserve(R_all)) || (rc = f->info.reserve(R_all)) || (rc = f->segs.reserve(R_all + 1)) || (rc = f->quals.reserve(R_all + 1)) ||
+        (rc = f->cols.reserve(R_all + 1)) || (rc = f->soff.reserve(R_all + 1)) || (rc = f->qoff.reserve(R_all + 1)) || (rc = f->coff.reserve(R_all + 1)))
+        return rc;
+    HIPCHK(hipMemsetAsync(f->ctr.p, 0, sizeof(DfCounters), f->stream));
+    return VGAN_OK;
+}
+
+// (ABI 5) The same over the arrays the GAM front end on the device left in HBM (vgan_gamdev_parse): nothing crosses the link but the
+// duplicate marks (skip: host, per read of the parse, or NULL) on their way up and the host-read mask on its way down.
+extern "C" int vgan_hc_devflat_run_gamdev(vgan_hc_devflat *f, const vgan_gamdev *gd, const uint8_t *skip, int skip_on_device, uint32_t base,
+                                          vgan_hc_packed_view *out, uint8_t *host_mask, vgan_hc_flatten_stats *stats) {
+    if (!f || !gd || !out || !host_mask) return fail(VGAN_EINVAL, "vgan_hc_devflat_run_gamdev: null argument");
+    memset(out, 0, sizeof *out);
+    if (stats) memset(stats, 0, sizeof *stats);
+    GamdevSlice gs{};
+    if (!gamdev_slice(gd, &gs)) return fail(VGAN_ESTATE, "vgan_hc_devflat_run_gamdev: the front end holds no parse");
+    if (gs.n_reads == 0) return VGAN_OK;
+    if (gs.device != f->device) return fail(VGAN_EINVAL, "vgan_hc_devflat_run_gamdev: the parse lives on another device");
+    if (gs.n_reads > 0x7FFFFFF0ull || (uint64_t)base + gs.n_reads > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "vgan_hc_devflat_run_gamdev: too many reads in one parse");
+    HIPCHK(hipSetDevice(f->device));
+    {
+        const hipStream_t now = hc_ctx_info(f->ctx).stream;
+        if (now != f->stream) {
+            if (f->stream) HIPCHK(hipStreamSynchronize(f->stream));
+            f->stream = now;
+        }
+    }
+    const uint32_t R_all = (uint32_t)gs.n_reads;
+    int rc;
+    if ((rc = df_prepare(f, R_all, 1))) return rc;
+    PhaseTimer pt("hc_devflat (device parse)");
+    const uint8_t *d_skip = nullptr;
+    if (skip && skip_on_device) {
+        d_skip = skip;
+    } else if (skip) {
+        if ((rc = f->stage.reserve(R_all))) return rc;
+        HIPCHK(hipMemcpyAsync(f->stage.p, skip, R_all, hipMemcpyHostToDevice, f->stream));
+        d_skip = f->stage.p;
+    }
+    std::vector<DfSlice> hs(1);
+    DfSlice &s = hs[0];
+    s.map_off = gs.map_off, s.qual_off = gs.qual_off, s.edit_off = gs.edit_off, s.e_seq_off = gs.e_seq_off, s.m_node = gs.m_node;
+    s.m_offset = gs.m_offset, s.mapq = gs.mapq, s.e_len = gs.e_len;
+    s.unmapped = gs.unmapped, s.m_rev = gs.m_rev, s.e_seq = gs.e_seq, s.qual = gs.qual, s.skip = d_skip;
+    s.n_reads = R_all, s.read0 = 0;
+    return df_run_slices(f, hs, R_all, base, out, host_mask, stats, pt);
 }

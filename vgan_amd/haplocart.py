@@ -501,9 +501,48 @@ class DeviceFlatten:
         N.check(N.lib().vgan_hc_devflat_run(self._h, parts._h, None if sk is None else sk.ctypes.data, C.byref(pk), mask.ctypes.data, C.byref(st)))
         return DeviceFlatten.Result(pk, mask[:parts.n_reads], st)
 
+    def run_gamdev(self, gd, skip=None, base=0):
+        """The same over the arrays a GamDevice.parse left on the device: nothing but the marks and the mask crosses the link."""
+        sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+        n = gd.sizes["reads"]
+        mask = np.zeros(max(n, 1), np.uint8)
+        pk, st = N.HcPackedView(), N.FlattenStats()
+        N.check(N.lib().vgan_hc_devflat_run_gamdev(self._h, gd._h, None if sk is None else sk.ctypes.data, 0, base, C.byref(pk), mask.ctypes.data, C.byref(st)))
+        return DeviceFlatten.Result(pk, mask[:n], st)
+
     def close(self):
         if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_hc_devflat_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class GamDevice:
+    """The GAM front end on the device (vgan_gamdev; csrc/gam_kernels.hip): a BGZF GAM file's bytes -> the parser's arrays in HBM, as
+    kernels (inflate, framing, protobuf wire walk).  parse() raises NativeError (VGAN_EIO) for input the device cannot take: the caller
+    then reads the file through AlnParts / GamStream."""
+
+    _NAMES = ("inflated_bytes", "messages", "reads", "mappings", "edits", "edit_seq_bytes", "quality_bytes")
+
+    def __init__(self, device=0):
+        self._h = N.vp()
+        N.check(N.lib().vgan_gamdev_create(device, None, C.byref(self._h)))
+        self.sizes, self.ms = {k: 0 for k in self._NAMES}, {}
+
+    def parse(self, data, keep_unmapped=False):
+        buf = np.frombuffer(data, np.uint8)
+        N.check(N.lib().vgan_gamdev_parse(self._h, buf.ctypes.data, len(data), int(keep_unmapped)))
+        sizes, ms = np.zeros(8, np.uint64), np.zeros(4)
+        N.check(N.lib().vgan_gamdev_sizes(self._h, sizes.ctypes.data, ms.ctypes.data))
+        self.sizes = dict(zip(self._NAMES, (int(x) for x in sizes[:7])))
+        self.ms = dict(zip(("upload", "inflate", "frame", "parse"), (float(x) for x in ms)))
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None) and N is not None:
+            N.lib().vgan_gamdev_free(self._h)
             self._h = None
 
     def __del__(self):
