@@ -384,6 +384,16 @@ int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, int keep_un
 /* sizes[8]: inflated bytes, messages, reads, mappings, edits, edit-sequence bytes, quality bytes, 0; ms[4]: upload, inflate, framing,
  * parsing (wall, synchronous) */
 int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double ms[4]);
+/* Duplicate marks of the last parse's reads on the device (src/rmdup.cpp's single-end rule, keep-first by the first mapping's (node
+ * id, offset): two stable radix sorts + a mark pass); vgan_gamdev_dup_marks: the device array (uint8 per read), for
+ * vgan_hc_devflat_run_gamdev(skip = it, skip_on_device = 1). */
+int vgan_gamdev_mark_duplicates(vgan_gamdev *g, int64_t *n_dup);
+const uint8_t *vgan_gamdev_dup_marks(const vgan_gamdev *g);
+/* The messages of the reads read_mask names (host, uint8 per read of the last parse: the device flatten's host_mask), gathered on the
+ * device; vgan_gamdev_picked copies them down (offsets [n_msgs + 1], bytes [n_bytes]); vgan_alnparts_from_messages parses them. */
+int vgan_gamdev_pick(vgan_gamdev *g, const uint8_t *read_mask, uint64_t *n_msgs, uint64_t *n_bytes);
+int vgan_gamdev_picked(const vgan_gamdev *g, uint64_t *offsets, uint8_t *bytes);
+int vgan_alnparts_from_messages(const uint8_t *bytes, const uint64_t *offsets, int64_t n, int keep_unmapped, vgan_alnparts **out);
 /* test aid: array `which` of the last parse copied to the host (the list is beside the definition, csrc/gam_kernels.hip) */
 int vgan_gamdev_download(const vgan_gamdev *g, int which, void *dst);
 /* (ABI 4) a1 on the device: reconstruct_graph_sequence (vgan_utils.h:6-79), the slicing of update_likelihood.cpp:28-45 and the

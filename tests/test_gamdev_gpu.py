@@ -232,3 +232,42 @@ def test_device_parse_feeds_the_device_flatten_like_the_host_parser(tmp_path):
         assert np.array_equal(g2[name], w2[name]), name
     df.close()
     gdev.close()
+
+
+def test_whole_chain_on_the_device_against_the_host_pipeline(tmp_path):
+    """What `vgan haplocart` does with a BGZF GAM when the front end runs on the device: parse, duplicate marks, flatten, segment
+    kernel -- and the reads the device flatten leaves (indels, soft clips) handed back as their messages, parsed and flattened on the
+    host.  Against the host pipeline on the same file: the same marks, the same reads on either side, the same final vector."""
+    g = hc.synth_graph(seed=25, genome_len=5000, n_nodes=3300, n_paths=120)
+    a = hc.synth_reads(g, 50000, seed=26, read_len=150, indel_rate=0.04, softclip_rate=0.04)
+    p = str(tmp_path / "x.gam")
+    a.write_gam(p)
+    data = open(p, "rb").read()
+    ctx = hc.HcContext(g)
+    df = hc.DeviceFlatten(ctx, g)
+    # ---- the host pipeline
+    parts = hc.AlnParts.read_gam(p)
+    dup = parts.mark_duplicates()
+    assert 0 < dup.sum() < parts.n_reads
+    hb = hc.HostBatch(g, parts, skip=dup, packed=True)
+    ctx.accumulate(hb)
+    want = ctx.finalize()
+    # ---- the device's
+    gd = hc.GamDevice().parse(data)
+    assert gd.mark_duplicates() == int(dup.sum())
+    res = df.run_gamdev(gd, device_marks=True)
+    want_dev = df.run(parts, skip=dup)
+    assert np.array_equal(np.array(res.host_mask), np.array(want_dev.host_mask))
+    ctx.reset()
+    ctx.accumulate(res)
+    n_left = int(np.array(res.host_mask).sum())
+    assert 0 < n_left < 0.2 * parts.n_reads
+    left = gd.picked_parts(res.host_mask)
+    assert left.n_reads == n_left
+    hb2 = hc.HostBatch(g, left, packed=True)
+    assert hb2.n_reads + res.n_reads == hb.n_reads
+    ctx.accumulate(hb2)
+    got = ctx.finalize()
+    assert np.max(np.abs(got - want) / np.abs(want)) < 1e-12
+    df.close()
+    gd.close()

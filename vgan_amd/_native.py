@@ -226,6 +226,11 @@ SYMBOLS = {
     "vgan_hc_reduce_why": (C.c_int, [C.c_char_p, C.c_int64]),
     "vgan_gamdev_inflate_bytes": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
     "vgan_hc_devflat_run_gamdev": (C.c_int, [vp, vp, vp, C.c_int, C.c_uint32, vp, vp, vp]),
+    "vgan_gamdev_mark_duplicates": (C.c_int, [vp, vp]),
+    "vgan_gamdev_dup_marks": (vp, [vp]),
+    "vgan_gamdev_pick": (C.c_int, [vp, vp, vp, vp]),
+    "vgan_gamdev_picked": (C.c_int, [vp, vp, vp]),
+    "vgan_alnparts_from_messages": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "vgan_gamdev_create": (C.c_int, [C.c_int, vp, vp]),
     "vgan_gamdev_free": (None, [vp]),
     "vgan_gamdev_parse": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),

@@ -712,6 +712,52 @@ __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict_
     o.first_offset[r] = fo;
 }
 
+// ------------------------------------------------------------------------------------------------------------------ duplicates
+// src/rmdup.cpp:20-41,68-110 (single-end): a read is a duplicate when an EARLIER read has the same (node id, offset) in its first
+// mapping.  Two stable radix sorts (by offset, then by node id) bring equal keys together in input order: every read of a run but
+// its first is a duplicate.
+__global__ __launch_bounds__(256) void gd_dup_keys_kernel(const int64_t *__restrict__ v, const uint32_t *__restrict__ perm, uint32_t n, uint64_t *__restrict__ key) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) key[i] = (uint64_t)v[perm ? perm[i] : i] ^ 0x8000000000000000ull; // (signed order, not that it matters: equal keys must meet)
+}
+__global__ __launch_bounds__(256) void gd_dup_mark_kernel(const uint32_t *__restrict__ perm, const int64_t *__restrict__ node, const int64_t *__restrict__ off,
+                                                          const uint32_t *__restrict__ map_off, uint32_t n, uint8_t *__restrict__ dup, uint32_t *__restrict__ n_dup) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = perm[i];
+    uint8_t d = 0;
+    if (i > 0 && map_off[r + 1] > map_off[r]) { // (a read without mappings is no duplicate and no earlier read to anyone)
+        const uint32_t q = perm[i - 1];
+        d = map_off[q + 1] > map_off[q] && node[q] == node[r] && off[q] == off[r] ? 1 : 0;
+        // (reads without mappings carry the key (-1, 0): they sort together, in front, and are skipped here)
+    }
+    dup[r] = d;
+    if (d) atomicAdd(n_dup, 1u);
+}
+
+// ------------------------------------------------------------------------------------------------------ messages back to the host
+// The messages of the reads a mask names, one after the other in a buffer of their own (the reads the device flatten leaves to the
+// host: their bytes go down, the host parses and flattens them as it always did).
+__global__ __launch_bounds__(256) void gd_pick_kernel(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ r_at, const uint8_t *__restrict__ read_mask,
+                                                      const uint32_t *__restrict__ msg_len, uint32_t n_msg, uint32_t *__restrict__ pick, uint32_t *__restrict__ bytes) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_msg) return;
+    const bool on = keep[i] && read_mask[r_at[i]];
+    pick[i] = on ? 1u : 0u;
+    bytes[i] = on ? msg_len[i] : 0u;
+}
+__global__ __launch_bounds__(256) void gd_gather_kernel(const uint8_t *__restrict__ u, const uint64_t *__restrict__ msg_off, const uint32_t *__restrict__ msg_len,
+                                                        const uint32_t *__restrict__ pick, const uint32_t *__restrict__ k_at, const uint32_t *__restrict__ b_at,
+                                                        uint32_t n_msg, uint8_t *__restrict__ out, uint64_t *__restrict__ out_off) {
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u; // a wave per message
+    if (wave >= n_msg || !pick[wave]) return;
+    const uint8_t *src = u + msg_off[wave];
+    uint8_t *dst = out + b_at[wave];
+    for (uint32_t k = lane; k < msg_len[wave]; k += 64u) dst[k] = src[k];
+    if (lane == 0) out_off[k_at[wave] + 1] = (uint64_t)b_at[wave] + msg_len[wave];
+    if (wave == 0 && lane == 0) out_off[0] = 0;
+}
+
 } // namespace gd
 } // namespace vgan
 
@@ -832,6 +878,10 @@ struct vgan_gamdev {
     GBuf<int32_t> m_offset, mapq, e_len;
     GBuf<uint8_t> unmapped, m_rev, e_seq, qual;
     GBuf<int64_t> first_node, first_offset;
+    GBuf<uint8_t> dup, picked_bytes;           // duplicate marks per read; the messages handed back to the host
+    GBuf<uint64_t> sort_key, sort_key2, picked_off;
+    GBuf<uint32_t> perm_a, perm_b, pick, pick_bytes, k_at, b_at;
+    uint64_t n_picked = 0, n_picked_bytes = 0;
     uint64_t n_inflated = 0, n_messages = 0, R = 0, M = 0, E = 0, S = 0, Q = 0;
     double ms_inflate = 0, ms_frame = 0, ms_parse = 0, ms_upload = 0;
     void release_all() {
@@ -843,6 +893,8 @@ struct vgan_gamdev {
         for (auto *b : {&m_offset, &mapq, &e_len}) b->release();
         for (auto *b : {&unmapped, &m_rev, &e_seq, &qual}) b->release();
         first_node.release(), first_offset.release();
+        dup.release(), picked_bytes.release(), sort_key.release(), sort_key2.release(), picked_off.release();
+        for (auto *b : {&perm_a, &perm_b, &pick, &pick_bytes, &k_at, &b_at}) b->release();
     }
 };
 
@@ -1063,4 +1115,99 @@ bool vgan::gamdev_slice(const vgan_gamdev *g, GamdevSlice *o) {
     *o = GamdevSlice{g->map_off.p, g->qual_off.p, g->edit_off.p, g->e_seq_off.p, g->m_node.p, g->m_offset.p, g->mapq.p, g->e_len.p, g->unmapped.p, g->m_rev.p,
                      g->e_seq.p, g->qual.p, g->first_node.p, g->first_offset.p, g->R, g->device};
     return true;
+}
+
+// Duplicate marks of the last parse's reads (keep-first by the first mapping's (node id, offset): src/rmdup.cpp), left on the device for
+// vgan_hc_devflat_run_gamdev (vgan_gamdev_dup_marks: the device pointer) and counted.
+extern "C" int vgan_gamdev_mark_duplicates(vgan_gamdev *g, int64_t *n_dup) {
+    if (!g) return fail(VGAN_EINVAL, "vgan_gamdev_mark_duplicates: null argument");
+    if (n_dup) *n_dup = 0;
+    if (g->R == 0) return VGAN_OK;
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    const uint32_t R = (uint32_t)g->R;
+    int rc;
+    if ((rc = g->dup.reserve(R)) || (rc = g->sort_key.reserve(R)) || (rc = g->sort_key2.reserve(R)) || (rc = g->perm_a.reserve(R)) || (rc = g->perm_b.reserve(R)) ||
+        (rc = g->bad.reserve(4)))
+        return rc;
+    // perm_a = 0, 1, 2, ... (an exclusive sum of ones)
+    {
+        size_t tmp = 0;
+        auto ones = hipcub::ConstantInputIterator<uint32_t>(1u);
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, ones, g->perm_a.p, (int)R, st) != hipSuccess) return fail(VGAN_ENODEV, "vgan_gamdev_mark_duplicates: scan sizing failed");
+        if ((rc = g->cub_tmp.reserve(tmp + 16))) return rc;
+        if (hipcub::DeviceScan::ExclusiveSum(g->cub_tmp.p, tmp, ones, g->perm_a.p, (int)R, st) != hipSuccess) return fail(VGAN_ENODEV, "vgan_gamdev_mark_duplicates: scan failed");
+    }
+    auto sort_by = [&](const int64_t *values, const uint32_t *perm_in, uint32_t *perm_out) -> int {
+        hipLaunchKernelGGL(gd_dup_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, st, values, perm_in, R, g->sort_key.p);
+        size_t tmp = 0;
+        if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, g->sort_key.p, g->sort_key2.p, perm_in, perm_out, (int)R, 0, 64, st) != hipSuccess)
+            return fail(VGAN_ENODEV, "vgan_gamdev_mark_duplicates: sort sizing failed");
+        int rc2;
+        if ((rc2 = g->cub_tmp.reserve(tmp + 16))) return rc2;
+        if (hipcub::DeviceRadixSort::SortPairs(g->cub_tmp.p, tmp, g->sort_key.p, g->sort_key2.p, perm_in, perm_out, (int)R, 0, 64, st) != hipSuccess)
+            return fail(VGAN_ENODEV, "vgan_gamdev_mark_duplicates: sort failed");
+        return VGAN_OK;
+    };
+    if ((rc = sort_by(g->first_offset.p, g->perm_a.p, g->perm_b.p)) || (rc = sort_by(g->first_node.p, g->perm_b.p, g->perm_a.p))) return rc;
+    HIPCHK(hipMemsetAsync(g->bad.p, 0, 4, st));
+    hipLaunchKernelGGL(gd_dup_mark_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g->perm_a.p, g->first_node.p, g->first_offset.p, g->map_off.p, R, g->dup.p, g->bad.p);
+    HIPCHK(hipGetLastError());
+    uint32_t nd = 0;
+    HIPCHK(hipMemcpyAsync(&nd, g->bad.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_dup) *n_dup = nd;
+    return VGAN_OK;
+}
+
+extern "C" const uint8_t *vgan_gamdev_dup_marks(const vgan_gamdev *g) { return g ? g->dup.p : nullptr; }
+
+// The messages of the reads read_mask names (host, per read of the last parse) are put one after the other on the device; sizes
+// come back here, the bytes and their offsets ([n + 1]) through vgan_gamdev_picked.
+extern "C" int vgan_gamdev_pick(vgan_gamdev *g, const uint8_t *read_mask, uint64_t *n_msgs, uint64_t *n_bytes) {
+    if (!g || !read_mask || !n_msgs || !n_bytes) return fail(VGAN_EINVAL, "vgan_gamdev_pick: null argument");
+    *n_msgs = *n_bytes = 0;
+    g->n_picked = g->n_picked_bytes = 0;
+    if (g->R == 0 || g->n_messages == 0) return VGAN_OK;
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    const uint32_t NM = (uint32_t)g->n_messages;
+    int rc;
+    if ((rc = g->picked_bytes.reserve(g->R)) || (rc = g->pick.reserve(NM)) || (rc = g->pick_bytes.reserve(NM)) || (rc = g->k_at.reserve(NM)) || (rc = g->b_at.reserve(NM)))
+        return rc;
+    uint8_t *d_mask = g->picked_bytes.p; // (borrowed for the mask until the bytes' size is known)
+    HIPCHK(hipMemcpyAsync(d_mask, read_mask, g->R, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gd_pick_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, g->keep.p, g->r_at.p, d_mask, g->msg_len.p, NM, g->pick.p, g->pick_bytes.p);
+    if ((rc = exclusive_sum(g, g->pick.p, g->k_at.p, NM)) || (rc = exclusive_sum(g, g->pick_bytes.p, g->b_at.p, NM))) return rc;
+    uint32_t last[4];
+    HIPCHK(hipMemcpyAsync(&last[0], g->pick.p + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[1], g->k_at.p + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[2], g->pick_bytes.p + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[3], g->b_at.p + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    g->n_picked = (uint64_t)last[0] + last[1];
+    g->n_picked_bytes = (uint64_t)last[2] + last[3];
+    *n_msgs = g->n_picked;
+    *n_bytes = g->n_picked_bytes;
+    if (g->n_picked == 0) return VGAN_OK;
+    // (the mask's buffer is read by nothing any more: the pick flags hold what it said)
+    if ((rc = g->picked_off.reserve(g->n_picked + 1))) return rc;
+    if ((rc = g->picked_bytes.reserve(std::max<uint64_t>(g->n_picked_bytes, g->R)))) return rc;
+    hipLaunchKernelGGL(gd_gather_kernel, dim3((uint32_t)(((uint64_t)NM * 64 + 255) / 256)), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, g->pick.p, g->k_at.p,
+                       g->b_at.p, NM, g->picked_bytes.p, g->picked_off.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return VGAN_OK;
+}
+
+extern "C" int vgan_gamdev_picked(const vgan_gamdev *g, uint64_t *offsets, uint8_t *bytes) {
+    if (!g || !offsets || !bytes) return fail(VGAN_EINVAL, "vgan_gamdev_picked: null argument");
+    if (g->n_picked == 0) {
+        offsets[0] = 0;
+        return VGAN_OK;
+    }
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipMemcpy(offsets, g->picked_off.p, (g->n_picked + 1) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(bytes, g->picked_bytes.p, g->n_picked_bytes, hipMemcpyDeviceToHost));
+    return VGAN_OK;
 }

@@ -1239,6 +1239,26 @@ extern "C" int vgan_aln_view_get(const vgan_alnset *a, vgan_alnset_view *out) {
 
 extern "C" void vgan_aln_free(vgan_alnset *a) { delete a; }
 
+// Alignment messages lying one after the other in memory (message k = bytes[offsets[k], offsets[k + 1]): what the GAM front end on
+// the device hands back for the reads its flatten leaves to the host, csrc/gam_kernels.hip) -> a sliced set of one slice, parsed by
+// the parser every other input goes through.
+extern "C" int vgan_alnparts_from_messages(const uint8_t *bytes, const uint64_t *offsets, int64_t n, int keep_unmapped, vgan_alnparts **out) {
+    if (!out || n < 0 || (n > 0 && (!bytes || !offsets))) return fail(VGAN_EINVAL, "vgan_alnparts_from_messages: null argument");
+    auto ps = new vgan_alnparts();
+    ps->parts.emplace_back();
+    vgan_alnset &a = ps->parts.back();
+    if (n) reserve_for(a, (size_t)(offsets[n] - offsets[0]), (size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        if (offsets[k + 1] < offsets[k] || !parse_alignment(Cur{bytes + offsets[k], bytes + offsets[k + 1], true}, a, keep_unmapped)) {
+            delete ps;
+            return fail(VGAN_EIO, "vgan_alnparts_from_messages: message %lld is malformed", (long long)k);
+        }
+    }
+    ps->index();
+    *out = ps;
+    return VGAN_OK;
+}
+
 // Duplicate marking with the reference's single-end semantics (src/rmdup.cpp:20-41,68-110): a read is a
 // duplicate when an EARLIER read of the set has the same (node id, offset) in its first mapping -- strand is not
 // compared.  The reference does this in O(n^2); a hash of first-seen keys gives the same marks in O(n).

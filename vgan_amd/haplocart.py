@@ -501,13 +501,17 @@ class DeviceFlatten:
         N.check(N.lib().vgan_hc_devflat_run(self._h, parts._h, None if sk is None else sk.ctypes.data, C.byref(pk), mask.ctypes.data, C.byref(st)))
         return DeviceFlatten.Result(pk, mask[:parts.n_reads], st)
 
-    def run_gamdev(self, gd, skip=None, base=0):
-        """The same over the arrays a GamDevice.parse left on the device: nothing but the marks and the mask crosses the link."""
+    def run_gamdev(self, gd, skip=None, base=0, device_marks=False):
+        """The same over the arrays a GamDevice.parse left on the device: nothing but the marks and the mask crosses the link
+        (device_marks: the marks GamDevice.mark_duplicates left on the device)."""
         sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
         n = gd.sizes["reads"]
         mask = np.zeros(max(n, 1), np.uint8)
         pk, st = N.HcPackedView(), N.FlattenStats()
-        N.check(N.lib().vgan_hc_devflat_run_gamdev(self._h, gd._h, None if sk is None else sk.ctypes.data, 0, base, C.byref(pk), mask.ctypes.data, C.byref(st)))
+        skp, on_dev = (None if sk is None else sk.ctypes.data), 0
+        if device_marks:
+            skp, on_dev = N.lib().vgan_gamdev_dup_marks(gd._h), 1
+        N.check(N.lib().vgan_hc_devflat_run_gamdev(self._h, gd._h, skp, on_dev, base, C.byref(pk), mask.ctypes.data, C.byref(st)))
         return DeviceFlatten.Result(pk, mask[:n], st)
 
     def close(self):
@@ -539,6 +543,24 @@ class GamDevice:
         self.sizes = dict(zip(self._NAMES, (int(x) for x in sizes[:7])))
         self.ms = dict(zip(("upload", "inflate", "frame", "parse"), (float(x) for x in ms)))
         return self
+
+    def mark_duplicates(self):
+        """src/rmdup.cpp's marks of the parse's reads, left on the device; returns their number."""
+        nd = C.c_int64(0)
+        N.check(N.lib().vgan_gamdev_mark_duplicates(self._h, C.byref(nd)))
+        return int(nd.value)
+
+    def picked_parts(self, read_mask, keep_unmapped=False):
+        """The reads read_mask names (the device flatten's host_mask), parsed on the host from their messages: an AlnParts of one slice."""
+        m = np.ascontiguousarray(read_mask, np.uint8)
+        assert len(m) == self.sizes["reads"]
+        nm, nb = C.c_uint64(0), C.c_uint64(0)
+        N.check(N.lib().vgan_gamdev_pick(self._h, m.ctypes.data, C.byref(nm), C.byref(nb)))
+        offs, byts = np.zeros(int(nm.value) + 1, np.uint64), np.zeros(max(int(nb.value), 1), np.uint8)
+        N.check(N.lib().vgan_gamdev_picked(self._h, offs.ctypes.data, byts.ctypes.data))
+        h = N.vp()
+        N.check(N.lib().vgan_alnparts_from_messages(byts.ctypes.data, offs.ctypes.data, int(nm.value), int(keep_unmapped), C.byref(h)))
+        return AlnParts(h)
 
     def close(self):
         if getattr(self, "_h", None) and N is not None:
