@@ -671,7 +671,10 @@ def test_cli_chunk_loop_lanes_and_small_batches_give_the_same_log_likelihoods(tm
     for tag, env in (("one", {"VGAN_HC_LANES": "1", "VGAN_HC_BATCH": "1000000", "VGAN_HC_HOST_FLATTEN": "1"}),
                      ("lanes", {"VGAN_HC_LANES": "3", "VGAN_HC_BATCH": "1024", "VGAN_HC_QUEUE": "3", "VGAN_GAM_SEG_BLOCKS": "4", "VGAN_HC_HOST_FLATTEN": "1"}),
                      ("device", {"VGAN_HC_BATCH": "1000000", "VGAN_HC_DEVICE_AFTER": "0"}),
-                     ("device_small", {"VGAN_HC_BATCH": "1024", "VGAN_HC_QUEUE": "3", "VGAN_GAM_SEG_BLOCKS": "4", "VGAN_TIMING": "1", "VGAN_HC_DEVICE_AFTER": "2"})):
+                     ("device_small", {"VGAN_HC_BATCH": "1024", "VGAN_HC_QUEUE": "3", "VGAN_GAM_SEG_BLOCKS": "4", "VGAN_TIMING": "1", "VGAN_HC_DEVICE_AFTER": "2"}),
+                     # the whole front end on the device (csrc/gam_kernels.hip: inflate, framing, protobuf walk, duplicate marks, flatten);
+                     # the reads its flatten leaves come back as messages and take the host's parser and flatten
+                     ("device_gam", {"VGAN_HC_DEVICE_GAM": "1", "VGAN_TIMING": "1"})):
         out = str(tmp_path / (tag + ".tsv"))
         r = subprocess.run([os.path.join(root, "vgan_amd", "bin", "vgan"), "haplocart", "-g", str(tmp_path / "r.gam"), "--hc-files",
                             str(tmp_path), "-q", "-np", "-d", "-o", out, "-s", "s", "-t", "6"],
@@ -681,9 +684,12 @@ def test_cli_chunk_loop_lanes_and_small_batches_give_the_same_log_likelihoods(tm
             line = [ln for ln in r.stderr.splitlines() if "device flatten" in ln][0]
             n_host = int(line.split("host flatten of the ")[1].split()[0])
             assert 0 < n_host < 30000, line
+        if tag == "device_gam":
+            line = [ln for ln in r.stderr.splitlines() if "device front end" in ln]
+            assert line and "30000 messages" in line[0] and 0 < int(line[0].split(", the ")[1].split()[0]) < 30000, r.stderr[-1500:]
         ll = dict((ln.split("\t")[0], float(ln.split("\t")[1])) for ln in open(out + ".loglik.tsv").read().splitlines())
         res[tag] = (open(out).read().splitlines()[1], ll)
-    for other in ("lanes", "device", "device_small"):
+    for other in ("lanes", "device", "device_small", "device_gam"):
         assert res["one"][0] == res[other][0]  # sample, predicted haplogroup, reads kept
         assert res["one"][1].keys() == res[other][1].keys() and len(res["one"][1]) == 60
         for k, v in res["one"][1].items():

@@ -9,6 +9,11 @@
 //     and pass the sorted GAM with -g (for a consensus FASTA mapped that way add -f NAME to get the reference's
 //     consensus arithmetic);
 //   * the likelihood loop runs on the GPU through the C-ABI (include/vgan_gpu.h); -t only sizes the host front end.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
@@ -150,7 +155,39 @@ int haplocart(int argc, char **argv) {
         vgan_gam_stream *s = nullptr;
         ~StreamCloser() { vgan_gam_stream_close(s); }
     } stream;
-    check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
+    // A long BGZF input on one GPU: the front end runs ON THE DEVICE (vgan_gamdev: inflate, framing, protobuf walk, duplicate marks and
+    // flatten as kernels; csrc/gam_kernels.hip) -- the file's bytes go up as they are and the host parses only the reads the device
+    // flatten leaves (indels, soft clips: a percent or two).  The host pipeline costs ~3 us of CPU per read, which on a CPU quota
+    // is what a long input's wall time follows.  VGAN_HC_DEVICE_GAM=0 / 1: never / whenever the input is a regular file;
+    // anything the device refuses (not BGZF, a stream its segment walks cannot frame, no memory) goes through the host pipeline.
+    struct FileMap {
+        const uint8_t *p = nullptr;
+        size_t n = 0;
+        ~FileMap() {
+            if (p) munmap(const_cast<uint8_t *>(p), n);
+        }
+    } gam_map;
+    bool device_gam = false;
+    {
+        const char *e = getenv("VGAN_HC_DEVICE_GAM");
+        struct stat sb;
+        const bool one_gpu = gpu_spec.empty() && !getenv("VGAN_GPUS");
+        if (!(e && e[0] == '0') && one_gpu && !per_read && fastafilename.empty() && stat(gamfilename.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) &&
+            ((e && e[0] == '1') || (uint64_t)sb.st_size >= (128ull << 20)) && sb.st_size > 28) {
+            const int fd = open(gamfilename.c_str(), O_RDONLY);
+            if (fd >= 0) {
+                void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                close(fd);
+                if (m != MAP_FAILED) {
+                    gam_map.p = (const uint8_t *)m;
+                    gam_map.n = (size_t)sb.st_size;
+                    device_gam = gam_map.p[0] == 0x1f && gam_map.p[1] == 0x8b && gam_map.p[2] == 8 && (gam_map.p[3] & 4); // (BGZF members carry an extra field)
+                    if (device_gam) (void)madvise(m, gam_map.n, MADV_WILLNEED);
+                }
+            }
+        }
+    }
+    if (!device_gam) check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
     // -j -jf FILE: every alignment of the GAM as a line of JSON (readGAM.h:37-38 writes them while it reads; here a pass of
     // its own, on a thread beside the run).  The reference opens -jf FILE even without -j (and leaves it empty).
     struct JsonDump {
@@ -433,6 +470,79 @@ int haplocart(int argc, char **argv) {
             uploader.cv.notify_all();
         }
     });
+    if (device_gam) {
+        contexts_ready();
+        vgan_hc_ctx *cx = ctxs.v[0];
+        struct GdCloser {
+            vgan_gamdev *g = nullptr;
+            ~GdCloser() { vgan_gamdev_free(g); }
+        } gd;
+        auto t0 = std::chrono::steady_clock::now();
+        std::string why;
+        if (vgan_gamdev_create(gpu_list[0], nullptr, &gd.g) < 0 || vgan_gamdev_parse(gd.g, gam_map.p, gam_map.n, 0) < 0) why = vgan_last_error();
+        if (!why.empty()) {
+            if (getenv("VGAN_TIMING")) fprintf(stderr, "[vgan timing] haplocart: the device front end does not take this input (%s): the host pipeline does\n", why.c_str());
+            device_gam = false;
+            check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
+        } else {
+            uint64_t sz[8];
+            double ms[4];
+            (void)vgan_gamdev_sizes(gd.g, sz, ms);
+            const double t_parse = since_ms(t0);
+            stamp("GAM inflated, framed and parsed on the device");
+            n_in = (int64_t)sz[2];
+            const uint8_t *d_dup = nullptr;
+            t0 = std::chrono::steady_clock::now();
+            if (rmdup && n_in) {
+                int64_t nd = 0;
+                check(vgan_gamdev_mark_duplicates(gd.g, &nd), "duplicate removal");
+                n_dup = nd;
+                d_dup = vgan_gamdev_dup_marks(gd.g);
+            }
+            const double t_dup = since_ms(t0);
+            double t_df = 0, t_host = 0;
+            if (n_in) {
+                t0 = std::chrono::steady_clock::now();
+                devflats.v.resize(1, nullptr);
+                check(vgan_hc_devflat_create(cx, graph, &devflats.v[0]), "device flatten");
+                std::vector<uint8_t> mask((size_t)n_in, 0);
+                vgan_hc_packed_view pk;
+                vgan_hc_flatten_stats st{}, sh{};
+                check(vgan_hc_devflat_run_gamdev(devflats.v[0], gd.g, d_dup, 1, 0, &pk, mask.data(), &st), "device flatten");
+                check(vgan_hc_accumulate_packed(cx, &pk), "accumulate");
+                t_df = since_ms(t0);
+                stamp("packed batch flattened on the device and handed to the segment kernel");
+                int64_t n_host = 0;
+                for (uint8_t m : mask) n_host += m;
+                if (n_host) { // the reads the device flatten left: their messages come down, the host parses and flattens them
+                    t0 = std::chrono::steady_clock::now();
+                    uint64_t nm = 0, nb = 0;
+                    check(vgan_gamdev_pick(gd.g, mask.data(), &nm, &nb), "reads left to the host");
+                    std::vector<uint64_t> offs((size_t)nm + 1);
+                    std::vector<uint8_t> bytes((size_t)std::max<uint64_t>(nb, 1));
+                    check(vgan_gamdev_picked(gd.g, offs.data(), bytes.data()), "reads left to the host");
+                    vgan_alnparts *left = nullptr;
+                    check(vgan_alnparts_from_messages(bytes.data(), offs.data(), (int64_t)nm, 0, &left), "reads left to the host");
+                    vgan_hc_host_batch *hb = nullptr;
+                    const int rc = vgan_hc_flatten_parts_packed(graph, left, 0, vgan_alnparts_count(left), nullptr, 0, &hb, &sh);
+                    vgan_alnparts_free(left);
+                    check(rc, "flattening");
+                    const std::string err = hand_over(cx, hb);
+                    vgan_hc_host_batch_free(hb);
+                    if (!err.empty()) die(err);
+                    t_host = since_ms(t0);
+                }
+                tot.n_bad += sh.n_bad;
+                tot.n_unmapped += st.n_unmapped;
+                tot.n_out += st.n_out + sh.n_out;
+                n_host_reads = n_host;
+            }
+            if (getenv("VGAN_TIMING"))
+                fprintf(stderr, "[vgan timing] haplocart device front end: %.1f MB -> %.1f MB, %lld messages, %lld reads; parse %.0f ms (upload %.0f, inflate %.0f, framing %.0f, "
+                                "protobuf walk %.0f), duplicate marks %.0f ms, device flatten + hand-over %.0f ms, the %lld reads left to the host %.0f ms\n",
+                        gam_map.n / 1e6, sz[0] / 1e6, (long long)sz[1], (long long)sz[2], t_parse, ms[0], ms[1], ms[2], ms[3], t_dup, t_df, (long long)n_host_reads, t_host);
+        }
+    }
     // The loop: next chunk of decoded reads -> duplicate marks -> (host flatten ->) device queue.  Taking a chunk and marking
     // its duplicates is serial (input order); with the host flatten the flattening of several chunks runs side by side on `lanes`
     // threads (each call spreads over its own share of the host threads), and the queue takes the batches back in input order.
@@ -521,7 +631,7 @@ int haplocart(int argc, char **argv) {
             at_end = true;
         }
     };
-    {
+    if (!device_gam) {
         std::vector<std::thread> lane_threads_v;
         for (int l = 1; l < lanes; ++l) lane_threads_v.emplace_back(lane);
         lane();
