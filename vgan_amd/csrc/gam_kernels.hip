@@ -170,13 +170,23 @@ __device__ const uint8_t gd_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 
 // the lane's own earlier output, read past the vector L1 (a line the lane loaded before it stored into it may sit there)
 __device__ __forceinline__ uint8_t out_byte(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(64) void gd_inflate_kernel(const uint8_t *__restrict__ in, const GdBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                        uint8_t *out, uint32_t *__restrict__ status) {
+#ifndef GD_INFLATE_LDS
+#define GD_INFLATE_LDS 0 // the lane's symbol tables in LDS (41 KB per wave: three waves to a CU) or in its private memory (as many waves as
+#endif                   // the registers allow: a block takes ~80 ms either way, so the waves in flight set the rate -- measured on a 10 M-read file)
+__global__ __launch_bounds__(64, 4) void gd_inflate_kernel(const uint8_t *__restrict__ in, const GdBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                           uint8_t *out, uint32_t *__restrict__ status) {
+#if GD_INFLATE_LDS
     __shared__ uint16_t sym_s[64][INF_ROW];
+#endif
     const uint32_t lane = threadIdx.x, b = blockIdx.x * 64u + lane;
     if (b >= n_blocks) return;
     const GdBlock bl = blocks[b];
+#if GD_INFLATE_LDS
     uint16_t *lsym = sym_s[lane], *dsym = lsym + INF_LIT;
+#else
+    uint16_t sym_p[INF_ROW];
+    uint16_t *lsym = sym_p, *dsym = lsym + INF_LIT;
+#endif
     uint8_t *o = out + bl.out_off;
     const uint32_t o_cap = bl.out_size;
     uint32_t pos = 0, err = GD_OK;

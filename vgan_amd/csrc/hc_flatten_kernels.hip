@@ -80,8 +80,10 @@ __device__ __forceinline__ uint8_t df_comp(uint8_t c) { // csrc/host/flatten.cpp
 __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph g, uint8_t *__restrict__ flag, uint32_t *__restrict__ key,
                                                              uint4 *__restrict__ info, DfCounters *__restrict__ ctr) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (r >= s.n_reads) return;
+    // (a wave takes many reads and sends its counts once: an atomic per read on the same few words serialises the whole launch --
+    // 10 M reads x 6 atomics at ~12 ns were 0.69 of the 0.8 s a 10 M-read file's flatten took)
+    uint32_t c_in = 0, c_unm = 0, c_dev = 0, c_clamped = 0, mx_segs = 0, mx_qual = 0, mx_cols = 0, mx_span = 0;
+    for (uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6); r < s.n_reads; r += gridDim.x * 4u) {
     const uint32_t gr = s.read0 + r;
     uint8_t f = DF_HOST;
     uint32_t A = 0, G = 0, kmin = 0xFFFFFFFFu, kmax = 0u, nm = 0, nq = 0;
@@ -201,22 +203,35 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
             G = g_len;
         }
     }
-    if (lane != 0) return;
-    flag[gr] = f;
-    // (csrc/host/flatten.cpp: sort_key() -- the reads of mapping quality VGAN_HC_MAPQ_MAJOR first, the others behind them)
-    key[gr] = f == DF_DEVICE ? (min(kmin, 0x3FFFFFFFu) | (s.mapq[r] == VGAN_HC_MAPQ_MAJOR ? 0u : 0x40000000u)) : 0xFFFFFFFFu;
-    info[gr] = uint4{G, nm, nq, A};
-    if (f != DF_SKIP) atomicAdd(&ctr->n_in, 1u);
-    if (f == DF_UNMAPPED) atomicAdd(&ctr->n_unmapped, 1u);
-    if (f == DF_DEVICE) {
-        atomicAdd(&ctr->n_dev, 1u);
-        atomicMax(&ctr->max_segs, nm);
-        atomicMax(&ctr->max_qual, nq);
-        atomicMax(&ctr->max_cols, A);
-        atomicMax(&ctr->max_span, kmax - kmin);
-        const int32_t mq = s.mapq[r];
-        if (mq < 0 || mq > 99) atomicAdd(&ctr->n_clamped, 1u);
+    if (lane == 0) {
+        flag[gr] = f;
+        // (csrc/host/flatten.cpp: sort_key() -- the reads of mapping quality VGAN_HC_MAPQ_MAJOR first, the others behind them)
+        key[gr] = f == DF_DEVICE ? (min(kmin, 0x3FFFFFFFu) | (s.mapq[r] == VGAN_HC_MAPQ_MAJOR ? 0u : 0x40000000u)) : 0xFFFFFFFFu;
+        info[gr] = uint4{G, nm, nq, A};
+        c_in += f != DF_SKIP ? 1u : 0u;
+        c_unm += f == DF_UNMAPPED ? 1u : 0u;
+        if (f == DF_DEVICE) {
+            c_dev += 1u;
+            mx_segs = max(mx_segs, nm);
+            mx_qual = max(mx_qual, nq);
+            mx_cols = max(mx_cols, A);
+            mx_span = max(mx_span, kmax - kmin);
+            const int32_t mq = s.mapq[r];
+            c_clamped += mq < 0 || mq > 99 ? 1u : 0u;
+        }
     }
+    } // (the wave's next read)
+    if (lane != 0) return;
+    if (c_in) atomicAdd(&ctr->n_in, c_in);
+    if (c_unm) atomicAdd(&ctr->n_unmapped, c_unm);
+    if (c_dev) {
+        atomicAdd(&ctr->n_dev, c_dev);
+        atomicMax(&ctr->max_segs, mx_segs);
+        atomicMax(&ctr->max_qual, mx_qual);
+        atomicMax(&ctr->max_cols, mx_cols);
+        atomicMax(&ctr->max_span, mx_span);
+    }
+    if (c_clamped) atomicAdd(&ctr->n_clamped, c_clamped);
 }
 
 // sizes of the taken reads in sorted order (the sort's values are chunk read indices; taken reads come first)
@@ -645,7 +660,8 @@ static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uin
     int rc;
     for (size_t i = 0; i < np; ++i)
         if (hs[i].n_reads)
-            hipLaunchKernelGGL(hc_df_classify_kernel, dim3((hs[i].n_reads + 3) / 4), dim3(256), 0, st, hs[i], f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
+            hipLaunchKernelGGL(hc_df_classify_kernel, dim3(std::min<uint32_t>((hs[i].n_reads + 3) / 4, 8192u)), dim3(256), 0, st, hs[i], f->g, f->flag.p, f->key.p,
+                               f->info.p, f->ctr.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(f->slices.p, hs.data(), np * sizeof(DfSlice), hipMemcpyHostToDevice, st));
     // ---- the taken reads in ascending order of their lowest node id, input order kept among equals (the others' key is 2^32 - 1)
