@@ -388,12 +388,17 @@ int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double ms[4]);
  * id, offset): two stable radix sorts + a mark pass); vgan_gamdev_dup_marks: the device array (uint8 per read), for
  * vgan_hc_devflat_run_gamdev(skip = it, skip_on_device = 1). */
 int vgan_gamdev_mark_duplicates(vgan_gamdev *g, int64_t *n_dup);
+/* vgan_gamdev_create + vgan_gamdev_parse in one call, the host's walk over the BGZF member headers made BEFORE the first HIP call: a
+ * thread that calls this while another thread brings the HIP runtime up (~0.25 s in a fresh process) has the index ready when the
+ * runtime is.  *out is null on failure. */
+int vgan_gamdev_open(int device, void *hip_stream, const void *bytes, uint64_t n, int keep_unmapped, vgan_gamdev **out);
 const uint8_t *vgan_gamdev_dup_marks(const vgan_gamdev *g);
 /* The messages of the reads read_mask names (host, uint8 per read of the last parse: the device flatten's host_mask), gathered on the
- * device; vgan_gamdev_picked copies them down (offsets [n_msgs + 1], bytes [n_bytes]); vgan_alnparts_from_messages parses them. */
+ * device; vgan_gamdev_picked copies them down (offsets [n_msgs + 1], bytes [n_bytes]); vgan_alnparts_from_messages parses them
+ * (slices of them on n_threads threads; <= 0: all hardware threads). */
 int vgan_gamdev_pick(vgan_gamdev *g, const uint8_t *read_mask, uint64_t *n_msgs, uint64_t *n_bytes);
 int vgan_gamdev_picked(const vgan_gamdev *g, uint64_t *offsets, uint8_t *bytes);
-int vgan_alnparts_from_messages(const uint8_t *bytes, const uint64_t *offsets, int64_t n, int keep_unmapped, vgan_alnparts **out);
+int vgan_alnparts_from_messages(const uint8_t *bytes, const uint64_t *offsets, int64_t n, int keep_unmapped, int n_threads, vgan_alnparts **out);
 /* test aid: array `which` of the last parse copied to the host (the list is beside the definition, csrc/gam_kernels.hip) */
 int vgan_gamdev_download(const vgan_gamdev *g, int which, void *dst);
 /* (ABI 4) a1 on the device: reconstruct_graph_sequence (vgan_utils.h:6-79), the slicing of update_likelihood.cpp:28-45 and the

@@ -186,6 +186,31 @@ def test_device_front_end_on_synthetic_files(tmp_path):
     gd.close()
 
 
+def test_open_is_create_plus_parse_and_the_pieces_of_the_upload_do_not_show(tmp_path, monkeypatch):
+    """vgan_gamdev_open (member index before the first HIP call) against vgan_gamdev_parse; the file sent up in pieces of 100 kB (each
+    piece's members inflated while the next is copied) against one piece."""
+    g = hc.synth_graph(seed=5, genome_len=3000, n_nodes=2000, n_paths=50)
+    a = hc.synth_reads(g, 20000, seed=77, read_len=150, indel_rate=0.05)
+    p = str(tmp_path / "s.gam")
+    a.write_gam(p)
+    data = open(p, "rb").read()
+    gd = GamDev()
+    n = check_against_host(gd, data, False)
+    want = {w: gd.array(w) for w in range(17)}
+    gd.close()
+    monkeypatch.setenv("VGAN_GAMDEV_PIECE", "100000")
+    o = hc.GamDevice.open(data)
+    assert o.sizes["reads"] == n
+    g2 = GamDev()
+    g2.parse(data)
+    for w, v in want.items():
+        assert np.array_equal(g2.array(w), v), w
+    g2.close()
+    o.close()
+    with pytest.raises(N.NativeError):
+        hc.GamDevice.open(b"not a BGZF stream at all, not even close")
+
+
 def test_an_empty_file_and_a_stream_without_tags(tmp_path):
     import gamio
     gd = GamDev()

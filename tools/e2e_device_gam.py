@@ -41,6 +41,8 @@ for tag, env in (("host", {"VGAN_HC_DEVICE_GAM": "0"}), ("device", {"VGAN_HC_DEV
     for ln in r.stderr.splitlines():
         if "device front end" in ln or "does not take" in ln or "hc_devflat" in ln or ("haplocart @" in ln and ("parsed on the device" in ln or "contexts ready" in ln or "handed to the segment" in ln)):
             print("   ", ln[:400])
+    if tag == "device2" and os.environ.get("E2E_FULL"):
+        print(r.stderr[-6000:])
     if r.returncode:
         print(r.stderr[-1500:])
     outs[tag] = open(d + "/" + tag + ".tsv").read().splitlines()[-1] if os.path.exists(d + "/" + tag + ".tsv") else None

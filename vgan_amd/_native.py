@@ -230,10 +230,11 @@ SYMBOLS = {
     "vgan_gamdev_dup_marks": (vp, [vp]),
     "vgan_gamdev_pick": (C.c_int, [vp, vp, vp, vp]),
     "vgan_gamdev_picked": (C.c_int, [vp, vp, vp]),
-    "vgan_alnparts_from_messages": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
+    "vgan_alnparts_from_messages": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "vgan_gamdev_create": (C.c_int, [C.c_int, vp, vp]),
     "vgan_gamdev_free": (None, [vp]),
     "vgan_gamdev_parse": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
+    "vgan_gamdev_open": (C.c_int, [C.c_int, vp, vp, C.c_uint64, C.c_int, vp]),
     "vgan_gamdev_sizes": (C.c_int, [vp, vp, vp]),
     "vgan_gamdev_download": (C.c_int, [vp, C.c_int, vp]),
     "vgan_hc_pack": (C.c_int, [vp, C.POINTER(HcBatch), C.POINTER(vp)]),

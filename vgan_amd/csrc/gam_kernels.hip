@@ -875,6 +875,8 @@ template <class T> struct GBuf {
 };
 } // namespace
 
+static constexpr int GD_PIECES = 4;
+
 struct vgan_gamdev {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -891,6 +893,7 @@ struct vgan_gamdev {
     GBuf<uint8_t> dup, picked_bytes;           // duplicate marks per read; the messages handed back to the host
     GBuf<uint64_t> sort_key, sort_key2, picked_off;
     GBuf<uint32_t> perm_a, perm_b, pick, pick_bytes, k_at, b_at;
+    hipStream_t piece_stream[GD_PIECES] = {}; // vgan_gamdev_parse: the file's pieces, each copied and inflated on a stream of its own
     uint64_t n_picked = 0, n_picked_bytes = 0;
     uint64_t n_inflated = 0, n_messages = 0, R = 0, M = 0, E = 0, S = 0, Q = 0;
     double ms_inflate = 0, ms_frame = 0, ms_parse = 0, ms_upload = 0;
@@ -934,6 +937,8 @@ extern "C" void vgan_gamdev_free(vgan_gamdev *g) {
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     g->release_all();
+    for (hipStream_t ps : g->piece_stream)
+        if (ps) (void)hipStreamDestroy(ps);
     if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
@@ -950,36 +955,97 @@ int exclusive_sum(vgan_gamdev *g, const uint32_t *in, uint32_t *out, size_t n) {
 double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 } // namespace
 
-// A BGZF GAM file's bytes -> the parser's arrays on the device (what vgan_gam_stream + the narrowing of vgan_hc_devflat_run make of the
-// same file on the host).  VGAN_EIO: not BGZF, a member that does not inflate, a stream the segment walks cannot frame consistently
-// (the caller takes the host pipeline), a malformed message.
-extern "C" int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, int keep_unmapped) {
-    if (!g || (!bytes && n)) return fail(VGAN_EINVAL, "vgan_gamdev_parse: null argument");
-    HIPCHK(hipSetDevice(g->device));
-    hipStream_t st = g->stream;
-    g->n_inflated = g->n_messages = g->R = g->M = g->E = g->S = g->Q = 0;
+namespace {
+// the host's share of a parse: where the BGZF members lie (no HIP call: vgan_gamdev_open makes it while another thread brings the runtime up)
+bool gd_index(const void *bytes, uint64_t n, std::vector<GdBlock> &gb, uint64_t &total) {
     std::vector<BgzfBlock> blocks;
-    if (!bgzf_index((const unsigned char *)bytes, (size_t)n, blocks)) return fail(VGAN_EIO, "vgan_gamdev_parse: not a BGZF stream");
-    std::vector<GdBlock> gb;
-    uint64_t total = 0;
+    if (!bgzf_index((const unsigned char *)bytes, (size_t)n, blocks)) return false;
+    gb.clear();
+    gb.reserve(blocks.size());
     for (const BgzfBlock &b : blocks) {
         const unsigned char *p = (const unsigned char *)bytes + b.in_off;
         const size_t xlen = p[10] | (p[11] << 8), hdr = 12 + xlen;
         if (b.out_size == 0) continue; // (the end-of-file member, empty members: nothing to write)
         gb.push_back(GdBlock{(uint64_t)(b.in_off + hdr), (uint64_t)b.out_off, (uint32_t)(b.in_size - hdr - 8), (uint32_t)b.out_size});
-        total = b.out_off + b.out_size;
     }
-    if (!blocks.empty()) total = blocks.back().out_off + blocks.back().out_size;
+    total = blocks.empty() ? 0 : blocks.back().out_off + blocks.back().out_size;
+    return true;
+}
+int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::vector<GdBlock> &gb, uint64_t total, int keep_unmapped);
+} // namespace
+
+// A BGZF GAM file's bytes -> the parser's arrays on the device (what vgan_gam_stream + the narrowing of vgan_hc_devflat_run make of the
+// same file on the host).  VGAN_EIO: not BGZF, a member that does not inflate, a stream the segment walks cannot frame consistently
+// (the caller takes the host pipeline), a malformed message.
+extern "C" int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, int keep_unmapped) {
+    if (!g || (!bytes && n)) return fail(VGAN_EINVAL, "vgan_gamdev_parse: null argument");
+    std::vector<GdBlock> gb;
+    uint64_t total = 0;
+    if (!gd_index(bytes, n, gb, total)) return fail(VGAN_EIO, "vgan_gamdev_parse: not a BGZF stream");
+    return gd_parse_indexed(g, bytes, n, gb, total, keep_unmapped);
+}
+
+// vgan_gamdev_create + vgan_gamdev_parse with the member index made first: a thread that calls this while another one makes the
+// process's first HIP call has the index (a walk over every member's header, ~0.5 us each) ready when the runtime is.
+extern "C" int vgan_gamdev_open(int device, void *hip_stream, const void *bytes, uint64_t n, int keep_unmapped, vgan_gamdev **out) {
+    if (!out || (!bytes && n)) return fail(VGAN_EINVAL, "vgan_gamdev_open: null argument");
+    *out = nullptr;
+    std::vector<GdBlock> gb;
+    uint64_t total = 0;
+    if (!gd_index(bytes, n, gb, total)) return fail(VGAN_EIO, "vgan_gamdev_open: not a BGZF stream");
+    vgan_gamdev *g = nullptr;
+    int rc = vgan_gamdev_create(device, hip_stream, &g);
+    if (rc < 0) return rc;
+    if ((rc = gd_parse_indexed(g, bytes, n, gb, total, keep_unmapped)) < 0) {
+        vgan_gamdev_free(g);
+        return rc;
+    }
+    *out = g;
+    return VGAN_OK;
+}
+
+namespace {
+int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::vector<GdBlock> &gb, uint64_t total, int keep_unmapped) {
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    g->n_inflated = g->n_messages = g->R = g->M = g->E = g->S = g->Q = 0;
     g->n_inflated = total;
     int rc;
     auto t0 = std::chrono::steady_clock::now();
     if ((rc = g->in.reserve(n + 64)) || (rc = g->infl.reserve(total + 64)) || (rc = g->blocks.reserve(gb.size() + 1)) || (rc = g->status.reserve(gb.size() + 1))) return rc;
-    HIPCHK(hipMemcpyAsync(g->in.p, bytes, n, hipMemcpyHostToDevice, st));
     if (!gb.empty()) HIPCHK(hipMemcpyAsync(g->blocks.p, gb.data(), gb.size() * sizeof(GdBlock), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
-    g->ms_upload = ms_since(t0);
-    t0 = std::chrono::steady_clock::now();
-    if ((rc = gamdev_inflate(g->in.p, g->blocks.p, (uint32_t)gb.size(), g->infl.p, g->status.p, st))) return rc;
+    // The file goes up in a few pieces, each on a stream of its own with the inflate of its members behind it: a member takes one lane
+    // ~80 ms however few of them run (the decode is a chain of dependent loads), so a piece's kernel has to run BESIDE the next piece's
+    // copy and the other pieces' kernels, not before them (pieces on ONE stream ran one after the other: 12 x 80 ms).
+    g->ms_upload = 0;
+    {
+        HIPCHK(hipStreamSynchronize(st)); // (the member list is up)
+        uint64_t piece = std::max<uint64_t>(64ull << 20, n / GD_PIECES + 1);
+        if (const char *e = getenv("VGAN_GAMDEV_PIECE")) piece = std::max<uint64_t>(1, strtoull(e, nullptr, 10)); // (test aid: many small pieces)
+        size_t b0 = 0, k = 0;
+        uint64_t sent = 0;
+        while (sent < n) {
+            size_t b1 = b0;
+            while (b1 < gb.size() && gb[b1].in_off + gb[b1].in_size + 8 <= sent + piece) ++b1;
+            if (b1 == b0 && b0 < gb.size()) b1 = b0 + 1; // (a piece below a member's size: one member at a time)
+            const uint64_t upto = b1 < gb.size() ? std::min<uint64_t>(n, gb[b1 - 1].in_off + gb[b1 - 1].in_size + 8) : n;
+            hipStream_t ps = st;
+            if (upto < n || k) { // (a file of one piece stays on the object's stream)
+                const size_t slot = k % GD_PIECES;
+                if (!g->piece_stream[slot]) HIPCHK(hipStreamCreateWithFlags(&g->piece_stream[slot], hipStreamNonBlocking));
+                ps = g->piece_stream[slot];
+            }
+            const auto tc = std::chrono::steady_clock::now();
+            if (upto > sent) HIPCHK(hipMemcpyAsync(g->in.p + sent, (const uint8_t *)bytes + sent, upto - sent, hipMemcpyHostToDevice, ps));
+            g->ms_upload += ms_since(tc);
+            sent = upto;
+            if (b1 > b0 && (rc = gamdev_inflate(g->in.p, g->blocks.p + b0, (uint32_t)(b1 - b0), g->infl.p, g->status.p + b0, ps))) return rc;
+            b0 = b1;
+            ++k;
+        }
+        for (hipStream_t ps : g->piece_stream)
+            if (ps) HIPCHK(hipStreamSynchronize(ps));
+    }
     {
         std::vector<uint32_t> stt(gb.size());
         if (!gb.empty()) HIPCHK(hipMemcpyAsync(stt.data(), g->status.p, gb.size() * 4, hipMemcpyDeviceToHost, st));
@@ -987,7 +1053,7 @@ extern "C" int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, 
         for (size_t i = 0; i < stt.size(); ++i)
             if (stt[i] != GD_OK) return fail(VGAN_EIO, "vgan_gamdev_parse: BGZF member %zu does not inflate (code %u)", i, stt[i]);
     }
-    g->ms_inflate = ms_since(t0);
+    g->ms_inflate = ms_since(t0) - g->ms_upload;
     if (total == 0) return VGAN_OK;
     // ---- framing
     t0 = std::chrono::steady_clock::now();
@@ -1070,6 +1136,7 @@ extern "C" int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, 
     g->ms_parse = ms_since(t0);
     return VGAN_OK;
 }
+} // namespace
 
 // sizes[8]: inflated bytes, messages, reads, mappings, edits, edit-sequence bytes, quality bytes, 0;  ms[4]: upload, inflate, framing, parsing (wall)
 extern "C" int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double ms[4]) {

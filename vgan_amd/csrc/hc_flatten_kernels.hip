@@ -712,9 +712,11 @@ static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uin
     HIPCHK(hipMemcpyAsync(&tot[1], f->qoff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&tot[2], f->coff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    pt.lap("offsets");
     if ((rc = f->rhdr.reserve((size_t)n_dev + 1)) || (rc = f->srec.reserve(tot[0] + 1)) || (rc = f->crec.reserve(tot[2] + 1)) ||
         (rc = f->qualp.reserve((size_t)tot[1] + 32)) || (rc = f->read_src.reserve(n_dev)))
         return rc;
+    pt.lap("output blocks");
     DfOut o{f->rhdr.p, f->srec.p, f->crec.p, f->qualp.p, f->read_src.p};
     hipLaunchKernelGGL(hc_df_write_kernel, dim3(std::min<uint32_t>((n_dev + 1 + 3) / 4, 16384u)), dim3(256), 0, st, f->slices.p, (uint32_t)np, f->g,
                        f->val_out.p, f->soff.p, f->qoff.p, f->coff.p, n_dev, base, o);
@@ -722,7 +724,7 @@ static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uin
     f->h_src.resize(n_dev);
     HIPCHK(hipMemcpyAsync(f->h_src.data(), f->read_src.p, (size_t)n_dev * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st)); // (the staging block is reused by the next call; the caller's arrays may go)
-    pt.lap("offsets + write");
+    pt.lap("write");
     out->n_reads = n_dev;
     out->n_segments = tot[0];
     out->n_qual = tot[1];

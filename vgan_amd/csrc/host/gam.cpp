@@ -1242,18 +1242,30 @@ extern "C" void vgan_aln_free(vgan_alnset *a) { delete a; }
 // Alignment messages lying one after the other in memory (message k = bytes[offsets[k], offsets[k + 1]): what the GAM front end on
 // the device hands back for the reads its flatten leaves to the host, csrc/gam_kernels.hip) -> a sliced set of one slice, parsed by
 // the parser every other input goes through.
-extern "C" int vgan_alnparts_from_messages(const uint8_t *bytes, const uint64_t *offsets, int64_t n, int keep_unmapped, vgan_alnparts **out) {
+extern "C" int vgan_alnparts_from_messages(const uint8_t *bytes, const uint64_t *offsets, int64_t n, int keep_unmapped, int n_threads, vgan_alnparts **out) {
     if (!out || n < 0 || (n > 0 && (!bytes || !offsets))) return fail(VGAN_EINVAL, "vgan_alnparts_from_messages: null argument");
     auto ps = new vgan_alnparts();
-    ps->parts.emplace_back();
-    vgan_alnset &a = ps->parts.back();
-    if (n) reserve_for(a, (size_t)(offsets[n] - offsets[0]), (size_t)n);
-    for (int64_t k = 0; k < n; ++k) {
-        if (offsets[k + 1] < offsets[k] || !parse_alignment(Cur{bytes + offsets[k], bytes + offsets[k + 1], true}, a, keep_unmapped)) {
+    // (slices of the messages on threads of their own: 135 k messages on one thread were 167 ms of a 10 M-read file's 1.45 s)
+    const int64_t T = std::max<int64_t>(1, std::min<int64_t>({n_threads > 0 ? (int64_t)n_threads : (int64_t)vgan_host_cpus(), 32, n / 4096}));
+    ps->parts.resize((size_t)T);
+    std::vector<int64_t> bad((size_t)T, -1);
+    auto slice = [&](int64_t t) {
+        const int64_t k0 = n * t / T, k1 = n * (t + 1) / T;
+        vgan_alnset &a = ps->parts[(size_t)t];
+        if (k1 > k0) reserve_for(a, (size_t)(offsets[k1] - offsets[k0]), (size_t)(k1 - k0));
+        for (int64_t k = k0; k < k1; ++k)
+            if (offsets[k + 1] < offsets[k] || !parse_alignment(Cur{bytes + offsets[k], bytes + offsets[k + 1], true}, a, keep_unmapped)) {
+                bad[(size_t)t] = k;
+                return;
+            }
+    };
+    parallel_run((int)T, [&](int t) { slice(t); });
+    for (int64_t t = 0; t < T; ++t)
+        if (bad[(size_t)t] >= 0) {
+            const int64_t k = bad[(size_t)t];
             delete ps;
             return fail(VGAN_EIO, "vgan_alnparts_from_messages: message %lld is malformed", (long long)k);
         }
-    }
     ps->index();
     *out = ps;
     return VGAN_OK;

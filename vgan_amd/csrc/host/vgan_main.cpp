@@ -201,9 +201,8 @@ int haplocart(int argc, char **argv) {
     } gd;
     if (device_gam)
         gd.t = std::thread([&, d = gpu_list.empty() ? device : gpu_list[0]] {
-            (void)vgan_device_warmup(d);
             const auto t0 = std::chrono::steady_clock::now();
-            if (vgan_gamdev_create(d, nullptr, &gd.g) < 0 || vgan_gamdev_parse(gd.g, gam_map.p, gam_map.n, 0) < 0) gd.why = vgan_last_error();
+            if (vgan_gamdev_open(d, nullptr, gam_map.p, gam_map.n, 0, &gd.g) < 0) gd.why = vgan_last_error(); // (the member index first, beside the runtime's start)
             gd.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         });
     // -j -jf FILE: every alignment of the GAM as a line of JSON (readGAM.h:37-38 writes them while it reads; here a pass of
@@ -532,19 +531,24 @@ int haplocart(int argc, char **argv) {
                     t0 = std::chrono::steady_clock::now();
                     uint64_t nm = 0, nb = 0;
                     check(vgan_gamdev_pick(gd.g, mask.data(), &nm, &nb), "reads left to the host");
+                    stamp("the reads left to the host: picked");
                     std::vector<uint64_t> offs((size_t)nm + 1);
                     std::vector<uint8_t> bytes((size_t)std::max<uint64_t>(nb, 1));
                     check(vgan_gamdev_picked(gd.g, offs.data(), bytes.data()), "reads left to the host");
+                    stamp("the reads left to the host: their messages down");
                     vgan_alnparts *left = nullptr;
-                    check(vgan_alnparts_from_messages(bytes.data(), offs.data(), (int64_t)nm, 0, &left), "reads left to the host");
+                    check(vgan_alnparts_from_messages(bytes.data(), offs.data(), (int64_t)nm, 0, n_threads, &left), "reads left to the host");
+                    stamp("the reads left to the host: parsed");
                     vgan_hc_host_batch *hb = nullptr;
                     const int rc = vgan_hc_flatten_parts_packed(graph, left, 0, vgan_alnparts_count(left), nullptr, 0, &hb, &sh);
                     vgan_alnparts_free(left);
                     check(rc, "flattening");
+                    stamp("the reads left to the host: flattened");
                     const std::string err = hand_over(cx, hb);
                     vgan_hc_host_batch_free(hb);
                     if (!err.empty()) die(err);
                     t_host = since_ms(t0);
+                    stamp("the reads left to the host: handed over");
                 }
                 tot.n_bad += sh.n_bad;
                 tot.n_unmapped += st.n_unmapped;

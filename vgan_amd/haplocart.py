@@ -535,9 +535,21 @@ class GamDevice:
         N.check(N.lib().vgan_gamdev_create(device, None, C.byref(self._h)))
         self.sizes, self.ms = {k: 0 for k in self._NAMES}, {}
 
+    @classmethod
+    def open(cls, data, device=0, keep_unmapped=False):
+        """vgan_gamdev_open: create + parse, the member index made before the first HIP call."""
+        self = cls.__new__(cls)
+        self._h = N.vp()
+        buf = np.frombuffer(data, np.uint8)
+        N.check(N.lib().vgan_gamdev_open(device, None, buf.ctypes.data, len(data), int(keep_unmapped), C.byref(self._h)))
+        return self._sizes()
+
     def parse(self, data, keep_unmapped=False):
         buf = np.frombuffer(data, np.uint8)
         N.check(N.lib().vgan_gamdev_parse(self._h, buf.ctypes.data, len(data), int(keep_unmapped)))
+        return self._sizes()
+
+    def _sizes(self):
         sizes, ms = np.zeros(8, np.uint64), np.zeros(4)
         N.check(N.lib().vgan_gamdev_sizes(self._h, sizes.ctypes.data, ms.ctypes.data))
         self.sizes = dict(zip(self._NAMES, (int(x) for x in sizes[:7])))
@@ -559,7 +571,7 @@ class GamDevice:
         offs, byts = np.zeros(int(nm.value) + 1, np.uint64), np.zeros(max(int(nb.value), 1), np.uint8)
         N.check(N.lib().vgan_gamdev_picked(self._h, offs.ctypes.data, byts.ctypes.data))
         h = N.vp()
-        N.check(N.lib().vgan_alnparts_from_messages(byts.ctypes.data, offs.ctypes.data, int(nm.value), int(keep_unmapped), C.byref(h)))
+        N.check(N.lib().vgan_alnparts_from_messages(byts.ctypes.data, offs.ctypes.data, int(nm.value), int(keep_unmapped), 0, C.byref(h)))
         return AlnParts(h)
 
     def close(self):
