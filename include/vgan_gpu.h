@@ -792,6 +792,18 @@ int vgan_sb_group_best_paths(vgan_sb_group *g, int64_t *sig_count, int64_t *n_re
 /* the engine's refresh is one fused kernel plus a fold into pinned host memory; on != 0 brackets it with HIP events so that
  * vgan_sb_kernel_ms (slot 1) reports it as well -- off by default: the chain is launch bound and two event records cost */
 int vgan_sb_time_engine(vgan_sb_ctx *c, int on);
+/* The engine's refresh as a RESIDENT kernel (csrc/sb_kernels.hip: sb_refresh_resident_kernel), off unless asked for (on = 1 here, or
+ * VGAN_SB_RESIDENT=1 in the environment when the context is made).  MCMC.cpp:738-993 wants one likelihood per iteration and cannot go on
+ * without it; with this on the first refresh starts a kernel that stays: the host writes a refresh's sources into a pinned mailbox, the
+ * kernel answers into pinned memory -- no launch per iteration.  Measured (soibean): 21 us instead of 24 per iteration up to
+ * ~30 k reads, no gain from there to ~250 k, slower beyond (the kernel keeps half the device free for whatever else the process runs).
+ * One context per device has the kernel at a time (another context's refreshes are launched); the kernel leaves when any other call on
+ * the context needs the device's tables (the next refresh starts it again) and by itself after 5 ms without a refresh; a refresh timed
+ * with HIP events (vgan_sb_time_engine) is a launched one.  Results are the launched refresh's, bit for bit.  on < 0: returns the setting.
+ * vgan_sb_resident_launches: how often the kernel was started (test aid).  vgan_sb_kernel_ms slot 1 then counts the kernel's own clock
+ * from seeing a refresh to publishing it (read when the kernel leaves: the call makes it leave). */
+int vgan_sb_resident(vgan_sb_ctx *c, int on);
+int vgan_sb_resident_launches(const vgan_sb_ctx *c, uint64_t *launches);
 
 typedef struct vgan_sb_estimate_cfg {
     uint32_t max_iter;  /* --iter (500000) */

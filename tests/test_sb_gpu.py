@@ -353,6 +353,65 @@ def test_sums_over_reads_do_not_depend_on_how_the_reads_are_dealt(tmp_path):
     assert rc == 0 and abs(grp.refresh(k3[0], 0.01, FREQS)[0] - ref) <= 1e-10 * abs(ref)
 
 
+def test_resident_refresh_kernel_gives_the_launched_refresh_bit_for_bit(tmp_path):
+    """vgan_sb_resident: the engine's refresh served by a kernel that stays on the device, against the launched refresh -- states of one
+    and three sources, the chains' batched call, other calls on the context in between (the kernel leaves and comes back), a pause
+    beyond the kernel's idle limit, a second context on the same device (its refreshes are launched), and whole chains."""
+    import time
+    g, a, profs, newick, one, parts = _group_case(tmp_path)
+    rng = np.random.default_rng(5)
+    pairs = tree_pairs(g)
+    states = []
+    for i in range(60):
+        k = 1 if i % 3 == 0 else 3
+        th = rng.dirichlet([1] * k)
+        states.append([(*pairs[rng.integers(len(pairs))], 0.01 + 0.05 * rng.random(), rng.random() * 0.98 + 0.01, float(th[y])) for y in range(k)])
+    assert one.resident() is False
+    want = [one.refresh(st, 0.01, FREQS) for st in states]
+    one.resident(True)
+    assert one.resident() is True and one.resident_launches() == 0
+    got = [one.refresh(st, 0.01, FREQS) for st in states]
+    assert got == want and one.resident_launches() == 1
+    # another call on the context: the kernel leaves, the next refresh starts it again
+    v = one.mixture_loglike([0, 3, 5], float(np.log(1 / 3)))
+    assert one.refresh(states[1], 0.01, FREQS) == want[1] and one.resident_launches() == 2
+    assert one.mixture_loglike([0, 3, 5], float(np.log(1 / 3))) == v
+    # 5 ms without a refresh: it leaves by itself
+    assert one.refresh(states[2], 0.01, FREQS) == want[2]
+    n = one.resident_launches()
+    time.sleep(0.05)
+    assert one.refresh(states[3], 0.01, FREQS) == want[3] and one.resident_launches() == n + 1
+    # back to back with pauses around the limit (the kernel may be leaving while the refresh is posted)
+    for i, ms in enumerate((4.0, 4.5, 5.0, 5.5, 6.0, 5.2, 4.8, 5.1)):
+        time.sleep(ms * 1e-3)
+        assert one.refresh(states[i], 0.01, FREQS) == want[i]
+    # a second context on the device keeps launching; the group's refresh (its contexts' sums added) is unchanged
+    parts[0].resident(True)
+    before = parts[0].resident_launches()
+    grp = sb.SbGroup(parts)
+    for st in states[:6]:
+        assert grp.refresh(st, 0.01, FREQS)[0] == one.refresh(st, 0.01, FREQS)[0]
+    assert parts[0].resident_launches() == before  # (`one` holds the device)
+    km = one.kernel_ms()["refresh"]
+    assert km[1] > 0 and 0 < km[0] / km[1] < 5.0  # the kernel's own clock per refresh, ms
+    # whole chains, file for file
+    tree = sb.Tree.parse(newick)
+    node_path = tree.node_paths(g.path_names)
+    _, sig, n_ok = one.best_paths()
+    paths = sb.signature_paths(sig, n_ok, cutk=2)
+    inv = {int(p): v for v, p in enumerate(node_path)}
+    sig_nodes = [inv[int(p)] for p in paths]
+    kw = dict(con=0.004, iters=150, burnin=30, chains=3, seed=11)
+    sb.estimate(one, tree, node_path, sig_nodes, str(tmp_path / "res_"), g.n_paths, FREQS, **kw)
+    assert one.resident_launches() > n + 1
+    one.resident(False)
+    sb.estimate(one, tree, node_path, sig_nodes, str(tmp_path / "lau_"), g.n_paths, FREQS, **kw)
+    f1, f2 = _chain_files(str(tmp_path / "res_")), _chain_files(str(tmp_path / "lau_"))
+    assert sorted(f1) == sorted(f2) and len(f1) >= 7
+    for name in f1:
+        assert f1[name] == f2[name], name
+
+
 def test_chains_over_a_group_of_contexts_write_the_files_of_one_context(tmp_path):
     """vgan_sb_estimate over vgan_sb_engine_group (three contexts on this GPU, uneven shares) against the same chains over one
     context: every output file byte for byte."""

@@ -296,6 +296,8 @@ SYMBOLS = {
     "vgan_tree_free": (None, [vp]),
     "vgan_sb_engine_gpu": (C.c_int, [vp, C.POINTER(SbEngine)]),
     "vgan_sb_time_engine": (C.c_int, [vp, C.c_int]),
+    "vgan_sb_resident": (C.c_int, [vp, C.c_int]),
+    "vgan_sb_resident_launches": (C.c_int, [vp, vp]),
     "vgan_sb_estimate": (C.c_int, [C.POINTER(SbEngine), vp, vp, vp, C.c_uint32, C.POINTER(SbEstimateCfg), C.c_char_p]),
     "vgan_sb_best_paths": (C.c_int, [vp, vp, vp, vp]),
     "vgan_sb_mixture_loglike": (C.c_int, [vp, C.c_uint32, vp, C.c_double, vp]),

@@ -4,6 +4,7 @@
 #include <thread>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <sstream>
@@ -78,6 +79,15 @@ struct vgan_sb_ctx {
     bool time_refresh = false;           // HIP events around the engine's refresh too (vgan_sb_time_engine)
     uint64_t refresh_seq = 0;            // refreshes launched so far (the finishing kernel leaves the number in the pinned block)
     Buf<unsigned long long> ticket;      // guard counts (one per state) of the fused refresh, zero between refreshes
+    // the resident refresh (sb_kernels.hip: sb_refresh_resident_kernel): a stream of its own, the mailbox (pinned), the device block
+    hipStream_t res_stream = nullptr;
+    void *mailbox = nullptr;
+    Buf<uint8_t> resident;
+    Buf<SbFix> res_partial;
+    uint32_t res_grid = 0;
+    bool res_on = false, res_running = false; // wanted (vgan_sb_resident / VGAN_SB_RESIDENT); a launch is out
+    uint64_t res_launch = 0, res_launches = 0; // the id of the last launch; how many there were (test aid)
+    unsigned long long res_busy_seen = 0, res_served_seen = 0; // the mailbox's counters at the last vgan_sb_kernel_ms
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[2] = {false, false};
     double ms[2] = {0, 0};
@@ -94,6 +104,21 @@ static void resolve(vgan_sb_ctx *c, int i) {
     c->pending[i] = false;
 }
 
+// Every entry point that is not the engine's refresh calls this first: the resident kernel holds the tables' addresses of its launch
+// and half the device; it is told to leave and waited for (it relaunches with the next refresh).
+static std::atomic<vgan_sb_ctx *> g_res_owner[64]; // per device: the context whose resident kernel is out (one at a time: each takes half the device)
+static int res_quiesce(vgan_sb_ctx *c) {
+    if (!c->res_running) return VGAN_OK;
+    sb_mailbox_stop(c->mailbox, true);
+    const hipError_t e = hipStreamSynchronize(c->res_stream);
+    sb_mailbox_stop(c->mailbox, false);
+    c->res_running = false;
+    vgan_sb_ctx *me = c;
+    (void)g_res_owner[c->device & 63].compare_exchange_strong(me, nullptr);
+    if (e != hipSuccess) return fail(VGAN_ENODEV, "the resident refresh kernel failed: %s", hipGetErrorString(e));
+    return VGAN_OK;
+}
+
 extern "C" int vgan_sb_create(const vgan_graph_view *gv, const vgan_damage_view *dmg, const vgan_sb_params *prm, int device,
                               vgan_sb_ctx **out) {
     if (!gv || !dmg || !prm || !out) return fail(VGAN_EINVAL, "vgan_sb_create: null argument");
@@ -108,6 +133,7 @@ extern "C" int vgan_sb_create(const vgan_graph_view *gv, const vgan_damage_view 
     HIPCHK(hipSetDevice(device));
     auto c = new vgan_sb_ctx();
     c->device = device;
+    if (const char *e = getenv("VGAN_SB_RESIDENT")) c->res_on = atoi(e) != 0; // (vgan_sb_resident sets it per context; off unless asked for)
     c->P = gv->n_paths;
     const uint32_t W = (gv->n_paths + 63) / 64, rows = (uint32_t)gv->max_id + 1;
     std::vector<uint8_t> findable(c->P, 1);
@@ -150,8 +176,17 @@ extern "C" int vgan_sb_create(const vgan_graph_view *gv, const vgan_damage_view 
 extern "C" void vgan_sb_destroy(vgan_sb_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)res_quiesce(c);
+    {
+        vgan_sb_ctx *me = c; // (a kernel that left by itself leaves the claim standing)
+        (void)g_res_owner[c->device & 63].compare_exchange_strong(me, nullptr);
+    }
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->mailbox) (void)hipHostFree(c->mailbox);
+    if (c->res_stream) (void)hipStreamDestroy(c->res_stream);
+    c->resident.release();
+    c->res_partial.release();
     c->ticket.release();
     c->mask.release();
     c->findable.release();
@@ -185,6 +220,7 @@ extern "C" void vgan_sb_destroy(vgan_sb_ctx *c) {
 
 extern "C" int vgan_sb_set_stream(vgan_sb_ctx *c, void *s) {
     if (!c) return fail(VGAN_EINVAL, "vgan_sb_set_stream: null context");
+    if (int rq = res_quiesce(c)) return rq;
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return VGAN_OK;
 }
@@ -192,6 +228,7 @@ extern "C" int vgan_sb_set_stream(vgan_sb_ctx *c, void *s) {
 extern "C" int vgan_sb_precompute(vgan_sb_ctx *c, const vgan_sb_batch *b, int64_t *n_bad) {
     if (!c || !b) return fail(VGAN_EINVAL, "vgan_sb_precompute: null argument");
     HIPCHK(hipSetDevice(c->device));
+    if (int rq = res_quiesce(c)) return rq;
     resolve(c, 0);
     const size_t R = b->n_reads, S = b->n_segments;
     int rc;
@@ -293,6 +330,7 @@ extern "C" int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, dou
     if (!c) return fail(VGAN_EINVAL, "vgan_sb_read_tables: null context");
     if (r0 > r1 || r1 > c->t.n_reads) return fail(VGAN_EINVAL, "vgan_sb_read_tables: bad range");
     HIPCHK(hipSetDevice(c->device));
+    if (int rq = res_quiesce(c)) return rq;
     const size_t n = r1 - r0, R = c->t.n_reads;
     if (n == 0) return VGAN_OK;
     // (the counts lie tiled by 64 reads on the device: the tiles covering [r0, r1) come over per path and are laid out
@@ -320,6 +358,7 @@ extern "C" int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, dou
 extern "C" int vgan_sb_best_paths(vgan_sb_ctx *c, int32_t *best, int64_t *sig_count, int64_t *n_reads_ok) {
     if (!c) return fail(VGAN_EINVAL, "vgan_sb_best_paths: null context");
     HIPCHK(hipSetDevice(c->device));
+    if (int rq = res_quiesce(c)) return rq;
     const uint32_t R = c->t.n_reads;
     int rc;
     if ((rc = c->sig.reserve(c->P + 1)) || (best && (rc = c->best.reserve(R)))) return rc;
@@ -365,6 +404,7 @@ static int mixture_impl(vgan_sb_ctx *c, uint32_t n, const int32_t *paths, double
     for (uint32_t i = 0; i < n; ++i)
         if (paths[i] < 0 || (uint32_t)paths[i] >= c->P) return fail(VGAN_EINVAL, "vgan_sb_mixture_loglike: path index out of range");
     HIPCHK(hipSetDevice(c->device));
+    if (int rq = res_quiesce(c)) return rq;
     const uint32_t R = c->t.n_reads;
     const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
     int rc;
@@ -395,6 +435,7 @@ static int loglike_impl(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vga
     if (n_states == 0 || k == 0) return fail(VGAN_EINVAL, "vgan_sb_loglike: need at least one state and one source");
     if ((size_t)n_states * k * 2 * SB_NCNT * 8 > 60000) return fail(VGAN_ERANGE, "vgan_sb_loglike: n_states*k too large for one launch (<= 150)");
     HIPCHK(hipSetDevice(c->device));
+    if (int rq = res_quiesce(c)) return rq;
     resolve(c, 1);
     const uint32_t ne = n_states * k;
     std::vector<SbSourceDev> sd(ne);
@@ -452,12 +493,66 @@ constexpr size_t SB_PIN_BYTES = SB_PIN_SEQ_OFF + SB_FUSED_MAX_K * 8;
 // launch half: everything is queued on the context's stream, nothing is waited for.  *general: the states did not fit the
 // kernel-argument staging and went through vgan_sb_loglike (already complete: results in gen_*).
 struct SbPending {
-    bool general = false;
+    bool general = false, resident = false;
     uint64_t seq = 0; // the refresh's number: what the finishing kernel leaves in the pinned block behind its results
     std::vector<double> gen_out;
     std::vector<vgan_sb_sum> gen_sum;
     std::vector<uint64_t> gen_guard;
 };
+// Launches the resident kernel: `done` = the number of the last refresh served (the kernel waits for another one in the mailbox).  A device
+// that cannot hold the grid as a whole leaves res_running false: the caller launches per refresh.
+constexpr unsigned long long SB_RES_IDLE_TICKS = 500000; // 5 ms of the 100 MHz clock without a refresh: the kernel leaves
+static int res_start(vgan_sb_ctx *c, uint64_t done, bool posted /* the mailbox holds refresh done + 1: it is left alone */) {
+    int rc;
+    if (!c->mailbox) {
+        HIPCHK(hipHostMalloc(&c->mailbox, sb_mailbox_bytes(), hipHostMallocDefault));
+        memset(c->mailbox, 0, sb_mailbox_bytes());
+        HIPCHK(hipStreamCreateWithFlags(&c->res_stream, hipStreamNonBlocking));
+        if ((rc = c->resident.reserve(sb_resident_bytes()))) return rc;
+        HIPCHK(hipMemset(c->resident.p, 0, sb_resident_bytes()));
+        c->res_grid = sb_resident_grid(c->device, 1024u);
+        if (const char *e = getenv("VGAN_SB_RESIDENT_GRID")) c->res_grid = std::min<uint32_t>(std::max(1, atoi(e)), 2u * c->res_grid); // (developer aid; at most all that fits)
+    }
+    if (c->res_grid == 0) return VGAN_OK;
+    {
+        vgan_sb_ctx *none = nullptr;
+        auto &owner = g_res_owner[c->device & 63];
+        if (owner.load() != c && !owner.compare_exchange_strong(none, c)) return VGAN_OK; // (another context's kernel holds this device: launches here)
+    }
+    if (!posted) sb_mailbox_idle(c->mailbox, done);
+    const uint32_t R = c->t.n_reads;
+    const uint32_t n_blocks = std::max(1u, std::min(c->res_grid, (R + 255) / 256));
+    if ((rc = c->res_partial.reserve((size_t)SB_FUSED_MAX_K * n_blocks))) return rc;
+    if (!c->pin) {
+        HIPCHK(hipHostMalloc((void **)&c->pin, SB_PIN_BYTES, hipHostMallocDefault));
+        memset(c->pin, 0, SB_PIN_BYTES);
+    }
+    if (!c->ticket.p) {
+        if ((rc = c->ticket.reserve(SB_FUSED_MAX_K))) return rc;
+        HIPCHK(hipMemsetAsync(c->ticket.p, 0, SB_FUSED_MAX_K * 8, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream)); // (the tables are final; the guard words are zero)
+    double *pin_out = reinterpret_cast<double *>(c->pin);
+    unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + SB_FUSED_MAX_K * 8);
+    SbFix *pin_fix = reinterpret_cast<SbFix *>(c->pin + 2 * SB_FUSED_MAX_K * 8);
+    c->res_launch += 1;
+    c->res_launches += 1;
+    launch_sb_refresh_resident(c->t, c->mailbox, c->resident.p, c->res_partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, pin_fix,
+                               reinterpret_cast<unsigned long long *>(c->pin + SB_PIN_SEQ_OFF), done, SB_RES_IDLE_TICKS, c->res_launch, c->res_stream);
+    HIPCHK(hipGetLastError());
+    c->res_running = true;
+    return VGAN_OK;
+}
+// before a refresh is posted: a kernel is out, or one is started
+static int res_ensure(vgan_sb_ctx *c) {
+    if (c->res_running) {
+        if (sb_mailbox_exited(c->mailbox) != c->res_launch) return VGAN_OK;
+        HIPCHK(hipStreamSynchronize(c->res_stream)); // it left by itself
+        c->res_running = false;
+    }
+    return res_start(c, c->refresh_seq, false);
+}
+
 static int refresh_launch(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vgan_sb_source *src, double con, const double *freqs7,
                           SbPending &pd) {
     if (!c || !src || !freqs7) return fail(VGAN_EINVAL, "vgan_sb_engine refresh: null argument");
@@ -506,6 +601,15 @@ static int refresh_launch(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const v
     double *pin_out = reinterpret_cast<double *>(c->pin);
     unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + SB_FUSED_MAX_K * 8);
     SbFix *pin_fix = reinterpret_cast<SbFix *>(c->pin + 2 * SB_FUSED_MAX_K * 8);
+    if (c->res_on && !c->time_refresh && R > 0) {
+        if ((rc = res_ensure(c))) return rc;
+        if (c->res_running) {
+            pd.seq = ++c->refresh_seq;
+            pd.resident = true;
+            sb_mailbox_post(c->mailbox, n_states, k, a, pd.seq);
+            return VGAN_OK;
+        }
+    }
     if (c->time_refresh) {
         resolve(c, 1);
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
@@ -532,7 +636,42 @@ static int refresh_collect(vgan_sb_ctx *c, uint32_t n_states, const SbPending &p
     // The finishing kernel writes the refresh's number behind each state's results (system-scope fence in between): the host
     // watches those words instead of sleeping in hipStreamSynchronize -- an MCMC iteration is one such wait, and the wake-up
     // was a tenth of it.  The stream is asked now and then so that a failed launch ends the wait.
-    {
+    if (pd.resident) {
+        // the resident kernel writes the same words; what can go wrong is that it left (5 ms without a refresh) just before this one was
+        // posted: it is started again on the mailbox as it stands
+        const volatile uint64_t *seq = reinterpret_cast<const volatile uint64_t *>(c->pin + SB_PIN_SEQ_OFF);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; ++spins) {
+            bool all = true;
+            for (uint32_t e = 0; e < n_states; ++e) all = all && seq[e] == pd.seq;
+            if (all) break;
+            if ((spins & 0x3FFu) == 0x3FFu) {
+                if (sb_mailbox_exited(c->mailbox) == c->res_launch) {
+                    if (hipStreamSynchronize(c->res_stream) != hipSuccess) return fail(VGAN_ENODEV, "vgan_sb_engine refresh: the resident kernel failed");
+                    c->res_running = false;
+                    all = true;
+                    for (uint32_t e = 0; e < n_states; ++e) all = all && seq[e] == pd.seq;
+                    if (all) break; // (served, then left)
+                    int rc = res_start(c, pd.seq - 1, true);
+                    if (rc) return rc;
+                    if (!c->res_running) return fail(VGAN_ENODEV, "vgan_sb_engine refresh: the resident kernel cannot be started again");
+                } else if ((spins & 0xFFFFFu) == 0xFFFFFu) {
+                    const hipError_t q = hipStreamQuery(c->res_stream);
+                    if (q != hipSuccess && q != hipErrorNotReady) return fail(VGAN_ENODEV, "vgan_sb_engine refresh: the resident kernel failed: %s", hipGetErrorString(q));
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) {
+                        sb_mailbox_stop(c->mailbox, true);
+                        return fail(VGAN_ENODEV, "vgan_sb_engine refresh: no answer from the resident kernel within 60 s");
+                    }
+                }
+            }
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
         const volatile uint64_t *seq = reinterpret_cast<const volatile uint64_t *>(c->pin + SB_PIN_SEQ_OFF);
         for (uint32_t spins = 0;; ++spins) {
             bool all = true;
@@ -588,7 +727,23 @@ static int engine_mixture(void *user, uint32_t n, const int32_t *paths, double l
 
 extern "C" int vgan_sb_time_engine(vgan_sb_ctx *c, int on) {
     if (!c) return fail(VGAN_EINVAL, "vgan_sb_time_engine: null context");
+    if (int rq = res_quiesce(c)) return rq; // (HIP events bracket launches: a timed refresh is a launched one)
     c->time_refresh = on != 0;
+    return VGAN_OK;
+}
+
+// The engine's refresh served by a kernel that stays on the device between refreshes (include/vgan_gpu.h); -1 asks, 0 / 1 sets.
+extern "C" int vgan_sb_resident(vgan_sb_ctx *c, int on) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_sb_resident: null context");
+    if (on < 0) return c->res_on ? 1 : 0;
+    HIPCHK(hipSetDevice(c->device));
+    if (int rq = res_quiesce(c)) return rq;
+    c->res_on = on != 0;
+    return VGAN_OK;
+}
+extern "C" int vgan_sb_resident_launches(const vgan_sb_ctx *c, uint64_t *launches) {
+    if (!c || !launches) return fail(VGAN_EINVAL, "vgan_sb_resident_launches: null argument");
+    *launches = c->res_launches;
     return VGAN_OK;
 }
 
@@ -692,6 +847,19 @@ extern "C" int vgan_sb_kernel_ms(vgan_sb_ctx *c, double ms[2], uint64_t launches
     HIPCHK(hipSetDevice(c->device));
     resolve(c, 0);
     resolve(c, 1);
+    if (c->mailbox) { // the resident kernel's own account (it writes it when it leaves): 100 MHz ticks between seeing a refresh's number and publishing its results
+        if (int rq = res_quiesce(c)) return rq;
+        unsigned long long ticks = 0, served = 0, stamp[8];
+        sb_mailbox_busy(c->mailbox, &ticks, &served, stamp);
+        if (getenv("VGAN_TIMING") && served != c->res_served_seen)
+            fprintf(stderr, "[vgan timing] soibean resident refresh, the last one (us since its number was seen): arguments over %.2f, tables built %.2f, reads done %.2f, "
+                            "last workgroup in %.2f, folded %.2f, published %.2f\n",
+                    stamp[0] * 1e-2, stamp[1] * 1e-2, stamp[2] * 1e-2, stamp[3] * 1e-2, stamp[4] * 1e-2, stamp[5] * 1e-2);
+        c->ms[1] += (double)(ticks - c->res_busy_seen) * 1e-5;
+        c->launches[1] += served - c->res_served_seen;
+        c->res_busy_seen = ticks;
+        c->res_served_seen = served;
+    }
     for (int i = 0; i < 2; ++i) {
         if (ms) ms[i] = c->ms[i];
         if (launches) launches[i] = c->launches[i];

@@ -102,6 +102,20 @@ void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const
 void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, SbFix *partial, uint32_t n_blocks,
                              unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host,
                              unsigned long long *seq_host, unsigned long long seq, hipStream_t st, hipEvent_t after_main);
+// The same refresh served by a kernel that stays on the device (sb_kernels.hip: sb_refresh_resident_kernel): mailbox = sb_mailbox_bytes() of
+// zeroed pinned host memory, resident = sb_resident_bytes() of zeroed device memory (seq = done), n_blocks <= sb_resident_grid().  The host
+// posts a refresh with sb_mailbox_post and watches seq_host as after launch_sb_refresh_fused.
+size_t sb_mailbox_bytes();
+size_t sb_resident_bytes();
+void sb_mailbox_post(void *mailbox, uint32_t n_states, uint32_t k, const SbFusedArgs &a, unsigned long long seq);
+void sb_mailbox_idle(void *mailbox, unsigned long long done); // nothing posted: the number of the last refresh served
+void sb_mailbox_stop(void *mailbox, bool on);
+unsigned long long sb_mailbox_exited(const void *mailbox);
+void sb_mailbox_busy(void *mailbox, unsigned long long *ticks, unsigned long long *served, unsigned long long stamp[8]); // (as the kernel left them when it last left)
+uint32_t sb_resident_grid(int device, uint32_t want);
+void launch_sb_refresh_resident(const SbTablesDev &t, void *mailbox, void *resident, SbFix *partial, uint32_t n_blocks, unsigned long long *guard,
+                                double *out_host, unsigned long long *guard_host, SbFix *fix_host, unsigned long long *seq_host, unsigned long long done,
+                                unsigned long long idle_ticks, unsigned long long launch_id, hipStream_t st);
 // per-read best path (-1: tie or excluded read), per-path signature counts and the number of usable reads; counters zeroed by the caller
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,
                           unsigned long long *n_ok, hipStream_t st);

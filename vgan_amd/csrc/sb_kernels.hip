@@ -707,6 +707,222 @@ __global__ __launch_bounds__(64) void sb_finish_host_kernel(const SbFix *__restr
     }
 }
 
+// The refresh as a resident kernel (MCMC.cpp:738-993 asks for one likelihood per iteration, and the iteration cannot go on before it has
+// it: at 1 M reads the two launches above and the wait for them were 22 us around 76 us of kernel; at 20 k reads 25 us around 5).  The
+// workgroups stay on the device between refreshes: workgroup 0 watches a mailbox in pinned host memory (the host writes the sources,
+// then the refresh's number), copies the arguments into device memory and publishes the number there for the others; each workgroup
+// computes its partial sums as sb_refresh_fused_kernel does, the last one to finish folds them and writes the results and the number into
+// pinned host memory.  A refresh costs two trips over the host link and one through L2 instead of two launches.
+// The kernel leaves when the host says so (any other call on the context: the tables may move), and BY ITSELF when no refresh came for
+// idle_ticks of the 100 MHz clock -- a host that died or forgot leaves nothing running.  Its grid must be resident as a whole (the
+// launcher sizes it; a workgroup that never started would be waited for by the last-to-finish count).
+struct SbMailbox { // pinned host memory
+    SbFusedArgs a;
+    uint32_t n_states, k;
+    unsigned long long seq;    // host: the number of the refresh whose arguments stand above (written last)
+    unsigned long long stop;   // host: non-zero = leave
+    unsigned long long exited; // device: the launch id, once the kernel of that launch has left
+    unsigned long long busy;   // device, written when the kernel leaves: ticks between seeing a number and publishing its results, summed
+    unsigned long long served; // device, likewise: refreshes served (both summed over the launches: vgan_sb_kernel_ms)
+    unsigned long long stamp[8]; // device, likewise: the last refresh's way through the kernel (developer aid, 100 MHz ticks since it was seen)
+};
+struct SbResident { // device memory
+    SbFusedArgs a;
+    uint32_t n_states, k;
+    unsigned long long seq, stop, t_seen;
+    unsigned int ticket;
+    unsigned long long busy, served, stamp[8];
+};
+
+// Everything one workgroup writes for another (or for the host) goes and comes as RELAXED atomic accesses of the scope that reaches the
+// reader (they pass the caches on their own), ordered by the issuing thread's wait for its own stores: an acquire / release FENCE of agent
+// scope on this device writes back and invalidates the whole L2 of the XCD it runs on -- the first version, with fences, took 107 us for
+// the reads' loop the launched kernel does in 76, and 26 us for the fold.
+__device__ __forceinline__ unsigned long long sbr_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sbr_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long sbr_ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sbr_st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sbr_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); } // (the thread's stores are acknowledged)
+static_assert(sizeof(SbFusedArgs) % 8 == 0 && sizeof(SbSourceDev) % 8 == 0 && sizeof(SbFix) == 24, "the resident kernel moves these as 64-bit words");
+
+__global__ __launch_bounds__(SBL_THREADS) void sb_refresh_resident_kernel(SbTablesDev t, SbMailbox *mb, SbResident *rs, SbFix *partial,
+                                                                           unsigned long long *guard, double *out_host, unsigned long long *guard_host,
+                                                                           SbFix *fix_host, unsigned long long *seq_host, unsigned long long done,
+                                                                           unsigned long long idle_ticks, unsigned long long launch_id) {
+    __shared__ double hk_s[SB_FUSED_MAX_K * 2 * SB_NCNT];
+    __shared__ SbSourceDev src_s[SB_FUSED_MAX_K];
+    __shared__ double fr_s[8];
+    __shared__ SbFix red_s[SBL_THREADS / 64];
+    __shared__ unsigned long long seq_s;
+    __shared__ uint32_t stop_s, last_s, nk_s[2];
+    const uint32_t R = t.n_reads;
+    constexpr uint32_t n_arg_words = (uint32_t)(sizeof(SbFusedArgs) / 8) + 1; // a; {n_states, k}
+    constexpr uint32_t W_SRC = (uint32_t)(sizeof(SbSourceDev) * SB_FUSED_MAX_K / 8);
+    static_assert(n_arg_words == W_SRC + 9 && n_arg_words <= SBL_THREADS, "sources, seven frequencies, con, the two counts: a word per thread");
+    unsigned long long *rs_w = reinterpret_cast<unsigned long long *>(rs);
+    for (;;) {
+        // ---- the next refresh's number (or the order to leave)
+        if (threadIdx.x == 0) {
+            unsigned long long s = done;
+            uint32_t stop = 0;
+            if (blockIdx.x == 0) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    s = sbr_ld_sys(&mb->seq);
+                    if (s != done) break;
+                    if (sbr_ld_sys(&mb->stop) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) {
+                        stop = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!stop) sbr_st(&rs->t_seen, __builtin_amdgcn_s_memrealtime());
+            } else {
+                for (;;) {
+                    s = sbr_ld(&rs->seq);
+                    if (s != done) break;
+                    if (sbr_ld(&rs->stop) != 0) {
+                        stop = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            seq_s = s;
+            stop_s = stop;
+        }
+        __syncthreads();
+        if (stop_s) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                sbr_st(&rs->stop, 1ull);
+                // (a refresh the others are still finishing is not in these sums yet: rs keeps them for the next launch)
+                sbr_st_sys(&mb->busy, sbr_ld(&rs->busy));
+                sbr_st_sys(&mb->served, sbr_ld(&rs->served));
+                for (int q = 0; q < 8; ++q) sbr_st_sys(&mb->stamp[q], sbr_ld(&rs->stamp[q]));
+                sbr_stores_done();
+                sbr_st_sys(&mb->exited, launch_id);
+            }
+            return;
+        }
+        const unsigned long long seq = seq_s;
+        // ---- the arguments: workgroup 0 has them from the host and passes them on through device memory
+        if (blockIdx.x == 0) {
+            const unsigned long long *from = reinterpret_cast<const unsigned long long *>(mb);
+            unsigned long long w = 0;
+            if (threadIdx.x < n_arg_words) {
+                w = sbr_ld_sys(from + threadIdx.x);
+                sbr_st(rs_w + threadIdx.x, w);
+                sbr_stores_done();
+            }
+            if (threadIdx.x < n_arg_words) { // (its own copy straight from the registers)
+                if (threadIdx.x < W_SRC) reinterpret_cast<unsigned long long *>(src_s)[threadIdx.x] = w;
+                else if (threadIdx.x < W_SRC + 7) fr_s[threadIdx.x - W_SRC] = __longlong_as_double((long long)w);
+                else if (threadIdx.x == W_SRC + 7) fr_s[7] = __longlong_as_double((long long)w); // con
+                else nk_s[0] = (uint32_t)w, nk_s[1] = (uint32_t)(w >> 32);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                sbr_st(&rs->stamp[0], __builtin_amdgcn_s_memrealtime() - sbr_ld(&rs->t_seen)); // the arguments are over
+                sbr_st(&rs->seq, seq);
+            }
+        } else {
+            if (threadIdx.x < n_arg_words) {
+                const unsigned long long w = sbr_ld(rs_w + threadIdx.x);
+                if (threadIdx.x < W_SRC) reinterpret_cast<unsigned long long *>(src_s)[threadIdx.x] = w;
+                else if (threadIdx.x < W_SRC + 7) fr_s[threadIdx.x - W_SRC] = __longlong_as_double((long long)w);
+                else if (threadIdx.x == W_SRC + 7) fr_s[7] = __longlong_as_double((long long)w);
+                else nk_s[0] = (uint32_t)w, nk_s[1] = (uint32_t)(w >> 32);
+            }
+            __syncthreads();
+        }
+        // ---- as sb_refresh_fused_kernel
+        const uint32_t n_states = nk_s[0], k = nk_s[1], ne = n_states * k;
+        const double con = fr_s[7];
+        for (uint32_t i = threadIdx.x; i < ne * 2 * SB_NCNT; i += SBL_THREADS) {
+            const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
+            SbSourceDev sd;
+            sd.t1 = src_s[e].t1;
+            sd.t2 = src_s[e].t2;
+            hk_s[i] = sb_hky_entry(sd, which, j, con, fr_s);
+        }
+        __syncthreads();
+        const unsigned long long t_tab = __builtin_amdgcn_s_memrealtime();
+        for (uint32_t e = 0; e < n_states; ++e) {
+            SbFix sum{0, 0, 0.0};
+            unsigned long long bad = 0;
+            for (uint32_t r = blockIdx.x * SBL_THREADS + threadIdx.x; r < R; r += gridDim.x * SBL_THREADS) {
+                if (!t.ok[r]) continue;
+                sb_fix_add(sum, sb_read_term(t, r, k, src_s + (size_t)e * k, hk_s + (size_t)e * k * 2 * SB_NCNT, bad));
+            }
+            if (bad) atomicAdd(&guard[e], bad);
+            sum = sb_fix_wave_sum(sum);
+            if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                SbFix s2{0, 0, 0.0};
+                for (int w = 0; w < SBL_THREADS / 64; ++w) {
+                    s2.hi += red_s[w].hi;
+                    s2.lo += red_s[w].lo;
+                    s2.nf += red_s[w].nf;
+                }
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(&partial[(size_t)e * gridDim.x + blockIdx.x]);
+                sbr_st(dst, (unsigned long long)s2.hi);
+                sbr_st(dst + 1, s2.lo);
+                sbr_st(dst + 2, (unsigned long long)__double_as_longlong(s2.nf));
+            }
+            __syncthreads();
+        }
+        const unsigned long long t_loop = __builtin_amdgcn_s_memrealtime();
+        // ---- the last workgroup to get here folds
+        if (threadIdx.x == 0) {
+            sbr_stores_done(); // (its partial sums are out, its guard counts too)
+            last_s = __hip_atomic_fetch_add(&rs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (last_s) {
+            const unsigned long long t_last = __builtin_amdgcn_s_memrealtime();
+            const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+            for (uint32_t e = wave; e < n_states; e += SBL_THREADS / 64) { // the results first ...
+                SbFix f{0, 0, 0.0};
+                for (uint32_t i = lane; i < gridDim.x; i += 64) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&partial[(size_t)e * gridDim.x + i]);
+                    f.hi += (long long)sbr_ld(src);
+                    f.lo += sbr_ld(src + 1);
+                    f.nf += __longlong_as_double((long long)sbr_ld(src + 2));
+                }
+                f = sb_fix_wave_sum(f);
+                if (lane == 0) {
+                    sbr_st_sys(reinterpret_cast<unsigned long long *>(&out_host[e]), (unsigned long long)__double_as_longlong(sb_fix_value(f)));
+                    unsigned long long *fx = reinterpret_cast<unsigned long long *>(&fix_host[e]);
+                    sbr_st_sys(fx, (unsigned long long)f.hi);
+                    sbr_st_sys(fx + 1, f.lo);
+                    sbr_st_sys(fx + 2, (unsigned long long)__double_as_longlong(f.nf));
+                    sbr_st_sys(&guard_host[e], sbr_ld(&guard[e]));
+                    sbr_st(&guard[e], 0ull);
+                    sbr_stores_done();
+                }
+            }
+            const unsigned long long t_fold = __builtin_amdgcn_s_memrealtime();
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&rs->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the next refresh's counts start after the host has seen this one's number)
+                sbr_stores_done();
+            }
+            __syncthreads();
+            // ... then the number the host is watching
+            if (threadIdx.x < n_states) sbr_st_sys(&seq_host[threadIdx.x], seq);
+            if (threadIdx.x == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime(), t_seen = sbr_ld(&rs->t_seen);
+                sbr_st(&rs->stamp[1], t_tab - t_seen), sbr_st(&rs->stamp[2], t_loop - t_seen), sbr_st(&rs->stamp[3], t_last - t_seen);
+                sbr_st(&rs->stamp[4], t_fold - t_seen), sbr_st(&rs->stamp[5], now - t_seen);
+                sbr_st(&rs->busy, sbr_ld(&rs->busy) + now - t_seen);
+                sbr_st(&rs->served, sbr_ld(&rs->served) + 1);
+            }
+        }
+        done = seq;
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- read summaries
 // analyse_GAM's mostProbPath (getLCAfromGAM.h:563-579): the paths holding the read's highest pathMap value.  One lane per
 // read walks the pm rows (coalesced across lanes); best = that path when exactly one path holds the maximum, else -1.
@@ -780,6 +996,49 @@ void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k
     if (after_main) (void)hipEventRecord(after_main, st); // the timed interval is the fused kernel alone
     hipLaunchKernelGGL(sb_finish_host_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host, fix_host,
                        seq_host, seq);
+}
+
+size_t sb_mailbox_bytes() { return sizeof(SbMailbox); }
+size_t sb_resident_bytes() { return sizeof(SbResident); }
+void sb_mailbox_post(void *mailbox, uint32_t n_states, uint32_t k, const SbFusedArgs &a, unsigned long long seq) {
+    SbMailbox *mb = static_cast<SbMailbox *>(mailbox);
+    mb->a = a;
+    mb->n_states = n_states;
+    mb->k = k;
+    __atomic_store_n(&mb->seq, seq, __ATOMIC_RELEASE);
+}
+void sb_mailbox_idle(void *mailbox, unsigned long long done) { __atomic_store_n(&static_cast<SbMailbox *>(mailbox)->seq, done, __ATOMIC_RELEASE); }
+void sb_mailbox_stop(void *mailbox, bool on) { __atomic_store_n(&static_cast<SbMailbox *>(mailbox)->stop, on ? 1ull : 0ull, __ATOMIC_RELEASE); }
+unsigned long long sb_mailbox_exited(const void *mailbox) { return __atomic_load_n(&static_cast<const SbMailbox *>(mailbox)->exited, __ATOMIC_ACQUIRE); }
+void sb_mailbox_busy(void *mailbox, unsigned long long *ticks, unsigned long long *served, unsigned long long stamp[8]) {
+    SbMailbox *mb = static_cast<SbMailbox *>(mailbox);
+    *ticks = __atomic_load_n(&mb->busy, __ATOMIC_ACQUIRE);
+    *served = __atomic_load_n(&mb->served, __ATOMIC_ACQUIRE);
+    if (stamp)
+        for (int q = 0; q < 8; ++q) stamp[q] = mb->stamp[q];
+}
+// the largest grid the device holds as a whole, capped (0: the query failed)
+uint32_t sb_resident_grid(int device, uint32_t want) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sb_refresh_resident_kernel, SBL_THREADS, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu <= 0 || cus <= 0)
+        return 0;
+    // (half of what fits at most: a second context's kernel, or any other kernel of the process, still finds room beside it)
+    return std::min<uint32_t>(want, (uint32_t)per_cu * (uint32_t)cus / 2u);
+}
+__global__ void sb_resident_init_kernel(SbResident *rs, unsigned long long done) {
+    rs->seq = done;
+    rs->stop = 0;
+    rs->t_seen = 0;
+    rs->ticket = 0;
+}
+// (busy / served / stamp live on from launch to launch: the block is zeroed when it is made)
+void launch_sb_refresh_resident(const SbTablesDev &t, void *mailbox, void *resident, SbFix *partial, uint32_t n_blocks, unsigned long long *guard,
+                                double *out_host, unsigned long long *guard_host, SbFix *fix_host, unsigned long long *seq_host, unsigned long long done,
+                                unsigned long long idle_ticks, unsigned long long launch_id, hipStream_t st) {
+    hipLaunchKernelGGL(sb_resident_init_kernel, dim3(1), dim3(1), 0, st, static_cast<SbResident *>(resident), done);
+    hipLaunchKernelGGL(sb_refresh_resident_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, static_cast<SbMailbox *>(mailbox),
+                       static_cast<SbResident *>(resident), partial, guard, out_host, guard_host, fix_host, seq_host, done, idle_ticks, launch_id);
 }
 
 void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best, unsigned long long *sig_count,

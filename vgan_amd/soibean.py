@@ -117,6 +117,17 @@ class SbContext:
     def time_engine(self, on=True):
         N.check(N.lib().vgan_sb_time_engine(self._h, int(on)))
 
+    def resident(self, on=None):
+        """The engine's refresh through the kernel that stays on the device (vgan_sb_resident): set it, or ask with on=None."""
+        rc = N.lib().vgan_sb_resident(self._h, -1 if on is None else int(on))
+        N.check(rc)
+        return bool(rc) if on is None else None
+
+    def resident_launches(self):
+        n = C.c_uint64(0)
+        N.check(N.lib().vgan_sb_resident_launches(self._h, C.addressof(n)))
+        return int(n.value)
+
     def best_paths(self):
         """analyse_GAM's mostProbPath: (best[n_reads] with -1 for ties / excluded reads, sig_count[n_paths], n_reads_ok)."""
         best = np.zeros(max(self.n_reads, 1), np.int32)
