@@ -485,8 +485,8 @@ static int loglike_impl(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const vga
 }
 
 // n_states states of k sources each, results to the host: the per-iteration call of the chain driver (the chains of one source
-// count advance together) -- sb_refresh_fused_kernel with the sources as kernel arguments, then one wave per state folding
-// the partials into pinned host memory; bit-identical to vgan_sb_loglike.
+// count advance together) -- sb_refresh_fused_kernel with the sources as kernel arguments, its last workgroup folding the partials into
+// pinned host memory; bit-identical to vgan_sb_loglike.
 constexpr size_t SB_PIN_SEQ_OFF = 2 * SB_FUSED_MAX_K * 8 + SB_FUSED_MAX_K * sizeof(SbFix); // u64[16]: the refresh that wrote the entry
 constexpr size_t SB_PIN_BYTES = SB_PIN_SEQ_OFF + SB_FUSED_MAX_K * 8;
 
@@ -528,8 +528,8 @@ static int res_start(vgan_sb_ctx *c, uint64_t done, bool posted /* the mailbox h
         memset(c->pin, 0, SB_PIN_BYTES);
     }
     if (!c->ticket.p) {
-        if ((rc = c->ticket.reserve(SB_FUSED_MAX_K))) return rc;
-        HIPCHK(hipMemsetAsync(c->ticket.p, 0, SB_FUSED_MAX_K * 8, c->stream));
+        if ((rc = c->ticket.reserve(SB_FUSED_MAX_K + 1))) return rc; // (the guard words, then the last-to-finish count of the launched refresh)
+        HIPCHK(hipMemsetAsync(c->ticket.p, 0, (SB_FUSED_MAX_K + 1) * 8, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream)); // (the tables are final; the guard words are zero)
     double *pin_out = reinterpret_cast<double *>(c->pin);
@@ -595,8 +595,8 @@ static int refresh_launch(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const v
         memset(c->pin, 0, SB_PIN_BYTES);
     }
     if (!c->ticket.p) {
-        if ((rc = c->ticket.reserve(SB_FUSED_MAX_K))) return rc;
-        HIPCHK(hipMemsetAsync(c->ticket.p, 0, SB_FUSED_MAX_K * 8, c->stream));
+        if ((rc = c->ticket.reserve(SB_FUSED_MAX_K + 1))) return rc; // (the guard words, then the last-to-finish count of the launched refresh)
+        HIPCHK(hipMemsetAsync(c->ticket.p, 0, (SB_FUSED_MAX_K + 1) * 8, c->stream));
     }
     double *pin_out = reinterpret_cast<double *>(c->pin);
     unsigned long long *pin_guard = reinterpret_cast<unsigned long long *>(c->pin + SB_FUSED_MAX_K * 8);
@@ -615,10 +615,12 @@ static int refresh_launch(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const v
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
     }
     pd.seq = ++c->refresh_seq;
-    launch_sb_refresh_fused(c->t, n_states, k, a, c->partial.p, n_blocks, c->ticket.p, pin_out, pin_guard, pin_fix,
-                            reinterpret_cast<unsigned long long *>(c->pin + SB_PIN_SEQ_OFF), pd.seq, c->stream,
-                            c->time_refresh ? c->ev[3] : nullptr);
-    if (c->time_refresh) c->pending[1] = true;
+    launch_sb_refresh_fused(c->t, n_states, k, a, c->partial.p, n_blocks, c->ticket.p, reinterpret_cast<unsigned int *>(c->ticket.p + SB_FUSED_MAX_K), pin_out,
+                            pin_guard, pin_fix, reinterpret_cast<unsigned long long *>(c->pin + SB_PIN_SEQ_OFF), pd.seq, c->stream);
+    if (c->time_refresh) {
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        c->pending[1] = true;
+    }
     HIPCHK(hipGetLastError());
     return VGAN_OK;
 }

@@ -95,13 +95,13 @@ void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states
 void launch_sb_hky(uint32_t n_entries, const SbSourceDev *src, double con, const double *freqs7, double *hky,
                    unsigned long long *guard, uint32_t n_states, hipStream_t st);
 
-// n_states * k <= SB_FUSED_MAX_K sources, two launches, no copies: out_host / guard_host[n_states] are pinned host memory;
+// n_states * k <= SB_FUSED_MAX_K sources, one launch, no copies: out_host / guard_host[n_states] are pinned host memory;
 // fix_host[n_states] likewise (the sums themselves: a caller adding over several contexts takes these);
-// guard = n_states zeroed device words (left zeroed); partial: n_states * n_blocks entries.  Bit-identical to launch_sb_hky +
-// launch_sb_loglike.
+// guard = n_states zeroed device words (left zeroed), ticket = one zeroed device word (left zeroed); partial: n_states * n_blocks
+// entries.  Bit-identical to launch_sb_hky + launch_sb_loglike.
 void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, SbFix *partial, uint32_t n_blocks,
-                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host,
-                             unsigned long long *seq_host, unsigned long long seq, hipStream_t st, hipEvent_t after_main);
+                             unsigned long long *guard, unsigned int *ticket, double *out_host, unsigned long long *guard_host, SbFix *fix_host,
+                             unsigned long long *seq_host, unsigned long long seq, hipStream_t st);
 // The same refresh served by a kernel that stays on the device (sb_kernels.hip: sb_refresh_resident_kernel): mailbox = sb_mailbox_bytes() of
 // zeroed pinned host memory, resident = sb_resident_bytes() of zeroed device memory (seq = done), n_blocks <= sb_resident_grid().  The host
 // posts a refresh with sb_mailbox_post and watches seq_host as after launch_sb_refresh_fused.

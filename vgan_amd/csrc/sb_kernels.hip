@@ -645,17 +645,30 @@ __global__ __launch_bounds__(64) void sb_finish_kernel(const SbFix *__restrict__
     }
 }
 
-// The chain driver's refresh: one state, no copies.  The sources and frequencies arrive as kernel arguments and every block
-// builds the HKY table it needs in LDS (150 entries for k = 3); a one-wave kernel then folds the partials in the order
-// sb_finish_kernel uses -- so the result is bit-identical to the three-kernel path -- and stores the log-likelihood and the
-// guard count straight into pinned host memory.  An MCMC iteration is launch bound at typical read counts (10 us of kernel
-// time at 20k reads): this takes it from five stream operations to two.  (Folding in the last block to finish, behind a
-// device-scope fence and a ticket per block, measured slower at 1024 blocks than the second launch.)
-__global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesDev t, uint32_t n_states, uint32_t k, SbFusedArgs a,
-                                                                        SbFix *__restrict__ partial, unsigned long long *__restrict__ guard) {
+// Everything one workgroup writes for another (or for the host) goes and comes as RELAXED atomic accesses of the scope that reaches the
+// reader (they pass the caches on their own), ordered by the issuing thread's wait for its own stores: an acquire / release FENCE of agent
+// scope on this device writes back and invalidates the whole L2 of the XCD it runs on -- the first version, with fences, took 107 us for
+// the reads' loop the launched kernel does in 76, and 26 us for the fold.
+__device__ __forceinline__ unsigned long long sbr_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sbr_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long sbr_ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sbr_st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sbr_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); } // (the thread's stores are acknowledged)
+
+// The chain driver's refresh: one launch, no copies.  The sources and frequencies arrive as kernel arguments and every block builds the
+// HKY table it needs in LDS (150 entries for k = 3); the last workgroup to finish folds the workgroups' sums (integers: any order gives
+// the same bits as sb_finish_kernel's) and stores the log-likelihood, the sums and the guard count straight into pinned host memory,
+// then the refresh's number, which the host watches.  An MCMC iteration is launch bound at typical read counts (5 us of kernel time at
+// 20k reads).  (The fold was a second launch -- sb_finish_host_kernel -- through round 4: behind agent-scope fences the last workgroup's
+// fold measured slower than that launch; with the relaxed accesses above it is 4 us against the launch's 7 + the gap before it.)
+__global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesDev t, uint32_t n_states, uint32_t k, SbFusedArgs a, SbFix *partial,
+                                                                        unsigned long long *guard, unsigned int *ticket, double *out_host,
+                                                                        unsigned long long *guard_host, SbFix *fix_host, unsigned long long *seq_host,
+                                                                        unsigned long long seq) {
     __shared__ double hk_s[SB_FUSED_MAX_K * 2 * SB_NCNT];
     __shared__ SbSourceDev src_s[SB_FUSED_MAX_K];
     __shared__ SbFix red_s[SBL_THREADS / 64];
+    __shared__ uint32_t last_s;
     const uint32_t ne = n_states * k; // <= SB_FUSED_MAX_K
 #pragma unroll
     for (uint32_t y = 0; y < SB_FUSED_MAX_K; ++y)
@@ -684,27 +697,57 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesD
             sb_fix_add(sum, sb_read_term(t, r, k, src_s + (size_t)e * k, hk_s + (size_t)e * k * 2 * SB_NCNT, bad));
         }
         if (bad) atomicAdd(&guard[e], bad);
-        sb_fix_block_store(sum, red_s, &partial[(size_t)e * gridDim.x + blockIdx.x]);
+        sum = sb_fix_wave_sum(sum);
+        if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            SbFix s2{0, 0, 0.0};
+            for (int w = 0; w < SBL_THREADS / 64; ++w) {
+                s2.hi += red_s[w].hi;
+                s2.lo += red_s[w].lo;
+                s2.nf += red_s[w].nf;
+            }
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&partial[(size_t)e * gridDim.x + blockIdx.x]);
+            sbr_st(dst, (unsigned long long)s2.hi);
+            sbr_st(dst + 1, s2.lo);
+            sbr_st(dst + 2, (unsigned long long)__double_as_longlong(s2.nf));
+        }
+        __syncthreads();
     }
-}
-
-// one wave per state
-__global__ __launch_bounds__(64) void sb_finish_host_kernel(const SbFix *__restrict__ partial, uint32_t n_blocks,
-                                                            unsigned long long *__restrict__ guard, double *__restrict__ out_host,
-                                                            unsigned long long *__restrict__ guard_host, SbFix *__restrict__ fix_host,
-                                                            unsigned long long *__restrict__ seq_host, unsigned long long seq) {
-    const uint32_t e = blockIdx.x;
-    const SbFix s = sb_fix_fold(partial + (size_t)e * n_blocks, n_blocks);
+    // ---- the last workgroup to get here folds
     if (threadIdx.x == 0) {
-        out_host[e] = sb_fix_value(s);
-        if (fix_host) fix_host[e] = s;
-        guard_host[e] = guard[e];
-        guard[e] = 0; // ready for the next refresh (stream ordered)
-        if (seq_host) { // the host may be watching this word instead of waiting for the stream: results first, then the number
-            __threadfence_system();
-            __hip_atomic_store(&seq_host[e], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        sbr_stores_done(); // (its partial sums are out, its guard counts too)
+        last_s = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t e = wave; e < n_states; e += SBL_THREADS / 64) { // the results first ...
+        SbFix f{0, 0, 0.0};
+        for (uint32_t i = lane; i < gridDim.x; i += 64) {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&partial[(size_t)e * gridDim.x + i]);
+            f.hi += (long long)sbr_ld(src);
+            f.lo += sbr_ld(src + 1);
+            f.nf += __longlong_as_double((long long)sbr_ld(src + 2));
+        }
+        f = sb_fix_wave_sum(f);
+        if (lane == 0) {
+            sbr_st_sys(reinterpret_cast<unsigned long long *>(&out_host[e]), (unsigned long long)__double_as_longlong(sb_fix_value(f)));
+            if (fix_host) {
+                unsigned long long *fx = reinterpret_cast<unsigned long long *>(&fix_host[e]);
+                sbr_st_sys(fx, (unsigned long long)f.hi);
+                sbr_st_sys(fx + 1, f.lo);
+                sbr_st_sys(fx + 2, (unsigned long long)__double_as_longlong(f.nf));
+            }
+            sbr_st_sys(&guard_host[e], sbr_ld(&guard[e]));
+            sbr_st(&guard[e], 0ull); // ready for the next refresh (stream ordered)
+            sbr_stores_done();
         }
     }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // ... then the number the host may be watching instead of waiting for the stream
+    if (seq_host && threadIdx.x < n_states) sbr_st_sys(&seq_host[threadIdx.x], seq);
 }
 
 // The refresh as a resident kernel (MCMC.cpp:738-993 asks for one likelihood per iteration, and the iteration cannot go on before it has
@@ -734,15 +777,6 @@ struct SbResident { // device memory
     unsigned long long busy, served, stamp[8];
 };
 
-// Everything one workgroup writes for another (or for the host) goes and comes as RELAXED atomic accesses of the scope that reaches the
-// reader (they pass the caches on their own), ordered by the issuing thread's wait for its own stores: an acquire / release FENCE of agent
-// scope on this device writes back and invalidates the whole L2 of the XCD it runs on -- the first version, with fences, took 107 us for
-// the reads' loop the launched kernel does in 76, and 26 us for the fold.
-__device__ __forceinline__ unsigned long long sbr_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void sbr_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long sbr_ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void sbr_st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void sbr_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); } // (the thread's stores are acknowledged)
 static_assert(sizeof(SbFusedArgs) % 8 == 0 && sizeof(SbSourceDev) % 8 == 0 && sizeof(SbFix) == 24, "the resident kernel moves these as 64-bit words");
 
 __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_resident_kernel(SbTablesDev t, SbMailbox *mb, SbResident *rs, SbFix *partial,
@@ -990,12 +1024,10 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_mixture_kernel(SbTablesDev t, 
 
 // ---------------------------------------------------------------------------------------------- launchers
 void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k, const SbFusedArgs &a, SbFix *partial, uint32_t n_blocks,
-                             unsigned long long *guard, double *out_host, unsigned long long *guard_host, SbFix *fix_host,
-                             unsigned long long *seq_host, unsigned long long seq, hipStream_t st, hipEvent_t after_main) {
-    hipLaunchKernelGGL(sb_refresh_fused_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, n_states, k, a, partial, guard);
-    if (after_main) (void)hipEventRecord(after_main, st); // the timed interval is the fused kernel alone
-    hipLaunchKernelGGL(sb_finish_host_kernel, dim3(n_states), dim3(64), 0, st, partial, n_blocks, guard, out_host, guard_host, fix_host,
-                       seq_host, seq);
+                             unsigned long long *guard, unsigned int *ticket, double *out_host, unsigned long long *guard_host, SbFix *fix_host,
+                             unsigned long long *seq_host, unsigned long long seq, hipStream_t st) {
+    hipLaunchKernelGGL(sb_refresh_fused_kernel, dim3(n_blocks), dim3(SBL_THREADS), 0, st, t, n_states, k, a, partial, guard, ticket, out_host, guard_host,
+                       fix_host, seq_host, seq);
 }
 
 size_t sb_mailbox_bytes() { return sizeof(SbMailbox); }
