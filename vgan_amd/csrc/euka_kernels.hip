@@ -94,7 +94,10 @@ __device__ __forceinline__ double row_sum16(double v) {
 // plus a carry, so the columns are independent; per-read sums are row reductions; the per-read epilogue (log-sum-exp,
 // outputs, base shifts, bin coverage) runs for the wave's four reads at once.
 template <bool DMG_LDS>
-__global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, EukaBatchDev b, EukaOutDev o) {
+#ifndef EK_MIN_WAVES
+#define EK_MIN_WAVES 4 // waves per SIMD the register allocation aims at
+#endif
+__global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(EukaDev d, EukaBatchDev b, EukaOutDev o) {
     // {w_miss, w_hit - w_miss} = {eps(Q) / 3, (1 - eps(Q)) - eps(Q) / 3}: from a table -- an fp64 division is eleven instructions,
     // one of them the quarter-rate reciprocal, per column (w_hit itself is only needed on a softclip column: 1 - d.qscore[q] there)
     __shared__ double2 qs_s[100];
@@ -102,7 +105,9 @@ __global__ __launch_bounds__(EK_WAVES * 64, 4) void euka_read_kernel(EukaDev d, 
     // per (5' row, 3' row) pair, read base rb and original base o: {M[o][rb], rowsum[o]} -- what a column needs for one original
     // base in ONE 16-byte read, and the four original bases of a column (o, o ^ 1, o ^ 2, o ^ 3) at addresses that differ by an
     // exclusive-or of the 16-byte index (256 bytes per pair; the global table of euka_device.h keeps its 160)
-    __shared__ double2 dmg_s[DMG_LDS ? EK_DMG_LDS_PAIRS * 16 : 1];
+    // (sized by the launch: 256 bytes per pair of the context's tables, not the 64 pairs the variant allows -- the workgroups a CU holds
+    // follow its LDS)
+    extern __shared__ double2 dmg_s[];
     // byte -> class: low nibble = ACGT index 0..3, else 8; high nibble = the rank of the lambda's special cases in
     // the order it tests them (readGAM_Euka.h:236-280): 0 'N', 1 '-', 2 rare IUPAC code, 3 'S', 4 none
     __shared__ uint8_t cls_s[256];
@@ -683,7 +688,7 @@ void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev
     if (const char *e = getenv("VGAN_EUKA_BLOCKS")) cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap; // developer aid
     blocks = blocks < cap ? blocks : cap;
     if (d.n5 * d.n3 <= EK_DMG_LDS_PAIRS)
-        hipLaunchKernelGGL(euka_read_kernel<true>, dim3(blocks), dim3(EK_WAVES * 64), 0, st, d, b, o);
+        hipLaunchKernelGGL(euka_read_kernel<true>, dim3(blocks), dim3(EK_WAVES * 64), (size_t)d.n5 * d.n3 * 16u * sizeof(double2), st, d, b, o);
     else
         hipLaunchKernelGGL(euka_read_kernel<false>, dim3(blocks), dim3(EK_WAVES * 64), 0, st, d, b, o);
 }
