@@ -578,6 +578,33 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
         # on a CPU quota that, not the wall time of one stage, is what a long input's throughput follows)
         dev = {"reads_per_s": parts.n_reads / t_df, "host_cpu_us_per_read": cpu_df / parts.n_reads * 1e6, "reads_taken": int(res.pk.n_reads),
                "reads_left_to_the_host": int(res.host_mask.sum())}
+        # f1 on the device (vgan_gamdev): the FILE's bytes go up, BGZF inflate + framing + protobuf wire walk + duplicate marks + flatten
+        # are kernels; nothing but the mask of the reads left to the host comes back.  What `vgan haplocart` does with a BGZF GAM of
+        # 128 MB and more on one GPU (on this sample the fixed costs of a dozen launches and syncs weigh: tools/e2e_device_gam.py has
+        # the 10 M-read file)
+        try:
+            with tempfile.TemporaryDirectory(prefix="vgan_fe_") as d:
+                p = os.path.join(d, "sample.gam")
+                a.write_gam(p)
+                data = open(p, "rb").read()
+            gd = hc.GamDevice()
+            gd.parse(data)
+            df.run_gamdev(gd)  # (buffers)
+            t0, c0 = time.perf_counter(), time.process_time()
+            gd.parse(data)
+            t_parse = time.perf_counter() - t0
+            nd = gd.mark_duplicates()
+            t_dup = time.perf_counter() - t0 - t_parse
+            res2 = df.run_gamdev(gd, device_marks=True)
+            t_all, cpu_all = time.perf_counter() - t0, time.process_time() - c0
+            dev["device_gam"] = {"reads_per_s": gd.sizes["reads"] / t_all, "host_cpu_us_per_read": cpu_all / max(gd.sizes["reads"], 1) * 1e6,
+                                 "gam_bytes": len(data), "inflated_bytes": gd.sizes["inflated_bytes"], "parse_ms": t_parse * 1e3,
+                                 "parse_parts_ms": {k: round(v, 3) for k, v in gd.ms.items()}, "duplicate_marks_ms": t_dup * 1e3,
+                                 "duplicates": int(nd), "flatten_ms": (t_all - t_parse - t_dup) * 1e3,
+                                 "reads_taken": int(res2.pk.n_reads), "reads_left_to_the_host": int(res2.host_mask.sum())}
+            gd.close()
+        except Exception as e:  # (a figure beside the metric: its failure is reported, not fatal)
+            dev["device_gam"] = {"failed": repr(e)[:300]}
         df.close()
     from vgan_amd import _native as N
     return {"sample_reads": n, "gam_bytes": size, "decode_reads_per_s": n / t_dec, "flatten_reads_per_s": hb.n_reads / t_fl,

@@ -760,12 +760,12 @@ __global__ __launch_bounds__(256) void gd_gather_kernel(const uint8_t *__restric
                                                         const uint32_t *__restrict__ pick, const uint32_t *__restrict__ k_at, const uint32_t *__restrict__ b_at,
                                                         uint32_t n_msg, uint8_t *__restrict__ out, uint64_t *__restrict__ out_off) {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u; // a wave per message
+    if (wave == 0 && lane == 0) out_off[0] = 0; // (whether message 0 is among the picked or not)
     if (wave >= n_msg || !pick[wave]) return;
     const uint8_t *src = u + msg_off[wave];
     uint8_t *dst = out + b_at[wave];
     for (uint32_t k = lane; k < msg_len[wave]; k += 64u) dst[k] = src[k];
     if (lane == 0) out_off[k_at[wave] + 1] = (uint64_t)b_at[wave] + msg_len[wave];
-    if (wave == 0 && lane == 0) out_off[0] = 0;
 }
 
 } // namespace gd
@@ -865,6 +865,13 @@ template <class T> struct GBuf {
         const size_t want = n + n / 8 + 64;
         HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
+        // (test aid: fresh device memory is often zero in a young process and someone's old data in an old one -- a kernel that leaves
+        // an entry unwritten passes every test but the one that runs late)
+        static const bool poison = getenv("VGAN_POISON_ALLOCS") != nullptr;
+        if (poison) {
+            HIPCHK(hipMemset(p, 0xA5, want * sizeof(T)));
+            HIPCHK(hipDeviceSynchronize()); // (the fill runs on the null stream, the kernels that write the block on others)
+        }
         return VGAN_OK;
     }
     void release() {

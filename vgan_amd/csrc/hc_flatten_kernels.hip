@@ -412,6 +412,11 @@ template <class T> struct DBuf {
         const size_t want = n + n / 4 + 256;
         HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
+        static const bool poison = getenv("VGAN_POISON_ALLOCS") != nullptr; // (test aid, as csrc/gam_kernels.hip: GBuf)
+        if (poison) {
+            HIPCHK(hipMemset(p, 0xA5, want * sizeof(T)));
+            HIPCHK(hipDeviceSynchronize()); // (the fill runs on the null stream, the kernels that write the block on others)
+        }
         return VGAN_OK;
     }
     void release() {

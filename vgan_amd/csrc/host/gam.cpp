@@ -1252,12 +1252,16 @@ extern "C" int vgan_alnparts_from_messages(const uint8_t *bytes, const uint64_t 
     auto slice = [&](int64_t t) {
         const int64_t k0 = n * t / T, k1 = n * (t + 1) / T;
         vgan_alnset &a = ps->parts[(size_t)t];
-        if (k1 > k0) reserve_for(a, (size_t)(offsets[k1] - offsets[k0]), (size_t)(k1 - k0));
-        for (int64_t k = k0; k < k1; ++k)
-            if (offsets[k + 1] < offsets[k] || !parse_alignment(Cur{bytes + offsets[k], bytes + offsets[k + 1], true}, a, keep_unmapped)) {
-                bad[(size_t)t] = k;
-                return;
-            }
+        try {
+            if (k1 > k0 && offsets[k1] >= offsets[k0]) reserve_for(a, (size_t)(offsets[k1] - offsets[k0]), (size_t)(k1 - k0));
+            for (int64_t k = k0; k < k1; ++k)
+                if (offsets[k + 1] < offsets[k] || !parse_alignment(Cur{bytes + offsets[k], bytes + offsets[k + 1], true}, a, keep_unmapped)) {
+                    bad[(size_t)t] = k;
+                    return;
+                }
+        } catch (const std::bad_alloc &) { // (offsets that do not describe the bytes: a request for memory nobody has)
+            bad[(size_t)t] = k0;
+        }
     };
     parallel_run((int)T, [&](int t) { slice(t); });
     for (int64_t t = 0; t < T; ++t)
