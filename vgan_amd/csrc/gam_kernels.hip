@@ -2,10 +2,12 @@
 // protobuf's parser, serially): a BGZF file's bytes go up as they are, and
 //
 //   gd_inflate_kernel   DEFLATE (RFC 1951), one LANE per BGZF block: blocks are independent members of at most 64 KB.  A lane
-//                       decodes serially as a CPU would (canonical Huffman decoding bit by bit: the counts per code length
-//                       sit in registers, the symbol tables of the lane in LDS); a match is copied from the lane's own
-//                       output in groups of eight independent loads.  A lane is slow -- a 64 KB block takes milliseconds --
-//                       but a 10 M-read file is 75 000 blocks: every lane of the chip has one.
+//                       decodes serially as a CPU would, a wave steps its 64 lanes through one loop (a step = a block header, a
+//                       symbol, or eight bytes of a match).  A code's length comes from fifteen compares against limits kept in
+//                       registers (no loop over its bits), its symbol from the lane's column of the wave's tables in LDS; output
+//                       gathers in a register and leaves in aligned 8-byte words, a match is copied eight bytes to a load.  A lane
+//                       is slow -- a 64 KB block takes ~70 ms -- but a 10 M-read file is 200 000 blocks: every lane of the chip has
+//                       one, and the wave's instruction issue (~350 a step), not memory, is what the launch waits for.
 //   gd_anchor_kernel,   the framing of libvgio's stream ({count, count x (length, bytes)} groups, every group vg writes opened by the
 //   gd_frame_kernel     item "GAM"), one lane per SEGMENT of the inflated bytes: a lane finds the first group tag in its segment, walks
 //                       the items from there (csrc/host/gam.cpp: frame_segment) and goes on into the next segments until it
@@ -45,44 +47,48 @@ namespace gd {
 constexpr int INF_LIT = 288, INF_DIST = 30, INF_ROW = 322; // symbols per lane: 288 + 30, padded to an odd number of dwords (161)
 enum : uint32_t { GD_OK = 0, GD_BAD_BLOCK = 1, GD_BAD_CODE = 2, GD_OVERRUN_IN = 3, GD_OVERRUN_OUT = 4, GD_BAD_STORED = 5 };
 
-struct Bits { // LSB-first bit reader over 4-byte words (the payload is followed by the member's 8-byte trailer: a word read past
-    const uint8_t *p; // the payload's end stays inside the file)
-    const uint8_t *e;
+// LSB-first bit reader over 4-byte words, one word ahead: the word that refills `buf` was requested a refill earlier.  (The payload is
+// followed by the member's 8-byte trailer: a word read past the payload's end stays inside the file; past that nothing is read and zero
+// bits are fed -- bits_overran says whether any were consumed.)  A ring of the lane's input in LDS, topped up by all lanes together every
+// other step, was tried against the wait for these loads and measured SLOWER (110 against 76 ms for a wave alone): a wave alone spends its
+// time issuing instructions, ~350 a step with every path of the loop taken by some lane, not waiting.
+struct Bits {
+    const uint8_t *p; // the next word to request
+    const uint8_t *e; // the payload's end
     uint64_t buf;
-    uint32_t cnt;
-    bool over;
+    uint32_t cnt, nxt; // valid bits in buf; the word that goes in next
 };
+__device__ __forceinline__ uint32_t bits_word(Bits &b) {
+    uint32_t w = 0;
+    if (b.p + 4 <= b.e + 8) {
+        w = *reinterpret_cast<const uint32_t *>(b.p);
+        const int64_t left = b.e - b.p;
+        if (left < 4) w = left <= 0 ? 0u : w & ((1u << (8 * left)) - 1u);
+    }
+    b.p += 4;
+    return w;
+}
 __device__ __forceinline__ void bits_init(Bits &b, const uint8_t *p, const uint8_t *e) {
     b.p = p;
     b.e = e;
     b.buf = 0;
     b.cnt = 0;
-    b.over = false;
     while (((uintptr_t)b.p & 3u) && b.p < b.e) { // up to the first aligned word
         b.buf |= (uint64_t)*b.p++ << b.cnt;
         b.cnt += 8;
     }
+    if ((uintptr_t)b.p & 3u) { // a payload that ended before it: the bytes up to the word are fed as zero bits (bits_overran counts from p)
+        const uint32_t skip = 4u - (uint32_t)((uintptr_t)b.p & 3u);
+        b.p += skip;
+        b.cnt += 8u * skip;
+    }
+    b.nxt = bits_word(b);
 }
-__device__ __forceinline__ void bits_fill(Bits &b) { // at least 32 bits, or what is left
+__device__ __forceinline__ void bits_fill(Bits &b) { // at least 32 bits
     if (b.cnt < 32) {
-        if (b.p + 4 <= b.e + 8) { // (the trailer is readable)
-            uint32_t w = *reinterpret_cast<const uint32_t *>(b.p);
-            const int64_t left = b.e - b.p;
-            if (left < 4) {
-                if (left <= 0) {
-                    w = 0;
-                    b.over = b.over || b.cnt == 0; // (nothing real left at all)
-                } else {
-                    w &= (1u << (8 * left)) - 1u;
-                }
-            }
-            b.buf |= (uint64_t)w << b.cnt;
-            b.p += 4;
-            b.cnt += 32;
-        } else {
-            b.cnt += 32;
-            b.over = true;
-        }
+        b.buf |= (uint64_t)b.nxt << b.cnt;
+        b.cnt += 32;
+        b.nxt = bits_word(b);
     }
 }
 __device__ __forceinline__ uint32_t bits_get(Bits &b, uint32_t n) { // n <= 16
@@ -92,13 +98,14 @@ __device__ __forceinline__ uint32_t bits_get(Bits &b, uint32_t n) { // n <= 16
     b.cnt -= n;
     return v;
 }
-// bits consumed beyond the payload's end? (cnt counts phantom zero bits once p passed e)
-__device__ __forceinline__ bool bits_overran(const Bits &b) {
-    const int64_t avail = (int64_t)(b.e - b.p) * 8 + (int64_t)b.cnt;
-    return b.over || avail < 0;
+__device__ __forceinline__ void bits_drop(Bits &b, uint32_t n) { // behind a bits_fill
+    b.buf >>= n;
+    b.cnt -= n;
 }
+// bits consumed beyond the payload's end?  (fed so far: everything below p; not consumed: cnt and the 32 of nxt)
+__device__ __forceinline__ bool bits_overran(const Bits &b) { return (int64_t)(b.e - b.p) * 8 + (int64_t)b.cnt + 32 < 0; }
 
-// counts per code length 0..15, packed four to a 64-bit word (registers: the decode loop reads them without touching memory)
+// counts per code length 0..15, packed four to a 64-bit word
 struct Counts {
     uint64_t w[4];
 };
@@ -114,34 +121,48 @@ __device__ __forceinline__ void cnt_add(Counts &c, uint32_t len, uint32_t v) {
     else c.w[3] += add;
 }
 
-// canonical Huffman decode, one bit at a time (RFC 1951 3.2.2): -1 on an invalid code
-__device__ __forceinline__ int huff_decode(Bits &b, const Counts &c, const uint16_t *sym) {
-    bits_fill(b);
-    uint32_t code = 0, first = 0, index = 0;
-    uint64_t bitbuf = b.buf;
-    uint32_t left = b.cnt;
+// Canonical Huffman decoding without a loop over the code's bits.  With the next 15 stream bits as a number `peek` whose most significant
+// bit is the first bit read (codes are packed that way round, RFC 1951 3.1.1), the codes of length L are the numbers in
+// [limit[L-1], limit[L]) where limit[L] = (first code of length L + their count) << (15 - L): the length of the code in front is one more
+// than the number of limits not above peek -- fifteen compares against registers, the same for every lane -- and its symbol is
+// sym[base[L] + (peek >> (15 - L))] with base[L] = (symbols of shorter codes) - (first code of length L).  (The first version
+// walked the code bit by bit, as puff.c does: a literal of nine bits was nine rounds of the loop for the whole wave, 80 ms per block.)
+struct Dec {
+    uint32_t lim[8]; // limit[1..15], two to a word: limit[2i + 1] in the low half of lim[i], limit[2i + 2] in the high one (lim[7]: 0xFFFF)
+};
+__device__ __forceinline__ uint32_t dec_len(const Dec &d, uint32_t peek) { // 1..15, or 16: no code
+    uint32_t n = 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        n += peek >= (d.lim[i] & 0xFFFFu) ? 1u : 0u;
+        n += peek >= (d.lim[i] >> 16) ? 1u : 0u;
+    }
+    return n;
+}
+// {limits, bases} of the code whose counts are c (base[L] into base_t[(L - 1) * 64], the lane's column of the wave's table); returns the
+// number of coded symbols
+__device__ __forceinline__ uint32_t dec_build(const Counts &c, Dec &d, uint16_t *base_t) {
+    uint32_t code = 0, idx = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d.lim[i] = 0xFFFF0000u;
+#pragma unroll
     for (uint32_t len = 1; len <= 15; ++len) {
-        if (left == 0) return -1; // (fill gives >= 32 bits: not reached for codes of <= 15 bits)
-        code |= (uint32_t)bitbuf & 1u;
-        bitbuf >>= 1;
-        left -= 1;
-        const uint32_t count = cnt_get(c, len);
-        if (code < first + count) {
-            b.buf = bitbuf;
-            b.cnt = left;
-            return (int)sym[index + (code - first)];
-        }
-        index += count;
-        first += count;
-        first <<= 1;
+        const uint32_t cnt = cnt_get(c, len);
+        base_t[(len - 1u) * 64u] = (uint16_t)(idx - code);
+        code += cnt;
+        idx += cnt;
+        const uint32_t lim = code << (15u - len); // <= 2^15 for a set that is not over-subscribed
+        if ((len - 1u) & 1u) d.lim[(len - 1u) >> 1] = (d.lim[(len - 1u) >> 1] & 0xFFFFu) | (lim << 16);
+        else d.lim[(len - 1u) >> 1] = (d.lim[(len - 1u) >> 1] & 0xFFFF0000u) | lim;
         code <<= 1;
     }
-    return -1;
+    return idx;
 }
+__device__ __forceinline__ uint32_t bits_peek15(const Bits &b) { return __builtin_bitreverse32((uint32_t)b.buf) >> 17; }
 
-// builds {counts, symbols in canonical order} from code lengths; returns false for an over-subscribed set (an incomplete one
-// is allowed where RFC 1951 allows it: a single distance code)
-__device__ bool huff_build(const uint8_t *lengths, int n, Counts &c, uint16_t *sym) {
+// counts per length of `n` code lengths; false for an over-subscribed set (an incomplete one is allowed where RFC 1951 allows it: a
+// single distance code); offs[L] = symbols of shorter codes
+__device__ __forceinline__ bool huff_counts(const uint8_t *lengths, int n, Counts &c, uint16_t (&offs)[16]) {
     c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
     for (int s = 0; s < n; ++s) cnt_add(c, lengths[s], 1u);
     int left = 1;
@@ -150,13 +171,10 @@ __device__ bool huff_build(const uint8_t *lengths, int n, Counts &c, uint16_t *s
         left -= (int)cnt_get(c, len);
         if (left < 0) return false;
     }
-    uint16_t offs[16];
+    offs[0] = 0;
     offs[1] = 0;
     for (uint32_t len = 1; len < 15; ++len) offs[len + 1] = (uint16_t)(offs[len] + cnt_get(c, len));
-    for (int s = 0; s < n; ++s)
-        if (lengths[s] != 0) sym[offs[lengths[s]]++] = (uint16_t)s;
-    // (codes of length 0 are not codes: their count must not take part in decoding)
-    c.w[0] &= ~0xFFFFull;
+    c.w[0] &= ~0xFFFFull; // (codes of length 0 are not codes: their count must not take part in decoding)
     return true;
 }
 
@@ -167,178 +185,296 @@ __device__ const uint16_t gd_dist_base[30] = {1,   2,   3,   4,   5,   7,    9, 
 __device__ const uint8_t gd_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ const uint8_t gd_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// the lane's own earlier output, read past the vector L1 (a line the lane loaded before it stored into it may sit there)
-__device__ __forceinline__ uint8_t out_byte(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-#ifndef GD_INFLATE_LDS
-#define GD_INFLATE_LDS 0 // the lane's symbol tables in LDS (41 KB per wave: three waves to a CU) or in its private memory (as many waves as
-#endif                   // the registers allow: a block takes ~80 ms either way, so the waves in flight set the rate -- measured on a 10 M-read file)
-__global__ __launch_bounds__(64, 4) void gd_inflate_kernel(const uint8_t *__restrict__ in, const GdBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                           uint8_t *out, uint32_t *__restrict__ status) {
-#if GD_INFLATE_LDS
-    __shared__ uint16_t sym_s[64][INF_ROW];
+// eight bytes at any address (the hardware takes unaligned global accesses; the compiler is told so by the packed type)
+struct __attribute__((packed)) GdU64 {
+    uint64_t v;
+};
+#ifdef GD_X_NOLOAD
+__device__ __forceinline__ uint64_t gd_load8(const uint8_t *p) { return (uint64_t)(uintptr_t)p; }
+#else
+__device__ __forceinline__ uint64_t gd_load8(const uint8_t *p) { return reinterpret_cast<const GdU64 *>(p)->v; }
 #endif
+
+// The lane's output goes out in aligned 8-byte words: bytes gather in a register, a full word is ONE store.  (A byte store per literal
+// and eight byte loads + eight byte stores per piece of a match were ten vector-memory instructions per symbol, each to 64 different
+// cache lines -- 64 cycles of a CU's address unit each: with every lane of the chip busy that, not the decoding, set the 250 ms a
+// 10 M-read file took.)  `hole`: bytes of the first word that belong to the member in front (another lane's).
+struct OutBuf {
+    uint64_t w;
+    uint32_t fill, hole; // bytes of w that are decided (the hole included); of those, the first `hole` are not ours
+};
+__device__ __forceinline__ void ob_store(OutBuf &ob, uint8_t *word_at) { // a full word, or what there is of it (hole .. fill)
+    if (ob.fill == 8u && ob.hole == 0u) {
+#ifndef GD_X_NOSTORE
+        *reinterpret_cast<uint64_t *>(word_at) = ob.w;
+#endif
+    } else {
+        for (uint32_t k = ob.hole; k < ob.fill; ++k) word_at[k] = (uint8_t)(ob.w >> (8u * k));
+    }
+}
+
+// One lane per BGZF member, the wave stepped by ONE loop: a step is a block header (with the code tables: the cold part, a few per
+// member), one symbol, or eight bytes of a match -- a lane in the middle of a long match or at a block header holds the other 63 up for a
+// step of its own kind and no longer.  The symbol tables (canonical order; low byte + a bit for the symbols from 256 on) and the bases are
+// in LDS, one column per lane (26 KB per wave: six waves to a CU); the fifteen limits of either code in registers.
+constexpr uint32_t GD_LIT_ROWS = 288, GD_DIST_ROWS = 30;
+__global__ __launch_bounds__(64) void gd_inflate_kernel(const uint8_t *__restrict__ in, const GdBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                        uint8_t *out, uint32_t *__restrict__ status) {
+    __shared__ uint8_t lit_s[GD_LIT_ROWS][64];
+    __shared__ uint32_t hi_s[(GD_LIT_ROWS + 31) / 32][64];
+    __shared__ uint8_t dsym_s[GD_DIST_ROWS][64];
+    __shared__ uint16_t base_s[2][15][64];
+    __shared__ uint32_t len_s[29], dist_s[30]; // base | extra bits << 16
     const uint32_t lane = threadIdx.x, b = blockIdx.x * 64u + lane;
+    if (lane < 29) len_s[lane] = gd_len_base[lane] | ((uint32_t)gd_len_extra[lane] << 16);
+    if (lane < 30) dist_s[lane] = gd_dist_base[lane] | ((uint32_t)gd_dist_extra[lane] << 16);
+    __syncthreads();
     if (b >= n_blocks) return;
     const GdBlock bl = blocks[b];
-#if GD_INFLATE_LDS
-    uint16_t *lsym = sym_s[lane], *dsym = lsym + INF_LIT;
-#else
-    uint16_t sym_p[INF_ROW];
-    uint16_t *lsym = sym_p, *dsym = lsym + INF_LIT;
-#endif
+    uint8_t *lit = &lit_s[0][lane], *dsy = &dsym_s[0][lane];
+    uint32_t *hi = &hi_s[0][lane];
+    uint16_t *lbase = &base_s[0][0][lane], *dbase = &base_s[1][0][lane];
     uint8_t *o = out + bl.out_off;
     const uint32_t o_cap = bl.out_size;
-    uint32_t pos = 0, err = GD_OK;
+    uint32_t pos = 0, err = GD_OK; // pos: bytes decoded (those waiting in ob included)
+    OutBuf ob;
+    ob.hole = ob.fill = (uint32_t)((uintptr_t)o & 7u);
+    ob.w = 0;
     Bits br;
     bits_init(br, in + bl.in_off, in + bl.in_off + bl.in_size);
-    uint8_t lengths[INF_LIT + INF_DIST + 2]; // (scratch)
-    for (bool last = false; !last && err == GD_OK;) {
-        last = bits_get(br, 1) != 0;
-        const uint32_t type = bits_get(br, 2);
-        if (type == 0) { // stored
-            const uint32_t drop = br.cnt & 7u;
-            br.buf >>= drop;
-            br.cnt -= drop;
-            const uint32_t len = bits_get(br, 16), nlen = bits_get(br, 16);
-            if ((len ^ 0xFFFFu) != nlen) {
-                err = GD_BAD_STORED;
-                break;
-            }
-            if (pos + len > o_cap) {
-                err = GD_OVERRUN_OUT;
-                break;
-            }
-            for (uint32_t i = 0; i < len; ++i) o[pos + i] = (uint8_t)bits_get(br, 8);
-            pos += len;
-            continue;
+    Dec ld, dd;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld.lim[i] = dd.lim[i] = 0u;
+    uint32_t n_lit = 0, n_dist = 0;
+    bool in_block = false, last = false;
+    uint32_t cp_len = 0, cp_dist = 0;
+    // the word the next byte goes into starts at o + pos - ob.fill (pos counts the bytes that wait in ob; fill counts the hole too)
+    auto put = [&](uint64_t v, uint32_t n) { // n <= 8 bytes (the bytes of v above them zero) behind what is there
+        const uint32_t f = ob.fill;
+        ob.w |= v << (8u * f);
+        if (f + n >= 8u) {
+            ob.fill = 8u;
+            ob_store(ob, o + pos - f);
+            ob.hole = 0u;
+            ob.w = f ? v >> (8u * (8u - f)) : 0ull;
+            ob.fill = f + n - 8u;
+        } else {
+            ob.fill = f + n;
         }
-        if (type == 3) {
-            err = GD_BAD_BLOCK;
-            break;
-        }
-        Counts lc, dc;
-        if (type == 1) { // fixed codes
-            for (int s = 0; s < 144; ++s) lengths[s] = 8;
-            for (int s = 144; s < 256; ++s) lengths[s] = 9;
-            for (int s = 256; s < 280; ++s) lengths[s] = 7;
-            for (int s = 280; s < 288; ++s) lengths[s] = 8;
-            (void)huff_build(lengths, 288, lc, lsym);
-            for (int s = 0; s < 30; ++s) lengths[s] = 5;
-            (void)huff_build(lengths, 30, dc, dsym);
-        } else { // dynamic codes
-            const uint32_t nlen = bits_get(br, 5) + 257, ndist = bits_get(br, 5) + 1, ncode = bits_get(br, 4) + 4;
-            if (nlen > 286 || ndist > 30) {
-                err = GD_BAD_BLOCK;
-                break;
-            }
-            for (int s = 0; s < 19; ++s) lengths[s] = 0;
-            for (uint32_t i = 0; i < ncode; ++i) lengths[gd_clen_order[i]] = (uint8_t)bits_get(br, 3);
-            Counts cc;
-            if (!huff_build(lengths, 19, cc, lsym)) { // (the code-length code borrows the literal table's room)
-                err = GD_BAD_BLOCK;
-                break;
-            }
-            uint32_t idx = 0;
-            while (idx < nlen + ndist) {
-                const int s = huff_decode(br, cc, lsym);
-                if (s < 0) {
-                    err = GD_BAD_CODE;
-                    break;
+        pos += n;
+    };
+    auto flush = [&]() { // what waits goes out as bytes; the word goes on from there
+        ob_store(ob, o + pos - ob.fill);
+        ob.hole = ob.fill; // (those bytes are in memory: not to be written again)
+    };
+    for (;;) {
+        if (!in_block) { // ---- a block header (cold)
+            if (last || err != GD_OK) break;
+            last = bits_get(br, 1) != 0;
+            const uint32_t type = bits_get(br, 2);
+            if (type == 0) { // stored
+                const uint32_t drop = br.cnt & 7u;
+                bits_drop(br, drop);
+                const uint32_t len = bits_get(br, 16), nlen = bits_get(br, 16);
+                if ((len ^ 0xFFFFu) != nlen) {
+                    err = GD_BAD_STORED;
+                    continue;
                 }
-                if (s < 16) {
-                    lengths[idx++] = (uint8_t)s;
-                } else {
-                    uint32_t rep, val = 0;
-                    if (s == 16) {
-                        if (idx == 0) {
+                if (pos + len > o_cap) {
+                    err = GD_OVERRUN_OUT;
+                    continue;
+                }
+                for (uint32_t i = 0; i < len; ++i) put(bits_get(br, 8), 1u);
+                if (bits_overran(br)) err = GD_OVERRUN_IN;
+                continue;
+            }
+            if (type == 3) {
+                err = GD_BAD_BLOCK;
+                continue;
+            }
+            uint8_t lengths[GD_LIT_ROWS + GD_DIST_ROWS + 4]; // (scratch)
+            uint32_t nlen = 288, ndist = 30;
+            if (type == 1) { // fixed codes
+                for (int s = 0; s < 144; ++s) lengths[s] = 8;
+                for (int s = 144; s < 256; ++s) lengths[s] = 9;
+                for (int s = 256; s < 280; ++s) lengths[s] = 7;
+                for (int s = 280; s < 288; ++s) lengths[s] = 8; // (286 and 287 never occur but take part in the code's construction)
+                for (int s = 0; s < 30; ++s) lengths[nlen + s] = 5;
+            } else { // dynamic codes
+                nlen = bits_get(br, 5) + 257;
+                ndist = bits_get(br, 5) + 1;
+                const uint32_t ncode = bits_get(br, 4) + 4;
+                if (nlen > 286 || ndist > 30) {
+                    err = GD_BAD_BLOCK;
+                    continue;
+                }
+                uint8_t cl[19];
+                for (int s = 0; s < 19; ++s) cl[s] = 0;
+                for (uint32_t i = 0; i < ncode; ++i) cl[gd_clen_order[i]] = (uint8_t)bits_get(br, 3);
+                Counts cc;
+                uint16_t offs[16];
+                if (!huff_counts(cl, 19, cc, offs)) {
+                    err = GD_BAD_BLOCK;
+                    continue;
+                }
+                for (int s = 0; s < 19; ++s) // (the code-length code's symbols borrow the distance table's column)
+                    if (cl[s] != 0) dsy[(uint32_t)(offs[cl[s]]++) * 64u] = (uint8_t)s;
+                Dec cd;
+                (void)dec_build(cc, cd, dbase);
+                uint32_t idx = 0;
+                while (idx < nlen + ndist && err == GD_OK) {
+                    bits_fill(br);
+                    const uint32_t pk = bits_peek15(br), cl_len = dec_len(cd, pk);
+                    const uint32_t ci = cl_len > 15u ? 0xFFFFu : ((uint32_t)dbase[(cl_len - 1u) * 64u] + (pk >> (15u - cl_len))) & 0xFFFFu;
+                    if (ci >= 19u) {
+                        err = GD_BAD_CODE;
+                        break;
+                    }
+                    const uint32_t s = dsy[ci * 64u];
+                    bits_drop(br, cl_len);
+                    if (s < 16u) {
+                        lengths[idx++] = (uint8_t)s;
+                    } else {
+                        uint32_t rep, val = 0;
+                        if (s == 16u) {
+                            if (idx == 0) {
+                                err = GD_BAD_BLOCK;
+                                break;
+                            }
+                            val = lengths[idx - 1];
+                            rep = 3 + bits_get(br, 2);
+                        } else if (s == 17u) {
+                            rep = 3 + bits_get(br, 3);
+                        } else {
+                            rep = 11 + bits_get(br, 7);
+                        }
+                        if (idx + rep > nlen + ndist) {
                             err = GD_BAD_BLOCK;
                             break;
                         }
-                        val = lengths[idx - 1];
-                        rep = 3 + bits_get(br, 2);
-                    } else if (s == 17) {
-                        rep = 3 + bits_get(br, 3);
-                    } else {
-                        rep = 11 + bits_get(br, 7);
+                        while (rep--) lengths[idx++] = (uint8_t)val;
                     }
-                    if (idx + rep > nlen + ndist) {
-                        err = GD_BAD_BLOCK;
-                        break;
-                    }
-                    while (rep--) lengths[idx++] = (uint8_t)val;
+                }
+                if (err != GD_OK) continue;
+                if (lengths[256] == 0) {
+                    err = GD_BAD_BLOCK;
+                    continue;
                 }
             }
-            if (err != GD_OK) break;
-            if (lengths[256] == 0 || !huff_build(lengths, (int)nlen, lc, lsym) || !huff_build(lengths + nlen, (int)ndist, dc, dsym)) {
+            Counts lc, dc;
+            uint16_t offs[16];
+            if (!huff_counts(lengths, (int)nlen, lc, offs)) {
                 err = GD_BAD_BLOCK;
-                break;
-            }
-        }
-        // ---- the block's symbols
-        for (;;) {
-            const int s = huff_decode(br, lc, lsym);
-            if (s < 0) {
-                err = GD_BAD_CODE;
-                break;
-            }
-            if (s < 256) {
-                if (pos >= o_cap) {
-                    err = GD_OVERRUN_OUT;
-                    break;
-                }
-                o[pos++] = (uint8_t)s;
                 continue;
             }
-            if (s == 256) break;
-            if (s > 285) {
-                err = GD_BAD_CODE;
-                break;
-            }
-            const uint32_t len = gd_len_base[s - 257] + bits_get(br, gd_len_extra[s - 257]);
-            const int ds = huff_decode(br, dc, dsym);
-            if (ds < 0 || ds > 29) {
-                err = GD_BAD_CODE;
-                break;
-            }
-            const uint32_t dist = gd_dist_base[ds] + bits_get(br, gd_dist_extra[ds]);
-            if (dist > pos) { // (BGZF members carry no preset dictionary: nothing lies before the member's own output)
-                err = GD_BAD_CODE;
-                break;
-            }
-            if (pos + len > o_cap) {
-                err = GD_OVERRUN_OUT;
-                break;
-            }
-            const uint8_t *src = o + pos - dist;
-            uint8_t *dst = o + pos;
-            if (dist >= 8) { // groups of eight independent loads (a group never reaches into bytes it writes itself)
-                uint32_t i = 0;
-                for (; i + 8 <= len; i += 8) {
-                    uint8_t t[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) t[k] = out_byte(src + i + k);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) dst[i + k] = t[k];
+            for (uint32_t k = 0; k < (GD_LIT_ROWS + 31) / 32; ++k) hi[k * 64u] = 0u;
+            for (uint32_t s = 0; s < nlen; ++s)
+                if (lengths[s] != 0) {
+                    const uint32_t at = offs[lengths[s]]++;
+                    lit[at * 64u] = (uint8_t)s;
+                    if (s >= 256u) hi[(at >> 5) * 64u] |= 1u << (at & 31u);
                 }
-                for (; i < len; ++i) dst[i] = out_byte(src + i);
-            } else { // a short period: the pattern is read once and repeated out of registers
-                uint8_t pat[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) pat[k] = k < (int)dist ? out_byte(src + k) : 0;
-                uint32_t k = 0;
-                for (uint32_t i = 0; i < len; ++i) {
-                    uint8_t v = pat[0];
-#pragma unroll
-                    for (int j = 1; j < 8; ++j) v = k == (uint32_t)j ? pat[j] : v;
-                    dst[i] = v;
-                    k = k + 1 == dist ? 0 : k + 1;
-                }
+            n_lit = dec_build(lc, ld, lbase);
+            if (!huff_counts(lengths + nlen, (int)ndist, dc, offs)) {
+                err = GD_BAD_BLOCK;
+                continue;
             }
-            pos += len;
+            for (uint32_t s = 0; s < ndist; ++s)
+                if (lengths[nlen + s] != 0) dsy[(uint32_t)(offs[lengths[nlen + s]]++) * 64u] = (uint8_t)s;
+            n_dist = dec_build(dc, dd, dbase);
+            in_block = true;
+            continue;
         }
-        if (err == GD_OK && bits_overran(br)) err = GD_OVERRUN_IN;
+        if (cp_len) { // ---- eight bytes of a match whose source lies sixteen bytes and more behind: all of them are in memory
+            const uint32_t n = min(cp_len, 8u);
+            uint64_t v = gd_load8(o + pos - cp_dist);
+            if (n < 8u) v &= (1ull << (8u * n)) - 1ull;
+            put(v, n);
+            cp_len -= n;
+            continue;
+        }
+        // ---- a symbol
+        bits_fill(br);
+        uint32_t peek = bits_peek15(br);
+        const uint32_t ll = dec_len(ld, peek);
+        const uint32_t li = ll > 15u ? 0xFFFFu : ((uint32_t)lbase[(ll - 1u) * 64u] + (peek >> (15u - ll))) & 0xFFFFu;
+        if (li >= n_lit) { // no code (or one of a set that holds fewer)
+            err = GD_BAD_CODE;
+            in_block = false;
+            continue;
+        }
+        const uint32_t lo = lit[li * 64u], is_hi = (hi[(li >> 5) * 64u] >> (li & 31u)) & 1u;
+        bits_drop(br, ll);
+        if (!is_hi) {
+            if (pos >= o_cap) {
+                err = GD_OVERRUN_OUT;
+                in_block = false;
+                continue;
+            }
+            put(lo, 1u);
+            continue;
+        }
+        if (lo == 0u) { // 256: end of block
+            in_block = false;
+            if (bits_overran(br)) err = GD_OVERRUN_IN;
+            continue;
+        }
+        if (lo > 29u) { // (286, 287: in the fixed code, never in a stream)
+            err = GD_BAD_CODE;
+            in_block = false;
+            continue;
+        }
+        const uint32_t lt = len_s[lo - 1u];
+        const uint32_t len = (lt & 0xFFFFu) + bits_get(br, lt >> 16); // (the extra bits: at most 5 of the >= 17 left)
+        bits_fill(br);
+        peek = bits_peek15(br);
+        const uint32_t dl = dec_len(dd, peek);
+        const uint32_t di = dl > 15u ? 0xFFFFu : ((uint32_t)dbase[(dl - 1u) * 64u] + (peek >> (15u - dl))) & 0xFFFFu;
+        if (di >= n_dist) { // (no code, or a code of an incomplete set that is not there)
+            err = GD_BAD_CODE;
+            in_block = false;
+            continue;
+        }
+        const uint32_t ds = dsy[di * 64u];
+        bits_drop(br, dl);
+        if (ds > 29u) {
+            err = GD_BAD_CODE;
+            in_block = false;
+            continue;
+        }
+        const uint32_t dt = dist_s[ds];
+        const uint32_t dist = (dt & 0xFFFFu) + bits_get(br, dt >> 16); // (bits_get refills: up to 13 more)
+        if (dist > pos) { // (BGZF members carry no preset dictionary: nothing lies before the member's own output)
+            err = GD_BAD_CODE;
+            in_block = false;
+            continue;
+        }
+        if (pos + len > o_cap) {
+            err = GD_OVERRUN_OUT;
+            in_block = false;
+            continue;
+        }
+        if (dist >= 16u) { // the copy goes on in the steps that follow
+            cp_len = len;
+            cp_dist = dist;
+        } else { // a short period: what waits goes out, the pattern is read once and repeated out of registers
+            flush();
+            const uint8_t *src = o + pos - dist;
+            uint8_t pat[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pat[k] = k < (int)dist ? src[k] : 0;
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < len; ++i) {
+                uint8_t v = pat[0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j) v = k == (uint32_t)j ? pat[j] : v;
+                put(v, 1u);
+                k = k + 1 == dist ? 0 : k + 1;
+            }
+        }
     }
+    flush();
+    if (err == GD_OK && bits_overran(br)) err = GD_OVERRUN_IN;
     if (err == GD_OK && pos != o_cap) err = GD_OVERRUN_OUT; // (ISIZE says how long the member's output is)
     status[b] = err;
 }
@@ -822,7 +958,7 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
             return fail(VGAN_ENODEV, "vgan_gamdev_inflate_bytes: %s failed", #expr);      \
         }                                                                                 \
     } while (0)
-    GDCHK(hipMalloc((void **)&d_in, n + 16));
+    GDCHK(hipMalloc((void **)&d_in, n + 64));
     GDCHK(hipMalloc((void **)&d_out, total + 16));
     GDCHK(hipMalloc((void **)&d_b, gb.size() * sizeof(GdBlock) + 16));
     GDCHK(hipMalloc((void **)&d_s, gb.size() * 4 + 16));
