@@ -714,8 +714,10 @@ struct GdOut { // the arrays of one DfSlice (hc_flatten_kernels.hip) and what th
 // the places the exclusive sums give it.
 template <bool FILL>
 __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, double &identity, int32_t &mapq, const GdOut &o, uint32_t m0, uint32_t e0,
-                                 uint32_t s0, uint32_t q0, int64_t &first_node, int64_t &first_off) {
+                                 uint32_t s0, uint32_t q0, int64_t &first_node, int64_t &first_off, const uint8_t *&q_src, uint32_t &q_n) {
     GdCur c{mp, mp + mlen, true};
+    q_src = nullptr; // FILL: the message's first quality string is left to the caller (the wave copies its lanes' strings together)
+    q_n = 0;
     sz = GdSizes{0, 0, 0, 0};
     identity = 0.0;
     mapq = 0;
@@ -793,8 +795,14 @@ __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, 
         } else if (f == 4 && wt == 2) {
             GdCur sc = gc_sub(c);
             const uint32_t nb = (uint32_t)(sc.e - sc.p);
-            if (FILL && sc.ok)
-                for (uint32_t k = 0; k < nb; ++k) o.qual[q0 + sz.qual + k] = sc.p[k];
+            if (FILL && sc.ok) {
+                if (!q_src && sz.qual == 0) {
+                    q_src = sc.p;
+                    q_n = nb;
+                } else { // (a second quality field: appended, as the host parser does)
+                    for (uint32_t k = 0; k < nb; ++k) o.qual[q0 + sz.qual + k] = sc.p[k];
+                }
+            }
             sz.qual += sc.ok ? nb : 0u;
         } else if (f == 5 && wt == 0) {
             mapq = (int32_t)gc_varint(c);
@@ -822,7 +830,9 @@ __global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict
     double identity;
     int32_t mapq;
     int64_t fn, fo;
-    const bool ok = gd_parse_message<false>(u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, 0, 0, 0, 0, fn, fo);
+    const uint8_t *qs;
+    uint32_t qn;
+    const bool ok = gd_parse_message<false>(u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, 0, 0, 0, 0, fn, fo, qs, qn);
     if (!ok) atomicAdd(bad, 1u);
     const bool kp = ok && (keep_unmapped || identity != 0.0); // readGAM.h:47: "Discard unmapped reads"
     keep[i] = kp ? 1u : 0u;
@@ -843,19 +853,36 @@ __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict_
         o.edit_off[0] = 0;
         o.e_seq_off[0] = 0;
     }
-    if (i >= n_msg || !keep[i]) return;
-    GdSizes sz;
-    double identity;
-    int32_t mapq;
-    int64_t fn, fo;
-    const uint32_t r = r_at[i];
-    (void)gd_parse_message<true>(u + msg_off[i], msg_len[i], sz, identity, mapq, o, m_at[i], e_at[i], s_at[i], q_at[i], fn, fo);
-    o.map_off[r + 1] = m_at[i] + sz.n_map;
-    o.qual_off[r + 1] = q_at[i] + sz.qual;
-    o.mapq[r] = mapq;
-    o.unmapped[r] = identity < 1e-10 ? 1 : 0; // HaploCart.cpp:410
-    o.first_node[r] = fn;
-    o.first_offset[r] = fo;
+    const uint8_t *q_src = nullptr;
+    uint32_t q_n = 0, q_dst = 0;
+    if (i < n_msg && keep[i]) {
+        GdSizes sz;
+        double identity;
+        int32_t mapq;
+        int64_t fn, fo;
+        const uint32_t r = r_at[i];
+        (void)gd_parse_message<true>(u + msg_off[i], msg_len[i], sz, identity, mapq, o, m_at[i], e_at[i], s_at[i], q_at[i], fn, fo, q_src, q_n);
+        q_dst = q_at[i];
+        o.map_off[r + 1] = m_at[i] + sz.n_map;
+        o.qual_off[r + 1] = q_at[i] + sz.qual;
+        o.mapq[r] = mapq;
+        o.unmapped[r] = identity < 1e-10 ? 1 : 0; // HaploCart.cpp:410
+        o.first_node[r] = fn;
+        o.first_offset[r] = fo;
+    }
+    // the quality strings of the wave's 64 messages, one after the other with all lanes: 64 bytes to a load (a lane copying its own string
+    // byte by byte is a load and a store to 64 different cache lines per byte: two thirds of this kernel's time)
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t has = __builtin_amdgcn_ballot_w64(q_n != 0u);
+    while (has) {
+        const int l = __builtin_ctzll(has);
+        has &= has - 1;
+        const uint64_t sp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)(uintptr_t)q_src >> 32), l) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)q_src, l);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)q_n, l), d = (uint32_t)__builtin_amdgcn_readlane((int)q_dst, l);
+        const uint8_t *src = reinterpret_cast<const uint8_t *>((uintptr_t)sp);
+        for (uint32_t k = lane; k < n; k += 64u) o.qual[d + k] = src[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ duplicates
