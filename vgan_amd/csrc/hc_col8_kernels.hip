@@ -138,7 +138,10 @@ __device__ __forceinline__ c8_rsrc c8_make_rsrc(const void *p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, (int)C8_BUF_FLAGS);
 }
 __device__ __forceinline__ uint32_t c8_load_u16(c8_rsrc r, uint32_t off) { return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0); }
-__device__ __forceinline__ uint32_t c8_load1(c8_rsrc r, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); }
+#ifndef C8_STREAM_AUX
+#define C8_STREAM_AUX 0 // cache policy of the loads that stream the batch through (records read once): 2 = non-temporal
+#endif
+__device__ __forceinline__ uint32_t c8_load1(c8_rsrc r, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, C8_STREAM_AUX); }
 __device__ __forceinline__ uint2 c8_load2(c8_rsrc r, uint32_t off) {
     using v2 = __attribute__((__vector_size__(2 * sizeof(int)))) int;
     const v2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
@@ -146,7 +149,7 @@ __device__ __forceinline__ uint2 c8_load2(c8_rsrc r, uint32_t off) {
 }
 __device__ __forceinline__ uint4 c8_load4(c8_rsrc r, uint32_t off) {
     using v4 = __attribute__((__vector_size__(4 * sizeof(int)))) int;
-    const v4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    const v4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, C8_STREAM_AUX);
     return uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
 }
 
