@@ -601,7 +601,10 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
                                  "gam_bytes": len(data), "inflated_bytes": gd.sizes["inflated_bytes"], "parse_ms": t_parse * 1e3,
                                  "parse_parts_ms": {k: round(v, 3) for k, v in gd.ms.items()}, "duplicate_marks_ms": t_dup * 1e3,
                                  "duplicates": int(nd), "flatten_ms": (t_all - t_parse - t_dup) * 1e3,
-                                 "reads_taken": int(res2.pk.n_reads), "reads_left_to_the_host": int(res2.host_mask.sum())}
+                                 "reads_taken": int(res2.pk.n_reads), "reads_left_to_the_host": int(res2.host_mask.sum()),
+                                 "what": "the sample GAM's bytes -> inflate, framing, protobuf walk, duplicate marks, flatten as kernels.  A BGZF member is "
+                                         "one lane's work for ~75 ms however few members there are, so a sample this size is all latency: the 10 M-read "
+                                         "file of tools/e2e_device_gam.py runs at 9 M reads/s end to end through `vgan haplocart` (DESIGN.md section 4.6)"}
             gd.close()
         except Exception as e:  # (a figure beside the metric: its failure is reported, not fatal)
             dev["device_gam"] = {"failed": repr(e)[:300]}
