@@ -434,7 +434,7 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
             const uint32_t q_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h_q, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
             if ((uint32_t)lane < T.n) {
                 const uint32_t A = h_am & 0xFFFFu, QL = min(q_next - h_q, 0xFFFFu);
-                const uint32_t mq = min(h_am >> 16, 99u), major = mq == (uint32_t)VGAN_HC_MAPQ_MAJOR ? 0x800000u : 0u;
+                const uint32_t mq = min(h_am >> 16, 99u), major = mq == (uint32_t)VGAN_HC_MAPQ_MAJOR ? 0x80000000u : 0u; // (the sign bit: one compare tells)
                 L.rdA[lane] = uint2{A | (QL << 16), min(h_c - T.c_base, (uint32_t)C8_CAPC) | (mq << 16) | major};
             }
         }
@@ -450,15 +450,29 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
         // ---- Q: prefix sums of {Q above 2: Q << 11, else 1} over the tile's columns, from byte 2 of the records
         bool q_plain, tile_hot; // every quality byte of the tile in [0, C8_QMAX); one at 90 or above (bytes are signed, as the reference reads them)
         {
-            uint32_t loc[C8_CPL], run = 0u;
-            int mn = 127, mx = -128;
+            uint32_t loc[C8_CPL], run = 0u, mxu = 0u; // mxu: the largest quality byte read as UNSIGNED (a negative one is 128 and above)
 #pragma unroll
             for (int e = 0; e < C8_CPL; ++e) {
-                const int Q = __builtin_amdgcn_sbfe((int)rec[e], 16u, 8u);
-                run += Q > 2 ? (uint32_t)Q << 11 : 1u;
+                // byte 2 taken where it is used (SDWA): Q << 11, Q > 2, max -- no extraction of its own
+                uint32_t q11, term;
+                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(q11) : "v"(11u), "v"(rec[e]));
+                asm("v_cmp_lt_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_2\n\tv_cndmask_b32 %0, 1, %3, vcc" : "=v"(term) : "v"(2u), "v"(rec[e]), "v"(q11) : "vcc");
+                asm("v_max_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(mxu) : "v"(rec[e]), "v"(mxu));
+                run += term;
                 loc[e] = run;
-                mn = min(mn, Q);
-                mx = max(mx, Q);
+            }
+            int mn = 0, mx = (int)mxu;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mxu >= 90u) != 0, 0)) { // a byte at 90 or above, or a negative one: the signed form
+                run = 0u;
+                mn = 127, mx = -128;
+#pragma unroll
+                for (int e = 0; e < C8_CPL; ++e) {
+                    const int Q = __builtin_amdgcn_sbfe((int)rec[e], 16u, 8u);
+                    run += Q > 2 ? (uint32_t)Q << 11 : 1u;
+                    loc[e] = run;
+                    mn = min(mn, Q);
+                    mx = max(mx, Q);
+                }
             }
             const uint32_t incl = c8_scan_u32(run);
             const uint32_t before = incl - run;
@@ -508,12 +522,14 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
         bool tile_out = false; // a mapping of the tile lies outside the W window (wave uniform)
         bool tile_bep = false; // a mapping of the tile takes the background error rate on its own (wave uniform)
         uint64_t sticky_m[C8_SPASS];
-        uint32_t seg_rb[C8_SPASS]; // byte offset of the read's mapping quality in the context's table of column terms
+        uint2 rd[C8_SPASS]; // the mappings' reads (rdA)
         {
             // (the three passes side by side, stage by stage: their LDS round trips overlap; a pass beyond the tile's segments works
             // on zero records and changes nothing)
-            uint32_t kr[C8_SPASS], hi[C8_SPASS], gap[C8_SPASS], p_lo[C8_SPASS], p_hi[C8_SPASS], seg_flags = 0u;
-            uint2 rd[C8_SPASS];
+            uint32_t kr[C8_SPASS], hi[C8_SPASS], gap[C8_SPASS], p_lo[C8_SPASS], p_hi[C8_SPASS];
+            // lanes with a mapping outside the window / on a node class outside the tables / of a read of another mapping quality: the
+            // compares' own masks, combined on the scalar unit (the vector unit is what this kernel waits for)
+            uint64_t out_m = 0, cls_m = 0, minor_m = 0;
 #pragma unroll
             for (int k = 0; k < C8_SPASS; ++k) {
                 kr[k] = ((sr[k] >> 29) - T.r) & 7u;
@@ -533,11 +549,18 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
             for (int k = 0; k < C8_SPASS; ++k) {
                 sticky_m[k] = 0;
                 const uint32_t ls = (uint32_t)k * 64u + (uint32_t)lane;
-                const bool on = ls < T.n_seg;
                 const uint32_t pkd = p_hi[k] - p_lo[k];
                 const uint32_t n_low = (pkd & 2047u) + gap[k], sq = pkd >> 11;
                 const uint32_t node = sr[k] & VGAN_HC_SREC_MAX_NODE, sl = node - winbase;
-                const bool inside = sl < (uint32_t)C8_WIN;
+                uint64_t on_m, in_m, c_m, mj_m;
+                asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(on_m) : "v"(ls), "s"(T.n_seg));
+                asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(in_m) : "v"(sl), "s"((uint32_t)C8_WIN));
+                asm("v_cmp_le_u32 %0, %2, %1" : "=s"(c_m) : "v"(nhi[k]), "s"(0xE000u));
+                asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(mj_m) : "v"(rd[k].y));
+                const bool on = __builtin_amdgcn_inverse_ballot_w64(on_m), inside = __builtin_amdgcn_inverse_ballot_w64(in_m);
+                out_m |= on_m & ~in_m;
+                cls_m |= on_m & c_m;
+                minor_m |= on_m & ~mj_m;
 
                 L.info[ls + 1u] = (inside ? sl * 8u : C8_OUTSIDE) | ((nhi[k] + memo_base) << 16);
                 if (on) {
@@ -554,17 +577,10 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                     sticky_m[k] = __builtin_amdgcn_ballot_w64(sticky);
                     tile_bep = tile_bep || sticky_m[k] != 0;
                 }
-                // per lane, counted over its mappings (one a pass, eight passes at most): those outside the window (bits 0-7), on a node
-                // class outside the tables (bits 8-15), of a read of another mapping quality (bits 16-23) -- three ballots a tile
-                // instead of three a pass
-                const uint32_t bits = (inside ? 0u : 1u) + (nhi[k] >= 0xE000u ? 0x100u : 0u) + ((rd[k].y & 0x800000u) ? 0u : 0x10000u);
-                seg_flags += on ? bits : 0u;
-                seg_rb[k] = ((rd[k].y >> 16) & 0x7Fu) * (uint32_t)(C8_NMEMO * C8_CLS_BYTES);
             }
-            static_assert(C8_SPASS <= 255, "the counts' fields");
-            all_cls = __builtin_amdgcn_ballot_w64((seg_flags & 0xFF00u) != 0u) == 0;
-            all_major = __builtin_amdgcn_ballot_w64((seg_flags & 0xFF0000u) != 0u) == 0;
-            const uint32_t n_out = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((seg_flags & 0xFFu) != 0u));
+            all_cls = cls_m == 0;
+            all_major = minor_m == 0;
+            const uint32_t n_out = (uint32_t)__builtin_popcountll(out_m);
             tile_out = n_out != 0;
             if (n_out > 8) need_place = true; // (the next tile places the window anew)
         }
@@ -573,7 +589,8 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
         C8_MARK(2);
         if (gfast) {
 #pragma unroll
-            for (int k = 0; k < C8_SPASS; ++k) L.ps[4 + k * 64 + lane] = seg_rb[k]; // (over the dead prefix sums; ps[3] = 0 stays)
+            for (int k = 0; k < C8_SPASS; ++k) // byte offset of the read's mapping quality in the context's table (over the dead prefix sums; ps[3] = 0 stays)
+                L.ps[4 + k * 64 + lane] = ((rd[k].y >> 16) & 0x7Fu) * (uint32_t)(C8_NMEMO * C8_CLS_BYTES);
         }
         if (__builtin_expect(!tabled, 0)) {
             // a general tile: {kappa, lw} per segment over the (now dead) prefix sums
