@@ -46,9 +46,13 @@ for tag, env in (("host", {"VGAN_HC_DEVICE_GAM": "0"}), ("device", {"VGAN_HC_DEV
     if r.returncode:
         print(r.stderr[-1500:])
     outs[tag] = open(d + "/" + tag + ".tsv").read().splitlines()[-1] if os.path.exists(d + "/" + tag + ".tsv") else None
-print(outs["host"])
+print(outs["host"], "|", outs["device"])
 print("same result line:", outs["host"] == outs["device"])
 ll = {}
 for tag in ("host", "device"):
     ll[tag] = dict((ln.split("\t")[0], float(ln.split("\t")[1])) for ln in open(d + "/" + tag + ".tsv.loglik.tsv").read().splitlines())
 print("max rel diff of the log-likelihoods:", max(abs(ll["host"][k] - ll["device"][k]) / abs(ll["host"][k]) for k in ll["host"]))
+if outs["host"] != outs["device"]:  # (paths the reads do not tell apart: the sums' last bits -- the order of the additions -- pick among them)
+    a, b = outs["host"].split("\t")[1], outs["device"].split("\t")[1]
+    print("predicted %s against %s: their log-likelihoods as printed (10 digits) %r and %r -- %s" % (
+        a, b, ll["host"][a], ll["host"][b], "a tie" if ll["host"][a] == ll["host"][b] else "NOT a tie"))

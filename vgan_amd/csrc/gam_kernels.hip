@@ -6,8 +6,8 @@
 //                       symbol, or eight bytes of a match).  A code's length comes from fifteen compares against limits kept in
 //                       registers (no loop over its bits), its symbol from the lane's column of the wave's tables in LDS; output
 //                       gathers in a register and leaves in aligned 8-byte words, a match is copied eight bytes to a load.  A lane
-//                       is slow -- a 64 KB block takes ~70 ms -- but a 10 M-read file is 200 000 blocks: every lane of the chip has
-//                       one, and the wave's instruction issue (~350 a step), not memory, is what the launch waits for.
+//                       is slow -- a 64 KB block takes ~50 ms -- but a 10 M-read file is 200 000 blocks: every lane of the chip has
+//                       one.
 //   gd_anchor_kernel,   the framing of libvgio's stream ({count, count x (length, bytes)} groups, every group vg writes opened by the
 //   gd_frame_kernel     item "GAM"), one lane per SEGMENT of the inflated bytes: a lane finds the first group tag in its segment, walks
 //                       the items from there (csrc/host/gam.cpp: frame_segment) and goes on into the next segments until it
@@ -247,9 +247,23 @@ __global__ __launch_bounds__(64) void gd_inflate_kernel(const uint8_t *__restric
     for (int i = 0; i < 8; ++i) ld.lim[i] = dd.lim[i] = 0u;
     uint32_t n_lit = 0, n_dist = 0;
     bool in_block = false, last = false;
-    uint32_t cp_len = 0, cp_dist = 0;
+    uint32_t cp_len = 0, cp_dist = 0, m_len = 0, sp_n = 0; // a match under way: bytes to go, distance; the length waiting for its distance; bytes a step of a short period
+    uint64_t sp0 = 0, sp1 = 0;                              // a short period's bytes
+    bool cp_short = false, want_dist = false;
     // the word the next byte goes into starts at o + pos - ob.fill (pos counts the bytes that wait in ob; fill counts the hole too)
-    auto put = [&](uint64_t v, uint32_t n) { // n <= 8 bytes (the bytes of v above them zero) behind what is there
+    // the last 16 bytes of output, newest last (byte 7 of h_hi): a match whose source begins less than 16 bytes back takes its period from
+    // here -- some of those bytes are still waiting in ob, and sending them out as single bytes first (and the rest of their word as
+    // single bytes later) was most of the kernel's store instructions
+    uint64_t h_lo = 0, h_hi = 0;
+    auto put = [&](uint64_t v, uint32_t n) { // n in 1..8 bytes (the bytes of v above them zero) behind what is there
+        if (n == 8u) {
+            h_lo = h_hi;
+            h_hi = v;
+        } else {
+            const uint32_t sh = 8u * n; // 8..56
+            h_lo = (h_lo >> sh) | (h_hi << (64u - sh));
+            h_hi = (h_hi >> sh) | (v << (64u - sh));
+        }
         const uint32_t f = ob.fill;
         ob.w |= v << (8u * f);
         if (f + n >= 8u) {
@@ -385,92 +399,108 @@ __global__ __launch_bounds__(64) void gd_inflate_kernel(const uint8_t *__restric
             in_block = true;
             continue;
         }
-        if (cp_len) { // ---- eight bytes of a match whose source lies sixteen bytes and more behind: all of them are in memory
-            const uint32_t n = min(cp_len, 8u);
-            uint64_t v = gd_load8(o + pos - cp_dist);
-            if (n < 8u) v &= (1ull << (8u * n)) - 1ull;
-            put(v, n);
-            cp_len -= n;
+        if (cp_len) { // ---- eight bytes of a match
+            if (!cp_short) { // its source lies sixteen bytes and more behind: all of it is in memory
+                const uint32_t n = min(cp_len, 8u);
+                uint64_t v = gd_load8(o + pos - cp_dist);
+                if (n < 8u) v &= (1ull << (8u * n)) - 1ull;
+                put(v, n);
+                cp_len -= n;
+            } else { // a short period: out of the registers that hold it (a whole number of periods a step: the phase stays 0)
+                const uint32_t n0 = min(cp_len, min(sp_n, 8u));
+                put(n0 < 8u ? sp0 & ((1ull << (8u * n0)) - 1ull) : sp0, n0);
+                cp_len -= n0;
+                if (sp_n > 8u && cp_len) {
+                    const uint32_t n1 = min(cp_len, sp_n - 8u); // < 8
+                    put(sp1 & ((1ull << (8u * n1)) - 1ull), n1);
+                    cp_len -= n1;
+                }
+            }
             continue;
         }
-        // ---- a symbol
+        // ---- a code: of the literal / length alphabet, or -- the step after a length -- of the distance alphabet, through the same
+        // instructions (a lane that stood at a distance code used to run them a second time with the other 63 waiting)
         bits_fill(br);
-        uint32_t peek = bits_peek15(br);
-        const uint32_t ll = dec_len(ld, peek);
-        const uint32_t li = ll > 15u ? 0xFFFFu : ((uint32_t)lbase[(ll - 1u) * 64u] + (peek >> (15u - ll))) & 0xFFFFu;
-        if (li >= n_lit) { // no code (or one of a set that holds fewer)
+        const uint32_t peek = bits_peek15(br);
+        Dec cur;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur.lim[i] = want_dist ? dd.lim[i] : ld.lim[i];
+        const uint32_t cl = dec_len(cur, peek);
+        const uint32_t ci = cl > 15u ? 0xFFFFu : ((uint32_t)(want_dist ? dbase : lbase)[(cl - 1u) * 64u] + (peek >> (15u - cl))) & 0xFFFFu;
+        if (ci >= (want_dist ? n_dist : n_lit)) { // no code (or one of a set that holds fewer)
             err = GD_BAD_CODE;
             in_block = false;
             continue;
         }
-        const uint32_t lo = lit[li * 64u], is_hi = (hi[(li >> 5) * 64u] >> (li & 31u)) & 1u;
-        bits_drop(br, ll);
-        if (!is_hi) {
+        const uint32_t sym = (want_dist ? dsy : lit)[ci * 64u];
+        const uint32_t is_hi = want_dist ? 0u : (hi[(ci >> 5) * 64u] >> (ci & 31u)) & 1u;
+        bits_drop(br, cl); // (at least 17 bits are left: the extra bits of a length, 5 at most, or of a distance, 13 at most, need no refill)
+        if (want_dist) { // ---- the distance: the match begins
+            want_dist = false;
+            if (sym > 29u) {
+                err = GD_BAD_CODE;
+                in_block = false;
+                continue;
+            }
+            const uint32_t dt = dist_s[sym], xb = dt >> 16;
+            const uint32_t dist = (dt & 0xFFFFu) + ((uint32_t)br.buf & ((1u << xb) - 1u));
+            bits_drop(br, xb);
+            if (dist > pos) { // (BGZF members carry no preset dictionary: nothing lies before the member's own output)
+                err = GD_BAD_CODE;
+                in_block = false;
+                continue;
+            }
+            if (pos + m_len > o_cap) {
+                err = GD_OVERRUN_OUT;
+                in_block = false;
+                continue;
+            }
+            cp_len = m_len;
+            cp_dist = dist;
+            cp_short = dist < 16u;
+            if (cp_short) { // the period's bytes: the last `dist` of the sixteen kept in registers
+                if (dist >= 8u) {
+                    const uint32_t sh = 8u * (16u - dist); // 8..64
+                    sp0 = sh == 64u ? h_hi : (h_lo >> sh) | (h_hi << (64u - sh));
+                    sp1 = sh == 64u ? 0ull : h_hi >> sh; // (its first dist - 8 bytes are used)
+                    sp_n = dist;
+                } else {
+                    const uint64_t v0 = h_hi >> (8u * (8u - dist));
+                    uint64_t ext = v0 & ((1ull << (8u * dist)) - 1ull);
+                    ext |= ext << (8u * dist);                  // 2 periods (dist < 8: the shifts stay below 64)
+                    if (dist < 4u) ext |= ext << (16u * dist);  // 4
+                    if (dist < 2u) ext |= ext << 32;            // 8
+                    sp0 = ext;
+                    sp1 = 0;
+                    sp_n = (8u / dist) * dist;
+                }
+            }
+            continue;
+        }
+        if (!is_hi) { // ---- a literal
             if (pos >= o_cap) {
                 err = GD_OVERRUN_OUT;
                 in_block = false;
                 continue;
             }
-            put(lo, 1u);
+            put(sym, 1u);
             continue;
         }
-        if (lo == 0u) { // 256: end of block
+        if (sym == 0u) { // 256: end of block
             in_block = false;
             if (bits_overran(br)) err = GD_OVERRUN_IN;
             continue;
         }
-        if (lo > 29u) { // (286, 287: in the fixed code, never in a stream)
+        if (sym > 29u) { // (286, 287: in the fixed code, never in a stream)
             err = GD_BAD_CODE;
             in_block = false;
             continue;
         }
-        const uint32_t lt = len_s[lo - 1u];
-        const uint32_t len = (lt & 0xFFFFu) + bits_get(br, lt >> 16); // (the extra bits: at most 5 of the >= 17 left)
-        bits_fill(br);
-        peek = bits_peek15(br);
-        const uint32_t dl = dec_len(dd, peek);
-        const uint32_t di = dl > 15u ? 0xFFFFu : ((uint32_t)dbase[(dl - 1u) * 64u] + (peek >> (15u - dl))) & 0xFFFFu;
-        if (di >= n_dist) { // (no code, or a code of an incomplete set that is not there)
-            err = GD_BAD_CODE;
-            in_block = false;
-            continue;
-        }
-        const uint32_t ds = dsy[di * 64u];
-        bits_drop(br, dl);
-        if (ds > 29u) {
-            err = GD_BAD_CODE;
-            in_block = false;
-            continue;
-        }
-        const uint32_t dt = dist_s[ds];
-        const uint32_t dist = (dt & 0xFFFFu) + bits_get(br, dt >> 16); // (bits_get refills: up to 13 more)
-        if (dist > pos) { // (BGZF members carry no preset dictionary: nothing lies before the member's own output)
-            err = GD_BAD_CODE;
-            in_block = false;
-            continue;
-        }
-        if (pos + len > o_cap) {
-            err = GD_OVERRUN_OUT;
-            in_block = false;
-            continue;
-        }
-        if (dist >= 16u) { // the copy goes on in the steps that follow
-            cp_len = len;
-            cp_dist = dist;
-        } else { // a short period: what waits goes out, the pattern is read once and repeated out of registers
-            flush();
-            const uint8_t *src = o + pos - dist;
-            uint8_t pat[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) pat[k] = k < (int)dist ? src[k] : 0;
-            uint32_t k = 0;
-            for (uint32_t i = 0; i < len; ++i) {
-                uint8_t v = pat[0];
-#pragma unroll
-                for (int j = 1; j < 16; ++j) v = k == (uint32_t)j ? pat[j] : v;
-                put(v, 1u);
-                k = k + 1 == dist ? 0 : k + 1;
-            }
+        { // ---- a length: its distance code is the next step's
+            const uint32_t lt = len_s[sym - 1u], xb = lt >> 16;
+            m_len = (lt & 0xFFFFu) + ((uint32_t)br.buf & ((1u << xb) - 1u));
+            bits_drop(br, xb);
+            want_dist = true;
         }
     }
     flush();
