@@ -189,11 +189,7 @@ __device__ const uint8_t gd_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 
 struct __attribute__((packed)) GdU64 {
     uint64_t v;
 };
-#ifdef GD_X_NOLOAD
-__device__ __forceinline__ uint64_t gd_load8(const uint8_t *p) { return (uint64_t)(uintptr_t)p; }
-#else
 __device__ __forceinline__ uint64_t gd_load8(const uint8_t *p) { return reinterpret_cast<const GdU64 *>(p)->v; }
-#endif
 
 // The lane's output goes out in aligned 8-byte words: bytes gather in a register, a full word is ONE store.  (A byte store per literal
 // and eight byte loads + eight byte stores per piece of a match were ten vector-memory instructions per symbol, each to 64 different
@@ -205,9 +201,7 @@ struct OutBuf {
 };
 __device__ __forceinline__ void ob_store(OutBuf &ob, uint8_t *word_at) { // a full word, or what there is of it (hole .. fill)
     if (ob.fill == 8u && ob.hole == 0u) {
-#ifndef GD_X_NOSTORE
         *reinterpret_cast<uint64_t *>(word_at) = ob.w;
-#endif
     } else {
         for (uint32_t k = ob.hole; k < ob.fill; ++k) word_at[k] = (uint8_t)(ob.w >> (8u * k));
     }
@@ -689,23 +683,46 @@ struct GdCur {
     const uint8_t *p, *e;
     bool ok;
 };
+// The walk's bytes come eight to a load: the window holds bytes [base, base + 8) of the inflated stream (which has 64 bytes of slack
+// behind it), a byte outside it moves it.  (A byte to a load, every load of the wave touched 64 cache lines and the next byte waited
+// for it: a message of 60 mappings was ~1000 dependent loads.)
+struct GdWin {
+    const uint8_t *base;
+    uint64_t w;
+};
+__device__ __forceinline__ uint32_t gc_byte(GdWin &win, const uint8_t *p) {
+    uint64_t d = (uint64_t)(p - win.base);
+    if (d >= 8u) {
+        win.base = p;
+        win.w = gd_load8(p);
+        d = 0;
+    }
+    return (uint32_t)(win.w >> (8u * (uint32_t)d)) & 0xFFu;
+}
 __device__ __forceinline__ bool gc_done(const GdCur &c) { return c.p >= c.e; }
-__device__ __forceinline__ uint64_t gc_varint(GdCur &c) {
-    if (c.p < c.e && !(*c.p & 0x80)) return *c.p++;
+__device__ __forceinline__ uint64_t gc_varint(GdCur &c, GdWin &win) {
+    if (c.p < c.e) {
+        const uint32_t b0 = gc_byte(win, c.p);
+        if (!(b0 & 0x80u)) {
+            c.p += 1;
+            return b0;
+        }
+    }
     uint64_t v = 0;
     int shift = 0;
     while (c.p < c.e) {
-        const uint8_t b = *c.p++;
-        v |= (uint64_t)(b & 0x7f) << shift;
-        if (!(b & 0x80)) return v;
+        const uint32_t b = gc_byte(win, c.p);
+        c.p += 1;
+        v |= (uint64_t)(b & 0x7fu) << shift;
+        if (!(b & 0x80u)) return v;
         shift += 7;
         if (shift > 63) break;
     }
     c.ok = false;
     return 0;
 }
-__device__ __forceinline__ GdCur gc_sub(GdCur &c) {
-    const uint64_t n = gc_varint(c);
+__device__ __forceinline__ GdCur gc_sub(GdCur &c, GdWin &win) {
+    const uint64_t n = gc_varint(c, win);
     if (!c.ok || n > (uint64_t)(c.e - c.p)) {
         c.ok = false;
         return GdCur{c.p, c.p, false};
@@ -714,14 +731,14 @@ __device__ __forceinline__ GdCur gc_sub(GdCur &c) {
     c.p += n;
     return s;
 }
-__device__ __forceinline__ void gc_skip(GdCur &c, int wt) {
+__device__ __forceinline__ void gc_skip(GdCur &c, int wt, GdWin &win) {
     switch (wt) {
-    case 0: (void)gc_varint(c); break;
+    case 0: (void)gc_varint(c, win); break;
     case 1:
         if (c.e - c.p >= 8) c.p += 8;
         else c.ok = false;
         break;
-    case 2: (void)gc_sub(c); break;
+    case 2: (void)gc_sub(c, win); break;
     case 5:
         if (c.e - c.p >= 4) c.p += 4;
         else c.ok = false;
@@ -746,6 +763,7 @@ template <bool FILL>
 __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, double &identity, int32_t &mapq, const GdOut &o, uint32_t m0, uint32_t e0,
                                  uint32_t s0, uint32_t q0, int64_t &first_node, int64_t &first_off, const uint8_t *&q_src, uint32_t &q_n) {
     GdCur c{mp, mp + mlen, true};
+    GdWin win{mp - 8, 0}; // (nothing loaded yet: the first byte asked for moves it)
     q_src = nullptr; // FILL: the message's first quality string is left to the caller (the wave copies its lanes' strings together)
     q_n = 0;
     sz = GdSizes{0, 0, 0, 0};
@@ -754,47 +772,47 @@ __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, 
     first_node = -1;
     first_off = 0;
     while (!gc_done(c) && c.ok) {
-        const uint64_t key = gc_varint(c);
+        const uint64_t key = gc_varint(c, win);
         const int f = (int)(key >> 3), wt = (int)(key & 7);
         if (f == 2 && wt == 2) {
-            GdCur path = gc_sub(c);
+            GdCur path = gc_sub(c, win);
             while (!gc_done(path) && path.ok) {
-                const uint64_t k2 = gc_varint(path);
+                const uint64_t k2 = gc_varint(path, win);
                 const int f2 = (int)(k2 >> 3), w2 = (int)(k2 & 7);
                 if (f2 == 2 && w2 == 2) { // a mapping
-                    GdCur mc = gc_sub(path);
+                    GdCur mc = gc_sub(path, win);
                     if (!path.ok) return false;
                     int64_t node = 0, off = 0;
                     uint8_t rev = 0;
                     while (!gc_done(mc) && mc.ok) {
-                        const uint64_t k3 = gc_varint(mc);
+                        const uint64_t k3 = gc_varint(mc, win);
                         const int f3 = (int)(k3 >> 3), w3 = (int)(k3 & 7);
                         if (f3 == 1 && w3 == 2) { // position
-                            GdCur pc = gc_sub(mc);
+                            GdCur pc = gc_sub(mc, win);
                             while (!gc_done(pc) && pc.ok) {
-                                const uint64_t k4 = gc_varint(pc);
+                                const uint64_t k4 = gc_varint(pc, win);
                                 const int f4 = (int)(k4 >> 3), w4 = (int)(k4 & 7);
-                                if (f4 == 1 && w4 == 0) node = (int64_t)gc_varint(pc);
-                                else if (f4 == 2 && w4 == 0) off = (int64_t)gc_varint(pc);
-                                else if (f4 == 4 && w4 == 0) rev = gc_varint(pc) != 0;
-                                else gc_skip(pc, w4);
+                                if (f4 == 1 && w4 == 0) node = (int64_t)gc_varint(pc, win);
+                                else if (f4 == 2 && w4 == 0) off = (int64_t)gc_varint(pc, win);
+                                else if (f4 == 4 && w4 == 0) rev = gc_varint(pc, win) != 0;
+                                else gc_skip(pc, w4, win);
                             }
                             if (!pc.ok) return false;
                         } else if (f3 == 2 && w3 == 2) { // an edit
-                            GdCur ec = gc_sub(mc);
+                            GdCur ec = gc_sub(mc, win);
                             if (!mc.ok) return false;
                             int32_t from = 0, to = 0;
                             const uint8_t *sb = nullptr, *se = nullptr;
                             while (!gc_done(ec) && ec.ok) {
-                                const uint64_t k4 = gc_varint(ec);
+                                const uint64_t k4 = gc_varint(ec, win);
                                 const int f4 = (int)(k4 >> 3), w4 = (int)(k4 & 7);
-                                if (f4 == 1 && w4 == 0) from = (int32_t)gc_varint(ec);
-                                else if (f4 == 2 && w4 == 0) to = (int32_t)gc_varint(ec);
+                                if (f4 == 1 && w4 == 0) from = (int32_t)gc_varint(ec, win);
+                                else if (f4 == 2 && w4 == 0) to = (int32_t)gc_varint(ec, win);
                                 else if (f4 == 3 && w4 == 2) {
-                                    GdCur sc = gc_sub(ec);
+                                    GdCur sc = gc_sub(ec, win);
                                     sb = sc.p;
                                     se = sc.e;
-                                } else gc_skip(ec, w4);
+                                } else gc_skip(ec, w4, win);
                             }
                             if (!ec.ok) return false;
                             const uint32_t nb = sb ? (uint32_t)(se - sb) : 0u;
@@ -805,7 +823,7 @@ __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, 
                             }
                             sz.n_edit += 1;
                             sz.eseq += nb;
-                        } else gc_skip(mc, w3);
+                        } else gc_skip(mc, w3, win);
                     }
                     if (!mc.ok) return false;
                     if (sz.n_map == 0) {
@@ -819,11 +837,11 @@ __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, 
                         o.edit_off[m0 + sz.n_map + 1] = e0 + sz.n_edit;
                     }
                     sz.n_map += 1;
-                } else gc_skip(path, w2);
+                } else gc_skip(path, w2, win);
             }
             if (!path.ok) return false;
         } else if (f == 4 && wt == 2) {
-            GdCur sc = gc_sub(c);
+            GdCur sc = gc_sub(c, win);
             const uint32_t nb = (uint32_t)(sc.e - sc.p);
             if (FILL && sc.ok) {
                 if (!q_src && sz.qual == 0) {
@@ -835,17 +853,15 @@ __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, 
             }
             sz.qual += sc.ok ? nb : 0u;
         } else if (f == 5 && wt == 0) {
-            mapq = (int32_t)gc_varint(c);
+            mapq = (int32_t)gc_varint(c, win);
         } else if (f == 16 && wt == 1) {
             if (c.e - c.p < 8) return false;
-            uint64_t bits = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) bits |= (uint64_t)c.p[k] << (8 * k);
+            const uint64_t bits = gd_load8(c.p);
             identity = __longlong_as_double((long long)bits);
             c.p += 8;
         } else if ((f == 1 || f == 3) && wt == 2) { // sequence, name: not needed on the device
-            (void)gc_sub(c);
-        } else gc_skip(c, wt);
+            (void)gc_sub(c, win);
+        } else gc_skip(c, wt, win);
     }
     return c.ok;
 }
