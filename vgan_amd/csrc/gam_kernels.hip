@@ -1071,7 +1071,7 @@ template <class T> struct GBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        const size_t want = n + n / 8 + 64;
+        const size_t want = n + std::min<size_t>(n / 8, ((size_t)16 << 20) / sizeof(T)) + 64; // (device memory is cleared when it is handed out: ~5-10 ms a GB)
         HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
         // (test aid: fresh device memory is often zero in a young process and someone's old data in an old one -- a kernel that leaves
