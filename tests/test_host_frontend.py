@@ -350,6 +350,43 @@ def test_sliced_alignment_set_matches_the_merged_one(tmp_path):
     assert m2.n_reads == n and np.array_equal(m2.arrays()["seq"], merged.arrays()["seq"])
 
 
+def test_messages_parsed_in_slices_on_threads_equal_the_file(tmp_path):
+    """vgan_alnparts_from_messages (what the device front end's host-left reads come through): the Alignment messages of a GAM file,
+    laid one after the other, parsed in slices on several threads -- against the file's own parse, on one thread and on many."""
+    import ctypes as C
+    g = hc.synth_graph(seed=12, genome_len=1500, n_nodes=900, n_paths=48)
+    a = hc.synth_reads(g, 30000, seed=14, read_len=90, indel_rate=0.05)
+    f = str(tmp_path / "x.gam")
+    a.write_gam(f)
+    raw = gamio.gunzip_all(open(f, "rb").read())
+    msgs, i = [], 0
+    while i < len(raw):  # groups {count, count x (length, bytes)}; a group's first item is its tag
+        cnt, i = gamio._varint(raw, i)
+        for j in range(cnt):
+            ln, i = gamio._varint(raw, i)
+            if j > 0:
+                msgs.append(raw[i:i + ln])
+            i += ln
+    assert len(msgs) == 30000
+    offs = np.zeros(len(msgs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(m) for m in msgs])
+    byts = np.frombuffer(b"".join(msgs), np.uint8)
+    want = hc.AlnSet.read_gam(f).arrays()
+    for threads in (1, 7, 0):
+        h = N.vp()
+        N.check(N.lib().vgan_alnparts_from_messages(byts.ctypes.data, offs.ctypes.data, len(msgs), 0, threads, C.byref(h)))
+        parts = hc.AlnParts(h)
+        assert parts.n_parts == (1 if threads == 1 else 7) and parts.n_reads == want["n_reads"]
+        got = parts.merge().arrays()
+        for k in ("seq_off", "qual_off", "map_off", "seq", "qual", "mapq", "m_node", "m_offset", "edit_off", "e_from", "e_to"):
+            assert np.array_equal(got[k], want[k]), (threads, k)
+    # offsets that do not describe the bytes are an error, not an allocation of what they ask for
+    bad = offs.copy()
+    bad[0] = 1 << 60
+    h = N.vp()
+    assert N.lib().vgan_alnparts_from_messages(byts.ctypes.data, bad.ctypes.data, len(msgs), 0, 1, C.byref(h)) < 0
+
+
 def test_gam_stream_chunks_equal_the_whole(tmp_path):
     """vgan_gam_stream_*: chunks arrive in input order with consecutive bases, their streamed duplicate marks equal the
     marks over the whole file, and their batches concatenate to the whole file's batch content."""
