@@ -78,6 +78,7 @@ struct vgan_sb_ctx {
     char *pin = nullptr;                 // out double[16] | guard u64[16] | sums SbFix[16]
     bool time_refresh = false;           // HIP events around the engine's refresh too (vgan_sb_time_engine)
     uint64_t refresh_seq = 0;            // refreshes launched so far (the finishing kernel leaves the number in the pinned block)
+    uint32_t refresh_grid = 0;           // workgroups of the fused refresh: what the device holds at once (asked once)
     Buf<unsigned long long> ticket;      // guard counts (one per state) of the fused refresh, zero between refreshes
     // the resident refresh (sb_kernels.hip: sb_refresh_resident_kernel): a stream of its own, the mailbox (pinned), the device block
     hipStream_t res_stream = nullptr;
@@ -587,7 +588,11 @@ static int refresh_launch(vgan_sb_ctx *c, uint32_t n_states, uint32_t k, const v
     memcpy(a.freqs7, freqs7, 7 * 8);
     a.con = con;
     const uint32_t R = c->t.n_reads;
-    const uint32_t n_blocks = std::max(1u, std::min(1024u, (R + 255) / 256));
+    if (c->refresh_grid == 0) {
+        const char *e = getenv("VGAN_SB_REFRESH_BLOCKS"); // (developer aid)
+        c->refresh_grid = e && atoi(e) > 0 ? (uint32_t)atoi(e) : sb_refresh_grid(c->device);
+    }
+    const uint32_t n_blocks = std::max(1u, std::min(c->refresh_grid, (R + 255) / 256));
     int rc;
     if ((rc = c->partial.reserve((size_t)n_states * n_blocks))) return rc;
     if (!c->pin) {

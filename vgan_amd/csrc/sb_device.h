@@ -105,6 +105,7 @@ void launch_sb_refresh_fused(const SbTablesDev &t, uint32_t n_states, uint32_t k
 // The same refresh served by a kernel that stays on the device (sb_kernels.hip: sb_refresh_resident_kernel): mailbox = sb_mailbox_bytes() of
 // zeroed pinned host memory, resident = sb_resident_bytes() of zeroed device memory (seq = done), n_blocks <= sb_resident_grid().  The host
 // posts a refresh with sb_mailbox_post and watches seq_host as after launch_sb_refresh_fused.
+uint32_t sb_refresh_grid(int device); // workgroups of launch_sb_refresh_fused the device holds at once
 size_t sb_mailbox_bytes();
 size_t sb_resident_bytes();
 void sb_mailbox_post(void *mailbox, uint32_t n_states, uint32_t k, const SbFusedArgs &a, unsigned long long seq);
