@@ -450,19 +450,26 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
         // ---- Q: prefix sums of {Q above 2: Q << 11, else 1} over the tile's columns, from byte 2 of the records
         bool q_plain, tile_hot; // every quality byte of the tile in [0, C8_QMAX); one at 90 or above (bytes are signed, as the reference reads them)
         {
-            uint32_t loc[C8_CPL], run = 0u, mxu = 0u; // mxu: the largest quality byte read as UNSIGNED (a negative one is 128 and above)
+            uint32_t loc[C8_CPL], run = 0u, mxu = 255u; // mxu: the largest quality byte read as UNSIGNED (a negative one is 128 and above)
+            // (the short variant only: with two waves or one to a SIMD -- the long variants -- the compiler's own schedule of the plain
+            // form is faster: 0.59 against 0.68 ms at 300 bp)
+            if constexpr (C8_CPL <= 8) {
+                mxu = 0u;
 #pragma unroll
-            for (int e = 0; e < C8_CPL; ++e) {
-                // byte 2 taken where it is used (SDWA): Q << 11, Q > 2, max -- no extraction of its own
-                uint32_t q11, term;
-                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(q11) : "v"(11u), "v"(rec[e]));
-                asm("v_cmp_lt_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:BYTE_2\n\tv_cndmask_b32 %0, 1, %3, vcc" : "=v"(term) : "v"(2u), "v"(rec[e]), "v"(q11) : "vcc");
-                asm("v_max_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(mxu) : "v"(rec[e]), "v"(mxu));
-                run += term;
-                loc[e] = run;
+                for (int e = 0; e < C8_CPL; ++e) {
+                    // byte 2 taken where it is used (SDWA): Q << 11, Q > 2, max -- no extraction of its own
+                    uint32_t q11, term;
+                    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(q11) : "v"(11u), "v"(rec[e]));
+                    uint64_t gt2; // (a mask of its own per column: through vcc the columns' compares and selects would queue up behind each other)
+                    asm("v_cmp_lt_u32_sdwa %0, %1, %2 src0_sel:DWORD src1_sel:BYTE_2" : "=s"(gt2) : "v"(2u), "v"(rec[e]));
+                    asm("v_cndmask_b32 %0, 1, %1, %2" : "=v"(term) : "v"(q11), "s"(gt2));
+                    asm("v_max_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(mxu) : "v"(rec[e]), "v"(mxu));
+                    run += term;
+                    loc[e] = run;
+                }
             }
             int mn = 0, mx = (int)mxu;
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mxu >= 90u) != 0, 0)) { // a byte at 90 or above, or a negative one: the signed form
+            if (C8_CPL > 8 || __builtin_expect(__builtin_amdgcn_ballot_w64(mxu >= 90u) != 0, 0)) { // a byte at 90 or above, or a negative one: the signed form
                 run = 0u;
                 mn = 127, mx = -128;
 #pragma unroll
@@ -530,6 +537,7 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
             // lanes with a mapping outside the window / on a node class outside the tables / of a read of another mapping quality: the
             // compares' own masks, combined on the scalar unit (the vector unit is what this kernel waits for)
             uint64_t out_m = 0, cls_m = 0, minor_m = 0;
+            uint32_t seg_flags = 0u; // (the long variants: per lane, counts of its mappings outside the window, bits 0-7 / on a class outside the tables, 8-15 / of a minor read, 16-23)
 #pragma unroll
             for (int k = 0; k < C8_SPASS; ++k) {
                 kr[k] = ((sr[k] >> 29) - T.r) & 7u;
@@ -552,15 +560,22 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                 const uint32_t pkd = p_hi[k] - p_lo[k];
                 const uint32_t n_low = (pkd & 2047u) + gap[k], sq = pkd >> 11;
                 const uint32_t node = sr[k] & VGAN_HC_SREC_MAX_NODE, sl = node - winbase;
-                uint64_t on_m, in_m, c_m, mj_m;
-                asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(on_m) : "v"(ls), "s"(T.n_seg));
-                asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(in_m) : "v"(sl), "s"((uint32_t)C8_WIN));
-                asm("v_cmp_le_u32 %0, %2, %1" : "=s"(c_m) : "v"(nhi[k]), "s"(0xE000u));
-                asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(mj_m) : "v"(rd[k].y));
-                const bool on = __builtin_amdgcn_inverse_ballot_w64(on_m), inside = __builtin_amdgcn_inverse_ballot_w64(in_m);
-                out_m |= on_m & ~in_m;
-                cls_m |= on_m & c_m;
-                minor_m |= on_m & ~mj_m;
+                bool on, inside;
+                if constexpr (C8_SPASS <= 3) {
+                    uint64_t on_m, in_m, c_m, mj_m;
+                    asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(on_m) : "v"(ls), "s"(T.n_seg));
+                    asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(in_m) : "v"(sl), "s"((uint32_t)C8_WIN));
+                    asm("v_cmp_le_u32 %0, %2, %1" : "=s"(c_m) : "v"(nhi[k]), "s"(0xE000u));
+                    asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(mj_m) : "v"(rd[k].y));
+                    on = __builtin_amdgcn_inverse_ballot_w64(on_m), inside = __builtin_amdgcn_inverse_ballot_w64(in_m);
+                    out_m |= on_m & ~in_m;
+                    cls_m |= on_m & c_m;
+                    minor_m |= on_m & ~mj_m;
+                } else { // (six or eight passes: that many masks do not fit the scalar registers -- counted per lane, three ballots a tile)
+                    on = ls < T.n_seg, inside = sl < (uint32_t)C8_WIN;
+                    const uint32_t bits = (inside ? 0u : 1u) + (nhi[k] >= 0xE000u ? 0x100u : 0u) + ((int32_t)rd[k].y < 0 ? 0u : 0x10000u);
+                    seg_flags += on ? bits : 0u;
+                }
 
                 L.info[ls + 1u] = (inside ? sl * 8u : C8_OUTSIDE) | ((nhi[k] + memo_base) << 16);
                 if (on) {
@@ -577,6 +592,12 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                     sticky_m[k] = __builtin_amdgcn_ballot_w64(sticky);
                     tile_bep = tile_bep || sticky_m[k] != 0;
                 }
+            }
+            if constexpr (C8_SPASS > 3) {
+                static_assert(C8_SPASS <= 255, "the counts' fields");
+                cls_m = __builtin_amdgcn_ballot_w64((seg_flags & 0xFF00u) != 0u);
+                minor_m = __builtin_amdgcn_ballot_w64((seg_flags & 0xFF0000u) != 0u);
+                out_m = __builtin_amdgcn_ballot_w64((seg_flags & 0xFFu) != 0u);
             }
             all_cls = cls_m == 0;
             all_major = minor_m == 0;
