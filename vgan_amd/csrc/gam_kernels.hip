@@ -1063,6 +1063,7 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
 
 // ------------------------------------------------------------------------------------------------------------ the C-ABI object
 namespace {
+double g_alloc_ms = 0; // (VGAN_TIMING: what hipMalloc took, summed)
 template <class T> struct GBuf {
     T *p = nullptr;
     size_t cap = 0;
@@ -1071,7 +1072,12 @@ template <class T> struct GBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        const size_t want = n + std::min<size_t>(n / 8, ((size_t)16 << 20) / sizeof(T)) + 64; // (device memory is cleared when it is handed out: ~5-10 ms a GB)
+        const auto t_alloc = std::chrono::steady_clock::now();
+        struct Acc {
+            std::chrono::steady_clock::time_point t0;
+            ~Acc() { g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+        } acc{t_alloc};
+        const size_t want = n + std::min<size_t>(n / 8, ((size_t)16 << 20) / sizeof(T)) + 64;
         HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
         // (test aid: fresh device memory is often zero in a young process and someone's old data in an old one -- a kernel that leaves
@@ -1350,6 +1356,7 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     g->ms_parse = ms_since(t0);
+    if (getenv("VGAN_TIMING")) fprintf(stderr, "[vgan timing] gamdev: device memory asked for so far took %.1f ms\n", g_alloc_ms);
     return VGAN_OK;
 }
 } // namespace

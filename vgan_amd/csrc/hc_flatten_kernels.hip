@@ -409,7 +409,7 @@ template <class T> struct DBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        const size_t want = n + std::min<size_t>(n / 4, ((size_t)16 << 20) / sizeof(T)) + 256; // (slack for the next chunk to fit; device memory costs ~5-10 ms a GB to get)
+        const size_t want = n + std::min<size_t>(n / 4, ((size_t)16 << 20) / sizeof(T)) + 256; // (slack for the next chunk to fit)
         HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
         static const bool poison = getenv("VGAN_POISON_ALLOCS") != nullptr; // (test aid, as csrc/gam_kernels.hip: GBuf)
