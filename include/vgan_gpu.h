@@ -472,7 +472,12 @@ int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[5], uint64_t launches[5]);
  * conf[i] beside it.  Returns the number of records (>= 1) or a negative error. */
 int vgan_hc_posterior(vgan_hc_ctx *c, const double *final_vec /* host [P] */, const char *predicted,
                       char *clade_buf, int64_t clade_cap, double *conf, int32_t conf_cap);
-/* argmax with the reference's first-maximum tie rule (std::max_element, HaploCart.cpp:423). */
+/* argmax with the reference's first-maximum tie rule (std::max_element, HaploCart.cpp:423) -- with a tie taken as the arithmetic
+ * means it: paths the reads do not tell apart (identical over every node a read touches) have EQUAL sums in exact arithmetic and sums
+ * that differ in their last bits in floating point, by the order of the additions -- which under the reference's OpenMP loop, and
+ * under this library's atomics, is not the same from run to run.  The first path within 1e-12 (relative) of the maximum is returned:
+ * what std::max_element gives on the exact sums, the same name on every run.  (One column's term moves a sum by 1e-10 and more of
+ * its size: paths a read does tell apart are not within the tolerance.) */
 int vgan_hc_argmax(const double *final_vec, uint32_t n_paths);
 
 /* ------------------------------------------------------------------------------------------------

@@ -387,6 +387,20 @@ def test_messages_parsed_in_slices_on_threads_equal_the_file(tmp_path):
     assert N.lib().vgan_alnparts_from_messages(byts.ctypes.data, bad.ctypes.data, len(msgs), 0, 1, C.byref(h)) < 0
 
 
+def test_argmax_names_the_first_of_the_paths_the_sums_do_not_tell_apart():
+    """vgan_hc_argmax (HaploCart.cpp:423): the first maximum, ties taken as exact arithmetic means them -- sums equal up to the order
+    of their additions (1e-12 relative) are one maximum; a sum a column's term apart is not."""
+    def am(v):
+        a = np.ascontiguousarray(v, np.float64)
+        return N.lib().vgan_hc_argmax(a.ctypes.data, len(a))
+    m = -1.0e7
+    assert am([m - 5, m + 1e-9, m, m + 2e-9, m - 1e-3]) == 1   # 1, 2, 3 are one maximum: the first of them
+    assert am([m, m + 1e-3]) == 1 and am([m + 1e-3, m]) == 0      # told apart: the larger
+    assert am([m, m, m]) == 0 and am([3.0]) == 0
+    assert am([-np.inf, -np.inf]) == 0 and am([-np.inf, m]) == 1
+    assert am([0.0, 1e-300, -1e-300]) == 1                        # (around zero the tolerance is zero)
+
+
 def test_gam_stream_chunks_equal_the_whole(tmp_path):
     """vgan_gam_stream_*: chunks arrive in input order with consecutive bases, their streamed duplicate marks equal the
     marks over the whole file, and their batches concatenate to the whole file's batch content."""

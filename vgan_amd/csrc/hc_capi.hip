@@ -1232,6 +1232,10 @@ extern "C" int vgan_hc_argmax(const double *v, uint32_t n) {
     uint32_t best = 0;
     for (uint32_t i = 1; i < n; ++i)
         if (v[i] > v[best]) best = i; // std::max_element: first maximum
+    // (include/vgan_gpu.h) the first of the paths whose sums are that maximum up to the order of the additions
+    const double floor_ = v[best] - 1e-12 * fabs(v[best]);
+    for (uint32_t i = 0; i < best; ++i)
+        if (v[i] >= floor_) return (int)i;
     return (int)best;
 }
 
