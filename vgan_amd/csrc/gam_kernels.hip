@@ -14,8 +14,9 @@
 //                       stands exactly on the tag the next anchored segment started from -- every walk is then the true one, or the
 //                       launch says so (a tag-like byte pattern inside a message: the host pipeline takes the file).
 //   gd_count_kernel,    protobuf wire walk of vg.Alignment (csrc/host/gam.cpp: parse_alignment, field numbers SURVEY 8b), one lane
-//   gd_fill_kernel      per message: sizes first, then -- behind exclusive sums -- the arrays hc_flatten_kernels.hip reads
-//                       (a DfSlice: 32-bit offsets, node ids, edit lengths, quality and substitution bytes) written in place.
+//   gd_fill_kernel,     per message: sizes first, then -- behind exclusive sums -- what is per read and a record per mapping (where its
+//   gd_fill_maps_kernel bytes lie, where its edits go); then one lane per MAPPING writes the mappings' and edits' arrays
+//                       hc_flatten_kernels.hip reads (a DfSlice: 32-bit offsets, node ids, edit lengths, substitution bytes).
 //
 // Integer / byte work throughout: every array is bit for bit what the host pipeline (gam.cpp + the narrowing of
 // vgan_hc_devflat_run) hands the device flatten for the same file (tests/test_gamdev_gpu.py).
@@ -757,11 +758,71 @@ struct GdOut { // the arrays of one DfSlice (hc_flatten_kernels.hip) and what th
     int64_t *first_node, *first_offset; // of the read's first mapping (-1, 0: no mapping): src/rmdup.cpp's key
 };
 
-// FILL false: the message's sizes, its keep flag (identity != 0 or keep_unmapped) and whether it parses; true: its arrays, written at
-// the places the exclusive sums give it.
+struct GdMapRec { // what the message pass leaves per mapping for the lane that fills its arrays
+    uint64_t pos;   // the mapping's bytes: offset in the inflated stream | length << 40
+    uint32_t e_at;  // its first edit's index
+    uint32_t s_at;  // its first edit-sequence byte's index
+};
+static_assert(sizeof(GdMapRec) == 16, "one 16-byte store per mapping");
+
+// One mapping's bytes (csrc/host/gam.cpp: parse_mapping, parse_edit): position, edits.  STORE false: its node / offset / strand and the
+// counts of its edits and their sequence bytes; true: the edits' arrays too, from (e_at, s_at) on.  False when it is malformed.
+template <bool STORE>
+__device__ __forceinline__ bool gd_walk_mapping(GdCur mc, GdWin &win, int64_t &node, int64_t &off, uint8_t &rev, uint32_t &n_edit, uint32_t &n_eseq,
+                                                const GdOut &o, uint32_t e_at, uint32_t s_at) {
+    node = 0, off = 0, rev = 0, n_edit = 0, n_eseq = 0;
+    while (!gc_done(mc) && mc.ok) {
+        const uint64_t k3 = gc_varint(mc, win);
+        const int f3 = (int)(k3 >> 3), w3 = (int)(k3 & 7);
+        if (f3 == 1 && w3 == 2) { // position
+            GdCur pc = gc_sub(mc, win);
+            while (!gc_done(pc) && pc.ok) {
+                const uint64_t k4 = gc_varint(pc, win);
+                const int f4 = (int)(k4 >> 3), w4 = (int)(k4 & 7);
+                if (f4 == 1 && w4 == 0) node = (int64_t)gc_varint(pc, win);
+                else if (f4 == 2 && w4 == 0) off = (int64_t)gc_varint(pc, win);
+                else if (f4 == 4 && w4 == 0) rev = gc_varint(pc, win) != 0;
+                else gc_skip(pc, w4, win);
+            }
+            if (!pc.ok) return false;
+        } else if (f3 == 2 && w3 == 2) { // an edit
+            GdCur ec = gc_sub(mc, win);
+            if (!mc.ok) return false;
+            int32_t from = 0, to = 0;
+            const uint8_t *sb = nullptr, *se = nullptr;
+            while (!gc_done(ec) && ec.ok) {
+                const uint64_t k4 = gc_varint(ec, win);
+                const int f4 = (int)(k4 >> 3), w4 = (int)(k4 & 7);
+                if (f4 == 1 && w4 == 0) from = (int32_t)gc_varint(ec, win);
+                else if (f4 == 2 && w4 == 0) to = (int32_t)gc_varint(ec, win);
+                else if (f4 == 3 && w4 == 2) {
+                    GdCur sc = gc_sub(ec, win);
+                    sb = sc.p;
+                    se = sc.e;
+                } else gc_skip(ec, w4, win);
+            }
+            if (!ec.ok) return false;
+            const uint32_t nb = sb ? (uint32_t)(se - sb) : 0u;
+            if (STORE) {
+                o.e_len[e_at + n_edit] = from == to && from >= 0 ? from : -1;
+                for (uint32_t k = 0; k < nb; ++k) o.e_seq[s_at + n_eseq + k] = sb[k];
+                o.e_seq_off[e_at + n_edit + 1] = s_at + n_eseq + nb;
+            }
+            n_edit += 1;
+            n_eseq += nb;
+        } else gc_skip(mc, w3, win);
+    }
+    return mc.ok;
+}
+
+// FILL false: the message's sizes, its keep flag (identity != 0 or keep_unmapped) and whether it parses; true: what is per READ, written at
+// the places the exclusive sums give it, and a GdMapRec per mapping -- the mappings' and edits' arrays are filled by a lane per MAPPING
+// (gd_fill_maps_kernel: neighbouring lanes write neighbouring elements; a lane per message wrote six arrays at 64 places 240 bytes apart,
+// every line of them filled over thirty stores and long gone from the L2 by then: 100 ms for the 10 M-read file around a walk of 26).
 template <bool FILL>
-__device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, double &identity, int32_t &mapq, const GdOut &o, uint32_t m0, uint32_t e0,
-                                 uint32_t s0, uint32_t q0, int64_t &first_node, int64_t &first_off, const uint8_t *&q_src, uint32_t &q_n) {
+__device__ bool gd_parse_message(const uint8_t *u, const uint8_t *mp, uint32_t mlen, GdSizes &sz, double &identity, int32_t &mapq, const GdOut &o,
+                                 GdMapRec *recs, uint32_t m0, uint32_t e0, uint32_t s0, uint32_t q0, int64_t &first_node, int64_t &first_off,
+                                 const uint8_t *&q_src, uint32_t &q_n) {
     GdCur c{mp, mp + mlen, true};
     GdWin win{mp - 8, 0}; // (nothing loaded yet: the first byte asked for moves it)
     q_src = nullptr; // FILL: the message's first quality string is left to the caller (the wave copies its lanes' strings together)
@@ -781,62 +842,19 @@ __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, 
                 const int f2 = (int)(k2 >> 3), w2 = (int)(k2 & 7);
                 if (f2 == 2 && w2 == 2) { // a mapping
                     GdCur mc = gc_sub(path, win);
-                    if (!path.ok) return false;
-                    int64_t node = 0, off = 0;
-                    uint8_t rev = 0;
-                    while (!gc_done(mc) && mc.ok) {
-                        const uint64_t k3 = gc_varint(mc, win);
-                        const int f3 = (int)(k3 >> 3), w3 = (int)(k3 & 7);
-                        if (f3 == 1 && w3 == 2) { // position
-                            GdCur pc = gc_sub(mc, win);
-                            while (!gc_done(pc) && pc.ok) {
-                                const uint64_t k4 = gc_varint(pc, win);
-                                const int f4 = (int)(k4 >> 3), w4 = (int)(k4 & 7);
-                                if (f4 == 1 && w4 == 0) node = (int64_t)gc_varint(pc, win);
-                                else if (f4 == 2 && w4 == 0) off = (int64_t)gc_varint(pc, win);
-                                else if (f4 == 4 && w4 == 0) rev = gc_varint(pc, win) != 0;
-                                else gc_skip(pc, w4, win);
-                            }
-                            if (!pc.ok) return false;
-                        } else if (f3 == 2 && w3 == 2) { // an edit
-                            GdCur ec = gc_sub(mc, win);
-                            if (!mc.ok) return false;
-                            int32_t from = 0, to = 0;
-                            const uint8_t *sb = nullptr, *se = nullptr;
-                            while (!gc_done(ec) && ec.ok) {
-                                const uint64_t k4 = gc_varint(ec, win);
-                                const int f4 = (int)(k4 >> 3), w4 = (int)(k4 & 7);
-                                if (f4 == 1 && w4 == 0) from = (int32_t)gc_varint(ec, win);
-                                else if (f4 == 2 && w4 == 0) to = (int32_t)gc_varint(ec, win);
-                                else if (f4 == 3 && w4 == 2) {
-                                    GdCur sc = gc_sub(ec, win);
-                                    sb = sc.p;
-                                    se = sc.e;
-                                } else gc_skip(ec, w4, win);
-                            }
-                            if (!ec.ok) return false;
-                            const uint32_t nb = sb ? (uint32_t)(se - sb) : 0u;
-                            if (FILL) {
-                                o.e_len[e0 + sz.n_edit] = from == to && from >= 0 ? from : -1;
-                                for (uint32_t k = 0; k < nb; ++k) o.e_seq[s0 + sz.eseq + k] = sb[k];
-                                o.e_seq_off[e0 + sz.n_edit + 1] = s0 + sz.eseq + nb;
-                            }
-                            sz.n_edit += 1;
-                            sz.eseq += nb;
-                        } else gc_skip(mc, w3, win);
-                    }
-                    if (!mc.ok) return false;
+                    if (!path.ok || (uint64_t)(mc.e - mc.p) >= (1ull << 24)) return false; // (GdMapRec holds a mapping's length in 24 bits)
+                    int64_t node, off;
+                    uint8_t rev;
+                    uint32_t ne, ns;
+                    if (!gd_walk_mapping<false>(mc, win, node, off, rev, ne, ns, o, 0, 0)) return false;
                     if (sz.n_map == 0) {
                         first_node = node;
                         first_off = off;
                     }
-                    if (FILL) {
-                        o.m_node[m0 + sz.n_map] = node < 0 || node > 0xFFFFFFFEll ? 0xFFFFFFFFu : (uint32_t)node;
-                        o.m_offset[m0 + sz.n_map] = off != (int64_t)(int32_t)off || (int32_t)off == INT32_MIN ? INT32_MIN : (int32_t)off;
-                        o.m_rev[m0 + sz.n_map] = rev;
-                        o.edit_off[m0 + sz.n_map + 1] = e0 + sz.n_edit;
-                    }
+                    if (FILL) recs[m0 + sz.n_map] = GdMapRec{(uint64_t)(mc.p - u) | (uint64_t)(mc.e - mc.p) << 40, e0 + sz.n_edit, s0 + sz.eseq};
                     sz.n_map += 1;
+                    sz.n_edit += ne;
+                    sz.eseq += ns;
                 } else gc_skip(path, w2, win);
             }
             if (!path.ok) return false;
@@ -866,6 +884,24 @@ __device__ bool gd_parse_message(const uint8_t *mp, uint32_t mlen, GdSizes &sz, 
     return c.ok;
 }
 
+// a lane per mapping: its node / offset / strand, its edits' lengths and sequence bytes, the offsets behind them
+__global__ __launch_bounds__(256) void gd_fill_maps_kernel(const uint8_t *__restrict__ u, const GdMapRec *__restrict__ recs, uint32_t n_maps, GdOut o) {
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= n_maps) return;
+    const GdMapRec r = recs[m];
+    const uint8_t *p = u + (r.pos & ((1ull << 40) - 1ull));
+    GdCur mc{p, p + (r.pos >> 40), true};
+    GdWin win{p - 8, 0};
+    int64_t node, off;
+    uint8_t rev;
+    uint32_t ne, ns;
+    (void)gd_walk_mapping<true>(mc, win, node, off, rev, ne, ns, o, r.e_at, r.s_at);
+    o.m_node[m] = node < 0 || node > 0xFFFFFFFEll ? 0xFFFFFFFFu : (uint32_t)node;
+    o.m_offset[m] = off != (int64_t)(int32_t)off || (int32_t)off == INT32_MIN ? INT32_MIN : (int32_t)off;
+    o.m_rev[m] = rev;
+    o.edit_off[m + 1] = r.e_at + ne;
+}
+
 __global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict__ u, const uint64_t *__restrict__ msg_off, const uint32_t *__restrict__ msg_len,
                                                        uint32_t n_msg, int keep_unmapped, uint32_t *__restrict__ keep, uint32_t *__restrict__ n_map,
                                                        uint32_t *__restrict__ n_edit, uint32_t *__restrict__ n_eseq, uint32_t *__restrict__ n_qual,
@@ -878,7 +914,7 @@ __global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict
     int64_t fn, fo;
     const uint8_t *qs;
     uint32_t qn;
-    const bool ok = gd_parse_message<false>(u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, 0, 0, 0, 0, fn, fo, qs, qn);
+    const bool ok = gd_parse_message<false>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, nullptr, 0, 0, 0, 0, fn, fo, qs, qn);
     if (!ok) atomicAdd(bad, 1u);
     const bool kp = ok && (keep_unmapped || identity != 0.0); // readGAM.h:47: "Discard unmapped reads"
     keep[i] = kp ? 1u : 0u;
@@ -891,7 +927,7 @@ __global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict
 __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict__ u, const uint64_t *__restrict__ msg_off, const uint32_t *__restrict__ msg_len,
                                                       uint32_t n_msg, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ r_at,
                                                       const uint32_t *__restrict__ m_at, const uint32_t *__restrict__ e_at, const uint32_t *__restrict__ s_at,
-                                                      const uint32_t *__restrict__ q_at, GdOut o) {
+                                                      const uint32_t *__restrict__ q_at, GdOut o, GdMapRec *__restrict__ recs) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) { // the offsets' leading zeros
         o.map_off[0] = 0;
@@ -907,7 +943,7 @@ __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict_
         int32_t mapq;
         int64_t fn, fo;
         const uint32_t r = r_at[i];
-        (void)gd_parse_message<true>(u + msg_off[i], msg_len[i], sz, identity, mapq, o, m_at[i], e_at[i], s_at[i], q_at[i], fn, fo, q_src, q_n);
+        (void)gd_parse_message<true>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, o, recs, m_at[i], e_at[i], s_at[i], q_at[i], fn, fo, q_src, q_n);
         q_dst = q_at[i];
         o.map_off[r + 1] = m_at[i] + sz.n_map;
         o.qual_off[r + 1] = q_at[i] + sz.qual;
@@ -1107,6 +1143,7 @@ struct vgan_gamdev {
     GBuf<GdBlock> blocks;
     GBuf<uint32_t> status, seg_msgs, seg_status, msg_len, keep, n_map, n_edit, n_eseq, n_qual, r_at, m_at, e_at, s_at, q_at, bad;
     GBuf<uint64_t> anchor, next_anchor, msg_base, msg_off;
+    GBuf<GdMapRec> map_rec; // per mapping: where its bytes lie, where its edits go (gd_fill_kernel -> gd_fill_maps_kernel)
     // one DfSlice's arrays (hc_flatten_kernels.hip) of the file's reads
     GBuf<uint32_t> map_off, qual_off, edit_off, e_seq_off, m_node;
     GBuf<int32_t> m_offset, mapq, e_len;
@@ -1125,6 +1162,7 @@ struct vgan_gamdev {
                         &qual_off, &edit_off, &e_seq_off, &m_node})
             b->release();
         for (auto *b : {&anchor, &next_anchor, &msg_base, &msg_off}) b->release();
+        map_rec.release();
         for (auto *b : {&m_offset, &mapq, &e_len}) b->release();
         for (auto *b : {&unmapped, &m_rev, &e_seq, &qual}) b->release();
         first_node.release(), first_offset.release();
@@ -1347,12 +1385,14 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
     if ((rc = g->map_off.reserve(g->R + 1)) || (rc = g->qual_off.reserve(g->R + 1)) || (rc = g->edit_off.reserve(g->M + 1)) || (rc = g->e_seq_off.reserve(g->E + 1)) ||
         (rc = g->m_node.reserve(g->M + 1)) || (rc = g->m_offset.reserve(g->M + 1)) || (rc = g->mapq.reserve(g->R + 1)) || (rc = g->e_len.reserve(g->E + 1)) ||
         (rc = g->unmapped.reserve(g->R + 1)) || (rc = g->m_rev.reserve(g->M + 1)) || (rc = g->e_seq.reserve(g->S + 1)) || (rc = g->qual.reserve(g->Q + 1)) ||
-        (rc = g->first_node.reserve(g->R + 1)) || (rc = g->first_offset.reserve(g->R + 1)))
+        (rc = g->first_node.reserve(g->R + 1)) || (rc = g->first_offset.reserve(g->R + 1)) || (rc = g->map_rec.reserve(g->M + 1)))
         return rc;
+    if (total >= (1ull << 40)) return fail(VGAN_ERANGE, "vgan_gamdev_parse: more than 2^40 inflated bytes; parse fewer bytes at a time");
     GdOut o{g->map_off.p, g->qual_off.p, g->edit_off.p, g->e_seq_off.p, g->m_node.p, g->m_offset.p, g->mapq.p, g->e_len.p, g->unmapped.p, g->m_rev.p, g->e_seq.p,
             g->qual.p, g->first_node.p, g->first_offset.p};
     hipLaunchKernelGGL(gd_fill_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, NM, g->keep.p, g->r_at.p, g->m_at.p, g->e_at.p,
-                       g->s_at.p, g->q_at.p, o);
+                       g->s_at.p, g->q_at.p, o, g->map_rec.p);
+    if (g->M) hipLaunchKernelGGL(gd_fill_maps_kernel, dim3((uint32_t)((g->M + 255) / 256)), dim3(256), 0, st, g->infl.p, g->map_rec.p, (uint32_t)g->M, o);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     g->ms_parse = ms_since(t0);
