@@ -421,6 +421,11 @@ void vgan_hc_devflat_free(vgan_hc_devflat *f);
 struct vgan_gamdev;
 int vgan_hc_devflat_run_gamdev(vgan_hc_devflat *f, const struct vgan_gamdev *gd, const uint8_t *skip, int skip_on_device, uint32_t base,
                                vgan_hc_packed_view *out, uint8_t *host_mask, vgan_hc_flatten_stats *stats);
+/* The same, with mask_ready(user) called (on the calling thread) as soon as host_mask is final -- before the offsets and the write pass:
+ * the caller's work on the reads left to the host (vgan_gamdev_pick ...) can run beside them, on a thread the callback starts. */
+int vgan_hc_devflat_run_gamdev_cb(vgan_hc_devflat *f, const struct vgan_gamdev *gd, const uint8_t *skip, int skip_on_device, uint32_t base,
+                                  vgan_hc_packed_view *out, uint8_t *host_mask, vgan_hc_flatten_stats *stats, void (*mask_ready)(void *user),
+                                  void *user);
 /* Host check of a packed batch against the layout above and the context's graph (offsets, node ids, head bits, maxima). */
 int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
 /* D_m = S_m - U_m per segment of a packed batch (test / debug aid). Host output [n_segments]. */

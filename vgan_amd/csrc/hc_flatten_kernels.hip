@@ -517,7 +517,7 @@ extern "C" void vgan_hc_devflat_free(vgan_hc_devflat *f) {
 }
 
 static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uint32_t R_all, uint32_t base, vgan_hc_packed_view *out, uint8_t *host_mask,
-                         vgan_hc_flatten_stats *stats, PhaseTimer &pt);
+                         vgan_hc_flatten_stats *stats, PhaseTimer &pt, void (*mask_ready)(void *) = nullptr, void *user = nullptr);
 static int df_prepare(vgan_hc_devflat *f, uint32_t R_all, size_t n_slices);
 
 extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chunk, const uint8_t *skip, vgan_hc_packed_view *out,
@@ -659,7 +659,7 @@ extern "C" int vgan_hc_devflat_run(vgan_hc_devflat *f, const vgan_alnparts *chun
 // classify -> sort -> offsets -> write over slices whose arrays are on the device (uploaded above, or left there by the GAM front
 // end on the device: gam_kernels.hip)
 static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uint32_t R_all, uint32_t base, vgan_hc_packed_view *out, uint8_t *host_mask,
-                         vgan_hc_flatten_stats *stats, PhaseTimer &pt) {
+                         vgan_hc_flatten_stats *stats, PhaseTimer &pt, void (*mask_ready)(void *), void *user) {
     hipStream_t st = f->stream;
     const size_t np = hs.size();
     int rc;
@@ -692,6 +692,7 @@ static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uin
     HIPCHK(hipStreamSynchronize(st));
     pt.lap("upload + classify + sort");
     for (uint32_t i = 0; i < R_all; ++i) host_mask[i] = host_mask[i] == DF_HOST ? 1 : 0;
+    if (mask_ready) mask_ready(user); // (the caller's work on the reads left to the host can start beside the offsets and the write pass)
     const uint32_t n_dev = hc.n_dev;
     if (stats) {
         stats->n_in = hc.n_in;
@@ -765,6 +766,12 @@ static int df_prepare(vgan_hc_devflat *f, uint32_t R_all, size_t n_slices) {
 // duplicate marks (skip: host, per read of the parse, or NULL) on their way up and the host-read mask on its way down.
 extern "C" int vgan_hc_devflat_run_gamdev(vgan_hc_devflat *f, const vgan_gamdev *gd, const uint8_t *skip, int skip_on_device, uint32_t base,
                                           vgan_hc_packed_view *out, uint8_t *host_mask, vgan_hc_flatten_stats *stats) {
+    return vgan_hc_devflat_run_gamdev_cb(f, gd, skip, skip_on_device, base, out, host_mask, stats, nullptr, nullptr);
+}
+
+extern "C" int vgan_hc_devflat_run_gamdev_cb(vgan_hc_devflat *f, const vgan_gamdev *gd, const uint8_t *skip, int skip_on_device, uint32_t base,
+                                             vgan_hc_packed_view *out, uint8_t *host_mask, vgan_hc_flatten_stats *stats, void (*mask_ready)(void *),
+                                             void *user) {
     if (!f || !gd || !out || !host_mask) return fail(VGAN_EINVAL, "vgan_hc_devflat_run_gamdev: null argument");
     memset(out, 0, sizeof *out);
     if (stats) memset(stats, 0, sizeof *stats);
@@ -799,5 +806,5 @@ extern "C" int vgan_hc_devflat_run_gamdev(vgan_hc_devflat *f, const vgan_gamdev 
     s.m_offset = gs.m_offset, s.mapq = gs.mapq, s.e_len = gs.e_len;
     s.unmapped = gs.unmapped, s.m_rev = gs.m_rev, s.e_seq = gs.e_seq, s.qual = gs.qual, s.skip = d_skip;
     s.n_reads = R_all, s.read0 = 0;
-    return df_run_slices(f, hs, R_all, base, out, host_mask, stats, pt);
+    return df_run_slices(f, hs, R_all, base, out, host_mask, stats, pt, mask_ready, user);
 }

@@ -521,35 +521,63 @@ int haplocart(int argc, char **argv) {
                 std::vector<uint8_t> mask((size_t)n_in, 0);
                 vgan_hc_packed_view pk;
                 vgan_hc_flatten_stats st{}, sh{};
-                check(vgan_hc_devflat_run_gamdev(devflats.v[0], gd.g, d_dup, 1, 0, &pk, mask.data(), &st), "device flatten");
+                // The reads the device flatten leaves (indels, soft clips): their messages come down and the host parses and flattens them --
+                // on a thread of its own from the moment the mask is known, beside the device's offsets and write pass.
+                struct HostLeft {
+                    std::thread t;
+                    std::string err;
+                    vgan_hc_host_batch *hb = nullptr;
+                    int64_t n = 0;
+                    double ms = 0;
+                    ~HostLeft() {
+                        if (t.joinable()) t.join();
+                        vgan_hc_host_batch_free(hb);
+                    }
+                } left_run;
+                std::function<void()> host_left = [&] {
+                    const auto t1 = std::chrono::steady_clock::now();
+                    for (uint8_t m : mask) left_run.n += m;
+                    if (left_run.n == 0) return;
+                    uint64_t nm = 0, nb = 0;
+                    if (vgan_gamdev_pick(gd.g, mask.data(), &nm, &nb) < 0) {
+                        left_run.err = vgan_last_error();
+                        return;
+                    }
+                    std::vector<uint64_t> offs((size_t)nm + 1);
+                    std::vector<uint8_t> bytes((size_t)std::max<uint64_t>(nb, 1));
+                    vgan_alnparts *left = nullptr;
+                    if (vgan_gamdev_picked(gd.g, offs.data(), bytes.data()) < 0 ||
+                        vgan_alnparts_from_messages(bytes.data(), offs.data(), (int64_t)nm, 0, n_threads, &left) < 0) {
+                        left_run.err = vgan_last_error();
+                        return;
+                    }
+                    const int rc = vgan_hc_flatten_parts_packed(graph, left, 0, vgan_alnparts_count(left), nullptr, 0, &left_run.hb, &sh);
+                    vgan_alnparts_free(left);
+                    if (rc < 0) left_run.err = vgan_last_error();
+                    left_run.ms = since_ms(t1);
+                };
+                struct Hook {
+                    HostLeft *run;
+                    std::function<void()> *fn;
+                    static void go(void *u) {
+                        auto *h = static_cast<Hook *>(u);
+                        h->run->t = std::thread(*h->fn);
+                    }
+                } hook{&left_run, &host_left};
+                check(vgan_hc_devflat_run_gamdev_cb(devflats.v[0], gd.g, d_dup, 1, 0, &pk, mask.data(), &st, &Hook::go, &hook), "device flatten");
                 check(vgan_hc_accumulate_packed(cx, &pk), "accumulate");
                 t_df = since_ms(t0);
                 stamp("packed batch flattened on the device and handed to the segment kernel");
-                int64_t n_host = 0;
-                for (uint8_t m : mask) n_host += m;
-                if (n_host) { // the reads the device flatten left: their messages come down, the host parses and flattens them
-                    t0 = std::chrono::steady_clock::now();
-                    uint64_t nm = 0, nb = 0;
-                    check(vgan_gamdev_pick(gd.g, mask.data(), &nm, &nb), "reads left to the host");
-                    stamp("the reads left to the host: picked");
-                    std::vector<uint64_t> offs((size_t)nm + 1);
-                    std::vector<uint8_t> bytes((size_t)std::max<uint64_t>(nb, 1));
-                    check(vgan_gamdev_picked(gd.g, offs.data(), bytes.data()), "reads left to the host");
-                    stamp("the reads left to the host: their messages down");
-                    vgan_alnparts *left = nullptr;
-                    check(vgan_alnparts_from_messages(bytes.data(), offs.data(), (int64_t)nm, 0, n_threads, &left), "reads left to the host");
-                    stamp("the reads left to the host: parsed");
-                    vgan_hc_host_batch *hb = nullptr;
-                    const int rc = vgan_hc_flatten_parts_packed(graph, left, 0, vgan_alnparts_count(left), nullptr, 0, &hb, &sh);
-                    vgan_alnparts_free(left);
-                    check(rc, "flattening");
-                    stamp("the reads left to the host: flattened");
-                    const std::string err = hand_over(cx, hb);
-                    vgan_hc_host_batch_free(hb);
+                if (left_run.t.joinable()) left_run.t.join();
+                if (!left_run.err.empty()) die("[HaploCart] reads left to the host: " + left_run.err);
+                const int64_t n_host = left_run.n;
+                if (left_run.hb) {
+                    stamp("the reads left to the host: parsed and flattened (beside the device's write pass)");
+                    const std::string err = hand_over(cx, left_run.hb);
                     if (!err.empty()) die(err);
-                    t_host = since_ms(t0);
                     stamp("the reads left to the host: handed over");
                 }
+                t_host = left_run.ms;
                 tot.n_bad += sh.n_bad;
                 tot.n_unmapped += st.n_unmapped;
                 tot.n_out += st.n_out + sh.n_out;
