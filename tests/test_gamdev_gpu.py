@@ -259,6 +259,33 @@ def test_device_parse_feeds_the_device_flatten_like_the_host_parser(tmp_path):
     gdev.close()
 
 
+def test_the_mask_call_back_comes_once_with_the_final_mask(tmp_path):
+    """vgan_hc_devflat_run_gamdev_cb: the call-back runs on the calling thread when host_mask is final (before the write pass), once;
+    the batch is the one vgan_hc_devflat_run_gamdev gives."""
+    g = hc.synth_graph(seed=25, genome_len=5000, n_nodes=3300, n_paths=120)
+    a = hc.synth_reads(g, 20000, seed=27, read_len=150, indel_rate=0.04, softclip_rate=0.04)
+    p = str(tmp_path / "x.gam")
+    a.write_gam(p)
+    ctx = hc.HcContext(g)
+    df = hc.DeviceFlatten(ctx, g)
+    gd = hc.GamDevice().parse(open(p, "rb").read())
+    want = df.run_gamdev(gd)
+    want_arrays, want_mask = want.download(), np.array(want.host_mask)
+    n = gd.sizes["reads"]
+    mask = np.zeros(n, np.uint8)
+    seen = []
+    CB = C.CFUNCTYPE(None, C.c_void_p)
+    cb = CB(lambda user: seen.append(mask.copy()))
+    pk, st = N.HcPackedView(), N.FlattenStats()
+    N.check(N.lib().vgan_hc_devflat_run_gamdev_cb(df._h, gd._h, None, 0, 0, C.byref(pk), mask.ctypes.data, C.byref(st), C.cast(cb, C.c_void_p), None))
+    assert len(seen) == 1 and np.array_equal(seen[0], want_mask) and np.array_equal(mask, want_mask) and 0 < want_mask.sum() < n
+    got = hc.DeviceFlatten.Result(pk, mask, st).download()
+    for name in ("rhdr", "srec", "crec", "read_src"):
+        assert np.array_equal(got[name], want_arrays[name]), name
+    df.close()
+    gd.close()
+
+
 def test_whole_chain_on_the_device_against_the_host_pipeline(tmp_path):
     """What `vgan haplocart` does with a BGZF GAM when the front end runs on the device: parse, duplicate marks, flatten, segment
     kernel -- and the reads the device flatten leaves (indels, soft clips) handed back as their messages, parsed and flattened on the
