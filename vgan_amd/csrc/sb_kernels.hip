@@ -673,19 +673,20 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_fused_kernel(SbTablesD
 #pragma unroll
     for (uint32_t y = 0; y < SB_FUSED_MAX_K; ++y)
         if (threadIdx.x == y && y < ne) src_s[y] = a.src[y]; // constant indices into the kernel arguments
-    // one lane per table entry (splitting an entry's chain of transcendentals over two steps saved 3 us of prologue but made
-    // the compiler allocate 85 instead of 116 VGPRs and serialise the loads of the main loop: 82 -> 200 us at 1M reads)
+    // the table in two steps: the 20 transition log-probabilities of a (source, branch) once (sb_hky_entry computes the four its entry
+    // needs: every one five times over the table), then the 25 folds over them -- the same functions on the same arguments, so the same
+    // bits as sb_hky_entry's, in 1.3 - 1.8 us less per refresh.  (Round 4's attempt at splitting the entries' chains made the compiler
+    // allocate 85 instead of 116 VGPRs and serialise the loads of the main loop, 82 -> 200 us at 1M reads; this one: 144, as before.)
+    __shared__ double lp_s[SB_FUSED_MAX_K * 2 * 20];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ne * 2 * 20; i += SBL_THREADS) {
+        const uint32_t e = i / 40, which = (i / 20) & 1u, ref = (i % 20) / 4, bpo = i % 4;
+        lp_s[i] = sb_hky_logp(which ? src_s[e].t1 : src_s[e].t2, (int)ref, (int)bpo, a.freqs7);
+    }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < ne * 2 * SB_NCNT; i += SBL_THREADS) {
-        const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
-        SbSourceDev s;
-        s.t1 = 0.0, s.t2 = 0.0;
-#pragma unroll
-        for (uint32_t y = 0; y < SB_FUSED_MAX_K; ++y)
-            if (e == y) {
-                s.t1 = a.src[y].t1;
-                s.t2 = a.src[y].t2;
-            }
-        hk_s[i] = sb_hky_entry(s, which, j, a.con, a.freqs7);
+        const uint32_t ew = i / SB_NCNT, j = i % SB_NCNT;
+        hk_s[i] = sb_hky_fold(&lp_s[ew * 20 + (j / 5) * 4], (int)(j % 5), a.con);
     }
     __syncthreads();
     const uint32_t R = t.n_reads;
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_resident_kernel(SbTabl
     __shared__ double hk_s[SB_FUSED_MAX_K * 2 * SB_NCNT];
     __shared__ SbSourceDev src_s[SB_FUSED_MAX_K];
     __shared__ double fr_s[8];
+    __shared__ double lp_s[SB_FUSED_MAX_K * 2 * 20];
     __shared__ SbFix red_s[SBL_THREADS / 64];
     __shared__ unsigned long long seq_s;
     __shared__ uint32_t stop_s, last_s, nk_s[2];
@@ -872,12 +874,14 @@ __global__ __launch_bounds__(SBL_THREADS) void sb_refresh_resident_kernel(SbTabl
         // ---- as sb_refresh_fused_kernel
         const uint32_t n_states = nk_s[0], k = nk_s[1], ne = n_states * k;
         const double con = fr_s[7];
+        for (uint32_t i = threadIdx.x; i < ne * 2 * 20; i += SBL_THREADS) { // (the table in two steps, as sb_refresh_fused_kernel)
+            const uint32_t e = i / 40, which = (i / 20) & 1u, ref = (i % 20) / 4, bpo = i % 4;
+            lp_s[i] = sb_hky_logp(which ? src_s[e].t1 : src_s[e].t2, (int)ref, (int)bpo, fr_s);
+        }
+        __syncthreads();
         for (uint32_t i = threadIdx.x; i < ne * 2 * SB_NCNT; i += SBL_THREADS) {
-            const uint32_t e = i / (2 * SB_NCNT), which = (i / SB_NCNT) & 1u, j = i % SB_NCNT;
-            SbSourceDev sd;
-            sd.t1 = src_s[e].t1;
-            sd.t2 = src_s[e].t2;
-            hk_s[i] = sb_hky_entry(sd, which, j, con, fr_s);
+            const uint32_t ew = i / SB_NCNT, j = i % SB_NCNT;
+            hk_s[i] = sb_hky_fold(&lp_s[ew * 20 + (j / 5) * 4], (int)(j % 5), con);
         }
         __syncthreads();
         const unsigned long long t_tab = __builtin_amdgcn_s_memrealtime();
