@@ -580,7 +580,7 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
                "reads_left_to_the_host": int(res.host_mask.sum())}
         # f1 on the device (vgan_gamdev): the FILE's bytes go up, BGZF inflate + framing + protobuf wire walk + duplicate marks + flatten
         # are kernels; nothing but the mask of the reads left to the host comes back.  What `vgan haplocart` does with a BGZF GAM of
-        # 128 MB and more on one GPU (on this sample the fixed costs of a dozen launches and syncs weigh: tools/e2e_device_gam.py has
+        # 384 MB and more on one GPU (on this sample the fixed costs of a dozen launches and syncs weigh: tools/e2e_device_gam.py has
         # the 10 M-read file)
         try:
             with tempfile.TemporaryDirectory(prefix="vgan_fe_") as d:

@@ -173,7 +173,7 @@ int haplocart(int argc, char **argv) {
         struct stat sb;
         const bool one_gpu = gpu_spec.empty() && !getenv("VGAN_GPUS");
         if (!(e && e[0] == '0') && one_gpu && !per_read && fastafilename.empty() && stat(gamfilename.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) &&
-            ((e && e[0] == '1') || (uint64_t)sb.st_size >= (128ull << 20)) && sb.st_size > 28) {
+            ((e && e[0] == '1') || (uint64_t)sb.st_size >= (384ull << 20)) && sb.st_size > 28) {
             const int fd = open(gamfilename.c_str(), O_RDONLY);
             if (fd >= 0) {
                 void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
