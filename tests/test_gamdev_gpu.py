@@ -73,6 +73,45 @@ def test_device_inflate_of_a_synthetic_gam_and_of_odd_members(tmp_path):
         assert got == b"".join(chunks), level
 
 
+def test_device_inflate_of_every_period_strategy_and_many_random_members():
+    """The decode loop's corners: matches of every period from 1 to 20 (those below 16 come out of registers), overlapping long matches,
+    zlib's strategies (fixed codes only, run-length only, Huffman only, filtered), members that end a few bytes into a word, and a few
+    hundred random members of random sizes -- a lane each, side by side in the same waves."""
+    def member(c, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+        z = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        payload = z.compress(c) + z.flush()
+        assert len(payload) + 25 < 65536
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + (len(payload) + 25).to_bytes(2, "little") + payload +
+                zlib.crc32(c).to_bytes(4, "little") + len(c).to_bytes(4, "little"))
+    rng = np.random.default_rng(7)
+    chunks = []
+    for period in range(1, 21):
+        pat = bytes(rng.integers(65, 91, period, dtype=np.uint8))
+        for total in (period + 3, 259, 777, 4001):
+            chunks.append(bytes(rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8)) + (pat * (total // period + 1))[:total])
+    text = bytes(rng.integers(97, 101, 3000, dtype=np.uint8))
+    chunks += [text * 15, (text[:300] + b"#") * 100, bytes(40000), b"x" * 65000]
+    for _ in range(300):
+        n = int(rng.integers(0, 3000))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            c = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        elif kind == 1:
+            c = bytes(rng.integers(65, 69, n, dtype=np.uint8))
+        elif kind == 2:
+            c = bytes(np.repeat(rng.integers(0, 256, n // 7 + 1, dtype=np.uint8), rng.integers(1, 14, n // 7 + 1)))[:n]
+        else:
+            w = bytes(rng.integers(97, 123, 40, dtype=np.uint8))
+            c = b"".join(w[int(a):int(a) + int(b)] for a, b in zip(rng.integers(0, 30, n // 5 + 1), rng.integers(1, 10, n // 5 + 1)))[:n]
+        chunks.append(c)
+    for level, strategy in ((6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_RLE),
+                            (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FILTERED), (0, zlib.Z_DEFAULT_STRATEGY)):
+        order = rng.permutation(len(chunks))
+        data = b"".join(member(chunks[i], level, strategy) for i in order)
+        got, _ = device_inflate(data)
+        assert got == b"".join(chunks[i] for i in order), (level, strategy)
+
+
 def test_a_damaged_member_is_refused(tmp_path):
     g = hc.synth_graph(seed=5, genome_len=3000, n_nodes=2000, n_paths=50)
     a = hc.synth_reads(g, 3000, seed=7, read_len=150)
