@@ -298,6 +298,62 @@ def test_device_parse_feeds_the_device_flatten_like_the_host_parser(tmp_path):
     gdev.close()
 
 
+def _bgzf(raw, chunk=60000):
+    out = b""
+    for i in range(0, len(raw), chunk):
+        c = raw[i:i + chunk]
+        z = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = z.compress(c) + z.flush()
+        out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + (len(payload) + 25).to_bytes(2, "little") + payload +
+                zlib.crc32(c).to_bytes(4, "little") + len(c).to_bytes(4, "little"))
+    return out + b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00"
+
+
+def test_messages_with_a_damaged_byte_are_taken_or_refused_as_the_host_parser_does(tmp_path):
+    """One byte of one Alignment message changed (the framing left whole), 150 times: the device's wire walk accepts exactly the files
+    the host parser accepts, with the same arrays, and refuses the others."""
+    import gamio
+    g = hc.synth_graph(seed=5, genome_len=3000, n_nodes=2000, n_paths=50)
+    a = hc.synth_reads(g, 60, seed=8, read_len=120, indel_rate=0.1, softclip_rate=0.1)
+    p = str(tmp_path / "s.gam")
+    a.write_gam(p, group_size=16)
+    raw = gunzip_members(open(p, "rb").read())
+    spans, i = [], 0
+    while i < len(raw):  # {count, count x (length, bytes)}: the bodies of the alignment messages
+        cnt, i = gamio._varint(raw, i)
+        for j in range(cnt):
+            ln, i = gamio._varint(raw, i)
+            if j > 0:
+                spans.append((i, ln))
+            i += ln
+    assert len(spans) == 60
+    rng = np.random.default_rng(11)
+    gd = GamDev()
+    taken = refused = 0
+    for trial in range(150):
+        at, ln = spans[int(rng.integers(len(spans)))]
+        k = at + int(rng.integers(ln))
+        bad = bytearray(raw)
+        bad[k] ^= int(rng.integers(1, 256))
+        data = _bgzf(bytes(bad))
+        f = str(tmp_path / "bad.gam")
+        open(f, "wb").write(data)
+        try:
+            hc.AlnSet.read_gam(f, keep_unmapped=True)
+            host_ok = True
+        except N.NativeError:
+            host_ok = False
+        if host_ok:
+            assert check_against_host(gd, data, True) <= 60, (trial, k)
+            taken += 1
+        else:
+            with pytest.raises(N.NativeError):
+                gd.parse(data, True)
+            refused += 1
+    assert taken > 20 and refused > 20, (taken, refused)
+    gd.close()
+
+
 def test_the_mask_call_back_comes_once_with_the_final_mask(tmp_path):
     """vgan_hc_devflat_run_gamdev_cb: the call-back runs on the calling thread when host_mask is final (before the write pass), once;
     the batch is the one vgan_hc_devflat_run_gamdev gives."""
