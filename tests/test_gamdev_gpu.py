@@ -354,6 +354,44 @@ def test_messages_with_a_damaged_byte_are_taken_or_refused_as_the_host_parser_do
     gd.close()
 
 
+def test_tag_like_bytes_inside_messages_never_give_another_framing(tmp_path):
+    """Read names and sequences that hold the group tag's bytes (03 'G' 'A' 'M', with a plausible count in front): a segment whose first
+    tag-like bytes are not a group's start cannot be walked consistently -- the file is then refused (the caller takes the host
+    pipeline) -- and a file that IS taken has the host parser's arrays."""
+    import gamio
+    rng = np.random.default_rng(21)
+    fake = bytes([5, 3]) + b"GAM" + bytes([40]) + b"\x0a\x10ACGTACGTACGTACGT"  # count, tag, a length, the start of an Alignment
+    taken = refused = 0
+    for trial in range(6):
+        alns = []
+        for r in range(16000):
+            node = int(rng.integers(1, 500))
+            n = int(rng.integers(30, 120))
+            name = b"read%d" % r
+            seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+            if trial and rng.random() < 0.02 * trial:
+                name = name + fake
+            if trial > 2 and rng.random() < 0.01:
+                seq = seq + fake
+            alns.append({"sequence": seq, "name": name, "quality": bytes(rng.integers(2, 41, n, dtype=np.uint8)), "mapping_quality": 60, "identity": 1.0,
+                         "path": {"mapping": [{"position": {"node_id": node, "offset": int(rng.integers(0, 5))},
+                                               "edit": [{"from_length": n, "to_length": n}], "rank": 1}]}})
+        raw = gamio.write_gam(alns, group=int(rng.integers(3, 700)), compress=False)
+        assert len(raw) > 2 * (1 << 20)  # several segments
+        data = _bgzf(raw)
+        gd = GamDev()
+        try:
+            n_reads = check_against_host(gd, data, True)
+            assert n_reads == 16000
+            taken += 1
+        except N.NativeError as e:
+            assert "framed" in str(e) or "malformed" in str(e), str(e)
+            refused += 1
+        gd.close()
+    assert taken >= 1, (taken, refused)  # (trial 0 holds no such bytes)
+    print("tag-like bytes: %d files taken, %d refused" % (taken, refused))
+
+
 def test_the_mask_call_back_comes_once_with_the_final_mask(tmp_path):
     """vgan_hc_devflat_run_gamdev_cb: the call-back runs on the calling thread when host_mask is final (before the write pass), once;
     the batch is the one vgan_hc_devflat_run_gamdev gives."""
