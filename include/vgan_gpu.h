@@ -371,7 +371,8 @@ int vgan_hc_accumulate_packed(vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
 int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *out, uint64_t out_cap, uint64_t *out_size, double *kernel_ms);
 /* (ABI 5) The whole front end: a BGZF GAM file's bytes -> the parser's arrays on the device, as kernels: inflate (a lane per BGZF
  * member), framing of libvgio's groups (a lane per 1 MiB segment, from the first group tag "GAM" it finds to the next segment's: the
- * walks must meet, or the call fails with VGAN_EIO and the caller takes the host pipeline), protobuf wire walk of vg.Alignment (a lane
+ * walks must meet -- a segment whose first tag-like bytes the walk in front does not arrive at takes the next ones --, or the call fails
+ * with VGAN_EIO and the caller takes the host pipeline), protobuf wire walk of vg.Alignment (a lane
  * per message: sizes, exclusive sums, fill).  What it leaves on the device is, bit for bit, what vgan_gam_stream's parser and the
  * narrowing of vgan_hc_devflat_run make of the same file: 32-bit offsets, node ids, mapping offsets, edit lengths (-1: not a match
  * or substitution), quality and substitution bytes, the identity as HaploCart.cpp:410's one bit, and the first mapping's
@@ -381,8 +382,8 @@ typedef struct vgan_gamdev vgan_gamdev;
 int vgan_gamdev_create(int device, void *hip_stream, vgan_gamdev **out);
 void vgan_gamdev_free(vgan_gamdev *g);
 int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, int keep_unmapped);
-/* sizes[8]: inflated bytes, messages, reads, mappings, edits, edit-sequence bytes, quality bytes, 0; ms[4]: upload, inflate, framing,
- * parsing (wall, synchronous) */
+/* sizes[8]: inflated bytes, messages, reads, mappings, edits, edit-sequence bytes, quality bytes, and (test aid) the tag-like bytes the
+ * framing of the object's parses took for a group's tag and gave up again; ms[4]: upload, inflate, framing, parsing (wall, synchronous) */
 int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double ms[4]);
 /* Duplicate marks of the last parse's reads on the device (src/rmdup.cpp's single-end rule, keep-first by the first mapping's (node
  * id, offset): two stable radix sorts + a mark pass); vgan_gamdev_dup_marks: the device array (uint8 per read), for

@@ -149,7 +149,7 @@ class GamDev:
         sizes = np.zeros(8, np.uint64)
         ms = np.zeros(4)
         N.check(N.lib().vgan_gamdev_sizes(self._h, sizes.ctypes.data, ms.ctypes.data))
-        self.sizes = dict(zip(("inflated", "messages", "R", "M", "E", "S", "Q"), (int(x) for x in sizes[:7])))
+        self.sizes = dict(zip(("inflated", "messages", "R", "M", "E", "S", "Q", "reanchored"), (int(x) for x in sizes[:8])))
         self.ms = dict(zip(("upload", "inflate", "frame", "parse"), ms))
         return self
 
@@ -356,8 +356,8 @@ def test_messages_with_a_damaged_byte_are_taken_or_refused_as_the_host_parser_do
 
 def test_tag_like_bytes_inside_messages_never_give_another_framing(tmp_path):
     """Read names and sequences that hold the group tag's bytes (03 'G' 'A' 'M', with a plausible count in front): a segment whose first
-    tag-like bytes are not a group's start cannot be walked consistently -- the file is then refused (the caller takes the host
-    pipeline) -- and a file that IS taken has the host parser's arrays."""
+    tag-like bytes are not a group's start is found out by the walk in front of it, which does not arrive there, and takes the next
+    ones; the file is framed as the host frames it, array for array."""
     import gamio
     rng = np.random.default_rng(21)
     fake = bytes([5, 3]) + b"GAM" + bytes([40]) + b"\x0a\x10ACGTACGTACGTACGT"  # count, tag, a length, the start of an Alignment
@@ -380,16 +380,12 @@ def test_tag_like_bytes_inside_messages_never_give_another_framing(tmp_path):
         assert len(raw) > 2 * (1 << 20)  # several segments
         data = _bgzf(raw)
         gd = GamDev()
-        try:
-            n_reads = check_against_host(gd, data, True)
-            assert n_reads == 16000
-            taken += 1
-        except N.NativeError as e:
-            assert "framed" in str(e) or "malformed" in str(e), str(e)
-            refused += 1
+        assert check_against_host(gd, data, True) == 16000
+        refused += gd.sizes["reanchored"]
+        taken += 1
         gd.close()
-    assert taken >= 1, (taken, refused)  # (trial 0 holds no such bytes)
-    print("tag-like bytes: %d files taken, %d refused" % (taken, refused))
+    assert taken == 6 and refused > 0, (taken, refused)  # (tag-like bytes were met first in some segment, and given up)
+    print("tag-like bytes: %d files framed, %d false tags given up" % (taken, refused))
 
 
 def test_the_mask_call_back_comes_once_with_the_final_mask(tmp_path):

@@ -532,17 +532,9 @@ __device__ __forceinline__ int gd_varint(const uint8_t *u, uint64_t e, uint64_t 
 }
 
 // One WAVE per segment: the first tag in [seg start (or 1), seg end); a match may begin in the segment and end beyond it.
-__global__ __launch_bounds__(256) void gd_anchor_kernel(const uint8_t *__restrict__ u, uint64_t n, uint64_t seg_bytes, uint32_t n_segs,
-                                                        uint64_t *__restrict__ anchor) {
-    const uint32_t lane = threadIdx.x & 63u, seg = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (seg >= n_segs) return;
-    const uint64_t s0 = (uint64_t)seg * seg_bytes, s1 = min(n, s0 + seg_bytes);
-    uint64_t found = GD_NO_ANCHOR;
-    if (seg == 0) { // the stream's own start: the walk begins in header state at offset 0, no tag is looked for
-        if (lane == 0) anchor[0] = 0;
-        return;
-    }
-    for (uint64_t base = s0 & ~15ull; base < s1; base += 64u * 16u) {
+// the first tag in [from, s1) (a wave searches: every lane gets the result), GD_NO_ANCHOR when there is none
+__device__ __forceinline__ uint64_t gd_find_tag(const uint8_t *__restrict__ u, uint64_t n, uint64_t from, uint64_t s1, uint32_t lane) {
+    for (uint64_t base = from & ~15ull; base < s1; base += 64u * 16u) {
         const uint64_t at = base + (uint64_t)lane * 16u;
         uint32_t w[5] = {0, 0, 0, 0, 0};
         if (at + 20 <= n) {
@@ -559,17 +551,37 @@ __global__ __launch_bounds__(256) void gd_anchor_kernel(const uint8_t *__restric
             const uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
             const uint32_t win = (i & 3) ? (uint32_t)(((uint64_t)hi << 32 | lo) >> (8 * (i & 3))) : lo;
             const uint64_t pos = at + (uint64_t)i;
-            if (win == GD_TAG && pos >= s0 && pos < s1 && pos >= 1) hit = (uint32_t)i;
+            if (win == GD_TAG && pos >= from && pos < s1 && pos >= 1) hit = (uint32_t)i;
         }
         const uint64_t m = __builtin_amdgcn_ballot_w64(hit < 16);
         if (m) {
             const uint32_t l0 = (uint32_t)__builtin_ctzll(m);
             const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hit, (int)l0);
-            found = base + (uint64_t)l0 * 16u + h0;
-            break;
+            return base + (uint64_t)l0 * 16u + h0;
         }
     }
+    return GD_NO_ANCHOR;
+}
+__global__ __launch_bounds__(256) void gd_anchor_kernel(const uint8_t *__restrict__ u, uint64_t n, uint64_t seg_bytes, uint32_t n_segs,
+                                                        uint64_t *__restrict__ anchor) {
+    const uint32_t lane = threadIdx.x & 63u, seg = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (seg >= n_segs) return;
+    const uint64_t s0 = (uint64_t)seg * seg_bytes, s1 = min(n, s0 + seg_bytes);
+    if (seg == 0) { // the stream's own start: the walk begins in header state at offset 0, no tag is looked for
+        if (lane == 0) anchor[0] = 0;
+        return;
+    }
+    const uint64_t found = gd_find_tag(u, n, s0, s1, lane);
     if (lane == 0) anchor[seg] = found;
+}
+// One segment's anchor again, from behind the one it had: the walk in front of it did not arrive there -- those four bytes were not a
+// group's tag but a message's own (a stream of random bytes holds them every 4 GB; a segment begins with ~300 KB that are not a tag)
+__global__ __launch_bounds__(64) void gd_reanchor_kernel(const uint8_t *__restrict__ u, uint64_t n, uint64_t seg_bytes, uint32_t seg,
+                                                         uint64_t *__restrict__ anchor) {
+    const uint64_t s0 = (uint64_t)seg * seg_bytes, s1 = min(n, s0 + seg_bytes);
+    const uint64_t old = anchor[seg];
+    const uint64_t found = old == GD_NO_ANCHOR ? GD_NO_ANCHOR : gd_find_tag(u, n, max(s0, old + 1), s1, threadIdx.x);
+    if (threadIdx.x == 0) anchor[seg] = found;
 }
 
 // One LANE per anchored segment: the walk from its tag to the next anchored segment's tag (or the stream's end).  emit = false:
@@ -1153,6 +1165,7 @@ struct vgan_gamdev {
     GBuf<uint64_t> sort_key, sort_key2, picked_off;
     GBuf<uint32_t> perm_a, perm_b, pick, pick_bytes, k_at, b_at;
     hipStream_t piece_stream[GD_PIECES] = {}; // vgan_gamdev_parse: the file's pieces, each copied and inflated on a stream of its own
+    uint64_t n_reanchored = 0; // (test aid) tag-like bytes the framing of the parses so far took for a group's tag and gave up again
     uint64_t n_picked = 0, n_picked_bytes = 0;
     uint64_t n_inflated = 0, n_messages = 0, R = 0, M = 0, E = 0, S = 0, Q = 0;
     double ms_inflate = 0, ms_frame = 0, ms_parse = 0, ms_upload = 0;
@@ -1323,20 +1336,34 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
         (rc = g->msg_base.reserve(n_segs)))
         return rc;
     hipLaunchKernelGGL(gd_anchor_kernel, dim3((n_segs + 3) / 4), dim3(256), 0, st, g->infl.p, total, seg_bytes, n_segs, g->anchor.p);
-    hipLaunchKernelGGL(gd_next_anchor_kernel, dim3(1), dim3(1), 0, st, g->anchor.p, n_segs, total, g->next_anchor.p);
-    hipLaunchKernelGGL(gd_frame_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, g->infl.p, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
-                       (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, g->seg_status.p);
-    HIPCHK(hipGetLastError());
     std::vector<uint32_t> seg_n(n_segs), seg_st(n_segs);
-    HIPCHK(hipMemcpyAsync(seg_n.data(), g->seg_msgs.p, n_segs * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(seg_st.data(), g->seg_status.p, n_segs * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint64_t> nxt(n_segs);
+    // The walks must meet: segment 0's walk is the true one, so the FIRST walk that misses the next anchored segment's tag says that
+    // tag is not a group's -- that segment takes the next tag-like bytes behind it (or none: the walk in front goes on through it),
+    // and the walks are counted again.  A walk that breaks (not: misses) is a malformed stream.
+    for (uint32_t again = 0;; ++again) {
+        hipLaunchKernelGGL(gd_next_anchor_kernel, dim3(1), dim3(1), 0, st, g->anchor.p, n_segs, total, g->next_anchor.p);
+        hipLaunchKernelGGL(gd_frame_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, g->infl.p, total, n_segs, g->anchor.p, g->next_anchor.p,
+                           g->seg_msgs.p, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, g->seg_status.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(seg_n.data(), g->seg_msgs.p, n_segs * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(seg_st.data(), g->seg_status.p, n_segs * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        uint32_t f = 0;
+        while (f < n_segs && seg_st[f] == GF_OK) ++f;
+        if (f == n_segs) break;
+        if (seg_st[f] != GF_MISSED || again >= 256u)
+            return fail(VGAN_EIO, "vgan_gamdev_parse: the stream cannot be framed from segment %u (code %u: %s)", f, seg_st[f],
+                        seg_st[f] == GF_MISSED ? "a segment's walk does not meet the next one's group tag" : "malformed or truncated");
+        HIPCHK(hipMemcpy(nxt.data(), g->next_anchor.p, n_segs * 8, hipMemcpyDeviceToHost));
+        if (nxt[f] >= total) return fail(VGAN_EIO, "vgan_gamdev_parse: the stream cannot be framed from segment %u (its walk passes the stream's end)", f);
+        const uint32_t suspect = (uint32_t)(nxt[f] / seg_bytes);
+        hipLaunchKernelGGL(gd_reanchor_kernel, dim3(1), dim3(64), 0, st, g->infl.p, total, seg_bytes, suspect, g->anchor.p);
+        g->n_reanchored += 1;
+    }
     std::vector<uint64_t> base(n_segs);
     uint64_t n_msg = 0;
     for (uint32_t s = 0; s < n_segs; ++s) {
-        if (seg_st[s] != GF_OK)
-            return fail(VGAN_EIO, "vgan_gamdev_parse: the stream cannot be framed from segment %u (code %u: %s)", s, seg_st[s],
-                        seg_st[s] == GF_MISSED ? "a segment's walk does not meet the next one's group tag" : "malformed or truncated");
         base[s] = n_msg;
         n_msg += seg_n[s];
     }
@@ -1405,7 +1432,7 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
 extern "C" int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double ms[4]) {
     if (!g) return fail(VGAN_EINVAL, "vgan_gamdev_sizes: null argument");
     if (sizes) {
-        const uint64_t v[8] = {g->n_inflated, g->n_messages, g->R, g->M, g->E, g->S, g->Q, 0};
+        const uint64_t v[8] = {g->n_inflated, g->n_messages, g->R, g->M, g->E, g->S, g->Q, g->n_reanchored};
         memcpy(sizes, v, sizeof v);
     }
     if (ms) {
