@@ -45,7 +45,6 @@ namespace vgan {
 namespace gd {
 
 // ------------------------------------------------------------------------------------------------------------------ inflate
-constexpr int INF_LIT = 288, INF_DIST = 30, INF_ROW = 322; // symbols per lane: 288 + 30, padded to an odd number of dwords (161)
 enum : uint32_t { GD_OK = 0, GD_BAD_BLOCK = 1, GD_BAD_CODE = 2, GD_OVERRUN_IN = 3, GD_OVERRUN_OUT = 4, GD_BAD_STORED = 5 };
 
 // LSB-first bit reader over 4-byte words, one word ahead: the word that refills `buf` was requested a refill earlier.  (The payload is
@@ -1145,7 +1144,10 @@ template <class T> struct GBuf {
 };
 } // namespace
 
-static constexpr int GD_PIECES = 4;
+#ifndef GD_PIECES_N
+#define GD_PIECES_N 4
+#endif
+static constexpr int GD_PIECES = GD_PIECES_N;
 
 struct vgan_gamdev {
     int device = 0;

@@ -606,7 +606,10 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
             if (n_out > 8) need_place = true; // (the next tile places the window anew)
         }
         // fast: every column term comes from the workgroup's table; gfast: from the context's (a read of another mapping quality)
-        const bool tabled = all_cls && !tile_out && q_plain, fast = tabled && all_major, gfast = tabled && !all_major;
+        const bool tabled = all_cls && !tile_out && q_plain, gfast = tabled && !all_major;
+#ifdef C8_PHASES
+        const bool fast = tabled && all_major;
+#endif
         C8_MARK(2);
         if (gfast) {
 #pragma unroll
