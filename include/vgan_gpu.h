@@ -466,7 +466,9 @@ void vgan_hc_destroy(vgan_hc_ctx *c);
  * has to run it (a batch without .packed). */
 enum { VGAN_HC_K_SEGMENT = 0, VGAN_HC_K_SWEEP_SEG = 1, VGAN_HC_K_SWEEP_NODE = 2, VGAN_HC_K_FINISH = 3, VGAN_HC_K_PACK = 4,
        VGAN_HC_K_COUNT = 5 };
-int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable);  /* also clears the counters */
+/* enable: 0 off, 1 events around every kernel, 2 around the segment kernel alone (a pair of events is ~8 us of the stream's time: a
+ * caller timing whole steps at the same time -- bench.py -- asks for the one kernel its roofline is about).  Also clears the counters. */
+int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable);
 /* synchronises the stream; ms[i] = summed device time of kernel i, launches[i] = number of launches timed */
 int vgan_hc_profile_read(vgan_hc_ctx *c, double ms[5], uint64_t launches[5]);
 

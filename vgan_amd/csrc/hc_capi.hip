@@ -136,7 +136,7 @@ struct vgan_hc_ctx {
     std::string post_predicted, post_clades;
     uint32_t post_n_off = 0, post_ns = 0;
     // profiling: pairs of events per timed launch, resolved in vgan_hc_profile_read
-    bool profiling = false;
+    int profiling = 0; // 0 off, 1 HIP events around every kernel, 2 around the segment kernel only
     struct Timed {
         int slot;
         hipEvent_t a, b;
@@ -165,7 +165,7 @@ struct ScopedTimer {
         return e;
     }
     ScopedTimer(vgan_hc_ctx *ctx, int s) : c(ctx), slot(s) {
-        if (!c->profiling) return;
+        if (!c->profiling || (c->profiling == 2 && slot != VGAN_HC_K_SEGMENT)) return;
         a = get(c);
         b = get(c);
         if (a) (void)hipEventRecord(a, c->stream);
@@ -1211,7 +1211,7 @@ extern "C" int vgan_hc_profile_enable(vgan_hc_ctx *c, int enable) {
         c->prof_ms[i] = 0;
         c->prof_n[i] = 0;
     }
-    c->profiling = enable != 0;
+    c->profiling = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return VGAN_OK;
 }
 

@@ -656,8 +656,9 @@ class HcContext:
     def finalize_device(self, device_out):
         N.check(N.lib().vgan_hc_finalize(self._h, device_out.data_ptr(), None))
 
-    def profile_enable(self, enable=True):
-        N.check(N.lib().vgan_hc_profile_enable(self._h, int(enable)))
+    def profile_enable(self, enable=True, segment_only=False):
+        """HIP events around the context's kernels (segment_only: around the segment kernel alone -- a pair of events is ~8 us of stream time)."""
+        N.check(N.lib().vgan_hc_profile_enable(self._h, 2 if (enable and segment_only) else int(bool(enable))))
 
     def profile_read(self):
         """{kernel: (summed device ms, launches)} measured with HIP events on the context's stream."""
