@@ -144,7 +144,7 @@ extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_v
         return code;
     };
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev0, hipEventDisableSystemFence) != hipSuccess || hipEventCreateWithFlags(&c->ev1, hipEventDisableSystemFence) != hipSuccess)
         return bail(fail(VGAN_ENODEV, "stream/event creation failed"));
     c->stream = c->own_stream;
     if ((rc = c->bp.upload(bp)) || (rc = c->bp_clade.upload(bpc)) ||

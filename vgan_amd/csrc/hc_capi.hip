@@ -161,7 +161,7 @@ struct ScopedTimer {
             return e;
         }
         hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
+        (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); // (timing only: no system-scope fence with every record)
         return e;
     }
     ScopedTimer(vgan_hc_ctx *ctx, int s) : c(ctx), slot(s) {

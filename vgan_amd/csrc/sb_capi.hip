@@ -152,7 +152,7 @@ extern "C" int vgan_sb_create(const vgan_graph_view *gv, const vgan_damage_view 
     };
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(VGAN_ENODEV, "stream creation failed"));
     for (auto &e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) return bail(fail(VGAN_ENODEV, "event creation failed"));
+        if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return bail(fail(VGAN_ENODEV, "event creation failed"));
     c->stream = c->own_stream;
     int rc;
     if ((rc = c->mask.upload(gv->mask, (size_t)rows * W)) || (rc = c->findable.upload(findable.data(), findable.size())) ||
