@@ -149,3 +149,24 @@ def test_soa_batches_whose_quality_strings_outrun_their_columns_keep_to_the_othe
         ctx.accumulate(hc.ArrayBatch(arr, n_tileable=nt))
         outs.append(ctx.finalize())
     assert util.rel_err(outs[0], outs[1]) < 1e-12
+
+
+def test_profile_events_around_every_kernel_or_the_segment_kernel_alone():
+    """vgan_hc_profile_enable: 1 times every kernel of a step, 2 the segment kernel alone (what bench.py's timed steps ask for); the
+    sums come out the same with either."""
+    g = hc.synth_graph(seed=41, genome_len=4000, n_nodes=2600, n_paths=200)
+    a = hc.synth_reads(g, 20000, seed=42, read_len=150)
+    hb = hc.HostBatch(g, a, packed=True)
+    ctx = hc.HcContext(g)
+    got = {}
+    for mode, kw in ((1, {}), (2, {"segment_only": True})):
+        ctx.reset()
+        ctx.profile_enable(True, **kw)
+        for _ in range(3):
+            ctx.accumulate(hb)
+        got[mode] = ctx.finalize()
+        pr = ctx.profile_read()
+        ctx.profile_enable(False)
+        assert pr["segment"][1] == 3 and pr["segment"][0] > 0
+        assert (pr["sweep_nodes"][1], pr["finish"][1]) == ((1, 1) if mode == 1 else (0, 0))
+    assert np.max(np.abs(got[1] - got[2]) / np.abs(got[1])) < 1e-13
