@@ -40,7 +40,7 @@ constexpr int EK_WAVES = 4;
 constexpr int EK_GROUP = 16;                              // lanes per read: a DPP row
 constexpr int EK_READS_PER_WAVE = 64 / EK_GROUP;          // 4 reads per wave,
 constexpr int EK_READS_PER_BLOCK = EK_WAVES * EK_READS_PER_WAVE; // 16 per workgroup
-constexpr uint32_t EK_DMG_LDS_PAIRS = 64;                 // (5' row, 3' row) pairs kept in LDS (10 KB)
+constexpr uint32_t EK_DMG_LDS_PAIRS = 64;                 // (5' row, 3' row) pairs kept in LDS (512 bytes each)
 constexpr int EK_ACC_LTP = 8;                             // lengthToProf up to which a wave keeps the base shifts in LDS,
 constexpr int EK_ACC_BINS = 32;                           // bins per clade up to which it keeps the coverage there
 
@@ -102,10 +102,13 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
     // one of them the quarter-rate reciprocal, per column (w_hit itself is only needed on a softclip column: 1 - d.qscore[q] there)
     __shared__ double2 qs_s[100];
     __shared__ LogTabEntry logtab_s[64];
-    // per (5' row, 3' row) pair, read base rb and original base o: {M[o][rb], rowsum[o]} -- what a column needs for one original
-    // base in ONE 16-byte read, and the four original bases of a column (o, o ^ 1, o ^ 2, o ^ 3) at addresses that differ by an
-    // exclusive-or of the 16-byte index (256 bytes per pair; the global table of euka_device.h keeps its 160)
-    // (sized by the launch: 256 bytes per pair of the context's tables, not the 64 pairs the variant allows -- the workgroups a CU holds
+    // per (5' row, 3' row) pair, read base rb and graph base g, the column's sum over the original bases with everything that does
+    // not depend on the read's clade folded in:  p = sum_o pre[o] * (w_miss * rowsum[o] + dw * M[o][rb]),  pre = 1 - dist at g,
+    // dist * 0.95238 at g ^ 2, dist * 0.02381 at the other two, is  w_miss * (rs + dist * D_rs) + dw * (M + dist * D_M)  with
+    // rs = rowsum[g], M = M[g][rb], D_x = 0.95238 * x[g ^ 2] + 0.02381 * (x[g ^ 1] + x[g ^ 3]) - x[g]: an entry {M, rs, D_M, D_rs}
+    // of 32 bytes -- two 16-byte reads and four fused multiply-adds per column where the four original bases took four reads
+    // and thirteen operations (512 bytes per pair; the global table of euka_device.h keeps its 160)
+    // (sized by the launch: per pair of the context's tables, not the 64 pairs the variant allows -- the workgroups a CU holds
     // follow its LDS)
     extern __shared__ double2 dmg_s[];
     // byte -> class: low nibble = ACGT index 0..3, else 8; high nibble = the rank of the lambda's special cases in
@@ -133,8 +136,11 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
     for (int i = threadIdx.x; i < 64; i += blockDim.x) logtab_s[i] = euka_log_table[i];
     if (DMG_LDS)
         for (uint32_t i = threadIdx.x; i < d.n5 * d.n3 * 16u; i += blockDim.x) {
-            const uint32_t pair = i >> 4, rb = (i >> 2) & 3u, o = i & 3u;
-            dmg_s[i] = double2{d.dmg_pair[pair * 20u + 4u * rb + o], d.dmg_pair[pair * 20u + 16u + o]};
+            const uint32_t pair = i >> 4, rb = (i >> 2) & 3u, g = i & 3u;
+            const double *m = d.dmg_pair + pair * 20u + 4u * rb, *rs = d.dmg_pair + pair * 20u + 16u;
+            dmg_s[2u * i] = double2{m[g], rs[g]};
+            dmg_s[2u * i + 1u] = double2{(0.95238 * m[g ^ 2u] + 0.02381 * (m[g ^ 1u] + m[g ^ 3u])) - m[g],
+                                         (0.95238 * rs[g ^ 2u] + 0.02381 * (rs[g ^ 1u] + rs[g ^ 3u])) - rs[g]};
         }
     {
         uint32_t *z = reinterpret_cast<uint32_t *>(acc_s);
@@ -343,18 +349,13 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 // (a read byte outside ACGT matches no column: dw = 0 there -- a case for the branch of the odd columns below)
                 double dw = qe.y;
                 const uint32_t o0 = gi & 3u;
-                double d0, d1, d2, d3;
+                double p;
                 if constexpr (DMG_LDS) {
-                    // byte offset of entry {M[o0][rb], rowsum[o0]}: pair * 256 + rb * 64 + o0 * 16; the other three original bases
-                    // differ in the o bits by an exclusive-or
-                    const uint32_t a0 = ((pair_ix << 8) | ((rcl << 6) & 0xC0u)) | ((gcl << 4) & 0x30u);
+                    // byte offset of the entry of (pair, rb, g): pair * 512 + rb * 128 + g * 32
+                    const uint32_t a0 = ((pair_ix << 9) | ((rcl << 7) & 0x180u)) | ((gcl << 5) & 0x60u);
                     const uint8_t *tab = reinterpret_cast<const uint8_t *>(dmg_s);
-                    const double2 e0 = *reinterpret_cast<const double2 *>(tab + a0), e1 = *reinterpret_cast<const double2 *>(tab + (a0 ^ 16u)),
-                                  e2 = *reinterpret_cast<const double2 *>(tab + (a0 ^ 32u)), e3 = *reinterpret_cast<const double2 *>(tab + (a0 ^ 48u));
-                    d0 = w_miss * e0.y + dw * e0.x;
-                    d2 = w_miss * e2.y + dw * e2.x;
-                    d1 = w_miss * e1.y + dw * e1.x;
-                    d3 = w_miss * e3.y + dw * e3.x;
+                    const double2 e0 = *reinterpret_cast<const double2 *>(tab + a0), e1 = *reinterpret_cast<const double2 *>(tab + a0 + 16u);
+                    p = w_miss * (e0.y + pair_dist * e1.y) + dw * (e0.x + pair_dist * e1.x);
                 } else {
                     dw = ri < 4u ? dw : 0.0;
                     uint32_t e_ix;
@@ -362,12 +363,10 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                     const double *e = d.dmg_pair + e_ix; // pair table layout: euka_device.h
                     const double *mcol = e + 4u * (ri & 3u); // M[.][read base]
                     const uint32_t o1 = o0 ^ 1u, o2 = o0 ^ 2u, o3 = o0 ^ 3u;
-                    d0 = w_miss * e[16 + o0] + dw * mcol[o0];
-                    d2 = w_miss * e[16 + o2] + dw * mcol[o2];
-                    d1 = w_miss * e[16 + o1] + dw * mcol[o1];
-                    d3 = w_miss * e[16 + o3] + dw * mcol[o3];
+                    const double d0 = w_miss * e[16 + o0] + dw * mcol[o0], d2 = w_miss * e[16 + o2] + dw * mcol[o2];
+                    const double d1 = w_miss * e[16 + o1] + dw * mcol[o1], d3 = w_miss * e[16 + o3] + dw * mcol[o3];
+                    p = (1.0 - pair_dist) * d0 + pair_dist * (0.95238 * d2 + 0.02381 * (d1 + d3));
                 }
-                double p = (1.0 - pair_dist) * d0 + pair_dist * (0.95238 * d2 + 0.02381 * (d1 + d3));
                 // model 1 = c1 + log(a1), model 2 = l2.  A regular column of two ACGT bytes -- all but a few per thousand -- has
                 // a1 = p, c1 = 0 and l2 one of two constants, which are counted instead of added; everything else (an inactive
                 // lane included) starts from a1 = 1, c1 = l2 = 0 and the cases below pick what differs
@@ -402,10 +401,8 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                         a1 = 0.0;
                         if (gi < 4u) {
                             if constexpr (DMG_LDS) {
-                                const uint32_t ix = (pair_ix << 4) | o0; // (any read base: only the row sums are used)
-                                const double z0 = w_miss * dmg_s[ix].y, z1 = w_miss * dmg_s[ix ^ 1u].y, z2 = w_miss * dmg_s[ix ^ 2u].y,
-                                             z3 = w_miss * dmg_s[ix ^ 3u].y;
-                                a1 = (1.0 - pair_dist) * z0 + pair_dist * (0.95238 * z2 + 0.02381 * (z1 + z3));
+                                const uint32_t ix = ((pair_ix << 4) | o0) * 2u; // (any read base: only the row sums are used)
+                                a1 = w_miss * (dmg_s[ix].y + pair_dist * dmg_s[ix + 1u].y);
                             } else {
                                 a1 = p; // (dw was selected above)
                             }
@@ -688,7 +685,7 @@ void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev
     if (const char *e = getenv("VGAN_EUKA_BLOCKS")) cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap; // developer aid
     blocks = blocks < cap ? blocks : cap;
     if (d.n5 * d.n3 <= EK_DMG_LDS_PAIRS)
-        hipLaunchKernelGGL(euka_read_kernel<true>, dim3(blocks), dim3(EK_WAVES * 64), (size_t)d.n5 * d.n3 * 16u * sizeof(double2), st, d, b, o);
+        hipLaunchKernelGGL(euka_read_kernel<true>, dim3(blocks), dim3(EK_WAVES * 64), (size_t)d.n5 * d.n3 * 32u * sizeof(double2), st, d, b, o);
     else
         hipLaunchKernelGGL(euka_read_kernel<false>, dim3(blocks), dim3(EK_WAVES * 64), 0, st, d, b, o);
 }
