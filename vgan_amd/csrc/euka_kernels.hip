@@ -77,6 +77,7 @@ struct EkBlk {
     int32_t mapq[64], cn[64];
     double pd[64], in[64], out[64];
     uint8_t passed[64]; // the block's reads that passed, in order (stage D takes them four at a time)
+    uint8_t order[64];  // the block's reads by their number of columns (stage B takes them four at a time)
 };
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
@@ -247,6 +248,17 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 blk.bins[lane] = (b0 & 0xFFFFFFu) | (min(d.bin_off[c_n + 1] - b0, 255u) << 24);
             }
             blk.mapq[lane] = b.read_mapq[r];
+            {
+                // the four rows of a step walk their columns together, to the longest of the four: the block's reads are taken in
+                // the order of their lengths, so that four of about one length share the steps (in file order the longest of
+                // four fragments of 75 +- 17 columns costs a step more than the average one -- a sixth of the column loop).  What
+                // a read adds to its outputs and to the sums does not depend on the rows beside it.
+                const uint32_t key = (uint32_t)lane < nb ? ((uint32_t)b.read_gseq_len[r] << 6) | (uint32_t)lane : 0xFFFFFFFFu;
+                uint32_t rank = 0;
+#pragma unroll
+                for (int j = 0; j < 64; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key ? 1u : 0u;
+                blk.order[rank] = (uint8_t)lane;
+            }
             blk.cn[lane] = c_n;
             blk.pd[lane] = d.clade_dist[c_n];
             // the block's first read names the wave's clade; a read of another clade (a boundary block) adds to the global tables
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
         uint32_t gc_next, rc_next;
         int q_next;
         auto first_bytes = [&](uint32_t g4n) {
-            const uint32_t i = min(g4n + grp, nb - 1u);
+            const uint32_t i = blk.order[min(g4n + grp, nb - 1u)];
             const uint32_t col0 = blk.col0[i], q0 = blk.q0[i];
             const uint32_t g_last = max(blk.ga[i] & 0xFFFFu, 1u) - 1u, q_last = max(blk.lq[i] >> 16, 1u) - 1u;
             gc_next = b.graph_seq[col0 + min(sub, g_last)];
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
         first_bytes(0);
         for (uint32_t g4 = 0; g4 < nb; g4 += EK_READS_PER_WAVE) {
             const bool have = g4 + grp < nb; // this row has a read
-            const uint32_t i = min(g4 + grp, nb - 1u);
+            const uint32_t i = blk.order[min(g4 + grp, nb - 1u)];
             const uint32_t col0 = blk.col0[i], ga = blk.ga[i], lq = blk.lq[i], q0 = blk.q0[i];
             const uint32_t G = have ? (ga & 0xFFFFu) : 0u, A = ga >> 16, Lseq = lq & 0xFFFFu, QL = lq >> 16;
             const bool rev = (blk.flags[i] & 1u) != 0;
