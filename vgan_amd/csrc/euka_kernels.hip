@@ -80,6 +80,16 @@ struct EkBlk {
     uint8_t order[64];  // the block's reads by their number of columns (stage B takes them four at a time)
 };
 
+// cnt += the number of lanes k of the DPP row whose value v has v - lo <= w (unsigned): sixteen subtractions that take their operand
+// from lane k of the row
+template <int K> __device__ __forceinline__ void ek_count_row(int32_t v, uint32_t lo, uint32_t w, uint32_t &cnt) {
+    if constexpr (K < 16) {
+        const uint32_t vk = (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
+        cnt += vk - lo <= w ? 1u : 0u;
+        ek_count_row<K + 1>(v, lo, w, cnt);
+    }
+}
+
 // sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
 __device__ __forceinline__ double row_sum16(double v) {
     v += dpp_mov0<0x128, 0xf>(v);
@@ -590,15 +600,9 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                     for (uint32_t mb = 0; mb < max_nm; mb += EK_GROUP) {
                         int32_t node = mb == 0u ? here.n0 : here.n1;
                         if (mb >= 2u * EK_GROUP) node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1; // (beyond 32 mappings)
-                        const uint32_t inn = min((uint32_t)EK_GROUP, max_nm - mb);
-                        // four nodes of the row per step: the four lane exchanges are in flight together (one at a time, each
-                        // step waited for its own)
-                        for (uint32_t k = 0; k < inn; k += 4u) {
-                            const int32_t n0 = __shfl(node, (int)(gshift + k), 64), n1 = __shfl(node, (int)(gshift + k + 1u), 64),
-                                          n2 = __shfl(node, (int)(gshift + k + 2u), 64), n3 = __shfl(node, (int)(gshift + k + 3u), 64);
-                            cnt += ((uint32_t)n0 - my_lo <= my_w ? 1u : 0u) + ((uint32_t)n1 - my_lo <= my_w ? 1u : 0u) +
-                                   ((uint32_t)n2 - my_lo <= my_w ? 1u : 0u) + ((uint32_t)n3 - my_lo <= my_w ? 1u : 0u);
-                        }
+                        // lane k of the row hands its node to the whole row (DPP row_newbcast:k -- an operand of the subtraction, no
+                        // trip through the LDS crossbar as a lane exchange is); a lane without a mapping holds -1, which no bin holds
+                        ek_count_row<0>(node, my_lo, my_w, cnt);
                     }
                     if (cnt) {
                         if (in_acc && jb + sub < (uint32_t)EK_ACC_BINS) unsafeAtomicAdd(&acc.cov[jb + sub], (double)cnt * inv);
