@@ -193,6 +193,54 @@ def test_long_reads_and_ragged_read_counts():
     assert got["pass"].sum() >= 5 and (fin["bin_cov"] > 0).sum() >= 8
 
 
+def test_bin_coverage_of_scattered_and_repeated_nodes():
+    """Bin coverage (readGAM_Euka.h:520-546) when a read's nodes are NOT a short run of ids: nodes 64 ids and more apart, a node
+    met twice, exactly 63 / 64 ids of span, in rows beside ordinary reads and on their own -- the device counts a bin's nodes
+    from a 64-bit word of node bits where it can and by comparison where it cannot, and both must give the oracle's sums."""
+    import ctypes as C
+    from vgan_amd import _native as N
+    rng = np.random.default_rng(23)
+    n_nodes = 260
+    lens = rng.integers(4, 9, n_nodes)
+    seqs = [bytes(rng.choice(list(b"ACGT"), int(L)).astype(np.uint8)) for L in lens]
+    off = np.zeros(n_nodes + 2, np.int64)
+    off[2:] = np.cumsum(lens)
+    g = hc.Graph.from_arrays(1, n_nodes, off, b"".join(seqs), 1, np.zeros((n_nodes + 1, 1), np.uint64),
+                             np.full(n_nodes + 1, -1, np.int32), np.ones(1))
+    # clade 0: nodes 1..130 in overlapping bins (one of a single node, one the wrong way round); clade 1: the rest, 18 bins
+    lo0, hi0 = [1, 30, 64, 64, 100, 90], [40, 70, 64, 130, 99, 130]
+    lo1 = [131 + 7 * k for k in range(18)]
+    hi1 = [min(260, x + 9) for x in lo1]
+    bo = np.array([0, len(lo0), len(lo0) + len(lo1)], np.uint32)
+    lo, hi = np.array(lo0 + lo1, np.int32), np.array(hi0 + hi1, np.int32)
+    cd = np.array([0.09, 0.17])
+    en = np.zeros(len(lo))
+    v = N.EukaDbView(2, None, cd.ctypes.data, None, None, None, b"c0\nc1\n", bo.ctypes.data, lo.ctypes.data, hi.ctypes.data, en.ctypes.data)
+    h = N.vp()
+    N.check(N.lib().vgan_euka_db_from_arrays(C.byref(v), C.byref(h)))
+    db = ek.EukaDb(h)
+    shapes = [lambda a: list(range(a, a + 6)),                       # ordinary
+              lambda a: [a, a + 1, a + 100, a + 101, a + 2],         # far apart
+              lambda a: [a, a + 1, a, a + 1, a + 2],                 # met twice
+              lambda a: [a, a + 63, a + 1],                          # the last bit of the word
+              lambda a: [a, a + 64, a + 1],                          # one beyond it
+              lambda a: [a + 70, a + 3, a],                          # the smallest node last
+              lambda a: list(range(a, a + 30)),                      # both registers of the row
+              lambda a: list(range(a, a + 34))]                      # beyond them
+    alns = []
+    order = [0] * 8 + list(range(8)) * 4 + [0, 0, 0, 1, 0, 2, 0, 0, 6, 6, 6, 6, 7, 0, 0, 0]
+    for i, k in enumerate(order):
+        a0 = int(rng.integers(1, 25)) if i % 2 else int(rng.integers(131, 150))
+        nodes = shapes[k](a0)
+        read = b"".join(seqs[nd - 1] for nd in nodes)
+        maps = [(nd, 0, False, [(len(seqs[nd - 1]), len(seqs[nd - 1]), b"")]) for nd in nodes]
+        alns.append(_mk(read, rng.integers(30, 42, len(read)).tolist(), maps, mapq=60))
+    a = hc.AlnSet.parse_gam(gamio.write_gam(alns))
+    d = os.path.join(GOLD, "damageProfiles")
+    got, fin, ref = compare(g, db, a, (open(d + "/dhigh5p.prof").read(), open(d + "/dhigh3p.prof").read()))
+    assert got["pass"].sum() >= 40 and (fin["bin_cov"] > 0).sum() >= 12
+
+
 def test_accumulate_in_batches_and_after_finalize():
     """Per-clade accumulators are kept in replicas that finalize folds together: batches before and after a finalize
     must add up to the single-batch result."""

@@ -90,6 +90,23 @@ template <int K> __device__ __forceinline__ void ek_count_row(int32_t v, uint32_
     }
 }
 
+// minimum / bitwise or over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
+__device__ __forceinline__ uint32_t row_min16(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ uint64_t row_or16(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xf, 0xf, false), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xf, 0xf, false);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x124, 0xf, 0xf, false), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x124, 0xf, 0xf, false);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x122, 0xf, 0xf, false), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x122, 0xf, 0xf, false);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x121, 0xf, 0xf, false), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x121, 0xf, 0xf, false);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 // sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
 __device__ __forceinline__ double row_sum16(double v) {
     v += dpp_mov0<0x128, 0xf>(v);
@@ -493,13 +510,16 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
         bool any_pass;
         uint32_t n_pass_blk = 0u;
         {
+            // (lane k takes the k-th read in the order of the lengths: the reads that pass come out in that order, and stage D's
+            // rows, too, hold four reads of about one length -- and of about as many mappings)
             const bool mine = (uint32_t)lane < nb;
-            const uint32_t r = bstart + min((uint32_t)lane, nb - 1u);
-            const uint32_t fl = blk.flags[lane];
+            const uint32_t li = blk.order[min((uint32_t)lane, nb - 1u)];
+            const uint32_t r = bstart + li;
+            const uint32_t fl = blk.flags[li];
             const bool bad = mine && (fl & 2u) != 0;
             const bool live = mine && !bad;
-            const double in = blk.in[lane], out = blk.out[lane];
-            const int32_t mapq = blk.mapq[lane], c_n = blk.cn[lane];
+            const double in = blk.in[li], out = blk.out[li];
+            const int32_t mapq = blk.mapq[li], c_n = blk.cn[li];
             const bool in_acc = c_n == cur;
             if (bad) {
                 o.clade[r] = -1;
@@ -523,9 +543,9 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 o.not_like[r] = 1.0 - like;
                 o.pass[r] = pass ? 1 : 0;
             }
-            if (pass) blk.flags[lane] = fl | 4u;
+            if (pass) blk.flags[li] = fl | 4u;
             const uint64_t pass_m = __builtin_amdgcn_ballot_w64(pass);
-            if (pass) blk.passed[__builtin_popcountll(pass_m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+            if (pass) blk.passed[__builtin_popcountll(pass_m & ((1ull << lane) - 1ull))] = (uint8_t)li;
             n_pass_blk = (uint32_t)__builtin_popcountll(pass_m);
             // the abundance MCMC only ever uses sum_k log(frac * clade_like[k]) per clade (MCMC.cpp:1175-1215, (1/334) == 0):
             // keep the count and the sum of logs; a read with like == 0 (mapq 0, or exp underflow) makes the sum -inf as there
@@ -584,6 +604,21 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 const uint32_t nm = pass ? nm_all : 0u;
                 const double inv = 1.0 / (double)nm_all;
                 const uint32_t max_nb = wave_max4(nbin), max_nm = wave_max4(nm);
+                // A read's nodes lie close together -- a walk of a few dozen mappings through nodes numbered along the graph --:
+                // as bits of one 64-bit word, counted from the smallest of them, a bin's count is the population of the bits
+                // between its bounds, a dozen instructions where the comparison of every node with every bin is three per node.
+                // The word holds every node exactly when its population is the number of mappings: a node further than 64 ids from
+                // the smallest, one met twice, or more than the 32 mappings the row holds in registers leave it short, and the
+                // step (all four rows of it) counts by comparison instead.
+                uint64_t node_bits;
+                uint32_t node_min;
+                bool by_bits;
+                {
+                    node_min = row_min16(min((uint32_t)here.n0, (uint32_t)here.n1)); // (no mapping: -1, the largest)
+                    const uint32_t d0 = (uint32_t)here.n0 - node_min, d1 = (uint32_t)here.n1 - node_min;
+                    node_bits = row_or16((here.n0 >= 0 && d0 < 64u ? 1ull << d0 : 0ull) | (here.n1 >= 0 && d1 < 64u ? 1ull << d1 : 0ull));
+                    by_bits = __builtin_amdgcn_ballot_w64((uint32_t)__builtin_popcountll(node_bits) != nm) == 0;
+                }
                 for (uint32_t jb = 0; jb < max_nb; jb += EK_GROUP) {
                     const bool mine = jb + sub < nbin;
                     // node in [lo, hi] as ONE unsigned compare: node - lo <= hi - lo; a lane without a bin (and a bin whose bounds
@@ -597,6 +632,13 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                     b_lo = max(b_lo, 0); // (node ids are >= 0)
                     const uint32_t my_lo = b_hi >= b_lo ? (uint32_t)b_lo : 0x80000000u, my_w = b_hi >= b_lo ? (uint32_t)(b_hi - b_lo) : 0u;
                     uint32_t cnt = 0;
+                    if (by_bits) {
+                        const int64_t a = (int64_t)my_lo - (int64_t)node_min, z = a + (int64_t)my_w; // the bin, in bit positions
+                        if (a <= 63 && z >= 0) {
+                            const uint32_t lo_c = (uint32_t)max(a, (int64_t)0), hi_c = (uint32_t)min(z, (int64_t)63);
+                            cnt = (uint32_t)__builtin_popcountll(node_bits & (~0ull << lo_c) & (~0ull >> (63u - hi_c)));
+                        }
+                    } else
                     for (uint32_t mb = 0; mb < max_nm; mb += EK_GROUP) {
                         int32_t node = mb == 0u ? here.n0 : here.n1;
                         if (mb >= 2u * EK_GROUP) node = mb + sub < nm ? (int32_t)b.map_node[m0 + mb + sub] : -1; // (beyond 32 mappings)
