@@ -55,13 +55,18 @@ struct vgan_euka_ctx {
     Buf<uint32_t> bp, bin_off;
     Buf<int32_t> bp_clade, bin_lo, bin_hi, node_clade;
     Buf<double> clade_dist, sub5p, sub3p, tables, dmg_pair;
-    // accumulators
-    Buf<int32_t> clade_count;
-    Buf<uint32_t> baseshift;
-    Buf<double> bin_cov;
-    Buf<uint32_t> like_n;
-    Buf<double> like_logsum;
-    Buf<unsigned long long> n_bad;
+    // accumulators: slices of one allocation (one launch clears them all: vgan_euka_reset)
+    template <class T> struct Slice {
+        T *p = nullptr;
+    };
+    Buf<uint8_t> acc_all;
+    size_t acc_bytes = 0;
+    Slice<int32_t> clade_count;
+    Slice<uint32_t> baseshift;
+    Slice<double> bin_cov;
+    Slice<uint32_t> like_n;
+    Slice<double> like_logsum;
+    Slice<unsigned long long> n_bad;
     // staging (host batches) and per-read outputs
     Buf<uint32_t> s32;
     Buf<uint16_t> s16;
@@ -155,11 +160,23 @@ extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_v
         (rc = c->sub5p.upload(std::vector<double>(dmg->sub5p, dmg->sub5p + (size_t)dmg->n5 * 16))) ||
         (rc = c->sub3p.upload(std::vector<double>(dmg->sub3p, dmg->sub3p + (size_t)dmg->n3 * 16))) ||
         (rc = c->tables.upload(tb)) || (rc = c->dmg_pair.upload(pair)) ||
-        (!node_clade.empty() && (rc = c->node_clade.upload(node_clade))) || (rc = c->clade_count.reserve((size_t)EUKA_REPLICAS * c->n_clades)) ||
-        (rc = c->like_n.reserve((size_t)EUKA_REPLICAS * c->n_clades)) || (rc = c->like_logsum.reserve((size_t)EUKA_REPLICAS * c->n_clades)) ||
-        (rc = c->baseshift.reserve((size_t)EUKA_REPLICAS * c->n_clades * 2 * std::max(1, c->ltp) * 16)) ||
-        (rc = c->bin_cov.reserve((size_t)EUKA_REPLICAS * std::max<uint32_t>(1, c->n_bins))) || (rc = c->n_bad.reserve(1)))
+        (!node_clade.empty() && (rc = c->node_clade.upload(node_clade))))
         return bail(rc);
+    {
+        auto up256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
+        const size_t n_cc = up256((size_t)EUKA_REPLICAS * c->n_clades * 4), n_ln = n_cc, n_ls = up256((size_t)EUKA_REPLICAS * c->n_clades * 8),
+                     n_bs = up256((size_t)EUKA_REPLICAS * c->n_clades * 2 * std::max(1, c->ltp) * 16 * 4),
+                     n_bc = up256((size_t)EUKA_REPLICAS * std::max<uint32_t>(1, c->n_bins) * 8);
+        c->acc_bytes = n_cc + n_ln + n_ls + n_bs + n_bc + 256;
+        if ((rc = c->acc_all.reserve(c->acc_bytes))) return bail(rc);
+        uint8_t *q = c->acc_all.p;
+        c->bin_cov.p = reinterpret_cast<double *>(q), q += n_bc;
+        c->like_logsum.p = reinterpret_cast<double *>(q), q += n_ls;
+        c->n_bad.p = reinterpret_cast<unsigned long long *>(q), q += 256;
+        c->baseshift.p = reinterpret_cast<uint32_t *>(q), q += n_bs;
+        c->clade_count.p = reinterpret_cast<int32_t *>(q), q += n_cc;
+        c->like_n.p = reinterpret_cast<uint32_t *>(q);
+    }
     c->d.bp = c->bp.p;
     c->d.bp_clade = c->bp_clade.p;
     c->d.n_bp = (uint32_t)bp.size();
@@ -200,12 +217,7 @@ extern "C" void vgan_euka_destroy(vgan_euka_ctx *c) {
     c->sub5p.release();
     c->sub3p.release();
     c->tables.release();
-    c->clade_count.release();
-    c->baseshift.release();
-    c->bin_cov.release();
-    c->like_n.release();
-    c->like_logsum.release();
-    c->n_bad.release();
+    c->acc_all.release();
     c->s32.release();
     c->s16.release();
     c->s8.release();
@@ -228,12 +240,8 @@ extern "C" int vgan_euka_set_stream(vgan_euka_ctx *c, void *s) {
 extern "C" int vgan_euka_reset(vgan_euka_ctx *c) {
     if (!c) return fail(VGAN_EINVAL, "vgan_euka_reset: null context");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->clade_count.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->baseshift.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 2 * std::max(1, c->ltp) * 16 * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->bin_cov.p, 0, (size_t)EUKA_REPLICAS * std::max<uint32_t>(1, c->n_bins) * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->like_n.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->like_logsum.p, 0, (size_t)EUKA_REPLICAS * c->n_clades * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->n_bad.p, 0, 8, c->stream));
+    launch_euka_clear(c->acc_all.p, c->acc_bytes, c->stream);
+    HIPCHK(hipGetLastError());
     return VGAN_OK;
 }
 

@@ -67,5 +67,6 @@ struct EukaOutDev {
 void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev &o, hipStream_t st);
 // sums the replicas into replica 0 (count/baseshift/bin_cov element-wise)
 void launch_euka_reduce(const EukaOutDev &o, uint32_t n_clades, int32_t ltp, hipStream_t st);
+void launch_euka_clear(void *p, size_t bytes, hipStream_t st); // zero fill, bytes a multiple of 16
 
 } // namespace vgan
