@@ -84,6 +84,7 @@ extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_v
                                 int device, vgan_euka_ctx **out) {
     if (!db || !dmg || !prm || !out) return fail(VGAN_EINVAL, "vgan_euka_create: null argument");
     if (db->n_clades == 0 || !db->clade_dist || !db->bin_off) return fail(VGAN_EINVAL, "vgan_euka_create: empty clade table");
+    if (db->n_clades > (1u << 20)) return fail(VGAN_ERANGE, "vgan_euka_create: %u clades (the kernel indexes the per-clade tables in 32 bits: at most 2^20)", db->n_clades);
     if (dmg->n5 == 0 || dmg->n3 == 0) return fail(VGAN_EINVAL, "vgan_euka_create: empty damage tables");
     if (prm->length_to_prof < 0 || prm->length_to_prof > 32) return fail(VGAN_EINVAL, "vgan_euka_create: length_to_prof must be 0..32");
     int ndev = 0;

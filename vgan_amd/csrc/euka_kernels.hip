@@ -92,27 +92,27 @@ template <int K> __device__ __forceinline__ void ek_count_row(int32_t v, uint32_
 
 // minimum / bitwise or over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
 __device__ __forceinline__ uint32_t row_min16(uint32_t v) {
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, true));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, true));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, true));
     return v;
 }
 __device__ __forceinline__ uint64_t row_or16(uint64_t v) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xf, 0xf, false), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xf, 0xf, false);
-    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x124, 0xf, 0xf, false), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x124, 0xf, 0xf, false);
-    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x122, 0xf, 0xf, false), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x122, 0xf, 0xf, false);
-    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x121, 0xf, 0xf, false), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x121, 0xf, 0xf, false);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xf, 0xf, true), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xf, 0xf, true);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x124, 0xf, 0xf, true), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x124, 0xf, 0xf, true);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x122, 0xf, 0xf, true), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x122, 0xf, 0xf, true);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x121, 0xf, 0xf, true), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x121, 0xf, 0xf, true);
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
 __device__ __forceinline__ double row_sum16(double v) {
-    v += dpp_mov0<0x128, 0xf>(v);
-    v += dpp_mov0<0x124, 0xf>(v);
-    v += dpp_mov0<0x122, 0xf>(v);
-    v += dpp_mov0<0x121, 0xf>(v);
+    v += dpp_mov0<0x128, 0xf, true>(v);
+    v += dpp_mov0<0x124, 0xf, true>(v);
+    v += dpp_mov0<0x122, 0xf, true>(v);
+    v += dpp_mov0<0x121, 0xf, true>(v);
     return v;
 }
 
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                     const uint32_t g4i = up4_s[gb], r4i = up4_s[rb];
                     if ((g4i | r4i) < 4u) {
                         if (in_acc && shift_in_lds) atomicAdd(&acc.shift[p * 16 + g4i * 4 + r4i], 1u);
-                        else atomicAdd(&baseshift[((size_t)c_n * 2 * d.ltp + p) * 16 + g4i * 4 + r4i], 1u);
+                        else atomicAdd(&baseshift[(__umul24((uint32_t)c_n, 2u * (uint32_t)d.ltp) + (uint32_t)p) * 16u + g4i * 4u + r4i], 1u); // (32 bits: at most 2^20 clades, vgan_euka_create)
                     }
                 }
             }
