@@ -40,6 +40,9 @@ constexpr int EK_WAVES = 4;
 constexpr int EK_GROUP = 16;                              // lanes per read: a DPP row
 constexpr int EK_READS_PER_WAVE = 64 / EK_GROUP;          // 4 reads per wave,
 constexpr int EK_READS_PER_BLOCK = EK_WAVES * EK_READS_PER_WAVE; // 16 per workgroup
+#ifndef EK_BG
+#define EK_BG 8 // lanes per read in the column stage (16: a DPP row per read, four reads per step; 8: eight reads per step)
+#endif
 constexpr uint32_t EK_DMG_LDS_PAIRS = 64;                 // (5' row, 3' row) pairs kept in LDS (512 bytes each)
 constexpr int EK_ACC_LTP = 8;                             // lengthToProf up to which a wave keeps the base shifts in LDS,
 constexpr int EK_ACC_BINS = 32;                           // bins per clade up to which it keeps the coverage there
@@ -105,6 +108,14 @@ __device__ __forceinline__ uint64_t row_or16(uint64_t v) {
     lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x122, 0xf, 0xf, true), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x122, 0xf, 0xf, true);
     lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x121, 0xf, 0xf, true), hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x121, 0xf, 0xf, true);
     return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// sum over the 8 lanes of half a DPP row, result in every lane of the half (row_half_mirror, then the two exchanges within a quad)
+__device__ __forceinline__ double row_sum8(double v) {
+    v += dpp_mov0<0x141, 0xf, true>(v); // lane i <-> 7 - i
+    v += dpp_mov0<0xB1, 0xf, true>(v);  // quad_perm [1,0,3,2]
+    v += dpp_mov0<0x4E, 0xf, true>(v);  // quad_perm [2,3,0,1]
+    return v;
 }
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8/4/2/1)
@@ -185,6 +196,20 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
         return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
                    max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
     };
+    // the column stage's rows: BG lanes per read.  What a step costs beside its columns -- a read's set-up, the closing logarithm,
+    // the row sums, the base shifts: some 210 vector instructions, four 16-column steps' worth -- is paid once per step whatever
+    // the number of reads in it: with eight lanes per read a step takes eight reads (and twice the steps of half the columns)
+    constexpr uint32_t BG = EK_BG, BROWS = 64u / BG;
+    const uint32_t subB = lane & (BG - 1u), gshiftB = (uint32_t)lane & (64u - BG), grpB = (uint32_t)lane / BG;
+    const uint32_t belowB = (1u << subB) - 1u;
+    auto row_bitsB = [&](bool p) { return (uint32_t)(__builtin_amdgcn_ballot_w64(p) >> gshiftB) & ((1u << BG) - 1u); };
+    auto wave_maxB = [&](uint32_t v) { // max over the rows of a value that is uniform within each row
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < BROWS; ++k) m = max(m, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(k * BG)));
+        return m;
+    };
+    auto row_sumB = [&](double v) { return BG == 16u ? row_sum16(v) : row_sum8(v); };
     // this workgroup's replica of the per-clade accumulators
     const uint32_t rep = blockIdx.x % EUKA_REPLICAS;
     int32_t *const clade_count = o.clade_count + (size_t)rep * d.n_clades;
@@ -297,22 +322,22 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- B: a row per read, four reads per step
+        // ---- B: a row of BG lanes per read, 64 / BG reads per step
         // (a group's first three bytes per lane are requested while the group in front is closed: see the column loop)
         uint32_t gc_next, rc_next;
         int q_next;
         auto first_bytes = [&](uint32_t g4n) {
-            const uint32_t i = blk.order[min(g4n + grp, nb - 1u)];
+            const uint32_t i = blk.order[min(g4n + grpB, nb - 1u)];
             const uint32_t col0 = blk.col0[i], q0 = blk.q0[i];
             const uint32_t g_last = max(blk.ga[i] & 0xFFFFu, 1u) - 1u, q_last = max(blk.lq[i] >> 16, 1u) - 1u;
-            gc_next = b.graph_seq[col0 + min(sub, g_last)];
-            rc_next = b.read_seq[col0 + min(sub, g_last)];
-            q_next = (int)(int8_t)b.qual[q0 + min(sub, q_last)];
+            gc_next = b.graph_seq[col0 + min(subB, g_last)];
+            rc_next = b.read_seq[col0 + min(subB, g_last)];
+            q_next = (int)(int8_t)b.qual[q0 + min(subB, q_last)];
         };
         first_bytes(0);
-        for (uint32_t g4 = 0; g4 < nb; g4 += EK_READS_PER_WAVE) {
-            const bool have = g4 + grp < nb; // this row has a read
-            const uint32_t i = blk.order[min(g4 + grp, nb - 1u)];
+        for (uint32_t g4 = 0; g4 < nb; g4 += BROWS) {
+            const bool have = g4 + grpB < nb; // this row has a read
+            const uint32_t i = blk.order[min(g4 + grpB, nb - 1u)];
             const uint32_t col0 = blk.col0[i], ga = blk.ga[i], lq = blk.lq[i], q0 = blk.q0[i];
             const uint32_t G = have ? (ga & 0xFFFFu) : 0u, A = ga >> 16, Lseq = lq & 0xFFFFu, QL = lq >> 16;
             const bool rev = (blk.flags[i] & 1u) != 0;
@@ -328,25 +353,29 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
             bool bad = false;
             // the base-shift columns of the read's ends (Baseshift::baseshift_calc: the first / last lengthToProf columns): a lane's
             // first one is loaded here, behind the column loop it would be a load waited for on the spot
-            uint32_t bs_g = 0u, bs_r = 0u;
-            bool bs_ok = false;
-            if ((int)sub < 2 * d.ltp) {
-                const int p = (int)sub;
-                const int gp = p < d.ltp ? p : (int)G - 2 * d.ltp + p; // (lengths are below 2^16)
-                const int rp = p < d.ltp ? p : (int)A - 2 * d.ltp + p;
-                bs_ok = have && gp >= 0 && rp >= 0 && gp < (int)G && rp < (int)A;
-                if (bs_ok) {
-                    bs_g = b.graph_seq[col0 + (uint32_t)gp];
-                    bs_r = b.read_seq[col0 + (uint32_t)rp];
+            // (two of them: lengthToProf 5 is ten columns, a lane more than a row of eight has)
+            uint32_t bs_g[2] = {0u, 0u}, bs_r[2] = {0u, 0u};
+            bool bs_ok[2] = {false, false};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int p = (int)subB + k * (int)BG;
+                if (p < 2 * d.ltp) {
+                    const int gp = p < d.ltp ? p : (int)G - 2 * d.ltp + p; // (lengths are below 2^16)
+                    const int rp = p < d.ltp ? p : (int)A - 2 * d.ltp + p;
+                    bs_ok[k] = have && gp >= 0 && rp >= 0 && gp < (int)G && rp < (int)A;
+                    if (bs_ok[k]) {
+                        bs_g[k] = b.graph_seq[col0 + (uint32_t)gp];
+                        bs_r[k] = b.read_seq[col0 + (uint32_t)rp];
+                    }
                 }
             }
-            const uint32_t maxG = wave_max4(G);
+            const uint32_t maxG = wave_maxB(G);
             // a step's three bytes are loaded a step ahead (unconditional loads at clamped addresses, selected afterwards):
             // their latency lies behind the step in front instead of in front of their own
             const uint32_t g_last = max(ga & 0xFFFFu, 1u) - 1u, q_last = max(QL, 1u) - 1u;
             const uint32_t n_sign = rev ? 0xFFFFFFFFu : 1u, n_base = rev ? Lseq - 1u : 0u; // the damage position from the non-gap count
-            for (uint32_t base = 0; base < maxG; base += EK_GROUP) {
-                const uint32_t m = base + sub;
+            for (uint32_t base = 0; base < maxG; base += BG) {
+                const uint32_t m = base + subB;
                 // lane masks are kept as what the compares write -- a pair of scalar registers -- and combined there: as a bool a
                 // condition that is the AND of two compares goes through a register and a second compare before a ballot
                 uint64_t act_m, in_a_m, in_q_m;
@@ -358,7 +387,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 const uint32_t rc = __builtin_amdgcn_inverse_ballot_w64(act_m & in_a_m) ? rc_next : 0u;
                 const int q_raw = q_next;
                 {
-                    const uint32_t m2 = m + EK_GROUP;
+                    const uint32_t m2 = m + BG;
                     gc_next = b.graph_seq[col0 + min(m2, g_last)];
                     rc_next = b.read_seq[col0 + min(m2, g_last)];
                     q_next = (int)(int8_t)b.qual[q0 + min(m2, q_last)];
@@ -367,8 +396,8 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 uint64_t nongap_m;
                 asm("v_cmp_ne_u32 %0, 45, %1" : "=s"(nongap_m) : "v"(rc)); // '-'
                 nongap_m &= act_m;
-                const uint32_t nongap = (uint32_t)(nongap_m >> gshift) & 0xFFFFu;
-                const uint32_t n_before = carry_n + (uint32_t)__builtin_popcount(nongap & below);
+                const uint32_t nongap = (uint32_t)(nongap_m >> gshiftB) & ((1u << BG) - 1u);
+                const uint32_t n_before = carry_n + (uint32_t)__builtin_popcount(nongap & belowB);
                 // forward: n_before; reverse strand: Lseq - 1 - n_before (unsigned wrap as in the reference)
                 uint32_t n;
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(n) : "v"(n_before), "v"(n_sign), "v"(n_base));
@@ -430,8 +459,8 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 // N / gap / rare / softclip columns are a few per thousand: the whole wave skips their selects unless it has one
                 if ((act_m & ~regular_m) != 0) {
                     const uint32_t kind = min(gcl >> 4, rcl >> 4); // 0 N, 1 gap, 2 rare, 3 softclip, 4 regular
-                    const uint32_t scb = row_bits(active && kind == 3u);
-                    const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & below) + 1u; // ++softclip_count
+                    const uint32_t scb = row_bitsB(active && kind == 3u);
+                    const uint32_t sc_index = carry_sc + (uint32_t)__builtin_popcount(scb & belowB) + 1u; // ++softclip_count
                     carry_sc += (uint32_t)__builtin_popcount(scb);
                     const double bfl = bfl_s[rcl & 15u];
                     if (active && kind == 4u && !regular) {
@@ -471,22 +500,22 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 }
                 carry_n += (uint32_t)__builtin_popcount(nongap);
             }
-            if (g4 + EK_READS_PER_WAVE < nb) first_bytes(g4 + EK_READS_PER_WAVE);
+            if (g4 + BROWS < nb) first_bytes(g4 + BROWS);
             if (step & 7u) lik += log_tab(prod, true, logtab_s);
             lik2 += (double)n_same * -0.2948543988682102 /* log(1-0.25536) */ + (double)(n_reg - n_same) * -1.3650809647206932 /* log(0.25536) */;
-            const double in = row_sum16(lik), out = row_sum16(lik2);
-            bad = row_bits(bad) != 0u;
-            if (sub == 0 && have) {
+            const double in = row_sumB(lik), out = row_sumB(lik2);
+            bad = row_bitsB(bad) != 0u;
+            if (subB == 0 && have) {
                 blk.in[i] = in;
                 blk.out[i] = out;
                 if (bad) blk.flags[i] |= 2u;
             }
             const bool live = have && !bad;
             // Baseshift::baseshift_calc: first / last lengthToProf columns (baseshift.cpp:57-88)
-            for (int p = (int)sub; p < 2 * d.ltp; p += EK_GROUP) {
-                uint32_t gb = bs_g, rb = bs_r;
-                bool ok = bs_ok;
-                if (p >= EK_GROUP) { // (lengthToProf above 8: the further columns are loaded here)
+            for (int p = (int)subB, k = 0; p < 2 * d.ltp; p += (int)BG, ++k) {
+                uint32_t gb = k == 0 ? bs_g[0] : bs_g[1], rb = k == 0 ? bs_r[0] : bs_r[1];
+                bool ok = k == 0 ? bs_ok[0] : bs_ok[1];
+                if (k >= 2) { // (a long lengthToProf: the further columns are loaded here)
                     const int gp = p < d.ltp ? p : (int)G - 2 * d.ltp + p;
                     const int rp = p < d.ltp ? p : (int)A - 2 * d.ltp + p;
                     ok = have && gp >= 0 && rp >= 0 && gp < (int)G && rp < (int)A;
