@@ -1012,16 +1012,23 @@ __global__ __launch_bounds__(256) void gd_pick_kernel(const uint32_t *__restrict
     pick[i] = on ? 1u : 0u;
     bytes[i] = on ? msg_len[i] : 0u;
 }
+// the picked messages' numbers, in order (pick's exclusive sums say where)
+__global__ __launch_bounds__(256) void gd_pick_list_kernel(const uint32_t *__restrict__ pick, const uint32_t *__restrict__ k_at, uint32_t n_msg, uint32_t *__restrict__ list) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_msg && pick[i]) list[k_at[i]] = i;
+}
+// a wave per PICKED message (a wave per message of the file, most of them leaving at once, was 48 ms of launches for 10 M messages)
 __global__ __launch_bounds__(256) void gd_gather_kernel(const uint8_t *__restrict__ u, const uint64_t *__restrict__ msg_off, const uint32_t *__restrict__ msg_len,
-                                                        const uint32_t *__restrict__ pick, const uint32_t *__restrict__ k_at, const uint32_t *__restrict__ b_at,
-                                                        uint32_t n_msg, uint8_t *__restrict__ out, uint64_t *__restrict__ out_off) {
-    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u; // a wave per message
-    if (wave == 0 && lane == 0) out_off[0] = 0; // (whether message 0 is among the picked or not)
-    if (wave >= n_msg || !pick[wave]) return;
-    const uint8_t *src = u + msg_off[wave];
-    uint8_t *dst = out + b_at[wave];
-    for (uint32_t k = lane; k < msg_len[wave]; k += 64u) dst[k] = src[k];
-    if (lane == 0) out_off[k_at[wave] + 1] = (uint64_t)b_at[wave] + msg_len[wave];
+                                                        const uint32_t *__restrict__ list, const uint32_t *__restrict__ b_at, uint32_t n_picked,
+                                                        uint8_t *__restrict__ out, uint64_t *__restrict__ out_off) {
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (wave == 0 && lane == 0) out_off[0] = 0;
+    if (wave >= n_picked) return;
+    const uint32_t i = list[wave], len = msg_len[i];
+    const uint8_t *src = u + msg_off[i];
+    uint8_t *dst = out + b_at[i];
+    for (uint32_t k = lane; k < len; k += 64u) dst[k] = src[k];
+    if (lane == 0) out_off[wave + 1] = (uint64_t)b_at[i] + len;
 }
 
 } // namespace gd
@@ -1165,7 +1172,7 @@ struct vgan_gamdev {
     GBuf<int64_t> first_node, first_offset;
     GBuf<uint8_t> dup, picked_bytes;           // duplicate marks per read; the messages handed back to the host
     GBuf<uint64_t> sort_key, sort_key2, picked_off;
-    GBuf<uint32_t> perm_a, perm_b, pick, pick_bytes, k_at, b_at;
+    GBuf<uint32_t> perm_a, perm_b;
     hipStream_t piece_stream[GD_PIECES] = {}; // vgan_gamdev_parse: the file's pieces, each copied and inflated on a stream of its own
     uint64_t n_reanchored = 0; // (test aid) tag-like bytes the framing of the parses so far took for a group's tag and gave up again
     uint64_t n_picked = 0, n_picked_bytes = 0;
@@ -1182,7 +1189,7 @@ struct vgan_gamdev {
         for (auto *b : {&unmapped, &m_rev, &e_seq, &qual}) b->release();
         first_node.release(), first_offset.release();
         dup.release(), picked_bytes.release(), sort_key.release(), sort_key2.release(), picked_off.release();
-        for (auto *b : {&perm_a, &perm_b, &pick, &pick_bytes, &k_at, &b_at}) b->release();
+        for (auto *b : {&perm_a, &perm_b}) b->release();
     }
 };
 
@@ -1423,6 +1430,9 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
                        g->s_at.p, g->q_at.p, o, g->map_rec.p);
     if (g->M) hipLaunchKernelGGL(gd_fill_maps_kernel, dim3((uint32_t)((g->M + 255) / 256)), dim3(256), 0, st, g->infl.p, g->map_rec.p, (uint32_t)g->M, o);
     HIPCHK(hipGetLastError());
+    // what vgan_gamdev_pick will want, asked for now: device memory asked for while another thread asks for the packed batch's 12 GB
+    // and the device is busy took 180 ms there (its four arrays per message are the count arrays above, done with by then)
+    if ((rc = g->picked_bytes.reserve(std::max<uint64_t>(g->R, total / 32 + 1))) || (rc = g->picked_off.reserve(NM / 32 + 2))) return rc;
     HIPCHK(hipStreamSynchronize(st));
     g->ms_parse = ms_since(t0);
     if (getenv("VGAN_TIMING")) fprintf(stderr, "[vgan timing] gamdev: device memory asked for so far took %.1f ms\n", g_alloc_ms);
@@ -1541,29 +1551,32 @@ extern "C" int vgan_gamdev_pick(vgan_gamdev *g, const uint8_t *read_mask, uint64
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
     const uint32_t NM = (uint32_t)g->n_messages;
+    // the parse's four count arrays (one word per message, done with when the parse ends) hold the flags, the lengths and their sums
+    uint32_t *pick = g->n_map.p, *pick_bytes = g->n_edit.p, *k_at = g->n_eseq.p, *b_at = g->n_qual.p;
     int rc;
-    if ((rc = g->picked_bytes.reserve(g->R)) || (rc = g->pick.reserve(NM)) || (rc = g->pick_bytes.reserve(NM)) || (rc = g->k_at.reserve(NM)) || (rc = g->b_at.reserve(NM)))
-        return rc;
+    if ((rc = g->picked_bytes.reserve(g->R))) return rc;
     uint8_t *d_mask = g->picked_bytes.p; // (borrowed for the mask until the bytes' size is known)
     HIPCHK(hipMemcpyAsync(d_mask, read_mask, g->R, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gd_pick_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, g->keep.p, g->r_at.p, d_mask, g->msg_len.p, NM, g->pick.p, g->pick_bytes.p);
-    if ((rc = exclusive_sum(g, g->pick.p, g->k_at.p, NM)) || (rc = exclusive_sum(g, g->pick_bytes.p, g->b_at.p, NM))) return rc;
+    hipLaunchKernelGGL(gd_pick_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, g->keep.p, g->r_at.p, d_mask, g->msg_len.p, NM, pick, pick_bytes);
+    if ((rc = exclusive_sum(g, pick, k_at, NM)) || (rc = exclusive_sum(g, pick_bytes, b_at, NM))) return rc;
     uint32_t last[4];
-    HIPCHK(hipMemcpyAsync(&last[0], g->pick.p + (NM - 1), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&last[1], g->k_at.p + (NM - 1), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&last[2], g->pick_bytes.p + (NM - 1), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&last[3], g->b_at.p + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[0], pick + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[1], k_at + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[2], pick_bytes + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[3], b_at + (NM - 1), 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     g->n_picked = (uint64_t)last[0] + last[1];
     g->n_picked_bytes = (uint64_t)last[2] + last[3];
     *n_msgs = g->n_picked;
     *n_bytes = g->n_picked_bytes;
     if (g->n_picked == 0) return VGAN_OK;
-    // (the mask's buffer is read by nothing any more: the pick flags hold what it said)
+    // (the mask's buffer is read by nothing any more: the pick flags hold what it said; the lengths' array takes the list)
     if ((rc = g->picked_off.reserve(g->n_picked + 1))) return rc;
     if ((rc = g->picked_bytes.reserve(std::max<uint64_t>(g->n_picked_bytes, g->R)))) return rc;
-    hipLaunchKernelGGL(gd_gather_kernel, dim3((uint32_t)(((uint64_t)NM * 64 + 255) / 256)), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, g->pick.p, g->k_at.p,
-                       g->b_at.p, NM, g->picked_bytes.p, g->picked_off.p);
+    uint32_t *list = pick_bytes;
+    hipLaunchKernelGGL(gd_pick_list_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, pick, k_at, NM, list);
+    hipLaunchKernelGGL(gd_gather_kernel, dim3((uint32_t)((g->n_picked * 64 + 255) / 256)), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, list, b_at,
+                       (uint32_t)g->n_picked, g->picked_bytes.p, g->picked_off.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     return VGAN_OK;

@@ -543,18 +543,27 @@ int haplocart(int argc, char **argv) {
                         left_run.err = vgan_last_error();
                         return;
                     }
+                    const double t_pick = since_ms(t1);
                     std::vector<uint64_t> offs((size_t)nm + 1);
                     std::vector<uint8_t> bytes((size_t)std::max<uint64_t>(nb, 1));
                     vgan_alnparts *left = nullptr;
-                    if (vgan_gamdev_picked(gd.g, offs.data(), bytes.data()) < 0 ||
-                        vgan_alnparts_from_messages(bytes.data(), offs.data(), (int64_t)nm, 0, n_threads, &left) < 0) {
+                    if (vgan_gamdev_picked(gd.g, offs.data(), bytes.data()) < 0) {
                         left_run.err = vgan_last_error();
                         return;
                     }
+                    const double t_down = since_ms(t1);
+                    if (vgan_alnparts_from_messages(bytes.data(), offs.data(), (int64_t)nm, 0, n_threads, &left) < 0) {
+                        left_run.err = vgan_last_error();
+                        return;
+                    }
+                    const double t_parsed = since_ms(t1);
                     const int rc = vgan_hc_flatten_parts_packed(graph, left, 0, vgan_alnparts_count(left), nullptr, 0, &left_run.hb, &sh);
                     vgan_alnparts_free(left);
                     if (rc < 0) left_run.err = vgan_last_error();
                     left_run.ms = since_ms(t1);
+                    if (getenv("VGAN_TIMING"))
+                        fprintf(stderr, "[vgan timing] reads left to the host: %llu messages, %.1f MB; pick %.0f ms, down %.0f, parsed %.0f, flattened %.0f\n",
+                                (unsigned long long)nm, nb / 1e6, t_pick, t_down - t_pick, t_parsed - t_down, left_run.ms - t_parsed);
                 };
                 struct Hook {
                     HostLeft *run;
