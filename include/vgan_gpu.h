@@ -381,6 +381,10 @@ int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *out, uint64_t
 typedef struct vgan_gamdev vgan_gamdev;
 int vgan_gamdev_create(int device, void *hip_stream, vgan_gamdev **out);
 void vgan_gamdev_free(vgan_gamdev *g);
+/* Gives device memory back before the object goes: what = 1 the file's bytes (done with when a parse returns), what = 2 the inflated
+ * bytes as well (after which vgan_gamdev_pick fails with VGAN_EINVAL until the next parse; the parsed arrays stay).  A caller that
+ * frees on a thread of its own beside later kernels shortens the process's end: the driver takes 44 GB apart in ~0.2 s. */
+int vgan_gamdev_drop_bytes(vgan_gamdev *g, int what);
 int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, int keep_unmapped);
 /* sizes[8]: inflated bytes, messages, reads, mappings, edits, edit-sequence bytes, quality bytes, and (test aid) the tag-like bytes the
  * framing of the object's parses took for a group's tag and gave up again; ms[4]: upload, inflate, framing, parsing (wall, synchronous) */

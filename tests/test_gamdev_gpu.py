@@ -450,5 +450,17 @@ def test_whole_chain_on_the_device_against_the_host_pipeline(tmp_path):
     ctx.accumulate(hb2)
     got = ctx.finalize()
     assert np.max(np.abs(got - want) / np.abs(want)) < 1e-12
+    # ---- device memory given back early (the CLI does, beside the kernels that follow): the file's bytes change nothing; without the
+    # inflated bytes the flatten still runs on the parsed arrays, the hand-back of messages says why it cannot, a new parse brings all back
+    gd.drop_bytes()
+    assert gd.picked_parts(res.host_mask).n_reads == n_left
+    gd.drop_bytes(inflated=True)
+    again = df.run_gamdev(gd, device_marks=True)
+    assert np.array_equal(np.array(again.host_mask), np.array(res.host_mask)) and again.n_reads == res.n_reads
+    with pytest.raises(Exception, match="given back"):
+        gd.picked_parts(res.host_mask)
+    gd.parse(data)
+    assert gd.mark_duplicates() == int(dup.sum())
+    assert gd.picked_parts(res.host_mask).n_reads == n_left
     df.close()
     gd.close()

@@ -233,6 +233,7 @@ SYMBOLS = {
     "vgan_alnparts_from_messages": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "vgan_gamdev_create": (C.c_int, [C.c_int, vp, vp]),
     "vgan_gamdev_free": (None, [vp]),
+    "vgan_gamdev_drop_bytes": (C.c_int, [vp, C.c_int]),
     "vgan_gamdev_parse": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
     "vgan_gamdev_open": (C.c_int, [C.c_int, vp, vp, C.c_uint64, C.c_int, vp]),
     "vgan_hc_devflat_run_gamdev_cb": (C.c_int, [vp, vp, vp, C.c_int, C.c_uint32, vp, vp, vp, vp, vp]),

@@ -1225,6 +1225,14 @@ extern "C" void vgan_gamdev_free(vgan_gamdev *g) {
     delete g;
 }
 
+extern "C" int vgan_gamdev_drop_bytes(vgan_gamdev *g, int what) {
+    if (!g || what < 1 || what > 2) return fail(VGAN_EINVAL, "vgan_gamdev_drop_bytes: null object or what not 1 / 2");
+    HIPCHK(hipSetDevice(g->device));
+    g->in.release();
+    if (what >= 2) g->infl.release();
+    return VGAN_OK;
+}
+
 namespace {
 int exclusive_sum(vgan_gamdev *g, const uint32_t *in, uint32_t *out, size_t n) {
     size_t tmp = 0;
@@ -1548,6 +1556,7 @@ extern "C" int vgan_gamdev_pick(vgan_gamdev *g, const uint8_t *read_mask, uint64
     *n_msgs = *n_bytes = 0;
     g->n_picked = g->n_picked_bytes = 0;
     if (g->R == 0 || g->n_messages == 0) return VGAN_OK;
+    if (!g->infl.p) return fail(VGAN_EINVAL, "vgan_gamdev_pick: the inflated bytes were given back (vgan_gamdev_drop_bytes)");
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
     const uint32_t NM = (uint32_t)g->n_messages;

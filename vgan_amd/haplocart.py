@@ -574,6 +574,10 @@ class GamDevice:
         N.check(N.lib().vgan_alnparts_from_messages(byts.ctypes.data, offs.ctypes.data, int(nm.value), int(keep_unmapped), 0, C.byref(h)))
         return AlnParts(h)
 
+    def drop_bytes(self, inflated=False):
+        """vgan_gamdev_drop_bytes: the file's bytes (and, inflated=True, their inflated form: picked_parts is over then) go back to the device."""
+        N.check(N.lib().vgan_gamdev_drop_bytes(self._h, 2 if inflated else 1))
+
     def close(self):
         if getattr(self, "_h", None) and N is not None:
             N.lib().vgan_gamdev_free(self._h)
