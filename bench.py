@@ -607,7 +607,7 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
                                  "reads_taken": int(res2.pk.n_reads), "reads_left_to_the_host": int(res2.host_mask.sum()),
                                  "what": "ten copies of the sample GAM's bytes, one after the other -> inflate, framing, protobuf walk, duplicate marks, "
                                          "flatten as kernels; the file's bytes start in pageable host memory (PCIe inside the figure).  End to end through "
-                                         "`vgan haplocart`, HIP start-up and process exit included: 9-10 M reads/s on a 10 M-read file "
+                                         "`vgan haplocart`, HIP start-up and process exit included: 10-11 M reads/s on a 10 M-read file "
                                          "(tools/e2e_device_gam.py, DESIGN.md section 4.6)"}
             gd.close()
         except Exception as e:  # (a figure beside the metric: its failure is reported, not fatal)
