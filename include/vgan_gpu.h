@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGAN_ABI_VERSION 5
+#define VGAN_ABI_VERSION 6
 
 enum {
     VGAN_OK = 0,
@@ -431,6 +431,56 @@ int vgan_hc_devflat_run_gamdev(vgan_hc_devflat *f, const struct vgan_gamdev *gd,
 int vgan_hc_devflat_run_gamdev_cb(vgan_hc_devflat *f, const struct vgan_gamdev *gd, const uint8_t *skip, int skip_on_device, uint32_t base,
                                   vgan_hc_packed_view *out, uint8_t *host_mask, vgan_hc_flatten_stats *stats, void (*mask_ready)(void *user),
                                   void *user);
+/* (ABI 6) The GAM front end on the device as a PIPELINE over the file's pieces (csrc/gam_pipe.hip; reference: src/readGAM.h:20-68 feeding
+ * HaploCart.cpp:383-421, readGAM_Euka.h:581, getLCAfromGAM.h:31-45).  The BGZF file is cut at member boundaries into pieces of at most
+ * piece_bytes compressed bytes; every piece goes upload -> inflate -> framing -> protobuf walk -> (duplicate marks) -> device flatten ->
+ * likelihood kernels on one of `slots` fixed sets of device buffers of its lane, each set driven by a host thread and a stream of its own:
+ * piece k + 1 is copied and inflated while piece k is framed and parsed and piece k - 1 is flattened and accumulated.  What crosses from a
+ * piece to the next: the framing walk's state and the bytes of the item the piece's end cut (a few hundred bytes: they go in front of the
+ * next piece's inflated bytes), the index of its first read, and -- with duplicate marks -- the (node id, offset) keys seen so far
+ * (src/rmdup.cpp keeps the FIRST read of a key in input order).  With several lanes (one per context: --gpus LIST) piece i goes to lane
+ * i mod n: every device inflates and parses its own pieces, and no data-path collective is needed before the final reduce.  Device
+ * memory: slots x ~(1 + 2.1 x compression ratio) x piece_bytes + one flattened piece per lane, whatever the file's size.
+ * Every array a piece's parse leaves is, bit for bit, the host parser's for the same reads (tests/test_gampipe_gpu.py). */
+typedef struct vgan_gampipe_opts {
+    uint64_t piece_bytes;     /* compressed bytes per piece at most; 0: 256 MB (VGAN_GAMPIPE_PIECE overrides) */
+    int32_t slots;            /* pieces in flight per lane; 0: 3 (VGAN_GAMPIPE_SLOTS overrides) */
+    int32_t keep_unmapped;    /* 0: identity == 0 is dropped (readGAM.h:47) */
+    int32_t mark_duplicates;  /* src/rmdup.cpp's single-end rule */
+    int32_t n_threads;        /* host threads for the reads the device flatten leaves to the host; <= 0: what the process may use */
+    uint64_t tail_bytes;      /* room for the item a piece's end cuts; 0: 8 MB (an item longer than this: VGAN_ERANGE) */
+} vgan_gampipe_opts;
+typedef struct vgan_gampipe_stats {
+    uint64_t n_pieces, compressed_bytes, inflated_bytes, n_messages, n_reads, n_duplicates;
+    uint64_t n_device_reads, n_host_reads; /* flattened on the device / handed back to the host as their messages */
+    uint64_t device_bytes;                 /* device memory the front end held at its peak, summed over lanes (the contexts' own not counted) */
+    uint64_t n_reanchored;                 /* (test aid) tag-like bytes taken for a group's tag and given up again */
+    double ms_wall;                        /* start -> finish */
+    double ms_upload, ms_inflate, ms_frame, ms_parse, ms_dedup, ms_consume; /* summed over pieces (they overlap: not a partition of ms_wall) */
+    double ms_wait_contexts;               /* what the first pieces waited for vgan_hc_gam_attach */
+} vgan_gampipe_stats;
+/* The pieces the options cut a BGZF buffer into (host only; test aid): returns their number, or < 0 when the buffer is not BGZF;
+ * first_member / n_members (or NULL): [n] of them, capacity cap. */
+int64_t vgan_gampipe_plan(const void *bytes, uint64_t n, const vgan_gampipe_opts *opts, uint64_t *piece_in_off, uint64_t *piece_in_bytes,
+                          uint64_t *piece_out_bytes, int64_t cap);
+/* (test aid) One piece of the plan through one vgan_gamdev object, as the pipeline's slot threads do it: upload + inflate, framing from
+ * *carry (an opaque state, NULL-initialised by the caller for piece 0, freed by vgan_gampipe_carry_free), protobuf walk.  The object then
+ * holds the piece's arrays (vgan_gamdev_download, vgan_gamdev_sizes). */
+typedef struct vgan_gampipe_carry vgan_gampipe_carry;
+int vgan_gampipe_parse_piece(vgan_gamdev *g, const void *bytes, uint64_t n, const vgan_gampipe_opts *opts, int64_t piece, vgan_gampipe_carry **carry);
+void vgan_gampipe_carry_free(vgan_gampipe_carry *c);
+/* HaploCart over a BGZF GAM's bytes: everything from the file's bytes to W[node] / Stot of the contexts (one lane per context, which
+ * may share devices).  start: host-only index of the first piece, then threads; upload, inflate, framing and parse begin at once and do
+ * not need the contexts -- attach hands them over when they are ready (the flatten and the kernels start then); finish waits for the
+ * last piece, reports and frees.  A failure (not BGZF, a member that does not inflate, a stream that cannot be framed, no memory) is
+ * reported by finish: the contexts then hold a partial sum -- vgan_hc_reset them and take the host pipeline.  `bytes` must stay valid
+ * until finish returns.  vgan_hc_accumulate_gam_bytes: the three in one call. */
+typedef struct vgan_hc_gamrun vgan_hc_gamrun;
+int vgan_hc_gam_start(const int *devices, int n_lanes, const void *bytes, uint64_t n, const vgan_gampipe_opts *opts, vgan_hc_gamrun **out);
+int vgan_hc_gam_attach(vgan_hc_gamrun *r, vgan_hc_ctx *const *ctxs, int n_ctx, const vgan_graph *graph);
+int vgan_hc_gam_finish(vgan_hc_gamrun *r, vgan_hc_flatten_stats *stats, vgan_gampipe_stats *pstats);
+int vgan_hc_accumulate_gam_bytes(vgan_hc_ctx *const *ctxs, int n_ctx, const vgan_graph *graph, const void *bytes, uint64_t n,
+                                 const vgan_gampipe_opts *opts, vgan_hc_flatten_stats *stats, vgan_gampipe_stats *pstats);
 /* Host check of a packed batch against the layout above and the context's graph (offsets, node ids, head bits, maxima). */
 int vgan_hc_packed_validate(const vgan_hc_ctx *c, const vgan_hc_packed_view *batch);
 /* D_m = S_m - U_m per segment of a packed batch (test / debug aid). Host output [n_segments]. */

@@ -686,7 +686,7 @@ def test_cli_chunk_loop_lanes_and_small_batches_give_the_same_log_likelihoods(tm
             assert 0 < n_host < 30000, line
         if tag == "device_gam":
             line = [ln for ln in r.stderr.splitlines() if "device front end" in ln]
-            assert line and "30000 messages" in line[0] and 0 < int(line[0].split(", the ")[1].split()[0]) < 30000, r.stderr[-1500:]
+            assert line and "30000 messages" in line[0] and 0 < int(line[0].split(" left to the")[0].split()[-1]) < 30000, r.stderr[-1500:]
         ll = dict((ln.split("\t")[0], float(ln.split("\t")[1])) for ln in open(out + ".loglik.tsv").read().splitlines())
         res[tag] = (open(out).read().splitlines()[1], ll)
     for other in ("lanes", "device", "device_small", "device_gam"):

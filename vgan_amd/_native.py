@@ -54,6 +54,21 @@ class FlattenStats(C.Structure):
                 ("n_clamped", C.c_int64), ("n_segments", C.c_int64), ("n_cols", C.c_int64)]
 
 
+class GamPipeOpts(C.Structure):
+    _fields_ = [("piece_bytes", C.c_uint64), ("slots", C.c_int32), ("keep_unmapped", C.c_int32), ("mark_duplicates", C.c_int32),
+                ("n_threads", C.c_int32), ("tail_bytes", C.c_uint64)]
+
+
+class GamPipeStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_pieces", "compressed_bytes", "inflated_bytes", "n_messages", "n_reads", "n_duplicates",
+                                          "n_device_reads", "n_host_reads", "device_bytes", "n_reanchored")] + \
+               [(k, C.c_double) for k in ("ms_wall", "ms_upload", "ms_inflate", "ms_frame", "ms_parse", "ms_dedup", "ms_consume",
+                                          "ms_wait_contexts")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class HcParams(C.Structure):
     _fields_ = [("background_error_prob", C.c_double), ("use_background_error_prob", C.c_int32),
                 ("is_consensus_fasta", C.c_int32)]
@@ -238,6 +253,14 @@ SYMBOLS = {
     "vgan_gamdev_open": (C.c_int, [C.c_int, vp, vp, C.c_uint64, C.c_int, vp]),
     "vgan_hc_devflat_run_gamdev_cb": (C.c_int, [vp, vp, vp, C.c_int, C.c_uint32, vp, vp, vp, vp, vp]),
     "vgan_gamdev_sizes": (C.c_int, [vp, vp, vp]),
+    "vgan_gampipe_plan": (C.c_int64, [vp, C.c_uint64, C.POINTER(GamPipeOpts), vp, vp, vp, C.c_int64]),
+    "vgan_gampipe_parse_piece": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(GamPipeOpts), C.c_int64, C.POINTER(vp)]),
+    "vgan_gampipe_carry_free": (None, [vp]),
+    "vgan_hc_gam_start": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.POINTER(GamPipeOpts), C.POINTER(vp)]),
+    "vgan_hc_gam_attach": (C.c_int, [vp, C.POINTER(vp), C.c_int, vp]),
+    "vgan_hc_gam_finish": (C.c_int, [vp, C.POINTER(FlattenStats), C.POINTER(GamPipeStats)]),
+    "vgan_hc_accumulate_gam_bytes": (C.c_int, [C.POINTER(vp), C.c_int, vp, vp, C.c_uint64, C.POINTER(GamPipeOpts), C.POINTER(FlattenStats),
+                                              C.POINTER(GamPipeStats)]),
     "vgan_gamdev_download": (C.c_int, [vp, C.c_int, vp]),
     "vgan_hc_pack": (C.c_int, [vp, C.POINTER(HcBatch), C.POINTER(vp)]),
     "vgan_hc_packed_free": (None, [vp]),
@@ -318,7 +341,7 @@ SYMBOLS = {
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),
 }
 
-ABI_VERSION = 5  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
+ABI_VERSION = 6  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
 
 HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the null stream by name (a NULL argument selects the context's own stream)
 

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "gam_device.h"
+#include "gam_object.h"
 #include "host/common.h"
 #include "vgan_gpu.h"
 
@@ -45,7 +46,7 @@ namespace vgan {
 namespace gd {
 
 // ------------------------------------------------------------------------------------------------------------------ inflate
-enum : uint32_t { GD_OK = 0, GD_BAD_BLOCK = 1, GD_BAD_CODE = 2, GD_OVERRUN_IN = 3, GD_OVERRUN_OUT = 4, GD_BAD_STORED = 5 };
+// (the GD_* status codes: gam_object.h)
 
 // LSB-first bit reader over 4-byte words, one word ahead: the word that refills `buf` was requested a refill earlier.  (The payload is
 // followed by the member's 8-byte trailer: a word read past the payload's end stays inside the file; past that nothing is read and zero
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(64) void gd_inflate_kernel(const uint8_t *__restric
 // libvgio's stream: groups {count, count x (length, bytes)}; the first item of every group vg writes is the tag "GAM".
 constexpr uint32_t GD_TAG = 0x4D414703u; // the bytes 03 'G' 'A' 'M' as they sit in memory
 constexpr uint64_t GD_NO_ANCHOR = ~0ull;
-enum : uint32_t { GF_OK = 0, GF_BAD_VARINT = 1, GF_MISSED = 2, GF_TRUNCATED = 3, GF_BAD_MESSAGE = 4 };
+// (the GF_* status codes: gam_object.h)
 
 __device__ __forceinline__ uint32_t gd_u32_at(const uint8_t *u, uint64_t n, uint64_t p) { // four bytes at any offset (zeros beyond n)
     uint32_t v = 0;
@@ -585,24 +586,38 @@ __global__ __launch_bounds__(64) void gd_reanchor_kernel(const uint8_t *__restri
 
 // One LANE per anchored segment: the walk from its tag to the next anchored segment's tag (or the stream's end).  emit = false:
 // count the messages; true: write {offset, length} from msg_base[seg].
+// A stream in pieces (gam_object.h: GdCarryState): segment 0 takes up the state the piece before left (`in`); with `open_end` (another
+// piece follows) the walk that reaches the stream's end -- the one whose stop_tag is n -- ends wherever an item is cut by it and leaves its
+// state in `carry`; a walk that runs into the end with a tag still in front of it has missed that tag.
 struct GdWalkOut {
     uint32_t n_msg, status;
 };
 template <bool EMIT>
-__device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t start, bool at_tag, uint64_t stop_tag, uint64_t *msg_off, uint32_t *msg_len,
-                                     uint64_t out_base) {
+__device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t start, uint32_t mode0, uint64_t rem0, uint32_t first0, uint64_t stop_tag,
+                                     uint64_t *msg_off, uint32_t *msg_len, uint64_t out_base, bool open_end, GdCarryState *carry) {
     uint64_t p = start, cnt = 0;
-    uint64_t rem = 0;
-    bool in_group = false, first = false;
-    if (at_tag) {
+    uint64_t rem = rem0;
+    bool in_group = mode0 == 1u, first = first0 != 0u;
+    // the stream ends inside the item at p (or exactly in front of it)
+    auto cut = [&](uint32_t mode) -> GdWalkOut {
+        if (!open_end) return GdWalkOut{(uint32_t)cnt, GF_TRUNCATED};
+        if (stop_tag != n) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
+        *carry = GdCarryState{p, rem, mode, first ? 1u : 0u};
+        return GdWalkOut{(uint32_t)cnt, GF_OK};
+    };
+    if (mode0 == 2u) {
         // the anchor's own group: its count lies before the tag and cannot be told from the previous message's last bytes, so its end
         // is recognised instead -- a count followed by the tag (no message starts with field number 0)   (gam.cpp: frame_segment)
-        p = start + 4;
         for (;;) {
             uint64_t v, q;
-            if (p >= n) return GdWalkOut{(uint32_t)cnt, stop_tag == n && p == n ? GF_OK : GF_TRUNCATED};
+            if (p >= n) {
+                if (open_end) return cut(2u);
+                return GdWalkOut{(uint32_t)cnt, stop_tag == n && p == n ? GF_OK : GF_TRUNCATED};
+            }
             const int r = gd_varint(u, n, p, v, q);
-            if (r <= 0) return GdWalkOut{(uint32_t)cnt, r < 0 ? GF_BAD_VARINT : GF_TRUNCATED};
+            if (r < 0) return GdWalkOut{(uint32_t)cnt, GF_BAD_VARINT};
+            if (r == 0) return cut(2u);
+            if (open_end && q + 4 > n) return cut(2u); // (whether a tag follows cannot be told from these bytes alone)
             if (gd_u32_at(u, n, q) == GD_TAG && q + 4 <= n) { // p is a group header
                 if (q == stop_tag) return GdWalkOut{(uint32_t)cnt, GF_OK};
                 if (q > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
@@ -612,7 +627,7 @@ __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t star
                 p = q;
                 break;
             }
-            if (v > n - q) return GdWalkOut{(uint32_t)cnt, GF_TRUNCATED};
+            if (v > n - q) return cut(2u);
             if (q + v > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED}; // (the next anchor lies inside this item: one of the two tags is no tag)
             if (EMIT) {
                 msg_off[out_base + cnt] = q;
@@ -626,20 +641,25 @@ __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t star
     for (;;) { // the walk proper (gam.cpp: walk)
         uint64_t v, q;
         if (!in_group) {
-            if (p == n) return GdWalkOut{(uint32_t)cnt, stop_tag == n ? GF_OK : GF_MISSED};
+            if (p == n) {
+                if (open_end) return cut(0u);
+                return GdWalkOut{(uint32_t)cnt, stop_tag == n ? GF_OK : GF_MISSED};
+            }
             const int r = gd_varint(u, n, p, v, q);
-            if (r <= 0) return GdWalkOut{(uint32_t)cnt, r < 0 ? GF_BAD_VARINT : GF_TRUNCATED};
+            if (r < 0) return GdWalkOut{(uint32_t)cnt, GF_BAD_VARINT};
+            if (r == 0) return cut(0u);
             rem = v;
             first = true;
             in_group = v != 0;
             p = q;
-            if (in_group && p == stop_tag) return GdWalkOut{(uint32_t)cnt, GF_OK}; // the next anchored segment starts on this group's tag
+            // the next anchored segment starts on this group's tag (a piece that ends behind a group's count: the walk goes on, into the cut)
+            if (in_group && p == stop_tag && !(open_end && stop_tag == n)) return GdWalkOut{(uint32_t)cnt, GF_OK};
             if (p > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
             continue;
         }
         const int r = gd_varint(u, n, p, v, q);
-        if (r <= 0) return GdWalkOut{(uint32_t)cnt, r < 0 ? GF_BAD_VARINT : GF_TRUNCATED};
-        if (v > n - q) return GdWalkOut{(uint32_t)cnt, GF_TRUNCATED};
+        if (r < 0) return GdWalkOut{(uint32_t)cnt, GF_BAD_VARINT};
+        if (r == 0 || v > n - q) return cut(1u);
         const bool tag = first && v == 3 && u[q] == 'G' && u[q + 1] == 'A' && u[q + 2] == 'M';
         if (!tag) {
             if (v > 0xFFFFFFFFull) return GdWalkOut{(uint32_t)cnt, GF_BAD_MESSAGE};
@@ -660,7 +680,7 @@ template <bool EMIT>
 __global__ __launch_bounds__(64) void gd_frame_kernel(const uint8_t *__restrict__ u, uint64_t n, uint32_t n_segs, const uint64_t *__restrict__ anchor,
                                                       const uint64_t *__restrict__ next_anchor, uint32_t *__restrict__ seg_msgs,
                                                       const uint64_t *__restrict__ msg_base, uint64_t *__restrict__ msg_off, uint32_t *__restrict__ msg_len,
-                                                      uint32_t *__restrict__ seg_status) {
+                                                      uint32_t *__restrict__ seg_status, GdCarryState in, int open_end, GdCarryState *__restrict__ carry) {
     const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
     if (seg >= n_segs) return;
     const uint64_t a = anchor[seg];
@@ -671,7 +691,10 @@ __global__ __launch_bounds__(64) void gd_frame_kernel(const uint8_t *__restrict_
         }
         return;
     }
-    const GdWalkOut w = gd_walk_segment<EMIT>(u, n, a, seg != 0, next_anchor[seg], msg_off, msg_len, EMIT ? msg_base[seg] : 0);
+    // segment 0 starts in the state the stream starts in (a file: before a group's count); the others on a tag, inside its group
+    const GdWalkOut w = seg == 0 ? gd_walk_segment<EMIT>(u, n, a, in.mode, in.rem, in.first, next_anchor[seg], msg_off, msg_len, EMIT ? msg_base[seg] : 0,
+                                                         open_end != 0, carry)
+                                 : gd_walk_segment<EMIT>(u, n, a + 4, 2u, 0, 0u, next_anchor[seg], msg_off, msg_len, EMIT ? msg_base[seg] : 0, open_end != 0, carry);
     if (!EMIT) {
         seg_msgs[seg] = w.n_msg;
         seg_status[seg] = w.status;
@@ -760,21 +783,17 @@ __device__ __forceinline__ void gc_skip(GdCur &c, int wt, GdWin &win) {
 }
 
 struct GdSizes { // per message
-    uint32_t n_map, n_edit, eseq, qual;
+    uint32_t n_map, n_edit, eseq, qual, seq;
 };
 struct GdOut { // the arrays of one DfSlice (hc_flatten_kernels.hip) and what the host's duplicate marks need
     uint32_t *map_off, *qual_off, *edit_off, *e_seq_off, *m_node;
     int32_t *m_offset, *mapq, *e_len;
     uint8_t *unmapped, *m_rev, *e_seq, *qual;
     int64_t *first_node, *first_offset; // of the read's first mapping (-1, 0: no mapping): src/rmdup.cpp's key
+    uint32_t *seq_len;                  // |Alignment.sequence| (euka, soibean: the damage tables' Lseq)
 };
 
-struct GdMapRec { // what the message pass leaves per mapping for the lane that fills its arrays
-    uint64_t pos;   // the mapping's bytes: offset in the inflated stream | length << 40
-    uint32_t e_at;  // its first edit's index
-    uint32_t s_at;  // its first edit-sequence byte's index
-};
-static_assert(sizeof(GdMapRec) == 16, "one 16-byte store per mapping");
+// (GdMapRec -- what the message pass leaves per mapping for the lane that fills its arrays: gam_object.h)
 
 // One mapping's bytes (csrc/host/gam.cpp: parse_mapping, parse_edit): position, edits.  STORE false: its node / offset / strand and the
 // counts of its edits and their sequence bytes; true: the edits' arrays too, from (e_at, s_at) on.  False when it is malformed.
@@ -838,7 +857,7 @@ __device__ bool gd_parse_message(const uint8_t *u, const uint8_t *mp, uint32_t m
     GdWin win{mp - 8, 0}; // (nothing loaded yet: the first byte asked for moves it)
     q_src = nullptr; // FILL: the message's first quality string is left to the caller (the wave copies its lanes' strings together)
     q_n = 0;
-    sz = GdSizes{0, 0, 0, 0};
+    sz = GdSizes{0, 0, 0, 0, 0};
     identity = 0.0;
     mapq = 0;
     first_node = -1;
@@ -888,7 +907,10 @@ __device__ bool gd_parse_message(const uint8_t *u, const uint8_t *mp, uint32_t m
             const uint64_t bits = gd_load8(c.p);
             identity = __longlong_as_double((long long)bits);
             c.p += 8;
-        } else if ((f == 1 || f == 3) && wt == 2) { // sequence, name: not needed on the device
+        } else if (f == 1 && wt == 2) { // sequence: its length alone (a second one is appended, as the host parser does)
+            const GdCur sc = gc_sub(c, win);
+            sz.seq += sc.ok ? (uint32_t)(sc.e - sc.p) : 0u;
+        } else if (f == 3 && wt == 2) { // name: not needed on the device
             (void)gc_sub(c, win);
         } else gc_skip(c, wt, win);
     }
@@ -962,6 +984,7 @@ __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict_
         o.unmapped[r] = identity < 1e-10 ? 1 : 0; // HaploCart.cpp:410
         o.first_node[r] = fn;
         o.first_offset[r] = fo;
+        o.seq_len[r] = sz.seq;
     }
     // the quality strings of the wave's 64 messages, one after the other with all lanes: 64 bytes to a load (a lane copying its own string
     // byte by byte is a load and a store to 64 different cache lines per byte: two thirds of this kernel's time)
@@ -999,6 +1022,76 @@ __global__ __launch_bounds__(256) void gd_dup_mark_kernel(const uint32_t *__rest
     }
     dup[r] = d;
     if (d) atomicAdd(n_dup, 1u);
+}
+
+// A file in pieces: a read is a duplicate when an earlier read OF ANY PIECE SO FAR has its key.  `seen`: the keys of the pieces before,
+// ascending (node first, signed -- the order the two sorts above give).  new_flag[i] (i: place in the piece's sorted order): the read
+// brings a key nobody had.
+__device__ __forceinline__ bool gd_key_less(int64_t an, int64_t ao, int64_t bn, int64_t bo) { return an < bn || (an == bn && ao < bo); }
+__device__ __forceinline__ uint64_t gd_lower_bound(const int64_t *__restrict__ sn, const int64_t *__restrict__ so, uint64_t n, int64_t kn, int64_t ko) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (gd_key_less(sn[mid], so[mid], kn, ko)) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint64_t gd_upper_bound(const int64_t *__restrict__ sn, const int64_t *__restrict__ so, uint64_t n, int64_t kn, int64_t ko) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (!gd_key_less(kn, ko, sn[mid], so[mid])) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void gd_dup_mark_seen_kernel(const uint32_t *__restrict__ perm, const int64_t *__restrict__ node, const int64_t *__restrict__ off,
+                                                               const uint32_t *__restrict__ map_off, uint32_t n, const int64_t *__restrict__ seen_node,
+                                                               const int64_t *__restrict__ seen_off, uint64_t n_seen, uint8_t *__restrict__ dup,
+                                                               uint32_t *__restrict__ new_flag, uint32_t *__restrict__ n_dup) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = perm[i];
+    uint8_t d = 0;
+    uint32_t nf = 0;
+    if (map_off[r + 1] > map_off[r]) {
+        if (i > 0) {
+            const uint32_t q = perm[i - 1];
+            d = map_off[q + 1] > map_off[q] && node[q] == node[r] && off[q] == off[r] ? 1 : 0;
+        }
+        if (!d) {
+            const uint64_t lb = gd_lower_bound(seen_node, seen_off, n_seen, node[r], off[r]);
+            d = lb < n_seen && seen_node[lb] == node[r] && seen_off[lb] == off[r] ? 1 : 0;
+            nf = d ? 0u : 1u;
+        }
+    }
+    dup[r] = d;
+    new_flag[i] = nf;
+    if (d) atomicAdd(n_dup, 1u);
+}
+__global__ __launch_bounds__(256) void gd_new_keys_kernel(const uint32_t *__restrict__ perm, const int64_t *__restrict__ node, const int64_t *__restrict__ off,
+                                                          const uint32_t *__restrict__ new_flag, const uint32_t *__restrict__ new_at, uint32_t n,
+                                                          int64_t *__restrict__ out_node, int64_t *__restrict__ out_off) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || !new_flag[i]) return;
+    const uint32_t r = perm[i];
+    out_node[new_at[i]] = node[r];
+    out_off[new_at[i]] = off[r];
+}
+// two ascending key lists into one: an element's place is its own index plus the elements of the other list in front of it
+__global__ __launch_bounds__(256) void gd_merge_keys_kernel(const int64_t *__restrict__ an, const int64_t *__restrict__ ao, uint64_t na, const int64_t *__restrict__ bn,
+                                                            const int64_t *__restrict__ bo, uint64_t nb, int64_t *__restrict__ out_node, int64_t *__restrict__ out_off) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t < na) {
+        const uint64_t at = t + gd_lower_bound(bn, bo, nb, an[t], ao[t]);
+        out_node[at] = an[t];
+        out_off[at] = ao[t];
+    } else if (t < na + nb) {
+        const uint64_t j = t - na, at = j + gd_upper_bound(an, ao, na, bn[j], bo[j]);
+        out_node[at] = bn[j];
+        out_off[at] = bo[j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------ messages back to the host
@@ -1116,82 +1209,13 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
 }
 
 // ------------------------------------------------------------------------------------------------------------ the C-ABI object
-namespace {
-double g_alloc_ms = 0; // (VGAN_TIMING: what hipMalloc took, summed)
-template <class T> struct GBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t n) {
-        if (n <= cap && p) return VGAN_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        const auto t_alloc = std::chrono::steady_clock::now();
-        struct Acc {
-            std::chrono::steady_clock::time_point t0;
-            ~Acc() { g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
-        } acc{t_alloc};
-        const size_t want = n + std::min<size_t>(n / 8, ((size_t)16 << 20) / sizeof(T)) + 64;
-        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
-        cap = want;
-        // (test aid: fresh device memory is often zero in a young process and someone's old data in an old one -- a kernel that leaves
-        // an entry unwritten passes every test but the one that runs late)
-        static const bool poison = getenv("VGAN_POISON_ALLOCS") != nullptr;
-        if (poison) {
-            HIPCHK(hipMemset(p, 0xA5, want * sizeof(T)));
-            HIPCHK(hipDeviceSynchronize()); // (the fill runs on the null stream, the kernels that write the block on others)
-        }
-        return VGAN_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-} // namespace
-
-#ifndef GD_PIECES_N
-#define GD_PIECES_N 4
-#endif
-static constexpr int GD_PIECES = GD_PIECES_N;
-
-struct vgan_gamdev {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    GBuf<uint8_t> in, infl, cub_tmp;
-    GBuf<GdBlock> blocks;
-    GBuf<uint32_t> status, seg_msgs, seg_status, msg_len, keep, n_map, n_edit, n_eseq, n_qual, r_at, m_at, e_at, s_at, q_at, bad;
-    GBuf<uint64_t> anchor, next_anchor, msg_base, msg_off;
-    GBuf<GdMapRec> map_rec; // per mapping: where its bytes lie, where its edits go (gd_fill_kernel -> gd_fill_maps_kernel)
-    // one DfSlice's arrays (hc_flatten_kernels.hip) of the file's reads
-    GBuf<uint32_t> map_off, qual_off, edit_off, e_seq_off, m_node;
-    GBuf<int32_t> m_offset, mapq, e_len;
-    GBuf<uint8_t> unmapped, m_rev, e_seq, qual;
-    GBuf<int64_t> first_node, first_offset;
-    GBuf<uint8_t> dup, picked_bytes;           // duplicate marks per read; the messages handed back to the host
-    GBuf<uint64_t> sort_key, sort_key2, picked_off;
-    GBuf<uint32_t> perm_a, perm_b;
-    hipStream_t piece_stream[GD_PIECES] = {}; // vgan_gamdev_parse: the file's pieces, each copied and inflated on a stream of its own
-    uint64_t n_reanchored = 0; // (test aid) tag-like bytes the framing of the parses so far took for a group's tag and gave up again
-    uint64_t n_picked = 0, n_picked_bytes = 0;
-    uint64_t n_inflated = 0, n_messages = 0, R = 0, M = 0, E = 0, S = 0, Q = 0;
-    double ms_inflate = 0, ms_frame = 0, ms_parse = 0, ms_upload = 0;
-    void release_all() {
-        in.release(), infl.release(), cub_tmp.release(), blocks.release();
-        for (auto *b : {&status, &seg_msgs, &seg_status, &msg_len, &keep, &n_map, &n_edit, &n_eseq, &n_qual, &r_at, &m_at, &e_at, &s_at, &q_at, &bad, &map_off,
-                        &qual_off, &edit_off, &e_seq_off, &m_node})
-            b->release();
-        for (auto *b : {&anchor, &next_anchor, &msg_base, &msg_off}) b->release();
-        map_rec.release();
-        for (auto *b : {&m_offset, &mapq, &e_len}) b->release();
-        for (auto *b : {&unmapped, &m_rev, &e_seq, &qual}) b->release();
-        first_node.release(), first_offset.release();
-        dup.release(), picked_bytes.release(), sort_key.release(), sort_key2.release(), picked_off.release();
-        for (auto *b : {&perm_a, &perm_b}) b->release();
-    }
-};
+// (struct vgan_gamdev: gam_object.h)
+namespace vgan {
+namespace gd {
+double g_alloc_ms = 0;
+}
+} // namespace vgan
+static constexpr int GD_PIECES = vgan_gamdev::GD_PIECES;
 
 extern "C" int vgan_gamdev_create(int device, void *hip_stream, vgan_gamdev **out) {
     if (!out) return fail(VGAN_EINVAL, "vgan_gamdev_create: null argument");
@@ -1229,7 +1253,10 @@ extern "C" int vgan_gamdev_drop_bytes(vgan_gamdev *g, int what) {
     if (!g || what < 1 || what > 2) return fail(VGAN_EINVAL, "vgan_gamdev_drop_bytes: null object or what not 1 / 2");
     HIPCHK(hipSetDevice(g->device));
     g->in.release();
-    if (what >= 2) g->infl.release();
+    if (what >= 2) {
+        g->infl.release();
+        g->u = nullptr;
+    }
     return VGAN_OK;
 }
 
@@ -1295,64 +1322,121 @@ extern "C" int vgan_gamdev_open(int device, void *hip_stream, const void *bytes,
 }
 
 namespace {
+// a whole file as one piece that is the stream's first and last
 int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::vector<GdBlock> &gb, uint64_t total, int keep_unmapped) {
+    // every offset the parse leaves is 32 bits wide and every array it fills is a subset of the inflated bytes (a mapping, an edit, a
+    // message take at least a byte each): a stream below 2^32 bytes cannot wrap any of them.  Longer files go through in pieces
+    // (vgan_gampipe_*: gam_pipe.hip), or through the host pipeline.
+    if (total > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "vgan_gamdev_parse: %llu inflated bytes are beyond the parse's 32-bit offsets; parse the file in pieces", (unsigned long long)total);
+    int rc;
+    if ((rc = gd::gd_piece_upload_inflate(g, (const uint8_t *)bytes, n, gb.data(), gb.size(), total, 0))) return rc;
+    return gd::gd_piece_parse(g, GdCarry{}, true, nullptr, keep_unmapped, nullptr, nullptr);
+}
+} // namespace
+
+int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint64_t n, const GdBlock *gb, size_t n_gb, uint64_t total, uint64_t tail_cap) {
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
     g->n_inflated = g->n_messages = g->R = g->M = g->E = g->S = g->Q = 0;
     g->n_inflated = total;
+    g->n_blocks = n_gb;
+    g->tail_cap = tail_cap;
+    g->u = nullptr;
+    g->n_stream = 0;
+    int rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = g->in.reserve(n + 64)) || (rc = g->infl.reserve(tail_cap + total + 64)) || (rc = g->blocks.reserve(n_gb + 1)) || (rc = g->status.reserve(n_gb + 1))) return rc;
+    uint8_t *d_out = g->infl.p + tail_cap;
+    if (n_gb) HIPCHK(hipMemcpyAsync(g->blocks.p, gb, n_gb * sizeof(GdBlock), hipMemcpyHostToDevice, st));
+    // The bytes go up in a few parts, each on a stream of its own with the inflate of its members behind it: a part's kernel runs BESIDE
+    // the next part's copy and the other parts' kernels, not before them (parts on ONE stream ran one after the other).
+    g->ms_upload = 0;
+    HIPCHK(hipStreamSynchronize(st)); // (the member list is up)
+    uint64_t piece = std::max<uint64_t>(64ull << 20, n / GD_PIECES + 1);
+    if (const char *e = getenv("VGAN_GAMDEV_PIECE")) piece = std::max<uint64_t>(1, strtoull(e, nullptr, 10)); // (test aid: many small parts)
+    size_t b0 = 0, k = 0;
+    uint64_t sent = 0;
+    while (sent < n) {
+        size_t b1 = b0;
+        while (b1 < n_gb && gb[b1].in_off + gb[b1].in_size + 8 <= sent + piece) ++b1;
+        if (b1 == b0 && b0 < n_gb) b1 = b0 + 1; // (a part below a member's size: one member at a time)
+        const uint64_t upto = b1 < n_gb ? std::min<uint64_t>(n, gb[b1 - 1].in_off + gb[b1 - 1].in_size + 8) : n;
+        hipStream_t ps = st;
+        if (upto < n || k) { // (a file of one part stays on the object's stream)
+            const size_t slot = k % GD_PIECES;
+            if (!g->piece_stream[slot]) HIPCHK(hipStreamCreateWithFlags(&g->piece_stream[slot], hipStreamNonBlocking));
+            ps = g->piece_stream[slot];
+        }
+        const auto tc = std::chrono::steady_clock::now();
+        if (upto > sent) HIPCHK(hipMemcpyAsync(g->in.p + sent, bytes + sent, upto - sent, hipMemcpyHostToDevice, ps));
+        g->ms_upload += ms_since(tc);
+        sent = upto;
+        if (b1 > b0 && (rc = gamdev_inflate(g->in.p, g->blocks.p + b0, (uint32_t)(b1 - b0), d_out, g->status.p + b0, ps))) return rc;
+        b0 = b1;
+        ++k;
+    }
+    g->ms_inflate = ms_since(t0) - g->ms_upload; // (what the calls took: gd_piece_parse adds its wait)
+    return VGAN_OK;
+}
+
+int vgan::gd::gd_piece_parse(vgan_gamdev *g, const GdCarry &cin, bool last_piece, GdCarry *cout, int keep_unmapped, void (*frame_done)(void *), void *user) {
+    HIPCHK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
     int rc;
     auto t0 = std::chrono::steady_clock::now();
-    if ((rc = g->in.reserve(n + 64)) || (rc = g->infl.reserve(total + 64)) || (rc = g->blocks.reserve(gb.size() + 1)) || (rc = g->status.reserve(gb.size() + 1))) return rc;
-    if (!gb.empty()) HIPCHK(hipMemcpyAsync(g->blocks.p, gb.data(), gb.size() * sizeof(GdBlock), hipMemcpyHostToDevice, st));
-    // The file goes up in a few pieces, each on a stream of its own with the inflate of its members behind it: a member takes one lane
-    // ~80 ms however few of them run (the decode is a chain of dependent loads), so a piece's kernel has to run BESIDE the next piece's
-    // copy and the other pieces' kernels, not before them (pieces on ONE stream ran one after the other: 12 x 80 ms).
-    g->ms_upload = 0;
-    {
-        HIPCHK(hipStreamSynchronize(st)); // (the member list is up)
-        uint64_t piece = std::max<uint64_t>(64ull << 20, n / GD_PIECES + 1);
-        if (const char *e = getenv("VGAN_GAMDEV_PIECE")) piece = std::max<uint64_t>(1, strtoull(e, nullptr, 10)); // (test aid: many small pieces)
-        size_t b0 = 0, k = 0;
-        uint64_t sent = 0;
-        while (sent < n) {
-            size_t b1 = b0;
-            while (b1 < gb.size() && gb[b1].in_off + gb[b1].in_size + 8 <= sent + piece) ++b1;
-            if (b1 == b0 && b0 < gb.size()) b1 = b0 + 1; // (a piece below a member's size: one member at a time)
-            const uint64_t upto = b1 < gb.size() ? std::min<uint64_t>(n, gb[b1 - 1].in_off + gb[b1 - 1].in_size + 8) : n;
-            hipStream_t ps = st;
-            if (upto < n || k) { // (a file of one piece stays on the object's stream)
-                const size_t slot = k % GD_PIECES;
-                if (!g->piece_stream[slot]) HIPCHK(hipStreamCreateWithFlags(&g->piece_stream[slot], hipStreamNonBlocking));
-                ps = g->piece_stream[slot];
-            }
-            const auto tc = std::chrono::steady_clock::now();
-            if (upto > sent) HIPCHK(hipMemcpyAsync(g->in.p + sent, (const uint8_t *)bytes + sent, upto - sent, hipMemcpyHostToDevice, ps));
-            g->ms_upload += ms_since(tc);
-            sent = upto;
-            if (b1 > b0 && (rc = gamdev_inflate(g->in.p, g->blocks.p + b0, (uint32_t)(b1 - b0), g->infl.p, g->status.p + b0, ps))) return rc;
-            b0 = b1;
-            ++k;
+    const uint64_t n_tail = cin.tail.size(), total = g->n_inflated + n_tail;
+    struct Done { // the next piece's framing waits for this piece's: whatever way this call ends, it is told -- a failure by a state no walk leaves
+        void (*fn)(void *);
+        void *user;
+        GdCarry *out;
+        bool called = false;
+        void operator()() {
+            if (fn && !called) fn(user);
+            called = true;
         }
-        for (hipStream_t ps : g->piece_stream)
-            if (ps) HIPCHK(hipStreamSynchronize(ps));
-    }
+        ~Done() {
+            if (!called && out) out->st.mode = 0xFFFFFFFFu;
+            (*this)();
+        }
+    } done{frame_done, user, cout};
+    if (!last_piece && !cout) return fail(VGAN_EINVAL, "gd_piece_parse: a piece that is not the last needs a place for what it leaves over");
+    if (n_tail > g->tail_cap) return fail(VGAN_ERANGE, "the GAM front end on the device: %llu bytes of an item are left over from the piece before, room was kept for %llu",
+                                          (unsigned long long)n_tail, (unsigned long long)g->tail_cap);
+    if (total > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "the GAM front end on the device: a piece of %llu inflated bytes is beyond the parse's 32-bit offsets", (unsigned long long)total);
+    uint8_t *u = g->infl.p + (g->tail_cap - n_tail);
+    if (n_tail) HIPCHK(hipMemcpyAsync(u, cin.tail.data(), n_tail, hipMemcpyHostToDevice, st));
+    for (hipStream_t ps : g->piece_stream)
+        if (ps) HIPCHK(hipStreamSynchronize(ps));
     {
-        std::vector<uint32_t> stt(gb.size());
-        if (!gb.empty()) HIPCHK(hipMemcpyAsync(stt.data(), g->status.p, gb.size() * 4, hipMemcpyDeviceToHost, st));
+        std::vector<uint32_t> stt(g->n_blocks);
+        if (g->n_blocks) HIPCHK(hipMemcpyAsync(stt.data(), g->status.p, g->n_blocks * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         for (size_t i = 0; i < stt.size(); ++i)
             if (stt[i] != GD_OK) return fail(VGAN_EIO, "vgan_gamdev_parse: BGZF member %zu does not inflate (code %u)", i, stt[i]);
     }
-    g->ms_inflate = ms_since(t0) - g->ms_upload;
-    if (total == 0) return VGAN_OK;
+    g->ms_inflate += ms_since(t0);
+    g->u = u;
+    g->n_stream = total;
+    if (cout) {
+        cout->st = GdCarryState{total, 0, 0, 0};
+        cout->tail.clear();
+    }
+    if (total == 0) {
+        if (cout) cout->st = cin.st, cout->st.p = 0;
+        done();
+        return VGAN_OK;
+    }
     // ---- framing
     t0 = std::chrono::steady_clock::now();
     const uint64_t seg_bytes = 1u << 20;
     const uint32_t n_segs = (uint32_t)((total + seg_bytes - 1) / seg_bytes);
     if ((rc = g->anchor.reserve(n_segs)) || (rc = g->next_anchor.reserve(n_segs)) || (rc = g->seg_msgs.reserve(n_segs)) || (rc = g->seg_status.reserve(n_segs)) ||
-        (rc = g->msg_base.reserve(n_segs)))
+        (rc = g->msg_base.reserve(n_segs)) || (rc = g->carry.reserve(1)))
         return rc;
-    hipLaunchKernelGGL(gd_anchor_kernel, dim3((n_segs + 3) / 4), dim3(256), 0, st, g->infl.p, total, seg_bytes, n_segs, g->anchor.p);
+    const int open_end = last_piece ? 0 : 1;
+    GdCarryState in = cin.st;
+    in.p = 0;
+    hipLaunchKernelGGL(gd_anchor_kernel, dim3((n_segs + 3) / 4), dim3(256), 0, st, u, total, seg_bytes, n_segs, g->anchor.p);
     std::vector<uint32_t> seg_n(n_segs), seg_st(n_segs);
     std::vector<uint64_t> nxt(n_segs);
     // The walks must meet: segment 0's walk is the true one, so the FIRST walk that misses the next anchored segment's tag says that
@@ -1360,8 +1444,8 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
     // and the walks are counted again.  A walk that breaks (not: misses) is a malformed stream.
     for (uint32_t again = 0;; ++again) {
         hipLaunchKernelGGL(gd_next_anchor_kernel, dim3(1), dim3(1), 0, st, g->anchor.p, n_segs, total, g->next_anchor.p);
-        hipLaunchKernelGGL(gd_frame_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, g->infl.p, total, n_segs, g->anchor.p, g->next_anchor.p,
-                           g->seg_msgs.p, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, g->seg_status.p);
+        hipLaunchKernelGGL(gd_frame_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, u, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
+                           (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, g->seg_status.p, in, open_end, g->carry.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(seg_n.data(), g->seg_msgs.p, n_segs * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(seg_st.data(), g->seg_status.p, n_segs * 4, hipMemcpyDeviceToHost, st));
@@ -1375,9 +1459,18 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
         HIPCHK(hipMemcpy(nxt.data(), g->next_anchor.p, n_segs * 8, hipMemcpyDeviceToHost));
         if (nxt[f] >= total) return fail(VGAN_EIO, "vgan_gamdev_parse: the stream cannot be framed from segment %u (its walk passes the stream's end)", f);
         const uint32_t suspect = (uint32_t)(nxt[f] / seg_bytes);
-        hipLaunchKernelGGL(gd_reanchor_kernel, dim3(1), dim3(64), 0, st, g->infl.p, total, seg_bytes, suspect, g->anchor.p);
+        hipLaunchKernelGGL(gd_reanchor_kernel, dim3(1), dim3(64), 0, st, u, total, seg_bytes, suspect, g->anchor.p);
         g->n_reanchored += 1;
     }
+    if (open_end) { // what the piece leaves over: the state of the walk that reached its end, and the bytes of the item it stood in
+        GdCarryState cs{};
+        HIPCHK(hipMemcpy(&cs, g->carry.p, sizeof cs, hipMemcpyDeviceToHost));
+        if (cs.p > total || cs.mode > 2u) return fail(VGAN_EIO, "vgan_gamdev_parse: the framing left no state at the piece's end");
+        cout->st = cs;
+        cout->tail.resize((size_t)(total - cs.p));
+        if (total > cs.p) HIPCHK(hipMemcpy(cout->tail.data(), u + cs.p, (size_t)(total - cs.p), hipMemcpyDeviceToHost));
+    }
+    done(); // (the next piece's framing can start: it needs nothing else of this one)
     std::vector<uint64_t> base(n_segs);
     uint64_t n_msg = 0;
     for (uint32_t s = 0; s < n_segs; ++s) {
@@ -1392,8 +1485,8 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
     }
     if ((rc = g->msg_off.reserve(n_msg)) || (rc = g->msg_len.reserve(n_msg))) return rc;
     HIPCHK(hipMemcpyAsync(g->msg_base.p, base.data(), n_segs * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gd_frame_kernel<true>, dim3((n_segs + 63) / 64), dim3(64), 0, st, g->infl.p, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
-                       g->msg_base.p, g->msg_off.p, g->msg_len.p, g->seg_status.p);
+    hipLaunchKernelGGL(gd_frame_kernel<true>, dim3((n_segs + 63) / 64), dim3(64), 0, st, u, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
+                       g->msg_base.p, g->msg_off.p, g->msg_len.p, g->seg_status.p, in, open_end, g->carry.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     g->ms_frame = ms_since(t0);
@@ -1404,7 +1497,7 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
         if ((rc = b->reserve((size_t)NM + 1))) return rc;
     if ((rc = g->bad.reserve(4))) return rc;
     HIPCHK(hipMemsetAsync(g->bad.p, 0, 4, st));
-    hipLaunchKernelGGL(gd_count_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, NM, keep_unmapped, g->keep.p, g->n_map.p,
+    hipLaunchKernelGGL(gd_count_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, u, g->msg_off.p, g->msg_len.p, NM, keep_unmapped, g->keep.p, g->n_map.p,
                        g->n_edit.p, g->n_eseq.p, g->n_qual.p, g->bad.p);
     HIPCHK(hipGetLastError());
     if ((rc = exclusive_sum(g, g->keep.p, g->r_at.p, NM)) || (rc = exclusive_sum(g, g->n_map.p, g->m_at.p, NM)) || (rc = exclusive_sum(g, g->n_edit.p, g->e_at.p, NM)) ||
@@ -1418,41 +1511,37 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
         HIPCHK(hipStreamSynchronize(st));
     }
     if (bad) return fail(VGAN_EIO, "vgan_gamdev_parse: %u malformed alignment messages", bad);
+    // (32-bit sums: every array is a subset of the stream's bytes, which are fewer than 2^32 -- checked above -- so none of them wraps)
     g->R = (uint64_t)last[0] + last[5];
     g->M = (uint64_t)last[1] + last[6];
     g->E = (uint64_t)last[2] + last[7];
     g->S = (uint64_t)last[3] + last[8];
     g->Q = (uint64_t)last[4] + last[9];
-    // (the sums are 32-bit: a total that does not fit shows as a sum below one of its terms -- checked through 64-bit sizes of the
-    // inflated bytes: every array is a subset of them)
-    if (total > 0xFFFFFFF0ull && (g->S > total || g->Q > total)) return fail(VGAN_ERANGE, "vgan_gamdev_parse: a chunk beyond 32-bit offsets; parse fewer bytes at a time");
     if ((rc = g->map_off.reserve(g->R + 1)) || (rc = g->qual_off.reserve(g->R + 1)) || (rc = g->edit_off.reserve(g->M + 1)) || (rc = g->e_seq_off.reserve(g->E + 1)) ||
         (rc = g->m_node.reserve(g->M + 1)) || (rc = g->m_offset.reserve(g->M + 1)) || (rc = g->mapq.reserve(g->R + 1)) || (rc = g->e_len.reserve(g->E + 1)) ||
         (rc = g->unmapped.reserve(g->R + 1)) || (rc = g->m_rev.reserve(g->M + 1)) || (rc = g->e_seq.reserve(g->S + 1)) || (rc = g->qual.reserve(g->Q + 1)) ||
-        (rc = g->first_node.reserve(g->R + 1)) || (rc = g->first_offset.reserve(g->R + 1)) || (rc = g->map_rec.reserve(g->M + 1)))
+        (rc = g->first_node.reserve(g->R + 1)) || (rc = g->first_offset.reserve(g->R + 1)) || (rc = g->map_rec.reserve(g->M + 1)) || (rc = g->seq_len.reserve(g->R + 1)))
         return rc;
-    if (total >= (1ull << 40)) return fail(VGAN_ERANGE, "vgan_gamdev_parse: more than 2^40 inflated bytes; parse fewer bytes at a time");
     GdOut o{g->map_off.p, g->qual_off.p, g->edit_off.p, g->e_seq_off.p, g->m_node.p, g->m_offset.p, g->mapq.p, g->e_len.p, g->unmapped.p, g->m_rev.p, g->e_seq.p,
-            g->qual.p, g->first_node.p, g->first_offset.p};
-    hipLaunchKernelGGL(gd_fill_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, NM, g->keep.p, g->r_at.p, g->m_at.p, g->e_at.p,
+            g->qual.p, g->first_node.p, g->first_offset.p, g->seq_len.p};
+    hipLaunchKernelGGL(gd_fill_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, u, g->msg_off.p, g->msg_len.p, NM, g->keep.p, g->r_at.p, g->m_at.p, g->e_at.p,
                        g->s_at.p, g->q_at.p, o, g->map_rec.p);
-    if (g->M) hipLaunchKernelGGL(gd_fill_maps_kernel, dim3((uint32_t)((g->M + 255) / 256)), dim3(256), 0, st, g->infl.p, g->map_rec.p, (uint32_t)g->M, o);
+    if (g->M) hipLaunchKernelGGL(gd_fill_maps_kernel, dim3((uint32_t)((g->M + 255) / 256)), dim3(256), 0, st, u, g->map_rec.p, (uint32_t)g->M, o);
     HIPCHK(hipGetLastError());
     // what vgan_gamdev_pick will want, asked for now: device memory asked for while another thread asks for the packed batch's 12 GB
     // and the device is busy took 180 ms there (its four arrays per message are the count arrays above, done with by then)
     if ((rc = g->picked_bytes.reserve(std::max<uint64_t>(g->R, total / 32 + 1))) || (rc = g->picked_off.reserve(NM / 32 + 2))) return rc;
     HIPCHK(hipStreamSynchronize(st));
     g->ms_parse = ms_since(t0);
-    if (getenv("VGAN_TIMING")) fprintf(stderr, "[vgan timing] gamdev: device memory asked for so far took %.1f ms\n", g_alloc_ms);
+    if (getenv("VGAN_TIMING") && g->tail_cap == 0) fprintf(stderr, "[vgan timing] gamdev: device memory asked for so far took %.1f ms\n", g_alloc_ms);
     return VGAN_OK;
 }
-} // namespace
 
 // sizes[8]: inflated bytes, messages, reads, mappings, edits, edit-sequence bytes, quality bytes, 0;  ms[4]: upload, inflate, framing, parsing (wall)
 extern "C" int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double ms[4]) {
     if (!g) return fail(VGAN_EINVAL, "vgan_gamdev_sizes: null argument");
     if (sizes) {
-        const uint64_t v[8] = {g->n_inflated, g->n_messages, g->R, g->M, g->E, g->S, g->Q, g->n_reanchored};
+        const uint64_t v[8] = {g->u ? g->n_stream : g->n_inflated, g->n_messages, g->R, g->M, g->E, g->S, g->Q, g->n_reanchored};
         memcpy(sizes, v, sizeof v);
     }
     if (ms) {
@@ -1463,7 +1552,7 @@ extern "C" int vgan_gamdev_sizes(const vgan_gamdev *g, uint64_t sizes[8], double
 
 // Copies one of the arrays of the last parse to the host (test aid).  which: 0 map_off[R+1] 1 qual_off[R+1] 2 edit_off[M+1] 3 e_seq_off[E+1]
 // 4 m_node[M] 5 m_offset[M] 6 mapq[R] 7 e_len[E] 8 unmapped[R] 9 m_rev[M] 10 e_seq[S] 11 qual[Q] 12 first_node[R] 13 first_offset[R]
-// 14 the inflated bytes 15 msg_off[messages] (uint64) 16 msg_len[messages]
+// 14 the inflated bytes 15 msg_off[messages] (uint64) 16 msg_len[messages] 17 seq_len[R] (|Alignment.sequence|)
 extern "C" int vgan_gamdev_download(const vgan_gamdev *g, int which, void *dst) {
     if (!g || !dst) return fail(VGAN_EINVAL, "vgan_gamdev_download: null argument");
     HIPCHK(hipSetDevice(g->device));
@@ -1484,9 +1573,10 @@ extern "C" int vgan_gamdev_download(const vgan_gamdev *g, int which, void *dst) 
     case 11: src = g->qual.p, bytes = g->Q; break;
     case 12: src = g->first_node.p, bytes = g->R * 8; break;
     case 13: src = g->first_offset.p, bytes = g->R * 8; break;
-    case 14: src = g->infl.p, bytes = g->n_inflated; break;
+    case 14: src = g->u, bytes = g->n_stream; break; // (a piece: what the piece before left over, then its own inflated bytes)
     case 15: src = g->msg_off.p, bytes = g->n_messages * 8; break;
     case 16: src = g->msg_len.p, bytes = g->n_messages * 4; break;
+    case 17: src = g->seq_len.p, bytes = g->R * 4; break;
     default: return fail(VGAN_EINVAL, "vgan_gamdev_download: no array %d", which);
     }
     if (g->R == 0 && which <= 3) { // (an empty parse: the offsets' leading zero)
@@ -1506,16 +1596,48 @@ bool vgan::gamdev_slice(const vgan_gamdev *g, GamdevSlice *o) {
 
 // Duplicate marks of the last parse's reads (keep-first by the first mapping's (node id, offset): src/rmdup.cpp), left on the device for
 // vgan_hc_devflat_run_gamdev (vgan_gamdev_dup_marks: the device pointer) and counted.
-extern "C" int vgan_gamdev_mark_duplicates(vgan_gamdev *g, int64_t *n_dup) {
-    if (!g) return fail(VGAN_EINVAL, "vgan_gamdev_mark_duplicates: null argument");
+namespace {
+// two ascending lists on the device -> seen's other pair of buffers, which becomes the current one
+int gd_seen_take(vgan_gamdev *g, GdSeen &seen, const int64_t *d_node, const int64_t *d_off, uint64_t nk) {
+    if (nk == 0) return VGAN_OK;
+    hipStream_t st = g->stream;
+    const int cur = seen.cur, oth = cur ^ 1;
+    const uint64_t total = seen.n + nk;
+    int rc;
+    if (total > seen.node[oth].cap || !seen.node[oth].p) { // (room for twice what is needed: a set that grows piece by piece is re-allocated log times)
+        if ((rc = seen.node[oth].reserve(total * 2)) || (rc = seen.off[oth].reserve(total * 2))) return rc;
+    }
+    hipLaunchKernelGGL(gd_merge_keys_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, seen.node[cur].p, seen.off[cur].p, seen.n, d_node, d_off, nk,
+                       seen.node[oth].p, seen.off[oth].p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st)); // (the lists given may go when this returns)
+    seen.cur = oth;
+    seen.n = total;
+    return VGAN_OK;
+}
+} // namespace
+
+int vgan::gd::gd_seen_merge(vgan_gamdev *g, GdSeen &seen, const GdKeyList &keys) {
+    const uint64_t nk = keys.node.size();
+    if (nk == 0) return VGAN_OK;
+    HIPCHK(hipSetDevice(g->device));
+    int rc;
+    if ((rc = g->new_node.reserve(nk)) || (rc = g->new_off.reserve(nk))) return rc;
+    HIPCHK(hipMemcpyAsync(g->new_node.p, keys.node.data(), nk * 8, hipMemcpyHostToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(g->new_off.p, keys.off.data(), nk * 8, hipMemcpyHostToDevice, g->stream));
+    return gd_seen_take(g, seen, g->new_node.p, g->new_off.p, nk);
+}
+
+int vgan::gd::gd_piece_mark_duplicates(vgan_gamdev *g, GdSeen &seen, GdKeyList *added, int64_t *n_dup) {
     if (n_dup) *n_dup = 0;
+    if (added) added->node.clear(), added->off.clear();
     if (g->R == 0) return VGAN_OK;
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
     const uint32_t R = (uint32_t)g->R;
     int rc;
     if ((rc = g->dup.reserve(R)) || (rc = g->sort_key.reserve(R)) || (rc = g->sort_key2.reserve(R)) || (rc = g->perm_a.reserve(R)) || (rc = g->perm_b.reserve(R)) ||
-        (rc = g->bad.reserve(4)))
+        (rc = g->bad.reserve(4)) || (rc = g->new_flag.reserve(R)) || (rc = g->new_at.reserve(R)))
         return rc;
     // perm_a = 0, 1, 2, ... (an exclusive sum of ones)
     {
@@ -1538,13 +1660,37 @@ extern "C" int vgan_gamdev_mark_duplicates(vgan_gamdev *g, int64_t *n_dup) {
     };
     if ((rc = sort_by(g->first_offset.p, g->perm_a.p, g->perm_b.p)) || (rc = sort_by(g->first_node.p, g->perm_b.p, g->perm_a.p))) return rc;
     HIPCHK(hipMemsetAsync(g->bad.p, 0, 4, st));
-    hipLaunchKernelGGL(gd_dup_mark_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g->perm_a.p, g->first_node.p, g->first_offset.p, g->map_off.p, R, g->dup.p, g->bad.p);
+    hipLaunchKernelGGL(gd_dup_mark_seen_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g->perm_a.p, g->first_node.p, g->first_offset.p, g->map_off.p, R,
+                       seen.node[seen.cur].p, seen.off[seen.cur].p, seen.n, g->dup.p, g->new_flag.p, g->bad.p);
     HIPCHK(hipGetLastError());
-    uint32_t nd = 0;
+    if ((rc = exclusive_sum(g, g->new_flag.p, g->new_at.p, R))) return rc;
+    uint32_t nd = 0, last[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(&nd, g->bad.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[0], g->new_flag.p + (R - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last[1], g->new_at.p + (R - 1), 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (n_dup) *n_dup = nd;
-    return VGAN_OK;
+    const uint64_t nk = (uint64_t)last[0] + last[1];
+    if (nk == 0) return VGAN_OK;
+    if ((rc = g->new_node.reserve(nk)) || (rc = g->new_off.reserve(nk))) return rc;
+    hipLaunchKernelGGL(gd_new_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, st, g->perm_a.p, g->first_node.p, g->first_offset.p, g->new_flag.p, g->new_at.p, R,
+                       g->new_node.p, g->new_off.p);
+    HIPCHK(hipGetLastError());
+    if (added) {
+        added->node.resize(nk), added->off.resize(nk);
+        HIPCHK(hipMemcpyAsync(added->node.data(), g->new_node.p, nk * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(added->off.data(), g->new_off.p, nk * 8, hipMemcpyDeviceToHost, st));
+    }
+    return gd_seen_take(g, seen, g->new_node.p, g->new_off.p, nk);
+}
+
+extern "C" int vgan_gamdev_mark_duplicates(vgan_gamdev *g, int64_t *n_dup) {
+    if (!g) return fail(VGAN_EINVAL, "vgan_gamdev_mark_duplicates: null argument");
+    GdSeen none; // (a file in one go: nothing was seen before it)
+    const int rc = gd::gd_piece_mark_duplicates(g, none, nullptr, n_dup);
+    (void)hipSetDevice(g->device);
+    none.release();
+    return rc;
 }
 
 extern "C" const uint8_t *vgan_gamdev_dup_marks(const vgan_gamdev *g) { return g ? g->dup.p : nullptr; }
@@ -1556,7 +1702,7 @@ extern "C" int vgan_gamdev_pick(vgan_gamdev *g, const uint8_t *read_mask, uint64
     *n_msgs = *n_bytes = 0;
     g->n_picked = g->n_picked_bytes = 0;
     if (g->R == 0 || g->n_messages == 0) return VGAN_OK;
-    if (!g->infl.p) return fail(VGAN_EINVAL, "vgan_gamdev_pick: the inflated bytes were given back (vgan_gamdev_drop_bytes)");
+    if (!g->infl.p || !g->u) return fail(VGAN_EINVAL, "vgan_gamdev_pick: the inflated bytes were given back (vgan_gamdev_drop_bytes)");
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
     const uint32_t NM = (uint32_t)g->n_messages;
@@ -1584,7 +1730,7 @@ extern "C" int vgan_gamdev_pick(vgan_gamdev *g, const uint8_t *read_mask, uint64
     if ((rc = g->picked_bytes.reserve(std::max<uint64_t>(g->n_picked_bytes, g->R)))) return rc;
     uint32_t *list = pick_bytes;
     hipLaunchKernelGGL(gd_pick_list_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, pick, k_at, NM, list);
-    hipLaunchKernelGGL(gd_gather_kernel, dim3((uint32_t)((g->n_picked * 64 + 255) / 256)), dim3(256), 0, st, g->infl.p, g->msg_off.p, g->msg_len.p, list, b_at,
+    hipLaunchKernelGGL(gd_gather_kernel, dim3((uint32_t)((g->n_picked * 64 + 255) / 256)), dim3(256), 0, st, g->u, g->msg_off.p, g->msg_len.p, list, b_at,
                        (uint32_t)g->n_picked, g->picked_bytes.p, g->picked_off.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));

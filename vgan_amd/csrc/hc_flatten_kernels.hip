@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "gam_device.h"
+#include "gam_object.h"
 #include "hc_device.h"
 #include "host/common.h"
 #include "vgan_gpu.h"
@@ -506,6 +507,14 @@ extern "C" int vgan_hc_devflat_create(vgan_hc_ctx *c, const vgan_graph *graph, v
     f->g.n_mapp = graph->mappability.size();
     *out = f;
     return VGAN_OK;
+}
+
+size_t vgan::hc_devflat_device_bytes(const vgan_hc_devflat *f) {
+    if (!f) return 0;
+    size_t b = f->node_seq_off.cap * 8 + f->node_seq.cap + f->pangenome_base.cap * 4 + f->stage.cap + f->slices.cap * sizeof(DfSlice) + f->flag.cap + f->qualp.cap +
+               f->ctr.cap * sizeof(DfCounters) + f->cub_tmp.cap + (f->info.cap + f->rhdr.cap) * 16;
+    for (auto *x : {&f->key, &f->key_out, &f->val, &f->val_out, &f->segs, &f->quals, &f->cols, &f->soff, &f->qoff, &f->coff, &f->read_src, &f->srec, &f->crec}) b += x->cap * 4;
+    return b;
 }
 
 extern "C" void vgan_hc_devflat_free(vgan_hc_devflat *f) {

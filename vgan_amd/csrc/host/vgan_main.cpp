@@ -155,9 +155,10 @@ int haplocart(int argc, char **argv) {
         vgan_gam_stream *s = nullptr;
         ~StreamCloser() { vgan_gam_stream_close(s); }
     } stream;
-    // A long BGZF input on one GPU: the front end runs ON THE DEVICE (vgan_gamdev: inflate, framing, protobuf walk, duplicate marks and
-    // flatten as kernels; csrc/gam_kernels.hip) -- the file's bytes go up as they are and the host parses only the reads the device
-    // flatten leaves (indels, soft clips: a percent or two).  The host pipeline costs ~3 us of CPU per read, which on a CPU quota
+    // A long BGZF input: the front end runs ON THE DEVICE (vgan_hc_gam_*: the file in pieces through inflate, framing, protobuf walk,
+    // duplicate marks and flatten as kernels; csrc/gam_pipe.hip, gam_kernels.hip) -- the file's bytes go up as they are and the host
+    // parses only the reads the device flatten leaves (indels, soft clips: a percent or two).  With --gpus LIST piece i goes to context
+    // i mod n: every device inflates and parses its own pieces.  The host pipeline costs ~3 us of CPU per read, which on a CPU quota
     // is what a long input's wall time follows.  VGAN_HC_DEVICE_GAM=0 / 1: never / whenever the input is a regular file;
     // anything the device refuses (not BGZF, a stream its segment walks cannot frame, no memory) goes through the host pipeline.
     struct FileMap {
@@ -171,8 +172,7 @@ int haplocart(int argc, char **argv) {
     {
         const char *e = getenv("VGAN_HC_DEVICE_GAM");
         struct stat sb;
-        const bool one_gpu = gpu_spec.empty() && !getenv("VGAN_GPUS");
-        if (!(e && e[0] == '0') && one_gpu && !per_read && fastafilename.empty() && stat(gamfilename.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) &&
+        if (!(e && e[0] == '0') && !per_read && fastafilename.empty() && stat(gamfilename.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) &&
             ((e && e[0] == '1') || (uint64_t)sb.st_size >= (384ull << 20)) && sb.st_size > 28) {
             const int fd = open(gamfilename.c_str(), O_RDONLY);
             if (fd >= 0) {
@@ -188,23 +188,58 @@ int haplocart(int argc, char **argv) {
         }
     }
     if (!device_gam) check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
-    // (the device front end needs no graph: it starts as soon as the HIP runtime is up, beside the graph load and the contexts' set-up)
-    struct GdRun {
-        vgan_gamdev *g = nullptr;
+    // the HIP runtime comes up on a thread of its own while the graph is read (its failure shows at context creation)
+    struct Warm {
         std::thread t;
-        std::string why;
-        double ms = 0;
-        ~GdRun() {
+        ~Warm() {
             if (t.joinable()) t.join();
-            vgan_gamdev_free(g);
+        }
+    } warm;
+    {
+        int warm_dev = device; // (the first GPU the run will use: the runtime's start-up creates its context there)
+        const std::string spec = !gpu_spec.empty() ? gpu_spec : (getenv("VGAN_GPUS") ? std::string(getenv("VGAN_GPUS")) : std::string());
+        if (!spec.empty() && spec != "all" && isdigit((unsigned char)spec[0])) warm_dev = atoi(spec.c_str());
+        warm.t = std::thread([d = warm_dev] { (void)vgan_device_warmup(d); });
+    }
+    // which GPUs: --gpus LIST, the environment's VGAN_GPUS, or the one of --device
+    // (the HIP runtime is still coming up: only "--gpus all" has to wait for it here, to know how many contexts there will
+    // be; otherwise the first chunks are decoded and flattened beside it and the context thread below is the one that waits)
+    if (gpu_spec.empty())
+        if (const char *e = getenv("VGAN_GPUS")) gpu_spec = e;
+    if (gpu_spec == "all") {
+        if (warm.t.joinable()) warm.t.join();
+        const int n_visible = vgan_device_count();
+        if (n_visible <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
+        for (int d = 0; d < n_visible; ++d) gpu_list.push_back(d);
+    } else if (!gpu_spec.empty()) {
+        size_t p0 = 0;
+        while (p0 <= gpu_spec.size()) {
+            size_t c1 = gpu_spec.find(',', p0);
+            if (c1 == std::string::npos) c1 = gpu_spec.size();
+            const int d = parse_int(gpu_spec.substr(p0, c1 - p0), "--gpus", "[HaploCart]");
+            if (d < 0) die("[HaploCart] Error, --gpus needs non-negative GPU indices");
+            gpu_list.push_back(d);
+            p0 = c1 + 1;
+        }
+    }
+    if (gpu_list.empty()) gpu_list.push_back(device);
+    // (the device front end needs neither graph nor contexts for its first stages: it starts now -- the member index of the first piece,
+    // then, as soon as the HIP runtime is up, upload, inflate, framing and parse -- beside the graph load and the contexts' set-up)
+    struct GdRun {
+        vgan_hc_gamrun *r = nullptr;
+        ~GdRun() {
+            if (r) (void)vgan_hc_gam_finish(r, nullptr, nullptr); // (an error's unwinding: the pieces give up, the threads are joined)
         }
     } gd;
-    if (device_gam)
-        gd.t = std::thread([&, d = gpu_list.empty() ? device : gpu_list[0]] {
-            const auto t0 = std::chrono::steady_clock::now();
-            if (vgan_gamdev_open(d, nullptr, gam_map.p, gam_map.n, 0, &gd.g) < 0) gd.why = vgan_last_error(); // (the member index first, beside the runtime's start)
-            gd.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        });
+    if (device_gam) {
+        vgan_gampipe_opts po{};
+        po.mark_duplicates = rmdup ? 1 : 0;
+        po.n_threads = n_threads;
+        if (vgan_hc_gam_start(gpu_list.data(), (int)gpu_list.size(), gam_map.p, gam_map.n, &po, &gd.r) < 0) {
+            device_gam = false;
+            check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
+        }
+    }
     // -j -jf FILE: every alignment of the GAM as a line of JSON (readGAM.h:37-38 writes them while it reads; here a pass of
     // its own, on a thread beside the run).  The reference opens -jf FILE even without -j (and leaves it empty).
     struct JsonDump {
@@ -223,14 +258,6 @@ int haplocart(int argc, char **argv) {
     } else if (!jsonfilename.empty()) {
         std::ofstream touch(jsonfilename);
     }
-    // the HIP runtime comes up on a thread of its own while the graph is read (its failure shows at context creation)
-    struct Warm {
-        std::thread t;
-        ~Warm() {
-            if (t.joinable()) t.join();
-        }
-    } warm;
-    warm.t = std::thread([d = gpu_list.empty() ? device : gpu_list[0]] { (void)vgan_device_warmup(d); });
     vgan_graph *graph = nullptr;
     // graph.gfa when there is one, else the hcfiles' own graph.og (read natively: node sequences, path names, path membership)
     const std::string graphfile = hcfiledir + (std::ifstream(hcfiledir + "graph.gfa") ? "graph.gfa" : "graph.og");
@@ -256,33 +283,19 @@ int haplocart(int argc, char **argv) {
     prm.background_error_prob = background_error_prob;
     prm.use_background_error_prob = !fastafilename.empty(); // HaploCart.cpp:397-400
     prm.is_consensus_fasta = !fastafilename.empty();
-    // (the HIP runtime is still coming up: only "--gpus all" has to wait for it here, to know how many contexts there will
-    // be; otherwise the first chunks are decoded and flattened beside it and the context thread below is the one that waits)
-    if (gpu_spec.empty())
-        if (const char *e = getenv("VGAN_GPUS")) gpu_spec = e;
-    if (gpu_spec == "all") {
-        if (warm.t.joinable()) warm.t.join();
-        const int n_visible = vgan_device_count();
-        if (n_visible <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
-        for (int d = 0; d < n_visible; ++d) gpu_list.push_back(d);
-    } else if (!gpu_spec.empty()) {
-        size_t p0 = 0;
-        while (p0 <= gpu_spec.size()) {
-            size_t c1 = gpu_spec.find(',', p0);
-            if (c1 == std::string::npos) c1 = gpu_spec.size();
-            const int d = parse_int(gpu_spec.substr(p0, c1 - p0), "--gpus", "[HaploCart]");
-            if (d < 0) die("[HaploCart] Error, --gpus needs non-negative GPU indices");
-            gpu_list.push_back(d);
-            p0 = c1 + 1;
-        }
-    }
-    if (gpu_list.empty()) gpu_list.push_back(device);
     struct Contexts { // one device context per entry of the list (an index may repeat: several contexts on one GPU)
         std::vector<vgan_hc_ctx *> v;
         ~Contexts() {
             for (auto c : v) vgan_hc_destroy(c);
         }
     } ctxs;
+    struct GdStop { // (an error's unwinding: the front end's threads use the contexts -- they are joined before the contexts go)
+        vgan_hc_gamrun *&r;
+        ~GdStop() {
+            if (r) (void)vgan_hc_gam_finish(r, nullptr, nullptr);
+            r = nullptr;
+        }
+    } gd_stop{gd.r};
     // the contexts come up on a thread of their own (mask transposition, uploads: ~0.2 s) while this one already flattens
     // the first chunk of reads, which needs the graph only
     std::atomic<bool> contexts_up{false}; // (the lanes flatten on the host until the device can: see the chunk loop)
@@ -489,142 +502,36 @@ int haplocart(int argc, char **argv) {
     });
     if (device_gam) {
         contexts_ready();
-        vgan_hc_ctx *cx = ctxs.v[0];
-        if (gd.t.joinable()) gd.t.join();
-        auto t0 = std::chrono::steady_clock::now();
-        const std::string why = gd.why;
-        if (!why.empty()) {
-            if (getenv("VGAN_TIMING")) fprintf(stderr, "[vgan timing] haplocart: the device front end does not take this input (%s): the host pipeline does\n", why.c_str());
+        const auto t0 = std::chrono::steady_clock::now();
+        vgan_hc_flatten_stats st{};
+        vgan_gampipe_stats ps{};
+        int rc = vgan_hc_gam_attach(gd.r, ctxs.v.data(), (int)ctxs.v.size(), graph);
+        vgan_hc_gamrun *run = gd.r;
+        gd.r = nullptr;
+        const int rc2 = vgan_hc_gam_finish(run, &st, &ps);
+        if (rc >= 0) rc = rc2;
+        if (rc < 0) {
+            // nothing else has been accumulated: the contexts are cleared and the host pipeline takes the file from its start
+            const std::string why = vgan_last_error();
+            if (!quiet) std::cerr << "[HaploCart] the device front end does not take this input (" << why << "): the host pipeline does" << std::endl;
+            for (auto c : ctxs.v) check(vgan_hc_reset(c), "reset");
             device_gam = false;
             check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
         } else {
-            uint64_t sz[8];
-            double ms[4];
-            (void)vgan_gamdev_sizes(gd.g, sz, ms);
-            const double t_parse = gd.ms;
-            stamp("GAM inflated, framed and parsed on the device");
-            // Device memory goes back as soon as it is done with, on threads of their own, one after the other: the file's bytes now, the
-            // inflated bytes when the messages of the reads left to the host are down, the parse's arrays behind the flatten -- beside
-            // the kernels that follow.  What is still held when the process ends is the driver's to take apart in the process's last
-            // 0.2 s (32 GB of front end at 10 M reads).
-            struct Freer { // (left to itself when the scope goes, by an error's unwinding too: the process's end does not wait for it)
-                std::thread t;
-                ~Freer() {
-                    if (t.joinable()) t.detach();
-                }
-            } freer;
-            const bool give_back = !getenv("VGAN_HC_KEEP_GAMDEV") && !getenv("VGAN_KEEP_TEARDOWN"); // (exit handlers run: nothing may be mid-free then)
-            auto later = [&freer, give_back](std::function<void()> fn) {
-                if (!give_back) return;
-                std::thread prev = std::move(freer.t);
-                freer.t = std::thread([p = std::move(prev), fn]() mutable {
-                    if (p.joinable()) p.join();
-                    fn();
-                });
-            };
-            later([g = gd.g] { (void)vgan_gamdev_drop_bytes(g, 1); });
-            n_in = (int64_t)sz[2];
-            const uint8_t *d_dup = nullptr;
-            t0 = std::chrono::steady_clock::now();
-            if (rmdup && n_in) {
-                int64_t nd = 0;
-                check(vgan_gamdev_mark_duplicates(gd.g, &nd), "duplicate removal");
-                n_dup = nd;
-                d_dup = vgan_gamdev_dup_marks(gd.g);
-            }
-            const double t_dup = since_ms(t0);
-            double t_df = 0, t_host = 0;
-            if (n_in) {
-                t0 = std::chrono::steady_clock::now();
-                devflats.v.resize(1, nullptr);
-                check(vgan_hc_devflat_create(cx, graph, &devflats.v[0]), "device flatten");
-                std::vector<uint8_t> mask((size_t)n_in, 0);
-                vgan_hc_packed_view pk;
-                vgan_hc_flatten_stats st{}, sh{};
-                // The reads the device flatten leaves (indels, soft clips): their messages come down and the host parses and flattens them --
-                // on a thread of its own from the moment the mask is known, beside the device's offsets and write pass.
-                struct HostLeft {
-                    std::thread t;
-                    std::string err;
-                    vgan_hc_host_batch *hb = nullptr;
-                    int64_t n = 0;
-                    double ms = 0;
-                    ~HostLeft() {
-                        if (t.joinable()) t.join();
-                        vgan_hc_host_batch_free(hb);
-                    }
-                } left_run;
-                std::function<void()> host_left = [&] {
-                    const auto t1 = std::chrono::steady_clock::now();
-                    for (uint8_t m : mask) left_run.n += m;
-                    if (left_run.n == 0) return;
-                    uint64_t nm = 0, nb = 0;
-                    if (vgan_gamdev_pick(gd.g, mask.data(), &nm, &nb) < 0) {
-                        left_run.err = vgan_last_error();
-                        return;
-                    }
-                    const double t_pick = since_ms(t1);
-                    std::vector<uint64_t> offs((size_t)nm + 1);
-                    std::vector<uint8_t> bytes((size_t)std::max<uint64_t>(nb, 1));
-                    vgan_alnparts *left = nullptr;
-                    if (vgan_gamdev_picked(gd.g, offs.data(), bytes.data()) < 0) {
-                        left_run.err = vgan_last_error();
-                        return;
-                    }
-                    const double t_down = since_ms(t1);
-                    later([g = gd.g] { (void)vgan_gamdev_drop_bytes(g, 2); });
-                    if (vgan_alnparts_from_messages(bytes.data(), offs.data(), (int64_t)nm, 0, n_threads, &left) < 0) {
-                        left_run.err = vgan_last_error();
-                        return;
-                    }
-                    const double t_parsed = since_ms(t1);
-                    const int rc = vgan_hc_flatten_parts_packed(graph, left, 0, vgan_alnparts_count(left), nullptr, 0, &left_run.hb, &sh);
-                    vgan_alnparts_free(left);
-                    if (rc < 0) left_run.err = vgan_last_error();
-                    left_run.ms = since_ms(t1);
-                    if (getenv("VGAN_TIMING"))
-                        fprintf(stderr, "[vgan timing] reads left to the host: %llu messages, %.1f MB; pick %.0f ms, down %.0f, parsed %.0f, flattened %.0f\n",
-                                (unsigned long long)nm, nb / 1e6, t_pick, t_down - t_pick, t_parsed - t_down, left_run.ms - t_parsed);
-                };
-                struct Hook {
-                    HostLeft *run;
-                    std::function<void()> *fn;
-                    static void go(void *u) {
-                        auto *h = static_cast<Hook *>(u);
-                        h->run->t = std::thread(*h->fn);
-                    }
-                } hook{&left_run, &host_left};
-                check(vgan_hc_devflat_run_gamdev_cb(devflats.v[0], gd.g, d_dup, 1, 0, &pk, mask.data(), &st, &Hook::go, &hook), "device flatten");
-                check(vgan_hc_accumulate_packed(cx, &pk), "accumulate");
-                t_df = since_ms(t0);
-                stamp("packed batch flattened on the device and handed to the segment kernel");
-                if (left_run.t.joinable()) left_run.t.join();
-                if (!left_run.err.empty()) die("[HaploCart] reads left to the host: " + left_run.err);
-                const int64_t n_host = left_run.n;
-                if (left_run.hb) {
-                    stamp("the reads left to the host: parsed and flattened (beside the device's write pass)");
-                    const std::string err = hand_over(cx, left_run.hb);
-                    if (!err.empty()) die(err);
-                    stamp("the reads left to the host: handed over");
-                }
-                t_host = left_run.ms;
-                // the file's bytes, their inflated form and the parse's arrays (32 GB at 10 M reads) are done with: given back on a thread
-                // of its own from here on, beside the segment kernel and the posterior -- what is left of them when the process ends is the
-                // driver's to take apart, at the price of the process's last 0.2 s
-                if (give_back) {
-                    vgan_gamdev *done_with = gd.g;
-                    gd.g = nullptr;
-                    later([done_with] { vgan_gamdev_free(done_with); });
-                }
-                tot.n_bad += sh.n_bad;
-                tot.n_unmapped += st.n_unmapped;
-                tot.n_out += st.n_out + sh.n_out;
-                n_host_reads = n_host;
-            }
+            n_in = (int64_t)ps.n_reads;
+            n_dup = (int64_t)ps.n_duplicates;
+            tot.n_bad += st.n_bad;
+            tot.n_unmapped += st.n_unmapped;
+            tot.n_out += st.n_out;
+            n_host_reads = (int64_t)ps.n_host_reads;
+            stamp("the file's pieces inflated, framed, parsed, flattened and accumulated on the device");
             if (getenv("VGAN_TIMING"))
-                fprintf(stderr, "[vgan timing] haplocart device front end: %.1f MB -> %.1f MB, %lld messages, %lld reads; parse %.0f ms (upload %.0f, inflate %.0f, framing %.0f, "
-                                "protobuf walk %.0f), duplicate marks %.0f ms, device flatten + hand-over %.0f ms, the %lld reads left to the host %.0f ms\n",
-                        gam_map.n / 1e6, sz[0] / 1e6, (long long)sz[1], (long long)sz[2], t_parse, ms[0], ms[1], ms[2], ms[3], t_dup, t_df, (long long)n_host_reads, t_host);
+                fprintf(stderr, "[vgan timing] haplocart device front end: %.1f MB -> %.1f MB in %llu pieces on %zu lane(s), %llu messages, %llu reads (%llu duplicates, %llu left to the "
+                                "host); %.0f ms from start to finish (%.0f after the contexts were ready; the first pieces waited %.0f ms for them); summed over pieces: upload %.0f, "
+                                "inflate %.0f, framing %.0f, protobuf walk %.0f, duplicate marks %.0f, flatten + kernels + host-left reads %.0f ms; %.2f GB of device memory\n",
+                        ps.compressed_bytes / 1e6, ps.inflated_bytes / 1e6, (unsigned long long)ps.n_pieces, ctxs.v.size(), (unsigned long long)ps.n_messages,
+                        (unsigned long long)ps.n_reads, (unsigned long long)ps.n_duplicates, (unsigned long long)ps.n_host_reads, ps.ms_wall, since_ms(t0), ps.ms_wait_contexts,
+                        ps.ms_upload, ps.ms_inflate, ps.ms_frame, ps.ms_parse, ps.ms_dedup, ps.ms_consume, ps.device_bytes / 1e9);
         }
     }
     // The loop: next chunk of decoded reads -> duplicate marks -> (host flatten ->) device queue.  Taking a chunk and marking

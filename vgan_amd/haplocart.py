@@ -549,6 +549,16 @@ class GamDevice:
         N.check(N.lib().vgan_gamdev_parse(self._h, buf.ctypes.data, len(data), int(keep_unmapped)))
         return self._sizes()
 
+    def parse_piece(self, data, piece, carry=None, piece_bytes=0, keep_unmapped=False, tail_bytes=0):
+        """vgan_gampipe_parse_piece: piece `piece` of the plan over `data` through this object, framed from `carry` (what the piece before
+        left: None for piece 0).  Returns the state for the next piece (GamCarry)."""
+        carry = carry or GamCarry()
+        buf = np.frombuffer(data, np.uint8)
+        o = N.GamPipeOpts(int(piece_bytes), 0, int(keep_unmapped), 0, 0, int(tail_bytes))
+        N.check(N.lib().vgan_gampipe_parse_piece(self._h, buf.ctypes.data, len(data), C.byref(o), int(piece), C.byref(carry._h)))
+        self._sizes()
+        return carry
+
     def _sizes(self):
         sizes, ms = np.zeros(8, np.uint64), np.zeros(4)
         N.check(N.lib().vgan_gamdev_sizes(self._h, sizes.ctypes.data, ms.ctypes.data))
@@ -585,6 +595,41 @@ class GamDevice:
 
     def __del__(self):
         self.close()
+
+
+class GamCarry:
+    """What a piece's framing leaves for the next piece (opaque: vgan_gampipe_carry)."""
+
+    def __init__(self):
+        self._h = N.vp()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and N is not None:
+            N.lib().vgan_gampipe_carry_free(self._h)
+            self._h = None
+
+
+def gampipe_plan(data, piece_bytes=0):
+    """The pieces a BGZF buffer is cut into: [(offset in the file, compressed bytes, inflated bytes)]."""
+    buf = np.frombuffer(data, np.uint8)
+    o = N.GamPipeOpts(int(piece_bytes), 0, 0, 0, 0, 0)
+    n = N.lib().vgan_gampipe_plan(buf.ctypes.data, len(data), C.byref(o), None, None, None, 0)
+    if n < 0:
+        N.check(int(n))
+    a, b, c = (np.zeros(max(int(n), 1), np.uint64) for _ in range(3))
+    N.lib().vgan_gampipe_plan(buf.ctypes.data, len(data), C.byref(o), a.ctypes.data, b.ctypes.data, c.ctypes.data, int(n))
+    return [(int(a[i]), int(b[i]), int(c[i])) for i in range(int(n))]
+
+
+def accumulate_gam_bytes(ctxs, graph, data, piece_bytes=0, slots=0, mark_duplicates=False, keep_unmapped=False, n_threads=0, tail_bytes=0):
+    """vgan_hc_accumulate_gam_bytes: a BGZF GAM's bytes through the device front end's pipeline into the contexts (piece i -> context
+    i mod n).  Returns (FlattenStats, pipeline statistics as a dict)."""
+    buf = np.frombuffer(data, np.uint8)
+    o = N.GamPipeOpts(int(piece_bytes), int(slots), int(keep_unmapped), int(mark_duplicates), int(n_threads), int(tail_bytes))
+    arr = (N.vp * len(ctxs))(*[c._h for c in ctxs])
+    st, ps = N.FlattenStats(), N.GamPipeStats()
+    N.check(N.lib().vgan_hc_accumulate_gam_bytes(arr, len(ctxs), graph._h, buf.ctypes.data, len(data), C.byref(o), C.byref(st), C.byref(ps)))
+    return st, ps.as_dict()
 
 
 class HcContext:
