@@ -12,6 +12,10 @@ struct GdBlock { // one BGZF member: its DEFLATE payload within the file's bytes
 
 // inflates n_blocks BGZF members (device pointers); d_status[b] = 0 or a GD_* code
 int gamdev_inflate(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_status, hipStream_t st);
+// the same in two kernels (gam_inflate_wave.hip: a wave per member for the Huffman half, tokens through a scratch, a lane per member for
+// the LZ77 half); members left with a status other than 0 are to be done again by gamdev_inflate
+int gamdev_inflate_wave(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_tok, uint32_t tok_cap,
+                        uint32_t *d_cursor, void *d_reg, uint32_t *d_n_reg, hipStream_t st);
 
 } // namespace vgan
 struct vgan_gamdev;

@@ -1141,6 +1141,9 @@ int gamdev_inflate(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n_bloc
 
 } // namespace vgan
 
+namespace {
+int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_blocks, uint8_t *d_out, uint32_t *d_status, hipStream_t st, uint64_t *n_redone);
+}
 // Developer / test entry: inflates a BGZF file's bytes on the device and copies the result back (the host's bgzf_index says where the
 // members lie).  Returns VGAN_EIO when a member does not inflate to its stated size.
 extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *out, uint64_t out_cap, uint64_t *out_size, double *kernel_ms) {
@@ -1160,10 +1163,13 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
     if (out_cap < total) return fail(VGAN_EINVAL, "vgan_gamdev_inflate_bytes: the output buffer is too small");
     uint8_t *d_in = nullptr, *d_out = nullptr;
     GdBlock *d_b = nullptr;
-    uint32_t *d_s = nullptr;
+    uint32_t *d_s = nullptr, *d_tok = nullptr, *d_nreg = nullptr, *d_cur = nullptr;
+    void *d_reg = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = VGAN_OK;
     auto cleanup = [&] {
+        for (void *q : {(void *)d_tok, (void *)d_nreg, (void *)d_cur, d_reg})
+            if (q) (void)hipFree(q);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
         if (d_b) (void)hipFree(d_b);
@@ -1186,21 +1192,31 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
     GDCHK(hipMemcpy(d_b, gb.data(), gb.size() * sizeof(GdBlock), hipMemcpyHostToDevice));
     GDCHK(hipEventCreate(&e0));
     GDCHK(hipEventCreate(&e1));
+    // (as gd_piece_upload_inflate: the two-kernel inflate, its leftovers through the older kernel; VGAN_GAMDEV_INFLATE=lane: the older one alone)
+    const bool lane_inflate = getenv("VGAN_GAMDEV_INFLATE") && !strcmp(getenv("VGAN_GAMDEV_INFLATE"), "lane");
+    const uint32_t tok_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, total * 3 / 10 + 65536);
+    if (!lane_inflate) {
+        GDCHK(hipMalloc((void **)&d_tok, (size_t)tok_cap * 4 + 16));
+        GDCHK(hipMalloc((void **)&d_reg, gb.size() * 32 + 16));
+        GDCHK(hipMalloc((void **)&d_nreg, gb.size() * 4 + 16));
+        GDCHK(hipMalloc((void **)&d_cur, 16));
+        GDCHK(hipMemset(d_cur, 0, 16));
+    }
     GDCHK(hipEventRecord(e0, nullptr));
-    rc = gamdev_inflate(d_in, d_b, (uint32_t)gb.size(), d_out, d_s, nullptr);
+    rc = lane_inflate ? gamdev_inflate(d_in, d_b, (uint32_t)gb.size(), d_out, d_s, nullptr)
+                      : gamdev_inflate_wave(d_in, d_b, (uint32_t)gb.size(), d_out, d_s, d_tok, tok_cap, d_cur, d_reg, d_nreg, nullptr);
     GDCHK(hipEventRecord(e1, nullptr));
     GDCHK(hipDeviceSynchronize());
     if (rc == VGAN_OK) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (kernel_ms) *kernel_ms = ms;
-        std::vector<uint32_t> stt(gb.size());
-        GDCHK(hipMemcpy(stt.data(), d_s, gb.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < stt.size(); ++i)
-            if (stt[i] != GD_OK) {
-                cleanup();
-                return fail(VGAN_EIO, "vgan_gamdev_inflate_bytes: BGZF member %zu does not inflate (code %u)", i, stt[i]);
-            }
+        uint64_t redone = 0;
+        if ((rc = gd_check_inflate(d_in, d_b, gb.size(), d_out, d_s, nullptr, &redone)) < 0) {
+            cleanup();
+            return rc;
+        }
+        if (getenv("VGAN_TIMING")) fprintf(stderr, "[vgan timing] vgan_gamdev_inflate_bytes: %zu members, %llu of them through the older kernel\n", gb.size(), (unsigned long long)redone);
         GDCHK(hipMemcpy(out, d_out, total, hipMemcpyDeviceToHost));
     }
 #undef GDCHK
@@ -1322,6 +1338,49 @@ extern "C" int vgan_gamdev_open(int device, void *hip_stream, const void *bytes,
 }
 
 namespace {
+// The members' statuses after the inflate kernels.  Whatever the two-kernel inflate did not finish (stored blocks, many blocks, no room in
+// its scratch -- and whatever it calls an error) goes through the older kernel, a lane per member: an error is that kernel's to report.
+int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_blocks, uint8_t *d_out, uint32_t *d_status, hipStream_t st, uint64_t *n_redone) {
+    if (n_blocks == 0) return VGAN_OK;
+    std::vector<uint32_t> stt(n_blocks);
+    HIPCHK(hipMemcpyAsync(stt.data(), d_status, n_blocks * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint32_t> again;
+    for (size_t i = 0; i < n_blocks; ++i)
+        if (stt[i] != GD_OK) again.push_back((uint32_t)i);
+    if (again.empty()) return VGAN_OK;
+    if (n_redone) *n_redone += again.size();
+    if (getenv("VGAN_TIMING")) { // (developer aid: why the two-kernel inflate left them)
+        size_t h[16] = {};
+        for (uint32_t i : again) h[std::min<uint32_t>(stt[i], 15u)] += 1;
+        fprintf(stderr, "[vgan timing] inflate: %zu of %zu members go through the older kernel; by status:", again.size(), n_blocks);
+        for (int k = 0; k < 16; ++k)
+            if (h[k]) fprintf(stderr, " %d: %zu", k, h[k]);
+        fprintf(stderr, "\n");
+    }
+    std::vector<GdBlock> all(n_blocks), sub(again.size());
+    HIPCHK(hipMemcpy(all.data(), d_blocks, n_blocks * sizeof(GdBlock), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < again.size(); ++k) sub[k] = all[again[k]];
+    GdBlock *d_sub = nullptr;
+    uint32_t *d_st = nullptr;
+    if (hipMalloc((void **)&d_sub, sub.size() * sizeof(GdBlock)) != hipSuccess || hipMalloc((void **)&d_st, sub.size() * 4) != hipSuccess) {
+        if (d_sub) (void)hipFree(d_sub);
+        return fail(VGAN_ENOMEM, "vgan_gamdev_parse: no device memory for the members to inflate again");
+    }
+    std::vector<uint32_t> st2(sub.size(), 0xFFu);
+    int rc = VGAN_OK;
+    if (hipMemcpy(d_sub, sub.data(), sub.size() * sizeof(GdBlock), hipMemcpyHostToDevice) != hipSuccess) rc = fail(VGAN_ENODEV, "vgan_gamdev_parse: upload failed");
+    if (rc == VGAN_OK) rc = gamdev_inflate(d_in, d_sub, (uint32_t)sub.size(), d_out, d_st, st);
+    if (rc == VGAN_OK && (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(st2.data(), d_st, sub.size() * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(VGAN_ENODEV, "vgan_gamdev_parse: the members inflated again: no status");
+    (void)hipFree(d_sub);
+    (void)hipFree(d_st);
+    if (rc < 0) return rc;
+    for (size_t k = 0; k < st2.size(); ++k)
+        if (st2[k] != GD_OK) return fail(VGAN_EIO, "vgan_gamdev_parse: BGZF member %u does not inflate (code %u)", again[k], st2[k]);
+    return VGAN_OK;
+}
+
 // a whole file as one piece that is the stream's first and last
 int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::vector<GdBlock> &gb, uint64_t total, int keep_unmapped) {
     // every offset the parse leaves is 32 bits wide and every array it fills is a subset of the inflated bytes (a mapping, an edit, a
@@ -1347,6 +1406,16 @@ int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint
     const auto t0 = std::chrono::steady_clock::now();
     if ((rc = g->in.reserve(n + 64)) || (rc = g->infl.reserve(tail_cap + total + 64)) || (rc = g->blocks.reserve(n_gb + 1)) || (rc = g->status.reserve(n_gb + 1))) return rc;
     uint8_t *d_out = g->infl.p + tail_cap;
+    // the two-kernel inflate's scratch: ~0.22 tokens per output byte on GAM data (room for 0.3; a member that finds none goes to the older
+    // kernel); the tokens borrow the parse's per-mapping records, which are written long after the inflate is done with them
+    static const bool lane_inflate = getenv("VGAN_GAMDEV_INFLATE") && !strcmp(getenv("VGAN_GAMDEV_INFLATE"), "lane"); // (developer aid: the older kernel alone)
+    const uint32_t tok_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, total * 3 / 10 + 65536);
+    if (!lane_inflate) {
+        if ((rc = g->map_rec.reserve(((size_t)tok_cap + 3) / 4)) || (rc = g->tok_reg.reserve(n_gb * 4 + 4)) || (rc = g->tok_nreg.reserve(n_gb + 1)) ||
+            (rc = g->tok_cursor.reserve(4)))
+            return rc;
+        HIPCHK(hipMemsetAsync(g->tok_cursor.p, 0, 4, st));
+    }
     if (n_gb) HIPCHK(hipMemcpyAsync(g->blocks.p, gb, n_gb * sizeof(GdBlock), hipMemcpyHostToDevice, st));
     // The bytes go up in a few parts, each on a stream of its own with the inflate of its members behind it: a part's kernel runs BESIDE
     // the next part's copy and the other parts' kernels, not before them (parts on ONE stream ran one after the other).
@@ -1371,7 +1440,12 @@ int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint
         if (upto > sent) HIPCHK(hipMemcpyAsync(g->in.p + sent, bytes + sent, upto - sent, hipMemcpyHostToDevice, ps));
         g->ms_upload += ms_since(tc);
         sent = upto;
-        if (b1 > b0 && (rc = gamdev_inflate(g->in.p, g->blocks.p + b0, (uint32_t)(b1 - b0), d_out, g->status.p + b0, ps))) return rc;
+        if (b1 > b0) {
+            if (lane_inflate) rc = gamdev_inflate(g->in.p, g->blocks.p + b0, (uint32_t)(b1 - b0), d_out, g->status.p + b0, ps);
+            else rc = gamdev_inflate_wave(g->in.p, g->blocks.p + b0, (uint32_t)(b1 - b0), d_out, g->status.p + b0, reinterpret_cast<uint32_t *>(g->map_rec.p), tok_cap,
+                                          g->tok_cursor.p, g->tok_reg.p + (size_t)b0 * 4, g->tok_nreg.p + b0, ps);
+            if (rc) return rc;
+        }
         b0 = b1;
         ++k;
     }
@@ -1407,13 +1481,7 @@ int vgan::gd::gd_piece_parse(vgan_gamdev *g, const GdCarry &cin, bool last_piece
     if (n_tail) HIPCHK(hipMemcpyAsync(u, cin.tail.data(), n_tail, hipMemcpyHostToDevice, st));
     for (hipStream_t ps : g->piece_stream)
         if (ps) HIPCHK(hipStreamSynchronize(ps));
-    {
-        std::vector<uint32_t> stt(g->n_blocks);
-        if (g->n_blocks) HIPCHK(hipMemcpyAsync(stt.data(), g->status.p, g->n_blocks * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        for (size_t i = 0; i < stt.size(); ++i)
-            if (stt[i] != GD_OK) return fail(VGAN_EIO, "vgan_gamdev_parse: BGZF member %zu does not inflate (code %u)", i, stt[i]);
-    }
+    if ((rc = gd_check_inflate(g->in.p, g->blocks.p, g->n_blocks, g->infl.p + g->tail_cap, g->status.p, st, &g->n_redone)) < 0) return rc;
     g->ms_inflate += ms_since(t0);
     g->u = u;
     g->n_stream = total;

@@ -16,7 +16,7 @@
 namespace vgan {
 namespace gd {
 
-enum : uint32_t { GD_OK = 0, GD_BAD_BLOCK = 1, GD_BAD_CODE = 2, GD_OVERRUN_IN = 3, GD_OVERRUN_OUT = 4, GD_BAD_STORED = 5, GD_BAD_CRC = 6 };
+enum : uint32_t { GD_OK = 0, GD_BAD_BLOCK = 1, GD_BAD_CODE = 2, GD_OVERRUN_IN = 3, GD_OVERRUN_OUT = 4, GD_BAD_STORED = 5, GD_BAD_CRC = 6, GD_PUNT = 7 /* gd_tokens_kernel leaves the member to gd_inflate_kernel */ };
 enum : uint32_t { GF_OK = 0, GF_BAD_VARINT = 1, GF_MISSED = 2, GF_TRUNCATED = 3, GF_BAD_MESSAGE = 4 };
 
 struct GdMapRec { // what the message pass leaves per mapping for the lane that fills its arrays
@@ -113,6 +113,8 @@ struct vgan_gamdev {
     vgan::gd::GBuf<uint32_t> status, seg_msgs, seg_status, msg_len, keep, n_map, n_edit, n_eseq, n_qual, r_at, m_at, e_at, s_at, q_at, bad;
     vgan::gd::GBuf<uint64_t> anchor, next_anchor, msg_base, msg_off;
     vgan::gd::GBuf<vgan::gd::GdCarryState> carry;
+    vgan::gd::GBuf<uint64_t> tok_reg;              // gd_tokens_kernel -> gd_lz_kernel: {first token, tokens} per block of a member (the tokens themselves borrow map_rec)
+    vgan::gd::GBuf<uint32_t> tok_nreg, tok_cursor; // blocks per member; the scratch's fill
     vgan::gd::GBuf<vgan::gd::GdMapRec> map_rec; // per mapping: where its bytes lie, where its edits go (gd_fill_kernel -> gd_fill_maps_kernel)
     // one DfSlice's arrays (hc_flatten_kernels.hip) of the file's reads
     vgan::gd::GBuf<uint32_t> map_off, qual_off, edit_off, e_seq_off, m_node, seq_len;
@@ -129,6 +131,7 @@ struct vgan_gamdev {
     const uint8_t *u = nullptr;
     uint64_t n_stream = 0;
     size_t n_blocks = 0;
+    uint64_t n_redone = 0;     // (test aid) members the two-kernel inflate left to the older kernel
     uint64_t n_reanchored = 0; // (test aid) tag-like bytes the framing of the parses so far took for a group's tag and gave up again
     uint64_t n_picked = 0, n_picked_bytes = 0;
     uint64_t n_inflated = 0, n_messages = 0, R = 0, M = 0, E = 0, S = 0, Q = 0;
@@ -138,7 +141,8 @@ struct vgan_gamdev {
         for (auto *x : {&status, &seg_msgs, &seg_status, &msg_len, &keep, &n_map, &n_edit, &n_eseq, &n_qual, &r_at, &m_at, &e_at, &s_at, &q_at, &bad, &map_off, &qual_off,
                         &edit_off, &e_seq_off, &m_node, &seq_len, &perm_a, &perm_b, &new_flag, &new_at})
             b += x->cap * 4;
-        for (auto *x : {&anchor, &next_anchor, &msg_base, &msg_off, &sort_key, &sort_key2, &picked_off}) b += x->cap * 8;
+        for (auto *x : {&anchor, &next_anchor, &msg_base, &msg_off, &sort_key, &sort_key2, &picked_off, &tok_reg}) b += x->cap * 8;
+        b += (tok_nreg.cap + tok_cursor.cap) * 4;
         for (auto *x : {&m_offset, &mapq, &e_len}) b += x->cap * 4;
         for (auto *x : {&unmapped, &m_rev, &e_seq, &qual, &dup, &picked_bytes}) b += x->cap;
         for (auto *x : {&first_node, &first_offset, &new_node, &new_off}) b += x->cap * 8;
@@ -151,6 +155,7 @@ struct vgan_gamdev {
             b->release();
         for (auto *b : {&anchor, &next_anchor, &msg_base, &msg_off}) b->release();
         carry.release();
+        tok_reg.release(), tok_nreg.release(), tok_cursor.release();
         map_rec.release();
         for (auto *b : {&m_offset, &mapq, &e_len}) b->release();
         for (auto *b : {&unmapped, &m_rev, &e_seq, &qual}) b->release();
