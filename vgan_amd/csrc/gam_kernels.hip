@@ -531,6 +531,33 @@ __device__ __forceinline__ int gd_varint(const uint8_t *u, uint64_t e, uint64_t 
     return -1;
 }
 
+// The same with the eight bytes at p in one load when the stream has them (a byte to a load, a message was three dependent loads and
+// more: the walk of a 1 MiB segment is ~800 messages, one after the other); `word` / `have`: those bytes, for the caller to look at what
+// follows the varint (a group's tag) without another load.
+__device__ __forceinline__ int gd_varint_w(const uint8_t *u, uint64_t e, uint64_t p, uint64_t &v, uint64_t &q, uint64_t &word, bool &have) {
+    have = p + 8 <= e;
+    if (!have) return gd_varint(u, e, p, v, q);
+    word = reinterpret_cast<const GdU64 *>(u + p)->v;
+    // the first byte without its continuation bit ends the varint: bit 7 of byte k is bit 8k + 7
+    const uint64_t stop = ~word & 0x8080808080808080ull;
+    if (!stop) { // (eight bytes and more: lengths and counts never are; the byte loop says what it is)
+        have = false;
+        return gd_varint(u, e, p, v, q);
+    }
+    const uint32_t nb = ((uint32_t)__builtin_ctzll(stop) >> 3) + 1u; // bytes of the varint: 1..8
+    uint64_t x = nb == 8u ? word : word & ((1ull << (8u * nb)) - 1ull), r = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) r |= ((x >> (8u * k)) & 0x7Full) << (7u * k);
+    v = r;
+    q = p + nb;
+    return 1;
+}
+// the bytes [q, q + 3) "GAM", out of the word loaded at p when it holds them
+__device__ __forceinline__ bool gd_is_gam(const uint8_t *u, uint64_t p, uint64_t q, uint64_t word, bool have) {
+    if (have && q + 3 <= p + 8) return ((uint32_t)(word >> (8u * (uint32_t)(q - p))) & 0xFFFFFFu) == 0x4D4147u;
+    return u[q] == 'G' && u[q + 1] == 'A' && u[q + 2] == 'M';
+}
+
 // One WAVE per segment: the first tag in [seg start (or 1), seg end); a match may begin in the segment and end beyond it.
 // the first tag in [from, s1) (a wave searches: every lane gets the result), GD_NO_ANCHOR when there is none
 __device__ __forceinline__ uint64_t gd_find_tag(const uint8_t *__restrict__ u, uint64_t n, uint64_t from, uint64_t s1, uint32_t lane) {
@@ -614,11 +641,14 @@ __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t star
                 if (open_end) return cut(2u);
                 return GdWalkOut{(uint32_t)cnt, stop_tag == n && p == n ? GF_OK : GF_TRUNCATED};
             }
-            const int r = gd_varint(u, n, p, v, q);
+            uint64_t word = 0;
+            bool have = false;
+            const int r = gd_varint_w(u, n, p, v, q, word, have);
             if (r < 0) return GdWalkOut{(uint32_t)cnt, GF_BAD_VARINT};
             if (r == 0) return cut(2u);
             if (open_end && q + 4 > n) return cut(2u); // (whether a tag follows cannot be told from these bytes alone)
-            if (gd_u32_at(u, n, q) == GD_TAG && q + 4 <= n) { // p is a group header
+            const uint32_t four = have && q + 4 <= p + 8 ? (uint32_t)(word >> (8u * (uint32_t)(q - p))) : gd_u32_at(u, n, q);
+            if (four == GD_TAG && q + 4 <= n) { // p is a group header
                 if (q == stop_tag) return GdWalkOut{(uint32_t)cnt, GF_OK};
                 if (q > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
                 rem = v;
@@ -657,10 +687,12 @@ __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t star
             if (p > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
             continue;
         }
-        const int r = gd_varint(u, n, p, v, q);
+        uint64_t word = 0;
+        bool have = false;
+        const int r = gd_varint_w(u, n, p, v, q, word, have);
         if (r < 0) return GdWalkOut{(uint32_t)cnt, GF_BAD_VARINT};
         if (r == 0 || v > n - q) return cut(1u);
-        const bool tag = first && v == 3 && u[q] == 'G' && u[q + 1] == 'A' && u[q + 2] == 'M';
+        const bool tag = first && v == 3 && gd_is_gam(u, p, q, word, have);
         if (!tag) {
             if (v > 0xFFFFFFFFull) return GdWalkOut{(uint32_t)cnt, GF_BAD_MESSAGE};
             if (EMIT) {

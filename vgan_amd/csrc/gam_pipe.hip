@@ -41,7 +41,7 @@ vgan_gampipe_opts with_defaults(const vgan_gampipe_opts *o) {
     if (o) r = *o;
     if (const char *e = getenv("VGAN_GAMPIPE_PIECE")) r.piece_bytes = strtoull(e, nullptr, 10);
     if (const char *e = getenv("VGAN_GAMPIPE_SLOTS")) r.slots = atoi(e);
-    if (r.piece_bytes == 0) r.piece_bytes = 256ull << 20;
+    if (r.piece_bytes == 0) r.piece_bytes = 192ull << 20;
     if (r.slots <= 0) r.slots = 3;
     if (r.slots > 16) r.slots = 16;
     if (r.tail_bytes == 0) r.tail_bytes = 8ull << 20;
@@ -191,6 +191,9 @@ struct Pipe {
         cv.notify_all();
     }
 
+    std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
+    bool timing = getenv("VGAN_TIMING") != nullptr;
+
     void slot_thread(int lane, int slot) {
         Lane &L = lanes[(size_t)lane];
         vgan_gamdev *g = nullptr;
@@ -212,12 +215,15 @@ struct Pipe {
                 break;
             }
             int rc;
+            double ts[8] = {ms_since(t_start)}; // (VGAN_TIMING: when the piece's stages ended, from the pipeline's start)
             if ((rc = gd_piece_upload_inflate(g, cut.p + pc.in0, pc.in1 - pc.in0, pc.blocks, pc.n_blocks, pc.out_bytes, o.tail_bytes)) < 0) {
                 fail_with(rc, last_error());
                 break;
             }
+            ts[1] = ms_since(t_start);
             // ---- the framing turn: the state the piece before left, and what this one leaves
             if (!wait_turn(framed, i)) break;
+            ts[2] = ms_since(t_start);
             GdCarry cin, cout;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -246,6 +252,7 @@ struct Pipe {
                 fail_with(rc, last_error());
                 break;
             }
+            ts[3] = ms_since(t_start);
             // ---- the index of the piece's first read
             if (!wait_turn(counted, i)) break;
             uint64_t base;
@@ -292,6 +299,7 @@ struct Pipe {
                 cv.notify_all();
                 d_dup = g->R ? vgan_gamdev_dup_marks(g) : nullptr;
             }
+            ts[4] = ms_since(t_start);
             // ---- the subcommand's share
             const auto t0 = std::chrono::steady_clock::now();
             if (g->R && (rc = consumer.consume(lane, g, base, d_dup, (int64_t)i)) < 0) {
@@ -302,6 +310,9 @@ struct Pipe {
                 std::lock_guard<std::mutex> lk(mu);
                 st.ms_consume += ms_since(t0);
             }
+            if (timing)
+                fprintf(stderr, "[vgan timing] gampipe piece %zu (lane %d slot %d, %llu reads): from %.0f ms: sent %.0f, its framing turn at %.0f, parsed %.0f (inflate wait %.0f, framing %.0f, walk %.0f), marked %.0f, consumed %.0f\n",
+                        i, lane, slot, (unsigned long long)g->R, ts[0], ts[1], ts[2], ts[3], g->ms_inflate, g->ms_frame, g->ms_parse, ts[4], ms_since(t_start));
         }
     }
 };
@@ -417,7 +428,20 @@ extern "C" int vgan_gampipe_parse_piece(vgan_gamdev *g, const void *bytes, uint6
 // vgan haplocart's consumer: device flatten of the piece into the packed batch + the segment kernel, on the lane's context; the reads the
 // device flatten leaves (indels, soft clips, long reads) come back as their messages and go through the host's parser and flatten,
 // beside the device's write pass.
+namespace {
+struct LeftJob { // the reads of one piece that the device flatten leaves to the host
+    std::thread t;
+    std::vector<uint8_t> mask;
+    uint64_t n = 0;
+    int rc = VGAN_OK;
+    std::string err;
+    std::mutex m;
+    std::condition_variable cv;
+    bool dev_done = false; // the messages are down: the piece's device object is free
+};
+} // namespace
 struct vgan_hc_gamrun : GamConsumer {
+    std::vector<std::shared_ptr<LeftJob>> bg;
     std::vector<int> devices;
     const void *bytes = nullptr;
     uint64_t n = 0;
@@ -468,72 +492,97 @@ struct vgan_hc_gamrun : GamConsumer {
         (void)vgan_gamdev_sizes(g, sz, nullptr);
         const uint64_t R = sz[2];
         if (read_base + R > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "vgan_hc_gam: more than 2^32 reads");
-        std::vector<uint8_t> mask((size_t)R, 0);
+        // the reads the device flatten leaves: their messages come down (on a thread of its own from the moment the mask is known, beside
+        // the device's offsets and write pass) -- the piece's slot waits for that much, the object's buffers are free then -- and the
+        // host parses, flattens and hands them over behind the slot's back, while it already takes its next piece
+        auto job = std::make_shared<LeftJob>();
+        job->mask.assign((size_t)R, 0);
         vgan_hc_packed_view pk;
-        vgan_hc_flatten_stats st{}, sh{};
-        // the reads the device flatten leaves: their messages come down and the host parses and flattens them -- on a thread of its own
-        // from the moment the mask is known, beside the device's offsets and write pass
-        struct HostLeft {
-            std::thread t;
-            int rc = VGAN_OK;
-            std::string err;
-            vgan_hc_host_batch *hb = nullptr;
-            uint64_t n = 0;
-            ~HostLeft() {
-                if (t.joinable()) t.join();
-                vgan_hc_host_batch_free(hb);
-            }
-        } left;
-        std::function<void()> host_left = [&] {
-            for (uint8_t m : mask) left.n += m;
-            if (left.n == 0) return;
+        vgan_hc_flatten_stats st{};
+        vgan_hc_gamrun *self = this;
+        std::function<void()> host_left = [self, job, g, cx, lane] {
+            auto device_done = [&] {
+                {
+                    std::lock_guard<std::mutex> lk(job->m);
+                    job->dev_done = true;
+                }
+                job->cv.notify_all();
+            };
+            for (uint8_t m : job->mask) job->n += m;
             uint64_t nm = 0, nb = 0;
+            std::vector<uint64_t> offs;
+            std::vector<uint8_t> msgs;
+            if (job->n) {
+                if ((job->rc = vgan_gamdev_pick(g, job->mask.data(), &nm, &nb)) >= 0) {
+                    offs.resize((size_t)nm + 1);
+                    msgs.resize((size_t)std::max<uint64_t>(nb, 1));
+                    job->rc = vgan_gamdev_picked(g, offs.data(), msgs.data());
+                }
+                if (job->rc < 0) job->err = last_error();
+            }
+            device_done();
+            if (job->n == 0 || job->rc < 0) return;
             vgan_alnparts *parts = nullptr;
-            if ((left.rc = vgan_gamdev_pick(g, mask.data(), &nm, &nb)) < 0) {
-                left.err = last_error();
-                return;
+            vgan_hc_host_batch *hb = nullptr;
+            vgan_hc_flatten_stats sh{};
+            if ((job->rc = vgan_alnparts_from_messages(msgs.data(), offs.data(), (int64_t)nm, self->opts.keep_unmapped, self->host_threads, &parts)) >= 0) {
+                job->rc = vgan_hc_flatten_parts_packed(self->graph, parts, 0, vgan_alnparts_count(parts), nullptr, self->host_threads, &hb, &sh);
+                vgan_alnparts_free(parts);
             }
-            std::vector<uint64_t> offs((size_t)nm + 1);
-            std::vector<uint8_t> msgs((size_t)std::max<uint64_t>(nb, 1));
-            if ((left.rc = vgan_gamdev_picked(g, offs.data(), msgs.data())) < 0 ||
-                (left.rc = vgan_alnparts_from_messages(msgs.data(), offs.data(), (int64_t)nm, opts.keep_unmapped, host_threads, &parts)) < 0) {
-                left.err = last_error();
-                return;
+            if (job->rc >= 0 && hb) {
+                std::lock_guard<std::mutex> lk(self->lane_mu[(size_t)lane]);
+                job->rc = self->hand_over(cx, hb); // (the batch's host arrays are copied inside these calls: it may go when they return)
             }
-            left.rc = vgan_hc_flatten_parts_packed(graph, parts, 0, vgan_alnparts_count(parts), nullptr, host_threads, &left.hb, &sh);
-            if (left.rc < 0) left.err = last_error();
-            vgan_alnparts_free(parts);
+            if (job->rc < 0) job->err = last_error();
+            vgan_hc_host_batch_free(hb);
+            std::lock_guard<std::mutex> lk(self->mu);
+            self->fst.n_bad += sh.n_bad;
+            self->fst.n_unmapped += sh.n_unmapped;
+            self->fst.n_clamped += sh.n_clamped;
+            self->fst.n_out += sh.n_out;
+            self->fst.n_segments += sh.n_segments;
+            self->fst.n_cols += sh.n_cols;
         };
         struct Hook {
-            HostLeft *run;
+            LeftJob *job;
             std::function<void()> *fn;
             static void go(void *u) {
                 auto *h = static_cast<Hook *>(u);
-                h->run->t = std::thread(*h->fn);
+                h->job->t = std::thread(*h->fn);
             }
-        } hook{&left, &host_left};
+        } hook{job.get(), &host_left};
+        {
+            std::lock_guard<std::mutex> lk(mu); // (from here on the run joins the thread, whatever way this call ends)
+            bg.push_back(job);
+        }
         int r;
+        const auto tc0 = std::chrono::steady_clock::now();
+        double t_lock = 0, t_flat = 0;
         {
             std::lock_guard<std::mutex> lk(lane_mu[(size_t)lane]); // (the lane's context, its stream and its flatten object: one piece at a time)
+            t_lock = ms_since(tc0);
             if (!df[(size_t)lane] && (r = vgan_hc_devflat_create(cx, graph, &df[(size_t)lane])) < 0) return r;
-            if ((r = vgan_hc_devflat_run_gamdev_cb(df[(size_t)lane], g, d_dup, d_dup ? 1 : 0, (uint32_t)read_base, &pk, mask.data(), &st, &Hook::go, &hook)) < 0) return r;
-            if ((r = vgan_hc_accumulate_packed(cx, &pk)) < 0) return r;
+            r = vgan_hc_devflat_run_gamdev_cb(df[(size_t)lane], g, d_dup, d_dup ? 1 : 0, (uint32_t)read_base, &pk, job->mask.data(), &st, &Hook::go, &hook);
+            if (r >= 0) r = vgan_hc_accumulate_packed(cx, &pk);
+            t_flat = ms_since(tc0);
         }
-        if (left.t.joinable()) left.t.join();
-        if (left.rc < 0) return fail(left.rc, "the reads left to the host: %s", left.err.c_str());
-        if (left.hb) {
-            std::lock_guard<std::mutex> lk(lane_mu[(size_t)lane]);
-            if ((r = hand_over(cx, left.hb)) < 0) return r; // (the batch's host arrays are copied inside these calls: it may go when they return)
+        if (job->t.joinable()) { // (started when the mask was final: the object's buffers are the thread's until it says so)
+            std::unique_lock<std::mutex> lk(job->m);
+            job->cv.wait(lk, [&] { return job->dev_done; });
         }
+        if (r < 0) return r;
+        if (job->rc < 0) return fail(job->rc, "the reads left to the host: %s", job->err.c_str());
+        if (getenv("VGAN_TIMING"))
+            fprintf(stderr, "[vgan timing] hc consume: waited %.1f ms for the lane, flattened + handed over at %.1f, the messages of the %llu reads left to the host down at %.1f\n", t_lock,
+                    t_flat, (unsigned long long)job->n, ms_since(tc0));
         std::lock_guard<std::mutex> lk(mu);
         fst.n_in += st.n_in;
-        fst.n_bad += sh.n_bad;
-        fst.n_unmapped += st.n_unmapped + sh.n_unmapped;
-        fst.n_clamped += st.n_clamped + sh.n_clamped;
-        fst.n_out += st.n_out + sh.n_out;
-        fst.n_segments += st.n_segments + sh.n_segments;
-        fst.n_cols += st.n_cols + sh.n_cols;
-        n_host_reads += left.n;
+        fst.n_unmapped += st.n_unmapped;
+        fst.n_clamped += st.n_clamped;
+        fst.n_out += st.n_out;
+        fst.n_segments += st.n_segments;
+        fst.n_cols += st.n_cols;
+        n_host_reads += job->n;
         n_device_reads += (uint64_t)st.n_out;
         return VGAN_OK;
     }
@@ -580,6 +629,13 @@ extern "C" int vgan_hc_gam_finish(vgan_hc_gamrun *r, vgan_hc_flatten_stats *stat
     }
     r->cv.notify_all();
     if (r->coord.joinable()) r->coord.join();
+    for (auto &j : r->bg) { // the host's share of the pieces (parse, flatten, hand-over of the reads the device left)
+        if (j->t.joinable()) j->t.join();
+        if (j->rc < 0 && r->rc >= 0) {
+            r->rc = j->rc;
+            r->err = "the reads left to the host: " + j->err;
+        }
+    }
     for (size_t l = 0; l < r->df.size(); ++l) {
         if (r->df[l] && l < r->ctx.size()) (void)vgan_hc_synchronize(r->ctx[l]); // (the segment kernel reads the flatten object's buffers)
         r->df_bytes += hc_devflat_device_bytes(r->df[l]);
