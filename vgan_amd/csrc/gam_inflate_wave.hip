@@ -56,6 +56,7 @@ __device__ __forceinline__ uint64_t gw_bits(const uint8_t *pay, uint32_t p) { re
 
 constexpr uint32_t GW_TB = 9, GW_DB = 9;   // bits the direct tables are indexed by
 constexpr uint32_t GW_MAX_REGIONS = 4;
+constexpr uint32_t GW_SPEC = 1280; // bits a speculative decode runs before its end is taken for a true boundary (~11 codes of ~13 bits are the mean)
 
 // One alphabet's canonical code (RFC 1951 3.2.2) in LDS: limit[L] = (first code of length L + their count) << (15 - L), base[L] =
 // (symbols of shorter codes) - (first code of length L), the symbols in code order -- gam_kernels.hip: Dec, dec_len, dec_build.
@@ -149,15 +150,46 @@ __device__ void gw_fill(const GwCode &c, const SymT *sorted, uint32_t *tab, uint
         tab[idx] = e;
     }
 }
-// the entry of a code longer than the table's index (rare symbols), from the next 15 bits
+// Codes longer than a table's index: a SECOND table per index whose code is longer, the two of an alphabet's and both alphabets' out of
+// one pool.  The first table's entry then says where the second lies and how many more bits index it (GW_LONG | offset << 8 | bits); a
+// second table's entries are ready entries (their length: the whole code's).  Canonical codes grow with their left-aligned value, so
+// the longest code behind an index is the one in front of the index's LARGEST 15-bit continuation.  All lanes fill one second table at
+// a time (64 entries at most: codes are 15 bits at most, the first tables take 9).  False: the pool is full (the older kernel's member).
+// (A wave decodes 64 chunks in step: a path for long codes that ONE lane takes is a path the wave takes, in most steps -- it must cost
+// a table look-up, not a canonical decode.)
+constexpr uint32_t GW_POOL = 768;
 template <int ALPHA, class SymT>
-__device__ __noinline__ uint32_t gw_long(const GwCode &c, const SymT *sorted, uint32_t w, const uint32_t *len_tab, const uint32_t *dist_tab) {
-    const uint32_t pk = __builtin_bitreverse32(w) >> 17;
-    const uint32_t len = gw_code_len(c, pk);
-    if (len > 15u) return 0u;
-    const uint32_t at = (uint32_t)(c.base[len] + (int32_t)(pk >> (15u - len)));
-    if (at >= c.n_coded) return 0u;
-    return gw_entry<ALPHA>((uint32_t)sorted[at], len, len_tab, dist_tab);
+__device__ bool gw_fill_long(const GwCode &c, const SymT *sorted, uint32_t *tab, uint32_t bits, uint32_t *pool, uint32_t &pool_n, uint32_t lane, const uint32_t *len_tab,
+                             const uint32_t *dist_tab) {
+    for (uint32_t i0 = 0; i0 < (1u << bits); i0 += 64u) {
+        uint64_t todo = __builtin_amdgcn_ballot_w64(tab[i0 + lane] == GW_LONG);
+        while (todo) {
+            const uint32_t idx = i0 + (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t pk0 = __builtin_bitreverse32(idx) >> 17; // (its low 15 - bits bits are zero)
+            const uint32_t lmax = min(gw_code_len(c, pk0 | ((1u << (15u - bits)) - 1u)), 15u), sb = lmax - bits;
+            if (pool_n + (1u << sb) > GW_POOL) return false;
+            if (lane < (1u << sb)) {
+                const uint32_t pk = __builtin_bitreverse32(idx | (lane << bits)) >> 17;
+                const uint32_t len = gw_code_len(c, pk);
+                uint32_t e = 0;
+                if (len <= lmax) {
+                    const uint32_t at = (uint32_t)(c.base[len] + (int32_t)(pk >> (15u - len)));
+                    if (at < c.n_coded) e = gw_entry<ALPHA>((uint32_t)sorted[at], len, len_tab, dist_tab);
+                }
+                pool[pool_n + lane] = e;
+            }
+            if (lane == 0) tab[idx] = GW_LONG | (pool_n << 8) | sb;
+            pool_n += 1u << sb;
+        }
+    }
+    return true;
+}
+// the ready entry of the code at the low bits of w (two look-ups for a long code)
+__device__ __forceinline__ uint32_t gw_lookup(const uint32_t *tab, uint32_t bits, const uint32_t *pool, uint32_t w) {
+    uint32_t e = tab[w & ((1u << bits) - 1u)];
+    if (e & GW_LONG) e = pool[((e >> 8) & 0xFFFFu) + __builtin_amdgcn_ubfe(w, bits, e & 15u)];
+    return e;
 }
 
 struct GwHeader { // what a block's header is read with: done with when the two alphabets' codes are built
@@ -173,6 +205,7 @@ struct GwShared {
         uint32_t lt[1u << GW_TB];
     };
     uint32_t dt[1u << GW_DB];
+    uint32_t pool[GW_POOL]; // the second tables of both alphabets
     uint16_t lsym[288];
     uint8_t dsym[32];
     GwCode lc, dc;
@@ -224,8 +257,7 @@ __device__ __forceinline__ uint32_t gw_chunk(const GwShared &sh, const uint8_t *
     while (p < stop) {
         const uint64_t w = gw_win_peek(br, p);
         const uint32_t w0 = (uint32_t)w;
-        uint32_t e = sh.lt[w0 & ((1u << GW_TB) - 1u)];
-        if (e & GW_LONG) e = gw_long<GW_ALPHA_LIT>(sh.lc, sh.lsym, w0, sh.len_tab, sh.dist_tab);
+        const uint32_t e = gw_lookup(sh.lt, GW_TB, sh.pool, w0);
         const uint32_t len = e & 15u, xb = (e >> 4) & 15u, val = (e >> 8) & 511u;
         uint32_t used = len + xb;
         bool ok = (e & (GW_LIT | GW_EOB | GW_MATCH)) != 0u;
@@ -234,8 +266,7 @@ __device__ __forceinline__ uint32_t gw_chunk(const GwShared &sh, const uint8_t *
             // (the length's extra bits lie within the first 20 bits; the distance code and its extra bits, 28 at most, behind them)
             const uint32_t L = val + __builtin_amdgcn_ubfe(w0, len, xb);
             const uint32_t w2 = (uint32_t)(w >> used);
-            uint32_t de = sh.dt[w2 & ((1u << GW_DB) - 1u)];
-            if (de & GW_LONG) de = gw_long<GW_ALPHA_DIST>(sh.dc, sh.dsym, w2, sh.len_tab, sh.dist_tab);
+            const uint32_t de = gw_lookup(sh.dt, GW_DB, sh.pool, w2);
             const uint32_t dl = de & 15u, dxb = (de >> 4) & 15u;
             ok = (de & GW_DIST) != 0u;
             if (ok) {
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(64, 8) void gd_tokens_kernel(const uint8_t *__restr
     const GdBlock bl = blocks[b];
     const uint8_t *pay = in + bl.in_off;
     const uint32_t end_bits = bl.in_size * 8u;
-    uint32_t pos = 0, st = GD_OK, n_regions = 0, total_bytes = 0;
+    uint32_t pos = 0, st = GD_OK, n_regions = 0, total_bytes = 0, rounds = 0;
     bool last = false;
     while (!last && st == GD_OK) {
         if (pos + 3u > end_bits) {
@@ -428,13 +459,26 @@ __global__ __launch_bounds__(64, 8) void gd_tokens_kernel(const uint8_t *__restr
         gw_fill<GW_ALPHA_LIT>(sh.lc, sh.lsym, sh.lt, GW_TB, lane, sh.len_tab, sh.dist_tab);
         gw_fill<GW_ALPHA_DIST>(sh.dc, sh.dsym, sh.dt, GW_DB, lane, sh.len_tab, sh.dist_tab);
         __syncthreads();
+        {
+            uint32_t pool_n = 0;
+            const bool fits = gw_fill_long<GW_ALPHA_LIT>(sh.lc, sh.lsym, sh.lt, GW_TB, sh.pool, pool_n, lane, sh.len_tab, sh.dist_tab) &&
+                              gw_fill_long<GW_ALPHA_DIST>(sh.dc, sh.dsym, sh.dt, GW_DB, sh.pool, pool_n, lane, sh.len_tab, sh.dist_tab);
+            if (!fits) {
+                st = GD_PUNT;
+                break;
+            }
+        }
+        __syncthreads();
         // ---- the block's codes: 64 chunks at once, starts moved to true boundaries until none moves
         const uint32_t rem = end_bits - pos;
         const uint32_t C = max((rem + 63u) / 64u, 256u);
         const uint32_t limit = lane == 63u ? 0x7FFFFFF0u : pos + (lane + 1u) * C;
-        uint32_t t = pos + lane * C, e = 0, ntok = 0, nbytes = 0, fl = 0;
+        // (the first round only has to find where each chunk ENDS: it starts GW_SPEC bits in front of that end -- far enough for the decode to
+        // stand on true boundaries when it gets there, a third of a chunk of a full member; the last lane's end is nobody's start)
+        uint32_t t = lane == 63u ? end_bits : max(pos + lane * C, limit > GW_SPEC ? limit - GW_SPEC : 0u), e = 0, ntok = 0, nbytes = 0, fl = 0;
         bool need = true;
         for (uint32_t it = 0; it < 70u; ++it) {
+            rounds += 1;
             if (need) e = gw_chunk<false>(sh, pay, t, limit, end_bits, nullptr, ntok, nbytes, fl);
             const uint32_t pe = (uint32_t)__shfl_up((int)e, 1);
             const uint32_t nt = lane == 0 ? pos : pe;
@@ -479,7 +523,7 @@ __global__ __launch_bounds__(64, 8) void gd_tokens_kernel(const uint8_t *__restr
     }
     if (st == GD_OK && total_bytes != bl.out_size) st = GD_OVERRUN_OUT;
     if (lane == 0) {
-        n_reg[b] = n_regions;
+        n_reg[b] = n_regions | (rounds << 8); // (the rounds the chunks' starts took to settle: a developer's figure, kept in the upper bits)
         status[b] = st;
     }
 }
@@ -492,7 +536,7 @@ __global__ __launch_bounds__(64) void gd_lz_kernel(const GdBlock *__restrict__ b
     if (b >= n_blocks || status[b] != GD_OK) return;
     const GdBlock bl = blocks[b];
     uint8_t *o = out + bl.out_off;
-    const uint32_t o_cap = bl.out_size, nr = n_reg[b];
+    const uint32_t o_cap = bl.out_size, nr = n_reg[b] & 255u;
     uint32_t pos = 0, err = GD_OK;
     uint64_t ob_w = 0, h_lo = 0, h_hi = 0;
     uint32_t ob_fill = (uint32_t)((uintptr_t)o & 7u), ob_hole = ob_fill;
@@ -631,7 +675,7 @@ __global__ __launch_bounds__(64) void gd_lzw_kernel(const GdBlock *__restrict__ 
     if (b >= n_blocks || status[b] != GD_OK) return;
     const GdBlock bl = blocks[b];
     uint8_t *o = out + bl.out_off;
-    const uint32_t o_cap = bl.out_size, nr = n_reg[b];
+    const uint32_t o_cap = bl.out_size, nr = n_reg[b] & 255u;
     uint32_t pos = 0, err = GD_OK;
     for (uint32_t r = 0; r < nr && err == GD_OK; ++r) {
         const uint2 rg = reg[b * GW_MAX_REGIONS + r];

@@ -1248,7 +1248,16 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
             cleanup();
             return rc;
         }
-        if (getenv("VGAN_TIMING")) fprintf(stderr, "[vgan timing] vgan_gamdev_inflate_bytes: %zu members, %llu of them through the older kernel\n", gb.size(), (unsigned long long)redone);
+        if (getenv("VGAN_TIMING")) {
+            double rounds = 0;
+            if (d_nreg) {
+                std::vector<uint32_t> nr(gb.size());
+                GDCHK(hipMemcpy(nr.data(), d_nreg, gb.size() * 4, hipMemcpyDeviceToHost));
+                for (uint32_t v : nr) rounds += v >> 8;
+            }
+            fprintf(stderr, "[vgan timing] vgan_gamdev_inflate_bytes: %zu members, %llu of them through the older kernel; %.2f rounds per member for the chunks' starts to settle\n",
+                    gb.size(), (unsigned long long)redone, gb.empty() ? 0.0 : rounds / gb.size());
+        }
         GDCHK(hipMemcpy(out, d_out, total, hipMemcpyDeviceToHost));
     }
 #undef GDCHK
