@@ -628,6 +628,7 @@ int vgan_euka_reset(vgan_euka_ctx *c);
 int vgan_euka_accumulate(vgan_euka_ctx *c, const vgan_euka_batch *b, const vgan_euka_read_out *out);
 /* per-clade results of everything accumulated: Clade::count [n_clades], baseshift_clade_array
  * [n_clades][2*length_to_prof][16], bin coverage get<3>(chunks[c][j]) [n_bins]; host arrays; synchronises */
+int vgan_euka_synchronize(vgan_euka_ctx *c); /* (ABI 6) waits for the context's stream: a device batch's kernel is asynchronous */
 int vgan_euka_finalize(vgan_euka_ctx *c, int32_t *clade_count, uint32_t *baseshift, double *bin_cov, int64_t *n_bad);
 int vgan_euka_kernel_ms(vgan_euka_ctx *c, double *ms, uint64_t *launches); /* HIP-event time of the read kernel */
 void vgan_euka_destroy(vgan_euka_ctx *c);
@@ -653,6 +654,42 @@ int vgan_euka_reduce(vgan_euka_ctx **ctxs, int n, int32_t *clade_count, uint32_t
  * acceptance draws, so its output is not reproducible.  seed = 0 does the same; any other seed replaces the successive
  * random_device calls by the high 32 bits of a splitmix64 stream started at seed (run() first, then one per proposal).
  * ------------------------------------------------------------------------------------------------ */
+/* (ABI 6) euka's front half on the device (csrc/euka_flatten_kernels.hip; reference: src/readGAM_Euka.h:67-216 through
+ * csrc/host/euka_host.cpp): the arrays a vgan_gamdev parse left in HBM -> a vgan_euka_batch in HBM (on_device = 1, valid until the next run
+ * on the object; read_src is a DEVICE array here: vgan_euka_devflat_host_arrays has its host copy and read_seq_len's), for the reads whose
+ * edits are all matches or substitutions on known nodes and whose lengths euka's tables hold -- array for array vgan_euka_flatten's batch
+ * of those reads.  Every other read is left to the host: host_mask[r] = 1 (caller array, one byte per read of the parse).  base: index of
+ * the parse's first read in the whole input (read_src = base + index).  Runs on the context's stream; synchronises it. */
+typedef struct vgan_euka_devflat vgan_euka_devflat;
+struct vgan_gamdev;
+int vgan_euka_devflat_create(vgan_euka_ctx *c, const vgan_graph *graph, vgan_euka_devflat **out);
+int vgan_euka_devflat_run_gamdev(vgan_euka_devflat *f, const struct vgan_gamdev *gd, uint32_t base, vgan_euka_batch *out, uint8_t *host_mask,
+                                 vgan_euka_flatten_stats *stats);
+int vgan_euka_devflat_host_arrays(const vgan_euka_devflat *f, const uint32_t **read_src, const uint16_t **read_seq_len);
+void vgan_euka_devflat_free(vgan_euka_devflat *f);
+/* (test aid) a device batch's arrays copied into the caller's arrays (the pointers of *host; any may be NULL) */
+int vgan_euka_batch_download(const vgan_euka_batch *dev, const vgan_euka_batch *host);
+/* (ABI 6) vgan euka over a BGZF GAM's bytes through the device front end's pipeline (vgan_gampipe_*: the file in pieces, piece i to lane
+ * i mod n; reference: readGAM_Euka.h:581 feeding the lambda of :67-577): start / attach / finish as vgan_hc_gam_*.  The contexts hold the
+ * per-clade tables afterwards (vgan_euka_reduce); the per-read lists the abundance chain and the report read come back here, in the order
+ * of the file: read_index = the read's index among the file's mapped reads (identity != 0, readGAM_Euka.h:72), for the reads that were
+ * processed (n_reads of them; n_bad more were skipped: the reference would index out of bounds on them).  The arrays belong to the run
+ * until vgan_euka_gam_free. */
+typedef struct vgan_euka_gamrun vgan_euka_gamrun;
+typedef struct vgan_euka_gam_result {
+    int64_t n_messages; /* alignments in the file */
+    int64_t n_mapped;   /* identity != 0 */
+    int64_t n_bad, n_reads;
+    const uint32_t *read_index;
+    const int32_t *read_clade;
+    const uint8_t *read_pass;
+    const uint16_t *read_seq_len;
+} vgan_euka_gam_result;
+int vgan_euka_gam_start(const int *devices, int n_lanes, const void *bytes, uint64_t n, const vgan_gampipe_opts *opts, vgan_euka_gamrun **out);
+int vgan_euka_gam_attach(vgan_euka_gamrun *r, vgan_euka_ctx *const *ctxs, int n_ctx, const vgan_graph *graph);
+int vgan_euka_gam_finish(vgan_euka_gamrun *r, vgan_euka_gam_result *res, vgan_gampipe_stats *pstats);
+void vgan_euka_gam_free(vgan_euka_gamrun *r);
+
 typedef struct vgan_euka_detect_params {
     uint32_t min_bins;        /* MINNUMOFBINS  --minBins (6), Euka.cpp:183 */
     uint32_t min_reads;       /* MINNUMOFREADS --minFrag (10) */

@@ -96,6 +96,11 @@ class EukaFlattenStats(C.Structure):
     _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64), ("n_unmapped", C.c_int64), ("n_bad", C.c_int64)]
 
 
+class EukaGamResult(C.Structure):
+    _fields_ = [("n_messages", C.c_int64), ("n_mapped", C.c_int64), ("n_bad", C.c_int64), ("n_reads", C.c_int64), ("read_index", vp),
+                ("read_clade", vp), ("read_pass", vp), ("read_seq_len", vp)]
+
+
 class EukaParams(C.Structure):
     _fields_ = [("min_mapq", C.c_uint32), ("length_to_prof", C.c_int32)]
 
@@ -306,6 +311,15 @@ SYMBOLS = {
     "vgan_euka_abundance_mcmc": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_uint64, vp]),
     "vgan_euka_report": (C.c_int, [C.POINTER(EukaResults), C.POINTER(EukaReportCfg), C.c_char_p, vp, vp, vp]),
     "vgan_euka_destroy": (None, [vp]),
+    "vgan_euka_synchronize": (C.c_int, [vp]),
+    "vgan_euka_devflat_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "vgan_euka_devflat_run_gamdev": (C.c_int, [vp, vp, C.c_uint32, C.POINTER(EukaBatch), vp, C.POINTER(EukaFlattenStats)]),
+    "vgan_euka_devflat_free": (None, [vp]),
+    "vgan_euka_batch_download": (C.c_int, [C.POINTER(EukaBatch), C.POINTER(EukaBatch)]),
+    "vgan_euka_gam_start": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.POINTER(GamPipeOpts), C.POINTER(vp)]),
+    "vgan_euka_gam_attach": (C.c_int, [vp, C.POINTER(vp), C.c_int, vp]),
+    "vgan_euka_gam_finish": (C.c_int, [vp, C.POINTER(EukaGamResult), C.POINTER(GamPipeStats)]),
+    "vgan_euka_gam_free": (None, [vp]),
     "vgan_sb_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(SbFlattenStats)]),
     "vgan_sb_host_batch_get": (C.c_int, [vp, C.POINTER(SbBatch)]),
     "vgan_sb_host_batch_free": (None, [vp]),

@@ -80,6 +80,8 @@ struct vgan_euka_ctx {
     bool ev_pending = false;
 };
 
+vgan::EukaCtxInfo vgan::euka_ctx_info(const vgan_euka_ctx *c) { return EukaCtxInfo{c->device, c->stream}; }
+
 extern "C" int vgan_euka_create(const vgan_euka_db_view *db, const vgan_damage_view *dmg, const vgan_euka_params *prm,
                                 int device, vgan_euka_ctx **out) {
     if (!db || !dmg || !prm || !out) return fail(VGAN_EINVAL, "vgan_euka_create: null argument");
@@ -365,6 +367,13 @@ extern "C" int vgan_euka_accumulate(vgan_euka_ctx *c, const vgan_euka_batch *b, 
         HIPCHK(hipMemcpyAsync(out->pass, o.pass, R, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
+    return VGAN_OK;
+}
+
+extern "C" int vgan_euka_synchronize(vgan_euka_ctx *c) {
+    if (!c) return fail(VGAN_EINVAL, "vgan_euka_synchronize: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return VGAN_OK;
 }
 

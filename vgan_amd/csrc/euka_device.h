@@ -69,4 +69,15 @@ void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev
 void launch_euka_reduce(const EukaOutDev &o, uint32_t n_clades, int32_t ltp, hipStream_t st);
 void launch_euka_clear(void *p, size_t bytes, hipStream_t st); // zero fill, bytes a multiple of 16
 
+struct EukaCtxInfo { // what another translation unit needs of a context (euka_flatten_kernels.hip)
+    int device;
+    hipStream_t stream;
+};
+
 } // namespace vgan
+struct vgan_euka_ctx;
+struct vgan_euka_devflat;
+namespace vgan {
+EukaCtxInfo euka_ctx_info(const vgan_euka_ctx *c);
+size_t euka_devflat_device_bytes(const vgan_euka_devflat *f);
+}

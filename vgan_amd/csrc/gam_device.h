@@ -26,6 +26,7 @@ struct GamdevSlice {
     const int32_t *m_offset, *mapq, *e_len;
     const uint8_t *unmapped, *m_rev, *e_seq, *qual;
     const int64_t *first_node, *first_offset;
+    const uint32_t *seq_len; // |Alignment.sequence| per read
     uint64_t n_reads;
     int device;
 };

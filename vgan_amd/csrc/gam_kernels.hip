@@ -1699,7 +1699,7 @@ extern "C" int vgan_gamdev_download(const vgan_gamdev *g, int which, void *dst) 
 bool vgan::gamdev_slice(const vgan_gamdev *g, GamdevSlice *o) {
     if (!g || !o) return false;
     *o = GamdevSlice{g->map_off.p, g->qual_off.p, g->edit_off.p, g->e_seq_off.p, g->m_node.p, g->m_offset.p, g->mapq.p, g->e_len.p, g->unmapped.p, g->m_rev.p,
-                     g->e_seq.p, g->qual.p, g->first_node.p, g->first_offset.p, g->R, g->device};
+                     g->e_seq.p, g->qual.p, g->first_node.p, g->first_offset.p, g->seq_len.p, g->R, g->device};
     return true;
 }
 

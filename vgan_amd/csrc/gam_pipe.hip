@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "euka_device.h"
 #include "gam_device.h"
 #include "gam_object.h"
 #include "hc_device.h"
@@ -670,4 +671,285 @@ extern "C" int vgan_hc_accumulate_gam_bytes(vgan_hc_ctx *const *ctxs, int n_ctx,
         return rc;
     }
     return vgan_hc_gam_finish(r, stats, pstats);
+}
+
+// ------------------------------------------------------------------------------------------------------------ euka
+// vgan euka's consumer (reference: src/readGAM_Euka.h:581 -- readGAM3's loop over the stream -- feeding the lambda of :67-577): device
+// flatten of the piece into a vgan_euka_batch in HBM + the read kernel on the lane's context; the per-read results (clade, pass, |sequence|:
+// what the abundance chain and the report read, MCMC.cpp:1192-1193) come down with the index of their read in the file.  The reads the
+// device flatten leaves go through the host's parser, vgan_euka_flatten and the same context, behind the slot's back.
+namespace {
+struct DevArr { // a device array that grows
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap && p) return VGAN_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+            return fail(VGAN_ENOMEM, "vgan_euka_gam: hipMalloc of %zu bytes failed", want);
+        }
+        cap = want;
+        return VGAN_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+struct EukaLeftJob {
+    std::thread t;
+    int rc = VGAN_OK;
+    std::string err;
+};
+} // namespace
+
+struct vgan_euka_gamrun : GamConsumer {
+    std::vector<int> devices;
+    const void *bytes = nullptr;
+    uint64_t n = 0;
+    vgan_gampipe_opts opts{};
+    std::thread coord;
+    int rc = VGAN_OK;
+    std::string err;
+    vgan_gampipe_stats pst{};
+    std::mutex mu;
+    std::condition_variable cv;
+    bool attached = false, gave_up = false;
+    std::vector<vgan_euka_ctx *> ctx;
+    const vgan_graph *graph = nullptr;
+    std::vector<vgan_euka_devflat *> df;
+    std::vector<DevArr> o_clade, o_d, o_pass;
+    std::deque<std::mutex> lane_mu;
+    std::vector<std::shared_ptr<EukaLeftJob>> bg;
+    // per processed read, in the order the pieces came (sorted by `idx` at the end)
+    std::vector<uint32_t> idx;
+    std::vector<int32_t> clade;
+    std::vector<uint8_t> pass;
+    std::vector<uint16_t> len;
+    int64_t n_bad = 0;
+    uint64_t n_host_reads = 0, n_device_reads = 0;
+    size_t df_bytes = 0;
+    double ms_wait_contexts = 0;
+    int host_threads = 2;
+
+    void aborted() override {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            gave_up = true;
+        }
+        cv.notify_all();
+    }
+    int consume(int lane, vgan_gamdev *g, uint64_t read_base, const uint8_t *, int64_t) override {
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return attached || gave_up; });
+            if (!attached) return fail(VGAN_ESTATE, "vgan_euka_gam: no contexts were attached");
+            ms_wait_contexts = std::max(ms_wait_contexts, ms_since(t0));
+        }
+        vgan_euka_ctx *cx = ctx[(size_t)lane];
+        uint64_t sz[8];
+        (void)vgan_gamdev_sizes(g, sz, nullptr);
+        const uint64_t R = sz[2];
+        if (read_base + R > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "vgan_euka_gam: more than 2^32 reads");
+        std::vector<uint8_t> mask((size_t)R, 0);
+        std::vector<int32_t> h_clade;
+        std::vector<uint8_t> h_pass;
+        int r;
+        {
+            std::lock_guard<std::mutex> lk(lane_mu[(size_t)lane]); // (the lane's context, its stream and its flatten object: one piece at a time)
+            const size_t l = (size_t)lane;
+            if (!df[l] && (r = vgan_euka_devflat_create(cx, graph, &df[l])) < 0) return r;
+            vgan_euka_batch b;
+            vgan_euka_flatten_stats st{};
+            if ((r = vgan_euka_devflat_run_gamdev(df[l], g, (uint32_t)read_base, &b, mask.data(), &st)) < 0) return r;
+            if (b.n_reads) {
+                const size_t nr = b.n_reads;
+                if ((r = o_clade[l].reserve(nr * 4)) || (r = o_d[l].reserve(nr * 32)) || (r = o_pass[l].reserve(nr))) return r;
+                double *d = (double *)o_d[l].p;
+                vgan_euka_read_out out{(int32_t *)o_clade[l].p, d, d + nr, d + 2 * nr, d + 3 * nr, (uint8_t *)o_pass[l].p};
+                if ((r = vgan_euka_accumulate(cx, &b, &out)) < 0) return r;
+                if ((r = vgan_euka_synchronize(cx)) < 0) return r;
+                h_clade.resize(nr);
+                h_pass.resize(nr);
+                if (hipMemcpy(h_clade.data(), o_clade[l].p, nr * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(h_pass.data(), o_pass[l].p, nr, hipMemcpyDeviceToHost) != hipSuccess)
+                    return fail(VGAN_ENODEV, "vgan_euka_gam: the per-read results did not come down");
+                const uint32_t *src = nullptr;
+                const uint16_t *sl = nullptr;
+                (void)vgan_euka_devflat_host_arrays(df[l], &src, &sl);
+                std::lock_guard<std::mutex> lk2(mu);
+                idx.insert(idx.end(), src, src + nr);
+                len.insert(len.end(), sl, sl + nr);
+                clade.insert(clade.end(), h_clade.begin(), h_clade.end());
+                pass.insert(pass.end(), h_pass.begin(), h_pass.end());
+                n_device_reads += nr;
+            }
+        }
+        // ---- the reads left to the host: their messages down now (the object's buffers are the next piece's after this call), the rest behind
+        std::vector<uint32_t> where;
+        for (uint64_t i = 0; i < R; ++i)
+            if (mask[(size_t)i]) where.push_back((uint32_t)(read_base + i));
+        if (where.empty()) return VGAN_OK;
+        uint64_t nm = 0, nb = 0;
+        if ((r = vgan_gamdev_pick(g, mask.data(), &nm, &nb)) < 0) return r;
+        if (nm != where.size()) return fail(VGAN_ESTATE, "vgan_euka_gam: %llu messages picked for %zu reads", (unsigned long long)nm, where.size());
+        auto offs = std::make_shared<std::vector<uint64_t>>((size_t)nm + 1);
+        auto msgs = std::make_shared<std::vector<uint8_t>>((size_t)std::max<uint64_t>(nb, 1));
+        if ((r = vgan_gamdev_picked(g, offs->data(), msgs->data())) < 0) return r;
+        auto job = std::make_shared<EukaLeftJob>();
+        vgan_euka_gamrun *self = this;
+        auto whr = std::make_shared<std::vector<uint32_t>>(std::move(where));
+        job->t = std::thread([self, job, offs, msgs, whr, cx, lane] {
+            vgan_alnparts *parts = nullptr;
+            vgan_alnset merged;
+            vgan_euka_host_batch *hb = nullptr;
+            vgan_euka_flatten_stats st{};
+            // (keep_unmapped: the parse on the device dropped identity == 0 already; every message handed back is a read)
+            if ((job->rc = vgan_alnparts_from_messages(msgs->data(), offs->data(), (int64_t)whr->size(), 1, self->host_threads, &parts)) >= 0) {
+                merge_alnsets(parts->parts, merged);
+                vgan_alnparts_free(parts);
+                if (merged.n_reads() != (int64_t)whr->size()) job->rc = fail(VGAN_ESTATE, "vgan_euka_gam: %lld reads parsed of %zu messages", (long long)merged.n_reads(), whr->size());
+            }
+            if (job->rc >= 0) job->rc = vgan_euka_flatten(self->graph, &merged, 0, merged.n_reads(), self->host_threads, &hb, &st);
+            std::vector<int32_t> c;
+            std::vector<uint8_t> p;
+            vgan_euka_batch b{};
+            if (job->rc >= 0 && (job->rc = vgan_euka_host_batch_get(hb, &b)) >= 0 && b.n_reads) {
+                const size_t nr = b.n_reads;
+                c.resize(nr);
+                p.resize(nr);
+                std::vector<double> d(4 * nr);
+                vgan_euka_read_out out{c.data(), d.data(), d.data() + nr, d.data() + 2 * nr, d.data() + 3 * nr, p.data()};
+                std::lock_guard<std::mutex> lk(self->lane_mu[(size_t)lane]);
+                job->rc = vgan_euka_accumulate(cx, &b, &out);
+            }
+            if (job->rc < 0) {
+                job->err = last_error();
+            } else {
+                std::lock_guard<std::mutex> lk(self->mu);
+                for (size_t i = 0; i < b.n_reads; ++i) {
+                    self->idx.push_back((*whr)[b.read_src[i]]);
+                    self->len.push_back(b.read_seq_len[i]);
+                    self->clade.push_back(c[i]);
+                    self->pass.push_back(p[i]);
+                }
+                self->n_bad += st.n_bad;
+                self->n_host_reads += whr->size();
+            }
+            vgan_euka_host_batch_free(hb);
+        });
+        std::lock_guard<std::mutex> lk(mu);
+        bg.push_back(job);
+        return VGAN_OK;
+    }
+};
+
+extern "C" int vgan_euka_gam_start(const int *devices, int n_lanes, const void *bytes, uint64_t n, const vgan_gampipe_opts *opts, vgan_euka_gamrun **out) {
+    if (!devices || n_lanes <= 0 || (!bytes && n) || !out) return fail(VGAN_EINVAL, "vgan_euka_gam_start: null argument");
+    auto *r = new vgan_euka_gamrun();
+    r->devices.assign(devices, devices + n_lanes);
+    r->bytes = bytes;
+    r->n = n;
+    r->opts = with_defaults(opts);
+    r->opts.keep_unmapped = 0;   // readGAM_Euka.h:72: identity == 0 is no fragment of any clade (the messages are counted all the same)
+    r->opts.mark_duplicates = 0; // (euka removes no duplicates)
+    r->df.assign((size_t)n_lanes, nullptr);
+    r->o_clade.resize((size_t)n_lanes), r->o_d.resize((size_t)n_lanes), r->o_pass.resize((size_t)n_lanes);
+    r->lane_mu.resize((size_t)n_lanes);
+    const int cpus = r->opts.n_threads > 0 ? r->opts.n_threads : (int)usable_cpus();
+    r->host_threads = std::max(1, std::min(8, cpus / std::max(1, n_lanes * r->opts.slots)));
+    r->coord = std::thread([r] {
+        r->rc = gampipe_run(r->bytes, r->n, r->devices, r->opts, *r, &r->pst);
+        if (r->rc < 0) r->err = last_error();
+    });
+    *out = r;
+    return VGAN_OK;
+}
+
+extern "C" int vgan_euka_gam_attach(vgan_euka_gamrun *r, vgan_euka_ctx *const *ctxs, int n_ctx, const vgan_graph *graph) {
+    if (!r || !ctxs || !graph) return fail(VGAN_EINVAL, "vgan_euka_gam_attach: null argument");
+    if (n_ctx != (int)r->devices.size()) return fail(VGAN_EINVAL, "vgan_euka_gam_attach: %d contexts for %zu lanes", n_ctx, r->devices.size());
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        if (r->attached) return fail(VGAN_ESTATE, "vgan_euka_gam_attach: called twice");
+        r->ctx.assign(ctxs, ctxs + n_ctx);
+        r->graph = graph;
+        r->attached = true;
+    }
+    r->cv.notify_all();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_euka_gam_finish(vgan_euka_gamrun *r, vgan_euka_gam_result *res, vgan_gampipe_stats *pstats) {
+    if (!r) return fail(VGAN_EINVAL, "vgan_euka_gam_finish: null argument");
+    if (res) memset(res, 0, sizeof *res);
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        if (!r->attached) r->gave_up = true;
+    }
+    r->cv.notify_all();
+    if (r->coord.joinable()) r->coord.join();
+    for (auto &j : r->bg) {
+        if (j->t.joinable()) j->t.join();
+        if (j->rc < 0 && r->rc >= 0) {
+            r->rc = j->rc;
+            r->err = "the reads left to the host: " + j->err;
+        }
+    }
+    r->bg.clear();
+    for (size_t l = 0; l < r->df.size(); ++l) {
+        if (l < r->ctx.size() && r->ctx[l]) (void)vgan_euka_synchronize(r->ctx[l]);
+        r->df_bytes += euka_devflat_device_bytes(r->df[l]) + r->o_clade[l].cap + r->o_d[l].cap + r->o_pass[l].cap;
+        vgan_euka_devflat_free(r->df[l]);
+        r->df[l] = nullptr;
+        if (l < r->devices.size()) (void)hipSetDevice(r->devices[l]);
+        r->o_clade[l].release(), r->o_d[l].release(), r->o_pass[l].release();
+    }
+    r->pst.device_bytes += r->df_bytes;
+    r->pst.n_host_reads = r->n_host_reads;
+    r->pst.n_device_reads = r->n_device_reads;
+    r->pst.ms_wait_contexts = r->ms_wait_contexts;
+    if (pstats) *pstats = r->pst;
+    if (r->rc < 0) return fail(r->rc, "%s", r->err.c_str());
+    { // the per-read lists in the order of the file
+        const size_t nr = r->idx.size();
+        std::vector<uint32_t> ord(nr);
+        for (size_t i = 0; i < nr; ++i) ord[i] = (uint32_t)i;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return r->idx[a] < r->idx[b]; });
+        std::vector<uint32_t> i2(nr);
+        std::vector<int32_t> c2(nr);
+        std::vector<uint8_t> p2(nr);
+        std::vector<uint16_t> l2(nr);
+        for (size_t i = 0; i < nr; ++i) {
+            i2[i] = r->idx[ord[i]];
+            c2[i] = r->clade[ord[i]];
+            p2[i] = r->pass[ord[i]];
+            l2[i] = r->len[ord[i]];
+        }
+        r->idx.swap(i2), r->clade.swap(c2), r->pass.swap(p2), r->len.swap(l2);
+    }
+    if (res) {
+        res->n_messages = (int64_t)r->pst.n_messages;
+        res->n_mapped = (int64_t)r->pst.n_reads;
+        res->n_bad = r->n_bad;
+        res->n_reads = (int64_t)r->idx.size();
+        res->read_index = r->idx.data();
+        res->read_clade = r->clade.data();
+        res->read_pass = r->pass.data();
+        res->read_seq_len = r->len.data();
+    }
+    return VGAN_OK;
+}
+
+extern "C" void vgan_euka_gam_free(vgan_euka_gamrun *r) {
+    if (!r) return;
+    if (r->coord.joinable()) (void)vgan_euka_gam_finish(r, nullptr, nullptr);
+    delete r;
 }

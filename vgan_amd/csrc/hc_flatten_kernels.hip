@@ -447,6 +447,7 @@ struct vgan_hc_devflat {
     DBuf<uint32_t> crec;
     DBuf<uint8_t> qualp;
     DBuf<DfCounters> ctr;
+    DBuf<uint64_t> tot64;
     DBuf<uint8_t> cub_tmp;
     std::vector<uint32_t> h_src;
     // the parser's arrays reach the device through pinned staging: the pieces are copied into it on several host threads (a
@@ -472,6 +473,7 @@ struct vgan_hc_devflat {
         srec.release();
         qualp.release();
         ctr.release();
+        tot64.release();
         cub_tmp.release();
     }
 };
@@ -722,11 +724,34 @@ static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uin
             hipcub::DeviceScan::ExclusiveSum(f->cub_tmp.p, tmp, f->cols.p, f->coff.p, (int)(n_dev + 1), st) != hipSuccess)
             return fail(VGAN_ENODEV, "vgan_hc_devflat_run: scan failed");
     }
+    // (the offsets are 32 bits wide: segments and quality bytes are subsets of the parsed bytes, whose number the parse bounds; columns are
+    // sums of edit LENGTHS -- up to DF_COLS per read whatever its bytes -- so their total is taken in 64 bits too and a chunk whose
+    // columns would wrap the offsets is refused: the caller flattens fewer reads at a time, or on the host)
+    if ((rc = f->tot64.reserve(1))) return rc;
+    {
+        struct Widen {
+            __host__ __device__ uint64_t operator()(uint32_t v) const { return v; }
+        };
+        hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> it(f->cols.p, Widen());
+        size_t tmp = 0;
+        if (hipcub::DeviceReduce::Sum(nullptr, tmp, it, f->tot64.p, (int)n_dev, st) != hipSuccess) return fail(VGAN_ENODEV, "vgan_hc_devflat_run: sum sizing failed");
+        if ((rc = f->cub_tmp.reserve(tmp))) return rc;
+        if (hipcub::DeviceReduce::Sum(f->cub_tmp.p, tmp, it, f->tot64.p, (int)n_dev, st) != hipSuccess) return fail(VGAN_ENODEV, "vgan_hc_devflat_run: sum failed");
+    }
     uint32_t tot[3] = {0, 0, 0};
+    uint64_t cols64 = 0;
     HIPCHK(hipMemcpyAsync(&tot[0], f->soff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&tot[1], f->qoff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&tot[2], f->coff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&cols64, f->tot64.p, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    {
+        static const char *lim = getenv("VGAN_HC_DEVFLAT_MAX_COLS"); // (test aid: the refusal without four billion columns)
+        const uint64_t max_cols = lim ? strtoull(lim, nullptr, 10) : 0xFFFFFFF0ull;
+        if (cols64 > max_cols)
+            return fail(VGAN_ERANGE, "vgan_hc_devflat_run: %llu alignment columns in one chunk are beyond the packed batch's 32-bit offsets; flatten fewer reads at a time",
+                        (unsigned long long)cols64);
+    }
     pt.lap("offsets");
     if ((rc = f->rhdr.reserve((size_t)n_dev + 1)) || (rc = f->srec.reserve(tot[0] + 1)) || (rc = f->crec.reserve(tot[2] + 1)) ||
         (rc = f->qualp.reserve((size_t)tot[1] + 32)) || (rc = f->read_src.reserve(n_dev)))

@@ -10,6 +10,11 @@
 //   * FASTQ input needs vg giraffe in-process (src/map_giraffe.cpp): map with vg and pass the GAM with -g;
 //   * readGAM3's per-alignment lambda runs on the GPU (vgan_euka_*), the abundance MCMC in closed form on the host
 //     (vgan_euka_report); --seed N makes the chain reproducible (default 0 = std::random_device, as the reference).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -160,8 +165,69 @@ int euka_main(int argc, char **argv) {
     if (run_mcmc && iter - burnin - 1 <= 0) die("[euka] Error, --iter must exceed --burnin + 1");
 
     PhaseTimer pt("euka");
+    // which GPUs: --gpus LIST, the environment's VGAN_GPUS (`all` or a list), or the one of --device
+    if (gpu_list.empty()) {
+        const char *e = getenv("VGAN_GPUS");
+        if (e && std::string(e) == "all") {
+            const int n_visible = vgan_device_count();
+            for (int d = 0; d < n_visible; ++d) gpu_list.push_back(d);
+        } else if (e && *e) {
+            const std::string v = e;
+            size_t p0 = 0;
+            while (p0 <= v.size()) {
+                size_t c1 = v.find(',', p0);
+                if (c1 == std::string::npos) c1 = v.size();
+                const int d = parse_int(v.substr(p0, c1 - p0), "VGAN_GPUS", T);
+                if (d < 0) die("[euka] Error, VGAN_GPUS needs non-negative GPU indices");
+                gpu_list.push_back(d);
+                p0 = c1 + 1;
+            }
+        }
+        if (gpu_list.empty()) gpu_list.push_back(device);
+    }
+    // A long BGZF input: the front end runs ON THE DEVICE (vgan_euka_gam_*: the file in pieces through inflate, framing, protobuf walk
+    // and euka's flatten as kernels, piece i to context i mod n; csrc/gam_pipe.hip, euka_flatten_kernels.hip); the host parses only the
+    // reads the device flatten leaves (indels, soft clips).  VGAN_EUKA_DEVICE_GAM=0 / 1: never / whenever the input is a regular file.
+    // --outFrag needs the reads' names, which the device does not keep: the host pipeline's.  Anything the device refuses goes through
+    // the host pipeline as well.
+    struct FileMap {
+        const uint8_t *p = nullptr;
+        size_t n = 0;
+        ~FileMap() {
+            if (p) munmap(const_cast<uint8_t *>(p), n);
+        }
+    } gam_map;
+    struct GdRun {
+        vgan_euka_gamrun *r = nullptr;
+        ~GdRun() { vgan_euka_gam_free(r); }
+    };
+    bool device_gam = false;
+    {
+        const char *e = getenv("VGAN_EUKA_DEVICE_GAM");
+        struct stat sb;
+        if (!(e && e[0] == '0') && !out_frag && stat(gam.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && ((e && e[0] == '1') || (uint64_t)sb.st_size >= (128ull << 20)) &&
+            sb.st_size > 28) {
+            const int fd = open(gam.c_str(), O_RDONLY);
+            if (fd >= 0) {
+                void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                close(fd);
+                if (m != MAP_FAILED) {
+                    gam_map.p = (const uint8_t *)m;
+                    gam_map.n = (size_t)sb.st_size;
+                    device_gam = gam_map.p[0] == 0x1f && gam_map.p[1] == 0x8b && gam_map.p[2] == 8 && (gam_map.p[3] & 4); // (BGZF members carry an extra field)
+                    if (device_gam) (void)madvise(m, gam_map.n, MADV_WILLNEED);
+                }
+            }
+        }
+    }
     GamReader reader; // unmapped reads are kept so that they are counted
-    reader.start(gam, 1);
+    GdRun gd; // (started now: upload, inflate, framing and parse need neither tables nor contexts and run beside their set-up)
+    if (device_gam) {
+        vgan_gampipe_opts po{};
+        po.n_threads = n_threads;
+        if (vgan_euka_gam_start(gpu_list.data(), (int)gpu_list.size(), gam_map.p, gam_map.n, &po, &gd.r) < 0) device_gam = false;
+    }
+    if (!device_gam) reader.start(gam, 1);
     Handle<vgan_damage> dmg(vgan_damage_free);
     check(vgan_damage_load(deam5.empty() ? nullptr : deam5.c_str(), deam3.empty() ? nullptr : deam3.c_str(), &dmg.p), "damage profiles");
     std::cerr << "Reading in taxa information ..." << std::endl;
@@ -197,31 +263,19 @@ int euka_main(int argc, char **argv) {
     vgan_euka_params prm;
     prm.min_mapq = (uint32_t)min_mq;
     prm.length_to_prof = ltp;
-    const int n_visible = vgan_device_count();
-    if (gpu_list.empty()) {
-        const char *e = getenv("VGAN_GPUS"); // `all` or a comma separated list, as --gpus
-        if (e && std::string(e) == "all") {
-            for (int d = 0; d < n_visible; ++d) gpu_list.push_back(d);
-        } else if (e && *e) {
-            const std::string v = e;
-            size_t p0 = 0;
-            while (p0 <= v.size()) {
-                size_t c1 = v.find(',', p0);
-                if (c1 == std::string::npos) c1 = v.size();
-                const int d = parse_int(v.substr(p0, c1 - p0), "VGAN_GPUS", T);
-                if (d < 0) die("[euka] Error, VGAN_GPUS needs non-negative GPU indices");
-                gpu_list.push_back(d);
-                p0 = c1 + 1;
-            }
-        }
-        if (gpu_list.empty()) gpu_list.push_back(device);
-    }
     struct Contexts {
         std::vector<vgan_euka_ctx *> v;
         ~Contexts() {
             for (auto c : v) vgan_euka_destroy(c);
         }
     } ctxs;
+    struct GdStop { // (an error's unwinding: the front end's threads use the contexts -- they are joined before the contexts go)
+        vgan_euka_gamrun *&r;
+        ~GdStop() {
+            vgan_euka_gam_free(r);
+            r = nullptr;
+        }
+    } gd_stop{gd.r};
     for (int d : gpu_list) {
         vgan_euka_ctx *c = nullptr;
         check(vgan_euka_create(&dv, &dmv, &prm, d, &c), "creating the device context");
@@ -230,23 +284,49 @@ int euka_main(int argc, char **argv) {
     pt.lap("device context");
 
     std::cerr << "Estimating clades: Please be patient! Depending on the size of your input file, this process can take some time." << std::endl;
-    Handle<vgan_alnset> aln(vgan_aln_free);
-    aln.p = reader.take();
-    vgan_alnset_view av;
-    check(vgan_aln_view_get(aln.p, &av), "alignment view");
-    pt.lap("GAM decode");
-
     // per processed read, in input order
     std::vector<int32_t> read_clade;
     std::vector<uint8_t> read_pass;
     std::vector<uint16_t> read_len;
     std::vector<int64_t> name_off{0};
     std::string names;
-    int64_t n_mapped = 0, n_bad = 0;
+    int64_t n_mapped = 0, n_bad = 0, n_in_file = 0;
+    const size_t K = ctxs.v.size();
+    if (device_gam) {
+        vgan_euka_gam_result gr{};
+        vgan_gampipe_stats ps{};
+        int rc = vgan_euka_gam_attach(gd.r, ctxs.v.data(), (int)K, graph.p);
+        if (rc >= 0) rc = vgan_euka_gam_finish(gd.r, &gr, &ps);
+        if (rc < 0) { // nothing else has been accumulated: the contexts are cleared and the host pipeline takes the file from its start
+            std::cerr << "[euka] the device front end does not take this input (" << vgan_last_error() << "): the host pipeline does" << std::endl;
+            for (auto c : ctxs.v) check(vgan_euka_reset(c), "reset");
+            device_gam = false;
+            reader.start(gam, 1);
+        } else {
+            read_clade.assign(gr.read_clade, gr.read_clade + gr.n_reads);
+            read_pass.assign(gr.read_pass, gr.read_pass + gr.n_reads);
+            read_len.assign(gr.read_seq_len, gr.read_seq_len + gr.n_reads);
+            n_mapped = gr.n_mapped;
+            n_bad = gr.n_bad;
+            n_in_file = gr.n_messages;
+            if (getenv("VGAN_TIMING"))
+                fprintf(stderr, "[vgan timing] euka device front end: %.1f MB -> %.1f MB in %llu pieces on %zu lane(s), %llu messages, %llu mapped reads (%llu left to the host); %.0f ms "
+                                "from start to finish; summed over pieces: upload %.0f, inflate %.0f, framing %.0f, protobuf walk %.0f, flatten + kernel %.0f ms; %.2f GB of device memory\n",
+                        ps.compressed_bytes / 1e6, ps.inflated_bytes / 1e6, (unsigned long long)ps.n_pieces, K, (unsigned long long)ps.n_messages, (unsigned long long)ps.n_reads,
+                        (unsigned long long)ps.n_host_reads, ps.ms_wall, ps.ms_upload, ps.ms_inflate, ps.ms_frame, ps.ms_parse, ps.ms_consume, ps.device_bytes / 1e9);
+        }
+    }
+    if (!device_gam) {
+    Handle<vgan_alnset> aln(vgan_aln_free);
+    aln.p = reader.take();
+    vgan_alnset_view av;
+    check(vgan_aln_view_get(aln.p, &av), "alignment view");
+    n_in_file = av.n_reads;
+    pt.lap("GAM decode");
+
     // Batches of fragments in input order; with several contexts every context has a host thread of its own taking the
     // next batch (vgan_euka_accumulate returns the per-read results, so it is synchronous), and the per-read results go
     // back in batch order: readGAM3 hands them to the abundance chain per read (MCMC.cpp:1192-1193).
-    const size_t K = ctxs.v.size();
     const int64_t BATCH = K > 1 ? std::max<int64_t>(100000, 1000000 / (int64_t)K) : 1000000;
     const int64_t n_batches = (av.n_reads + BATCH - 1) / BATCH;
     struct BatchOut {
@@ -330,6 +410,7 @@ int euka_main(int argc, char **argv) {
                 name_off.push_back((int64_t)names.size());
             }
     }
+    } // (the host pipeline)
     std::vector<int32_t> clade_count(dv.n_clades);
     std::vector<uint32_t> baseshift((size_t)dv.n_clades * 2 * std::max(ltp, 1) * 16);
     std::vector<double> bin_cov(dv.bin_off[dv.n_clades]), sum_log_like(dv.n_clades);
@@ -342,7 +423,7 @@ int euka_main(int argc, char **argv) {
     std::cerr << " .. done!" << std::endl;
     int64_t passed = 0;
     for (int32_t c : clade_count) passed += c;
-    std::cerr << "Number of fragments in input file: " << av.n_reads << std::endl; // readGAM_Euka.h:635-637
+    std::cerr << "Number of fragments in input file: " << n_in_file << std::endl; // readGAM_Euka.h:635-637
     std::cerr << "Number of mapped fragments: " << n_mapped << std::endl;
     std::cerr << "Number of fragments after filtering: " << passed << std::endl;
     if (n_bad + n_bad_dev)

@@ -216,6 +216,77 @@ class EukaContext:
         self.close()
 
 
+class EukaDeviceFlatten:
+    """euka's front half on the device (vgan_euka_devflat): a GamDevice parse -> a vgan_euka_batch in HBM + the mask of the reads left to
+    the host."""
+
+    def __init__(self, ctx, graph):
+        self._h = N.vp()
+        self.ctx = ctx
+        N.check(N.lib().vgan_euka_devflat_create(ctx._h, graph._h, C.byref(self._h)))
+
+    def run_gamdev(self, gd, base=0):
+        n = gd.sizes["reads"]
+        self.mask = np.zeros(max(n, 1), np.uint8)
+        self.c = N.EukaBatch()
+        self.stats = N.EukaFlattenStats()
+        N.check(N.lib().vgan_euka_devflat_run_gamdev(self._h, gd._h, base, C.byref(self.c), self.mask.ctypes.data, C.byref(self.stats)))
+        self.mask = self.mask[:n]
+        return self
+
+    def download(self):
+        c = self.c
+        n = {"R1": c.n_reads + 1, "R": c.n_reads, "M": c.n_maps, "C": c.n_cols, "Q": c.n_qual}
+        out = {name: np.zeros(max(int(n[k]), 1), dt) for name, dt, k in _EB_FIELDS}
+        h = N.EukaBatch()
+        for name, _, _ in _EB_FIELDS:
+            setattr(h, name, out[name].ctypes.data)
+        N.check(N.lib().vgan_euka_batch_download(C.byref(c), C.byref(h)))
+        return {name: out[name][:int(n[k])] for name, _, k in _EB_FIELDS}
+
+    def accumulate(self):
+        """The batch through the context's read kernel: per-read clade / pass as numpy arrays (in the batch's order)."""
+        import torch
+        R = self.c.n_reads
+        dev = "cuda:%d" % self.ctx.device
+        o = {"clade": torch.zeros(R, dtype=torch.int32, device=dev), "pass": torch.zeros(R, dtype=torch.uint8, device=dev)}
+        d = torch.zeros(4 * R, dtype=torch.float64, device=dev)
+        oc = N.EukaReadOut(o["clade"].data_ptr(), d.data_ptr(), d.data_ptr() + 8 * R, d.data_ptr() + 16 * R, d.data_ptr() + 24 * R, o["pass"].data_ptr())
+        N.check(N.lib().vgan_euka_accumulate(self.ctx._h, C.byref(self.c), C.byref(oc)))
+        N.check(N.lib().vgan_euka_synchronize(self.ctx._h))
+        return {"clade": o["clade"].cpu().numpy(), "pass": o["pass"].cpu().numpy(), "in_lik": d[:R].cpu().numpy(), "out_lik": d[R:2 * R].cpu().numpy()}
+
+    def close(self):
+        if getattr(self, "_h", None) and N is not None:
+            N.lib().vgan_euka_devflat_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def gam_run(ctxs, graph, data, piece_bytes=0, slots=0, n_threads=0):
+    """vgan_euka_gam_*: a BGZF GAM's bytes through the device front end's pipeline into the contexts (piece i -> context i mod n).
+    Returns ({n_messages, n_mapped, n_bad, read_index, read_clade, read_pass, read_seq_len}, pipeline statistics)."""
+    buf = np.frombuffer(data, np.uint8)
+    o = N.GamPipeOpts(int(piece_bytes), int(slots), 0, 0, int(n_threads), 0)
+    dev = (C.c_int * len(ctxs))(*[c.device for c in ctxs])
+    arr = (N.vp * len(ctxs))(*[c._h for c in ctxs])
+    run = N.vp()
+    N.check(N.lib().vgan_euka_gam_start(dev, len(ctxs), buf.ctypes.data, len(data), C.byref(o), C.byref(run)))
+    res, ps = N.EukaGamResult(), N.GamPipeStats()
+    try:
+        N.check(N.lib().vgan_euka_gam_attach(run, arr, len(ctxs), graph._h))
+        N.check(N.lib().vgan_euka_gam_finish(run, C.byref(res), C.byref(ps)))
+        n = int(res.n_reads)
+        out = {"n_messages": int(res.n_messages), "n_mapped": int(res.n_mapped), "n_bad": int(res.n_bad),
+               "read_index": np.array(_np_view(res.read_index, n, np.uint32)), "read_clade": np.array(_np_view(res.read_clade, n, np.int32)),
+               "read_pass": np.array(_np_view(res.read_pass, n, np.uint8)), "read_seq_len": np.array(_np_view(res.read_seq_len, n, np.uint16))}
+    finally:
+        N.lib().vgan_euka_gam_free(run)
+    return out, ps.as_dict()
+
+
 def detect(db, clade_count, bin_cov, min_bins=6, min_reads=10, max_zero_bins=0, entropy=1.17):
     """Detected clade ids (readGAM_Euka.h:582-630)."""
     p = N.EukaDetectParams(min_bins, min_reads, max_zero_bins, entropy)
