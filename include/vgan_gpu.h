@@ -443,7 +443,7 @@ int vgan_hc_devflat_run_gamdev_cb(vgan_hc_devflat *f, const struct vgan_gamdev *
  * memory: slots x ~(1 + 2.1 x compression ratio) x piece_bytes + one flattened piece per lane, whatever the file's size.
  * Every array a piece's parse leaves is, bit for bit, the host parser's for the same reads (tests/test_gampipe_gpu.py). */
 typedef struct vgan_gampipe_opts {
-    uint64_t piece_bytes;     /* compressed bytes per piece at most; 0: 192 MB (VGAN_GAMPIPE_PIECE overrides) */
+    uint64_t piece_bytes;     /* compressed bytes per piece at most; 0: 1/24 of a lane's share of the file within 32..192 MB (VGAN_GAMPIPE_PIECE overrides) */
     int32_t slots;            /* pieces in flight per lane; 0: 3 (VGAN_GAMPIPE_SLOTS overrides) */
     int32_t keep_unmapped;    /* 0: identity == 0 is dropped (readGAM.h:47) */
     int32_t mark_duplicates;  /* src/rmdup.cpp's single-end rule */

@@ -102,12 +102,14 @@ def test_tiles_outside_the_tables_compute_every_column(kernel_switch):
 
 
 def test_graphs_with_many_node_classes(kernel_switch):
-    """More node classes than the tables cover (16), and more than the kernel keeps the scalars of (32: the wave kernel takes the
-    batch): a mappability track with many distinct values."""
+    """More node classes than the workgroup's table covers (16: the tiles with the others read the context's wide table), more than
+    the kernel keeps the scalars of in LDS (32), as many as it takes at all (256 values of mappability x the mutation rates: beyond 256
+    classes the wave kernel takes the batch): a mappability track with many distinct values.  With quality bytes from 48 to 89 on a
+    third of the reads as well (the wide table's other axis)."""
     kernel_switch(None)
     g0 = hc.synth_graph(seed=81, genome_len=5000, n_nodes=3300, n_paths=120)
     rng = np.random.default_rng(8)
-    for n_values in (12, 60):
+    for n_values in (12, 60, 256):
         mp = np.array(g0.mappability).copy()
         vals = np.round(rng.uniform(0.3, 1.0, n_values), 3)
         for w in range(0, len(mp), 40):
@@ -122,6 +124,14 @@ def test_graphs_with_many_node_classes(kernel_switch):
         _, ref, _ = orc.hc_run(og, oa, n_threads=8, faithful=False)
         got, wave = finals(ctx, hb, kernel_switch)
         assert util.rel_err(got, ref) < 1e-9 and util.rel_err(got, wave) < 1e-12
+
+        def edit(r, q):
+            if r % 3 == 0 and len(q):
+                q[:] = rng.integers(48, 90, len(q))
+            return q
+        _edit_qualities(hb, edit)
+        got2, wave2 = finals(ctx, hb, kernel_switch)
+        assert np.all(np.isfinite(got2)) and util.rel_err(got2, wave2) < 1e-12 and util.rel_err(got2, got) > 1e-6
 
 
 def test_soa_batches_whose_quality_strings_outrun_their_columns_keep_to_the_other_kernels():

@@ -109,7 +109,7 @@ struct vgan_hc_ctx {
     DevBuf<HcNodeDev> node_tab, cls_tab;
     DevBuf<uint16_t> node_hi;
     DevBuf<double> tables; // lq[256] qscore[100] incmap[100]
-    DevBuf<double> col_memo; // hc_col8_kernels.hip: the table of column terms
+    DevBuf<double> col_memo, col_memo2; // hc_col8_kernels.hip: the tables of column terms
     DevBuf<double> accum;                                    // one block: nodeW | acc_seg | acc_node | totals (one memset)
     struct View { double *p = nullptr; } nodeW, acc_seg, acc_node, totals;
     size_t accum_n = 0;
@@ -552,7 +552,8 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         nt[r] = {(double)logl(consensus ? (long double)mt : mm), (double)(1.0L / mm), mp, mt};
     }
     // node classes: the distinct {ln_w, inv_mm, mappability} triples, most frequent first (hc_col8_kernels.hip keeps a table of
-    // column terms for the first HC_MEMO_CLASSES of them; a graph with more than HC_MAX_NODE_CLASSES takes the older kernels)
+    // column terms for the first HC_MEMO_CLASSES of them in LDS and one for all of them in HBM; a graph with more than
+    // HC_EXT_NODE_CLASSES -- a mappability track with that many distinct values -- takes the older kernels)
     std::vector<HcNodeDev> cls;
     std::vector<uint16_t> nhi(c->rows, 0);
     {
@@ -563,7 +564,7 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
             uint32_t k = 0;
             while (k < cls.size() && !same(cls[k], nt[r])) ++k;
             if (k == cls.size()) {
-                if (cls.size() == HC_MAX_NODE_CLASSES) {
+                if (cls.size() == HC_EXT_NODE_CLASSES) {
                     many = true;
                     break;
                 }
@@ -638,11 +639,16 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     c->g.cls_tab = c->cls_tab.p;
     c->g.n_cls = (uint32_t)cls.size();
     c->g.col_memo = nullptr;
+    c->g.col_memo2 = nullptr;
     if (c->g.n_cls) { // the table of column terms (a pure function of the graph's node classes and the error-rate parameters)
         if ((rc = c->col_memo.reserve(hc_col8_memo_doubles()))) return bail(rc);
         launch_hc_col8_memo(c->g, c->prm, c->col_memo.p, c->stream);
         if (hipGetLastError() != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: the table of column terms could not be built"));
         c->g.col_memo = c->col_memo.p;
+        if ((rc = c->col_memo2.reserve(hc_col8_memo2_doubles(c->g.n_cls)))) return bail(rc);
+        launch_hc_col8_memo2(c->g, c->prm, c->col_memo2.p, c->stream);
+        if (hipGetLastError() != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: the wide table of column terms could not be built"));
+        c->g.col_memo2 = c->col_memo2.p;
     }
     c->g.rows = c->rows;
     c->g.mask_words = c->W;
@@ -680,6 +686,7 @@ extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
     c->node_tab.release();
     c->cls_tab.release();
     c->col_memo.release();
+    c->col_memo2.release();
     c->node_hi.release();
     c->tables.release();
     c->accum.release();

@@ -52,6 +52,7 @@ constexpr int C8_NR = 8;                // reads per tile at most (the segment r
 constexpr int C8_QMAX = 48;             // quality values the table of column terms covers: [0, C8_QMAX)
 constexpr int C8_NMEMO = 16;            // node classes it covers (the most frequent ones)
 constexpr uint32_t C8_CLS_BYTES = C8_QMAX * 64u; // a class's part of the table: [quality][match][read base] doubles
+constexpr uint32_t C8_CLS2_BYTES = HC_EXT_QMAX * 64u; // ... of the wide table (every class, every quality below HC_EXT_QMAX)
 static_assert(C8_NMEMO == (int)HC_MEMO_CLASSES && C8_CLS_BYTES == HC_MEMO_CLASS_BYTES, "hc_capi.hip writes node_hi[] with these");
 constexpr uint32_t C8_BUF_FLAGS = 0x00020000u;   // raw buffer descriptor, 32-bit data format (gfx9)
 constexpr uint32_t C8_BLOCK = 32u;               // reads per block of the work queue
@@ -214,6 +215,7 @@ struct C8Args {
     const double *qscore;
     const double *rdtab;
     const double *gmemo;      // [100 mapping qualities][C8_NMEMO classes][C8_QMAX][match][read base] column terms (hc_col8_memo_kernel)
+    const double *gmemo2;     // [100 mapping qualities][n_cls classes][HC_EXT_QMAX][match][read base]: the wide table (hc_col8_memo2_kernel)
     double *nodeW;
     double *totals;
     double bep;
@@ -448,7 +450,7 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
         }
 
         // ---- Q: prefix sums of {Q above 2: Q << 11, else 1} over the tile's columns, from byte 2 of the records
-        bool q_plain, tile_hot; // every quality byte of the tile in [0, C8_QMAX); one at 90 or above (bytes are signed, as the reference reads them)
+        bool q_plain, q_ext, tile_hot; // every quality byte of the tile in [0, C8_QMAX); one at 90 or above (bytes are signed, as the reference reads them)
         {
             uint32_t loc[C8_CPL], run = 0u, mxu = 255u; // mxu: the largest quality byte read as UNSIGNED (a negative one is 128 and above)
             // (the short variant only: with two waves or one to a SIMD -- the long variants -- the compiler's own schedule of the plain
@@ -488,6 +490,7 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
             for (int g = 0; g < C8_NG; ++g) dst[g] = uint4{before + loc[4 * g], before + loc[4 * g + 1], before + loc[4 * g + 2], before + loc[4 * g + 3]};
             // (columns past the tile's come back as zero records: quality 0)
             q_plain = __builtin_amdgcn_ballot_w64(mn < 0 || mx >= C8_QMAX) == 0;
+            q_ext = __builtin_amdgcn_ballot_w64(mn < 0 || mx >= 90) == 0; // (the wide table's range, short of the sticky qualities)
             tile_hot = __builtin_amdgcn_ballot_w64(mx >= 90) != 0; // switches the rest of a read to the background error rate (update_likelihood.cpp:40-44)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -606,7 +609,9 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
             if (n_out > 8) need_place = true; // (the next tile places the window anew)
         }
         // fast: every column term comes from the workgroup's table; gfast: from the context's (a read of another mapping quality)
-        const bool tabled = all_cls && !tile_out && q_plain, gfast = tabled && !all_major;
+        // wide: from the context's wide table -- a node class beyond the sixteen, a quality byte from C8_QMAX up to 89
+        const bool narrow = all_cls && !tile_out && q_plain, wide = !narrow && !tile_out && q_ext && a.gmemo2 != nullptr;
+        const bool tabled = narrow || wide, gfast = narrow && !all_major;
 #ifdef C8_PHASES
         const bool fast = tabled && all_major;
 #endif
@@ -615,6 +620,17 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
 #pragma unroll
             for (int k = 0; k < C8_SPASS; ++k) // byte offset of the read's mapping quality in the context's table (over the dead prefix sums; ps[3] = 0 stays)
                 L.ps[4 + k * 64 + lane] = ((rd[k].y >> 16) & 0x7Fu) * (uint32_t)(C8_NMEMO * C8_CLS_BYTES);
+        }
+        if (__builtin_expect(wide, 0)) {
+            // the same for the wide table; a mapping's info[] gets its class's offset there in units of 64 bytes (a class's part is
+            // HC_EXT_QMAX of them), where the narrow tiles keep the LDS address of the class's part of the workgroup's table
+#pragma unroll
+            for (int k = 0; k < C8_SPASS; ++k) {
+                const uint32_t ls = (uint32_t)k * 64u + (uint32_t)lane;
+                const uint32_t cls = nhi[k] < 0xE000u ? nhi[k] / C8_CLS_BYTES : min(nhi[k] - 0xE000u, a.n_cls - 1u);
+                L.ps[4 + ls] = ((rd[k].y >> 16) & 0x7Fu) * (a.n_cls * C8_CLS2_BYTES);
+                L.info[ls + 1u] = (L.info[ls + 1u] & 0xFFFFu) | ((cls * HC_EXT_QMAX) << 16);
+            }
         }
         if (__builtin_expect(!tabled, 0)) {
             // a general tile: {kappa, lw} per segment over the (now dead) prefix sums
@@ -633,8 +649,9 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                 if ((uint32_t)k * 64u < T.n_seg) {
                     const uint32_t ls = (uint32_t)k * 64u + (uint32_t)lane;
                     const uint32_t kr = ((sr[k] >> 29) - T.r) & 7u;
-                    const uint32_t cls = nhi[k] < 0xE000u ? nhi[k] / C8_CLS_BYTES : min(nhi[k] - 0xE000u, (uint32_t)HC_MAX_NODE_CLASSES - 1u);
-                    C8KL kl = c8_seg_kl(L.rdB[kr][0], L.rdB[kr][1], L.rdB[kr][2], S.cls[cls], a.consensus != 0);
+                    const uint32_t cls = nhi[k] < 0xE000u ? nhi[k] / C8_CLS_BYTES : min(nhi[k] - 0xE000u, a.n_cls - 1u);
+                    const HcNodeDev nd = cls < HC_MAX_NODE_CLASSES ? S.cls[cls] : a.cls_tab[cls]; // (the rarer classes' scalars: the context's array)
+                    C8KL kl = c8_seg_kl(L.rdB[kr][0], L.rdB[kr][1], L.rdB[kr][2], nd, a.consensus != 0);
                     if ((sticky_m[k] >> lane) & 1ull) kl.kappa = -kl.kappa;
                     L.kl[ls] = kl;
                 }
@@ -655,8 +672,8 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
             const uint32_t excl = incl - own[C8_CPL - 1];
             const uint32_t ibase = excl + info_base; // (info[0] stands for "no mapping yet")
             if (__builtin_expect(tabled, 1)) {
-                auto steps = [&](auto from_global, const uint32_t *rec8, const uint32_t *own8) {
-                    constexpr bool G = decltype(from_global)::value;
+                auto steps = [&](auto mode, const uint32_t *rec8, const uint32_t *own8) { // 0: the workgroup's table; 1: the context's; 2: its wide one
+                    constexpr bool G = decltype(mode)::value != 0, W2 = decltype(mode)::value == 2;
                     double t[8];
                     uint64_t valid[8];
                     uint32_t inf[8], rbo[8];
@@ -666,7 +683,7 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                         // the read's part of the context's table, less the LDS address info[] carries (the "no mapping yet" slot reads ps[3] = 0)
                         const uint32_t rbase = ibase + (lds_addr(&L.ps[3]) - info_base);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) rbo[e] = lds_ld32(rbase + own8[e]) - memo_base;
+                        for (int e = 0; e < 8; ++e) rbo[e] = lds_ld32(rbase + own8[e]) - (W2 ? 0u : memo_base);
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -680,8 +697,9 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                         uint32_t row; // 2 q + (graph base == read base): the compare writes VCC, the add takes it as carry
                         asm("v_cmp_eq_u32_sdwa vcc, %1, %1 src0_sel:BYTE_0 src1_sel:BYTE_1\n\tv_addc_co_u32 %0, vcc, %2, %2, vcc" : "=v"(row) : "v"(rec8[e]), "v"(q) : "vcc");
                         const uint32_t rc = __builtin_amdgcn_ubfe(rec8[e], 9u, 2u);
-                        const uint32_t ad = (rc << 3) + ((row << 5) + (inf[e] >> 16));
-                        if constexpr (G) t[e] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(a.gmemo) + (ad + rbo[e]));
+                        const uint32_t ad = (rc << 3) + ((row << 5) + (W2 ? (inf[e] >> 16) << 6 : inf[e] >> 16));
+                        if constexpr (W2) t[e] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(a.gmemo2) + (ad + rbo[e]));
+                        else if constexpr (G) t[e] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(a.gmemo) + (ad + rbo[e]));
                         else t[e] = lds_ld64(ad);
                     }
 #pragma unroll
@@ -693,8 +711,9 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                 };
 #pragma unroll
                 for (int g8 = 0; g8 < C8_CPL; g8 += 8) {
-                    if (gfast) steps(std::true_type{}, &rec[g8], &own[g8]);
-                    else steps(std::false_type{}, &rec[g8], &own[g8]);
+                    if (__builtin_expect(wide, 0)) steps(std::integral_constant<int, 2>{}, &rec[g8], &own[g8]);
+                    else if (gfast) steps(std::integral_constant<int, 1>{}, &rec[g8], &own[g8]);
+                    else steps(std::integral_constant<int, 0>{}, &rec[g8], &own[g8]);
                 }
             } else {
                 const uint32_t klbase = lds_addr(&L.kl[0]) - 4u * 4u; // (own counts from 4: segment 0)
@@ -821,10 +840,43 @@ __global__ __launch_bounds__(256) void hc_col8_memo_kernel(const double *__restr
     }
 }
 
+// The wide table: [mapping quality][class][quality below HC_EXT_QMAX][match][read base], every class of the graph, with the same
+// c8_seg_kl / c8_col_term as the tiles that compute their columns -- a tile that reads it gets the bits a general tile would compute.
+// A workgroup per (mapping quality, class).
+__global__ __launch_bounds__(256) void hc_col8_memo2_kernel(const double *__restrict__ qscore, const double *__restrict__ rdtab, const HcNodeDev *__restrict__ cls_tab,
+                                                            uint32_t n_cls, double bep, uint32_t use_bep, uint32_t consensus, double *__restrict__ out) {
+    __shared__ C8Lom lom[HC_EXT_QMAX][2];
+    __shared__ double2 bg[4];
+    __shared__ LogTabEntry logtab[64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (int)HC_EXT_QMAX * 2; i += 256) {
+        const int qi = i >> 1;
+        const double e = use_bep ? bep : qscore[qi];
+        const double om = (i & 1) ? 1.0 - e : 1.0 - (1.0 - e); // (get_p_obs_base.cpp:21,67: see hc_segment_col8_kernel)
+        lom[qi][i & 1] = C8Lom{log_pos(om), 1.0 / om};
+    }
+    if (tid < 4) {
+        const double f = tid == 0 ? 0.27532 : tid == 1 ? 0.30044 : tid == 2 ? 0.25780 : 0.16644;
+        bg[tid] = double2{f, f * (1.0 / 6.0)};
+    }
+    if (tid >= 64 && tid < 128) logtab[tid - 64] = c8_log_table[tid - 64];
+    __syncthreads();
+    const uint32_t mq = blockIdx.x, cls = blockIdx.y;
+    const C8KL kl = c8_seg_kl(rdtab[3 * mq], rdtab[3 * mq + 1], rdtab[3 * mq + 2], cls_tab[cls], consensus != 0);
+    double *dst = out + ((size_t)mq * n_cls + cls) * (HC_EXT_QMAX * 8);
+    for (int i = tid; i < (int)HC_EXT_QMAX * 8; i += 256) dst[i] = c8_col_term(kl.kappa, kl.lw, lom[i >> 3][(i >> 2) & 1], bg[i & 3], logtab);
+}
+
 } // namespace c8
 using namespace c8;
 
 size_t hc_col8_memo_doubles() { return (size_t)100 * C8_NMEMO * C8_QMAX * 8; }
+size_t hc_col8_memo2_doubles(uint32_t n_cls) { return (size_t)100 * n_cls * HC_EXT_QMAX * 8; }
+void launch_hc_col8_memo2(const HcGraphDev &g, const HcParamsDev &prm, double *out, hipStream_t st) {
+    if (g.n_cls == 0) return;
+    hipLaunchKernelGGL(hc_col8_memo2_kernel, dim3(100, g.n_cls), dim3(256), 0, st, g.qscore, g.rdtab, g.cls_tab, g.n_cls, prm.bep, prm.use_bep ? 1u : 0u,
+                       prm.consensus ? 1u : 0u, out);
+}
 void launch_hc_col8_memo(const HcGraphDev &g, const HcParamsDev &prm, double *out, hipStream_t st) {
     hipLaunchKernelGGL(hc_col8_memo_kernel, dim3(100), dim3(256), 0, st, g.qscore, g.rdtab, g.cls_tab, g.n_cls, prm.bep, prm.use_bep ? 1u : 0u,
                        prm.consensus ? 1u : 0u, out);
@@ -897,6 +949,7 @@ void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const H
     a.qscore = g.qscore;
     a.rdtab = g.rdtab;
     a.gmemo = g.col_memo;
+    a.gmemo2 = g.col_memo2;
     a.nodeW = nodeW;
     a.totals = totals;
     a.bep = prm.bep;

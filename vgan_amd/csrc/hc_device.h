@@ -43,8 +43,9 @@ struct HcGraphDev {
     const uint16_t *node_hi;  // [rows] class * (bytes of a class in the kernel's table of column terms) for the classes the table
                               // covers, 0xE000 | class for the others
     const HcNodeDev *cls_tab; // [n_cls]
-    uint32_t n_cls;           // 0: more than HC_MAX_NODE_CLASSES classes (the kernel is not taken)
+    uint32_t n_cls;           // 0: more than HC_EXT_NODE_CLASSES classes (the kernel is not taken)
     const double *col_memo;   // the context's table of column terms (hc_col8_memo_kernel), or NULL
+    const double *col_memo2;  // ... and its wide form: every class of the graph, every quality below HC_EXT_QMAX (hc_col8_memo2_kernel), or NULL
     uint32_t rows;
     uint32_t mask_words;
     uint32_t row_entries; // n_tiles * 64
@@ -113,7 +114,9 @@ struct HcParamsDev {
 constexpr uint32_t HC_TOTAL_SLOTS = 64;
 constexpr uint32_t HC_TOTAL_STRIDE = 16; // doubles
 
-constexpr uint32_t HC_MAX_NODE_CLASSES = 32;   // node classes hc_segment_col8_kernel keeps the scalars of
+constexpr uint32_t HC_MAX_NODE_CLASSES = 32;   // node classes hc_segment_col8_kernel keeps the scalars of in LDS (the others': the context's array)
+constexpr uint32_t HC_EXT_NODE_CLASSES = 256;  // node classes the kernel takes at all (the wide table of column terms covers every one of them)
+constexpr uint32_t HC_EXT_QMAX = 94;           // quality values the wide table covers: [0, HC_EXT_QMAX) -- printable FASTQ qualities end at 93
 constexpr uint32_t HC_MEMO_CLASSES = 16;       // ... of which its table of column terms covers the most frequent (C8_NMEMO)
 constexpr uint32_t HC_MEMO_CLASS_BYTES = 3072; // a class's part of that table (C8_CLS_BYTES)
 
@@ -146,6 +149,8 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
 bool hc_col8_kernel_fits(const HcGraphDev &g, const HcPackedDev &pk);
 size_t hc_col8_memo_doubles(); // the context's table of column terms: its size, and the launch that fills it (after the graph side is up)
 void launch_hc_col8_memo(const HcGraphDev &g, const HcParamsDev &prm, double *out, hipStream_t st);
+size_t hc_col8_memo2_doubles(uint32_t n_cls); // the wide table: [100 mapping qualities][n_cls][HC_EXT_QMAX][match][read base]
+void launch_hc_col8_memo2(const HcGraphDev &g, const HcParamsDev &prm, double *out, hipStream_t st);
 void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const HcParamsDev &prm, double *nodeW, double *totals, hipStream_t st);
 // node ids of the packed segment records into a plain array (the per-segment mask sweep reads them eight at a time)
 void launch_hc_srec_nodes(const uint32_t *srec, uint32_t n_segments, uint32_t *out, hipStream_t st);
