@@ -15,6 +15,7 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -50,6 +51,7 @@ def parse():
     ap.add_argument("--preflight", action="store_true", help="N > 1: initialise the process group, run the collectives' self-test, print its record and leave")
     ap.add_argument("--preflight-timeout", type=float, default=60.0, help="seconds a rank may spend inside the self-test's collectives")
     ap.add_argument("--no-ingest", action="store_true", help="skip the host-to-device / streamed single-pass figures")
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the file the end_to_end record runs `vgan haplocart` on (0: skip; --no-frontend skips it too)")
     ap.add_argument("--path", choices=["haplocart", "euka", "soibean"], default="haplocart",
                     help="haplocart = the BASELINE metric; euka / soibean = configs 4 / 5 as extra lines")
     return ap.parse_args()
@@ -578,38 +580,33 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
         # on a CPU quota that, not the wall time of one stage, is what a long input's throughput follows)
         dev = {"reads_per_s": parts.n_reads / t_df, "host_cpu_us_per_read": cpu_df / parts.n_reads * 1e6, "reads_taken": int(res.pk.n_reads),
                "reads_left_to_the_host": int(res.host_mask.sum())}
-        # f1 on the device (vgan_gamdev): the FILE's bytes go up, BGZF inflate + framing + protobuf wire walk + duplicate marks + flatten
-        # are kernels; nothing but the mask of the reads left to the host comes back.  What `vgan haplocart` does with a BGZF GAM of
-        # 384 MB and more on one GPU (on this sample the fixed costs of a dozen launches and syncs weigh: tools/e2e_device_gam.py has
-        # the 10 M-read file)
+        # f1 on the device as `vgan haplocart` runs it (vgan_hc_accumulate_gam_bytes: csrc/gam_pipe.hip): the FILE's bytes go up in
+        # pieces, and BGZF inflate + framing + protobuf wire walk + flatten + the segment kernel run as a pipeline over them; only the
+        # messages of the reads the device flatten leaves to the host come back.  (The whole-file figure, with HIP start-up and process
+        # exit: the `end_to_end` record.)
         try:
             with tempfile.TemporaryDirectory(prefix="vgan_fe_") as d:
                 p = os.path.join(d, "sample.gam")
                 a.write_gam(p)
                 data = open(p, "rb").read()
             # (ten copies of the sample's file one after the other -- BGZF members concatenate, the end-of-file member of all but the last
-            # dropped: a file of the size the device front end is for; a BGZF member is one lane's work for ~50 ms however few there are)
+            # dropped: a file of the size the device front end is for)
             data = data[:-28] * 9 + data
-            gd = hc.GamDevice()
-            gd.parse(data)
-            df.run_gamdev(gd)  # (buffers)
+            ctx.reset()
+            hc.accumulate_gam_bytes([ctx], graph, data)  # (buffers, code objects)
+            ctx.reset()
             t0, c0 = time.perf_counter(), time.process_time()
-            gd.parse(data)
-            t_parse = time.perf_counter() - t0
-            nd = gd.mark_duplicates()
-            t_dup = time.perf_counter() - t0 - t_parse
-            res2 = df.run_gamdev(gd)  # (every read flattened: the copies are one another's duplicates, and the marks would leave the flatten idle)
+            st, ps = hc.accumulate_gam_bytes([ctx], graph, data)
+            ctx.synchronize()
             t_all, cpu_all = time.perf_counter() - t0, time.process_time() - c0
-            dev["device_gam"] = {"reads_per_s": gd.sizes["reads"] / t_all, "host_cpu_us_per_read": cpu_all / max(gd.sizes["reads"], 1) * 1e6,
-                                 "gam_bytes": len(data), "inflated_bytes": gd.sizes["inflated_bytes"], "parse_ms": t_parse * 1e3,
-                                 "parse_parts_ms": {k: round(v, 3) for k, v in gd.ms.items()}, "duplicate_marks_ms": t_dup * 1e3,
-                                 "duplicates": int(nd), "flatten_ms": (t_all - t_parse - t_dup) * 1e3,
-                                 "reads_taken": int(res2.pk.n_reads), "reads_left_to_the_host": int(res2.host_mask.sum()),
-                                 "what": "ten copies of the sample GAM's bytes, one after the other -> inflate, framing, protobuf walk, duplicate marks, "
-                                         "flatten as kernels; the file's bytes start in pageable host memory (PCIe inside the figure).  End to end through "
-                                         "`vgan haplocart`, HIP start-up and process exit included: 10-11 M reads/s on a 10 M-read file "
-                                         "(tools/e2e_device_gam.py, DESIGN.md section 4.6)"}
-            gd.close()
+            ctx.reset()
+            dev["device_gam"] = {"reads_per_s": ps["n_reads"] / t_all, "host_cpu_us_per_read": cpu_all / max(ps["n_reads"], 1) * 1e6,
+                                 "gam_bytes": len(data), "inflated_bytes": ps["inflated_bytes"], "pieces": ps["n_pieces"], "wall_ms": t_all * 1e3,
+                                 "device_bytes": ps["device_bytes"], "reads_taken": ps["n_device_reads"], "reads_left_to_the_host": ps["n_host_reads"],
+                                 "summed_over_pieces_ms": {k[3:]: round(ps[k], 2) for k in ("ms_upload", "ms_inflate", "ms_frame", "ms_parse", "ms_consume")},
+                                 "what": "ten copies of the sample GAM's bytes, one after the other -> the device front end's pipeline over the file's pieces "
+                                         "(inflate, framing, protobuf walk, flatten, segment kernel); the file's bytes start in pageable host memory (PCIe inside "
+                                         "the figure)"}
         except Exception as e:  # (a figure beside the metric: its failure is reported, not fatal)
             dev["device_gam"] = {"failed": repr(e)[:300]}
         df.close()
@@ -620,6 +617,50 @@ def front_end_rates(graph, hc, seed, n=200_000, ctx=None):
             # what the container may keep busy (affinity mask and cgroup CPU quota): a sample this size is a burst on the
             # quota's slack; a long input runs at ~7 us of CPU per read on this many processors
             "cpu_quota": int(N.lib().vgan_host_cpus())}
+
+
+def end_to_end(graph, hc, args):
+    """`vgan haplocart -g FILE` measured in-run: a synthetic GAM of args.e2e_reads 150 bp reads is written (not timed), then the C++ binary
+    runs on it twice -- process start, HIP start-up, the device front end's pipeline over the file, posterior, output files and process
+    exit inside the wall time -- and once through the host pipeline (VGAN_HC_DEVICE_GAM=0) beside it."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vgan_amd", "bin", "vgan")
+    n = args.e2e_reads
+    if n <= 0 or not os.path.exists(exe):
+        return None
+    rec = {"reads": n, "read_len": args.read_len}
+    with tempfile.TemporaryDirectory(prefix="vgan_e2e_", dir="/tmp") as d:
+        graph.write(d)
+        t0 = time.perf_counter()
+        CH = 1_000_000
+        with open(d + "/r.gam", "wb") as f:  # (chunks of 1 M reads: BGZF files concatenate)
+            for c0 in range(0, n, CH):
+                a = hc.synth_reads(graph, min(CH, n - c0), seed=args.seed, read_len=args.read_len, first_read=c0)
+                a.write_gam(d + "/part.gam")
+                blob = open(d + "/part.gam", "rb").read()
+                f.write(blob[:-28] if c0 + CH < n else blob)
+                del a
+        rec["gam_bytes"] = os.path.getsize(d + "/r.gam")
+        rec["file_written_in_s"] = round(time.perf_counter() - t0, 1)
+        cmd = [exe, "haplocart", "-g", d + "/r.gam", "--hc-files", d, "-q", "-t", "-1", "--keep-duplicates", "-o", d + "/o.tsv", "-pf", d + "/p.txt"]
+        runs = []
+        for tag, env in (("device", {"VGAN_HC_DEVICE_GAM": "1"}), ("device", {"VGAN_HC_DEVICE_GAM": "1"}), ("host", {"VGAN_HC_DEVICE_GAM": "0"})):
+            t0, c0 = time.perf_counter(), os.times()
+            r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, VGAN_TIMING="1", **env))
+            dt, c1 = time.perf_counter() - t0, os.times()
+            cpu = (c1.children_user - c0.children_user) + (c1.children_system - c0.children_system)
+            line = [ln for ln in r.stderr.splitlines() if "device front end" in ln]
+            runs.append({"front_end": tag, "rc": r.returncode, "wall_s": round(dt, 3), "reads_per_s": n / dt, "host_cpu_s": round(cpu, 2),
+                         "result": open(d + "/o.tsv").read().splitlines()[-1].split("\t")[1:] if os.path.exists(d + "/o.tsv") else None,
+                         "pipeline": line[0].split("front end: ")[1][:600] if line else None})
+    dev_runs = [x for x in runs if x["front_end"] == "device" and x["rc"] == 0]
+    rec["runs"] = runs
+    if dev_runs:
+        best = min(dev_runs, key=lambda x: x["wall_s"])
+        rec["wall_s"], rec["reads_per_s"] = best["wall_s"], best["reads_per_s"]
+    rec["what"] = ("`vgan haplocart -g FILE --keep-duplicates` on a synthetic BGZF GAM, the whole process timed from outside (start, HIP runtime, graph load, "
+                   "device front end in pieces, segment kernel, posterior, output, exit); the better of two runs with the device front end, the host pipeline beside them")
+    return rec
 
 
 def ingest_rates(graph, hc, ctx, dev, args, n_batches=3, passes=8):
@@ -952,6 +993,12 @@ def main():
             out["ingest"] = ingest_rates(graph, hc, ctx, dev, args)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(graph, alns0, args.cpu_seconds, ctx, hc)
+        if world == 1 and not args.no_frontend and args.e2e_reads > 0 and mode == hc.MODE_NODE_WEIGHTS and args.path == "haplocart":
+            try:
+                del ctx  # (the binary brings its own contexts up: this process's device memory goes first)
+                out["end_to_end"] = end_to_end(graph, hc, args)
+            except Exception as e:  # (a figure beside the metric: its failure is reported, not fatal)
+                out["end_to_end"] = {"failed": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

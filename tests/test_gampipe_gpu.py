@@ -285,3 +285,26 @@ def test_cli_takes_the_device_path_with_several_contexts_and_falls_back(tmp_path
     r = subprocess.run([exe, "haplocart", "-g", gam, "--hc-files", str(tmp_path), "-np", "-o", str(tmp_path / "bad.tsv"), "-s", "s"],
                        capture_output=True, text=True, env=dict(os.environ, VGAN_HC_DEVICE_GAM="1", VGAN_GAMPIPE_PIECE="300000"))
     assert "the host pipeline does" in r.stderr and r.returncode != 0  # (the host pipeline reads the same damaged member: an I/O error, said once)
+
+
+def test_a_piece_whose_columns_would_wrap_the_offsets_is_refused_and_the_cli_takes_the_host_pipeline(tmp_path, monkeypatch):
+    """The packed batch's offsets are 32 bits wide; the device flatten sums a chunk's alignment columns in 64 bits and refuses a chunk
+    that would wrap them (VGAN_HC_DEVFLAT_MAX_COLS puts the limit where a test can reach it).  Through the library the pipeline fails
+    with that reason; `vgan haplocart` clears its contexts and runs the host pipeline, which writes the host pipeline's files."""
+    g = hc.synth_graph(seed=15, genome_len=5000, n_nodes=3400, n_paths=60)
+    a = hc.synth_reads(g, 20000, seed=3, read_len=100)
+    g.write(str(tmp_path))
+    gam = str(tmp_path / "r.gam")
+    a.write_gam(gam)
+    exe = os.path.join(ROOT, "vgan_amd", "bin", "vgan")
+    outs = {}
+    for tag, env in (("host", {"VGAN_HC_DEVICE_GAM": "0"}), ("refused", {"VGAN_HC_DEVICE_GAM": "1", "VGAN_HC_DEVFLAT_MAX_COLS": "100000"})):
+        out = str(tmp_path / (tag + ".tsv"))
+        r = subprocess.run([exe, "haplocart", "-g", gam, "--hc-files", str(tmp_path), "-np", "-d", "-o", out, "-s", "s", "-t", "4"], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert ("the host pipeline does" in r.stderr and "32-bit offsets" in r.stderr) == (tag == "refused"), r.stderr[-1500:]
+        outs[tag] = (open(out).read(), open(out + ".loglik.tsv").read())
+    assert outs["host"][0] == outs["refused"][0]
+    ll = [dict((ln.split("\t")[0], float(ln.split("\t")[1])) for ln in o[1].splitlines()) for o in (outs["host"], outs["refused"])]
+    assert ll[0].keys() == ll[1].keys() and all(ll[1][k] == pytest.approx(v, rel=1e-9) for k, v in ll[0].items())
