@@ -779,6 +779,39 @@ __global__ __launch_bounds__(64) void gd_lzw_kernel(const GdBlock *__restrict__ 
     if (err != GD_OK && lane == 0) status[b] = err;
 }
 
+// The members' CRC-32 (RFC 1952 8: the gzip trailer's first word), a wave per member: lane j takes the j-th kilobyte counted from the
+// member's END (the first chunk is the short one), byte by byte through the 256-entry table; the chunks' registers are then folded front
+// to back -- processing B from register r equals (r moved across |B| zero bytes) xor (B processed from 0), and moving across GW_CRC_CHUNK
+// zero bytes is four look-ups in a table made for that length.  A member whose bytes do not give the trailer's value gets GD_BAD_CRC:
+// the host pipeline's zlib / libdeflate refuse such a file, and so does this one (the member goes through the older kernel first, as
+// every status but GD_OK does).  tabs: [256] the CRC table, then [4][256] the zero-bytes operator.
+constexpr uint32_t GW_CRC_CHUNK = 1024;
+__global__ __launch_bounds__(64) void gd_crc_kernel(const uint8_t *__restrict__ out, const GdBlock *__restrict__ blocks, uint32_t n_blocks, const uint32_t *__restrict__ want,
+                                                    const uint32_t *__restrict__ tabs, uint32_t *__restrict__ status) {
+    __shared__ uint32_t t[256 + 1024];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    if (b >= n_blocks || status[b] != GD_OK) return;
+    for (uint32_t i = lane; i < 256u + 1024u; i += 64u) t[i] = tabs[i];
+    __syncthreads();
+    const GdBlock bl = blocks[b];
+    const uint8_t *o = out + bl.out_off;
+    const uint32_t n = bl.out_size, n_chunks = (n + GW_CRC_CHUNK - 1u) / GW_CRC_CHUNK; // <= 64: a BGZF member holds 64 KB at most
+    if (n_chunks > 64u) return; // (not BGZF's: left unchecked)
+    const uint32_t first_len = n - (n_chunks ? (n_chunks - 1u) * GW_CRC_CHUNK : 0u);
+    uint32_t r = 0;
+    if (lane < n_chunks) {
+        const uint32_t at = lane == 0 ? 0u : first_len + (lane - 1u) * GW_CRC_CHUNK, len = lane == 0 ? first_len : GW_CRC_CHUNK;
+        r = lane == 0 ? 0xFFFFFFFFu : 0u;
+        for (uint32_t k = 0; k < len; ++k) r = t[(r ^ o[at + k]) & 255u] ^ (r >> 8);
+    }
+    uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)r, 0);
+    for (uint32_t j = 1; j < n_chunks; ++j) {
+        const uint32_t rj = (uint32_t)__shfl((int)r, (int)j);
+        total = t[256u + (total & 255u)] ^ t[512u + ((total >> 8) & 255u)] ^ t[768u + ((total >> 16) & 255u)] ^ t[1024u + (total >> 24)] ^ rj;
+    }
+    if (lane == 0 && (n ? (total ^ 0xFFFFFFFFu) : 0u) != want[b]) status[b] = GD_BAD_CRC;
+}
+
 } // namespace gd
 
 // Inflates n_blocks members: the two kernels above on the stream.  The scratch belongs to the caller (tok: tok_cap tokens shared by all
@@ -791,6 +824,33 @@ int gamdev_inflate_wave(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n
     static const bool lane_lz = getenv("VGAN_GAMDEV_LZ") && !strcmp(getenv("VGAN_GAMDEV_LZ"), "lane"); // (developer aid: the LZ77 half a lane per member)
     if (lane_lz) hipLaunchKernelGGL(gd::gd_lz_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, d_blocks, n_blocks, d_tok, (const uint2 *)d_reg, d_n_reg, d_out, d_status);
     else hipLaunchKernelGGL(gd::gd_lzw_kernel, dim3(n_blocks), dim3(64), 0, st, d_blocks, n_blocks, d_tok, (const uint2 *)d_reg, d_n_reg, d_out, d_status);
+    HIPCHK(hipGetLastError());
+    return VGAN_OK;
+}
+
+// [256] the CRC-32 table (reflected polynomial 0xEDB88320), then [4][256]: byte k of a register moved across GW_CRC_CHUNK zero bytes
+const uint32_t *gamdev_crc_tables() {
+    static uint32_t tabs[256 + 1024];
+    static const bool made = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            tabs[i] = c;
+        }
+        for (uint32_t k = 0; k < 4; ++k)
+            for (uint32_t v = 0; v < 256; ++v) {
+                uint32_t r = v << (8 * k);
+                for (uint32_t z = 0; z < gd::GW_CRC_CHUNK; ++z) r = tabs[r & 255u] ^ (r >> 8);
+                tabs[256 + 256 * k + v] = r;
+            }
+        return true;
+    }();
+    (void)made;
+    return tabs;
+}
+int gamdev_crc(const uint8_t *d_out, const GdBlock *d_blocks, uint32_t n_blocks, const uint32_t *d_want, const uint32_t *d_tabs, uint32_t *d_status, hipStream_t st) {
+    if (n_blocks == 0) return VGAN_OK;
+    hipLaunchKernelGGL(gd::gd_crc_kernel, dim3(n_blocks), dim3(64), 0, st, d_out, d_blocks, n_blocks, d_want, d_tabs, d_status);
     HIPCHK(hipGetLastError());
     return VGAN_OK;
 }

@@ -1174,7 +1174,8 @@ int gamdev_inflate(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n_bloc
 } // namespace vgan
 
 namespace {
-int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_blocks, uint8_t *d_out, uint32_t *d_status, hipStream_t st, uint64_t *n_redone);
+int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_blocks, uint8_t *d_out, uint32_t *d_status, hipStream_t st, uint64_t *n_redone,
+                     const uint32_t *h_want, const uint32_t *d_tabs);
 }
 // Developer / test entry: inflates a BGZF file's bytes on the device and copies the result back (the host's bgzf_index says where the
 // members lie).  Returns VGAN_EIO when a member does not inflate to its stated size.
@@ -1183,11 +1184,14 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
     std::vector<BgzfBlock> blocks;
     if (!bgzf_index((const unsigned char *)bytes, (size_t)n, blocks)) return fail(VGAN_EIO, "vgan_gamdev_inflate_bytes: not a BGZF stream");
     std::vector<GdBlock> gb;
+    std::vector<uint32_t> want;
     uint64_t total = 0;
     for (const BgzfBlock &b : blocks) {
         const unsigned char *p = (const unsigned char *)bytes + b.in_off;
         const size_t xlen = p[10] | (p[11] << 8), hdr = 12 + xlen;
         gb.push_back(GdBlock{(uint64_t)(b.in_off + hdr), (uint64_t)b.out_off, (uint32_t)(b.in_size - hdr - 8), (uint32_t)b.out_size});
+        const unsigned char *t = p + b.in_size - 8;
+        want.push_back((uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24));
         total = b.out_off + b.out_size;
     }
     *out_size = total;
@@ -1195,12 +1199,12 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
     if (out_cap < total) return fail(VGAN_EINVAL, "vgan_gamdev_inflate_bytes: the output buffer is too small");
     uint8_t *d_in = nullptr, *d_out = nullptr;
     GdBlock *d_b = nullptr;
-    uint32_t *d_s = nullptr, *d_tok = nullptr, *d_nreg = nullptr, *d_cur = nullptr;
+    uint32_t *d_s = nullptr, *d_tok = nullptr, *d_nreg = nullptr, *d_cur = nullptr, *d_want = nullptr;
     void *d_reg = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = VGAN_OK;
     auto cleanup = [&] {
-        for (void *q : {(void *)d_tok, (void *)d_nreg, (void *)d_cur, d_reg})
+        for (void *q : {(void *)d_tok, (void *)d_nreg, (void *)d_cur, d_reg, (void *)d_want})
             if (q) (void)hipFree(q);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
@@ -1238,13 +1242,18 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
     rc = lane_inflate ? gamdev_inflate(d_in, d_b, (uint32_t)gb.size(), d_out, d_s, nullptr)
                       : gamdev_inflate_wave(d_in, d_b, (uint32_t)gb.size(), d_out, d_s, d_tok, tok_cap, d_cur, d_reg, d_nreg, nullptr);
     GDCHK(hipEventRecord(e1, nullptr));
+    GDCHK(hipMalloc((void **)&d_want, gb.size() * 4 + 16 + 1280 * 4));
+    GDCHK(hipMemcpy(d_want, want.data(), gb.size() * 4, hipMemcpyHostToDevice));
+    uint32_t *d_tabs = d_want + ((gb.size() + 3) & ~(size_t)3);
+    GDCHK(hipMemcpy(d_tabs, gamdev_crc_tables(), 1280 * 4, hipMemcpyHostToDevice));
+    if (rc == VGAN_OK) rc = gamdev_crc(d_out, d_b, (uint32_t)gb.size(), d_want, d_tabs, d_s, nullptr);
     GDCHK(hipDeviceSynchronize());
     if (rc == VGAN_OK) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (kernel_ms) *kernel_ms = ms;
         uint64_t redone = 0;
-        if ((rc = gd_check_inflate(d_in, d_b, gb.size(), d_out, d_s, nullptr, &redone)) < 0) {
+        if ((rc = gd_check_inflate(d_in, d_b, gb.size(), d_out, d_s, nullptr, &redone, want.data(), d_tabs)) < 0) {
             cleanup();
             return rc;
         }
@@ -1331,21 +1340,24 @@ double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::
 
 namespace {
 // the host's share of a parse: where the BGZF members lie (no HIP call: vgan_gamdev_open makes it while another thread brings the runtime up)
-bool gd_index(const void *bytes, uint64_t n, std::vector<GdBlock> &gb, uint64_t &total) {
+bool gd_index(const void *bytes, uint64_t n, std::vector<GdBlock> &gb, std::vector<uint32_t> &crcs, uint64_t &total) {
     std::vector<BgzfBlock> blocks;
     if (!bgzf_index((const unsigned char *)bytes, (size_t)n, blocks)) return false;
     gb.clear();
+    crcs.clear();
     gb.reserve(blocks.size());
     for (const BgzfBlock &b : blocks) {
         const unsigned char *p = (const unsigned char *)bytes + b.in_off;
         const size_t xlen = p[10] | (p[11] << 8), hdr = 12 + xlen;
         if (b.out_size == 0) continue; // (the end-of-file member, empty members: nothing to write)
         gb.push_back(GdBlock{(uint64_t)(b.in_off + hdr), (uint64_t)b.out_off, (uint32_t)(b.in_size - hdr - 8), (uint32_t)b.out_size});
+        const unsigned char *t = p + b.in_size - 8;
+        crcs.push_back((uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24));
     }
     total = blocks.empty() ? 0 : blocks.back().out_off + blocks.back().out_size;
     return true;
 }
-int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::vector<GdBlock> &gb, uint64_t total, int keep_unmapped);
+int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::vector<GdBlock> &gb, const std::vector<uint32_t> &crcs, uint64_t total, int keep_unmapped);
 } // namespace
 
 // A BGZF GAM file's bytes -> the parser's arrays on the device (what vgan_gam_stream + the narrowing of vgan_hc_devflat_run make of the
@@ -1354,9 +1366,10 @@ int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::v
 extern "C" int vgan_gamdev_parse(vgan_gamdev *g, const void *bytes, uint64_t n, int keep_unmapped) {
     if (!g || (!bytes && n)) return fail(VGAN_EINVAL, "vgan_gamdev_parse: null argument");
     std::vector<GdBlock> gb;
+    std::vector<uint32_t> crcs;
     uint64_t total = 0;
-    if (!gd_index(bytes, n, gb, total)) return fail(VGAN_EIO, "vgan_gamdev_parse: not a BGZF stream");
-    return gd_parse_indexed(g, bytes, n, gb, total, keep_unmapped);
+    if (!gd_index(bytes, n, gb, crcs, total)) return fail(VGAN_EIO, "vgan_gamdev_parse: not a BGZF stream");
+    return gd_parse_indexed(g, bytes, n, gb, crcs, total, keep_unmapped);
 }
 
 // vgan_gamdev_create + vgan_gamdev_parse with the member index made first: a thread that calls this while another one makes the
@@ -1365,12 +1378,13 @@ extern "C" int vgan_gamdev_open(int device, void *hip_stream, const void *bytes,
     if (!out || (!bytes && n)) return fail(VGAN_EINVAL, "vgan_gamdev_open: null argument");
     *out = nullptr;
     std::vector<GdBlock> gb;
+    std::vector<uint32_t> crcs;
     uint64_t total = 0;
-    if (!gd_index(bytes, n, gb, total)) return fail(VGAN_EIO, "vgan_gamdev_open: not a BGZF stream");
+    if (!gd_index(bytes, n, gb, crcs, total)) return fail(VGAN_EIO, "vgan_gamdev_open: not a BGZF stream");
     vgan_gamdev *g = nullptr;
     int rc = vgan_gamdev_create(device, hip_stream, &g);
     if (rc < 0) return rc;
-    if ((rc = gd_parse_indexed(g, bytes, n, gb, total, keep_unmapped)) < 0) {
+    if ((rc = gd_parse_indexed(g, bytes, n, gb, crcs, total, keep_unmapped)) < 0) {
         vgan_gamdev_free(g);
         return rc;
     }
@@ -1381,7 +1395,8 @@ extern "C" int vgan_gamdev_open(int device, void *hip_stream, const void *bytes,
 namespace {
 // The members' statuses after the inflate kernels.  Whatever the two-kernel inflate did not finish (stored blocks, many blocks, no room in
 // its scratch -- and whatever it calls an error) goes through the older kernel, a lane per member: an error is that kernel's to report.
-int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_blocks, uint8_t *d_out, uint32_t *d_status, hipStream_t st, uint64_t *n_redone) {
+int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_blocks, uint8_t *d_out, uint32_t *d_status, hipStream_t st, uint64_t *n_redone,
+                     const uint32_t *h_want, const uint32_t *d_tabs) {
     if (n_blocks == 0) return VGAN_OK;
     std::vector<uint32_t> stt(n_blocks);
     HIPCHK(hipMemcpyAsync(stt.data(), d_status, n_blocks * 4, hipMemcpyDeviceToHost, st));
@@ -1403,8 +1418,8 @@ int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_bloc
     HIPCHK(hipMemcpy(all.data(), d_blocks, n_blocks * sizeof(GdBlock), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < again.size(); ++k) sub[k] = all[again[k]];
     GdBlock *d_sub = nullptr;
-    uint32_t *d_st = nullptr;
-    if (hipMalloc((void **)&d_sub, sub.size() * sizeof(GdBlock)) != hipSuccess || hipMalloc((void **)&d_st, sub.size() * 4) != hipSuccess) {
+    uint32_t *d_st = nullptr; // (statuses, then -- with a CRC check -- the trailers' values)
+    if (hipMalloc((void **)&d_sub, sub.size() * sizeof(GdBlock)) != hipSuccess || hipMalloc((void **)&d_st, sub.size() * 8) != hipSuccess) {
         if (d_sub) (void)hipFree(d_sub);
         return fail(VGAN_ENOMEM, "vgan_gamdev_parse: no device memory for the members to inflate again");
     }
@@ -1412,6 +1427,12 @@ int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_bloc
     int rc = VGAN_OK;
     if (hipMemcpy(d_sub, sub.data(), sub.size() * sizeof(GdBlock), hipMemcpyHostToDevice) != hipSuccess) rc = fail(VGAN_ENODEV, "vgan_gamdev_parse: upload failed");
     if (rc == VGAN_OK) rc = gamdev_inflate(d_in, d_sub, (uint32_t)sub.size(), d_out, d_st, st);
+    if (rc == VGAN_OK && h_want && d_tabs) {
+        std::vector<uint32_t> w2(sub.size());
+        for (size_t k = 0; k < again.size(); ++k) w2[k] = h_want[again[k]];
+        if (hipMemcpy(d_st + sub.size(), w2.data(), sub.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(VGAN_ENODEV, "vgan_gamdev_parse: upload failed");
+        if (rc == VGAN_OK) rc = gamdev_crc(d_out, d_sub, (uint32_t)sub.size(), d_st + sub.size(), d_tabs, d_st, st);
+    }
     if (rc == VGAN_OK && (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(st2.data(), d_st, sub.size() * 4, hipMemcpyDeviceToHost) != hipSuccess))
         rc = fail(VGAN_ENODEV, "vgan_gamdev_parse: the members inflated again: no status");
     (void)hipFree(d_sub);
@@ -1423,18 +1444,19 @@ int gd_check_inflate(const uint8_t *d_in, const GdBlock *d_blocks, size_t n_bloc
 }
 
 // a whole file as one piece that is the stream's first and last
-int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::vector<GdBlock> &gb, uint64_t total, int keep_unmapped) {
+int gd_parse_indexed(vgan_gamdev *g, const void *bytes, uint64_t n, const std::vector<GdBlock> &gb, const std::vector<uint32_t> &crcs, uint64_t total, int keep_unmapped) {
     // every offset the parse leaves is 32 bits wide and every array it fills is a subset of the inflated bytes (a mapping, an edit, a
     // message take at least a byte each): a stream below 2^32 bytes cannot wrap any of them.  Longer files go through in pieces
     // (vgan_gampipe_*: gam_pipe.hip), or through the host pipeline.
     if (total > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "vgan_gamdev_parse: %llu inflated bytes are beyond the parse's 32-bit offsets; parse the file in pieces", (unsigned long long)total);
     int rc;
-    if ((rc = gd::gd_piece_upload_inflate(g, (const uint8_t *)bytes, n, gb.data(), gb.size(), total, 0))) return rc;
+    if ((rc = gd::gd_piece_upload_inflate(g, (const uint8_t *)bytes, n, gb.data(), crcs.data(), gb.size(), total, 0))) return rc;
     return gd::gd_piece_parse(g, GdCarry{}, true, nullptr, keep_unmapped, nullptr, nullptr);
 }
 } // namespace
 
-int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint64_t n, const GdBlock *gb, size_t n_gb, uint64_t total, uint64_t tail_cap) {
+int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint64_t n, const GdBlock *gb, const uint32_t *crcs, size_t n_gb, uint64_t total,
+                                      uint64_t tail_cap) {
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
     g->n_inflated = g->n_messages = g->R = g->M = g->E = g->S = g->Q = 0;
@@ -1458,6 +1480,16 @@ int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint
         HIPCHK(hipMemsetAsync(g->tok_cursor.p, 0, 4, st));
     }
     if (n_gb) HIPCHK(hipMemcpyAsync(g->blocks.p, gb, n_gb * sizeof(GdBlock), hipMemcpyHostToDevice, st));
+    g->h_crc.clear();
+    if (crcs && n_gb) { // the trailers' CRC-32 and the kernel's tables
+        g->h_crc.assign(crcs, crcs + n_gb);
+        if ((rc = g->crc_want.reserve(n_gb + 1))) return rc;
+        HIPCHK(hipMemcpyAsync(g->crc_want.p, g->h_crc.data(), n_gb * 4, hipMemcpyHostToDevice, st));
+        if (!g->crc_tab.p) {
+            if ((rc = g->crc_tab.reserve(1280))) return rc;
+            HIPCHK(hipMemcpyAsync(g->crc_tab.p, gamdev_crc_tables(), 1280 * 4, hipMemcpyHostToDevice, st));
+        }
+    }
     // The bytes go up in a few parts, each on a stream of its own with the inflate of its members behind it: a part's kernel runs BESIDE
     // the next part's copy and the other parts' kernels, not before them (parts on ONE stream ran one after the other).
     g->ms_upload = 0;
@@ -1486,6 +1518,7 @@ int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint
             else rc = gamdev_inflate_wave(g->in.p, g->blocks.p + b0, (uint32_t)(b1 - b0), d_out, g->status.p + b0, reinterpret_cast<uint32_t *>(g->map_rec.p), tok_cap,
                                           g->tok_cursor.p, g->tok_reg.p + (size_t)b0 * 4, g->tok_nreg.p + b0, ps);
             if (rc) return rc;
+            if (!g->h_crc.empty() && (rc = gamdev_crc(d_out, g->blocks.p + b0, (uint32_t)(b1 - b0), g->crc_want.p + b0, g->crc_tab.p, g->status.p + b0, ps))) return rc;
         }
         b0 = b1;
         ++k;
@@ -1522,7 +1555,9 @@ int vgan::gd::gd_piece_parse(vgan_gamdev *g, const GdCarry &cin, bool last_piece
     if (n_tail) HIPCHK(hipMemcpyAsync(u, cin.tail.data(), n_tail, hipMemcpyHostToDevice, st));
     for (hipStream_t ps : g->piece_stream)
         if (ps) HIPCHK(hipStreamSynchronize(ps));
-    if ((rc = gd_check_inflate(g->in.p, g->blocks.p, g->n_blocks, g->infl.p + g->tail_cap, g->status.p, st, &g->n_redone)) < 0) return rc;
+    if ((rc = gd_check_inflate(g->in.p, g->blocks.p, g->n_blocks, g->infl.p + g->tail_cap, g->status.p, st, &g->n_redone, g->h_crc.empty() ? nullptr : g->h_crc.data(),
+                               g->crc_tab.p)) < 0)
+        return rc;
     g->ms_inflate += ms_since(t0);
     g->u = u;
     g->n_stream = total;

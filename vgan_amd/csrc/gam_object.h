@@ -115,6 +115,8 @@ struct vgan_gamdev {
     vgan::gd::GBuf<vgan::gd::GdCarryState> carry;
     vgan::gd::GBuf<uint64_t> tok_reg;              // gd_tokens_kernel -> gd_lz_kernel: {first token, tokens} per block of a member (the tokens themselves borrow map_rec)
     vgan::gd::GBuf<uint32_t> tok_nreg, tok_cursor; // blocks per member; the scratch's fill
+    vgan::gd::GBuf<uint32_t> crc_want, crc_tab;    // the members' CRC-32 as their trailers say; gd_crc_kernel's tables
+    std::vector<uint32_t> h_crc;                   // (host copy of crc_want: the members the older kernel does again are checked again)
     vgan::gd::GBuf<vgan::gd::GdMapRec> map_rec; // per mapping: where its bytes lie, where its edits go (gd_fill_kernel -> gd_fill_maps_kernel)
     // one DfSlice's arrays (hc_flatten_kernels.hip) of the file's reads
     vgan::gd::GBuf<uint32_t> map_off, qual_off, edit_off, e_seq_off, m_node, seq_len;
@@ -142,7 +144,7 @@ struct vgan_gamdev {
                         &edit_off, &e_seq_off, &m_node, &seq_len, &perm_a, &perm_b, &new_flag, &new_at})
             b += x->cap * 4;
         for (auto *x : {&anchor, &next_anchor, &msg_base, &msg_off, &sort_key, &sort_key2, &picked_off, &tok_reg}) b += x->cap * 8;
-        b += (tok_nreg.cap + tok_cursor.cap) * 4;
+        b += (tok_nreg.cap + tok_cursor.cap + crc_want.cap + crc_tab.cap) * 4;
         for (auto *x : {&m_offset, &mapq, &e_len}) b += x->cap * 4;
         for (auto *x : {&unmapped, &m_rev, &e_seq, &qual, &dup, &picked_bytes}) b += x->cap;
         for (auto *x : {&first_node, &first_offset, &new_node, &new_off}) b += x->cap * 8;
@@ -155,7 +157,7 @@ struct vgan_gamdev {
             b->release();
         for (auto *b : {&anchor, &next_anchor, &msg_base, &msg_off}) b->release();
         carry.release();
-        tok_reg.release(), tok_nreg.release(), tok_cursor.release();
+        tok_reg.release(), tok_nreg.release(), tok_cursor.release(), crc_want.release(), crc_tab.release();
         map_rec.release();
         for (auto *b : {&m_offset, &mapq, &e_len}) b->release();
         for (auto *b : {&unmapped, &m_rev, &e_seq, &qual}) b->release();
@@ -171,8 +173,9 @@ namespace gd {
 // ---- a file in pieces (gam_kernels.hip): what vgan_gamdev_parse does in one go, cut at BGZF member boundaries
 // The piece's bytes go up and its members are inflated behind them (asynchronous: gd_piece_parse waits).  blocks: the piece's members,
 // in_off relative to `bytes`, out_off relative to the piece's first inflated byte; tail_cap: room kept in front of the inflated bytes
-// for what the piece before leaves over.
-int gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint64_t n_bytes, const GdBlock *blocks, size_t n_blocks, uint64_t total_out, uint64_t tail_cap);
+// for what the piece before leaves over; crcs: the members' CRC-32 as their trailers say (checked on the device: GD_BAD_CRC).
+int gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint64_t n_bytes, const GdBlock *blocks, const uint32_t *crcs, size_t n_blocks, uint64_t total_out,
+                            uint64_t tail_cap);
 // Framing from the state `in` (its tail in front of the inflated bytes) + the protobuf walk: the piece's arrays as vgan_gamdev_parse
 // leaves a file's.  `last`: the stream ends with this piece (a walk that ends inside an item is then a truncated file); otherwise `out`
 // takes the state and the bytes left over.  frame_done (or null) is called once `out` is final: the next piece's framing may start then.

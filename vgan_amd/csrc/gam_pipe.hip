@@ -57,6 +57,7 @@ vgan_gampipe_opts with_defaults(const vgan_gampipe_opts *o, uint64_t n_bytes = 0
 struct PiecePlan {
     uint64_t in0 = 0, in1 = 0;       // the piece's bytes in the file: its first member's header .. its last member's trailer
     const GdBlock *blocks = nullptr; // its members: in_off relative to in0, out_off relative to the piece's first inflated byte
+    const uint32_t *crcs = nullptr;  // ... and the CRC-32 their trailers state
     size_t n_blocks = 0;
     uint64_t out_bytes = 0;
 };
@@ -68,11 +69,12 @@ struct Cutter {
     uint64_t off = 0;
     bool bad = false, at_end = false;
     std::deque<std::vector<GdBlock>> blocks;
+    std::deque<std::vector<uint32_t>> crcs;
     std::deque<PiecePlan> pieces;
     std::mutex mu;
     Cutter(const void *bytes, uint64_t n_, uint64_t piece, uint64_t max_out_) : p((const uint8_t *)bytes), n(n_), piece_bytes(piece), max_out(max_out_) {}
 
-    bool member_at(uint64_t o, uint64_t &bsize, uint64_t &hdr, uint64_t &isize) const {
+    bool member_at(uint64_t o, uint64_t &bsize, uint64_t &hdr, uint64_t &isize, uint32_t &crc) const {
         if (n - o < 18 || p[o] != 0x1f || p[o + 1] != 0x8b || p[o + 2] != 8 || !(p[o + 3] & 4)) return false;
         const uint64_t xlen = p[o + 10] | (p[o + 11] << 8);
         if (n - o < 12 + xlen) return false;
@@ -85,6 +87,7 @@ struct Cutter {
         if (bsize < 12 + xlen + 8 || bsize > n - o) return false;
         const uint8_t *t = p + o + bsize - 4;
         isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+        crc = (uint32_t)t[-4] | ((uint32_t)t[-3] << 8) | ((uint32_t)t[-2] << 16) | ((uint32_t)t[-1] << 24);
         hdr = 12 + xlen;
         return true;
     }
@@ -92,10 +95,12 @@ struct Cutter {
         PiecePlan pc;
         pc.in0 = off;
         std::vector<GdBlock> gb;
+        std::vector<uint32_t> cr;
         uint64_t out = 0, end = off;
         while (off < n) {
             uint64_t bsize, hdr, isize;
-            if (!member_at(off, bsize, hdr, isize)) {
+            uint32_t crc;
+            if (!member_at(off, bsize, hdr, isize, crc)) {
                 bad = true;
                 break;
             }
@@ -106,6 +111,7 @@ struct Cutter {
             }
             if (!gb.empty() && (off + bsize - pc.in0 > piece_bytes || out + isize > max_out)) break;
             gb.push_back(GdBlock{off + hdr - pc.in0, out, (uint32_t)(bsize - hdr - 8), (uint32_t)isize});
+            cr.push_back(crc);
             out += isize;
             off += bsize;
             end = off;
@@ -113,8 +119,10 @@ struct Cutter {
         if (off >= n || bad) at_end = true;
         if (gb.empty()) return;
         blocks.push_back(std::move(gb));
+        crcs.push_back(std::move(cr));
         pc.in1 = end;
         pc.blocks = blocks.back().data();
+        pc.crcs = crcs.back().data();
         pc.n_blocks = blocks.back().size();
         pc.out_bytes = out;
         pieces.push_back(pc);
@@ -221,7 +229,7 @@ struct Pipe {
             }
             int rc;
             double ts[8] = {ms_since(t_start)}; // (VGAN_TIMING: when the piece's stages ended, from the pipeline's start)
-            if ((rc = gd_piece_upload_inflate(g, cut.p + pc.in0, pc.in1 - pc.in0, pc.blocks, pc.n_blocks, pc.out_bytes, o.tail_bytes)) < 0) {
+            if ((rc = gd_piece_upload_inflate(g, cut.p + pc.in0, pc.in1 - pc.in0, pc.blocks, pc.crcs, pc.n_blocks, pc.out_bytes, o.tail_bytes)) < 0) {
                 fail_with(rc, last_error());
                 break;
             }
@@ -421,7 +429,7 @@ extern "C" int vgan_gampipe_parse_piece(vgan_gamdev *g, const void *bytes, uint6
     const bool last = !c.get((size_t)piece + 1, nxt);
     if (last && c.is_bad()) return fail(VGAN_EIO, "vgan_gampipe_parse_piece: not a BGZF stream");
     int rc;
-    if ((rc = gd_piece_upload_inflate(g, c.p + pc.in0, pc.in1 - pc.in0, pc.blocks, pc.n_blocks, pc.out_bytes, o.tail_bytes)) < 0) return rc;
+    if ((rc = gd_piece_upload_inflate(g, c.p + pc.in0, pc.in1 - pc.in0, pc.blocks, pc.crcs, pc.n_blocks, pc.out_bytes, o.tail_bytes)) < 0) return rc;
     if (!*carry) *carry = new vgan_gampipe_carry();
     GdCarry out;
     if ((rc = gd_piece_parse(g, (*carry)->c, last, &out, o.keep_unmapped, nullptr, nullptr)) < 0) return rc;
