@@ -92,7 +92,7 @@ def test_full_shape_fixture_is_what_the_script_computes_on_a_sample():
     the sampled entries of the first reads' vectors are recomputed from the committed inputs."""
     p = _pyref()
     fix = json.load(open(os.path.join(FULL, "hc_pyref.json")))
-    assert fix["default"]["literal_reads_checked"] == 50 and len(fix["default"]["final_vec"]) == 5179
+    assert fix["default"]["literal_reads_checked"] == 200 and len(fix["default"]["first_reads"]) == 50 and len(fix["default"]["final_vec"]) == 5179
     seqs = p.load_gfa(os.path.join(FULL, "graph.gfa"))
     hcf = p.load_hcfiles(FULL, supports_as_numpy=True, supports_lists=False)
     alns = gamio.read_gam(os.path.join(FULL, "reads.gam"))

@@ -527,7 +527,7 @@ def segment_sums(seqs, hc, aln, background_error_prob, use_background_error_prob
     return out
 
 
-def run_full(d, background_error_prob=0.0001, use_background_error_prob=False, is_consensus_fasta=False, literal_reads=50, sample_paths=64):
+def run_full(d, background_error_prob=0.0001, use_background_error_prob=False, is_consensus_fasta=False, literal_reads=200, sample_paths=64, vector_reads=50):
     """run() at the reference's real shape (thousands of paths): the per-mapping sums in mpmath as everywhere in this file, the sum
     over a read's mappings THROUGH the path_supports rows in numpy long double (x87: 64-bit mantissa) over all paths at once -- the
     literal statement `ll[p] += supported ? mapped : unsupported` for every p -- and, for the first `literal_reads` usable reads,
@@ -557,7 +557,7 @@ def run_full(d, background_error_prob=0.0001, use_background_error_prob=False, i
             lit = read_loglik(seqs, hc, a, background_error_prob, use_background_error_prob, is_consensus_fasta)
             worst = max(abs(mp.mpf(str(ll[p_])) - lit[p_]) / abs(lit[p_]) for p_ in range(n_paths) if lit[p_] != 0)
             assert worst < mp.mpf("1e-17"), (r, worst)
-            if len(per_read) < 8:
+            if len(per_read) < vector_reads:
                 per_read.append({"read": r, "paths": pick, "loglik": [mp.nstr(lit[p_], 25) for p_ in pick]})
         used += 1
         final += ll
@@ -630,7 +630,7 @@ def make_full(d):
     open(os.path.join(d, "reads.gam"), "wb").write(gamio.write_gam(alns, group=256))
     out = {"_what": "tools/pyref_hc.py --make-full: the independent Python + mpmath restatement at the reference's shape (5 179 paths, "
                     "11 820 nodes, ~150-base reads); inputs by tools/pyref_inputs.py; NOT generated by oracle/ or by the product",
-           "default": run_full(d), "background": run_full(d, background_error_prob=0.02, use_background_error_prob=True, literal_reads=10)}
+           "default": run_full(d), "background": run_full(d, background_error_prob=0.02, use_background_error_prob=True, literal_reads=10, vector_reads=8)}
     json.dump(out, open(os.path.join(d, "hc_pyref.json"), "w"), indent=0)
     print("wrote", d, "used", out["default"]["n_used"], "undefined", len(out["default"]["undefined_reads"]))
 

@@ -21,9 +21,10 @@ def revcomp(s):
     return "".join(COMP.get(c, "N") for c in reversed(s))
 
 
-def variation_graph(seed, genome_len=700, n_paths=64, site_rate=0.16, indel_share=0.15, name_fmt="hg%05d", first_id=1):
+def variation_graph(seed, genome_len=700, n_paths=64, site_rate=0.16, indel_share=0.15, name_fmt="hg%05d", first_id=1, parent_of=None, names=None):
     """-> dict: seqs {node id: str}, paths [[node ids]], names, pos {node id: 0-based reference coordinate of its first base},
-    parent [path index or -1], genome_len."""
+    parent [path index or -1], genome_len.  parent_of / names: a given tree (parent_of[q] < q, -1 for the root) and its nodes'
+    names instead of a random one."""
     rng = random.Random(seed)
     genome = "".join(rng.choice(BASES) for _ in range(genome_len))
     elems = []  # ("node", id) shared by every path | ("site", [allele node ids]) -- an allele may be None (deletion allele)
@@ -55,7 +56,7 @@ def variation_graph(seed, genome_len=700, n_paths=64, site_rate=0.16, indel_shar
     n_sites = sum(1 for e in elems if e[0] == "site")
     parent, alleles = [-1], [[0] * n_sites]
     for q in range(1, n_paths):
-        par = rng.randrange(q)
+        par = parent_of[q] if parent_of is not None else rng.randrange(q)
         a = list(alleles[par])
         for _ in range(rng.randint(1, max(2, n_sites // 12))):
             a[rng.randrange(n_sites)] ^= 1
@@ -73,7 +74,8 @@ def variation_graph(seed, genome_len=700, n_paths=64, site_rate=0.16, indel_shar
                 if v is not None:
                     walk.append(v)
         paths.append(walk)
-    return {"seqs": seqs, "paths": paths, "names": [name_fmt % q for q in range(n_paths)], "pos": pos, "parent": parent, "genome_len": genome_len}
+    return {"seqs": seqs, "paths": paths, "names": list(names) if names is not None else [name_fmt % q for q in range(n_paths)], "pos": pos, "parent": parent,
+            "genome_len": genome_len}
 
 
 def write_gfa(path, g, with_paths=True):
@@ -253,7 +255,7 @@ def covering_graph(seed, alns, n_paths=24, name_fmt="hg%05d"):
     order = sorted(seqs)
     paths, parent = [order], [-1]
     for q in range(1, n_paths):
-        par = rng.randrange(q)
+        par = parent_of[q] if parent_of is not None else rng.randrange(q)
         keep = [v for v in paths[par] if rng.random() < 0.97]
         paths.append(keep if keep else order)
         parent.append(par)

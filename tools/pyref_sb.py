@@ -316,13 +316,96 @@ def make(d):
           [s["loglike"] for s in out["default"]["states"]])
 
 
+def newick_tree(text):
+    """(names, parent_of) of a Newick string's nodes in pre-order (the root first: parent_of[q] < q), unnamed nodes as "N<k>"."""
+    text = text.strip().rstrip(";")
+    names, parent_of = [], []
+
+    def node(i, par):
+        me = len(names)
+        names.append(None)
+        parent_of.append(par)
+        if text[i] == "(":
+            i += 1
+            while True:
+                i = node(i, me)
+                if text[i] == ",":
+                    i += 1
+                    continue
+                assert text[i] == ")"
+                i += 1
+                break
+        j = i
+        while j < len(text) and text[j] not in ",():":
+            j += 1
+        names[me] = text[i:j] or "N%d" % me
+        i = j
+        if i < len(text) and text[i] == ":":
+            j = i + 1
+            while j < len(text) and text[j] not in ",()":
+                j += 1
+            i = j
+        return i
+
+    end = node(0, -1)
+    assert end == len(text), (end, len(text))
+    return names, parent_of
+
+
+def make_full(d):
+    """The shape of the reference's own soibean test (test.cpp:243-248: the Ursidae tree, 28 nodes / 15 leaves): a graph of 28 paths drawn
+    down THAT tree (tests/golden/trees/Ursidae.new.dnd), 510 reads of 50-75 bp on both strands, states of one, two and three sources
+    with branch positions 0 and 1 and a branch of length zero (MCMC.cpp:756,906)."""
+    import pyref_inputs as pi
+    os.makedirs(d, exist_ok=True)
+    gold = os.path.join(ROOT, "tests", "golden", "damageProfiles")
+    open(os.path.join(d, "damage5p.prof"), "w").write(open(gold + "/dhigh5p.prof").read())
+    open(os.path.join(d, "damage3p.prof"), "w").write(open(gold + "/dhigh3p.prof").read())
+    names, parent_of = newick_tree(open(os.path.join(ROOT, "tests", "golden", "trees", "Ursidae.new.dnd")).read())
+    assert len(names) == 28 and sum(1 for q in range(28) if q not in parent_of) == 15, (len(names), names)
+    g = pi.variation_graph(seed=71, genome_len=1400, n_paths=28, parent_of=parent_of, names=names)
+    pi.write_hcfiles(d, g)
+    alns = []
+    for k, (n, rl) in enumerate(((170, 50), (170, 62), (170, 75))):
+        alns += pi.simulate_reads(72 + k, g, n, read_len=rl, sub_rate=0.03, indel_rate=0.08, softclip_rate=0.08, reverse_rate=0.5, low_mapq_rate=0.1, name="r%d_" % k)
+    tmp = os.path.join(d, "reads.gam")
+    open(tmp, "wb").write(gamio.write_gam(alns, group=64))
+    leaf = [q for q in range(28) if q not in parent_of]
+    inner = [q for q in range(1, 28) if q in parent_of]
+    pr = lambda q: [q, parent_of[q]]
+    states = [{"sources": [pr(leaf[0]) + [0.042357, 0.4, 1.0]], "con": 0.01},
+              {"sources": [pr(leaf[3]) + [0.0, 0.5, 1.0]], "con": 0.01},                       # a branch of length zero
+              {"sources": [pr(inner[2]) + [0.0293, 0.0, 1.0]], "con": 0.02},                   # at the branch's start
+              {"sources": [pr(leaf[5]) + [0.0036, 1.0, 1.0]], "con": 0.02},                    # ... and at its end
+              {"sources": [pr(leaf[1]) + [0.0442, 0.35, 0.6], pr(leaf[9]) + [0.0303, 0.8, 0.4]], "con": 0.01},
+              {"sources": [pr(leaf[2]) + [0.0078, 0.0, 0.5], pr(inner[5]) + [0.0011, 1.0, 0.3], pr(leaf[12]) + [0.0501, 0.25, 0.2]], "con": 0.02},
+              {"sources": [pr(leaf[14]) + [0.1128, 0.6, 0.5], pr(leaf[7]) + [0.0, 0.5, 0.3], pr(leaf[10]) + [0.0113, 0.02, 0.2]], "con": 0.015}]
+    json.dump(states, open(os.path.join(d, "states.json"), "w"))
+    for _ in range(3):
+        und = {u["read"] for u in run(d)["undefined_reads"]}
+        if not und:
+            break
+        alns = [al for r, al in enumerate(alns) if r not in und]
+        open(tmp, "wb").write(gamio.write_gam(alns, group=64))
+    out = {"_what": "tools/pyref_sb.py --make-full: the independent Python + mpmath (40 digits) restatement of soibean's analyse_GAM tables and "
+                    "state likelihood at the shape of the reference's own soibean test (the Ursidae tree: 28 paths, 15 leaves), on the inputs beside "
+                    "this file (tools/pyref_inputs.py: plain seeded Python); NOT generated by oracle/ or by the product",
+           "default": run(d)}
+    json.dump(out, open(os.path.join(d, "sb_pyref.json"), "w"), indent=0)
+    print("wrote", d, "reads", len(out["default"]["reads"]), "undefined", len(out["default"]["undefined_reads"]),
+          [s["loglike"] for s in out["default"]["states"]])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--make")
+    ap.add_argument("--make-full", help="the fixture at the shape of the reference's soibean test (Ursidae: 28 paths): tests/golden/sb_pyref_full")
     ap.add_argument("--run")
     ap.add_argument("--out")
     args = ap.parse_args()
-    if args.make:
+    if args.make_full:
+        make_full(args.make_full)
+    elif args.make:
         make(args.make)
     elif args.run:
         json.dump(run(args.run), open(args.out, "w") if args.out else sys.stdout, indent=0)

@@ -19,6 +19,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "hc_ctx.h"
 #include "hc_device.h"
 #include "host/common.h"
 #include "vgan_gpu.h"
@@ -30,122 +31,6 @@ using namespace vgan;
         hipError_t e_ = (expr);                                                                          \
         if (e_ != hipSuccess) return fail(VGAN_ENODEV, "%s failed: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
-
-namespace {
-
-template <class T> struct DevBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t n) {
-        if (n <= cap) return VGAN_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        const size_t want = n + n / 8 + 64;
-        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
-        cap = want;
-        return VGAN_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-inline bool in_range(unsigned lo, unsigned hi, unsigned x) { return lo <= x && x <= hi; }
-
-// src/get_p_obs_base.cpp:44-64 (Q1/Q2: the protein-coding rate is 0 by integer division)
-double match_prob(int pangenome_base) {
-    const unsigned b = (unsigned)pangenome_base;
-    double mu;
-    if (in_range(57, 372, b)) mu = 1.64273e-7;
-    else if (in_range(1, 56, b) || in_range(373, 576, b)) mu = 2.29640e-8;
-    else if (in_range(16384, 16569, b)) mu = 1.54555e-8;
-    else if (in_range(3307, 4262, b) || in_range(4470, 5511, b) || in_range(5904, 7445, b) || in_range(7586, 8269, b) ||
-             in_range(8366, 9990, b) || in_range(10059, 10403, b) || in_range(10470, 12137, b) ||
-             in_range(12337, 14673, b) || in_range(14747, 15886, b))
-        mu = 0.0;
-    else if (in_range(577, 647, b) || in_range(1602, 1670, b) || in_range(3230, 3304, b) || in_range(4263, 4400, b) ||
-             in_range(4402, 4469, b) || in_range(5512, 5579, b) || in_range(5587, 5654, b) || in_range(5657, 5728, b) ||
-             in_range(5761, 5891, b) || in_range(7446, 7514, b) || in_range(7518, 7585, b) || in_range(8295, 8364, b) ||
-             in_range(15888, 15953, b) || in_range(15956, 16023, b))
-        mu = 6.91285e-9;
-    else if (in_range(648, 1601, b) || in_range(1671, 3229, b)) mu = 6.91285e-9;
-    else mu = 2.48537e-8;
-    mu *= 30;
-    return pow((1 - mu), 8);
-}
-
-} // namespace
-
-// the tileable reads of one batch in the wave kernel's layout (hc_device.h: HcPackedDev), device resident
-struct vgan_hc_packed {
-    int device = 0;
-    DevBuf<uint4> rhdr;
-    DevBuf<uint32_t> srec;
-    DevBuf<uint32_t> crec;
-    DevBuf<uint8_t> qualp;
-    DevBuf<uint32_t> maxima;
-    HcPackedDev d{};
-    void release() {
-        rhdr.release();
-        srec.release();
-        crec.release();
-        qualp.release();
-        maxima.release();
-    }
-};
-
-struct vgan_hc_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    int mode = VGAN_HC_MODE_NODE_WEIGHTS;
-    uint32_t P = 0, W = 0, rows = 0, n_tiles = 0;
-    HcGraphDev g{};
-    HcParamsDev prm{};
-    DevBuf<uint64_t> umask;
-    DevBuf<uint16_t> umaskT, tile_word0;
-    DevBuf<HcNodeDev> node_tab, cls_tab;
-    DevBuf<uint16_t> node_hi;
-    DevBuf<double> tables; // lq[256] qscore[100] incmap[100]
-    DevBuf<double> col_memo, col_memo2; // hc_col8_kernels.hip: the tables of column terms
-    DevBuf<double> accum;                                    // one block: nodeW | acc_seg | acc_node | totals (one memset)
-    struct View { double *p = nullptr; } nodeW, acc_seg, acc_node, totals;
-    size_t accum_n = 0;
-    DevBuf<double> final_vec;
-    DevBuf<double> segD, segS, segU, dump;
-    // staging for host batches
-    DevBuf<uint32_t> s_u32;
-    DevBuf<uint16_t> s_u16;
-    DevBuf<uint8_t> s_u8;
-    vgan_hc_packed scratch_pack; // layout pass output of batches that come without a packed companion
-    DevBuf<uint32_t> work_ctr;   // the segment kernel's work queue (hc_wave_kernels.hip)
-    uint32_t work_base = 0;
-    bool work_dirty = false;     // a launch failed or the stream changed: counter and mirror start over
-    bool touched = false;        // something was accumulated since the last reset (vgan_hc_reduce leaves the others out)
-    // posterior
-    std::vector<std::string> path_names;
-    std::unordered_map<std::string, uint32_t> path_index;
-    std::unordered_map<std::string, std::vector<std::string>> parents, children;
-    DevBuf<uint32_t> lists; // posterior: list offsets, then the path indices
-    DevBuf<double> conf;
-    // posterior: name -> path indices (built at the first call), and the lists of the last predicted haplotype as they sit on
-    // the device (a caller asks about the same prediction again and again: the walk and its upload are done once)
-    std::unordered_map<std::string, std::vector<uint32_t>> by_name;
-    std::string post_predicted, post_clades;
-    uint32_t post_n_off = 0, post_ns = 0;
-    // profiling: pairs of events per timed launch, resolved in vgan_hc_profile_read
-    int profiling = 0; // 0 off, 1 HIP events around every kernel, 2 around the segment kernel only
-    struct Timed {
-        int slot;
-        hipEvent_t a, b;
-    };
-    std::vector<Timed> timed;
-    std::vector<hipEvent_t> event_pool;
-    double prof_ms[VGAN_HC_K_COUNT] = {0, 0, 0, 0, 0};
-    uint64_t prof_n[VGAN_HC_K_COUNT] = {0, 0, 0, 0, 0};
-};
 
 vgan::HcCtxInfo vgan::hc_ctx_info(const vgan_hc_ctx *c) { return HcCtxInfo{c->device, c->stream, c->rows}; }
 
@@ -179,22 +64,6 @@ struct ScopedTimer {
 } // namespace
 
 namespace {
-
-void parse_relatives(const char *txt, std::unordered_map<std::string, std::vector<std::string>> &rel) {
-    // src/load.cpp:303-345: "name tok tok ...", tokens containing '[' dropped, first insertion wins
-    std::istringstream in(txt ? txt : "");
-    std::string line, tok;
-    while (std::getline(in, line)) {
-        std::istringstream ls(line);
-        std::vector<std::string> t;
-        while (ls >> tok) t.push_back(tok);
-        if (t.empty()) continue;
-        std::vector<std::string> v;
-        for (size_t j = 1; j < t.size(); ++j)
-            if (t[j].find('[') == std::string::npos) v.push_back(t[j]);
-        rel.emplace(t[0], std::move(v));
-    }
-}
 
 int stage_batch(vgan_hc_ctx *c, const vgan_hc_batch *b, HcBatchDev &d) {
     d.n_reads = b->n_reads;
@@ -449,267 +318,6 @@ int run_packed(vgan_hc_ctx *c, const HcPackedDev &d, double *segD, double *nodeW
 }
 
 } // namespace
-
-extern "C" int vgan_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-// The first HIP call of a process loads the runtime and the library's code objects (~0.25 s): a front end calls this on a
-// thread of its own at start-up, while it reads its graph, so that the context creation finds the device ready.
-extern "C" int vgan_device_warmup(int device) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(VGAN_ENODEV, "vgan_device_warmup: no HIP device %d", device);
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipFree(nullptr));
-    return VGAN_OK;
-}
-
-extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *params, int device, vgan_hc_ctx **out) {
-    if (!gv || !params || !out) return fail(VGAN_EINVAL, "vgan_hc_create: null argument");
-    if (gv->n_paths == 0 || gv->max_id < 0 || !gv->mask || !gv->pangenome_base || !gv->mappability)
-        return fail(VGAN_EINVAL, "vgan_hc_create: incomplete graph view");
-    if (!(params->background_error_prob >= 0.0 && params->background_error_prob <= 1.0))
-        return fail(VGAN_EINVAL, "Error: background error probability must be between 0 and 1"); // HaploCart.cpp:107-113
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(VGAN_ENODEV, "vgan_hc_create: no HIP device is visible (this library has no CPU path)");
-    if (device < 0 || device >= ndev) return fail(VGAN_EINVAL, "vgan_hc_create: device %d out of range (%d visible)", device, ndev);
-    HIPCHK(hipSetDevice(device));
-    auto c = new vgan_hc_ctx();
-    c->device = device;
-    c->P = gv->n_paths;
-    c->W = (gv->n_paths + 63) / 64;
-    c->rows = (uint32_t)gv->max_id + 1;
-    c->n_tiles = 8 * ((c->W + 126) / 127); // at most 16 words per tile (one bit each in a 16-bit entry): floor(W / n_tiles) <= 15
-    c->prm.bep = params->background_error_prob;
-    c->prm.use_bep = params->use_background_error_prob != 0;
-    c->prm.consensus = params->is_consensus_fasta != 0;
-    int rc = VGAN_OK;
-    auto bail = [&](int code) {
-        vgan_hc_destroy(c);
-        return code;
-    };
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(fail(VGAN_ENODEV, "hipStreamCreate failed"));
-    c->stream = c->own_stream;
-    // unsupported-path mask: plain rows + the per-tile bit-transposed copy the sweep reads (hc_device.h)
-    std::vector<uint64_t> um((size_t)c->rows * c->W, 0);
-    for (uint32_t r = 0; r < c->rows; ++r) {
-        const uint64_t *src = gv->mask + (size_t)r * c->W;
-        uint64_t *dst = &um[(size_t)r * c->W];
-        for (uint32_t w = 0; w < c->W; ++w) {
-            uint64_t valid = ~0ull;
-            if (w == c->W - 1 && (c->P & 63)) valid = (1ull << (c->P & 63)) - 1;
-            dst[w] = ~src[w] & valid;
-        }
-    }
-    const uint32_t tile_base = c->W / c->n_tiles, tile_rem = c->W % c->n_tiles;
-    if (tile_base > 15) return bail(fail(VGAN_ERANGE, "vgan_hc_create: internal tile split out of range (%u words per tile)", tile_base));
-    std::vector<uint16_t> tw0(c->n_tiles + 1, 0);
-    for (uint32_t t = 0; t < c->n_tiles; ++t) tw0[t + 1] = (uint16_t)(tw0[t] + tile_base + (t < tile_rem ? 1 : 0));
-    const uint32_t row_entries = c->n_tiles * 64;
-    std::vector<uint16_t> umT((size_t)c->rows * row_entries, 0);
-    {
-        auto rows_range = [&](uint32_t r0, uint32_t r1) {
-            for (uint32_t r = r0; r < r1; ++r) {
-                const uint64_t *src = &um[(size_t)r * c->W];
-                uint16_t *dst = &umT[(size_t)r * row_entries];
-                for (uint32_t t = 0; t < c->n_tiles; ++t) {
-                    for (uint32_t k = 0; k < (uint32_t)(tw0[t + 1] - tw0[t]); ++k) {
-                        uint64_t bits = src[tw0[t] + k];
-                        while (bits) {
-                            const int l = __builtin_ctzll(bits);
-                            bits &= bits - 1;
-                            dst[t * 64 + l] |= (uint16_t)(1u << (15 - k));
-                        }
-                    }
-                }
-            }
-        };
-        const uint32_t nth = std::min<uint32_t>(16, std::max<uint32_t>(1, std::min<uint32_t>(std::thread::hardware_concurrency(), c->rows / 256)));
-        if (nth <= 1) {
-            rows_range(0, c->rows);
-        } else {
-            std::vector<std::thread> th;
-            for (uint32_t t = 0; t < nth; ++t)
-                th.emplace_back(rows_range, (uint32_t)((uint64_t)c->rows * t / nth), (uint32_t)((uint64_t)c->rows * (t + 1) / nth));
-            for (auto &t : th) t.join();
-        }
-    }
-    std::vector<HcNodeDev> nt(c->rows);
-    const bool consensus = params->is_consensus_fasta != 0;
-    for (uint32_t r = 0; r < c->rows; ++r) {
-        const int32_t pb = gv->pangenome_base[r];
-        double mp = 0.0, mt = 1.0;
-        if (pb >= 0 && (uint64_t)pb < gv->n_mappability) {
-            mp = gv->mappability[pb];
-            mt = match_prob(pb);
-        }
-        // log(0) = -inf and 1/0 = inf are meant: the kernel scores such a segment from wbg alone (hc_kernels.hip)
-        const long double mm = (long double)mp * (long double)mt;
-        nt[r] = {(double)logl(consensus ? (long double)mt : mm), (double)(1.0L / mm), mp, mt};
-    }
-    // node classes: the distinct {ln_w, inv_mm, mappability} triples, most frequent first (hc_col8_kernels.hip keeps a table of
-    // column terms for the first HC_MEMO_CLASSES of them in LDS and one for all of them in HBM; a graph with more than
-    // HC_EXT_NODE_CLASSES -- a mappability track with that many distinct values -- takes the older kernels)
-    std::vector<HcNodeDev> cls;
-    std::vector<uint16_t> nhi(c->rows, 0);
-    {
-        auto same = [](const HcNodeDev &x, const HcNodeDev &y) { return memcmp(&x, &y, 3 * sizeof(double)) == 0; };
-        std::vector<uint32_t> of(c->rows), cnt;
-        bool many = false;
-        for (uint32_t r = 0; r < c->rows && !many; ++r) {
-            uint32_t k = 0;
-            while (k < cls.size() && !same(cls[k], nt[r])) ++k;
-            if (k == cls.size()) {
-                if (cls.size() == HC_EXT_NODE_CLASSES) {
-                    many = true;
-                    break;
-                }
-                cls.push_back(nt[r]);
-                cnt.push_back(0);
-            }
-            of[r] = k;
-            cnt[k]++;
-        }
-        if (many) {
-            cls.clear();
-        } else {
-            std::vector<uint32_t> ord(cls.size()), rank(cls.size());
-            for (uint32_t k = 0; k < ord.size(); ++k) ord[k] = k;
-            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return cnt[x] > cnt[y]; });
-            std::vector<HcNodeDev> sorted(cls.size());
-            for (uint32_t i = 0; i < ord.size(); ++i) {
-                rank[ord[i]] = i;
-                sorted[i] = cls[ord[i]];
-            }
-            cls.swap(sorted);
-            for (uint32_t r = 0; r < c->rows; ++r) {
-                const uint32_t k = rank[of[r]];
-                nhi[r] = (uint16_t)(k < HC_MEMO_CLASSES ? k * HC_MEMO_CLASS_BYTES : 0xE000u | k);
-            }
-        }
-    }
-    std::vector<double> tb(756);
-    for (int bte = 0; bte < 256; ++bte) { // src/miscfunc.h:180-188 on int(char)
-        const int Q = (int)(int8_t)bte;
-        tb[bte] = log(Q > 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25);
-    }
-    for (int Q = 0; Q < 100; ++Q) { // src/miscfunc.h:199-212, src/haplocart_functions.cpp:101-107
-        tb[256 + Q] = Q > 2 ? pow(10, ((-1 * Q) * 0.1)) : 0.25;
-        tb[356 + Q] = pow(10, ((-1 * Q) * 0.1));
-        const double om = 1.0 - tb[356 + Q]; // process_mapping.cpp:41: pcm = (1 - incorrect_mapping_vec[mapq]) * mappability
-        tb[456 + 3 * Q] = om;
-        tb[456 + 3 * Q + 1] = consensus ? (double)logl(1.0L - (long double)params->background_error_prob) : (double)logl((long double)om);
-        tb[456 + 3 * Q + 2] = (double)(1.0L / (long double)om);
-    }
-    const size_t accn = (size_t)c->W * 64;
-    if ((rc = c->umask.reserve(um.size())) || (rc = c->umaskT.reserve(umT.size())) ||
-        (rc = c->tile_word0.reserve(tw0.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(756)) ||
-        (rc = c->node_hi.reserve(nhi.size())) || (rc = c->cls_tab.reserve(std::max<size_t>(1, cls.size()))) ||
-        (rc = c->accum.reserve(((size_t)c->rows + 7) / 8 * 8 + 2 * accn + HC_TOTAL_SLOTS * HC_TOTAL_STRIDE)) || (rc = c->final_vec.reserve(c->P)))
-        return bail(rc);
-    { // sub-ranges of the accumulator block (sweep kernels read 64-byte aligned blocks of weights: keep 64-byte offsets)
-        const size_t nW = ((size_t)c->rows + 7) / 8 * 8;
-        c->nodeW.p = c->accum.p;
-        c->acc_seg.p = c->accum.p + nW;
-        c->acc_node.p = c->acc_seg.p + accn;
-        c->totals.p = c->acc_node.p + accn;
-        c->accum_n = nW + 2 * accn + HC_TOTAL_SLOTS * HC_TOTAL_STRIDE;
-    }
-    if (hipMemcpy(c->umask.p, um.data(), um.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->umaskT.p, umT.data(), umT.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->tile_word0.p, tw0.data(), tw0.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->node_tab.p, nt.data(), nt.size() * sizeof(HcNodeDev), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->tables.p, tb.data(), tb.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->node_hi.p, nhi.data(), nhi.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
-        (!cls.empty() && hipMemcpy(c->cls_tab.p, cls.data(), cls.size() * sizeof(HcNodeDev), hipMemcpyHostToDevice) != hipSuccess))
-        return bail(fail(VGAN_ENODEV, "vgan_hc_create: upload failed"));
-    c->g.umask = c->umask.p;
-    c->g.umaskT = c->umaskT.p;
-    c->g.tile_word0 = c->tile_word0.p;
-    c->g.node_tab = c->node_tab.p;
-    c->g.lq = c->tables.p;
-    c->g.qscore = c->tables.p + 256;
-    c->g.incmap = c->tables.p + 356;
-    c->g.rdtab = c->tables.p + 456;
-    c->g.node_hi = c->node_hi.p;
-    c->g.cls_tab = c->cls_tab.p;
-    c->g.n_cls = (uint32_t)cls.size();
-    c->g.col_memo = nullptr;
-    c->g.col_memo2 = nullptr;
-    if (c->g.n_cls) { // the table of column terms (a pure function of the graph's node classes and the error-rate parameters)
-        if ((rc = c->col_memo.reserve(hc_col8_memo_doubles()))) return bail(rc);
-        launch_hc_col8_memo(c->g, c->prm, c->col_memo.p, c->stream);
-        if (hipGetLastError() != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: the table of column terms could not be built"));
-        c->g.col_memo = c->col_memo.p;
-        if ((rc = c->col_memo2.reserve(hc_col8_memo2_doubles(c->g.n_cls)))) return bail(rc);
-        launch_hc_col8_memo2(c->g, c->prm, c->col_memo2.p, c->stream);
-        if (hipGetLastError() != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: the wide table of column terms could not be built"));
-        c->g.col_memo2 = c->col_memo2.p;
-    }
-    c->g.rows = c->rows;
-    c->g.mask_words = c->W;
-    c->g.row_entries = row_entries;
-    c->g.n_tiles = c->n_tiles;
-    c->g.tile_base_words = tile_base;
-    c->g.n_paths = c->P;
-    // posterior side tables
-    {
-        std::istringstream in(gv->path_names ? gv->path_names : "");
-        std::string line;
-        while (std::getline(in, line)) {
-            std::istringstream ls(line);
-            std::string tok;
-            if (!(ls >> tok)) continue;
-            c->path_index.emplace(tok, (uint32_t)c->path_names.size());
-            c->path_names.push_back(tok);
-        }
-        parse_relatives(gv->parents_txt, c->parents);
-        parse_relatives(gv->children_txt, c->children);
-    }
-    if ((rc = vgan_hc_reset(c))) return bail(rc);
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: sync failed"));
-    *out = c;
-    return VGAN_OK;
-}
-
-extern "C" void vgan_hc_destroy(vgan_hc_ctx *c) {
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    c->umask.release();
-    c->umaskT.release();
-    c->tile_word0.release();
-    c->node_tab.release();
-    c->cls_tab.release();
-    c->col_memo.release();
-    c->col_memo2.release();
-    c->node_hi.release();
-    c->tables.release();
-    c->accum.release();
-    c->final_vec.release();
-    c->segD.release();
-    c->segS.release();
-    c->segU.release();
-    c->dump.release();
-    c->s_u32.release();
-    c->s_u16.release();
-    c->s_u8.release();
-    c->scratch_pack.release();
-    c->work_ctr.release();
-    c->lists.release();
-    c->conf.release();
-    for (auto &t : c->timed) {
-        (void)hipEventDestroy(t.a);
-        (void)hipEventDestroy(t.b);
-    }
-    for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-    delete c;
-}
 
 extern "C" int vgan_hc_set_stream(vgan_hc_ctx *c, void *hip_stream) {
     if (!c) return fail(VGAN_EINVAL, "vgan_hc_set_stream: null context");
@@ -1015,177 +623,6 @@ extern "C" int vgan_hc_finalize(vgan_hc_ctx *c, double *d_out, double *out) {
         HIPCHK(hipMemcpyAsync(out, c->final_vec.p, (size_t)c->P * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    return VGAN_OK;
-}
-
-// ---------------------------------------------------------------------------------------------- several GPUs, one process
-// RCCL is bound at run time (dlopen) and only on this path: the library carries no link-time dependency on it, and a
-// process that already holds another RCCL (PyTorch ships its own) never sees two.
-namespace {
-struct Rccl {
-    void *h = nullptr;
-    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    bool ok = false;
-    std::string why_not; // (not ok: what was missing)
-    Rccl() {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (h) break;
-        }
-        if (!h) {
-            const char *e = dlerror();
-            why_not = std::string("librccl could not be loaded") + (e ? std::string(": ") + e : std::string());
-            return;
-        }
-        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
-        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
-        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
-        GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
-        Reduce = (decltype(Reduce))dlsym(h, "ncclReduce");
-        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
-        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Reduce;
-        if (!ok) why_not = "librccl lacks one of ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclReduce";
-    }
-};
-Rccl &rccl() {
-    static Rccl r;
-    return r;
-}
-// one communicator per set of devices, for the life of the process (never destroyed: RCCL tears down with the runtime)
-struct CommCache {
-    std::mutex mu;
-    std::map<std::vector<int>, std::vector<ncclComm_t>> m;
-    double last_setup_ms = 0.0, last_reduce_ms = 0.0; // (the reduce's wall time includes a set-up made inside it)
-    int n_setups = 0, last_was_rccl = 0;
-    std::string last_why; // why the last reduce was summed on the host ("" when it went through RCCL)
-};
-CommCache &comm_cache() {
-    static CommCache c;
-    return c;
-}
-} // namespace
-
-// Sum over contexts of final_vec (src/HaploCart.cpp:419-420, the accumulate the reference does under `omp critical`, here
-// across GPUs): every context finalizes on its own device, then ONE reduce of P doubles onto the first context's device --
-// ncclReduce over the contexts' streams when they sit on distinct devices (xGMI), through the host otherwise (several
-// contexts on one device, RCCL not loadable).  out: host double[P].  *used_rccl (or NULL) tells which way it went.
-extern "C" int vgan_hc_reduce(vgan_hc_ctx **ctxs, int n, double *out, int *used_rccl) {
-    if (!ctxs || n <= 0 || !out) return fail(VGAN_EINVAL, "vgan_hc_reduce: null argument");
-    for (int i = 0; i < n; ++i)
-        if (!ctxs[i] || ctxs[i]->P != ctxs[0]->P) return fail(VGAN_EINVAL, "vgan_hc_reduce: contexts of different graphs");
-    const uint32_t P = ctxs[0]->P;
-    int rc;
-    if (used_rccl) *used_rccl = 0;
-    // contexts nothing was accumulated into add nothing: a short input that reached one GPU only is that context's finalize,
-    // whatever the number of contexts standing by
-    std::vector<vgan_hc_ctx *> live;
-    for (int i = 0; i < n; ++i)
-        if (ctxs[i]->touched) live.push_back(ctxs[i]);
-    if (live.size() <= 1) return vgan_hc_finalize(live.empty() ? ctxs[0] : live[0], nullptr, out);
-    const bool partial = (int)live.size() < n; // (a communicator is per device set: a partial set goes through the host)
-    if (partial) {
-        ctxs = live.data();
-        n = (int)live.size();
-    }
-    for (int i = 0; i < n; ++i)
-        if ((rc = vgan_hc_finalize(ctxs[i], nullptr, nullptr))) return rc; // final_vec on every device, asynchronously
-    bool distinct = n > 1 && !partial;
-    for (int i = 0; i < n && distinct; ++i)
-        for (int j = 0; j < i; ++j) distinct = distinct && ctxs[i]->device != ctxs[j]->device;
-    // Contexts on distinct devices reduce with ncclReduce over xGMI (BASELINE.json's north_star: reads shard across GPUs, one RCCL
-    // reduce of the per-path vector): the communicator is created once per device set and kept for the life of the process
-    // (its set-up time is reported: vgan_hc_reduce_info).  VGAN_HC_REDUCE=host keeps the sum on the host -- for ONE reduce of
-    // 41 KB per context that is the cheaper way, a communicator costs more to set up than it saves --, contexts sharing a
-    // device always take it, and so does a set for which RCCL cannot be loaded or initialised.
-    const auto t_red0 = std::chrono::steady_clock::now();
-    const char *how = getenv("VGAN_HC_REDUCE");
-    std::string why; // the host sum is never taken silently: vgan_hc_reduce_why() says what sent the reduce there
-    if (!distinct) why = partial ? "a chunk reached only some of the contexts (a communicator is per device set)" : "contexts share a device";
-    else if (how && strcmp(how, "host") == 0) why = "VGAN_HC_REDUCE=host";
-    else if (!rccl().ok) why = rccl().why_not;
-    if (distinct && rccl().ok && !(how && strcmp(how, "host") == 0)) {
-        std::vector<int> devs((size_t)n);
-        for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
-        std::vector<ncclComm_t> *comms = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(comm_cache().mu);
-            auto it = comm_cache().m.find(devs);
-            if (it != comm_cache().m.end()) {
-                comms = &it->second;
-            } else {
-                std::vector<ncclComm_t> fresh((size_t)n, nullptr);
-                const auto t0 = std::chrono::steady_clock::now();
-                const ncclResult_t ir = rccl().CommInitAll(fresh.data(), n, devs.data());
-                if (ir == ncclSuccess) {
-                    comm_cache().last_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                    comm_cache().n_setups += 1;
-                    comms = &(comm_cache().m[devs] = std::move(fresh));
-                } else {
-                    why = std::string("ncclCommInitAll failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(ir) : "unknown error");
-                }
-            }
-        }
-        if (comms) {
-            bool good = rccl().GroupStart() == ncclSuccess;
-            for (int i = 0; i < n && good; ++i) {
-                good = hipSetDevice(ctxs[i]->device) == hipSuccess &&
-                       rccl().Reduce(ctxs[i]->final_vec.p, ctxs[i]->final_vec.p, P, ncclDouble, ncclSum, 0, (*comms)[(size_t)i], ctxs[i]->stream) == ncclSuccess;
-            }
-            good = rccl().GroupEnd() == ncclSuccess && good;
-            for (int i = 0; i < n; ++i) {
-                (void)hipSetDevice(ctxs[i]->device);
-                good = hipStreamSynchronize(ctxs[i]->stream) == hipSuccess && good;
-            }
-            if (!good) return fail(VGAN_ENODEV, "vgan_hc_reduce: the RCCL reduce failed");
-            HIPCHK(hipSetDevice(ctxs[0]->device));
-            HIPCHK(hipMemcpy(out, ctxs[0]->final_vec.p, (size_t)P * 8, hipMemcpyDeviceToHost));
-            if (used_rccl) *used_rccl = 1;
-            std::lock_guard<std::mutex> lk(comm_cache().mu);
-            comm_cache().last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_red0).count();
-            comm_cache().last_was_rccl = 1;
-            comm_cache().last_why.clear();
-            return VGAN_OK;
-        }
-    }
-    std::vector<double> part(P);
-    for (uint32_t p = 0; p < P; ++p) out[p] = 0.0;
-    for (int i = 0; i < n; ++i) {
-        HIPCHK(hipSetDevice(ctxs[i]->device));
-        HIPCHK(hipMemcpyAsync(part.data(), ctxs[i]->final_vec.p, (size_t)P * 8, hipMemcpyDeviceToHost, ctxs[i]->stream));
-        HIPCHK(hipStreamSynchronize(ctxs[i]->stream));
-        for (uint32_t p = 0; p < P; ++p) out[p] += part[p];
-    }
-    {
-        std::lock_guard<std::mutex> lk(comm_cache().mu);
-        comm_cache().last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_red0).count();
-        comm_cache().last_was_rccl = 0;
-        comm_cache().last_why = why;
-    }
-    return VGAN_OK;
-}
-
-extern "C" int vgan_hc_reduce_why(char *buf, int64_t cap) {
-    std::lock_guard<std::mutex> lk(comm_cache().mu);
-    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", comm_cache().last_why.c_str());
-    return comm_cache().last_was_rccl;
-}
-
-extern "C" int vgan_hc_reduce_last(double *reduce_ms, int *was_rccl) {
-    std::lock_guard<std::mutex> lk(comm_cache().mu);
-    if (reduce_ms) *reduce_ms = comm_cache().last_reduce_ms;
-    if (was_rccl) *was_rccl = comm_cache().last_was_rccl;
-    return VGAN_OK;
-}
-
-extern "C" int vgan_hc_reduce_info(double *last_setup_ms, int *n_setups) {
-    std::lock_guard<std::mutex> lk(comm_cache().mu);
-    if (last_setup_ms) *last_setup_ms = comm_cache().last_setup_ms;
-    if (n_setups) *n_setups = comm_cache().n_setups;
     return VGAN_OK;
 }
 
