@@ -42,7 +42,7 @@ for tag, env in (("host", {"VGAN_EUKA_DEVICE_GAM": "0"}), ("device", {"VGAN_EUKA
     cpu = (c1.children_user - c0.children_user) + (c1.children_system - c0.children_system)
     print("%-8s rc=%d  %.2f s wall, %.2f s of host CPU, %.2f M reads/s" % (tag, r.returncode, dt, cpu, n / dt / 1e6), flush=True)
     for ln in r.stderr.splitlines():
-        if "device front end" in ln or "does not take" in ln or "Number of" in ln or ("[vgan timing] euka:" in ln):
+        if "device front end" in ln or "does not take" in ln or "Number of" in ln or ("[vgan timing] euka:" in ln) or ("gampipe piece" in ln and tag == "device2" and os.environ.get("E2E_PIECES")):
             print("   ", ln[:700])
     if r.returncode:
         print(r.stderr[-1500:])

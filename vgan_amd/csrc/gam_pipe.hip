@@ -930,21 +930,26 @@ extern "C" int vgan_euka_gam_finish(vgan_euka_gamrun *r, vgan_euka_gam_result *r
     r->pst.ms_wait_contexts = r->ms_wait_contexts;
     if (pstats) *pstats = r->pst;
     if (r->rc < 0) return fail(r->rc, "%s", r->err.c_str());
-    { // the per-read lists in the order of the file
-        const size_t nr = r->idx.size();
-        std::vector<uint32_t> ord(nr);
-        for (size_t i = 0; i < nr; ++i) ord[i] = (uint32_t)i;
-        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return r->idx[a] < r->idx[b]; });
-        std::vector<uint32_t> i2(nr);
-        std::vector<int32_t> c2(nr);
-        std::vector<uint8_t> p2(nr);
-        std::vector<uint16_t> l2(nr);
-        for (size_t i = 0; i < nr; ++i) {
-            i2[i] = r->idx[ord[i]];
-            c2[i] = r->clade[ord[i]];
-            p2[i] = r->pass[ord[i]];
-            l2[i] = r->len[ord[i]];
+    { // the per-read lists in the order of the file: every index below n_mapped occurs at most once -- a placement, not a sort
+      // (std::sort through an index array took 0.4 s for 5 M reads: as long as the whole pipeline)
+        const size_t nr = r->idx.size(), nm = (size_t)r->pst.n_reads;
+        std::vector<uint32_t> at(nm, 0xFFFFFFFFu);
+        for (size_t i = 0; i < nr; ++i)
+            if (r->idx[i] < nm) at[r->idx[i]] = (uint32_t)i;
+        std::vector<uint32_t> i2;
+        std::vector<int32_t> c2;
+        std::vector<uint8_t> p2;
+        std::vector<uint16_t> l2;
+        i2.reserve(nr), c2.reserve(nr), p2.reserve(nr), l2.reserve(nr);
+        for (size_t k = 0; k < nm; ++k) {
+            const uint32_t i = at[k];
+            if (i == 0xFFFFFFFFu) continue;
+            i2.push_back((uint32_t)k);
+            c2.push_back(r->clade[i]);
+            p2.push_back(r->pass[i]);
+            l2.push_back(r->len[i]);
         }
+        if (i2.size() != nr) return fail(VGAN_ESTATE, "vgan_euka_gam_finish: %zu results for %zu distinct reads", nr, i2.size());
         r->idx.swap(i2), r->clade.swap(c2), r->pass.swap(p2), r->len.swap(l2);
     }
     if (res) {
