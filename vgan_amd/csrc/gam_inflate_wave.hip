@@ -693,6 +693,21 @@ __global__ __launch_bounds__(64) void gd_lzw_kernel(const GdBlock *__restrict__ 
             }
             uint32_t x = gw_scan_incl(sum, lane) - sum, taken = 0, w_end = 0;
             bool bad = false;
+            // the bytes a match takes from BEFORE the window (written out already): asked for now, all of the lane's tokens' at once -- eight
+            // bytes a match, which is most matches whole -- and put into the references below (a load per byte inside that loop was a trip
+            // to L2 per byte, one after the other: most of this kernel's time)
+            uint64_t pre[GW_TPL];
+            {
+                uint32_t xx = x;
+#pragma unroll
+                for (uint32_t j = 0; j < GW_TPL; ++j) {
+                    const uint32_t kind = t[j] >> 30, len = i0 + j < n ? (kind ? kind : (t[j] & 511u)) : 0u;
+                    const uint32_t dist = ((t[j] >> 9) & 0x7FFFu) + 1u;
+                    pre[j] = 0;
+                    if (!kind && len && xx + len <= GW_W && dist > xx && dist <= pos + xx) pre[j] = reinterpret_cast<const GwU64 *>(o + (pos + xx - dist))->v;
+                    xx += len;
+                }
+            }
             __syncthreads(); // (the window before is written out)
 #pragma unroll
             for (uint32_t j = 0; j < GW_TPL; ++j) {
@@ -707,10 +722,10 @@ __global__ __launch_bounds__(64) void gd_lzw_kernel(const GdBlock *__restrict__ 
                         bad = true;
                         break;
                     }
-                    for (uint32_t q = 0; q < len; ++q) {
-                        const int32_t src = (int32_t)(x + q) - (int32_t)dist;
-                        ref[x + q] = src >= 0 ? (uint16_t)src : (uint16_t)(0x8000u | o[(int32_t)pos + src]);
-                    }
+                    const uint32_t n_ext = dist > x ? min(len, dist - x) : 0u; // bytes whose source lies before the window
+                    for (uint32_t q = 0; q < min(n_ext, 8u); ++q) ref[x + q] = (uint16_t)(0x8000u | ((uint32_t)(pre[j] >> (8u * q)) & 255u));
+                    for (uint32_t q = 8u; q < n_ext; ++q) ref[x + q] = (uint16_t)(0x8000u | o[pos + x + q - dist]); // (a long match across the window's start)
+                    for (uint32_t q = n_ext; q < len; ++q) ref[x + q] = (uint16_t)(x + q - dist);
                 }
                 x += len;
                 taken += 1;
