@@ -212,9 +212,11 @@ def test_the_cpp_euka_oracle_agrees_with_the_python_restatement_on_the_shipped_t
 
 # ---------------------------------------------------------------------------------------------------------------- soibean
 SFIX = os.path.join(HERE, "golden", "sb_pyref")
+SFIX_FULL = os.path.join(HERE, "golden", "sb_pyref_full")  # the shape of the reference's own soibean test (test.cpp:243-248: Ursidae, 28 paths)
+SFIXES = [SFIX, SFIX_FULL]
 
 
-def _sb_inputs():
+def _sb_inputs(SFIX=SFIX):
     from vgan_amd import haplocart as hc
     g = hc.Graph.load(os.path.join(SFIX, "graph.gfa"), SFIX)
     a = hc.AlnSet.read_gam(os.path.join(SFIX, "reads.gam"), keep_unmapped=True)
@@ -222,7 +224,8 @@ def _sb_inputs():
     return g, a, texts
 
 
-def test_soibean_restatement_recomputes_its_fixture_on_a_sample():
+@pytest.mark.parametrize("SFIX", SFIXES, ids=["sb_pyref", "sb_pyref_full"])
+def test_soibean_restatement_recomputes_its_fixture_on_a_sample(SFIX):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pyref_sb as ps
     fix = json.load(open(os.path.join(SFIX, "sb_pyref.json")))["default"]
@@ -233,9 +236,10 @@ def test_soibean_restatement_recomputes_its_fixture_on_a_sample():
         assert [ps.mp.nstr(x, 25) for x in pm] == rec["pm"]
 
 
-def test_the_cpp_soibean_oracle_agrees_with_the_python_restatement():
+@pytest.mark.parametrize("SFIX", SFIXES, ids=["sb_pyref", "sb_pyref_full"])
+def test_the_cpp_soibean_oracle_agrees_with_the_python_restatement(SFIX):
     fix = json.load(open(os.path.join(SFIX, "sb_pyref.json")))["default"]
-    g, a, texts = _sb_inputs()
+    g, a, texts = _sb_inputs(SFIX)
     og, oa = util.orc_graph_from_product(g), util.orc_alnset_from_product(a)
     findable = np.array([len(n) <= 101 for n in g.path_names], np.uint8)
     o = orc.SbOracle(og, oa, orc.OrcDamage(*texts), penalty=fix["params"]["penalty"], path_findable=findable)

@@ -126,14 +126,18 @@ def test_euka_on_the_shipped_335_clade_tables_against_the_python_restatement():
     check_euka_against_fixture(got, fin, fix, list(hb.arrays()["read_src"]), 1e-9)
 
 
-def test_soibean_tables_and_state_likelihoods_against_the_python_restatement():
-    """tools/pyref_sb.py's fixture (tests/golden/sb_pyref/): pathMap and the (reference, read) pair counts per read and path,
-    and the log-likelihood of k = 1 and k = 3 states computed by the restatement from the per-base records themselves."""
-    from test_pyref_cpu import _sb_inputs, SFIX
+@pytest.mark.parametrize("which", ["sb_pyref", "sb_pyref_full"])
+def test_soibean_tables_and_state_likelihoods_against_the_python_restatement(which):
+    """tools/pyref_sb.py's fixtures (tests/golden/sb_pyref/: 12 paths, 120 reads; sb_pyref_full/: the Ursidae tree's 28 paths, 510 reads
+    of 50-75 bp, states of one, two and three sources with branch positions 0 and 1 and a branch of length zero): pathMap and the
+    (reference, read) pair counts per read and path, and the log-likelihood of the states computed by the restatement from the per-base
+    records themselves."""
+    from test_pyref_cpu import _sb_inputs, HERE
     from vgan_amd import euka as ek
     from vgan_amd import soibean as sb
+    SFIX = os.path.join(HERE, "golden", which)
     fix = json.load(open(os.path.join(SFIX, "sb_pyref.json")))["default"]
-    g, a, texts = _sb_inputs()
+    g, a, texts = _sb_inputs(SFIX)
     hb = sb.SbHostBatch(g, a)
     assert hb.stats.n_bad == 0 and hb.n_reads == len(fix["reads"])
     ctx = sb.SbContext(g, ek.Damage.from_text(*texts), penalty=fix["params"]["penalty"])
