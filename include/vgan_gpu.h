@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VGAN_ABI_VERSION 6
+#define VGAN_ABI_VERSION 7
 
 enum {
     VGAN_OK = 0,
@@ -798,6 +798,40 @@ int vgan_sb_create(const vgan_graph_view *graph, const vgan_damage_view *dmg, co
 int vgan_sb_set_stream(vgan_sb_ctx *c, void *hip_stream);
 /* analyse_GAM over the batch: (re)builds the device-resident factorised tables.  n_bad: reads excluded on the device */
 int vgan_sb_precompute(vgan_sb_ctx *c, const vgan_sb_batch *b, int64_t *n_bad);
+/* (ABI 7) soibean's front half on the device (csrc/sb_flatten_kernels.hip; reference: src/getLCAfromGAM.h:92-186,537-544): the arrays of
+ * the last vgan_gamdev_parse -> rows of a vgan_sb_batch in HBM, APPENDED to the batch the object holds (analyse_GAM runs once over a
+ * context's reads), in input order, for the reads whose edits are all matches or substitutions on known nodes and whose slices cannot
+ * leave the strings (the conditions are beside sb_df_classify_kernel); host_mask[r] = 1 for every other read of the parse: the host
+ * flattens those (vgan_sb_flatten) and appends its batch (vgan_sb_devflat_append_host; src_map: read_src[i] -> src_map[read_src[i]]).
+ * Array for array vgan_sb_flatten's batch of the same reads.  base: the index of the parse's first read (read_src = base + r).
+ * vgan_sb_devflat_batch: the batch so far (device pointers, on_device = 1; valid until the next append).  vgan_sb_devflat_expect: the
+ * first append sizes the arrays for `scale` times what it brings.  vgan_sb_batch_download: a device batch's arrays into host arrays. */
+typedef struct vgan_sb_devflat vgan_sb_devflat;
+struct vgan_gamdev;
+int vgan_sb_devflat_create(vgan_sb_ctx *c, const vgan_graph *graph, vgan_sb_devflat **out);
+int vgan_sb_devflat_expect(vgan_sb_devflat *f, double scale);
+int vgan_sb_devflat_append_gamdev(vgan_sb_devflat *f, const struct vgan_gamdev *gd, uint32_t base, uint8_t *host_mask, vgan_sb_flatten_stats *stats);
+int vgan_sb_devflat_append_host(vgan_sb_devflat *f, const vgan_sb_batch *host_batch, const uint32_t *src_map);
+int vgan_sb_devflat_batch(const vgan_sb_devflat *f, vgan_sb_batch *out);
+void vgan_sb_devflat_free(vgan_sb_devflat *f);
+int vgan_sb_batch_download(const vgan_sb_batch *dev, const vgan_sb_batch *host);
+/* `vgan soibean` over the device front end's pipeline (csrc/sb_gam_run.hip; vgan_hc_gam_* / vgan_euka_gam_* are its siblings): start
+ * begins upload, inflate, framing and the protobuf walk of the file's pieces at once (they need no context); attach gives the contexts
+ * (one per lane) and the graph; finish waits for the pieces, appends the host's share and makes analyse_GAM's tables once per context
+ * (vgan_sb_precompute over the context's whole batch) -- the contexts are then as after the host pipeline's vgan_sb_precompute calls,
+ * with the reads dealt by pieces instead of contiguous shares (the chains' sums are integers: the same bits).  n_bad: reads of the
+ * host's share that vgan_sb_flatten refuses; n_dev_bad: vgan_sb_precompute's.  vgan_sb_gam_batch: lane `lane`'s batch (device
+ * pointers; read_src = the reads' places among the file's mapped reads) until vgan_sb_gam_free. */
+typedef struct vgan_sb_gamrun vgan_sb_gamrun;
+typedef struct vgan_sb_gam_result {
+    int64_t n_messages, n_mapped, n_reads, n_bad, n_dev_bad;
+    double ms_tables; /* appending the host's share + vgan_sb_precompute */
+} vgan_sb_gam_result;
+int vgan_sb_gam_start(const int *devices, int n_lanes, const void *bytes, uint64_t n, const vgan_gampipe_opts *opts, vgan_sb_gamrun **out);
+int vgan_sb_gam_attach(vgan_sb_gamrun *r, vgan_sb_ctx *const *ctxs, int n_ctx, const vgan_graph *graph);
+int vgan_sb_gam_finish(vgan_sb_gamrun *r, vgan_sb_gam_result *res, vgan_gampipe_stats *pstats);
+int vgan_sb_gam_batch(const vgan_sb_gamrun *r, int lane, vgan_sb_batch *out);
+void vgan_sb_gam_free(vgan_sb_gamrun *r);
 /* test aid: pm [n_paths][r1-r0], cnt [n_paths][25][r1-r0], ok [r1-r0] of the resident reads, host arrays */
 int vgan_sb_read_tables(vgan_sb_ctx *c, uint32_t r0, uint32_t r1, double *pm, uint16_t *cnt, uint8_t *ok);
 /* n_states likelihood refreshes in one launch (e.g. the independent chains, soibean.cpp:805-840); src has n_states*k

@@ -160,6 +160,11 @@ class SbFlattenStats(C.Structure):
     _fields_ = [("n_in", C.c_int64), ("n_out", C.c_int64), ("n_unmapped", C.c_int64), ("n_bad", C.c_int64)]
 
 
+class SbGamResult(C.Structure):
+    _fields_ = [("n_messages", C.c_int64), ("n_mapped", C.c_int64), ("n_reads", C.c_int64), ("n_bad", C.c_int64), ("n_dev_bad", C.c_int64),
+                ("ms_tables", C.c_double)]
+
+
 class SbParams(C.Structure):
     _fields_ = [("penalty", C.c_int32), ("reserved", C.c_int32)]
 
@@ -320,6 +325,18 @@ SYMBOLS = {
     "vgan_euka_gam_attach": (C.c_int, [vp, C.POINTER(vp), C.c_int, vp]),
     "vgan_euka_gam_finish": (C.c_int, [vp, C.POINTER(EukaGamResult), C.POINTER(GamPipeStats)]),
     "vgan_euka_gam_free": (None, [vp]),
+    "vgan_sb_devflat_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "vgan_sb_devflat_expect": (C.c_int, [vp, C.c_double]),
+    "vgan_sb_devflat_append_gamdev": (C.c_int, [vp, vp, C.c_uint32, vp, C.POINTER(SbFlattenStats)]),
+    "vgan_sb_devflat_append_host": (C.c_int, [vp, C.POINTER(SbBatch), vp]),
+    "vgan_sb_devflat_batch": (C.c_int, [vp, C.POINTER(SbBatch)]),
+    "vgan_sb_devflat_free": (None, [vp]),
+    "vgan_sb_batch_download": (C.c_int, [C.POINTER(SbBatch), C.POINTER(SbBatch)]),
+    "vgan_sb_gam_start": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.POINTER(GamPipeOpts), C.POINTER(vp)]),
+    "vgan_sb_gam_attach": (C.c_int, [vp, C.POINTER(vp), C.c_int, vp]),
+    "vgan_sb_gam_finish": (C.c_int, [vp, C.POINTER(SbGamResult), C.POINTER(GamPipeStats)]),
+    "vgan_sb_gam_batch": (C.c_int, [vp, C.c_int, C.POINTER(SbBatch)]),
+    "vgan_sb_gam_free": (None, [vp]),
     "vgan_sb_flatten": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(vp), C.POINTER(SbFlattenStats)]),
     "vgan_sb_host_batch_get": (C.c_int, [vp, C.POINTER(SbBatch)]),
     "vgan_sb_host_batch_free": (None, [vp]),
@@ -355,7 +372,7 @@ SYMBOLS = {
     "vgan_synth_hc_reads": (C.c_int, [vp, C.POINTER(SynthReadsCfg), C.POINTER(vp)]),
 }
 
-ABI_VERSION = 6  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
+ABI_VERSION = 7  # include/vgan_gpu.h: VGAN_ABI_VERSION this binding was written against
 
 HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the null stream by name (a NULL argument selects the context's own stream)
 

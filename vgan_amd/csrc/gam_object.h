@@ -196,6 +196,8 @@ struct GamConsumer {
 };
 int gampipe_run(const void *bytes, uint64_t n, const std::vector<int> &lane_devices, const vgan_gampipe_opts &opts, GamConsumer &consumer,
                 vgan_gampipe_stats *stats);
+// the options a run takes when the caller leaves them open (piece size from the input's size, slots, tail room; VGAN_GAMPIPE_* environment)
+vgan_gampipe_opts gampipe_defaults(const vgan_gampipe_opts *o, uint64_t n_bytes, int n_lanes);
 } // namespace gd
 } // namespace vgan
 struct vgan_hc_devflat;

@@ -332,6 +332,8 @@ struct Pipe {
 
 } // namespace
 
+vgan_gampipe_opts vgan::gd::gampipe_defaults(const vgan_gampipe_opts *o, uint64_t n_bytes, int n_lanes) { return with_defaults(o, n_bytes, n_lanes); }
+
 int vgan::gd::gampipe_run(const void *bytes, uint64_t n, const std::vector<int> &lane_devices, const vgan_gampipe_opts &opts_in, GamConsumer &consumer,
                           vgan_gampipe_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);

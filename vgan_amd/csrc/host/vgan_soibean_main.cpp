@@ -8,6 +8,11 @@
 //     paths from the .gbwt, which this build does not read); FASTQ input needs vg giraffe in-process: map with vg and pass -g;
 //   * analyse_GAM, the initial estimate and every likelihood refresh of the chains run on the GPU (vgan_sb_*); the chain
 //     itself is host control flow (vgan_sb_estimate); --seed N makes it reproducible (0 = std::random_device, as there).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
 #include <fstream>
@@ -150,8 +155,58 @@ int soibean_main(int argc, char **argv) {
     if (!is_readable_input(gam)) die("[soibean] Error, GAM input file " + gam + " does not exist");
 
     PhaseTimer pt("soibean");
+    if (gpu_list.empty()) {
+        if (const char *e = getenv("VGAN_GPUS")) {
+            if (std::string(e) == "all")
+                for (int d = 0; d < vgan_device_count(); ++d) gpu_list.push_back(d);
+            else if (*e) parse_gpu_list(e, "VGAN_GPUS", T, gpu_list);
+        }
+        if (gpu_list.empty()) gpu_list.push_back(device);
+    }
+    // A long BGZF input: the front end runs ON THE DEVICE (vgan_sb_gam_*: the file in pieces through inflate, framing, protobuf walk and
+    // soibean's flatten as kernels, piece i to context i mod n; csrc/gam_pipe.hip, sb_flatten_kernels.hip, sb_gam_run.hip); the host parses
+    // only the reads the device flatten leaves (indels, soft clips).  VGAN_SB_DEVICE_GAM=0 / 1: never / whenever the input is a regular
+    // file.  Anything the device refuses goes through the host pipeline.
+    struct FileMap {
+        const uint8_t *p = nullptr;
+        size_t n = 0;
+        ~FileMap() {
+            if (p) munmap(const_cast<uint8_t *>(p), n);
+        }
+    } gam_map;
+    struct GdRun {
+        vgan_sb_gamrun *r = nullptr;
+        ~GdRun() { vgan_sb_gam_free(r); }
+    };
+    bool device_gam = false;
+    {
+        const char *e = getenv("VGAN_SB_DEVICE_GAM");
+        struct stat sb;
+        if (!(e && e[0] == '0') && vgan_device_count() > 0 && stat(gam.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) &&
+            ((e && e[0] == '1') || (uint64_t)sb.st_size >= (128ull << 20)) && sb.st_size > 28) {
+            const int fd = open(gam.c_str(), O_RDONLY);
+            if (fd >= 0) {
+                void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                close(fd);
+                if (m != MAP_FAILED) {
+                    gam_map.p = (const uint8_t *)m;
+                    gam_map.n = (size_t)sb.st_size;
+                    device_gam = gam_map.p[0] == 0x1f && gam_map.p[1] == 0x8b && gam_map.p[2] == 8 && (gam_map.p[3] & 4); // (BGZF members carry an extra field)
+                    if (device_gam) (void)madvise(m, gam_map.n, MADV_WILLNEED);
+                }
+            }
+        }
+        for (int d : gpu_list)
+            if (d >= vgan_device_count()) device_gam = false; // (reported below, once the tables are read)
+    }
     GamReader reader;
-    reader.start(gam, 0);
+    GdRun gd; // (started now: upload, inflate, framing and parse need neither graph nor contexts and run beside their set-up)
+    if (device_gam) {
+        vgan_gampipe_opts po{};
+        po.n_threads = n_threads;
+        if (vgan_sb_gam_start(gpu_list.data(), (int)gpu_list.size(), gam_map.p, gam_map.n, &po, &gd.r) < 0) device_gam = false;
+    }
+    if (!device_gam) reader.start(gam, 0);
     Handle<vgan_damage> dmg(vgan_damage_free);
     check(vgan_damage_load(deam5.empty() ? nullptr : deam5.c_str(), deam3.empty() ? nullptr : deam3.c_str(), &dmg.p), "damage profiles");
     std::cerr << "Reading in variation graph ..." << std::endl;
@@ -219,14 +274,6 @@ int soibean_main(int argc, char **argv) {
     // one device context per GPU (--gpus / VGAN_GPUS; a GPU may be named twice: two contexts on it), the reads dealt to them
     // once in contiguous shares: MCMC.cpp:739 runs its loop over the reads in parallel with `reduction(+:logLike)`, here the
     // reduction runs over devices -- in integers (vgan_sb_sum), so the number of devices does not change a bit of the result
-    if (gpu_list.empty()) {
-        if (const char *e = getenv("VGAN_GPUS")) {
-            if (std::string(e) == "all")
-                for (int d = 0; d < vgan_device_count(); ++d) gpu_list.push_back(d);
-            else if (*e) parse_gpu_list(e, "VGAN_GPUS", T, gpu_list);
-        }
-        if (gpu_list.empty()) gpu_list.push_back(device);
-    }
     struct Contexts {
         std::vector<vgan_sb_ctx *> v;
         vgan_sb_group *group = nullptr;
@@ -235,6 +282,13 @@ int soibean_main(int argc, char **argv) {
             for (auto c : v) vgan_sb_destroy(c);
         }
     } ctxs;
+    struct GdStop { // (an error's unwinding: the front end's threads use the contexts -- they are joined before the contexts go)
+        vgan_sb_gamrun *&r;
+        ~GdStop() {
+            vgan_sb_gam_free(r);
+            r = nullptr;
+        }
+    } gd_stop{gd.r};
     for (int d : gpu_list) {
         if (d >= vgan_device_count()) die("[soibean] Error, GPU " + std::to_string(d) + " asked for, " + std::to_string(vgan_device_count()) + " visible");
         vgan_sb_ctx *c = nullptr;
@@ -242,14 +296,38 @@ int soibean_main(int argc, char **argv) {
         ctxs.v.push_back(c);
     }
     check(vgan_sb_group_create(ctxs.v.data(), (int)ctxs.v.size(), &ctxs.group), "grouping the device contexts");
-    Handle<vgan_alnset> aln(vgan_aln_free);
-    aln.p = reader.take();
-    vgan_alnset_view av;
-    check(vgan_aln_view_get(aln.p, &av), "alignment view");
     vgan_sb_flatten_stats st{};
     int64_t dev_bad = 0;
     const int64_t n_ctx = (int64_t)ctxs.v.size();
-    for (int64_t i = 0; i < n_ctx; ++i) {
+    if (device_gam) {
+        vgan_sb_gam_result gr{};
+        vgan_gampipe_stats ps{};
+        int rc = vgan_sb_gam_attach(gd.r, ctxs.v.data(), (int)n_ctx, graph.p);
+        if (rc >= 0) rc = vgan_sb_gam_finish(gd.r, &gr, &ps);
+        if (rc < 0) { // (vgan_sb_precompute replaces a context's tables: the host pipeline takes the file from its start)
+            std::cerr << "[soibean] the device front end does not take this input (" << vgan_last_error() << "): the host pipeline does" << std::endl;
+            device_gam = false;
+            reader.start(gam, 0);
+        } else {
+            st.n_bad = gr.n_bad;
+            dev_bad = gr.n_dev_bad;
+            if (getenv("VGAN_TIMING"))
+                fprintf(stderr, "[vgan timing] soibean device front end: %.1f MB -> %.1f MB in %llu pieces on %lld lane(s), %llu messages, %llu mapped reads (%llu left to the host); %.0f ms "
+                                "from start to the last piece, analyse_GAM's tables %.0f ms; summed over pieces: upload %.0f, inflate %.0f, framing %.0f, protobuf walk %.0f, flatten %.0f ms; "
+                                "%.2f GB of device memory\n",
+                        ps.compressed_bytes / 1e6, ps.inflated_bytes / 1e6, (unsigned long long)ps.n_pieces, (long long)n_ctx, (unsigned long long)ps.n_messages, (unsigned long long)ps.n_reads,
+                        (unsigned long long)ps.n_host_reads, ps.ms_wall, gr.ms_tables, ps.ms_upload, ps.ms_inflate, ps.ms_frame, ps.ms_parse, ps.ms_consume, ps.device_bytes / 1e9);
+        }
+        vgan_sb_gam_free(gd.r); // (the batch's memory back: the tables stay in the contexts)
+        gd.r = nullptr;
+    }
+    Handle<vgan_alnset> aln(vgan_aln_free);
+    vgan_alnset_view av{};
+    if (!device_gam) {
+        aln.p = reader.take();
+        check(vgan_aln_view_get(aln.p, &av), "alignment view");
+    }
+    for (int64_t i = 0; i < n_ctx && !device_gam; ++i) {
         const int64_t r0 = av.n_reads * i / n_ctx, r1 = av.n_reads * (i + 1) / n_ctx;
         Handle<vgan_sb_host_batch> hb(vgan_sb_host_batch_free);
         vgan_sb_flatten_stats sti{};
@@ -267,7 +345,7 @@ int soibean_main(int argc, char **argv) {
     std::vector<int64_t> sig(gv.n_paths);
     int64_t n_ok = 0;
     check(vgan_sb_group_best_paths(ctxs.group, sig.data(), &n_ok), "signature counts");
-    if (n_ctx > 1) std::cerr << "[soibean] " << n_ctx << " device contexts, the reads dealt in contiguous shares" << std::endl;
+    if (n_ctx > 1) std::cerr << "[soibean] " << n_ctx << " device contexts, the reads dealt " << (device_gam ? "piece by piece" : "in contiguous shares") << std::endl;
     pt.lap("GAM + analyse_GAM");
     std::cerr << "Number of paths: " << gv.n_paths << std::endl << "Number of reads: " << n_ok << std::endl;
     if (st.n_bad + dev_bad) std::cerr << "[soibean] warning: " << st.n_bad + dev_bad << " reads skipped (the reference would index out of bounds on them)\n";

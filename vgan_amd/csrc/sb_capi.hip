@@ -95,6 +95,8 @@ struct vgan_sb_ctx {
     uint64_t launches[2] = {0, 0};
 };
 
+vgan::SbCtxInfo vgan::sb_ctx_info(const vgan_sb_ctx *c) { return SbCtxInfo{c->device, c->stream}; }
+
 static void resolve(vgan_sb_ctx *c, int i) {
     if (!c->pending[i]) return;
     float ms = 0.f;

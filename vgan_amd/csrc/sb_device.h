@@ -124,4 +124,15 @@ void launch_sb_best_paths(const SbTablesDev &t, uint32_t n_paths, int32_t *best,
 void launch_sb_mixture(const SbTablesDev &t, uint32_t n, const int32_t *paths, double log_freq, SbFix *partial, uint32_t n_blocks,
                        double *out, SbFix *out_fix, hipStream_t st);
 
+struct SbCtxInfo { // what another translation unit needs of a context (sb_flatten_kernels.hip)
+    int device;
+    hipStream_t stream;
+};
+
 } // namespace vgan
+struct vgan_sb_ctx;
+struct vgan_sb_devflat;
+namespace vgan {
+SbCtxInfo sb_ctx_info(const vgan_sb_ctx *c);
+size_t sb_devflat_device_bytes(const vgan_sb_devflat *f);
+}

@@ -37,6 +37,90 @@ class SbHostBatch:
             self._h = None
 
 
+def download_batch(c):
+    """A device vgan_sb_batch's arrays as numpy arrays (vgan_sb_batch_download)."""
+    n = {"R1": c.n_reads + 1, "R": c.n_reads, "S": c.n_segments, "C": c.n_cols, "Q": c.n_qual}
+    out = {name: np.zeros(max(int(n[k]), 1), dt) for name, dt, k in _SB_FIELDS}
+    h = N.SbBatch()
+    for name, _, _ in _SB_FIELDS:
+        setattr(h, name, out[name].ctypes.data)
+    N.check(N.lib().vgan_sb_batch_download(C.byref(c), C.byref(h)))
+    return {name: out[name][:int(n[k])] if c.n_reads else out[name][:0] for name, _, k in _SB_FIELDS}
+
+
+class SbDeviceBatch:
+    """What SbContext.precompute takes: a vgan_sb_batch whose arrays live on the device."""
+
+    def __init__(self, c):
+        self.c = c
+        self.n_reads, self.n_segments = c.n_reads, c.n_segments
+
+
+class SbDeviceFlatten:
+    """soibean's front half on the device (vgan_sb_devflat): GamDevice parses -> rows appended to a vgan_sb_batch in HBM + the masks of the
+    reads left to the host."""
+
+    def __init__(self, ctx, graph):
+        self._h = N.vp()
+        self.ctx = ctx
+        N.check(N.lib().vgan_sb_devflat_create(ctx._h, graph._h, C.byref(self._h)))
+
+    def append_gamdev(self, gd, base=0):
+        n = gd.sizes["reads"]
+        mask = np.zeros(max(n, 1), np.uint8)
+        self.stats = N.SbFlattenStats()
+        N.check(N.lib().vgan_sb_devflat_append_gamdev(self._h, gd._h, base, mask.ctypes.data, C.byref(self.stats)))
+        return mask[:n]
+
+    def append_host(self, host_batch, src_map=None):
+        m = None if src_map is None else np.ascontiguousarray(src_map, np.uint32)
+        N.check(N.lib().vgan_sb_devflat_append_host(self._h, C.byref(host_batch.c), None if m is None else m.ctypes.data))
+
+    def batch(self):
+        c = N.SbBatch()
+        N.check(N.lib().vgan_sb_devflat_batch(self._h, C.byref(c)))
+        return SbDeviceBatch(c)
+
+    def download(self):
+        return download_batch(self.batch().c)
+
+    def close(self):
+        if getattr(self, "_h", None) and N is not None:
+            N.lib().vgan_sb_devflat_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def gam_run(ctxs, graph, data, piece_bytes=0, slots=0, n_threads=0, batches=False):
+    """vgan_sb_gam_*: a BGZF GAM's bytes through the device front end's pipeline into the contexts (piece i -> context i mod n) and
+    analyse_GAM's tables made once per context.  Returns ({n_messages, n_mapped, n_reads, n_bad, n_dev_bad[, batches: per lane, downloaded]},
+    pipeline statistics)."""
+    buf = np.frombuffer(data, np.uint8)
+    o = N.GamPipeOpts(int(piece_bytes), int(slots), 0, 0, int(n_threads), 0)
+    dev = (C.c_int * len(ctxs))(*[c.device for c in ctxs])
+    arr = (N.vp * len(ctxs))(*[c._h for c in ctxs])
+    run = N.vp()
+    N.check(N.lib().vgan_sb_gam_start(dev, len(ctxs), buf.ctypes.data, len(data), C.byref(o), C.byref(run)))
+    res, ps = N.SbGamResult(), N.GamPipeStats()
+    try:
+        N.check(N.lib().vgan_sb_gam_attach(run, arr, len(ctxs), graph._h))
+        N.check(N.lib().vgan_sb_gam_finish(run, C.byref(res), C.byref(ps)))
+        out = {k: int(getattr(res, k)) for k in ("n_messages", "n_mapped", "n_reads", "n_bad", "n_dev_bad")}
+        out["lane_reads"] = []
+        for l, c in enumerate(ctxs):
+            b = N.SbBatch()
+            N.check(N.lib().vgan_sb_gam_batch(run, l, C.byref(b)))
+            c.n_reads = int(b.n_reads)
+            out["lane_reads"].append(int(b.n_reads))
+            if batches:
+                out.setdefault("batches", []).append(download_batch(b))
+    finally:
+        N.lib().vgan_sb_gam_free(run)
+    return out, ps.as_dict()
+
+
 class SbContext:
     def __init__(self, graph, damage, penalty=7, device=0):
         self.graph, self.damage = graph, damage
