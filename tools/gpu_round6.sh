@@ -2,7 +2,7 @@
 # round 6 closing session (GPU box): full GPU suite, smoke, the node-weights trace + FETCH/WRITE passes, SQ passes of the segment
 # kernel, the length and class sweeps, the bench lines (the default one with its end_to_end record; euka; soibean at 1 M and 2 M reads),
 # traces + counter passes of euka's and soibean's kernels, the inflate kernels alone (trace + SQ passes), `vgan haplocart` on a 10 M-read
-# GAM under the kernel trace, and `vgan euka` on a 5 M-read GAM.
+# GAM under the kernel trace, `vgan euka` on a 5 M-read GAM and `vgan soibean` on a 2 M-read one.
 export TMPDIR=/tmp
 tag=${1:-round6_v1}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -25,6 +25,7 @@ bash tools/dev/pmc_cmd.sh ${tag}_inflate $R/tools/dev/inflate_time.py 1000000 > 
 bash tools/gpu_profile_gamdev.sh ${tag}_gamdev 10000000 > gpurun_out/${tag}_gamdev_run.log 2>&1
 python3 tools/e2e_device_gam.py 10000000 2>&1 | grep -v "gampipe piece\|hc consume\|hc_devflat" | cut -c1-1500 > gpurun_out/${tag}_e2e_haplocart.log
 python3 tools/e2e_device_euka.py 5000000 2>&1 | cut -c1-900 > gpurun_out/${tag}_e2e_euka.log
+python3 tools/e2e_device_soibean.py 2000000 2>&1 | cut -c1-900 > gpurun_out/${tag}_e2e_soibean.log
 cat gpurun_out/${tag}_pytest_gpu.log gpurun_out/${tag}_smoke.log gpurun_out/${tag}_len_sweep.jsonl
 for f in default euka soibean soibean2m; do head -c 600 gpurun_out/${tag}_bench_$f.json; echo; done
-tail -5 gpurun_out/${tag}_e2e_haplocart.log gpurun_out/${tag}_e2e_euka.log
+tail -5 gpurun_out/${tag}_e2e_haplocart.log gpurun_out/${tag}_e2e_euka.log gpurun_out/${tag}_e2e_soibean.log

@@ -319,6 +319,7 @@ SYMBOLS = {
     "vgan_euka_synchronize": (C.c_int, [vp]),
     "vgan_euka_devflat_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
     "vgan_euka_devflat_run_gamdev": (C.c_int, [vp, vp, C.c_uint32, C.POINTER(EukaBatch), vp, C.POINTER(EukaFlattenStats)]),
+    "vgan_euka_devflat_host_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "vgan_euka_devflat_free": (None, [vp]),
     "vgan_euka_batch_download": (C.c_int, [C.POINTER(EukaBatch), C.POINTER(EukaBatch)]),
     "vgan_euka_gam_start": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.POINTER(GamPipeOpts), C.POINTER(vp)]),

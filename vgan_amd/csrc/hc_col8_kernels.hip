@@ -700,12 +700,19 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                         const uint32_t ad = (rc << 3) + ((row << 5) + (W2 ? (inf[e] >> 16) << 6 : inf[e] >> 16));
                         if constexpr (W2) t[e] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(a.gmemo2) + (ad + rbo[e]));
                         else if constexpr (G) t[e] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(a.gmemo) + (ad + rbo[e]));
+#if defined(C8_EXP) && (C8_EXP & 2) // (developer pricing run: the table read without bank conflicts -- wrong sums)
+                        else t[e] = lds_ld64(memo_base + (uint32_t)lane * 8u + (uint32_t)e * 512u + (ad & 0u));
+#else
                         else t[e] = lds_ld64(ad);
+#endif
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         uint32_t sa;
                         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(sa) : "v"(inf[e]), "s"(wind_base));
+#if defined(C8_EXP) && (C8_EXP & 1) // (developer pricing run: the window adds without conflicts -- wrong sums)
+                        sa = wind_base + (uint32_t)lane * 8u + (sa & 0u);
+#endif
                         if (__builtin_amdgcn_inverse_ballot_w64(valid[e])) lds_fadd(sa, t[e]);
                     }
                 };
