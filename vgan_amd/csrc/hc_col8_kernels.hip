@@ -701,7 +701,10 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
                         if constexpr (W2) t[e] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(a.gmemo2) + (ad + rbo[e]));
                         else if constexpr (G) t[e] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(a.gmemo) + (ad + rbo[e]));
 #if defined(C8_EXP) && (C8_EXP & 2) // (developer pricing run: the table read without bank conflicts -- wrong sums)
-                        else t[e] = lds_ld64(memo_base + (uint32_t)lane * 8u + (uint32_t)e * 512u + (ad & 0u));
+                        else {
+                            asm volatile("" ::"v"(ad)); // (the address is still computed: only the conflicts go)
+                            t[e] = lds_ld64(memo_base + (uint32_t)lane * 8u + (uint32_t)e * 512u);
+                        }
 #else
                         else t[e] = lds_ld64(ad);
 #endif
