@@ -44,6 +44,14 @@ constexpr int EK_READS_PER_BLOCK = EK_WAVES * EK_READS_PER_WAVE; // 16 per workg
 #define EK_BG 8 // lanes per read in the column stage (16: a DPP row per read, four reads per step; 8: eight reads per step)
 #endif
 constexpr uint32_t EK_DMG_LDS_PAIRS = 64;                 // (5' row, 3' row) pairs kept in LDS (512 bytes each)
+#ifndef EK_ORDER_SPAN
+// A block's reads are taken in the order of their lengths within spans of this many neighbours.  Over the whole block (64; round 5) a
+// 128-byte line of the strings -- it holds the ends of two neighbouring reads -- is wanted twice, up to a whole block's column loops
+// apart, and what the waves of an XCD hold in between (512 waves x 14 KB of strings) is more than its 4 MB of L2: the launch fetched
+// 1.37 x its algorithmic bytes (524 MB against 384; `tools/dev/ek_order.sh`: spans 1 / 8 / 16: 388-390 MB, 32: 415-419 MB, 64: 524 MB, the
+// same 0.317-0.321 ms at every span from 16 up, 0.324 without the ordering).
+#define EK_ORDER_SPAN 32u
+#endif
 constexpr int EK_ACC_LTP = 8;                             // lengthToProf up to which a wave keeps the base shifts in LDS,
 constexpr int EK_ACC_BINS = 32;                           // bins per clade up to which it keeps the coverage there
 
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(EK_WAVES * 64, EK_MIN_WAVES) void euka_read_kernel(
                 // the order of their lengths, so that four of about one length share the steps (in file order the longest of
                 // four fragments of 75 +- 17 columns costs a step more than the average one -- a sixth of the column loop).  What
                 // a read adds to its outputs and to the sums does not depend on the rows beside it.
-                const uint32_t key = (uint32_t)lane < nb ? ((uint32_t)b.read_gseq_len[r] << 6) | (uint32_t)lane : 0xFFFFFFFFu;
+                const uint32_t key = (uint32_t)lane < nb ? (((uint32_t)lane / EK_ORDER_SPAN) << 26) | ((uint32_t)b.read_gseq_len[r] << 6) | (uint32_t)lane : 0xFFFFFFFFu;
                 uint32_t rank = 0;
 #pragma unroll
                 for (int j = 0; j < 64; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key ? 1u : 0u;
