@@ -17,7 +17,8 @@ int gamdev_inflate(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n_bloc
 int gamdev_inflate_wave(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_status, uint32_t *d_tok, uint32_t tok_cap,
                         uint32_t *d_cursor, void *d_reg, uint32_t *d_n_reg, hipStream_t st);
 // the members' CRC-32 against the trailers' (d_want[b]): GD_BAD_CRC into the status of a member that is GD_OK and does not match; the
-// tables (1280 words: gamdev_crc_tables, host) on the device
+// tables (GAMDEV_CRC_TABS words: gamdev_crc_tables, host) on the device
+constexpr uint32_t GAMDEV_CRC_TABS = 2048;
 const uint32_t *gamdev_crc_tables();
 int gamdev_crc(const uint8_t *d_out, const GdBlock *d_blocks, uint32_t n_blocks, const uint32_t *d_want, const uint32_t *d_tabs, uint32_t *d_status, hipStream_t st);
 

@@ -795,29 +795,54 @@ __global__ __launch_bounds__(64) void gd_lzw_kernel(const GdBlock *__restrict__ 
 }
 
 // The members' CRC-32 (RFC 1952 8: the gzip trailer's first word), a wave per member: lane j takes the j-th kilobyte counted from the
-// member's END (the first chunk is the short one), byte by byte through the 256-entry table; the chunks' registers are then folded front
-// to back -- processing B from register r equals (r moved across |B| zero bytes) xor (B processed from 0), and moving across GW_CRC_CHUNK
-// zero bytes is four look-ups in a table made for that length.  A member whose bytes do not give the trailer's value gets GD_BAD_CRC:
-// the host pipeline's zlib / libdeflate refuse such a file, and so does this one (the member goes through the older kernel first, as
-// every status but GD_OK does).  tabs: [256] the CRC table, then [4][256] the zero-bytes operator.
+// member's END (the first chunk is the short one); the chunks' registers are then folded front to back -- processing B from register r
+// equals (r moved across |B| zero bytes) xor (B processed from 0), and moving across GW_CRC_CHUNK zero bytes is four look-ups in a table
+// made for that length.  A lane takes its kilobyte sixteen bytes to a load and four bytes to a step ("slicing by four": the register
+// xor the next word, then one look-up per byte in the tables of a byte followed by 3, 2, 1, 0 zero bytes -- four look-ups that do not wait
+// for each other).  (First form: a byte to a load and to a step -- lanes a kilobyte apart, so every byte load of a wave touched 64 lines
+// that the other waves of the CU had pushed out of L1 since: 3.2 ms per 1 M reads' members, more than half of what inflating them takes.)
+// A member whose bytes do not give the trailer's value gets GD_BAD_CRC: the host pipeline's zlib / libdeflate refuse such a file, and so
+// does this one (the member goes through the older kernel first, as every status but GD_OK does).
+// tabs (GW_CRC_TABS words): [256] the CRC table, [4][256] the zero-bytes operator, [3][256] the table moved across 1, 2, 3 zero bytes.
 constexpr uint32_t GW_CRC_CHUNK = 1024;
 __global__ __launch_bounds__(64) void gd_crc_kernel(const uint8_t *__restrict__ out, const GdBlock *__restrict__ blocks, uint32_t n_blocks, const uint32_t *__restrict__ want,
                                                     const uint32_t *__restrict__ tabs, uint32_t *__restrict__ status) {
-    __shared__ uint32_t t[256 + 1024];
+    __shared__ uint32_t t[GAMDEV_CRC_TABS];
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     if (b >= n_blocks || status[b] != GD_OK) return;
-    for (uint32_t i = lane; i < 256u + 1024u; i += 64u) t[i] = tabs[i];
+    for (uint32_t i = lane; i < GAMDEV_CRC_TABS; i += 64u) t[i] = tabs[i];
     __syncthreads();
     const GdBlock bl = blocks[b];
     const uint8_t *o = out + bl.out_off;
     const uint32_t n = bl.out_size, n_chunks = (n + GW_CRC_CHUNK - 1u) / GW_CRC_CHUNK; // <= 64: a BGZF member holds 64 KB at most
     if (n_chunks > 64u) return; // (not BGZF's: left unchecked)
     const uint32_t first_len = n - (n_chunks ? (n_chunks - 1u) * GW_CRC_CHUNK : 0u);
+    const uint32_t *t1 = t + 1280u, *t2 = t + 1536u, *t3 = t + 1792u;
     uint32_t r = 0;
     if (lane < n_chunks) {
         const uint32_t at = lane == 0 ? 0u : first_len + (lane - 1u) * GW_CRC_CHUNK, len = lane == 0 ? first_len : GW_CRC_CHUNK;
         r = lane == 0 ? 0xFFFFFFFFu : 0u;
-        for (uint32_t k = 0; k < len; ++k) r = t[(r ^ o[at + k]) & 255u] ^ (r >> 8);
+        struct __attribute__((packed)) U128 { // (a member's output starts at any byte)
+            uint4 v;
+        };
+        const uint8_t *p = o + at;
+        uint32_t k = 0;
+        if (len >= 16u) {
+            uint4 nx = reinterpret_cast<const U128 *>(p)->v;
+            for (; k + 16u <= len; k += 16u) {
+                const uint4 w = nx;
+                if (k + 32u <= len) nx = reinterpret_cast<const U128 *>(p + k + 16u)->v; // (asked for a step ahead)
+                r ^= w.x;
+                r = t3[r & 255u] ^ t2[(r >> 8) & 255u] ^ t1[(r >> 16) & 255u] ^ t[r >> 24];
+                r ^= w.y;
+                r = t3[r & 255u] ^ t2[(r >> 8) & 255u] ^ t1[(r >> 16) & 255u] ^ t[r >> 24];
+                r ^= w.z;
+                r = t3[r & 255u] ^ t2[(r >> 8) & 255u] ^ t1[(r >> 16) & 255u] ^ t[r >> 24];
+                r ^= w.w;
+                r = t3[r & 255u] ^ t2[(r >> 8) & 255u] ^ t1[(r >> 16) & 255u] ^ t[r >> 24];
+            }
+        }
+        for (; k < len; ++k) r = t[(r ^ p[k]) & 255u] ^ (r >> 8);
     }
     uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)r, 0);
     for (uint32_t j = 1; j < n_chunks; ++j) {
@@ -843,9 +868,10 @@ int gamdev_inflate_wave(const uint8_t *d_in, const GdBlock *d_blocks, uint32_t n
     return VGAN_OK;
 }
 
-// [256] the CRC-32 table (reflected polynomial 0xEDB88320), then [4][256]: byte k of a register moved across GW_CRC_CHUNK zero bytes
+// [256] the CRC-32 table (reflected polynomial 0xEDB88320), then [4][256]: byte k of a register moved across GW_CRC_CHUNK zero bytes, then
+// [3][256]: the table's entries moved across 1, 2, 3 zero bytes (slicing by four)
 const uint32_t *gamdev_crc_tables() {
-    static uint32_t tabs[256 + 1024];
+    static uint32_t tabs[GAMDEV_CRC_TABS];
     static const bool made = [] {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
@@ -857,6 +883,11 @@ const uint32_t *gamdev_crc_tables() {
                 uint32_t r = v << (8 * k);
                 for (uint32_t z = 0; z < gd::GW_CRC_CHUNK; ++z) r = tabs[r & 255u] ^ (r >> 8);
                 tabs[256 + 256 * k + v] = r;
+            }
+        for (uint32_t k = 1; k < 4; ++k)
+            for (uint32_t v = 0; v < 256; ++v) {
+                const uint32_t prev = k == 1 ? tabs[v] : tabs[1280 + 256 * (k - 2) + v];
+                tabs[1280 + 256 * (k - 1) + v] = tabs[prev & 255u] ^ (prev >> 8);
             }
         return true;
     }();

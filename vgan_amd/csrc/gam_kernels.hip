@@ -816,10 +816,10 @@ extern "C" int vgan_gamdev_inflate_bytes(const void *bytes, uint64_t n, void *ou
     rc = lane_inflate ? gamdev_inflate(d_in, d_b, (uint32_t)gb.size(), d_out, d_s, nullptr)
                       : gamdev_inflate_wave(d_in, d_b, (uint32_t)gb.size(), d_out, d_s, d_tok, tok_cap, d_cur, d_reg, d_nreg, nullptr);
     GDCHK(hipEventRecord(e1, nullptr));
-    GDCHK(hipMalloc((void **)&d_want, gb.size() * 4 + 16 + 1280 * 4));
+    GDCHK(hipMalloc((void **)&d_want, gb.size() * 4 + 16 + GAMDEV_CRC_TABS * 4));
     GDCHK(hipMemcpy(d_want, want.data(), gb.size() * 4, hipMemcpyHostToDevice));
     uint32_t *d_tabs = d_want + ((gb.size() + 3) & ~(size_t)3);
-    GDCHK(hipMemcpy(d_tabs, gamdev_crc_tables(), 1280 * 4, hipMemcpyHostToDevice));
+    GDCHK(hipMemcpy(d_tabs, gamdev_crc_tables(), GAMDEV_CRC_TABS * 4, hipMemcpyHostToDevice));
     if (rc == VGAN_OK) rc = gamdev_crc(d_out, d_b, (uint32_t)gb.size(), d_want, d_tabs, d_s, nullptr);
     GDCHK(hipDeviceSynchronize());
     if (rc == VGAN_OK) {
@@ -1060,8 +1060,8 @@ int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint
         if ((rc = g->crc_want.reserve(n_gb + 1))) return rc;
         HIPCHK(hipMemcpyAsync(g->crc_want.p, g->h_crc.data(), n_gb * 4, hipMemcpyHostToDevice, st));
         if (!g->crc_tab.p) {
-            if ((rc = g->crc_tab.reserve(1280))) return rc;
-            HIPCHK(hipMemcpyAsync(g->crc_tab.p, gamdev_crc_tables(), 1280 * 4, hipMemcpyHostToDevice, st));
+            if ((rc = g->crc_tab.reserve(GAMDEV_CRC_TABS))) return rc;
+            HIPCHK(hipMemcpyAsync(g->crc_tab.p, gamdev_crc_tables(), GAMDEV_CRC_TABS * 4, hipMemcpyHostToDevice, st));
         }
     }
     // The bytes go up in a few parts, each on a stream of its own with the inflate of its members behind it: a part's kernel runs BESIDE
