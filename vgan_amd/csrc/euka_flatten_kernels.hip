@@ -360,7 +360,7 @@ extern "C" int vgan_euka_devflat_run_gamdev(vgan_euka_devflat *f, const vgan_gam
         (rc = f->moff.reserve(R + 1)))
         return rc;
     HIPCHK(hipMemsetAsync(f->ctr.p, 0, sizeof(EdfCounters), st));
-    hipLaunchKernelGGL(euka_df_classify_kernel, dim3(std::min<uint32_t>((R + 3) / 4, 8192u)), dim3(256), 0, st, gs, R, f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
+    hipLaunchKernelGGL(euka_df_classify_kernel, dim3(std::min<uint32_t>((R + 3) / 4, 2048u)), dim3(256), 0, st, gs, R, f->g, f->flag.p, f->key.p, f->info.p, f->ctr.p);
     HIPCHK(hipGetLastError());
     { // the taken reads in ascending order of their first node id, input order kept among equals (the others' key is 2^32 - 1)
         if (f->iota_on_dev < R) {

@@ -334,21 +334,36 @@ struct GdCur {
     const uint8_t *p, *e;
     bool ok;
 };
-// The walk's bytes come eight to a load: the window holds bytes [base, base + 8) of the inflated stream (which has 64 bytes of slack
-// behind it), a byte outside it moves it.  (A byte to a load, every load of the wave touched 64 cache lines and the next byte waited
-// for it: a message of 60 mappings was ~1000 dependent loads.)
+// The walk's bytes come through a window of GD_WIN bytes per lane, kept in LDS: bytes [base, base + GD_WIN) of the inflated stream (which
+// has 64 bytes of slack behind it), four 16-byte loads when a byte outside it is asked for.  (A byte to a load, every load of the wave
+// touched 64 cache lines and the next byte waited for it: a message of 60 mappings was ~1000 dependent loads.  Eight bytes to a load --
+// a window in a register pair, the form before this one -- every 128-byte line was still asked for sixteen times by its lane, and what
+// the lanes of an XCD hold open at a time -- 32 CUs x 2 048 lanes x 128 bytes = 8 MB -- is twice its L2: the walks ran at what HBM gives
+// for sixteen times their bytes, 1.8 and 2.4 ms for the two passes over 500 k messages.)
+constexpr uint32_t GD_WIN = 64;
+typedef uint32_t gd_v4u __attribute__((ext_vector_type(4)));
+struct __attribute__((packed)) GdU128 {
+    gd_v4u v;
+};
+using gd_lds_u8p = __attribute__((address_space(3))) uint8_t *;
+using gd_lds_u128p = __attribute__((address_space(3))) gd_v4u *;
 struct GdWin {
     const uint8_t *base;
-    uint64_t w;
+    gd_lds_u8p row; // this lane's GD_WIN bytes of LDS (16-byte aligned)
 };
+#define GD_WIN_ROWS(name) __shared__ uint4 name[256][GD_WIN / 16] // a workgroup's rows: one per thread
+__device__ __forceinline__ gd_lds_u8p gd_win_row(uint4 (*rows)[GD_WIN / 16]) { return (gd_lds_u8p)(__attribute__((address_space(3))) void *)&rows[threadIdx.x][0]; }
 __device__ __forceinline__ uint32_t gc_byte(GdWin &win, const uint8_t *p) {
     uint64_t d = (uint64_t)(p - win.base);
-    if (d >= 8u) {
+    if (d >= GD_WIN) {
         win.base = p;
-        win.w = gd_load8(p);
+        const GdU128 *src = reinterpret_cast<const GdU128 *>(p);
+        const gd_v4u a0 = src[0].v, a1 = src[1].v, a2 = src[2].v, a3 = src[3].v;
+        gd_lds_u128p dst = (gd_lds_u128p)win.row;
+        dst[0] = a0, dst[1] = a1, dst[2] = a2, dst[3] = a3;
         d = 0;
     }
-    return (uint32_t)(win.w >> (8u * (uint32_t)d)) & 0xFFu;
+    return win.row[d];
 }
 __device__ __forceinline__ bool gc_done(const GdCur &c) { return c.p >= c.e; }
 __device__ __forceinline__ uint64_t gc_varint(GdCur &c, GdWin &win) {
@@ -468,9 +483,9 @@ __device__ __forceinline__ bool gd_walk_mapping(GdCur mc, GdWin &win, int64_t &n
 template <bool FILL>
 __device__ bool gd_parse_message(const uint8_t *u, const uint8_t *mp, uint32_t mlen, GdSizes &sz, double &identity, int32_t &mapq, const GdOut &o,
                                  GdMapRec *recs, uint32_t m0, uint32_t e0, uint32_t s0, uint32_t q0, int64_t &first_node, int64_t &first_off,
-                                 const uint8_t *&q_src, uint32_t &q_n) {
+                                 const uint8_t *&q_src, uint32_t &q_n, gd_lds_u8p row) {
     GdCur c{mp, mp + mlen, true};
-    GdWin win{mp - 8, 0}; // (nothing loaded yet: the first byte asked for moves it)
+    GdWin win{mp - GD_WIN, row}; // (nothing loaded yet: the first byte asked for moves it)
     q_src = nullptr; // FILL: the message's first quality string is left to the caller (the wave copies its lanes' strings together)
     q_n = 0;
     sz = GdSizes{0, 0, 0, 0, 0};
@@ -535,12 +550,13 @@ __device__ bool gd_parse_message(const uint8_t *u, const uint8_t *mp, uint32_t m
 
 // a lane per mapping: its node / offset / strand, its edits' lengths and sequence bytes, the offsets behind them
 __global__ __launch_bounds__(256) void gd_fill_maps_kernel(const uint8_t *__restrict__ u, const GdMapRec *__restrict__ recs, uint32_t n_maps, GdOut o) {
+    GD_WIN_ROWS(rows);
     const uint32_t m = blockIdx.x * 256u + threadIdx.x;
     if (m >= n_maps) return;
     const GdMapRec r = recs[m];
     const uint8_t *p = u + (r.pos & ((1ull << 40) - 1ull));
     GdCur mc{p, p + (r.pos >> 40), true};
-    GdWin win{p - 8, 0};
+    GdWin win{p - GD_WIN, gd_win_row(rows)};
     int64_t node, off;
     uint8_t rev;
     uint32_t ne, ns;
@@ -555,6 +571,7 @@ __global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict
                                                        uint32_t n_msg, int keep_unmapped, uint32_t *__restrict__ keep, uint32_t *__restrict__ n_map,
                                                        uint32_t *__restrict__ n_edit, uint32_t *__restrict__ n_eseq, uint32_t *__restrict__ n_qual,
                                                        uint32_t *__restrict__ bad) {
+    GD_WIN_ROWS(rows);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_msg) return;
     GdSizes sz;
@@ -563,7 +580,7 @@ __global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict
     int64_t fn, fo;
     const uint8_t *qs;
     uint32_t qn;
-    const bool ok = gd_parse_message<false>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, nullptr, 0, 0, 0, 0, fn, fo, qs, qn);
+    const bool ok = gd_parse_message<false>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, nullptr, 0, 0, 0, 0, fn, fo, qs, qn, gd_win_row(rows));
     if (!ok) atomicAdd(bad, 1u);
     const bool kp = ok && (keep_unmapped || identity != 0.0); // readGAM.h:47: "Discard unmapped reads"
     keep[i] = kp ? 1u : 0u;
@@ -577,6 +594,7 @@ __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict_
                                                       uint32_t n_msg, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ r_at,
                                                       const uint32_t *__restrict__ m_at, const uint32_t *__restrict__ e_at, const uint32_t *__restrict__ s_at,
                                                       const uint32_t *__restrict__ q_at, GdOut o, GdMapRec *__restrict__ recs) {
+    GD_WIN_ROWS(rows);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) { // the offsets' leading zeros
         o.map_off[0] = 0;
@@ -592,7 +610,7 @@ __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict_
         int32_t mapq;
         int64_t fn, fo;
         const uint32_t r = r_at[i];
-        (void)gd_parse_message<true>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, o, recs, m_at[i], e_at[i], s_at[i], q_at[i], fn, fo, q_src, q_n);
+        (void)gd_parse_message<true>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, o, recs, m_at[i], e_at[i], s_at[i], q_at[i], fn, fo, q_src, q_n, gd_win_row(rows));
         q_dst = q_at[i];
         o.map_off[r + 1] = m_at[i] + sz.n_map;
         o.qual_off[r + 1] = q_at[i] + sz.qual;

@@ -100,39 +100,47 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
         nm = (uint32_t)(m1 - m0);
         nq = (uint32_t)q_len;
         uint32_t a_len = 0, g_len = 0;
-        if (ok) { // ---- pass 1: every mapping on known ground, the read's lengths
+        bool empty_seg = false; // one of the read's first nm edits takes no column
+        if (ok) { // ---- every mapping on known ground, the read's lengths
             bool bad = false;
             uint32_t gn = 0, an = 0;
             for (uint32_t mi = lane; mi < nm; mi += 64u) {
+                // everything a mapping's checks read is asked for at once, at indices made safe first (an id outside the graph reads the
+                // lowest node's words, a mapping without an edit the read's first edit's): the loads of a mapping are then two trips to
+                // memory deep -- the mapping's own words, then what they point at -- where the checks between them made them five
                 const int64_t m = m0 + mi;
                 const int64_t id = s.m_node[m];
-                if (id < g.min_id || id > g.max_id) {
-                    bad = true;
-                    continue;
-                }
-                const int32_t pb = g.pangenome_base[id];
-                if (pb < 0 || (uint64_t)pb >= g.n_mapp) {
+                const int64_t off_raw = s.m_offset[m];
+                const int64_t ea = s.edit_off[m], eb = s.edit_off[m + 1];
+                const bool id_ok = id >= g.min_id && id <= g.max_id;
+                const int64_t idc = id_ok ? id : g.min_id;
+                const int32_t pb = g.pangenome_base[idc];
+                const int64_t len = g.node_seq_off[idc + 1] - g.node_seq_off[idc];
+                const int64_t ec = eb > ea ? ea : e0; // (e0 is an edit of this read: e1 - e0 >= nm > 0)
+                const int64_t from_first = s.e_len[ec];
+                const int64_t sl_first = (int64_t)s.e_seq_off[ec + 1] - (int64_t)s.e_seq_off[ec];
+                if (!id_ok || pb < 0 || (uint64_t)pb >= g.n_mapp) {
                     bad = true;
                     continue;
                 }
                 kmin = min(kmin, (uint32_t)id);
                 kmax = max(kmax, (uint32_t)id);
-                const int64_t len = g.node_seq_off[id + 1] - g.node_seq_off[id];
-                int64_t off = s.m_offset[m];
+                int64_t off = off_raw;
                 if (off == (int64_t)INT32_MIN) { // (the offset did not fit 32 bits: the two walks of the general form disagree on such a read)
                     bad = true;
                     continue;
                 }
-                for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
-                    const int64_t from = s.e_len[e];
+                for (int64_t e = ea; e < eb; ++e) {
+                    const int64_t from = e == ea ? from_first : (int64_t)s.e_len[e];
                     if (from < 0 || off > len || off < 0) { // (an edit that is not a match or a substitution: -1)
                         bad = true;
                         break;
                     }
-                    const int64_t sl = (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
+                    const int64_t sl = e == ea ? sl_first : (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
                     const int64_t n = min(from, len - off);
                     gn += (uint32_t)n;
                     an += (uint32_t)(sl > 0 ? sl : n);
+                    empty_seg = empty_seg || (n == 0 && e - e0 < (int64_t)nm);
                     off += from;
                 }
             }
@@ -149,55 +157,11 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
             // (|quality| <= |algnseq| and node ids within VGAN_HC_SREC's 18 bits: flatten.cpp's tile contract of a packed batch)
             ok = ok && a_len == g_len && a_len <= DF_COLS && a_len > 0 && nq <= a_len && kmax <= VGAN_HC_SREC_MAX_NODE;
         }
-        if (ok) {
-            // ---- pass 2: segment i = mapping i with the size of the read's i-th EDIT: start = min(A, sum of the sizes before), length
-            // min(size, A - start); a segment without a column sends the read to the general kernel (the host's business)
-            bool empty_seg = false;
-            uint32_t g_base = 0, e_base = 0;
-            for (uint32_t mb = 0; mb < nm && e_base < nm; mb += 64u) {
-                const uint32_t mi = mb + lane;
-                const bool on = mi < nm;
-                uint32_t gn = 0, ne = 0;
-                int64_t len = 0, off0 = 0;
-                if (on) {
-                    const int64_t m = m0 + mi, id = s.m_node[m];
-                    len = g.node_seq_off[id + 1] - g.node_seq_off[id];
-                    off0 = s.m_offset[m];
-                    int64_t off = off0;
-                    for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
-                        const int64_t from = s.e_len[e];
-                        gn += (uint32_t)min(from, len - off);
-                        off += from;
-                        ++ne;
-                    }
-                }
-                uint32_t gp = gn, ep = ne;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t x = __shfl_up(gp, d, 64), z = __shfl_up(ep, d, 64);
-                    if ((int)lane >= d) {
-                        gp += x;
-                        ep += z;
-                    }
-                }
-                const uint32_t g_tot = __shfl(gp, 63, 64), e_tot = __shfl(ep, 63, 64);
-                if (on) {
-                    uint32_t before = g_base + gp - gn, eq = e_base + ep - ne; // sizes of the edits before this mapping's first; its index
-                    int64_t off = off0;
-                    for (int64_t e = s.edit_off[m0 + mi]; e < s.edit_off[m0 + mi + 1] && eq < nm; ++e, ++eq) {
-                        const int64_t from = s.e_len[e];
-                        const uint32_t n = (uint32_t)min(from, len - off);
-                        const uint32_t start = min(a_len, before);
-                        empty_seg = empty_seg || min(n, a_len - start) == 0;
-                        before += n;
-                        off += from;
-                    }
-                }
-                g_base += g_tot;
-                e_base += e_tot;
-            }
-            ok = __builtin_amdgcn_ballot_w64(empty_seg) == 0;
-        }
+        // (segment i = mapping i with the size of the read's i-th EDIT, start = min(A, sum of the sizes before), length min(size, A - start);
+        // a segment without a column sends the read to the general kernel, the host's business.  For a read that got here the sizes add
+        // up to A, so a segment is empty exactly when its edit's size is zero: seen in the pass above, edit by edit -- a second pass over
+        // the mappings with a scan of the sizes stood here and was half of this kernel's time)
+        ok = ok && __builtin_amdgcn_ballot_w64(empty_seg) == 0;
         if (ok) {
             f = DF_DEVICE;
             A = a_len;
@@ -222,7 +186,19 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
         }
     }
     } // (the wave's next read)
-    if (lane != 0) return;
+    // the workgroup's counts through LDS, then one lane's atomics: a launch of 32 768 waves sending seven atomics each to the same few
+    // words took 2.4 ms for 500 k reads whatever else it did -- ~10 ns an atomic, one after the other (the launch is now 2 048 workgroups)
+    __shared__ uint32_t red_s[4][8];
+    if (lane == 0) {
+        uint32_t *w = red_s[threadIdx.x >> 6];
+        w[0] = c_in, w[1] = c_unm, w[2] = c_dev, w[3] = c_clamped, w[4] = mx_segs, w[5] = mx_qual, w[6] = mx_cols, w[7] = mx_span;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int k = 1; k < 4; ++k) {
+        c_in += red_s[k][0], c_unm += red_s[k][1], c_dev += red_s[k][2], c_clamped += red_s[k][3];
+        mx_segs = max(mx_segs, red_s[k][4]), mx_qual = max(mx_qual, red_s[k][5]), mx_cols = max(mx_cols, red_s[k][6]), mx_span = max(mx_span, red_s[k][7]);
+    }
     if (c_in) atomicAdd(&ctr->n_in, c_in);
     if (c_unm) atomicAdd(&ctr->n_unmapped, c_unm);
     if (c_dev) {
@@ -676,7 +652,7 @@ static int df_run_slices(vgan_hc_devflat *f, const std::vector<DfSlice> &hs, uin
     int rc;
     for (size_t i = 0; i < np; ++i)
         if (hs[i].n_reads)
-            hipLaunchKernelGGL(hc_df_classify_kernel, dim3(std::min<uint32_t>((hs[i].n_reads + 3) / 4, 8192u)), dim3(256), 0, st, hs[i], f->g, f->flag.p, f->key.p,
+            hipLaunchKernelGGL(hc_df_classify_kernel, dim3(std::min<uint32_t>((hs[i].n_reads + 3) / 4, 2048u)), dim3(256), 0, st, hs[i], f->g, f->flag.p, f->key.p,
                                f->info.p, f->ctr.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(f->slices.p, hs.data(), np * sizeof(DfSlice), hipMemcpyHostToDevice, st));
