@@ -48,6 +48,13 @@ int vgan_device_count(void);
 /* Brings the HIP runtime and the device up (the first HIP call of a process costs ~0.25 s): call it on a thread of its
  * own while the graph loads.  Optional. */
 int vgan_device_warmup(int device);       /* number of visible HIP devices (0 if none) */
+/* (ABI 7) loads the code objects of the kernels a run will launch, now and beside each other, instead of one by one at their first
+ * launches (what: VGAN_PRELOAD_* bits; call after vgan_device_warmup, on a thread of its own) */
+#define VGAN_PRELOAD_GAM 1u  /* the GAM front end on the device: inflate, framing, protobuf walk */
+#define VGAN_PRELOAD_HC 2u   /* HaploCart: flatten, segment kernels, mask pass */
+#define VGAN_PRELOAD_EUKA 4u /* euka: read kernel, flatten */
+#define VGAN_PRELOAD_SB 8u   /* soibean: analyse_GAM, refresh, flatten */
+int vgan_device_preload(int device, unsigned what);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph (host side).  Replaces bdsg::ODGI + NodeInfo[] + the hcfiles sidecars.

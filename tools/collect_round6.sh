@@ -9,5 +9,5 @@ f=$(ls gpurun_out/prof_${tag}_inflate/*/*kernel_stats.csv 2>/dev/null | head -1)
 f=$(ls gpurun_out/prof_${tag}_gamdev/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f profiles/${tag}_gamdev_kernel_stats.csv
 for f in default euka soibean soibean2m; do cp gpurun_out/${tag}_bench_$f.json profiles/; done
 cp gpurun_out/${tag}_len_sweep.jsonl gpurun_out/${tag}_class_sweep.jsonl profiles/
-for f in inflate gamdev e2e_haplocart e2e_euka e2e_soibean pytest_gpu smoke; do [ -f gpurun_out/${tag}_$f.log ] && cp gpurun_out/${tag}_$f.log profiles/${tag}_$f.log; done
+for f in inflate gamdev e2e_haplocart e2e_euka e2e_soibean pytest_gpu smoke frontend_kernels bench_default_wall; do [ -f gpurun_out/${tag}_$f.log ] && cp gpurun_out/${tag}_$f.log profiles/${tag}_$f.log; done
 ls -la profiles | grep ${tag}

@@ -39,7 +39,7 @@ for tag, env in (("host", {"VGAN_HC_DEVICE_GAM": "0"}), ("device", {"VGAN_HC_DEV
     cpu = (c1.children_user - c0.children_user) + (c1.children_system - c0.children_system)
     print("%-8s rc=%d  %.2f s wall, %.2f s of host CPU (%.2f us per read), %.2f M reads/s" % (tag, r.returncode, dt, cpu, cpu / n * 1e6, n / dt / 1e6), flush=True)
     for ln in r.stderr.splitlines():
-        if "device front end" in ln or "does not take" in ln or (("gampipe piece" in ln or "hc consume" in ln or "hc_devflat" in ln) and tag == "device2") or ("haplocart @" in ln and ("contexts ready" in ln or "on the device" in ln)):
+        if "device front end" in ln or "code objects" in ln or "HIP runtime up" in ln or "does not take" in ln or (("gampipe piece" in ln or "hc consume" in ln or "hc_devflat" in ln) and tag == "device2") or ("haplocart @" in ln and ("contexts ready" in ln or "on the device" in ln)):
             print("   ", ln[:1200])
     if tag == "device2" and os.environ.get("E2E_FULL"):
         print(r.stderr[-6000:])

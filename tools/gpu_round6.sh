@@ -15,17 +15,18 @@ bash tools/gpu_profile.sh ${tag}_soibean --path soibean --reads 2000000 --steps 
 bash tools/gpu_profile.sh ${tag}_euka --path euka --steps 20 --warmup 5 > gpurun_out/${tag}_profile_euka.log 2>&1
 python3 tools/len_sweep.py 2>&1 | grep read_len > gpurun_out/${tag}_len_sweep.jsonl
 python3 tools/class_sweep.py 2>&1 | grep mappability_values > gpurun_out/${tag}_class_sweep.jsonl
-timeout 1200 python3 bench.py --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/${tag}_bench_default.json
+t0=$(date +%s); timeout 1200 python3 bench.py 2>&1 | tail -1 > gpurun_out/${tag}_bench_default.json; echo "python3 bench.py (no flags): $(( $(date +%s) - t0 )) s of wall clock" > gpurun_out/${tag}_bench_default_wall.log
 timeout 900 python3 bench.py --path euka --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/${tag}_bench_euka.json
 timeout 900 python3 bench.py --path soibean --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/${tag}_bench_soibean.json
 timeout 900 python3 bench.py --path soibean --reads 2000000 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/${tag}_bench_soibean2m.json
 # the inflate kernels alone on a 1 M-read file: trace, then SQ counters
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_inflate -- python3 $R/tools/dev/inflate_time.py 1000000 > $R/gpurun_out/${tag}_inflate.log 2>&1)
 bash tools/dev/pmc_cmd.sh ${tag}_inflate $R/tools/dev/inflate_time.py 1000000 > gpurun_out/${tag}_inflate_pmc.log 2>&1
+bash tools/dev/frontend_kernels.sh 500000 > gpurun_out/${tag}_frontend_kernels.log 2>&1
 bash tools/gpu_profile_gamdev.sh ${tag}_gamdev 10000000 > gpurun_out/${tag}_gamdev_run.log 2>&1
 python3 tools/e2e_device_gam.py 10000000 2>&1 | grep -v "gampipe piece\|hc consume\|hc_devflat" | cut -c1-1500 > gpurun_out/${tag}_e2e_haplocart.log
 python3 tools/e2e_device_euka.py 5000000 2>&1 | cut -c1-900 > gpurun_out/${tag}_e2e_euka.log
 python3 tools/e2e_device_soibean.py 2000000 2>&1 | cut -c1-900 > gpurun_out/${tag}_e2e_soibean.log
-cat gpurun_out/${tag}_pytest_gpu.log gpurun_out/${tag}_smoke.log gpurun_out/${tag}_len_sweep.jsonl
+cat gpurun_out/${tag}_pytest_gpu.log gpurun_out/${tag}_smoke.log gpurun_out/${tag}_len_sweep.jsonl gpurun_out/${tag}_bench_default_wall.log
 for f in default euka soibean soibean2m; do head -c 600 gpurun_out/${tag}_bench_$f.json; echo; done
 tail -5 gpurun_out/${tag}_e2e_haplocart.log gpurun_out/${tag}_e2e_euka.log gpurun_out/${tag}_e2e_soibean.log

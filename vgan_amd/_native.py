@@ -194,6 +194,7 @@ SYMBOLS = {
     "vgan_host_release_memory": (None, [C.c_int]),
     "vgan_device_count": (C.c_int, []),
     "vgan_device_warmup": (C.c_int, [C.c_int]),
+    "vgan_device_preload": (C.c_int, [C.c_int, C.c_uint]),
     "vgan_graph_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp)]),
     "vgan_graph_from_arrays": (C.c_int, [C.POINTER(GraphView), C.POINTER(vp)]),
     "vgan_graph_view_get": (C.c_int, [vp, C.POINTER(GraphView)]),

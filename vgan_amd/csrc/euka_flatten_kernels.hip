@@ -489,3 +489,5 @@ extern "C" int vgan_euka_batch_download(const vgan_euka_batch *dev, const vgan_e
 #undef DL
     return VGAN_OK;
 }
+#include "module_anchor.h"
+const void *vgan::anchor_euka_flatten() { return (const void *)&vgan::edf::euka_df_gather_kernel; }

@@ -798,3 +798,5 @@ void launch_euka_reads(const EukaDev &d, const EukaBatchDev &b, const EukaOutDev
 }
 
 } // namespace vgan
+#include "module_anchor.h"
+const void *vgan::anchor_euka_kernels() { return (const void *)&vgan::euka_clear_kernel; }

@@ -902,3 +902,5 @@ int gamdev_crc(const uint8_t *d_out, const GdBlock *d_blocks, uint32_t n_blocks,
 }
 
 } // namespace vgan
+#include "module_anchor.h"
+const void *vgan::anchor_gam_inflate_wave() { return (const void *)&vgan::gd::gd_crc_kernel; }

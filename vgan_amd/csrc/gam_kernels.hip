@@ -1505,3 +1505,5 @@ extern "C" int vgan_gamdev_picked(const vgan_gamdev *g, uint64_t *offsets, uint8
     HIPCHK(hipMemcpy(bytes, g->picked_bytes.p, g->n_picked_bytes, hipMemcpyDeviceToHost));
     return VGAN_OK;
 }
+#include "module_anchor.h"
+const void *vgan::anchor_gam_kernels() { return (const void *)&vgan::gd::gd_next_anchor_kernel; }

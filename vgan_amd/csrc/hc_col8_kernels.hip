@@ -976,3 +976,5 @@ void launch_hc_segments_col8(const HcGraphDev &g, const HcPackedDev &pk, const H
 }
 
 } // namespace vgan
+#include "module_anchor.h"
+const void *vgan::anchor_hc_col8() { return (const void *)&vgan::c8::hc_col8_memo_kernel; }

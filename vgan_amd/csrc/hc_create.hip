@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "hc_ctx.h"
+#include "module_anchor.h"
 #include "hc_device.h"
 #include "host/common.h"
 #include "vgan_gpu.h"
@@ -88,6 +89,44 @@ extern "C" int vgan_device_warmup(int device) {
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(VGAN_ENODEV, "vgan_device_warmup: no HIP device %d", device);
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
+    return VGAN_OK;
+}
+
+// The code objects of the kernels a run will launch, loaded now and beside each other (a thread per translation unit): left to the first
+// launch of each, they load one after the other along the first piece's way through the stages -- upload, inflate, framing, protobuf walk,
+// flatten each waited 40-70 ms for the next one's on the 10 M-read file, ~0.25 s in all.  what: VGAN_PRELOAD_* bits.
+extern "C" int vgan_device_preload(int device, unsigned what) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(VGAN_ENODEV, "vgan_device_preload: no HIP device %d", device);
+    std::vector<std::pair<const char *, const void *>> fns;
+    // (the runtime loads them one after the other whatever the threads do, roughly in the order they ask: what the contexts' creation
+    // launches first -- small --, then the stages of a piece in the order it meets them)
+    if (what & VGAN_PRELOAD_HC) fns.push_back({"hc col8", anchor_hc_col8()}), fns.push_back({"hc sweep", anchor_hc_kernels()});
+    if (what & VGAN_PRELOAD_EUKA) fns.push_back({"euka", anchor_euka_kernels()});
+    if (what & VGAN_PRELOAD_SB) fns.push_back({"soibean", anchor_sb_kernels()});
+    if (what & VGAN_PRELOAD_GAM) fns.push_back({"inflate", anchor_gam_inflate_wave()}), fns.push_back({"framing + protobuf", anchor_gam_kernels()});
+    if (what & VGAN_PRELOAD_HC) fns.push_back({"hc flatten", anchor_hc_flatten()}), fns.push_back({"hc wave", anchor_hc_wave()});
+    if (what & VGAN_PRELOAD_EUKA) fns.push_back({"euka flatten", anchor_euka_flatten()});
+    if (what & VGAN_PRELOAD_SB) fns.push_back({"soibean flatten", anchor_sb_flatten()});
+    const bool timing = getenv("VGAN_TIMING") != nullptr;
+    std::vector<std::thread> ts;
+    std::vector<double> ms(fns.size(), 0.0);
+    for (size_t i = 0; i < fns.size(); ++i) {
+        if (i) std::this_thread::sleep_for(std::chrono::microseconds(200)); // (so that they ask in this order)
+        ts.emplace_back([&, i] {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipFuncAttributes a;
+            if (hipSetDevice(device) == hipSuccess) (void)hipFuncGetAttributes(&a, fns[i].second);
+            (void)hipGetLastError();
+            ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+    }
+    for (auto &t : ts) t.join();
+    if (timing) {
+        std::string line;
+        for (size_t i = 0; i < fns.size(); ++i) line += (i ? ", " : "") + std::string(fns[i].first) + " " + std::to_string((int)(ms[i] + 0.5));
+        fprintf(stderr, "[vgan timing] code objects loaded beside each other (ms each, from the common start): %s\n", line.c_str());
+    }
     return VGAN_OK;
 }
 

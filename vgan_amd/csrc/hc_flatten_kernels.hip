@@ -818,3 +818,5 @@ extern "C" int vgan_hc_devflat_run_gamdev_cb(vgan_hc_devflat *f, const vgan_gamd
     s.n_reads = R_all, s.read0 = 0;
     return df_run_slices(f, hs, R_all, base, out, host_mask, stats, pt, mask_ready, user);
 }
+#include "module_anchor.h"
+const void *vgan::anchor_hc_flatten() { return (const void *)&vgan::df::hc_df_gather_kernel; }

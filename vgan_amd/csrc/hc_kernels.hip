@@ -1131,3 +1131,5 @@ void launch_hc_posterior(const double *final_vec, uint32_t n_paths, const uint32
 }
 
 } // namespace vgan
+#include "module_anchor.h"
+const void *vgan::anchor_hc_kernels() { return (const void *)&vgan::hc_finish_kernel; }

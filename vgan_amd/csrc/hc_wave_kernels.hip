@@ -983,3 +983,5 @@ void launch_hc_segments_wave(const HcGraphDev &g, const HcPackedDev &pk, const H
 }
 
 } // namespace vgan
+#include "module_anchor.h"
+const void *vgan::anchor_hc_wave() { return (const void *)&vgan::wv::hc_srec_nodes_kernel; }

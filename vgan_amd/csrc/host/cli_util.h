@@ -27,6 +27,24 @@ namespace vgan_cli {
 
 [[noreturn]] inline void die(const std::string &msg) { throw std::runtime_error(msg); }
 
+// The HIP runtime comes up on a thread of its own while the tables are read (its failure shows at context creation), and behind it the
+// code objects of the run's kernels are loaded beside each other (vgan_device_preload; VGAN_NO_PRELOAD=1: left to their first launches).
+struct DeviceWarm {
+    std::thread t, pre;
+    void start(int device, unsigned what) {
+        t = std::thread([this, device, what] {
+            if (vgan_device_warmup(device) >= 0 && !getenv("VGAN_NO_PRELOAD")) pre = std::thread([device, what] { (void)vgan_device_preload(device, what); });
+        });
+    }
+    void wait_runtime() { // (the runtime is up -- or has failed; the code objects may still be loading)
+        if (t.joinable()) t.join();
+    }
+    ~DeviceWarm() {
+        if (t.joinable()) t.join();
+        if (pre.joinable()) pre.join();
+    }
+};
+
 // ---- leaving without waiting for the teardown ------------------------------------------------------------------------
 // A run leaves gigabytes resident and a GPU context behind; the kernel takes them apart inside the process's exit
 // (0.2-0.6 s for the 3-4 GB of a million reads), after every output has been written.  So the work runs in a CHILD process

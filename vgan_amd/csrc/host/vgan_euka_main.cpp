@@ -220,6 +220,8 @@ int euka_main(int argc, char **argv) {
             }
         }
     }
+    DeviceWarm warm; // (the runtime and the run's code objects, beside the tables' loading)
+    warm.start(gpu_list.empty() ? 0 : gpu_list[0], VGAN_PRELOAD_EUKA | (device_gam ? VGAN_PRELOAD_GAM : 0u));
     GamReader reader; // unmapped reads are kept so that they are counted
     GdRun gd; // (started now: upload, inflate, framing and parse need neither tables nor contexts and run beside their set-up)
     if (device_gam) {

@@ -188,18 +188,13 @@ int haplocart(int argc, char **argv) {
         }
     }
     if (!device_gam) check(vgan_gam_stream_open(gamfilename.c_str(), 0, &stream.s), "reading GAM");
-    // the HIP runtime comes up on a thread of its own while the graph is read (its failure shows at context creation)
-    struct Warm {
-        std::thread t;
-        ~Warm() {
-            if (t.joinable()) t.join();
-        }
-    } warm;
+    // the HIP runtime comes up on a thread of its own while the graph is read, the run's code objects behind it (cli_util.h: DeviceWarm)
+    DeviceWarm warm;
     {
         int warm_dev = device; // (the first GPU the run will use: the runtime's start-up creates its context there)
         const std::string spec = !gpu_spec.empty() ? gpu_spec : (getenv("VGAN_GPUS") ? std::string(getenv("VGAN_GPUS")) : std::string());
         if (!spec.empty() && spec != "all" && isdigit((unsigned char)spec[0])) warm_dev = atoi(spec.c_str());
-        warm.t = std::thread([d = warm_dev] { (void)vgan_device_warmup(d); });
+        warm.start(warm_dev, VGAN_PRELOAD_HC | (device_gam ? VGAN_PRELOAD_GAM : 0u));
     }
     // which GPUs: --gpus LIST, the environment's VGAN_GPUS, or the one of --device
     // (the HIP runtime is still coming up: only "--gpus all" has to wait for it here, to know how many contexts there will
@@ -207,7 +202,7 @@ int haplocart(int argc, char **argv) {
     if (gpu_spec.empty())
         if (const char *e = getenv("VGAN_GPUS")) gpu_spec = e;
     if (gpu_spec == "all") {
-        if (warm.t.joinable()) warm.t.join();
+        warm.wait_runtime();
         const int n_visible = vgan_device_count();
         if (n_visible <= 0) die("[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only");
         for (int d = 0; d < n_visible; ++d) gpu_list.push_back(d);
@@ -307,7 +302,7 @@ int haplocart(int argc, char **argv) {
         }
     } creator;
     creator.t = std::thread([&] {
-        if (warm.t.joinable()) warm.t.join();
+        warm.wait_runtime();
         stamp("HIP runtime up");
         if (vgan_device_count() <= 0) {
             creator.err = "[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only";

@@ -199,6 +199,8 @@ int soibean_main(int argc, char **argv) {
         for (int d : gpu_list)
             if (d >= vgan_device_count()) device_gam = false; // (reported below, once the tables are read)
     }
+    DeviceWarm warm; // (the runtime and the run's code objects, beside the graph's and the tree's loading)
+    warm.start(gpu_list.empty() ? 0 : gpu_list[0], VGAN_PRELOAD_SB | (device_gam ? VGAN_PRELOAD_GAM : 0u));
     GamReader reader;
     GdRun gd; // (started now: upload, inflate, framing and parse need neither graph nor contexts and run beside their set-up)
     if (device_gam) {

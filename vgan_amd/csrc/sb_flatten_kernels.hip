@@ -574,3 +574,5 @@ extern "C" int vgan_sb_batch_download(const vgan_sb_batch *dev, const vgan_sb_ba
 #undef DL
     return VGAN_OK;
 }
+#include "module_anchor.h"
+const void *vgan::anchor_sb_flatten() { return (const void *)&vgan::sdf::sb_df_classify_kernel; }

@@ -1151,3 +1151,5 @@ void launch_sb_loglike(const SbTablesDev &t, uint32_t n_paths, uint32_t n_states
 }
 
 } // namespace vgan
+#include "module_anchor.h"
+const void *vgan::anchor_sb_kernels() { return (const void *)&vgan::sb_finish_kernel; }
