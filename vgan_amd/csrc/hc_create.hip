@@ -136,11 +136,9 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         return fail(VGAN_EINVAL, "vgan_hc_create: incomplete graph view");
     if (!(params->background_error_prob >= 0.0 && params->background_error_prob <= 1.0))
         return fail(VGAN_EINVAL, "Error: background error probability must be between 0 and 1"); // HaploCart.cpp:107-113
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(VGAN_ENODEV, "vgan_hc_create: no HIP device is visible (this library has no CPU path)");
-    if (device < 0 || device >= ndev) return fail(VGAN_EINVAL, "vgan_hc_create: device %d out of range (%d visible)", device, ndev);
-    HIPCHK(hipSetDevice(device));
+    // (what follows until the first device call is host work -- the mask's transposition, the node classes, the tables, the names: ~0.1 s
+    // on the hcfiles graph.  A caller that starts this beside the runtime's start-up, vgan_device_warmup on another thread, has it done
+    // when the runtime is: the device is first asked for below, where the arrays go up.)
     auto c = new vgan_hc_ctx();
     c->device = device;
     c->P = gv->n_paths;
@@ -155,9 +153,6 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         vgan_hc_destroy(c);
         return code;
     };
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(fail(VGAN_ENODEV, "hipStreamCreate failed"));
-    c->stream = c->own_stream;
     // unsupported-path mask: plain rows + the per-tile bit-transposed copy the sweep reads (hc_device.h)
     std::vector<uint64_t> um((size_t)c->rows * c->W, 0);
     for (uint32_t r = 0; r < c->rows; ++r) {
@@ -269,6 +264,30 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
         tb[456 + 3 * Q + 1] = consensus ? (double)logl(1.0L - (long double)params->background_error_prob) : (double)logl((long double)om);
         tb[456 + 3 * Q + 2] = (double)(1.0L / (long double)om);
     }
+    // posterior side tables
+    {
+        std::istringstream in(gv->path_names ? gv->path_names : "");
+        std::string line;
+        while (std::getline(in, line)) {
+            std::istringstream ls(line);
+            std::string tok;
+            if (!(ls >> tok)) continue;
+            c->path_index.emplace(tok, (uint32_t)c->path_names.size());
+            c->path_names.push_back(tok);
+        }
+        parse_relatives(gv->parents_txt, c->parents);
+        parse_relatives(gv->children_txt, c->children);
+    }
+    // ---- the device
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return bail(fail(VGAN_ENODEV, "vgan_hc_create: no HIP device is visible (this library has no CPU path)"));
+        if (device < 0 || device >= ndev) return bail(fail(VGAN_EINVAL, "vgan_hc_create: device %d out of range (%d visible)", device, ndev));
+        if (hipSetDevice(device) != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: hipSetDevice(%d) failed", device));
+        if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(VGAN_ENODEV, "hipStreamCreate failed"));
+        c->stream = c->own_stream;
+    }
     const size_t accn = (size_t)c->W * 64;
     if ((rc = c->umask.reserve(um.size())) || (rc = c->umaskT.reserve(umT.size())) ||
         (rc = c->tile_word0.reserve(tw0.size())) || (rc = c->node_tab.reserve(nt.size())) || (rc = c->tables.reserve(756)) ||
@@ -320,20 +339,6 @@ extern "C" int vgan_hc_create(const vgan_graph_view *gv, const vgan_hc_params *p
     c->g.n_tiles = c->n_tiles;
     c->g.tile_base_words = tile_base;
     c->g.n_paths = c->P;
-    // posterior side tables
-    {
-        std::istringstream in(gv->path_names ? gv->path_names : "");
-        std::string line;
-        while (std::getline(in, line)) {
-            std::istringstream ls(line);
-            std::string tok;
-            if (!(ls >> tok)) continue;
-            c->path_index.emplace(tok, (uint32_t)c->path_names.size());
-            c->path_names.push_back(tok);
-        }
-        parse_relatives(gv->parents_txt, c->parents);
-        parse_relatives(gv->children_txt, c->children);
-    }
     if ((rc = vgan_hc_reset(c))) return bail(rc);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(VGAN_ENODEV, "vgan_hc_create: sync failed"));
     *out = c;

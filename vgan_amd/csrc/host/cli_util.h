@@ -15,6 +15,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 #include <iostream>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,9 +32,12 @@ namespace vgan_cli {
 // code objects of the run's kernels are loaded beside each other (vgan_device_preload; VGAN_NO_PRELOAD=1: left to their first launches).
 struct DeviceWarm {
     std::thread t, pre;
+    std::function<void()> on_up; // (called on the warm-up's thread when the runtime is up)
     void start(int device, unsigned what) {
         t = std::thread([this, device, what] {
-            if (vgan_device_warmup(device) >= 0 && !getenv("VGAN_NO_PRELOAD")) pre = std::thread([device, what] { (void)vgan_device_preload(device, what); });
+            const int rc = vgan_device_warmup(device);
+            if (on_up) on_up();
+            if (rc >= 0 && !getenv("VGAN_NO_PRELOAD")) pre = std::thread([device, what] { (void)vgan_device_preload(device, what); });
         });
     }
     void wait_runtime() { // (the runtime is up -- or has failed; the code objects may still be loading)

@@ -194,6 +194,7 @@ int haplocart(int argc, char **argv) {
         int warm_dev = device; // (the first GPU the run will use: the runtime's start-up creates its context there)
         const std::string spec = !gpu_spec.empty() ? gpu_spec : (getenv("VGAN_GPUS") ? std::string(getenv("VGAN_GPUS")) : std::string());
         if (!spec.empty() && spec != "all" && isdigit((unsigned char)spec[0])) warm_dev = atoi(spec.c_str());
+        warm.on_up = [&stamp] { stamp("HIP runtime up"); };
         warm.start(warm_dev, VGAN_PRELOAD_HC | (device_gam ? VGAN_PRELOAD_GAM : 0u));
     }
     // which GPUs: --gpus LIST, the environment's VGAN_GPUS, or the one of --device
@@ -302,12 +303,9 @@ int haplocart(int argc, char **argv) {
         }
     } creator;
     creator.t = std::thread([&] {
-        warm.wait_runtime();
-        stamp("HIP runtime up");
-        if (vgan_device_count() <= 0) {
-            creator.err = "[HaploCart] no HIP device is visible: the likelihood path runs on the GPU only";
-            return;
-        }
+        // (not waited for: vgan_hc_create's host work -- the mask's transposition, the tables -- runs beside the runtime's start-up and asks
+        // for the device when it is done)
+        if (getenv("VGAN_HC_CREATE_AFTER_RUNTIME")) warm.wait_runtime(); // (developer A/B)
         for (int d : gpu_list) {
             vgan_hc_ctx *c = nullptr;
             if (vgan_hc_create(&gv, &prm, d, &c) < 0 ||
