@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: `vgan euka --no-mcmc` end to end on one synthetic GAM of 75 bp aDNA-like reads (BASELINE configs[3] is 5 M of them), host
 pipeline (VGAN_EUKA_DEVICE_GAM=0) against the front end on the device (=1): python3 tools/e2e_device_euka.py [n_reads]"""
+import atexit
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -18,6 +20,7 @@ exe = os.path.join(ROOT, "vgan_amd/bin/vgan")
 gold = os.path.join(ROOT, "tests/golden/damageProfiles")
 p5, p3 = gold + "/dhigh5p.prof", gold + "/dhigh3p.prof"
 d = tempfile.mkdtemp(dir="/tmp")
+atexit.register(shutil.rmtree, d, True)  # (5 GB per run: a box that is used again would fill up)
 dm = ek.Damage.load(p5, p3)
 CH = 1000000
 t0 = time.time()

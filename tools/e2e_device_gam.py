@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: `vgan haplocart` end to end on one synthetic GAM, host pipeline (VGAN_HC_DEVICE_GAM=0) against the front end on the device
 (=1), with VGAN_TIMING's lines (python3 tools/e2e_device_gam.py [n_reads] [keep|dedup])."""
+import atexit
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -15,6 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 dedup = len(sys.argv) > 2 and sys.argv[2] == "dedup"
 g = hc.synth_graph()
 d = tempfile.mkdtemp(dir="/tmp")
+atexit.register(shutil.rmtree, d, True)  # (5 GB per run: a box that is used again would fill up)
 g.write(d)
 t0 = time.time()
 CH = 1000000
@@ -29,7 +32,7 @@ print("GAM of %d reads: %.1f MB, written in %.0f s" % (n, os.path.getsize(d + "/
 outs = {}
 for tag, env in (("host", {"VGAN_HC_DEVICE_GAM": "0"}), ("device", {"VGAN_HC_DEVICE_GAM": "1"}), ("host2", {"VGAN_HC_DEVICE_GAM": "0"}), ("device2", {"VGAN_HC_DEVICE_GAM": "1"})):
     t = time.time()
-    cmd = [os.path.join(ROOT, "vgan_amd/bin/vgan"), "haplocart", "-g", d + "/r.gam", "--hc-files", d, "-q", "-t", "-1", "-d", "-o", d + "/" + tag + ".tsv"]
+    cmd = [os.environ.get("VGAN_EXE") or os.path.join(ROOT, "vgan_amd/bin/vgan"), "haplocart", "-g", d + "/r.gam", "--hc-files", d, "-q", "-t", "-1", "-d", "-o", d + "/" + tag + ".tsv"]
     if not dedup:
         cmd.append("--keep-duplicates")
     c0 = os.times()

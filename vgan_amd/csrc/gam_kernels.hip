@@ -480,7 +480,10 @@ __device__ __forceinline__ bool gd_walk_mapping(GdCur mc, GdWin &win, int64_t &n
 // the places the exclusive sums give it, and a GdMapRec per mapping -- the mappings' and edits' arrays are filled by a lane per MAPPING
 // (gd_fill_maps_kernel: neighbouring lanes write neighbouring elements; a lane per message wrote six arrays at 64 places 240 bytes apart,
 // every line of them filled over thirty stores and long gone from the L2 by then: 100 ms for the 10 M-read file around a walk of 26).
-template <bool FILL>
+// WALK true: every mapping is walked here (its edits counted into sz.n_edit / sz.eseq); false: a mapping is hopped over -- its tag, its
+// length -- and its inside is the per-mapping passes' (gd_map_count_kernel, gd_fill_maps_kernel), where the lanes of a wave sit at the same
+// place of neighbouring mappings instead of at 64 different places of 64 messages' nested fields.
+template <bool FILL, bool WALK>
 __device__ bool gd_parse_message(const uint8_t *u, const uint8_t *mp, uint32_t mlen, GdSizes &sz, double &identity, int32_t &mapq, const GdOut &o,
                                  GdMapRec *recs, uint32_t m0, uint32_t e0, uint32_t s0, uint32_t q0, int64_t &first_node, int64_t &first_off,
                                  const uint8_t *&q_src, uint32_t &q_n, gd_lds_u8p row) {
@@ -504,18 +507,22 @@ __device__ bool gd_parse_message(const uint8_t *u, const uint8_t *mp, uint32_t m
                 if (f2 == 2 && w2 == 2) { // a mapping
                     GdCur mc = gc_sub(path, win);
                     if (!path.ok || (uint64_t)(mc.e - mc.p) >= (1ull << 24)) return false; // (GdMapRec holds a mapping's length in 24 bits)
-                    int64_t node, off;
-                    uint8_t rev;
-                    uint32_t ne, ns;
-                    if (!gd_walk_mapping<false>(mc, win, node, off, rev, ne, ns, o, 0, 0)) return false;
-                    if (sz.n_map == 0) {
-                        first_node = node;
-                        first_off = off;
+                    if (WALK || (FILL && sz.n_map == 0)) { // (the read's first mapping says its duplicate key: src/rmdup.cpp)
+                        int64_t node, off;
+                        uint8_t rev;
+                        uint32_t ne, ns;
+                        // (a first mapping that does not parse: the message pass that only hops goes on -- every mapping's record must be
+                        // written -- and the per-mapping pass reports it)
+                        if (!gd_walk_mapping<false>(mc, win, node, off, rev, ne, ns, o, 0, 0) && WALK) return false;
+                        if (sz.n_map == 0) {
+                            first_node = node;
+                            first_off = off;
+                        }
+                        sz.n_edit += ne;
+                        sz.eseq += ns;
                     }
-                    if (FILL) recs[m0 + sz.n_map] = GdMapRec{(uint64_t)(mc.p - u) | (uint64_t)(mc.e - mc.p) << 40, e0 + sz.n_edit, s0 + sz.eseq};
+                    if (FILL) recs[m0 + sz.n_map] = GdMapRec{(uint64_t)(mc.p - u) | (uint64_t)(mc.e - mc.p) << 40, 0u, 0u};
                     sz.n_map += 1;
-                    sz.n_edit += ne;
-                    sz.eseq += ns;
                 } else gc_skip(path, w2, win);
             }
             if (!path.ok) return false;
@@ -548,10 +555,39 @@ __device__ bool gd_parse_message(const uint8_t *u, const uint8_t *mp, uint32_t m
     return c.ok;
 }
 
-// a lane per mapping: its node / offset / strand, its edits' lengths and sequence bytes, the offsets behind them
-__global__ __launch_bounds__(256) void gd_fill_maps_kernel(const uint8_t *__restrict__ u, const GdMapRec *__restrict__ recs, uint32_t n_maps, GdOut o) {
+// a lane per mapping, first pass: how many edits it has and how many bytes their sequences take (exclusive sums of the two say where every
+// mapping's edits go: the first of them IS edit_off[]); a mapping that does not parse counts as a malformed message
+__global__ __launch_bounds__(256) void gd_map_count_kernel(const uint8_t *__restrict__ u, const GdMapRec *__restrict__ recs, uint32_t n_maps, uint32_t *__restrict__ n_edit,
+                                                           uint32_t *__restrict__ n_eseq, uint32_t *__restrict__ bad) {
     GD_WIN_ROWS(rows);
     const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m > n_maps) return;
+    if (m == n_maps) { // (the sums' last input: their output there is the total)
+        n_edit[m] = 0;
+        n_eseq[m] = 0;
+        return;
+    }
+    const GdMapRec r = recs[m];
+    const uint8_t *p = u + (r.pos & ((1ull << 40) - 1ull));
+    GdCur mc{p, p + (r.pos >> 40), true};
+    GdWin win{p - GD_WIN, gd_win_row(rows)};
+    int64_t node, off;
+    uint8_t rev;
+    uint32_t ne = 0, ns = 0;
+    if (!gd_walk_mapping<false>(mc, win, node, off, rev, ne, ns, GdOut{}, 0, 0)) {
+        atomicAdd(bad, 1u);
+        ne = ns = 0;
+    }
+    n_edit[m] = ne;
+    n_eseq[m] = ns;
+}
+
+// a lane per mapping, second pass: its node / offset / strand, its edits' lengths and sequence bytes, the offsets behind them.  s_at[m] (the
+// mapping's first edit-sequence byte) lies where m_offset[m] will: read before it is written
+__global__ __launch_bounds__(256) void gd_fill_maps_kernel(const uint8_t *__restrict__ u, const GdMapRec *__restrict__ recs, uint32_t n_maps, const uint32_t *s_at, GdOut o) {
+    GD_WIN_ROWS(rows);
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m == 0) o.e_seq_off[0] = 0;
     if (m >= n_maps) return;
     const GdMapRec r = recs[m];
     const uint8_t *p = u + (r.pos & ((1ull << 40) - 1ull));
@@ -560,17 +596,16 @@ __global__ __launch_bounds__(256) void gd_fill_maps_kernel(const uint8_t *__rest
     int64_t node, off;
     uint8_t rev;
     uint32_t ne, ns;
-    (void)gd_walk_mapping<true>(mc, win, node, off, rev, ne, ns, o, r.e_at, r.s_at);
+    const uint32_t e_at = o.edit_off[m], sa = s_at[m];
+    (void)gd_walk_mapping<true>(mc, win, node, off, rev, ne, ns, o, e_at, sa);
     o.m_node[m] = node < 0 || node > 0xFFFFFFFEll ? 0xFFFFFFFFu : (uint32_t)node;
     o.m_offset[m] = off != (int64_t)(int32_t)off || (int32_t)off == INT32_MIN ? INT32_MIN : (int32_t)off;
     o.m_rev[m] = rev;
-    o.edit_off[m + 1] = r.e_at + ne;
 }
 
 __global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict__ u, const uint64_t *__restrict__ msg_off, const uint32_t *__restrict__ msg_len,
                                                        uint32_t n_msg, int keep_unmapped, uint32_t *__restrict__ keep, uint32_t *__restrict__ n_map,
-                                                       uint32_t *__restrict__ n_edit, uint32_t *__restrict__ n_eseq, uint32_t *__restrict__ n_qual,
-                                                       uint32_t *__restrict__ bad) {
+                                                       uint32_t *__restrict__ n_qual, uint32_t *__restrict__ bad) {
     GD_WIN_ROWS(rows);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_msg) return;
@@ -580,27 +615,25 @@ __global__ __launch_bounds__(256) void gd_count_kernel(const uint8_t *__restrict
     int64_t fn, fo;
     const uint8_t *qs;
     uint32_t qn;
-    const bool ok = gd_parse_message<false>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, nullptr, 0, 0, 0, 0, fn, fo, qs, qn, gd_win_row(rows));
-    if (!ok) atomicAdd(bad, 1u);
+    bool ok = gd_parse_message<false, false>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, nullptr, 0, 0, 0, 0, fn, fo, qs, qn, gd_win_row(rows));
     const bool kp = ok && (keep_unmapped || identity != 0.0); // readGAM.h:47: "Discard unmapped reads"
+    // (a message that is dropped is never seen by the per-mapping passes: its mappings are walked here -- the host parser refuses a file
+    // with a malformed mapping whether or not the read is kept)
+    if (ok && !kp && sz.n_map) ok = gd_parse_message<false, true>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, GdOut{}, nullptr, 0, 0, 0, 0, fn, fo, qs, qn, gd_win_row(rows));
+    if (!ok) atomicAdd(bad, 1u);
     keep[i] = kp ? 1u : 0u;
     n_map[i] = kp ? sz.n_map : 0u;
-    n_edit[i] = kp ? sz.n_edit : 0u;
-    n_eseq[i] = kp ? sz.eseq : 0u;
     n_qual[i] = kp ? sz.qual : 0u;
 }
 
 __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict__ u, const uint64_t *__restrict__ msg_off, const uint32_t *__restrict__ msg_len,
                                                       uint32_t n_msg, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ r_at,
-                                                      const uint32_t *__restrict__ m_at, const uint32_t *__restrict__ e_at, const uint32_t *__restrict__ s_at,
-                                                      const uint32_t *__restrict__ q_at, GdOut o, GdMapRec *__restrict__ recs) {
+                                                      const uint32_t *__restrict__ m_at, const uint32_t *__restrict__ q_at, GdOut o, GdMapRec *__restrict__ recs) {
     GD_WIN_ROWS(rows);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) { // the offsets' leading zeros
         o.map_off[0] = 0;
         o.qual_off[0] = 0;
-        o.edit_off[0] = 0;
-        o.e_seq_off[0] = 0;
     }
     const uint8_t *q_src = nullptr;
     uint32_t q_n = 0, q_dst = 0;
@@ -610,7 +643,7 @@ __global__ __launch_bounds__(256) void gd_fill_kernel(const uint8_t *__restrict_
         int32_t mapq;
         int64_t fn, fo;
         const uint32_t r = r_at[i];
-        (void)gd_parse_message<true>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, o, recs, m_at[i], e_at[i], s_at[i], q_at[i], fn, fo, q_src, q_n, gd_win_row(rows));
+        (void)gd_parse_message<true, false>(u, u + msg_off[i], msg_len[i], sz, identity, mapq, o, recs, m_at[i], 0, 0, q_at[i], fn, fo, q_src, q_n, gd_win_row(rows));
         q_dst = q_at[i];
         o.map_off[r + 1] = m_at[i] + sz.n_map;
         o.qual_off[r + 1] = q_at[i] + sz.qual;
@@ -1255,35 +1288,56 @@ int vgan::gd::gd_piece_parse(vgan_gamdev *g, const GdCarry &cin, bool last_piece
     if ((rc = g->bad.reserve(4))) return rc;
     HIPCHK(hipMemsetAsync(g->bad.p, 0, 4, st));
     hipLaunchKernelGGL(gd_count_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, u, g->msg_off.p, g->msg_len.p, NM, keep_unmapped, g->keep.p, g->n_map.p,
-                       g->n_edit.p, g->n_eseq.p, g->n_qual.p, g->bad.p);
+                       g->n_qual.p, g->bad.p);
     HIPCHK(hipGetLastError());
-    if ((rc = exclusive_sum(g, g->keep.p, g->r_at.p, NM)) || (rc = exclusive_sum(g, g->n_map.p, g->m_at.p, NM)) || (rc = exclusive_sum(g, g->n_edit.p, g->e_at.p, NM)) ||
-        (rc = exclusive_sum(g, g->n_eseq.p, g->s_at.p, NM)) || (rc = exclusive_sum(g, g->n_qual.p, g->q_at.p, NM)))
+    if ((rc = exclusive_sum(g, g->keep.p, g->r_at.p, NM)) || (rc = exclusive_sum(g, g->n_map.p, g->m_at.p, NM)) || (rc = exclusive_sum(g, g->n_qual.p, g->q_at.p, NM)))
         return rc;
-    uint32_t last[10], bad = 0;
+    uint32_t last[6], bad = 0;
     {
-        const uint32_t *srcs[10] = {g->keep.p, g->n_map.p, g->n_edit.p, g->n_eseq.p, g->n_qual.p, g->r_at.p, g->m_at.p, g->e_at.p, g->s_at.p, g->q_at.p};
-        for (int k = 0; k < 10; ++k) HIPCHK(hipMemcpyAsync(&last[k], srcs[k] + (NM - 1), 4, hipMemcpyDeviceToHost, st));
+        const uint32_t *srcs[6] = {g->keep.p, g->n_map.p, g->n_qual.p, g->r_at.p, g->m_at.p, g->q_at.p};
+        for (int k = 0; k < 6; ++k) HIPCHK(hipMemcpyAsync(&last[k], srcs[k] + (NM - 1), 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&bad, g->bad.p, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     if (bad) return fail(VGAN_EIO, "vgan_gamdev_parse: %u malformed alignment messages", bad);
     // (32-bit sums: every array is a subset of the stream's bytes, which are fewer than 2^32 -- checked above -- so none of them wraps)
-    g->R = (uint64_t)last[0] + last[5];
-    g->M = (uint64_t)last[1] + last[6];
-    g->E = (uint64_t)last[2] + last[7];
-    g->S = (uint64_t)last[3] + last[8];
-    g->Q = (uint64_t)last[4] + last[9];
-    if ((rc = g->map_off.reserve(g->R + 1)) || (rc = g->qual_off.reserve(g->R + 1)) || (rc = g->edit_off.reserve(g->M + 1)) || (rc = g->e_seq_off.reserve(g->E + 1)) ||
-        (rc = g->m_node.reserve(g->M + 1)) || (rc = g->m_offset.reserve(g->M + 1)) || (rc = g->mapq.reserve(g->R + 1)) || (rc = g->e_len.reserve(g->E + 1)) ||
-        (rc = g->unmapped.reserve(g->R + 1)) || (rc = g->m_rev.reserve(g->M + 1)) || (rc = g->e_seq.reserve(g->S + 1)) || (rc = g->qual.reserve(g->Q + 1)) ||
-        (rc = g->first_node.reserve(g->R + 1)) || (rc = g->first_offset.reserve(g->R + 1)) || (rc = g->map_rec.reserve(g->M + 1)) || (rc = g->seq_len.reserve(g->R + 1)))
+    g->R = (uint64_t)last[0] + last[3];
+    g->M = (uint64_t)last[1] + last[4];
+    g->Q = (uint64_t)last[2] + last[5];
+    g->E = g->S = 0;
+    if ((rc = g->map_off.reserve(g->R + 1)) || (rc = g->qual_off.reserve(g->R + 1)) || (rc = g->edit_off.reserve(g->M + 2)) || (rc = g->m_node.reserve(g->M + 1)) ||
+        (rc = g->m_offset.reserve(g->M + 2)) || (rc = g->mapq.reserve(g->R + 1)) || (rc = g->unmapped.reserve(g->R + 1)) || (rc = g->m_rev.reserve(g->M + 1)) ||
+        (rc = g->qual.reserve(g->Q + 1)) || (rc = g->first_node.reserve(g->R + 1)) || (rc = g->first_offset.reserve(g->R + 1)) || (rc = g->map_rec.reserve(g->M + 1)) ||
+        (rc = g->seq_len.reserve(g->R + 1)))
         return rc;
-    GdOut o{g->map_off.p, g->qual_off.p, g->edit_off.p, g->e_seq_off.p, g->m_node.p, g->m_offset.p, g->mapq.p, g->e_len.p, g->unmapped.p, g->m_rev.p, g->e_seq.p,
+    GdOut o{g->map_off.p, g->qual_off.p, g->edit_off.p, nullptr, g->m_node.p, g->m_offset.p, g->mapq.p, nullptr, g->unmapped.p, g->m_rev.p, nullptr,
             g->qual.p, g->first_node.p, g->first_offset.p, g->seq_len.p};
-    hipLaunchKernelGGL(gd_fill_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, u, g->msg_off.p, g->msg_len.p, NM, g->keep.p, g->r_at.p, g->m_at.p, g->e_at.p,
-                       g->s_at.p, g->q_at.p, o, g->map_rec.p);
-    if (g->M) hipLaunchKernelGGL(gd_fill_maps_kernel, dim3((uint32_t)((g->M + 255) / 256)), dim3(256), 0, st, u, g->map_rec.p, (uint32_t)g->M, o);
+    // per message: what is per read, and where every mapping's bytes lie
+    hipLaunchKernelGGL(gd_fill_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, u, g->msg_off.p, g->msg_len.p, NM, g->keep.p, g->r_at.p, g->m_at.p, g->q_at.p, o,
+                       g->map_rec.p);
+    HIPCHK(hipGetLastError());
+    // per mapping: its edits counted (into edit_off[] itself and, for their sequence bytes, into the words m_offset[] will take), the two
+    // summed in place -- edit_off[] is then final --, the totals read, the edits' arrays asked for and filled
+    uint32_t *s_at_m = reinterpret_cast<uint32_t *>(g->m_offset.p);
+    const uint32_t NMAP = (uint32_t)g->M;
+    hipLaunchKernelGGL(gd_map_count_kernel, dim3((NMAP + 1 + 255) / 256), dim3(256), 0, st, u, g->map_rec.p, NMAP, g->edit_off.p, s_at_m, g->bad.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = exclusive_sum(g, g->edit_off.p, g->edit_off.p, (size_t)NMAP + 1)) || (rc = exclusive_sum(g, s_at_m, s_at_m, (size_t)NMAP + 1))) return rc;
+    {
+        uint32_t tot[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(&tot[0], g->edit_off.p + NMAP, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&tot[1], s_at_m + NMAP, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&bad, g->bad.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (bad) return fail(VGAN_EIO, "vgan_gamdev_parse: %u malformed alignment messages", bad);
+        g->E = tot[0];
+        g->S = tot[1];
+    }
+    if ((rc = g->e_seq_off.reserve(g->E + 1)) || (rc = g->e_len.reserve(g->E + 1)) || (rc = g->e_seq.reserve(g->S + 1))) return rc;
+    o.e_seq_off = g->e_seq_off.p;
+    o.e_len = g->e_len.p;
+    o.e_seq = g->e_seq.p;
+    hipLaunchKernelGGL(gd_fill_maps_kernel, dim3((NMAP + 1 + 255) / 256), dim3(256), 0, st, u, g->map_rec.p, NMAP, s_at_m, o);
     HIPCHK(hipGetLastError());
     // what vgan_gamdev_pick will want, asked for now: device memory asked for while another thread asks for the packed batch's 12 GB
     // and the device is busy took 180 ms there (its four arrays per message are the count arrays above, done with by then)

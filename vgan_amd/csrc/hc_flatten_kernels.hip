@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "gam_device.h"
+#include "wave_scan.h"
 #include "gam_object.h"
 #include "hc_device.h"
 #include "host/common.h"
@@ -84,7 +85,9 @@ __global__ __launch_bounds__(256) void hc_df_classify_kernel(DfSlice s, DfGraph 
     // (a wave takes many reads and sends its counts once: an atomic per read on the same few words serialises the whole launch --
     // 10 M reads x 6 atomics at ~12 ns were 0.69 of the 0.8 s a 10 M-read file's flatten took)
     uint32_t c_in = 0, c_unm = 0, c_dev = 0, c_clamped = 0, mx_segs = 0, mx_qual = 0, mx_cols = 0, mx_span = 0;
-    for (uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6); r < s.n_reads; r += gridDim.x * 4u) {
+    // (the wave's index through a scalar register: the read's offsets and the slice's pointers are then scalar loads, not 64 copies of one)
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (uint32_t r = blockIdx.x * 4u + wv; r < s.n_reads; r += gridDim.x * 4u) {
     const uint32_t gr = s.read0 + r;
     uint8_t f = DF_HOST;
     uint32_t A = 0, G = 0, kmin = 0xFFFFFFFFu, kmax = 0u, nm = 0, nq = 0;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restr
                                                           uint32_t src_base, DfOut out) {
     __shared__ uint8_t gs_s[4][DF_COLS], ps_s[4][DF_COLS];
     __shared__ uint16_t own_s[4][DF_COLS], sz_s[4][DF_SEGS];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (scalar: see the classify kernel)
     uint8_t *gs = gs_s[wave], *ps = ps_s[wave];
     uint16_t *own = own_s[wave], *sz = sz_s[wave];
     for (uint32_t o = blockIdx.x * 4u + wave; o <= n_dev; o += gridDim.x * 4u) {
@@ -273,17 +276,26 @@ __global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restr
             const uint32_t mi = mb + lane;
             const bool on = mi < nm;
             uint32_t gn = 0, an = 0, ne = 0;
-            int64_t id = 0, len = 0, off0 = 0;
+            int64_t id = 0, len = 0, off0 = 0, ea = 0, eb = 0, nso = 0, from_first = 0, sl_first = 0;
             bool rev = false;
             if (on) {
+                // (a mapping's words asked for at once, then what they point at -- its node's place, its first edit: the mappings of
+                // these files have one edit --, as in the classify kernel; the second loop below takes them from here)
                 const int64_t m = m0 + mi;
                 id = s.m_node[m];
-                len = g.node_seq_off[id + 1] - g.node_seq_off[id];
                 off0 = s.m_offset[m];
                 rev = s.m_rev[m] != 0;
+                ea = s.edit_off[m], eb = s.edit_off[m + 1];
+                nso = g.node_seq_off[id];
+                len = g.node_seq_off[id + 1] - nso;
+                if (eb > ea) {
+                    from_first = s.e_len[ea];
+                    sl_first = (int64_t)s.e_seq_off[ea + 1] - (int64_t)s.e_seq_off[ea];
+                }
                 int64_t off = off0;
-                for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e) {
-                    const int64_t from = s.e_len[e], sl = (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
+                for (int64_t e = ea; e < eb; ++e) {
+                    const int64_t from = e == ea ? from_first : (int64_t)s.e_len[e];
+                    const int64_t sl = e == ea ? sl_first : (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
                     const uint32_t n = (uint32_t)min(from, len - off);
                     gn += n;
                     an += sl > 0 ? (uint32_t)sl : n;
@@ -291,24 +303,15 @@ __global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restr
                     ++ne;
                 }
             }
-            uint32_t gp = gn, ap = an, ep = ne; // inclusive prefix sums over the lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t x = __shfl_up(gp, d, 64), y = __shfl_up(ap, d, 64), z = __shfl_up(ep, d, 64);
-                if ((int)lane >= d) {
-                    gp += x;
-                    ap += y;
-                    ep += z;
-                }
-            }
-            const uint32_t g_tot = __shfl(gp, 63, 64), a_tot = __shfl(ap, 63, 64), e_tot = __shfl(ep, 63, 64);
+            const uint32_t gp = wave_incl_scan_u32(gn), ap = wave_incl_scan_u32(an), ep = wave_incl_scan_u32(ne); // inclusive prefix sums over the lanes
+            const uint32_t g_tot = wave_last_u32(gp), a_tot = wave_last_u32(ap), e_tot = wave_last_u32(ep);
             uint32_t gq = g_base + gp - gn, aq = a_base + ap - an, eq = e_base + ep - ne; // this mapping's first places
             if (on) {
-                const int64_t m = m0 + mi;
-                const uint8_t *ns = g.node_seq + g.node_seq_off[id];
+                const uint8_t *ns = g.node_seq + nso;
                 int64_t off = off0;
-                for (int64_t e = s.edit_off[m]; e < s.edit_off[m + 1]; ++e, ++eq) {
-                    const int64_t from = s.e_len[e], sl = (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
+                for (int64_t e = ea; e < eb; ++e, ++eq) {
+                    const int64_t from = e == ea ? from_first : (int64_t)s.e_len[e];
+                    const int64_t sl = e == ea ? sl_first : (int64_t)s.e_seq_off[e + 1] - (int64_t)s.e_seq_off[e];
                     const uint32_t n = (uint32_t)min(from, len - off);
                     for (uint32_t k = 0; k < n && gq + k < A; ++k) {
                         const uint8_t b = rev ? df_comp(ns[len - 1 - (off + k)]) : ns[off + k];
@@ -338,13 +341,8 @@ __global__ __launch_bounds__(256) void hc_df_write_kernel(const DfSlice *__restr
                 const uint32_t i = sb + lane;
                 const bool on = i < nm;
                 const uint32_t n = on ? sz[i] : 0u;
-                uint32_t pp = n;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t a = __shfl_up(pp, d, 64);
-                    if ((int)lane >= d) pp += a;
-                }
-                const uint32_t p_tot = __shfl(pp, 63, 64);
+                const uint32_t pp = wave_incl_scan_u32(n);
+                const uint32_t p_tot = wave_last_u32(pp);
                 if (on) {
                     const uint32_t start = min(A, p_base + pp - n), sl = min(n, A - start);
                     out.srec[s0 + i] = VGAN_HC_SREC(s.m_node[m0 + i], start, o);
