@@ -21,6 +21,10 @@ with tempfile.TemporaryDirectory(prefix="vgan_pt_", dir="/tmp") as d:
         blobs.append(b[:-28] if c0 + CH < n else b)
 data = b"".join(blobs)
 del blobs
+if os.environ.get("PIPE_PINNED"):  # (the file's bytes in page-locked memory: what the uploads cost when they are plain DMA)
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+    data = t.numpy()
 ctx = hc.HcContext(g)
 ts = []
 for i in range(6):
@@ -30,5 +34,5 @@ for i in range(6):
     ts.append(time.perf_counter() - t0)
     if i == 5:
         print("summed over pieces:", {k: round(v) for k, v in ps.items() if k.startswith("ms_")}, "pieces", ps["n_pieces"])
-print("%s: %d reads, %.0f MB: pipeline %s ms (first run: %.0f)" % (os.path.basename(os.environ.get("VGAN_LIB", "libvgan_gpu.so")), n, len(data) / 1e6,
+print("%s: %d reads, %.0f MB: pipeline %s ms (first run: %.0f)" % (os.path.basename(os.environ.get("VGAN_LIB", "libvgan_gpu.so")), n, (data.nbytes if hasattr(data, "nbytes") else len(data)) / 1e6,
                                                                    " ".join("%.0f" % (t * 1e3) for t in ts[1:]), ts[0] * 1e3))

@@ -1090,6 +1090,7 @@ int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint
     g->tail_cap = tail_cap;
     g->u = nullptr;
     g->n_stream = 0;
+    g->inflate_checked = false;
     int rc;
     const auto t0 = std::chrono::steady_clock::now();
     if ((rc = g->in.reserve(n + 64)) || (rc = g->infl.reserve(tail_cap + total + 64)) || (rc = g->blocks.reserve(n_gb + 1)) || (rc = g->status.reserve(n_gb + 1))) return rc;
@@ -1152,6 +1153,21 @@ int vgan::gd::gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint
     return VGAN_OK;
 }
 
+int vgan::gd::gd_piece_inflated(vgan_gamdev *g) {
+    if (g->inflate_checked) return VGAN_OK;
+    HIPCHK(hipSetDevice(g->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (hipStream_t ps : g->piece_stream)
+        if (ps) HIPCHK(hipStreamSynchronize(ps));
+    int rc;
+    if ((rc = gd_check_inflate(g->in.p, g->blocks.p, g->n_blocks, g->infl.p + g->tail_cap, g->status.p, g->stream, &g->n_redone, g->h_crc.empty() ? nullptr : g->h_crc.data(),
+                               g->crc_tab.p)) < 0)
+        return rc;
+    g->ms_inflate += ms_since(t0);
+    g->inflate_checked = true;
+    return VGAN_OK;
+}
+
 int vgan::gd::gd_piece_parse(vgan_gamdev *g, const GdCarry &cin, bool last_piece, GdCarry *cout, int keep_unmapped, void (*frame_done)(void *), void *user) {
     HIPCHK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
@@ -1178,12 +1194,7 @@ int vgan::gd::gd_piece_parse(vgan_gamdev *g, const GdCarry &cin, bool last_piece
     if (total > 0xFFFFFFF0ull) return fail(VGAN_ERANGE, "the GAM front end on the device: a piece of %llu inflated bytes is beyond the parse's 32-bit offsets", (unsigned long long)total);
     uint8_t *u = g->infl.p + (g->tail_cap - n_tail);
     if (n_tail) HIPCHK(hipMemcpyAsync(u, cin.tail.data(), n_tail, hipMemcpyHostToDevice, st));
-    for (hipStream_t ps : g->piece_stream)
-        if (ps) HIPCHK(hipStreamSynchronize(ps));
-    if ((rc = gd_check_inflate(g->in.p, g->blocks.p, g->n_blocks, g->infl.p + g->tail_cap, g->status.p, st, &g->n_redone, g->h_crc.empty() ? nullptr : g->h_crc.data(),
-                               g->crc_tab.p)) < 0)
-        return rc;
-    g->ms_inflate += ms_since(t0);
+    if ((rc = gd_piece_inflated(g)) < 0) return rc; // (done already by a caller that waits for its inflate before its turn)
     g->u = u;
     g->n_stream = total;
     if (cout) {

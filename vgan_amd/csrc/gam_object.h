@@ -134,6 +134,7 @@ struct vgan_gamdev {
     uint64_t n_stream = 0;
     size_t n_blocks = 0;
     uint64_t n_redone = 0;     // (test aid) members the two-kernel inflate left to the older kernel
+    bool inflate_checked = false; // gd_piece_inflated has waited for this piece's inflate and looked at its members' states
     uint64_t n_reanchored = 0; // (test aid) tag-like bytes the framing of the parses so far took for a group's tag and gave up again
     uint64_t n_picked = 0, n_picked_bytes = 0;
     uint64_t n_inflated = 0, n_messages = 0, R = 0, M = 0, E = 0, S = 0, Q = 0;
@@ -179,6 +180,10 @@ int gd_piece_upload_inflate(vgan_gamdev *g, const uint8_t *bytes, uint64_t n_byt
 // Framing from the state `in` (its tail in front of the inflated bytes) + the protobuf walk: the piece's arrays as vgan_gamdev_parse
 // leaves a file's.  `last`: the stream ends with this piece (a walk that ends inside an item is then a truncated file); otherwise `out`
 // takes the state and the bytes left over.  frame_done (or null) is called once `out` is final: the next piece's framing may start then.
+// Waits for the piece's inflate and checks its members (a member the two kernels left is done again by the older one; a wrong CRC-32 is an
+// error).  Needs nothing of the piece before: a caller makes it BEFORE it takes its turn at the framing's hand-over (gd_piece_parse calls
+// it if the caller did not).
+int gd_piece_inflated(vgan_gamdev *g);
 int gd_piece_parse(vgan_gamdev *g, const GdCarry &in, bool last, GdCarry *out, int keep_unmapped, void (*frame_done)(void *), void *user);
 // Duplicate marks of the piece's reads against the reads of the piece itself and the keys of every piece before it (`seen`, updated);
 // added (or null): the keys the piece adds, for the other lanes' sets.

@@ -234,6 +234,12 @@ struct Pipe {
                 break;
             }
             ts[1] = ms_since(t_start);
+            // (the piece's own inflate is waited for BEFORE its turn: taken first, the turn held the pieces behind it for as long as this
+            // one's inflate still had to run -- 9 ms a piece where the hand-over itself takes 3)
+            if ((rc = gd_piece_inflated(g)) < 0) {
+                fail_with(rc, last_error());
+                break;
+            }
             // ---- the framing turn: the state the piece before left, and what this one leaves
             if (!wait_turn(framed, i)) break;
             ts[2] = ms_since(t_start);
