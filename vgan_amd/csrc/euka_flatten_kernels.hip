@@ -16,6 +16,7 @@
 #include "euka_device.h"
 #include "gam_device.h"
 #include "gam_object.h"
+#include "wave_scan.h"
 #include "host/common.h"
 #include "vgan_gpu.h"
 
@@ -59,9 +60,9 @@ __device__ __forceinline__ uint8_t edf_comp(uint8_t c) { // csrc/host/flatten.cp
 // quality bytes}; key = the first mapping's node id (vgan_euka_flatten orders its batch by it).
 __global__ __launch_bounds__(256) void euka_df_classify_kernel(GamdevSlice s, uint32_t n_reads, EdfGraph g, uint8_t *__restrict__ flag, uint32_t *__restrict__ key,
                                                                uint4 *__restrict__ info, EdfCounters *__restrict__ ctr) {
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (scalar: the read's offsets are scalar loads)
     uint32_t c_dev = 0;
-    for (uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6); r < n_reads; r += gridDim.x * 4u) {
+    for (uint32_t r = blockIdx.x * 4u + wv; r < n_reads; r += gridDim.x * 4u) {
         const int64_t m0 = s.map_off[r], m1 = s.map_off[r + 1];
         const int64_t q_len = (int64_t)s.qual_off[r + 1] - (int64_t)s.qual_off[r];
         const uint32_t nm = (uint32_t)(m1 - m0), lseq = s.seq_len[r];
@@ -144,7 +145,7 @@ struct EdfOut {
 __global__ __launch_bounds__(256) void euka_df_write_kernel(GamdevSlice s, EdfGraph g, const uint32_t *__restrict__ order, const uint32_t *__restrict__ coff,
                                                             const uint32_t *__restrict__ qoff, const uint32_t *__restrict__ moff, uint32_t n_dev, uint32_t src_base,
                                                             EdfOut out) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (uint32_t o = blockIdx.x * 4u + wave; o <= n_dev; o += gridDim.x * 4u) {
         if (lane == 0) {
             out.read_col_off[o] = coff[o];
@@ -179,16 +180,8 @@ __global__ __launch_bounds__(256) void euka_df_write_kernel(GamdevSlice s, EdfGr
                     off += from;
                 }
             }
-            uint32_t gp = gn, ap = an; // inclusive prefix sums over the lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t x = __shfl_up(gp, d, 64), y = __shfl_up(ap, d, 64);
-                if ((int)lane >= d) {
-                    gp += x;
-                    ap += y;
-                }
-            }
-            const uint32_t g_tot = __shfl(gp, 63, 64), a_tot = __shfl(ap, 63, 64);
+            const uint32_t gp = wave_incl_scan_u32(gn), ap = wave_incl_scan_u32(an); // inclusive prefix sums over the lanes (DPP)
+            const uint32_t g_tot = wave_last_u32(gp), a_tot = wave_last_u32(ap);
             uint32_t gq = g_base + gp - gn, aq = a_base + ap - an; // this mapping's first places
             if (on) {
                 const int64_t m = m0 + mi;

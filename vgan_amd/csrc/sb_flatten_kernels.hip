@@ -16,6 +16,7 @@
 
 #include "gam_device.h"
 #include "gam_object.h"
+#include "wave_scan.h"
 #include "host/common.h"
 #include "sb_device.h"
 #include "vgan_gpu.h"
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void sb_df_classify_kernel(GamdevSlice s, uint
                                                              uint32_t *__restrict__ segs) {
     const uint32_t lane = threadIdx.x & 63u;
     const int64_t lo_id = g.min_id > 1 ? g.min_id : 1;
-    for (uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6); r <= n_reads; r += gridDim.x * 4u) {
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (scalar: the read's offsets are scalar loads)
+    for (uint32_t r = blockIdx.x * 4u + wv; r <= n_reads; r += gridDim.x * 4u) {
         if (r == n_reads) { // (the scans' last input: their output there is the total)
             if (lane == 0) take[r] = cols[r] = quals[r] = segs[r] = 0;
             break;
@@ -144,7 +146,7 @@ struct SdfBase { // what the batch holds already: the piece's rows go behind
 __global__ __launch_bounds__(256) void sb_df_write_kernel(GamdevSlice s, SdfGraph g, const uint8_t *__restrict__ flag, const uint4 *__restrict__ info,
                                                           const uint32_t *__restrict__ tpos, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ qoff,
                                                           const uint32_t *__restrict__ soff, uint32_t n_reads, uint32_t src_base, SdfBase base, SdfOut out) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (uint32_t r = blockIdx.x * 4u + wave; r < n_reads; r += gridDim.x * 4u) {
         if (flag[r] != SDF_DEVICE) continue;
         const uint32_t o = base.reads + tpos[r], c0 = base.cols + coff[r], q0 = base.quals + qoff[r], sg0 = base.segs + soff[r];
@@ -177,17 +179,8 @@ __global__ __launch_bounds__(256) void sb_df_write_kernel(GamdevSlice s, SdfGrap
                     off += from;
                 }
             }
-            uint32_t gp = gn, ap = an, ep = ne; // inclusive prefix sums over the lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t x = __shfl_up(gp, d, 64), y = __shfl_up(ap, d, 64), z = __shfl_up(ep, d, 64);
-                if ((int)lane >= d) {
-                    gp += x;
-                    ap += y;
-                    ep += z;
-                }
-            }
-            const uint32_t g_tot = __shfl(gp, 63, 64), a_tot = __shfl(ap, 63, 64), e_tot = __shfl(ep, 63, 64);
+            const uint32_t gp = wave_incl_scan_u32(gn), ap = wave_incl_scan_u32(an), ep = wave_incl_scan_u32(ne); // inclusive prefix sums over the lanes (DPP)
+            const uint32_t g_tot = wave_last_u32(gp), a_tot = wave_last_u32(ap), e_tot = wave_last_u32(ep);
             uint32_t gq = g_base + gp - gn, aq = a_base + ap - an, ei = e_base + ep - ne; // this mapping's first places
             if (on) {
                 const int64_t m = m0 + mi;
