@@ -140,17 +140,20 @@ def test_vgan_euka_over_the_device_front_end_writes_the_host_pipelines_files(tmp
     outs = {}
     for tag, extra, env in (("host", [], {"VGAN_EUKA_DEVICE_GAM": "0"}), ("dev", [], {"VGAN_EUKA_DEVICE_GAM": "1", "VGAN_GAMPIPE_PIECE": "400000", "VGAN_TIMING": "1"}),
                             ("dev3", ["--gpus", "0,0,0"], {"VGAN_EUKA_DEVICE_GAM": "1", "VGAN_GAMPIPE_PIECE": "400000", "VGAN_TIMING": "1"}),
-                            ("frag", ["--outFrag"], {"VGAN_EUKA_DEVICE_GAM": "1", "VGAN_TIMING": "1"})):
+                            ("frag", ["--outFrag"], {"VGAN_EUKA_DEVICE_GAM": "1", "VGAN_TIMING": "1"}),
+                            # (a piece the device flatten refuses -- its columns beyond the cap the test sets: the contexts are cleared and the host pipeline takes the file)
+                            ("refused", [], {"VGAN_EUKA_DEVICE_GAM": "1", "VGAN_GAMPIPE_PIECE": "400000", "VGAN_TIMING": "1", "VGAN_EUKA_DEVFLAT_MAX_COLS": "1000"})):
         r = subprocess.run([exe, "euka", "-g", gam, "--euka_dir", str(tmp_path), "--deam5p", p5, "--deam3p", p3, "-o", str(tmp_path / tag)] + args + extra,
                            capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         assert ("euka device front end" in r.stderr) == (tag in ("dev", "dev3")), r.stderr[-1500:]
+        assert ("the host pipeline does" in r.stderr and "32-bit offsets" in r.stderr) == (tag == "refused"), r.stderr[-1500:]
         if tag == "dev3":
             assert "on 3 lane(s)" in r.stderr
         outs[tag] = _tree(str(tmp_path / tag))
         outs[tag + "_counts"] = [ln for ln in r.stderr.splitlines() if ln.startswith("Number of")]
-    assert outs["host_counts"] == outs["dev_counts"] == outs["dev3_counts"] and len(outs["host_counts"]) == 3
-    for other in ("dev", "dev3"):
+    assert outs["host_counts"] == outs["dev_counts"] == outs["dev3_counts"] == outs["refused_counts"] and len(outs["host_counts"]) == 3
+    for other in ("dev", "dev3", "refused"):
         assert sorted(outs["host"]) == sorted(outs[other]) and len(outs["host"]) >= 6
         for k in outs["host"]:
             if outs["host"][k] != outs[other][k]:  # only rounding of summed doubles may differ

@@ -173,17 +173,20 @@ def test_vgan_soibean_over_the_device_front_end_writes_the_host_pipelines_files(
     exe = os.path.join(ROOT, "vgan_amd", "bin", "vgan")
     outs = {}
     for tag, gpus, env in (("host", "0", {"VGAN_SB_DEVICE_GAM": "0"}), ("dev", "0", {"VGAN_SB_DEVICE_GAM": "1", "VGAN_GAMPIPE_PIECE": "300000", "VGAN_TIMING": "1"}),
-                           ("dev3", "0,0,0", {"VGAN_SB_DEVICE_GAM": "1", "VGAN_GAMPIPE_PIECE": "300000", "VGAN_TIMING": "1"})):
+                           ("dev3", "0,0,0", {"VGAN_SB_DEVICE_GAM": "1", "VGAN_GAMPIPE_PIECE": "300000", "VGAN_TIMING": "1"}),
+                           # (a piece the device flatten refuses -- its columns beyond the cap the test sets: the host pipeline takes the file from its start)
+                           ("refused", "0", {"VGAN_SB_DEVICE_GAM": "1", "VGAN_GAMPIPE_PIECE": "300000", "VGAN_TIMING": "1", "VGAN_SB_DEVFLAT_MAX_COLS": "1000"})):
         out = str(tmp_path / (tag + "_"))
         r = subprocess.run([exe, "soibean", "-g", gam, "--soibean_dir", str(db), "--dbprefix", "Synth", "--deam5p", profs[0], "--deam3p", profs[1], "--iter", "120",
                             "--burnin", "20", "--chains", "2", "--seed", "7", "-o", out, "--gpus", gpus, "-t", "-1"], capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-3000:]
-        assert ("soibean device front end" in r.stderr) == (tag != "host"), r.stderr[-1500:]
+        assert ("soibean device front end" in r.stderr) == (tag in ("dev", "dev3")), r.stderr[-1500:]
+        assert ("the host pipeline does" in r.stderr and "32-bit offsets" in r.stderr) == (tag == "refused"), r.stderr[-1500:]
         if tag == "dev3":
             assert "on 3 lane(s)" in r.stderr and "3 device contexts, the reads dealt piece by piece" in r.stderr
         outs[tag] = (_chain_files(out), [l for l in r.stderr.splitlines() if "log-likelihood" in l or "signature" in l or l.startswith("Number of")])
     assert len(outs["host"][0]) >= 7 and len(outs["host"][1]) >= 3
-    for other in ("dev", "dev3"):
+    for other in ("dev", "dev3", "refused"):
         assert sorted(outs["host"][0]) == sorted(outs[other][0])
         for name in outs["host"][0]:
             assert outs["host"][0][name] == outs[other][0][name], name

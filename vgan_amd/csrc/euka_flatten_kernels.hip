@@ -413,7 +413,8 @@ extern "C" int vgan_euka_devflat_run_gamdev(vgan_euka_devflat *f, const vgan_gam
     HIPCHK(hipMemcpyAsync(&tot[2], f->moff.p + n_dev, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&cols64, f->tot64.p, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (cols64 > 0xFFFFFFF0ull)
+    static const char *lim = getenv("VGAN_EUKA_DEVFLAT_MAX_COLS"); // (test aid: the refusal without four billion columns)
+    if (cols64 > (lim ? strtoull(lim, nullptr, 10) : 0xFFFFFFF0ull))
         return fail(VGAN_ERANGE, "vgan_euka_devflat_run_gamdev: %llu alignment columns in one piece are beyond 32-bit offsets; parse fewer bytes at a time", (unsigned long long)cols64);
     const size_t nd = n_dev;
     if ((rc = f->read_col_off.reserve(nd + 1)) || (rc = f->read_qual_off.reserve(nd + 1)) || (rc = f->read_map_off.reserve(nd + 1)) || (rc = f->read_src.reserve(nd)) ||

@@ -454,7 +454,8 @@ extern "C" int vgan_sb_devflat_append_gamdev(vgan_sb_devflat *f, const vgan_gamd
         stats->n_out = n_dev;
     }
     if (n_dev == 0) return VGAN_OK;
-    if (cols64 > 0xFFFFFFF0ull)
+    static const char *lim = getenv("VGAN_SB_DEVFLAT_MAX_COLS"); // (test aid: the refusal without four billion columns)
+    if (cols64 > (lim ? strtoull(lim, nullptr, 10) : 0xFFFFFFF0ull))
         return fail(VGAN_ERANGE, "vgan_sb_devflat_append_gamdev: %llu alignment columns in one piece are beyond 32-bit offsets; parse fewer bytes at a time", (unsigned long long)cols64);
     if ((rc = f->grow(n_dev, tot[1], tot[2], tot[3]))) return rc;
     SdfOut o{f->read_seg_off.p, f->read_col_off.p, f->read_qual_off.p, f->read_src.p, f->seg_node.p,  f->read_gseq_len.p, f->read_rseq_len.p,
