@@ -308,3 +308,13 @@ def test_a_piece_whose_columns_would_wrap_the_offsets_is_refused_and_the_cli_tak
     assert outs["host"][0] == outs["refused"][0]
     ll = [dict((ln.split("\t")[0], float(ln.split("\t")[1])) for ln in o[1].splitlines()) for o in (outs["host"], outs["refused"])]
     assert ll[0].keys() == ll[1].keys() and all(ll[1][k] == pytest.approx(v, rel=1e-9) for k, v in ll[0].items())
+
+
+def test_the_code_objects_of_every_translation_unit_can_be_loaded_ahead():
+    """vgan_device_preload: every VGAN_PRELOAD_* bit names kernels the runtime finds (a stale anchor would fail here, not at a run's start)."""
+    L = N.lib()
+    assert L.vgan_device_warmup(0) == 0
+    for what in (1, 2, 4, 8, 15):
+        assert L.vgan_device_preload(0, what) == 0
+    assert L.vgan_device_preload(1 << 20, 15) < 0  # (no such device)
+

@@ -116,12 +116,15 @@ extern "C" int vgan_device_preload(int device, unsigned what) {
         ts.emplace_back([&, i] {
             const auto t0 = std::chrono::steady_clock::now();
             hipFuncAttributes a;
-            if (hipSetDevice(device) == hipSuccess) (void)hipFuncGetAttributes(&a, fns[i].second);
+            ms[i] = -1.0; // (until the kernel has been found)
+            const bool ok = hipSetDevice(device) == hipSuccess && hipFuncGetAttributes(&a, fns[i].second) == hipSuccess;
             (void)hipGetLastError();
-            ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ok) ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         });
     }
     for (auto &t : ts) t.join();
+    for (size_t i = 0; i < fns.size(); ++i)
+        if (ms[i] < 0) return fail(VGAN_ENODEV, "vgan_device_preload: the runtime does not find the kernels of \"%s\"", fns[i].first);
     if (timing) {
         std::string line;
         for (size_t i = 0; i < fns.size(); ++i) line += (i ? ", " : "") + std::string(fns[i].first) + " " + std::to_string((int)(ms[i] + 0.5));
