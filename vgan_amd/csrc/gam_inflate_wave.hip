@@ -714,6 +714,11 @@ __global__ __launch_bounds__(64) void gd_lzw_kernel(const GdBlock *__restrict__ 
                 if (i0 + j >= n) break;
                 const uint32_t kind = t[j] >> 30, len = kind ? kind : (t[j] & 511u);
                 if (x + len > GW_W) break; // (this token and every one behind it: the next window's)
+#if defined(LZW_EXP) && (LZW_EXP & 1) // (developer pricing run: what the references' filling costs -- wrong output)
+                if (true) {
+                    if (len) ref[x] = (uint16_t)(0x8000u | (t[j] & 255u));
+                } else
+#endif
                 if (kind) {
                     for (uint32_t q = 0; q < kind; ++q) ref[x + q] = (uint16_t)(0x8000u | ((t[j] >> (8u * q)) & 255u));
                 } else {
@@ -746,27 +751,39 @@ __global__ __launch_bounds__(64) void gd_lzw_kernel(const GdBlock *__restrict__ 
                 break;
             }
             __syncthreads();
-            // ---- pointer jumping: a lane owns four consecutive references out of every 256
+            // ---- pointer jumping, 256 references at a time from the window's front (a lane owns four consecutive ones of them): a reference
+            // points backwards, so what lies in front of the 256 at hand is bytes already -- ONE look-up settles a reference into it -- and only
+            // the references into the 256 themselves (copies of copies a few bytes back) take more rounds, over 256 entries, not 4 096.  (Every
+            // round over the whole window, until no reference anywhere was open: ~7 rounds x 16 quads a lane, three quarters of this
+            // kernel's instructions.)
             const uint32_t n_quads = (w_end + 3u) / 4u;
-            for (uint32_t round = 0; round < 16u; ++round) {
-                bool open = false;
-                for (uint32_t qd = lane; qd < n_quads; qd += 64u) {
-                    uint64_t v = *reinterpret_cast<const uint64_t *>(&ref[qd * 4u]);
-                    if ((v & 0x8000800080008000ull) == 0x8000800080008000ull) continue;
-                    uint64_t nv = 0;
+#if defined(LZW_EXP) && (LZW_EXP & 2) // (developer pricing run: without the pointer jumping -- wrong output)
+            for (uint32_t qb = 0; qb < 0u; qb += 64u) {
+#else
+            for (uint32_t qb = 0; qb < n_quads; qb += 64u) {
+#endif
+                const uint32_t qd = qb + lane;
+                for (uint32_t round = 0; round < 16u; ++round) {
+                    bool open = false;
+                    if (qd < n_quads) {
+                        const uint64_t v = *reinterpret_cast<const uint64_t *>(&ref[qd * 4u]);
+                        if ((v & 0x8000800080008000ull) != 0x8000800080008000ull) {
+                            uint64_t nv = 0;
 #pragma unroll
-                    for (uint32_t c = 0; c < 4u; ++c) {
-                        uint32_t e = (uint32_t)(v >> (16u * c)) & 0xFFFFu;
-                        if (!(e & 0x8000u) && qd * 4u + c < w_end) {
-                            e = ref[e];
-                            open |= !(e & 0x8000u);
+                            for (uint32_t c = 0; c < 4u; ++c) {
+                                uint32_t e = (uint32_t)(v >> (16u * c)) & 0xFFFFu;
+                                if (!(e & 0x8000u) && qd * 4u + c < w_end) {
+                                    e = ref[e];
+                                    open |= !(e & 0x8000u);
+                                }
+                                nv |= (uint64_t)e << (16u * c);
+                            }
+                            *reinterpret_cast<uint64_t *>(&ref[qd * 4u]) = nv;
                         }
-                        nv |= (uint64_t)e << (16u * c);
                     }
-                    *reinterpret_cast<uint64_t *>(&ref[qd * 4u]) = nv;
+                    __syncthreads();
+                    if (!__builtin_amdgcn_ballot_w64(open)) break;
                 }
-                __syncthreads();
-                if (!__builtin_amdgcn_ballot_w64(open)) break;
             }
             // ---- the window's bytes: four to a lane and store
             for (uint32_t qd = lane; qd < n_quads; qd += 64u) {
