@@ -18,6 +18,10 @@ import sys
 import tempfile
 import time
 
+# (as the vgan CLI does: the device front end's pipeline -- the `front_end.device_flatten.device_gam` record -- keeps a dozen streams busy,
+# which the runtime's default four hardware queues serialise; the timed step is one stream and does not care.  Before the runtime starts.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
