@@ -159,3 +159,28 @@ def test_vgan_euka_over_the_device_front_end_writes_the_host_pipelines_files(tmp
             if outs["host"][k] != outs[other][k]:  # only rounding of summed doubles may differ
                 _same_tables(outs["host"][k], outs[other][k], 1e-9)
     assert set(outs["host"]) <= set(outs["frag"])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_corrupted_alignments_give_the_host_pipelines_results(tmp_path, seed):
+    """Alignments with node ids, offsets, edit lengths and strands changed at random through the pipeline: the same reads processed, the
+    same per-read results and counts of refused reads as host parse -> vgan_euka_flatten -> the read kernel."""
+    from test_sb_pipe_gpu import _corrupted
+    p5, p3 = _damage()
+    dm = ek.Damage.load(p5, p3)
+    g, db, a0 = ek.synth_euka(4000, dm, seed=50 + seed, n_clades=8, nodes_per_clade=150)
+    a = _corrupted(a0, g, seed)
+    gam = str(tmp_path / "c.gam")
+    a.write_gam(gam)
+    data = open(gam, "rb").read()
+    want = _host_run(g, db, dm, gam)
+    ctx = ek.EukaContext(db, dm)
+    got, ps = ek.gam_run([ctx], g, data, piece_bytes=100_000, slots=2, n_threads=4)
+    for k in ("n_messages", "n_mapped", "n_bad"):
+        assert got[k] == want[k], k
+    for k in ("read_index", "read_clade", "read_pass", "read_seq_len"):
+        assert np.array_equal(got[k], want[k]), k
+    assert want["n_bad"] > 0 and ps["n_device_reads"] > 0 and ps["n_host_reads"] > 0
+    fin = ctx.finalize()
+    assert np.array_equal(fin["clade_count"], want["fin"]["clade_count"]) and np.array_equal(fin["baseshift"], want["fin"]["baseshift"])
+    ctx.close()

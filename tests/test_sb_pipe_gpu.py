@@ -191,3 +191,63 @@ def test_vgan_soibean_over_the_device_front_end_writes_the_host_pipelines_files(
         for name in outs["host"][0]:
             assert outs["host"][0][name] == outs[other][0][name], name
         assert outs["host"][1] == outs[other][1]
+
+
+def _corrupted(a, g, seed, n_max=400):
+    """The alignment set with node ids, edit lengths, offsets and strands changed at random (what a front half has to judge, not to trust)."""
+    import orc
+    from vgan_amd import _native as N
+    rng = np.random.default_rng(seed)
+    arr = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in a.arrays().items()}
+    for _ in range(int(rng.integers(50, n_max))):
+        w = rng.integers(7)
+        if w == 0:
+            arr["m_node"][rng.integers(len(arr["m_node"]))] = rng.choice([0, 1, int(g.max_id), int(g.max_id) + 1, int(rng.integers(1, g.max_id + 1))])
+        elif w == 1:
+            arr["e_from"][rng.integers(len(arr["e_from"]))] = rng.integers(0, 6)
+        elif w == 2:
+            arr["e_to"][rng.integers(len(arr["e_to"]))] = rng.integers(0, 6)
+        elif w == 3:
+            arr["m_offset"][rng.integers(len(arr["m_offset"]))] = rng.choice([0, 1, 2, 3, 7, 1 << 20])
+        elif w == 4:
+            arr["m_rev"][rng.integers(len(arr["m_rev"]))] ^= 1
+        elif w == 5:  # (both lengths of an edit, together: still a match, of another length)
+            e = rng.integers(len(arr["e_from"]))
+            arr["e_from"][e] = arr["e_to"][e] = rng.integers(0, 40)
+        else:  # (a whole read onto the other strand)
+            r = rng.integers(a.n_reads)
+            arr["m_rev"][arr["map_off"][r]:arr["map_off"][r + 1]] ^= 1
+    oa = orc.AlnSet.from_arrays(**arr)
+    v = N.AlnSetView(oa.n_reads, *[getattr(oa, k).ctypes.data for k in ("seq_off", "seq", "qual_off", "qual", "mapq", "identity")], None, None,
+                     *[getattr(oa, k).ctypes.data for k in ("map_off", "m_node", "m_offset", "m_rev", "edit_off", "e_from", "e_to", "e_seq_off", "e_seq")])
+    h = N.vp()
+    N.check(N.lib().vgan_aln_from_arrays(v, h))
+    out = hc.AlnSet(h)
+    out._keep = oa
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_corrupted_alignments_are_taken_or_left_as_the_host_flatten_judges_them(tmp_path, seed):
+    """Alignments with node ids, offsets, edit lengths and strands changed at random: every read the device flatten takes has the host
+    flatten's rows -- none that the host refuses is taken --, the others are the host's: the batches of the pipeline are the host batch."""
+    g, _, profs, _ = _soibean_case(n_reads=10)
+    a0 = hc.synth_reads(g, 3000, seed=40 + seed, read_len=50, indel_rate=0.1, softclip_rate=0.1)
+    a = _corrupted(a0, g, seed)
+    gam = str(tmp_path / "c.gam")
+    a.write_gam(gam)
+    data = open(gam, "rb").read()
+    a2 = hc.AlnSet.read_gam(gam, keep_unmapped=False)
+    hb = sb.SbHostBatch(g, a2)
+    want = hb.arrays()
+    assert hb.stats.n_bad > 0 and hb.n_reads > 1000
+    dm = ek.Damage.from_text(*(open(p).read() for p in profs))
+    ctx = sb.SbContext(g, dm, penalty=7)
+    got, ps = sb.gam_run([ctx], g, data, piece_bytes=100_000, slots=2, n_threads=4, batches=True)
+    assert got["n_reads"] == hb.n_reads and got["n_bad"] == hb.stats.n_bad and ps["n_device_reads"] > 0 and ps["n_host_reads"] > 0
+    w = _by_read(want)
+    gt = _by_read(got["batches"][0])
+    assert len(gt) == len(w)
+    for src, v in gt.items():
+        assert v == w[src], src
+    ctx.close()
