@@ -318,3 +318,23 @@ def test_the_code_objects_of_every_translation_unit_can_be_loaded_ahead():
         assert L.vgan_device_preload(0, what) == 0
     assert L.vgan_device_preload(1 << 20, 15) < 0  # (no such device)
 
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_corrupted_alignments_give_the_host_pipelines_sums(tmp_path, seed):
+    """Alignments with node ids, offsets, edit lengths and strands changed at random through the HaploCart pipeline: the same reads kept and
+    refused, the same final vector as host parse + host flatten."""
+    from test_sb_pipe_gpu import _corrupted
+    g = hc.synth_graph(seed=25, genome_len=5000, n_nodes=3300, n_paths=120)
+    a0 = hc.synth_reads(g, 6000, seed=70 + seed, read_len=100, indel_rate=0.05, softclip_rate=0.05, low_mapq_rate=0.1)
+    a = _corrupted(a0, g, seed, n_max=600)
+    p = str(tmp_path / "c.gam")
+    a.write_gam(p)
+    data = open(p, "rb").read()
+    want, n_reads, _, n_kept = _host_final(g, p, False)
+    ctx = hc.HcContext(g)
+    st, ps = hc.accumulate_gam_bytes([ctx], g, data, piece_bytes=150_000, slots=2, n_threads=4)
+    assert ps["n_reads"] == n_reads and st.n_out == n_kept and ps["n_device_reads"] > 0 and ps["n_host_reads"] > 0
+    got = ctx.finalize()
+    assert np.max(np.abs(got - want) / np.abs(want)) < 1e-12
+    ctx.close()
