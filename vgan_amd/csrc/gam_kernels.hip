@@ -105,30 +105,41 @@ __device__ __forceinline__ bool gd_is_gam(const uint8_t *u, uint64_t p, uint64_t
 // One WAVE per segment: the first tag in [seg start (or 1), seg end); a match may begin in the segment and end beyond it.
 // the first tag in [from, s1) (a wave searches: every lane gets the result), GD_NO_ANCHOR when there is none
 __device__ __forceinline__ uint64_t gd_find_tag(const uint8_t *__restrict__ u, uint64_t n, uint64_t from, uint64_t s1, uint32_t lane) {
-    for (uint64_t base = from & ~15ull; base < s1; base += 64u * 16u) {
-        const uint64_t at = base + (uint64_t)lane * 16u;
-        uint32_t w[5] = {0, 0, 0, 0, 0};
-        if (at + 20 <= n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(u + at);
-            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
-            w[4] = *reinterpret_cast<const uint32_t *>(u + at + 16);
-        } else {
+    // (four kilobytes to a round -- four loads a lane asked for before any is looked at: a round is a trip to memory, and a tag lies some
+    // hundred kilobytes into the segment)
+    constexpr int GD_FT = 4;
+    for (uint64_t base = from & ~15ull; base < s1; base += GD_FT * 64u * 16u) {
+        uint32_t w[GD_FT][5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) w[k] = gd_u32_at(u, n, at + 4u * k);
-        }
-        uint32_t hit = 16;
+        for (int b = 0; b < GD_FT; ++b) {
+            const uint64_t at = base + (uint64_t)b * 1024u + (uint64_t)lane * 16u;
+            if (at + 20 <= n) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(u + at);
+                w[b][0] = v.x, w[b][1] = v.y, w[b][2] = v.z, w[b][3] = v.w;
+                w[b][4] = *reinterpret_cast<const uint32_t *>(u + at + 16);
+            } else {
 #pragma unroll
-        for (int i = 15; i >= 0; --i) {
-            const uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
-            const uint32_t win = (i & 3) ? (uint32_t)(((uint64_t)hi << 32 | lo) >> (8 * (i & 3))) : lo;
-            const uint64_t pos = at + (uint64_t)i;
-            if (win == GD_TAG && pos >= from && pos < s1 && pos >= 1) hit = (uint32_t)i;
+                for (int k = 0; k < 5; ++k) w[b][k] = gd_u32_at(u, n, at + 4u * k);
+            }
         }
-        const uint64_t m = __builtin_amdgcn_ballot_w64(hit < 16);
-        if (m) {
-            const uint32_t l0 = (uint32_t)__builtin_ctzll(m);
-            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hit, (int)l0);
-            return base + (uint64_t)l0 * 16u + h0;
+#pragma unroll
+        for (int b = 0; b < GD_FT; ++b) {
+            const uint64_t bb = base + (uint64_t)b * 1024u, at = bb + (uint64_t)lane * 16u;
+            if (bb >= s1) break;
+            uint32_t hit = 16;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                const uint32_t lo = w[b][i >> 2], hi = w[b][(i >> 2) + 1];
+                const uint32_t win = (i & 3) ? (uint32_t)(((uint64_t)hi << 32 | lo) >> (8 * (i & 3))) : lo;
+                const uint64_t pos = at + (uint64_t)i;
+                if (win == GD_TAG && pos >= from && pos < s1 && pos >= 1) hit = (uint32_t)i;
+            }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(hit < 16);
+            if (m) {
+                const uint32_t l0 = (uint32_t)__builtin_ctzll(m);
+                const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hit, (int)l0);
+                return bb + (uint64_t)l0 * 16u + h0;
+            }
         }
     }
     return GD_NO_ANCHOR;
@@ -163,17 +174,46 @@ __global__ __launch_bounds__(64) void gd_reanchor_kernel(const uint8_t *__restri
 struct GdWalkOut {
     uint32_t n_msg, status;
 };
+// A walk is a chain of loads, each at an address the one before gave: a hop is a trip to HBM (~2.3 us under this kernel's load; a segment's
+// ~800 hops were 1.9 ms).  So a whole WAVE walks a segment -- every lane the same walk, the same addresses: one request -- and the lanes
+// touch the stream ahead of it, a line each: the bytes of the next 16-32 KB are on their way to the L2 before the walk asks for them, and a
+// hop is a trip there.  (The touches' values are folded into a word nobody reads: they are asked for at one touch and looked at at the
+// next, when they have long arrived -- loads come back in the order they were sent, and a hop sent behind a touch waits for it.)
+constexpr uint64_t GD_AHEAD_STEP = 16384;
+struct GdAhead {
+    uint64_t front = 0; // bytes below it have been touched
+    uint64_t sink = 0, p0 = 0, p1 = 0;
+    uint32_t lane = 0;
+    bool on = false, all_write = false; // all_write: the walk's state goes to a place of each lane's own
+};
+__device__ __forceinline__ void gd_touch(GdAhead &h, const uint8_t *u, uint64_t n, uint64_t p) {
+    if (!h.on || p + GD_AHEAD_STEP <= h.front || h.front >= n) return; // (the same in every lane)
+    if (h.front < p) h.front = p & ~127ull;
+    h.sink ^= h.p0 ^ h.p1;
+    const uint64_t a0 = h.front + (uint64_t)h.lane * 128u, a1 = a0 + GD_AHEAD_STEP / 2;
+    h.p0 = a0 + 8 <= n ? gd_load8(u + a0) : 0;
+    h.p1 = a1 + 8 <= n ? gd_load8(u + a1) : 0;
+    h.front += GD_AHEAD_STEP;
+}
+__device__ __forceinline__ void gd_touch_end(GdAhead &h) { // (the touches are loads the compiler may not drop)
+    const uint64_t v = h.sink ^ h.p0 ^ h.p1;
+    asm volatile("" ::"v"((uint32_t)v), "v"((uint32_t)(v >> 32)));
+}
+// (ahead: null -- one lane walks alone, as the kernels that walk once do -- or the wave's: every lane walks, lane 0 writes)
 template <bool EMIT>
 __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t start, uint32_t mode0, uint64_t rem0, uint32_t first0, uint64_t stop_tag,
-                                     uint64_t *msg_off, uint32_t *msg_len, uint64_t out_base, bool open_end, GdCarryState *carry) {
+                                     uint64_t *msg_off, uint32_t *msg_len, uint64_t out_base, bool open_end, GdCarryState *carry, GdAhead *ahead = nullptr) {
     uint64_t p = start, cnt = 0;
     uint64_t rem = rem0;
     bool in_group = mode0 == 1u, first = first0 != 0u;
+    GdAhead none;
+    GdAhead &ah = ahead ? *ahead : none;
+    const bool writer = !ahead || ahead->lane == 0 || ahead->all_write;
     // the stream ends inside the item at p (or exactly in front of it)
     auto cut = [&](uint32_t mode) -> GdWalkOut {
         if (!open_end) return GdWalkOut{(uint32_t)cnt, GF_TRUNCATED};
         if (stop_tag != n) return GdWalkOut{(uint32_t)cnt, GF_MISSED};
-        *carry = GdCarryState{p, rem, mode, first ? 1u : 0u};
+        if (writer) *carry = GdCarryState{p, rem, mode, first ? 1u : 0u};
         return GdWalkOut{(uint32_t)cnt, GF_OK};
     };
     if (mode0 == 2u) {
@@ -181,6 +221,7 @@ __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t star
         // is recognised instead -- a count followed by the tag (no message starts with field number 0)   (gam.cpp: frame_segment)
         for (;;) {
             uint64_t v, q;
+            gd_touch(ah, u, n, p);
             if (p >= n) {
                 if (open_end) return cut(2u);
                 return GdWalkOut{(uint32_t)cnt, stop_tag == n && p == n ? GF_OK : GF_TRUNCATED};
@@ -203,7 +244,7 @@ __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t star
             }
             if (v > n - q) return cut(2u);
             if (q + v > stop_tag) return GdWalkOut{(uint32_t)cnt, GF_MISSED}; // (the next anchor lies inside this item: one of the two tags is no tag)
-            if (EMIT) {
+            if (EMIT && writer) {
                 msg_off[out_base + cnt] = q;
                 msg_len[out_base + cnt] = (uint32_t)v;
             }
@@ -214,6 +255,7 @@ __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t star
     }
     for (;;) { // the walk proper (gam.cpp: walk)
         uint64_t v, q;
+        gd_touch(ah, u, n, p);
         if (!in_group) {
             if (p == n) {
                 if (open_end) return cut(0u);
@@ -239,7 +281,7 @@ __device__ GdWalkOut gd_walk_segment(const uint8_t *u, uint64_t n, uint64_t star
         const bool tag = first && v == 3 && gd_is_gam(u, p, q, word, have);
         if (!tag) {
             if (v > 0xFFFFFFFFull) return GdWalkOut{(uint32_t)cnt, GF_BAD_MESSAGE};
-            if (EMIT) {
+            if (EMIT && writer) {
                 msg_off[out_base + cnt] = q;
                 msg_len[out_base + cnt] = (uint32_t)v;
             }
@@ -257,21 +299,25 @@ __global__ __launch_bounds__(64) void gd_frame_kernel(const uint8_t *__restrict_
                                                       const uint64_t *__restrict__ next_anchor, uint32_t *__restrict__ seg_msgs,
                                                       const uint64_t *__restrict__ msg_base, uint64_t *__restrict__ msg_off, uint32_t *__restrict__ msg_len,
                                                       uint32_t *__restrict__ seg_status, GdCarryState in, int open_end, GdCarryState *__restrict__ carry) {
-    const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t seg = blockIdx.x, lane = threadIdx.x; // a wave per segment (gd_touch)
     if (seg >= n_segs) return;
     const uint64_t a = anchor[seg];
     if (a == GD_NO_ANCHOR) { // (its bytes are walked from the anchored segment before it)
-        if (!EMIT) {
+        if (!EMIT && lane == 0) {
             seg_msgs[seg] = 0;
             seg_status[seg] = GF_OK;
         }
         return;
     }
+    GdAhead ah;
+    ah.lane = lane;
+    ah.on = true;
     // segment 0 starts in the state the stream starts in (a file: before a group's count); the others on a tag, inside its group
     const GdWalkOut w = seg == 0 ? gd_walk_segment<EMIT>(u, n, a, in.mode, in.rem, in.first, next_anchor[seg], msg_off, msg_len, EMIT ? msg_base[seg] : 0,
-                                                         open_end != 0, carry)
-                                 : gd_walk_segment<EMIT>(u, n, a + 4, 2u, 0, 0u, next_anchor[seg], msg_off, msg_len, EMIT ? msg_base[seg] : 0, open_end != 0, carry);
-    if (!EMIT) {
+                                                         open_end != 0, carry, &ah)
+                                 : gd_walk_segment<EMIT>(u, n, a + 4, 2u, 0, 0u, next_anchor[seg], msg_off, msg_len, EMIT ? msg_base[seg] : 0, open_end != 0, carry, &ah);
+    gd_touch_end(ah);
+    if (!EMIT && lane == 0) {
         seg_msgs[seg] = w.n_msg;
         seg_status[seg] = w.status;
     }
@@ -310,21 +356,26 @@ __global__ __launch_bounds__(64) void gd_tail_walk_kernel(const uint8_t *__restr
             break;
         }
     }
-    if (lane != 0) return;
+    // (every lane walks -- the same walk --, touching the stream ahead of it: gd_touch; the states are each lane's own copies)
     GdCarryState out{~0ull, 0, 0xFFFFFFFFu, 0}, none{};
+    GdAhead ah;
+    ah.lane = lane;
+    ah.on = true;
+    ah.all_write = true; // (the states are each lane's own: every lane writes its copy)
     if (a2 == GD_NO_ANCHOR) { // a short piece: the walk of all of it, from the state it starts in
-        const GdWalkOut w = gd_walk_segment<false>(u, n, 0, in.mode, in.rem, in.first, n, nullptr, nullptr, 0, true, &out);
+        const GdWalkOut w = gd_walk_segment<false>(u, n, 0, in.mode, in.rem, in.first, n, nullptr, nullptr, 0, true, &out, &ah);
         if (w.status != GF_OK) out.mode = 0xFFFFFFFFu;
     } else {
         // from the tag before (or, with one tagged segment only, from the piece's start) the walk must stand on the last tag
-        const GdWalkOut w1 = a1 == GD_NO_ANCHOR ? gd_walk_segment<false>(u, n, 0, in.mode, in.rem, in.first, a2, nullptr, nullptr, 0, true, &none)
-                                                : gd_walk_segment<false>(u, n, a1 + 4, 2u, 0, 0u, a2, nullptr, nullptr, 0, true, &none);
+        const GdWalkOut w1 = a1 == GD_NO_ANCHOR ? gd_walk_segment<false>(u, n, 0, in.mode, in.rem, in.first, a2, nullptr, nullptr, 0, true, &none, &ah)
+                                                : gd_walk_segment<false>(u, n, a1 + 4, 2u, 0, 0u, a2, nullptr, nullptr, 0, true, &none, &ah);
         if (w1.status == GF_OK) {
-            const GdWalkOut w2 = gd_walk_segment<false>(u, n, a2 + 4, 2u, 0, 0u, n, nullptr, nullptr, 0, true, &out);
+            const GdWalkOut w2 = gd_walk_segment<false>(u, n, a2 + 4, 2u, 0, 0u, n, nullptr, nullptr, 0, true, &out, &ah);
             if (w2.status != GF_OK) out.mode = 0xFFFFFFFFu;
         }
     }
-    *carry = out;
+    gd_touch_end(ah);
+    if (lane == 0) *carry = out;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ parsing
@@ -1239,7 +1290,7 @@ int vgan::gd::gd_piece_parse(vgan_gamdev *g, const GdCarry &cin, bool last_piece
     // and the walks are counted again.  A walk that breaks (not: misses) is a malformed stream.
     for (uint32_t again = 0;; ++again) {
         hipLaunchKernelGGL(gd_next_anchor_kernel, dim3(1), dim3(1), 0, st, g->anchor.p, n_segs, total, g->next_anchor.p);
-        hipLaunchKernelGGL(gd_frame_kernel<false>, dim3((n_segs + 63) / 64), dim3(64), 0, st, u, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
+        hipLaunchKernelGGL(gd_frame_kernel<false>, dim3(n_segs), dim3(64), 0, st, u, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
                            (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, g->seg_status.p, in, open_end, g->carry.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(seg_n.data(), g->seg_msgs.p, n_segs * 4, hipMemcpyDeviceToHost, st));
@@ -1286,7 +1337,7 @@ int vgan::gd::gd_piece_parse(vgan_gamdev *g, const GdCarry &cin, bool last_piece
     }
     if ((rc = g->msg_off.reserve(n_msg)) || (rc = g->msg_len.reserve(n_msg))) return rc;
     HIPCHK(hipMemcpyAsync(g->msg_base.p, base.data(), n_segs * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gd_frame_kernel<true>, dim3((n_segs + 63) / 64), dim3(64), 0, st, u, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
+    hipLaunchKernelGGL(gd_frame_kernel<true>, dim3(n_segs), dim3(64), 0, st, u, total, n_segs, g->anchor.p, g->next_anchor.p, g->seg_msgs.p,
                        g->msg_base.p, g->msg_off.p, g->msg_len.p, g->seg_status.p, in, open_end, g->carry.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
