@@ -25,12 +25,14 @@ if os.environ.get("PIPE_PINNED"):  # (the file's bytes in page-locked memory: wh
     import torch
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
     data = t.numpy()
-ctx = hc.HcContext(g)
+n_lanes = int(os.environ.get("PIPE_LANES", "1"))  # (several contexts on the one GPU: does the GPU have room for more than a lane gives it?)
+ctxs = [hc.HcContext(g) for _ in range(n_lanes)]
 ts = []
 for i in range(6):
-    ctx.reset()
+    for c in ctxs:
+        c.reset()
     t0 = time.perf_counter()
-    st, ps = hc.accumulate_gam_bytes([ctx], g, data, n_threads=16)
+    st, ps = hc.accumulate_gam_bytes(ctxs, g, data, n_threads=16)
     ts.append(time.perf_counter() - t0)
     if i == 5:
         print("summed over pieces:", {k: round(v) for k, v in ps.items() if k.startswith("ms_")}, "pieces", ps["n_pieces"])
