@@ -51,7 +51,7 @@ def build(verbose=False, force=False):
     os.makedirs(OBJDIR, exist_ok=True)
     hip, cpp = sources()
     hdrs = headers() + [os.path.abspath(__file__)]
-    objs = []
+    objs, cmds = [], []
     for src in hip + cpp:
         obj = os.path.join(OBJDIR, os.path.relpath(src, CSRC).replace(os.sep, "_") + ".o")
         objs.append(obj)
@@ -62,9 +62,18 @@ def build(verbose=False, force=False):
             else:
                 cmd += ["-x", "c++"]
             cmd += ["-c", src, "-o", obj]
+            cmds.append(cmd)
+    if cmds:  # (a from-scratch build is thirty translation units, up to a minute and ~1.5 GB each: a few at a time)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+
+        jobs = max(1, min(int(os.environ.get("VGAN_BUILD_JOBS", "0")) or min(6, os.cpu_count() or 1), len(cmds)))
+        with ThreadPoolExecutor(jobs) as ex:
+            list(ex.map(run, cmds))
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-lz", "-lpthread", "-ldl"]
         if verbose:
