@@ -39,6 +39,10 @@
 namespace vgan {
 namespace c8 {
 
+#ifndef C8_ROTATE
+#define C8_UNROLL2
+#endif
+
 // A variant of the kernel: columns per lane (a multiple of 8: the tile holds 64 * CPL columns), segments per tile (whole passes
 // of 64), node ids covered by a wave's W window, waves of the one workgroup a CU holds (what its LDS can carry).
 template <int CPL_, int CAPS_, int WIN_, int WAVES_> struct C8Cfg {
@@ -402,7 +406,15 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
 #ifdef C8_PHASES
     unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
 #endif
+    // The tile loop is a step taken twice, the second time with the records' registers in each other's roles: what the step loads for the
+    // next tile is where the next step reads its own from, and nothing is moved at a step's end (14 register moves a tile: 1.3 % of the
+    // launch; -DC8_ROTATE keeps the one-step loop that moved them, for A/B runs).
+#ifdef C8_UNROLL2
+    auto tile_step = [&](uint4(&rq)[C8_NG], uint4(&rqN)[C8_NG], uint32_t(&sr)[C8_SPASS], uint32_t(&srN)[C8_SPASS], uint32_t(&nhi)[C8_SPASS],
+                         uint32_t(&nhiN)[C8_SPASS]) __attribute__((always_inline)) -> bool {
+#else
     while (true) {
+#endif
         // ---- the next tile: formed from its header; its segment and column records, its reads' scalars and the header after it requested
         const bool has_next = fn < a.n_reads;
         const C8Tile Tn = tile_form(Hn, fn, wn);
@@ -771,18 +783,24 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
         ph_acc[7] += fast ? 0 : 1;
         ph_acc[9] += gfast ? 1 : 0;
 #endif
+#ifdef C8_UNROLL2
+        if (!has_next) return false;
+#else
         if (!has_next) break;
+#endif
         request_classes(srN, nhiN); // (the next tile's segment records have been on their way for a whole tile; these land during its Q)
 #ifdef C8_L2_PREFETCH
         asm volatile("" ::"v"(pf_touch)); // (the touch's register is its own until here)
 #endif
         C8_MARK(8);
         T = Tn;
+#ifndef C8_UNROLL2
 #pragma unroll
         for (int k = 0; k < C8_SPASS; ++k) {
             sr[k] = srN[k];
             nhi[k] = nhiN[k];
         }
+#endif
 
         h_q = hn_q;
         h_c = hn_c;
@@ -791,9 +809,18 @@ template <class K> __global__ __launch_bounds__(K::THREADS) void hc_segment_col8
         wn = w2;
         fresh = fresh_n;
         fresh_n = fresh_2;
+#ifdef C8_UNROLL2
+        return true;
+    };
+    while (true) {
+        if (!tile_step(rq, rqN, sr, srN, nhi, nhiN)) break;
+        if (!tile_step(rqN, rq, srN, sr, nhiN, nhi)) break;
+    }
+#else
 #pragma unroll
         for (int g = 0; g < C8_NG; ++g) rq[g] = rqN[g];
     }
+#endif
     if (winbase != 0xFFFFFFFFu) window_flush(winbase);
 #ifdef C8_PHASES
     if (lane == 0)
